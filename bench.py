@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched env.step() hot path on MI355X.
+
+Workload (BASELINE.json metric): CliffordGym, 16 qubits, line-16
+bidirectional coupling map, all 8 gate kinds (170 actions), 65 536 envs per GPU, start = identity
+scrambled by 256 uniform random actions, then uniform random actions, add_inverts=False,
+add_perms=False, track_solution=False, default metric weights, free-running (no reset inside the
+timed loop).  A "step" is ONE env.step() of every env = one `clifford step` kernel launch that reads
+each env's packed tableau from device memory, applies its own action, tests for identity, writes
+reward / done / success / depth and the touched rows back.  Inputs (actions) are resident in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank owns 65 536 envs
+(weak scaling) and after every step all-gathers the bit-packed observation (8 MiB per rank) on a
+side stream, overlapped with the following steps, as BASELINE.json's north_star prescribes.
+
+Prints one JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+NUM_QUBITS = 16
+ENVS_PER_GPU = 65536
+SCRAMBLE = 256
+CHUNK = 64  # steps per hipGraph replay (single-GPU path)
+ALGO_BYTES_PER_STEP = 160  # 128 B state read + 16 B touched rows + 16 B scalars
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def build_gateset():
+    from qiskit_gym_amd.envs.gateset import gateset_from_coupling_map, line_edges
+
+    kinds = ["H", "S", "Sdg", "SX", "SXdg", "CX", "CZ", "SWAP"]
+    return gateset_from_coupling_map(line_edges(NUM_QUBITS, True), None, kinds)
+
+
+def cpu_baseline(gateset, seed: int, budget_s: float = 12.0):
+    """Time the CPU oracle (a C port of the reference's scalar Rust path, one env object per env,
+    OpenMP over envs like twisterl's rayon-over-clones) on this box's host cores."""
+    from oracle import OracleEnv, OracleVec
+
+    cores = os.cpu_count() or 1
+    B = 16384
+    A = len(gateset)
+    proto = OracleEnv("clifford", NUM_QUBITS, gateset, add_inverts=0, add_perms=0, track_solution=0, difficulty=SCRAMBLE)
+    ov = OracleVec(proto, B)
+    rng = np.random.default_rng(seed)
+    ov.reset_with(rng.integers(0, A, size=(SCRAMBLE, B)))
+    acts = rng.integers(0, A, size=(32, B)).astype(np.int32)
+    t0 = time.perf_counter()
+    for t in range(4):
+        ov.step_only(acts[t], threads=cores)
+    per_step = (time.perf_counter() - t0) / 4
+    n_steps = int(max(8, min(4096, budget_s / max(per_step, 1e-6))))
+    t0 = time.perf_counter()
+    for t in range(n_steps):
+        ov.step_only(acts[t % 32], threads=cores)
+    dt = time.perf_counter() - t0
+    return {
+        "value": B * n_steps / dt,
+        "unit": "env-steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"CliffordGym 16q, {B} envs x {n_steps} steps ({dt:.1f} s), C port of the reference scalar path "
+                  f"(byte-per-entry state, per-env objects), OpenMP over envs on {cores} threads",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1 diagnostics: skip the per-step all-gather")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    n_gpus = world
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from qiskit_gym_amd.vec import VecEnv
+
+    n, gateset = build_gateset()
+    A = len(gateset)
+    B = ENVS_PER_GPU
+    seed = 0x5EED0003 + rank
+    env = VecEnv("clifford", n, gateset, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=SCRAMBLE)
+    stream = torch.cuda.Stream(device=dev)
+    K, W = args.steps, args.warmup
+
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    actions = torch.randint(0, A, (CHUNK, B), dtype=torch.int32, device=dev, generator=gen)
+
+    def run_steps_single(nsteps: int):
+        """nsteps env.step() launches: whole chunks replay a cached hipGraph of CHUNK launches."""
+        done = 0
+        while nsteps - done >= CHUNK:
+            env.rollout(actions, fused=False)
+            done += CHUNK
+        for t in range(nsteps - done):
+            env.step(actions[t])
+
+    # ---- multi-GPU: step + all-gather of the packed observation, double buffered -------------
+    if world > 1:
+        comm = torch.cuda.Stream(device=dev)
+        snap = [torch.empty((B, 32), dtype=torch.int32, device=dev) for _ in range(2)]
+        gathered = [torch.empty((world * B, 32), dtype=torch.int32, device=dev) for _ in range(2)]
+        snap_ready = [torch.cuda.Event() for _ in range(2)]
+        gather_done = [torch.cuda.Event() for _ in range(2)]
+
+        def run_steps_multi(nsteps: int):
+            for t in range(nsteps):
+                b = t & 1
+                env.step(actions[t % CHUNK])
+                if args.no_gather:
+                    continue
+                stream.wait_event(gather_done[b])  # the gather that last read snap[b] has finished
+                env.observe_packed(out=snap[b])
+                snap_ready[b].record(stream)
+                comm.wait_event(snap_ready[b])
+                with torch.cuda.stream(comm):
+                    dist.all_gather_into_tensor(gathered[b], snap[b])
+                    gather_done[b].record(comm)
+
+        run_steps = run_steps_multi
+    else:
+        run_steps = run_steps_single
+
+    with torch.cuda.stream(stream):
+        env.reset(seed)
+        if world > 1:
+            for e in gather_done:
+                e.record(stream)
+        run_steps(CHUNK)  # builds and caches the rollout graph (setup, not a step)
+        env.reset(seed)
+        run_steps(W)  # untimed warmup steps
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        ev0.record(stream)
+        run_steps(K)
+        ev1.record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    env.sync()  # raises if any env faulted
+    stream_ms = ev0.elapsed_time(ev1)
+
+    # ---- roofline leg: duration of the step kernel itself, HIP events around single launches --
+    reps = 200
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    with torch.cuda.stream(stream):
+        for i in range(reps):
+            starts[i].record(stream)
+            env.step(actions[i % CHUNK])
+            stops[i].record(stream)
+    torch.cuda.synchronize()
+    per_launch_us = sorted(s.elapsed_time(e) * 1e3 for s, e in zip(starts, stops))
+    single_launch_us = float(np.median(per_launch_us))
+    b2b_us = stream_ms * 1e3 / K  # back-to-back launches incl. the inter-kernel boundary
+    kernel_us = min(single_launch_us, b2b_us)
+    algo_bytes = ALGO_BYTES_PER_STEP * B
+    achieved = algo_bytes / (kernel_us * 1e-6) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("clifford_step_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    # ---- fused rollout (state in registers across steps), reported beside the headline --------
+    fused = None
+    if world == 1:
+        with torch.cuda.stream(stream):
+            env.rollout(actions, fused=True)
+            torch.cuda.synchronize()
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record(stream)
+            for _ in range(8):
+                env.rollout(actions, fused=True)
+            f1.record(stream)
+        torch.cuda.synchronize()
+        fms = f0.elapsed_time(f1)
+        fused = {"value": B * CHUNK * 8 / (fms * 1e-3), "unit": "env-steps/s", "steps_per_launch": CHUNK}
+
+    out = None
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(gateset, seed)
+        total_steps = B * K * n_gpus
+        out = {
+            "metric": "env-steps/sec (whole node), CliffordGym 16q x 65536 envs/GPU; bit-exact vs CPU",
+            "value": total_steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": n_gpus,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed * 1e3 / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": "CliffordGym 16 qubits, line-16 bidirectional, 170 actions (H,S,Sdg,SX,SXdg,CX,CZ,SWAP), "
+                            f"{B} envs per GPU, start = identity + {SCRAMBLE} random gates, uniform random actions, "
+                            "add_inverts=False, add_perms=False, track_solution=False, default weights, free-running",
+                "envs_per_gpu": B,
+                "total_envs": B * n_gpus,
+                "launch": "one step kernel per env.step(); chunks of %d launches replayed from a hipGraph" % CHUNK
+                if n_gpus == 1 else "one step kernel per env.step() + all_gather_into_tensor(packed obs, 8 MiB/rank) per step, overlapped",
+                "collective": None if n_gpus == 1 or args.no_gather else "RCCL all-gather of the bit-packed observation every step",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "rows_step_kernel<uint32_t>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "launch_us": kernel_us,
+                "launch_us_single_event_pair": single_launch_us,
+                "launch_us_back_to_back": b2b_us,
+            },
+            "cpu_baseline": cpu,
+            "fused_rollout": fused,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,238 @@
+/*
+ * qgym.h -- C ABI of the MI355X-native batched env.step() path (libqgym.so).
+ *
+ * This is the drop-in boundary for qiskit-gym's Rust `env.step()` hot path.  The reference
+ * exposes each environment to its callers through the `twisterl::rl::env::Env` trait
+ * (implemented at rust/src/envs/clifford.rs:285-382, linear_function.rs:259-365,
+ * permutation.rs:148-257, pauli.rs:492-720 of the reference) and to Python through PyO3 classes
+ * registered in rust/src/lib.rs:24-31.  A Rust (or cgo / ctypes) host binds the functions below
+ * instead; INTEGRATION.md shows the `impl Env` shim a maintainer would add.
+ *
+ * Two flavours:
+ *   qg_vec_*  a batch of B independent environments resident in one GPU's HBM, stepped by one
+ *             kernel launch per `step` (new surface: the reference has no vector env, every
+ *             method is the batched counterpart of one trait method and cites it);
+ *   qg_env_*  one environment with exactly the trait's method set (a batch of 1 on the same
+ *             kernels), for callers that hold a `Box<dyn Env>`.
+ *
+ * Conventions: plain pointers and sizes only.  Pointers named *_dev are device pointers on the
+ * handle's GPU; `stream` is a `hipStream_t` passed as `void*` (NULL = the null stream).  All
+ * qg_vec_* device work is enqueued on `stream` and returns without synchronising unless stated.
+ * Every function returns QG_OK (0) or a negative qg_status; qg_last_error() gives the message
+ * (thread-local).  There is no CPU fallback: without a visible gfx950 device creation fails.
+ */
+#ifndef QGYM_H
+#define QGYM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QG_ABI_VERSION 1
+
+typedef enum {
+    QG_OK = 0,
+    QG_ERR_INVALID = -1,     /* bad argument (PyValueError in the reference's ctor path) */
+    QG_ERR_TYPE = -2,        /* malformed gate (PyTypeError, common.rs:51-76) */
+    QG_ERR_UNSUPPORTED = -3, /* outside the limits documented in DESIGN.md */
+    QG_ERR_DEVICE = -4,      /* HIP runtime failure / no GPU */
+    QG_ERR_PANIC = -5,       /* the reference would have panicked (singular inverse, malformed Pauli state, ...) */
+    QG_ERR_FINAL = -6        /* qg_env_step on a final env when `strict` (adapters.py:63-65) */
+} qg_status;
+
+/* rust/src/envs/common.rs:19-29 (enum order) */
+typedef enum { QG_H = 0, QG_S = 1, QG_SDG = 2, QG_SX = 3, QG_SXDG = 4, QG_CX = 5, QG_CZ = 6, QG_SWAP = 7 } qg_gate_kind;
+
+/* the four `impl Env` blocks; numbering shared with the oracle */
+typedef enum { QG_PERMUTATION = 0, QG_LINEAR_FUNCTION = 1, QG_CLIFFORD = 2, QG_PAULI = 3 } qg_env_kind;
+
+typedef struct {
+    int32_t kind; /* qg_gate_kind */
+    int32_t q0;
+    int32_t q1; /* ignored for one-qubit gates */
+} qg_gate;
+
+/* Constructor arguments of Py{Clifford,LinearFunction,Permutation,Pauli}Env::new
+ * (clifford.rs:401-426, linear_function.rs:384-410, permutation.rs:277-303, pauli.rs:743-778). */
+typedef struct {
+    int32_t env_kind; /* qg_env_kind */
+    int32_t num_qubits;
+    int32_t difficulty;
+    int32_t depth_slope;
+    int32_t max_depth;
+    /* MetricsWeights (metrics.rs:150-166) */
+    float w_n_cnots, w_n_layers_cnots, w_n_layers, w_n_gates;
+    int32_t add_inverts;
+    int32_t add_perms;
+    int32_t track_solution;
+    /* PauliEnv only */
+    int32_t max_rotations;
+    int32_t pauli_diff_scale;
+    int32_t final_pauli_layers; /* < 0: None -> max_rotations + 2 (pauli.rs:760) */
+    float num_qubits_decay;
+    float pauli_layer_reward;
+} qg_config;
+
+/* Fill the reference's defaults for `env_kind` (clifford.rs:420-422, metrics.rs:157-166,
+ * envs/synthesis.py:182-204,380-412). */
+void qg_config_default(qg_config *cfg, int32_t env_kind, int32_t num_qubits);
+
+const char *qg_last_error(void);
+int qg_abi_version(void);
+/* Number of visible gfx950 devices (0 when none / no driver). Never fails. */
+int qg_device_count(void);
+
+/* Parse one gate given as (name, indices) -- the FromPyObject of common.rs:46-100: name is
+ * trimmed and matched case-insensitively; wrong arity / unknown name -> QG_ERR_INVALID with the
+ * reference's message. */
+int qg_gate_parse(const char *name, const int64_t *indices, size_t n_indices, qg_gate *out);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched environments
+ * ---------------------------------------------------------------------------------------- */
+typedef struct qg_vec qg_vec;
+
+/* Formats understood by qg_vec_set_state / qg_vec_get_state. */
+typedef enum {
+    QG_FMT_I64 = 0,   /* the trait's `set_state(Vec<i64>)` wire format per env (clifford.rs:299-304:
+                         D*D entries, >0 => 1; permutation.rs:168-173: N entries; pauli.rs:517-552:
+                         [rot_count, 4N^2 tableau, (len, chars...)*], fixed stride per env) */
+    QG_FMT_U8 = 1,    /* dense 0/1 bytes in observation layout (the Gym int8 observation) */
+    QG_FMT_PACKED = 2 /* bit-packed rows, reference row order: row r of env e is word e*D + r;
+                         word = uint32 when D <= 32 else uint64; bit c = entry (r, c).
+                         Permutation: one uint8 per entry. */
+} qg_state_format;
+
+/* Action tensor element type for qg_vec_step / qg_vec_rollout. */
+typedef enum { QG_ACT_I32 = 0, QG_ACT_I64 = 1 } qg_action_dtype;
+
+typedef struct {
+    int32_t env_kind;
+    int32_t num_qubits;
+    int32_t num_actions;   /* Env::num_actions (clifford.rs:289) */
+    int32_t obs_rows;      /* Env::obs_shape (clifford.rs:291-294, pauli.rs:505-507) */
+    int32_t obs_cols;
+    int32_t device;
+    uint64_t batch;
+    uint32_t packed_word_bytes;   /* 4 or 8 (1 for Permutation) */
+    uint32_t packed_words_per_env; /* D (N for Permutation) */
+    uint64_t packed_env_stride_bytes; /* stride of one env in the resident packed state */
+    /* resident device buffers (owned by the handle; valid until destroy) */
+    void *state_dev;    /* resident packed state, layout in DESIGN.md section 3 */
+    float *reward_dev;  /* [B] Env::reward   (clifford.rs:355) */
+    uint8_t *done_dev;  /* [B] Env::is_final (clifford.rs:353) */
+    uint8_t *success_dev; /* [B] Env::success (clifford.rs:357-359) */
+    int32_t *depth_dev; /* [B] remaining depth */
+    uint32_t *error_dev; /* [B] sticky per-env fault bits (QG_FAULT_*) */
+} qg_vec_info;
+
+#define QG_FAULT_SINGULAR 1u     /* inverse of a singular matrix requested (clifford.rs:155 panic) */
+#define QG_FAULT_ZERO_WEIGHT 2u  /* weight-0 rotation in the front layer (pauli_network.rs:114 unwrap) */
+#define QG_FAULT_BAD_STATE 4u    /* set_state produced an unusable state (e.g. non-permutation) */
+
+/* Build B environments, all in the constructor state (identity, depth 1, success, reward 1.0;
+ * clifford.rs:214-245), on GPU `device`. */
+int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, uint64_t batch, int device, qg_vec **out);
+void qg_vec_destroy(qg_vec *v);
+int qg_vec_get_info(const qg_vec *v, qg_vec_info *out);
+
+/* Make the handle keep its per-env result arrays in caller-owned device memory (e.g. tensors of
+ * the learner's framework) instead of its own: reward f32[B], done u8[B], success u8[B],
+ * depth i32[B].  Current contents are carried over.  The caller keeps the memory alive until the
+ * handle is destroyed or re-bound; NULL leaves that array where it is.  Synchronises. */
+int qg_vec_bind_outputs(qg_vec *v, float *reward_dev, uint8_t *done_dev, uint8_t *success_dev, int32_t *depth_dev);
+
+/* Env::set_difficulty / get_difficulty (clifford.rs:296-297) -- one value for the whole batch */
+int qg_vec_set_difficulty(qg_vec *v, int64_t difficulty);
+int64_t qg_vec_get_difficulty(const qg_vec *v);
+
+/* Env::set_state for every env (clifford.rs:299-304): states + e*stride_elems is env e's record in
+ * `format`; depth := max_depth, metrics zeroed, reward := success ? 1 : 0, inverted := false.
+ * `on_device` != 0: `states` is a device pointer.  Host input is staged and copied on `stream`. */
+int qg_vec_set_state(qg_vec *v, const void *states, int format, size_t stride_elems, int on_device, void *stream);
+/* Inverse of the above for inspection / checkpointing (QG_FMT_I64 of a PauliEnv returns the
+ * tableau only). */
+int qg_vec_get_state(qg_vec *v, void *out, int format, size_t stride_elems, int on_device, void *stream);
+
+/* Env::reset for every env (clifford.rs:306-319).  The reference draws `difficulty` uniform
+ * actions from an unseedable RNG; here draw t of env e is
+ *   action = mulhi64(splitmix64(seed ^ splitmix64(e * 0x9E3779B97F4A7C15 + t)), num_actions)
+ * so the oracle can replay it.  (PauliEnv: see qg_vec_pauli_reset_from.) */
+int qg_vec_reset(qg_vec *v, uint64_t seed, void *stream);
+/* Same, with the draws supplied: actions_dev[t*B + e], t < n_draws (int32). */
+int qg_vec_reset_with(qg_vec *v, const int32_t *actions_dev, size_t n_draws, void *stream);
+
+/* Env::step for every env (clifford.rs:321-347): one kernel launch.
+ *   actions_dev[B]  element type `action_dtype`; out-of-range (incl. negative) = "no gate" but
+ *                   depth still decrements (clifford.rs:324,342)
+ *   coins_dev[B]    the gen_bool(0.5) draws of maybe_random_invert (clifford.rs:266); NULL = use
+ *                   the handle's counter RNG when add_inverts is set; ignored otherwise
+ * Results land in the resident reward/done/success/depth buffers (qg_vec_info). */
+int qg_vec_step(qg_vec *v, const void *actions_dev, int action_dtype, const uint8_t *coins_dev, void *stream);
+
+/* T consecutive steps.  actions_dev[t*B + e]; optional per-step outputs rewards_dev[t*B + e],
+ * dones_dev[t*B + e] (NULL = only the final values in the resident buffers).
+ *   fused == 0: T single-step launches replayed from a cached hipGraph (same results and same
+ *               memory traffic as T qg_vec_step calls, without T host launches)
+ *   fused != 0: one launch that keeps each env's state in registers across the T steps */
+int qg_vec_rollout(qg_vec *v, const void *actions_dev, int action_dtype, size_t n_steps, const uint8_t *coins_dev,
+                   float *rewards_dev, uint8_t *dones_dev, int fused, void *stream);
+
+/* Env::observe for every env, densified the way the Gym adapter does it (adapters.py:50-54):
+ * out_dev[e * obs_rows*obs_cols + r*obs_cols + c] in {0,1}, int8. */
+int qg_vec_observe_dense(qg_vec *v, int8_t *out_dev, void *stream);
+/* Bit-packed observation in QG_FMT_PACKED layout (what the multi-GPU all-gather moves). */
+int qg_vec_observe_packed(qg_vec *v, void *out_dev, void *stream);
+/* Env::masks (clifford.rs:349-351): out_dev[e*num_actions + a] = !success[e] */
+int qg_vec_masks(qg_vec *v, uint8_t *out_dev, void *stream);
+
+/* PauliEnv: rebuild every env from an explicit target, the deterministic tail of
+ * PauliEnv::reset (pauli.rs:573-585).  tableaus: [B, 2N*2N] uint8 (host), labels: per env
+ * `n_rot[e]` Pauli labels of N characters each, concatenated without separators. */
+int qg_vec_pauli_reset_from(qg_vec *v, const uint8_t *tableaus, const char *labels, const int32_t *n_rot, void *stream);
+
+/* Blocks until everything enqueued on `stream` by this handle has finished; returns
+ * QG_ERR_PANIC if any env has a fault bit set. */
+int qg_vec_sync(qg_vec *v, void *stream);
+
+/* Solution log (Env::solution, clifford.rs:376-381 / pauli.rs:685-719) of env e, host side.
+ * Returns the length (may exceed cap) or a negative status. */
+int64_t qg_vec_solution(qg_vec *v, uint64_t env, uint64_t *out, size_t cap);
+
+/* ------------------------------------------------------------------------------------------
+ * Scalar environment: the `Env` trait method for method (clifford.rs:285-382).
+ * Every call synchronises; this flavour exists for API parity, not for speed.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct qg_env qg_env;
+
+int qg_env_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, int device, qg_env **out);
+int qg_env_clone(const qg_env *e, qg_env **out); /* Env: DynClone */
+void qg_env_destroy(qg_env *e);
+int64_t qg_env_num_actions(const qg_env *e);
+int qg_env_obs_shape(const qg_env *e, int64_t out[2]);
+int qg_env_set_difficulty(qg_env *e, int64_t d);
+int64_t qg_env_get_difficulty(const qg_env *e);
+int qg_env_set_state(qg_env *e, const int64_t *state, size_t n);
+int qg_env_reset(qg_env *e, uint64_t seed);
+int qg_env_step(qg_env *e, int64_t action);
+/* step with the inversion coin supplied (parity runs with add_inverts) */
+int qg_env_step_coin(qg_env *e, int64_t action, int coin);
+int64_t qg_env_masks(const qg_env *e, uint8_t *out, size_t cap);
+int qg_env_is_final(const qg_env *e);
+float qg_env_reward(const qg_env *e);
+int qg_env_success(const qg_env *e);
+/* ascending flat indices of set observation entries; returns the count */
+int64_t qg_env_observe(qg_env *e, int64_t *out, size_t cap);
+int qg_env_track_solution(const qg_env *e);
+int64_t qg_env_solution(const qg_env *e, uint64_t *out, size_t cap);
+/* twists(): (obs_perms, act_perms) (clifford.rs:370-372).  Returns the number of twists;
+ * obs_perms_out[n * obs_size], act_perms_out[n * num_actions] when non-NULL. */
+int64_t qg_env_twists(const qg_env *e, int64_t *obs_perms_out, int64_t *act_perms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QGYM_H */

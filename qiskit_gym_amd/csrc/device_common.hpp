@@ -1,0 +1,86 @@
+// device_common.hpp -- device helpers shared by the step kernels (gfx950, wave64).
+#pragma once
+
+#include "qgym_internal.hpp"
+
+namespace qg {
+
+#define QG_WAVE 64
+
+__device__ inline int64_t load_action(const void *actions, uint64_t idx, bool act64) {
+    return act64 ? reinterpret_cast<const int64_t *>(actions)[idx]
+                 : (int64_t) reinterpret_cast<const int32_t *>(actions)[idx];
+}
+
+// MetricsTracker with running maxima instead of HashSets (metrics.rs:83-123).
+// `lay` = this env's record: last_gates[N], last_cxs[N], n_layers, n_layers_cnots (int32 each;
+// last_* start at -1).  |layers| == max(last_gates)+1 and |cnot_layers| == max(last_cxs)+1
+// because every inserted layer index is one more than an index already present (or 0).
+struct LayerDelta {
+    int dc, dlc, dl, dg;
+};
+__device__ inline void layers_single(int32_t *lay, uint32_t N, uint32_t t, LayerDelta &d) {
+    if (t >= N) return;  // metrics.rs:84-86
+    d.dg += 1;
+    int32_t gl = lay[t] + 1;
+    lay[t] = gl;
+    int32_t nl = lay[2 * N];
+    if (gl + 1 > nl) {
+        d.dl += gl + 1 - nl;
+        lay[2 * N] = gl + 1;
+    }
+}
+__device__ inline void layers_cx(int32_t *lay, uint32_t N, uint32_t c, uint32_t t, LayerDelta &d) {
+    if (c == t || c >= N || t >= N) return;  // metrics.rs:98-103
+    d.dc += 1;
+    d.dg += 1;
+    int32_t a = lay[c], b = lay[t];
+    int32_t gl = (a > b ? a : b) + 1;
+    lay[c] = gl;
+    lay[t] = gl;
+    int32_t nl = lay[2 * N];
+    if (gl + 1 > nl) {
+        d.dl += gl + 1 - nl;
+        lay[2 * N] = gl + 1;
+    }
+    a = lay[N + c];
+    b = lay[N + t];
+    int32_t cl = (a > b ? a : b) + 1;
+    lay[N + c] = cl;
+    lay[N + t] = cl;
+    int32_t nlc = lay[2 * N + 1];
+    if (cl + 1 > nlc) {
+        d.dlc += cl + 1 - nlc;
+        lay[2 * N + 1] = cl + 1;
+    }
+}
+// metrics.rs:64-81 + 135-146: apply the gate to the tracker, return the f32 penalty.
+// (This translation unit is compiled with -ffp-contract=off: no fused multiply-add.)
+__device__ inline float layers_penalty(int32_t *lay, uint32_t N, uint32_t desc, const float w[4]) {
+    uint32_t kind = desc & 0xFFu, q0 = (desc >> 8) & 0xFFu, q1 = (desc >> 16) & 0xFFu;
+    LayerDelta d = {0, 0, 0, 0};
+    switch (kind) {
+    case QG_CX: layers_cx(lay, N, q0, q1, d); break;
+    case QG_SWAP:
+        layers_cx(lay, N, q0, q1, d);
+        layers_cx(lay, N, q1, q0, d);
+        layers_cx(lay, N, q0, q1, d);
+        break;
+    case QG_CZ:
+        layers_single(lay, N, q1, d);
+        layers_cx(lay, N, q0, q1, d);
+        layers_single(lay, N, q1, d);
+        break;
+    default: layers_single(lay, N, q0, d); break;
+    }
+    float t0 = w[0] * (float)d.dc;
+    float t1 = w[1] * (float)d.dlc;
+    float t2 = w[2] * (float)d.dl;
+    float t3 = w[3] * (float)d.dg;
+    float s = t0 + t1;
+    s = s + t2;
+    s = s + t3;
+    return s;
+}
+
+}  // namespace qg

@@ -1,0 +1,810 @@
+// qgym_api.cpp -- host side of libqgym: the C ABI of include/qgym.h over the gfx950 kernels.
+//
+// What lives here is what the reference does in its constructors and trait plumbing:
+//   gate parsing/validation        rust/src/envs/common.rs:46-100
+//   constructor defaults           rust/src/envs/clifford.rs:401-426, pauli.rs:743-778
+//   MetricsWeights / per-gate cost rust/src/envs/metrics.rs:64-81,135-185
+//   Env trait method set           rust/src/envs/clifford.rs:285-382
+// plus device memory ownership, stream-ordered launches and the hipGraph cache for rollouts.
+// There is deliberately no CPU implementation of the env in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "qgym_host.hpp"
+
+namespace qg {
+
+static thread_local std::string g_err;
+
+int set_error(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+static uint32_t pow2ceil_log2(uint32_t x) {
+    uint32_t l = 0;
+    while ((1u << l) < x) ++l;
+    return l;
+}
+
+// ---- per-gate metric deltas (metrics.rs:64-123 with its guards) -----------------------------
+static void gate_deltas(const qg_gate &g, uint32_t N, int &dc, int &dg) {
+    dc = dg = 0;
+    const uint32_t a = (uint32_t)g.q0, b = (uint32_t)g.q1;
+    auto single = [&](uint32_t t) { if (t < N) dg += 1; };
+    auto cx = [&](uint32_t c, uint32_t t) { if (c != t && c < N && t < N) { dc += 1; dg += 1; } };
+    switch (g.kind) {
+    case QG_CX: cx(a, b); break;
+    case QG_SWAP: cx(a, b); cx(b, a); cx(a, b); break;
+    case QG_CZ: single(b); cx(a, b); single(b); break;
+    default: single(a); break;
+    }
+}
+
+// weighted_delta (metrics.rs:135-146) for an action whose layer deltas are multiplied by zero
+// weights: f32, left to right.  Built with -ffp-contract=off.
+static float table_penalty(const float w[4], int dc, int dg) {
+    volatile float t0 = w[0] * (float)dc;
+    volatile float t1 = w[1] * 1.0f;  // weight is +-0 here; keeps its sign like w * delta would
+    volatile float t2 = w[2] * 1.0f;
+    volatile float t3 = w[3] * (float)dg;
+    volatile float s = t0 + t1;
+    s = s + t2;
+    s = s + t3;
+    return s;
+}
+
+// row operations of one gate (clifford.rs:89-133; linear_function.rs:62-83,237-243; permutation.rs:205-208)
+static uint32_t gate_ops(int env_kind, const qg_gate &g, uint32_t N) {
+    const uint32_t a = (uint32_t)g.q0, b = (uint32_t)g.q1;
+    switch (env_kind) {
+    case QG_CLIFFORD:
+        switch (g.kind) {
+        case QG_H: return make_op(OP_SWAP, a, N + a);
+        case QG_S:
+        case QG_SDG: return make_op(OP_XOR, N + a, a);
+        case QG_SX:
+        case QG_SXDG: return make_op(OP_XOR, a, N + a);
+        case QG_CX: return a == b ? 0u : make_op(OP_XOR, b, a) | (make_op(OP_XOR, N + a, N + b) << 14);
+        case QG_CZ: return a == b ? 0u : make_op(OP_XOR, N + a, b) | (make_op(OP_XOR, N + b, a) << 14);
+        case QG_SWAP: return a == b ? 0u : make_op(OP_SWAP, a, b) | (make_op(OP_SWAP, N + a, N + b) << 14);
+        }
+        return 0u;
+    case QG_LINEAR_FUNCTION:
+        if (g.kind == QG_CX) return a == b ? 0u : make_op(OP_XOR, b, a);
+        if (g.kind == QG_SWAP) return a == b ? 0u : make_op(OP_SWAP, a, b);
+        return 0u;
+    case QG_PERMUTATION:
+        if (g.kind == QG_SWAP) return a == b ? 0u : make_op(OP_SWAP, a, b);
+        return 0u;
+    }
+    return 0u;
+}
+
+int ensure_scratch_public(qg_vec *v, size_t bytes) {
+    if (bytes <= v->scratch_bytes) return QG_OK;
+    if (v->scratch) {
+        if (hipDeviceSynchronize() != hipSuccess || hipFree(v->scratch) != hipSuccess) {
+            (void)hipGetLastError();
+            return set_error(QG_ERR_DEVICE, "scratch release failed");
+        }
+        v->scratch = nullptr;
+        v->scratch_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&v->scratch, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return set_error(QG_ERR_DEVICE, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    v->scratch_bytes = bytes;
+    return QG_OK;
+}
+
+}  // namespace qg
+
+using namespace qg;
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char *qg_last_error(void) { return g_err.c_str(); }
+int qg_abi_version(void) { return QG_ABI_VERSION; }
+
+int qg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+void qg_config_default(qg_config *c, int32_t env_kind, int32_t num_qubits) {
+    memset(c, 0, sizeof *c);
+    c->env_kind = env_kind;
+    c->num_qubits = num_qubits;
+    c->difficulty = 1;   // envs/synthesis.py:186
+    c->depth_slope = 2;  // :187
+    c->max_depth = 128;  // :188
+    c->w_n_cnots = 0.01f;       // metrics.rs:160
+    c->w_n_layers_cnots = 0.0f; // :161
+    c->w_n_layers = 0.0f;       // :162
+    c->w_n_gates = 0.0001f;     // :163
+    c->add_inverts = env_kind == QG_PAULI ? 0 : 1;  // clifford.rs:420 (PauliEnv has no inversion)
+    c->add_perms = 1;                               // clifford.rs:421
+    c->track_solution = 1;                          // clifford.rs:422
+    c->max_rotations = 5;                           // envs/synthesis.py:387
+    c->pauli_diff_scale = 16;                       // envs/synthesis.py:388 (Rust-side default 8)
+    c->final_pauli_layers = -1;                     // None -> max_rotations + 2 (pauli.rs:760)
+    c->num_qubits_decay = 0.5f;                     // pauli.rs:769
+    c->pauli_layer_reward = 0.01f;                  // pauli.rs:773
+}
+
+int qg_gate_parse(const char *name_in, const int64_t *idx, size_t n, qg_gate *out) {
+    if (!name_in || !out) return set_error(QG_ERR_TYPE, "Gate name must be a string");
+    std::string name(name_in);
+    size_t b = 0, e = name.size();
+    while (b < e && isspace((unsigned char)name[b])) ++b;
+    while (e > b && isspace((unsigned char)name[e - 1])) --e;
+    name = name.substr(b, e - b);  // common.rs:64 trim
+    std::string key = name;
+    for (auto &ch : key) ch = (char)tolower((unsigned char)ch);  // :65
+    for (size_t i = 0; i < n; ++i)
+        if (idx[i] < 0) return set_error(QG_ERR_TYPE, "Gate indices must be non-negative integers (usize)");
+    static const char *one_q[] = {"h", "s", "sdg", "sx", "sxdg"};
+    static const char *two_q[] = {"cx", "cz", "swap"};
+    for (int k = 0; k < 5; ++k)
+        if (key == one_q[k]) {
+            if (n != 1) return set_error(QG_ERR_INVALID, "Gate `%s` expects 1 index, got %zu", name.c_str(), n);
+            out->kind = k;
+            out->q0 = (int32_t)idx[0];
+            out->q1 = 0;
+            return QG_OK;
+        }
+    for (int k = 0; k < 3; ++k)
+        if (key == two_q[k]) {
+            if (n != 2) return set_error(QG_ERR_INVALID, "Gate `%s` expects 2 indices, got %zu", name.c_str(), n);
+            out->kind = 5 + k;
+            out->q0 = (int32_t)idx[0];
+            out->q1 = (int32_t)idx[1];
+            return QG_OK;
+        }
+    return set_error(QG_ERR_INVALID, "Unknown gate name `%s`. Allowed: H, S, Sdg, SX, SXdg, CX, CZ, SWAP", name.c_str());
+}
+
+// ------------------------------------------------------------------------------------------------
+// qg_vec
+// ------------------------------------------------------------------------------------------------
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            (void)hipGetLastError();                                                               \
+            return set_error(QG_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(_e));        \
+        }                                                                                          \
+    } while (0)
+
+static int vec_free_buffers(qg_vec *v) {
+    void *ptrs[] = {v->state, v->own_depth ? v->depth : nullptr, v->own_reward ? v->reward : nullptr,
+                    v->own_done ? v->done : nullptr, v->own_success ? v->success : nullptr, v->inverted, v->error, v->sol,
+                    v->sol_len, v->layers, v->d_gates, v->d_descs, v->scratch, v->rot, v->pmeta, v->d_prog};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto &g : v->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    v->graphs.clear();
+    if (v->capture_stream) (void)hipStreamDestroy(v->capture_stream);
+    return 0;
+}
+
+static int ensure_scratch(qg_vec *v, size_t bytes) { return qg::ensure_scratch_public(v, bytes); }
+
+static void fill_init_args(const qg_vec *v, InitArgs &a) {
+    memset(&a, 0, sizeof a);
+    a.state = v->state;
+    a.depth = v->depth;
+    a.reward = v->reward;
+    a.done = v->done;
+    a.success = v->success;
+    a.inverted = v->inverted;
+    a.error = v->error;
+    a.sol_len = v->sol_len;
+    a.layers = v->layers;
+    a.layers_len = v->layers_len;
+    a.gates = v->d_gates;
+    a.B = v->B;
+    a.D = v->D;
+    a.N = v->N;
+    a.log2L = v->log2L;
+    a.num_actions = (uint32_t)v->gates.size();
+}
+
+static hipError_t launch_init(const qg_vec *v, const InitArgs &a, hipStream_t s) {
+    switch (v->layout) {
+    case LAYOUT_ROWS32: return rows_init(a, false, s);
+    case LAYOUT_ROWS64: return rows_init(a, true, s);
+    case LAYOUT_LF8: return lf8_init(a, s);
+    case LAYOUT_PERM: return perm_init(a, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+static void fill_step_args(const qg_vec *v, StepArgs &a) {
+    memset(&a, 0, sizeof a);
+    a.state = v->state;
+    a.gates = v->d_gates;
+    a.descs = v->d_descs;
+    a.depth = v->depth;
+    a.reward = v->reward;
+    a.done = v->done;
+    a.success = v->success;
+    a.inverted = v->inverted;
+    a.error = v->error;
+    a.sol = v->sol;
+    a.sol_len = v->sol_len;
+    a.layers = v->layers;
+    a.B = v->B;
+    a.seed = v->coin_seed;
+    a.step_index = v->step_index;
+    a.D = v->D;
+    a.N = v->N;
+    a.log2L = v->log2L;
+    a.num_actions = (uint32_t)v->gates.size();
+    a.T = 1;
+    a.flags = v->flags;
+    a.sol_cap = v->sol_cap;
+    a.w[0] = v->cfg.w_n_cnots;
+    a.w[1] = v->cfg.w_n_layers_cnots;
+    a.w[2] = v->cfg.w_n_layers;
+    a.w[3] = v->cfg.w_n_gates;
+    a.pauli_layer_reward = v->cfg.pauli_layer_reward;
+    a.max_rotations = (uint32_t)v->cfg.max_rotations;
+}
+
+static hipError_t launch_step(const qg_vec *v, const StepArgs &a, hipStream_t s) {
+    switch (v->layout) {
+    case LAYOUT_ROWS32: return rows_step(a, false, s);
+    case LAYOUT_ROWS64: return rows_step(a, true, s);
+    case LAYOUT_LF8: return lf8_step(a, a.T > 1, s);
+    case LAYOUT_PERM: return perm_step(a, a.T > 1, s);
+    case LAYOUT_PAULI: return pauli_step(v, a, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, uint64_t batch, int device, qg_vec **out) {
+    if (!cfg || !out || (!gates && n_gates)) return set_error(QG_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->num_qubits <= 0) return set_error(QG_ERR_INVALID, "num_qubits must be positive");
+    if (cfg->max_depth < 0 || cfg->depth_slope < 0 || cfg->difficulty < 0)
+        return set_error(QG_ERR_INVALID, "difficulty, depth_slope and max_depth are usize in the reference");
+    if (batch == 0) return set_error(QG_ERR_INVALID, "batch must be positive");
+    const uint32_t N = (uint32_t)cfg->num_qubits;
+    for (size_t i = 0; i < n_gates; ++i) {
+        const qg_gate &g = gates[i];
+        if (g.kind < 0 || g.kind > QG_SWAP) return set_error(QG_ERR_INVALID, "gate %zu: unknown kind %d", i, g.kind);
+        bool two = g.kind >= QG_CX;
+        // the reference indexes rows by these qubits and would panic on the first step that uses them
+        if (g.q0 < 0 || (uint32_t)g.q0 >= N || (two && (g.q1 < 0 || (uint32_t)g.q1 >= N)))
+            return set_error(QG_ERR_INVALID, "gate %zu: qubit index out of range for %u qubits", i, N);
+    }
+
+    int ndev = qg_device_count();
+    if (ndev <= 0) return set_error(QG_ERR_DEVICE, "no HIP device visible: libqgym has no CPU fallback");
+    if (device < 0 || device >= ndev) return set_error(QG_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_error(QG_ERR_DEVICE, "device %d is %s; libqgym is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+
+    std::unique_ptr<qg_vec> v(new qg_vec());
+    v->cfg = *cfg;
+    v->gates.assign(gates, gates + n_gates);
+    v->B = batch;
+    v->N = N;
+    v->device = device;
+    v->difficulty = cfg->difficulty;
+    v->coin_seed = 0x5EED0000C01Full;
+
+    switch (cfg->env_kind) {
+    case QG_PERMUTATION:
+        if (N > 16) return set_error(QG_ERR_UNSUPPORTED, "PermutationEnv: N <= 16 supported (nibble-packed), got %u", N);
+        v->layout = LAYOUT_PERM;
+        v->D = N;
+        v->stride_bytes = 8;
+        break;
+    case QG_LINEAR_FUNCTION:
+        v->D = N;
+        if (N <= 8) {
+            v->layout = LAYOUT_LF8;
+            v->stride_bytes = 8;
+        } else if (N <= 64) {
+            v->layout = N <= 32 ? LAYOUT_ROWS32 : LAYOUT_ROWS64;
+        } else {
+            return set_error(QG_ERR_UNSUPPORTED, "LinearFunctionEnv: N <= 64 supported, got %u", N);
+        }
+        break;
+    case QG_CLIFFORD:
+        v->D = 2 * N;
+        if (N <= 16) v->layout = LAYOUT_ROWS32;
+        else if (N <= 32) v->layout = LAYOUT_ROWS64;
+        else return set_error(QG_ERR_UNSUPPORTED, "CliffordEnv: N <= 32 supported, got %u", N);
+        break;
+    case QG_PAULI:
+        v->D = 2 * N;
+        v->layout = LAYOUT_PAULI;
+        break;
+    default: return set_error(QG_ERR_INVALID, "unknown env_kind %d", cfg->env_kind);
+    }
+    if (v->layout == LAYOUT_ROWS32 || v->layout == LAYOUT_ROWS64) {
+        const uint32_t rpl = v->layout == LAYOUT_ROWS32 ? 4 : 2;
+        v->log2L = pow2ceil_log2((v->D + rpl - 1) / rpl);
+        v->stride_bytes = (size_t)16 << v->log2L;
+    }
+
+    // behaviour flags
+    v->flags = 0;
+    const bool inverts = cfg->add_inverts && cfg->env_kind != QG_PAULI;
+    if (inverts) v->flags |= F_INVERTS;
+    if (cfg->track_solution) v->flags |= F_TRACK;
+    const bool layers = !(cfg->w_n_layers == 0.0f && cfg->w_n_layers_cnots == 0.0f);
+    if (layers) v->flags |= F_LAYERS;
+
+    // gate table
+    std::vector<GateEntry> table(std::max<size_t>(n_gates, 1));
+    std::vector<uint32_t> descs(std::max<size_t>(n_gates, 1));
+    const float w[4] = {cfg->w_n_cnots, cfg->w_n_layers_cnots, cfg->w_n_layers, cfg->w_n_gates};
+    for (size_t i = 0; i < n_gates; ++i) {
+        int dc, dg;
+        gate_deltas(gates[i], N, dc, dg);
+        table[i].ops = cfg->env_kind == QG_PAULI ? 0u : gate_ops(cfg->env_kind, gates[i], N);
+        table[i].penalty = table_penalty(w, dc, dg);
+        descs[i] = make_desc((uint32_t)gates[i].kind, (uint32_t)gates[i].q0, (uint32_t)gates[i].q1);
+    }
+
+    qg_vec *p = v.get();
+    auto fail = [&](int rc) {
+        vec_free_buffers(p);
+        return rc;
+    };
+#define HIP_TRY_V(expr)                                                                            \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            (void)hipGetLastError();                                                               \
+            return fail(set_error(QG_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(_e)));  \
+        }                                                                                          \
+    } while (0)
+
+    if (v->layout == LAYOUT_PAULI) {
+        int rc = pauli_plan(p);
+        if (rc) return fail(rc);
+    }
+    HIP_TRY_V(hipMalloc(&p->state, p->stride_bytes * batch));
+    HIP_TRY_V(hipMalloc(&p->depth, sizeof(int32_t) * batch));
+    HIP_TRY_V(hipMalloc(&p->reward, sizeof(float) * batch));
+    HIP_TRY_V(hipMalloc(&p->done, batch));
+    HIP_TRY_V(hipMalloc(&p->success, batch));
+    HIP_TRY_V(hipMalloc(&p->inverted, batch));
+    HIP_TRY_V(hipMalloc(&p->error, sizeof(uint32_t) * batch));
+    HIP_TRY_V(hipMalloc(&p->sol_len, sizeof(int32_t) * 2 * batch));
+    if (cfg->track_solution) {
+        // Clifford/LF/Permutation push one entry per step; PauliEnv one per step plus one per removed rotation
+        p->sol_cap = (uint32_t)std::max(cfg->max_depth, 1);
+        if (v->layout == LAYOUT_PAULI) p->sol_cap += p->rmax;
+        HIP_TRY_V(hipMalloc(&p->sol, sizeof(uint32_t) * (size_t)p->sol_cap * batch));
+    }
+    if (layers) {
+        p->layers_len = 2 * N + 2;
+        HIP_TRY_V(hipMalloc(&p->layers, sizeof(int32_t) * (size_t)p->layers_len * batch));
+    }
+    HIP_TRY_V(hipMalloc(&p->d_gates, sizeof(GateEntry) * table.size()));
+    HIP_TRY_V(hipMalloc(&p->d_descs, sizeof(uint32_t) * descs.size()));
+    HIP_TRY_V(hipMemcpy(p->d_gates, table.data(), sizeof(GateEntry) * table.size(), hipMemcpyHostToDevice));
+    HIP_TRY_V(hipMemcpy(p->d_descs, descs.data(), sizeof(uint32_t) * descs.size(), hipMemcpyHostToDevice));
+    if (v->layout == LAYOUT_PAULI) {
+        int rc = pauli_alloc(p);
+        if (rc) return fail(rc);
+    }
+
+    // constructor state: identity, depth 1, success, reward 1.0 (clifford.rs:214-245)
+    if (v->layout == LAYOUT_PAULI) {
+        int rc = pauli_init_identity(p, nullptr);
+        if (rc) return fail(rc);
+    } else {
+        InitArgs ia;
+        fill_init_args(p, ia);
+        ia.mode = 0;
+        ia.depth_value = 1;
+        HIP_TRY_V(launch_init(p, ia, nullptr));
+    }
+    HIP_TRY_V(hipDeviceSynchronize());
+#undef HIP_TRY_V
+    *out = v.release();
+    return QG_OK;
+}
+
+void qg_vec_destroy(qg_vec *v) {
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    (void)hipDeviceSynchronize();
+    vec_free_buffers(v);
+    delete v;
+}
+
+int qg_vec_get_info(const qg_vec *v, qg_vec_info *o) {
+    if (!v || !o) return set_error(QG_ERR_INVALID, "null argument");
+    memset(o, 0, sizeof *o);
+    o->env_kind = v->cfg.env_kind;
+    o->num_qubits = (int32_t)v->N;
+    o->num_actions = (int32_t)v->gates.size();
+    switch (v->cfg.env_kind) {
+    case QG_CLIFFORD: o->obs_rows = o->obs_cols = (int32_t)(2 * v->N); break;  // clifford.rs:291-294
+    case QG_PAULI:                                                             // pauli.rs:505-507
+        o->obs_rows = (int32_t)(2 * v->N);
+        o->obs_cols = (int32_t)(2 * v->N + std::max(v->cfg.max_rotations, 1));
+        break;
+    default: o->obs_rows = o->obs_cols = (int32_t)v->N; break;
+    }
+    o->device = v->device;
+    o->batch = v->B;
+    o->packed_word_bytes = v->layout == LAYOUT_PERM ? 1 : ((v->layout == LAYOUT_ROWS64 || v->layout == LAYOUT_PAULI) ? 8 : 4);
+    o->packed_words_per_env = v->D;
+    o->packed_env_stride_bytes = v->stride_bytes;
+    o->state_dev = v->state;
+    o->reward_dev = v->reward;
+    o->done_dev = v->done;
+    o->success_dev = v->success;
+    o->depth_dev = v->depth;
+    o->error_dev = v->error;
+    return QG_OK;
+}
+
+static void drop_graphs(qg_vec *v) {
+    for (auto &g : v->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    v->graphs.clear();
+}
+
+int qg_vec_bind_outputs(qg_vec *v, float *reward_dev, uint8_t *done_dev, uint8_t *success_dev, int32_t *depth_dev) {
+    if (!v) return set_error(QG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(v->device));
+    HIP_TRY(hipDeviceSynchronize());
+    drop_graphs(v);  // cached graphs have the old pointers baked in
+    auto rebind = [&](auto *&cur, auto *ext, bool &own, size_t bytes) -> int {
+        if (!ext || ext == cur) return QG_OK;
+        HIP_TRY(hipMemcpy(ext, cur, bytes, hipMemcpyDeviceToDevice));
+        if (own) HIP_TRY(hipFree(cur));
+        cur = ext;
+        own = false;
+        return QG_OK;
+    };
+    int rc;
+    if ((rc = rebind(v->reward, reward_dev, v->own_reward, sizeof(float) * v->B))) return rc;
+    if ((rc = rebind(v->done, done_dev, v->own_done, v->B))) return rc;
+    if ((rc = rebind(v->success, success_dev, v->own_success, v->B))) return rc;
+    if ((rc = rebind(v->depth, depth_dev, v->own_depth, sizeof(int32_t) * v->B))) return rc;
+    return QG_OK;
+}
+
+int qg_vec_set_difficulty(qg_vec *v, int64_t d) {
+    if (!v || d < 0) return set_error(QG_ERR_INVALID, "bad difficulty");
+    v->difficulty = d;
+    return QG_OK;
+}
+int64_t qg_vec_get_difficulty(const qg_vec *v) { return v ? v->difficulty : -1; }
+
+static size_t format_elem_bytes(const qg_vec *v, int format) {
+    if (format == QG_FMT_I64) return 8;
+    if (format == QG_FMT_U8) return 1;
+    return v->layout == LAYOUT_PERM ? 1 : ((v->layout == LAYOUT_ROWS64 || v->layout == LAYOUT_PAULI) ? 8 : 4);
+}
+static size_t format_min_elems(const qg_vec *v, int format) {
+    if (v->layout == LAYOUT_PERM) return v->N;
+    if (format == QG_FMT_PACKED) return v->D;
+    return (size_t)v->D * v->D;
+}
+
+int qg_vec_set_state(qg_vec *v, const void *states, int format, size_t stride, int on_device, void *stream) {
+    if (!v || !states) return set_error(QG_ERR_INVALID, "null argument");
+    if (format < QG_FMT_I64 || format > QG_FMT_PACKED) return set_error(QG_ERR_INVALID, "unknown state format %d", format);
+    HIP_TRY(hipSetDevice(v->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (v->layout == LAYOUT_PAULI) return pauli_set_state(v, states, format, stride, on_device, s);
+    if (stride < format_min_elems(v, format))
+        return set_error(QG_ERR_INVALID, "set_state: %zu elements per env, need %zu (the reference would index out of bounds)",
+                         stride, format_min_elems(v, format));
+    const void *src = states;
+    if (!on_device) {
+        size_t bytes = format_elem_bytes(v, format) * stride * v->B;
+        int rc = ensure_scratch(v, bytes);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(v->scratch, states, bytes, hipMemcpyHostToDevice, s));
+        src = v->scratch;
+    }
+    InitArgs ia;
+    fill_init_args(v, ia);
+    ia.mode = 1;
+    ia.src = src;
+    ia.src_stride = stride;
+    ia.format = (uint32_t)format;
+    ia.depth_value = v->cfg.max_depth;  // clifford.rs:302
+    HIP_TRY(launch_init(v, ia, s));
+    if (!on_device) HIP_TRY(hipStreamSynchronize(s));  // the host buffer may be reused by the caller
+    return QG_OK;
+}
+
+static hipError_t launch_export(const qg_vec *v, const ObsArgs &a, hipStream_t s) {
+    switch (v->layout) {
+    case LAYOUT_ROWS32: return rows_export(a, false, s);
+    case LAYOUT_ROWS64: return rows_export(a, true, s);
+    case LAYOUT_LF8: return lf8_export(a, s);
+    case LAYOUT_PERM: return perm_export(a, s);
+    case LAYOUT_PAULI: return pauli_export(v, a, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+static void fill_obs_args(const qg_vec *v, ObsArgs &a, void *out, int format, size_t stride) {
+    memset(&a, 0, sizeof a);
+    a.state = v->state;
+    a.out = out;
+    a.B = v->B;
+    a.out_stride = stride;
+    a.D = v->D;
+    a.N = v->N;
+    a.log2L = v->log2L;
+    a.format = (uint32_t)format;
+    qg_vec_info info;
+    qg_vec_get_info(v, &info);
+    a.obs_rows = (uint32_t)info.obs_rows;
+    a.obs_cols = (uint32_t)info.obs_cols;
+}
+
+int qg_vec_get_state(qg_vec *v, void *out, int format, size_t stride, int on_device, void *stream) {
+    if (!v || !out) return set_error(QG_ERR_INVALID, "null argument");
+    if (format < QG_FMT_I64 || format > QG_FMT_PACKED) return set_error(QG_ERR_INVALID, "unknown state format %d", format);
+    if (stride < format_min_elems(v, format)) return set_error(QG_ERR_INVALID, "get_state: stride too small");
+    HIP_TRY(hipSetDevice(v->device));
+    hipStream_t s = (hipStream_t)stream;
+    void *dst = out;
+    size_t bytes = format_elem_bytes(v, format) * stride * v->B;
+    if (!on_device) {
+        int rc = ensure_scratch(v, bytes);
+        if (rc) return rc;
+        dst = v->scratch;
+    }
+    ObsArgs oa;
+    fill_obs_args(v, oa, dst, format, stride);
+    if (v->layout == LAYOUT_PAULI) {  // tableau only, square
+        oa.obs_cols = oa.obs_rows;
+    }
+    HIP_TRY(launch_export(v, oa, s));
+    if (!on_device) {
+        HIP_TRY(hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return QG_OK;
+}
+
+static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint64_t seed, hipStream_t s) {
+    HIP_TRY(hipSetDevice(v->device));
+    if (v->layout == LAYOUT_PAULI)
+        return set_error(QG_ERR_UNSUPPORTED, "PauliEnv reset needs a generated target: use qg_vec_pauli_reset_from");
+    if (v->gates.empty() && n_draws)  // Uniform::new(0, 0) panics in the reference
+        return set_error(QG_ERR_PANIC, "reset with an empty gateset (the reference panics in Uniform::new(0, 0))");
+    InitArgs ia;
+    fill_init_args(v, ia);
+    ia.mode = 2;
+    ia.actions = actions_dev;
+    ia.n_draws = (uint32_t)n_draws;
+    ia.seed = seed;
+    int64_t d = (int64_t)v->cfg.depth_slope * v->difficulty;  // clifford.rs:317
+    ia.depth_value = (int32_t)std::min<int64_t>(d, v->cfg.max_depth);
+    HIP_TRY(launch_init(v, ia, s));
+    return QG_OK;
+}
+
+int qg_vec_reset(qg_vec *v, uint64_t seed, void *stream) {
+    if (!v) return set_error(QG_ERR_INVALID, "null argument");
+    return do_reset(v, nullptr, (size_t)v->difficulty, seed, (hipStream_t)stream);
+}
+int qg_vec_reset_with(qg_vec *v, const int32_t *actions_dev, size_t n_draws, void *stream) {
+    if (!v || (!actions_dev && n_draws)) return set_error(QG_ERR_INVALID, "null argument");
+    if ((int64_t)n_draws != v->difficulty)
+        return set_error(QG_ERR_INVALID, "reset_with: need exactly `difficulty` (%lld) draws per env, got %zu",
+                         (long long)v->difficulty, n_draws);
+    return do_reset(v, actions_dev, n_draws, 0, (hipStream_t)stream);
+}
+
+int qg_vec_step(qg_vec *v, const void *actions_dev, int action_dtype, const uint8_t *coins_dev, void *stream) {
+    if (!v || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
+    if (action_dtype != QG_ACT_I32 && action_dtype != QG_ACT_I64) return set_error(QG_ERR_INVALID, "bad action dtype");
+    HIP_TRY(hipSetDevice(v->device));
+    StepArgs a;
+    fill_step_args(v, a);
+    a.actions = actions_dev;
+    a.coins = coins_dev;
+    if (action_dtype == QG_ACT_I64) a.flags |= F_ACT64;
+    HIP_TRY(launch_step(v, a, (hipStream_t)stream));
+    v->step_index += 1;
+    return QG_OK;
+}
+
+int qg_vec_rollout(qg_vec *v, const void *actions_dev, int action_dtype, size_t T, const uint8_t *coins_dev,
+                   float *rewards_dev, uint8_t *dones_dev, int fused, void *stream) {
+    if (!v || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
+    if (action_dtype != QG_ACT_I32 && action_dtype != QG_ACT_I64) return set_error(QG_ERR_INVALID, "bad action dtype");
+    if (T == 0) return QG_OK;
+    if (T > 0x7fffffffu) return set_error(QG_ERR_INVALID, "too many steps");
+    HIP_TRY(hipSetDevice(v->device));
+    hipStream_t s = (hipStream_t)stream;
+    StepArgs a;
+    fill_step_args(v, a);
+    a.actions = actions_dev;
+    a.coins = coins_dev;
+    a.rewards_seq = rewards_dev;
+    a.dones_seq = dones_dev;
+    if (action_dtype == QG_ACT_I64) a.flags |= F_ACT64;
+    if (fused) {
+        a.T = (uint32_t)T;
+        HIP_TRY(launch_step(v, a, s));
+        v->step_index += T;
+        return QG_OK;
+    }
+    const size_t act_bytes = action_dtype == QG_ACT_I64 ? 8 : 4;
+    auto enqueue_steps = [&](hipStream_t st) -> hipError_t {
+        for (size_t t = 0; t < T; ++t) {
+            StepArgs b = a;
+            b.T = 1;
+            b.actions = (const char *)actions_dev + t * v->B * act_bytes;
+            b.coins = coins_dev ? coins_dev + t * v->B : nullptr;
+            b.rewards_seq = rewards_dev ? rewards_dev + t * v->B : nullptr;
+            b.dones_seq = dones_dev ? dones_dev + t * v->B : nullptr;
+            b.step_index = v->step_index + t;
+            hipError_t e = launch_step(v, b, st);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    };
+    // A graph bakes kernel arguments in: the counter-RNG coin path changes per call, and a stream
+    // that is already being captured by the caller must not be captured again.
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s) (void)hipStreamIsCapturing(s, &cs);
+    const bool rng_coins = (v->flags & F_INVERTS) && !coins_dev;
+    if (cs != hipStreamCaptureStatusNone || rng_coins || T == 1) {
+        HIP_TRY(enqueue_steps(s));
+        v->step_index += T;
+        return QG_OK;
+    }
+    GraphKey key{actions_dev, coins_dev, rewards_dev, dones_dev, T, action_dtype};
+    CachedGraph *cg = nullptr;
+    for (auto &g : v->graphs)
+        if (g.key == key) cg = &g;
+    if (!cg) {
+        if (!v->capture_stream) HIP_TRY(hipStreamCreateWithFlags(&v->capture_stream, hipStreamNonBlocking));
+        CachedGraph ng;
+        ng.key = key;
+        HIP_TRY(hipStreamBeginCapture(v->capture_stream, hipStreamCaptureModeThreadLocal));
+        hipError_t e = enqueue_steps(v->capture_stream);
+        hipError_t e2 = hipStreamEndCapture(v->capture_stream, &ng.graph);
+        if (e != hipSuccess || e2 != hipSuccess) {
+            (void)hipGetLastError();
+            if (ng.graph) (void)hipGraphDestroy(ng.graph);
+            return set_error(QG_ERR_DEVICE, "graph capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        }
+        HIP_TRY(hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0));
+        if (v->graphs.size() >= 8) {  // small LRU-less cache: drop the oldest
+            (void)hipGraphExecDestroy(v->graphs.front().exec);
+            (void)hipGraphDestroy(v->graphs.front().graph);
+            v->graphs.erase(v->graphs.begin());
+        }
+        v->graphs.push_back(ng);
+        cg = &v->graphs.back();
+    }
+    HIP_TRY(hipGraphLaunch(cg->exec, s));
+    v->step_index += T;
+    return QG_OK;
+}
+
+int qg_vec_observe_dense(qg_vec *v, int8_t *out_dev, void *stream) {
+    if (!v || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(v->device));
+    ObsArgs oa;
+    qg_vec_info info;
+    qg_vec_get_info(v, &info);
+    fill_obs_args(v, oa, out_dev, QG_FMT_U8, (size_t)info.obs_rows * info.obs_cols);
+    HIP_TRY(launch_export(v, oa, (hipStream_t)stream));
+    return QG_OK;
+}
+
+int qg_vec_observe_packed(qg_vec *v, void *out_dev, void *stream) {
+    if (!v || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(v->device));
+    if (v->layout == LAYOUT_PAULI) return set_error(QG_ERR_UNSUPPORTED, "packed observation of PauliEnv: use observe_dense");
+    const bool rows = v->layout == LAYOUT_ROWS32 || v->layout == LAYOUT_ROWS64;
+    const size_t word = v->layout == LAYOUT_ROWS64 ? 8 : 4;
+    if (rows && v->stride_bytes == (size_t)v->D * word) {  // no padding: the resident state is the packed observation
+        HIP_TRY(hipMemcpyAsync(out_dev, v->state, v->stride_bytes * v->B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return QG_OK;
+    }
+    ObsArgs oa;
+    fill_obs_args(v, oa, out_dev, QG_FMT_PACKED, format_min_elems(v, QG_FMT_PACKED));
+    HIP_TRY(launch_export(v, oa, (hipStream_t)stream));
+    return QG_OK;
+}
+
+int qg_vec_masks(qg_vec *v, uint8_t *out_dev, void *stream) {
+    if (!v || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(v->device));
+    HIP_TRY(masks_fill(v->success, out_dev, v->B, (uint32_t)v->gates.size(), (hipStream_t)stream));
+    return QG_OK;
+}
+
+int qg_vec_pauli_reset_from(qg_vec *v, const uint8_t *tableaus, const char *labels, const int32_t *n_rot, void *stream) {
+    if (!v || !tableaus || !n_rot) return set_error(QG_ERR_INVALID, "null argument");
+    if (v->layout != LAYOUT_PAULI) return set_error(QG_ERR_INVALID, "not a PauliEnv batch");
+    HIP_TRY(hipSetDevice(v->device));
+    return pauli_reset_from(v, tableaus, labels, n_rot, (hipStream_t)stream);
+}
+
+int qg_vec_sync(qg_vec *v, void *stream) {
+    if (!v) return set_error(QG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(v->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    std::vector<uint32_t> err(v->B);
+    HIP_TRY(hipMemcpy(err.data(), v->error, sizeof(uint32_t) * v->B, hipMemcpyDeviceToHost));
+    for (uint64_t e = 0; e < v->B; ++e)
+        if (err[e]) {
+            const char *what = (err[e] & QG_FAULT_SINGULAR)      ? "singular matrix in inverse() (reference panics, clifford.rs:155)"
+                               : (err[e] & QG_FAULT_ZERO_WEIGHT) ? "weight-0 rotation in the front layer (reference panics, pauli_network.rs:114)"
+                               : (err[e] & QG_FAULT_BAD_STATE)   ? "set_state produced an unusable state"
+                                                                 : "solution log overflow";
+            return set_error(QG_ERR_PANIC, "env %llu: %s (fault bits 0x%x)", (unsigned long long)e, what, err[e]);
+        }
+    return QG_OK;
+}
+
+int64_t qg_vec_solution(qg_vec *v, uint64_t env, uint64_t *out, size_t cap) {
+    if (!v) return set_error(QG_ERR_INVALID, "null argument");
+    if (env >= v->B) return set_error(QG_ERR_INVALID, "env index out of range");
+    if (!v->cfg.track_solution) return 0;
+    if (hipSetDevice(v->device) != hipSuccess) return set_error(QG_ERR_DEVICE, "hipSetDevice failed");
+    int32_t len[2];
+    std::vector<uint32_t> row(v->sol_cap);
+    if (hipMemcpy(len, v->sol_len + env * 2, sizeof len, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(row.data(), v->sol + env * v->sol_cap, sizeof(uint32_t) * v->sol_cap, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return set_error(QG_ERR_DEVICE, "solution copy failed");
+    }
+    // solution ++ reverse(solution_inv) (clifford.rs:376-381): the inverse-frame pushes were
+    // written from the back of the row, so reading the tail forwards is the reversed list.
+    size_t n = 0;
+    for (int32_t i = 0; i < len[0]; ++i, ++n)
+        if (n < cap && out) out[n] = row[i];
+    for (uint32_t i = v->sol_cap - (uint32_t)len[1]; i < v->sol_cap; ++i, ++n)
+        if (n < cap && out) out[n] = row[i];
+    return (int64_t)n;
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+// qgym_host.hpp -- host-side handle of a batched env (private to libqgym).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "qgym_internal.hpp"
+
+namespace qg {
+
+enum Layout { LAYOUT_ROWS32 = 0, LAYOUT_ROWS64 = 1, LAYOUT_LF8 = 2, LAYOUT_PERM = 3, LAYOUT_PAULI = 4 };
+
+struct GraphKey {
+    const void *actions;
+    const void *coins;
+    const void *rewards;
+    const void *dones;
+    size_t T;
+    int dtype;
+    bool operator==(const GraphKey &o) const {
+        return actions == o.actions && coins == o.coins && rewards == o.rewards && dones == o.dones && T == o.T &&
+               dtype == o.dtype;
+    }
+};
+struct CachedGraph {
+    GraphKey key{};
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+int set_error(int code, const char *fmt, ...);
+
+}  // namespace qg
+
+struct qg_vec {
+    qg_config cfg{};
+    std::vector<qg_gate> gates;
+    uint64_t B = 0;
+    uint32_t N = 0, D = 0, log2L = 0;
+    int device = 0;
+    qg::Layout layout = qg::LAYOUT_ROWS32;
+    size_t stride_bytes = 0;
+    uint32_t flags = 0;
+    int64_t difficulty = 1;
+    uint64_t coin_seed = 0;
+    uint64_t step_index = 0;
+
+    // device buffers
+    void *state = nullptr;
+    int32_t *depth = nullptr;
+    float *reward = nullptr;
+    uint8_t *done = nullptr;
+    uint8_t *success = nullptr;
+    uint8_t *inverted = nullptr;
+    uint32_t *error = nullptr;
+    uint32_t *sol = nullptr;
+    int32_t *sol_len = nullptr;
+    int32_t *layers = nullptr;
+    qg::GateEntry *d_gates = nullptr;
+    uint32_t *d_descs = nullptr;
+    uint32_t sol_cap = 0;
+    uint32_t layers_len = 0;
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    bool own_reward = true, own_done = true, own_success = true, own_depth = true;
+
+    // PauliEnv (kernels_pauli.hip)
+    void *rot = nullptr;     // [B][rmax] 16-byte rotation records
+    void *pmeta = nullptr;   // [B] per-env rotation bookkeeping (alive mask, node order, count)
+    void *d_prog = nullptr;  // [num_actions] micro-programs
+    uint32_t rmax = 0;
+
+    // rollout graphs
+    std::vector<qg::CachedGraph> graphs;
+    hipStream_t capture_stream = nullptr;
+};
+
+namespace qg {
+int ensure_scratch_public(qg_vec *v, size_t bytes);
+void compute_qubit_and_action_perms(uint32_t N, const std::vector<qg_gate> &gates, std::vector<std::vector<int64_t>> &qubit_perms,
+                                    std::vector<std::vector<int64_t>> &act_perms);
+// PauliEnv host hooks (kernels_pauli.hip)
+int pauli_plan(qg_vec *v);
+int pauli_alloc(qg_vec *v);
+int pauli_init_identity(qg_vec *v, hipStream_t s);
+int pauli_set_state(qg_vec *v, const void *states, int format, size_t stride, int on_device, hipStream_t s);
+int pauli_reset_from(qg_vec *v, const uint8_t *tableaus, const char *labels, const int32_t *n_rot, hipStream_t s);
+hipError_t pauli_step(const qg_vec *v, const StepArgs &a, hipStream_t s);
+hipError_t pauli_export(const qg_vec *v, const ObsArgs &a, hipStream_t s);
+}  // namespace qg

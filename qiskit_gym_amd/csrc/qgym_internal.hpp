@@ -1,0 +1,159 @@
+// qgym_internal.hpp -- shared host/device definitions of libqgym (gfx950 only).
+//
+// Resident state layouts (also documented in DESIGN.md section 3):
+//
+//  ROWS layout  (CliffordEnv any N<=32, LinearFunctionEnv N>8): the GF(2) matrix of one env is D
+//    rows (D = 2N Clifford, N LinearFunction) in the reference's row order, one machine word per
+//    row (uint32 when D<=32, else uint64), bit c = entry (r, c).  A lane owns 16 contiguous bytes
+//    (RPL = 4 uint32 rows or 2 uint64 rows); an env is L = pow2ceil(ceil(D/RPL)) lanes, padded
+//    with zero rows, so env e starts at byte e*L*16 and a wavefront's load is one fully
+//    coalesced 1 KiB transaction covering 64/L envs.  CliffordEnv N=16: D=32, L=8, 128 B/env,
+//    no padding -- the resident state IS the packed observation.
+//  LF8 layout   (LinearFunctionEnv N<=8): one uint64 per env, byte r = row r.
+//  PERM layout  (PermutationEnv N<=16): one uint64 per env, nibble i = state[i].
+//  PAULI layout (PauliEnv N<=32): lane q owns qubit q's tableau rows {X row q, Z row N+q} as two
+//    uint64 (16 B), 32 lanes per env; rotations are 16-byte records {x mask, z mask, phase,
+//    predecessor mask}, RMAX per env, owned by lanes 0..RMAX-1.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/qgym.h"
+
+namespace qg {
+
+// ---- gate table entry: what one action does to the rows, plus its reward penalty ----------
+// ops: two row operations, 14 bits each: [0:6) dst row, [6:12) src row, [12:14) type.
+//   type 0 = none, 1 = dst ^= src, 2 = swap(dst, src).
+// The host guarantees the two operations touch disjoint rows (clifford.rs:111-133: CX, CZ and
+// SWAP with distinct qubits always do), so they commute.
+// For PauliEnv `ops` holds the micro-program instead (see kernels_pauli.hip).
+struct GateEntry {
+    uint32_t ops;
+    float penalty;  // metrics-weighted penalty of this action (metrics.rs:135-146), f32
+};
+static_assert(sizeof(GateEntry) == 8, "GateEntry must be 8 bytes");
+
+enum : uint32_t { OP_NONE = 0, OP_XOR = 1, OP_SWAP = 2 };
+__host__ __device__ inline uint32_t make_op(uint32_t type, uint32_t dst, uint32_t src) {
+    return (dst & 63u) | ((src & 63u) << 6) | ((type & 3u) << 12);
+}
+
+// gate descriptor for the F_LAYERS metrics path and PauliEnv: kind | q0 << 8 | q1 << 16
+__host__ __device__ inline uint32_t make_desc(uint32_t kind, uint32_t q0, uint32_t q1) {
+    return (kind & 0xFFu) | ((q0 & 0xFFu) << 8) | ((q1 & 0xFFu) << 16);
+}
+
+// step-kernel behaviour flags
+enum : uint32_t {
+    F_ACT64 = 1u << 0,     // actions are int64
+    F_INVERTS = 1u << 1,   // add_inverts (clifford.rs:262-270)
+    F_TRACK = 1u << 2,     // track_solution (clifford.rs:334-340)
+    F_LAYERS = 1u << 3,    // non-zero n_layers / n_layers_cnots weights: track per-qubit layers
+    F_PERM_ORDER = 1u << 4 // PermutationEnv step order (invert before depth, push only if valid)
+};
+
+// counter RNG shared by host, device and the tests
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline uint64_t rng_draw(uint64_t seed, uint64_t env, uint64_t t) {
+    return splitmix64(seed ^ splitmix64(env * 0x9E3779B97F4A7C15ull + t));
+}
+__host__ __device__ inline uint32_t rng_action(uint64_t seed, uint64_t env, uint64_t t, uint32_t num_actions) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__umul64hi(rng_draw(seed, env, t), (uint64_t)num_actions);
+#else
+    return (uint32_t)(((unsigned __int128)rng_draw(seed, env, t) * (unsigned __int128)num_actions) >> 64);
+#endif
+}
+
+// Per-step / per-rollout kernel arguments common to every env kind.
+struct StepArgs {
+    void *state;
+    const void *actions;      // [T][B]
+    const uint8_t *coins;     // [T][B] or null
+    const GateEntry *gates;   // [num_actions]
+    const uint32_t *descs;    // [num_actions] kind | q0<<8 | q1<<16 (F_LAYERS, PauliEnv)
+    int32_t *depth;
+    float *reward;
+    uint8_t *done;
+    uint8_t *success;
+    uint8_t *inverted;
+    uint32_t *error;
+    uint32_t *sol;            // [B][sol_cap] solution log (front: solution, back: solution_inv)
+    int32_t *sol_len;         // [B][2]
+    int32_t *layers;          // F_LAYERS: [B][2N + 2] last_gates, last_cxs, then (n_layers, n_layers_cnots)
+    float *rewards_seq;       // [T][B] or null
+    uint8_t *dones_seq;       // [T][B] or null
+    uint64_t B;
+    uint64_t seed;            // counter-RNG seed for coins when coins == null
+    uint64_t step_index;      // number of steps taken since creation (RNG counter)
+    uint32_t D;               // rows (ROWS layout) / N (LF8, PERM)
+    uint32_t N;               // qubits
+    uint32_t log2L;
+    uint32_t num_actions;
+    uint32_t T;
+    uint32_t flags;
+    uint32_t sol_cap;
+    float w[4];               // MetricsWeights, F_LAYERS only
+    float pauli_layer_reward;
+    uint32_t max_rotations;
+};
+
+// state (re)initialisation
+struct InitArgs {
+    void *state;
+    int32_t *depth;
+    float *reward;
+    uint8_t *done;
+    uint8_t *success;
+    uint8_t *inverted;
+    uint32_t *error;
+    int32_t *sol_len;
+    int32_t *layers;
+    const GateEntry *gates;
+    const int32_t *actions;   // reset_with draws [n_draws][B] or null (use RNG)
+    const void *src;          // set_state source
+    uint64_t src_stride;      // elements per env in src
+    uint64_t B;
+    uint64_t seed;
+    uint32_t D, N, log2L, num_actions;
+    uint32_t n_draws;
+    int32_t depth_value;
+    uint32_t format;          // qg_state_format
+    uint32_t mode;            // 0 identity, 1 set_state, 2 scramble
+    uint32_t layers_len;
+};
+
+struct ObsArgs {
+    const void *state;
+    void *out;
+    uint64_t B;
+    uint64_t out_stride;      // elements per env in out
+    uint32_t D, N, log2L;
+    uint32_t format;          // qg_state_format (U8 -> int8 dense, I64, PACKED)
+    uint32_t obs_rows, obs_cols;
+};
+
+// launchers (one translation unit per layout)
+hipError_t rows_step(const StepArgs &a, bool word64, hipStream_t s);
+hipError_t rows_rollout_fused(const StepArgs &a, bool word64, hipStream_t s);
+hipError_t rows_init(const InitArgs &a, bool word64, hipStream_t s);
+hipError_t rows_export(const ObsArgs &a, bool word64, hipStream_t s);
+
+hipError_t lf8_step(const StepArgs &a, bool fused, hipStream_t s);
+hipError_t lf8_init(const InitArgs &a, hipStream_t s);
+hipError_t lf8_export(const ObsArgs &a, hipStream_t s);
+
+hipError_t perm_step(const StepArgs &a, bool fused, hipStream_t s);
+hipError_t perm_init(const InitArgs &a, hipStream_t s);
+hipError_t perm_export(const ObsArgs &a, hipStream_t s);
+
+hipError_t masks_fill(const uint8_t *success, uint8_t *out, uint64_t B, uint32_t num_actions, hipStream_t s);
+
+}  // namespace qg

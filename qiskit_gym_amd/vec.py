@@ -1,0 +1,200 @@
+"""VecEnv -- B independent synthesis environments resident on one MI355X.
+
+The batched counterpart of the reference's scalar env objects (`qiskit_gym_rs.CliffordEnv` etc.,
+reference rust/src/envs/clifford.rs:285-382): same method names, every method acting on the whole
+batch, tensors in and out.  All state lives in HBM behind the C ABI (`include/qgym.h`); this class
+only marshals pointers.  torch is used for device memory and streams, nothing else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .envs.gateset import parse_gateset
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class VecEnv:
+    """`batch` copies of one env kind (`"clifford" | "linear_function" | "permutation" | "pauli"`)."""
+
+    def __init__(self, env_kind: str, num_qubits: int, gateset: Sequence, batch: int, device: int | None = None,
+                 metrics_weights: dict | None = None, **config):
+        if not torch.cuda.is_available():
+            raise RuntimeError("qiskit_gym_amd.VecEnv needs a ROCm GPU (MI355X / gfx950); there is no CPU fallback")
+        self._L = _lib.load()
+        self.env_kind = env_kind
+        self.num_qubits = int(num_qubits)
+        self.gateset = [(g[0], tuple(int(q) for q in g[1])) for g in gateset]
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.batch = int(batch)
+        self._cfg = _lib.make_config(env_kind, num_qubits, metrics_weights=metrics_weights, **config)
+        self._gates = _lib.make_gates(parse_gateset(self.gateset))
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.qg_vec_create(C.byref(self._cfg), self._gates, len(self.gateset), self.batch,
+                                             self.device_index, C.byref(h)))
+        self._h = h
+        info = _lib.QGVecInfo()
+        _lib.check(self._L.qg_vec_get_info(self._h, C.byref(info)))
+        self.num_actions_ = info.num_actions
+        self.obs_shape_ = (info.obs_rows, info.obs_cols)
+        self.packed_word_bytes = info.packed_word_bytes
+        self.packed_words_per_env = info.packed_words_per_env
+        # result arrays live in torch tensors bound into the handle (zero-copy for the learner)
+        self.reward = torch.empty(self.batch, dtype=torch.float32, device=self.device)
+        self.done = torch.empty(self.batch, dtype=torch.uint8, device=self.device)
+        self.success = torch.empty(self.batch, dtype=torch.uint8, device=self.device)
+        self.depth = torch.empty(self.batch, dtype=torch.int32, device=self.device)
+        _lib.check(self._L.qg_vec_bind_outputs(self._h, self.reward.data_ptr(), self.done.data_ptr(),
+                                               self.success.data_ptr(), self.depth.data_ptr()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.qg_vec_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- Env trait, batched -------------------------------------------------------------------
+    def num_actions(self) -> int:
+        return self.num_actions_
+
+    def obs_shape(self):
+        return list(self.obs_shape_)
+
+    @property
+    def difficulty(self) -> int:
+        return int(self._L.qg_vec_get_difficulty(self._h))
+
+    @difficulty.setter
+    def difficulty(self, d: int):
+        _lib.check(self._L.qg_vec_set_difficulty(self._h, int(d)))
+
+    def set_state(self, states, fmt: str = "i64"):
+        """states: [B, n] tensor/array in the trait's `Vec<i64>` wire format (`fmt="i64"`), dense
+        0/1 bytes (`"u8"`) or bit-packed rows (`"packed"`)."""
+        code = {"i64": _lib.FMT_I64, "u8": _lib.FMT_U8, "packed": _lib.FMT_PACKED}[fmt]
+        if isinstance(states, torch.Tensor) and states.is_cuda:
+            t = states.contiguous().view(self.batch, -1)
+            _lib.check(self._L.qg_vec_set_state(self._h, t.data_ptr(), code, t.shape[1], 1, _stream_ptr()))
+            return
+        dt = {"i64": np.int64, "u8": np.uint8}.get(fmt)
+        if dt is None:
+            dt = {1: np.uint8, 4: np.uint32, 8: np.uint64}[self.packed_word_bytes]
+        a = np.ascontiguousarray(np.asarray(states.cpu() if isinstance(states, torch.Tensor) else states, dtype=dt)).reshape(self.batch, -1)
+        _lib.check(self._L.qg_vec_set_state(self._h, a.ctypes.data, code, a.shape[1], 0, _stream_ptr()))
+
+    def get_state(self, fmt: str = "i64") -> torch.Tensor:
+        code = {"i64": _lib.FMT_I64, "u8": _lib.FMT_U8, "packed": _lib.FMT_PACKED}[fmt]
+        if self.env_kind == "permutation":
+            n = self.num_qubits
+        elif fmt == "packed":
+            n = self.packed_words_per_env
+        else:
+            d = self.obs_shape_[0]
+            n = d * d
+        dt = {"i64": torch.int64, "u8": torch.uint8}.get(fmt)
+        if dt is None:
+            dt = {1: torch.uint8, 4: torch.int32, 8: torch.int64}[self.packed_word_bytes]
+        out = torch.empty((self.batch, n), dtype=dt, device=self.device)
+        _lib.check(self._L.qg_vec_get_state(self._h, out.data_ptr(), code, n, 1, _stream_ptr()))
+        return out
+
+    def reset(self, seed: int = 0):
+        _lib.check(self._L.qg_vec_reset(self._h, int(seed) & (2**64 - 1), _stream_ptr()))
+
+    def reset_with(self, actions: torch.Tensor):
+        """actions: int32 [difficulty, B] scramble draws (the reference's reset() RNG made explicit)."""
+        a = actions.to(device=self.device, dtype=torch.int32).contiguous().view(-1, self.batch)
+        _lib.check(self._L.qg_vec_reset_with(self._h, a.data_ptr(), a.shape[0], _stream_ptr()))
+
+    def _act(self, actions: torch.Tensor) -> Tuple[int, int]:
+        if actions.device != self.device:
+            raise ValueError("actions must live on the env's device")
+        if actions.dtype == torch.int32:
+            return actions.data_ptr(), _lib.ACT_I32
+        if actions.dtype == torch.int64:
+            return actions.data_ptr(), _lib.ACT_I64
+        raise TypeError("actions must be int32 or int64")
+
+    def step(self, actions: torch.Tensor, coins: Optional[torch.Tensor] = None):
+        """One env.step() for every env: one kernel launch.  Returns (reward, done) views."""
+        actions = actions.contiguous()
+        ptr, dt = self._act(actions)
+        cp = None
+        if coins is not None:
+            coins = coins.to(device=self.device, dtype=torch.uint8).contiguous()
+            cp = coins.data_ptr()
+        _lib.check(self._L.qg_vec_step(self._h, ptr, dt, cp, _stream_ptr()))
+        return self.reward, self.done
+
+    def rollout(self, actions: torch.Tensor, fused: bool = False, coins: Optional[torch.Tensor] = None,
+                rewards_out: Optional[torch.Tensor] = None, dones_out: Optional[torch.Tensor] = None):
+        """actions [T, B].  fused=False: T single-step launches replayed from a hipGraph;
+        fused=True: one launch with the state held in registers across the T steps."""
+        actions = actions.contiguous()
+        T = actions.shape[0]
+        ptr, dt = self._act(actions)
+        cp = None
+        if coins is not None:
+            coins = coins.to(device=self.device, dtype=torch.uint8).contiguous()
+            cp = coins.data_ptr()
+        rp = rewards_out.data_ptr() if rewards_out is not None else None
+        dp = dones_out.data_ptr() if dones_out is not None else None
+        _lib.check(self._L.qg_vec_rollout(self._h, ptr, dt, T, cp, rp, dp, 1 if fused else 0, _stream_ptr()))
+        return self.reward, self.done
+
+    def observe(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Dense int8 observation [B, rows, cols] (the Gym adapter's `_full_obs`, adapters.py:50-54)."""
+        r, c = self.obs_shape_
+        if out is None:
+            out = torch.empty((self.batch, r, c), dtype=torch.int8, device=self.device)
+        _lib.check(self._L.qg_vec_observe_dense(self._h, out.data_ptr(), _stream_ptr()))
+        return out
+
+    def observe_packed(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Bit-packed observation [B, D] words (what the multi-GPU all-gather moves)."""
+        dt = {1: torch.uint8, 4: torch.int32, 8: torch.int64}[self.packed_word_bytes]
+        if out is None:
+            out = torch.empty((self.batch, self.packed_words_per_env), dtype=dt, device=self.device)
+        _lib.check(self._L.qg_vec_observe_packed(self._h, out.data_ptr(), _stream_ptr()))
+        return out
+
+    def masks(self) -> torch.Tensor:
+        out = torch.empty((self.batch, self.num_actions_), dtype=torch.uint8, device=self.device)
+        _lib.check(self._L.qg_vec_masks(self._h, out.data_ptr(), _stream_ptr()))
+        return out
+
+    def pauli_reset_from(self, tableaus: np.ndarray, labels: Sequence[Sequence[str]]):
+        t = np.ascontiguousarray(np.asarray(tableaus, dtype=np.uint8).reshape(self.batch, -1))
+        n_rot = np.ascontiguousarray(np.array([len(l) for l in labels], dtype=np.int32))
+        blob = "".join("".join(l) for l in labels).encode()
+        _lib.check(self._L.qg_vec_pauli_reset_from(self._h, t.ctypes.data, blob, n_rot.ctypes.data, _stream_ptr()))
+
+    def sync(self):
+        """Wait for the current stream and raise if any env hit a fault the reference panics on."""
+        _lib.check(self._L.qg_vec_sync(self._h, _stream_ptr()))
+
+    def solution(self, env: int):
+        n = self._L.qg_vec_solution(self._h, env, None, 0)
+        if n < 0:
+            _lib.check(int(n))
+        buf = (C.c_uint64 * max(int(n), 1))()
+        self._L.qg_vec_solution(self._h, env, buf, int(n))
+        return [int(buf[i]) for i in range(int(n))]
+
+
+def make_vec(env_cls_or_kind, *args, **kwargs) -> VecEnv:  # convenience used by bench/tests
+    return VecEnv(env_cls_or_kind, *args, **kwargs)

@@ -1,0 +1,195 @@
+"""GPU parity: the HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact on every integer/byte output (state, success, is_final, depth, observation,
+solution) and on the f32 reward bit pattern (the path's only floating-point value).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from util import f32_bits, grid_gateset, line_gateset, make_pair, rng_actions  # noqa: E402
+
+
+def _dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    return t.to(dtype) if dtype is not None else t
+
+
+def _compare_step(ov, gv, actions, coins=None, label=""):
+    r_o, s_o, f_o, d_o = ov.step(actions, coins)
+    gv.step(_dev(actions, torch.int32), None if coins is None else _dev(coins, torch.uint8))
+    gv.sync()
+    np.testing.assert_array_equal(f32_bits(gv.reward.cpu().numpy()), f32_bits(r_o), err_msg=f"reward {label}")
+    np.testing.assert_array_equal(gv.success.cpu().numpy(), s_o, err_msg=f"success {label}")
+    np.testing.assert_array_equal(gv.done.cpu().numpy(), f_o, err_msg=f"is_final {label}")
+    np.testing.assert_array_equal(gv.depth.cpu().numpy(), d_o, err_msg=f"depth {label}")
+
+
+def _compare_state(ov, gv, per_env, label=""):
+    np.testing.assert_array_equal(gv.get_state("i64").cpu().numpy(), ov.get_state(per_env), err_msg=f"state {label}")
+    np.testing.assert_array_equal(gv.observe().cpu().numpy().reshape(gv.batch, -1), ov.observe_dense(), err_msg=f"obs {label}")
+
+
+def _scramble(ov, gv, rng, n_draws, num_actions):
+    draws = rng.integers(0, num_actions, size=(n_draws, gv.batch))
+    ov.proto.difficulty = n_draws
+    for i in range(ov.batch):
+        ov.env(i).difficulty = n_draws
+    gv.difficulty = n_draws
+    ov.reset_with(draws)
+    gv.reset_with(_dev(draws, torch.int32))
+    gv.sync()
+
+
+CASES = [
+    # kind, N, gateset builder, batch, per-env state size
+    ("clifford", 16, lambda: line_gateset("clifford", 16), 1024),
+    ("clifford", 3, lambda: line_gateset("clifford", 3), 130),
+    ("clifford", 5, lambda: line_gateset("clifford", 5), 257),
+    ("clifford", 20, lambda: line_gateset("clifford", 20), 96),  # uint64 rows
+    ("linear_function", 8, lambda: line_gateset("linear_function", 8), 1024),
+    ("linear_function", 3, lambda: line_gateset("linear_function", 3), 77),
+    ("linear_function", 12, lambda: line_gateset("linear_function", 12), 300),  # ROWS layout
+    ("linear_function", 40, lambda: line_gateset("linear_function", 40), 65),  # uint64 rows
+    ("permutation", 9, lambda: grid_gateset("permutation", 3, 3), 128),
+    ("permutation", 16, lambda: grid_gateset("permutation", 4, 4), 100),
+]
+
+
+def _per_env(kind, n):
+    return {"clifford": 4 * n * n, "linear_function": n * n, "permutation": n}[kind]
+
+
+@pytest.mark.parametrize("kind,n,gs,batch", CASES)
+def test_step_parity_free_running(kind, n, gs, batch):
+    gateset = gs()
+    A = len(gateset)
+    ov, gv = make_pair(kind, n, gateset, batch, add_inverts=False, add_perms=False, track_solution=False, max_depth=24)
+    rng = np.random.default_rng(1234 + n)
+    _scramble(ov, gv, rng, 3 * n, A)
+    _compare_state(ov, gv, _per_env(kind, n), "after reset")
+    for t in range(32):  # runs past depth 0: free-running stepping is allowed by the trait
+        acts = rng.integers(0, A, size=batch)
+        if t % 5 == 4:  # out-of-range and negative actions are silent no-ops that still use depth
+            acts[:: 7] = A + 3
+            acts[1:: 11] = -1
+        _compare_step(ov, gv, acts, label=f"t={t}")
+    _compare_state(ov, gv, _per_env(kind, n), "end")
+
+
+@pytest.mark.parametrize("kind,n,gs,batch", CASES)
+def test_step_parity_with_inverts_and_solution(kind, n, gs, batch):
+    gateset = gs()
+    A = len(gateset)
+    ov, gv = make_pair(kind, n, gateset, batch, add_inverts=True, add_perms=False, track_solution=True, max_depth=40)
+    rng = np.random.default_rng(99 + n)
+    _scramble(ov, gv, rng, 2 * n, A)
+    for t in range(20):
+        acts = rng.integers(0, A, size=batch)
+        if t == 7:
+            acts[::5] = A  # invalid: Clifford/LF still log it, Permutation does not
+        coins = rng.integers(0, 2, size=batch)
+        _compare_step(ov, gv, acts, coins, label=f"t={t}")
+    _compare_state(ov, gv, _per_env(kind, n), "end")
+    for e in (0, 1, batch // 2, batch - 1):
+        assert gv.solution(e) == ov.env(e).solution(), e
+
+
+@pytest.mark.parametrize("kind,n", [("clifford", 16), ("clifford", 4), ("linear_function", 8), ("linear_function", 12), ("permutation", 9)])
+def test_layer_weighted_rewards(kind, n):
+    gateset = line_gateset(kind, n) if kind != "permutation" else grid_gateset("permutation", 3, 3)
+    A = len(gateset)
+    w = {"n_cnots": 0.02, "n_layers_cnots": 0.3, "n_layers": 0.07, "n_gates": 0.0005}
+    ov, gv = make_pair(kind, n, gateset, 200, add_inverts=False, add_perms=False, track_solution=False, metrics_weights=w)
+    rng = np.random.default_rng(5)
+    _scramble(ov, gv, rng, 10, A)
+    for t in range(40):
+        _compare_step(ov, gv, rng.integers(0, A, size=200), label=f"t={t}")
+
+
+def test_rollout_graph_and_fused_match_single_steps():
+    gateset = line_gateset("clifford", 16)
+    A = len(gateset)
+    B, T = 2048, 16
+    ov, gv = make_pair("clifford", 16, gateset, B, add_inverts=False, add_perms=False, track_solution=False)
+    from qiskit_gym_amd.vec import VecEnv
+
+    rng = np.random.default_rng(7)
+    draws = rng.integers(0, A, size=(64, B))
+    acts = rng.integers(0, A, size=(T, B))
+    rew_o = np.zeros((T, B), np.float32)
+    fin_o = np.zeros((T, B), np.uint8)
+    ov.proto.difficulty = 64
+    for i in range(B):
+        ov.env(i).difficulty = 64
+    ov.reset_with(draws)
+    for t in range(T):
+        r, s, f, d = ov.step(acts[t])
+        rew_o[t], fin_o[t] = r, f
+    want_state = ov.get_state(1024)
+    for fused in (False, True):
+        gv.difficulty = 64
+        gv.reset_with(_dev(draws, torch.int32))
+        rew = torch.zeros((T, B), dtype=torch.float32, device="cuda")
+        fin = torch.zeros((T, B), dtype=torch.uint8, device="cuda")
+        gv.rollout(_dev(acts, torch.int64), fused=fused, rewards_out=rew, dones_out=fin)
+        gv.sync()
+        np.testing.assert_array_equal(f32_bits(rew.cpu().numpy()), f32_bits(rew_o))
+        np.testing.assert_array_equal(fin.cpu().numpy(), fin_o)
+        np.testing.assert_array_equal(gv.get_state("i64").cpu().numpy(), want_state)
+        if not fused:  # replay the cached graph once more from the same start
+            gv.reset_with(_dev(draws, torch.int32))
+            gv.rollout(_dev(acts, torch.int64), fused=False, rewards_out=rew, dones_out=fin)
+            gv.sync()
+            np.testing.assert_array_equal(gv.get_state("i64").cpu().numpy(), want_state)
+
+
+def test_device_reset_matches_replayed_draws():
+    gateset = line_gateset("clifford", 16)
+    A = len(gateset)
+    B = 512
+    ov, gv = make_pair("clifford", 16, gateset, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=37)
+    gv.reset(seed=0xABCDEF)
+    gv.sync()
+    ov.reset_with(rng_actions(0xABCDEF, B, 37, A))
+    _compare_state(ov, gv, 1024, "reset(seed)")
+    assert int(gv.depth[0]) == min(2 * 37, 128)
+
+
+def test_set_state_formats_and_packed_observation():
+    gateset = line_gateset("clifford", 16)
+    B = 300
+    ov, gv = make_pair("clifford", 16, gateset, B, add_inverts=False, add_perms=False, track_solution=False)
+    rng = np.random.default_rng(3)
+    dense = rng.integers(0, 2, size=(B, 32, 32)).astype(np.int64)
+    dense[0] = np.eye(32, dtype=np.int64)  # one solved env
+    dense[1] = 5 * np.eye(32, dtype=np.int64)  # "> 0 => 1"
+    ov.set_state(dense.reshape(B, -1))
+    gv.set_state(dense.reshape(B, -1), "i64")
+    gv.sync()
+    _compare_state(ov, gv, 1024, "i64 host")
+    assert gv.success.cpu().numpy().tolist()[:3] == [1, 1, 0]
+    assert gv.reward.cpu().numpy()[0] == 1.0 and int(gv.depth[0]) == 128
+    gv.set_state(_dev((dense > 0).astype(np.uint8).reshape(B, -1)), "u8")
+    _compare_state(ov, gv, 1024, "u8 device")
+    packed = ((dense > 0).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(axis=2).astype(np.uint32)
+    gv.set_state(packed, "packed")
+    _compare_state(ov, gv, 1024, "packed host")
+    np.testing.assert_array_equal(gv.observe_packed().cpu().numpy().view(np.uint32), packed)
+    np.testing.assert_array_equal(gv.get_state("packed").cpu().numpy().view(np.uint32), packed)
+    m = gv.masks().cpu().numpy()
+    assert m.shape == (B, len(gateset)) and m[0].sum() == 0 and m[2].all()
+
+
+def test_singular_inverse_is_reported():
+    gateset = line_gateset("clifford", 4)
+    ov, gv = make_pair("clifford", 4, gateset, 8, add_inverts=True, add_perms=False, track_solution=False)
+    gv.set_state(np.zeros((8, 64), dtype=np.int64), "i64")  # all-zero matrix: singular
+    gv.step(_dev(np.zeros(8), torch.int32), _dev(np.ones(8), torch.uint8))
+    from qiskit_gym_amd._lib import QGymError
+
+    with pytest.raises(QGymError):
+        gv.sync()
