@@ -52,7 +52,7 @@ def cpu_baseline(gateset, seed: int, budget_s: float = 12.0):
     OpenMP over envs like twisterl's rayon-over-clones) on this box's host cores."""
     from oracle import OracleEnv, OracleVec
 
-    cores = os.cpu_count() or 1
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     B = 16384
     A = len(gateset)
     proto = OracleEnv("clifford", NUM_QUBITS, gateset, add_inverts=0, add_perms=0, track_solution=0, difficulty=SCRAMBLE)
@@ -60,10 +60,22 @@ def cpu_baseline(gateset, seed: int, budget_s: float = 12.0):
     rng = np.random.default_rng(seed)
     ov.reset_with(rng.integers(0, A, size=(SCRAMBLE, B)))
     acts = rng.integers(0, A, size=(32, B)).astype(np.int32)
-    t0 = time.perf_counter()
-    for t in range(4):
-        ov.step_only(acts[t], threads=cores)
-    per_step = (time.perf_counter() - t0) / 4
+    for t in range(8):  # warm-up: thread pool, first-touch, allocator
+        ov.step_only(acts[t], threads=min(avail, 8))
+    # the box may expose more hardware threads than it lets one container run: pick the thread
+    # count that actually delivers the most steps/s and report that count as `cores`
+    best = (0.0, 1)
+    cand = sorted({c for c in (1, 2, 4, 8, 16, 32, 64, 128, 256) if c <= avail} | {min(avail, 256)})
+    for c in cand:
+        ov.step_only(acts[0], threads=c)
+        t0 = time.perf_counter()
+        for t in range(4):
+            ov.step_only(acts[t], threads=c)
+        rate = 4 * B / (time.perf_counter() - t0)
+        if rate > best[0]:
+            best = (rate, c)
+    cores = best[1]
+    per_step = B / best[0]
     n_steps = int(max(8, min(4096, budget_s / max(per_step, 1e-6))))
     t0 = time.perf_counter()
     for t in range(n_steps):

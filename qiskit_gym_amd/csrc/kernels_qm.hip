@@ -1,0 +1,351 @@
+// kernels_qm.hip -- TILE layout ("qubit machine"): thread-per-env kernels for GF(2) matrices of at
+// most 32 rows: CliffordEnv N <= 16 (the headline shape) and LinearFunctionEnv 8 < N <= 32.
+//
+// Reference semantics: same as kernels_rows.hip --
+//   Clifford::step rust/src/envs/clifford.rs:321-347, gates :89-133, solved :136-145;
+//   LinearFunction::step rust/src/envs/linear_function.rs:302-328, cx/swap :62-83.
+//
+// Why a second layout: the ROWS layout spends ~19 wave-instructions per env-step (8 lanes per env)
+// and is instruction-issue-bound on MI355X.  Here one lane owns one whole env (its <= 32 row words
+// live in VGPRs), so every wave instruction advances 64 envs (~4 per env-step), and nothing crosses
+// lanes: no shuffles, no ballots, no LDS traffic besides the staged gate table.
+//
+// Memory (TILE layout): envs are grouped in tiles of 64 (one wavefront).  A tile stores its rows as
+// R/4 "row groups" of 1 KiB: group g holds, for lane l, the uint4 {slot 4g .. 4g+3} of env
+// tile*64 + l.  Every load/store instruction of a wave is therefore one contiguous, fully
+// coalesced 1 KiB access (16 B per lane), and a tile is one contiguous R*256-byte block.
+// Slots: X-type row j (matrix row j, j < N) is slot j; for CliffordEnv the Z-type row N+j is slot
+// NXP + j, NXP = N rounded up to a multiple of 4; unused slots hold zero.
+//
+// An action is (q0, q1, M): the four rows {X[q0], Z[q0], X[q1], Z[q1]} are replaced by GF(2)
+// combinations of themselves given by the 4x4 bit matrix M (H, S, SX, CX, CZ, SWAP and "no gate"
+// are all of this form).  Per-lane row selection is a compare + conditional-move sweep over the
+// register file, the identity test an xor/or sweep.
+#include "device_common.hpp"
+
+namespace qg {
+
+// ops word of the TILE layout: [0:5) q0, [5:10) q1, [10:26) M.
+// M bit 4*k + i: output k takes input i, inputs/outputs ordered {X[q0], Z[q0], X[q1], Z[q1]}.
+__host__ __device__ inline uint32_t qm_ops(uint32_t q0, uint32_t q1, uint32_t m) { return (q0 & 31u) | ((q1 & 31u) << 5) | (m << 10); }
+#define QM_IDENTITY 0x8421u
+
+template <int NXP, bool HAS_Z>
+struct QmRows {
+    static constexpr int R = HAS_Z ? 2 * NXP : NXP;  // row slots per env
+    static constexpr int G = R / 4;                  // 16-byte groups per env
+    uint32_t r[R];
+};
+
+template <int NXP, bool HAS_Z>
+__device__ inline void qm_load(const uint4 *tile, uint32_t lane, QmRows<NXP, HAS_Z> &s) {
+#pragma unroll
+    for (int g = 0; g < QmRows<NXP, HAS_Z>::G; ++g) {
+        const uint4 q = tile[g * 64 + lane];
+        s.r[4 * g + 0] = q.x; s.r[4 * g + 1] = q.y; s.r[4 * g + 2] = q.z; s.r[4 * g + 3] = q.w;
+    }
+}
+
+template <int NXP, bool HAS_Z>
+__device__ inline void qm_identity(QmRows<NXP, HAS_Z> &s, uint32_t N) {
+#pragma unroll
+    for (int j = 0; j < NXP; ++j) {
+        s.r[j] = (uint32_t)j < N ? 1u << j : 0u;
+        if (HAS_Z) s.r[NXP + j] = (uint32_t)j < N ? (1u << N) << j : 0u;
+    }
+}
+
+// CFState::solved / LFState::solved (clifford.rs:136-145, linear_function.rs:91-100)
+template <int NXP, bool HAS_Z>
+__device__ inline bool qm_solved(const QmRows<NXP, HAS_Z> &s, uint32_t N) {
+    uint32_t acc = 0;
+    const uint32_t zb = 1u << N;
+#pragma unroll
+    for (int j = 0; j < NXP; ++j) {
+        acc |= s.r[j] ^ ((uint32_t)j < N ? 1u << j : 0u);
+        if (HAS_Z) acc |= s.r[NXP + j] ^ ((uint32_t)j < N ? zb << j : 0u);
+    }
+    return acc == 0;
+}
+
+// apply one action; returns a bit mask of the 16-byte groups that were written
+template <int NXP, bool HAS_Z>
+__device__ inline uint32_t qm_apply(QmRows<NXP, HAS_Z> &s, uint32_t ops) {
+    const uint32_t q0 = ops & 31u, q1 = (ops >> 5) & 31u, m = (ops >> 10) & 0xFFFFu;
+    uint32_t x0 = 0, z0 = 0, x1 = 0, z1 = 0;
+#pragma unroll
+    for (int j = 0; j < NXP; ++j) {
+        const bool h0 = q0 == (uint32_t)j, h1 = q1 == (uint32_t)j;
+        x0 = h0 ? s.r[j] : x0;
+        x1 = h1 ? s.r[j] : x1;
+        if (HAS_Z) {
+            z0 = h0 ? s.r[NXP + j] : z0;
+            z1 = h1 ? s.r[NXP + j] : z1;
+        }
+    }
+    // GF(2) mix: out_k = xor_i M[k][i] * in_i   (-(bit) is an all-ones / all-zeros lane mask)
+    auto mix = [&](uint32_t k) -> uint32_t {
+        const uint32_t b = m >> (4 * k);
+        uint32_t o = (0u - (b & 1u)) & x0;
+        o ^= (0u - ((b >> 2) & 1u)) & x1;
+        if (HAS_Z) {
+            o ^= (0u - ((b >> 1) & 1u)) & z0;
+            o ^= (0u - ((b >> 3) & 1u)) & z1;
+        }
+        return o;
+    };
+    const uint32_t nx0 = mix(0), nx1 = mix(2);
+    const uint32_t nz0 = HAS_Z ? mix(1) : 0u, nz1 = HAS_Z ? mix(3) : 0u;
+    // re-derive the lane masks for the write-back sweep: keeping 2*NXP compare results alive across
+    // the mix would spill SGPR pairs (the opaque asm stops the compiler from reusing them)
+    uint32_t w0 = q0, w1 = q1;
+    asm volatile("" : "+v"(w0), "+v"(w1));
+#pragma unroll
+    for (int j = 0; j < NXP; ++j) {
+        const bool h0 = w0 == (uint32_t)j, h1 = w1 == (uint32_t)j;
+        // two flat selects (q0's value wins when q0 == q1): keeps this a v_cndmask sweep
+        uint32_t vx = s.r[j];
+        vx = h1 ? nx1 : vx;
+        vx = h0 ? nx0 : vx;
+        s.r[j] = vx;
+        if (HAS_Z) {
+            uint32_t vz = s.r[NXP + j];
+            vz = h1 ? nz1 : vz;
+            vz = h0 ? nz0 : vz;
+            s.r[NXP + j] = vz;
+        }
+    }
+    uint32_t dirty = (1u << (q0 >> 2)) | (1u << (q1 >> 2));
+    if (HAS_Z) dirty |= dirty << (NXP / 4);
+    return m == QM_IDENTITY ? 0u : dirty;  // "no gate" writes nothing back
+}
+
+// FEAT: compile in the rarely used per-step extras (solution log, layer-weighted metrics); the
+// plain instantiation keeps the hot path free of their code and registers.
+template <int NXP, bool HAS_Z, bool FEAT>
+__global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
+    using Rows = QmRows<NXP, HAS_Z>;
+    extern __shared__ GateEntry s_gates[];
+    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    const bool valid = env < a.B;
+    const bool act64 = a.flags & F_ACT64;
+    uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Rows::G * 64);
+
+    // long-latency loads first: rows, action, depth
+    Rows s;
+    int64_t act = -1;
+    int32_t depth = 0;
+    if (valid) {
+        qm_load<NXP, HAS_Z>(tile, lane, s);
+        act = load_action(a.actions, env, act64);
+        depth = a.depth[env];
+    }
+    // gate table -> LDS while they are in flight
+    const bool lds_table = a.num_actions * sizeof(GateEntry) <= 32768;
+    if (lds_table) {
+        for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) s_gates[i] = a.gates[i];
+        __syncthreads();
+    }
+    if (!valid) return;
+
+    uint32_t dirty = 0;
+    bool solved = false;
+    float reward = 0.0f;
+    uint32_t fault = 0;
+    int32_t sol_n = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2] : 0;
+
+    for (uint32_t t = 0; t < a.T; ++t) {
+        if (t) act = load_action(a.actions, (uint64_t)t * a.B + env, act64);
+        const bool in_range = act >= 0 && act < (int64_t)a.num_actions;  // gateset.get(action) (clifford.rs:324)
+        GateEntry g = {QM_IDENTITY << 10, 0.0f};
+        if (in_range) g = lds_table ? s_gates[act] : a.gates[act];
+        float penalty = g.penalty;
+        if (FEAT && (a.flags & F_LAYERS) && in_range)
+            penalty = layers_penalty(a.layers + env * (2 * a.N + 2), a.N, a.descs[act], a.w);
+
+        dirty |= qm_apply<NXP, HAS_Z>(s, g.ops);  // apply_gate_to_state (clifford.rs:331)
+
+        if (FEAT && (a.flags & F_TRACK)) {  // clifford.rs:334-340 (never inverted in this layout)
+            if ((uint32_t)sol_n < a.sol_cap) a.sol[env * a.sol_cap + (uint32_t)sol_n++] = (uint32_t)act;
+            else fault |= 8u;
+        }
+        depth = depth > 0 ? depth - 1 : 0;          // clifford.rs:342
+        solved = qm_solved<NXP, HAS_Z>(s, a.N);     // clifford.rs:344
+        const float achieved = solved ? 1.0f : 0.0f;
+        reward = achieved - penalty;                // clifford.rs:345-346
+        if (a.rewards_seq) a.rewards_seq[(uint64_t)t * a.B + env] = reward;
+        if (a.dones_seq) a.dones_seq[(uint64_t)t * a.B + env] = (uint8_t)(depth == 0 || solved);
+    }
+
+#pragma unroll
+    for (int g = 0; g < Rows::G; ++g)
+        if ((dirty >> g) & 1u) tile[g * 64 + lane] = make_uint4(s.r[4 * g], s.r[4 * g + 1], s.r[4 * g + 2], s.r[4 * g + 3]);
+    a.depth[env] = depth;
+    a.reward[env] = reward;
+    a.done[env] = (uint8_t)(depth == 0 || solved);  // is_final (clifford.rs:353)
+    a.success[env] = (uint8_t)solved;
+    if (FEAT && (a.flags & F_TRACK)) a.sol_len[env * 2] = sol_n;
+    if (FEAT && fault) atomicOr(&a.error[env], fault);
+}
+
+// slot of matrix row `row`
+__device__ inline uint32_t qm_slot(uint32_t row, uint32_t N, uint32_t nxp, bool has_z) {
+    return (has_z && row >= N) ? nxp + (row - N) : row;
+}
+
+template <int NXP, bool HAS_Z>
+__global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
+    using Rows = QmRows<NXP, HAS_Z>;
+    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    if (env >= a.B) return;
+    uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Rows::G * 64);
+    Rows s;
+    qm_identity<NXP, HAS_Z>(s, a.N);
+    if (a.mode == 1) {  // set_state (clifford.rs:299-304)
+#pragma unroll
+        for (int sl = 0; sl < Rows::R; ++sl) {
+            const uint32_t j = HAS_Z ? (uint32_t)sl % NXP : (uint32_t)sl;
+            const uint32_t row = (HAS_Z && sl >= NXP) ? a.N + j : j;
+            uint32_t w = 0;
+            if (j < a.N) {
+                if (a.format == QG_FMT_PACKED) {
+                    w = reinterpret_cast<const uint32_t *>(a.src)[env * a.src_stride + row];
+                    if (a.D < 32) w &= (1u << a.D) - 1u;
+                } else if (a.format == QG_FMT_I64) {
+                    const int64_t *p = reinterpret_cast<const int64_t *>(a.src) + env * a.src_stride + (uint64_t)row * a.D;
+                    for (uint32_t c = 0; c < a.D; ++c) w |= (uint32_t)(p[c] > 0) << c;
+                } else {
+                    const int8_t *p = reinterpret_cast<const int8_t *>(a.src) + env * a.src_stride + (uint64_t)row * a.D;
+                    for (uint32_t c = 0; c < a.D; ++c) w |= (uint32_t)(p[c] > 0) << c;
+                }
+            }
+            s.r[sl] = w;
+        }
+    } else if (a.mode == 2) {  // reset scramble (clifford.rs:306-316)
+        for (uint32_t t = 0; t < a.n_draws; ++t) {
+            const int64_t act = a.actions ? (int64_t)a.actions[(uint64_t)t * a.B + env]
+                                          : (int64_t)rng_action(a.seed, env, t, a.num_actions);
+            const uint32_t ops = (act >= 0 && act < (int64_t)a.num_actions) ? a.gates[act].ops : (QM_IDENTITY << 10);
+            qm_apply<NXP, HAS_Z>(s, ops);
+        }
+    }
+    const bool solved = qm_solved<NXP, HAS_Z>(s, a.N);
+#pragma unroll
+    for (int g = 0; g < Rows::G; ++g) tile[g * 64 + lane] = make_uint4(s.r[4 * g], s.r[4 * g + 1], s.r[4 * g + 2], s.r[4 * g + 3]);
+    a.depth[env] = a.depth_value;  // reset_internals (clifford.rs:272-283)
+    a.success[env] = (uint8_t)solved;
+    a.reward[env] = solved ? 1.0f : 0.0f;
+    a.done[env] = (uint8_t)(a.depth_value == 0 || solved);
+    a.inverted[env] = 0;
+    a.error[env] = 0;
+    a.sol_len[env * 2] = 0;
+    a.sol_len[env * 2 + 1] = 0;
+    if (a.layers) {
+        int32_t *lay = a.layers + env * a.layers_len;
+        for (uint32_t i = 0; i + 2 < a.layers_len; ++i) lay[i] = -1;
+        lay[a.layers_len - 2] = 0;
+        lay[a.layers_len - 1] = 0;
+    }
+}
+
+// export: one thread per (env, matrix row).  log2L carries NXP/4, flag bit 31 of D's companion
+// field is avoided: has_z is passed through `obs_rows != N` (Clifford: D = 2N rows).
+__global__ __launch_bounds__(256) void qm_export_kernel(ObsArgs a, uint32_t nxp, uint32_t has_z) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t env = gid / a.D;
+    const uint32_t row = (uint32_t)(gid % a.D);
+    if (env >= a.B) return;
+    const uint32_t R = has_z ? 2 * nxp : nxp, slot = qm_slot(row, a.N, nxp, has_z);
+    const uint32_t *tile = reinterpret_cast<const uint32_t *>(a.state) + (env >> 6) * (uint64_t)(R * 64);
+    const uint32_t w = tile[((slot >> 2) * 64 + (uint32_t)(env & 63)) * 4 + (slot & 3)];
+    if (a.format == QG_FMT_PACKED) {
+        reinterpret_cast<uint32_t *>(a.out)[env * a.out_stride + row] = w;
+    } else if (a.format == QG_FMT_I64) {
+        int64_t *o = reinterpret_cast<int64_t *>(a.out) + env * a.out_stride + (uint64_t)row * a.D;
+        for (uint32_t c = 0; c < a.D; ++c) o[c] = (int64_t)((w >> c) & 1u);
+    } else {
+        int8_t *o = reinterpret_cast<int8_t *>(a.out) + env * a.out_stride + (uint64_t)row * a.D;
+        for (uint32_t c = 0; c < a.D; ++c) o[c] = (int8_t)((w >> c) & 1u);
+    }
+}
+
+// Dense int8 observation for D == 32 (CliffordEnv N = 16): one lane expands one packed row into
+// 32 bytes (two 16 B stores); a wave writes 2 KiB contiguously.
+__global__ __launch_bounds__(256) void qm_dense32_kernel(ObsArgs a) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // env * 32 + row
+    if (gid >= a.B * 32ull) return;
+    const uint64_t env = gid >> 5;
+    const uint32_t slot = (uint32_t)gid & 31u;  // N = 16: slot == row
+    const uint32_t *tile = reinterpret_cast<const uint32_t *>(a.state) + (env >> 6) * (uint64_t)(32 * 64);
+    const uint32_t w = tile[((slot >> 2) * 64 + (uint32_t)(env & 63)) * 4 + (slot & 3)];
+    uint32_t o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t nb = (w >> (4 * k)) & 0xFu;
+        o[k] = (nb & 1u) | ((nb & 2u) << 7) | ((nb & 4u) << 14) | ((nb & 8u) << 21);  // bit i -> byte i
+    }
+    uint4 *out = reinterpret_cast<uint4 *>(reinterpret_cast<int8_t *>(a.out) + gid * 32ull);
+    out[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    out[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+static inline unsigned grid_for(uint64_t threads, unsigned block) { return (unsigned)((threads + block - 1) / block); }
+
+template <int NXP, bool HAS_Z>
+static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
+    const size_t lds = (a.num_actions * sizeof(GateEntry) <= 32768) ? a.num_actions * sizeof(GateEntry) : 0;
+    if (a.flags & (F_TRACK | F_LAYERS))
+        hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true>), dim3(grid_for(a.B, 256)), dim3(256), lds, s, a);
+    else
+        hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, false>), dim3(grid_for(a.B, 256)), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+template <int NXP, bool HAS_Z>
+static hipError_t launch_init(const InitArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL((qm_init_kernel<NXP, HAS_Z>), dim3(grid_for(a.B, 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+#define QM_DISPATCH(FN, ARGS)                                         \
+    if (has_z) {                                                      \
+        switch (nxp) {                                                \
+        case 4: return FN<4, true>(ARGS, s);                          \
+        case 8: return FN<8, true>(ARGS, s);                          \
+        case 12: return FN<12, true>(ARGS, s);                        \
+        case 16: return FN<16, true>(ARGS, s);                        \
+        }                                                             \
+    } else {                                                          \
+        switch (nxp) {                                                \
+        case 4: return FN<4, false>(ARGS, s);                         \
+        case 8: return FN<8, false>(ARGS, s);                         \
+        case 12: return FN<12, false>(ARGS, s);                       \
+        case 16: return FN<16, false>(ARGS, s);                       \
+        case 20: return FN<20, false>(ARGS, s);                       \
+        case 24: return FN<24, false>(ARGS, s);                       \
+        case 28: return FN<28, false>(ARGS, s);                       \
+        case 32: return FN<32, false>(ARGS, s);                       \
+        }                                                             \
+    }                                                                 \
+    return hipErrorInvalidValue;
+
+hipError_t qm_step(const StepArgs &a, uint32_t nxp, bool has_z, hipStream_t s) {
+    if (!a.B) return hipSuccess;
+    QM_DISPATCH(launch_step, a)
+}
+hipError_t qm_init(const InitArgs &a, uint32_t nxp, bool has_z, hipStream_t s) {
+    if (!a.B) return hipSuccess;
+    QM_DISPATCH(launch_init, a)
+}
+hipError_t qm_export(const ObsArgs &a, uint32_t nxp, bool has_z, hipStream_t s) {
+    if (!a.B) return hipSuccess;
+    if (has_z && a.N == 16 && a.format == QG_FMT_U8 && a.out_stride == 1024 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
+        hipLaunchKernelGGL(qm_dense32_kernel, dim3(grid_for(a.B * 32ull, 256)), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(qm_export_kernel, dim3(grid_for(a.B * a.D, 256)), dim3(256), 0, s, a, nxp, has_z ? 1u : 0u);
+    return hipGetLastError();
+}
+
+}  // namespace qg

@@ -13,6 +13,7 @@
 #include <cctype>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -111,6 +112,32 @@ int ensure_scratch_public(qg_vec *v, size_t bytes) {
     }
     v->scratch_bytes = bytes;
     return QG_OK;
+}
+
+// TILE layout action word (kernels_qm.hip): q0, q1 and the 4x4 GF(2) matrix acting on
+// {X[q0], Z[q0], X[q1], Z[q1]} (clifford.rs:89-133 / linear_function.rs:62-83 as linear maps)
+static uint32_t tile_ops(int env_kind, const qg_gate &g) {
+    const uint32_t a = (uint32_t)g.q0, b = (uint32_t)g.q1;
+    enum { X0 = 1, Z0 = 2, X1 = 4, Z1 = 8 };
+    auto M = [](uint32_t ox0, uint32_t oz0, uint32_t ox1, uint32_t oz1) { return ox0 | (oz0 << 4) | (ox1 << 8) | (oz1 << 12); };
+    const uint32_t ident = M(X0, Z0, X1, Z1);
+    uint32_t m = ident, q1 = a;
+    if (env_kind == QG_CLIFFORD) {
+        switch (g.kind) {
+        case QG_H: m = M(Z0, X0, X1, Z1); break;
+        case QG_S:
+        case QG_SDG: m = M(X0, Z0 | X0, X1, Z1); break;
+        case QG_SX:
+        case QG_SXDG: m = M(X0 | Z0, Z0, X1, Z1); break;
+        case QG_CX: if (a != b) { m = M(X0, Z0 | Z1, X1 | X0, Z1); q1 = b; } break;
+        case QG_CZ: if (a != b) { m = M(X0, Z0 | X1, X1, Z1 | X0); q1 = b; } break;
+        case QG_SWAP: if (a != b) { m = M(X1, Z1, X0, Z0); q1 = b; } break;
+        }
+    } else {  // LinearFunction: rows are the X-type slots only
+        if (g.kind == QG_CX && a != b) { m = M(X0, Z0, X1 | X0, Z1); q1 = b; }
+        if (g.kind == QG_SWAP && a != b) { m = M(X1, Z0, X0, Z1); q1 = b; }
+    }
+    return (a & 31u) | ((q1 & 31u) << 5) | (m << 10);
 }
 
 }  // namespace qg
@@ -242,6 +269,7 @@ static hipError_t launch_init(const qg_vec *v, const InitArgs &a, hipStream_t s)
     case LAYOUT_ROWS64: return rows_init(a, true, s);
     case LAYOUT_LF8: return lf8_init(a, s);
     case LAYOUT_PERM: return perm_init(a, s);
+    case LAYOUT_TILE: return qm_init(a, v->nxp, v->has_z, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -285,6 +313,7 @@ static hipError_t launch_step(const qg_vec *v, const StepArgs &a, hipStream_t s)
     case LAYOUT_LF8: return lf8_step(a, a.T > 1, s);
     case LAYOUT_PERM: return perm_step(a, a.T > 1, s);
     case LAYOUT_PAULI: return pauli_step(v, a, s);
+    case LAYOUT_TILE: return qm_step(a, v->nxp, v->has_z, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -354,6 +383,17 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
         break;
     default: return set_error(QG_ERR_INVALID, "unknown env_kind %d", cfg->env_kind);
     }
+    const bool inverts = cfg->add_inverts && cfg->env_kind != QG_PAULI;
+    // thread-per-env TILE layout for matrices of <= 32 rows (the hot path); the inversion path
+    // (add_inverts) lives in the lane-group ROWS kernels
+    if (v->layout == LAYOUT_ROWS32 && !inverts && getenv("QGYM_FORCE_ROWS") == nullptr) {
+        v->layout = LAYOUT_TILE;
+        v->nxp = (N + 3u) & ~3u;
+        v->has_z = cfg->env_kind == QG_CLIFFORD;
+        const size_t R = v->has_z ? 2 * v->nxp : v->nxp;
+        v->stride_bytes = 0;
+        v->state_bytes = ((batch + 63) / 64) * R * 256;
+    }
     if (v->layout == LAYOUT_ROWS32 || v->layout == LAYOUT_ROWS64) {
         const uint32_t rpl = v->layout == LAYOUT_ROWS32 ? 4 : 2;
         v->log2L = pow2ceil_log2((v->D + rpl - 1) / rpl);
@@ -362,7 +402,6 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
 
     // behaviour flags
     v->flags = 0;
-    const bool inverts = cfg->add_inverts && cfg->env_kind != QG_PAULI;
     if (inverts) v->flags |= F_INVERTS;
     if (cfg->track_solution) v->flags |= F_TRACK;
     const bool layers = !(cfg->w_n_layers == 0.0f && cfg->w_n_layers_cnots == 0.0f);
@@ -375,7 +414,9 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     for (size_t i = 0; i < n_gates; ++i) {
         int dc, dg;
         gate_deltas(gates[i], N, dc, dg);
-        table[i].ops = cfg->env_kind == QG_PAULI ? 0u : gate_ops(cfg->env_kind, gates[i], N);
+        table[i].ops = cfg->env_kind == QG_PAULI ? 0u
+                       : v->layout == LAYOUT_TILE ? tile_ops(cfg->env_kind, gates[i])
+                                                  : gate_ops(cfg->env_kind, gates[i], N);
         table[i].penalty = table_penalty(w, dc, dg);
         descs[i] = make_desc((uint32_t)gates[i].kind, (uint32_t)gates[i].q0, (uint32_t)gates[i].q1);
     }
@@ -398,7 +439,9 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
         int rc = pauli_plan(p);
         if (rc) return fail(rc);
     }
-    HIP_TRY_V(hipMalloc(&p->state, p->stride_bytes * batch));
+    if (!p->state_bytes) p->state_bytes = p->stride_bytes * batch;
+    HIP_TRY_V(hipMalloc(&p->state, p->state_bytes));
+    HIP_TRY_V(hipMemset(p->state, 0, p->state_bytes));
     HIP_TRY_V(hipMalloc(&p->depth, sizeof(int32_t) * batch));
     HIP_TRY_V(hipMalloc(&p->reward, sizeof(float) * batch));
     HIP_TRY_V(hipMalloc(&p->done, batch));
@@ -561,6 +604,7 @@ static hipError_t launch_export(const qg_vec *v, const ObsArgs &a, hipStream_t s
     case LAYOUT_LF8: return lf8_export(a, s);
     case LAYOUT_PERM: return perm_export(a, s);
     case LAYOUT_PAULI: return pauli_export(v, a, s);
+    case LAYOUT_TILE: return qm_export(a, v->nxp, v->has_z, s);
     default: return hipErrorInvalidValue;
     }
 }

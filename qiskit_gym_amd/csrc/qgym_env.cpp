@@ -195,7 +195,7 @@ int qg_env_clone(const qg_env *e, qg_env **out) {  // Env: DynClone -- deep copy
     d->step_index = s->step_index;
     d->coin_seed = s->coin_seed;
     struct { void *dst; const void *src; size_t bytes; } copies[] = {
-        {d->state, s->state, s->stride_bytes},
+        {d->state, s->state, s->state_bytes},
         {d->depth, s->depth, 4},
         {d->reward, s->reward, 4},
         {d->done, s->done, 1},

@@ -8,7 +8,7 @@
 
 namespace qg {
 
-enum Layout { LAYOUT_ROWS32 = 0, LAYOUT_ROWS64 = 1, LAYOUT_LF8 = 2, LAYOUT_PERM = 3, LAYOUT_PAULI = 4 };
+enum Layout { LAYOUT_ROWS32 = 0, LAYOUT_ROWS64 = 1, LAYOUT_LF8 = 2, LAYOUT_PERM = 3, LAYOUT_PAULI = 4, LAYOUT_TILE = 5 };
 
 struct GraphKey {
     const void *actions;
@@ -39,7 +39,10 @@ struct qg_vec {
     uint32_t N = 0, D = 0, log2L = 0;
     int device = 0;
     qg::Layout layout = qg::LAYOUT_ROWS32;
-    size_t stride_bytes = 0;
+    size_t stride_bytes = 0;   // per-env stride (0 for the tiled layout)
+    size_t state_bytes = 0;    // total resident state size
+    uint32_t nxp = 0;          // TILE layout: X-row slots per env (N rounded up to 4)
+    bool has_z = false;        // TILE layout: Z-type rows present (CliffordEnv)
     uint32_t flags = 0;
     int64_t difficulty = 1;
     uint64_t coin_seed = 0;

@@ -9,6 +9,9 @@
 //    with zero rows, so env e starts at byte e*L*16 and a wavefront's load is one fully
 //    coalesced 1 KiB transaction covering 64/L envs.  CliffordEnv N=16: D=32, L=8, 128 B/env,
 //    no padding -- the resident state IS the packed observation.
+//  TILE layout (CliffordEnv N<=16 and LinearFunctionEnv 8<N<=32 without add_inverts; the hot
+//    path): thread-per-env, envs in tiles of 64, each tile = R/4 row groups of 1 KiB holding one
+//    uint4 (4 row slots) per lane -- see kernels_qm.hip.
 //  LF8 layout   (LinearFunctionEnv N<=8): one uint64 per env, byte r = row r.
 //  PERM layout  (PermutationEnv N<=16): one uint64 per env, nibble i = state[i].
 //  PAULI layout (PauliEnv N<=32): lane q owns qubit q's tableau rows {X row q, Z row N+q} as two
@@ -145,6 +148,10 @@ hipError_t rows_step(const StepArgs &a, bool word64, hipStream_t s);
 hipError_t rows_rollout_fused(const StepArgs &a, bool word64, hipStream_t s);
 hipError_t rows_init(const InitArgs &a, bool word64, hipStream_t s);
 hipError_t rows_export(const ObsArgs &a, bool word64, hipStream_t s);
+
+hipError_t qm_step(const StepArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
+hipError_t qm_init(const InitArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
+hipError_t qm_export(const ObsArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
 
 hipError_t lf8_step(const StepArgs &a, bool fused, hipStream_t s);
 hipError_t lf8_init(const InitArgs &a, hipStream_t s);
