@@ -35,7 +35,7 @@ import torch  # noqa: E402
 NUM_QUBITS = 16
 ENVS_PER_GPU = 65536
 SCRAMBLE = 256
-CHUNK = 64  # steps per hipGraph replay (single-GPU path)
+CHUNK = 256  # steps per hipGraph replay (single-GPU path)
 ALGO_BYTES_PER_STEP = 160  # 128 B state read + 16 B touched rows + 16 B scalars
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 

@@ -194,6 +194,15 @@ int qg_vec_masks(qg_vec *v, uint8_t *out_dev, void *stream);
  * `n_rot[e]` Pauli labels of N characters each, concatenated without separators. */
 int qg_vec_pauli_reset_from(qg_vec *v, const uint8_t *tableaus, const char *labels, const int32_t *n_rot, void *stream);
 
+/* PauliEnv with add_perms: observe() draws one of the coupling map's qubit automorphisms per env,
+ * permutes the observation with it and remembers it so that the next step() un-permutes the
+ * action (pauli.rs:594-599, 653-665).  qg_vec_observe_dense draws from the handle's counter RNG;
+ * this variant takes the draws explicitly: perm_idx_dev[B] (int32, reduced mod the number of
+ * perms), or NULL for the RNG. */
+int qg_vec_pauli_observe_dense(qg_vec *v, int8_t *out_dev, const int32_t *perm_idx_dev, void *stream);
+/* number of (qubit, action) permutation pairs of a PauliEnv batch (0 when add_perms is off) */
+int qg_vec_pauli_num_perms(const qg_vec *v);
+
 /* Blocks until everything enqueued on `stream` by this handle has finished; returns
  * QG_ERR_PANIC if any env has a fault bit set. */
 int qg_vec_sync(qg_vec *v, void *stream);

@@ -77,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "qg_config_default", "qg_last_error", "qg_abi_version", "qg_device_count", "qg_gate_parse",
     "qg_vec_create", "qg_vec_destroy", "qg_vec_get_info", "qg_vec_bind_outputs", "qg_vec_set_difficulty", "qg_vec_get_difficulty",
     "qg_vec_set_state", "qg_vec_get_state", "qg_vec_reset", "qg_vec_reset_with", "qg_vec_step", "qg_vec_rollout",
-    "qg_vec_observe_dense", "qg_vec_observe_packed", "qg_vec_masks", "qg_vec_pauli_reset_from", "qg_vec_sync",
+    "qg_vec_observe_dense", "qg_vec_observe_packed", "qg_vec_masks", "qg_vec_pauli_reset_from", "qg_vec_pauli_observe_dense", "qg_vec_pauli_num_perms", "qg_vec_sync",
     "qg_vec_solution",
     "qg_env_create", "qg_env_clone", "qg_env_destroy", "qg_env_num_actions", "qg_env_obs_shape",
     "qg_env_set_difficulty", "qg_env_get_difficulty", "qg_env_set_state", "qg_env_reset", "qg_env_step",
@@ -126,6 +126,8 @@ def load():
     L.qg_vec_observe_packed.argtypes = [vp, vp, vp]
     L.qg_vec_masks.argtypes = [vp, vp, vp]
     L.qg_vec_pauli_reset_from.argtypes = [vp, vp, C.c_char_p, vp, vp]
+    L.qg_vec_pauli_observe_dense.argtypes = [vp, vp, vp, vp]
+    L.qg_vec_pauli_num_perms.argtypes = [vp]
     L.qg_vec_sync.argtypes = [vp, vp]
     L.qg_vec_solution.argtypes = [vp, u64, C.POINTER(u64), sz]
     L.qg_vec_solution.restype = i64

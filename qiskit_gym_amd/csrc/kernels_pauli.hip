@@ -153,6 +153,10 @@ struct PauliArgs {
     uint32_t rmax;
     uint32_t do_clean;  // init kernel: run the initial clean (PauliEnv::reset, pauli.rs:576)
     int32_t depth_value;
+    // add_perms (pauli.rs:594-599): action un-permutation through the perm chosen by the last observe()
+    const int32_t *act_perms;  // [n_perms][num_actions] or null
+    const uint32_t *perm_idx;  // [B] current_perm_idx
+    uint32_t n_perms;
 };
 
 __global__ __launch_bounds__(256) void pauli_step_kernel(PauliArgs pa) {
@@ -196,7 +200,11 @@ __global__ __launch_bounds__(256) void pauli_step_kernel(PauliArgs pa) {
     uint32_t fault = 0;
 
     for (uint32_t t = 0; t < a.T; ++t) {
-        const int64_t act = load_action(a.actions, (uint64_t)t * a.B + env, act64);
+        int64_t act = load_action(a.actions, (uint64_t)t * a.B + env, act64);
+        if (pa.n_perms) {  // actual_action = act_perms[current_perm_idx][action] (pauli.rs:594-599)
+            if (act >= 0 && act < (int64_t)a.num_actions) act = pa.act_perms[(uint64_t)pa.perm_idx[env] * a.num_actions + act];
+            else fault |= 16u;  // the reference indexes act_perms out of bounds here and panics
+        }
         const bool in_range = act >= 0 && act < (int64_t)a.num_actions;  // pauli.rs:601
         uint64_t prog = 0;
         float penalty = 0.0f;
@@ -347,6 +355,14 @@ struct PauliObsArgs {
     const PauliMeta *meta;
     uint32_t rmax;
     uint32_t max_rot;
+    // observe() with add_perms (pauli.rs:653-665, 445-485): a qubit permutation per env
+    const uint8_t *qubit_perms;  // [n_perms][N] or null
+    uint32_t *perm_idx;          // [B] current_perm_idx, (re)drawn by this launch when draw != 0
+    const int32_t *perm_in;      // [B] explicit draws or null (counter RNG)
+    uint32_t n_perms;
+    uint32_t draw;
+    uint64_t seed;
+    uint64_t counter;
 };
 __global__ __launch_bounds__(256) void pauli_export_kernel(PauliObsArgs pa) {
     const ObsArgs &a = pa.o;
@@ -355,21 +371,45 @@ __global__ __launch_bounds__(256) void pauli_export_kernel(PauliObsArgs pa) {
     const uint64_t env = gid / D;
     const uint32_t row = (uint32_t)(gid % D);
     if (env >= a.B) return;
-    const ulonglong2 t = reinterpret_cast<const ulonglong2 *>(a.state)[env * N + (row < N ? row : row - N)];
-    const uint64_t w = row < N ? t.x : t.y;
+    const uint32_t cols = a.obs_cols;
+    // qubit permutation of this observation (identity when perms are off or for get_state)
+    const uint8_t *perm = nullptr;
+    if (pa.n_perms && cols > D && a.format != QG_FMT_PACKED) {
+        uint32_t pi;
+        if (pa.draw) {  // `rng.gen_range(0..qubit_perms.len())` (pauli.rs:660), made reproducible
+            pi = pa.perm_in ? (uint32_t)pa.perm_in[env] % pa.n_perms
+                            : (uint32_t)__umul64hi(rng_draw(pa.seed ^ 0x7065726Dull, env, pa.counter), (uint64_t)pa.n_perms);
+            if (row == 0) pa.perm_idx[env] = pi;  // current_perm_idx.store (pauli.rs:661)
+        } else {
+            pi = pa.perm_idx[env];
+        }
+        perm = pa.qubit_perms + (uint64_t)pi * N;
+    }
+    const uint32_t q = row < N ? row : row - N;
+    const uint32_t sq = perm ? perm[q] : q;  // row i takes data from row perm[i] (pauli.rs:455-464)
+    const ulonglong2 t = reinterpret_cast<const ulonglong2 *>(a.state)[env * N + sq];
+    uint64_t w = row < N ? t.x : t.y;
+    if (perm) {  // column i takes data from column perm[i], X and Z halves alike (pauli.rs:469-477)
+        uint64_t pw = 0;
+        for (uint32_t i = 0; i < N; ++i) {
+            pw |= ((w >> perm[i]) & 1ull) << i;
+            pw |= ((w >> (N + perm[i])) & 1ull) << (N + i);
+        }
+        w = pw;
+    }
     if (a.format == QG_FMT_PACKED) {
         reinterpret_cast<uint64_t *>(a.out)[env * a.out_stride + row] = w;
         return;
     }
-    const uint32_t cols = a.obs_cols;
-    // pad_and_collect (pauli.rs:411-437): tableau, then the active rotations in DAG node order
+    // pad_and_collect (pauli.rs:411-437): tableau, then the active rotations in DAG node order;
+    // rotation columns are permuted along rows only (pauli.rs:478-481)
     uint32_t extra = 0;
     if (cols > D) {
         const PauliMeta m = pa.meta[env];
         const uint32_t shown = m.count < pa.max_rot ? m.count : pa.max_rot;
         for (uint32_t i = 0; i < shown; ++i) {
             const PauliRot r = pa.rot[env * pa.rmax + nib(m.order, i)];
-            const uint32_t bit = row < N ? (r.x >> row) & 1u : (r.z >> (row - N)) & 1u;
+            const uint32_t bit = row < N ? (r.x >> sq) & 1u : (r.z >> sq) & 1u;
             extra |= bit << i;
         }
     }
@@ -420,6 +460,25 @@ int pauli_alloc(qg_vec *v) {
     for (size_t i = 0; i < v->gates.size(); ++i) prog[i] = gate_program(v->gates[i]);
     HIP_TRY(hipMalloc(&v->d_prog, sizeof(uint64_t) * prog.size()));
     HIP_TRY(hipMemcpy(v->d_prog, prog.data(), sizeof(uint64_t) * prog.size(), hipMemcpyHostToDevice));
+    if (v->cfg.add_perms) {  // compute_qubit_perms (symmetry.rs:307-361)
+        std::vector<std::vector<int64_t>> qp, ap;
+        compute_qubit_and_action_perms(v->N, v->gates, qp, ap);
+        if (!qp.empty()) {
+            std::vector<uint8_t> hq(qp.size() * v->N);
+            std::vector<int32_t> ha(qp.size() * std::max<size_t>(v->gates.size(), 1));
+            for (size_t i = 0; i < qp.size(); ++i) {
+                for (uint32_t q = 0; q < v->N; ++q) hq[i * v->N + q] = (uint8_t)qp[i][q];
+                for (size_t g = 0; g < v->gates.size(); ++g) ha[i * v->gates.size() + g] = (int32_t)ap[i][g];
+            }
+            HIP_TRY(hipMalloc(&v->d_qubit_perms, hq.size()));
+            HIP_TRY(hipMalloc(&v->d_act_perms, sizeof(int32_t) * ha.size()));
+            HIP_TRY(hipMemcpy(v->d_qubit_perms, hq.data(), hq.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(v->d_act_perms, ha.data(), sizeof(int32_t) * ha.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc(&v->perm_idx, sizeof(uint32_t) * v->B));
+            HIP_TRY(hipMemset(v->perm_idx, 0, sizeof(uint32_t) * v->B));  // AtomicUsize::new(0) (pauli.rs:400)
+            v->n_perms = (uint32_t)qp.size();
+        }
+    }
     return QG_OK;
 }
 
@@ -431,6 +490,9 @@ static void fill_pauli_args(const qg_vec *v, const StepArgs &a, PauliArgs &pa) {
     pa.rmax = v->rmax;
     pa.do_clean = 0;
     pa.depth_value = 0;
+    pa.act_perms = v->d_act_perms;
+    pa.perm_idx = v->perm_idx;
+    pa.n_perms = v->n_perms;
 }
 
 hipError_t pauli_step(const qg_vec *v, const StepArgs &a, hipStream_t s) {
@@ -449,6 +511,13 @@ hipError_t pauli_export(const qg_vec *v, const ObsArgs &a, hipStream_t s) {
     pa.meta = reinterpret_cast<const PauliMeta *>(v->pmeta);
     pa.rmax = v->rmax;
     pa.max_rot = (uint32_t)v->cfg.max_rotations;
+    pa.qubit_perms = v->d_qubit_perms;
+    pa.perm_idx = v->perm_idx;
+    pa.perm_in = v->perm_in;
+    pa.n_perms = v->n_perms;
+    pa.draw = v->perm_draw ? 1u : 0u;
+    pa.seed = v->coin_seed;
+    pa.counter = v->observe_counter;
     hipLaunchKernelGGL(pauli_export_kernel, dim3(grid_for(a.B * 2ull * a.N, 256)), dim3(256), 0, s, pa);
     return hipGetLastError();
 }

@@ -58,31 +58,46 @@ __device__ inline void qm_identity(QmRows<NXP, HAS_Z> &s, uint32_t N) {
 // CFState::solved / LFState::solved (clifford.rs:136-145, linear_function.rs:91-100)
 template <int NXP, bool HAS_Z>
 __device__ inline bool qm_solved(const QmRows<NXP, HAS_Z> &s, uint32_t N) {
-    uint32_t acc = 0;
+    uint32_t acc[4] = {0, 0, 0, 0};  // four independent or-chains (ILP: one wave per SIMD at B = 65536)
     const uint32_t zb = 1u << N;
 #pragma unroll
     for (int j = 0; j < NXP; ++j) {
-        acc |= s.r[j] ^ ((uint32_t)j < N ? 1u << j : 0u);
-        if (HAS_Z) acc |= s.r[NXP + j] ^ ((uint32_t)j < N ? zb << j : 0u);
+        acc[j & 1] |= s.r[j] ^ ((uint32_t)j < N ? 1u << j : 0u);
+        if (HAS_Z) acc[2 + (j & 1)] |= s.r[NXP + j] ^ ((uint32_t)j < N ? zb << j : 0u);
     }
-    return acc == 0;
+    return ((acc[0] | acc[1]) | (acc[2] | acc[3])) == 0;
+}
+
+// r[q] for a per-lane q: a binary select tree on the bits of q (depth log2(n) instead of an n-long
+// dependent chain).  Each level blends pairs with an all-ones/all-zeros lane mask,
+// (hi & m) | (lo & ~m) = one v_bfi_b32; written as bit arithmetic on purpose: a `b ? t[2k+1] : t[2k]`
+// select gets folded by the compiler into a runtime-indexed (scratch-memory) array read.
+template <int n>
+__device__ inline uint32_t tree_select(const uint32_t (&t)[n], uint32_t q) {
+    if constexpr (n == 1) {
+        return t[0];
+    } else {
+        constexpr int m = (n + 1) / 2;
+        uint32_t u[m];
+        const uint32_t mb = 0u - (q & 1u);
+#pragma unroll
+        for (int k = 0; k < m; ++k) u[k] = (2 * k + 1 < n) ? ((t[2 * k + 1] & mb) | (t[2 * k] & ~mb)) : t[2 * k];
+        return tree_select<m>(u, q >> 1);
+    }
 }
 
 // apply one action; returns a bit mask of the 16-byte groups that were written
 template <int NXP, bool HAS_Z>
 __device__ inline uint32_t qm_apply(QmRows<NXP, HAS_Z> &s, uint32_t ops) {
     const uint32_t q0 = ops & 31u, q1 = (ops >> 5) & 31u, m = (ops >> 10) & 0xFFFFu;
-    uint32_t x0 = 0, z0 = 0, x1 = 0, z1 = 0;
+    uint32_t xs[NXP], zs[NXP];
 #pragma unroll
     for (int j = 0; j < NXP; ++j) {
-        const bool h0 = q0 == (uint32_t)j, h1 = q1 == (uint32_t)j;
-        x0 = h0 ? s.r[j] : x0;
-        x1 = h1 ? s.r[j] : x1;
-        if (HAS_Z) {
-            z0 = h0 ? s.r[NXP + j] : z0;
-            z1 = h1 ? s.r[NXP + j] : z1;
-        }
+        xs[j] = s.r[j];
+        zs[j] = HAS_Z ? s.r[NXP + j] : 0u;
     }
+    const uint32_t x0 = tree_select<NXP>(xs, q0), x1 = tree_select<NXP>(xs, q1);
+    const uint32_t z0 = HAS_Z ? tree_select<NXP>(zs, q0) : 0u, z1 = HAS_Z ? tree_select<NXP>(zs, q1) : 0u;
     // GF(2) mix: out_k = xor_i M[k][i] * in_i   (-(bit) is an all-ones / all-zeros lane mask)
     auto mix = [&](uint32_t k) -> uint32_t {
         const uint32_t b = m >> (4 * k);
@@ -96,10 +111,7 @@ __device__ inline uint32_t qm_apply(QmRows<NXP, HAS_Z> &s, uint32_t ops) {
     };
     const uint32_t nx0 = mix(0), nx1 = mix(2);
     const uint32_t nz0 = HAS_Z ? mix(1) : 0u, nz1 = HAS_Z ? mix(3) : 0u;
-    // re-derive the lane masks for the write-back sweep: keeping 2*NXP compare results alive across
-    // the mix would spill SGPR pairs (the opaque asm stops the compiler from reusing them)
-    uint32_t w0 = q0, w1 = q1;
-    asm volatile("" : "+v"(w0), "+v"(w1));
+    const uint32_t w0 = q0, w1 = q1;
 #pragma unroll
     for (int j = 0; j < NXP; ++j) {
         const bool h0 = w0 == (uint32_t)j, h1 = w1 == (uint32_t)j;
@@ -122,32 +134,24 @@ __device__ inline uint32_t qm_apply(QmRows<NXP, HAS_Z> &s, uint32_t ops) {
 
 // FEAT: compile in the rarely used per-step extras (solution log, layer-weighted metrics); the
 // plain instantiation keeps the hot path free of their code and registers.
-template <int NXP, bool HAS_Z, bool FEAT>
+// SEQ: several steps per launch (fused rollout) and/or per-step reward/done outputs.
+template <int NXP, bool HAS_Z, bool FEAT, bool SEQ>
 __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
     using Rows = QmRows<NXP, HAS_Z>;
-    extern __shared__ GateEntry s_gates[];
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
     const bool valid = env < a.B;
     const bool act64 = a.flags & F_ACT64;
     uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Rows::G * 64);
 
-    // long-latency loads first: rows, action, depth
+    if (!valid) return;  // no cross-lane operation below: idle lanes of the last tile just leave
+    // the action first (the gate-table read depends on it), then the rows and the depth; the
+    // table (<= a few KiB) is read straight from global memory: it stays L1/L2 resident, and
+    // measured faster than staging it in LDS behind a barrier
+    int64_t act = load_action(a.actions, env, act64);
     Rows s;
-    int64_t act = -1;
-    int32_t depth = 0;
-    if (valid) {
-        qm_load<NXP, HAS_Z>(tile, lane, s);
-        act = load_action(a.actions, env, act64);
-        depth = a.depth[env];
-    }
-    // gate table -> LDS while they are in flight
-    const bool lds_table = a.num_actions * sizeof(GateEntry) <= 32768;
-    if (lds_table) {
-        for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) s_gates[i] = a.gates[i];
-        __syncthreads();
-    }
-    if (!valid) return;
+    qm_load<NXP, HAS_Z>(tile, lane, s);
+    int32_t depth = a.depth[env];
 
     uint32_t dirty = 0;
     bool solved = false;
@@ -155,11 +159,12 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
     uint32_t fault = 0;
     int32_t sol_n = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2] : 0;
 
-    for (uint32_t t = 0; t < a.T; ++t) {
-        if (t) act = load_action(a.actions, (uint64_t)t * a.B + env, act64);
+    const uint32_t T = SEQ ? a.T : 1u;
+    for (uint32_t t = 0; t < T; ++t) {
+        if (SEQ && t) act = load_action(a.actions, (uint64_t)t * a.B + env, act64);
         const bool in_range = act >= 0 && act < (int64_t)a.num_actions;  // gateset.get(action) (clifford.rs:324)
         GateEntry g = {QM_IDENTITY << 10, 0.0f};
-        if (in_range) g = lds_table ? s_gates[act] : a.gates[act];
+        if (in_range) g = a.gates[act];
         float penalty = g.penalty;
         if (FEAT && (a.flags & F_LAYERS) && in_range)
             penalty = layers_penalty(a.layers + env * (2 * a.N + 2), a.N, a.descs[act], a.w);
@@ -174,8 +179,8 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
         solved = qm_solved<NXP, HAS_Z>(s, a.N);     // clifford.rs:344
         const float achieved = solved ? 1.0f : 0.0f;
         reward = achieved - penalty;                // clifford.rs:345-346
-        if (a.rewards_seq) a.rewards_seq[(uint64_t)t * a.B + env] = reward;
-        if (a.dones_seq) a.dones_seq[(uint64_t)t * a.B + env] = (uint8_t)(depth == 0 || solved);
+        if (SEQ && a.rewards_seq) a.rewards_seq[(uint64_t)t * a.B + env] = reward;
+        if (SEQ && a.dones_seq) a.dones_seq[(uint64_t)t * a.B + env] = (uint8_t)(depth == 0 || solved);
     }
 
 #pragma unroll
@@ -295,11 +300,13 @@ static inline unsigned grid_for(uint64_t threads, unsigned block) { return (unsi
 
 template <int NXP, bool HAS_Z>
 static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
-    const size_t lds = (a.num_actions * sizeof(GateEntry) <= 32768) ? a.num_actions * sizeof(GateEntry) : 0;
-    if (a.flags & (F_TRACK | F_LAYERS))
-        hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true>), dim3(grid_for(a.B, 256)), dim3(256), lds, s, a);
-    else
-        hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, false>), dim3(grid_for(a.B, 256)), dim3(256), lds, s, a);
+    const dim3 grid(grid_for(a.B, 256)), block(256);
+    const bool feat = a.flags & (F_TRACK | F_LAYERS);
+    const bool seq = a.T != 1 || a.rewards_seq || a.dones_seq;
+    if (feat && seq) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true>), grid, block, 0, s, a);
+    else if (feat) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, false>), grid, block, 0, s, a);
+    else if (seq) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, false, false>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 template <int NXP, bool HAS_Z>

@@ -229,7 +229,8 @@ int qg_gate_parse(const char *name_in, const int64_t *idx, size_t n, qg_gate *ou
 static int vec_free_buffers(qg_vec *v) {
     void *ptrs[] = {v->state, v->own_depth ? v->depth : nullptr, v->own_reward ? v->reward : nullptr,
                     v->own_done ? v->done : nullptr, v->own_success ? v->success : nullptr, v->inverted, v->error, v->sol,
-                    v->sol_len, v->layers, v->d_gates, v->d_descs, v->scratch, v->rot, v->pmeta, v->d_prog};
+                    v->sol_len, v->layers, v->d_gates, v->d_descs, v->scratch, v->rot, v->pmeta, v->d_prog,
+                    v->d_qubit_perms, v->d_act_perms, v->perm_idx};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &g : v->graphs) {
@@ -771,16 +772,34 @@ int qg_vec_rollout(qg_vec *v, const void *actions_dev, int action_dtype, size_t 
     return QG_OK;
 }
 
-int qg_vec_observe_dense(qg_vec *v, int8_t *out_dev, void *stream) {
-    if (!v || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
+static int observe_dense_impl(qg_vec *v, int8_t *out_dev, const int32_t *perm_idx_dev, void *stream) {
     HIP_TRY(hipSetDevice(v->device));
     ObsArgs oa;
     qg_vec_info info;
     qg_vec_get_info(v, &info);
     fill_obs_args(v, oa, out_dev, QG_FMT_U8, (size_t)info.obs_rows * info.obs_cols);
-    HIP_TRY(launch_export(v, oa, (hipStream_t)stream));
+    v->perm_draw = true;  // PauliEnv::observe draws a new qubit permutation (pauli.rs:657-662)
+    v->perm_in = perm_idx_dev;
+    hipError_t e = launch_export(v, oa, (hipStream_t)stream);
+    v->perm_draw = false;
+    v->perm_in = nullptr;
+    v->observe_counter += 1;
+    HIP_TRY(e);
     return QG_OK;
 }
+
+int qg_vec_observe_dense(qg_vec *v, int8_t *out_dev, void *stream) {
+    if (!v || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
+    return observe_dense_impl(v, out_dev, nullptr, stream);
+}
+
+int qg_vec_pauli_observe_dense(qg_vec *v, int8_t *out_dev, const int32_t *perm_idx_dev, void *stream) {
+    if (!v || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
+    if (v->layout != LAYOUT_PAULI) return set_error(QG_ERR_INVALID, "not a PauliEnv batch");
+    return observe_dense_impl(v, out_dev, perm_idx_dev, stream);
+}
+
+int qg_vec_pauli_num_perms(const qg_vec *v) { return v ? (int)v->n_perms : -1; }
 
 int qg_vec_observe_packed(qg_vec *v, void *out_dev, void *stream) {
     if (!v || !out_dev) return set_error(QG_ERR_INVALID, "null argument");

@@ -72,6 +72,13 @@ struct qg_vec {
     void *pmeta = nullptr;   // [B] per-env rotation bookkeeping (alive mask, node order, count)
     void *d_prog = nullptr;  // [num_actions] micro-programs
     uint32_t rmax = 0;
+    uint8_t *d_qubit_perms = nullptr;  // [n_perms][N]  (add_perms)
+    int32_t *d_act_perms = nullptr;    // [n_perms][num_actions]
+    uint32_t *perm_idx = nullptr;      // [B] current_perm_idx
+    const int32_t *perm_in = nullptr;  // explicit draws for the next observe (not owned)
+    uint32_t n_perms = 0;
+    bool perm_draw = false;            // the export in flight is an observe() (draws a new perm)
+    uint64_t observe_counter = 0;
 
     // rollout graphs
     std::vector<qg::CachedGraph> graphs;

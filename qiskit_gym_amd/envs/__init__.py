@@ -8,3 +8,15 @@ from .gateset import (  # noqa: F401
     parse_gate,
     parse_gateset,
 )
+
+
+def __getattr__(name):  # lazy: the env classes need the built library only when used
+    if name in ("CliffordGym", "LinearFunctionGym", "PermutationGym", "PauliGym", "SYNTH_ENVS", "decode_pauli_solution"):
+        from . import synthesis
+
+        return getattr(synthesis, name)
+    if name == "RawEnv":
+        from .raw import RawEnv
+
+        return RawEnv
+    raise AttributeError(name)

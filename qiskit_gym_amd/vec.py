@@ -164,6 +164,21 @@ class VecEnv:
         _lib.check(self._L.qg_vec_observe_dense(self._h, out.data_ptr(), _stream_ptr()))
         return out
 
+    def pauli_observe(self, perm_idx: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """PauliEnv observe() with the qubit-permutation draws given explicitly (int32 [B])."""
+        r, c = self.obs_shape_
+        if out is None:
+            out = torch.empty((self.batch, r, c), dtype=torch.int8, device=self.device)
+        pp = None
+        if perm_idx is not None:
+            perm_idx = perm_idx.to(device=self.device, dtype=torch.int32).contiguous()
+            pp = perm_idx.data_ptr()
+        _lib.check(self._L.qg_vec_pauli_observe_dense(self._h, out.data_ptr(), pp, _stream_ptr()))
+        return out
+
+    def pauli_num_perms(self) -> int:
+        return int(self._L.qg_vec_pauli_num_perms(self._h))
+
     def observe_packed(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Bit-packed observation [B, D] words (what the multi-GPU all-gather moves)."""
         dt = {1: torch.uint8, 4: torch.int32, 8: torch.int64}[self.packed_word_bytes]

@@ -1,0 +1,102 @@
+"""The scalar `Env`-trait flavour of the C ABI (qg_env_*) replaying the reference's own recorded
+notebook transcripts (tests/golden/) on the GPU, plus clone / twists behaviour."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import OracleEnv  # noqa: E402
+from qiskit_gym_amd.envs.raw import RawEnv  # noqa: E402
+from util import line_gateset, grid_gateset  # noqa: E402
+
+
+def load(golden_dir, name):
+    return json.load(open(os.path.join(golden_dir, name)))
+
+
+def norm(gs):
+    return [(n, tuple(q)) for n, q in gs]
+
+
+def test_lf_notebook_transcripts_on_gpu(golden_dir):
+    d = load(golden_dir, "lf_line3_transcripts.json")
+    for seq in d["sequences"]:
+        env = RawEnv("linear_function", d["num_qubits"], d["gateset"], add_inverts=False, add_perms=False)
+        assert env.num_actions() == d["action_space_n"] and env.obs_shape() == d["obs_shape"]
+        env.set_state(np.array(d["start_state"]).flatten().tolist())
+        for a, want, fin in zip(seq["actions"], seq["states"], seq["is_final"]):
+            assert not env.is_final()
+            env.step(a)
+            full = np.zeros(9, dtype=np.int8)
+            full[env.observe()] = 1  # adapters.py:50-54
+            assert full.reshape(3, 3).tolist() == want
+            assert env.is_final() == fin
+
+
+@pytest.mark.parametrize("key", ["permutation_swap_0_8", "linear_function_cx_0_4", "clifford_h_2"])
+def test_recorded_synthesis_outputs_on_gpu(golden_dir, key):
+    rec = load(golden_dir, "notebook_solutions.json")[key]
+    gs = norm(rec["gateset"])
+    env = RawEnv(rec["env"], rec["num_qubits"], gs, add_inverts=False, add_perms=False)
+    env.set_state(np.array(rec["state"]).flatten().tolist())
+    actions = [gs.index((n, tuple(q))) for n, q in rec["circuit"]]
+    for a in actions:
+        assert not env.is_final()
+        env.step(a)
+    assert env.success() and env.is_final() and env.reward() > 0.9
+    assert env.solution() == actions
+    assert env.masks() == [False] * len(gs)
+
+
+def test_constructor_state_clone_and_inverts():
+    gs = line_gateset("clifford", 4)
+    env = RawEnv("clifford", 4, gs, add_perms=False)  # add_inverts defaults to True (clifford.rs:420)
+    ora = OracleEnv("clifford", 4, gs, add_perms=0)
+    # fresh env: identity, depth 1, success, reward 1.0 -> is_final (clifford.rs:214-245)
+    assert env.is_final() and env.success() and env.reward() == 1.0
+    rng = np.random.default_rng(0)
+    state = rng.integers(0, 2, size=64)
+    state = (np.eye(8, dtype=np.int64) + np.triu(state.reshape(8, 8), 1)) % 2  # unit upper triangular: invertible
+    env.set_state(state.flatten().tolist())
+    ora.set_state(state.flatten().tolist())
+    clone = env.clone()
+    for t in range(12):
+        a, coin = int(rng.integers(len(gs))), int(rng.integers(2))
+        env.step(a, coin)
+        ora.step(a, coin)
+        assert env.observe() == ora.observe()
+        assert np.float32(env.reward()).view(np.uint32) == ora.reward_bits()
+    assert env.solution() == ora.solution()
+    # the clone still holds the state it was cloned at
+    full = np.zeros(64, dtype=np.int64)
+    full[clone.observe()] = 1
+    assert full.tolist() == state.flatten().tolist()
+
+
+def test_twists_match_symmetry_rules():
+    # line-3 CX+SWAP: automorphisms {id, reversal}; both map the gateset onto itself
+    gs = line_gateset("linear_function", 3)
+    env = RawEnv("linear_function", 3, gs, add_inverts=False)
+    obs_perms, act_perms = env.twists()
+    assert len(obs_perms) == 2 and len(act_perms) == 2
+    assert obs_perms[0] == list(range(9)) and act_perms[0] == list(range(len(gs)))
+    perm = [2, 1, 0]
+    assert obs_perms[1] == [perm[r] * 3 + perm[c] for r in range(3) for c in range(3)]  # symmetry.rs:265-274
+    want_act = []
+    for name, (a, b) in gs:
+        key = (name, tuple(sorted((perm[a], perm[b]))) if name == "SWAP" else (perm[a], perm[b]))
+        idx = [i for i, (n2, q2) in enumerate(gs) if (n2, tuple(sorted(q2)) if n2 == "SWAP" else tuple(q2)) == key][-1]
+        want_act.append(idx)
+    assert act_perms[1] == want_act
+    # custom 3q Clifford gateset with H/S only on qubit 0: only the identity survives
+    cg = [("CX", (0, 1)), ("CX", (1, 0)), ("CX", (1, 2)), ("CX", (2, 1)), ("SWAP", (0, 1)), ("SWAP", (1, 2)), ("H", (0,)), ("S", (0,))]
+    env = RawEnv("clifford", 3, cg, add_inverts=False)
+    obs_perms, act_perms = env.twists()
+    assert len(obs_perms) == 1 and obs_perms[0] == list(range(36))
+    env = RawEnv("clifford", 3, cg, add_inverts=False, add_perms=False)
+    assert env.twists() == ([], [])
