@@ -84,15 +84,19 @@ def test_twists_match_symmetry_rules():
     env = RawEnv("linear_function", 3, gs, add_inverts=False)
     obs_perms, act_perms = env.twists()
     assert len(obs_perms) == 2 and len(act_perms) == 2
-    assert obs_perms[0] == list(range(9)) and act_perms[0] == list(range(len(gs)))
-    perm = [2, 1, 0]
-    assert obs_perms[1] == [perm[r] * 3 + perm[c] for r in range(3) for c in range(3)]  # symmetry.rs:265-274
-    want_act = []
-    for name, (a, b) in gs:
-        key = (name, tuple(sorted((perm[a], perm[b]))) if name == "SWAP" else (perm[a], perm[b]))
-        idx = [i for i, (n2, q2) in enumerate(gs) if (n2, tuple(sorted(q2)) if n2 == "SWAP" else tuple(q2)) == key][-1]
-        want_act.append(idx)
-    assert act_perms[1] == want_act
+    # the gate index map keeps the LAST gate of each canonical key (symmetry.rs:217-223), so with
+    # both SWAP(a,b) and SWAP(b,a) in the gateset even the identity twist maps SWAP(0,1) -> SWAP(1,0)
+    def want_act(perm):
+        out = []
+        for name, (a, b) in gs:
+            key = (name, tuple(sorted((perm[a], perm[b]))) if name == "SWAP" else (perm[a], perm[b]))
+            out.append([i for i, (n2, q2) in enumerate(gs) if (n2, tuple(sorted(q2)) if n2 == "SWAP" else tuple(q2)) == key][-1])
+        return out
+
+    for k, perm in enumerate(([0, 1, 2], [2, 1, 0])):  # sorted automorphisms of the 3-line
+        assert obs_perms[k] == [perm[r] * 3 + perm[c] for r in range(3) for c in range(3)]  # symmetry.rs:265-274
+        assert act_perms[k] == want_act(perm)
+    assert act_perms[0] == [0, 1, 2, 3, 5, 5, 7, 7]
     # custom 3q Clifford gateset with H/S only on qubit 0: only the identity survives
     cg = [("CX", (0, 1)), ("CX", (1, 0)), ("CX", (1, 2)), ("CX", (2, 1)), ("SWAP", (0, 1)), ("SWAP", (1, 2)), ("H", (0,)), ("S", (0,))]
     env = RawEnv("clifford", 3, cg, add_inverts=False)
