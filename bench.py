@@ -263,7 +263,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "rows_step_kernel<uint32_t>",
+                "kernel": "qg::qm_step_kernel<16, true, false, false>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -1,0 +1,87 @@
+"""World-size-2 (and 3) gloo tests of the multi-GPU host logic: shard ranges partition the batch,
+each rank's slice of the actions is its own, and the all-gathered packed observation is the
+global tensor in env order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from qiskit_gym_amd.distributed import all_gather_observation, local_actions, shard_range, unpack_rows_u32
+
+
+def test_shard_ranges_partition_the_batch():
+    for total in (1, 7, 64, 65536, 524288, 1000003):
+        for world in (1, 2, 3, 8):
+            covered = 0
+            for r in range(world):
+                start, count = shard_range(total, r, world)
+                assert start == covered
+                covered += count
+            assert covered == total
+    assert shard_range(524288, 3, 8) == (3 * 65536, 65536)
+    with pytest.raises(ValueError):
+        shard_range(8, 8, 8)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _global_packed(total, d):
+    g = torch.Generator().manual_seed(1234)
+    return torch.randint(-(2**31), 2**31 - 1, (total, d), dtype=torch.int64, generator=g).to(torch.int32)
+
+
+def _worker(rank, world, port, per_rank, d, result_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        total = per_rank * world
+        full = _global_packed(total, d)
+        start, count = shard_range(total, rank, world)
+        assert count == per_rank
+        local = full[start:start + count].clone()
+        gathered = all_gather_observation(local)
+        ok = torch.equal(gathered, full)
+        acts = torch.arange(3 * total).reshape(3, total)
+        mine = local_actions(acts, rank, world)
+        ok = ok and mine.shape == (3, per_rank) and int(mine[0, 0]) == start
+        # max-over-ranks timing reduction used by bench.py
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ok = ok and float(t.item()) == float(world)
+        result_q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_all_gather_of_packed_observations_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 96, 32, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    results = sorted(q.get(timeout=10) for _ in range(world))
+    assert results == [(r, True) for r in range(world)]
+
+
+def test_unpack_rows_matches_numpy():
+    rng = np.random.default_rng(0)
+    dense = rng.integers(0, 2, size=(5, 32, 32)).astype(np.uint64)
+    packed = (dense << np.arange(32, dtype=np.uint64)).sum(axis=2).astype(np.uint32).view(np.int32)
+    got = unpack_rows_u32(torch.from_numpy(packed.copy()), 32).numpy()
+    np.testing.assert_array_equal(got, dense.astype(np.int8))
