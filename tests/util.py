@@ -57,9 +57,11 @@ def rng_draw(seed: int, env: np.ndarray, t: int) -> np.ndarray:
         return splitmix64(np.uint64(seed) ^ inner)
 
 
-def rng_actions(seed: int, batch: int, n_draws: int, num_actions: int) -> np.ndarray:
-    """The draws qg_vec_reset(seed) uses: mulhi64(rng_draw, num_actions); shape [n_draws, B]."""
-    env = np.arange(batch, dtype=np.uint64)
+def rng_actions(seed: int, batch, n_draws: int, num_actions: int) -> np.ndarray:
+    """The draws qg_vec_reset(seed) uses: mulhi64(rng_draw, num_actions); shape [n_draws, B].
+    `batch`: an int (envs 0..B-1) or an array of env indices."""
+    env = np.arange(batch, dtype=np.uint64) if np.isscalar(batch) else np.asarray(batch, dtype=np.uint64)
+    batch = env.size
     out = np.zeros((n_draws, batch), dtype=np.int64)
     for t in range(n_draws):
         d = rng_draw(seed, env, t)
