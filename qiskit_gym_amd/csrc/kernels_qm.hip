@@ -132,10 +132,171 @@ __device__ inline uint32_t qm_apply(QmRows<NXP, HAS_Z> &s, uint32_t ops) {
     return m == QM_IDENTITY ? 0u : dirty;  // "no gate" writes nothing back
 }
 
+
+// ------------------------------------------------------------------------------------------
+// add_inverts (clifford.rs:262-270): state := state^-1 with probability 1/2 after every step.
+//
+// The reference runs Gauss-Jordan (clifford.rs:147-170).  The inverse of a matrix is unique, so
+// any correct algorithm is bit-exact.  CliffordEnv states are symplectic whenever they come from
+// reset() or from set_state(get_state(clifford)) -- then M^-1 = Omega M^T Omega with
+// Omega = [[0 I],[I 0]]: a 32x32 bit transpose in registers (~5x16 butterfly steps) instead of
+// O(D^3) row operations.  Whether a state is symplectic is established once, when it is installed
+// (qm_init_kernel verifies M * (Omega M^T Omega) == I and records it in bit 1 of the env's
+// `inverted` byte; gates and inversions preserve the property).  Envs holding any other matrix
+// take the Gauss-Jordan path below, which also detects singular matrices (the reference panics).
+//
+// Both work in "slot space": a square R x R matrix (R = 2*NXP) whose row i and column i belong to
+// the same slot; logical Z-columns N..2N-1 are moved to bit positions NXP..NXP+N-1 and back.
+#define QM_FLAG_INVERTED 1u
+#define QM_FLAG_SYMPLECTIC 2u
+
+__device__ inline uint32_t qm_cols_to_slots(uint32_t w, uint32_t N, uint32_t nxp) {
+    const uint32_t xm = (1u << N) - 1u;
+    return (w & xm) | (((w >> N) & xm) << nxp);
+}
+__device__ inline uint32_t qm_cols_from_slots(uint32_t w, uint32_t N, uint32_t nxp) {
+    const uint32_t xm = (1u << N) - 1u;
+    return (w & xm) | (((w >> nxp) & xm) << N);
+}
+
+// in-register 32x32 bit-matrix transpose (a[r] bit c <-> a[c] bit r)
+__device__ inline void qm_transpose32(uint32_t (&a)[32]) {
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int j = 16 >> st;
+        const uint32_t m = st == 0 ? 0x0000FFFFu : st == 1 ? 0x00FF00FFu : st == 2 ? 0x0F0F0F0Fu : st == 3 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            if ((k & j) == 0) {
+                const uint32_t t = ((a[k] >> j) ^ a[k + j]) & m;
+                a[k + j] ^= t;
+                a[k] ^= t << j;
+            }
+        }
+    }
+}
+
+// candidate inverse Omega M^T Omega of a CliffordEnv state, slot space in and out
+template <int NXP>
+__device__ inline void qm_symplectic_candidate(const uint32_t (&m)[32], uint32_t (&c)[32]) {
+    constexpr int R = 2 * NXP;
+    uint32_t t[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t[i] = m[i];
+    qm_transpose32(t);
+    const uint32_t rmask = R == 32 ? 0xFFFFFFFFu : ((1u << R) - 1u);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (i < R) {
+            const uint32_t w = t[(i + NXP) % R];
+            c[i] = ((w >> NXP) | (w << NXP)) & rmask;  // swap the X and Z column halves
+        } else {
+            c[i] = 0;
+        }
+    }
+}
+
+template <int NXP>
+__device__ inline void qm_to_slot_space(const QmRows<NXP, true> &s, uint32_t N, uint32_t (&m)[32]) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) m[i] = i < 2 * NXP ? qm_cols_to_slots(s.r[i], N, NXP) : 0u;
+}
+template <int NXP>
+__device__ inline void qm_from_slot_space(QmRows<NXP, true> &s, uint32_t N, const uint32_t (&m)[32]) {
+#pragma unroll
+    for (int i = 0; i < 2 * NXP; ++i) s.r[i] = qm_cols_from_slots(m[i], N, NXP);
+}
+
+// is `c` the inverse of `m`?  (both slot space; unused slots must be all-zero rows of the product)
+template <int NXP>
+__device__ inline bool qm_is_inverse(const uint32_t (&m)[32], const uint32_t (&c)[32], uint32_t N) {
+    constexpr int R = 2 * NXP;
+    uint32_t bad = 0;
+#pragma unroll 1
+    for (int i = 0; i < R; ++i) {
+        uint32_t row = 0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) row = (k == i) ? m[k] : row;  // m[i], i uniform
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) acc ^= (0u - ((row >> j) & 1u)) & c[j];
+        const bool real = (uint32_t)(i % NXP) < N;
+        bad |= acc ^ (real ? 1u << i : 0u);
+    }
+    return bad == 0;
+}
+
+// Gauss-Jordan in slot space for the envs that are not known to be symplectic.  Row operations
+// only (the first row below with the pivot bit is xor-ed into the pivot row instead of swapped
+// with it: a different elimination path to the same, unique, inverse).  Returns false for a
+// singular matrix -- the reference's `expect("CFState is singular; cannot invert")`.
+template <int NXP>
+__device__ __noinline__ bool qm_gauss_jordan(QmRows<NXP, true> &s, uint32_t N) {
+    constexpr int R = 2 * NXP;
+    uint32_t m[32], v[32];
+    qm_to_slot_space<NXP>(s, N, m);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const bool pad = i < R && (uint32_t)(i % NXP) >= N;
+        if (pad) m[i] = 1u << i;  // unused slots: a decoupled identity block, removed again below
+        v[i] = i < R ? 1u << i : 0u;
+    }
+    uint32_t singular = 0;
+#pragma unroll 1
+    for (int col = 0; col < R; ++col) {
+        uint32_t pm = 0, pv = 0;  // the pivot row (row `col`; col is wave-uniform)
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            pm = (k == col) ? m[k] : pm;
+            pv = (k == col) ? v[k] : pv;
+        }
+        uint32_t need = ((pm >> col) & 1u) - 1u;  // all ones while the diagonal bit is missing
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const uint32_t t = (r > col && r < R) ? (need & (0u - ((m[r] >> col) & 1u))) : 0u;
+            pm ^= m[r] & t;
+            pv ^= v[r] & t;
+            need &= ~t;
+        }
+        singular |= need;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const uint32_t t = (r != col && r < R) ? (0u - ((m[r] >> col) & 1u)) : 0u;
+            m[r] = (r == col) ? pm : (m[r] ^ (pm & t));
+            v[r] = (r == col) ? pv : (v[r] ^ (pv & t));
+        }
+    }
+    if (singular) return false;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const bool pad = i < R && (uint32_t)(i % NXP) >= N;
+        if (pad) v[i] = 0;
+    }
+    qm_from_slot_space<NXP>(s, N, v);
+    return true;
+}
+
+template <int NXP>
+__device__ inline void qm_symplectic_inverse(QmRows<NXP, true> &s, uint32_t N) {
+    uint32_t m[32], c[32];
+    qm_to_slot_space<NXP>(s, N, m);
+    qm_symplectic_candidate<NXP>(m, c);
+    qm_from_slot_space<NXP>(s, N, c);
+}
+
+template <int NXP>
+__device__ inline bool qm_check_symplectic(const QmRows<NXP, true> &s, uint32_t N) {
+    uint32_t m[32], c[32];
+    qm_to_slot_space<NXP>(s, N, m);
+    qm_symplectic_candidate<NXP>(m, c);
+    return qm_is_inverse<NXP>(m, c, N);
+}
+
 // FEAT: compile in the rarely used per-step extras (solution log, layer-weighted metrics); the
 // plain instantiation keeps the hot path free of their code and registers.
 // SEQ: several steps per launch (fused rollout) and/or per-step reward/done outputs.
-template <int NXP, bool HAS_Z, bool FEAT, bool SEQ>
+// INV: add_inverts (CliffordEnv only in this layout).
+template <int NXP, bool HAS_Z, bool FEAT, bool SEQ, bool INV = false>
 __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
     using Rows = QmRows<NXP, HAS_Z>;
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -152,12 +313,14 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
     Rows s;
     qm_load<NXP, HAS_Z>(tile, lane, s);
     int32_t depth = a.depth[env];
+    uint32_t iflags = INV ? a.inverted[env] : 0u;
 
     uint32_t dirty = 0;
     bool solved = false;
     float reward = 0.0f;
     uint32_t fault = 0;
     int32_t sol_n = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2] : 0;
+    int32_t sol_b = (FEAT && INV && (a.flags & F_TRACK)) ? a.sol_len[env * 2 + 1] : 0;
 
     const uint32_t T = SEQ ? a.T : 1u;
     for (uint32_t t = 0; t < T; ++t) {
@@ -171,11 +334,31 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
 
         dirty |= qm_apply<NXP, HAS_Z>(s, g.ops);  // apply_gate_to_state (clifford.rs:331)
 
-        if (FEAT && (a.flags & F_TRACK)) {  // clifford.rs:334-340 (never inverted in this layout)
-            if ((uint32_t)sol_n < a.sol_cap) a.sol[env * a.sol_cap + (uint32_t)sol_n++] = (uint32_t)act;
-            else fault |= 8u;
+        if (FEAT && (a.flags & F_TRACK)) {  // clifford.rs:334-340: the inverse-frame list grows from the back
+            if ((uint32_t)(sol_n + sol_b) < a.sol_cap) {
+                if (INV && (iflags & QM_FLAG_INVERTED)) a.sol[env * a.sol_cap + a.sol_cap - 1 - (uint32_t)sol_b++] = (uint32_t)act;
+                else a.sol[env * a.sol_cap + (uint32_t)sol_n++] = (uint32_t)act;
+            } else {
+                fault |= 8u;
+            }
         }
         depth = depth > 0 ? depth - 1 : 0;          // clifford.rs:342
+        if constexpr (INV && HAS_Z) {               // maybe_random_invert (clifford.rs:262-270)
+            const uint32_t coin = a.coins ? a.coins[(uint64_t)t * a.B + env]
+                                          : (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, env, a.step_index + t) >> 63);
+            if (coin & 1u) {
+                if (iflags & QM_FLAG_SYMPLECTIC) {
+                    qm_symplectic_inverse<NXP>(s, a.N);
+                    iflags ^= QM_FLAG_INVERTED;
+                    dirty = 0xFFFFFFFFu;
+                } else if (qm_gauss_jordan<NXP>(s, a.N)) {
+                    iflags ^= QM_FLAG_INVERTED;
+                    dirty = 0xFFFFFFFFu;
+                } else {
+                    fault |= QG_FAULT_SINGULAR;
+                }
+            }
+        }
         solved = qm_solved<NXP, HAS_Z>(s, a.N);     // clifford.rs:344
         const float achieved = solved ? 1.0f : 0.0f;
         reward = achieved - penalty;                // clifford.rs:345-346
@@ -190,8 +373,12 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
     a.reward[env] = reward;
     a.done[env] = (uint8_t)(depth == 0 || solved);  // is_final (clifford.rs:353)
     a.success[env] = (uint8_t)solved;
-    if (FEAT && (a.flags & F_TRACK)) a.sol_len[env * 2] = sol_n;
-    if (FEAT && fault) atomicOr(&a.error[env], fault);
+    if (FEAT && (a.flags & F_TRACK)) {
+        a.sol_len[env * 2] = sol_n;
+        if (INV) a.sol_len[env * 2 + 1] = sol_b;
+    }
+    if (INV) a.inverted[env] = (uint8_t)iflags;
+    if ((FEAT || INV) && fault) atomicOr(&a.error[env], fault);
 }
 
 // slot of matrix row `row`
@@ -243,7 +430,13 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
     a.success[env] = (uint8_t)solved;
     a.reward[env] = solved ? 1.0f : 0.0f;
     a.done[env] = (uint8_t)(a.depth_value == 0 || solved);
-    a.inverted[env] = 0;
+    // bit 1: the state is symplectic (identity and everything reached from it by gates is; an
+    // arbitrary set_state matrix is checked once, here), so inversions may use the transpose form
+    uint32_t symp = 0;
+    if constexpr (HAS_Z) {
+        if (a.check_symplectic) symp = (a.mode != 1 || qm_check_symplectic<NXP>(s, a.N)) ? QM_FLAG_SYMPLECTIC : 0u;
+    }
+    a.inverted[env] = (uint8_t)symp;
     a.error[env] = 0;
     a.sol_len[env * 2] = 0;
     a.sol_len[env * 2 + 1] = 0;
@@ -303,6 +496,12 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
     const dim3 grid(grid_for(a.B, 256)), block(256);
     const bool feat = a.flags & (F_TRACK | F_LAYERS);
     const bool seq = a.T != 1 || a.rewards_seq || a.dones_seq;
+    if constexpr (HAS_Z) {
+        if (a.flags & F_INVERTS) {  // the inversion variants always carry FEAT and SEQ (two kernels per NXP)
+            hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true>), grid, block, 0, s, a);
+            return hipGetLastError();
+        }
+    }
     if (feat && seq) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true>), grid, block, 0, s, a);
     else if (feat) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, false>), grid, block, 0, s, a);
     else if (seq) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, false, true>), grid, block, 0, s, a);

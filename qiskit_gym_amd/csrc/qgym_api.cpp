@@ -262,6 +262,7 @@ static void fill_init_args(const qg_vec *v, InitArgs &a) {
     a.N = v->N;
     a.log2L = v->log2L;
     a.num_actions = (uint32_t)v->gates.size();
+    a.check_symplectic = (v->layout == LAYOUT_TILE && (v->flags & F_INVERTS)) ? 1u : 0u;
 }
 
 static hipError_t launch_init(const qg_vec *v, const InitArgs &a, hipStream_t s) {
@@ -387,7 +388,8 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     const bool inverts = cfg->add_inverts && cfg->env_kind != QG_PAULI;
     // thread-per-env TILE layout for matrices of <= 32 rows (the hot path); the inversion path
     // (add_inverts) lives in the lane-group ROWS kernels
-    if (v->layout == LAYOUT_ROWS32 && !inverts && getenv("QGYM_FORCE_ROWS") == nullptr) {
+    const bool tile_ok = !inverts || cfg->env_kind == QG_CLIFFORD;  // LinearFunction inversion stays in ROWS
+    if (v->layout == LAYOUT_ROWS32 && tile_ok && getenv("QGYM_FORCE_ROWS") == nullptr) {
         v->layout = LAYOUT_TILE;
         v->nxp = (N + 3u) & ~3u;
         v->has_z = cfg->env_kind == QG_CLIFFORD;

@@ -131,6 +131,7 @@ struct InitArgs {
     uint32_t format;          // qg_state_format
     uint32_t mode;            // 0 identity, 1 set_state, 2 scramble
     uint32_t layers_len;
+    uint32_t check_symplectic; // TILE layout with add_inverts: record whether the state is symplectic
 };
 
 struct ObsArgs {
