@@ -193,3 +193,32 @@ def test_singular_inverse_is_reported():
 
     with pytest.raises(QGymError):
         gv.sync()
+
+
+@pytest.mark.parametrize("n", [16, 5])
+def test_inverts_on_arbitrary_invertible_states(n):
+    """set_state with invertible but NOT symplectic matrices: the inversion must take the general
+    Gauss-Jordan path (and symplectic ones the transpose path) with identical results."""
+    gateset = line_gateset("clifford", n)
+    A = len(gateset)
+    B, D = 192, 2 * n
+    ov, gv = make_pair("clifford", n, gateset, B, add_inverts=True, add_perms=False, track_solution=True, max_depth=64)
+    rng = np.random.default_rng(77 + n)
+    states = np.zeros((B, D, D), dtype=np.int64)
+    for e in range(B):
+        m = np.eye(D, dtype=np.int64)
+        for _ in range(6 * D):  # random row operations: invertible, almost never symplectic
+            a, b = rng.integers(D, size=2)
+            if a != b:
+                m[a] ^= m[b]
+        states[e] = m
+    states[0] = np.eye(D, dtype=np.int64)  # symplectic member of the batch
+    ov.set_state(states.reshape(B, -1))
+    gv.set_state(states.reshape(B, -1), "i64")
+    for t in range(24):
+        acts = rng.integers(0, A, size=B)
+        coins = rng.integers(0, 2, size=B)
+        _compare_step(ov, gv, acts, coins, label=f"t={t}")
+    _compare_state(ov, gv, D * D, "end")
+    for e in (0, 1, B - 1):
+        assert gv.solution(e) == ov.env(e).solution()
