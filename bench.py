@@ -36,6 +36,7 @@ NUM_QUBITS = 16
 ENVS_PER_GPU = 65536
 SCRAMBLE = 256
 CHUNK = 256  # steps per hipGraph replay (single-GPU path)
+RING = 16    # pre-sampled action buffers the steps cycle through (a policy rewrites ONE buffer per step)
 ALGO_BYTES_PER_STEP = 160  # 128 B state read + 16 B touched rows + 16 B scalars
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -128,16 +129,16 @@ def main():
 
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
-    actions = torch.randint(0, A, (CHUNK, B), dtype=torch.int32, device=dev, generator=gen)
+    actions = torch.randint(0, A, (RING, B), dtype=torch.int32, device=dev, generator=gen)
 
     def run_steps_single(nsteps: int):
         """nsteps env.step() launches: whole chunks replay a cached hipGraph of CHUNK launches."""
         done = 0
         while nsteps - done >= CHUNK:
-            env.rollout(actions, fused=False)
+            env.rollout_ring(actions, CHUNK)
             done += CHUNK
         for t in range(nsteps - done):
-            env.step(actions[t])
+            env.step(actions[t % RING])
 
     # ---- multi-GPU: step + all-gather of the packed observation, double buffered -------------
     if world > 1:
@@ -150,7 +151,7 @@ def main():
         def run_steps_multi(nsteps: int):
             for t in range(nsteps):
                 b = t & 1
-                env.step(actions[t % CHUNK])
+                env.step(actions[t % RING])
                 if args.no_gather:
                     continue
                 stream.wait_event(gather_done[b])  # the gather that last read snap[b] has finished
@@ -200,7 +201,7 @@ def main():
     with torch.cuda.stream(stream):
         for i in range(reps):
             starts[i].record(stream)
-            env.step(actions[i % CHUNK])
+            env.step(actions[i % RING])
             stops[i].record(stream)
     torch.cuda.synchronize()
     per_launch_us = sorted(s.elapsed_time(e) * 1e3 for s, e in zip(starts, stops))
@@ -220,17 +221,19 @@ def main():
     # ---- fused rollout (state in registers across steps), reported beside the headline --------
     fused = None
     if world == 1:
+        FT = 128
+        facts = torch.randint(0, A, (FT, B), dtype=torch.int32, device=dev, generator=gen)
         with torch.cuda.stream(stream):
-            env.rollout(actions, fused=True)
+            env.rollout(facts, fused=True)
             torch.cuda.synchronize()
             f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             f0.record(stream)
             for _ in range(8):
-                env.rollout(actions, fused=True)
+                env.rollout(facts, fused=True)
             f1.record(stream)
         torch.cuda.synchronize()
         fms = f0.elapsed_time(f1)
-        fused = {"value": B * CHUNK * 8 / (fms * 1e-3), "unit": "env-steps/s", "steps_per_launch": CHUNK}
+        fused = {"value": B * FT * 8 / (fms * 1e-3), "unit": "env-steps/s", "steps_per_launch": FT}
 
     out = None
     if rank == 0:
@@ -253,7 +256,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "CliffordGym 16 qubits, line-16 bidirectional, 170 actions (H,S,Sdg,SX,SXdg,CX,CZ,SWAP), "
-                            f"{B} envs per GPU, start = identity + {SCRAMBLE} random gates, uniform random actions, "
+                            f"{B} envs per GPU, start = identity + {SCRAMBLE} random gates, uniform random actions "
+                            f"(ring of {RING} pre-sampled action buffers, as a policy rewriting one resident buffer per step), "
                             "add_inverts=False, add_perms=False, track_solution=False, default weights, free-running",
                 "envs_per_gpu": B,
                 "total_envs": B * n_gpus,

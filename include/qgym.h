@@ -181,6 +181,12 @@ int qg_vec_step(qg_vec *v, const void *actions_dev, int action_dtype, const uint
 int qg_vec_rollout(qg_vec *v, const void *actions_dev, int action_dtype, size_t n_steps, const uint8_t *coins_dev,
                    float *rewards_dev, uint8_t *dones_dev, int fused, void *stream);
 
+/* Graph rollout whose step t reads the action slice t % period of actions_dev[period][B]: n_steps
+ * single-step launches over a small ring of action buffers -- the access pattern of a policy that
+ * rewrites one resident action buffer every step (cache-hot), where qg_vec_rollout streams a
+ * [n_steps][B] tensor from HBM. */
+int qg_vec_rollout_ring(qg_vec *v, const void *actions_dev, int action_dtype, size_t n_steps, size_t period, void *stream);
+
 /* Env::observe for every env, densified the way the Gym adapter does it (adapters.py:50-54):
  * out_dev[e * obs_rows*obs_cols + r*obs_cols + c] in {0,1}, int8. */
 int qg_vec_observe_dense(qg_vec *v, int8_t *out_dev, void *stream);

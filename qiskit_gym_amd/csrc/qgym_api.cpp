@@ -698,8 +698,21 @@ int qg_vec_step(qg_vec *v, const void *actions_dev, int action_dtype, const uint
     return QG_OK;
 }
 
+static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, size_t T, size_t period, const uint8_t *coins_dev,
+                        float *rewards_dev, uint8_t *dones_dev, int fused, void *stream);
+
 int qg_vec_rollout(qg_vec *v, const void *actions_dev, int action_dtype, size_t T, const uint8_t *coins_dev,
                    float *rewards_dev, uint8_t *dones_dev, int fused, void *stream) {
+    return rollout_impl(v, actions_dev, action_dtype, T, T, coins_dev, rewards_dev, dones_dev, fused, stream);
+}
+
+int qg_vec_rollout_ring(qg_vec *v, const void *actions_dev, int action_dtype, size_t T, size_t period, void *stream) {
+    if (period == 0) return set_error(QG_ERR_INVALID, "period must be positive");
+    return rollout_impl(v, actions_dev, action_dtype, T, period, nullptr, nullptr, nullptr, 0, stream);
+}
+
+static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, size_t T, size_t period, const uint8_t *coins_dev,
+                        float *rewards_dev, uint8_t *dones_dev, int fused, void *stream) {
     if (!v || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
     if (action_dtype != QG_ACT_I32 && action_dtype != QG_ACT_I64) return set_error(QG_ERR_INVALID, "bad action dtype");
     if (T == 0) return QG_OK;
@@ -714,6 +727,7 @@ int qg_vec_rollout(qg_vec *v, const void *actions_dev, int action_dtype, size_t 
     a.dones_seq = dones_dev;
     if (action_dtype == QG_ACT_I64) a.flags |= F_ACT64;
     if (fused) {
+        if (period != T) return set_error(QG_ERR_INVALID, "fused rollouts read actions[t] for every t");
         a.T = (uint32_t)T;
         HIP_TRY(launch_step(v, a, s));
         v->step_index += T;
@@ -724,7 +738,8 @@ int qg_vec_rollout(qg_vec *v, const void *actions_dev, int action_dtype, size_t 
         for (size_t t = 0; t < T; ++t) {
             StepArgs b = a;
             b.T = 1;
-            b.actions = (const char *)actions_dev + t * v->B * act_bytes;
+            b.actions = (const char *)actions_dev + (t % period) * v->B * act_bytes;
+            b.next_actions = nullptr;
             b.coins = coins_dev ? coins_dev + t * v->B : nullptr;
             b.rewards_seq = rewards_dev ? rewards_dev + t * v->B : nullptr;
             b.dones_seq = dones_dev ? dones_dev + t * v->B : nullptr;
@@ -744,7 +759,7 @@ int qg_vec_rollout(qg_vec *v, const void *actions_dev, int action_dtype, size_t 
         v->step_index += T;
         return QG_OK;
     }
-    GraphKey key{actions_dev, coins_dev, rewards_dev, dones_dev, T, action_dtype};
+    GraphKey key{actions_dev, coins_dev, rewards_dev, dones_dev, T, action_dtype, period};
     CachedGraph *cg = nullptr;
     for (auto &g : v->graphs)
         if (g.key == key) cg = &g;

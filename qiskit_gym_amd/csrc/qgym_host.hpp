@@ -17,9 +17,10 @@ struct GraphKey {
     const void *dones;
     size_t T;
     int dtype;
+    size_t period;
     bool operator==(const GraphKey &o) const {
         return actions == o.actions && coins == o.coins && rewards == o.rewards && dones == o.dones && T == o.T &&
-               dtype == o.dtype;
+               dtype == o.dtype && period == o.period;
     }
 };
 struct CachedGraph {

@@ -79,6 +79,7 @@ __host__ __device__ inline uint32_t rng_action(uint64_t seed, uint64_t env, uint
 struct StepArgs {
     void *state;
     const void *actions;      // [T][B]
+    const void *next_actions; // unused (a next-slice cache warm-up was measured to change nothing)
     const uint8_t *coins;     // [T][B] or null
     const GateEntry *gates;   // [num_actions]
     const uint32_t *descs;    // [num_actions] kind | q0<<8 | q1<<16 (F_LAYERS, PauliEnv)

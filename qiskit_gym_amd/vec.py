@@ -156,6 +156,13 @@ class VecEnv:
         _lib.check(self._L.qg_vec_rollout(self._h, ptr, dt, T, cp, rp, dp, 1 if fused else 0, _stream_ptr()))
         return self.reward, self.done
 
+    def rollout_ring(self, actions: torch.Tensor, n_steps: int):
+        """n_steps single-step launches (one cached hipGraph); step t uses actions[t % len(actions)]."""
+        actions = actions.contiguous()
+        ptr, dt = self._act(actions)
+        _lib.check(self._L.qg_vec_rollout_ring(self._h, ptr, dt, int(n_steps), actions.shape[0], _stream_ptr()))
+        return self.reward, self.done
+
     def observe(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Dense int8 observation [B, rows, cols] (the Gym adapter's `_full_obs`, adapters.py:50-54)."""
         r, c = self.obs_shape_

@@ -100,6 +100,7 @@ static float time_variant(const StepArgs &a, int iters, hipStream_t st) {
     return ms * 1e3f / iters;
 }
 
+static int g_ring = 1 << 30;
 static float time_real(const StepArgs &a, int iters, hipStream_t st, bool distinct) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -107,8 +108,45 @@ static float time_real(const StepArgs &a, int iters, hipStream_t st, bool distin
     CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     for (int i = 0; i < iters; ++i) {
         StepArgs b = a;
-        if (distinct) b.actions = (const char *)a.actions + (size_t)i * a.B * 4;
+        if (distinct) b.actions = (const char *)a.actions + (size_t)(i % g_ring) * a.B * 4;
         CK(qm_step(b, 16, true, st));
+    }
+    CK(hipStreamEndCapture(st, &graph));
+    CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(exec, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    CK(hipGraphLaunch(exec, st));
+    CK(hipEventRecord(e1, st));
+    CK(hipStreamSynchronize(st));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    hipGraphExecDestroy(exec); hipGraphDestroy(graph);
+    return ms * 1e3f / iters;
+}
+
+// S independent sub-batch chains inside one graph (fork at the start, join at the end)
+static float time_real_chains(const StepArgs &a, int iters, hipStream_t st, int S) {
+    hipEvent_t e0, e1, fork, joins[16];
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    hipStream_t sub[16];
+    for (int i = 0; i < S; ++i) { CK(hipStreamCreateWithFlags(&sub[i], hipStreamNonBlocking)); CK(hipEventCreateWithFlags(&joins[i], hipEventDisableTiming)); }
+    hipGraph_t graph; hipGraphExec_t exec;
+    const uint64_t Bs = a.B / S;  // multiple of 64 for the sizes used here
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    CK(hipEventRecord(fork, st));
+    for (int c = 0; c < S; ++c) {
+        CK(hipStreamWaitEvent(sub[c], fork, 0));
+        for (int i = 0; i < iters; ++i) {
+            StepArgs b = a;
+            const uint64_t base = c * Bs;
+            b.B = Bs;
+            b.state = (char *)a.state + base * 128;
+            b.actions = (const char *)a.actions + ((size_t)i * a.B + base) * 4;
+            b.depth = a.depth + base; b.reward = a.reward + base; b.done = a.done + base; b.success = a.success + base;
+            CK(qm_step(b, 16, true, sub[c]));
+        }
+        CK(hipEventRecord(joins[c], sub[c]));
+        CK(hipStreamWaitEvent(st, joins[c], 0));
     }
     CK(hipStreamEndCapture(st, &graph));
     CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
@@ -153,6 +191,9 @@ int main(int argc, char **argv) {
     printf("V7 reward only     block256: %.2f\n", time_variant<7, 256>(a, it, st));
     printf("REAL qm_step_kernel same actions : %.2f\n", time_real(a, it, st, false));
     printf("REAL qm_step_kernel distinct     : %.2f\n", time_real(a, it, st, true));
+    for (int ring : {2, 4, 16, 64, 256}) { g_ring = ring; printf("REAL distinct, ring of %3d action slices : %.2f\n", ring, time_real(a, it, st, true)); }
+    g_ring = 1 << 30;
+    for (int S : {1}) printf("REAL distinct, %2d sub-batch chains : %.2f us per full step\n", S, time_real_chains(a, it, st, S));
     g_distinct_actions = true;
     printf("-- distinct action slice per launch --\n");
     printf("V2 +compute(glob)  block256: %.2f\n", time_variant<2, 256>(a, it, st));
