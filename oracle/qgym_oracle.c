@@ -951,6 +951,154 @@ int og_pauli_reset_from(og_env *e, const uint8_t *tableau, const char *labels, s
     return pauli_finish_rebuild(e);                  /* :579-585 */
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * PauliEnv::reset target generator (rust/src/envs/pauli.rs:54-271, 554-586).
+ * The reference draws from rand::thread_rng(); here every draw comes from the counter RNG
+ * `rng_draw(seed ^ 0x7061756C, env_index, k)`, k = 0,1,2,... (the same stream libqgym uses), with
+ *   gen_range(0..n) = mulhi64(u, n)        gen::<f32>() = (u >> 40) * 2^-24.
+ * `for q in &qubits` iterates a HashSet in the reference (random order); the per-qubit axis draws
+ * are i.i.d., so iterating in ascending order leaves the distribution unchanged.
+ * ---------------------------------------------------------------------------------------- */
+static uint64_t og_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+typedef struct {
+    uint64_t seed, env, k;
+} og_rng;
+static uint64_t og_next(og_rng *r) {
+    uint64_t v = og_splitmix64(r->seed ^ og_splitmix64(r->env * 0x9E3779B97F4A7C15ull + r->k));
+    r->k++;
+    return v;
+}
+static size_t og_range(og_rng *r, size_t n) { return (size_t)(((unsigned __int128)og_next(r) * (unsigned __int128)n) >> 64); }
+static float og_f32(og_rng *r) { return (float)(og_next(r) >> 40) * (1.0f / 16777216.0f); }
+
+int og_pauli_reset_seeded(og_env *e, uint64_t seed, uint64_t env_index) {
+    if (e->kind != OG_ENV_PAULI) return fail("not a PauliEnv");
+    const size_t n = e->n;
+    og_rng rng = {seed ^ 0x7061756Cull, env_index, 0};
+    /* valid_pairs: the CX gates of the gateset, in order (pauli.rs:360-366) */
+    size_t np = 0;
+    size_t *pa = (size_t *)malloc(sizeof(size_t) * (e->n_gates ? e->n_gates : 1) * 2);
+    for (size_t i = 0; i < e->n_gates; i++)
+        if (e->gates[i].kind == OG_CX) {
+            pa[2 * np] = (size_t)e->gates[i].q0;
+            pa[2 * np + 1] = (size_t)e->gates[i].q1;
+            np++;
+        }
+    /* compute_graph_distances (pauli.rs:56-91): BFS over the undirected CX graph */
+    uint8_t *adj = (uint8_t *)calloc(n * n ? n * n : 1, 1);
+    for (size_t i = 0; i < np; i++) {
+        adj[pa[2 * i] * n + pa[2 * i + 1]] = 1;
+        adj[pa[2 * i + 1] * n + pa[2 * i]] = 1;
+    }
+    long *dist = (long *)malloc(sizeof(long) * (n * n ? n * n : 1));
+    for (size_t i = 0; i < n * n; i++) dist[i] = -1;
+    size_t *queue = (size_t *)malloc(sizeof(size_t) * (n ? n : 1));
+    for (size_t st = 0; st < n; st++) {
+        size_t qh = 0, qt = 0;
+        queue[qt++] = st;
+        dist[st * n + st] = 0;
+        while (qh < qt) {
+            size_t u = queue[qh++];
+            for (size_t w = 0; w < n; w++)
+                if (adj[u * n + w] && dist[st * n + w] < 0) {
+                    dist[st * n + w] = dist[st * n + u] + 1;
+                    queue[qt++] = w;
+                }
+        }
+    }
+    /* build_dist_pairs (pauli.rs:95-111): pairs q1<q2 grouped by distance, distances ascending */
+    size_t maxd = 0;
+    for (size_t a = 0; a < n; a++)
+        for (size_t b = a + 1; b < n; b++)
+            if (dist[a * n + b] > (long)maxd) maxd = (size_t)dist[a * n + b];
+    /* pairs of distance d listed in (q1, q2) lexicographic order, as the nested loops push them */
+    const size_t pauli_difficulty = e->difficulty / e->pauli_diff_scale; /* pauli.rs:557 */
+    const size_t max_paulis = e->final_pauli_layers;
+    char *labels = (char *)malloc((n + 1) * (max_paulis ? max_paulis : 1) + 1);
+    size_t n_lab = 0, lp = 0;
+    size_t remaining = pauli_difficulty;
+    uint8_t *inset = (uint8_t *)malloc(n ? n : 1);
+    size_t *cand = (size_t *)malloc(sizeof(size_t) * (n * n ? n * n : 1) * 2);
+    size_t *vd = (size_t *)malloc(sizeof(size_t) * (maxd + 2));
+    while (remaining > 0 && n_lab < max_paulis) { /* generate_paulis_with_difficulty (pauli.rs:191-213) */
+        /* get_pauli_under_diff(remaining) (pauli.rs:115-188) */
+        const size_t difficulty = remaining;
+        size_t nvd = 0;
+        for (size_t d = 1; d <= maxd; d++) {
+            int present = 0;
+            for (size_t a = 0; a < n && !present; a++)
+                for (size_t b = a + 1; b < n; b++)
+                    if (dist[a * n + b] == (long)d) { present = 1; break; }
+            if (present && d <= difficulty) vd[nvd++] = d;
+        }
+        if (nvd == 0) break; /* None */
+        memset(inset, 0, n ? n : 1);
+        size_t pauli_diff = difficulty;
+        size_t next_dif = vd[og_range(&rng, nvd)];
+        size_t nc = 0;
+        for (size_t a = 0; a < n; a++)
+            for (size_t b = a + 1; b < n; b++)
+                if (dist[a * n + b] == (long)next_dif) { cand[2 * nc] = a; cand[2 * nc + 1] = b; nc++; }
+        size_t pick = og_range(&rng, nc);
+        inset[cand[2 * pick]] = 1;
+        inset[cand[2 * pick + 1]] = 1;
+        pauli_diff = sat_sub(pauli_diff, next_dif);
+        for (;;) {
+            size_t nv2 = 0, rem_q = 0;
+            for (size_t i = 0; i < nvd; i++) if (vd[i] <= pauli_diff) nv2++;
+            for (size_t q = 0; q < n; q++) if (!inset[q]) rem_q++;
+            if (pauli_diff == 0 || nv2 == 0 || rem_q == 0) break;
+            if (og_f32(&rng) <= e->num_qubits_decay) break; /* continue with probability 1 - decay */
+            next_dif = vd[og_range(&rng, nv2)]; /* valid_diffs is a prefix of the ascending valid_dists */
+            nc = 0;
+            for (size_t a = 0; a < n; a++)
+                for (size_t b = a + 1; b < n; b++)
+                    if (dist[a * n + b] == (long)next_dif && (inset[a] || inset[b])) { cand[2 * nc] = a; cand[2 * nc + 1] = b; nc++; }
+            if (nc == 0) continue;
+            pick = og_range(&rng, nc);
+            inset[cand[2 * pick]] = 1;
+            inset[cand[2 * pick + 1]] = 1;
+            pauli_diff = sat_sub(pauli_diff, next_dif);
+        }
+        for (size_t q = 0; q < n; q++) labels[lp + q] = inset[q] ? "XYZ"[og_range(&rng, 3)] : 'I';
+        labels[lp + n] = '\0';
+        lp += n + 1;
+        n_lab++;
+        const size_t cost = difficulty - pauli_diff;
+        remaining = sat_sub(remaining, cost > 1 ? cost : 1);
+    }
+    labels[lp] = '\0';
+    /* random_clifford_tableau (pauli.rs:220-271) */
+    const size_t dim = 2 * n;
+    uint8_t *tab = (uint8_t *)malloc(dim * dim ? dim * dim : 1);
+    mat_identity(tab, dim);
+    if (e->difficulty != 0 && np != 0) {
+        for (size_t it = 0; it < e->difficulty; it++) {
+            const float r = og_f32(&rng);
+            if (r > 0.3f) {
+                const size_t k = og_range(&rng, np), q0 = pa[2 * k], q1 = pa[2 * k + 1];
+                for (size_t c = 0; c < dim; c++) tab[q1 * dim + c] ^= tab[q0 * dim + c];
+                for (size_t c = 0; c < dim; c++) tab[(n + q0) * dim + c] ^= tab[(n + q1) * dim + c];
+            } else if (r > 0.15f) {
+                const size_t q = og_range(&rng, n);
+                swap_rows(tab, dim, q, n + q);
+            } else {
+                const size_t q = og_range(&rng, n);
+                for (size_t c = 0; c < dim; c++) tab[(n + q) * dim + c] ^= tab[q * dim + c];
+            }
+        }
+    }
+    int rc = og_pauli_reset_from(e, tab, labels, n_lab);
+    free(pa); free(adj); free(dist); free(queue); free(labels); free(inset); free(cand); free(vd); free(tab);
+    return rc;
+}
+
 int og_pauli_set_perms(og_env *e, const int64_t *qp, const int64_t *ap, size_t n_perms) {
     if (e->kind != OG_ENV_PAULI) return fail("not a PauliEnv");
     free(e->qubit_perms);

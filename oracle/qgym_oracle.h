@@ -110,6 +110,9 @@ void og_env_metrics(const og_env *e, size_t out[4]);
  * explicit tableau (row-major 2N x 2N of 0/1) and rotation labels ('\0'-separated, n_rot of
  * them), clean trivial rotations, apply the depth rule, reset internals. */
 int og_pauli_reset_from(og_env *e, const uint8_t *tableau, const char *labels, size_t n_rot);
+/* The whole of PauliEnv::reset (pauli.rs:554-586) including the random target generator
+ * (pauli.rs:54-271), every draw taken from the counter RNG stream of (seed, env_index). */
+int og_pauli_reset_seeded(og_env *e, uint64_t seed, uint64_t env_index);
 /* Install qubit/action permutations (symmetry.rs:307-361 output) for add_perms runs. */
 int og_pauli_set_perms(og_env *e, const int64_t *qubit_perms, const int64_t *act_perms, size_t n_perms);
 /* Active rotations in DAG node order (pauli_network.rs:176-181); returns count. */

@@ -447,6 +447,7 @@ int pauli_plan(qg_vec *v) {
         return set_error(QG_ERR_UNSUPPORTED, "PauliEnv: at most %u rotations per env supported (max_rotations=%d, final_pauli_layers=%d)",
                          PAULI_RMAX, max_rot, final_layers);
     v->rmax = (uint32_t)rmax;
+    v->rmax_generate = (uint32_t)final_layers;  // reset() generates at most final_pauli_layers rotations (pauli.rs:563)
     v->cfg.max_rotations = max_rot;
     v->stride_bytes = (size_t)16 * v->N;
     v->log2L = PAULI_LOG2L;
@@ -690,6 +691,136 @@ int pauli_reset_from(qg_vec *v, const uint8_t *tableaus, const char *labels, con
             lp += N;
         }
         int rc = host_net_build(v, h, e, tableaus + e * (size_t)D * D, labs);
+        if (rc) return rc;
+    }
+    const int64_t d = (int64_t)v->cfg.depth_slope * v->difficulty;  // pauli.rs:578
+    return host_net_upload(v, h, true, (int32_t)std::min<int64_t>(d, v->cfg.max_depth), s);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// PauliEnv::reset (pauli.rs:554-586) with its random target generator (pauli.rs:54-271).
+// Targets are generated on the host (reset is not on the step path) from the handle's counter RNG:
+// draw k of env e is rng_draw(seed ^ 0x7061756C, e, k); gen_range(0..n) = mulhi64(u, n),
+// gen::<f32>() = (u >> 40) * 2^-24.  The reference's RNG cannot be seeded, so only the
+// distribution is fixed by it; the stream definition is what tests replay.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Stream {
+    uint64_t seed, env, k = 0;
+    uint64_t next() { return rng_draw(seed, env, k++); }
+    size_t range(size_t n) { return (size_t)(((unsigned __int128)next() * (unsigned __int128)n) >> 64); }
+    float f32() { return (float)(next() >> 40) * (1.0f / 16777216.0f); }
+};
+
+struct CouplingInfo {  // constructor-time data of PauliEnv::new (pauli.rs:360-370)
+    std::vector<std::pair<uint32_t, uint32_t>> valid_pairs;         // CX gates, gateset order
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> by_dist; // by_dist[d]: pairs q1<q2 at graph distance d
+    std::vector<uint32_t> all_dists;                                  // ascending distances that occur
+};
+
+CouplingInfo coupling_info(const qg_vec *v) {
+    CouplingInfo ci;
+    const uint32_t n = v->N;
+    for (const qg_gate &g : v->gates)
+        if (g.kind == QG_CX) ci.valid_pairs.emplace_back((uint32_t)g.q0, (uint32_t)g.q1);
+    std::vector<std::vector<uint32_t>> adj(n);
+    for (auto &pr : ci.valid_pairs) {  // compute_graph_distances (pauli.rs:56-91)
+        auto add = [&](uint32_t a, uint32_t b) { if (std::find(adj[a].begin(), adj[a].end(), b) == adj[a].end()) adj[a].push_back(b); };
+        add(pr.first, pr.second);
+        add(pr.second, pr.first);
+    }
+    std::vector<std::vector<int>> dist(n, std::vector<int>(n, -1));
+    for (uint32_t st = 0; st < n; ++st) {
+        std::vector<uint32_t> q{st};
+        dist[st][st] = 0;
+        for (size_t h = 0; h < q.size(); ++h)
+            for (uint32_t w : adj[q[h]])
+                if (dist[st][w] < 0) { dist[st][w] = dist[st][q[h]] + 1; q.push_back(w); }
+    }
+    for (uint32_t a = 0; a < n; ++a)  // build_dist_pairs (pauli.rs:95-111)
+        for (uint32_t b = a + 1; b < n; ++b)
+            if (dist[a][b] >= 0) {
+                if (ci.by_dist.size() <= (size_t)dist[a][b]) ci.by_dist.resize(dist[a][b] + 1);
+                ci.by_dist[dist[a][b]].emplace_back(a, b);
+            }
+    for (uint32_t d = 0; d < ci.by_dist.size(); ++d)
+        if (!ci.by_dist[d].empty()) ci.all_dists.push_back(d);
+    return ci;
+}
+
+// get_pauli_under_diff (pauli.rs:115-188); false = None
+bool pauli_under_diff(const CouplingInfo &ci, uint32_t n, size_t difficulty, float decay, Stream &rng, std::string &label, size_t &cost) {
+    std::vector<uint32_t> valid;
+    for (uint32_t d : ci.all_dists) if (d <= difficulty) valid.push_back(d);
+    if (valid.empty()) return false;
+    std::vector<uint8_t> in(n, 0);
+    size_t budget = difficulty;
+    uint32_t d = valid[rng.range(valid.size())];
+    auto pr = ci.by_dist[d][rng.range(ci.by_dist[d].size())];
+    in[pr.first] = in[pr.second] = 1;
+    budget = budget > d ? budget - d : 0;
+    for (;;) {
+        size_t n_ok = 0, free_q = 0;
+        for (uint32_t x : valid) n_ok += x <= budget;  // `valid` is ascending: the usable ones are a prefix
+        for (uint32_t q = 0; q < n; ++q) free_q += !in[q];
+        if (budget == 0 || n_ok == 0 || free_q == 0) break;
+        if (rng.f32() <= decay) break;
+        d = valid[rng.range(n_ok)];
+        std::vector<std::pair<uint32_t, uint32_t>> touching;
+        for (auto &p2 : ci.by_dist[d]) if (in[p2.first] || in[p2.second]) touching.push_back(p2);
+        if (touching.empty()) continue;
+        pr = touching[rng.range(touching.size())];
+        in[pr.first] = in[pr.second] = 1;
+        budget = budget > d ? budget - d : 0;
+    }
+    label.assign(n, 'I');
+    for (uint32_t q = 0; q < n; ++q) if (in[q]) label[q] = "XYZ"[rng.range(3)];
+    cost = difficulty - budget;
+    return true;
+}
+}  // namespace
+
+int pauli_reset_seeded(qg_vec *v, uint64_t seed, hipStream_t s) {
+    const uint32_t n = v->N, D = 2 * n;
+    const CouplingInfo ci = coupling_info(v);
+    const size_t scale = (size_t)std::max(v->cfg.pauli_diff_scale, 1);  // pauli.rs:392
+    const size_t pauli_difficulty = (size_t)v->difficulty / scale;      // pauli.rs:557
+    HostNet h;
+    host_net_init(v, h);
+    std::vector<uint8_t> tab((size_t)D * D);
+    for (uint64_t e = 0; e < v->B; ++e) {
+        Stream rng{seed ^ 0x7061756Cull, e};
+        std::vector<std::string> labels;  // generate_paulis_with_difficulty (pauli.rs:191-213)
+        size_t remaining = pauli_difficulty;
+        while (remaining > 0 && labels.size() < (size_t)v->rmax_generate) {
+            std::string lab;
+            size_t cost = 0;
+            if (!pauli_under_diff(ci, n, remaining, v->cfg.num_qubits_decay, rng, lab, cost)) break;
+            labels.push_back(lab);
+            const size_t dec = std::max<size_t>(cost, 1);
+            remaining = remaining > dec ? remaining - dec : 0;
+        }
+        std::fill(tab.begin(), tab.end(), 0);  // random_clifford_tableau (pauli.rs:220-271)
+        for (uint32_t i = 0; i < D; ++i) tab[(size_t)i * D + i] = 1;
+        if (v->difficulty != 0 && !ci.valid_pairs.empty()) {
+            auto xor_rows = [&](uint32_t a, uint32_t b) { for (uint32_t c = 0; c < D; ++c) tab[(size_t)a * D + c] ^= tab[(size_t)b * D + c]; };
+            for (int64_t it = 0; it < v->difficulty; ++it) {
+                const float r = rng.f32();
+                if (r > 0.3f) {
+                    auto pr = ci.valid_pairs[rng.range(ci.valid_pairs.size())];
+                    xor_rows(pr.second, pr.first);
+                    xor_rows(n + pr.first, n + pr.second);
+                } else if (r > 0.15f) {
+                    const uint32_t q = (uint32_t)rng.range(n);
+                    for (uint32_t c = 0; c < D; ++c) std::swap(tab[(size_t)q * D + c], tab[(size_t)(n + q) * D + c]);
+                } else {
+                    const uint32_t q = (uint32_t)rng.range(n);
+                    xor_rows(n + q, q);
+                }
+            }
+        }
+        int rc = host_net_build(v, h, e, tab.data(), labels);
         if (rc) return rc;
     }
     const int64_t d = (int64_t)v->cfg.depth_slope * v->difficulty;  // pauli.rs:578

@@ -656,8 +656,10 @@ int qg_vec_get_state(qg_vec *v, void *out, int format, size_t stride, int on_dev
 
 static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint64_t seed, hipStream_t s) {
     HIP_TRY(hipSetDevice(v->device));
-    if (v->layout == LAYOUT_PAULI)
-        return set_error(QG_ERR_UNSUPPORTED, "PauliEnv reset needs a generated target: use qg_vec_pauli_reset_from");
+    if (v->layout == LAYOUT_PAULI) {
+        if (actions_dev) return set_error(QG_ERR_UNSUPPORTED, "PauliEnv reset draws a whole target, not `difficulty` actions: use qg_vec_reset(seed) or qg_vec_pauli_reset_from");
+        return pauli_reset_seeded(v, seed, s);
+    }
     if (v->gates.empty() && n_draws)  // Uniform::new(0, 0) panics in the reference
         return set_error(QG_ERR_PANIC, "reset with an empty gateset (the reference panics in Uniform::new(0, 0))");
     InitArgs ia;

@@ -73,6 +73,7 @@ struct qg_vec {
     void *pmeta = nullptr;   // [B] per-env rotation bookkeeping (alive mask, node order, count)
     void *d_prog = nullptr;  // [num_actions] micro-programs
     uint32_t rmax = 0;
+    uint32_t rmax_generate = 0;  // final_pauli_layers: most rotations reset() generates
     uint8_t *d_qubit_perms = nullptr;  // [n_perms][N]  (add_perms)
     int32_t *d_act_perms = nullptr;    // [n_perms][num_actions]
     uint32_t *perm_idx = nullptr;      // [B] current_perm_idx
@@ -96,6 +97,7 @@ int pauli_alloc(qg_vec *v);
 int pauli_init_identity(qg_vec *v, hipStream_t s);
 int pauli_set_state(qg_vec *v, const void *states, int format, size_t stride, int on_device, hipStream_t s);
 int pauli_reset_from(qg_vec *v, const uint8_t *tableaus, const char *labels, const int32_t *n_rot, hipStream_t s);
+int pauli_reset_seeded(qg_vec *v, uint64_t seed, hipStream_t s);
 hipError_t pauli_step(const qg_vec *v, const StepArgs &a, hipStream_t s);
 hipError_t pauli_export(const qg_vec *v, const ObsArgs &a, hipStream_t s);
 }  // namespace qg

@@ -106,6 +106,7 @@ def lib():
     L.og_env_get_state_i64.argtypes = [vp, i64p, sz]
     L.og_env_metrics.argtypes = [vp, C.POINTER(sz)]
     L.og_pauli_reset_from.argtypes = [vp, u8p, C.c_char_p, sz]
+    L.og_pauli_reset_seeded.argtypes = [vp, C.c_uint64, C.c_uint64]
     L.og_pauli_set_perms.argtypes = [vp, i64p, i64p, sz]
     L.og_pauli_active_rotations.restype = sz
     L.og_pauli_active_rotations.argtypes = [vp, i64p, sz]
@@ -281,6 +282,9 @@ class OracleEnv:
         t = np.ascontiguousarray(np.asarray(tableau, dtype=np.uint8).reshape(-1))
         blob = b"".join(s.encode() + b"\0" for s in labels) + b"\0"
         self._check(lib().og_pauli_reset_from(self._h, _ptr(t, C.c_uint8), blob, len(labels)))
+
+    def pauli_reset_seeded(self, seed: int, env_index: int):
+        self._check(lib().og_pauli_reset_seeded(self._h, int(seed), int(env_index)))
 
     def pauli_set_perms(self, qubit_perms, act_perms):
         qp = np.ascontiguousarray(np.asarray(qubit_perms, dtype=np.int64).reshape(-1))

@@ -191,3 +191,32 @@ def test_pauli_add_perms_observe_and_action_unpermute():
         np.testing.assert_array_equal(gv.success.cpu().numpy(), [int(o.success()) for o in envs])
     for e in range(0, batch, 9):
         assert gv.solution(e) == envs[e].solution()  # the log holds the un-permuted (actual) actions
+
+
+@pytest.mark.parametrize("n,difficulty,scale", [(6, 40, 4), (20, 96, 16), (4, 3, 8)])
+def test_pauli_reset_generates_the_replayed_target(n, difficulty, scale):
+    """qg_vec_reset(seed) on a PauliEnv batch = PauliEnv::reset with its target generator
+    (reference pauli.rs:54-271, 554-586) on the documented counter-RNG stream."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    gateset = line_gateset("pauli", n)
+    batch = 48
+    cfg = dict(add_perms=False, track_solution=False, max_rotations=5, difficulty=difficulty, pauli_diff_scale=scale)
+    gv = VecEnv("pauli", n, gateset, batch, **cfg)
+    gv.reset(seed=0xC0FFEE)
+    gv.sync()
+    envs = []
+    for e in range(batch):
+        o = OracleEnv("pauli", n, gateset, **{k: int(v) for k, v in cfg.items()})
+        o.pauli_reset_seeded(0xC0FFEE, e)
+        envs.append(o)
+    np.testing.assert_array_equal(gv.observe().cpu().numpy(), np.stack([o.dense_obs() for o in envs]))
+    np.testing.assert_array_equal(gv.depth.cpu().numpy(), [o.depth() for o in envs])
+    np.testing.assert_array_equal(gv.success.cpu().numpy(), [int(o.success()) for o in envs])
+    assert any(o.active_rotations() for o in envs) or difficulty // scale == 0
+    # and the scalar Gym front-end can reset a PauliGym
+    from qiskit_gym_amd.envs import PauliGym
+
+    g = PauliGym.from_coupling_map([(i, i + 1) for i in range(n - 1)] + [(i + 1, i) for i in range(n - 1)], difficulty=difficulty, add_perms=False)
+    obs, info = g.reset(seed=3)
+    assert obs.shape == (2 * n, 2 * n + 5) and obs.dtype == np.int8
