@@ -162,7 +162,11 @@ int qg_vec_get_state(qg_vec *v, void *out, int format, size_t stride_elems, int 
  *   action = mulhi64(splitmix64(seed ^ splitmix64(e * 0x9E3779B97F4A7C15 + t)), num_actions)
  * so the oracle can replay it.  (PauliEnv: see qg_vec_pauli_reset_from.) */
 int qg_vec_reset(qg_vec *v, uint64_t seed, void *stream);
-/* Same, with the draws supplied: actions_dev[t*B + e], t < n_draws (int32). */
+/* Env::reset for the envs whose episode is over (done flag set) only; the others are untouched.
+ * Lets a GPU-resident collector run episode after episode without a host round trip; pass a
+ * fresh seed per call (e.g. a step counter) so successive episodes of an env differ. */
+int qg_vec_reset_done(qg_vec *v, uint64_t seed, void *stream);
+/* Same as qg_vec_reset, with the draws supplied: actions_dev[t*B + e], t < n_draws (int32). */
 int qg_vec_reset_with(qg_vec *v, const int32_t *actions_dev, size_t n_draws, void *stream);
 
 /* Env::step for every env (clifford.rs:321-347): one kernel launch.

@@ -76,7 +76,7 @@ class QGymError(RuntimeError):
 EXPORTED_SYMBOLS = [
     "qg_config_default", "qg_last_error", "qg_abi_version", "qg_device_count", "qg_gate_parse",
     "qg_vec_create", "qg_vec_destroy", "qg_vec_get_info", "qg_vec_bind_outputs", "qg_vec_set_difficulty", "qg_vec_get_difficulty",
-    "qg_vec_set_state", "qg_vec_get_state", "qg_vec_reset", "qg_vec_reset_with", "qg_vec_step", "qg_vec_rollout", "qg_vec_rollout_ring",
+    "qg_vec_set_state", "qg_vec_get_state", "qg_vec_reset", "qg_vec_reset_done", "qg_vec_reset_with", "qg_vec_step", "qg_vec_rollout", "qg_vec_rollout_ring",
     "qg_vec_observe_dense", "qg_vec_observe_packed", "qg_vec_masks", "qg_vec_pauli_reset_from", "qg_vec_pauli_observe_dense", "qg_vec_pauli_num_perms", "qg_vec_sync",
     "qg_vec_solution",
     "qg_env_create", "qg_env_clone", "qg_env_destroy", "qg_env_num_actions", "qg_env_obs_shape",
@@ -119,6 +119,7 @@ def load():
     L.qg_vec_set_state.argtypes = [vp, vp, C.c_int, sz, C.c_int, vp]
     L.qg_vec_get_state.argtypes = [vp, vp, C.c_int, sz, C.c_int, vp]
     L.qg_vec_reset.argtypes = [vp, u64, vp]
+    L.qg_vec_reset_done.argtypes = [vp, u64, vp]
     L.qg_vec_reset_with.argtypes = [vp, vp, sz, vp]
     L.qg_vec_step.argtypes = [vp, vp, C.c_int, vp, vp]
     L.qg_vec_rollout.argtypes = [vp, vp, C.c_int, sz, vp, vp, vp, C.c_int, vp]

@@ -392,6 +392,7 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
     if (env >= a.B) return;
+    if (a.only_done && !a.done[env]) return;  // qg_vec_reset_done: live episodes keep running
     uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Rows::G * 64);
     Rows s;
     qm_identity<NXP, HAS_Z>(s, a.N);

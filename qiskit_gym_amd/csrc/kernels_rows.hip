@@ -290,8 +290,10 @@ __global__ __launch_bounds__(256) void rows_init_kernel(InitArgs a) {
     const uint32_t lie = (uint32_t)gid & (L - 1);
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
     const uint32_t base = lane & ~(L - 1);
-    const bool valid = env_raw < a.B;
-    const uint64_t env = valid ? env_raw : a.B - 1;
+    const uint64_t env = env_raw < a.B ? env_raw : a.B - 1;
+    // lanes of envs that are skipped (tail, or live episodes under qg_vec_reset_done) still take
+    // part in the shuffles and the ballot below; they just store nothing
+    const bool valid = env_raw < a.B && !(a.only_done && !a.done[env]);
 
     W ident[RPL], r[RPL];
     identity_rows<W>(ident, lie, a.D);

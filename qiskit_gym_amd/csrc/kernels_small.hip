@@ -144,6 +144,7 @@ template <bool PERM>
 __global__ __launch_bounds__(256) void word_init_kernel(InitArgs a) {
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= a.B) return;
+    if (a.only_done && !a.done[env]) return;  // qg_vec_reset_done
     const uint64_t ident = PERM ? perm_identity(a.N) : lf8_identity(a.N);
     uint64_t s = ident;
     uint32_t fault = 0;

@@ -654,8 +654,10 @@ int qg_vec_get_state(qg_vec *v, void *out, int format, size_t stride, int on_dev
     return QG_OK;
 }
 
-static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint64_t seed, hipStream_t s) {
+static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint64_t seed, hipStream_t s, bool only_done = false) {
     HIP_TRY(hipSetDevice(v->device));
+    if (only_done && v->layout == LAYOUT_PAULI)
+        return set_error(QG_ERR_UNSUPPORTED, "PauliEnv targets are generated on the host: reset the whole batch with qg_vec_reset");
     if (v->layout == LAYOUT_PAULI) {
         if (actions_dev) return set_error(QG_ERR_UNSUPPORTED, "PauliEnv reset draws a whole target, not `difficulty` actions: use qg_vec_reset(seed) or qg_vec_pauli_reset_from");
         return pauli_reset_seeded(v, seed, s);
@@ -668,6 +670,7 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
     ia.actions = actions_dev;
     ia.n_draws = (uint32_t)n_draws;
     ia.seed = seed;
+    ia.only_done = only_done ? 1u : 0u;
     int64_t d = (int64_t)v->cfg.depth_slope * v->difficulty;  // clifford.rs:317
     ia.depth_value = (int32_t)std::min<int64_t>(d, v->cfg.max_depth);
     HIP_TRY(launch_init(v, ia, s));
@@ -678,6 +681,11 @@ int qg_vec_reset(qg_vec *v, uint64_t seed, void *stream) {
     if (!v) return set_error(QG_ERR_INVALID, "null argument");
     return do_reset(v, nullptr, (size_t)v->difficulty, seed, (hipStream_t)stream);
 }
+int qg_vec_reset_done(qg_vec *v, uint64_t seed, void *stream) {
+    if (!v) return set_error(QG_ERR_INVALID, "null argument");
+    return do_reset(v, nullptr, (size_t)v->difficulty, seed, (hipStream_t)stream, true);
+}
+
 int qg_vec_reset_with(qg_vec *v, const int32_t *actions_dev, size_t n_draws, void *stream) {
     if (!v || (!actions_dev && n_draws)) return set_error(QG_ERR_INVALID, "null argument");
     if ((int64_t)n_draws != v->difficulty)

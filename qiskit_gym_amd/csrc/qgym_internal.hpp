@@ -133,6 +133,7 @@ struct InitArgs {
     uint32_t mode;            // 0 identity, 1 set_state, 2 scramble
     uint32_t layers_len;
     uint32_t check_symplectic; // TILE layout with add_inverts: record whether the state is symplectic
+    uint32_t only_done;        // reset only the envs whose `done` flag is set (auto-reset between episodes)
 };
 
 struct ObsArgs {

@@ -115,6 +115,10 @@ class VecEnv:
     def reset(self, seed: int = 0):
         _lib.check(self._L.qg_vec_reset(self._h, int(seed) & (2**64 - 1), _stream_ptr()))
 
+    def reset_done(self, seed: int):
+        """reset() only the envs whose episode is over (`done` set); stream-ordered, no host sync."""
+        _lib.check(self._L.qg_vec_reset_done(self._h, int(seed) & (2**64 - 1), _stream_ptr()))
+
     def reset_with(self, actions: torch.Tensor):
         """actions: int32 [difficulty, B] scramble draws (the reference's reset() RNG made explicit)."""
         a = actions.to(device=self.device, dtype=torch.int32).contiguous().view(-1, self.batch)
