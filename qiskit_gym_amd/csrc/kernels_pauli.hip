@@ -18,35 +18,19 @@
 //                rotation weight is one popcount, the DAG front layer is `pred & alive == 0`, and a
 //                clean pass is a wave ballot of (alive & front & weight<=1).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "device_common.hpp"
-#include "qgym_host.hpp"
+#include "pauli_common.hpp"
 
 namespace qg {
 
 #define PAULI_L 32u
 #define PAULI_LOG2L 5u
-#define PAULI_RMAX 16u
 
-struct PauliMeta {
-    uint32_t alive;  // bit k: rotation k still in the DAG
-    uint32_t count;  // number of DAG nodes
-    uint64_t order;  // nibble i = rotation index held by DAG node i (petgraph NodeIndex order)
-};
-static_assert(sizeof(PauliMeta) == 16, "PauliMeta must be 16 bytes");
-
-struct PauliRot {
-    uint32_t x, z;   // base_x / base_z bit q = qubit q (pauli.rs:41-42)
-    uint32_t phase;  // base_phase mod 4 (pauli.rs:43)
-    uint32_t pred;   // earlier rotations that do not commute with this one (DAG out-edges, pauli_dag.rs:35-41)
-};
-static_assert(sizeof(PauliRot) == 16, "PauliRot must be 16 bytes");
-
-// micro-ops a gate decomposes into (pauli_network.rs:225-260)
-enum : uint32_t { M_NOP = 0, M_H = 1, M_S = 2, M_SX = 3, M_CNOT = 4 };
 static inline uint64_t mop(uint32_t kind, uint32_t a, uint32_t b) { return (uint64_t)(kind | (a << 4) | (b << 10)); }
 static uint64_t gate_program(const qg_gate &g) {
     const uint32_t a = (uint32_t)g.q0, b = (uint32_t)g.q1;
@@ -451,16 +435,24 @@ int pauli_plan(qg_vec *v) {
     v->cfg.max_rotations = max_rot;
     v->stride_bytes = (size_t)16 * v->N;
     v->log2L = PAULI_LOG2L;
+    // thread-per-env PTILE family by default; QGYM_PAULI_LANES=1 keeps the lane-group kernels
+    v->pauli_tile = getenv("QGYM_PAULI_LANES") == nullptr;
+    if (v->pauli_tile) return ptile_plan(v);
     return QG_OK;
 }
 
 int pauli_alloc(qg_vec *v) {
-    HIP_TRY(hipMalloc(&v->rot, sizeof(PauliRot) * v->rmax * v->B));
-    HIP_TRY(hipMalloc(&v->pmeta, sizeof(PauliMeta) * v->B));
-    std::vector<uint64_t> prog(std::max<size_t>(v->gates.size(), 1));
-    for (size_t i = 0; i < v->gates.size(); ++i) prog[i] = gate_program(v->gates[i]);
-    HIP_TRY(hipMalloc(&v->d_prog, sizeof(uint64_t) * prog.size()));
-    HIP_TRY(hipMemcpy(v->d_prog, prog.data(), sizeof(uint64_t) * prog.size(), hipMemcpyHostToDevice));
+    if (v->pauli_tile) {
+        int rc = ptile_alloc(v);
+        if (rc) return rc;
+    } else {
+        HIP_TRY(hipMalloc(&v->rot, sizeof(PauliRot) * v->rmax * v->B));
+        HIP_TRY(hipMalloc(&v->pmeta, sizeof(PauliMeta) * v->B));
+        std::vector<uint64_t> prog(std::max<size_t>(v->gates.size(), 1));
+        for (size_t i = 0; i < v->gates.size(); ++i) prog[i] = gate_program(v->gates[i]);
+        HIP_TRY(hipMalloc(&v->d_prog, sizeof(uint64_t) * prog.size()));
+        HIP_TRY(hipMemcpy(v->d_prog, prog.data(), sizeof(uint64_t) * prog.size(), hipMemcpyHostToDevice));
+    }
     if (v->cfg.add_perms) {  // compute_qubit_perms (symmetry.rs:307-361)
         std::vector<std::vector<int64_t>> qp, ap;
         compute_qubit_and_action_perms(v->N, v->gates, qp, ap);
@@ -498,6 +490,7 @@ static void fill_pauli_args(const qg_vec *v, const StepArgs &a, PauliArgs &pa) {
 
 hipError_t pauli_step(const qg_vec *v, const StepArgs &a, hipStream_t s) {
     if (!a.B) return hipSuccess;
+    if (v->pauli_tile) return ptile_step(v, a, s);
     PauliArgs pa;
     fill_pauli_args(v, a, pa);
     hipLaunchKernelGGL(pauli_step_kernel, dim3(grid_for(a.B * PAULI_L, 256)), dim3(256), 0, s, pa);
@@ -506,6 +499,7 @@ hipError_t pauli_step(const qg_vec *v, const StepArgs &a, hipStream_t s) {
 
 hipError_t pauli_export(const qg_vec *v, const ObsArgs &a, hipStream_t s) {
     if (!a.B) return hipSuccess;
+    if (v->pauli_tile) return ptile_export(v, a, s);
     PauliObsArgs pa;
     pa.o = a;
     pa.rot = reinterpret_cast<const PauliRot *>(v->rot);
@@ -550,12 +544,6 @@ static bool parse_label(const std::string &label, uint32_t N, PauliRot &r, std::
 // !commutes_with (pauli.rs:112-123): parity of the symplectic product
 static bool anticommute(const PauliRot &a, const PauliRot &b) { return (__builtin_popcount(a.x & b.z) + __builtin_popcount(a.z & b.x)) & 1; }
 
-struct HostNet {
-    std::vector<uint64_t> tab;   // [B][N][2]
-    std::vector<PauliRot> rot;   // [B][rmax]
-    std::vector<PauliMeta> meta; // [B]
-};
-
 static void host_net_init(const qg_vec *v, HostNet &h) {
     h.tab.assign((size_t)v->B * v->N * 2, 0);
     h.rot.assign((size_t)v->B * v->rmax, PauliRot{0, 0, 0, 0});
@@ -591,6 +579,7 @@ static int host_net_build(const qg_vec *v, HostNet &h, uint64_t e, const uint8_t
 }
 
 static int host_net_upload(qg_vec *v, const HostNet &h, bool do_clean, int32_t depth_value, hipStream_t s) {
+    if (v->pauli_tile) return ptile_upload(v, h, do_clean, depth_value, s);
     HIP_TRY(hipMemcpyAsync(v->state, h.tab.data(), sizeof(uint64_t) * h.tab.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(v->rot, h.rot.data(), sizeof(PauliRot) * h.rot.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(v->pmeta, h.meta.data(), sizeof(PauliMeta) * h.meta.size(), hipMemcpyHostToDevice, s));

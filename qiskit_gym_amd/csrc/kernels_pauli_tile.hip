@@ -1,0 +1,607 @@
+// kernels_pauli_tile.hip -- PauliEnv, thread-per-env ("PTILE" layout).  The default PauliEnv path.
+//
+// Reference semantics (same as kernels_pauli.hip, the lane-group family it replaces by default):
+//   PauliEnv::step / observe / reset tail     rust/src/envs/pauli.rs:588-635, 411-485, 573-585
+//   PauliNetwork::{act,cnot,h,s,sx,clean_and_return_with_phases,solved}   rust/src/pauli/pauli_network.rs:139-260
+//   Pauli::{evolve_h,evolve_s,evolve_cx,evolve_sx,phase}                  rust/src/pauli/pauli.rs:83-133
+//   PauliDag::get_front_layer                 rust/src/pauli/pauli_dag.rs:47-57
+//   petgraph 0.6.5 Graph::retain_nodes / remove_node (reverse visit + Vec::swap_remove): third
+//   party, restated from its published source (fixes the observation's rotation-column order).
+//
+// Why: the lane-group kernel spends ~200 wave-instructions per env-step (32 lanes per env).  Here a
+// lane owns a whole env -- 2N tableau rows as uint64 plus <= RM rotation records in VGPRs -- so a
+// wave instruction advances 64 envs and nothing crosses lanes.
+//
+//  * Tableau: the micro-ops of one gate (pauli_network.rs:225-260) act on the rows of at most two
+//    qubits and are linear, and rotation removal never touches the tableau, so the whole gate is
+//    ONE 4x4 GF(2) map on {X[a], Z[a], X[b], Z[b]} compiled on the host (CX = the reference's
+//    reversed `cnot`, CZ = H.cnot.H, SWAP = three cnots, Sdg/SXdg = S/SX on bits).
+//  * Rotations: micro-op by micro-op, because `clean` runs after every cnot and phases are not
+//    linear.  A rotation is (x mask, z mask, 2-bit phase); phases of all rotations live in two
+//    bit-planes so one micro-op updates them with three logic ops.  Weight = popc(x|z), front layer
+//    = pred & alive == 0, node order = nibble-packed word (swap_remove order, high to low).
+//
+// Memory (PTILE layout): tiles of 64 envs; a tile is NQ + RM + 1 groups of 1 KiB, group g holding
+// one uint4 per lane: groups 0..NQ-1 = {X row q, Z row q} of qubit q (two uint64), groups
+// NQ..NQ+RM-1 = rotation k {x, z, phase, pred}, last group = {alive, count, order}.  Every wave
+// access is a contiguous 16 B/lane, 1 KiB transaction.
+#include <algorithm>
+#include <cstring>
+
+#include "device_common.hpp"
+#include "pauli_common.hpp"
+
+namespace qg {
+
+// ---- host: per-action program word --------------------------------------------------------------
+// [0:5) qa  [5:10) qb  [10:26) tableau map M (bit 4k+i: output k takes input i, order Xa,Za,Xb,Zb)
+// [26:38) three micro-ops, 4 bits each: kind | (operands swapped ? 8 : 0)
+static uint64_t ptile_program(const qg_gate &g) {
+    const uint32_t a = (uint32_t)g.q0, b = g.kind >= QG_CX ? (uint32_t)g.q1 : (uint32_t)g.q0;
+    struct Mop { uint32_t kind; bool swapped; };
+    Mop mops[3] = {{M_NOP, false}, {M_NOP, false}, {M_NOP, false}};
+    switch (g.kind) {  // PauliNetwork::act (pauli_network.rs:225-260)
+    case QG_H: mops[0] = {M_H, false}; break;
+    case QG_S: mops[0] = {M_S, false}; break;
+    case QG_SDG: mops[0] = mops[1] = mops[2] = {M_S, false}; break;
+    case QG_SX: mops[0] = {M_SX, false}; break;
+    case QG_SXDG: mops[0] = mops[1] = mops[2] = {M_SX, false}; break;
+    case QG_CX: mops[0] = {M_CNOT, false}; break;
+    case QG_CZ: mops[0] = {M_H, true}; mops[1] = {M_CNOT, false}; mops[2] = {M_H, true}; break;
+    case QG_SWAP: mops[0] = {M_CNOT, false}; mops[1] = {M_CNOT, true}; mops[2] = {M_CNOT, false}; break;
+    }
+    // symbolic execution of the micro-ops on {Xa, Za, Xb, Zb}; with a == b the b-slots alias the a-slots
+    uint32_t row[4] = {1, 2, 4, 8};
+    auto X = [&](bool second) -> uint32_t & { return row[(second && a != b) ? 2 : 0]; };
+    auto Z = [&](bool second) -> uint32_t & { return row[(second && a != b) ? 3 : 1]; };
+    uint64_t mbits = 0;
+    for (int k = 0; k < 3; ++k) {
+        const bool p = mops[k].swapped, q = !mops[k].swapped;  // operand -> "is it qubit b"
+        switch (mops[k].kind) {
+        case M_H: std::swap(X(p), Z(p)); break;                         // :189-194
+        case M_S: Z(p) ^= X(p); break;                                   // :209-215
+        case M_SX: X(p) ^= Z(p); break;                                  // :217-223
+        case M_CNOT: X(p) ^= X(q); Z(q) ^= Z(p); break;                  // cnot(i=p, j=q) :196-201
+        default: break;
+        }
+        mbits |= (uint64_t)(mops[k].kind | (mops[k].swapped ? 8u : 0u)) << (26 + 4 * k);
+    }
+    const uint64_t M = row[0] | (row[1] << 4) | (row[2] << 8) | (row[3] << 12);
+    return (uint64_t)(a & 31u) | ((uint64_t)(b & 31u) << 5) | (M << 10) | mbits;
+}
+
+// ---- device helpers ------------------------------------------------------------------------------
+template <int n>
+__device__ inline uint64_t tree_select64(const uint64_t (&t)[n], uint32_t q) {
+    if constexpr (n == 1) {
+        return t[0];
+    } else {
+        constexpr int m = (n + 1) / 2;
+        uint64_t u[m];
+        const uint64_t mb = 0ull - (uint64_t)(q & 1u);  // arithmetic blend, see kernels_qm.hip tree_select
+#pragma unroll
+        for (int k = 0; k < m; ++k) u[k] = (2 * k + 1 < n) ? ((t[2 * k + 1] & mb) | (t[2 * k] & ~mb)) : t[2 * k];
+        return tree_select64<m>(u, q >> 1);
+    }
+}
+__device__ inline uint32_t pnib(uint64_t order, uint32_t i) { return (uint32_t)(order >> (4 * i)) & 0xFu; }
+
+template <int NQ, int RM>
+struct PTState {
+    uint64_t X[NQ], Z[NQ];
+    uint32_t rx[RM], rz[RM], rpred[RM];
+    uint32_t plo, phi;  // phase bit-planes: phase of rotation k = ((phi >> k) & 1) * 2 + ((plo >> k) & 1)
+    uint32_t alive, count;
+    uint64_t order;
+};
+
+template <int NQ, int RM>
+__device__ inline void pt_load(const uint4 *tile, uint32_t lane, PTState<NQ, RM> &s) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const uint4 v = tile[q * 64 + lane];
+        s.X[q] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        s.Z[q] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    }
+    s.plo = s.phi = 0;
+#pragma unroll
+    for (int k = 0; k < RM; ++k) {
+        const uint4 v = tile[(NQ + k) * 64 + lane];
+        s.rx[k] = v.x;
+        s.rz[k] = v.y;
+        s.plo |= (v.z & 1u) << k;
+        s.phi |= ((v.z >> 1) & 1u) << k;
+        s.rpred[k] = v.w;
+    }
+    const uint4 m = tile[(NQ + RM) * 64 + lane];
+    s.alive = m.x;
+    s.count = m.y;
+    s.order = (uint64_t)m.z | ((uint64_t)m.w << 32);
+}
+
+// the gate's composite tableau map on {X[qa], Z[qa], X[qb], Z[qb]}
+template <int NQ, int RM>
+__device__ inline void pt_apply_tableau(PTState<NQ, RM> &s, uint32_t qa, uint32_t qb, uint32_t m) {
+    const uint64_t xa = tree_select64<NQ>(s.X, qa), za = tree_select64<NQ>(s.Z, qa);
+    const uint64_t xb = tree_select64<NQ>(s.X, qb), zb = tree_select64<NQ>(s.Z, qb);
+    auto mix = [&](uint32_t k) -> uint64_t {
+        const uint32_t b = m >> (4 * k);
+        return ((0ull - (uint64_t)(b & 1u)) & xa) ^ ((0ull - (uint64_t)((b >> 1) & 1u)) & za) ^
+               ((0ull - (uint64_t)((b >> 2) & 1u)) & xb) ^ ((0ull - (uint64_t)((b >> 3) & 1u)) & zb);
+    };
+    const uint64_t nxa = mix(0), nza = mix(1), nxb = mix(2), nzb = mix(3);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const bool h0 = qa == (uint32_t)j, h1 = qb == (uint32_t)j;
+        uint64_t vx = s.X[j], vz = s.Z[j];
+        vx = h1 ? nxb : vx;  // flat selects; qa's value wins when qa == qb
+        vz = h1 ? nzb : vz;
+        vx = h0 ? nxa : vx;
+        vz = h0 ? nza : vz;
+        s.X[j] = vx;
+        s.Z[j] = vz;
+    }
+}
+
+// one micro-op on every rotation (Pauli::evolve_*, pauli.rs:83-110), branch-free in `kind`:
+//   H(p):    x_p <-> z_p, phase += 2*(x_p & z_p)
+//   S(p):    z_p ^= x_p,  phase += x_p
+//   SX(p):   = H,S,H -> x_p ^= z_p, phase += 3*z_p
+//   CNOT(i=p, j=q) = evolve_cx(ctrl=q, tgt=p): x_p ^= x_q ; z_q ^= z_p
+template <int NQ, int RM>
+__device__ inline void pt_evolve(PTState<NQ, RM> &s, uint32_t kind, uint32_t p, uint32_t q) {
+    const uint32_t isH = kind == M_H, isS = kind == M_S, isSX = kind == M_SX, isCN = kind == M_CNOT;
+    uint32_t inc1 = 0, inc2 = 0;
+#pragma unroll
+    for (int k = 0; k < RM; ++k) {
+        const uint32_t bxp = (s.rx[k] >> p) & 1u, bzp = (s.rz[k] >> p) & 1u;
+        const uint32_t bxq = (s.rx[k] >> q) & 1u;
+        const uint32_t dxp = (isH & (bxp ^ bzp)) | (isSX & bzp) | (isCN & bxq);
+        const uint32_t dzp = (isH & (bxp ^ bzp)) | (isS & bxp);
+        const uint32_t dzq = isCN & bzp;
+        s.rx[k] ^= dxp << p;
+        s.rz[k] ^= (dzp << p) ^ (dzq << q);
+        inc1 |= ((isS & bxp) | (isSX & bzp)) << k;
+        inc2 |= ((isH & bxp & bzp) | (isSX & bzp)) << k;
+    }
+    const uint32_t carry = s.plo & inc1;  // phases += inc1 + 2*inc2 (mod 4), all rotations at once
+    s.plo ^= inc1;
+    s.phi ^= carry ^ inc2;
+}
+
+// clean_and_return_with_phases (pauli_network.rs:139-165).  `log`: solution-log sink or null.
+template <int NQ, int RM>
+__device__ inline void pt_clean(PTState<NQ, RM> &s, uint32_t &n_removed, uint32_t &fault, uint32_t *log, uint64_t (&rem_pos)[(RM + 7) / 8]) {
+    uint32_t trivial = 0, zero_w = 0;  // weights do not change while cleaning (:79-93)
+#pragma unroll
+    for (int k = 0; k < RM; ++k) {
+        const uint32_t sup = s.rx[k] | s.rz[k];
+        trivial |= (uint32_t)(__popc(sup) <= 1) << k;
+        zero_w |= (uint32_t)(sup == 0) << k;
+    }
+    for (;;) {
+        uint32_t front = 0;  // get_front_layer (pauli_dag.rs:47-57): no out-edge to a live node
+#pragma unroll
+        for (int k = 0; k < RM; ++k) front |= (uint32_t)((s.rpred[k] & s.alive) == 0) << k;
+        uint32_t doomed = front & trivial & s.alive;
+        if (doomed & zero_w) {  // which_qubit(..).unwrap() on None (:113-114): the reference panics
+            fault |= QG_FAULT_ZERO_WEIGHT;
+            doomed &= ~zero_w;
+        }
+        if (!doomed) break;
+        // removals are reported in DAG node order within a pass (:146-152)
+        uint32_t dpos = 0;  // bit i: DAG node i is removed in this pass
+#pragma unroll
+        for (int i = 0; i < RM; ++i) dpos |= (((uint32_t)i < s.count) ? ((doomed >> pnib(s.order, i)) & 1u) : 0u) << i;
+        if (log) {
+#pragma unroll
+            for (int k = 0; k < RM; ++k) {
+                if ((doomed >> k) & 1u) {
+                    uint32_t pos = 0;
+#pragma unroll
+                    for (int i = 0; i < RM; ++i) pos = (pnib(s.order, i) == (uint32_t)k && (uint32_t)i < s.count) ? (uint32_t)i : pos;
+                    const uint32_t seq = n_removed + (uint32_t)__popc(dpos & ((1u << pos) - 1u));
+                    const uint32_t sup = s.rx[k] | s.rz[k];
+                    const uint32_t qb = (uint32_t)__ffs((int)sup) - 1u;  // which_qubit / which_axis (:95-137)
+                    const uint32_t bx = (s.rx[k] >> qb) & 1u, bz = (s.rz[k] >> qb) & 1u;
+                    const uint32_t axis = bx ? (bz ? 1u : 0u) : 2u;
+                    log[seq] = 0x80000000u | (axis << 21) | (qb << 11) | ((uint32_t)k << 1);  // phase bit patched after the gate
+                    rem_pos[k / 8] |= (uint64_t)(seq + 1u) << (8 * (k % 8));
+                }
+            }
+        }
+        n_removed += (uint32_t)__popc(doomed);
+        // retain_nodes: visit NodeIndex high -> low, swap_remove each doomed node (:160-161)
+#pragma unroll
+        for (int i = RM - 1; i >= 0; --i) {
+            if ((uint32_t)i < s.count && ((dpos >> i) & 1u)) {
+                const uint64_t last = (uint64_t)pnib(s.order, s.count - 1);
+                s.order = (s.order & ~(0xFull << (4 * i))) | (last << (4 * i));
+                s.count -= 1;
+            }
+        }
+        s.alive &= ~doomed;
+    }
+}
+
+template <int NQ, int RM>
+__device__ inline bool pt_solved(const PTState<NQ, RM> &s, uint32_t N) {  // PauliNetwork::solved (:167-173)
+    uint64_t acc[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        acc[0] |= s.X[j] ^ ((uint32_t)j < N ? 1ull << j : 0ull);
+        acc[1] |= s.Z[j] ^ ((uint32_t)j < N ? (1ull << N) << j : 0ull);
+    }
+    return s.count == 0 && (acc[0] | acc[1]) == 0;
+}
+
+struct PTArgs {
+    StepArgs s;
+    const uint64_t *prog;
+    const int32_t *act_perms;  // add_perms (pauli.rs:594-599)
+    const uint32_t *perm_idx;
+    uint32_t n_perms;
+    uint32_t do_clean;
+    int32_t depth_value;
+};
+
+template <int NQ, int RM, bool FEAT>
+__global__ __launch_bounds__(256) void ptile_step_kernel(PTArgs pa) {
+    const StepArgs &a = pa.s;
+    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    if (env >= a.B) return;
+    const bool act64 = a.flags & F_ACT64;
+    const uint32_t N = a.N;
+    constexpr int G = NQ + RM + 1;
+    uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(G * 64);
+
+    int64_t act = load_action(a.actions, env, act64);
+    PTState<NQ, RM> s;
+    pt_load<NQ, RM>(tile, lane, s);
+    int32_t depth = a.depth[env];
+    int32_t sol_n = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2] : 0;
+    const uint32_t alive0 = s.alive, count0 = s.count;
+    const uint64_t order0 = s.order;
+    uint32_t touched_rot = 0;   // rotations whose record changed (alive when a gate was applied)
+    uint32_t dirty_q = 0;       // qubits whose tableau rows changed
+    bool solved = false;
+    float reward = 0.0f;
+    uint32_t fault = 0;
+
+    for (uint32_t t = 0; t < a.T; ++t) {
+        if (t) act = load_action(a.actions, (uint64_t)t * a.B + env, act64);
+        if (pa.n_perms) {  // actual_action = act_perms[current_perm_idx][action] (pauli.rs:594-599)
+            if (act >= 0 && act < (int64_t)a.num_actions) act = pa.act_perms[(uint64_t)pa.perm_idx[env] * a.num_actions + act];
+            else fault |= 16u;  // the reference indexes act_perms out of bounds here and panics
+        }
+        const bool in_range = act >= 0 && act < (int64_t)a.num_actions;  // pauli.rs:601
+        uint64_t prog = 0;
+        float penalty = 0.0f;
+        if (in_range) {
+            prog = pa.prog[act];
+            penalty = a.gates[act].penalty;
+            if (FEAT && (a.flags & F_LAYERS)) penalty = layers_penalty(a.layers + env * (2 * N + 2), N, a.descs[act], a.w);
+        }
+        const uint32_t qa = (uint32_t)prog & 31u, qb = (uint32_t)(prog >> 5) & 31u, m = (uint32_t)(prog >> 10) & 0xFFFFu;
+        uint32_t n_removed = 0;
+        uint64_t rem_pos[(RM + 7) / 8];
+#pragma unroll
+        for (int i = 0; i < (RM + 7) / 8; ++i) rem_pos[i] = 0;
+        uint32_t *log = nullptr;
+        if (FEAT && (a.flags & F_TRACK) && in_range && (uint32_t)sol_n + 1u + (uint32_t)s.count <= a.sol_cap)
+            log = a.sol + env * a.sol_cap + (uint32_t)sol_n + 1u;  // slot sol_n is the gate itself
+
+        if (in_range) {
+            pt_apply_tableau<NQ, RM>(s, qa, qb, m);
+            dirty_q |= (1u << qa) | (1u << qb);
+            touched_rot |= s.alive;
+#pragma unroll 1
+            for (uint32_t k = 0; k < 3; ++k) {  // PauliNetwork::act (pauli_network.rs:225-260)
+                const uint32_t mo = (uint32_t)(prog >> (26 + 4 * k)) & 15u;
+                const uint32_t kind = mo & 7u;
+                if (kind == M_NOP) continue;
+                const uint32_t p = (mo & 8u) ? qb : qa, q = (mo & 8u) ? qa : qb;
+                pt_evolve<NQ, RM>(s, kind, p, q);
+                if (kind == M_CNOT) pt_clean<NQ, RM>(s, n_removed, fault, log, rem_pos);
+            }
+        }
+
+        if (FEAT && (a.flags & F_TRACK) && in_range) {  // pauli.rs:612-626
+            if (log) {
+                a.sol[env * a.sol_cap + (uint32_t)sol_n] = (uint32_t)act;
+                // phase_mult is read after the whole gate has been applied (pauli.rs:618)
+#pragma unroll
+                for (int k = 0; k < RM; ++k) {
+                    const uint32_t pos = (uint32_t)(rem_pos[k / 8] >> (8 * (k % 8))) & 0xFFu;
+                    if (pos) {
+                        const uint32_t base = ((s.plo >> k) & 1u) | (((s.phi >> k) & 1u) << 1);
+                        const uint32_t ph = (base + 4u * N - (uint32_t)__popc(s.rx[k] & s.rz[k])) & 3u;  // Pauli::phase (pauli.rs:125-133)
+                        log[pos - 1u] |= (ph == 2u ? 0u : 1u);
+                    }
+                }
+                sol_n += 1 + (int32_t)n_removed;
+            } else {
+                fault |= 8u;
+            }
+        }
+
+        depth = depth > 0 ? depth - 1 : 0;  // pauli.rs:630
+        solved = pt_solved<NQ, RM>(s, N);
+        const float achieved = solved ? 1.0f : 0.0f;
+        const float tmp = achieved - penalty;
+        const float bonus = a.pauli_layer_reward * (float)n_removed;
+        reward = tmp + bonus;  // pauli.rs:634
+        if (a.rewards_seq) a.rewards_seq[(uint64_t)t * a.B + env] = reward;
+        if (a.dones_seq) a.dones_seq[(uint64_t)t * a.B + env] = (uint8_t)(depth == 0 || solved);
+    }
+
+    // write back what changed: the (<= 2 per step) touched qubits' row pairs, the rotations that
+    // were alive when a gate was applied, the DAG bookkeeping
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        if ((dirty_q >> q) & 1u)
+            tile[q * 64 + lane] = make_uint4((uint32_t)s.X[q], (uint32_t)(s.X[q] >> 32), (uint32_t)s.Z[q], (uint32_t)(s.Z[q] >> 32));
+#pragma unroll
+    for (int k = 0; k < RM; ++k)
+        if ((touched_rot >> k) & 1u)
+            tile[(NQ + k) * 64 + lane] = make_uint4(s.rx[k], s.rz[k], ((s.plo >> k) & 1u) | (((s.phi >> k) & 1u) << 1), s.rpred[k]);
+    if (s.alive != alive0 || s.count != count0 || s.order != order0)
+        tile[(NQ + RM) * 64 + lane] = make_uint4(s.alive, s.count, (uint32_t)s.order, (uint32_t)(s.order >> 32));
+    a.depth[env] = depth;
+    a.reward[env] = reward;
+    a.done[env] = (uint8_t)(depth == 0 || solved);
+    a.success[env] = (uint8_t)solved;
+    if (FEAT && (a.flags & F_TRACK)) a.sol_len[env * 2] = sol_n;
+    if (fault) atomicOr(&a.error[env], fault);
+}
+
+// after a host upload: optional initial clean (PauliEnv::reset, pauli.rs:576), then the scalar
+// resets of set_state (pauli.rs:544-551) / reset (pauli.rs:578-585)
+template <int NQ, int RM>
+__global__ __launch_bounds__(256) void ptile_init_kernel(PTArgs pa) {
+    const StepArgs &a = pa.s;
+    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    if (env >= a.B) return;
+    constexpr int G = NQ + RM + 1;
+    uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(G * 64);
+    PTState<NQ, RM> s;
+    pt_load<NQ, RM>(tile, lane, s);
+    uint32_t n_removed = 0, fault = 0;
+    uint64_t rem_pos[(RM + 7) / 8];
+#pragma unroll
+    for (int i = 0; i < (RM + 7) / 8; ++i) rem_pos[i] = 0;
+    if (pa.do_clean) pt_clean<NQ, RM>(s, n_removed, fault, nullptr, rem_pos);
+    const bool solved = pt_solved<NQ, RM>(s, a.N);
+    tile[(NQ + RM) * 64 + lane] = make_uint4(s.alive, s.count, (uint32_t)s.order, (uint32_t)(s.order >> 32));
+    a.depth[env] = pa.depth_value;
+    a.success[env] = (uint8_t)solved;
+    a.reward[env] = solved ? 1.0f : 0.0f;
+    a.done[env] = (uint8_t)(pa.depth_value == 0 || solved);
+    a.inverted[env] = 0;
+    a.error[env] = fault;
+    a.sol_len[env * 2] = 0;
+    a.sol_len[env * 2 + 1] = 0;
+    if (a.layers) {
+        int32_t *lay = a.layers + env * (2 * a.N + 2);
+        for (uint32_t i = 0; i < 2 * a.N; ++i) lay[i] = -1;
+        lay[2 * a.N] = 0;
+        lay[2 * a.N + 1] = 0;
+    }
+}
+
+// observe / get_state: one thread per (env, observation row)
+struct PTObsArgs {
+    ObsArgs o;
+    uint32_t nq, rm, max_rot;
+    const uint8_t *qubit_perms;  // add_perms (pauli.rs:653-665, 445-485)
+    uint32_t *perm_idx;
+    const int32_t *perm_in;
+    uint32_t n_perms, draw;
+    uint64_t seed, counter;
+};
+__global__ __launch_bounds__(256) void ptile_export_kernel(PTObsArgs pa) {
+    const ObsArgs &a = pa.o;
+    const uint32_t N = a.N, D = 2 * N;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t env = gid / D;
+    const uint32_t row = (uint32_t)(gid % D);
+    if (env >= a.B) return;
+    const uint32_t cols = a.obs_cols, G = pa.nq + pa.rm + 1, lane = (uint32_t)(env & 63);
+    const uint4 *tile = reinterpret_cast<const uint4 *>(a.state) + (env >> 6) * (uint64_t)(G * 64);
+    const uint8_t *perm = nullptr;
+    if (pa.n_perms && cols > D && a.format != QG_FMT_PACKED) {
+        uint32_t pi;
+        if (pa.draw) {  // `rng.gen_range(0..qubit_perms.len())` (pauli.rs:660), made reproducible
+            pi = pa.perm_in ? (uint32_t)pa.perm_in[env] % pa.n_perms
+                            : (uint32_t)__umul64hi(rng_draw(pa.seed ^ 0x7065726Dull, env, pa.counter), (uint64_t)pa.n_perms);
+            if (row == 0) pa.perm_idx[env] = pi;  // current_perm_idx.store (pauli.rs:661)
+        } else {
+            pi = pa.perm_idx[env];
+        }
+        perm = pa.qubit_perms + (uint64_t)pi * N;
+    }
+    const uint32_t q = row < N ? row : row - N;
+    const uint32_t sq = perm ? perm[q] : q;  // row i takes data from row perm[i] (pauli.rs:455-464)
+    const uint4 t = tile[sq * 64 + lane];
+    uint64_t w = row < N ? ((uint64_t)t.x | ((uint64_t)t.y << 32)) : ((uint64_t)t.z | ((uint64_t)t.w << 32));
+    if (perm) {  // column i takes data from column perm[i], X and Z halves alike (pauli.rs:469-477)
+        uint64_t pw = 0;
+        for (uint32_t i = 0; i < N; ++i) {
+            pw |= ((w >> perm[i]) & 1ull) << i;
+            pw |= ((w >> (N + perm[i])) & 1ull) << (N + i);
+        }
+        w = pw;
+    }
+    if (a.format == QG_FMT_PACKED) {
+        reinterpret_cast<uint64_t *>(a.out)[env * a.out_stride + row] = w;
+        return;
+    }
+    // pad_and_collect (pauli.rs:411-437): tableau, then the active rotations in DAG node order
+    uint32_t extra = 0;
+    if (cols > D) {
+        const uint4 m = tile[(pa.nq + pa.rm) * 64 + lane];
+        const uint64_t order = (uint64_t)m.z | ((uint64_t)m.w << 32);
+        const uint32_t shown = m.y < pa.max_rot ? m.y : pa.max_rot;
+        for (uint32_t i = 0; i < shown; ++i) {
+            const uint4 r = tile[(pa.nq + pnib(order, i)) * 64 + lane];
+            const uint32_t bit = row < N ? (r.x >> sq) & 1u : (r.y >> sq) & 1u;
+            extra |= bit << i;
+        }
+    }
+    if (a.format == QG_FMT_I64) {
+        int64_t *o = reinterpret_cast<int64_t *>(a.out) + env * a.out_stride + (uint64_t)row * cols;
+        for (uint32_t c = 0; c < D; ++c) o[c] = (int64_t)((w >> c) & 1ull);
+        for (uint32_t c = D; c < cols; ++c) o[c] = (int64_t)((extra >> (c - D)) & 1u);
+    } else {
+        int8_t *o = reinterpret_cast<int8_t *>(a.out) + env * a.out_stride + (uint64_t)row * cols;
+        for (uint32_t c = 0; c < D; ++c) o[c] = (int8_t)((w >> c) & 1ull);
+        for (uint32_t c = D; c < cols; ++c) o[c] = (int8_t)((extra >> (c - D)) & 1u);
+    }
+}
+
+static inline unsigned grid_for(uint64_t threads, unsigned block) { return (unsigned)((threads + block - 1) / block); }
+
+// ---- host hooks ----------------------------------------------------------------------------------
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            (void)hipGetLastError();                                                               \
+            return set_error(QG_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(_e));        \
+        }                                                                                          \
+    } while (0)
+
+int ptile_plan(qg_vec *v) {
+    v->pt_nq = (v->N + 3u) & ~3u;
+    v->pt_rm = v->rmax <= 8 ? 8u : 16u;
+    v->stride_bytes = 0;
+    v->state_bytes = ((v->B + 63) / 64) * (size_t)(v->pt_nq + v->pt_rm + 1) * 1024;
+    return QG_OK;
+}
+
+int ptile_alloc(qg_vec *v) {
+    std::vector<uint64_t> prog(std::max<size_t>(v->gates.size(), 1));
+    for (size_t i = 0; i < v->gates.size(); ++i) prog[i] = ptile_program(v->gates[i]);
+    HIP_TRY(hipMalloc(&v->d_prog, sizeof(uint64_t) * prog.size()));
+    HIP_TRY(hipMemcpy(v->d_prog, prog.data(), sizeof(uint64_t) * prog.size(), hipMemcpyHostToDevice));
+    return QG_OK;
+}
+
+static void fill_pt_args(const qg_vec *v, const StepArgs &a, PTArgs &pa) {
+    pa.s = a;
+    pa.prog = reinterpret_cast<const uint64_t *>(v->d_prog);
+    pa.act_perms = v->d_act_perms;
+    pa.perm_idx = v->perm_idx;
+    pa.n_perms = v->n_perms;
+    pa.do_clean = 0;
+    pa.depth_value = 0;
+}
+
+template <int NQ, int RM>
+static hipError_t pt_launch_step(const PTArgs &pa, hipStream_t s) {
+    const dim3 grid(grid_for(pa.s.B, 256)), block(256);
+    if (pa.s.flags & (F_TRACK | F_LAYERS)) hipLaunchKernelGGL((ptile_step_kernel<NQ, RM, true>), grid, block, 0, s, pa);
+    else hipLaunchKernelGGL((ptile_step_kernel<NQ, RM, false>), grid, block, 0, s, pa);
+    return hipGetLastError();
+}
+template <int NQ, int RM>
+static hipError_t pt_launch_init(const PTArgs &pa, hipStream_t s) {
+    hipLaunchKernelGGL((ptile_init_kernel<NQ, RM>), dim3(grid_for(pa.s.B, 256)), dim3(256), 0, s, pa);
+    return hipGetLastError();
+}
+
+#define PT_DISPATCH(FN)                                  \
+    switch (v->pt_nq * 100 + v->pt_rm) {                 \
+    case 408: return FN<4, 8>(pa, s);                    \
+    case 416: return FN<4, 16>(pa, s);                   \
+    case 808: return FN<8, 8>(pa, s);                    \
+    case 816: return FN<8, 16>(pa, s);                   \
+    case 1208: return FN<12, 8>(pa, s);                  \
+    case 1216: return FN<12, 16>(pa, s);                 \
+    case 1608: return FN<16, 8>(pa, s);                  \
+    case 1616: return FN<16, 16>(pa, s);                 \
+    case 2008: return FN<20, 8>(pa, s);                  \
+    case 2016: return FN<20, 16>(pa, s);                 \
+    case 2408: return FN<24, 8>(pa, s);                  \
+    case 2416: return FN<24, 16>(pa, s);                 \
+    case 2808: return FN<28, 8>(pa, s);                  \
+    case 2816: return FN<28, 16>(pa, s);                 \
+    case 3208: return FN<32, 8>(pa, s);                  \
+    case 3216: return FN<32, 16>(pa, s);                 \
+    }                                                    \
+    return hipErrorInvalidValue;
+
+hipError_t ptile_step(const qg_vec *v, const StepArgs &a, hipStream_t s) {
+    if (!a.B) return hipSuccess;
+    PTArgs pa;
+    fill_pt_args(v, a, pa);
+    PT_DISPATCH(pt_launch_step)
+}
+
+static hipError_t ptile_init(const qg_vec *v, const PTArgs &pa, hipStream_t s) { PT_DISPATCH(pt_launch_init) }
+
+hipError_t ptile_export(const qg_vec *v, const ObsArgs &a, hipStream_t s) {
+    if (!a.B) return hipSuccess;
+    PTObsArgs pa;
+    pa.o = a;
+    pa.nq = v->pt_nq;
+    pa.rm = v->pt_rm;
+    pa.max_rot = (uint32_t)v->cfg.max_rotations;
+    pa.qubit_perms = v->d_qubit_perms;
+    pa.perm_idx = v->perm_idx;
+    pa.perm_in = v->perm_in;
+    pa.n_perms = v->n_perms;
+    pa.draw = v->perm_draw ? 1u : 0u;
+    pa.seed = v->coin_seed;
+    pa.counter = v->observe_counter;
+    hipLaunchKernelGGL(ptile_export_kernel, dim3(grid_for(a.B * 2ull * a.N, 256)), dim3(256), 0, s, pa);
+    return hipGetLastError();
+}
+
+// scatter the per-env records into the tiled layout, upload, run the init kernel
+int ptile_upload(qg_vec *v, const HostNet &h, bool do_clean, int32_t depth_value, hipStream_t s) {
+    const uint32_t N = v->N, NQ = v->pt_nq, RM = v->pt_rm, G = NQ + RM + 1;
+    std::vector<uint32_t> img(v->state_bytes / 4, 0u);
+    for (uint64_t e = 0; e < v->B; ++e) {
+        uint32_t *tile = img.data() + (e >> 6) * (size_t)G * 256;
+        const uint32_t lane = (uint32_t)(e & 63);
+        for (uint32_t q = 0; q < N; ++q) {
+            uint32_t *g = tile + ((size_t)q * 64 + lane) * 4;
+            const uint64_t x = h.tab[(e * N + q) * 2], z = h.tab[(e * N + q) * 2 + 1];
+            g[0] = (uint32_t)x; g[1] = (uint32_t)(x >> 32); g[2] = (uint32_t)z; g[3] = (uint32_t)(z >> 32);
+        }
+        for (uint32_t k = 0; k < v->rmax; ++k) {
+            uint32_t *g = tile + ((size_t)(NQ + k) * 64 + lane) * 4;
+            const PauliRot &r = h.rot[e * v->rmax + k];
+            g[0] = r.x; g[1] = r.z; g[2] = r.phase; g[3] = r.pred;
+        }
+        uint32_t *g = tile + ((size_t)(NQ + RM) * 64 + lane) * 4;
+        const PauliMeta &m = h.meta[e];
+        g[0] = m.alive; g[1] = m.count; g[2] = (uint32_t)m.order; g[3] = (uint32_t)(m.order >> 32);
+    }
+    HIP_TRY(hipMemcpyAsync(v->state, img.data(), v->state_bytes, hipMemcpyHostToDevice, s));
+    StepArgs a;
+    memset(&a, 0, sizeof a);
+    a.state = v->state;
+    a.depth = v->depth;
+    a.reward = v->reward;
+    a.done = v->done;
+    a.success = v->success;
+    a.inverted = v->inverted;
+    a.error = v->error;
+    a.sol_len = v->sol_len;
+    a.layers = v->layers;
+    a.B = v->B;
+    a.N = N;
+    PTArgs pa;
+    fill_pt_args(v, a, pa);
+    pa.do_clean = do_clean ? 1u : 0u;
+    pa.depth_value = depth_value;
+    HIP_TRY(ptile_init(v, pa, s));
+    HIP_TRY(hipStreamSynchronize(s));  // the staging image dies with this frame
+    return QG_OK;
+}
+
+}  // namespace qg
