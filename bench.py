@@ -99,16 +99,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1 diagnostics: skip the per-step all-gather")
+    ap.add_argument("--force-multi", action="store_true",
+                    help="diagnostics: run the multi-GPU code path (RCCL init, side-stream all-gather) even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_multi
+    if multi:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -141,7 +147,7 @@ def main():
             env.step(actions[t % RING])
 
     # ---- multi-GPU: step + all-gather of the packed observation, double buffered -------------
-    if world > 1:
+    if multi:
         comm = torch.cuda.Stream(device=dev)
         snap = [torch.empty((B, 32), dtype=torch.int32, device=dev) for _ in range(2)]
         gathered = [torch.empty((world * B, 32), dtype=torch.int32, device=dev) for _ in range(2)]
@@ -168,7 +174,7 @@ def main():
 
     with torch.cuda.stream(stream):
         env.reset(seed)
-        if world > 1:
+        if multi:
             for e in gather_done:
                 e.record(stream)
         run_steps(CHUNK)  # builds and caches the rollout graph (setup, not a step)
@@ -220,7 +226,7 @@ def main():
 
     # ---- fused rollout (state in registers across steps), reported beside the headline --------
     fused = None
-    if world == 1:
+    if not multi:
         FT = 128
         facts = torch.randint(0, A, (FT, B), dtype=torch.int32, device=dev, generator=gen)
         with torch.cuda.stream(stream):
@@ -262,8 +268,8 @@ def main():
                 "envs_per_gpu": B,
                 "total_envs": B * n_gpus,
                 "launch": "one step kernel per env.step(); chunks of %d launches replayed from a hipGraph" % CHUNK
-                if n_gpus == 1 else "one step kernel per env.step() + all_gather_into_tensor(packed obs, 8 MiB/rank) per step, overlapped",
-                "collective": None if n_gpus == 1 or args.no_gather else "RCCL all-gather of the bit-packed observation every step",
+                if not multi else "one step kernel per env.step() + all_gather_into_tensor(packed obs, 8 MiB/rank) per step, overlapped",
+                "collective": None if not multi or args.no_gather else "RCCL all-gather of the bit-packed observation every step",
             },
             "roofline": {
                 "bound": "hbm",
