@@ -1,0 +1,137 @@
+"""Edge cases: maximum supported sizes, tiny sizes, empty gatesets, ragged batches, limits that
+must fail loudly."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import OracleEnv, OracleVec  # noqa: E402
+from qiskit_gym_amd._lib import QGymError  # noqa: E402
+from test_gpu_pauli import random_labels, random_tableau  # noqa: E402
+from util import f32_bits, grid_gateset, line_gateset, make_pair  # noqa: E402
+
+
+def _run(kind, n, gs, B, steps, inverts, per_env):
+    A = len(gs)
+    ov, gv = make_pair(kind, n, gs, B, add_inverts=inverts, add_perms=False, track_solution=True, difficulty=2 * n, max_depth=96)
+    rng = np.random.default_rng(n + B)
+    draws = rng.integers(0, A, size=(2 * n, B))
+    ov.reset_with(draws)
+    gv.reset_with(torch.as_tensor(draws, device="cuda", dtype=torch.int32))
+    for t in range(steps):
+        acts = rng.integers(0, A, size=B)
+        coins = rng.integers(0, 2, size=B) if inverts else None
+        r, s, f, d = ov.step(acts, coins)
+        gv.step(torch.as_tensor(acts, device="cuda", dtype=torch.int64),
+                None if coins is None else torch.as_tensor(coins, device="cuda", dtype=torch.uint8))
+        gv.sync()
+        np.testing.assert_array_equal(f32_bits(gv.reward.cpu().numpy()), f32_bits(r), err_msg=f"t={t}")
+        np.testing.assert_array_equal(gv.done.cpu().numpy(), f)
+    np.testing.assert_array_equal(gv.get_state("i64").cpu().numpy(), ov.get_state(per_env))
+    np.testing.assert_array_equal(gv.observe().cpu().numpy().reshape(B, -1), ov.observe_dense())
+    assert gv.solution(B - 1) == ov.env(B - 1).solution()
+
+
+@pytest.mark.parametrize("inverts", [False, True])
+def test_maximum_sizes(inverts):
+    _run("clifford", 32, line_gateset("clifford", 32), 70, 12, inverts, 64 * 64)          # 64 uint64 rows
+    _run("linear_function", 64, line_gateset("linear_function", 64), 66, 12, inverts, 64 * 64)
+    _run("linear_function", 32, line_gateset("linear_function", 32), 129, 12, inverts, 32 * 32)  # widest TILE / ROWS32 shape
+    _run("permutation", 16, grid_gateset("permutation", 4, 4), 65, 20, inverts, 16)
+
+
+@pytest.mark.parametrize("kind", ["clifford", "linear_function", "permutation"])
+def test_single_qubit_and_single_env(kind):
+    gs = [("SWAP", (0, 0))] if kind == "permutation" else ([("CX", (0, 0)), ("SWAP", (0, 0))] if kind == "linear_function" else
+                                                          [("H", (0,)), ("S", (0,)), ("SX", (0,)), ("CX", (0, 0)), ("CZ", (0, 0)), ("SWAP", (0, 0))])
+    _run(kind, 1, gs, 1, 6, False, {"clifford": 4, "linear_function": 1, "permutation": 1}[kind])
+
+
+def test_empty_gateset_steps_are_noops_and_reset_panics():
+    from qiskit_gym_amd.vec import VecEnv
+
+    gv = VecEnv("clifford", 3, [], 5, add_inverts=False, add_perms=False, track_solution=False)
+    o = OracleEnv("clifford", 3, [], add_inverts=0, add_perms=0, track_solution=0)
+    assert gv.num_actions() == 0
+    st = np.eye(6, dtype=np.int64)
+    st[0, 3] = 1
+    gv.set_state(np.tile(st.reshape(1, -1), (5, 1)), "i64")
+    o.set_state(st.reshape(-1).tolist())
+    for _ in range(3):  # every action is out of range: no gate, depth still decrements (clifford.rs:324,342)
+        gv.step(torch.zeros(5, dtype=torch.int32, device="cuda"))
+        o.step(0)
+    gv.sync()
+    assert int(gv.depth[0]) == o.depth() == 125 and float(gv.reward[0]) == o.reward() == 0.0
+    with pytest.raises(QGymError):  # Uniform::new(0, 0) panics in the reference's reset()
+        gv.reset(1)
+
+
+def test_pauli_maximum_size_32_qubits_16_rotations():
+    from qiskit_gym_amd.vec import VecEnv
+
+    n, B = 32, 40
+    gs = line_gateset("pauli", n)
+    A = len(gs)
+    pairs = [g[1] for g in gs if g[0] == "CX"]
+    cfg = dict(add_perms=False, track_solution=True, max_rotations=16, final_pauli_layers=16, max_depth=64)
+    rng = np.random.default_rng(9)
+    gv = VecEnv("pauli", n, gs, B, **cfg)
+    envs = [OracleEnv("pauli", n, gs, **{k: int(v) for k, v in cfg.items()}) for _ in range(B)]
+    tabs, labs = [], []
+    for o in envs:
+        t = random_tableau(rng, n, 40, pairs)
+        l = random_labels(rng, n, 16, 3)
+        o.pauli_reset_from(t, l)
+        tabs.append(t)
+        labs.append(l)
+    gv.pauli_reset_from(np.stack(tabs), labs)
+    for t in range(40):
+        acts = rng.integers(0, A, size=B)
+        for o, a in zip(envs, acts):
+            o.step(int(a))
+        gv.step(torch.as_tensor(acts, device="cuda", dtype=torch.int32))
+        gv.sync()
+        np.testing.assert_array_equal(f32_bits(gv.reward.cpu().numpy()), np.array([o.reward_bits() for o in envs], dtype=np.uint32), err_msg=f"t={t}")
+    np.testing.assert_array_equal(gv.observe().cpu().numpy(), np.stack([o.dense_obs() for o in envs]))
+    for e in range(0, B, 5):
+        assert gv.solution(e) == envs[e].solution()
+
+
+def test_limits_fail_loudly():
+    from qiskit_gym_amd.vec import VecEnv
+
+    with pytest.raises(QGymError, match="N <= 32"):
+        VecEnv("clifford", 33, line_gateset("clifford", 33), 4)
+    with pytest.raises(QGymError, match="N <= 64"):
+        VecEnv("linear_function", 65, line_gateset("linear_function", 65), 4)
+    with pytest.raises(QGymError, match="N <= 16"):
+        VecEnv("permutation", 17, [("SWAP", (0, 16))], 4)
+    with pytest.raises(QGymError, match="rotations"):
+        VecEnv("pauli", 4, line_gateset("pauli", 4), 4, max_rotations=17)
+    with pytest.raises(QGymError, match="out of range"):
+        VecEnv("clifford", 3, [("H", (3,))], 4)
+    with pytest.raises(QGymError, match="batch"):
+        VecEnv("clifford", 3, [("H", (0,))], 0)
+
+
+def test_pauli_weight_zero_rotation_is_reported():
+    """An all-identity rotation reaches the front layer with weight 0: the reference's
+    `which_qubit(..).unwrap()` panics (pauli_network.rs:113-114); here the env gets a fault bit."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    n = 3
+    gs = line_gateset("pauli", n)
+    gv = VecEnv("pauli", n, gs, 2, add_perms=False, track_solution=False)
+    state = [1] + np.eye(2 * n, dtype=np.int64).reshape(-1).tolist() + [n] + [ord("I")] * n
+    gv.set_state(np.array([state, state], dtype=np.int64), "i64")
+    cx = [i for i, g in enumerate(gs) if g[0] == "CX"][0]
+    gv.step(torch.full((2,), cx, dtype=torch.int32, device="cuda"))
+    with pytest.raises(QGymError, match="weight-0"):
+        gv.sync()
+    o = OracleEnv("pauli", n, gs, add_perms=0, track_solution=0)
+    o.set_state(state)
+    from oracle import OracleError
+
+    with pytest.raises(OracleError):
+        o.step(cx)
