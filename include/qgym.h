@@ -39,8 +39,7 @@ typedef enum {
     QG_ERR_TYPE = -2,        /* malformed gate (PyTypeError, common.rs:51-76) */
     QG_ERR_UNSUPPORTED = -3, /* outside the limits documented in DESIGN.md */
     QG_ERR_DEVICE = -4,      /* HIP runtime failure / no GPU */
-    QG_ERR_PANIC = -5,       /* the reference would have panicked (singular inverse, malformed Pauli state, ...) */
-    QG_ERR_FINAL = -6        /* qg_env_step on a final env when `strict` (adapters.py:63-65) */
+    QG_ERR_PANIC = -5        /* the reference would have panicked (singular inverse, malformed Pauli state, ...) */
 } qg_status;
 
 /* rust/src/envs/common.rs:19-29 (enum order) */

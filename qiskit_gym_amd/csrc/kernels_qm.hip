@@ -14,8 +14,11 @@
 // R/4 "row groups" of 1 KiB: group g holds, for lane l, the uint4 {slot 4g .. 4g+3} of env
 // tile*64 + l.  Every load/store instruction of a wave is therefore one contiguous, fully
 // coalesced 1 KiB access (16 B per lane), and a tile is one contiguous R*256-byte block.
-// Slots: X-type row j (matrix row j, j < N) is slot j; for CliffordEnv the Z-type row N+j is slot
-// NXP + j, NXP = N rounded up to a multiple of 4; unused slots hold zero.
+// Slots: LinearFunctionEnv row j is slot j.  CliffordEnv interleaves the two rows of a qubit: X-type
+// row j is slot 2j, Z-type row N+j is slot 2j+1, so a 16-byte group holds everything two
+// neighbouring qubits own and a one-qubit gate dirties ONE group (measured: the store phase, not
+// the loads, is what a step pays for; one dirty group instead of two is -16 % per launch at
+// B = 65 536 and -29 % at B = 2^20).  NXP = N rounded up to a multiple of 4; unused slots hold zero.
 //
 // An action is (q0, q1, M): the four rows {X[q0], Z[q0], X[q1], Z[q1]} are replaced by GF(2)
 // combinations of themselves given by the 4x4 bit matrix M (H, S, SX, CX, CZ, SWAP and "no gate"
@@ -27,13 +30,14 @@ namespace qg {
 
 // ops word of the TILE layout: [0:5) q0, [5:10) q1, [10:26) M.
 // M bit 4*k + i: output k takes input i, inputs/outputs ordered {X[q0], Z[q0], X[q1], Z[q1]}.
-__host__ __device__ inline uint32_t qm_ops(uint32_t q0, uint32_t q1, uint32_t m) { return (q0 & 31u) | ((q1 & 31u) << 5) | (m << 10); }
 #define QM_IDENTITY 0x8421u
 
 template <int NXP, bool HAS_Z>
 struct QmRows {
     static constexpr int R = HAS_Z ? 2 * NXP : NXP;  // row slots per env
     static constexpr int G = R / 4;                  // 16-byte groups per env
+    static constexpr int xs(int j) { return HAS_Z ? 2 * j : j; }      // slot of X-type row j
+    static constexpr int zs(int j) { return 2 * j + 1; }              // slot of Z-type row N+j
     uint32_t r[R];
 };
 
@@ -50,8 +54,8 @@ template <int NXP, bool HAS_Z>
 __device__ inline void qm_identity(QmRows<NXP, HAS_Z> &s, uint32_t N) {
 #pragma unroll
     for (int j = 0; j < NXP; ++j) {
-        s.r[j] = (uint32_t)j < N ? 1u << j : 0u;
-        if (HAS_Z) s.r[NXP + j] = (uint32_t)j < N ? (1u << N) << j : 0u;
+        s.r[QmRows<NXP, HAS_Z>::xs(j)] = (uint32_t)j < N ? 1u << j : 0u;
+        if (HAS_Z) s.r[QmRows<NXP, HAS_Z>::zs(j)] = (uint32_t)j < N ? (1u << N) << j : 0u;
     }
 }
 
@@ -62,8 +66,8 @@ __device__ inline bool qm_solved(const QmRows<NXP, HAS_Z> &s, uint32_t N) {
     const uint32_t zb = 1u << N;
 #pragma unroll
     for (int j = 0; j < NXP; ++j) {
-        acc[j & 1] |= s.r[j] ^ ((uint32_t)j < N ? 1u << j : 0u);
-        if (HAS_Z) acc[2 + (j & 1)] |= s.r[NXP + j] ^ ((uint32_t)j < N ? zb << j : 0u);
+        acc[j & 1] |= s.r[QmRows<NXP, HAS_Z>::xs(j)] ^ ((uint32_t)j < N ? 1u << j : 0u);
+        if (HAS_Z) acc[2 + (j & 1)] |= s.r[QmRows<NXP, HAS_Z>::zs(j)] ^ ((uint32_t)j < N ? zb << j : 0u);
     }
     return ((acc[0] | acc[1]) | (acc[2] | acc[3])) == 0;
 }
@@ -93,8 +97,8 @@ __device__ inline uint32_t qm_apply(QmRows<NXP, HAS_Z> &s, uint32_t ops) {
     uint32_t xs[NXP], zs[NXP];
 #pragma unroll
     for (int j = 0; j < NXP; ++j) {
-        xs[j] = s.r[j];
-        zs[j] = HAS_Z ? s.r[NXP + j] : 0u;
+        xs[j] = s.r[QmRows<NXP, HAS_Z>::xs(j)];
+        zs[j] = HAS_Z ? s.r[QmRows<NXP, HAS_Z>::zs(j)] : 0u;
     }
     const uint32_t x0 = tree_select<NXP>(xs, q0), x1 = tree_select<NXP>(xs, q1);
     const uint32_t z0 = HAS_Z ? tree_select<NXP>(zs, q0) : 0u, z1 = HAS_Z ? tree_select<NXP>(zs, q1) : 0u;
@@ -116,19 +120,20 @@ __device__ inline uint32_t qm_apply(QmRows<NXP, HAS_Z> &s, uint32_t ops) {
     for (int j = 0; j < NXP; ++j) {
         const bool h0 = w0 == (uint32_t)j, h1 = w1 == (uint32_t)j;
         // two flat selects (q0's value wins when q0 == q1): keeps this a v_cndmask sweep
-        uint32_t vx = s.r[j];
+        uint32_t vx = s.r[QmRows<NXP, HAS_Z>::xs(j)];
         vx = h1 ? nx1 : vx;
         vx = h0 ? nx0 : vx;
-        s.r[j] = vx;
+        s.r[QmRows<NXP, HAS_Z>::xs(j)] = vx;
         if (HAS_Z) {
-            uint32_t vz = s.r[NXP + j];
+            uint32_t vz = s.r[QmRows<NXP, HAS_Z>::zs(j)];
             vz = h1 ? nz1 : vz;
             vz = h0 ? nz0 : vz;
-            s.r[NXP + j] = vz;
+            s.r[QmRows<NXP, HAS_Z>::zs(j)] = vz;
         }
     }
-    uint32_t dirty = (1u << (q0 >> 2)) | (1u << (q1 >> 2));
-    if (HAS_Z) dirty |= dirty << (NXP / 4);
+    // groups of 4 slots: two qubits (CliffordEnv, X/Z interleaved) or four rows (LinearFunctionEnv)
+    const uint32_t gsh = HAS_Z ? 1u : 2u;
+    const uint32_t dirty = (1u << (q0 >> gsh)) | (1u << (q1 >> gsh));
     return m == QM_IDENTITY ? 0u : dirty;  // "no gate" writes nothing back
 }
 
@@ -199,12 +204,17 @@ __device__ inline void qm_symplectic_candidate(const uint32_t (&m)[32], uint32_t
 template <int NXP>
 __device__ inline void qm_to_slot_space(const QmRows<NXP, true> &s, uint32_t N, uint32_t (&m)[32]) {
 #pragma unroll
-    for (int i = 0; i < 32; ++i) m[i] = i < 2 * NXP ? qm_cols_to_slots(s.r[i], N, NXP) : 0u;
+    for (int i = 0; i < 32; ++i)  // slot-space row i: X-type rows first, then Z-type rows
+        m[i] = i < NXP ? qm_cols_to_slots(s.r[QmRows<NXP, true>::xs(i)], N, NXP)
+                       : (i < 2 * NXP ? qm_cols_to_slots(s.r[QmRows<NXP, true>::zs(i - NXP)], N, NXP) : 0u);
 }
 template <int NXP>
 __device__ inline void qm_from_slot_space(QmRows<NXP, true> &s, uint32_t N, const uint32_t (&m)[32]) {
 #pragma unroll
-    for (int i = 0; i < 2 * NXP; ++i) s.r[i] = qm_cols_from_slots(m[i], N, NXP);
+    for (int i = 0; i < NXP; ++i) {
+        s.r[QmRows<NXP, true>::xs(i)] = qm_cols_from_slots(m[i], N, NXP);
+        s.r[QmRows<NXP, true>::zs(i)] = qm_cols_from_slots(m[NXP + i], N, NXP);
+    }
 }
 
 // is `c` the inverse of `m`?  (both slot space; unused slots must be all-zero rows of the product)
@@ -383,7 +393,8 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
 
 // slot of matrix row `row`
 __device__ inline uint32_t qm_slot(uint32_t row, uint32_t N, uint32_t nxp, bool has_z) {
-    return (has_z && row >= N) ? nxp + (row - N) : row;
+    (void)nxp;
+    return has_z ? (row < N ? 2 * row : 2 * (row - N) + 1) : row;
 }
 
 template <int NXP, bool HAS_Z>
@@ -399,8 +410,8 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
     if (a.mode == 1) {  // set_state (clifford.rs:299-304)
 #pragma unroll
         for (int sl = 0; sl < Rows::R; ++sl) {
-            const uint32_t j = HAS_Z ? (uint32_t)sl % NXP : (uint32_t)sl;
-            const uint32_t row = (HAS_Z && sl >= NXP) ? a.N + j : j;
+            const uint32_t j = HAS_Z ? (uint32_t)sl >> 1 : (uint32_t)sl;
+            const uint32_t row = (HAS_Z && (sl & 1)) ? a.N + j : j;
             uint32_t w = 0;
             if (j < a.N) {
                 if (a.format == QG_FMT_PACKED) {
@@ -476,7 +487,8 @@ __global__ __launch_bounds__(256) void qm_dense32_kernel(ObsArgs a) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // env * 32 + row
     if (gid >= a.B * 32ull) return;
     const uint64_t env = gid >> 5;
-    const uint32_t slot = (uint32_t)gid & 31u;  // N = 16: slot == row
+    const uint32_t row = (uint32_t)gid & 31u;
+    const uint32_t slot = row < 16 ? 2 * row : 2 * (row - 16) + 1;  // X/Z interleaved slots
     const uint32_t *tile = reinterpret_cast<const uint32_t *>(a.state) + (env >> 6) * (uint64_t)(32 * 64);
     const uint32_t w = tile[((slot >> 2) * 64 + (uint32_t)(env & 63)) * 4 + (slot & 3)];
     uint32_t o[8];

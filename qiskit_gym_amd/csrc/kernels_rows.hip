@@ -276,7 +276,6 @@ hipError_t rows_step(const StepArgs &a, bool word64, hipStream_t s) {
         hipLaunchKernelGGL(rows_step_kernel<uint32_t>, dim3(grid_for(threads, block)), dim3(block), lds, s, a);
     return hipGetLastError();
 }
-hipError_t rows_rollout_fused(const StepArgs &a, bool word64, hipStream_t s) { return rows_step(a, word64, s); }
 
 // ------------------------------------------------------------------------------------------
 // init: constructor state / set_state / reset scramble

@@ -749,7 +749,6 @@ static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, si
             StepArgs b = a;
             b.T = 1;
             b.actions = (const char *)actions_dev + (t % period) * v->B * act_bytes;
-            b.next_actions = nullptr;
             b.coins = coins_dev ? coins_dev + t * v->B : nullptr;
             b.rewards_seq = rewards_dev ? rewards_dev + t * v->B : nullptr;
             b.dones_seq = dones_dev ? dones_dev + t * v->B : nullptr;

@@ -53,8 +53,7 @@ enum : uint32_t {
     F_ACT64 = 1u << 0,     // actions are int64
     F_INVERTS = 1u << 1,   // add_inverts (clifford.rs:262-270)
     F_TRACK = 1u << 2,     // track_solution (clifford.rs:334-340)
-    F_LAYERS = 1u << 3,    // non-zero n_layers / n_layers_cnots weights: track per-qubit layers
-    F_PERM_ORDER = 1u << 4 // PermutationEnv step order (invert before depth, push only if valid)
+    F_LAYERS = 1u << 3     // non-zero n_layers / n_layers_cnots weights: track per-qubit layers
 };
 
 // counter RNG shared by host, device and the tests
@@ -79,7 +78,6 @@ __host__ __device__ inline uint32_t rng_action(uint64_t seed, uint64_t env, uint
 struct StepArgs {
     void *state;
     const void *actions;      // [T][B]
-    const void *next_actions; // unused (a next-slice cache warm-up was measured to change nothing)
     const uint8_t *coins;     // [T][B] or null
     const GateEntry *gates;   // [num_actions]
     const uint32_t *descs;    // [num_actions] kind | q0<<8 | q1<<16 (F_LAYERS, PauliEnv)
@@ -148,7 +146,6 @@ struct ObsArgs {
 
 // launchers (one translation unit per layout)
 hipError_t rows_step(const StepArgs &a, bool word64, hipStream_t s);
-hipError_t rows_rollout_fused(const StepArgs &a, bool word64, hipStream_t s);
 hipError_t rows_init(const InitArgs &a, bool word64, hipStream_t s);
 hipError_t rows_export(const ObsArgs &a, bool word64, hipStream_t s);
 

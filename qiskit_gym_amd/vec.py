@@ -220,7 +220,3 @@ class VecEnv:
         buf = (C.c_uint64 * max(int(n), 1))()
         self._L.qg_vec_solution(self._h, env, buf, int(n))
         return [int(buf[i]) for i in range(int(n))]
-
-
-def make_vec(env_cls_or_kind, *args, **kwargs) -> VecEnv:  # convenience used by bench/tests
-    return VecEnv(env_cls_or_kind, *args, **kwargs)

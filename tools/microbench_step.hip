@@ -45,6 +45,8 @@ __global__ __launch_bounds__(BLOCK) void variant_kernel(StepArgs a) {
         if (solved) a.reward[env] = (float)depth + g.penalty + (float)dirty;
         return;
     }
+    if (V == 12) dirty &= (0u - dirty);                     // keep one dirty group
+    if (V == 13) { uint32_t lo = dirty & (0u - dirty); uint32_t rest = dirty ^ lo; dirty = lo | (rest & (0u - rest)); }  // two
     // V >= 4: full stores
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
@@ -199,6 +201,8 @@ int main(int argc, char **argv) {
     printf("V2 +compute(glob)  block256: %.2f\n", time_variant<2, 256>(a, it, st));
     printf("V4 full            block256: %.2f\n", time_variant<4, 256>(a, it, st));
     g_distinct_actions = false;
+    printf("V12 one dirty group block256: %.2f\n", time_variant<12, 256>(a, it, st));
+    printf("V13 two dirty groups block256: %.2f\n", time_variant<13, 256>(a, it, st));
     printf("V8 rows sc1        block256: %.2f\n", time_variant<8, 256>(a, it, st));
     printf("V9 rows nt         block256: %.2f\n", time_variant<9, 256>(a, it, st));
     printf("V10 rows sc0 sc1   block256: %.2f\n", time_variant<10, 256>(a, it, st));
