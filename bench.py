@@ -80,7 +80,7 @@ def cpu_baseline(gateset, seed: int, budget_s: float = 12.0):
             best = (rate, c)
     cores = best[1]
     per_step = B / best[0]
-    n_steps = int(max(8, min(4096, budget_s / max(per_step, 1e-6))))
+    n_steps = int(max(8, min(2_000_000, budget_s / max(per_step, 1e-6))))
     t0 = time.perf_counter()
     for t in range(n_steps):
         ov.step_only(acts[t % 32], threads=cores)
@@ -292,7 +292,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "qg::qm_step_kernel<16, true, false, false>",
+                "kernel": "qg::qm_step_kernel<16, true, false, false, false>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -1,0 +1,26 @@
+"""End-to-end collection rate with a policy in the loop (CliffordGym 16q, BasicPolicy-shaped MLP,
+bf16), everything on one MI355X.  Context for the reference's notebook timings (collect phase of
+1 024 short episodes in ~15 ms = ~1.4e5 env-steps/s including its CPU policy inference)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from qiskit_gym_amd.collector import BasicPolicy, RolloutCollector
+from qiskit_gym_amd.vec import VecEnv
+from util import line_gateset
+
+for B in (8192, 65536):
+    gs = line_gateset("clifford", 16)
+    env = VecEnv("clifford", 16, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=32)
+    col = RolloutCollector(env, BasicPolicy(1024, len(gs)), dtype=torch.bfloat16, seed=1)
+    T = 32
+    ro = col.collect(T)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ro = col.collect(T, out=ro)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    env.sync()
+    print(f"B={B}: {3 * T * B / dt:.3e} env-steps/s with the policy in the loop ({dt / (3 * T) * 1e6:.0f} us per step), "
+          f"success rate in last rollout {float(ro.dones.float().mean()):.3f} done/step")
