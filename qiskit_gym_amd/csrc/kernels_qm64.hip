@@ -1,0 +1,475 @@
+// kernels_qm64.hip -- TILE64 layout: the thread-per-env "qubit machine" of kernels_qm.hip for
+// matrices whose rows need 64-bit words: CliffordEnv 16 < N <= 32 (with or without add_inverts)
+// and LinearFunctionEnv 32 < N <= 64 without inverts.
+//
+// Reference semantics: Clifford::step rust/src/envs/clifford.rs:321-347 (gates :89-133, solved
+// :136-145, inverse :147-170, maybe_random_invert :262-270); LinearFunction::step
+// rust/src/envs/linear_function.rs:302-328 (cx/swap :62-83).
+//
+// Same design as kernels_qm.hip (one lane owns one env, rows in VGPRs, an action is (q0, q1, 4x4
+// GF(2) matrix) on {X[q0], Z[q0], X[q1], Z[q1]}, nothing crosses lanes); rows are uint64 and a
+// 16-byte group holds two of them.  Layout: tiles of 64 envs, NS/2 groups of 1 KiB per tile, group g
+// = for lane l the uint4 {slot 2g, slot 2g+1}.  CliffordEnv: slot 2j = X-type row j, slot 2j+1 =
+// Z-type row N+j, i.e. one group per qubit -- a one-qubit gate dirties one group, a two-qubit gate
+// two.  LinearFunctionEnv: slot j = row j.  The lane-group ROWS kernels these shapes used before
+// are instruction-issue-bound (14-15 us per step, 140-220 us with inversion at B = 65 536).
+#include "device_common.hpp"
+
+namespace qg {
+
+// ops word: [0:6) q0, [6:12) q1, [12:28) M (bit 4k+i: output k takes input i, order X0,Z0,X1,Z1)
+#define Q64_IDENTITY 0x8421u
+#define Q64_FLAG_INVERTED 1u
+#define Q64_FLAG_SYMPLECTIC 2u
+
+template <int NS>
+struct Q64Rows {
+    static constexpr int G = NS / 2;
+    uint64_t r[NS];
+};
+
+template <int n>
+__device__ inline uint64_t q64_tree_select(const uint64_t (&t)[n], uint32_t q) {
+    if constexpr (n == 1) {
+        return t[0];
+    } else {
+        constexpr int m = (n + 1) / 2;
+        uint64_t u[m];
+        const uint64_t mb = 0ull - (uint64_t)(q & 1u);  // arithmetic blend (see kernels_qm.hip tree_select)
+#pragma unroll
+        for (int k = 0; k < m; ++k) u[k] = (2 * k + 1 < n) ? ((t[2 * k + 1] & mb) | (t[2 * k] & ~mb)) : t[2 * k];
+        return q64_tree_select<m>(u, q >> 1);
+    }
+}
+
+template <int NS>
+__device__ inline void q64_load(const uint4 *tile, uint32_t lane, Q64Rows<NS> &s) {
+#pragma unroll
+    for (int g = 0; g < NS / 2; ++g) {
+        const uint4 v = tile[g * 64 + lane];
+        s.r[2 * g] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        s.r[2 * g + 1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    }
+}
+template <int NS>
+__device__ inline void q64_store_group(uint4 *tile, uint32_t lane, const Q64Rows<NS> &s, int g) {
+    tile[g * 64 + lane] = make_uint4((uint32_t)s.r[2 * g], (uint32_t)(s.r[2 * g] >> 32), (uint32_t)s.r[2 * g + 1], (uint32_t)(s.r[2 * g + 1] >> 32));
+}
+
+// identity word expected in `slot` when the env is solved (0 for unused slots)
+template <int NS, bool HAS_Z>
+__device__ inline uint64_t q64_identity_word(int slot, uint32_t N) {
+    if (HAS_Z) {
+        const uint32_t j = (uint32_t)slot >> 1;
+        if (j >= N) return 0ull;
+        return (slot & 1) ? (1ull << N) << j : 1ull << j;
+    }
+    return (uint32_t)slot < N ? 1ull << slot : 0ull;
+}
+
+template <int NS, bool HAS_Z>
+__device__ inline bool q64_solved(const Q64Rows<NS> &s, uint32_t N) {  // clifford.rs:136-145
+    uint64_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NS; ++i) acc[i & 3] |= s.r[i] ^ q64_identity_word<NS, HAS_Z>(i, N);
+    return ((acc[0] | acc[1]) | (acc[2] | acc[3])) == 0;
+}
+
+// apply one action; returns the mask of 16-byte groups written
+template <int NS, bool HAS_Z>
+__device__ inline uint64_t q64_apply(Q64Rows<NS> &s, uint32_t ops) {
+    constexpr int NX = HAS_Z ? NS / 2 : NS;  // number of X-type rows
+    const uint32_t q0 = ops & 63u, q1 = (ops >> 6) & 63u, m = (ops >> 12) & 0xFFFFu;
+    uint64_t xs[NX], zs[HAS_Z ? NX : 1];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        xs[j] = s.r[HAS_Z ? 2 * j : j];
+        if (HAS_Z) zs[j] = s.r[2 * j + 1];
+    }
+    const uint64_t x0 = q64_tree_select<NX>(xs, q0), x1 = q64_tree_select<NX>(xs, q1);
+    uint64_t z0 = 0, z1 = 0;
+    if constexpr (HAS_Z) {
+        z0 = q64_tree_select<NX>(zs, q0);
+        z1 = q64_tree_select<NX>(zs, q1);
+    }
+    auto mix = [&](uint32_t k) -> uint64_t {
+        const uint32_t b = m >> (4 * k);
+        uint64_t o = ((0ull - (uint64_t)(b & 1u)) & x0) ^ ((0ull - (uint64_t)((b >> 2) & 1u)) & x1);
+        if (HAS_Z) o ^= ((0ull - (uint64_t)((b >> 1) & 1u)) & z0) ^ ((0ull - (uint64_t)((b >> 3) & 1u)) & z1);
+        return o;
+    };
+    const uint64_t nx0 = mix(0), nx1 = mix(2);
+    const uint64_t nz0 = HAS_Z ? mix(1) : 0ull, nz1 = HAS_Z ? mix(3) : 0ull;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const bool h0 = q0 == (uint32_t)j, h1 = q1 == (uint32_t)j;
+        uint64_t vx = s.r[HAS_Z ? 2 * j : j];
+        vx = h1 ? nx1 : vx;  // flat selects; q0's value wins when q0 == q1
+        vx = h0 ? nx0 : vx;
+        s.r[HAS_Z ? 2 * j : j] = vx;
+        if (HAS_Z) {
+            uint64_t vz = s.r[2 * j + 1];
+            vz = h1 ? nz1 : vz;
+            vz = h0 ? nz0 : vz;
+            s.r[2 * j + 1] = vz;
+        }
+    }
+    const uint32_t gsh = HAS_Z ? 0u : 1u;  // CliffordEnv: group = qubit; LinearFunctionEnv: group = 2 rows
+    const uint64_t dirty = (1ull << (q0 >> gsh)) | (1ull << (q1 >> gsh));
+    return m == Q64_IDENTITY ? 0ull : dirty;
+}
+
+// ---- add_inverts for CliffordEnv (see the discussion in kernels_qm.hip) -------------------------
+// Slot space: a square R x R matrix, R = NS = 2*NQ, rows X-type first then Z-type, logical Z
+// columns N..2N-1 moved to bit positions NQ..NQ+N-1.
+__device__ inline uint64_t q64_cols_to_slots(uint64_t w, uint32_t N, uint32_t nq) {
+    const uint64_t xm = (1ull << N) - 1ull;
+    return (w & xm) | (((w >> N) & xm) << nq);
+}
+__device__ inline uint64_t q64_cols_from_slots(uint64_t w, uint32_t N, uint32_t nq) {
+    const uint64_t xm = (1ull << N) - 1ull;
+    return (w & xm) | (((w >> nq) & xm) << N);
+}
+__device__ inline void q64_transpose64(uint64_t (&a)[64]) {
+#pragma unroll
+    for (int st = 0; st < 6; ++st) {
+        const int j = 32 >> st;
+        const uint64_t m = st == 0 ? 0x00000000FFFFFFFFull : st == 1 ? 0x0000FFFF0000FFFFull : st == 2 ? 0x00FF00FF00FF00FFull
+                           : st == 3 ? 0x0F0F0F0F0F0F0F0Full : st == 4 ? 0x3333333333333333ull : 0x5555555555555555ull;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            if ((k & j) == 0) {
+                const uint64_t t = ((a[k] >> j) ^ a[k + j]) & m;
+                a[k + j] ^= t;
+                a[k] ^= t << j;
+            }
+        }
+    }
+}
+template <int NS>
+__device__ inline void q64_to_slot_space(const Q64Rows<NS> &s, uint32_t N, uint64_t (&m)[64]) {
+    constexpr int NQ = NS / 2;
+#pragma unroll
+    for (int i = 0; i < 64; ++i)
+        m[i] = i < NQ ? q64_cols_to_slots(s.r[2 * i], N, NQ) : (i < NS ? q64_cols_to_slots(s.r[2 * (i - NQ) + 1], N, NQ) : 0ull);
+}
+template <int NS>
+__device__ inline void q64_from_slot_space(Q64Rows<NS> &s, uint32_t N, const uint64_t (&m)[64]) {
+    constexpr int NQ = NS / 2;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        s.r[2 * i] = q64_cols_from_slots(m[i], N, NQ);
+        s.r[2 * i + 1] = q64_cols_from_slots(m[NQ + i], N, NQ);
+    }
+}
+// Omega M^T Omega in slot space
+template <int NS>
+__device__ inline void q64_symplectic_candidate(const uint64_t (&m)[64], uint64_t (&c)[64]) {
+    constexpr int NQ = NS / 2;
+    uint64_t t[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) t[i] = m[i];
+    q64_transpose64(t);
+    const uint64_t rmask = NS == 64 ? ~0ull : ((1ull << NS) - 1ull);
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        if (i < NS) {
+            const uint64_t w = t[(i + NQ) % NS];
+            c[i] = ((w >> NQ) | (w << NQ)) & rmask;
+        } else {
+            c[i] = 0;
+        }
+    }
+}
+template <int NS>
+__device__ inline bool q64_is_inverse(const uint64_t (&m)[64], const uint64_t (&c)[64], uint32_t N) {
+    constexpr int NQ = NS / 2;
+    uint64_t bad = 0;
+#pragma unroll 1
+    for (int i = 0; i < NS; ++i) {
+        uint64_t row = 0;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) row = (k == i) ? m[k] : row;
+        uint64_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) acc ^= (0ull - ((row >> j) & 1ull)) & c[j];
+        const bool real = (uint32_t)(i % NQ) < N;
+        bad |= acc ^ (real ? 1ull << i : 0ull);
+    }
+    return bad == 0;
+}
+// general Gauss-Jordan (row operations only) for envs not known to be symplectic
+template <int NS>
+__device__ __noinline__ bool q64_gauss_jordan(Q64Rows<NS> &s, uint32_t N) {
+    constexpr int NQ = NS / 2;
+    uint64_t m[64], v[64];
+    q64_to_slot_space<NS>(s, N, m);
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const bool pad = i < NS && (uint32_t)(i % NQ) >= N;
+        if (pad) m[i] = 1ull << i;
+        v[i] = i < NS ? 1ull << i : 0ull;
+    }
+    uint64_t singular = 0;
+#pragma unroll 1
+    for (int col = 0; col < NS; ++col) {
+        uint64_t pm = 0, pv = 0;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            pm = (k == col) ? m[k] : pm;
+            pv = (k == col) ? v[k] : pv;
+        }
+        uint64_t need = ((pm >> col) & 1ull) - 1ull;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            const uint64_t t = (r > col && r < NS) ? (need & (0ull - ((m[r] >> col) & 1ull))) : 0ull;
+            pm ^= m[r] & t;
+            pv ^= v[r] & t;
+            need &= ~t;
+        }
+        singular |= need;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            const uint64_t t = (r != col && r < NS) ? (0ull - ((m[r] >> col) & 1ull)) : 0ull;
+            m[r] = (r == col) ? pm : (m[r] ^ (pm & t));
+            v[r] = (r == col) ? pv : (v[r] ^ (pv & t));
+        }
+    }
+    if (singular) return false;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const bool pad = i < NS && (uint32_t)(i % NQ) >= N;
+        if (pad) v[i] = 0;
+    }
+    q64_from_slot_space<NS>(s, N, v);
+    return true;
+}
+template <int NS>
+__device__ __noinline__ void q64_symplectic_inverse(Q64Rows<NS> &s, uint32_t N) {
+    uint64_t m[64], c[64];
+    q64_to_slot_space<NS>(s, N, m);
+    q64_symplectic_candidate<NS>(m, c);
+    q64_from_slot_space<NS>(s, N, c);
+}
+template <int NS>
+__device__ __noinline__ bool q64_check_symplectic(const Q64Rows<NS> &s, uint32_t N) {
+    uint64_t m[64], c[64];
+    q64_to_slot_space<NS>(s, N, m);
+    q64_symplectic_candidate<NS>(m, c);
+    return q64_is_inverse<NS>(m, c, N);
+}
+
+// EXTRA: solution log / layer metrics / multi-step; INV: add_inverts (CliffordEnv)
+template <int NS, bool HAS_Z, bool EXTRA, bool INV>
+__global__ __launch_bounds__(256) void q64_step_kernel(StepArgs a) {
+    using Rows = Q64Rows<NS>;
+    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    if (env >= a.B) return;
+    const bool act64 = a.flags & F_ACT64;
+    uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Rows::G * 64);
+    int64_t act = load_action(a.actions, env, act64);
+    Rows s;
+    q64_load<NS>(tile, lane, s);
+    int32_t depth = a.depth[env];
+    uint32_t iflags = INV ? a.inverted[env] : 0u;
+    uint64_t dirty = 0;
+    bool solved = false;
+    float reward = 0.0f;
+    uint32_t fault = 0;
+    int32_t sol_n = (EXTRA && (a.flags & F_TRACK)) ? a.sol_len[env * 2] : 0;
+    int32_t sol_b = (EXTRA && INV && (a.flags & F_TRACK)) ? a.sol_len[env * 2 + 1] : 0;
+
+    const uint32_t T = EXTRA ? a.T : 1u;
+    for (uint32_t t = 0; t < T; ++t) {
+        if (EXTRA && t) act = load_action(a.actions, (uint64_t)t * a.B + env, act64);
+        const bool in_range = act >= 0 && act < (int64_t)a.num_actions;  // clifford.rs:324
+        GateEntry g = {Q64_IDENTITY << 12, 0.0f};
+        if (in_range) g = a.gates[act];
+        float penalty = g.penalty;
+        if (EXTRA && (a.flags & F_LAYERS) && in_range) penalty = layers_penalty(a.layers + env * (2 * a.N + 2), a.N, a.descs[act], a.w);
+        dirty |= q64_apply<NS, HAS_Z>(s, g.ops);  // clifford.rs:331
+        if (EXTRA && (a.flags & F_TRACK)) {  // clifford.rs:334-340
+            if ((uint32_t)(sol_n + sol_b) < a.sol_cap) {
+                if (INV && (iflags & Q64_FLAG_INVERTED)) a.sol[env * a.sol_cap + a.sol_cap - 1 - (uint32_t)sol_b++] = (uint32_t)act;
+                else a.sol[env * a.sol_cap + (uint32_t)sol_n++] = (uint32_t)act;
+            } else {
+                fault |= 8u;
+            }
+        }
+        depth = depth > 0 ? depth - 1 : 0;  // clifford.rs:342
+        if constexpr (INV && HAS_Z) {        // maybe_random_invert (clifford.rs:262-270)
+            const uint32_t coin = a.coins ? a.coins[(uint64_t)t * a.B + env]
+                                          : (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, env, a.step_index + t) >> 63);
+            if (coin & 1u) {
+                if (iflags & Q64_FLAG_SYMPLECTIC) {
+                    q64_symplectic_inverse<NS>(s, a.N);
+                    iflags ^= Q64_FLAG_INVERTED;
+                    dirty = ~0ull;
+                } else if (q64_gauss_jordan<NS>(s, a.N)) {
+                    iflags ^= Q64_FLAG_INVERTED;
+                    dirty = ~0ull;
+                } else {
+                    fault |= QG_FAULT_SINGULAR;
+                }
+            }
+        }
+        solved = q64_solved<NS, HAS_Z>(s, a.N);  // clifford.rs:344
+        const float achieved = solved ? 1.0f : 0.0f;
+        reward = achieved - penalty;             // clifford.rs:345-346
+        if (EXTRA && a.rewards_seq) a.rewards_seq[(uint64_t)t * a.B + env] = reward;
+        if (EXTRA && a.dones_seq) a.dones_seq[(uint64_t)t * a.B + env] = (uint8_t)(depth == 0 || solved);
+    }
+#pragma unroll
+    for (int g = 0; g < Rows::G; ++g)
+        if ((dirty >> g) & 1ull) q64_store_group<NS>(tile, lane, s, g);
+    a.depth[env] = depth;
+    a.reward[env] = reward;
+    a.done[env] = (uint8_t)(depth == 0 || solved);
+    a.success[env] = (uint8_t)solved;
+    if (EXTRA && (a.flags & F_TRACK)) {
+        a.sol_len[env * 2] = sol_n;
+        if (INV) a.sol_len[env * 2 + 1] = sol_b;
+    }
+    if (INV) a.inverted[env] = (uint8_t)iflags;
+    if ((EXTRA || INV) && fault) atomicOr(&a.error[env], fault);
+}
+
+template <int NS, bool HAS_Z>
+__global__ __launch_bounds__(256) void q64_init_kernel(InitArgs a) {
+    using Rows = Q64Rows<NS>;
+    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    if (env >= a.B) return;
+    if (a.only_done && !a.done[env]) return;
+    uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Rows::G * 64);
+    Rows s;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s.r[i] = q64_identity_word<NS, HAS_Z>(i, a.N);
+    if (a.mode == 1) {  // set_state (clifford.rs:299-304)
+#pragma unroll 1
+        for (int sl = 0; sl < NS; ++sl) {
+            const uint32_t j = HAS_Z ? (uint32_t)sl >> 1 : (uint32_t)sl;
+            const uint32_t row = (HAS_Z && (sl & 1)) ? a.N + j : j;
+            uint64_t w = 0;
+            if (j < a.N) {
+                if (a.format == QG_FMT_PACKED) {
+                    w = reinterpret_cast<const uint64_t *>(a.src)[env * a.src_stride + row];
+                    if (a.D < 64) w &= (1ull << a.D) - 1ull;
+                } else if (a.format == QG_FMT_I64) {
+                    const int64_t *p = reinterpret_cast<const int64_t *>(a.src) + env * a.src_stride + (uint64_t)row * a.D;
+                    for (uint32_t c = 0; c < a.D; ++c) w |= (uint64_t)(p[c] > 0) << c;
+                } else {
+                    const int8_t *p = reinterpret_cast<const int8_t *>(a.src) + env * a.src_stride + (uint64_t)row * a.D;
+                    for (uint32_t c = 0; c < a.D; ++c) w |= (uint64_t)(p[c] > 0) << c;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) s.r[k] = (k == sl) ? w : s.r[k];  // sl is wave-uniform
+        }
+    } else if (a.mode == 2) {  // reset scramble (clifford.rs:306-316)
+        for (uint32_t t = 0; t < a.n_draws; ++t) {
+            const int64_t act = a.actions ? (int64_t)a.actions[(uint64_t)t * a.B + env] : (int64_t)rng_action(a.seed, env, t, a.num_actions);
+            const uint32_t ops = (act >= 0 && act < (int64_t)a.num_actions) ? a.gates[act].ops : (Q64_IDENTITY << 12);
+            q64_apply<NS, HAS_Z>(s, ops);
+        }
+    }
+    const bool solved = q64_solved<NS, HAS_Z>(s, a.N);
+#pragma unroll
+    for (int g = 0; g < Rows::G; ++g) q64_store_group<NS>(tile, lane, s, g);
+    uint32_t symp = 0;
+    if constexpr (HAS_Z) {
+        if (a.check_symplectic) symp = (a.mode != 1 || q64_check_symplectic<NS>(s, a.N)) ? Q64_FLAG_SYMPLECTIC : 0u;
+    }
+    a.depth[env] = a.depth_value;  // reset_internals (clifford.rs:272-283)
+    a.success[env] = (uint8_t)solved;
+    a.reward[env] = solved ? 1.0f : 0.0f;
+    a.done[env] = (uint8_t)(a.depth_value == 0 || solved);
+    a.inverted[env] = (uint8_t)symp;
+    a.error[env] = 0;
+    a.sol_len[env * 2] = 0;
+    a.sol_len[env * 2 + 1] = 0;
+    if (a.layers) {
+        int32_t *lay = a.layers + env * a.layers_len;
+        for (uint32_t i = 0; i + 2 < a.layers_len; ++i) lay[i] = -1;
+        lay[a.layers_len - 2] = 0;
+        lay[a.layers_len - 1] = 0;
+    }
+}
+
+// export: one thread per (env, matrix row)
+__global__ __launch_bounds__(256) void q64_export_kernel(ObsArgs a, uint32_t ns, uint32_t has_z) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t env = gid / a.D;
+    const uint32_t row = (uint32_t)(gid % a.D);
+    if (env >= a.B) return;
+    const uint32_t slot = has_z ? (row < a.N ? 2 * row : 2 * (row - a.N) + 1) : row;
+    const uint64_t *tile = reinterpret_cast<const uint64_t *>(a.state) + (env >> 6) * (uint64_t)(ns * 64);
+    const uint64_t w = tile[((slot >> 1) * 64 + (uint32_t)(env & 63)) * 2 + (slot & 1)];
+    if (a.format == QG_FMT_PACKED) {
+        reinterpret_cast<uint64_t *>(a.out)[env * a.out_stride + row] = w;
+    } else if (a.format == QG_FMT_I64) {
+        int64_t *o = reinterpret_cast<int64_t *>(a.out) + env * a.out_stride + (uint64_t)row * a.D;
+        for (uint32_t c = 0; c < a.D; ++c) o[c] = (int64_t)((w >> c) & 1ull);
+    } else {
+        int8_t *o = reinterpret_cast<int8_t *>(a.out) + env * a.out_stride + (uint64_t)row * a.D;
+        for (uint32_t c = 0; c < a.D; ++c) o[c] = (int8_t)((w >> c) & 1ull);
+    }
+}
+
+static inline unsigned grid_for(uint64_t threads, unsigned block) { return (unsigned)((threads + block - 1) / block); }
+
+template <int NS, bool HAS_Z>
+static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
+    const dim3 grid(grid_for(a.B, 256)), block(256);
+    const bool extra = (a.flags & (F_TRACK | F_LAYERS)) || a.T != 1 || a.rewards_seq || a.dones_seq;
+    if constexpr (HAS_Z) {
+        if (a.flags & F_INVERTS) {
+            hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, true, true>), grid, block, 0, s, a);
+            return hipGetLastError();
+        }
+    }
+    if (extra) hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, true, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, false, false>), grid, block, 0, s, a);
+    return hipGetLastError();
+}
+template <int NS, bool HAS_Z>
+static hipError_t q64_launch_init(const InitArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL((q64_init_kernel<NS, HAS_Z>), dim3(grid_for(a.B, 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ns = slots: CliffordEnv 2 * (N rounded up to 4); LinearFunctionEnv N rounded up to 8
+#define Q64_DISPATCH(FN, ARGS)                        \
+    if (has_z) {                                      \
+        switch (ns) {                                 \
+        case 40: return FN<40, true>(ARGS, s);        \
+        case 48: return FN<48, true>(ARGS, s);        \
+        case 56: return FN<56, true>(ARGS, s);        \
+        case 64: return FN<64, true>(ARGS, s);        \
+        }                                             \
+    } else {                                          \
+        switch (ns) {                                 \
+        case 40: return FN<40, false>(ARGS, s);       \
+        case 48: return FN<48, false>(ARGS, s);       \
+        case 56: return FN<56, false>(ARGS, s);       \
+        case 64: return FN<64, false>(ARGS, s);       \
+        }                                             \
+    }                                                 \
+    return hipErrorInvalidValue;
+
+hipError_t q64_step(const StepArgs &a, uint32_t ns, bool has_z, hipStream_t s) {
+    if (!a.B) return hipSuccess;
+    Q64_DISPATCH(q64_launch_step, a)
+}
+hipError_t q64_init(const InitArgs &a, uint32_t ns, bool has_z, hipStream_t s) {
+    if (!a.B) return hipSuccess;
+    Q64_DISPATCH(q64_launch_init, a)
+}
+hipError_t q64_export(const ObsArgs &a, uint32_t ns, bool has_z, hipStream_t s) {
+    if (!a.B) return hipSuccess;
+    hipLaunchKernelGGL(q64_export_kernel, dim3(grid_for(a.B * a.D, 256)), dim3(256), 0, s, a, ns, has_z ? 1u : 0u);
+    return hipGetLastError();
+}
+
+}  // namespace qg

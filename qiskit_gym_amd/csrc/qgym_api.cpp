@@ -116,7 +116,7 @@ int ensure_scratch_public(qg_vec *v, size_t bytes) {
 
 // TILE layout action word (kernels_qm.hip): q0, q1 and the 4x4 GF(2) matrix acting on
 // {X[q0], Z[q0], X[q1], Z[q1]} (clifford.rs:89-133 / linear_function.rs:62-83 as linear maps)
-static uint32_t tile_ops(int env_kind, const qg_gate &g) {
+static uint32_t tile_ops(int env_kind, const qg_gate &g, bool wide) {
     const uint32_t a = (uint32_t)g.q0, b = (uint32_t)g.q1;
     enum { X0 = 1, Z0 = 2, X1 = 4, Z1 = 8 };
     auto M = [](uint32_t ox0, uint32_t oz0, uint32_t ox1, uint32_t oz1) { return ox0 | (oz0 << 4) | (ox1 << 8) | (oz1 << 12); };
@@ -137,6 +137,7 @@ static uint32_t tile_ops(int env_kind, const qg_gate &g) {
         if (g.kind == QG_CX && a != b) { m = M(X0, Z0, X1 | X0, Z1); q1 = b; }
         if (g.kind == QG_SWAP && a != b) { m = M(X1, Z0, X0, Z1); q1 = b; }
     }
+    if (wide) return (a & 63u) | ((q1 & 63u) << 6) | (m << 12);  // TILE64 (kernels_qm64.hip)
     return (a & 31u) | ((q1 & 31u) << 5) | (m << 10);
 }
 
@@ -262,7 +263,7 @@ static void fill_init_args(const qg_vec *v, InitArgs &a) {
     a.N = v->N;
     a.log2L = v->log2L;
     a.num_actions = (uint32_t)v->gates.size();
-    a.check_symplectic = (v->layout == LAYOUT_TILE && (v->flags & F_INVERTS)) ? 1u : 0u;
+    a.check_symplectic = ((v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) && (v->flags & F_INVERTS)) ? 1u : 0u;
 }
 
 static hipError_t launch_init(const qg_vec *v, const InitArgs &a, hipStream_t s) {
@@ -272,6 +273,7 @@ static hipError_t launch_init(const qg_vec *v, const InitArgs &a, hipStream_t s)
     case LAYOUT_LF8: return lf8_init(a, s);
     case LAYOUT_PERM: return perm_init(a, s);
     case LAYOUT_TILE: return qm_init(a, v->nxp, v->has_z, s);
+    case LAYOUT_TILE64: return q64_init(a, v->nxp, v->has_z, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -316,6 +318,7 @@ static hipError_t launch_step(const qg_vec *v, const StepArgs &a, hipStream_t s)
     case LAYOUT_PERM: return perm_step(a, a.T > 1, s);
     case LAYOUT_PAULI: return pauli_step(v, a, s);
     case LAYOUT_TILE: return qm_step(a, v->nxp, v->has_z, s);
+    case LAYOUT_TILE64: return q64_step(a, v->nxp, v->has_z, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -397,6 +400,13 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
         v->stride_bytes = 0;
         v->state_bytes = ((batch + 63) / 64) * R * 256;
     }
+    if (v->layout == LAYOUT_ROWS64 && tile_ok && getenv("QGYM_FORCE_ROWS") == nullptr) {
+        v->layout = LAYOUT_TILE64;  // uint64 rows, thread per env (kernels_qm64.hip)
+        v->has_z = cfg->env_kind == QG_CLIFFORD;
+        v->nxp = v->has_z ? 2u * ((N + 3u) & ~3u) : ((N + 7u) & ~7u);  // row slots per env
+        v->stride_bytes = 0;
+        v->state_bytes = ((batch + 63) / 64) * (size_t)v->nxp * 512;
+    }
     if (v->layout == LAYOUT_ROWS32 || v->layout == LAYOUT_ROWS64) {
         const uint32_t rpl = v->layout == LAYOUT_ROWS32 ? 4 : 2;
         v->log2L = pow2ceil_log2((v->D + rpl - 1) / rpl);
@@ -418,7 +428,8 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
         int dc, dg;
         gate_deltas(gates[i], N, dc, dg);
         table[i].ops = cfg->env_kind == QG_PAULI ? 0u
-                       : v->layout == LAYOUT_TILE ? tile_ops(cfg->env_kind, gates[i])
+                       : v->layout == LAYOUT_TILE ? tile_ops(cfg->env_kind, gates[i], false)
+                       : v->layout == LAYOUT_TILE64 ? tile_ops(cfg->env_kind, gates[i], true)
                                                   : gate_ops(cfg->env_kind, gates[i], N);
         table[i].penalty = table_penalty(w, dc, dg);
         descs[i] = make_desc((uint32_t)gates[i].kind, (uint32_t)gates[i].q0, (uint32_t)gates[i].q1);
@@ -512,7 +523,7 @@ int qg_vec_get_info(const qg_vec *v, qg_vec_info *o) {
     }
     o->device = v->device;
     o->batch = v->B;
-    o->packed_word_bytes = v->layout == LAYOUT_PERM ? 1 : ((v->layout == LAYOUT_ROWS64 || v->layout == LAYOUT_PAULI) ? 8 : 4);
+    o->packed_word_bytes = v->layout == LAYOUT_PERM ? 1 : ((v->layout == LAYOUT_ROWS64 || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_PAULI) ? 8 : 4);
     o->packed_words_per_env = v->D;
     o->packed_env_stride_bytes = v->stride_bytes;
     o->state_dev = v->state;
@@ -563,7 +574,7 @@ int64_t qg_vec_get_difficulty(const qg_vec *v) { return v ? v->difficulty : -1; 
 static size_t format_elem_bytes(const qg_vec *v, int format) {
     if (format == QG_FMT_I64) return 8;
     if (format == QG_FMT_U8) return 1;
-    return v->layout == LAYOUT_PERM ? 1 : ((v->layout == LAYOUT_ROWS64 || v->layout == LAYOUT_PAULI) ? 8 : 4);
+    return v->layout == LAYOUT_PERM ? 1 : ((v->layout == LAYOUT_ROWS64 || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_PAULI) ? 8 : 4);
 }
 static size_t format_min_elems(const qg_vec *v, int format) {
     if (v->layout == LAYOUT_PERM) return v->N;
@@ -608,6 +619,7 @@ static hipError_t launch_export(const qg_vec *v, const ObsArgs &a, hipStream_t s
     case LAYOUT_PERM: return perm_export(a, s);
     case LAYOUT_PAULI: return pauli_export(v, a, s);
     case LAYOUT_TILE: return qm_export(a, v->nxp, v->has_z, s);
+    case LAYOUT_TILE64: return q64_export(a, v->nxp, v->has_z, s);
     default: return hipErrorInvalidValue;
     }
 }

@@ -8,7 +8,7 @@
 
 namespace qg {
 
-enum Layout { LAYOUT_ROWS32 = 0, LAYOUT_ROWS64 = 1, LAYOUT_LF8 = 2, LAYOUT_PERM = 3, LAYOUT_PAULI = 4, LAYOUT_TILE = 5 };
+enum Layout { LAYOUT_ROWS32 = 0, LAYOUT_ROWS64 = 1, LAYOUT_LF8 = 2, LAYOUT_PERM = 3, LAYOUT_PAULI = 4, LAYOUT_TILE = 5, LAYOUT_TILE64 = 6 };
 
 struct GraphKey {
     const void *actions;

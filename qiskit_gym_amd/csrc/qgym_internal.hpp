@@ -12,6 +12,8 @@
 //  TILE layout (CliffordEnv N<=16 and LinearFunctionEnv 8<N<=32 without add_inverts; the hot
 //    path): thread-per-env, envs in tiles of 64, each tile = R/4 row groups of 1 KiB holding one
 //    uint4 (4 row slots) per lane -- see kernels_qm.hip.
+//  TILE64 layout: the same with uint64 rows (two per 16-byte group) for CliffordEnv 16<N<=32 and
+//    LinearFunctionEnv 32<N<=64 without add_inverts -- see kernels_qm64.hip.
 //  LF8 layout   (LinearFunctionEnv N<=8): one uint64 per env, byte r = row r.
 //  PERM layout  (PermutationEnv N<=16): one uint64 per env, nibble i = state[i].
 //  PAULI layout (PauliEnv N<=32): lane q owns qubit q's tableau rows {X row q, Z row N+q} as two
@@ -152,6 +154,10 @@ hipError_t rows_export(const ObsArgs &a, bool word64, hipStream_t s);
 hipError_t qm_step(const StepArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
 hipError_t qm_init(const InitArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
 hipError_t qm_export(const ObsArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
+
+hipError_t q64_step(const StepArgs &a, uint32_t ns, bool has_z, hipStream_t s);
+hipError_t q64_init(const InitArgs &a, uint32_t ns, bool has_z, hipStream_t s);
+hipError_t q64_export(const ObsArgs &a, uint32_t ns, bool has_z, hipStream_t s);
 
 hipError_t lf8_step(const StepArgs &a, bool fused, hipStream_t s);
 hipError_t lf8_init(const InitArgs &a, hipStream_t s);
