@@ -240,11 +240,16 @@ __device__ inline bool qm_is_inverse(const uint32_t (&m)[32], const uint32_t (&c
 // only (the first row below with the pivot bit is xor-ed into the pivot row instead of swapped
 // with it: a different elimination path to the same, unique, inverse).  Returns false for a
 // singular matrix -- the reference's `expect("CFState is singular; cannot invert")`.
-template <int NXP>
-__device__ __noinline__ bool qm_gauss_jordan(QmRows<NXP, true> &s, uint32_t N) {
-    constexpr int R = 2 * NXP;
+template <int NXP, bool HAS_Z>
+__device__ __noinline__ bool qm_gauss_jordan(QmRows<NXP, HAS_Z> &s, uint32_t N) {
+    constexpr int R = QmRows<NXP, HAS_Z>::R;
     uint32_t m[32], v[32];
-    qm_to_slot_space<NXP>(s, N, m);
+    if constexpr (HAS_Z) {
+        qm_to_slot_space<NXP>(s, N, m);
+    } else {  // LinearFunctionEnv: the slots already are a square matrix (linear_function.rs:124-146)
+#pragma unroll
+        for (int i = 0; i < 32; ++i) m[i] = i < R ? s.r[i] : 0u;
+    }
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
         const bool pad = i < R && (uint32_t)(i % NXP) >= N;
@@ -282,7 +287,12 @@ __device__ __noinline__ bool qm_gauss_jordan(QmRows<NXP, true> &s, uint32_t N) {
         const bool pad = i < R && (uint32_t)(i % NXP) >= N;
         if (pad) v[i] = 0;
     }
-    qm_from_slot_space<NXP>(s, N, v);
+    if constexpr (HAS_Z) {
+        qm_from_slot_space<NXP>(s, N, v);
+    } else {
+#pragma unroll
+        for (int i = 0; i < R; ++i) s.r[i] = v[i];
+    }
     return true;
 }
 
@@ -353,15 +363,21 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
             }
         }
         depth = depth > 0 ? depth - 1 : 0;          // clifford.rs:342
-        if constexpr (INV && HAS_Z) {               // maybe_random_invert (clifford.rs:262-270)
+        if constexpr (INV) {                        // maybe_random_invert (clifford.rs:262-270, linear_function.rs:227-235)
             const uint32_t coin = a.coins ? a.coins[(uint64_t)t * a.B + env]
                                           : (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, env, a.step_index + t) >> 63);
             if (coin & 1u) {
-                if (iflags & QM_FLAG_SYMPLECTIC) {
-                    qm_symplectic_inverse<NXP>(s, a.N);
+                bool fast = false;
+                if constexpr (HAS_Z) {
+                    if (iflags & QM_FLAG_SYMPLECTIC) {
+                        qm_symplectic_inverse<NXP>(s, a.N);
+                        fast = true;
+                    }
+                }
+                if (fast) {
                     iflags ^= QM_FLAG_INVERTED;
                     dirty = 0xFFFFFFFFu;
-                } else if (qm_gauss_jordan<NXP>(s, a.N)) {
+                } else if (qm_gauss_jordan<NXP, HAS_Z>(s, a.N)) {
                     iflags ^= QM_FLAG_INVERTED;
                     dirty = 0xFFFFFFFFu;
                 } else {
@@ -509,11 +525,9 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
     const dim3 grid(grid_for(a.B, 256)), block(256);
     const bool feat = a.flags & (F_TRACK | F_LAYERS);
     const bool seq = a.T != 1 || a.rewards_seq || a.dones_seq;
-    if constexpr (HAS_Z) {
-        if (a.flags & F_INVERTS) {  // the inversion variants always carry FEAT and SEQ (two kernels per NXP)
-            hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true>), grid, block, 0, s, a);
-            return hipGetLastError();
-        }
+    if (a.flags & F_INVERTS) {  // the inversion variants always carry FEAT and SEQ
+        hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true>), grid, block, 0, s, a);
+        return hipGetLastError();
     }
     if (feat && seq) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true>), grid, block, 0, s, a);
     else if (feat) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, false>), grid, block, 0, s, a);
