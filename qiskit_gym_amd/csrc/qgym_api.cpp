@@ -391,9 +391,10 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     const bool inverts = cfg->add_inverts && cfg->env_kind != QG_PAULI;
     // thread-per-env TILE layout for matrices of <= 32 rows (the hot path); the inversion path
     // (add_inverts) lives in the lane-group ROWS kernels
-    // thread-per-env layouts for everything but the 64-bit LinearFunction inversion (a general
-    // 64x64 Gauss-Jordan does not fit the register file; it stays in the lane-group ROWS kernels)
-    const bool tile_ok = !inverts || cfg->env_kind == QG_CLIFFORD || N <= 32;
+    // thread-per-env layouts for everything but LinearFunction inversion beyond 16 rows: a general
+    // Gauss-Jordan over that many register-resident rows is slower than the lane-group ROWS
+    // kernels' (measured at N = 32: 72 vs 46 us per step), and CliffordEnv has the transpose form
+    const bool tile_ok = !inverts || cfg->env_kind == QG_CLIFFORD || N <= 16;
     if (v->layout == LAYOUT_ROWS32 && tile_ok && getenv("QGYM_FORCE_ROWS") == nullptr) {
         v->layout = LAYOUT_TILE;
         v->nxp = (N + 3u) & ~3u;
