@@ -771,6 +771,7 @@ bool pauli_under_diff(const CouplingInfo &ci, uint32_t n, size_t difficulty, flo
 }  // namespace
 
 int pauli_reset_seeded(qg_vec *v, uint64_t seed, hipStream_t s) {
+    if (v->pauli_tile) return ptile_reset_seeded(v, seed, false, s);  // generated on the device
     const uint32_t n = v->N, D = 2 * n;
     const CouplingInfo ci = coupling_info(v);
     const size_t scale = (size_t)std::max(v->cfg.pauli_diff_scale, 1);  // pauli.rs:392

@@ -461,6 +461,175 @@ __global__ __launch_bounds__(256) void ptile_export_kernel(PTObsArgs pa) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// PauliEnv::reset on the device (pauli.rs:554-586): the random target generator
+// (get_pauli_under_diff / generate_paulis_with_difficulty / random_clifford_tableau, pauli.rs:115-271)
+// one env per lane, every draw from the counter-RNG stream rng_draw(seed ^ 0x7061756C, env, k),
+// k = 0, 1, 2, ... -- the stream the host generator (kernels_pauli.hip) and the tests use -- followed
+// by the initial clean and the scalar resets.  Coupling-graph tables come from the host.
+// ------------------------------------------------------------------------------------------------
+struct PTGenArgs {
+    StepArgs s;
+    const uint8_t *pairs;      // [n_pairs][2]: qubit pairs q1<q2 grouped by graph distance, (q1,q2) ascending
+    const uint32_t *dvals;     // [nd] distances that occur, ascending
+    const uint32_t *doff;      // [nd+1] offsets of each distance's group in `pairs`
+    const uint8_t *cx_pairs;   // [n_cx][2]: the CX gates of the gateset, in order (pauli.rs:360-366)
+    uint32_t nd, n_cx;
+    uint64_t seed;
+    uint32_t difficulty, pauli_difficulty, max_paulis;
+    float decay;
+    int32_t depth_value;
+    uint32_t only_done;
+};
+
+struct PTStream {
+    uint64_t seed, env, k;
+    __device__ uint64_t next() { return rng_draw(seed, env, k++); }
+    __device__ uint32_t range(uint32_t n) { return (uint32_t)__umul64hi(next(), (uint64_t)n); }
+    __device__ float f32() { return (float)(next() >> 40) * (1.0f / 16777216.0f); }
+};
+
+template <int NQ, int RM>
+__global__ __launch_bounds__(256) void ptile_generate_kernel(PTGenArgs ga) {
+    const StepArgs &a = ga.s;
+    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    if (env >= a.B) return;
+    if (ga.only_done && !a.done[env]) return;
+    const uint32_t N = a.N;
+    constexpr int G = NQ + RM + 1;
+    uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(G * 64);
+    PTStream rng{ga.seed ^ 0x7061756Cull, env, 0};
+    PTState<NQ, RM> s;
+#pragma unroll
+    for (int k = 0; k < RM; ++k) s.rx[k] = s.rz[k] = s.rpred[k] = 0;
+    s.plo = s.phi = 0;
+
+    // generate_paulis_with_difficulty (pauli.rs:191-213)
+    uint32_t n_lab = 0, remaining = ga.pauli_difficulty;
+    while (remaining > 0 && n_lab < ga.max_paulis) {
+        const uint32_t difficulty = remaining;  // get_pauli_under_diff(remaining) (pauli.rs:115-188)
+        uint32_t nvd = 0;
+        for (uint32_t i = 0; i < ga.nd; ++i) nvd += ga.dvals[i] <= difficulty;
+        if (nvd == 0) break;
+        uint32_t inset = 0, budget = difficulty;
+        uint32_t di = rng.range(nvd);
+        uint32_t d = ga.dvals[di];
+        uint32_t pick = ga.doff[di] + rng.range(ga.doff[di + 1] - ga.doff[di]);
+        inset |= (1u << ga.pairs[2 * pick]) | (1u << ga.pairs[2 * pick + 1]);
+        budget = budget > d ? budget - d : 0;
+        for (;;) {
+            uint32_t nv2 = 0;
+            for (uint32_t i = 0; i < nvd; ++i) nv2 += ga.dvals[i] <= budget;
+            if (budget == 0 || nv2 == 0 || (uint32_t)__popc(inset) >= N) break;
+            if (rng.f32() <= ga.decay) break;  // continue with probability 1 - num_qubits_decay
+            di = rng.range(nv2);
+            d = ga.dvals[di];
+            uint32_t nc = 0;
+            for (uint32_t p = ga.doff[di]; p < ga.doff[di + 1]; ++p) nc += ((inset >> ga.pairs[2 * p]) | (inset >> ga.pairs[2 * p + 1])) & 1u;
+            if (nc == 0) continue;
+            uint32_t want = rng.range(nc);
+            for (uint32_t p = ga.doff[di]; p < ga.doff[di + 1]; ++p) {
+                if (((inset >> ga.pairs[2 * p]) | (inset >> ga.pairs[2 * p + 1])) & 1u) {
+                    if (want == 0) {
+                        inset |= (1u << ga.pairs[2 * p]) | (1u << ga.pairs[2 * p + 1]);
+                        break;
+                    }
+                    --want;
+                }
+            }
+            budget = budget > d ? budget - d : 0;
+        }
+        // label: string index q carries the axis; Pauli::from_label reverses, so it is qubit N-1-q
+        uint32_t x = 0, z = 0, ys = 0;
+        for (uint32_t q = 0; q < N; ++q) {
+            if ((inset >> q) & 1u) {
+                const uint32_t ax = rng.range(3);  // "XYZ"
+                const uint32_t bit = 1u << (N - 1u - q);
+                if (ax != 2) x |= bit;
+                if (ax != 0) z |= bit;
+                ys += ax == 1;
+            }
+        }
+        uint32_t pred = 0;  // PauliDag::new (pauli_dag.rs:35-41): edge to every earlier non-commuting rotation
+#pragma unroll
+        for (int k = 0; k < RM; ++k)
+            if ((uint32_t)k < n_lab) pred |= (uint32_t)((__popc(x & s.rz[k]) + __popc(z & s.rx[k])) & 1) << k;
+#pragma unroll
+        for (int k = 0; k < RM; ++k) {
+            const bool here = (uint32_t)k == n_lab;
+            s.rx[k] = here ? x : s.rx[k];
+            s.rz[k] = here ? z : s.rz[k];
+            s.rpred[k] = here ? pred : s.rpred[k];
+        }
+        s.plo |= (ys & 1u) << n_lab;  // base_phase = (0 + #Y) mod 4 (pauli.rs:73)
+        s.phi |= ((ys >> 1) & 1u) << n_lab;
+        n_lab += 1;
+        const uint32_t cost = difficulty - budget, dec = cost > 1 ? cost : 1;
+        remaining = remaining > dec ? remaining - dec : 0;
+    }
+    s.alive = n_lab >= 32 ? ~0u : ((1u << n_lab) - 1u);
+    s.count = n_lab;
+    s.order = 0;
+#pragma unroll
+    for (int k = 0; k < RM; ++k) s.order |= ((uint32_t)k < n_lab) ? ((uint64_t)k << (4 * k)) : 0ull;
+
+    // random_clifford_tableau (pauli.rs:220-271): H / S / CX row operations on the identity
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        s.X[j] = (uint32_t)j < N ? 1ull << j : 0ull;
+        s.Z[j] = (uint32_t)j < N ? (1ull << N) << j : 0ull;
+    }
+    if (ga.difficulty != 0 && ga.n_cx != 0) {
+        for (uint32_t it = 0; it < ga.difficulty; ++it) {
+            const float r = rng.f32();
+            uint32_t qa, qb, m;
+            if (r > 0.3f) {  // CX: row q1 ^= row q0 ; row n+q0 ^= row n+q1  (a = q0, b = q1)
+                const uint32_t k = rng.range(ga.n_cx);
+                qa = ga.cx_pairs[2 * k];
+                qb = ga.cx_pairs[2 * k + 1];
+                m = qa == qb ? 0x8400u : 0x85A1u;  // a CX(q, q) entry xors rows into themselves: both become zero
+            } else if (r > 0.15f) {  // H: swap rows q, n+q
+                qa = qb = rng.range(N);
+                m = 0x8412u;
+            } else {  // S: row n+q ^= row q
+                qa = qb = rng.range(N);
+                m = 0x8431u;
+            }
+            pt_apply_tableau<NQ, RM>(s, qa, qb, m);
+        }
+    }
+
+    uint32_t n_removed = 0, fault = 0;  // clean initially trivial rotations (pauli.rs:576)
+    uint64_t rem_pos[(RM + 7) / 8];
+#pragma unroll
+    for (int i = 0; i < (RM + 7) / 8; ++i) rem_pos[i] = 0;
+    pt_clean<NQ, RM>(s, n_removed, fault, nullptr, rem_pos);
+    const bool solved = pt_solved<NQ, RM>(s, N);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        tile[q * 64 + lane] = make_uint4((uint32_t)s.X[q], (uint32_t)(s.X[q] >> 32), (uint32_t)s.Z[q], (uint32_t)(s.Z[q] >> 32));
+#pragma unroll
+    for (int k = 0; k < RM; ++k)
+        tile[(NQ + k) * 64 + lane] = make_uint4(s.rx[k], s.rz[k], ((s.plo >> k) & 1u) | (((s.phi >> k) & 1u) << 1), s.rpred[k]);
+    tile[(NQ + RM) * 64 + lane] = make_uint4(s.alive, s.count, (uint32_t)s.order, (uint32_t)(s.order >> 32));
+    a.depth[env] = ga.depth_value;  // pauli.rs:578-585
+    a.success[env] = (uint8_t)solved;
+    a.reward[env] = solved ? 1.0f : 0.0f;
+    a.done[env] = (uint8_t)(ga.depth_value == 0 || solved);
+    a.inverted[env] = 0;
+    a.error[env] = fault;
+    a.sol_len[env * 2] = 0;
+    a.sol_len[env * 2 + 1] = 0;
+    if (a.layers) {
+        int32_t *lay = a.layers + env * (2 * N + 2);
+        for (uint32_t i = 0; i < 2 * N; ++i) lay[i] = -1;
+        lay[2 * N] = 0;
+        lay[2 * N + 1] = 0;
+    }
+}
+
 static inline unsigned grid_for(uint64_t threads, unsigned block) { return (unsigned)((threads + block - 1) / block); }
 
 // ---- host hooks ----------------------------------------------------------------------------------
@@ -558,6 +727,93 @@ hipError_t ptile_export(const qg_vec *v, const ObsArgs &a, hipStream_t s) {
     pa.counter = v->observe_counter;
     hipLaunchKernelGGL(ptile_export_kernel, dim3(grid_for(a.B * 2ull * a.N, 256)), dim3(256), 0, s, pa);
     return hipGetLastError();
+}
+
+
+template <int NQ, int RM>
+static hipError_t pt_launch_generate(const PTGenArgs &pa, hipStream_t s) {
+    hipLaunchKernelGGL((ptile_generate_kernel<NQ, RM>), dim3(grid_for(pa.s.B, 256)), dim3(256), 0, s, pa);
+    return hipGetLastError();
+}
+static hipError_t ptile_generate(const qg_vec *v, const PTGenArgs &pa, hipStream_t s) { PT_DISPATCH(pt_launch_generate) }
+
+// PauliEnv::reset for the whole batch (or, with only_done, for the finished episodes) on the device
+int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s) {
+    const uint32_t n = v->N;
+    if (!v->d_gen_tables) {  // coupling-graph tables, once per handle (PauliEnv::new, pauli.rs:360-370)
+        std::vector<uint8_t> cx;
+        std::vector<std::vector<uint32_t>> adj(n);
+        for (const qg_gate &g : v->gates)
+            if (g.kind == QG_CX) {
+                cx.push_back((uint8_t)g.q0);
+                cx.push_back((uint8_t)g.q1);
+                auto add = [&](uint32_t a, uint32_t b) { if (std::find(adj[a].begin(), adj[a].end(), b) == adj[a].end()) adj[a].push_back(b); };
+                add((uint32_t)g.q0, (uint32_t)g.q1);
+                add((uint32_t)g.q1, (uint32_t)g.q0);
+            }
+        std::vector<std::vector<int>> dist(n, std::vector<int>(n, -1));  // compute_graph_distances (pauli.rs:56-91)
+        for (uint32_t st = 0; st < n; ++st) {
+            std::vector<uint32_t> q{st};
+            dist[st][st] = 0;
+            for (size_t h = 0; h < q.size(); ++h)
+                for (uint32_t w : adj[q[h]])
+                    if (dist[st][w] < 0) { dist[st][w] = dist[st][q[h]] + 1; q.push_back(w); }
+        }
+        std::vector<uint8_t> pairs;  // build_dist_pairs (pauli.rs:95-111)
+        std::vector<uint32_t> dvals, doff;
+        for (int d = 1; d < (int)n; ++d) {
+            const size_t before = pairs.size();
+            for (uint32_t a = 0; a < n; ++a)
+                for (uint32_t b = a + 1; b < n; ++b)
+                    if (dist[a][b] == d) { pairs.push_back((uint8_t)a); pairs.push_back((uint8_t)b); }
+            if (pairs.size() != before) { dvals.push_back((uint32_t)d); doff.push_back((uint32_t)(before / 2)); }
+        }
+        doff.push_back((uint32_t)(pairs.size() / 2));
+        // one allocation: [dvals | doff | pairs | cx]
+        const size_t o_dvals = 0, o_doff = o_dvals + 4 * std::max<size_t>(dvals.size(), 1), o_pairs = o_doff + 4 * doff.size();
+        const size_t o_cx = o_pairs + ((pairs.size() + 3) & ~size_t(3)) + 4, total = o_cx + cx.size() + 4;
+        std::vector<uint8_t> blob(total, 0);
+        if (!dvals.empty()) memcpy(blob.data() + o_dvals, dvals.data(), 4 * dvals.size());
+        memcpy(blob.data() + o_doff, doff.data(), 4 * doff.size());
+        if (!pairs.empty()) memcpy(blob.data() + o_pairs, pairs.data(), pairs.size());
+        if (!cx.empty()) memcpy(blob.data() + o_cx, cx.data(), cx.size());
+        HIP_TRY(hipMalloc(&v->d_gen_tables, total));
+        HIP_TRY(hipMemcpy(v->d_gen_tables, blob.data(), total, hipMemcpyHostToDevice));
+        v->gen_nd = (uint32_t)dvals.size();
+        v->gen_ncx = (uint32_t)(cx.size() / 2);
+        v->gen_off[0] = (uint32_t)o_dvals; v->gen_off[1] = (uint32_t)o_doff; v->gen_off[2] = (uint32_t)o_pairs; v->gen_off[3] = (uint32_t)o_cx;
+    }
+    PTGenArgs ga;
+    memset(&ga, 0, sizeof ga);
+    StepArgs &a = ga.s;
+    a.state = v->state;
+    a.depth = v->depth;
+    a.reward = v->reward;
+    a.done = v->done;
+    a.success = v->success;
+    a.inverted = v->inverted;
+    a.error = v->error;
+    a.sol_len = v->sol_len;
+    a.layers = v->layers;
+    a.B = v->B;
+    a.N = n;
+    const uint8_t *base = reinterpret_cast<const uint8_t *>(v->d_gen_tables);
+    ga.dvals = reinterpret_cast<const uint32_t *>(base + v->gen_off[0]);
+    ga.doff = reinterpret_cast<const uint32_t *>(base + v->gen_off[1]);
+    ga.pairs = base + v->gen_off[2];
+    ga.cx_pairs = base + v->gen_off[3];
+    ga.nd = v->gen_nd;
+    ga.n_cx = v->gen_ncx;
+    ga.seed = seed;
+    ga.difficulty = (uint32_t)v->difficulty;
+    ga.pauli_difficulty = (uint32_t)(v->difficulty / std::max(v->cfg.pauli_diff_scale, 1));  // pauli.rs:557,392
+    ga.max_paulis = v->rmax_generate;
+    ga.decay = v->cfg.num_qubits_decay;
+    const int64_t d = (int64_t)v->cfg.depth_slope * v->difficulty;  // pauli.rs:578
+    ga.depth_value = (int32_t)std::min<int64_t>(d, v->cfg.max_depth);
+    ga.only_done = only_done ? 1u : 0u;
+    HIP_TRY(ptile_generate(v, ga, s));
+    return QG_OK;
 }
 
 // scatter the per-env records into the tiled layout, upload, run the init kernel

@@ -19,7 +19,7 @@
 #include <string>
 #include <vector>
 
-#include "qgym_host.hpp"
+#include "pauli_common.hpp"
 
 namespace qg {
 
@@ -231,7 +231,7 @@ static int vec_free_buffers(qg_vec *v) {
     void *ptrs[] = {v->state, v->own_depth ? v->depth : nullptr, v->own_reward ? v->reward : nullptr,
                     v->own_done ? v->done : nullptr, v->own_success ? v->success : nullptr, v->inverted, v->error, v->sol,
                     v->sol_len, v->layers, v->d_gates, v->d_descs, v->scratch, v->rot, v->pmeta, v->d_prog,
-                    v->d_qubit_perms, v->d_act_perms, v->perm_idx};
+                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &g : v->graphs) {
@@ -671,8 +671,11 @@ int qg_vec_get_state(qg_vec *v, void *out, int format, size_t stride, int on_dev
 
 static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint64_t seed, hipStream_t s, bool only_done = false) {
     HIP_TRY(hipSetDevice(v->device));
-    if (only_done && v->layout == LAYOUT_PAULI)
-        return set_error(QG_ERR_UNSUPPORTED, "PauliEnv targets are generated on the host: reset the whole batch with qg_vec_reset");
+    if (only_done && v->layout == LAYOUT_PAULI) {
+        if (!v->pauli_tile)
+            return set_error(QG_ERR_UNSUPPORTED, "the lane-group PauliEnv family generates targets on the host: reset the whole batch with qg_vec_reset");
+        return ptile_reset_seeded(v, seed, true, s);
+    }
     if (v->layout == LAYOUT_PAULI) {
         if (actions_dev) return set_error(QG_ERR_UNSUPPORTED, "PauliEnv reset draws a whole target, not `difficulty` actions: use qg_vec_reset(seed) or qg_vec_pauli_reset_from");
         return pauli_reset_seeded(v, seed, s);

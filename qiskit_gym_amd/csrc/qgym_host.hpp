@@ -75,7 +75,9 @@ struct qg_vec {
     uint32_t rmax = 0;
     uint32_t rmax_generate = 0;
     bool pauli_tile = false;     // thread-per-env PTILE family (kernels_pauli_tile.hip)
-    uint32_t pt_nq = 0, pt_rm = 0;  // final_pauli_layers: most rotations reset() generates
+    uint32_t pt_nq = 0, pt_rm = 0;
+    void *d_gen_tables = nullptr;  // PTILE target generator: coupling-graph distance tables
+    uint32_t gen_nd = 0, gen_ncx = 0, gen_off[4] = {0, 0, 0, 0};  // final_pauli_layers: most rotations reset() generates
     uint8_t *d_qubit_perms = nullptr;  // [n_perms][N]  (add_perms)
     int32_t *d_act_perms = nullptr;    // [n_perms][num_actions]
     uint32_t *perm_idx = nullptr;      // [B] current_perm_idx
