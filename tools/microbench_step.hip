@@ -24,12 +24,16 @@ __global__ __launch_bounds__(BLOCK) void variant_kernel(StepArgs a) {
     qm_load<16, true>(tile, lane, s);
     int64_t act = reinterpret_cast<const int32_t *>(a.actions)[env];
     int32_t depth = a.depth[env];
-    if (V >= 3) {  // LDS table
+    if (V == 3) {  // LDS table
         for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) s_gates[i] = a.gates[i];
         __syncthreads();
     }
+    GateEntry *wtab = s_gates + (threadIdx.x >> 6) * 256;
+    if (V == 14) {  // wave-private LDS copy of the table: no block barrier
+        for (uint32_t i = lane; i < a.num_actions; i += 64) wtab[i] = a.gates[i];
+    }
     GateEntry g = {QM_IDENTITY << 10, 0.0f};
-    if (V >= 3) g = s_gates[act]; else if (V >= 2) g = a.gates[act];
+    if (V == 3) g = s_gates[act]; else if (V == 14) g = wtab[act]; else if (V >= 2) g = a.gates[act];
     uint32_t dirty = 0;
     bool solved = false;
     if (V >= 2) {
@@ -79,7 +83,7 @@ template <int V, int BLOCK>
 static float time_variant(const StepArgs &a, int iters, hipStream_t st) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    size_t lds = a.num_actions * sizeof(GateEntry);
+    size_t lds = (V == 14) ? (BLOCK / 64) * 256 * sizeof(GateEntry) : a.num_actions * sizeof(GateEntry);
     for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((variant_kernel<V, BLOCK>), dim3((unsigned)(a.B / BLOCK)), dim3(BLOCK), lds, st, a);
     // capture `iters` back-to-back launches into a graph to remove host launch overhead
     hipGraph_t graph; hipGraphExec_t exec;
@@ -201,6 +205,7 @@ int main(int argc, char **argv) {
     printf("V2 +compute(glob)  block256: %.2f\n", time_variant<2, 256>(a, it, st));
     printf("V4 full            block256: %.2f\n", time_variant<4, 256>(a, it, st));
     g_distinct_actions = false;
+    printf("V14 wave-private LDS table: %.2f\n", time_variant<14, 256>(a, it, st));
     printf("V12 one dirty group block256: %.2f\n", time_variant<12, 256>(a, it, st));
     printf("V13 two dirty groups block256: %.2f\n", time_variant<13, 256>(a, it, st));
     printf("V8 rows sc1        block256: %.2f\n", time_variant<8, 256>(a, it, st));
