@@ -316,7 +316,10 @@ __device__ inline bool qm_check_symplectic(const QmRows<NXP, true> &s, uint32_t 
 // plain instantiation keeps the hot path free of their code and registers.
 // SEQ: several steps per launch (fused rollout) and/or per-step reward/done outputs.
 // INV: add_inverts (CliffordEnv only in this layout).
-template <int NXP, bool HAS_Z, bool FEAT, bool SEQ, bool INV = false>
+// GJ:  with INV, also compile the general Gauss-Jordan inversion (LinearFunctionEnv always; CliffordEnv
+//      only when some env holds a non-symplectic matrix -- its mere presence costs the symplectic fast
+//      path 3.5 us per launch in register pressure and scratch, so the host picks the variant).
+template <int NXP, bool HAS_Z, bool FEAT, bool SEQ, bool INV = false, bool GJ = false>
 __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
     using Rows = QmRows<NXP, HAS_Z>;
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -377,11 +380,15 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
                 if (fast) {
                     iflags ^= QM_FLAG_INVERTED;
                     dirty = 0xFFFFFFFFu;
-                } else if (qm_gauss_jordan<NXP, HAS_Z>(s, a.N)) {
-                    iflags ^= QM_FLAG_INVERTED;
-                    dirty = 0xFFFFFFFFu;
+                } else if constexpr (GJ) {
+                    if (qm_gauss_jordan<NXP, HAS_Z>(s, a.N)) {
+                        iflags ^= QM_FLAG_INVERTED;
+                        dirty = 0xFFFFFFFFu;
+                    } else {
+                        fault |= QG_FAULT_SINGULAR;
+                    }
                 } else {
-                    fault |= QG_FAULT_SINGULAR;
+                    fault |= QG_FAULT_BAD_STATE;  // unreachable: the host launches the GJ variant whenever such an env may exist
                 }
             }
         }
@@ -462,7 +469,10 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
     // arbitrary set_state matrix is checked once, here), so inversions may use the transpose form
     uint32_t symp = 0;
     if constexpr (HAS_Z) {
-        if (a.check_symplectic) symp = (a.mode != 1 || qm_check_symplectic<NXP>(s, a.N)) ? QM_FLAG_SYMPLECTIC : 0u;
+        if (a.check_symplectic) {
+            symp = (a.mode != 1 || qm_check_symplectic<NXP>(s, a.N)) ? QM_FLAG_SYMPLECTIC : 0u;
+            if (!symp && a.nonsymp_flag) atomicOr(a.nonsymp_flag, 1u);
+        }
     }
     a.inverted[env] = (uint8_t)symp;
     a.error[env] = 0;
@@ -526,7 +536,8 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
     const bool feat = a.flags & (F_TRACK | F_LAYERS);
     const bool seq = a.T != 1 || a.rewards_seq || a.dones_seq;
     if (a.flags & F_INVERTS) {  // the inversion variants always carry FEAT and SEQ
-        hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true>), grid, block, 0, s, a);
+        if (!HAS_Z || (a.flags & F_GJ)) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true, false>), grid, block, 0, s, a);
         return hipGetLastError();
     }
     if (feat && seq) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true>), grid, block, 0, s, a);

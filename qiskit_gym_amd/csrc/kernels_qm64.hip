@@ -259,8 +259,9 @@ __device__ __noinline__ bool q64_check_symplectic(const Q64Rows<NS> &s, uint32_t
     return q64_is_inverse<NS>(m, c, N);
 }
 
-// EXTRA: solution log / layer metrics / multi-step; INV: add_inverts (CliffordEnv)
-template <int NS, bool HAS_Z, bool EXTRA, bool INV>
+// EXTRA: solution log / layer metrics / multi-step; INV: add_inverts (CliffordEnv); GJ: also compile
+// the general Gauss-Jordan inversion (needed only when some env holds a non-symplectic matrix)
+template <int NS, bool HAS_Z, bool EXTRA, bool INV, bool GJ = false>
 __global__ __launch_bounds__(256) void q64_step_kernel(StepArgs a) {
     using Rows = Q64Rows<NS>;
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -306,11 +307,15 @@ __global__ __launch_bounds__(256) void q64_step_kernel(StepArgs a) {
                     q64_symplectic_inverse<NS>(s, a.N);
                     iflags ^= Q64_FLAG_INVERTED;
                     dirty = ~0ull;
-                } else if (q64_gauss_jordan<NS>(s, a.N)) {
-                    iflags ^= Q64_FLAG_INVERTED;
-                    dirty = ~0ull;
+                } else if constexpr (GJ) {
+                    if (q64_gauss_jordan<NS>(s, a.N)) {
+                        iflags ^= Q64_FLAG_INVERTED;
+                        dirty = ~0ull;
+                    } else {
+                        fault |= QG_FAULT_SINGULAR;
+                    }
                 } else {
-                    fault |= QG_FAULT_SINGULAR;
+                    fault |= QG_FAULT_BAD_STATE;  // unreachable: see kernels_qm.hip
                 }
             }
         }
@@ -379,7 +384,10 @@ __global__ __launch_bounds__(256) void q64_init_kernel(InitArgs a) {
     for (int g = 0; g < Rows::G; ++g) q64_store_group<NS>(tile, lane, s, g);
     uint32_t symp = 0;
     if constexpr (HAS_Z) {
-        if (a.check_symplectic) symp = (a.mode != 1 || q64_check_symplectic<NS>(s, a.N)) ? Q64_FLAG_SYMPLECTIC : 0u;
+        if (a.check_symplectic) {
+            symp = (a.mode != 1 || q64_check_symplectic<NS>(s, a.N)) ? Q64_FLAG_SYMPLECTIC : 0u;
+            if (!symp && a.nonsymp_flag) atomicOr(a.nonsymp_flag, 1u);
+        }
     }
     a.depth[env] = a.depth_value;  // reset_internals (clifford.rs:272-283)
     a.success[env] = (uint8_t)solved;
@@ -425,7 +433,8 @@ static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
     const bool extra = (a.flags & (F_TRACK | F_LAYERS)) || a.T != 1 || a.rewards_seq || a.dones_seq;
     if constexpr (HAS_Z) {
         if (a.flags & F_INVERTS) {
-            hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, true, true>), grid, block, 0, s, a);
+            if (a.flags & F_GJ) hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, true, true, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, true, true, false>), grid, block, 0, s, a);
             return hipGetLastError();
         }
     }

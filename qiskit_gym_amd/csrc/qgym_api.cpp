@@ -231,7 +231,7 @@ static int vec_free_buffers(qg_vec *v) {
     void *ptrs[] = {v->state, v->own_depth ? v->depth : nullptr, v->own_reward ? v->reward : nullptr,
                     v->own_done ? v->done : nullptr, v->own_success ? v->success : nullptr, v->inverted, v->error, v->sol,
                     v->sol_len, v->layers, v->d_gates, v->d_descs, v->scratch, v->rot, v->pmeta, v->d_prog,
-                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables};
+                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &g : v->graphs) {
@@ -300,7 +300,7 @@ static void fill_step_args(const qg_vec *v, StepArgs &a) {
     a.log2L = v->log2L;
     a.num_actions = (uint32_t)v->gates.size();
     a.T = 1;
-    a.flags = v->flags;
+    a.flags = v->flags | (v->maybe_nonsymplectic ? F_GJ : 0u);
     a.sol_cap = v->sol_cap;
     a.w[0] = v->cfg.w_n_cnots;
     a.w[1] = v->cfg.w_n_layers_cnots;
@@ -609,8 +609,20 @@ int qg_vec_set_state(qg_vec *v, const void *states, int format, size_t stride, i
     ia.src_stride = stride;
     ia.format = (uint32_t)format;
     ia.depth_value = v->cfg.max_depth;  // clifford.rs:302
+    if (ia.check_symplectic) {  // the init kernel reports whether any installed matrix is not symplectic
+        if (!v->d_nonsymp) HIP_TRY(hipMalloc(&v->d_nonsymp, sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(v->d_nonsymp, 0, sizeof(uint32_t), s));
+        ia.nonsymp_flag = v->d_nonsymp;
+    }
     HIP_TRY(launch_init(v, ia, s));
-    if (!on_device) HIP_TRY(hipStreamSynchronize(s));  // the host buffer may be reused by the caller
+    if (ia.check_symplectic) {
+        uint32_t flag = 0;
+        HIP_TRY(hipMemcpyAsync(&flag, v->d_nonsymp, sizeof flag, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        v->maybe_nonsymplectic = flag != 0;  // picks the step-kernel variant with the Gauss-Jordan inversion
+    } else if (!on_device) {
+        HIP_TRY(hipStreamSynchronize(s));  // the host buffer may be reused by the caller
+    }
     return QG_OK;
 }
 
@@ -689,6 +701,7 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
     ia.n_draws = (uint32_t)n_draws;
     ia.seed = seed;
     ia.only_done = only_done ? 1u : 0u;
+    if (!only_done) v->maybe_nonsymplectic = false;  // identity + gates: every env is symplectic again
     int64_t d = (int64_t)v->cfg.depth_slope * v->difficulty;  // clifford.rs:317
     ia.depth_value = (int32_t)std::min<int64_t>(d, v->cfg.max_depth);
     HIP_TRY(launch_init(v, ia, s));

@@ -194,6 +194,7 @@ int qg_env_clone(const qg_env *e, qg_env **out) {  // Env: DynClone -- deep copy
     d->difficulty = s->difficulty;
     d->step_index = s->step_index;
     d->coin_seed = s->coin_seed;
+    d->maybe_nonsymplectic = s->maybe_nonsymplectic;
     struct { void *dst; const void *src; size_t bytes; } copies[] = {
         {d->state, s->state, s->state_bytes},
         {d->depth, s->depth, 4},

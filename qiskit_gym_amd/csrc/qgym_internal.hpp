@@ -55,7 +55,8 @@ enum : uint32_t {
     F_ACT64 = 1u << 0,     // actions are int64
     F_INVERTS = 1u << 1,   // add_inverts (clifford.rs:262-270)
     F_TRACK = 1u << 2,     // track_solution (clifford.rs:334-340)
-    F_LAYERS = 1u << 3     // non-zero n_layers / n_layers_cnots weights: track per-qubit layers
+    F_LAYERS = 1u << 3,    // non-zero n_layers / n_layers_cnots weights: track per-qubit layers
+    F_GJ = 1u << 4         // some env may hold a non-symplectic matrix: compile in the Gauss-Jordan inversion
 };
 
 // counter RNG shared by host, device and the tests
@@ -134,6 +135,7 @@ struct InitArgs {
     uint32_t layers_len;
     uint32_t check_symplectic; // TILE layout with add_inverts: record whether the state is symplectic
     uint32_t only_done;        // reset only the envs whose `done` flag is set (auto-reset between episodes)
+    uint32_t *nonsymp_flag;    // set_state with add_inverts: or-ed to 1 when some env is not symplectic
 };
 
 struct ObsArgs {
