@@ -244,12 +244,20 @@ __device__ __noinline__ bool q64_gauss_jordan(Q64Rows<NS> &s, uint32_t N) {
     q64_from_slot_space<NS>(s, N, v);
     return true;
 }
+// in-place form of Omega M^T Omega for the step kernel: one 64-register work array
 template <int NS>
-__device__ __noinline__ void q64_symplectic_inverse(Q64Rows<NS> &s, uint32_t N) {
-    uint64_t m[64], c[64];
+__device__ inline void q64_symplectic_inverse(Q64Rows<NS> &s, uint32_t N) {
+    constexpr int NQ = NS / 2;
+    uint64_t m[64];
     q64_to_slot_space<NS>(s, N, m);
-    q64_symplectic_candidate<NS>(m, c);
-    q64_from_slot_space<NS>(s, N, c);
+    q64_transpose64(m);
+    const uint64_t rmask = NS == 64 ? ~0ull : ((1ull << NS) - 1ull);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const uint64_t wx = m[i + NQ], wz = m[i];  // slot-space rows (i + NQ) % NS and (i + 2 NQ) % NS
+        s.r[2 * i] = q64_cols_from_slots(((wx >> NQ) | (wx << NQ)) & rmask, N, NQ);
+        s.r[2 * i + 1] = q64_cols_from_slots(((wz >> NQ) | (wz << NQ)) & rmask, N, NQ);
+    }
 }
 template <int NS>
 __device__ __noinline__ bool q64_check_symplectic(const Q64Rows<NS> &s, uint32_t N) {
