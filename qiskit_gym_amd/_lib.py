@@ -93,6 +93,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc"):
+        # a fresh checkout on a ROCm box: build the HIP library in-tree (never a fallback path)
+        import subprocess
+
+        subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], check=False, capture_output=True)
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -12,7 +12,7 @@ from .gateset import (  # noqa: F401
 
 def __getattr__(name):  # lazy: the env classes need the built library only when used
     if name in ("CliffordGym", "LinearFunctionGym", "PermutationGym", "PauliGym", "SYNTH_ENVS", "decode_pauli_solution"):
-        from . import synthesis
+        from . import gyms as synthesis
 
         return getattr(synthesis, name)
     if name == "RawEnv":

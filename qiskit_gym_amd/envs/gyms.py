@@ -16,7 +16,7 @@ from typing import Iterable, List, Tuple
 
 import numpy as np
 
-from .adapters import gym_adapter
+from .frontend import GymFrontEnd
 from .gateset import ONE_Q_GATES, TWO_Q_GATES, gateset_from_coupling_map
 from .raw import RawEnv
 
@@ -33,15 +33,6 @@ def decode_pauli_solution(encoded_solution: List[int]) -> List[Tuple[str, int, i
         else:
             result.append(("gate", val, 0, 0))
     return result
-
-
-def _raw_factory(kind):
-    def make(**kwargs):
-        return RawEnv(kind, kwargs.pop("num_qubits"), kwargs.pop("gateset"), **kwargs)
-
-    make.__name__ = {"clifford": "CliffordEnv", "linear_function": "LinearFunctionEnv", "permutation": "PermutationEnv",
-                     "pauli": "PauliNetworkEnv"}[kind]
-    return make
 
 
 class BaseSynthesisEnv:
@@ -90,7 +81,7 @@ def _tableau_state(x) -> List[int]:
     return np.asarray(x).astype(int).flatten().tolist()
 
 
-class CliffordGym(gym_adapter(_raw_factory("clifford")), BaseSynthesisEnv):
+class CliffordGym(GymFrontEnd, BaseSynthesisEnv):
     cls_name = "CliffordEnv"
     env_kind = "clifford"
     allowed_gates = ONE_Q_GATES + TWO_Q_GATES
@@ -114,7 +105,7 @@ class CliffordGym(gym_adapter(_raw_factory("clifford")), BaseSynthesisEnv):
         return _tableau_state(input)
 
 
-class LinearFunctionGym(gym_adapter(_raw_factory("linear_function")), BaseSynthesisEnv):
+class LinearFunctionGym(GymFrontEnd, BaseSynthesisEnv):
     cls_name = "LinearFunctionEnv"
     env_kind = "linear_function"
     allowed_gates = ["CX", "SWAP"]
@@ -135,7 +126,7 @@ class LinearFunctionGym(gym_adapter(_raw_factory("linear_function")), BaseSynthe
         return _tableau_state(input)
 
 
-class PermutationGym(gym_adapter(_raw_factory("permutation")), BaseSynthesisEnv):
+class PermutationGym(GymFrontEnd, BaseSynthesisEnv):
     cls_name = "PermutationEnv"
     env_kind = "permutation"
     allowed_gates = ["SWAP"]
@@ -147,7 +138,7 @@ class PermutationGym(gym_adapter(_raw_factory("permutation")), BaseSynthesisEnv)
                          track_solution=track_solution)
 
     def get_state(self, input: Iterable[int]):
-        if hasattr(input, "data") and not isinstance(input, np.ndarray):  # QuantumCircuit (envs/synthesis.py:295-303)
+        if hasattr(input, "data") and not isinstance(input, np.ndarray):  # QuantumCircuit (reference envs/synthesis.py:295-303)
             from qiskit.circuit.library.generalized_gates import LinearFunction
 
             input = LinearFunction(input).permutation_pattern()
@@ -156,7 +147,7 @@ class PermutationGym(gym_adapter(_raw_factory("permutation")), BaseSynthesisEnv)
         return np.argsort(np.array(input)).astype(int).tolist()
 
 
-class PauliGym(gym_adapter(_raw_factory("pauli")), BaseSynthesisEnv):
+class PauliGym(GymFrontEnd, BaseSynthesisEnv):
     cls_name = "PauliNetworkEnv"
     env_kind = "pauli"
     allowed_gates = ONE_Q_GATES + TWO_Q_GATES
@@ -170,7 +161,7 @@ class PauliGym(gym_adapter(_raw_factory("pauli")), BaseSynthesisEnv):
                          num_qubits_decay=num_qubits_decay, final_pauli_layers=final_pauli_layers,
                          metrics_weights=metrics_weights, add_perms=add_perms, pauli_layer_reward=pauli_layer_reward,
                          track_solution=track_solution)
-        self._rotation_params = []
+        object.__setattr__(self, "_rotation_params", [])
 
     def get_state(self, input, rotations: List[str] = None):
         """`(tableau, rotations)` -> the set_state wire format
