@@ -21,10 +21,14 @@
 //    bit-planes so one micro-op updates them with three logic ops.  Weight = popc(x|z), front layer
 //    = pred & alive == 0, node order = nibble-packed word (swap_remove order, high to low).
 //
-// Memory (PTILE layout): tiles of 64 envs; a tile is NQ + RM + 1 groups of 1 KiB, group g holding
-// one uint4 per lane: groups 0..NQ-1 = {X row q, Z row q} of qubit q (two uint64), groups
-// NQ..NQ+RM-1 = rotation k {x, z, phase, pred}, last group = {alive, count, order}.  Every wave
-// access is a contiguous 16 B/lane, 1 KiB transaction.
+// Memory (PTILE layout): tiles of 64 envs (one wavefront), every wave access a contiguous block.
+//   wide    (N > 24 or more than 8 rotations): NQ + RM + 1 groups of 1 KiB, one uint4 per lane:
+//           groups 0..NQ-1 = {X row q, Z row q} (two uint64), groups NQ.. = rotation k
+//           {x, z, phase, pred}, last group = {alive, count, order};
+//   compact (N <= 24 and <= 8 rotations, the common case): rows are <= 48 bits, so a qubit's two
+//           rows are 12 bytes {X[0:32), X[32:48) | Z[0:16) << 16, Z[16:48)} (768 B per group,
+//           dwordx3 accesses) and a rotation is 8 bytes {x | pred << 24, z | phase << 24}; N = 20:
+//           320 B per env instead of 464 -- the step is bandwidth-bound, so bytes are time.
 #include <algorithm>
 #include <cstring>
 
@@ -96,27 +100,76 @@ struct PTState {
 };
 
 template <int NQ, int RM>
-__device__ inline void pt_load(const uint4 *tile, uint32_t lane, PTState<NQ, RM> &s) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const uint4 v = tile[q * 64 + lane];
-        s.X[q] = (uint64_t)v.x | ((uint64_t)v.y << 32);
-        s.Z[q] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+struct PTLayout {
+    static constexpr bool COMPACT = NQ <= 24 && RM == 8;
+    static constexpr uint32_t QB = COMPACT ? 768u : 1024u;   // bytes of one qubit group
+    static constexpr uint32_t RB = COMPACT ? 512u : 1024u;   // bytes of one rotation group
+    static constexpr uint32_t TILE_BYTES = NQ * QB + RM * RB + 1024u;
+    static __device__ inline char *tile(void *state, uint64_t env) { return reinterpret_cast<char *>(state) + (env >> 6) * (uint64_t)TILE_BYTES; }
+
+    static __device__ inline void load_qubit(const char *t, uint32_t lane, int q, uint64_t &X, uint64_t &Z) {
+        if constexpr (COMPACT) {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(t + q * QB + lane * 12u);
+            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+            X = (uint64_t)d0 | ((uint64_t)(d1 & 0xFFFFu) << 32);
+            Z = (uint64_t)(d1 >> 16) | ((uint64_t)d2 << 16);
+        } else {
+            const uint4 v = *reinterpret_cast<const uint4 *>(t + q * QB + lane * 16u);
+            X = (uint64_t)v.x | ((uint64_t)v.y << 32);
+            Z = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        }
     }
+    static __device__ inline void store_qubit(char *t, uint32_t lane, int q, uint64_t X, uint64_t Z) {
+        if constexpr (COMPACT) {
+            uint32_t *p = reinterpret_cast<uint32_t *>(t + q * QB + lane * 12u);
+            p[0] = (uint32_t)X;
+            p[1] = ((uint32_t)(X >> 32) & 0xFFFFu) | ((uint32_t)Z << 16);
+            p[2] = (uint32_t)(Z >> 16);
+        } else {
+            *reinterpret_cast<uint4 *>(t + q * QB + lane * 16u) = make_uint4((uint32_t)X, (uint32_t)(X >> 32), (uint32_t)Z, (uint32_t)(Z >> 32));
+        }
+    }
+    static __device__ inline void load_rot(const char *t, uint32_t lane, int k, uint32_t &x, uint32_t &z, uint32_t &ph, uint32_t &pred) {
+        if constexpr (COMPACT) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(t + NQ * QB + k * RB + lane * 8u);
+            x = v.x & 0xFFFFFFu; pred = v.x >> 24; z = v.y & 0xFFFFFFu; ph = (v.y >> 24) & 3u;
+        } else {
+            const uint4 v = *reinterpret_cast<const uint4 *>(t + NQ * QB + k * RB + lane * 16u);
+            x = v.x; z = v.y; ph = v.z & 3u; pred = v.w;
+        }
+    }
+    static __device__ inline void store_rot(char *t, uint32_t lane, int k, uint32_t x, uint32_t z, uint32_t ph, uint32_t pred) {
+        if constexpr (COMPACT) *reinterpret_cast<uint2 *>(t + NQ * QB + k * RB + lane * 8u) = make_uint2(x | (pred << 24), z | (ph << 24));
+        else *reinterpret_cast<uint4 *>(t + NQ * QB + k * RB + lane * 16u) = make_uint4(x, z, ph, pred);
+    }
+    static __device__ inline uint4 *meta(char *t, uint32_t lane) { return reinterpret_cast<uint4 *>(t + NQ * QB + RM * RB + lane * 16u); }
+};
+
+template <int NQ, int RM>
+__device__ inline void pt_load(const char *tile, uint32_t lane, PTState<NQ, RM> &s) {
+    using L = PTLayout<NQ, RM>;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) L::load_qubit(tile, lane, q, s.X[q], s.Z[q]);
     s.plo = s.phi = 0;
 #pragma unroll
     for (int k = 0; k < RM; ++k) {
-        const uint4 v = tile[(NQ + k) * 64 + lane];
-        s.rx[k] = v.x;
-        s.rz[k] = v.y;
-        s.plo |= (v.z & 1u) << k;
-        s.phi |= ((v.z >> 1) & 1u) << k;
-        s.rpred[k] = v.w;
+        uint32_t ph;
+        L::load_rot(tile, lane, k, s.rx[k], s.rz[k], ph, s.rpred[k]);
+        s.plo |= (ph & 1u) << k;
+        s.phi |= ((ph >> 1) & 1u) << k;
     }
-    const uint4 m = tile[(NQ + RM) * 64 + lane];
+    const uint4 m = *L::meta(const_cast<char *>(tile), lane);
     s.alive = m.x;
     s.count = m.y;
     s.order = (uint64_t)m.z | ((uint64_t)m.w << 32);
+}
+template <int NQ, int RM>
+__device__ inline void pt_store_rot(char *tile, uint32_t lane, const PTState<NQ, RM> &s, int k) {
+    PTLayout<NQ, RM>::store_rot(tile, lane, k, s.rx[k], s.rz[k], ((s.plo >> k) & 1u) | (((s.phi >> k) & 1u) << 1), s.rpred[k]);
+}
+template <int NQ, int RM>
+__device__ inline void pt_store_meta(char *tile, uint32_t lane, const PTState<NQ, RM> &s) {
+    *PTLayout<NQ, RM>::meta(tile, lane) = make_uint4(s.alive, s.count, (uint32_t)s.order, (uint32_t)(s.order >> 32));
 }
 
 // the gate's composite tableau map on {X[qa], Z[qa], X[qb], Z[qb]}
@@ -253,8 +306,7 @@ __global__ __launch_bounds__(256) void ptile_step_kernel(PTArgs pa) {
     if (env >= a.B) return;
     const bool act64 = a.flags & F_ACT64;
     const uint32_t N = a.N;
-    constexpr int G = NQ + RM + 1;
-    uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(G * 64);
+    char *tile = PTLayout<NQ, RM>::tile(a.state, env);
 
     int64_t act = load_action(a.actions, env, act64);
     PTState<NQ, RM> s;
@@ -340,14 +392,11 @@ __global__ __launch_bounds__(256) void ptile_step_kernel(PTArgs pa) {
     // were alive when a gate was applied, the DAG bookkeeping
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
-        if ((dirty_q >> q) & 1u)
-            tile[q * 64 + lane] = make_uint4((uint32_t)s.X[q], (uint32_t)(s.X[q] >> 32), (uint32_t)s.Z[q], (uint32_t)(s.Z[q] >> 32));
+        if ((dirty_q >> q) & 1u) PTLayout<NQ, RM>::store_qubit(tile, lane, q, s.X[q], s.Z[q]);
 #pragma unroll
     for (int k = 0; k < RM; ++k)
-        if ((touched_rot >> k) & 1u)
-            tile[(NQ + k) * 64 + lane] = make_uint4(s.rx[k], s.rz[k], ((s.plo >> k) & 1u) | (((s.phi >> k) & 1u) << 1), s.rpred[k]);
-    if (s.alive != alive0 || s.count != count0 || s.order != order0)
-        tile[(NQ + RM) * 64 + lane] = make_uint4(s.alive, s.count, (uint32_t)s.order, (uint32_t)(s.order >> 32));
+        if ((touched_rot >> k) & 1u) pt_store_rot<NQ, RM>(tile, lane, s, k);
+    if (s.alive != alive0 || s.count != count0 || s.order != order0) pt_store_meta<NQ, RM>(tile, lane, s);
     a.depth[env] = depth;
     a.reward[env] = reward;
     a.done[env] = (uint8_t)(depth == 0 || solved);
@@ -364,8 +413,7 @@ __global__ __launch_bounds__(256) void ptile_init_kernel(PTArgs pa) {
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
     if (env >= a.B) return;
-    constexpr int G = NQ + RM + 1;
-    uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(G * 64);
+    char *tile = PTLayout<NQ, RM>::tile(a.state, env);
     PTState<NQ, RM> s;
     pt_load<NQ, RM>(tile, lane, s);
     uint32_t n_removed = 0, fault = 0;
@@ -374,7 +422,7 @@ __global__ __launch_bounds__(256) void ptile_init_kernel(PTArgs pa) {
     for (int i = 0; i < (RM + 7) / 8; ++i) rem_pos[i] = 0;
     if (pa.do_clean) pt_clean<NQ, RM>(s, n_removed, fault, nullptr, rem_pos);
     const bool solved = pt_solved<NQ, RM>(s, a.N);
-    tile[(NQ + RM) * 64 + lane] = make_uint4(s.alive, s.count, (uint32_t)s.order, (uint32_t)(s.order >> 32));
+    pt_store_meta<NQ, RM>(tile, lane, s);
     a.depth[env] = pa.depth_value;
     a.success[env] = (uint8_t)solved;
     a.reward[env] = solved ? 1.0f : 0.0f;
@@ -408,8 +456,10 @@ __global__ __launch_bounds__(256) void ptile_export_kernel(PTObsArgs pa) {
     const uint64_t env = gid / D;
     const uint32_t row = (uint32_t)(gid % D);
     if (env >= a.B) return;
-    const uint32_t cols = a.obs_cols, G = pa.nq + pa.rm + 1, lane = (uint32_t)(env & 63);
-    const uint4 *tile = reinterpret_cast<const uint4 *>(a.state) + (env >> 6) * (uint64_t)(G * 64);
+    const uint32_t cols = a.obs_cols, lane = (uint32_t)(env & 63);
+    const bool compact = pa.nq <= 24 && pa.rm == 8;  // PTLayout::COMPACT
+    const uint32_t QB = compact ? 768u : 1024u, RB = compact ? 512u : 1024u;
+    const char *tile = reinterpret_cast<const char *>(a.state) + (env >> 6) * (uint64_t)(pa.nq * QB + pa.rm * RB + 1024u);
     const uint8_t *perm = nullptr;
     if (pa.n_perms && cols > D && a.format != QG_FMT_PACKED) {
         uint32_t pi;
@@ -424,8 +474,14 @@ __global__ __launch_bounds__(256) void ptile_export_kernel(PTObsArgs pa) {
     }
     const uint32_t q = row < N ? row : row - N;
     const uint32_t sq = perm ? perm[q] : q;  // row i takes data from row perm[i] (pauli.rs:455-464)
-    const uint4 t = tile[sq * 64 + lane];
-    uint64_t w = row < N ? ((uint64_t)t.x | ((uint64_t)t.y << 32)) : ((uint64_t)t.z | ((uint64_t)t.w << 32));
+    uint64_t w;
+    if (compact) {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(tile + sq * QB + lane * 12u);
+        w = row < N ? ((uint64_t)p[0] | ((uint64_t)(p[1] & 0xFFFFu) << 32)) : ((uint64_t)(p[1] >> 16) | ((uint64_t)p[2] << 16));
+    } else {
+        const uint4 t = *reinterpret_cast<const uint4 *>(tile + sq * QB + lane * 16u);
+        w = row < N ? ((uint64_t)t.x | ((uint64_t)t.y << 32)) : ((uint64_t)t.z | ((uint64_t)t.w << 32));
+    }
     if (perm) {  // column i takes data from column perm[i], X and Z halves alike (pauli.rs:469-477)
         uint64_t pw = 0;
         for (uint32_t i = 0; i < N; ++i) {
@@ -441,12 +497,20 @@ __global__ __launch_bounds__(256) void ptile_export_kernel(PTObsArgs pa) {
     // pad_and_collect (pauli.rs:411-437): tableau, then the active rotations in DAG node order
     uint32_t extra = 0;
     if (cols > D) {
-        const uint4 m = tile[(pa.nq + pa.rm) * 64 + lane];
+        const uint4 m = *reinterpret_cast<const uint4 *>(tile + pa.nq * QB + pa.rm * RB + lane * 16u);
         const uint64_t order = (uint64_t)m.z | ((uint64_t)m.w << 32);
         const uint32_t shown = m.y < pa.max_rot ? m.y : pa.max_rot;
         for (uint32_t i = 0; i < shown; ++i) {
-            const uint4 r = tile[(pa.nq + pnib(order, i)) * 64 + lane];
-            const uint32_t bit = row < N ? (r.x >> sq) & 1u : (r.y >> sq) & 1u;
+            const char *rp = tile + pa.nq * QB + pnib(order, i) * RB;
+            uint32_t rx, rz;
+            if (compact) {
+                const uint2 r = *reinterpret_cast<const uint2 *>(rp + lane * 8u);
+                rx = r.x & 0xFFFFFFu; rz = r.y & 0xFFFFFFu;
+            } else {
+                const uint4 r = *reinterpret_cast<const uint4 *>(rp + lane * 16u);
+                rx = r.x; rz = r.y;
+            }
+            const uint32_t bit = row < N ? (rx >> sq) & 1u : (rz >> sq) & 1u;
             extra |= bit << i;
         }
     }
@@ -498,8 +562,7 @@ __global__ __launch_bounds__(256) void ptile_generate_kernel(PTGenArgs ga) {
     if (env >= a.B) return;
     if (ga.only_done && !a.done[env]) return;
     const uint32_t N = a.N;
-    constexpr int G = NQ + RM + 1;
-    uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(G * 64);
+    char *tile = PTLayout<NQ, RM>::tile(a.state, env);
     PTStream rng{ga.seed ^ 0x7061756Cull, env, 0};
     PTState<NQ, RM> s;
 #pragma unroll
@@ -608,12 +671,10 @@ __global__ __launch_bounds__(256) void ptile_generate_kernel(PTGenArgs ga) {
     pt_clean<NQ, RM>(s, n_removed, fault, nullptr, rem_pos);
     const bool solved = pt_solved<NQ, RM>(s, N);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-        tile[q * 64 + lane] = make_uint4((uint32_t)s.X[q], (uint32_t)(s.X[q] >> 32), (uint32_t)s.Z[q], (uint32_t)(s.Z[q] >> 32));
+    for (int q = 0; q < NQ; ++q) PTLayout<NQ, RM>::store_qubit(tile, lane, q, s.X[q], s.Z[q]);
 #pragma unroll
-    for (int k = 0; k < RM; ++k)
-        tile[(NQ + k) * 64 + lane] = make_uint4(s.rx[k], s.rz[k], ((s.plo >> k) & 1u) | (((s.phi >> k) & 1u) << 1), s.rpred[k]);
-    tile[(NQ + RM) * 64 + lane] = make_uint4(s.alive, s.count, (uint32_t)s.order, (uint32_t)(s.order >> 32));
+    for (int k = 0; k < RM; ++k) pt_store_rot<NQ, RM>(tile, lane, s, k);
+    pt_store_meta<NQ, RM>(tile, lane, s);
     a.depth[env] = ga.depth_value;  // pauli.rs:578-585
     a.success[env] = (uint8_t)solved;
     a.reward[env] = solved ? 1.0f : 0.0f;
@@ -646,7 +707,8 @@ int ptile_plan(qg_vec *v) {
     v->pt_nq = (v->N + 3u) & ~3u;
     v->pt_rm = v->rmax <= 8 ? 8u : 16u;
     v->stride_bytes = 0;
-    v->state_bytes = ((v->B + 63) / 64) * (size_t)(v->pt_nq + v->pt_rm + 1) * 1024;
+    const bool compact = v->pt_nq <= 24 && v->pt_rm == 8;  // PTLayout::COMPACT
+    v->state_bytes = ((v->B + 63) / 64) * ((size_t)v->pt_nq * (compact ? 768 : 1024) + (size_t)v->pt_rm * (compact ? 512 : 1024) + 1024);
     return QG_OK;
 }
 
@@ -818,24 +880,36 @@ int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s) 
 
 // scatter the per-env records into the tiled layout, upload, run the init kernel
 int ptile_upload(qg_vec *v, const HostNet &h, bool do_clean, int32_t depth_value, hipStream_t s) {
-    const uint32_t N = v->N, NQ = v->pt_nq, RM = v->pt_rm, G = NQ + RM + 1;
-    std::vector<uint32_t> img(v->state_bytes / 4, 0u);
+    const uint32_t N = v->N, NQ = v->pt_nq, RM = v->pt_rm;
+    const bool compact = NQ <= 24 && RM == 8;  // PTLayout::COMPACT
+    const size_t QB = compact ? 768 : 1024, RB = compact ? 512 : 1024, tile_bytes = NQ * QB + RM * RB + 1024;
+    std::vector<uint8_t> img(v->state_bytes, 0);
     for (uint64_t e = 0; e < v->B; ++e) {
-        uint32_t *tile = img.data() + (e >> 6) * (size_t)G * 256;
+        uint8_t *tile = img.data() + (e >> 6) * tile_bytes;
         const uint32_t lane = (uint32_t)(e & 63);
         for (uint32_t q = 0; q < N; ++q) {
-            uint32_t *g = tile + ((size_t)q * 64 + lane) * 4;
             const uint64_t x = h.tab[(e * N + q) * 2], z = h.tab[(e * N + q) * 2 + 1];
-            g[0] = (uint32_t)x; g[1] = (uint32_t)(x >> 32); g[2] = (uint32_t)z; g[3] = (uint32_t)(z >> 32);
+            if (compact) {
+                uint32_t g[3] = {(uint32_t)x, ((uint32_t)(x >> 32) & 0xFFFFu) | ((uint32_t)z << 16), (uint32_t)(z >> 16)};
+                memcpy(tile + q * QB + lane * 12, g, 12);
+            } else {
+                uint32_t g[4] = {(uint32_t)x, (uint32_t)(x >> 32), (uint32_t)z, (uint32_t)(z >> 32)};
+                memcpy(tile + q * QB + lane * 16, g, 16);
+            }
         }
         for (uint32_t k = 0; k < v->rmax; ++k) {
-            uint32_t *g = tile + ((size_t)(NQ + k) * 64 + lane) * 4;
             const PauliRot &r = h.rot[e * v->rmax + k];
-            g[0] = r.x; g[1] = r.z; g[2] = r.phase; g[3] = r.pred;
+            if (compact) {
+                uint32_t g[2] = {r.x | (r.pred << 24), r.z | (r.phase << 24)};
+                memcpy(tile + NQ * QB + k * RB + lane * 8, g, 8);
+            } else {
+                uint32_t g[4] = {r.x, r.z, r.phase, r.pred};
+                memcpy(tile + NQ * QB + k * RB + lane * 16, g, 16);
+            }
         }
-        uint32_t *g = tile + ((size_t)(NQ + RM) * 64 + lane) * 4;
         const PauliMeta &m = h.meta[e];
-        g[0] = m.alive; g[1] = m.count; g[2] = (uint32_t)m.order; g[3] = (uint32_t)(m.order >> 32);
+        uint32_t g[4] = {m.alive, m.count, (uint32_t)m.order, (uint32_t)(m.order >> 32)};
+        memcpy(tile + NQ * QB + RM * RB + lane * 16, g, 16);
     }
     HIP_TRY(hipMemcpyAsync(v->state, img.data(), v->state_bytes, hipMemcpyHostToDevice, s));
     StepArgs a;
