@@ -201,10 +201,11 @@ __device__ inline void pt_apply_tableau(PTState<NQ, RM> &s, uint32_t qa, uint32_
 //   S(p):    z_p ^= x_p,  phase += x_p
 //   SX(p):   = H,S,H -> x_p ^= z_p, phase += 3*z_p
 //   CNOT(i=p, j=q) = evolve_cx(ctrl=q, tgt=p): x_p ^= x_q ; z_q ^= z_p
+// Returns the mask of rotations whose record changed (most gates miss most rotations' supports).
 template <int NQ, int RM>
-__device__ inline void pt_evolve(PTState<NQ, RM> &s, uint32_t kind, uint32_t p, uint32_t q) {
+__device__ inline uint32_t pt_evolve(PTState<NQ, RM> &s, uint32_t kind, uint32_t p, uint32_t q) {
     const uint32_t isH = kind == M_H, isS = kind == M_S, isSX = kind == M_SX, isCN = kind == M_CNOT;
-    uint32_t inc1 = 0, inc2 = 0;
+    uint32_t inc1 = 0, inc2 = 0, changed = 0;
 #pragma unroll
     for (int k = 0; k < RM; ++k) {
         const uint32_t bxp = (s.rx[k] >> p) & 1u, bzp = (s.rz[k] >> p) & 1u;
@@ -216,10 +217,12 @@ __device__ inline void pt_evolve(PTState<NQ, RM> &s, uint32_t kind, uint32_t p, 
         s.rz[k] ^= (dzp << p) ^ (dzq << q);
         inc1 |= ((isS & bxp) | (isSX & bzp)) << k;
         inc2 |= ((isH & bxp & bzp) | (isSX & bzp)) << k;
+        changed |= (dxp | dzp | dzq) << k;
     }
     const uint32_t carry = s.plo & inc1;  // phases += inc1 + 2*inc2 (mod 4), all rotations at once
     s.plo ^= inc1;
     s.phi ^= carry ^ inc2;
+    return changed | inc1 | inc2;
 }
 
 // clean_and_return_with_phases (pauli_network.rs:139-165).  `log`: solution-log sink or null.
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(256) void ptile_step_kernel(PTArgs pa) {
     int32_t sol_n = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2] : 0;
     const uint32_t alive0 = s.alive, count0 = s.count;
     const uint64_t order0 = s.order;
-    uint32_t touched_rot = 0;   // rotations whose record changed (alive when a gate was applied)
+    uint32_t touched_rot = 0;   // rotations whose record changed while they were alive
     uint32_t dirty_q = 0;       // qubits whose tableau rows changed
     bool solved = false;
     float reward = 0.0f;
@@ -345,16 +348,16 @@ __global__ __launch_bounds__(256) void ptile_step_kernel(PTArgs pa) {
             log = a.sol + env * a.sol_cap + (uint32_t)sol_n + 1u;  // slot sol_n is the gate itself
 
         if (in_range) {
+            const uint32_t alive_at_gate = s.alive;
             pt_apply_tableau<NQ, RM>(s, qa, qb, m);
             dirty_q |= (1u << qa) | (1u << qb);
-            touched_rot |= s.alive;
 #pragma unroll 1
             for (uint32_t k = 0; k < 3; ++k) {  // PauliNetwork::act (pauli_network.rs:225-260)
                 const uint32_t mo = (uint32_t)(prog >> (26 + 4 * k)) & 15u;
                 const uint32_t kind = mo & 7u;
                 if (kind == M_NOP) continue;
                 const uint32_t p = (mo & 8u) ? qb : qa, q = (mo & 8u) ? qa : qb;
-                pt_evolve<NQ, RM>(s, kind, p, q);
+                touched_rot |= pt_evolve<NQ, RM>(s, kind, p, q) & alive_at_gate;  // dead rotations are never read again
                 if (kind == M_CNOT) pt_clean<NQ, RM>(s, n_removed, fault, log, rem_pos);
             }
         }
