@@ -95,12 +95,37 @@ def cpu_baseline(gateset, seed: int, budget_s: float = 12.0):
     }
 
 
+def parity_replay(gateset, seed, ids, ring_actions, trace, snap):
+    """Replay the run the GPU just did -- same seed, same scramble draws, same action buffers in the
+    same order -- on the CPU oracle for the sampled envs, and compare everything env.step() produces
+    (reward bits, success, is_final, depth, dense observation) after the last timed step."""
+    from oracle import OracleEnv, OracleVec
+    from util import f32_bits, rng_actions
+
+    proto = OracleEnv("clifford", NUM_QUBITS, gateset, add_inverts=0, add_perms=0, track_solution=0, difficulty=SCRAMBLE)
+    ov = OracleVec(proto, len(ids))
+    ov.reset_with(rng_actions(seed, ids, SCRAMBLE, len(gateset)))
+    r = s = f = d = None
+    for ring_idx in trace:
+        r, s, f, d = ov.step(ring_actions[ring_idx])
+    ok = {
+        "reward_bits": bool(np.array_equal(f32_bits(snap["reward"]), f32_bits(r))),
+        "success": bool(np.array_equal(snap["success"], s)),
+        "is_final": bool(np.array_equal(snap["done"], f)),
+        "depth": bool(np.array_equal(snap["depth"], d)),
+        "observation": bool(np.array_equal(snap["obs"].reshape(len(ids), -1), ov.observe_dense())),
+    }
+    return {"envs": int(len(ids)), "steps_replayed": len(trace), "checked": sorted(ok), "bit_exact": all(ok.values()),
+            "mismatch": [k for k, v in ok.items() if not v]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2048)
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the CPU-oracle replay of the timed run")
     ap.add_argument("--no-gather", action="store_true", help="N>1 diagnostics: skip the per-step all-gather")
     ap.add_argument("--gather-every", type=int, default=CHUNK,
                     help="N>1: all-gather the packed observation every this many steps (1 = after every step)")
@@ -142,14 +167,18 @@ def main():
     gen.manual_seed(seed)
     actions = torch.randint(0, A, (RING, B), dtype=torch.int32, device=dev, generator=gen)
 
+    ring_trace = []  # which action buffer every step since the last reset used (for the oracle replay)
+
     def run_steps_single(nsteps: int):
         """nsteps env.step() launches: whole chunks replay a cached hipGraph of CHUNK launches."""
         done = 0
         while nsteps - done >= CHUNK:
             env.rollout_ring(actions, CHUNK)
+            ring_trace.extend(i % RING for i in range(CHUNK))
             done += CHUNK
         for t in range(nsteps - done):
             env.step(actions[t % RING])
+            ring_trace.append(t % RING)
 
     # ---- multi-GPU: step + all-gather of the packed observation, double buffered -------------
     if multi:
@@ -178,9 +207,11 @@ def main():
                 n = min(G, nsteps - done)
                 if n >= 8:
                     env.rollout_ring(actions, n)  # cached hipGraph of n single-step launches
+                    ring_trace.extend(i % RING for i in range(n))
                 else:
                     for t in range(n):
                         env.step(actions[(done + t) % RING])
+                        ring_trace.append((done + t) % RING)
                 done += n
                 if not args.no_gather and n == G:
                     gather_now(n_gathers & 1)
@@ -197,6 +228,7 @@ def main():
                 e.record(stream)
         run_steps(CHUNK)  # builds and caches the rollout graph (setup, not a step)
         env.reset(seed)
+        ring_trace.clear()
         run_steps(W)  # untimed warmup steps
     torch.cuda.synchronize()
     if dist is not None:
@@ -217,6 +249,22 @@ def main():
         elapsed = float(tt.item())
     env.sync()  # raises if any env faulted
     stream_ms = ev0.elapsed_time(ev1)
+
+    # ---- snapshot of a sample of envs right after the timed steps, for the oracle replay -------
+    snap = None
+    if rank == 0 and not args.no_parity:
+        ids = np.arange(0, B, 64)
+        idx = torch.as_tensor(ids, device=dev)
+        with torch.cuda.stream(stream):
+            snap = {
+                "obs": env.observe()[idx].cpu().numpy(),
+                "reward": env.reward[idx].cpu().numpy(),
+                "success": env.success[idx].cpu().numpy(),
+                "done": env.done[idx].cpu().numpy(),
+                "depth": env.depth[idx].cpu().numpy(),
+            }
+        snap_trace = list(ring_trace)
+        snap_actions = actions[:, idx].cpu().numpy()
 
     # ---- roofline leg: duration of the step kernel itself, HIP events around single launches --
     reps = 200
@@ -264,6 +312,11 @@ def main():
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(gateset, seed)
+        parity = None
+        if snap is not None:
+            parity = parity_replay(gateset, seed, ids, snap_actions, snap_trace, snap)
+            if not parity["bit_exact"]:
+                raise SystemExit(f"bench.py: GPU run differs from the CPU oracle replay: {parity}")
         total_steps = B * K * n_gpus
         out = {
             "metric": "env-steps/sec (whole node), CliffordGym 16q x 65536 envs/GPU; bit-exact vs CPU",
@@ -304,6 +357,7 @@ def main():
                 "launch_us_back_to_back": b2b_us,
             },
             "cpu_baseline": cpu,
+            "parity": parity,
             "fused_rollout": fused,
         }
         print(json.dumps(out), flush=True)

@@ -221,6 +221,37 @@ int qg_vec_sync(qg_vec *v, void *stream);
 int64_t qg_vec_solution(qg_vec *v, uint64_t env, uint64_t *out, size_t cap);
 
 /* ------------------------------------------------------------------------------------------
+ * Collector support: the device-side steps between observe() and step() when a policy network
+ * is in the loop.  The reference runs these on the CPU inside twisterl's collector
+ * (rl/synthesis.py:128-138; collecting parameters gamma / lambda, rl/configs.py:134-144,219-220).
+ * The free functions work on the calling thread's current HIP device.
+ * ---------------------------------------------------------------------------------------- */
+typedef enum { QG_DT_I8 = 0, QG_DT_F32 = 1, QG_DT_BF16 = 2, QG_DT_F16 = 3 } qg_dtype;
+
+/* Env::observe densified (adapters.py:50-54) straight into the dtype the policy network reads:
+ * out_dev[e * obs_rows*obs_cols + r*obs_cols + c] in {0, 1} as `out_dtype`. */
+int qg_vec_observe_dense_as(qg_vec *v, void *out_dev, int out_dtype, void *stream);
+/* Dense {0,1} tensor from QG_FMT_PACKED rows (e.g. the gathered observation of other ranks, or
+ * the packed observations a rollout buffer keeps): n_rows words of `word_bytes` (4 / 8: bit c =
+ * column c; 1: PermutationEnv, the byte is the set column) -> out_dev[row * cols + c]. */
+int qg_expand_packed(const void *packed_dev, int word_bytes, uint64_t n_rows, uint32_t cols, void *out_dev, int out_dtype, void *stream);
+/* One categorical draw per env from softmax(logits[e, 0:num_actions]) by Gumbel-max on the counter
+ * RNG: key[a] = logit[a] - log(-log(u)), u = ((rng(seed ^ 0x73616D70, e, counter*num_actions + a)
+ * >> 41) + 0.5) * 2^-23, action = argmax key.  logits_dev: [batch, ld] of `logits_dtype` (f32 / bf16
+ * / f16), ld >= num_actions.  mask_dev: [batch, num_actions] (1 = allowed; Env::masks) or NULL.
+ * Outputs (each may be NULL except actions): action, log-prob of it, entropy of the row, and
+ * values_dev[e] = logits[e, value_col] (value_col >= 0: a value head fused into the same GEMM). */
+int qg_sample_actions(const void *logits_dev, int logits_dtype, uint64_t ld, uint64_t batch, uint32_t num_actions, const uint8_t *mask_dev,
+                      uint64_t seed, uint64_t counter, void *actions_dev, int action_dtype, float *logp_dev, float *entropy_dev,
+                      int32_t value_col, float *values_dev, void *stream);
+/* Generalised advantage estimation over a [n_steps, batch] rollout (f32, done_t = the episode ended
+ * with step t): delta_t = r_t + gamma*V_{t+1}*(1-done_t) - V_t, A_t = delta_t +
+ * gamma*lambda*(1-done_t)*A_{t+1}, returns = A + V.  last_values_dev: V after the last step
+ * (NULL = 0); returns_dev may be NULL. */
+int qg_gae(const float *rewards_dev, const float *values_dev, const uint8_t *dones_dev, const float *last_values_dev, float gamma,
+           float gae_lambda, size_t n_steps, uint64_t batch, float *advantages_dev, float *returns_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Scalar environment: the `Env` trait method for method (clifford.rs:285-382).
  * Every call synchronises; this flavour exists for API parity, not for speed.
  * ---------------------------------------------------------------------------------------- */

@@ -1,10 +1,17 @@
-"""GPU-resident rollout collection: policy forward, masked sampling, env.step and auto-reset all
-stay on the device.
+"""GPU-resident rollout collection: observation, policy forward, sampling, env.step, auto-reset and
+advantage estimation all stay on the device.
 
 The reference collects episodes inside twisterl: rayon workers clone the scalar env per episode and
 run a Rust copy of the policy on the CPU (`rl/synthesis.py:128-138`, notebook timing keys `collect`,
-`data_to_torch`).  With the env batch resident in HBM the same loop is a handful of stream-ordered
-launches per step and the trajectories are born as torch tensors -- there is no `data_to_torch`.
+`data_to_torch`).  With the env batch resident in HBM one collection step is
+
+    reset_done -> observe (bits -> policy dtype) -> 3 GEMMs -> sample -> step
+
+i.e. five libqgym launches plus the policy's GEMMs, and the trajectories are born as torch tensors --
+there is no `data_to_torch`.  The observation is written straight in the dtype the first layer
+reads (`qg_vec_observe_dense_as`), actions / log-probs / entropy / values come out of one sampling
+kernel (`qg_sample_actions`), rewards and episode ends are written by the step kernel into row t of
+the rollout, and GAE(lambda) runs as one kernel over the finished [T, B] rollout (`qg_gae`).
 
 `BasicPolicy` mirrors the shape of the reference's default policy network (`twisterl.nn.BasicPolicy`
 as configured by `BasicPolicyConfig`, `rl/configs.py:531-607`; checkpoint shapes in
@@ -14,12 +21,67 @@ as configured by `BasicPolicyConfig`, `rl/configs.py:531-607`; checkpoint shapes
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 import torch.nn as nn
 
-from .vec import VecEnv
+from . import _lib
+from .vec import VecEnv, _stream_ptr
+
+_DT = {torch.float32: _lib.QG_DT_F32, torch.bfloat16: _lib.QG_DT_BF16, torch.float16: _lib.QG_DT_F16, torch.int8: _lib.QG_DT_I8}
+
+
+def sample_actions(logits: torch.Tensor, seed: int, counter: int, num_actions: Optional[int] = None, mask: Optional[torch.Tensor] = None,
+                   value_col: Optional[int] = None, actions: Optional[torch.Tensor] = None, logp: Optional[torch.Tensor] = None,
+                   entropy: Optional[torch.Tensor] = None, values: Optional[torch.Tensor] = None):
+    """One categorical draw per row of `logits[:, :num_actions]` (f32 / bf16 / f16, row stride free).
+    Returns (actions int64, logp f32, entropy f32, values f32 or None); see `qg_sample_actions`."""
+    if logits.dim() != 2 or logits.stride(1) != 1:
+        raise ValueError("logits must be [B, >=num_actions] with unit column stride")
+    B, dev = logits.shape[0], logits.device
+    A = int(num_actions) if num_actions is not None else logits.shape[1]
+    actions = torch.empty(B, dtype=torch.int64, device=dev) if actions is None else actions
+    logp = torch.empty(B, dtype=torch.float32, device=dev) if logp is None else logp
+    entropy = torch.empty(B, dtype=torch.float32, device=dev) if entropy is None else entropy
+    if value_col is not None and values is None:
+        values = torch.empty(B, dtype=torch.float32, device=dev)
+    if mask is not None:
+        mask = mask.to(torch.uint8).contiguous()
+    act_dt = {torch.int32: _lib.ACT_I32, torch.int64: _lib.ACT_I64}[actions.dtype]
+    L = _lib.load()
+    _lib.check(L.qg_sample_actions(
+        logits.data_ptr(), _DT[logits.dtype], logits.stride(0), B, A, mask.data_ptr() if mask is not None else None,
+        int(seed) & (2**64 - 1), int(counter), actions.data_ptr(), act_dt, logp.data_ptr(), entropy.data_ptr(),
+        -1 if value_col is None else int(value_col), values.data_ptr() if value_col is not None else None, _stream_ptr()))
+    return actions, logp, entropy, values
+
+
+def gae(rewards: torch.Tensor, values: torch.Tensor, dones: torch.Tensor, last_values: Optional[torch.Tensor], gamma: float,
+        gae_lambda: float, advantages: Optional[torch.Tensor] = None, returns: Optional[torch.Tensor] = None):
+    """GAE(lambda) over a [T, B] rollout; `dones[t]` = the episode ended with step t.  Returns (advantages, returns)."""
+    T, B = rewards.shape
+    for x, dt in ((rewards, torch.float32), (values, torch.float32), (dones, torch.uint8)):
+        if x.shape != (T, B) or x.dtype != dt or not x.is_contiguous():
+            raise ValueError("gae: rewards/values must be contiguous f32 [T, B], dones uint8 [T, B]")
+    advantages = torch.empty_like(rewards) if advantages is None else advantages
+    returns = torch.empty_like(rewards) if returns is None else returns
+    lv = None
+    if last_values is not None:
+        lv = last_values.to(torch.float32).contiguous()
+    _lib.check(_lib.load().qg_gae(rewards.data_ptr(), values.data_ptr(), dones.data_ptr(), lv.data_ptr() if lv is not None else None,
+                                  float(gamma), float(gae_lambda), T, B, advantages.data_ptr(), returns.data_ptr(), _stream_ptr()))
+    return advantages, returns
+
+
+def expand_packed(packed: torch.Tensor, cols: int, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Bit-packed observation rows (`VecEnv.observe_packed`, any leading shape) -> dense {0,1} [..., rows, cols] in `dtype`."""
+    packed = packed.contiguous()
+    if out is None:
+        out = torch.empty((*packed.shape, cols), dtype=dtype, device=packed.device)
+    _lib.check(_lib.load().qg_expand_packed(packed.data_ptr(), packed.element_size(), packed.numel(), int(cols), out.data_ptr(), _DT[dtype],
+                                            _stream_ptr()))
+    return out
 
 
 class BasicPolicy(nn.Module):
@@ -35,56 +97,145 @@ class BasicPolicy(nn.Module):
         h = torch.relu(self.common(h))
         return self.policy_head(h), self.value_head(h).squeeze(-1)
 
+    @torch.no_grad()
+    def fused_heads(self) -> Tuple[torch.Tensor, torch.Tensor, int]:
+        """Policy and value heads as ONE weight [pad8(A + 1), common] / bias, so a collection step runs
+        three GEMMs; column A of the output is the value.  Rebuild after every optimiser step."""
+        A = self.policy_head.out_features
+        rows = (A + 1 + 7) // 8 * 8
+        w = torch.zeros((rows, self.common.out_features), dtype=self.policy_head.weight.dtype, device=self.policy_head.weight.device)
+        b = torch.zeros(rows, dtype=w.dtype, device=w.device)
+        w[:A], w[A] = self.policy_head.weight, self.value_head.weight[0]
+        b[:A], b[A] = self.policy_head.bias, self.value_head.bias[0]
+        return w, b, A
+
+
+def _linear_relu(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    try:  # bias + ReLU in the GEMM epilogue (hipBLASLt)
+        return torch._addmm_activation(b, x, w.t())
+    except Exception:  # pragma: no cover - older torch
+        return torch.relu_(torch.addmm(b, x, w.t()))
+
 
 @dataclass
 class Rollout:
-    obs: torch.Tensor       # [T, B, rows*cols] int8 (dense observation before each action)
-    actions: torch.Tensor   # [T, B] int64
-    logp: torch.Tensor      # [T, B] float32
-    values: torch.Tensor    # [T, B] float32
-    rewards: torch.Tensor   # [T, B] float32
-    dones: torch.Tensor     # [T, B] uint8 (episode ended with this step)
+    obs: torch.Tensor         # [T, B, rows*cols] int8 dense observation before each action, or
+                              # [T, B, words] bit-packed rows when the collector stores packed observations
+    actions: torch.Tensor     # [T, B] int64
+    logp: torch.Tensor        # [T, B] float32 log-prob of the action under the collecting policy
+    entropy: torch.Tensor     # [T, B] float32
+    values: torch.Tensor      # [T, B] float32
+    rewards: torch.Tensor     # [T, B] float32
+    dones: torch.Tensor       # [T, B] uint8 (episode ended with this step)
+    advantages: torch.Tensor  # [T, B] float32 GAE(lambda)
+    returns: torch.Tensor     # [T, B] float32 advantages + values
+    last_values: Optional[torch.Tensor] = None  # [B] float32 value of the state after the last step (GAE bootstrap)
+    obs_packed: bool = False
+    obs_cols: int = 0
+
+    def dense_obs(self, dtype: torch.dtype = torch.float32, t: Optional[slice] = None) -> torch.Tensor:
+        """[T', B, rows*cols] dense observation in `dtype` (re-expanded from the packed rows when stored packed)."""
+        o = self.obs if t is None else self.obs[t]
+        if not self.obs_packed:
+            return o.to(dtype)
+        return expand_packed(o, self.obs_cols, dtype).flatten(-2)
 
 
 class RolloutCollector:
-    """Steps `env` for T steps under `policy`, resetting finished episodes on the device."""
+    """Steps `env` for T steps under `policy`, resetting finished episodes on the device.
 
-    def __init__(self, env: VecEnv, policy: nn.Module, dtype: torch.dtype = torch.bfloat16, seed: int = 0):
+    store_obs: "dense" keeps the int8 observation of every step (the Gym adapter's format);
+    "packed" keeps the bit-packed rows (8x smaller for CliffordGym; `Rollout.dense_obs` expands them
+    on demand; not available for PauliGym, whose observation has no packed form)."""
+
+    def __init__(self, env: VecEnv, policy: nn.Module, dtype: torch.dtype = torch.bfloat16, seed: int = 0, gamma: float = 0.995,
+                 gae_lambda: float = 0.995, store_obs: str = "dense"):
         self.env = env
         self.policy = policy.to(device=env.device, dtype=dtype)
         self.dtype = dtype
         self.seed = int(seed)
+        self.gamma, self.gae_lambda = float(gamma), float(gae_lambda)  # rl/configs.py:136-137
         self.steps_done = 0
         r, c = env.obs_shape_
         self.obs_size = r * c
-        self._gen = torch.Generator(device=env.device)
-        self._gen.manual_seed(self.seed)
+        if store_obs not in ("dense", "packed"):
+            raise ValueError("store_obs must be 'dense' or 'packed'")
+        if store_obs == "packed" and env.env_kind == "pauli":
+            raise ValueError("PauliGym observations have no packed form")
+        self.store_obs = store_obs
+        self._x = torch.empty((env.batch, self.obs_size), dtype=dtype, device=env.device)  # policy input
+
+    def _alloc(self, T: int) -> Rollout:
+        env, B, dev = self.env, self.env.batch, self.env.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        if self.store_obs == "packed":
+            dt = {1: torch.uint8, 4: torch.int32, 8: torch.int64}[env.packed_word_bytes]
+            obs = torch.empty((T, B, env.packed_words_per_env), dtype=dt, device=dev)
+        else:
+            obs = torch.empty((T, B, self.obs_size), dtype=torch.int8, device=dev)
+        return Rollout(obs=obs, actions=torch.empty((T, B), dtype=torch.int64, device=dev), logp=torch.empty((T, B), **f32),
+                       entropy=torch.empty((T, B), **f32), values=torch.empty((T, B), **f32), rewards=torch.empty((T, B), **f32),
+                       dones=torch.empty((T, B), dtype=torch.uint8, device=dev), advantages=torch.empty((T, B), **f32),
+                       returns=torch.empty((T, B), **f32), obs_packed=self.store_obs == "packed", obs_cols=env.obs_shape_[1])
+
+    def _observe(self, ro: Rollout, t: int):
+        """Observation of the current state into row t of the rollout and, as `dtype`, into the policy input."""
+        env = self.env
+        if ro.obs_packed:
+            env.observe_packed(out=ro.obs[t])
+            expand_packed(ro.obs[t], ro.obs_cols, self.dtype, out=self._x)
+        else:
+            env.observe(out=ro.obs[t].view(env.batch, *env.obs_shape_))
+            if env.env_kind == "pauli":
+                # PauliEnv.observe() with add_perms draws a permutation (pauli.rs:657-662): observe once
+                self._x.copy_(ro.obs[t])
+            else:
+                env.observe_as(self.dtype, out=self._x)
+
+    def _forward_sample(self, heads, ro: Rollout, t: int, counter: int):
+        pol = self.policy
+        if heads is not None:
+            w, b, A = heads
+            h = _linear_relu(self._x, pol.embeddings.weight, pol.embeddings.bias)
+            h = _linear_relu(h, pol.common.weight, pol.common.bias)
+            out = torch.addmm(b, h, w.t())
+            sample_actions(out, self.seed, counter, num_actions=A, value_col=A, actions=ro.actions[t], logp=ro.logp[t],
+                           entropy=ro.entropy[t], values=ro.values[t])
+            return
+        logits, value = pol(self._x)
+        sample_actions(logits.contiguous(), self.seed, counter, actions=ro.actions[t], logp=ro.logp[t], entropy=ro.entropy[t])
+        ro.values[t].copy_(value)
+
+    def _value_of_current_state(self, heads) -> torch.Tensor:
+        env, pol = self.env, self.policy
+        if env.env_kind == "pauli":
+            raise RuntimeError("unreachable")
+        env.observe_as(self.dtype, out=self._x)
+        if heads is not None:
+            w, b, A = heads
+            h = _linear_relu(self._x, pol.embeddings.weight, pol.embeddings.bias)
+            h = _linear_relu(h, pol.common.weight, pol.common.bias)
+            return torch.addmm(b, h, w.t())[:, A].float()
+        return pol(self._x)[1].float()
 
     @torch.no_grad()
     def collect(self, T: int, out: Optional[Rollout] = None) -> Rollout:
-        env, B, dev = self.env, self.env.batch, self.env.device
-        if out is None:
-            out = Rollout(
-                obs=torch.empty((T, B, self.obs_size), dtype=torch.int8, device=dev),
-                actions=torch.empty((T, B), dtype=torch.int64, device=dev),
-                logp=torch.empty((T, B), dtype=torch.float32, device=dev),
-                values=torch.empty((T, B), dtype=torch.float32, device=dev),
-                rewards=torch.empty((T, B), dtype=torch.float32, device=dev),
-                dones=torch.empty((T, B), dtype=torch.uint8, device=dev),
-            )
+        env = self.env
+        ro = self._alloc(T) if out is None else out
+        heads = self.policy.fused_heads() if isinstance(self.policy, BasicPolicy) else None
         for t in range(T):
             # finished episodes start over (reference: the collector calls reset() on a fresh clone)
             env.reset_done(self.seed + 0x9E3779B9 * (self.steps_done + 1))
-            env.observe(out=out.obs[t].view(B, *env.obs_shape_))
-            logits, value = self.policy(out.obs[t].to(self.dtype))
-            logp_all = torch.log_softmax(logits.float(), dim=-1)
-            # masks() is all-true for a live env (clifford.rs:349-351), so sampling needs no masking
-            act = torch.multinomial(logp_all.exp(), 1, generator=self._gen).squeeze(1)
-            out.actions[t] = act
-            out.logp[t] = logp_all.gather(1, act.unsqueeze(1)).squeeze(1)
-            out.values[t] = value.float()
-            env.step(act)
-            out.rewards[t].copy_(env.reward)
-            out.dones[t].copy_(env.done)
+            self._observe(ro, t)
+            # masks() is all-true for a live env (clifford.rs:349-351), so sampling needs no mask
+            self._forward_sample(heads, ro, t, self.steps_done)
+            env.rollout(ro.actions[t : t + 1], rewards_out=ro.rewards[t : t + 1], dones_out=ro.dones[t : t + 1])
             self.steps_done += 1
-        return out
+        # bootstrap value of the state after the last step (masked by `dones` where the episode ended)
+        if env.env_kind == "pauli":
+            last_v = None  # observing would draw a permutation; episodes are short, bootstrap with 0
+        else:
+            last_v = self._value_of_current_state(heads)
+        ro.last_values = last_v
+        gae(ro.rewards, ro.values, ro.dones, last_v, self.gamma, self.gae_lambda, advantages=ro.advantages, returns=ro.returns)
+        return ro

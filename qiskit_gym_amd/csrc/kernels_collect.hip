@@ -1,0 +1,369 @@
+// kernels_collect.hip -- the device side of a GPU-resident rollout collector, i.e. what sits
+// between env.observe() and env.step() when a policy is in the loop:
+//
+//   qg_expand_packed / qg_vec_observe_dense_as   bit-packed observation -> dense {0,1} tensor in the
+//                                                dtype the policy network eats (bf16/f16/f32/int8)
+//   qg_sample_actions                            logits -> action, log-prob, entropy, value copy
+//   qg_gae                                       generalised advantage estimation over [T, B]
+//
+// The reference does all of this on the CPU inside twisterl (`collect`, `data_to_torch`;
+// rl/synthesis.py:128-138, collecting parameters rl/configs.py:134-144).  These are streaming
+// kernels: expand is write-bound (B*obs*sizeof(dtype) bytes), the other two read their inputs once.
+#include <hip/hip_fp16.h>
+
+#include "qgym_host.hpp"
+
+namespace qg {
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            (void)hipGetLastError();                                                               \
+            return set_error(QG_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(_e));        \
+        }                                                                                          \
+    } while (0)
+
+static inline unsigned blocks_for(uint64_t threads, unsigned block) { return (unsigned)((threads + block - 1) / block); }
+
+// ---------------------------------------------------------------------------------------------
+// expand: one thread produces one 16-byte chunk of the dense output (EPC elements of one row), so
+// every store instruction of a wave writes 1 KiB contiguously.  The packed input is 8x..64x
+// smaller than the output and is read through the cache (neighbouring threads share a word).
+// ---------------------------------------------------------------------------------------------
+// `one`: the bit pattern of 1 in the output dtype (int8 1, bf16 0x3F80, f16 0x3C00, f32 0x3F800000)
+template <int ES>
+__device__ inline uint4 expand_chunk(uint32_t bits, uint32_t one) {
+    uint32_t w[4];
+    if constexpr (ES == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t nb = (bits >> (4 * k)) & 0xFu;
+            w[k] = ((nb & 1u) | ((nb & 2u) << 7) | ((nb & 4u) << 14) | ((nb & 8u) << 21)) * one;
+        }
+    } else if constexpr (ES == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = (bits >> (2 * k)) & 1u, hi = (bits >> (2 * k + 1)) & 1u;
+            w[k] = (lo * one) | ((hi * one) << 16);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = ((bits >> k) & 1u) * one;
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// word_bytes: 4 / 8 = bit rows (bit c = column c); 1 = PermutationEnv rows (byte = the column that is set)
+template <int ES>
+__global__ __launch_bounds__(256) void expand_chunks_kernel(const void *packed, int word_bytes, uint64_t n_rows, uint32_t cols,
+                                                            uint32_t chunks_per_row, uint4 *out, uint32_t one) {
+    constexpr uint32_t EPC = 16 / ES;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t row = gid / chunks_per_row;
+    if (row >= n_rows) return;
+    const uint32_t c0 = (uint32_t)(gid - row * chunks_per_row) * EPC;
+    uint32_t bits;
+    if (word_bytes == 8) bits = (uint32_t)(reinterpret_cast<const uint64_t *>(packed)[row] >> c0);
+    else if (word_bytes == 4) bits = reinterpret_cast<const uint32_t *>(packed)[row] >> c0;
+    else {
+        const uint32_t col = reinterpret_cast<const uint8_t *>(packed)[row];
+        bits = (col >= c0 && col < c0 + EPC) ? 1u << (col - c0) : 0u;
+    }
+    out[gid] = expand_chunk<ES>(bits & ((1u << EPC) - 1u), one);
+}
+
+// any shape / alignment: one thread per element
+template <typename T>
+__global__ __launch_bounds__(256) void expand_elems_kernel(const void *packed, int word_bytes, uint64_t n_rows, uint32_t cols, T *out,
+                                                           T one) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t row = gid / cols;
+    if (row >= n_rows) return;
+    const uint32_t c = (uint32_t)(gid - row * cols);
+    bool bit;
+    if (word_bytes == 8) bit = (reinterpret_cast<const uint64_t *>(packed)[row] >> c) & 1u;
+    else if (word_bytes == 4) bit = (reinterpret_cast<const uint32_t *>(packed)[row] >> c) & 1u;
+    else bit = reinterpret_cast<const uint8_t *>(packed)[row] == c;
+    out[gid] = bit ? one : (T)0;
+}
+
+// dense int8 {0,1} -> dense dtype (PauliEnv, whose observation has no packed form): 16 input
+// bytes per thread
+template <int ES>
+__global__ __launch_bounds__(256) void widen01_kernel(const uint8_t *in, uint64_t n, void *out, uint32_t one) {
+    const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16ull;
+    if (i0 >= n) return;
+    if (i0 + 16 <= n && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(in + i0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t bits = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) bits |= ((w[k >> 2] >> (8 * (k & 3))) & 1u) << k;
+        uint4 *o = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(out) + i0 * ES);
+        constexpr uint32_t EPC = 16 / ES;
+#pragma unroll
+        for (uint32_t c = 0; c < (uint32_t)ES; ++c) o[c] = expand_chunk<ES>((bits >> (c * EPC)) & ((1u << EPC) - 1u), one);
+        return;
+    }
+    for (uint64_t i = i0; i < n && i < i0 + 16; ++i) {
+        const uint32_t b = in[i] & 1u;
+        if constexpr (ES == 1) reinterpret_cast<uint8_t *>(out)[i] = (uint8_t)(b * one);
+        else if constexpr (ES == 2) reinterpret_cast<uint16_t *>(out)[i] = (uint16_t)(b * one);
+        else reinterpret_cast<uint32_t *>(out)[i] = b * one;
+    }
+}
+
+static bool dtype_info(int dtype, uint32_t &elem_size, uint32_t &one) {
+    switch (dtype) {
+    case QG_DT_I8: elem_size = 1; one = 1u; return true;
+    case QG_DT_BF16: elem_size = 2; one = 0x3F80u; return true;
+    case QG_DT_F16: elem_size = 2; one = 0x3C00u; return true;
+    case QG_DT_F32: elem_size = 4; one = 0x3F800000u; return true;
+    }
+    return false;
+}
+
+static int expand_packed_impl(const void *packed_dev, int word_bytes, uint64_t n_rows, uint32_t cols, void *out_dev, int out_dtype,
+                              hipStream_t s) {
+    uint32_t es = 0, one = 0;
+    if (!dtype_info(out_dtype, es, one)) return set_error(QG_ERR_INVALID, "unknown output dtype %d", out_dtype);
+    if (word_bytes != 1 && word_bytes != 4 && word_bytes != 8) return set_error(QG_ERR_INVALID, "word_bytes must be 1, 4 or 8");
+    if (cols == 0 || (word_bytes != 1 && cols > (uint32_t)word_bytes * 8u) || (word_bytes == 1 && cols > 256u))
+        return set_error(QG_ERR_INVALID, "cols does not fit the packed word");
+    if (n_rows == 0) return QG_OK;
+    const uint32_t epc = 16 / es;
+    if (cols % epc == 0 && (reinterpret_cast<uintptr_t>(out_dev) & 15u) == 0) {
+        const uint32_t cpr = cols / epc;
+        const unsigned grid = blocks_for(n_rows * cpr, 256);
+        uint4 *o = reinterpret_cast<uint4 *>(out_dev);
+        if (es == 1) hipLaunchKernelGGL(expand_chunks_kernel<1>, dim3(grid), dim3(256), 0, s, packed_dev, word_bytes, n_rows, cols, cpr, o, one);
+        else if (es == 2) hipLaunchKernelGGL(expand_chunks_kernel<2>, dim3(grid), dim3(256), 0, s, packed_dev, word_bytes, n_rows, cols, cpr, o, one);
+        else hipLaunchKernelGGL(expand_chunks_kernel<4>, dim3(grid), dim3(256), 0, s, packed_dev, word_bytes, n_rows, cols, cpr, o, one);
+    } else {
+        const unsigned grid = blocks_for(n_rows * cols, 256);
+        if (es == 1)
+            hipLaunchKernelGGL(expand_elems_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, packed_dev, word_bytes, n_rows, cols,
+                               reinterpret_cast<uint8_t *>(out_dev), (uint8_t)one);
+        else if (es == 2)
+            hipLaunchKernelGGL(expand_elems_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, packed_dev, word_bytes, n_rows, cols,
+                               reinterpret_cast<uint16_t *>(out_dev), (uint16_t)one);
+        else
+            hipLaunchKernelGGL(expand_elems_kernel<uint32_t>, dim3(grid), dim3(256), 0, s, packed_dev, word_bytes, n_rows, cols,
+                               reinterpret_cast<uint32_t *>(out_dev), one);
+    }
+    HIP_TRY(hipGetLastError());
+    return QG_OK;
+}
+
+static int widen01_impl(const uint8_t *in_dev, uint64_t n, void *out_dev, int out_dtype, hipStream_t s) {
+    uint32_t es = 0, one = 0;
+    if (!dtype_info(out_dtype, es, one)) return set_error(QG_ERR_INVALID, "unknown output dtype %d", out_dtype);
+    if (n == 0) return QG_OK;
+    const unsigned grid = blocks_for((n + 15) / 16, 256);
+    if (es == 1) hipLaunchKernelGGL(widen01_kernel<1>, dim3(grid), dim3(256), 0, s, in_dev, n, out_dev, one);
+    else if (es == 2) hipLaunchKernelGGL(widen01_kernel<2>, dim3(grid), dim3(256), 0, s, in_dev, n, out_dev, one);
+    else hipLaunchKernelGGL(widen01_kernel<4>, dim3(grid), dim3(256), 0, s, in_dev, n, out_dev, one);
+    HIP_TRY(hipGetLastError());
+    return QG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sampling: 16 lanes per env (4 envs per wavefront).  Gumbel-max over the unmasked logits with
+// one counter-RNG draw per (env, draw counter, action):
+//   u   = ((rng_draw(seed, env, counter * A + a) >> 41) + 0.5) * 2^-23        in (0, 1), exact in f32
+//   key = logit[a] - log(-log(u));   action = argmax key (lowest index on ties)
+// which samples exactly softmax(logits) and is independent of how the row is split over lanes.
+// log-prob and entropy come from a second pass over the (cache-resident) row.
+// ---------------------------------------------------------------------------------------------
+struct SampleArgs {
+    const void *logits;
+    const uint8_t *mask;  // [B][A] 1 = allowed, or null
+    void *actions;
+    float *logp;
+    float *entropy;
+    float *values;
+    uint64_t ld, B, seed, counter;
+    uint32_t A;
+    int32_t value_col;
+    int32_t act64;
+};
+
+template <typename LT>
+__device__ inline float logit_to_float(LT v);
+template <>
+__device__ inline float logit_to_float<float>(float v) { return v; }
+template <>
+__device__ inline float logit_to_float<uint16_t>(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }  // bf16
+template <>
+__device__ inline float logit_to_float<__half>(__half v) { return __half2float(v); }
+
+__host__ __device__ inline float sample_uniform(uint64_t seed, uint64_t env, uint64_t k) {
+    return ((float)(uint32_t)(rng_draw(seed, env, k) >> 41) + 0.5f) * (1.0f / 8388608.0f);
+}
+
+template <typename LT>
+__global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
+    const uint32_t sl = threadIdx.x & 15u;
+    const uint64_t env_raw = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool live = env_raw < a.B;
+    const uint64_t env = live ? env_raw : a.B - 1;  // idle sub-groups recompute the last env, write nothing
+    const LT *row = reinterpret_cast<const LT *>(a.logits) + env * a.ld;
+    const uint8_t *mrow = a.mask ? a.mask + env * a.A : nullptr;
+    const float NEG_INF = -__builtin_huge_valf();
+    float m = NEG_INF, best_key = NEG_INF, best_l = 0.0f;
+    uint32_t best_a = 0xFFFFFFFFu;
+    for (uint32_t i = sl; i < a.A; i += 16) {
+        if (mrow && !mrow[i]) continue;
+        const float l = logit_to_float<LT>(row[i]);
+        m = fmaxf(m, l);
+        const float u = sample_uniform(a.seed, env, a.counter * a.A + i);
+        const float key = l - logf(-logf(u));
+        if (key > best_key || best_a == 0xFFFFFFFFu) {
+            best_key = key;
+            best_a = i;
+            best_l = l;
+        }
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+        const float ok = __shfl_xor(best_key, off, 16), ol = __shfl_xor(best_l, off, 16), om = __shfl_xor(m, off, 16);
+        const uint32_t oa = __shfl_xor(best_a, off, 16);
+        m = fmaxf(m, om);
+        const bool take = oa != 0xFFFFFFFFu && (best_a == 0xFFFFFFFFu || ok > best_key || (ok == best_key && oa < best_a));
+        if (take) {
+            best_key = ok;
+            best_a = oa;
+            best_l = ol;
+        }
+    }
+    float ssum = 0.0f, wsum = 0.0f;
+    for (uint32_t i = sl; i < a.A; i += 16) {
+        if (mrow && !mrow[i]) continue;
+        const float d = logit_to_float<LT>(row[i]) - m;
+        const float ex = expf(d);
+        ssum += ex;
+        wsum += ex * d;
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+        ssum += __shfl_xor(ssum, off, 16);
+        wsum += __shfl_xor(wsum, off, 16);
+    }
+    if (!live || sl != 0) return;
+    const bool none = best_a == 0xFFFFFFFFu;  // every action masked: the env is finished (clifford.rs:349-351)
+    const int64_t act = none ? 0 : (int64_t)best_a;
+    if (a.act64) reinterpret_cast<int64_t *>(a.actions)[env] = act;
+    else reinterpret_cast<int32_t *>(a.actions)[env] = (int32_t)act;
+    const float log_s = logf(ssum);
+    if (a.logp) a.logp[env] = none ? 0.0f : (best_l - m) - log_s;
+    if (a.entropy) a.entropy[env] = none ? 0.0f : log_s - wsum / ssum;
+    if (a.values && a.value_col >= 0) a.values[env] = logit_to_float<LT>(row[a.value_col]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GAE: one thread per env walks its T steps backwards; loads of a wave are contiguous in env.
+//   nd_t   = 1 - done_t
+//   delta  = r_t + (gamma * V_{t+1}) * nd_t - V_t
+//   A_t    = delta + ((gamma*lambda) * nd_t) * A_{t+1};   R_t = A_t + V_t
+// (f32, this operation order, no FMA: the numpy restatement in tests/ reproduces it bit for bit)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gae_kernel(const float *rewards, const float *values, const uint8_t *dones, const float *last_values,
+                                                  float gamma, float gamma_lambda, uint32_t T, uint64_t B, float *adv, float *ret) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B) return;
+    float next_v = last_values ? last_values[e] : 0.0f;
+    float acc = 0.0f;
+    for (uint32_t t = T; t-- > 0;) {
+        const uint64_t i = (uint64_t)t * B + e;
+        const float nd = dones[i] ? 0.0f : 1.0f;
+        const float v = values[i];
+        const float delta = rewards[i] + (gamma * next_v) * nd - v;
+        acc = delta + (gamma_lambda * nd) * acc;
+        adv[i] = acc;
+        if (ret) ret[i] = acc + v;
+        next_v = v;
+    }
+}
+
+}  // namespace qg
+
+using namespace qg;
+
+extern "C" {
+
+int qg_expand_packed(const void *packed_dev, int word_bytes, uint64_t n_rows, uint32_t cols, void *out_dev, int out_dtype, void *stream) {
+    if (!packed_dev || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
+    return expand_packed_impl(packed_dev, word_bytes, n_rows, cols, out_dev, out_dtype, (hipStream_t)stream);
+}
+
+int qg_vec_observe_dense_as(qg_vec *v, void *out_dev, int out_dtype, void *stream) {
+    if (!v || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
+    if (out_dtype == QG_DT_I8) return qg_vec_observe_dense(v, reinterpret_cast<int8_t *>(out_dev), stream);
+    qg_vec_info info;
+    int rc = qg_vec_get_info(v, &info);
+    if (rc != QG_OK) return rc;
+    HIP_TRY(hipSetDevice(v->device));
+    const uint64_t obs = (uint64_t)info.obs_rows * info.obs_cols;
+    if (v->layout == LAYOUT_PAULI) {  // no packed form: int8 observation, then widen
+        rc = ensure_scratch_public(v, v->B * obs);
+        if (rc != QG_OK) return rc;
+        rc = qg_vec_observe_dense(v, reinterpret_cast<int8_t *>(v->scratch), stream);
+        if (rc != QG_OK) return rc;
+        return widen01_impl(reinterpret_cast<const uint8_t *>(v->scratch), v->B * obs, out_dev, out_dtype, (hipStream_t)stream);
+    }
+    rc = ensure_scratch_public(v, v->B * (uint64_t)info.packed_words_per_env * info.packed_word_bytes);
+    if (rc != QG_OK) return rc;
+    rc = qg_vec_observe_packed(v, v->scratch, stream);
+    if (rc != QG_OK) return rc;
+    return expand_packed_impl(v->scratch, (int)info.packed_word_bytes, v->B * (uint64_t)info.packed_words_per_env, (uint32_t)info.obs_cols,
+                              out_dev, out_dtype, (hipStream_t)stream);
+}
+
+int qg_sample_actions(const void *logits_dev, int logits_dtype, uint64_t ld, uint64_t batch, uint32_t num_actions, const uint8_t *mask_dev,
+                      uint64_t seed, uint64_t counter, void *actions_dev, int action_dtype, float *logp_dev, float *entropy_dev,
+                      int32_t value_col, float *values_dev, void *stream) {
+    if (!logits_dev || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
+    if (num_actions == 0 || ld < num_actions) return set_error(QG_ERR_INVALID, "bad logits shape");
+    if (action_dtype != QG_ACT_I32 && action_dtype != QG_ACT_I64) return set_error(QG_ERR_INVALID, "bad action dtype");
+    if (value_col >= 0 && ((uint64_t)value_col >= ld || !values_dev)) return set_error(QG_ERR_INVALID, "bad value column");
+    if (batch == 0) return QG_OK;
+    SampleArgs a;
+    a.logits = logits_dev;
+    a.mask = mask_dev;
+    a.actions = actions_dev;
+    a.logp = logp_dev;
+    a.entropy = entropy_dev;
+    a.values = values_dev;
+    a.ld = ld;
+    a.B = batch;
+    a.seed = seed ^ 0x73616D70ull;  // "samp": a stream of its own next to reset / coin / perm draws
+    a.counter = counter;
+    a.A = num_actions;
+    a.value_col = value_col;
+    a.act64 = action_dtype == QG_ACT_I64;
+    const dim3 grid(blocks_for(batch * 16ull, 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (logits_dtype) {
+    case QG_DT_F32: hipLaunchKernelGGL(sample_kernel<float>, grid, block, 0, s, a); break;
+    case QG_DT_BF16: hipLaunchKernelGGL(sample_kernel<uint16_t>, grid, block, 0, s, a); break;
+    case QG_DT_F16: hipLaunchKernelGGL(sample_kernel<__half>, grid, block, 0, s, a); break;
+    default: return set_error(QG_ERR_INVALID, "logits dtype must be f32, bf16 or f16");
+    }
+    HIP_TRY(hipGetLastError());
+    return QG_OK;
+}
+
+int qg_gae(const float *rewards_dev, const float *values_dev, const uint8_t *dones_dev, const float *last_values_dev, float gamma,
+           float gae_lambda, size_t n_steps, uint64_t batch, float *advantages_dev, float *returns_dev, void *stream) {
+    if (!rewards_dev || !values_dev || !dones_dev || !advantages_dev) return set_error(QG_ERR_INVALID, "null argument");
+    if (n_steps > 0x7fffffffu) return set_error(QG_ERR_INVALID, "too many steps");
+    if (n_steps == 0 || batch == 0) return QG_OK;
+    const float gl = gamma * gae_lambda;
+    hipLaunchKernelGGL(gae_kernel, dim3(blocks_for(batch, 256)), dim3(256), 0, (hipStream_t)stream, rewards_dev, values_dev, dones_dev,
+                       last_values_dev, gamma, gl, (uint32_t)n_steps, batch, advantages_dev, returns_dev);
+    HIP_TRY(hipGetLastError());
+    return QG_OK;
+}
+
+}  // extern "C"

@@ -175,6 +175,18 @@ class VecEnv:
         _lib.check(self._L.qg_vec_observe_dense(self._h, out.data_ptr(), _stream_ptr()))
         return out
 
+    _DTYPES = {torch.int8: _lib.QG_DT_I8, torch.float32: _lib.QG_DT_F32, torch.bfloat16: _lib.QG_DT_BF16, torch.float16: _lib.QG_DT_F16}
+
+    def observe_as(self, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Dense observation [B, rows*cols] of {0, 1} written directly in `dtype` (what the policy's first layer reads)."""
+        r, c = self.obs_shape_
+        if out is None:
+            out = torch.empty((self.batch, r * c), dtype=dtype, device=self.device)
+        if out.dtype != dtype or out.numel() != self.batch * r * c or not out.is_contiguous():
+            raise ValueError("observe_as: `out` must be a contiguous [B, rows*cols] tensor of the requested dtype")
+        _lib.check(self._L.qg_vec_observe_dense_as(self._h, out.data_ptr(), self._DTYPES[dtype], _stream_ptr()))
+        return out
+
     def pauli_observe(self, perm_idx: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """PauliEnv observe() with the qubit-permutation draws given explicitly (int32 [B])."""
         r, c = self.obs_shape_

@@ -1,0 +1,145 @@
+"""Collector kernels (kernels_collect.hip) against their numpy restatements: observation expansion
+(bit-exact), action sampling (exact argmax of the same Gumbel keys, log-prob / entropy to f32
+round-off, distribution test), GAE (bit-exact f32)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from collect_ref import gae_f32, gumbel_keys, log_softmax, sample_uniforms  # noqa: E402
+from util import f32_bits, grid_gateset, line_gateset  # noqa: E402
+
+DTYPES = [torch.int8, torch.bfloat16, torch.float16, torch.float32]
+
+
+@pytest.mark.parametrize("word,cols", [(4, 32), (4, 16), (4, 7), (8, 64), (8, 40), (8, 33), (1, 9), (1, 16)])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_expand_packed_matches_numpy(word, cols, dtype):
+    from qiskit_gym_amd.collector import expand_packed
+
+    rng = np.random.default_rng(word * 100 + cols)
+    n_rows = 1000 * 3 + 5
+    if word == 1:
+        packed = rng.integers(0, cols, size=n_rows, dtype=np.uint8)
+        want = (packed[:, None] == np.arange(cols)[None, :]).astype(np.float32)
+    else:
+        raw = rng.integers(0, 2**63, size=n_rows, dtype=np.uint64) * 2 + rng.integers(0, 2, size=n_rows, dtype=np.uint64)
+        packed = raw.astype(np.uint32 if word == 4 else np.uint64)
+        want = ((packed[:, None].astype(np.uint64) >> np.arange(cols, dtype=np.uint64)[None, :]) & 1).astype(np.float32)
+    tdt = {1: torch.uint8, 4: torch.int32, 8: torch.int64}[word]
+    t = torch.from_numpy(packed.view({1: np.uint8, 4: np.int32, 8: np.int64}[word])).to("cuda").view(tdt)
+    got = expand_packed(t, cols, dtype)
+    assert got.shape == (n_rows, cols) and got.dtype == dtype
+    np.testing.assert_array_equal(got.float().cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("kind,n", [("clifford", 16), ("clifford", 5), ("clifford", 20), ("linear_function", 8), ("linear_function", 12),
+                                    ("linear_function", 40), ("permutation", 9), ("pauli", 6)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
+def test_observe_as_equals_the_int8_observation(kind, n, dtype):
+    from qiskit_gym_amd.vec import VecEnv
+
+    gs = grid_gateset("permutation", 3, 3) if kind == "permutation" else line_gateset(kind, n)
+    B = 517
+    cfg = dict(add_perms=False, track_solution=False, difficulty=7)
+    if kind != "pauli":
+        cfg["add_inverts"] = False
+    env = VecEnv(kind, n, gs, B, **cfg)
+    env.reset(3)
+    acts = torch.randint(0, len(gs), (5, B), dtype=torch.int32, device="cuda")
+    env.rollout(acts)
+    want = env.observe().reshape(B, -1).float()
+    got = env.observe_as(dtype)
+    env.sync()
+    assert got.dtype == dtype and got.shape == want.shape
+    assert torch.equal(got.float(), want)
+    assert set(np.unique(want.cpu().numpy())) <= {0.0, 1.0} and want.sum() > 0
+
+
+@pytest.mark.parametrize("ldt", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("A,pad", [(170, 6), (12, 0), (1, 0), (37, 3)])
+def test_sample_actions_is_the_argmax_of_the_gumbel_keys(ldt, A, pad):
+    from qiskit_gym_amd.collector import sample_actions
+
+    B, seed, counter = 3000, 1234, 17
+    g = torch.Generator(device="cuda")
+    g.manual_seed(A)
+    full = (torch.randn((B, A + pad), device="cuda", generator=g) * 3).to(ldt)
+    acts, logp, ent, vals = sample_actions(full, seed, counter, num_actions=A, value_col=(A if pad else None))
+    torch.cuda.synchronize()
+    logits = full[:, :A].float().cpu().numpy()
+    keys = gumbel_keys(logits, sample_uniforms(seed, B, counter, A))
+    order = np.sort(keys, axis=1)
+    margin = order[:, -1] - order[:, -2] if A > 1 else np.full(B, np.inf)
+    want = keys.argmax(axis=1)
+    got = acts.cpu().numpy()
+    clear = margin > 1e-4  # f32 log vs f64 log may reorder keys that are this close (none or a handful)
+    assert clear.mean() > 0.99
+    np.testing.assert_array_equal(got[clear], want[clear])
+    assert ((got >= 0) & (got < A)).all()
+    lsm = log_softmax(logits)
+    np.testing.assert_allclose(logp.cpu().numpy(), lsm[np.arange(B), got], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(ent.cpu().numpy(), -(np.exp(lsm) * lsm).sum(axis=1), rtol=0, atol=5e-5)
+    if pad:
+        np.testing.assert_array_equal(vals.cpu().numpy(), full[:, A].float().cpu().numpy())
+    # a different counter gives different draws; the same one reproduces
+    again, *_ = sample_actions(full, seed, counter, num_actions=A)
+    other, *_ = sample_actions(full, seed, counter + 1, num_actions=A)
+    assert torch.equal(again, acts)
+    if A > 1:
+        assert not torch.equal(other, acts)
+
+
+def test_sample_actions_respects_masks_and_int32_output():
+    from qiskit_gym_amd.collector import sample_actions
+
+    B, A = 2048, 28
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    logits = torch.randn((B, A), device="cuda", generator=g)
+    mask = (torch.rand((B, A), device="cuda", generator=g) < 0.4).to(torch.uint8)
+    mask[:7] = 0  # finished envs: masks() is all false (clifford.rs:349-351)
+    acts = torch.empty(B, dtype=torch.int32, device="cuda")
+    _, logp, ent, _ = sample_actions(logits, 9, 0, mask=mask, actions=acts)
+    torch.cuda.synchronize()
+    a, m = acts.cpu().numpy(), mask.cpu().numpy().astype(bool)
+    some = m.any(axis=1)
+    assert m[np.arange(B), a][some].all()
+    assert (a[~some] == 0).all() and (logp.cpu().numpy()[~some] == 0).all()
+    lsm = log_softmax(logits.cpu().numpy(), m)
+    np.testing.assert_allclose(logp.cpu().numpy()[some], lsm[np.arange(B), a][some], atol=2e-5, rtol=0)
+    keys = gumbel_keys(logits.cpu().numpy(), sample_uniforms(9, B, 0, A), m)
+    srt = np.sort(keys, axis=1)
+    clear = some & ((srt[:, -1] - srt[:, -2] > 1e-4) | ~np.isfinite(srt[:, -2]))
+    np.testing.assert_array_equal(a[clear], keys.argmax(axis=1)[clear])
+
+
+def test_sample_actions_follows_softmax():
+    """200k draws from one 6-way distribution: chi-square against softmax(logits)."""
+    from qiskit_gym_amd.collector import sample_actions
+
+    B = 200_000
+    row = torch.tensor([0.3, -1.2, 2.0, 0.0, 1.1, -3.0], device="cuda")
+    logits = row.repeat(B, 1).contiguous()
+    acts, *_ = sample_actions(logits, 42, 3)
+    counts = np.bincount(acts.cpu().numpy(), minlength=6).astype(np.float64)
+    p = torch.softmax(row.double(), 0).cpu().numpy()
+    chi2 = ((counts - B * p) ** 2 / (B * p)).sum()
+    assert chi2 < 30.0, (chi2, counts, B * p)  # 5 dof: P(chi2 > 30) ~ 1.5e-5
+
+
+@pytest.mark.parametrize("T,B,with_last", [(33, 1000, True), (1, 70, True), (128, 257, False)])
+def test_gae_is_bit_exact(T, B, with_last):
+    from qiskit_gym_amd.collector import gae
+
+    rng = np.random.default_rng(T)
+    r = rng.normal(size=(T, B)).astype(np.float32)
+    v = rng.normal(size=(T, B)).astype(np.float32)
+    d = (rng.random((T, B)) < 0.1).astype(np.uint8)
+    lv = rng.normal(size=B).astype(np.float32) if with_last else None
+    adv, ret = gae(torch.from_numpy(r).cuda(), torch.from_numpy(v).cuda(), torch.from_numpy(d).cuda(),
+                   torch.from_numpy(lv).cuda() if with_last else None, 0.995, 0.95)
+    want_adv, want_ret = gae_f32(r, v, d, lv, 0.995, 0.95)
+    np.testing.assert_array_equal(f32_bits(adv.cpu().numpy()), f32_bits(want_adv))
+    np.testing.assert_array_equal(f32_bits(ret.cpu().numpy()), f32_bits(want_ret))

@@ -7,10 +7,12 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 from oracle import OracleEnv  # noqa: E402
+from collect_ref import gae_f32  # noqa: E402
 from util import f32_bits, line_gateset, rng_actions  # noqa: E402
 
 
-def test_collector_trajectories_replay_on_the_oracle():
+@pytest.mark.parametrize("store_obs", ["dense", "packed"])
+def test_collector_trajectories_replay_on_the_oracle(store_obs):
     from qiskit_gym_amd.collector import BasicPolicy, RolloutCollector
     from qiskit_gym_amd.vec import VecEnv
 
@@ -21,11 +23,12 @@ def test_collector_trajectories_replay_on_the_oracle():
     env = VecEnv("clifford", n, gs, B, **cfg)
     torch.manual_seed(0)
     pol = BasicPolicy(4 * n * n, A, embedding_size=64, common=32)
-    col = RolloutCollector(env, pol, dtype=torch.float32, seed=77)
+    col = RolloutCollector(env, pol, dtype=torch.float32, seed=77, gamma=0.99, gae_lambda=0.9, store_obs=store_obs)
     ro = col.collect(T)
     torch.cuda.synchronize()
     env.sync()
-    obs, acts = ro.obs.cpu().numpy(), ro.actions.cpu().numpy()
+    assert ro.obs_packed == (store_obs == "packed")
+    obs, acts = ro.dense_obs(torch.int8).cpu().numpy(), ro.actions.cpu().numpy()
     rew, done = ro.rewards.cpu().numpy(), ro.dones.cpu().numpy()
     assert acts.min() >= 0 and acts.max() < A
     envs = [OracleEnv("clifford", n, gs, **{k: int(v) for k, v in cfg.items()}) for _ in range(B)]
@@ -42,4 +45,45 @@ def test_collector_trajectories_replay_on_the_oracle():
             assert o.reward_bits() == int(f32_bits(rew[t, e])), (t, e)
             assert int(o.is_final()) == int(done[t, e]), (t, e)
     assert n_episodes > B  # several episodes per env (depth_slope * difficulty = 4 steps)
-    assert torch.isfinite(ro.logp).all() and torch.isfinite(ro.values).all()
+    assert torch.isfinite(ro.logp).all() and torch.isfinite(ro.values).all() and (ro.logp <= 0).all() and (ro.entropy >= 0).all()
+    # the policy input the collector built is the observation; the sampled log-probs are the policy's
+    logits, value = col.policy(torch.from_numpy(obs[T - 1]).cuda().float())
+    lsm = torch.log_softmax(logits.float(), dim=-1)
+    torch.testing.assert_close(ro.logp[T - 1], lsm.gather(1, ro.actions[T - 1].unsqueeze(1)).squeeze(1), atol=1e-4, rtol=0)
+    torch.testing.assert_close(ro.values[T - 1], value.float(), atol=1e-4, rtol=0)
+    # GAE over the rollout, bootstrapped with the value of the state after the last step
+    want_adv, want_ret = gae_f32(rew, ro.values.cpu().numpy(), done, ro.last_values.cpu().numpy(), 0.99, 0.9)
+    np.testing.assert_array_equal(f32_bits(ro.advantages.cpu().numpy()), f32_bits(want_adv))
+    np.testing.assert_array_equal(f32_bits(ro.returns.cpu().numpy()), f32_bits(want_ret))
+
+
+def test_collector_runs_pauli_and_generic_policies():
+    """PauliGym (dense observation only, device-side target generator) and a policy that is not BasicPolicy."""
+    from qiskit_gym_amd.collector import RolloutCollector
+    from qiskit_gym_amd.vec import VecEnv
+
+    n, B, T = 5, 96, 12
+    gs = line_gateset("pauli", n)
+    env = VecEnv("pauli", n, gs, B, add_perms=False, track_solution=False, max_rotations=3, difficulty=4, depth_slope=1)
+    rows, cols = env.obs_shape_
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body = torch.nn.Linear(rows * cols, 48)
+            self.pi = torch.nn.Linear(48, len(gs))
+            self.v = torch.nn.Linear(48, 1)
+
+        def forward(self, x):
+            h = torch.tanh(self.body(x))
+            return self.pi(h), self.v(h).squeeze(-1)
+
+    torch.manual_seed(1)
+    col = RolloutCollector(env, Tiny(), dtype=torch.float32, seed=3)
+    ro = col.collect(T)
+    torch.cuda.synchronize()
+    env.sync()
+    assert ro.obs.shape == (T, B, rows * cols) and ro.dones.sum() > 0
+    assert torch.isfinite(ro.advantages).all() and ro.last_values is None
+    with pytest.raises(ValueError):
+        RolloutCollector(env, Tiny(), store_obs="packed")
