@@ -165,6 +165,18 @@ int qg_vec_reset(qg_vec *v, uint64_t seed, void *stream);
  * Lets a GPU-resident collector run episode after episode without a host round trip; pass a
  * fresh seed per call (e.g. a step counter) so successive episodes of an env differ. */
 int qg_vec_reset_done(qg_vec *v, uint64_t seed, void *stream);
+/* Device clock for launches that are replayed from a captured hipGraph (kernel arguments, hence
+ * seeds and RNG counters, are baked into a graph).  While set, every kernel of this handle adds
+ * *clock_dev to its RNG counter: reset / reset_done draw with seed + 0x9E3779B9 * clock, the
+ * add_inverts coin and the PauliEnv permutation draw use counter + clock.  The owner of the graph
+ * advances the clock (a device-side add inside the graph) between replays.  NULL detaches.  The
+ * word must stay valid while attached.  Synchronises and drops cached rollout graphs. */
+int qg_vec_set_clock(qg_vec *v, const uint64_t *clock_dev);
+/* The handle's host-side RNG counters: the next step's add_inverts coin is drawn with counter
+ * `step_index` (it advances by one per step) and the next PauliEnv observe() permutation with
+ * `observe_index`.  A caller that replays graphs sets them to the position inside the graph so
+ * that eager and replayed launches draw alike (effective counter = this + the device clock). */
+int qg_vec_set_counters(qg_vec *v, uint64_t step_index, uint64_t observe_index);
 /* Same as qg_vec_reset, with the draws supplied: actions_dev[t*B + e], t < n_draws (int32). */
 int qg_vec_reset_with(qg_vec *v, const int32_t *actions_dev, size_t n_draws, void *stream);
 
@@ -235,15 +247,17 @@ int qg_vec_observe_dense_as(qg_vec *v, void *out_dev, int out_dtype, void *strea
  * the packed observations a rollout buffer keeps): n_rows words of `word_bytes` (4 / 8: bit c =
  * column c; 1: PermutationEnv, the byte is the set column) -> out_dev[row * cols + c]. */
 int qg_expand_packed(const void *packed_dev, int word_bytes, uint64_t n_rows, uint32_t cols, void *out_dev, int out_dtype, void *stream);
-/* One categorical draw per env from softmax(logits[e, 0:num_actions]) by Gumbel-max on the counter
- * RNG: key[a] = logit[a] - log(-log(u)), u = ((rng(seed ^ 0x73616D70, e, counter*num_actions + a)
- * >> 41) + 0.5) * 2^-23, action = argmax key.  logits_dev: [batch, ld] of `logits_dtype` (f32 / bf16
- * / f16), ld >= num_actions.  mask_dev: [batch, num_actions] (1 = allowed; Env::masks) or NULL.
- * Outputs (each may be NULL except actions): action, log-prob of it, entropy of the row, and
- * values_dev[e] = logits[e, value_col] (value_col >= 0: a value head fused into the same GEMM). */
+/* One categorical draw per env from softmax(logits[e, 0:num_actions]) by an exponential race on
+ * the counter RNG: base = rng(seed ^ 0x73616D70, e, counter + *clock_dev) (clock_dev may be NULL);
+ * u[a] = ((hash32(base, a) >> 9) + 0.5) *
+ * 2^-23; action = argmin -log(u[a]) / exp(logit[a] - max) (kernels_collect.hip states hash32).
+ * logits_dev: [batch, ld] of `logits_dtype` (f32 / bf16 / f16), ld >= num_actions.  mask_dev:
+ * [batch, num_actions] (1 = allowed; Env::masks) or NULL.  Outputs (each may be NULL except
+ * actions): action, log-prob of it, entropy of the row, and values_dev[e] = logits[e, value_col]
+ * (value_col >= 0: a value head computed by the same GEMM as the logits). */
 int qg_sample_actions(const void *logits_dev, int logits_dtype, uint64_t ld, uint64_t batch, uint32_t num_actions, const uint8_t *mask_dev,
-                      uint64_t seed, uint64_t counter, void *actions_dev, int action_dtype, float *logp_dev, float *entropy_dev,
-                      int32_t value_col, float *values_dev, void *stream);
+                      uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev, int action_dtype, float *logp_dev,
+                      float *entropy_dev, int32_t value_col, float *values_dev, void *stream);
 /* Generalised advantage estimation over a [n_steps, batch] rollout (f32, done_t = the episode ended
  * with step t): delta_t = r_t + gamma*V_{t+1}*(1-done_t) - V_t, A_t = delta_t +
  * gamma*lambda*(1-done_t)*A_{t+1}, returns = A + V.  last_values_dev: V after the last step

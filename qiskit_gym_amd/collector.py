@@ -34,8 +34,9 @@ _DT = {torch.float32: _lib.QG_DT_F32, torch.bfloat16: _lib.QG_DT_BF16, torch.flo
 
 def sample_actions(logits: torch.Tensor, seed: int, counter: int, num_actions: Optional[int] = None, mask: Optional[torch.Tensor] = None,
                    value_col: Optional[int] = None, actions: Optional[torch.Tensor] = None, logp: Optional[torch.Tensor] = None,
-                   entropy: Optional[torch.Tensor] = None, values: Optional[torch.Tensor] = None):
+                   entropy: Optional[torch.Tensor] = None, values: Optional[torch.Tensor] = None, clock: Optional[torch.Tensor] = None):
     """One categorical draw per row of `logits[:, :num_actions]` (f32 / bf16 / f16, row stride free).
+    `clock`: optional int64 device scalar added to `counter` on the device (graph replays).
     Returns (actions int64, logp f32, entropy f32, values f32 or None); see `qg_sample_actions`."""
     if logits.dim() != 2 or logits.stride(1) != 1:
         raise ValueError("logits must be [B, >=num_actions] with unit column stride")
@@ -52,7 +53,7 @@ def sample_actions(logits: torch.Tensor, seed: int, counter: int, num_actions: O
     L = _lib.load()
     _lib.check(L.qg_sample_actions(
         logits.data_ptr(), _DT[logits.dtype], logits.stride(0), B, A, mask.data_ptr() if mask is not None else None,
-        int(seed) & (2**64 - 1), int(counter), actions.data_ptr(), act_dt, logp.data_ptr(), entropy.data_ptr(),
+        int(seed) & (2**64 - 1), int(counter), clock.data_ptr() if clock is not None else None, actions.data_ptr(), act_dt, logp.data_ptr(), entropy.data_ptr(),
         -1 if value_col is None else int(value_col), values.data_ptr() if value_col is not None else None, _stream_ptr()))
     return actions, logp, entropy, values
 
@@ -146,16 +147,24 @@ class RolloutCollector:
 
     store_obs: "dense" keeps the int8 observation of every step (the Gym adapter's format);
     "packed" keeps the bit-packed rows (8x smaller for CliffordGym; `Rollout.dense_obs` expands them
-    on demand; not available for PauliGym, whose observation has no packed form)."""
+    on demand; not available for PauliGym, whose observation has no packed form).
+
+    use_graph: capture the whole T-step collection (every env kernel, the policy GEMMs, sampling,
+    GAE) into one hipGraph on the first call and replay it afterwards -- one host call per rollout
+    instead of ~10 per step.  The rollout tensors are then reused between calls (clone what must
+    outlive the next `collect`), and policy parameters must be updated in place (optimisers do).
+
+    Randomness: step number n of the collector (counted over its lifetime, kept in a device clock
+    so that graph replays advance it) resets finished episodes with seed `seed + 0x9E3779B9 * (n + 1)`
+    and samples with counter n; both modes therefore produce the same trajectories."""
 
     def __init__(self, env: VecEnv, policy: nn.Module, dtype: torch.dtype = torch.bfloat16, seed: int = 0, gamma: float = 0.995,
-                 gae_lambda: float = 0.995, store_obs: str = "dense"):
+                 gae_lambda: float = 0.995, store_obs: str = "dense", use_graph: bool = False):
         self.env = env
         self.policy = policy.to(device=env.device, dtype=dtype)
         self.dtype = dtype
         self.seed = int(seed)
         self.gamma, self.gae_lambda = float(gamma), float(gae_lambda)  # rl/configs.py:136-137
-        self.steps_done = 0
         r, c = env.obs_shape_
         self.obs_size = r * c
         if store_obs not in ("dense", "packed"):
@@ -163,7 +172,21 @@ class RolloutCollector:
         if store_obs == "packed" and env.env_kind == "pauli":
             raise ValueError("PauliGym observations have no packed form")
         self.store_obs = store_obs
+        self.use_graph = bool(use_graph)
         self._x = torch.empty((env.batch, self.obs_size), dtype=dtype, device=env.device)  # policy input
+        self.clock = torch.zeros(1, dtype=torch.int64, device=env.device)  # collector steps taken so far
+        env.set_clock(self.clock)
+        self._heads = None
+        if isinstance(self.policy, BasicPolicy):
+            w, b, A = self.policy.fused_heads()
+            self._heads = (w, b, A)
+        self._graph = None
+        self._graph_T = 0
+        self._graph_ro: Optional[Rollout] = None
+
+    @property
+    def steps_done(self) -> int:
+        return int(self.clock.item())
 
     def _alloc(self, T: int) -> Rollout:
         env, B, dev = self.env, self.env.batch, self.env.device
@@ -183,7 +206,7 @@ class RolloutCollector:
         env = self.env
         if ro.obs_packed:
             env.observe_packed(out=ro.obs[t])
-            expand_packed(ro.obs[t], ro.obs_cols, self.dtype, out=self._x)
+            env.observe_as(self.dtype, out=self._x)
         else:
             env.observe(out=ro.obs[t].view(env.batch, *env.obs_shape_))
             if env.env_kind == "pauli":
@@ -192,50 +215,81 @@ class RolloutCollector:
             else:
                 env.observe_as(self.dtype, out=self._x)
 
-    def _forward_sample(self, heads, ro: Rollout, t: int, counter: int):
-        pol = self.policy
-        if heads is not None:
-            w, b, A = heads
-            h = _linear_relu(self._x, pol.embeddings.weight, pol.embeddings.bias)
-            h = _linear_relu(h, pol.common.weight, pol.common.bias)
-            out = torch.addmm(b, h, w.t())
-            sample_actions(out, self.seed, counter, num_actions=A, value_col=A, actions=ro.actions[t], logp=ro.logp[t],
-                           entropy=ro.entropy[t], values=ro.values[t])
+    def _refresh_heads(self):
+        """Copy the policy / value head parameters into the fused head (in place: graph-safe)."""
+        if self._heads is None:
             return
-        logits, value = pol(self._x)
-        sample_actions(logits.contiguous(), self.seed, counter, actions=ro.actions[t], logp=ro.logp[t], entropy=ro.entropy[t])
+        w, b, A = self._heads
+        pol = self.policy
+        w[:A].copy_(pol.policy_head.weight)
+        w[A].copy_(pol.value_head.weight[0])
+        b[:A].copy_(pol.policy_head.bias)
+        b[A : A + 1].copy_(pol.value_head.bias)
+
+    def _trunk(self) -> torch.Tensor:
+        """Fused-head forward of `self._x`: [B, pad8(A + 1)], column A is the value."""
+        pol = self.policy
+        w, b, _ = self._heads
+        h = _linear_relu(self._x, pol.embeddings.weight, pol.embeddings.bias)
+        h = _linear_relu(h, pol.common.weight, pol.common.bias)
+        return torch.addmm(b, h, w.t())
+
+    def _forward_sample(self, ro: Rollout, t: int):
+        if self._heads is not None:
+            A = self._heads[2]
+            sample_actions(self._trunk(), self.seed, t, num_actions=A, value_col=A, actions=ro.actions[t], logp=ro.logp[t],
+                           entropy=ro.entropy[t], values=ro.values[t], clock=self.clock)
+            return
+        logits, value = self.policy(self._x)
+        sample_actions(logits.contiguous(), self.seed, t, actions=ro.actions[t], logp=ro.logp[t], entropy=ro.entropy[t], clock=self.clock)
         ro.values[t].copy_(value)
 
-    def _value_of_current_state(self, heads) -> torch.Tensor:
-        env, pol = self.env, self.policy
-        if env.env_kind == "pauli":
-            raise RuntimeError("unreachable")
-        env.observe_as(self.dtype, out=self._x)
-        if heads is not None:
-            w, b, A = heads
-            h = _linear_relu(self._x, pol.embeddings.weight, pol.embeddings.bias)
-            h = _linear_relu(h, pol.common.weight, pol.common.bias)
-            return torch.addmm(b, h, w.t())[:, A].float()
-        return pol(self._x)[1].float()
+    def _value_of_current_state(self) -> torch.Tensor:
+        self.env.observe_as(self.dtype, out=self._x)
+        if self._heads is not None:
+            return self._trunk()[:, self._heads[2]].float()
+        return self.policy(self._x)[1].float()
 
-    @torch.no_grad()
-    def collect(self, T: int, out: Optional[Rollout] = None) -> Rollout:
+    def _body(self, ro: Rollout, T: int):
         env = self.env
-        ro = self._alloc(T) if out is None else out
-        heads = self.policy.fused_heads() if isinstance(self.policy, BasicPolicy) else None
+        self._refresh_heads()
         for t in range(T):
-            # finished episodes start over (reference: the collector calls reset() on a fresh clone)
-            env.reset_done(self.seed + 0x9E3779B9 * (self.steps_done + 1))
+            # finished episodes start over (reference: the collector calls reset() on a fresh clone);
+            # the kernels add the device clock: effective seed = seed + 0x9E3779B9 * (clock + t + 1)
+            env.set_counters(t, t)  # coin / permutation draws: counter t + clock, eager or replayed
+            env.reset_done(self.seed + 0x9E3779B9 * (t + 1))
             self._observe(ro, t)
             # masks() is all-true for a live env (clifford.rs:349-351), so sampling needs no mask
-            self._forward_sample(heads, ro, t, self.steps_done)
+            self._forward_sample(ro, t)
             env.rollout(ro.actions[t : t + 1], rewards_out=ro.rewards[t : t + 1], dones_out=ro.dones[t : t + 1])
-            self.steps_done += 1
         # bootstrap value of the state after the last step (masked by `dones` where the episode ended)
         if env.env_kind == "pauli":
             last_v = None  # observing would draw a permutation; episodes are short, bootstrap with 0
         else:
-            last_v = self._value_of_current_state(heads)
-        ro.last_values = last_v
-        gae(ro.rewards, ro.values, ro.dones, last_v, self.gamma, self.gae_lambda, advantages=ro.advantages, returns=ro.returns)
+            last_v = self._value_of_current_state()
+            if ro.last_values is None:
+                ro.last_values = torch.empty(env.batch, dtype=torch.float32, device=env.device)
+            ro.last_values.copy_(last_v)
+        gae(ro.rewards, ro.values, ro.dones, ro.last_values, self.gamma, self.gae_lambda, advantages=ro.advantages, returns=ro.returns)
+        self.clock.add_(T)
+
+    @torch.no_grad()
+    def collect(self, T: int, out: Optional[Rollout] = None) -> Rollout:
+        if not self.use_graph:
+            ro = self._alloc(T) if out is None else out
+            self._body(ro, T)
+            return ro
+        if self._graph is not None and self._graph_T == T:
+            self._graph.replay()
+            return self._graph_ro
+        # first call (or a new T): one eager pass (allocates scratch, warms the GEMM handles, and IS
+        # this call's rollout), then capture the same body for the calls that follow
+        ro = self._alloc(T)
+        self._body(ro, T)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):  # records, does not run: the env state and the clock are untouched
+            self._body(ro, T)
+        torch.cuda.synchronize()
+        self._graph, self._graph_T, self._graph_ro = graph, T, ro
         return ro

@@ -12,6 +12,30 @@ __device__ inline int64_t load_action(const void *actions, uint64_t idx, bool ac
                  : (int64_t) reinterpret_cast<const int32_t *>(actions)[idx];
 }
 
+// Dense {0,1} elements from packed bits: one 16-byte chunk = 16 / ES elements of ES bytes each.
+// `one`: the bit pattern of 1 in the output dtype (int8 1, bf16 0x3F80, f16 0x3C00, f32 0x3F800000)
+template <int ES>
+__device__ inline uint4 expand_chunk(uint32_t bits, uint32_t one) {
+    uint32_t w[4];
+    if constexpr (ES == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t nb = (bits >> (4 * k)) & 0xFu;
+            w[k] = ((nb & 1u) | ((nb & 2u) << 7) | ((nb & 4u) << 14) | ((nb & 8u) << 21)) * one;
+        }
+    } else if constexpr (ES == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = (bits >> (2 * k)) & 1u, hi = (bits >> (2 * k + 1)) & 1u;
+            w[k] = (lo * one) | ((hi * one) << 16);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = ((bits >> k) & 1u) * one;
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // MetricsTracker with running maxima instead of HashSets (metrics.rs:83-123).
 // `lay` = this env's record: last_gates[N], last_cxs[N], n_layers, n_layers_cnots (int32 each;
 // last_* start at -1).  |layers| == max(last_gates)+1 and |cnot_layers| == max(last_cxs)+1

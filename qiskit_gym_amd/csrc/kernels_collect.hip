@@ -11,6 +11,7 @@
 // kernels: expand is write-bound (B*obs*sizeof(dtype) bytes), the other two read their inputs once.
 #include <hip/hip_fp16.h>
 
+#include "device_common.hpp"
 #include "qgym_host.hpp"
 
 namespace qg {
@@ -31,29 +32,6 @@ static inline unsigned blocks_for(uint64_t threads, unsigned block) { return (un
 // every store instruction of a wave writes 1 KiB contiguously.  The packed input is 8x..64x
 // smaller than the output and is read through the cache (neighbouring threads share a word).
 // ---------------------------------------------------------------------------------------------
-// `one`: the bit pattern of 1 in the output dtype (int8 1, bf16 0x3F80, f16 0x3C00, f32 0x3F800000)
-template <int ES>
-__device__ inline uint4 expand_chunk(uint32_t bits, uint32_t one) {
-    uint32_t w[4];
-    if constexpr (ES == 1) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t nb = (bits >> (4 * k)) & 0xFu;
-            w[k] = ((nb & 1u) | ((nb & 2u) << 7) | ((nb & 4u) << 14) | ((nb & 8u) << 21)) * one;
-        }
-    } else if constexpr (ES == 2) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t lo = (bits >> (2 * k)) & 1u, hi = (bits >> (2 * k + 1)) & 1u;
-            w[k] = (lo * one) | ((hi * one) << 16);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = ((bits >> k) & 1u) * one;
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
 // word_bytes: 4 / 8 = bit rows (bit c = column c); 1 = PermutationEnv rows (byte = the column that is set)
 template <int ES>
 __global__ __launch_bounds__(256) void expand_chunks_kernel(const void *packed, int word_bytes, uint64_t n_rows, uint32_t cols,
@@ -169,12 +147,16 @@ static int widen01_impl(const uint8_t *in_dev, uint64_t n, void *out_dev, int ou
 }
 
 // ---------------------------------------------------------------------------------------------
-// sampling: 16 lanes per env (4 envs per wavefront).  Gumbel-max over the unmasked logits with
-// one counter-RNG draw per (env, draw counter, action):
-//   u   = ((rng_draw(seed, env, counter * A + a) >> 41) + 0.5) * 2^-23        in (0, 1), exact in f32
-//   key = logit[a] - log(-log(u));   action = argmax key (lowest index on ties)
-// which samples exactly softmax(logits) and is independent of how the row is split over lanes.
-// log-prob and entropy come from a second pass over the (cache-resident) row.
+// sampling: 16 lanes per env (4 envs per wavefront), two passes over the (cache-resident) row.
+// An exponential race draws from softmax(logits) exactly:
+//   base = rng_draw(seed, env, counter)                      one 64-bit counter-RNG draw per env
+//   h[a] = hash32(base, a)                                   (lowbias32 rounds keyed by both halves)
+//   u[a] = ((h[a] >> 9) + 0.5) * 2^-23                       in (0, 1), exact in f32
+//   E[a] = -log(u[a]);   action = argmin E[a] / exp(logit[a] - max)      (lowest index on ties)
+// P(a wins) = p_a / sum p: the minimum of independent exponentials with rates p_a.  The same
+// exp(logit - max) terms give the log-prob and the entropy, so the row is exponentiated once.
+// The result does not depend on how the row is split over lanes (min / max are associative; the
+// two f32 sums are reduced in a fixed order).
 // ---------------------------------------------------------------------------------------------
 struct SampleArgs {
     const void *logits;
@@ -184,6 +166,7 @@ struct SampleArgs {
     float *entropy;
     float *values;
     uint64_t ld, B, seed, counter;
+    const uint64_t *clock;  // device clock added to `counter`, or null
     uint32_t A;
     int32_t value_col;
     int32_t act64;
@@ -198,8 +181,15 @@ __device__ inline float logit_to_float<uint16_t>(uint16_t v) { return __uint_as_
 template <>
 __device__ inline float logit_to_float<__half>(__half v) { return __half2float(v); }
 
-__host__ __device__ inline float sample_uniform(uint64_t seed, uint64_t env, uint64_t k) {
-    return ((float)(uint32_t)(rng_draw(seed, env, k) >> 41) + 0.5f) * (1.0f / 8388608.0f);
+__host__ __device__ inline float sample_uniform(uint64_t base, uint32_t a) {
+    uint32_t x = (uint32_t)(base >> 32) + a * 0x9E3779B9u;
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= (uint32_t)base;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f);
 }
 
 template <typename LT>
@@ -210,45 +200,42 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     const uint64_t env = live ? env_raw : a.B - 1;  // idle sub-groups recompute the last env, write nothing
     const LT *row = reinterpret_cast<const LT *>(a.logits) + env * a.ld;
     const uint8_t *mrow = a.mask ? a.mask + env * a.A : nullptr;
-    const float NEG_INF = -__builtin_huge_valf();
-    float m = NEG_INF, best_key = NEG_INF, best_l = 0.0f;
-    uint32_t best_a = 0xFFFFFFFFu;
+    const float INF = __builtin_huge_valf();
+    float m = -INF;
     for (uint32_t i = sl; i < a.A; i += 16) {
         if (mrow && !mrow[i]) continue;
-        const float l = logit_to_float<LT>(row[i]);
-        m = fmaxf(m, l);
-        const float u = sample_uniform(a.seed, env, a.counter * a.A + i);
-        const float key = l - logf(-logf(u));
-        if (key > best_key || best_a == 0xFFFFFFFFu) {
-            best_key = key;
-            best_a = i;
-            best_l = l;
-        }
+        m = fmaxf(m, logit_to_float<LT>(row[i]));
     }
 #pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
-        const float ok = __shfl_xor(best_key, off, 16), ol = __shfl_xor(best_l, off, 16), om = __shfl_xor(m, off, 16);
-        const uint32_t oa = __shfl_xor(best_a, off, 16);
-        m = fmaxf(m, om);
-        const bool take = oa != 0xFFFFFFFFu && (best_a == 0xFFFFFFFFu || ok > best_key || (ok == best_key && oa < best_a));
-        if (take) {
-            best_key = ok;
-            best_a = oa;
-            best_l = ol;
-        }
-    }
-    float ssum = 0.0f, wsum = 0.0f;
+    for (int off = 8; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 16));
+    const uint64_t base = rng_draw(a.seed, env, a.counter + clock_of(a.clock));
+    float best_q = INF, best_d = 0.0f, ssum = 0.0f, wsum = 0.0f;
+    uint32_t best_a = 0xFFFFFFFFu;
     for (uint32_t i = sl; i < a.A; i += 16) {
         if (mrow && !mrow[i]) continue;
         const float d = logit_to_float<LT>(row[i]) - m;
         const float ex = expf(d);
         ssum += ex;
         wsum += ex * d;
+        const float q = -logf(sample_uniform(base, i)) / ex;  // ex == 0 (logit far below the max): q = inf, never wins
+        if (q < best_q || best_a == 0xFFFFFFFFu) {
+            best_q = q;
+            best_a = i;
+            best_d = d;
+        }
     }
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) {
+        const float oq = __shfl_xor(best_q, off, 16), od = __shfl_xor(best_d, off, 16);
+        const uint32_t oa = __shfl_xor(best_a, off, 16);
         ssum += __shfl_xor(ssum, off, 16);
         wsum += __shfl_xor(wsum, off, 16);
+        const bool take = oa != 0xFFFFFFFFu && (best_a == 0xFFFFFFFFu || oq < best_q || (oq == best_q && oa < best_a));
+        if (take) {
+            best_q = oq;
+            best_a = oa;
+            best_d = od;
+        }
     }
     if (!live || sl != 0) return;
     const bool none = best_a == 0xFFFFFFFFu;  // every action masked: the env is finished (clifford.rs:349-351)
@@ -256,7 +243,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     if (a.act64) reinterpret_cast<int64_t *>(a.actions)[env] = act;
     else reinterpret_cast<int32_t *>(a.actions)[env] = (int32_t)act;
     const float log_s = logf(ssum);
-    if (a.logp) a.logp[env] = none ? 0.0f : (best_l - m) - log_s;
+    if (a.logp) a.logp[env] = none ? 0.0f : best_d - log_s;
     if (a.entropy) a.entropy[env] = none ? 0.0f : log_s - wsum / ssum;
     if (a.values && a.value_col >= 0) a.values[env] = logit_to_float<LT>(row[a.value_col]);
 }
@@ -312,6 +299,13 @@ int qg_vec_observe_dense_as(qg_vec *v, void *out_dev, int out_dtype, void *strea
         if (rc != QG_OK) return rc;
         return widen01_impl(reinterpret_cast<const uint8_t *>(v->scratch), v->B * obs, out_dev, out_dtype, (hipStream_t)stream);
     }
+    uint32_t es = 0, one = 0;
+    if (!dtype_info(out_dtype, es, one)) return set_error(QG_ERR_INVALID, "unknown output dtype %d", out_dtype);
+    if (v->layout == LAYOUT_TILE && v->D % (16 / es) == 0 && (reinterpret_cast<uintptr_t>(out_dev) & 15u) == 0) {
+        // hot layout: expand straight from the resident tiles, no packed intermediate
+        HIP_TRY(qm_export_typed(v->state, v->B, v->N, v->D, v->nxp, v->has_z, out_dev, es, one, (hipStream_t)stream));
+        return QG_OK;
+    }
     rc = ensure_scratch_public(v, v->B * (uint64_t)info.packed_words_per_env * info.packed_word_bytes);
     if (rc != QG_OK) return rc;
     rc = qg_vec_observe_packed(v, v->scratch, stream);
@@ -321,8 +315,8 @@ int qg_vec_observe_dense_as(qg_vec *v, void *out_dev, int out_dtype, void *strea
 }
 
 int qg_sample_actions(const void *logits_dev, int logits_dtype, uint64_t ld, uint64_t batch, uint32_t num_actions, const uint8_t *mask_dev,
-                      uint64_t seed, uint64_t counter, void *actions_dev, int action_dtype, float *logp_dev, float *entropy_dev,
-                      int32_t value_col, float *values_dev, void *stream) {
+                      uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev, int action_dtype, float *logp_dev,
+                      float *entropy_dev, int32_t value_col, float *values_dev, void *stream) {
     if (!logits_dev || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
     if (num_actions == 0 || ld < num_actions) return set_error(QG_ERR_INVALID, "bad logits shape");
     if (action_dtype != QG_ACT_I32 && action_dtype != QG_ACT_I64) return set_error(QG_ERR_INVALID, "bad action dtype");
@@ -339,6 +333,7 @@ int qg_sample_actions(const void *logits_dev, int logits_dtype, uint64_t ld, uin
     a.B = batch;
     a.seed = seed ^ 0x73616D70ull;  // "samp": a stream of its own next to reset / coin / perm draws
     a.counter = counter;
+    a.clock = clock_dev;
     a.A = num_actions;
     a.value_col = value_col;
     a.act64 = action_dtype == QG_ACT_I64;

@@ -347,6 +347,7 @@ struct PauliObsArgs {
     uint32_t draw;
     uint64_t seed;
     uint64_t counter;
+    const uint64_t *clock;
 };
 __global__ __launch_bounds__(256) void pauli_export_kernel(PauliObsArgs pa) {
     const ObsArgs &a = pa.o;
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256) void pauli_export_kernel(PauliObsArgs pa) {
         uint32_t pi;
         if (pa.draw) {  // `rng.gen_range(0..qubit_perms.len())` (pauli.rs:660), made reproducible
             pi = pa.perm_in ? (uint32_t)pa.perm_in[env] % pa.n_perms
-                            : (uint32_t)__umul64hi(rng_draw(pa.seed ^ 0x7065726Dull, env, pa.counter), (uint64_t)pa.n_perms);
+                            : (uint32_t)__umul64hi(rng_draw(pa.seed ^ 0x7065726Dull, env, pa.counter + clock_of(pa.clock)), (uint64_t)pa.n_perms);
             if (row == 0) pa.perm_idx[env] = pi;  // current_perm_idx.store (pauli.rs:661)
         } else {
             pi = pa.perm_idx[env];
@@ -513,6 +514,7 @@ hipError_t pauli_export(const qg_vec *v, const ObsArgs &a, hipStream_t s) {
     pa.draw = v->perm_draw ? 1u : 0u;
     pa.seed = v->coin_seed;
     pa.counter = v->observe_counter;
+    pa.clock = v->clock_dev;
     hipLaunchKernelGGL(pauli_export_kernel, dim3(grid_for(a.B * 2ull * a.N, 256)), dim3(256), 0, s, pa);
     return hipGetLastError();
 }

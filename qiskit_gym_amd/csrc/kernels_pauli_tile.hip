@@ -451,6 +451,7 @@ struct PTObsArgs {
     const int32_t *perm_in;
     uint32_t n_perms, draw;
     uint64_t seed, counter;
+    const uint64_t *clock;
 };
 __global__ __launch_bounds__(256) void ptile_export_kernel(PTObsArgs pa) {
     const ObsArgs &a = pa.o;
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(256) void ptile_export_kernel(PTObsArgs pa) {
         uint32_t pi;
         if (pa.draw) {  // `rng.gen_range(0..qubit_perms.len())` (pauli.rs:660), made reproducible
             pi = pa.perm_in ? (uint32_t)pa.perm_in[env] % pa.n_perms
-                            : (uint32_t)__umul64hi(rng_draw(pa.seed ^ 0x7065726Dull, env, pa.counter), (uint64_t)pa.n_perms);
+                            : (uint32_t)__umul64hi(rng_draw(pa.seed ^ 0x7065726Dull, env, pa.counter + clock_of(pa.clock)), (uint64_t)pa.n_perms);
             if (row == 0) pa.perm_idx[env] = pi;  // current_perm_idx.store (pauli.rs:661)
         } else {
             pi = pa.perm_idx[env];
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(256) void ptile_generate_kernel(PTGenArgs ga) {
     if (ga.only_done && !a.done[env]) return;
     const uint32_t N = a.N;
     char *tile = PTLayout<NQ, RM>::tile(a.state, env);
-    PTStream rng{ga.seed ^ 0x7061756Cull, env, 0};
+    PTStream rng{(ga.seed + QG_CLOCK_SEED_STRIDE * clock_of(a.clock)) ^ 0x7061756Cull, env, 0};
     PTState<NQ, RM> s;
 #pragma unroll
     for (int k = 0; k < RM; ++k) s.rx[k] = s.rz[k] = s.rpred[k] = 0;
@@ -790,6 +791,7 @@ hipError_t ptile_export(const qg_vec *v, const ObsArgs &a, hipStream_t s) {
     pa.draw = v->perm_draw ? 1u : 0u;
     pa.seed = v->coin_seed;
     pa.counter = v->observe_counter;
+    pa.clock = v->clock_dev;
     hipLaunchKernelGGL(ptile_export_kernel, dim3(grid_for(a.B * 2ull * a.N, 256)), dim3(256), 0, s, pa);
     return hipGetLastError();
 }
@@ -870,6 +872,7 @@ int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s) 
     ga.nd = v->gen_nd;
     ga.n_cx = v->gen_ncx;
     ga.seed = seed;
+    a.clock = v->clock_dev;
     ga.difficulty = (uint32_t)v->difficulty;
     ga.pauli_difficulty = (uint32_t)(v->difficulty / std::max(v->cfg.pauli_diff_scale, 1));  // pauli.rs:557,392
     ga.max_paulis = v->rmax_generate;

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
         depth = depth > 0 ? depth - 1 : 0;          // clifford.rs:342
         if constexpr (INV) {                        // maybe_random_invert (clifford.rs:262-270, linear_function.rs:227-235)
             const uint32_t coin = a.coins ? a.coins[(uint64_t)t * a.B + env]
-                                          : (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, env, a.step_index + t) >> 63);
+                                          : (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, env, step_clock(a) + t) >> 63);
             if (coin & 1u) {
                 bool fast = false;
                 if constexpr (HAS_Z) {
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
     } else if (a.mode == 2) {  // reset scramble (clifford.rs:306-316)
         for (uint32_t t = 0; t < a.n_draws; ++t) {
             const int64_t act = a.actions ? (int64_t)a.actions[(uint64_t)t * a.B + env]
-                                          : (int64_t)rng_action(a.seed, env, t, a.num_actions);
+                                          : (int64_t)rng_action(init_seed(a), env, t, a.num_actions);
             const uint32_t ops = (act >= 0 && act < (int64_t)a.num_actions) ? a.gates[act].ops : (QM_IDENTITY << 10);
             qm_apply<NXP, HAS_Z>(s, ops);
         }
@@ -528,6 +528,24 @@ __global__ __launch_bounds__(256) void qm_dense32_kernel(ObsArgs a) {
     out[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
+// Dense observation in the policy's dtype straight from the tiles: one thread per 16-byte output
+// chunk (D % (16 / ES) == 0), so a wave's store is 1 KiB contiguous; the 4..16 threads that share a
+// row read the same resident word (cache hit).
+template <int ES>
+__global__ __launch_bounds__(256) void qm_dense_typed_kernel(const uint32_t *state, uint64_t B, uint32_t N, uint32_t D, uint32_t nxp,
+                                                             uint32_t has_z, uint32_t chunks_per_row, uint4 *out, uint32_t one) {
+    constexpr uint32_t EPC = 16 / ES;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t grow = gid / chunks_per_row;  // env * D + row
+    const uint64_t env = grow / D;
+    if (env >= B) return;
+    const uint32_t row = (uint32_t)(grow - env * D), c0 = (uint32_t)(gid - grow * chunks_per_row) * EPC;
+    const uint32_t R = has_z ? 2 * nxp : nxp, slot = qm_slot(row, N, nxp, has_z);
+    const uint32_t *tile = state + (env >> 6) * (uint64_t)(R * 64);
+    const uint32_t w = tile[((slot >> 2) * 64 + (uint32_t)(env & 63)) * 4 + (slot & 3)];
+    out[gid] = expand_chunk<ES>((w >> c0) & ((1u << EPC) - 1u), one);
+}
+
 static inline unsigned grid_for(uint64_t threads, unsigned block) { return (unsigned)((threads + block - 1) / block); }
 
 template <int NXP, bool HAS_Z>
@@ -589,6 +607,20 @@ hipError_t qm_export(const ObsArgs &a, uint32_t nxp, bool has_z, hipStream_t s) 
         return hipGetLastError();
     }
     hipLaunchKernelGGL(qm_export_kernel, dim3(grid_for(a.B * a.D, 256)), dim3(256), 0, s, a, nxp, has_z ? 1u : 0u);
+    return hipGetLastError();
+}
+
+hipError_t qm_export_typed(const void *state, uint64_t B, uint32_t N, uint32_t D, uint32_t nxp, bool has_z, void *out, uint32_t es,
+                           uint32_t one, hipStream_t s) {
+    if (!B) return hipSuccess;
+    const uint32_t cpr = D / (16 / es);
+    if (cpr == 0 || D % (16 / es) != 0) return hipErrorInvalidValue;
+    const dim3 grid(grid_for(B * D * cpr, 256)), block(256);
+    const uint32_t *st = reinterpret_cast<const uint32_t *>(state);
+    uint4 *o = reinterpret_cast<uint4 *>(out);
+    if (es == 1) hipLaunchKernelGGL(qm_dense_typed_kernel<1>, grid, block, 0, s, st, B, N, D, nxp, has_z ? 1u : 0u, cpr, o, one);
+    else if (es == 2) hipLaunchKernelGGL(qm_dense_typed_kernel<2>, grid, block, 0, s, st, B, N, D, nxp, has_z ? 1u : 0u, cpr, o, one);
+    else hipLaunchKernelGGL(qm_dense_typed_kernel<4>, grid, block, 0, s, st, B, N, D, nxp, has_z ? 1u : 0u, cpr, o, one);
     return hipGetLastError();
 }
 

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void q64_step_kernel(StepArgs a) {
         depth = depth > 0 ? depth - 1 : 0;  // clifford.rs:342
         if constexpr (INV && HAS_Z) {        // maybe_random_invert (clifford.rs:262-270)
             const uint32_t coin = a.coins ? a.coins[(uint64_t)t * a.B + env]
-                                          : (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, env, a.step_index + t) >> 63);
+                                          : (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, env, step_clock(a) + t) >> 63);
             if (coin & 1u) {
                 if (iflags & Q64_FLAG_SYMPLECTIC) {
                     q64_symplectic_inverse<NS>(s, a.N);
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void q64_init_kernel(InitArgs a) {
         }
     } else if (a.mode == 2) {  // reset scramble (clifford.rs:306-316)
         for (uint32_t t = 0; t < a.n_draws; ++t) {
-            const int64_t act = a.actions ? (int64_t)a.actions[(uint64_t)t * a.B + env] : (int64_t)rng_action(a.seed, env, t, a.num_actions);
+            const int64_t act = a.actions ? (int64_t)a.actions[(uint64_t)t * a.B + env] : (int64_t)rng_action(init_seed(a), env, t, a.num_actions);
             const uint32_t ops = (act >= 0 && act < (int64_t)a.num_actions) ? a.gates[act].ops : (Q64_IDENTITY << 12);
             q64_apply<NS, HAS_Z>(s, ops);
         }

@@ -263,6 +263,7 @@ static void fill_init_args(const qg_vec *v, InitArgs &a) {
     a.N = v->N;
     a.log2L = v->log2L;
     a.num_actions = (uint32_t)v->gates.size();
+    a.clock = v->clock_dev;
     a.check_symplectic = ((v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) && (v->flags & F_INVERTS)) ? 1u : 0u;
 }
 
@@ -295,6 +296,7 @@ static void fill_step_args(const qg_vec *v, StepArgs &a) {
     a.B = v->B;
     a.seed = v->coin_seed;
     a.step_index = v->step_index;
+    a.clock = v->clock_dev;
     a.D = v->D;
     a.N = v->N;
     a.log2L = v->log2L;
@@ -705,6 +707,29 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
     int64_t d = (int64_t)v->cfg.depth_slope * v->difficulty;  // clifford.rs:317
     ia.depth_value = (int32_t)std::min<int64_t>(d, v->cfg.max_depth);
     HIP_TRY(launch_init(v, ia, s));
+    return QG_OK;
+}
+
+int qg_vec_set_clock(qg_vec *v, const uint64_t *clock_dev) {
+    if (!v) return set_error(QG_ERR_INVALID, "null argument");
+    if (clock_dev && v->layout == LAYOUT_PAULI && !v->pauli_tile)
+        return set_error(QG_ERR_UNSUPPORTED, "the lane-group PauliEnv family generates targets on the host and cannot follow a device clock");
+    HIP_TRY(hipSetDevice(v->device));
+    HIP_TRY(hipDeviceSynchronize());
+    v->clock_dev = clock_dev;
+    // cached rollout graphs bake the old pointer in
+    for (auto &g : v->graphs) {
+        (void)hipGraphExecDestroy(g.exec);
+        (void)hipGraphDestroy(g.graph);
+    }
+    v->graphs.clear();
+    return QG_OK;
+}
+
+int qg_vec_set_counters(qg_vec *v, uint64_t step_index, uint64_t observe_index) {
+    if (!v) return set_error(QG_ERR_INVALID, "null argument");
+    v->step_index = step_index;
+    v->observe_counter = observe_index;
     return QG_OK;
 }
 

@@ -48,6 +48,7 @@ struct qg_vec {
     int64_t difficulty = 1;
     uint64_t coin_seed = 0;
     uint64_t step_index = 0;
+    const uint64_t *clock_dev = nullptr;  // qg_vec_set_clock (not owned)
 
     // device buffers
     void *state = nullptr;

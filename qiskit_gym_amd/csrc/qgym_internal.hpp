@@ -108,6 +108,7 @@ struct StepArgs {
     float w[4];               // MetricsWeights, F_LAYERS only
     float pauli_layer_reward;
     uint32_t max_rotations;
+    const uint64_t *clock;    // device clock added to every RNG counter (qg_vec_set_clock), or null
 };
 
 // state (re)initialisation
@@ -136,7 +137,16 @@ struct InitArgs {
     uint32_t check_symplectic; // TILE layout with add_inverts: record whether the state is symplectic
     uint32_t only_done;        // reset only the envs whose `done` flag is set (auto-reset between episodes)
     uint32_t *nonsymp_flag;    // set_state with add_inverts: or-ed to 1 when some env is not symplectic
+    const uint64_t *clock;     // device clock: the scramble seed becomes seed + 0x9E3779B9 * clock (qg_vec_set_clock)
 };
+
+// A handle may be given a device-resident clock (qg_vec_set_clock).  Launches replayed from a
+// captured graph carry their RNG counters as baked-in kernel arguments; adding the clock, which the
+// graph's owner advances between replays, keeps every replay's draws distinct and reproducible.
+#define QG_CLOCK_SEED_STRIDE 0x9E3779B9ull
+__device__ inline uint64_t clock_of(const uint64_t *c) { return c ? *c : 0ull; }
+__device__ inline uint64_t step_clock(const StepArgs &a) { return a.step_index + clock_of(a.clock); }
+__device__ inline uint64_t init_seed(const InitArgs &a) { return a.seed + QG_CLOCK_SEED_STRIDE * clock_of(a.clock); }
 
 struct ObsArgs {
     const void *state;
@@ -156,6 +166,9 @@ hipError_t rows_export(const ObsArgs &a, bool word64, hipStream_t s);
 hipError_t qm_step(const StepArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
 hipError_t qm_init(const InitArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
 hipError_t qm_export(const ObsArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
+// dense {0,1} observation in an element type of `elem_size` bytes whose 1 is the bit pattern `one`
+hipError_t qm_export_typed(const void *state, uint64_t B, uint32_t N, uint32_t D, uint32_t nxp, bool has_z, void *out, uint32_t elem_size,
+                           uint32_t one, hipStream_t s);
 
 hipError_t q64_step(const StepArgs &a, uint32_t ns, bool has_z, hipStream_t s);
 hipError_t q64_init(const InitArgs &a, uint32_t ns, bool has_z, hipStream_t s);

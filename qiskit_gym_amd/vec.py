@@ -119,6 +119,19 @@ class VecEnv:
         """reset() only the envs whose episode is over (`done` set); stream-ordered, no host sync."""
         _lib.check(self._L.qg_vec_reset_done(self._h, int(seed) & (2**64 - 1), _stream_ptr()))
 
+    def set_clock(self, clock: Optional[torch.Tensor]):
+        """Attach (or detach with None) a device clock: an int64 [1] tensor on this device that every
+        RNG-driven kernel of the handle adds to its counter (`qg_vec_set_clock`) -- what lets a captured
+        hipGraph of resets / steps draw fresh randomness on every replay."""
+        if clock is not None and (clock.dtype != torch.int64 or clock.numel() != 1 or clock.device != self.device):
+            raise ValueError("clock must be an int64 tensor with one element on the env's device")
+        _lib.check(self._L.qg_vec_set_clock(self._h, clock.data_ptr() if clock is not None else None))
+        self._clock = clock  # keep it alive while attached
+
+    def set_counters(self, step_index: int, observe_index: int = 0):
+        """Host-side RNG counters of the next step (add_inverts coin) and the next PauliEnv observe()."""
+        _lib.check(self._L.qg_vec_set_counters(self._h, int(step_index), int(observe_index)))
+
     def reset_with(self, actions: torch.Tensor):
         """actions: int32 [difficulty, B] scramble draws (the reference's reset() RNG made explicit)."""
         a = actions.to(device=self.device, dtype=torch.int32).contiguous().view(-1, self.batch)

@@ -9,17 +9,26 @@ SAMPLE_STREAM = 0x73616D70
 def sample_uniforms(seed: int, batch: int, counter: int, num_actions: int) -> np.ndarray:
     """u[e, a] exactly as qg_sample_actions builds it (f32)."""
     env = np.arange(batch, dtype=np.uint64)
-    u = np.zeros((batch, num_actions), dtype=np.float32)
-    for a in range(num_actions):
-        d = rng_draw((seed ^ SAMPLE_STREAM) & (2**64 - 1), env, counter * num_actions + a)
-        u[:, a] = (np.asarray(d >> np.uint64(41), dtype=np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
-    return u
+    base = rng_draw((seed ^ SAMPLE_STREAM) & (2**64 - 1), env, counter)
+    hi = (base >> np.uint64(32)).astype(np.uint32)[:, None]
+    lo = (base & np.uint64(0xFFFFFFFF)).astype(np.uint32)[:, None]
+    a = np.arange(num_actions, dtype=np.uint32)[None, :]
+    with np.errstate(over="ignore"):
+        x = hi + a * np.uint32(0x9E3779B9)
+        x ^= x >> np.uint32(16)
+        x *= np.uint32(0x7FEB352D)
+        x ^= lo
+        x ^= x >> np.uint32(15)
+        x *= np.uint32(0x846CA68B)
+        x ^= x >> np.uint32(16)
+    return ((x >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
 
 
-def gumbel_keys(logits: np.ndarray, u: np.ndarray, mask=None) -> np.ndarray:
-    keys = logits.astype(np.float64) - np.log(-np.log(u.astype(np.float64)))
+def race_keys(logits: np.ndarray, u: np.ndarray, mask=None) -> np.ndarray:
+    """log of the exponential-race times, f64: the sampled action is the argmin."""
+    keys = np.log(-np.log(u.astype(np.float64))) - logits.astype(np.float64)
     if mask is not None:
-        keys = np.where(mask.astype(bool), keys, -np.inf)
+        keys = np.where(mask.astype(bool), keys, np.inf)
     return keys
 
 

@@ -1,5 +1,5 @@
 """Collector kernels (kernels_collect.hip) against their numpy restatements: observation expansion
-(bit-exact), action sampling (exact argmax of the same Gumbel keys, log-prob / entropy to f32
+(bit-exact), action sampling (exact winner of the same exponential race, log-prob / entropy to f32
 round-off, distribution test), GAE (bit-exact f32)."""
 import numpy as np
 import pytest
@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-from collect_ref import gae_f32, gumbel_keys, log_softmax, sample_uniforms  # noqa: E402
+from collect_ref import gae_f32, log_softmax, race_keys, sample_uniforms  # noqa: E402
 from util import f32_bits, grid_gateset, line_gateset  # noqa: E402
 
 DTYPES = [torch.int8, torch.bfloat16, torch.float16, torch.float32]
@@ -59,7 +59,7 @@ def test_observe_as_equals_the_int8_observation(kind, n, dtype):
 
 @pytest.mark.parametrize("ldt", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("A,pad", [(170, 6), (12, 0), (1, 0), (37, 3)])
-def test_sample_actions_is_the_argmax_of_the_gumbel_keys(ldt, A, pad):
+def test_sample_actions_is_the_winner_of_the_exponential_race(ldt, A, pad):
     from qiskit_gym_amd.collector import sample_actions
 
     B, seed, counter = 3000, 1234, 17
@@ -69,10 +69,10 @@ def test_sample_actions_is_the_argmax_of_the_gumbel_keys(ldt, A, pad):
     acts, logp, ent, vals = sample_actions(full, seed, counter, num_actions=A, value_col=(A if pad else None))
     torch.cuda.synchronize()
     logits = full[:, :A].float().cpu().numpy()
-    keys = gumbel_keys(logits, sample_uniforms(seed, B, counter, A))
+    keys = race_keys(logits, sample_uniforms(seed, B, counter, A))
     order = np.sort(keys, axis=1)
-    margin = order[:, -1] - order[:, -2] if A > 1 else np.full(B, np.inf)
-    want = keys.argmax(axis=1)
+    margin = order[:, 1] - order[:, 0] if A > 1 else np.full(B, np.inf)
+    want = keys.argmin(axis=1)
     got = acts.cpu().numpy()
     clear = margin > 1e-4  # f32 log vs f64 log may reorder keys that are this close (none or a handful)
     assert clear.mean() > 0.99
@@ -109,10 +109,11 @@ def test_sample_actions_respects_masks_and_int32_output():
     assert (a[~some] == 0).all() and (logp.cpu().numpy()[~some] == 0).all()
     lsm = log_softmax(logits.cpu().numpy(), m)
     np.testing.assert_allclose(logp.cpu().numpy()[some], lsm[np.arange(B), a][some], atol=2e-5, rtol=0)
-    keys = gumbel_keys(logits.cpu().numpy(), sample_uniforms(9, B, 0, A), m)
+    keys = race_keys(logits.cpu().numpy(), sample_uniforms(9, B, 0, A), m)
     srt = np.sort(keys, axis=1)
-    clear = some & ((srt[:, -1] - srt[:, -2] > 1e-4) | ~np.isfinite(srt[:, -2]))
-    np.testing.assert_array_equal(a[clear], keys.argmax(axis=1)[clear])
+    with np.errstate(invalid="ignore"):
+        clear = some & ((srt[:, 1] - srt[:, 0] > 1e-4) | ~np.isfinite(srt[:, 1]))
+    np.testing.assert_array_equal(a[clear], keys.argmin(axis=1)[clear])
 
 
 def test_sample_actions_follows_softmax():

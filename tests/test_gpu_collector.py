@@ -45,6 +45,7 @@ def test_collector_trajectories_replay_on_the_oracle(store_obs):
             assert o.reward_bits() == int(f32_bits(rew[t, e])), (t, e)
             assert int(o.is_final()) == int(done[t, e]), (t, e)
     assert n_episodes > B  # several episodes per env (depth_slope * difficulty = 4 steps)
+    assert col.steps_done == T
     assert torch.isfinite(ro.logp).all() and torch.isfinite(ro.values).all() and (ro.logp <= 0).all() and (ro.entropy >= 0).all()
     # the policy input the collector built is the observation; the sampled log-probs are the policy's
     logits, value = col.policy(torch.from_numpy(obs[T - 1]).cuda().float())
@@ -87,3 +88,41 @@ def test_collector_runs_pauli_and_generic_policies():
     assert torch.isfinite(ro.advantages).all() and ro.last_values is None
     with pytest.raises(ValueError):
         RolloutCollector(env, Tiny(), store_obs="packed")
+
+
+
+@pytest.mark.parametrize("kind,n,kw", [("clifford", 4, dict(add_inverts=True)), ("linear_function", 6, dict(add_inverts=False)),
+                                       ("pauli", 5, dict(max_rotations=3, depth_slope=1))])
+def test_graph_replays_collect_the_same_rollouts_as_eager_calls(kind, n, kw):
+    """use_graph=True: the first call runs eagerly and captures, later calls replay one hipGraph.  The
+    device clock makes every replay draw fresh resets / actions / inversion coins, and they are the
+    very draws the eager collector makes at the same step numbers."""
+    from qiskit_gym_amd.collector import BasicPolicy, RolloutCollector
+    from qiskit_gym_amd.vec import VecEnv
+
+    B, T, calls = 160, 6, 4
+    gs = line_gateset(kind, n)
+    cfg = dict(add_perms=False, track_solution=False, difficulty=3, **kw)
+    rollouts = {}
+    for mode in (False, True):
+        env = VecEnv(kind, n, gs, B, **cfg)
+        torch.manual_seed(3)
+        pol = BasicPolicy(env.obs_shape_[0] * env.obs_shape_[1], len(gs), embedding_size=64, common=32)
+        col = RolloutCollector(env, pol, dtype=torch.float32, seed=21, use_graph=mode)
+        got = []
+        for _ in range(calls):
+            ro = col.collect(T)
+            torch.cuda.synchronize()
+            got.append({k: getattr(ro, k).clone() for k in ("obs", "actions", "logp", "values", "rewards", "dones", "advantages")})
+        env.sync()
+        assert col.steps_done == calls * T
+        rollouts[mode] = got
+    for k in range(calls):
+        for name, eager in rollouts[False][k].items():
+            if eager.dtype.is_floating_point:  # the GEMMs may pick different kernels under capture
+                torch.testing.assert_close(rollouts[True][k][name], eager, atol=1e-4, rtol=1e-4, msg=lambda m: f"call {k} {name}: {m}")
+            else:
+                assert torch.equal(rollouts[True][k][name], eager), (k, name)
+    # successive rollouts differ (the clock advanced)
+    assert not torch.equal(rollouts[True][1]["actions"], rollouts[True][2]["actions"])
+    assert sum(int(r["dones"].sum()) for r in rollouts[True]) > B

@@ -9,10 +9,10 @@ from qiskit_gym_amd.collector import BasicPolicy, RolloutCollector
 from qiskit_gym_amd.vec import VecEnv
 from util import line_gateset
 
-for B in (8192, 65536):
+for B, store, graph in ((1024, "packed", False), (1024, "packed", True), (8192, "packed", False), (8192, "packed", True), (65536, "dense", False), (65536, "packed", False), (65536, "packed", True)):
     gs = line_gateset("clifford", 16)
     env = VecEnv("clifford", 16, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=32)
-    col = RolloutCollector(env, BasicPolicy(1024, len(gs)), dtype=torch.bfloat16, seed=1)
+    col = RolloutCollector(env, BasicPolicy(1024, len(gs)), dtype=torch.bfloat16, seed=1, store_obs=store, use_graph=graph)
     T = 32
     ro = col.collect(T)
     torch.cuda.synchronize()
@@ -22,5 +22,5 @@ for B in (8192, 65536):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     env.sync()
-    print(f"B={B}: {3 * T * B / dt:.3e} env-steps/s with the policy in the loop ({dt / (3 * T) * 1e6:.0f} us per step), "
+    print(f"B={B} obs stored {store}{' hipGraph' if graph else ''}: {3 * T * B / dt:.3e} env-steps/s with the policy in the loop ({dt / (3 * T) * 1e6:.0f} us per step), "
           f"success rate in last rollout {float(ro.dones.float().mean()):.3f} done/step")
