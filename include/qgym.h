@@ -131,6 +131,10 @@ typedef struct {
 #define QG_FAULT_SINGULAR 1u     /* inverse of a singular matrix requested (clifford.rs:155 panic) */
 #define QG_FAULT_ZERO_WEIGHT 2u  /* weight-0 rotation in the front layer (pauli_network.rs:114 unwrap) */
 #define QG_FAULT_BAD_STATE 4u    /* set_state produced an unusable state (e.g. non-permutation) */
+#define QG_FAULT_SOLUTION_OVERFLOW 8u /* track_solution: more entries than an episode can produce were logged (the
+                                    log holds the max_depth steps an episode can last -- PauliEnv: plus one entry per
+                                    rotation; the reference's Vec grows without bound when a caller keeps stepping a
+                                    finished env) */
 
 /* Build B environments, all in the constructor state (identity, depth 1, success, reward 1.0;
  * clifford.rs:214-245), on GPU `device`. */
@@ -229,7 +233,10 @@ int qg_vec_pauli_num_perms(const qg_vec *v);
 int qg_vec_sync(qg_vec *v, void *stream);
 
 /* Solution log (Env::solution, clifford.rs:376-381 / pauli.rs:685-719) of env e, host side.
- * Returns the length (may exceed cap) or a negative status. */
+ * Returns the length (may exceed cap) or a negative status.  Entries are kept as 32-bit words on
+ * the device: an out-of-range action the reference would log verbatim (clifford.rs:334-340) is
+ * reported exactly when it is below 2^32 - 1; negative or larger ones are reported as
+ * UINT64_MAX (what `-1 as usize` is). */
 int64_t qg_vec_solution(qg_vec *v, uint64_t env, uint64_t *out, size_t cap);
 
 /* ------------------------------------------------------------------------------------------

@@ -12,6 +12,11 @@ __device__ inline int64_t load_action(const void *actions, uint64_t idx, bool ac
                  : (int64_t) reinterpret_cast<const int32_t *>(actions)[idx];
 }
 
+// Solution-log word of an action (clifford.rs:334-340 pushes the action verbatim, valid or not):
+// the log is 32-bit, so anything a `usize` action could hold beyond 2^32 - 2 -- and a negative
+// int64, which `as usize` turns into 2^64 - 1 -- saturates to 0xFFFFFFFF (read back as UINT64_MAX).
+__device__ inline uint32_t sol_word(int64_t act) { return (act < 0 || act > 0xFFFFFFFEll) ? 0xFFFFFFFFu : (uint32_t)act; }
+
 // Dense {0,1} elements from packed bits: one 16-byte chunk = 16 / ES elements of ES bytes each.
 // `one`: the bit pattern of 1 in the output dtype (int8 1, bf16 0x3F80, f16 0x3C00, f32 0x3F800000)
 template <int ES>

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void pauli_step_kernel(PauliArgs pa) {
         if ((a.flags & F_TRACK) && in_range) {  // pauli.rs:612-626 (only for a valid action)
             const int32_t nf = sol_n;
             if ((uint32_t)nf + 1u + n_removed <= a.sol_cap) {
-                if (leader) a.sol[env * a.sol_cap + (uint32_t)nf] = (uint32_t)act;
+                if (leader) a.sol[env * a.sol_cap + (uint32_t)nf] = sol_word(act);
                 if (valid && p.rem_seq != ~0u) {
                     // the phase is read after the whole gate has been applied (pauli.rs:618)
                     const uint32_t ph = rot_phase(p.rx, p.rz, p.rph, N);

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void ptile_step_kernel(PTArgs pa) {
 
         if (FEAT && (a.flags & F_TRACK) && in_range) {  // pauli.rs:612-626
             if (log) {
-                a.sol[env * a.sol_cap + (uint32_t)sol_n] = (uint32_t)act;
+                a.sol[env * a.sol_cap + (uint32_t)sol_n] = sol_word(act);
                 // phase_mult is read after the whole gate has been applied (pauli.rs:618)
 #pragma unroll
                 for (int k = 0; k < RM; ++k) {

@@ -359,8 +359,8 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
 
         if (FEAT && (a.flags & F_TRACK)) {  // clifford.rs:334-340: the inverse-frame list grows from the back
             if ((uint32_t)(sol_n + sol_b) < a.sol_cap) {
-                if (INV && (iflags & QM_FLAG_INVERTED)) a.sol[env * a.sol_cap + a.sol_cap - 1 - (uint32_t)sol_b++] = (uint32_t)act;
-                else a.sol[env * a.sol_cap + (uint32_t)sol_n++] = (uint32_t)act;
+                if (INV && (iflags & QM_FLAG_INVERTED)) a.sol[env * a.sol_cap + a.sol_cap - 1 - (uint32_t)sol_b++] = sol_word(act);
+                else a.sol[env * a.sol_cap + (uint32_t)sol_n++] = sol_word(act);
             } else {
                 fault |= 8u;
             }

@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256) void q64_step_kernel(StepArgs a) {
         dirty |= q64_apply<NS, HAS_Z>(s, g.ops);  // clifford.rs:331
         if (EXTRA && (a.flags & F_TRACK)) {  // clifford.rs:334-340
             if ((uint32_t)(sol_n + sol_b) < a.sol_cap) {
-                if (INV && (iflags & Q64_FLAG_INVERTED)) a.sol[env * a.sol_cap + a.sol_cap - 1 - (uint32_t)sol_b++] = (uint32_t)act;
-                else a.sol[env * a.sol_cap + (uint32_t)sol_n++] = (uint32_t)act;
+                if (INV && (iflags & Q64_FLAG_INVERTED)) a.sol[env * a.sol_cap + a.sol_cap - 1 - (uint32_t)sol_b++] = sol_word(act);
+                else a.sol[env * a.sol_cap + (uint32_t)sol_n++] = sol_word(act);
             } else {
                 fault |= 8u;
             }

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void word_step_kernel(StepArgs a) {
             int32_t nf = a.sol_len[env * 2], nb = a.sol_len[env * 2 + 1];
             if ((uint32_t)(nf + nb) < a.sol_cap) {
                 uint32_t pos = inverted ? a.sol_cap - 1 - (uint32_t)nb : (uint32_t)nf;
-                a.sol[env * a.sol_cap + pos] = (uint32_t)act;
+                a.sol[env * a.sol_cap + pos] = sol_word(act);
                 a.sol_len[env * 2 + (inverted ? 1 : 0)] = (inverted ? nb : nf) + 1;
             } else {
                 fault |= 8u;

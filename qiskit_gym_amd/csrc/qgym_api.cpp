@@ -924,7 +924,7 @@ int qg_vec_sync(qg_vec *v, void *stream) {
             const char *what = (err[e] & QG_FAULT_SINGULAR)      ? "singular matrix in inverse() (reference panics, clifford.rs:155)"
                                : (err[e] & QG_FAULT_ZERO_WEIGHT) ? "weight-0 rotation in the front layer (reference panics, pauli_network.rs:114)"
                                : (err[e] & QG_FAULT_BAD_STATE)   ? "set_state produced an unusable state"
-                                                                 : "solution log overflow";
+                                                                 : "solution log overflow (QG_FAULT_SOLUTION_OVERFLOW)";
             return set_error(QG_ERR_PANIC, "env %llu: %s (fault bits 0x%x)", (unsigned long long)e, what, err[e]);
         }
     return QG_OK;
@@ -944,11 +944,12 @@ int64_t qg_vec_solution(qg_vec *v, uint64_t env, uint64_t *out, size_t cap) {
     }
     // solution ++ reverse(solution_inv) (clifford.rs:376-381): the inverse-frame pushes were
     // written from the back of the row, so reading the tail forwards is the reversed list.
+    auto widen = [](uint32_t w) { return w == 0xFFFFFFFFu ? ~0ull : (uint64_t)w; };  // saturated invalid action
     size_t n = 0;
     for (int32_t i = 0; i < len[0]; ++i, ++n)
-        if (n < cap && out) out[n] = row[i];
+        if (n < cap && out) out[n] = widen(row[i]);
     for (uint32_t i = v->sol_cap - (uint32_t)len[1]; i < v->sol_cap; ++i, ++n)
-        if (n < cap && out) out[n] = row[i];
+        if (n < cap && out) out[n] = widen(row[i]);
     return (int64_t)n;
 }
 
