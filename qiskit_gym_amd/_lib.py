@@ -79,7 +79,7 @@ EXPORTED_SYMBOLS = [
     "qg_vec_set_state", "qg_vec_get_state", "qg_vec_reset", "qg_vec_reset_done", "qg_vec_set_clock", "qg_vec_set_counters", "qg_vec_reset_with", "qg_vec_step", "qg_vec_rollout", "qg_vec_rollout_ring",
     "qg_vec_observe_dense", "qg_vec_observe_packed", "qg_vec_masks", "qg_vec_pauli_reset_from", "qg_vec_pauli_observe_dense", "qg_vec_pauli_num_perms", "qg_vec_sync",
     "qg_vec_solution",
-    "qg_vec_observe_dense_as", "qg_expand_packed", "qg_sample_actions", "qg_gae",
+    "qg_vec_observe_dense_as", "qg_expand_packed", "qg_widen_dense", "qg_sample_actions", "qg_gae",
     "qg_env_create", "qg_env_clone", "qg_env_destroy", "qg_env_num_actions", "qg_env_obs_shape",
     "qg_env_set_difficulty", "qg_env_get_difficulty", "qg_env_set_state", "qg_env_reset", "qg_env_step",
     "qg_env_step_coin", "qg_env_masks", "qg_env_is_final", "qg_env_reward", "qg_env_success", "qg_env_observe",
@@ -142,6 +142,7 @@ def load():
     L.qg_vec_observe_dense_as.argtypes = [vp, vp, C.c_int, vp]
     L.qg_expand_packed.argtypes = [vp, C.c_int, u64, C.c_uint32, vp, C.c_int, vp]
     L.qg_sample_actions.argtypes = [vp, C.c_int, u64, u64, C.c_uint32, vp, u64, u64, vp, vp, C.c_int, vp, vp, C.c_int32, vp, vp]
+    L.qg_widen_dense.argtypes = [vp, u64, vp, C.c_int, vp]
     L.qg_vec_set_clock.argtypes = [vp, vp]
     L.qg_vec_set_counters.argtypes = [vp, u64, u64]
     L.qg_gae.argtypes = [vp, vp, vp, vp, C.c_float, C.c_float, sz, u64, vp, vp, vp]

@@ -211,7 +211,7 @@ class RolloutCollector:
             env.observe(out=ro.obs[t].view(env.batch, *env.obs_shape_))
             if env.env_kind == "pauli":
                 # PauliEnv.observe() with add_perms draws a permutation (pauli.rs:657-662): observe once
-                self._x.copy_(ro.obs[t])
+                _lib.check(_lib.load().qg_widen_dense(ro.obs[t].data_ptr(), ro.obs[t].numel(), self._x.data_ptr(), _DT[self.dtype], _stream_ptr()))
             else:
                 env.observe_as(self.dtype, out=self._x)
 

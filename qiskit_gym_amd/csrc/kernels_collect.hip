@@ -16,14 +16,6 @@
 
 namespace qg {
 
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t _e = (expr);                                                                    \
-        if (_e != hipSuccess) {                                                                    \
-            (void)hipGetLastError();                                                               \
-            return set_error(QG_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(_e));        \
-        }                                                                                          \
-    } while (0)
 
 static inline unsigned blocks_for(uint64_t threads, unsigned block) { return (unsigned)((threads + block - 1) / block); }
 
@@ -282,6 +274,11 @@ extern "C" {
 int qg_expand_packed(const void *packed_dev, int word_bytes, uint64_t n_rows, uint32_t cols, void *out_dev, int out_dtype, void *stream) {
     if (!packed_dev || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
     return expand_packed_impl(packed_dev, word_bytes, n_rows, cols, out_dev, out_dtype, (hipStream_t)stream);
+}
+
+int qg_widen_dense(const int8_t *obs_dev, uint64_t n_elems, void *out_dev, int out_dtype, void *stream) {
+    if (!obs_dev || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
+    return widen01_impl(reinterpret_cast<const uint8_t *>(obs_dev), n_elems, out_dev, out_dtype, (hipStream_t)stream);
 }
 
 int qg_vec_observe_dense_as(qg_vec *v, void *out_dev, int out_dtype, void *stream) {

@@ -414,14 +414,6 @@ static inline unsigned grid_for(uint64_t threads, unsigned block) { return (unsi
 // ------------------------------------------------------------------------------------------------
 // host hooks
 // ------------------------------------------------------------------------------------------------
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t _e = (expr);                                                                    \
-        if (_e != hipSuccess) {                                                                    \
-            (void)hipGetLastError();                                                               \
-            return set_error(QG_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(_e));        \
-        }                                                                                          \
-    } while (0)
 
 int pauli_plan(qg_vec *v) {
     if (v->N > 32) return set_error(QG_ERR_UNSUPPORTED, "PauliEnv: N <= 32 supported, got %u", v->N);

@@ -24,12 +24,20 @@
 // Memory (PTILE layout): tiles of 64 envs (one wavefront), every wave access a contiguous block.
 //   wide    (N > 24 or more than 8 rotations): NQ + RM + 1 groups of 1 KiB, one uint4 per lane:
 //           groups 0..NQ-1 = {X row q, Z row q} (two uint64), groups NQ.. = rotation k
-//           {x, z, phase, pred}, last group = {alive, count, order};
+//           {x, z, phase, pred}, last group = {alive | count << 16, bad, order} where bit q of `bad`
+//           says that qubit q's rows differ from the identity's (kept incrementally: a gate changes
+//           the rows of <= 2 qubits, so `solved` never needs the whole tableau);
 //   compact (N <= 24 and <= 8 rotations, the common case): rows are <= 48 bits, so a qubit's two
 //           rows are 12 bytes {X[0:32), X[32:48) | Z[0:16) << 16, Z[16:48)} (768 B per group,
 //           dwordx3 accesses) and a rotation is 8 bytes {x | pred << 24, z | phase << 24}; N = 20:
-//           320 B per env instead of 464 -- the step is bandwidth-bound, so bytes are time.
+//           320 B per env instead of 464.
+//
+// Two step kernels: ptile_step1_kernel (one step per launch, the env.step() path) keeps only the
+// rotations in registers and gathers / scatters the rows of the gate's <= 2 qubits at per-lane
+// addresses -- ~2x fewer instructions than holding the tableau, and the step is issue-bound at one
+// wave per SIMD; ptile_step_kernel (fused rollouts, T steps per launch) holds everything in VGPRs.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "device_common.hpp"
@@ -96,6 +104,7 @@ struct PTState {
     uint32_t rx[RM], rz[RM], rpred[RM];
     uint32_t plo, phi;  // phase bit-planes: phase of rotation k = ((phi >> k) & 1) * 2 + ((plo >> k) & 1)
     uint32_t alive, count;
+    uint32_t bad;  // bit q: rows X[q] / Z[q] differ from the identity tableau's
     uint64_t order;
 };
 
@@ -107,7 +116,7 @@ struct PTLayout {
     static constexpr uint32_t TILE_BYTES = NQ * QB + RM * RB + 1024u;
     static __device__ inline char *tile(void *state, uint64_t env) { return reinterpret_cast<char *>(state) + (env >> 6) * (uint64_t)TILE_BYTES; }
 
-    static __device__ inline void load_qubit(const char *t, uint32_t lane, int q, uint64_t &X, uint64_t &Z) {
+    static __device__ inline void load_qubit(const char *t, uint32_t lane, uint32_t q, uint64_t &X, uint64_t &Z) {
         if constexpr (COMPACT) {
             const uint32_t *p = reinterpret_cast<const uint32_t *>(t + q * QB + lane * 12u);
             const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
@@ -119,7 +128,7 @@ struct PTLayout {
             Z = (uint64_t)v.z | ((uint64_t)v.w << 32);
         }
     }
-    static __device__ inline void store_qubit(char *t, uint32_t lane, int q, uint64_t X, uint64_t Z) {
+    static __device__ inline void store_qubit(char *t, uint32_t lane, uint32_t q, uint64_t X, uint64_t Z) {
         if constexpr (COMPACT) {
             uint32_t *p = reinterpret_cast<uint32_t *>(t + q * QB + lane * 12u);
             p[0] = (uint32_t)X;
@@ -145,11 +154,10 @@ struct PTLayout {
     static __device__ inline uint4 *meta(char *t, uint32_t lane) { return reinterpret_cast<uint4 *>(t + NQ * QB + RM * RB + lane * 16u); }
 };
 
+// rotations and bookkeeping only (the one-step kernel gathers the two qubits it needs itself)
 template <int NQ, int RM>
-__device__ inline void pt_load(const char *tile, uint32_t lane, PTState<NQ, RM> &s) {
+__device__ inline void pt_load_rotations(const char *tile, uint32_t lane, PTState<NQ, RM> &s) {
     using L = PTLayout<NQ, RM>;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) L::load_qubit(tile, lane, q, s.X[q], s.Z[q]);
     s.plo = s.phi = 0;
 #pragma unroll
     for (int k = 0; k < RM; ++k) {
@@ -159,9 +167,16 @@ __device__ inline void pt_load(const char *tile, uint32_t lane, PTState<NQ, RM> 
         s.phi |= ((ph >> 1) & 1u) << k;
     }
     const uint4 m = *L::meta(const_cast<char *>(tile), lane);
-    s.alive = m.x;
-    s.count = m.y;
+    s.alive = m.x & 0xFFFFu;
+    s.count = m.x >> 16;
+    s.bad = m.y;
     s.order = (uint64_t)m.z | ((uint64_t)m.w << 32);
+}
+template <int NQ, int RM>
+__device__ inline void pt_load(const char *tile, uint32_t lane, PTState<NQ, RM> &s) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) PTLayout<NQ, RM>::load_qubit(tile, lane, (uint32_t)q, s.X[q], s.Z[q]);
+    pt_load_rotations<NQ, RM>(tile, lane, s);
 }
 template <int NQ, int RM>
 __device__ inline void pt_store_rot(char *tile, uint32_t lane, const PTState<NQ, RM> &s, int k) {
@@ -169,28 +184,40 @@ __device__ inline void pt_store_rot(char *tile, uint32_t lane, const PTState<NQ,
 }
 template <int NQ, int RM>
 __device__ inline void pt_store_meta(char *tile, uint32_t lane, const PTState<NQ, RM> &s) {
-    *PTLayout<NQ, RM>::meta(tile, lane) = make_uint4(s.alive, s.count, (uint32_t)s.order, (uint32_t)(s.order >> 32));
+    *PTLayout<NQ, RM>::meta(tile, lane) = make_uint4(s.alive | (s.count << 16), s.bad, (uint32_t)s.order, (uint32_t)(s.order >> 32));
 }
 
-// the gate's composite tableau map on {X[qa], Z[qa], X[qb], Z[qb]}
+// the gate's composite tableau map on {X[qa], Z[qa], X[qb], Z[qb]}: out[k] = xor of the inputs bit 4k+i of m selects
+__device__ inline void pt_mix(uint32_t m, uint64_t xa, uint64_t za, uint64_t xb, uint64_t zb, uint64_t (&out)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t b = m >> (4 * k);
+        out[k] = ((0ull - (uint64_t)(b & 1u)) & xa) ^ ((0ull - (uint64_t)((b >> 1) & 1u)) & za) ^
+                 ((0ull - (uint64_t)((b >> 2) & 1u)) & xb) ^ ((0ull - (uint64_t)((b >> 3) & 1u)) & zb);
+    }
+}
+// `bad` after qubits qa / qb received the rows n[0..3] (qa's rows win when qa == qb)
+__device__ inline uint32_t pt_bad_update(uint32_t bad, uint32_t N, uint32_t qa, uint32_t qb, const uint64_t (&n)[4]) {
+    const uint32_t bb = (uint32_t)(n[2] != (1ull << qb) || n[3] != ((1ull << N) << qb));
+    const uint32_t ba = (uint32_t)(n[0] != (1ull << qa) || n[1] != ((1ull << N) << qa));
+    bad = (bad & ~(1u << qb)) | (bb << qb);
+    return (bad & ~(1u << qa)) | (ba << qa);
+}
 template <int NQ, int RM>
-__device__ inline void pt_apply_tableau(PTState<NQ, RM> &s, uint32_t qa, uint32_t qb, uint32_t m) {
+__device__ inline void pt_apply_tableau(PTState<NQ, RM> &s, uint32_t N, uint32_t qa, uint32_t qb, uint32_t m) {
     const uint64_t xa = tree_select64<NQ>(s.X, qa), za = tree_select64<NQ>(s.Z, qa);
     const uint64_t xb = tree_select64<NQ>(s.X, qb), zb = tree_select64<NQ>(s.Z, qb);
-    auto mix = [&](uint32_t k) -> uint64_t {
-        const uint32_t b = m >> (4 * k);
-        return ((0ull - (uint64_t)(b & 1u)) & xa) ^ ((0ull - (uint64_t)((b >> 1) & 1u)) & za) ^
-               ((0ull - (uint64_t)((b >> 2) & 1u)) & xb) ^ ((0ull - (uint64_t)((b >> 3) & 1u)) & zb);
-    };
-    const uint64_t nxa = mix(0), nza = mix(1), nxb = mix(2), nzb = mix(3);
+    uint64_t n[4];
+    pt_mix(m, xa, za, xb, zb, n);
+    s.bad = pt_bad_update(s.bad, N, qa, qb, n);
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         const bool h0 = qa == (uint32_t)j, h1 = qb == (uint32_t)j;
         uint64_t vx = s.X[j], vz = s.Z[j];
-        vx = h1 ? nxb : vx;  // flat selects; qa's value wins when qa == qb
-        vz = h1 ? nzb : vz;
-        vx = h0 ? nxa : vx;
-        vz = h0 ? nza : vz;
+        vx = h1 ? n[2] : vx;  // flat selects; qa's value wins when qa == qb
+        vz = h1 ? n[3] : vz;
+        vx = h0 ? n[0] : vx;
+        vz = h0 ? n[1] : vz;
         s.X[j] = vx;
         s.Z[j] = vz;
     }
@@ -280,15 +307,20 @@ __device__ inline void pt_clean(PTState<NQ, RM> &s, uint32_t &n_removed, uint32_
     }
 }
 
+// `bad` from the whole tableau (after an upload; the step kernels keep it incrementally)
 template <int NQ, int RM>
-__device__ inline bool pt_solved(const PTState<NQ, RM> &s, uint32_t N) {  // PauliNetwork::solved (:167-173)
-    uint64_t acc[2] = {0, 0};
+__device__ inline uint32_t pt_badmask(const PTState<NQ, RM> &s, uint32_t N) {
+    uint32_t bad = 0;
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
-        acc[0] |= s.X[j] ^ ((uint32_t)j < N ? 1ull << j : 0ull);
-        acc[1] |= s.Z[j] ^ ((uint32_t)j < N ? (1ull << N) << j : 0ull);
+        const uint64_t ix = (uint32_t)j < N ? 1ull << j : 0ull, iz = (uint32_t)j < N ? (1ull << N) << j : 0ull;
+        bad |= (uint32_t)(s.X[j] != ix || s.Z[j] != iz) << j;
     }
-    return s.count == 0 && (acc[0] | acc[1]) == 0;
+    return bad;
+}
+template <int NQ, int RM>
+__device__ inline bool pt_solved(const PTState<NQ, RM> &s) {  // PauliNetwork::solved (:167-173)
+    return s.count == 0 && s.bad == 0;
 }
 
 struct PTArgs {
@@ -316,7 +348,7 @@ __global__ __launch_bounds__(256) void ptile_step_kernel(PTArgs pa) {
     pt_load<NQ, RM>(tile, lane, s);
     int32_t depth = a.depth[env];
     int32_t sol_n = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2] : 0;
-    const uint32_t alive0 = s.alive, count0 = s.count;
+    const uint32_t alive0 = s.alive, count0 = s.count, bad0 = s.bad;
     const uint64_t order0 = s.order;
     uint32_t touched_rot = 0;   // rotations whose record changed while they were alive
     uint32_t dirty_q = 0;       // qubits whose tableau rows changed
@@ -349,7 +381,7 @@ __global__ __launch_bounds__(256) void ptile_step_kernel(PTArgs pa) {
 
         if (in_range) {
             const uint32_t alive_at_gate = s.alive;
-            pt_apply_tableau<NQ, RM>(s, qa, qb, m);
+            pt_apply_tableau<NQ, RM>(s, N, qa, qb, m);
             dirty_q |= (1u << qa) | (1u << qb);
 #pragma unroll 1
             for (uint32_t k = 0; k < 3; ++k) {  // PauliNetwork::act (pauli_network.rs:225-260)
@@ -382,7 +414,7 @@ __global__ __launch_bounds__(256) void ptile_step_kernel(PTArgs pa) {
         }
 
         depth = depth > 0 ? depth - 1 : 0;  // pauli.rs:630
-        solved = pt_solved<NQ, RM>(s, N);
+        solved = pt_solved<NQ, RM>(s);
         const float achieved = solved ? 1.0f : 0.0f;
         const float tmp = achieved - penalty;
         const float bonus = a.pauli_layer_reward * (float)n_removed;
@@ -399,7 +431,107 @@ __global__ __launch_bounds__(256) void ptile_step_kernel(PTArgs pa) {
 #pragma unroll
     for (int k = 0; k < RM; ++k)
         if ((touched_rot >> k) & 1u) pt_store_rot<NQ, RM>(tile, lane, s, k);
-    if (s.alive != alive0 || s.count != count0 || s.order != order0) pt_store_meta<NQ, RM>(tile, lane, s);
+    if (s.alive != alive0 || s.count != count0 || s.order != order0 || s.bad != bad0) pt_store_meta<NQ, RM>(tile, lane, s);
+    a.depth[env] = depth;
+    a.reward[env] = reward;
+    a.done[env] = (uint8_t)(depth == 0 || solved);
+    a.success[env] = (uint8_t)solved;
+    if (FEAT && (a.flags & F_TRACK)) a.sol_len[env * 2] = sol_n;
+    if (fault) atomicOr(&a.error[env], fault);
+}
+
+// One step per launch (PauliEnv::step, pauli.rs:588-635): rotations and bookkeeping in registers,
+// the rows of the gate's qubits gathered from / scattered to the tile at per-lane addresses.
+template <int NQ, int RM, bool FEAT>
+__global__ __launch_bounds__(256) void ptile_step1_kernel(PTArgs pa) {
+    using L = PTLayout<NQ, RM>;
+    const StepArgs &a = pa.s;
+    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    if (env >= a.B) return;
+    const uint32_t N = a.N;
+    char *tile = L::tile(a.state, env);
+
+    int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
+    PTState<NQ, RM> s;
+    pt_load_rotations<NQ, RM>(tile, lane, s);
+    int32_t depth = a.depth[env];
+    int32_t sol_n = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2] : 0;
+    const uint32_t alive0 = s.alive, count0 = s.count, bad0 = s.bad;
+    const uint64_t order0 = s.order;
+    uint32_t touched_rot = 0, fault = 0;
+
+    if (pa.n_perms) {  // actual_action = act_perms[current_perm_idx][action] (pauli.rs:594-599)
+        if (act >= 0 && act < (int64_t)a.num_actions) act = pa.act_perms[(uint64_t)pa.perm_idx[env] * a.num_actions + act];
+        else fault |= 16u;  // the reference indexes act_perms out of bounds here and panics
+    }
+    const bool in_range = act >= 0 && act < (int64_t)a.num_actions;  // pauli.rs:601
+    uint64_t prog = 0;
+    float penalty = 0.0f;
+    if (in_range) {
+        prog = pa.prog[act];
+        penalty = a.gates[act].penalty;
+        if (FEAT && (a.flags & F_LAYERS)) penalty = layers_penalty(a.layers + env * (2 * N + 2), N, a.descs[act], a.w);
+    }
+    const uint32_t qa = (uint32_t)prog & 31u, qb = (uint32_t)(prog >> 5) & 31u, m = (uint32_t)(prog >> 10) & 0xFFFFu;
+    uint32_t n_removed = 0;
+    uint64_t rem_pos[(RM + 7) / 8];
+#pragma unroll
+    for (int i = 0; i < (RM + 7) / 8; ++i) rem_pos[i] = 0;
+    uint32_t *log = nullptr;
+    if (FEAT && (a.flags & F_TRACK) && in_range && (uint32_t)sol_n + 1u + (uint32_t)s.count <= a.sol_cap)
+        log = a.sol + env * a.sol_cap + (uint32_t)sol_n + 1u;  // slot sol_n is the gate itself
+
+    if (in_range) {
+        uint64_t xa, za, xb, zb, n[4];
+        L::load_qubit(tile, lane, qa, xa, za);
+        L::load_qubit(tile, lane, qb, xb, zb);  // one-qubit gates: qb == qa, the same (cached) record
+        pt_mix(m, xa, za, xb, zb, n);
+        if (qb != qa) L::store_qubit(tile, lane, qb, n[2], n[3]);
+        L::store_qubit(tile, lane, qa, n[0], n[1]);
+        s.bad = pt_bad_update(s.bad, N, qa, qb, n);
+        const uint32_t alive_at_gate = s.alive;
+#pragma unroll 1
+        for (uint32_t k = 0; k < 3; ++k) {  // PauliNetwork::act (pauli_network.rs:225-260)
+            const uint32_t mo = (uint32_t)(prog >> (26 + 4 * k)) & 15u;
+            const uint32_t kind = mo & 7u;
+            if (kind == M_NOP) continue;
+            const uint32_t p = (mo & 8u) ? qb : qa, q = (mo & 8u) ? qa : qb;
+            touched_rot |= pt_evolve<NQ, RM>(s, kind, p, q) & alive_at_gate;  // dead rotations are never read again
+            if (kind == M_CNOT) pt_clean<NQ, RM>(s, n_removed, fault, log, rem_pos);
+        }
+    }
+
+    if (FEAT && (a.flags & F_TRACK) && in_range) {  // pauli.rs:612-626
+        if (log) {
+            a.sol[env * a.sol_cap + (uint32_t)sol_n] = sol_word(act);
+#pragma unroll
+            for (int k = 0; k < RM; ++k) {  // phase_mult is read after the whole gate has been applied (pauli.rs:618)
+                const uint32_t pos = (uint32_t)(rem_pos[k / 8] >> (8 * (k % 8))) & 0xFFu;
+                if (pos) {
+                    const uint32_t base = ((s.plo >> k) & 1u) | (((s.phi >> k) & 1u) << 1);
+                    const uint32_t ph = (base + 4u * N - (uint32_t)__popc(s.rx[k] & s.rz[k])) & 3u;  // Pauli::phase (pauli.rs:125-133)
+                    log[pos - 1u] |= (ph == 2u ? 0u : 1u);
+                }
+            }
+            sol_n += 1 + (int32_t)n_removed;
+        } else {
+            fault |= 8u;
+        }
+    }
+
+    depth = depth > 0 ? depth - 1 : 0;  // pauli.rs:630
+    const bool solved = pt_solved<NQ, RM>(s);
+    const float achieved = solved ? 1.0f : 0.0f;
+    const float tmp = achieved - penalty;
+    const float bonus = a.pauli_layer_reward * (float)n_removed;
+    const float reward = tmp + bonus;  // pauli.rs:634
+    if (a.rewards_seq) a.rewards_seq[env] = reward;
+    if (a.dones_seq) a.dones_seq[env] = (uint8_t)(depth == 0 || solved);
+#pragma unroll
+    for (int k = 0; k < RM; ++k)
+        if ((touched_rot >> k) & 1u) pt_store_rot<NQ, RM>(tile, lane, s, k);
+    if (s.alive != alive0 || s.count != count0 || s.order != order0 || s.bad != bad0) pt_store_meta<NQ, RM>(tile, lane, s);
     a.depth[env] = depth;
     a.reward[env] = reward;
     a.done[env] = (uint8_t)(depth == 0 || solved);
@@ -424,7 +556,8 @@ __global__ __launch_bounds__(256) void ptile_init_kernel(PTArgs pa) {
 #pragma unroll
     for (int i = 0; i < (RM + 7) / 8; ++i) rem_pos[i] = 0;
     if (pa.do_clean) pt_clean<NQ, RM>(s, n_removed, fault, nullptr, rem_pos);
-    const bool solved = pt_solved<NQ, RM>(s, a.N);
+    s.bad = pt_badmask<NQ, RM>(s, a.N);
+    const bool solved = pt_solved<NQ, RM>(s);
     pt_store_meta<NQ, RM>(tile, lane, s);
     a.depth[env] = pa.depth_value;
     a.success[env] = (uint8_t)solved;
@@ -503,7 +636,7 @@ __global__ __launch_bounds__(256) void ptile_export_kernel(PTObsArgs pa) {
     if (cols > D) {
         const uint4 m = *reinterpret_cast<const uint4 *>(tile + pa.nq * QB + pa.rm * RB + lane * 16u);
         const uint64_t order = (uint64_t)m.z | ((uint64_t)m.w << 32);
-        const uint32_t shown = m.y < pa.max_rot ? m.y : pa.max_rot;
+        const uint32_t count = m.x >> 16, shown = count < pa.max_rot ? count : pa.max_rot;
         for (uint32_t i = 0; i < shown; ++i) {
             const char *rp = tile + pa.nq * QB + pnib(order, i) * RB;
             uint32_t rx, rz;
@@ -636,8 +769,9 @@ __global__ __launch_bounds__(256) void ptile_generate_kernel(PTGenArgs ga) {
         const uint32_t cost = difficulty - budget, dec = cost > 1 ? cost : 1;
         remaining = remaining > dec ? remaining - dec : 0;
     }
-    s.alive = n_lab >= 32 ? ~0u : ((1u << n_lab) - 1u);
+    s.alive = (1u << n_lab) - 1u;  // n_lab <= RM <= 16
     s.count = n_lab;
+    s.bad = 0;  // the scramble below starts from the identity and keeps `bad` current
     s.order = 0;
 #pragma unroll
     for (int k = 0; k < RM; ++k) s.order |= ((uint32_t)k < n_lab) ? ((uint64_t)k << (4 * k)) : 0ull;
@@ -664,7 +798,7 @@ __global__ __launch_bounds__(256) void ptile_generate_kernel(PTGenArgs ga) {
                 qa = qb = rng.range(N);
                 m = 0x8431u;
             }
-            pt_apply_tableau<NQ, RM>(s, qa, qb, m);
+            pt_apply_tableau<NQ, RM>(s, N, qa, qb, m);
         }
     }
 
@@ -673,7 +807,7 @@ __global__ __launch_bounds__(256) void ptile_generate_kernel(PTGenArgs ga) {
 #pragma unroll
     for (int i = 0; i < (RM + 7) / 8; ++i) rem_pos[i] = 0;
     pt_clean<NQ, RM>(s, n_removed, fault, nullptr, rem_pos);
-    const bool solved = pt_solved<NQ, RM>(s, N);
+    const bool solved = pt_solved<NQ, RM>(s);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) PTLayout<NQ, RM>::store_qubit(tile, lane, q, s.X[q], s.Z[q]);
 #pragma unroll
@@ -698,14 +832,6 @@ __global__ __launch_bounds__(256) void ptile_generate_kernel(PTGenArgs ga) {
 static inline unsigned grid_for(uint64_t threads, unsigned block) { return (unsigned)((threads + block - 1) / block); }
 
 // ---- host hooks ----------------------------------------------------------------------------------
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t _e = (expr);                                                                    \
-        if (_e != hipSuccess) {                                                                    \
-            (void)hipGetLastError();                                                               \
-            return set_error(QG_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(_e));        \
-        }                                                                                          \
-    } while (0)
 
 int ptile_plan(qg_vec *v) {
     v->pt_nq = (v->N + 3u) & ~3u;
@@ -737,8 +863,16 @@ static void fill_pt_args(const qg_vec *v, const StepArgs &a, PTArgs &pa) {
 template <int NQ, int RM>
 static hipError_t pt_launch_step(const PTArgs &pa, hipStream_t s) {
     const dim3 grid(grid_for(pa.s.B, 256)), block(256);
-    if (pa.s.flags & (F_TRACK | F_LAYERS)) hipLaunchKernelGGL((ptile_step_kernel<NQ, RM, true>), grid, block, 0, s, pa);
-    else hipLaunchKernelGGL((ptile_step_kernel<NQ, RM, false>), grid, block, 0, s, pa);
+    static const bool dense_only = getenv("QGYM_PTILE_DENSE") != nullptr;  // development switch: always hold the tableau in registers
+    const bool feat = pa.s.flags & (F_TRACK | F_LAYERS);
+    if (pa.s.T == 1 && !dense_only) {
+        if (feat) hipLaunchKernelGGL((ptile_step1_kernel<NQ, RM, true>), grid, block, 0, s, pa);
+        else hipLaunchKernelGGL((ptile_step1_kernel<NQ, RM, false>), grid, block, 0, s, pa);
+    } else if (feat) {
+        hipLaunchKernelGGL((ptile_step_kernel<NQ, RM, true>), grid, block, 0, s, pa);
+    } else {
+        hipLaunchKernelGGL((ptile_step_kernel<NQ, RM, false>), grid, block, 0, s, pa);
+    }
     return hipGetLastError();
 }
 template <int NQ, int RM>
@@ -914,7 +1048,7 @@ int ptile_upload(qg_vec *v, const HostNet &h, bool do_clean, int32_t depth_value
             }
         }
         const PauliMeta &m = h.meta[e];
-        uint32_t g[4] = {m.alive, m.count, (uint32_t)m.order, (uint32_t)(m.order >> 32)};
+        uint32_t g[4] = {m.alive | (m.count << 16), 0u /* bad: the init kernel computes it */, (uint32_t)m.order, (uint32_t)(m.order >> 32)};
         memcpy(tile + NQ * QB + RM * RB + lane * 16, g, 16);
     }
     HIP_TRY(hipMemcpyAsync(v->state, img.data(), v->state_bytes, hipMemcpyHostToDevice, s));

@@ -218,14 +218,6 @@ int qg_gate_parse(const char *name_in, const int64_t *idx, size_t n, qg_gate *ou
 // ------------------------------------------------------------------------------------------------
 // qg_vec
 // ------------------------------------------------------------------------------------------------
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t _e = (expr);                                                                    \
-        if (_e != hipSuccess) {                                                                    \
-            (void)hipGetLastError();                                                               \
-            return set_error(QG_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(_e));        \
-        }                                                                                          \
-    } while (0)
 
 static int vec_free_buffers(qg_vec *v) {
     void *ptrs[] = {v->state, v->own_depth ? v->depth : nullptr, v->own_reward ? v->reward : nullptr,

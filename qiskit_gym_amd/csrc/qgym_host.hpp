@@ -31,6 +31,16 @@ struct CachedGraph {
 
 int set_error(int code, const char *fmt, ...);
 
+// HIP call inside a function that returns a qg_status
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            (void)hipGetLastError();                                                               \
+            return set_error(QG_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(_e));        \
+        }                                                                                          \
+    } while (0)
+
 }  // namespace qg
 
 struct qg_vec {
