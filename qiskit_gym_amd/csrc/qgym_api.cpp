@@ -223,7 +223,7 @@ static int vec_free_buffers(qg_vec *v) {
     void *ptrs[] = {v->state, v->own_depth ? v->depth : nullptr, v->own_reward ? v->reward : nullptr,
                     v->own_done ? v->done : nullptr, v->own_success ? v->success : nullptr, v->inverted, v->error, v->sol,
                     v->sol_len, v->layers, v->d_gates, v->d_descs, v->scratch, v->rot, v->pmeta, v->d_prog,
-                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp};
+                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &g : v->graphs) {
@@ -256,6 +256,7 @@ static void fill_init_args(const qg_vec *v, InitArgs &a) {
     a.log2L = v->log2L;
     a.num_actions = (uint32_t)v->gates.size();
     a.clock = v->clock_dev;
+    a.bad = v->bad;
     a.check_symplectic = ((v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) && (v->flags & F_INVERTS)) ? 1u : 0u;
 }
 
@@ -289,6 +290,7 @@ static void fill_step_args(const qg_vec *v, StepArgs &a) {
     a.seed = v->coin_seed;
     a.step_index = v->step_index;
     a.clock = v->clock_dev;
+    a.bad = v->bad;
     a.D = v->D;
     a.N = v->N;
     a.log2L = v->log2L;
@@ -458,6 +460,10 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     HIP_TRY_V(hipMalloc(&p->done, batch));
     HIP_TRY_V(hipMalloc(&p->success, batch));
     HIP_TRY_V(hipMalloc(&p->inverted, batch));
+    // TILE layout without add_inverts: the one-step kernel keeps `solved` as a per-env mask (QGYM_TILE_DENSE=1:
+    // development switch that keeps every step on the register-resident kernel)
+    if (v->layout == LAYOUT_TILE && !(v->flags & F_INVERTS) && !getenv("QGYM_TILE_DENSE"))
+        HIP_TRY_V(hipMalloc(&p->bad, sizeof(uint32_t) * batch));
     HIP_TRY_V(hipMalloc(&p->error, sizeof(uint32_t) * batch));
     HIP_TRY_V(hipMalloc(&p->sol_len, sizeof(int32_t) * 2 * batch));
     if (cfg->track_solution) {

@@ -109,6 +109,7 @@ struct StepArgs {
     float pauli_layer_reward;
     uint32_t max_rotations;
     const uint64_t *clock;    // device clock added to every RNG counter (qg_vec_set_clock), or null
+    uint32_t *bad;            // TILE layout, CliffordEnv: bit q = qubit q's rows differ from the identity's (or null)
 };
 
 // state (re)initialisation
@@ -138,6 +139,7 @@ struct InitArgs {
     uint32_t only_done;        // reset only the envs whose `done` flag is set (auto-reset between episodes)
     uint32_t *nonsymp_flag;    // set_state with add_inverts: or-ed to 1 when some env is not symplectic
     const uint64_t *clock;     // device clock: the scramble seed becomes seed + 0x9E3779B9 * clock (qg_vec_set_clock)
+    uint32_t *bad;             // see StepArgs::bad
 };
 
 // A handle may be given a device-resident clock (qg_vec_set_clock).  Launches replayed from a
