@@ -75,6 +75,21 @@ __device__ inline bool q64_solved(const Q64Rows<NS> &s, uint32_t N) {  // cliffo
     return ((acc[0] | acc[1]) | (acc[2] | acc[3])) == 0;
 }
 
+// bit j: qubit j's rows (CliffordEnv) / row j (LinearFunctionEnv) differ from the identity's
+template <int NS, bool HAS_Z>
+__device__ inline uint64_t q64_badmask(const Q64Rows<NS> &s, uint32_t N) {
+    uint64_t bad = 0;
+    if constexpr (HAS_Z) {
+#pragma unroll
+        for (int j = 0; j < NS / 2; ++j)
+            bad |= (uint64_t)(s.r[2 * j] != q64_identity_word<NS, true>(2 * j, N) || s.r[2 * j + 1] != q64_identity_word<NS, true>(2 * j + 1, N)) << j;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) bad |= (uint64_t)(s.r[j] != q64_identity_word<NS, false>(j, N)) << j;
+    }
+    return bad;
+}
+
 // apply one action; returns the mask of 16-byte groups written
 template <int NS, bool HAS_Z>
 __device__ inline uint64_t q64_apply(Q64Rows<NS> &s, uint32_t ops) {
@@ -346,6 +361,88 @@ __global__ __launch_bounds__(256) void q64_step_kernel(StepArgs a) {
     }
     if (INV) a.inverted[env] = (uint8_t)iflags;
     if ((EXTRA || INV) && fault) atomicOr(&a.error[env], fault);
+    if (a.bad) reinterpret_cast<uint64_t *>(a.bad)[env] = q64_badmask<NS, HAS_Z>(s, a.N);  // the one-step kernel may run next
+}
+
+// One step per launch without holding the matrix (see qm_step1_kernel in kernels_qm.hip): the gate's
+// <= 2 groups ({X[q], Z[q]} of a qubit for CliffordEnv, a row pair for LinearFunctionEnv) are gathered
+// and scattered at per-lane addresses, `solved` comes from the incrementally kept 64-bit `bad` mask.
+template <int NS, bool HAS_Z, bool FEAT>
+__global__ __launch_bounds__(256) void q64_step1_kernel(StepArgs a) {
+    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    if (env >= a.B) return;
+    uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Q64Rows<NS>::G * 64);
+    uint64_t *badp = reinterpret_cast<uint64_t *>(a.bad) + env;
+    const int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
+    int32_t depth = a.depth[env];
+    const uint64_t bad0 = *badp;
+    uint64_t bad = bad0;
+    uint32_t fault = 0;
+    int32_t sol_n = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2] : 0;
+    const bool in_range = act >= 0 && act < (int64_t)a.num_actions;  // clifford.rs:324
+    float penalty = 0.0f;
+    if (in_range) {
+        const GateEntry g = a.gates[act];
+        penalty = g.penalty;
+        if (FEAT && (a.flags & F_LAYERS)) penalty = layers_penalty(a.layers + env * (2 * a.N + 2), a.N, a.descs[act], a.w);
+        const uint32_t q0 = g.ops & 63u, q1 = (g.ops >> 6) & 63u, m = (g.ops >> 12) & 0xFFFFu;
+        if (m != Q64_IDENTITY) {
+            constexpr uint32_t gsh = HAS_Z ? 0u : 1u;
+            const uint32_t g0 = q0 >> gsh, g1 = q1 >> gsh;
+            const uint4 va = tile[g0 * 64 + lane], vb = tile[g1 * 64 + lane];
+            uint64_t ua[2] = {(uint64_t)va.x | ((uint64_t)va.y << 32), (uint64_t)va.z | ((uint64_t)va.w << 32)};
+            uint64_t ub[2] = {(uint64_t)vb.x | ((uint64_t)vb.y << 32), (uint64_t)vb.z | ((uint64_t)vb.w << 32)};
+            const uint64_t o0 = 0ull - (uint64_t)(q0 & 1u), o1 = 0ull - (uint64_t)(q1 & 1u);  // LinearFunctionEnv: odd row of the pair
+            const uint64_t x0 = HAS_Z ? ua[0] : ((ua[1] & o0) | (ua[0] & ~o0)), z0 = HAS_Z ? ua[1] : 0ull;
+            const uint64_t x1 = HAS_Z ? ub[0] : ((ub[1] & o1) | (ub[0] & ~o1)), z1 = HAS_Z ? ub[1] : 0ull;
+            auto mix = [&](uint32_t k) -> uint64_t {
+                const uint32_t b = m >> (4 * k);
+                uint64_t o = ((0ull - (uint64_t)(b & 1u)) & x0) ^ ((0ull - (uint64_t)((b >> 2) & 1u)) & x1);
+                if (HAS_Z) o ^= ((0ull - (uint64_t)((b >> 1) & 1u)) & z0) ^ ((0ull - (uint64_t)((b >> 3) & 1u)) & z1);
+                return o;
+            };
+            const uint64_t nx0 = mix(0), nx1 = mix(2), nz0 = HAS_Z ? mix(1) : 0ull, nz1 = HAS_Z ? mix(3) : 0ull;
+            // q1's rows first, then q0's (q0's value wins when q0 == q1, as in q64_apply)
+            if constexpr (HAS_Z) {
+                ub[0] = nx1; ub[1] = nz1;
+            } else {
+                ub[0] = (ub[0] & o1) | (nx1 & ~o1); ub[1] = (nx1 & o1) | (ub[1] & ~o1);
+            }
+            const bool same = g0 == g1;
+            ua[0] = same ? ub[0] : ua[0];
+            ua[1] = same ? ub[1] : ua[1];
+            if constexpr (HAS_Z) {
+                ua[0] = nx0; ua[1] = nz0;
+            } else {
+                ua[0] = (ua[0] & o0) | (nx0 & ~o0); ua[1] = (nx0 & o0) | (ua[1] & ~o0);
+            }
+            if (!same) tile[g1 * 64 + lane] = make_uint4((uint32_t)ub[0], (uint32_t)(ub[0] >> 32), (uint32_t)ub[1], (uint32_t)(ub[1] >> 32));
+            tile[g0 * 64 + lane] = make_uint4((uint32_t)ua[0], (uint32_t)(ua[0] >> 32), (uint32_t)ua[1], (uint32_t)(ua[1] >> 32));
+            const uint64_t zb = 1ull << a.N;
+            const uint64_t b1 = (uint64_t)(nx1 != (1ull << q1) || (HAS_Z && nz1 != (zb << q1)));
+            const uint64_t b0 = (uint64_t)(nx0 != (1ull << q0) || (HAS_Z && nz0 != (zb << q0)));
+            bad = (bad & ~(1ull << q1)) | (b1 << q1);
+            bad = (bad & ~(1ull << q0)) | (b0 << q0);
+        }
+    }
+    if (FEAT && (a.flags & F_TRACK)) {  // clifford.rs:334-340
+        if ((uint32_t)sol_n < a.sol_cap) a.sol[env * a.sol_cap + (uint32_t)sol_n++] = sol_word(act);
+        else fault |= 8u;
+    }
+    depth = depth > 0 ? depth - 1 : 0;  // clifford.rs:342
+    const bool solved = bad == 0;       // clifford.rs:344
+    const float achieved = solved ? 1.0f : 0.0f;
+    const float reward = achieved - penalty;  // clifford.rs:345-346
+    if (a.rewards_seq) a.rewards_seq[env] = reward;
+    if (a.dones_seq) a.dones_seq[env] = (uint8_t)(depth == 0 || solved);
+    if (bad != bad0) *badp = bad;
+    a.depth[env] = depth;
+    a.reward[env] = reward;
+    a.done[env] = (uint8_t)(depth == 0 || solved);
+    a.success[env] = (uint8_t)solved;
+    if (FEAT && (a.flags & F_TRACK)) a.sol_len[env * 2] = sol_n;
+    if (FEAT && fault) atomicOr(&a.error[env], fault);
 }
 
 template <int NS, bool HAS_Z>
@@ -397,6 +494,7 @@ __global__ __launch_bounds__(256) void q64_init_kernel(InitArgs a) {
             if (!symp && a.nonsymp_flag) atomicOr(a.nonsymp_flag, 1u);
         }
     }
+    if (a.bad) reinterpret_cast<uint64_t *>(a.bad)[env] = q64_badmask<NS, HAS_Z>(s, a.N);
     a.depth[env] = a.depth_value;  // reset_internals (clifford.rs:272-283)
     a.success[env] = (uint8_t)solved;
     a.reward[env] = solved ? 1.0f : 0.0f;
@@ -439,6 +537,11 @@ template <int NS, bool HAS_Z>
 static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
     const dim3 grid(grid_for(a.B, 256)), block(256);
     const bool extra = (a.flags & (F_TRACK | F_LAYERS)) || a.T != 1 || a.rewards_seq || a.dones_seq;
+    if (a.bad && a.T == 1 && !(a.flags & F_INVERTS)) {  // the env.step() path
+        if (a.flags & (F_TRACK | F_LAYERS)) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, false>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
     if constexpr (HAS_Z) {
         if (a.flags & F_INVERTS) {
             if (a.flags & F_GJ) hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, true, true, true>), grid, block, 0, s, a);

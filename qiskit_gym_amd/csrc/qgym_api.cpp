@@ -460,10 +460,10 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     HIP_TRY_V(hipMalloc(&p->done, batch));
     HIP_TRY_V(hipMalloc(&p->success, batch));
     HIP_TRY_V(hipMalloc(&p->inverted, batch));
-    // TILE layout without add_inverts: the one-step kernel keeps `solved` as a per-env mask (QGYM_TILE_DENSE=1:
+    // TILE / TILE64 layouts without add_inverts: the one-step kernel keeps `solved` as a per-env mask (QGYM_TILE_DENSE=1:
     // development switch that keeps every step on the register-resident kernel)
-    if (v->layout == LAYOUT_TILE && !(v->flags & F_INVERTS) && !getenv("QGYM_TILE_DENSE"))
-        HIP_TRY_V(hipMalloc(&p->bad, sizeof(uint32_t) * batch));
+    if ((v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) && !(v->flags & F_INVERTS) && !getenv("QGYM_TILE_DENSE"))
+        HIP_TRY_V(hipMalloc(&p->bad, (v->layout == LAYOUT_TILE64 ? sizeof(uint64_t) : sizeof(uint32_t)) * batch));
     HIP_TRY_V(hipMalloc(&p->error, sizeof(uint32_t) * batch));
     HIP_TRY_V(hipMalloc(&p->sol_len, sizeof(int32_t) * 2 * batch));
     if (cfg->track_solution) {

@@ -77,7 +77,7 @@ struct qg_vec {
     uint32_t layers_len = 0;
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
-    uint32_t *bad = nullptr;            // TILE CliffordEnv: per-env "rows differ from identity" qubit mask (one-step kernel)
+    uint32_t *bad = nullptr;            // TILE / TILE64 without add_inverts: per-env "differs from identity" mask (one-step kernels)
     uint32_t *d_nonsymp = nullptr;      // device word behind InitArgs::nonsymp_flag
     bool maybe_nonsymplectic = false;   // CliffordEnv + add_inverts: some env may need the Gauss-Jordan inversion
     bool own_reward = true, own_done = true, own_success = true, own_depth = true;

@@ -109,7 +109,7 @@ struct StepArgs {
     float pauli_layer_reward;
     uint32_t max_rotations;
     const uint64_t *clock;    // device clock added to every RNG counter (qg_vec_set_clock), or null
-    uint32_t *bad;            // TILE layout, CliffordEnv: bit q = qubit q's rows differ from the identity's (or null)
+    uint32_t *bad;            // TILE (uint32) / TILE64 (uint64) per-env mask: bit j = qubit j's rows / row j differ from the identity's; or null
 };
 
 // state (re)initialisation

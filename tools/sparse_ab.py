@@ -6,9 +6,9 @@ if len(sys.argv) > 1:
     import torch
     from qiskit_gym_amd.vec import VecEnv
     from util import line_gateset
-    for kind, n in (("clifford", 16), ("clifford", 8), ("linear_function", 16), ("linear_function", 32)):
+    for kind, n in (("clifford", 16), ("clifford", 20), ("clifford", 32), ("linear_function", 32), ("linear_function", 48), ("linear_function", 64)):
         gs = line_gateset(kind, n)
-        for B in (65536, 1048576):
+        for B in (65536, 262144):
             env = VecEnv(kind, n, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=256)
             env.reset(1)
             acts = torch.randint(0, len(gs), (16, B), dtype=torch.int32, device="cuda")
