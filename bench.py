@@ -5,9 +5,10 @@ Workload (BASELINE.json metric): CliffordGym, 16
 bidirectional coupling map, all 8 gate kinds (170 actions), 65 536 envs per GPU, start = identity
 scrambled by 256 uniform random actions, then uniform random actions, add_inverts=False,
 add_perms=False, track_solution=False, default metric weights, free-running (no reset inside the
-timed loop).  A "step" is ONE env.step() of every env = one `clifford step` kernel launch that reads
-each env's packed tableau from device memory, applies its own action, tests for identity, writes
-reward / done / success / depth and the touched rows back.  Inputs (actions) are resident in HBM.
+timed loop).  A "step" is ONE env.step() of every env = one step-kernel launch that gathers the rows
+its env's action touches from the packed tableau in device memory, applies the gate, updates the
+solved test, writes reward / done / success / depth and the touched rows back.  Inputs (actions) are
+resident in HBM.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
@@ -345,7 +346,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "qg::qm_step_kernel<16, true, false, false, false>",
+                "kernel": "qg::qm_step1_kernel<16, true, false>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
