@@ -311,7 +311,7 @@ def main():
     out = None
     if rank == 0:
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only
             cpu = cpu_baseline(gateset, seed)
         parity = None
         if snap is not None:
