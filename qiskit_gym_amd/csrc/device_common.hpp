@@ -12,6 +12,19 @@ __device__ inline int64_t load_action(const void *actions, uint64_t idx, bool ac
                  : (int64_t) reinterpret_cast<const int32_t *>(actions)[idx];
 }
 
+// Length of the compacted list of finished envs (compact_done), read by every thread of the LAST kernel
+// that consumes it; the last block to have read it zeroes the counter (and the ticket) for the next
+// qg_vec_reset_done.  counter[0] = length, counter[1] = blocks that have read it.  Call from all threads.
+__device__ inline uint32_t list_count_take(uint32_t *counter) {
+    const uint32_t count = counter[0];
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&counter[1], 1u) == gridDim.x - 1u) {
+        counter[0] = 0;
+        counter[1] = 0;
+    }
+    return count;
+}
+
 // Solution-log word of an action (clifford.rs:334-340 pushes the action verbatim, valid or not):
 // the log is 32-bit, so anything a `usize` action could hold beyond 2^32 - 2 -- and a negative
 // int64, which `as usize` turns into 2^64 - 1 -- saturates to 0xFFFFFFFF (read back as UINT64_MAX).

@@ -534,44 +534,16 @@ __device__ inline uint32_t qm_slot(uint32_t row, uint32_t N, uint32_t nxp, bool 
     return has_z ? (row < N ? 2 * row : 2 * (row - N) + 1) : row;
 }
 
+// reset_done: lists of at most B / 32 finished envs go to the 16-lanes-per-env scramble kernel below
+#define QM_COOP_LANES 16
+__device__ inline bool qm_coop_takes(uint32_t count, uint64_t B) { return (uint64_t)count * QM_COOP_LANES * 2 <= B; }
+
+// the tail of set_state / reset for one env: rows to the tile, reset_internals (clifford.rs:272-283)
 template <int NXP, bool HAS_Z>
-__global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
+__device__ inline void qm_init_finish(const InitArgs &a, uint64_t env, const QmRows<NXP, HAS_Z> &s) {
     using Rows = QmRows<NXP, HAS_Z>;
-    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
-    if (env >= a.B) return;
-    if (a.only_done && !a.done[env]) return;  // qg_vec_reset_done: live episodes keep running
+    const uint32_t lane = (uint32_t)(env & (QG_WAVE - 1));
     uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Rows::G * 64);
-    Rows s;
-    qm_identity<NXP, HAS_Z>(s, a.N);
-    if (a.mode == 1) {  // set_state (clifford.rs:299-304)
-#pragma unroll
-        for (int sl = 0; sl < Rows::R; ++sl) {
-            const uint32_t j = HAS_Z ? (uint32_t)sl >> 1 : (uint32_t)sl;
-            const uint32_t row = (HAS_Z && (sl & 1)) ? a.N + j : j;
-            uint32_t w = 0;
-            if (j < a.N) {
-                if (a.format == QG_FMT_PACKED) {
-                    w = reinterpret_cast<const uint32_t *>(a.src)[env * a.src_stride + row];
-                    if (a.D < 32) w &= (1u << a.D) - 1u;
-                } else if (a.format == QG_FMT_I64) {
-                    const int64_t *p = reinterpret_cast<const int64_t *>(a.src) + env * a.src_stride + (uint64_t)row * a.D;
-                    for (uint32_t c = 0; c < a.D; ++c) w |= (uint32_t)(p[c] > 0) << c;
-                } else {
-                    const int8_t *p = reinterpret_cast<const int8_t *>(a.src) + env * a.src_stride + (uint64_t)row * a.D;
-                    for (uint32_t c = 0; c < a.D; ++c) w |= (uint32_t)(p[c] > 0) << c;
-                }
-            }
-            s.r[sl] = w;
-        }
-    } else if (a.mode == 2) {  // reset scramble (clifford.rs:306-316)
-        for (uint32_t t = 0; t < a.n_draws; ++t) {
-            const int64_t act = a.actions ? (int64_t)a.actions[(uint64_t)t * a.B + env]
-                                          : (int64_t)rng_action(init_seed(a), env, t, a.num_actions);
-            const uint32_t ops = (act >= 0 && act < (int64_t)a.num_actions) ? a.gates[act].ops : (QM_IDENTITY << 10);
-            qm_apply<NXP, HAS_Z>(s, ops);
-        }
-    }
     const bool solved = qm_solved<NXP, HAS_Z>(s, a.N);
 #pragma unroll
     for (int g = 0; g < Rows::G; ++g) tile[g * 64 + lane] = make_uint4(s.r[4 * g], s.r[4 * g + 1], s.r[4 * g + 2], s.r[4 * g + 3]);
@@ -599,6 +571,144 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
         lay[a.layers_len - 2] = 0;
         lay[a.layers_len - 1] = 0;
     }
+}
+
+template <int NXP, bool HAS_Z>
+__global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
+    using Rows = QmRows<NXP, HAS_Z>;
+    // reset scramble: the rows live in LDS (wave-private, [slot][lane]: conflict-free for any per-lane
+    // slot), so a gate is four dynamic-index reads and writes instead of a sweep over 32 registers
+    __shared__ uint32_t lds_rows[4][Rows::R][QG_WAVE];
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t env = tid;
+    if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
+        const uint32_t count = list_count_take(a.list_count);  // this kernel is the list's last reader
+        if (tid >= count || (a.coop && qm_coop_takes(count, a.B))) return;
+        env = a.list[tid];
+    } else {
+        if (env >= a.B) return;
+        if (a.only_done && !a.done[env]) return;  // live episodes keep running
+    }
+    Rows s;
+    qm_identity<NXP, HAS_Z>(s, a.N);
+    if (a.mode == 1) {  // set_state (clifford.rs:299-304)
+#pragma unroll
+        for (int sl = 0; sl < Rows::R; ++sl) {
+            const uint32_t j = HAS_Z ? (uint32_t)sl >> 1 : (uint32_t)sl;
+            const uint32_t row = (HAS_Z && (sl & 1)) ? a.N + j : j;
+            uint32_t w = 0;
+            if (j < a.N) {
+                if (a.format == QG_FMT_PACKED) {
+                    w = reinterpret_cast<const uint32_t *>(a.src)[env * a.src_stride + row];
+                    if (a.D < 32) w &= (1u << a.D) - 1u;
+                } else if (a.format == QG_FMT_I64) {
+                    const int64_t *p = reinterpret_cast<const int64_t *>(a.src) + env * a.src_stride + (uint64_t)row * a.D;
+                    for (uint32_t c = 0; c < a.D; ++c) w |= (uint32_t)(p[c] > 0) << c;
+                } else {
+                    const int8_t *p = reinterpret_cast<const int8_t *>(a.src) + env * a.src_stride + (uint64_t)row * a.D;
+                    for (uint32_t c = 0; c < a.D; ++c) w |= (uint32_t)(p[c] > 0) << c;
+                }
+            }
+            s.r[sl] = w;
+        }
+    } else if (a.mode == 2) {  // reset scramble (clifford.rs:306-316)
+        uint32_t(*rows)[QG_WAVE] = lds_rows[threadIdx.x >> 6];
+        const uint32_t L = threadIdx.x & (QG_WAVE - 1);
+#pragma unroll
+        for (int sl = 0; sl < Rows::R; ++sl) rows[sl][L] = s.r[sl];
+        const uint64_t seed = init_seed(a);
+        // a gate = two row operations on disjoint slots (clifford.rs:111-133); four draws and their table
+        // reads are issued ahead of the dependent LDS chain
+        auto rowop = [&](uint32_t op) {
+            const uint32_t type = op >> 12, dst = op & 63u, src = (op >> 6) & 63u;
+            const uint32_t va = rows[dst][L], vb = rows[src][L];
+            const uint32_t swap = 0u - (uint32_t)(type == OP_SWAP);
+            const uint32_t nd = (vb & swap) | ((va ^ vb) & ~swap), ns = (va & swap) | (vb & ~swap);
+            if (type != OP_NONE) {
+                rows[dst][L] = nd;
+                rows[src][L] = ns;
+            }
+        };
+        auto draw = [&](uint32_t t) -> uint32_t {
+            if (t >= a.n_draws) return 0u;
+            const int64_t act = a.actions ? (int64_t)a.actions[(uint64_t)t * a.B + env] : (int64_t)rng_action(seed, env, t, a.num_actions);
+            return (act >= 0 && act < (int64_t)a.num_actions) ? a.rowops[act] : 0u;
+        };
+        for (uint32_t t = 0; t < a.n_draws; t += 4) {
+            const uint32_t o0 = draw(t), o1 = draw(t + 1), o2 = draw(t + 2), o3 = draw(t + 3);
+            rowop(o0 & 0x3FFFu); rowop((o0 >> 14) & 0x3FFFu);
+            rowop(o1 & 0x3FFFu); rowop((o1 >> 14) & 0x3FFFu);
+            rowop(o2 & 0x3FFFu); rowop((o2 >> 14) & 0x3FFFu);
+            rowop(o3 & 0x3FFFu); rowop((o3 >> 14) & 0x3FFFu);
+        }
+#pragma unroll
+        for (int sl = 0; sl < Rows::R; ++sl) s.r[sl] = rows[sl][L];
+    }
+    qm_init_finish<NXP, HAS_Z>(a, env, s);
+}
+
+// qg_vec_reset_done with few finished envs: 16 lanes per env instead of one.  The counter-RNG draws of
+// a chunk (two splitmix64 rounds each, ~300 cycles of 64-bit multiplies) are spread over the 16 lanes
+// and parked in LDS as row-operation words; two lanes then apply them to the LDS-resident rows.  With a
+// few thousand finished envs of 65 536 this fills the otherwise idle SIMDs (measured per reset_done call
+// at difficulty 256, 3 % finished: 725 us in-register per-lane scramble, 115 us compacted + LDS rows, see
+// profiles).  Many finished envs (synchronised episode ends) stay on the one-lane-per-env kernel.
+
+template <int NXP, bool HAS_Z>
+__global__ __launch_bounds__(256) void qm_scramble_coop_kernel(InitArgs a) {
+    using Rows = QmRows<NXP, HAS_Z>;
+    constexpr uint32_t S = QM_COOP_LANES, EPW = QG_WAVE / S, CH = 64;
+    __shared__ uint32_t lrows[4][EPW][Rows::R];
+    __shared__ uint32_t lops[4][EPW][CH];
+    const uint32_t count = *a.list_count;
+    if (!qm_coop_takes(count, a.B)) return;
+    const uint64_t item = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / S;
+    if (item >= count) return;  // whole lane groups leave together
+    const uint32_t sl = threadIdx.x & (S - 1), w = threadIdx.x >> 6, g = (threadIdx.x & (QG_WAVE - 1)) / S;
+    const uint64_t env = a.list[item];
+    uint32_t *rows = lrows[w][g], *ops = lops[w][g];
+    for (uint32_t k = sl; k < (uint32_t)Rows::R; k += S) {  // identity (clifford.rs:307)
+        const uint32_t j = HAS_Z ? k >> 1 : k;
+        rows[k] = j < a.N ? ((HAS_Z && (k & 1u)) ? (1u << a.N) << j : 1u << j) : 0u;
+    }
+    const uint64_t seed = init_seed(a);
+    for (uint32_t c0 = 0; c0 < a.n_draws; c0 += CH) {
+        const uint32_t len = a.n_draws - c0 < CH ? a.n_draws - c0 : CH;
+        for (uint32_t k = sl; k < CH; k += S)  // the tail of the last chunk is padded with "no gate"
+            ops[k] = k < len ? a.rowops[rng_action(seed, env, c0 + k, a.num_actions)] : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (sl < 2) {
+            // a gate is two row operations on disjoint rows (clifford.rs:111-133): lane 0 does the first, lane 1
+            // the second, in lockstep; four gate words are fetched ahead of the dependent row reads
+            const uint32_t sh = 14u * sl;
+            auto rowop = [&](uint32_t o) {
+                const uint32_t op = (o >> sh) & 0x3FFFu, type = op >> 12, dst = op & 63u, src = (op >> 6) & 63u;
+                const uint32_t va = rows[dst], vb = rows[src];
+                const uint32_t swap = 0u - (uint32_t)(type == OP_SWAP);
+                const uint32_t nd = (vb & swap) | ((va ^ vb) & ~swap), ns = (va & swap) | (vb & ~swap);
+                if (type != OP_NONE) {
+                    rows[dst] = nd;
+                    rows[src] = ns;
+                }
+            };
+            const uint32_t padded = (len + 3u) & ~3u;
+            for (uint32_t k = 0; k < padded; k += 4) {
+                const uint32_t o0 = ops[k], o1 = ops[k + 1], o2 = ops[k + 2], o3 = ops[k + 3];
+                rowop(o0);
+                rowop(o1);
+                rowop(o2);
+                rowop(o3);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (sl != 0) return;
+    Rows s;
+#pragma unroll
+    for (int k = 0; k < Rows::R; ++k) s.r[k] = rows[k];
+    qm_init_finish<NXP, HAS_Z>(a, env, s);
 }
 
 // export: one thread per (env, matrix row).  log2L carries NXP/4, flag bit 31 of D's companion
@@ -686,6 +796,8 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
 }
 template <int NXP, bool HAS_Z>
 static hipError_t launch_init(const InitArgs &a, hipStream_t s) {
+    if (a.coop)  // device-side choice by the number of finished envs: exactly one of the two kernels does the work
+        hipLaunchKernelGGL((qm_scramble_coop_kernel<NXP, HAS_Z>), dim3(grid_for(a.B / 2, 256)), dim3(256), 0, s, a);
     hipLaunchKernelGGL((qm_init_kernel<NXP, HAS_Z>), dim3(grid_for(a.B, 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -223,7 +223,7 @@ static int vec_free_buffers(qg_vec *v) {
     void *ptrs[] = {v->state, v->own_depth ? v->depth : nullptr, v->own_reward ? v->reward : nullptr,
                     v->own_done ? v->done : nullptr, v->own_success ? v->success : nullptr, v->inverted, v->error, v->sol,
                     v->sol_len, v->layers, v->d_gates, v->d_descs, v->scratch, v->rot, v->pmeta, v->d_prog,
-                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad};
+                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad, v->done_list, v->d_rowops};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &g : v->graphs) {
@@ -257,6 +257,7 @@ static void fill_init_args(const qg_vec *v, InitArgs &a) {
     a.num_actions = (uint32_t)v->gates.size();
     a.clock = v->clock_dev;
     a.bad = v->bad;
+    a.rowops = v->d_rowops;
     a.check_symplectic = ((v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) && (v->flags & F_INVERTS)) ? 1u : 0u;
 }
 
@@ -464,6 +465,10 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     // development switch that keeps every step on the register-resident kernel)
     if ((v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) && !(v->flags & F_INVERTS) && !getenv("QGYM_TILE_DENSE"))
         HIP_TRY_V(hipMalloc(&p->bad, (v->layout == LAYOUT_TILE64 ? sizeof(uint64_t) : sizeof(uint32_t)) * batch));
+    if (v->layout == LAYOUT_TILE) {
+        HIP_TRY_V(hipMalloc(&p->done_list, sizeof(uint32_t) * (batch + 2)));
+        HIP_TRY_V(hipMemset(p->done_list + batch, 0, 2 * sizeof(uint32_t)));
+    }
     HIP_TRY_V(hipMalloc(&p->error, sizeof(uint32_t) * batch));
     HIP_TRY_V(hipMalloc(&p->sol_len, sizeof(int32_t) * 2 * batch));
     if (cfg->track_solution) {
@@ -480,6 +485,21 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     HIP_TRY_V(hipMalloc(&p->d_descs, sizeof(uint32_t) * descs.size()));
     HIP_TRY_V(hipMemcpy(p->d_gates, table.data(), sizeof(GateEntry) * table.size(), hipMemcpyHostToDevice));
     HIP_TRY_V(hipMemcpy(p->d_descs, descs.data(), sizeof(uint32_t) * descs.size(), hipMemcpyHostToDevice));
+    if (v->layout == LAYOUT_TILE) {  // the same gates as <= 2 row operations on tile slots (clifford.rs:89-133)
+        std::vector<uint32_t> rowops(table.size(), 0u);
+        auto slot = [&](uint32_t row) { return v->has_z ? (row < N ? 2 * row : 2 * (row - N) + 1) : row; };
+        for (size_t i = 0; i < n_gates; ++i) {
+            const uint32_t ops = gate_ops(cfg->env_kind, gates[i], N);
+            uint32_t out = 0;
+            for (int k = 0; k < 2; ++k) {
+                const uint32_t op = (ops >> (14 * k)) & 0x3FFFu, type = (op >> 12) & 3u;
+                if (type != OP_NONE) out |= make_op(type, slot(op & 63u), slot((op >> 6) & 63u)) << (14 * k);
+            }
+            rowops[i] = out;
+        }
+        HIP_TRY_V(hipMalloc(&p->d_rowops, sizeof(uint32_t) * rowops.size()));
+        HIP_TRY_V(hipMemcpy(p->d_rowops, rowops.data(), sizeof(uint32_t) * rowops.size(), hipMemcpyHostToDevice));
+    }
     if (v->layout == LAYOUT_PAULI) {
         int rc = pauli_alloc(p);
         if (rc) return fail(rc);
@@ -701,6 +721,14 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
     ia.n_draws = (uint32_t)n_draws;
     ia.seed = seed;
     ia.only_done = only_done ? 1u : 0u;
+    if (only_done && v->done_list) {
+        // few, scattered finished envs: pack their indices first so that the scramble runs in full waves
+        // instead of in every wave that holds one finished env
+        HIP_TRY(compact_done(v->done, v->B, v->done_list, v->done_list + v->B, s));
+        ia.list = v->done_list;
+        ia.list_count = v->done_list + v->B;
+        ia.coop = (!actions_dev && v->B >= 64 && v->d_rowops) ? 1u : 0u;
+    }
     if (!only_done) v->maybe_nonsymplectic = false;  // identity + gates: every env is symplectic again
     int64_t d = (int64_t)v->cfg.depth_slope * v->difficulty;  // clifford.rs:317
     ia.depth_value = (int32_t)std::min<int64_t>(d, v->cfg.max_depth);

@@ -78,6 +78,8 @@ struct qg_vec {
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
     uint32_t *bad = nullptr;            // TILE / TILE64 without add_inverts: per-env "differs from identity" mask (one-step kernels)
+    uint32_t *d_rowops = nullptr;       // TILE: gate table as pairs of row operations on slots (cooperative reset kernel)
+    uint32_t *done_list = nullptr;      // reset_done: [B] indices of finished envs + {length, reader ticket} at [B], [B + 1]
     uint32_t *d_nonsymp = nullptr;      // device word behind InitArgs::nonsymp_flag
     bool maybe_nonsymplectic = false;   // CliffordEnv + add_inverts: some env may need the Gauss-Jordan inversion
     bool own_reward = true, own_done = true, own_success = true, own_depth = true;

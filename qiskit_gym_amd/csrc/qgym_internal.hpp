@@ -140,6 +140,10 @@ struct InitArgs {
     uint32_t *nonsymp_flag;    // set_state with add_inverts: or-ed to 1 when some env is not symplectic
     const uint64_t *clock;     // device clock: the scramble seed becomes seed + 0x9E3779B9 * clock (qg_vec_set_clock)
     uint32_t *bad;             // see StepArgs::bad
+    const uint32_t *list;      // reset_done, compacted: thread i resets env list[i], i < *list_count (or null: thread = env)
+    uint32_t *list_count;      // [2]: length, reader ticket (device_common.hpp list_count_take)
+    uint32_t coop;             // list mode with RNG draws: the 16-lanes-per-env scramble kernel handles small lists
+    const uint32_t *rowops;    // TILE layout: per action two row operations (make_op, slot indices) for that kernel
 };
 
 // A handle may be given a device-resident clock (qg_vec_set_clock).  Launches replayed from a
@@ -184,6 +188,7 @@ hipError_t perm_step(const StepArgs &a, bool fused, hipStream_t s);
 hipError_t perm_init(const InitArgs &a, hipStream_t s);
 hipError_t perm_export(const ObsArgs &a, hipStream_t s);
 
+hipError_t compact_done(const uint8_t *done, uint64_t B, uint32_t *list, uint32_t *count, hipStream_t s);
 hipError_t masks_fill(const uint8_t *success, uint8_t *out, uint64_t B, uint32_t num_actions, hipStream_t s);
 
 }  // namespace qg

@@ -11,7 +11,7 @@ from util import line_gateset
 
 for B, store, graph in ((1024, "packed", False), (1024, "packed", True), (8192, "packed", False), (8192, "packed", True), (65536, "dense", False), (65536, "packed", False), (65536, "packed", True)):
     gs = line_gateset("clifford", 16)
-    env = VecEnv("clifford", 16, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=32)
+    env = VecEnv("clifford", 16, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=int(os.environ.get("DIFF", "32")))
     col = RolloutCollector(env, BasicPolicy(1024, len(gs)), dtype=torch.bfloat16, seed=1, store_obs=store, use_graph=graph)
     T = 32
     ro = col.collect(T)
