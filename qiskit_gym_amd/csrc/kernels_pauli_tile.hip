@@ -682,6 +682,8 @@ struct PTGenArgs {
     float decay;
     int32_t depth_value;
     uint32_t only_done;
+    const uint32_t *list;  // only_done, compacted (compact_done): thread i regenerates env list[i]
+    uint32_t *list_count;
 };
 
 struct PTStream {
@@ -692,12 +694,22 @@ struct PTStream {
 };
 
 template <int NQ, int RM>
-__global__ __launch_bounds__(256) void ptile_generate_kernel(PTGenArgs ga) {
+__global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
     const StepArgs &a = ga.s;
-    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
-    if (env >= a.B) return;
-    if (ga.only_done && !a.done[env]) return;
+    // the tableau scramble runs on LDS-resident rows ([row][lane], conflict-free for any per-lane row): a
+    // random CX / H / S is one or two row operations instead of a select sweep over 2N 64-bit registers
+    __shared__ uint64_t lds_tab[2 * NQ][QG_WAVE];
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t env = tid;
+    if (ga.list) {
+        const uint32_t count = list_count_take(ga.list_count);  // the list's only reader
+        if (tid >= count) return;
+        env = ga.list[tid];
+    } else {
+        if (env >= a.B) return;
+        if (ga.only_done && !a.done[env]) return;
+    }
+    const uint32_t lane = (uint32_t)(env & (QG_WAVE - 1)), L = threadIdx.x & (QG_WAVE - 1);
     const uint32_t N = a.N;
     char *tile = PTLayout<NQ, RM>::tile(a.state, env);
     PTStream rng{(ga.seed + QG_CLOCK_SEED_STRIDE * clock_of(a.clock)) ^ 0x7061756Cull, env, 0};
@@ -777,30 +789,38 @@ __global__ __launch_bounds__(256) void ptile_generate_kernel(PTGenArgs ga) {
     for (int k = 0; k < RM; ++k) s.order |= ((uint32_t)k < n_lab) ? ((uint64_t)k << (4 * k)) : 0ull;
 
     // random_clifford_tableau (pauli.rs:220-271): H / S / CX row operations on the identity
+    // (row q = X[q], row N + q = Z[q]; LDS slot NQ + q holds Z[q])
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
-        s.X[j] = (uint32_t)j < N ? 1ull << j : 0ull;
-        s.Z[j] = (uint32_t)j < N ? (1ull << N) << j : 0ull;
+        lds_tab[j][L] = (uint32_t)j < N ? 1ull << j : 0ull;
+        lds_tab[NQ + j][L] = (uint32_t)j < N ? (1ull << N) << j : 0ull;
     }
     if (ga.difficulty != 0 && ga.n_cx != 0) {
         for (uint32_t it = 0; it < ga.difficulty; ++it) {
             const float r = rng.f32();
-            uint32_t qa, qb, m;
-            if (r > 0.3f) {  // CX: row q1 ^= row q0 ; row n+q0 ^= row n+q1  (a = q0, b = q1)
+            if (r > 0.3f) {  // CX: row q1 ^= row q0 ; row n+q0 ^= row n+q1
                 const uint32_t k = rng.range(ga.n_cx);
-                qa = ga.cx_pairs[2 * k];
-                qb = ga.cx_pairs[2 * k + 1];
-                m = qa == qb ? 0x8400u : 0x85A1u;  // a CX(q, q) entry xors rows into themselves: both become zero
+                const uint32_t q0 = ga.cx_pairs[2 * k], q1 = ga.cx_pairs[2 * k + 1];
+                const uint64_t x0 = lds_tab[q0][L], z1 = lds_tab[NQ + q1][L];
+                lds_tab[q1][L] ^= x0;       // a CX(q, q) entry xors the rows into themselves: both become zero
+                lds_tab[NQ + q0][L] ^= z1;
             } else if (r > 0.15f) {  // H: swap rows q, n+q
-                qa = qb = rng.range(N);
-                m = 0x8412u;
+                const uint32_t q = rng.range(N);
+                const uint64_t x = lds_tab[q][L], z = lds_tab[NQ + q][L];
+                lds_tab[q][L] = z;
+                lds_tab[NQ + q][L] = x;
             } else {  // S: row n+q ^= row q
-                qa = qb = rng.range(N);
-                m = 0x8431u;
+                const uint32_t q = rng.range(N);
+                lds_tab[NQ + q][L] ^= lds_tab[q][L];
             }
-            pt_apply_tableau<NQ, RM>(s, N, qa, qb, m);
         }
     }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        s.X[j] = lds_tab[j][L];
+        s.Z[j] = lds_tab[NQ + j][L];
+    }
+    s.bad = pt_badmask<NQ, RM>(s, N);
 
     uint32_t n_removed = 0, fault = 0;  // clean initially trivial rotations (pauli.rs:576)
     uint64_t rem_pos[(RM + 7) / 8];
@@ -933,7 +953,7 @@ hipError_t ptile_export(const qg_vec *v, const ObsArgs &a, hipStream_t s) {
 
 template <int NQ, int RM>
 static hipError_t pt_launch_generate(const PTGenArgs &pa, hipStream_t s) {
-    hipLaunchKernelGGL((ptile_generate_kernel<NQ, RM>), dim3(grid_for(pa.s.B, 256)), dim3(256), 0, s, pa);
+    hipLaunchKernelGGL((ptile_generate_kernel<NQ, RM>), dim3(grid_for(pa.s.B, 64)), dim3(64), 0, s, pa);
     return hipGetLastError();
 }
 static hipError_t ptile_generate(const qg_vec *v, const PTGenArgs &pa, hipStream_t s) { PT_DISPATCH(pt_launch_generate) }
@@ -1014,6 +1034,11 @@ int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s) 
     const int64_t d = (int64_t)v->cfg.depth_slope * v->difficulty;  // pauli.rs:578
     ga.depth_value = (int32_t)std::min<int64_t>(d, v->cfg.max_depth);
     ga.only_done = only_done ? 1u : 0u;
+    if (only_done && v->done_list) {  // pack the finished envs: full waves instead of one live lane in every wave
+        HIP_TRY(compact_done(v->done, v->B, v->done_list, v->done_list + v->B, s));
+        ga.list = v->done_list;
+        ga.list_count = v->done_list + v->B;
+    }
     HIP_TRY(ptile_generate(v, ga, s));
     return QG_OK;
 }

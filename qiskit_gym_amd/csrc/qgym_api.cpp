@@ -465,7 +465,7 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     // development switch that keeps every step on the register-resident kernel)
     if ((v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) && !(v->flags & F_INVERTS) && !getenv("QGYM_TILE_DENSE"))
         HIP_TRY_V(hipMalloc(&p->bad, (v->layout == LAYOUT_TILE64 ? sizeof(uint64_t) : sizeof(uint32_t)) * batch));
-    if (v->layout == LAYOUT_TILE) {
+    if (v->layout == LAYOUT_TILE || (v->layout == LAYOUT_PAULI && v->pauli_tile)) {
         HIP_TRY_V(hipMalloc(&p->done_list, sizeof(uint32_t) * (batch + 2)));
         HIP_TRY_V(hipMemset(p->done_list + batch, 0, 2 * sizeof(uint32_t)));
     }
