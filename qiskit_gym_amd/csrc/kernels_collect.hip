@@ -13,6 +13,7 @@
 
 #include "device_common.hpp"
 #include "qgym_host.hpp"
+#include "pauli_common.hpp"
 
 namespace qg {
 
@@ -41,6 +42,38 @@ __global__ __launch_bounds__(256) void expand_chunks_kernel(const void *packed, 
         bits = (col >= c0 && col < c0 + EPC) ? 1u << (col - c0) : 0u;
     }
     out[gid] = expand_chunk<ES>(bits & ((1u << EPC) - 1u), one);
+}
+
+// rows whose length is not a multiple of the chunk (PauliEnv: 2N + max_rotations columns): the dense
+// output is still one flat array, so a thread still owns one aligned 16-byte chunk of it; the chunk's
+// elements are the tail of one row and the head of the next (or of several short rows)
+template <int ES>
+__global__ __launch_bounds__(256) void expand_ragged_kernel(const void *packed, int word_bytes, uint64_t n_rows, uint32_t cols, uint4 *out,
+                                                            uint32_t one) {
+    constexpr uint32_t EPC = 16 / ES;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = n_rows * cols, e0 = gid * EPC;
+    if (e0 >= total) return;
+    uint64_t row;
+    if (total <= 0xFFFFFFFFull) row = (uint32_t)e0 / cols;  // 32-bit division: the 64-bit one costs more than the rest of the thread
+    else row = e0 / cols;
+    uint32_t c = (uint32_t)(e0 - row * cols), bits = 0, filled = 0;
+    while (filled < EPC && row < n_rows) {
+        const uint64_t w = word_bytes == 8 ? reinterpret_cast<const uint64_t *>(packed)[row] : (uint64_t) reinterpret_cast<const uint32_t *>(packed)[row];
+        const uint32_t take = (EPC - filled) < (cols - c) ? (EPC - filled) : (cols - c);
+        bits |= ((uint32_t)(w >> c) & ((1u << take) - 1u)) << filled;
+        filled += take;
+        row += 1;
+        c = 0;
+    }
+    const uint4 v = expand_chunk<ES>(bits, one);
+    if (e0 + EPC <= total) {
+        out[gid] = v;
+    } else {  // the array's last, partial chunk
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint8_t *o = reinterpret_cast<uint8_t *>(out) + gid * 16ull;
+        for (uint32_t b = 0; b < (uint32_t)(total - e0) * ES; ++b) o[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3u)));
+    }
 }
 
 // any shape / alignment: one thread per element
@@ -110,6 +143,12 @@ static int expand_packed_impl(const void *packed_dev, int word_bytes, uint64_t n
         if (es == 1) hipLaunchKernelGGL(expand_chunks_kernel<1>, dim3(grid), dim3(256), 0, s, packed_dev, word_bytes, n_rows, cols, cpr, o, one);
         else if (es == 2) hipLaunchKernelGGL(expand_chunks_kernel<2>, dim3(grid), dim3(256), 0, s, packed_dev, word_bytes, n_rows, cols, cpr, o, one);
         else hipLaunchKernelGGL(expand_chunks_kernel<4>, dim3(grid), dim3(256), 0, s, packed_dev, word_bytes, n_rows, cols, cpr, o, one);
+    } else if (word_bytes != 1 && cols >= 1 && (reinterpret_cast<uintptr_t>(out_dev) & 15u) == 0) {
+        const unsigned grid = blocks_for((n_rows * cols + epc - 1) / epc, 256);
+        uint4 *o = reinterpret_cast<uint4 *>(out_dev);
+        if (es == 1) hipLaunchKernelGGL(expand_ragged_kernel<1>, dim3(grid), dim3(256), 0, s, packed_dev, word_bytes, n_rows, cols, o, one);
+        else if (es == 2) hipLaunchKernelGGL(expand_ragged_kernel<2>, dim3(grid), dim3(256), 0, s, packed_dev, word_bytes, n_rows, cols, o, one);
+        else hipLaunchKernelGGL(expand_ragged_kernel<4>, dim3(grid), dim3(256), 0, s, packed_dev, word_bytes, n_rows, cols, o, one);
     } else {
         const unsigned grid = blocks_for(n_rows * cols, 256);
         if (es == 1)
@@ -124,6 +163,10 @@ static int expand_packed_impl(const void *packed_dev, int word_bytes, uint64_t n
     }
     HIP_TRY(hipGetLastError());
     return QG_OK;
+}
+
+hipError_t expand_rows(const void *words_dev, int word_bytes, uint64_t n_rows, uint32_t cols, void *out_dev, int out_dtype, hipStream_t s) {
+    return expand_packed_impl(words_dev, word_bytes, n_rows, cols, out_dev, out_dtype, s) == QG_OK ? hipSuccess : hipErrorInvalidValue;
 }
 
 static int widen01_impl(const uint8_t *in_dev, uint64_t n, void *out_dev, int out_dtype, hipStream_t s) {
@@ -289,6 +332,14 @@ int qg_vec_observe_dense_as(qg_vec *v, void *out_dev, int out_dtype, void *strea
     if (rc != QG_OK) return rc;
     HIP_TRY(hipSetDevice(v->device));
     const uint64_t obs = (uint64_t)info.obs_rows * info.obs_cols;
+    if (v->layout == LAYOUT_PAULI && v->pauli_tile && (uint32_t)info.obs_cols <= 64u) {
+        v->perm_draw = true;  // PauliEnv::observe draws a new qubit permutation (pauli.rs:657-662)
+        const hipError_t e = ptile_observe_typed(v, out_dev, out_dtype, (hipStream_t)stream);
+        v->perm_draw = false;
+        v->observe_counter += 1;
+        HIP_TRY(e);
+        return QG_OK;
+    }
     if (v->layout == LAYOUT_PAULI) {  // no packed form: int8 observation, then widen
         rc = ensure_scratch_public(v, v->B * obs);
         if (rc != QG_OK) return rc;

@@ -586,13 +586,13 @@ struct PTObsArgs {
     uint64_t seed, counter;
     const uint64_t *clock;
 };
-__global__ __launch_bounds__(256) void ptile_export_kernel(PTObsArgs pa) {
+// the two observation rows qubit `q` of one env owns: tableau rows q and N + q (2N bits each, qubit-permuted
+// when add_perms) in wx / wz, and the active rotations' bits for those rows (DAG node order,
+// pad_and_collect pauli.rs:411-437) in ex / ez
+__device__ inline void ptile_obs_qubit(const PTObsArgs &pa, uint64_t env, uint32_t q, bool want_extra, uint64_t &wx, uint64_t &wz, uint32_t &ex,
+                                       uint32_t &ez) {
     const ObsArgs &a = pa.o;
     const uint32_t N = a.N, D = 2 * N;
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t env = gid / D;
-    const uint32_t row = (uint32_t)(gid % D);
-    if (env >= a.B) return;
     const uint32_t cols = a.obs_cols, lane = (uint32_t)(env & 63);
     const bool compact = pa.nq <= 24 && pa.rm == 8;  // PTLayout::COMPACT
     const uint32_t QB = compact ? 768u : 1024u, RB = compact ? 512u : 1024u;
@@ -603,37 +603,34 @@ __global__ __launch_bounds__(256) void ptile_export_kernel(PTObsArgs pa) {
         if (pa.draw) {  // `rng.gen_range(0..qubit_perms.len())` (pauli.rs:660), made reproducible
             pi = pa.perm_in ? (uint32_t)pa.perm_in[env] % pa.n_perms
                             : (uint32_t)__umul64hi(rng_draw(pa.seed ^ 0x7065726Dull, env, pa.counter + clock_of(pa.clock)), (uint64_t)pa.n_perms);
-            if (row == 0) pa.perm_idx[env] = pi;  // current_perm_idx.store (pauli.rs:661)
+            if (q == 0) pa.perm_idx[env] = pi;  // current_perm_idx.store (pauli.rs:661)
         } else {
             pi = pa.perm_idx[env];
         }
         perm = pa.qubit_perms + (uint64_t)pi * N;
     }
-    const uint32_t q = row < N ? row : row - N;
     const uint32_t sq = perm ? perm[q] : q;  // row i takes data from row perm[i] (pauli.rs:455-464)
-    uint64_t w;
     if (compact) {
         const uint32_t *p = reinterpret_cast<const uint32_t *>(tile + sq * QB + lane * 12u);
-        w = row < N ? ((uint64_t)p[0] | ((uint64_t)(p[1] & 0xFFFFu) << 32)) : ((uint64_t)(p[1] >> 16) | ((uint64_t)p[2] << 16));
+        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+        wx = (uint64_t)d0 | ((uint64_t)(d1 & 0xFFFFu) << 32);
+        wz = (uint64_t)(d1 >> 16) | ((uint64_t)d2 << 16);
     } else {
         const uint4 t = *reinterpret_cast<const uint4 *>(tile + sq * QB + lane * 16u);
-        w = row < N ? ((uint64_t)t.x | ((uint64_t)t.y << 32)) : ((uint64_t)t.z | ((uint64_t)t.w << 32));
+        wx = (uint64_t)t.x | ((uint64_t)t.y << 32);
+        wz = (uint64_t)t.z | ((uint64_t)t.w << 32);
     }
     if (perm) {  // column i takes data from column perm[i], X and Z halves alike (pauli.rs:469-477)
-        uint64_t pw = 0;
+        uint64_t px = 0, pz = 0;
         for (uint32_t i = 0; i < N; ++i) {
-            pw |= ((w >> perm[i]) & 1ull) << i;
-            pw |= ((w >> (N + perm[i])) & 1ull) << (N + i);
+            px |= (((wx >> perm[i]) & 1ull) << i) | (((wx >> (N + perm[i])) & 1ull) << (N + i));
+            pz |= (((wz >> perm[i]) & 1ull) << i) | (((wz >> (N + perm[i])) & 1ull) << (N + i));
         }
-        w = pw;
+        wx = px;
+        wz = pz;
     }
-    if (a.format == QG_FMT_PACKED) {
-        reinterpret_cast<uint64_t *>(a.out)[env * a.out_stride + row] = w;
-        return;
-    }
-    // pad_and_collect (pauli.rs:411-437): tableau, then the active rotations in DAG node order
-    uint32_t extra = 0;
-    if (cols > D) {
+    ex = ez = 0;
+    if (want_extra && cols > D) {
         const uint4 m = *reinterpret_cast<const uint4 *>(tile + pa.nq * QB + pa.rm * RB + lane * 16u);
         const uint64_t order = (uint64_t)m.z | ((uint64_t)m.w << 32);
         const uint32_t count = m.x >> 16, shown = count < pa.max_rot ? count : pa.max_rot;
@@ -647,10 +644,45 @@ __global__ __launch_bounds__(256) void ptile_export_kernel(PTObsArgs pa) {
                 const uint4 r = *reinterpret_cast<const uint4 *>(rp + lane * 16u);
                 rx = r.x; rz = r.y;
             }
-            const uint32_t bit = row < N ? (rx >> sq) & 1u : (rz >> sq) & 1u;
-            extra |= bit << i;
+            ex |= ((rx >> sq) & 1u) << i;
+            ez |= ((rz >> sq) & 1u) << i;
         }
     }
+}
+
+// dense observation, first half: one 64-bit word per (env, row) = tableau bits | rotation bits << 2N;
+// one thread per (env, qubit) writes the qubit's two rows
+__global__ __launch_bounds__(256) void ptile_rowwords_kernel(PTObsArgs pa, uint64_t *words) {
+    const uint32_t N = pa.o.N, D = 2 * N;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t env = gid <= 0xFFFFFFFFull ? (uint64_t)((uint32_t)gid / N) : gid / N;
+    if (env >= pa.o.B) return;
+    const uint32_t q = (uint32_t)(gid - env * N);
+    uint64_t wx, wz;
+    uint32_t ex, ez;
+    ptile_obs_qubit(pa, env, q, true, wx, wz, ex, ez);
+    words[env * D + q] = wx | ((uint64_t)ex << D);
+    words[env * D + N + q] = wz | ((uint64_t)ez << D);
+}
+
+__global__ __launch_bounds__(256) void ptile_export_kernel(PTObsArgs pa) {
+    const ObsArgs &a = pa.o;
+    const uint32_t N = a.N, D = 2 * N;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t env = gid / D;
+    const uint32_t row = (uint32_t)(gid % D);
+    if (env >= a.B) return;
+    const uint32_t cols = a.obs_cols;
+    uint64_t wx, wz;
+    uint32_t ex, ez;
+    ptile_obs_qubit(pa, env, row < N ? row : row - N, a.format != QG_FMT_PACKED, wx, wz, ex, ez);
+    const uint64_t w = row < N ? wx : wz;
+    const uint32_t extra = row < N ? ex : ez;
+    if (a.format == QG_FMT_PACKED) {
+        reinterpret_cast<uint64_t *>(a.out)[env * a.out_stride + row] = w;
+        return;
+    }
+    // pad_and_collect (pauli.rs:411-437): tableau, then the active rotations in DAG node order
     if (a.format == QG_FMT_I64) {
         int64_t *o = reinterpret_cast<int64_t *>(a.out) + env * a.out_stride + (uint64_t)row * cols;
         for (uint32_t c = 0; c < D; ++c) o[c] = (int64_t)((w >> c) & 1ull);
@@ -931,9 +963,7 @@ hipError_t ptile_step(const qg_vec *v, const StepArgs &a, hipStream_t s) {
 
 static hipError_t ptile_init(const qg_vec *v, const PTArgs &pa, hipStream_t s) { PT_DISPATCH(pt_launch_init) }
 
-hipError_t ptile_export(const qg_vec *v, const ObsArgs &a, hipStream_t s) {
-    if (!a.B) return hipSuccess;
-    PTObsArgs pa;
+static void fill_obs(const qg_vec *v, const ObsArgs &a, PTObsArgs &pa) {
     pa.o = a;
     pa.nq = v->pt_nq;
     pa.rm = v->pt_rm;
@@ -946,8 +976,43 @@ hipError_t ptile_export(const qg_vec *v, const ObsArgs &a, hipStream_t s) {
     pa.seed = v->coin_seed;
     pa.counter = v->observe_counter;
     pa.clock = v->clock_dev;
+}
+
+// dense observation in `out_dtype`: row words into the handle's scratch, then the write-bound expansion
+static hipError_t ptile_dense_via_words(qg_vec *v, const ObsArgs &a, void *out, int out_dtype, hipStream_t s) {
+    const uint64_t n_rows = a.B * 2ull * a.N;
+    if (ensure_scratch_public(v, n_rows * sizeof(uint64_t)) != QG_OK) return hipErrorOutOfMemory;
+    PTObsArgs pa;
+    fill_obs(v, a, pa);
+    pa.o.format = QG_FMT_U8;
+    hipLaunchKernelGGL(ptile_rowwords_kernel, dim3(grid_for(n_rows / 2, 256)), dim3(256), 0, s, pa, reinterpret_cast<uint64_t *>(v->scratch));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return expand_rows(v->scratch, 8, n_rows, a.obs_cols, out, out_dtype, s);
+}
+
+hipError_t ptile_export(const qg_vec *v, const ObsArgs &a, hipStream_t s) {
+    if (!a.B) return hipSuccess;
+    if (a.format == QG_FMT_U8 && a.obs_cols <= 64u && a.out_stride == (uint64_t)a.obs_rows * a.obs_cols && (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0)
+        return ptile_dense_via_words(const_cast<qg_vec *>(v), a, a.out, QG_DT_I8, s);  // the scratch buffer is a cache, not state
+    PTObsArgs pa;
+    fill_obs(v, a, pa);
     hipLaunchKernelGGL(ptile_export_kernel, dim3(grid_for(a.B * 2ull * a.N, 256)), dim3(256), 0, s, pa);
     return hipGetLastError();
+}
+
+hipError_t ptile_observe_typed(qg_vec *v, void *out_dev, int out_dtype, hipStream_t s) {
+    ObsArgs a;
+    memset(&a, 0, sizeof a);
+    a.state = v->state;
+    a.B = v->B;
+    a.N = v->N;
+    a.D = 2 * v->N;
+    a.obs_rows = 2 * v->N;
+    a.obs_cols = 2 * v->N + (uint32_t)std::max(v->cfg.max_rotations, 1);  // qg_vec_get_info
+    a.format = QG_FMT_U8;
+    if (!a.B) return hipSuccess;
+    return ptile_dense_via_words(v, a, out_dev, out_dtype, s);
 }
 
 

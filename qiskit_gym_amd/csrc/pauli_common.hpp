@@ -42,5 +42,7 @@ int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s);
 int ptile_upload(qg_vec *v, const HostNet &h, bool do_clean, int32_t depth_value, hipStream_t s);
 hipError_t ptile_step(const qg_vec *v, const StepArgs &a, hipStream_t s);
 hipError_t ptile_export(const qg_vec *v, const ObsArgs &a, hipStream_t s);
+// observe() as a dense tensor of `out_dtype` (obs_cols <= 64): row words, then expand_rows
+hipError_t ptile_observe_typed(qg_vec *v, void *out_dev, int out_dtype, hipStream_t s);
 
 }  // namespace qg

@@ -188,6 +188,8 @@ hipError_t perm_step(const StepArgs &a, bool fused, hipStream_t s);
 hipError_t perm_init(const InitArgs &a, hipStream_t s);
 hipError_t perm_export(const ObsArgs &a, hipStream_t s);
 
+// dense {0,1} tensor of `out_dtype` (qg_dtype) from rows packed one per word (kernels_collect.hip)
+hipError_t expand_rows(const void *words_dev, int word_bytes, uint64_t n_rows, uint32_t cols, void *out_dev, int out_dtype, hipStream_t s);
 hipError_t compact_done(const uint8_t *done, uint64_t B, uint32_t *list, uint32_t *count, hipStream_t s);
 hipError_t masks_fill(const uint8_t *success, uint8_t *out, uint64_t B, uint32_t num_actions, hipStream_t s);
 

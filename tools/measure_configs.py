@@ -40,6 +40,31 @@ def gpu_rate(env, A, T=128, fused=False, ring=16, reps=8):
     return us, B / us * 1e6
 
 
+def obs_times(env, reps=50):
+    """us per launch of the observation kernels: dense int8 (the Gym format), bf16 (policy input), bit-packed."""
+    out = {}
+    r, c = env.obs_shape_
+    bufs = {"int8": env.observe(), "bf16": env.observe_as(torch.bfloat16)}
+    calls = {"int8": lambda: env.observe(out=bufs["int8"]), "bf16": lambda: env.observe_as(torch.bfloat16, out=bufs["bf16"])}
+    if env.env_kind != "pauli":
+        bufs["packed"] = env.observe_packed()
+        calls["packed"] = lambda: env.observe_packed(out=bufs["packed"])
+    for name, fn in calls.items():
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = (e0.elapsed_time(e1) * 1e3 / reps, bufs[name].numel() * bufs[name].element_size())
+    return out
+
+
+OBS_ROWS = []
+
+
 def cpu_rate(ov, A, budget=4.0):
     B = ov.batch
     rng = np.random.default_rng(0)
@@ -73,6 +98,7 @@ def main():
         env = VecEnv(kind, n, gs, B, difficulty=scramble, **cfg)
         env.reset(1)
         us, rate = gpu_rate(env, A)
+        OBS_ROWS.append((name, B, us, algo_bytes, obs_times(env)))
         env.reset(1)
         fus, frate = gpu_rate(env, A, fused=True)
         env.sync()
@@ -102,6 +128,7 @@ def main():
     env = VecEnv("pauli", n, gs, B, **pcfg)
     env.pauli_reset_from(np.stack([tabs[e % U] for e in range(B)]), [labs[e % U] for e in range(B)])
     us, rate = gpu_rate(env, A)
+    OBS_ROWS.append(("C5 PauliGym 20q line, 1-7 rotations", B, us, 494, obs_times(env)))
     env.pauli_reset_from(np.stack([tabs[e % U] for e in range(B)]), [labs[e % U] for e in range(B)])
     fus, frate = gpu_rate(env, A, fused=True)
     env.sync()
@@ -115,6 +142,19 @@ def main():
     print("|---|---|---|---|---|---|---|---|---|---|---|")
     for name, B, A, us, rate, ab, gbs, frate, crate, cthreads in rows:
         print(f"| {name} | {B} | {A} | {us:.2f} | {rate:.3e} | {ab} | {gbs:.0f} | {gbs / 8000:.3f} | {frate:.3e} | {crate:.3e} ({cthreads}) | {rate / crate:.0f}x |")
+
+    print()
+    print("Observation kernels (eager launches, event-timed) and SURVEY section 8(d)'s dense-observation mode (one step + one dense int8 observation):")
+    print()
+    print("| config | envs | observe int8: us, GB/s written | observe bf16: us, GB/s | observe packed: us | step + int8 observe: us | B / env-step | GB/s | frac of 8 TB/s |")
+    print("|---|---|---|---|---|---|---|---|---|")
+    for name, B, us, ab, ot in OBS_ROWS:
+        i8, bf = ot["int8"], ot["bf16"]
+        pk = f"{ot['packed'][0]:.1f}" if "packed" in ot else "-"
+        per_env = ab + i8[1] // B
+        tot = us + i8[0]
+        gbs = per_env * B / tot / 1e3
+        print(f"| {name} | {B} | {i8[0]:.1f}, {i8[1] / i8[0] / 1e3:.0f} | {bf[0]:.1f}, {bf[1] / bf[0] / 1e3:.0f} | {pk} | {tot:.1f} | {per_env} | {gbs:.0f} | {gbs / 8000:.3f} |")
 
 
 if __name__ == "__main__":
