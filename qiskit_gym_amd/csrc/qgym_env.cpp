@@ -195,6 +195,7 @@ int qg_env_clone(const qg_env *e, qg_env **out) {  // Env: DynClone -- deep copy
     d->step_index = s->step_index;
     d->coin_seed = s->coin_seed;
     d->maybe_nonsymplectic = s->maybe_nonsymplectic;
+    d->observe_counter = s->observe_counter;
     struct { void *dst; const void *src; size_t bytes; } copies[] = {
         {d->state, s->state, s->state_bytes},
         {d->depth, s->depth, 4},
@@ -208,6 +209,8 @@ int qg_env_clone(const qg_env *e, qg_env **out) {  // Env: DynClone -- deep copy
         {d->layers, s->layers, (size_t)s->layers_len * 4},
         {d->rot, s->rot, (size_t)s->rmax * 16},
         {d->pmeta, s->pmeta, s->pmeta ? (size_t)16 : 0},
+        {d->bad, s->bad, s->layout == LAYOUT_TILE64 ? (size_t)8 : (size_t)4},  // incremental solved mask of the one-step kernels
+        {d->perm_idx, s->perm_idx, (size_t)4},                                 // PauliEnv current_perm_idx (pauli.rs:661)
     };
     for (auto &cp : copies)
         if (cp.dst && cp.src && cp.bytes && hipMemcpy(cp.dst, cp.src, cp.bytes, hipMemcpyDeviceToDevice) != hipSuccess) {

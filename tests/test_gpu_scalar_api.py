@@ -78,6 +78,43 @@ def test_constructor_state_clone_and_inverts():
     assert full.tolist() == state.flatten().tolist()
 
 
+@pytest.mark.parametrize("kind,n,inverts", [("clifford", 5, False), ("clifford", 20, False), ("linear_function", 12, False),
+                                            ("linear_function", 40, False), ("clifford", 4, True), ("permutation", 9, False), ("pauli", 4, False)])
+def test_clone_mid_episode_continues_like_the_original(kind, n, inverts):
+    """Env: DynClone -- a clone taken mid-episode carries every piece of resident state (including the
+    incremental solved mask of the one-step kernels) and then evolves independently."""
+    gs = grid_gateset("permutation", 3, 3) if kind == "permutation" else line_gateset(kind, n)
+    kw = dict(add_perms=False, difficulty=6)
+    if kind != "pauli":
+        kw["add_inverts"] = inverts
+    env = RawEnv(kind, n, gs, **kw)
+    ora = OracleEnv(kind, n, gs, **{k: int(v) for k, v in kw.items()})
+    rng = np.random.default_rng(3)
+    if kind == "pauli":
+        env.reset(5)
+        ora.pauli_reset_seeded(5, 0)
+    else:
+        ora.reset_with(rng.integers(0, len(gs), size=6))
+        start = ora.get_state().tolist()
+        env.set_state(start)  # the same scrambled state through the trait's own entry point
+        ora.set_state(start)
+    for t in range(3):
+        a = int(rng.integers(len(gs)))
+        env.step(a, 0) if kind != "pauli" else env.step(a)
+        ora.step(a, 0)
+    twin, ora_twin = env.clone(), ora.clone()
+    for t in range(10):
+        a, b = int(rng.integers(len(gs))), int(rng.integers(len(gs)))
+        for e, o, act in ((env, ora, a), (twin, ora_twin, b)):
+            e.step(act, 0) if kind != "pauli" else e.step(act)
+            o.step(act, 0)
+            assert e.observe() == o.observe(), (kind, t)
+            assert np.float32(e.reward()).view(np.uint32) == o.reward_bits(), (kind, t)
+            assert e.success() == o.success() and e.is_final() == o.is_final()
+    # a clone of a solved env reports success; a clone of an unsolved one must not
+    assert twin.success() == ora_twin.success()
+
+
 def test_twists_match_symmetry_rules():
     # line-3 CX+SWAP: automorphisms {id, reversal}; both map the gateset onto itself
     gs = line_gateset("linear_function", 3)
