@@ -176,6 +176,11 @@ int qg_vec_reset_done(qg_vec *v, uint64_t seed, void *stream);
  * advances the clock (a device-side add inside the graph) between replays.  NULL detaches.  The
  * word must stay valid while attached.  Synchronises and drops cached rollout graphs. */
 int qg_vec_set_clock(qg_vec *v, const uint64_t *clock_dev);
+/* Stream ordering without a system-scope fence: everything enqueued on `waiter_stream` after this call
+ * runs after everything enqueued on `producer_stream` before it (hipEventRecord + hipStreamWaitEvent with
+ * hipEventDisableTiming | hipEventDisableSystemFence).  For side-stream work next to the step stream
+ * (the multi-GPU observation all-gather). */
+int qg_stream_wait_stream(void *waiter_stream, void *producer_stream);
 /* The handle's host-side RNG counters: the next step's add_inverts coin is drawn with counter
  * `step_index` (it advances by one per step) and the next PauliEnv observe() permutation with
  * `observe_index`.  A caller that replays graphs sets them to the position inside the graph so

@@ -752,6 +752,15 @@ int qg_vec_set_clock(qg_vec *v, const uint64_t *clock_dev) {
     return QG_OK;
 }
 
+int qg_stream_wait_stream(void *waiter, void *producer) {
+    // one pooled event per thread: device-scope only (no system fence), no timing
+    static thread_local hipEvent_t ev = nullptr;
+    if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIP_TRY(hipEventRecord(ev, (hipStream_t)producer));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)waiter, ev, 0));
+    return QG_OK;
+}
+
 int qg_vec_set_counters(qg_vec *v, uint64_t step_index, uint64_t observe_index) {
     if (!v) return set_error(QG_ERR_INVALID, "null argument");
     v->step_index = step_index;

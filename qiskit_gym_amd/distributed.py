@@ -7,7 +7,7 @@ is the observation handed to the learner: ranks all-gather the *bit-packed* obse
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -41,6 +41,71 @@ def all_gather_observation(local: torch.Tensor, out: Optional[torch.Tensor] = No
     else:
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
     return out
+
+
+class OverlappedGather:
+    """Double-buffered all-gather of a per-rank snapshot that overlaps with the work enqueued after it.
+
+    `submit(fill)` lets `fill(buffer)` enqueue the snapshot (e.g. `env.observe_packed(out=buffer)`) on the
+    current stream and hands the PREVIOUS snapshot to a side stream for the collective; `flush()` hands
+    over the last one.  The hand-over goes through the host -- wait for the snapshot's event, then enqueue
+    the collective -- not through a stream-to-stream event wait: on ROCm 7 / MI355X, once a second stream
+    has waited on an event of the stepping stream, every later hipGraph replay on that stream runs ~40 %
+    slower per kernel (tools/gather_probe.py), while the host-mediated form costs nothing measurable.
+    The host therefore runs at most one snapshot ahead of the device.  CPU tensors (gloo) gather inline."""
+
+    def __init__(self, shard_shape, dtype: torch.dtype, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        shard_shape = tuple(shard_shape)
+        self.snap = [torch.empty(shard_shape, dtype=dtype, device=self.device) for _ in range(2)]
+        self.out = [torch.empty((self.world * shard_shape[0],) + shard_shape[1:], dtype=dtype, device=self.device) for _ in range(2)]
+        self.n = 0
+        self.pending: Optional[int] = None
+        self.completed: List[int] = []  # buffers whose gather has been enqueued, oldest first
+        if self.cuda:
+            self.comm = torch.cuda.Stream(device=self.device)
+            self.ready = [torch.cuda.Event() for _ in range(2)]
+            self.done = [torch.cuda.Event() for _ in range(2)]
+
+    def _hand_over(self, b: int):
+        if self.cuda:
+            self.ready[b].synchronize()
+            with torch.cuda.stream(self.comm):
+                all_gather_observation(self.snap[b], out=self.out[b], group=self.group)
+                self.done[b].record(self.comm)
+        else:
+            all_gather_observation(self.snap[b], out=self.out[b], group=self.group)
+        self.completed.append(b)
+        del self.completed[:-2]
+
+    def submit(self, fill: Callable[[torch.Tensor], None]):
+        b = self.n & 1
+        if self.cuda and self.n >= 2:
+            self.done[b].synchronize()  # the gather that read snap[b] is over
+        fill(self.snap[b])
+        if self.cuda:
+            self.ready[b].record(torch.cuda.current_stream(self.device))
+        if self.pending is not None:
+            self._hand_over(self.pending)
+        self.pending = b
+        self.n += 1
+
+    def flush(self):
+        if self.pending is not None:
+            self._hand_over(self.pending)
+            self.pending = None
+
+    def latest(self) -> Optional[torch.Tensor]:
+        """The most recently gathered `[W * B_local, ...]` tensor (waits for its collective), or None."""
+        if not self.completed:
+            return None
+        b = self.completed[-1]
+        if self.cuda:
+            self.done[b].synchronize()
+        return self.out[b]
 
 
 def unpack_rows_u32(packed: torch.Tensor, dim: int) -> torch.Tensor:

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from qiskit_gym_amd.distributed import all_gather_observation, local_actions, shard_range, unpack_rows_u32
+from qiskit_gym_amd.distributed import OverlappedGather, all_gather_observation, local_actions, shard_range, unpack_rows_u32
 
 
 def test_shard_ranges_partition_the_batch():
@@ -55,6 +55,15 @@ def _worker(rank, world, port, per_rank, d, result_q):
         acts = torch.arange(3 * total).reshape(3, total)
         mine = local_actions(acts, rank, world)
         ok = ok and mine.shape == (3, per_rank) and int(mine[0, 0]) == start
+        # the double-buffered gatherer bench.py uses: snapshot k is gathered when snapshot k + 1 is submitted (or on flush)
+        og = OverlappedGather((per_rank, d), torch.int32, "cpu")
+        ok = ok and og.latest() is None
+        for k in range(5):
+            og.submit(lambda buf, k=k: buf.copy_(local + k))
+            if k >= 1:
+                ok = ok and torch.equal(og.latest(), full + (k - 1))
+        og.flush()
+        ok = ok and torch.equal(og.latest(), full + 4)
         # max-over-ranks timing reduction used by bench.py
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
