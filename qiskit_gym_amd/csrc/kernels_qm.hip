@@ -573,6 +573,67 @@ __device__ inline void qm_init_finish(const InitArgs &a, uint64_t env, const QmR
     }
 }
 
+// qg_vec_reset_done with few finished envs: 16 lanes per env instead of one.  The counter-RNG draws of
+// a chunk (two splitmix64 rounds each, ~300 cycles of 64-bit multiplies) are spread over the 16 lanes
+// and parked in LDS as row-operation words; two lanes then apply them to the LDS-resident rows.  With a
+// few thousand finished envs of 65 536 this fills the otherwise idle SIMDs (measured per reset_done call
+// at difficulty 256, 3 % finished: 725 us in-register per-lane scramble, 115 us compacted + LDS rows, see
+// profiles).  Many finished envs (synchronised episode ends) stay on the one-lane-per-env path of the same launch.
+
+// `lds`: the block's shared array (the one-lane-per-env path's row storage, reused: 4 waves x 4 envs x (R rows + 64 words))
+template <int NXP, bool HAS_Z>
+__device__ inline void qm_scramble_coop(const InitArgs &a, uint32_t count, uint32_t *lds) {
+    using Rows = QmRows<NXP, HAS_Z>;
+    constexpr uint32_t S = QM_COOP_LANES, EPW = QG_WAVE / S, CH = 64;
+    const uint64_t item = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / S;
+    if (item >= count) return;  // whole lane groups leave together
+    const uint32_t sl = threadIdx.x & (S - 1), w = threadIdx.x >> 6, g = (threadIdx.x & (QG_WAVE - 1)) / S;
+    const uint64_t env = a.list[item];
+    uint32_t *rows = lds + (w * EPW + g) * (Rows::R + CH), *ops = rows + Rows::R;
+    for (uint32_t k = sl; k < (uint32_t)Rows::R; k += S) {  // identity (clifford.rs:307)
+        const uint32_t j = HAS_Z ? k >> 1 : k;
+        rows[k] = j < a.N ? ((HAS_Z && (k & 1u)) ? (1u << a.N) << j : 1u << j) : 0u;
+    }
+    const uint64_t seed = init_seed(a);
+    for (uint32_t c0 = 0; c0 < a.n_draws; c0 += CH) {
+        const uint32_t len = a.n_draws - c0 < CH ? a.n_draws - c0 : CH;
+        for (uint32_t k = sl; k < CH; k += S)  // the tail of the last chunk is padded with "no gate"
+            ops[k] = k < len ? a.rowops[rng_action(seed, env, c0 + k, a.num_actions)] : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (sl < 2) {
+            // a gate is two row operations on disjoint rows (clifford.rs:111-133): lane 0 does the first, lane 1
+            // the second, in lockstep; four gate words are fetched ahead of the dependent row reads
+            const uint32_t sh = 14u * sl;
+            auto rowop = [&](uint32_t o) {
+                const uint32_t op = (o >> sh) & 0x3FFFu, type = op >> 12, dst = op & 63u, src = (op >> 6) & 63u;
+                const uint32_t va = rows[dst], vb = rows[src];
+                const uint32_t swap = 0u - (uint32_t)(type == OP_SWAP);
+                const uint32_t nd = (vb & swap) | ((va ^ vb) & ~swap), ns = (va & swap) | (vb & ~swap);
+                if (type != OP_NONE) {
+                    rows[dst] = nd;
+                    rows[src] = ns;
+                }
+            };
+            const uint32_t padded = (len + 3u) & ~3u;
+            for (uint32_t k = 0; k < padded; k += 4) {
+                const uint32_t o0 = ops[k], o1 = ops[k + 1], o2 = ops[k + 2], o3 = ops[k + 3];
+                rowop(o0);
+                rowop(o1);
+                rowop(o2);
+                rowop(o3);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (sl != 0) return;
+    Rows s;
+#pragma unroll
+    for (int k = 0; k < Rows::R; ++k) s.r[k] = rows[k];
+    qm_init_finish<NXP, HAS_Z>(a, env, s);
+}
+
 template <int NXP, bool HAS_Z>
 __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
     using Rows = QmRows<NXP, HAS_Z>;
@@ -582,8 +643,13 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t env = tid;
     if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
-        const uint32_t count = list_count_take(a.list_count);  // this kernel is the list's last reader
-        if (tid >= count || (a.coop && qm_coop_takes(count, a.B))) return;
+        const uint32_t count = list_count_take(a.list_count);  // this kernel is the list's only reader
+        constexpr bool coop_fits = 16 * (Rows::R + 64) <= 4 * Rows::R * QG_WAVE;  // its LDS footprint inside lds_rows
+        if (coop_fits && a.coop && qm_coop_takes(count, a.B)) {  // few finished envs: 16 lanes each (count * 16 <= B / 2 threads)
+            qm_scramble_coop<NXP, HAS_Z>(a, count, &lds_rows[0][0][0]);
+            return;
+        }
+        if (tid >= count) return;
         env = a.list[tid];
     } else {
         if (env >= a.B) return;
@@ -644,70 +710,6 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
 #pragma unroll
         for (int sl = 0; sl < Rows::R; ++sl) s.r[sl] = rows[sl][L];
     }
-    qm_init_finish<NXP, HAS_Z>(a, env, s);
-}
-
-// qg_vec_reset_done with few finished envs: 16 lanes per env instead of one.  The counter-RNG draws of
-// a chunk (two splitmix64 rounds each, ~300 cycles of 64-bit multiplies) are spread over the 16 lanes
-// and parked in LDS as row-operation words; two lanes then apply them to the LDS-resident rows.  With a
-// few thousand finished envs of 65 536 this fills the otherwise idle SIMDs (measured per reset_done call
-// at difficulty 256, 3 % finished: 725 us in-register per-lane scramble, 115 us compacted + LDS rows, see
-// profiles).  Many finished envs (synchronised episode ends) stay on the one-lane-per-env kernel.
-
-template <int NXP, bool HAS_Z>
-__global__ __launch_bounds__(256) void qm_scramble_coop_kernel(InitArgs a) {
-    using Rows = QmRows<NXP, HAS_Z>;
-    constexpr uint32_t S = QM_COOP_LANES, EPW = QG_WAVE / S, CH = 64;
-    __shared__ uint32_t lrows[4][EPW][Rows::R];
-    __shared__ uint32_t lops[4][EPW][CH];
-    const uint32_t count = *a.list_count;
-    if (!qm_coop_takes(count, a.B)) return;
-    const uint64_t item = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / S;
-    if (item >= count) return;  // whole lane groups leave together
-    const uint32_t sl = threadIdx.x & (S - 1), w = threadIdx.x >> 6, g = (threadIdx.x & (QG_WAVE - 1)) / S;
-    const uint64_t env = a.list[item];
-    uint32_t *rows = lrows[w][g], *ops = lops[w][g];
-    for (uint32_t k = sl; k < (uint32_t)Rows::R; k += S) {  // identity (clifford.rs:307)
-        const uint32_t j = HAS_Z ? k >> 1 : k;
-        rows[k] = j < a.N ? ((HAS_Z && (k & 1u)) ? (1u << a.N) << j : 1u << j) : 0u;
-    }
-    const uint64_t seed = init_seed(a);
-    for (uint32_t c0 = 0; c0 < a.n_draws; c0 += CH) {
-        const uint32_t len = a.n_draws - c0 < CH ? a.n_draws - c0 : CH;
-        for (uint32_t k = sl; k < CH; k += S)  // the tail of the last chunk is padded with "no gate"
-            ops[k] = k < len ? a.rowops[rng_action(seed, env, c0 + k, a.num_actions)] : 0u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (sl < 2) {
-            // a gate is two row operations on disjoint rows (clifford.rs:111-133): lane 0 does the first, lane 1
-            // the second, in lockstep; four gate words are fetched ahead of the dependent row reads
-            const uint32_t sh = 14u * sl;
-            auto rowop = [&](uint32_t o) {
-                const uint32_t op = (o >> sh) & 0x3FFFu, type = op >> 12, dst = op & 63u, src = (op >> 6) & 63u;
-                const uint32_t va = rows[dst], vb = rows[src];
-                const uint32_t swap = 0u - (uint32_t)(type == OP_SWAP);
-                const uint32_t nd = (vb & swap) | ((va ^ vb) & ~swap), ns = (va & swap) | (vb & ~swap);
-                if (type != OP_NONE) {
-                    rows[dst] = nd;
-                    rows[src] = ns;
-                }
-            };
-            const uint32_t padded = (len + 3u) & ~3u;
-            for (uint32_t k = 0; k < padded; k += 4) {
-                const uint32_t o0 = ops[k], o1 = ops[k + 1], o2 = ops[k + 2], o3 = ops[k + 3];
-                rowop(o0);
-                rowop(o1);
-                rowop(o2);
-                rowop(o3);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (sl != 0) return;
-    Rows s;
-#pragma unroll
-    for (int k = 0; k < Rows::R; ++k) s.r[k] = rows[k];
     qm_init_finish<NXP, HAS_Z>(a, env, s);
 }
 
@@ -796,8 +798,6 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
 }
 template <int NXP, bool HAS_Z>
 static hipError_t launch_init(const InitArgs &a, hipStream_t s) {
-    if (a.coop)  // device-side choice by the number of finished envs: exactly one of the two kernels does the work
-        hipLaunchKernelGGL((qm_scramble_coop_kernel<NXP, HAS_Z>), dim3(grid_for(a.B / 2, 256)), dim3(256), 0, s, a);
     hipLaunchKernelGGL((qm_init_kernel<NXP, HAS_Z>), dim3(grid_for(a.B, 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
