@@ -440,6 +440,126 @@ __global__ __launch_bounds__(256) void ptile_step_kernel(PTArgs pa) {
     if (fault) atomicOr(&a.error[env], fault);
 }
 
+// ---- the gate's micro-ops on all rotations at once (one-step kernel) ---------------------------------
+// A gate's micro-ops only read and write bits qa / qb of every rotation's x and z masks.  Those bits are
+// gathered once into four "slices" (bit k = rotation k), the micro-ops become a handful of logic ops on
+// the slices (the 2-bit phases already are bit-planes), `clean` tests weights through the slices and two
+// masks computed once per gate (b0 / b1: rotations whose support OUTSIDE {qa, qb} has 0 / exactly 1 qubit),
+// and the slices are scattered back once.
+template <int RM>
+struct PTSlices {
+    uint32_t xa, za, xb, zb;  // bit k: bit qa (qb) of rotation k's x (z) mask; with qa == qb the b-slices stay zero
+    uint32_t b0, b1;
+};
+
+template <int NQ, int RM>
+__device__ inline void pt_slices_gather(const PTState<NQ, RM> &s, uint32_t qa, uint32_t qb, PTSlices<RM> &v) {
+    const uint32_t outside = ~((1u << qa) | (1u << qb));
+    const uint32_t two = qa != qb;
+    v.xa = v.za = v.xb = v.zb = v.b0 = v.b1 = 0;
+#pragma unroll
+    for (int k = 0; k < RM; ++k) {
+        v.xa |= ((s.rx[k] >> qa) & 1u) << k;
+        v.za |= ((s.rz[k] >> qa) & 1u) << k;
+        v.xb |= ((s.rx[k] >> qb) & two) << k;
+        v.zb |= ((s.rz[k] >> qb) & two) << k;
+        const uint32_t c = (uint32_t)__popc((s.rx[k] | s.rz[k]) & outside);
+        v.b0 |= (uint32_t)(c == 0) << k;
+        v.b1 |= (uint32_t)(c == 1) << k;
+    }
+}
+template <int NQ, int RM>
+__device__ inline void pt_slices_scatter(PTState<NQ, RM> &s, uint32_t qa, uint32_t qb, const PTSlices<RM> &v) {
+    const uint32_t two = qa != qb, keep = ~((1u << qa) | (1u << qb));
+#pragma unroll
+    for (int k = 0; k < RM; ++k) {
+        s.rx[k] = (s.rx[k] & keep) | (((v.xa >> k) & 1u) << qa) | ((((v.xb >> k) & 1u) & two) << qb);
+        s.rz[k] = (s.rz[k] & keep) | (((v.za >> k) & 1u) << qa) | ((((v.zb >> k) & 1u) & two) << qb);
+    }
+}
+// one micro-op (Pauli::evolve_*, pauli.rs:83-110); `on_b`: its first operand p is qubit qb
+template <int NQ, int RM>
+__device__ inline void pt_slices_evolve(PTState<NQ, RM> &s, PTSlices<RM> &v, uint32_t kind, bool on_b) {
+    uint32_t &xp = on_b ? v.xb : v.xa, &zp = on_b ? v.zb : v.za;
+    uint32_t &xq = on_b ? v.xa : v.xb, &zq = on_b ? v.za : v.zb;
+    uint32_t inc1 = 0, inc2 = 0;
+    if (kind == M_H) {          // x_p <-> z_p, phase += 2 * (x_p & z_p)
+        inc2 = xp & zp;
+        const uint32_t t = xp;
+        xp = zp;
+        zp = t;
+    } else if (kind == M_S) {   // z_p ^= x_p, phase += x_p
+        inc1 = xp;
+        zp ^= xp;
+    } else if (kind == M_SX) {  // x_p ^= z_p, phase += 3 * z_p
+        inc1 = inc2 = zp;
+        xp ^= zp;
+    } else if (kind == M_CNOT) {  // cnot(i = p, j = q) = evolve_cx(ctrl = q, tgt = p): x_p ^= x_q ; z_q ^= z_p
+        xp ^= xq;
+        zq ^= zp;
+    }
+    const uint32_t carry = s.plo & inc1;  // phases += inc1 + 2 * inc2 (mod 4)
+    s.plo ^= inc1;
+    s.phi ^= carry ^ inc2;
+}
+// clean_and_return_with_phases (pauli_network.rs:139-165) on the slices; see pt_clean for the bookkeeping
+template <int NQ, int RM>
+__device__ inline void pt_slices_clean(PTState<NQ, RM> &s, const PTSlices<RM> &v, uint32_t qa, uint32_t qb, uint32_t &n_removed, uint32_t &fault,
+                                       uint32_t *log, uint64_t (&rem_pos)[(RM + 7) / 8]) {
+    const uint32_t sa = v.xa | v.za, sb = v.xb | v.zb;  // weights do not change while cleaning (:79-93)
+    const uint32_t trivial = (v.b0 & ~(sa & sb)) | (v.b1 & ~(sa | sb)), zero_w = v.b0 & ~(sa | sb);
+    for (;;) {
+        uint32_t front = 0;  // get_front_layer (pauli_dag.rs:47-57): no out-edge to a live node
+#pragma unroll
+        for (int k = 0; k < RM; ++k) front |= (uint32_t)((s.rpred[k] & s.alive) == 0) << k;
+        uint32_t doomed = front & trivial & s.alive;
+        if (doomed & zero_w) {  // which_qubit(..).unwrap() on None (:113-114): the reference panics
+            fault |= QG_FAULT_ZERO_WEIGHT;
+            doomed &= ~zero_w;
+        }
+        if (!doomed) break;
+        uint32_t dpos = 0;  // bit i: DAG node i is removed in this pass (removals are reported in node order, :146-152)
+#pragma unroll
+        for (int i = 0; i < RM; ++i) dpos |= (((uint32_t)i < s.count) ? ((doomed >> pnib(s.order, i)) & 1u) : 0u) << i;
+        if (log) {
+#pragma unroll
+            for (int k = 0; k < RM; ++k) {
+                if ((doomed >> k) & 1u) {
+                    uint32_t pos = 0;
+#pragma unroll
+                    for (int i = 0; i < RM; ++i) pos = (pnib(s.order, i) == (uint32_t)k && (uint32_t)i < s.count) ? (uint32_t)i : pos;
+                    const uint32_t seq = n_removed + (uint32_t)__popc(dpos & ((1u << pos) - 1u));
+                    // which_qubit / which_axis (:95-137): the single support qubit is outside {qa, qb} (b1), qa or qb
+                    uint32_t q, bx, bz;
+                    if ((v.b1 >> k) & 1u) {
+                        const uint32_t sup = (s.rx[k] | s.rz[k]) & ~((1u << qa) | (1u << qb));
+                        q = (uint32_t)__ffs((int)sup) - 1u;
+                        bx = (s.rx[k] >> q) & 1u;
+                        bz = (s.rz[k] >> q) & 1u;
+                    } else if ((sa >> k) & 1u) {
+                        q = qa; bx = (v.xa >> k) & 1u; bz = (v.za >> k) & 1u;
+                    } else {
+                        q = qb; bx = (v.xb >> k) & 1u; bz = (v.zb >> k) & 1u;
+                    }
+                    const uint32_t axis = bx ? (bz ? 1u : 0u) : 2u;
+                    log[seq] = 0x80000000u | (axis << 21) | (q << 11) | ((uint32_t)k << 1);  // phase bit patched after the gate
+                    rem_pos[k / 8] |= (uint64_t)(seq + 1u) << (8 * (k % 8));
+                }
+            }
+        }
+        n_removed += (uint32_t)__popc(doomed);
+#pragma unroll
+        for (int i = RM - 1; i >= 0; --i) {  // retain_nodes: visit NodeIndex high -> low, swap_remove each doomed node (:160-161)
+            if ((uint32_t)i < s.count && ((dpos >> i) & 1u)) {
+                const uint64_t last = (uint64_t)pnib(s.order, s.count - 1);
+                s.order = (s.order & ~(0xFull << (4 * i))) | (last << (4 * i));
+                s.count -= 1;
+            }
+        }
+        s.alive &= ~doomed;
+    }
+}
+
 // One step per launch (PauliEnv::step, pauli.rs:588-635): rotations and bookkeeping in registers,
 // the rows of the gate's qubits gathered from / scattered to the tile at per-lane addresses.
 template <int NQ, int RM, bool FEAT>
@@ -490,16 +610,21 @@ __global__ __launch_bounds__(256) void ptile_step1_kernel(PTArgs pa) {
         if (qb != qa) L::store_qubit(tile, lane, qb, n[2], n[3]);
         L::store_qubit(tile, lane, qa, n[0], n[1]);
         s.bad = pt_bad_update(s.bad, N, qa, qb, n);
-        const uint32_t alive_at_gate = s.alive;
+        const uint32_t alive_at_gate = s.alive, plo0 = s.plo, phi0 = s.phi;
+        PTSlices<RM> v;
+        pt_slices_gather<NQ, RM>(s, qa, qb, v);
+        const PTSlices<RM> v0 = v;
 #pragma unroll 1
         for (uint32_t k = 0; k < 3; ++k) {  // PauliNetwork::act (pauli_network.rs:225-260)
             const uint32_t mo = (uint32_t)(prog >> (26 + 4 * k)) & 15u;
             const uint32_t kind = mo & 7u;
             if (kind == M_NOP) continue;
-            const uint32_t p = (mo & 8u) ? qb : qa, q = (mo & 8u) ? qa : qb;
-            touched_rot |= pt_evolve<NQ, RM>(s, kind, p, q) & alive_at_gate;  // dead rotations are never read again
-            if (kind == M_CNOT) pt_clean<NQ, RM>(s, n_removed, fault, log, rem_pos);
+            pt_slices_evolve<NQ, RM>(s, v, kind, (mo & 8u) != 0);
+            if (kind == M_CNOT) pt_slices_clean<NQ, RM>(s, v, qa, qb, n_removed, fault, log, rem_pos);
         }
+        pt_slices_scatter<NQ, RM>(s, qa, qb, v);
+        // records to write back: rotations alive at the gate whose bits or phase changed (dead ones are never read again)
+        touched_rot = ((v.xa ^ v0.xa) | (v.za ^ v0.za) | (v.xb ^ v0.xb) | (v.zb ^ v0.zb) | (s.plo ^ plo0) | (s.phi ^ phi0)) & alive_at_gate;
     }
 
     if (FEAT && (a.flags & F_TRACK) && in_range) {  // pauli.rs:612-626
