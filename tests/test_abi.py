@@ -89,3 +89,43 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not pat.search(text), (dirpath, f, pat.search(text).group(0))
+
+
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """The boundary is a C ABI: include/qgym.h compiles as C99 (no C++ or torch types) and a C program that
+    uses only the header links against libqgym.so and runs its host-only entry points."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "abi_user.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "qgym.h"
+int main(void) {
+    qg_config cfg;
+    qg_gate g;
+    int64_t idx[2] = {2, 0};
+    qg_config_default(&cfg, QG_CLIFFORD, 16);
+    if (cfg.max_depth != 128 || cfg.add_inverts != 1) return 1;
+    if (qg_gate_parse(" Cz", idx, 2, &g) != QG_OK || g.kind != QG_CZ || g.q0 != 2 || g.q1 != 0) return 2;
+    if (qg_gate_parse("cz", idx, 1, &g) != QG_ERR_INVALID || !strstr(qg_last_error(), "expects 2 indices")) return 3;
+    if (qg_abi_version() != QG_ABI_VERSION) return 4;
+    /* no GPU here: creation must fail loudly, never fall back */
+    if (qg_device_count() == 0) {
+        qg_vec *v = NULL;
+        if (qg_vec_create(&cfg, &g, 1, 8, 0, &v) != QG_ERR_DEVICE || v != NULL) return 5;
+    }
+    printf("ok %d\n", qg_device_count());
+    return 0;
+}
+''')
+    inc, libdir = os.path.join(ROOT, "include"), os.path.join(ROOT, "qiskit_gym_amd", "lib")
+    _lib.load()  # builds the library when missing
+    exe = tmp_path / "abi_user"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lqgym",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), (out.returncode, out.stdout, out.stderr)
