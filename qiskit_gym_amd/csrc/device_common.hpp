@@ -25,6 +25,96 @@ __device__ inline uint32_t list_count_take(uint32_t *counter) {
     return count;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Reset scramble on LDS-resident rows, shared by the TILE (uint32 rows) and TILE64 (uint64 rows) layouts.
+// reset() = identity followed by `difficulty` random gates (clifford.rs:306-316): a dependent chain per env,
+// so what matters is the latency of one gate.  The rows live in LDS, a gate is <= 2 row operations on
+// disjoint slots (clifford.rs:111-133) read from the row-op table (InitArgs::rowops, make_op with slot
+// indices), and the counter-RNG draws -- two splitmix64 rounds, ~300 cycles of 64-bit multiplies each --
+// are issued ahead of the dependent LDS chain.
+// ---------------------------------------------------------------------------------------------------
+#define QG_COOP_LANES 16
+// qg_vec_reset_done: lists of at most B / 32 finished envs take the 16-lanes-per-env path
+__device__ inline bool coop_takes(uint32_t count, uint64_t B) { return (uint64_t)count * QG_COOP_LANES * 2 <= B; }
+
+template <typename W>
+__device__ inline void lds_rowop(W *dst, W *src, uint32_t type) {
+    const W va = *dst, vb = *src;
+    const W swap = (W)0 - (W)(type == OP_SWAP);
+    const W nd = (vb & swap) | ((va ^ vb) & ~swap), ns = (va & swap) | (vb & ~swap);
+    if (type != OP_NONE) {
+        *dst = nd;
+        *src = ns;
+    }
+}
+
+// one lane per env: `rows` = this wave's [slot][QG_WAVE] array, L = the lane's column in it
+template <typename W>
+__device__ inline void scramble_flat(W (*rows)[QG_WAVE], uint32_t L, const InitArgs &a, uint64_t env) {
+    const uint64_t seed = init_seed(a);
+    auto draw = [&](uint32_t t) -> uint32_t {
+        if (t >= a.n_draws) return 0u;
+        const int64_t act = a.actions ? (int64_t)a.actions[(uint64_t)t * a.B + env] : (int64_t)rng_action(seed, env, t, a.num_actions);
+        return (act >= 0 && act < (int64_t)a.num_actions) ? a.rowops[act] : 0u;
+    };
+    auto gate = [&](uint32_t o) {
+        lds_rowop<W>(&rows[o & 63u][L], &rows[(o >> 6) & 63u][L], (o >> 12) & 3u);
+        lds_rowop<W>(&rows[(o >> 14) & 63u][L], &rows[(o >> 20) & 63u][L], (o >> 26) & 3u);
+    };
+    for (uint32_t t = 0; t < a.n_draws; t += 4) {
+        const uint32_t o0 = draw(t), o1 = draw(t + 1), o2 = draw(t + 2), o3 = draw(t + 3);
+        gate(o0);
+        gate(o1);
+        gate(o2);
+        gate(o3);
+    }
+}
+
+// 16 lanes per env (few finished envs: fills the otherwise idle SIMDs).  The draws of a 64-gate chunk are
+// spread over the 16 lanes and parked in LDS as row-op words; two lanes then apply them in lockstep, one
+// row operation each.  `lds`: R rows + 64 words per env, 64 / 16 envs per wave.  Returns the env's rows
+// on the one lane per env that has to finish it (its index in `env`), nullptr on every other lane.
+template <typename W, int R, typename Identity>
+__device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds, uint64_t &env, Identity identity) {
+    constexpr uint32_t S = QG_COOP_LANES, EPW = QG_WAVE / S, CH = 64, PER_ENV = R * sizeof(W) + CH * sizeof(uint32_t);
+    const uint64_t item = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / S;
+    if (item >= count) return nullptr;  // whole lane groups leave together
+    const uint32_t sl = threadIdx.x & (S - 1), w = threadIdx.x >> 6, g = (threadIdx.x & (QG_WAVE - 1)) / S;
+    env = a.list[item];
+    char *base = reinterpret_cast<char *>(lds) + (size_t)(w * EPW + g) * PER_ENV;
+    W *rows = reinterpret_cast<W *>(base);
+    uint32_t *ops = reinterpret_cast<uint32_t *>(base + R * sizeof(W));
+    for (uint32_t k = sl; k < (uint32_t)R; k += S) rows[k] = identity(k);  // clifford.rs:307
+    const uint64_t seed = init_seed(a);
+    for (uint32_t c0 = 0; c0 < a.n_draws; c0 += CH) {
+        const uint32_t len = a.n_draws - c0 < CH ? a.n_draws - c0 : CH;
+        for (uint32_t k = sl; k < CH; k += S)  // the tail of the last chunk is padded with "no gate"
+            ops[k] = k < len ? a.rowops[rng_action(seed, env, c0 + k, a.num_actions)] : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (sl < 2) {
+            const uint32_t sh = 14u * sl;
+            auto rowop = [&](uint32_t o) {
+                const uint32_t op = (o >> sh) & 0x3FFFu;
+                lds_rowop<W>(&rows[op & 63u], &rows[(op >> 6) & 63u], op >> 12);
+            };
+            const uint32_t padded = (len + 3u) & ~3u;
+            for (uint32_t k = 0; k < padded; k += 4) {  // four gate words fetched ahead of the dependent row reads
+                const uint32_t o0 = ops[k], o1 = ops[k + 1], o2 = ops[k + 2], o3 = ops[k + 3];
+                rowop(o0);
+                rowop(o1);
+                rowop(o2);
+                rowop(o3);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    return sl == 0 ? rows : nullptr;
+}
+template <typename W, int R>
+constexpr size_t scramble_coop_lds_bytes(int waves) { return (size_t)waves * (QG_WAVE / QG_COOP_LANES) * (R * sizeof(W) + 64 * sizeof(uint32_t)); }
+
 // Solution-log word of an action (clifford.rs:334-340 pushes the action verbatim, valid or not):
 // the log is 32-bit, so anything a `usize` action could hold beyond 2^32 - 2 -- and a negative
 // int64, which `as usize` turns into 2^64 - 1 -- saturates to 0xFFFFFFFF (read back as UINT64_MAX).

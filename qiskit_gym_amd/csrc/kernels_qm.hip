@@ -534,10 +534,6 @@ __device__ inline uint32_t qm_slot(uint32_t row, uint32_t N, uint32_t nxp, bool 
     return has_z ? (row < N ? 2 * row : 2 * (row - N) + 1) : row;
 }
 
-// reset_done: lists of at most B / 32 finished envs go to the 16-lanes-per-env scramble kernel below
-#define QM_COOP_LANES 16
-__device__ inline bool qm_coop_takes(uint32_t count, uint64_t B) { return (uint64_t)count * QM_COOP_LANES * 2 <= B; }
-
 // the tail of set_state / reset for one env: rows to the tile, reset_internals (clifford.rs:272-283)
 template <int NXP, bool HAS_Z>
 __device__ inline void qm_init_finish(const InitArgs &a, uint64_t env, const QmRows<NXP, HAS_Z> &s) {
@@ -573,80 +569,28 @@ __device__ inline void qm_init_finish(const InitArgs &a, uint64_t env, const QmR
     }
 }
 
-// qg_vec_reset_done with few finished envs: 16 lanes per env instead of one.  The counter-RNG draws of
-// a chunk (two splitmix64 rounds each, ~300 cycles of 64-bit multiplies) are spread over the 16 lanes
-// and parked in LDS as row-operation words; two lanes then apply them to the LDS-resident rows.  With a
-// few thousand finished envs of 65 536 this fills the otherwise idle SIMDs (measured per reset_done call
-// at difficulty 256, 3 % finished: 725 us in-register per-lane scramble, 115 us compacted + LDS rows, see
-// profiles).  Many finished envs (synchronised episode ends) stay on the one-lane-per-env path of the same launch.
-
-// `lds`: the block's shared array (the one-lane-per-env path's row storage, reused: 4 waves x 4 envs x (R rows + 64 words))
-template <int NXP, bool HAS_Z>
-__device__ inline void qm_scramble_coop(const InitArgs &a, uint32_t count, uint32_t *lds) {
-    using Rows = QmRows<NXP, HAS_Z>;
-    constexpr uint32_t S = QM_COOP_LANES, EPW = QG_WAVE / S, CH = 64;
-    const uint64_t item = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / S;
-    if (item >= count) return;  // whole lane groups leave together
-    const uint32_t sl = threadIdx.x & (S - 1), w = threadIdx.x >> 6, g = (threadIdx.x & (QG_WAVE - 1)) / S;
-    const uint64_t env = a.list[item];
-    uint32_t *rows = lds + (w * EPW + g) * (Rows::R + CH), *ops = rows + Rows::R;
-    for (uint32_t k = sl; k < (uint32_t)Rows::R; k += S) {  // identity (clifford.rs:307)
-        const uint32_t j = HAS_Z ? k >> 1 : k;
-        rows[k] = j < a.N ? ((HAS_Z && (k & 1u)) ? (1u << a.N) << j : 1u << j) : 0u;
-    }
-    const uint64_t seed = init_seed(a);
-    for (uint32_t c0 = 0; c0 < a.n_draws; c0 += CH) {
-        const uint32_t len = a.n_draws - c0 < CH ? a.n_draws - c0 : CH;
-        for (uint32_t k = sl; k < CH; k += S)  // the tail of the last chunk is padded with "no gate"
-            ops[k] = k < len ? a.rowops[rng_action(seed, env, c0 + k, a.num_actions)] : 0u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (sl < 2) {
-            // a gate is two row operations on disjoint rows (clifford.rs:111-133): lane 0 does the first, lane 1
-            // the second, in lockstep; four gate words are fetched ahead of the dependent row reads
-            const uint32_t sh = 14u * sl;
-            auto rowop = [&](uint32_t o) {
-                const uint32_t op = (o >> sh) & 0x3FFFu, type = op >> 12, dst = op & 63u, src = (op >> 6) & 63u;
-                const uint32_t va = rows[dst], vb = rows[src];
-                const uint32_t swap = 0u - (uint32_t)(type == OP_SWAP);
-                const uint32_t nd = (vb & swap) | ((va ^ vb) & ~swap), ns = (va & swap) | (vb & ~swap);
-                if (type != OP_NONE) {
-                    rows[dst] = nd;
-                    rows[src] = ns;
-                }
-            };
-            const uint32_t padded = (len + 3u) & ~3u;
-            for (uint32_t k = 0; k < padded; k += 4) {
-                const uint32_t o0 = ops[k], o1 = ops[k + 1], o2 = ops[k + 2], o3 = ops[k + 3];
-                rowop(o0);
-                rowop(o1);
-                rowop(o2);
-                rowop(o3);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (sl != 0) return;
-    Rows s;
-#pragma unroll
-    for (int k = 0; k < Rows::R; ++k) s.r[k] = rows[k];
-    qm_init_finish<NXP, HAS_Z>(a, env, s);
-}
-
 template <int NXP, bool HAS_Z>
 __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
     using Rows = QmRows<NXP, HAS_Z>;
-    // reset scramble: the rows live in LDS (wave-private, [slot][lane]: conflict-free for any per-lane
-    // slot), so a gate is four dynamic-index reads and writes instead of a sweep over 32 registers
+    // reset scramble (device_common.hpp): the rows live in LDS (wave-private, [slot][lane]: conflict-free for
+    // any per-lane slot), so a gate is dynamic-index reads and writes instead of a sweep over 32 registers
     __shared__ uint32_t lds_rows[4][Rows::R][QG_WAVE];
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t env = tid;
     if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
         const uint32_t count = list_count_take(a.list_count);  // this kernel is the list's only reader
-        constexpr bool coop_fits = 16 * (Rows::R + 64) <= 4 * Rows::R * QG_WAVE;  // its LDS footprint inside lds_rows
-        if (coop_fits && a.coop && qm_coop_takes(count, a.B)) {  // few finished envs: 16 lanes each (count * 16 <= B / 2 threads)
-            qm_scramble_coop<NXP, HAS_Z>(a, count, &lds_rows[0][0][0]);
+        constexpr bool coop_fits = scramble_coop_lds_bytes<uint32_t, Rows::R>(4) <= sizeof(lds_rows);
+        if (coop_fits && a.coop && coop_takes(count, a.B)) {  // few finished envs: 16 lanes each (count * 16 <= B / 2 threads)
+            const uint32_t N = a.N;
+            const uint32_t *rows = scramble_coop<uint32_t, Rows::R>(a, count, &lds_rows[0][0][0], env, [N](uint32_t k) -> uint32_t {
+                const uint32_t j = HAS_Z ? k >> 1 : k;
+                return j < N ? ((HAS_Z && (k & 1u)) ? (1u << N) << j : 1u << j) : 0u;
+            });
+            if (!rows) return;
+            Rows s;
+#pragma unroll
+            for (int k = 0; k < Rows::R; ++k) s.r[k] = rows[k];
+            qm_init_finish<NXP, HAS_Z>(a, env, s);
             return;
         }
         if (tid >= count) return;
@@ -682,31 +626,7 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
         const uint32_t L = threadIdx.x & (QG_WAVE - 1);
 #pragma unroll
         for (int sl = 0; sl < Rows::R; ++sl) rows[sl][L] = s.r[sl];
-        const uint64_t seed = init_seed(a);
-        // a gate = two row operations on disjoint slots (clifford.rs:111-133); four draws and their table
-        // reads are issued ahead of the dependent LDS chain
-        auto rowop = [&](uint32_t op) {
-            const uint32_t type = op >> 12, dst = op & 63u, src = (op >> 6) & 63u;
-            const uint32_t va = rows[dst][L], vb = rows[src][L];
-            const uint32_t swap = 0u - (uint32_t)(type == OP_SWAP);
-            const uint32_t nd = (vb & swap) | ((va ^ vb) & ~swap), ns = (va & swap) | (vb & ~swap);
-            if (type != OP_NONE) {
-                rows[dst][L] = nd;
-                rows[src][L] = ns;
-            }
-        };
-        auto draw = [&](uint32_t t) -> uint32_t {
-            if (t >= a.n_draws) return 0u;
-            const int64_t act = a.actions ? (int64_t)a.actions[(uint64_t)t * a.B + env] : (int64_t)rng_action(seed, env, t, a.num_actions);
-            return (act >= 0 && act < (int64_t)a.num_actions) ? a.rowops[act] : 0u;
-        };
-        for (uint32_t t = 0; t < a.n_draws; t += 4) {
-            const uint32_t o0 = draw(t), o1 = draw(t + 1), o2 = draw(t + 2), o3 = draw(t + 3);
-            rowop(o0 & 0x3FFFu); rowop((o0 >> 14) & 0x3FFFu);
-            rowop(o1 & 0x3FFFu); rowop((o1 >> 14) & 0x3FFFu);
-            rowop(o2 & 0x3FFFu); rowop((o2 >> 14) & 0x3FFFu);
-            rowop(o3 & 0x3FFFu); rowop((o3 >> 14) & 0x3FFFu);
-        }
+        scramble_flat<uint32_t>(rows, L, a, env);
 #pragma unroll
         for (int sl = 0; sl < Rows::R; ++sl) s.r[sl] = rows[sl][L];
     }

@@ -445,45 +445,12 @@ __global__ __launch_bounds__(256) void q64_step1_kernel(StepArgs a) {
     if (FEAT && fault) atomicOr(&a.error[env], fault);
 }
 
+// the tail of set_state / reset for one env: rows to the tile, reset_internals (clifford.rs:272-283)
 template <int NS, bool HAS_Z>
-__global__ __launch_bounds__(256) void q64_init_kernel(InitArgs a) {
+__device__ inline void q64_init_finish(const InitArgs &a, uint64_t env, const Q64Rows<NS> &s) {
     using Rows = Q64Rows<NS>;
-    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
-    if (env >= a.B) return;
-    if (a.only_done && !a.done[env]) return;
+    const uint32_t lane = (uint32_t)(env & (QG_WAVE - 1));
     uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Rows::G * 64);
-    Rows s;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) s.r[i] = q64_identity_word<NS, HAS_Z>(i, a.N);
-    if (a.mode == 1) {  // set_state (clifford.rs:299-304)
-#pragma unroll 1
-        for (int sl = 0; sl < NS; ++sl) {
-            const uint32_t j = HAS_Z ? (uint32_t)sl >> 1 : (uint32_t)sl;
-            const uint32_t row = (HAS_Z && (sl & 1)) ? a.N + j : j;
-            uint64_t w = 0;
-            if (j < a.N) {
-                if (a.format == QG_FMT_PACKED) {
-                    w = reinterpret_cast<const uint64_t *>(a.src)[env * a.src_stride + row];
-                    if (a.D < 64) w &= (1ull << a.D) - 1ull;
-                } else if (a.format == QG_FMT_I64) {
-                    const int64_t *p = reinterpret_cast<const int64_t *>(a.src) + env * a.src_stride + (uint64_t)row * a.D;
-                    for (uint32_t c = 0; c < a.D; ++c) w |= (uint64_t)(p[c] > 0) << c;
-                } else {
-                    const int8_t *p = reinterpret_cast<const int8_t *>(a.src) + env * a.src_stride + (uint64_t)row * a.D;
-                    for (uint32_t c = 0; c < a.D; ++c) w |= (uint64_t)(p[c] > 0) << c;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < NS; ++k) s.r[k] = (k == sl) ? w : s.r[k];  // sl is wave-uniform
-        }
-    } else if (a.mode == 2) {  // reset scramble (clifford.rs:306-316)
-        for (uint32_t t = 0; t < a.n_draws; ++t) {
-            const int64_t act = a.actions ? (int64_t)a.actions[(uint64_t)t * a.B + env] : (int64_t)rng_action(init_seed(a), env, t, a.num_actions);
-            const uint32_t ops = (act >= 0 && act < (int64_t)a.num_actions) ? a.gates[act].ops : (Q64_IDENTITY << 12);
-            q64_apply<NS, HAS_Z>(s, ops);
-        }
-    }
     const bool solved = q64_solved<NS, HAS_Z>(s, a.N);
 #pragma unroll
     for (int g = 0; g < Rows::G; ++g) q64_store_group<NS>(tile, lane, s, g);
@@ -509,6 +476,65 @@ __global__ __launch_bounds__(256) void q64_init_kernel(InitArgs a) {
         lay[a.layers_len - 2] = 0;
         lay[a.layers_len - 1] = 0;
     }
+}
+
+template <int NS, bool HAS_Z>
+__global__ __launch_bounds__(64) void q64_init_kernel(InitArgs a) {
+    using Rows = Q64Rows<NS>;
+    // reset scramble on LDS-resident rows (device_common.hpp); one wave per block: NS * 512 B <= 32 KiB
+    __shared__ uint64_t lds_rows[NS][QG_WAVE];
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t env = tid;
+    Rows s;
+    if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
+        const uint32_t count = list_count_take(a.list_count);  // this kernel is the list's only reader
+        if (a.coop && coop_takes(count, a.B)) {  // few finished envs: 16 lanes each
+            const uint32_t N = a.N;
+            const uint64_t *rows = scramble_coop<uint64_t, NS>(a, count, &lds_rows[0][0], env, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); });
+            if (!rows) return;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) s.r[k] = rows[k];
+            q64_init_finish<NS, HAS_Z>(a, env, s);
+            return;
+        }
+        if (tid >= count) return;
+        env = a.list[tid];
+    } else {
+        if (env >= a.B) return;
+        if (a.only_done && !a.done[env]) return;
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s.r[i] = q64_identity_word<NS, HAS_Z>(i, a.N);
+    if (a.mode == 1) {  // set_state (clifford.rs:299-304)
+#pragma unroll 1
+        for (int sl = 0; sl < NS; ++sl) {
+            const uint32_t j = HAS_Z ? (uint32_t)sl >> 1 : (uint32_t)sl;
+            const uint32_t row = (HAS_Z && (sl & 1)) ? a.N + j : j;
+            uint64_t w = 0;
+            if (j < a.N) {
+                if (a.format == QG_FMT_PACKED) {
+                    w = reinterpret_cast<const uint64_t *>(a.src)[env * a.src_stride + row];
+                    if (a.D < 64) w &= (1ull << a.D) - 1ull;
+                } else if (a.format == QG_FMT_I64) {
+                    const int64_t *p = reinterpret_cast<const int64_t *>(a.src) + env * a.src_stride + (uint64_t)row * a.D;
+                    for (uint32_t c = 0; c < a.D; ++c) w |= (uint64_t)(p[c] > 0) << c;
+                } else {
+                    const int8_t *p = reinterpret_cast<const int8_t *>(a.src) + env * a.src_stride + (uint64_t)row * a.D;
+                    for (uint32_t c = 0; c < a.D; ++c) w |= (uint64_t)(p[c] > 0) << c;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) s.r[k] = (k == sl) ? w : s.r[k];  // sl is wave-uniform
+        }
+    } else if (a.mode == 2) {  // reset scramble (clifford.rs:306-316)
+        const uint32_t L = threadIdx.x & (QG_WAVE - 1);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) lds_rows[k][L] = s.r[k];
+        scramble_flat<uint64_t>(lds_rows, L, a, env);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s.r[k] = lds_rows[k][L];
+    }
+    q64_init_finish<NS, HAS_Z>(a, env, s);
 }
 
 // export: one thread per (env, matrix row)
@@ -555,7 +581,7 @@ static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
 }
 template <int NS, bool HAS_Z>
 static hipError_t q64_launch_init(const InitArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL((q64_init_kernel<NS, HAS_Z>), dim3(grid_for(a.B, 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((q64_init_kernel<NS, HAS_Z>), dim3(grid_for(a.B, 64)), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

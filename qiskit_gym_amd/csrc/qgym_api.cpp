@@ -465,7 +465,7 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     // development switch that keeps every step on the register-resident kernel)
     if ((v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) && !(v->flags & F_INVERTS) && !getenv("QGYM_TILE_DENSE"))
         HIP_TRY_V(hipMalloc(&p->bad, (v->layout == LAYOUT_TILE64 ? sizeof(uint64_t) : sizeof(uint32_t)) * batch));
-    if (v->layout == LAYOUT_TILE || (v->layout == LAYOUT_PAULI && v->pauli_tile)) {
+    if (v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64 || (v->layout == LAYOUT_PAULI && v->pauli_tile)) {
         HIP_TRY_V(hipMalloc(&p->done_list, sizeof(uint32_t) * (batch + 2)));
         HIP_TRY_V(hipMemset(p->done_list + batch, 0, 2 * sizeof(uint32_t)));
     }
@@ -485,7 +485,7 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     HIP_TRY_V(hipMalloc(&p->d_descs, sizeof(uint32_t) * descs.size()));
     HIP_TRY_V(hipMemcpy(p->d_gates, table.data(), sizeof(GateEntry) * table.size(), hipMemcpyHostToDevice));
     HIP_TRY_V(hipMemcpy(p->d_descs, descs.data(), sizeof(uint32_t) * descs.size(), hipMemcpyHostToDevice));
-    if (v->layout == LAYOUT_TILE) {  // the same gates as <= 2 row operations on tile slots (clifford.rs:89-133)
+    if (v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) {  // the same gates as <= 2 row operations on tile slots (clifford.rs:89-133)
         std::vector<uint32_t> rowops(table.size(), 0u);
         auto slot = [&](uint32_t row) { return v->has_z ? (row < N ? 2 * row : 2 * (row - N) + 1) : row; };
         for (size_t i = 0; i < n_gates; ++i) {

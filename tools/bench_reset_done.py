@@ -4,10 +4,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from qiskit_gym_amd.vec import VecEnv
-from util import line_gateset
+from util import grid_gateset, line_gateset
 
-for kind, n, diff in (("clifford", 16, 256), ("clifford", 16, 32), ("pauli", 20, 128)):
-    gs = line_gateset(kind, n)
+for kind, n, diff in (("clifford", 16, 256), ("clifford", 16, 32), ("pauli", 20, 128), ("clifford", 32, 256), ("linear_function", 8, 64), ("permutation", 9, 16)):
+    gs = grid_gateset("permutation", 3, 3) if kind == "permutation" else line_gateset(kind, n)
     B = 65536
     kw = dict(add_perms=False, track_solution=False, difficulty=diff)
     if kind != "pauli":
