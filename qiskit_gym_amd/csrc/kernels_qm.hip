@@ -217,6 +217,12 @@ __device__ inline void qm_symplectic_candidate(const uint32_t (&m)[32], uint32_t
 
 template <int NXP>
 __device__ inline void qm_to_slot_space(const QmRows<NXP, true> &s, uint32_t N, uint32_t (&m)[32]) {
+    if (N == (uint32_t)NXP) {  // no padding slots (e.g. the 16-qubit flagship): columns already are slot positions
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            m[i] = i < NXP ? s.r[QmRows<NXP, true>::xs(i)] : (i < 2 * NXP ? s.r[QmRows<NXP, true>::zs(i - NXP)] : 0u);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 32; ++i)  // slot-space row i: X-type rows first, then Z-type rows
         m[i] = i < NXP ? qm_cols_to_slots(s.r[QmRows<NXP, true>::xs(i)], N, NXP)
@@ -224,6 +230,14 @@ __device__ inline void qm_to_slot_space(const QmRows<NXP, true> &s, uint32_t N, 
 }
 template <int NXP>
 __device__ inline void qm_from_slot_space(QmRows<NXP, true> &s, uint32_t N, const uint32_t (&m)[32]) {
+    if (N == (uint32_t)NXP) {
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+            s.r[QmRows<NXP, true>::xs(i)] = m[i];
+            s.r[QmRows<NXP, true>::zs(i)] = m[NXP + i];
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NXP; ++i) {
         s.r[QmRows<NXP, true>::xs(i)] = qm_cols_from_slots(m[i], N, NXP);
