@@ -6,9 +6,13 @@
 //   LinearFunction::step rust/src/envs/linear_function.rs:302-328, cx/swap :62-83.
 //
 // Why a second layout: the ROWS layout spends ~19 wave-instructions per env-step (8 lanes per env)
-// and is instruction-issue-bound on MI355X.  Here one lane owns one whole env (its <= 32 row words
-// live in VGPRs), so every wave instruction advances 64 envs (~4 per env-step), and nothing crosses
-// lanes: no shuffles, no ballots, no LDS traffic besides the staged gate table.
+// and is instruction-issue-bound on MI355X.  Here one lane owns one whole env, so every wave
+// instruction advances 64 envs and nothing crosses lanes: no shuffles, no ballots.  Three kernels:
+//   qm_step1_kernel   one env.step() per launch without add_inverts (the hot path): holds nothing, gathers and
+//                     scatters the gate's <= 2 row groups, `solved` from an incremental mask (~1.5 wave
+//                     instructions per env-step);
+//   qm_step_kernel    fused rollouts and add_inverts: the env's <= 32 row words live in VGPRs (~4.5);
+//   qm_init_kernel    set_state / reset / reset_done (scramble on LDS-resident rows).
 //
 // Memory (TILE layout): envs are grouped in tiles of 64 (one wavefront).  A tile stores its rows as
 // R/4 "row groups" of 1 KiB: group g holds, for lane l, the uint4 {slot 4g .. 4g+3} of env
