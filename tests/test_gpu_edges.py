@@ -135,3 +135,93 @@ def test_pauli_weight_zero_rotation_is_reported():
 
     with pytest.raises(OracleError):
         o.step(cx)
+
+
+def test_four_million_envs_index_arithmetic():
+    """B = 2^22 CliffordGym 16q envs (512 MiB of state, a 4 GiB dense observation: element counts beyond
+    2^32) -- every kernel's index arithmetic at a size no other test reaches; a strided sample of envs is
+    checked against the oracle."""
+    from oracle import OracleVec
+    from qiskit_gym_amd.vec import VecEnv
+    from util import rng_actions
+
+    n, B, T, diff = 16, 1 << 22, 6, 24
+    gs = line_gateset("clifford", n)
+    A = len(gs)
+    cfg = dict(add_inverts=False, add_perms=False, track_solution=False, difficulty=diff)
+    gv = VecEnv("clifford", n, gs, B, **cfg)
+    gv.reset(77)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    acts = torch.randint(0, A, (T, B), dtype=torch.int32, device="cuda", generator=gen)
+    for t in range(T):
+        gv.step(acts[t])
+    gv.sync()
+    ids = np.concatenate([np.arange(0, 64), np.arange(B - 64, B), np.arange(12345, B, 65537)])
+    proto = OracleEnv("clifford", n, gs, **{k: int(v) for k, v in cfg.items()})
+    ov = OracleVec(proto, len(ids))
+    ov.reset_with(rng_actions(77, ids, diff, A))
+    acts_h = acts[:, torch.as_tensor(ids, device="cuda")].cpu().numpy()
+    for t in range(T):
+        r, s, f, d = ov.step(acts_h[t])
+    idx = torch.as_tensor(ids, device="cuda")
+    np.testing.assert_array_equal(f32_bits(gv.reward[idx].cpu().numpy()), f32_bits(r))
+    np.testing.assert_array_equal(gv.depth[idx].cpu().numpy(), d)
+    obs = gv.observe()  # [B, 32, 32] int8 = 4 GiB
+    np.testing.assert_array_equal(obs[idx].cpu().numpy().reshape(len(ids), -1), ov.observe_dense())
+    del obs
+    x = gv.observe_as(torch.bfloat16)  # 8 GiB
+    assert torch.equal(x[idx].float(), torch.as_tensor(ov.observe_dense(), device="cuda").float())
+    del x
+    packed = gv.observe_packed()
+    want = (ov.observe_dense().reshape(len(ids), 32, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(axis=2).astype(np.uint32)
+    np.testing.assert_array_equal(packed[idx].cpu().numpy().view(np.uint32), want)
+    # reset_done over the whole batch (list compaction with 2^22 entries)
+    gv.done.fill_(1)
+    gv.reset_done(9)
+    gv.sync()
+    ov.reset_with(rng_actions(9, ids, diff, A))
+    np.testing.assert_array_equal(gv.observe_packed()[idx].cpu().numpy().view(np.uint32),
+                                  (ov.observe_dense().reshape(len(ids), 32, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(axis=2).astype(np.uint32))
+    gv.close()
+
+
+def test_four_million_pauli_envs_index_arithmetic():
+    """B = 2^22 PauliGym 16q envs: the ragged observation expansion beyond 2^32 elements, the device-side target
+    generator and the compacted reset at that size; a strided sample is checked against the oracle."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    n, B, T = 16, 1 << 22, 5
+    gs = line_gateset("pauli", n)
+    A = len(gs)
+    cfg = dict(add_perms=False, track_solution=False, max_rotations=5, difficulty=24, pauli_diff_scale=4)
+    gv = VecEnv("pauli", n, gs, B, **cfg)
+    rows, cols = gv.obs_shape_
+    assert B * rows * cols > 2**32
+    gv.reset(31)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(6)
+    acts = torch.randint(0, A, (T, B), dtype=torch.int32, device="cuda", generator=gen)
+    for t in range(T):
+        gv.step(acts[t])
+    gv.sync()
+    ids = np.concatenate([np.arange(0, 40), np.arange(B - 40, B), np.arange(999, B, 262147)])
+    envs = [OracleEnv("pauli", n, gs, **{k: int(v) for k, v in cfg.items()}) for _ in ids]
+    acts_h = acts[:, torch.as_tensor(ids, device="cuda")].cpu().numpy()
+    for o, e, col in zip(envs, ids, acts_h.T):
+        o.pauli_reset_seeded(31, int(e))
+        for a in col:
+            o.step(int(a))
+    idx = torch.as_tensor(ids, device="cuda")
+    np.testing.assert_array_equal(f32_bits(gv.reward[idx].cpu().numpy()), np.array([o.reward_bits() for o in envs], dtype=np.uint32))
+    obs = gv.observe()
+    np.testing.assert_array_equal(obs[idx].cpu().numpy(), np.stack([o.dense_obs() for o in envs]))
+    del obs
+    gv.done.fill_(1)
+    gv.reset_done(8)
+    gv.sync()
+    for o, e in zip(envs, ids):
+        o.pauli_reset_seeded(8, int(e))
+    np.testing.assert_array_equal(gv.observe_as(torch.float16)[idx].float().cpu().numpy().reshape(len(ids), rows, cols),
+                                  np.stack([o.dense_obs() for o in envs]).astype(np.float32))
+    gv.close()
