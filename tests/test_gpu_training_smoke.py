@@ -1,0 +1,22 @@
+"""The GPU-resident collector feeds a learner: a plain torch PPO update on its rollouts (examples/
+ppo_linear_function.py) raises the solve rate of LinearFunctionGym 4q from a few percent to a majority
+within ~30 iterations.  Checks the whole loop's semantics at once: auto-reset, observation, sampling
+log-probs, rewards, episode ends, GAE."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+
+
+def test_ppo_on_collector_rollouts_learns_to_synthesise():
+    from ppo_linear_function import train
+
+    history = train(qubits=4, difficulty=5, envs=4096, horizon=12, iters=30, log=lambda *_: None)
+    start, end = sum(history[:3]) / 3, sum(history[-3:]) / 3
+    assert start < 0.15, history[:3]          # an untrained policy rarely solves a 5-gate scramble in 10 steps
+    assert end > 0.4 and end > 4 * start, (start, end)
