@@ -29,8 +29,13 @@
 //           the rows of <= 2 qubits, so `solved` never needs the whole tableau);
 //   compact (N <= 24 and <= 8 rotations, the common case): rows are <= 48 bits, so a qubit's two
 //           rows are 12 bytes {X[0:32), X[32:48) | Z[0:16) << 16, Z[16:48)} (768 B per group,
-//           dwordx3 accesses) and a rotation is 8 bytes {x | pred << 24, z | phase << 24}; N = 20:
-//           320 B per env instead of 464.
+//           dwordx3 accesses).  The rotations are stored TRANSPOSED in the 8 x 8-byte rotation groups
+//           (64 bytes per env): bytes [0, 48) = {xs[q], zs[q]} for q < 24, where bit k of xs[q] is bit q
+//           of rotation k's x mask -- a gate only reads and writes the bytes of its two qubits, which are
+//           exactly the bit-slices its micro-ops work on; bytes [48, 56) = pred[k]; byte 56 / 57 = the two
+//           phase bit-planes; bytes 58..62 = the rotations' weights popc(x | z) as five bit-planes (bit k
+//           of plane j = bit j of rotation k's weight), so `clean` never needs the masks.  N = 20: 320 B
+//           per env instead of 464.
 //
 // Two step kernels: ptile_step1_kernel (one step per launch, the env.step() path) keeps only the
 // rotations in registers and gathers / scatters the rows of the gate's <= 2 qubits at per-lane
@@ -152,21 +157,54 @@ struct PTLayout {
         else *reinterpret_cast<uint4 *>(t + NQ * QB + k * RB + lane * 16u) = make_uint4(x, z, ph, pred);
     }
     static __device__ inline uint4 *meta(char *t, uint32_t lane) { return reinterpret_cast<uint4 *>(t + NQ * QB + RM * RB + lane * 16u); }
+    // compact layout: the transposed rotation region (see the file header)
+    static __device__ inline uint16_t *xz(char *t, uint32_t lane, uint32_t q) {
+        return reinterpret_cast<uint16_t *>(t + NQ * QB + (q >> 2) * RB + lane * 8u + (q & 3u) * 2u);
+    }
+    static __device__ inline uint2 *rotgroup(char *t, uint32_t lane, uint32_t g) { return reinterpret_cast<uint2 *>(t + NQ * QB + g * RB + lane * 8u); }
 };
 
-// rotations and bookkeeping only (the one-step kernel gathers the two qubits it needs itself)
+// rotations and bookkeeping (dense kernels; the compact layout's transposed rotation bytes are turned back
+// into one (x, z) mask pair per rotation here)
 template <int NQ, int RM>
 __device__ inline void pt_load_rotations(const char *tile, uint32_t lane, PTState<NQ, RM> &s) {
     using L = PTLayout<NQ, RM>;
+    char *t = const_cast<char *>(tile);
     s.plo = s.phi = 0;
+    if constexpr (L::COMPACT) {
+        uint32_t w[12];
 #pragma unroll
-    for (int k = 0; k < RM; ++k) {
-        uint32_t ph;
-        L::load_rot(tile, lane, k, s.rx[k], s.rz[k], ph, s.rpred[k]);
-        s.plo |= (ph & 1u) << k;
-        s.phi |= ((ph >> 1) & 1u) << k;
+        for (int g = 0; g < 6; ++g) {
+            const uint2 v = (2 * g < (NQ + 1) / 2) ? *L::rotgroup(t, lane, g) : make_uint2(0u, 0u);
+            w[2 * g] = v.x;
+            w[2 * g + 1] = v.y;
+        }
+#pragma unroll
+        for (int k = 0; k < RM; ++k) s.rx[k] = s.rz[k] = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const uint32_t v = w[q >> 1] >> (16 * (q & 1));
+#pragma unroll
+            for (int k = 0; k < RM; ++k) {
+                s.rx[k] |= ((v >> k) & 1u) << q;
+                s.rz[k] |= ((v >> (8 + k)) & 1u) << q;
+            }
+        }
+        const uint2 pv = *L::rotgroup(t, lane, 6), pw = *L::rotgroup(t, lane, 7);
+#pragma unroll
+        for (int k = 0; k < RM; ++k) s.rpred[k] = ((k < 4 ? pv.x : pv.y) >> (8 * (k & 3))) & 0xFFu;
+        s.plo = pw.x & 0xFFu;
+        s.phi = (pw.x >> 8) & 0xFFu;
+    } else {
+#pragma unroll
+        for (int k = 0; k < RM; ++k) {
+            uint32_t ph;
+            L::load_rot(tile, lane, k, s.rx[k], s.rz[k], ph, s.rpred[k]);
+            s.plo |= (ph & 1u) << k;
+            s.phi |= ((ph >> 1) & 1u) << k;
+        }
     }
-    const uint4 m = *L::meta(const_cast<char *>(tile), lane);
+    const uint4 m = *L::meta(t, lane);
     s.alive = m.x & 0xFFFFu;
     s.count = m.x >> 16;
     s.bad = m.y;
@@ -178,9 +216,47 @@ __device__ inline void pt_load(const char *tile, uint32_t lane, PTState<NQ, RM> 
     for (int q = 0; q < NQ; ++q) PTLayout<NQ, RM>::load_qubit(tile, lane, (uint32_t)q, s.X[q], s.Z[q]);
     pt_load_rotations<NQ, RM>(tile, lane, s);
 }
+// compact layout: the {xs, zs} bytes of qubit q from the per-rotation masks
 template <int NQ, int RM>
-__device__ inline void pt_store_rot(char *tile, uint32_t lane, const PTState<NQ, RM> &s, int k) {
-    PTLayout<NQ, RM>::store_rot(tile, lane, k, s.rx[k], s.rz[k], ((s.plo >> k) & 1u) | (((s.phi >> k) & 1u) << 1), s.rpred[k]);
+__device__ inline void pt_store_xz(char *tile, uint32_t lane, const PTState<NQ, RM> &s, uint32_t q) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < RM; ++k) v |= (((s.rx[k] >> q) & 1u) << k) | (((s.rz[k] >> q) & 1u) << (8 + k));
+    *PTLayout<NQ, RM>::xz(tile, lane, q) = (uint16_t)v;
+}
+// compact layout: pred bytes, phase planes and weight planes
+template <int NQ, int RM>
+__device__ inline void pt_store_rotmeta(char *tile, uint32_t lane, const PTState<NQ, RM> &s, bool with_pred) {
+    using L = PTLayout<NQ, RM>;
+    uint32_t wp[5] = {0, 0, 0, 0, 0}, p0 = 0, p1 = 0;
+#pragma unroll
+    for (int k = 0; k < RM; ++k) {
+        const uint32_t wk = (uint32_t)__popc(s.rx[k] | s.rz[k]);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) wp[j] |= ((wk >> j) & 1u) << k;
+        if (k < 4) p0 |= (s.rpred[k] & 0xFFu) << (8 * k);
+        else p1 |= (s.rpred[k] & 0xFFu) << (8 * (k - 4));
+    }
+    if (with_pred) *L::rotgroup(tile, lane, 6) = make_uint2(p0, p1);
+    *L::rotgroup(tile, lane, 7) = make_uint2((s.plo & 0xFFu) | ((s.phi & 0xFFu) << 8) | (wp[0] << 16) | (wp[1] << 24), wp[2] | (wp[3] << 8) | (wp[4] << 16));
+}
+// write back the rotations a dense kernel changed: `touched` = rotations whose record changed, `qubits` = the
+// qubits gates were applied to (the only bit positions a micro-op can change)
+template <int NQ, int RM>
+__device__ inline void pt_store_rotations(char *tile, uint32_t lane, const PTState<NQ, RM> &s, uint32_t touched, uint32_t qubits, bool everything) {
+    using L = PTLayout<NQ, RM>;
+    if constexpr (L::COMPACT) {
+        if (!touched && !everything) return;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (everything || ((qubits >> q) & 1u)) pt_store_xz<NQ, RM>(tile, lane, s, (uint32_t)q);
+        pt_store_rotmeta<NQ, RM>(tile, lane, s, everything);
+    } else {
+#pragma unroll
+        for (int k = 0; k < RM; ++k)
+            if (everything || ((touched >> k) & 1u))
+                L::store_rot(tile, lane, k, s.rx[k], s.rz[k], ((s.plo >> k) & 1u) | (((s.phi >> k) & 1u) << 1), s.rpred[k]);
+    }
 }
 template <int NQ, int RM>
 __device__ inline void pt_store_meta(char *tile, uint32_t lane, const PTState<NQ, RM> &s) {
@@ -428,9 +504,7 @@ __global__ __launch_bounds__(256) void ptile_step_kernel(PTArgs pa) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
         if ((dirty_q >> q) & 1u) PTLayout<NQ, RM>::store_qubit(tile, lane, q, s.X[q], s.Z[q]);
-#pragma unroll
-    for (int k = 0; k < RM; ++k)
-        if ((touched_rot >> k) & 1u) pt_store_rot<NQ, RM>(tile, lane, s, k);
+    pt_store_rotations<NQ, RM>(tile, lane, s, touched_rot, dirty_q, false);
     if (s.alive != alive0 || s.count != count0 || s.order != order0 || s.bad != bad0) pt_store_meta<NQ, RM>(tile, lane, s);
     a.depth[env] = depth;
     a.reward[env] = reward;
@@ -503,9 +577,10 @@ __device__ inline void pt_slices_evolve(PTState<NQ, RM> &s, PTSlices<RM> &v, uin
     s.phi ^= carry ^ inc2;
 }
 // clean_and_return_with_phases (pauli_network.rs:139-165) on the slices; see pt_clean for the bookkeeping
-template <int NQ, int RM>
+// `outside(k, rx, rz)`: rotation k's masks with bits qa / qb cleared (only the solution log asks)
+template <int NQ, int RM, typename Outside>
 __device__ inline void pt_slices_clean(PTState<NQ, RM> &s, const PTSlices<RM> &v, uint32_t qa, uint32_t qb, uint32_t &n_removed, uint32_t &fault,
-                                       uint32_t *log, uint64_t (&rem_pos)[(RM + 7) / 8]) {
+                                       uint32_t *log, uint64_t (&rem_pos)[(RM + 7) / 8], Outside outside) {
     const uint32_t sa = v.xa | v.za, sb = v.xb | v.zb;  // weights do not change while cleaning (:79-93)
     const uint32_t trivial = (v.b0 & ~(sa & sb)) | (v.b1 & ~(sa | sb)), zero_w = v.b0 & ~(sa | sb);
     for (;;) {
@@ -532,10 +607,11 @@ __device__ inline void pt_slices_clean(PTState<NQ, RM> &s, const PTSlices<RM> &v
                     // which_qubit / which_axis (:95-137): the single support qubit is outside {qa, qb} (b1), qa or qb
                     uint32_t q, bx, bz;
                     if ((v.b1 >> k) & 1u) {
-                        const uint32_t sup = (s.rx[k] | s.rz[k]) & ~((1u << qa) | (1u << qb));
-                        q = (uint32_t)__ffs((int)sup) - 1u;
-                        bx = (s.rx[k] >> q) & 1u;
-                        bz = (s.rz[k] >> q) & 1u;
+                        uint32_t ox, oz;
+                        outside((uint32_t)k, ox, oz);
+                        q = (uint32_t)__ffs((int)(ox | oz)) - 1u;
+                        bx = (ox >> q) & 1u;
+                        bz = (oz >> q) & 1u;
                     } else if ((sa >> k) & 1u) {
                         q = qa; bx = (v.xa >> k) & 1u; bz = (v.za >> k) & 1u;
                     } else {
@@ -620,7 +696,16 @@ __global__ __launch_bounds__(256) void ptile_step1_kernel(PTArgs pa) {
             const uint32_t kind = mo & 7u;
             if (kind == M_NOP) continue;
             pt_slices_evolve<NQ, RM>(s, v, kind, (mo & 8u) != 0);
-            if (kind == M_CNOT) pt_slices_clean<NQ, RM>(s, v, qa, qb, n_removed, fault, log, rem_pos);
+            if (kind == M_CNOT)
+                pt_slices_clean<NQ, RM>(s, v, qa, qb, n_removed, fault, log, rem_pos, [&](uint32_t k, uint32_t &ox, uint32_t &oz) {
+                    const uint32_t keep = ~((1u << qa) | (1u << qb));
+                    ox = oz = 0;
+#pragma unroll
+                    for (int i = 0; i < RM; ++i) {  // k is a per-lane value
+                        ox = (uint32_t)i == k ? s.rx[i] & keep : ox;
+                        oz = (uint32_t)i == k ? s.rz[i] & keep : oz;
+                    }
+                });
         }
         pt_slices_scatter<NQ, RM>(s, qa, qb, v);
         // records to write back: rotations alive at the gate whose bits or phase changed (dead ones are never read again)
@@ -653,10 +738,167 @@ __global__ __launch_bounds__(256) void ptile_step1_kernel(PTArgs pa) {
     const float reward = tmp + bonus;  // pauli.rs:634
     if (a.rewards_seq) a.rewards_seq[env] = reward;
     if (a.dones_seq) a.dones_seq[env] = (uint8_t)(depth == 0 || solved);
-#pragma unroll
-    for (int k = 0; k < RM; ++k)
-        if ((touched_rot >> k) & 1u) pt_store_rot<NQ, RM>(tile, lane, s, k);
+    pt_store_rotations<NQ, RM>(tile, lane, s, touched_rot, in_range ? (1u << qa) | (1u << qb) : 0u, false);
     if (s.alive != alive0 || s.count != count0 || s.order != order0 || s.bad != bad0) pt_store_meta<NQ, RM>(tile, lane, s);
+    a.depth[env] = depth;
+    a.reward[env] = reward;
+    a.done[env] = (uint8_t)(depth == 0 || solved);
+    a.success[env] = (uint8_t)solved;
+    if (FEAT && (a.flags & F_TRACK)) a.sol_len[env * 2] = sol_n;
+    if (fault) atomicOr(&a.error[env], fault);
+}
+
+// bit-sliced counters: plane j holds bit j of eight small integers (one per rotation); +/- a 0/1 per rotation
+__device__ inline void planes_sub(uint32_t (&w)[5], uint32_t bits) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const uint32_t t = w[j];
+        w[j] = t ^ bits;
+        bits &= ~t;
+    }
+}
+__device__ inline void planes_add(uint32_t (&w)[5], uint32_t bits) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const uint32_t t = w[j];
+        w[j] = t ^ bits;
+        bits &= t;
+    }
+}
+
+// One step per launch on the compact layout: the transposed rotation region hands the kernel the gate's
+// bit-slices directly (two 16-bit gathers), the weights live as bit-planes, so no per-rotation mask is ever
+// loaded: per env the step reads two qubit records, two slice pairs and 32 bytes of bookkeeping.
+template <int NQ, int RM, bool FEAT>
+__global__ __launch_bounds__(256) void ptile_step1c_kernel(PTArgs pa) {
+    using L = PTLayout<NQ, RM>;
+    static_assert(L::COMPACT && RM == 8, "compact layout only");
+    const StepArgs &a = pa.s;
+    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    if (env >= a.B) return;
+    const uint32_t N = a.N;
+    char *tile = L::tile(a.state, env);
+
+    int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
+    PTState<NQ, RM> s;  // rpred / phases / bookkeeping only; the masks stay in memory
+    const uint4 m0 = *L::meta(tile, lane);
+    const uint2 pv = *L::rotgroup(tile, lane, 6), pw0 = *L::rotgroup(tile, lane, 7);
+    s.alive = m0.x & 0xFFFFu;
+    s.count = m0.x >> 16;
+    s.bad = m0.y;
+    s.order = (uint64_t)m0.z | ((uint64_t)m0.w << 32);
+#pragma unroll
+    for (int k = 0; k < RM; ++k) s.rpred[k] = ((k < 4 ? pv.x : pv.y) >> (8 * (k & 3))) & 0xFFu;
+    s.plo = pw0.x & 0xFFu;
+    s.phi = (pw0.x >> 8) & 0xFFu;
+    uint32_t w[5] = {(pw0.x >> 16) & 0xFFu, pw0.x >> 24, pw0.y & 0xFFu, (pw0.y >> 8) & 0xFFu, (pw0.y >> 16) & 0xFFu};
+    int32_t depth = a.depth[env];
+    int32_t sol_n = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2] : 0;
+    uint32_t fault = 0;
+
+    if (pa.n_perms) {  // actual_action = act_perms[current_perm_idx][action] (pauli.rs:594-599)
+        if (act >= 0 && act < (int64_t)a.num_actions) act = pa.act_perms[(uint64_t)pa.perm_idx[env] * a.num_actions + act];
+        else fault |= 16u;  // the reference indexes act_perms out of bounds here and panics
+    }
+    const bool in_range = act >= 0 && act < (int64_t)a.num_actions;  // pauli.rs:601
+    uint64_t prog = 0;
+    float penalty = 0.0f;
+    if (in_range) {
+        prog = pa.prog[act];
+        penalty = a.gates[act].penalty;
+        if (FEAT && (a.flags & F_LAYERS)) penalty = layers_penalty(a.layers + env * (2 * N + 2), N, a.descs[act], a.w);
+    }
+    const uint32_t qa = (uint32_t)prog & 31u, qb = (uint32_t)(prog >> 5) & 31u, m = (uint32_t)(prog >> 10) & 0xFFFFu;
+    uint32_t n_removed = 0;
+    uint64_t rem_pos[(RM + 7) / 8];
+#pragma unroll
+    for (int i = 0; i < (RM + 7) / 8; ++i) rem_pos[i] = 0;
+    uint32_t *log = nullptr;
+    if (FEAT && (a.flags & F_TRACK) && in_range && (uint32_t)sol_n + 1u + (uint32_t)s.count <= a.sol_cap)
+        log = a.sol + env * a.sol_cap + (uint32_t)sol_n + 1u;  // slot sol_n is the gate itself
+
+    // rotation k's masks outside {qa, qb}, from the transposed bytes (solution log only: a removal is rare)
+    auto outside = [&](uint32_t k, uint32_t &ox, uint32_t &oz) {
+        ox = oz = 0;
+        for (uint32_t q = 0; q < (uint32_t)NQ; ++q) {
+            const uint32_t v = *L::xz(tile, lane, q);
+            ox |= ((v >> k) & 1u) << q;
+            oz |= ((v >> (8u + k)) & 1u) << q;
+        }
+        ox &= ~((1u << qa) | (1u << qb));
+        oz &= ~((1u << qa) | (1u << qb));
+    };
+
+    PTSlices<RM> v;
+    v.xa = v.za = v.xb = v.zb = v.b0 = v.b1 = 0;
+    if (in_range) {
+        uint64_t xa, za, xb, zb, n[4];
+        L::load_qubit(tile, lane, qa, xa, za);
+        L::load_qubit(tile, lane, qb, xb, zb);  // one-qubit gates: qb == qa, the same (cached) record
+        const uint32_t two = qa != qb;
+        const uint32_t sva = *L::xz(tile, lane, qa), svb = *L::xz(tile, lane, qb);
+        pt_mix(m, xa, za, xb, zb, n);
+        if (two) L::store_qubit(tile, lane, qb, n[2], n[3]);
+        L::store_qubit(tile, lane, qa, n[0], n[1]);
+        s.bad = pt_bad_update(s.bad, N, qa, qb, n);
+        v.xa = sva & 0xFFu;
+        v.za = sva >> 8;
+        v.xb = two ? svb & 0xFFu : 0u;
+        v.zb = two ? svb >> 8 : 0u;
+        planes_sub(w, v.xa | v.za);  // weights outside {qa, qb}
+        planes_sub(w, v.xb | v.zb);
+        const uint32_t hi = w[1] | w[2] | w[3] | w[4];
+        v.b0 = ~(w[0] | hi) & 0xFFu;
+        v.b1 = w[0] & ~hi & 0xFFu;
+        const PTSlices<RM> v0 = v;
+#pragma unroll 1
+        for (uint32_t k = 0; k < 3; ++k) {  // PauliNetwork::act (pauli_network.rs:225-260)
+            const uint32_t mo = (uint32_t)(prog >> (26 + 4 * k)) & 15u;
+            const uint32_t kind = mo & 7u;
+            if (kind == M_NOP) continue;
+            pt_slices_evolve<NQ, RM>(s, v, kind, (mo & 8u) != 0);
+            if (kind == M_CNOT) pt_slices_clean<NQ, RM>(s, v, qa, qb, n_removed, fault, log, rem_pos, outside);
+        }
+        planes_add(w, v.xa | v.za);
+        planes_add(w, v.xb | v.zb);
+        if ((v.xa ^ v0.xa) | (v.za ^ v0.za)) *L::xz(tile, lane, qa) = (uint16_t)(v.xa | (v.za << 8));
+        if ((v.xb ^ v0.xb) | (v.zb ^ v0.zb)) *L::xz(tile, lane, qb) = (uint16_t)(v.xb | (v.zb << 8));
+    }
+
+    if (FEAT && (a.flags & F_TRACK) && in_range) {  // pauli.rs:612-626
+        if (log) {
+            a.sol[env * a.sol_cap + (uint32_t)sol_n] = sol_word(act);
+#pragma unroll
+            for (int k = 0; k < RM; ++k) {  // phase_mult is read after the whole gate has been applied (pauli.rs:618)
+                const uint32_t pos = (uint32_t)(rem_pos[k / 8] >> (8 * (k % 8))) & 0xFFu;
+                if (pos) {
+                    uint32_t ox, oz;
+                    outside((uint32_t)k, ox, oz);
+                    const uint32_t ys = (uint32_t)__popc(ox & oz) + (((v.xa & v.za) >> k) & 1u) + (((v.xb & v.zb) >> k) & 1u);
+                    const uint32_t base = ((s.plo >> k) & 1u) | (((s.phi >> k) & 1u) << 1);
+                    const uint32_t ph = (base + 4u * N - ys) & 3u;  // Pauli::phase (pauli.rs:125-133)
+                    log[pos - 1u] |= (ph == 2u ? 0u : 1u);
+                }
+            }
+            sol_n += 1 + (int32_t)n_removed;
+        } else {
+            fault |= 8u;
+        }
+    }
+
+    depth = depth > 0 ? depth - 1 : 0;  // pauli.rs:630
+    const bool solved = pt_solved<NQ, RM>(s);
+    const float achieved = solved ? 1.0f : 0.0f;
+    const float tmp = achieved - penalty;
+    const float bonus = a.pauli_layer_reward * (float)n_removed;
+    const float reward = tmp + bonus;  // pauli.rs:634
+    if (a.rewards_seq) a.rewards_seq[env] = reward;
+    if (a.dones_seq) a.dones_seq[env] = (uint8_t)(depth == 0 || solved);
+    const uint2 pw = make_uint2((s.plo & 0xFFu) | ((s.phi & 0xFFu) << 8) | (w[0] << 16) | (w[1] << 24), w[2] | (w[3] << 8) | (w[4] << 16));
+    if (pw.x != pw0.x || pw.y != pw0.y) *L::rotgroup(tile, lane, 7) = pw;
+    const uint4 m1 = make_uint4(s.alive | (s.count << 16), s.bad, (uint32_t)s.order, (uint32_t)(s.order >> 32));
+    if (m1.x != m0.x || m1.y != m0.y || m1.z != m0.z || m1.w != m0.w) *L::meta(tile, lane) = m1;
     a.depth[env] = depth;
     a.reward[env] = reward;
     a.done[env] = (uint8_t)(depth == 0 || solved);
@@ -759,18 +1001,19 @@ __device__ inline void ptile_obs_qubit(const PTObsArgs &pa, uint64_t env, uint32
         const uint4 m = *reinterpret_cast<const uint4 *>(tile + pa.nq * QB + pa.rm * RB + lane * 16u);
         const uint64_t order = (uint64_t)m.z | ((uint64_t)m.w << 32);
         const uint32_t count = m.x >> 16, shown = count < pa.max_rot ? count : pa.max_rot;
-        for (uint32_t i = 0; i < shown; ++i) {
-            const char *rp = tile + pa.nq * QB + pnib(order, i) * RB;
-            uint32_t rx, rz;
-            if (compact) {
-                const uint2 r = *reinterpret_cast<const uint2 *>(rp + lane * 8u);
-                rx = r.x & 0xFFFFFFu; rz = r.y & 0xFFFFFFu;
-            } else {
-                const uint4 r = *reinterpret_cast<const uint4 *>(rp + lane * 16u);
-                rx = r.x; rz = r.y;
+        if (compact) {  // transposed rotation bytes: bit k of xs / zs = rotation k at this qubit
+            const uint32_t v = *reinterpret_cast<const uint16_t *>(tile + pa.nq * QB + (sq >> 2) * RB + lane * 8u + (sq & 3u) * 2u);
+            for (uint32_t i = 0; i < shown; ++i) {
+                const uint32_t k = pnib(order, i);
+                ex |= ((v >> k) & 1u) << i;
+                ez |= ((v >> (8 + k)) & 1u) << i;
             }
-            ex |= ((rx >> sq) & 1u) << i;
-            ez |= ((rz >> sq) & 1u) << i;
+        } else {
+            for (uint32_t i = 0; i < shown; ++i) {
+                const uint4 r = *reinterpret_cast<const uint4 *>(tile + pa.nq * QB + pnib(order, i) * RB + lane * 16u);
+                ex |= ((r.x >> sq) & 1u) << i;
+                ez |= ((r.y >> sq) & 1u) << i;
+            }
         }
     }
 }
@@ -987,8 +1230,7 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
     const bool solved = pt_solved<NQ, RM>(s);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) PTLayout<NQ, RM>::store_qubit(tile, lane, q, s.X[q], s.Z[q]);
-#pragma unroll
-    for (int k = 0; k < RM; ++k) pt_store_rot<NQ, RM>(tile, lane, s, k);
+    pt_store_rotations<NQ, RM>(tile, lane, s, ~0u, ~0u, true);
     pt_store_meta<NQ, RM>(tile, lane, s);
     a.depth[env] = ga.depth_value;  // pauli.rs:578-585
     a.success[env] = (uint8_t)solved;
@@ -1043,8 +1285,13 @@ static hipError_t pt_launch_step(const PTArgs &pa, hipStream_t s) {
     static const bool dense_only = getenv("QGYM_PTILE_DENSE") != nullptr;  // development switch: always hold the tableau in registers
     const bool feat = pa.s.flags & (F_TRACK | F_LAYERS);
     if (pa.s.T == 1 && !dense_only) {
-        if (feat) hipLaunchKernelGGL((ptile_step1_kernel<NQ, RM, true>), grid, block, 0, s, pa);
-        else hipLaunchKernelGGL((ptile_step1_kernel<NQ, RM, false>), grid, block, 0, s, pa);
+        if constexpr (PTLayout<NQ, RM>::COMPACT) {
+            if (feat) hipLaunchKernelGGL((ptile_step1c_kernel<NQ, RM, true>), grid, block, 0, s, pa);
+            else hipLaunchKernelGGL((ptile_step1c_kernel<NQ, RM, false>), grid, block, 0, s, pa);
+        } else {
+            if (feat) hipLaunchKernelGGL((ptile_step1_kernel<NQ, RM, true>), grid, block, 0, s, pa);
+            else hipLaunchKernelGGL((ptile_step1_kernel<NQ, RM, false>), grid, block, 0, s, pa);
+        }
     } else if (feat) {
         hipLaunchKernelGGL((ptile_step_kernel<NQ, RM, true>), grid, block, 0, s, pa);
     } else {
@@ -1252,12 +1499,28 @@ int ptile_upload(qg_vec *v, const HostNet &h, bool do_clean, int32_t depth_value
                 memcpy(tile + q * QB + lane * 16, g, 16);
             }
         }
-        for (uint32_t k = 0; k < v->rmax; ++k) {
-            const PauliRot &r = h.rot[e * v->rmax + k];
-            if (compact) {
-                uint32_t g[2] = {r.x | (r.pred << 24), r.z | (r.phase << 24)};
-                memcpy(tile + NQ * QB + k * RB + lane * 8, g, 8);
-            } else {
+        if (compact) {  // transposed rotation region (see the file header)
+            uint8_t *rb = tile + NQ * QB;
+            auto byte_at = [&](uint32_t b) -> uint8_t & { return rb[(b >> 3) * RB + lane * 8 + (b & 7u)]; };
+            uint32_t wp[5] = {0, 0, 0, 0, 0}, plo = 0, phi = 0;
+            for (uint32_t k = 0; k < v->rmax; ++k) {
+                const PauliRot &r = h.rot[e * v->rmax + k];
+                for (uint32_t q = 0; q < N; ++q) {
+                    byte_at(2 * q) |= (uint8_t)(((r.x >> q) & 1u) << k);
+                    byte_at(2 * q + 1) |= (uint8_t)(((r.z >> q) & 1u) << k);
+                }
+                byte_at(48 + k) = (uint8_t)r.pred;
+                plo |= (r.phase & 1u) << k;
+                phi |= ((r.phase >> 1) & 1u) << k;
+                const uint32_t wk = (uint32_t)__builtin_popcount(r.x | r.z);
+                for (int j = 0; j < 5; ++j) wp[j] |= ((wk >> j) & 1u) << k;
+            }
+            byte_at(56) = (uint8_t)plo;
+            byte_at(57) = (uint8_t)phi;
+            for (int j = 0; j < 5; ++j) byte_at(58 + j) = (uint8_t)wp[j];
+        } else {
+            for (uint32_t k = 0; k < v->rmax; ++k) {
+                const PauliRot &r = h.rot[e * v->rmax + k];
                 uint32_t g[4] = {r.x, r.z, r.phase, r.pred};
                 memcpy(tile + NQ * QB + k * RB + lane * 16, g, 16);
             }
