@@ -551,27 +551,25 @@ __device__ inline void pt_slices_scatter(PTState<NQ, RM> &s, uint32_t qa, uint32
         s.rz[k] = (s.rz[k] & keep) | (((v.za >> k) & 1u) << qa) | ((((v.zb >> k) & 1u) & two) << qb);
     }
 }
-// one micro-op (Pauli::evolve_*, pauli.rs:83-110); `on_b`: its first operand p is qubit qb
+// one micro-op (Pauli::evolve_*, pauli.rs:83-110), branch-free in the per-lane `kind` (M_NOP changes nothing);
+// `on_b`: its first operand p is qubit qb.
+//   H(p):  x_p <-> z_p, phase += 2 * (x_p & z_p)        S(p):  z_p ^= x_p, phase += x_p
+//   SX(p): x_p ^= z_p, phase += 3 * z_p                  CNOT(i = p, j = q) = evolve_cx(ctrl = q, tgt = p): x_p ^= x_q ; z_q ^= z_p
 template <int NQ, int RM>
 __device__ inline void pt_slices_evolve(PTState<NQ, RM> &s, PTSlices<RM> &v, uint32_t kind, bool on_b) {
-    uint32_t &xp = on_b ? v.xb : v.xa, &zp = on_b ? v.zb : v.za;
-    uint32_t &xq = on_b ? v.xa : v.xb, &zq = on_b ? v.za : v.zb;
-    uint32_t inc1 = 0, inc2 = 0;
-    if (kind == M_H) {          // x_p <-> z_p, phase += 2 * (x_p & z_p)
-        inc2 = xp & zp;
-        const uint32_t t = xp;
-        xp = zp;
-        zp = t;
-    } else if (kind == M_S) {   // z_p ^= x_p, phase += x_p
-        inc1 = xp;
-        zp ^= xp;
-    } else if (kind == M_SX) {  // x_p ^= z_p, phase += 3 * z_p
-        inc1 = inc2 = zp;
-        xp ^= zp;
-    } else if (kind == M_CNOT) {  // cnot(i = p, j = q) = evolve_cx(ctrl = q, tgt = p): x_p ^= x_q ; z_q ^= z_p
-        xp ^= xq;
-        zq ^= zp;
-    }
+    const uint32_t ob = 0u - (uint32_t)on_b;
+    const uint32_t xp = (v.xb & ob) | (v.xa & ~ob), zp = (v.zb & ob) | (v.za & ~ob);
+    const uint32_t xq = (v.xa & ob) | (v.xb & ~ob), zq = (v.za & ob) | (v.zb & ~ob);
+    const uint32_t H = 0u - (uint32_t)(kind == M_H), S = 0u - (uint32_t)(kind == M_S), SX = 0u - (uint32_t)(kind == M_SX),
+                   CN = 0u - (uint32_t)(kind == M_CNOT);
+    const uint32_t inc1 = (S & xp) | (SX & zp), inc2 = ((H & xp) | SX) & zp;
+    const uint32_t nxp = xp ^ (H & (xp ^ zp)) ^ (SX & zp) ^ (CN & xq);
+    const uint32_t nzp = zp ^ (H & (xp ^ zp)) ^ (S & xp);
+    const uint32_t nzq = zq ^ (CN & zp);
+    v.xa = (nxp & ~ob) | (xq & ob);
+    v.za = (nzp & ~ob) | (nzq & ob);
+    v.xb = (xq & ~ob) | (nxp & ob);
+    v.zb = (nzq & ~ob) | (nzp & ob);
     const uint32_t carry = s.plo & inc1;  // phases += inc1 + 2 * inc2 (mod 4)
     s.plo ^= inc1;
     s.phi ^= carry ^ inc2;
@@ -782,8 +780,12 @@ __global__ __launch_bounds__(256) void ptile_step1c_kernel(PTArgs pa) {
 
     int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
     PTState<NQ, RM> s;  // rpred / phases / bookkeeping only; the masks stay in memory
-    const uint4 m0 = *L::meta(tile, lane);
-    const uint2 pv = *L::rotgroup(tile, lane, 6), pw0 = *L::rotgroup(tile, lane, 7);
+    uint4 m0 = *L::meta(tile, lane);
+    uint2 pv = *L::rotgroup(tile, lane, 6), pw0 = *L::rotgroup(tile, lane, 7);
+    int32_t depth = a.depth[env];
+    // keep these loads up here, in flight together with the action load: left alone, the compiler sinks the ones only
+    // `clean` reads into that branch and every cnot pays another memory round trip (measured: 1.3 us per step)
+    asm volatile("" : "+v"(m0.x), "+v"(m0.y), "+v"(m0.z), "+v"(m0.w), "+v"(pv.x), "+v"(pv.y), "+v"(pw0.x), "+v"(pw0.y), "+v"(depth));
     s.alive = m0.x & 0xFFFFu;
     s.count = m0.x >> 16;
     s.bad = m0.y;
@@ -793,7 +795,6 @@ __global__ __launch_bounds__(256) void ptile_step1c_kernel(PTArgs pa) {
     s.plo = pw0.x & 0xFFu;
     s.phi = (pw0.x >> 8) & 0xFFu;
     uint32_t w[5] = {(pw0.x >> 16) & 0xFFu, pw0.x >> 24, pw0.y & 0xFFu, (pw0.y >> 8) & 0xFFu, (pw0.y >> 16) & 0xFFu};
-    int32_t depth = a.depth[env];
     int32_t sol_n = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2] : 0;
     uint32_t fault = 0;
 
@@ -852,11 +853,10 @@ __global__ __launch_bounds__(256) void ptile_step1c_kernel(PTArgs pa) {
         v.b0 = ~(w[0] | hi) & 0xFFu;
         v.b1 = w[0] & ~hi & 0xFFu;
         const PTSlices<RM> v0 = v;
-#pragma unroll 1
+#pragma unroll
         for (uint32_t k = 0; k < 3; ++k) {  // PauliNetwork::act (pauli_network.rs:225-260)
             const uint32_t mo = (uint32_t)(prog >> (26 + 4 * k)) & 15u;
             const uint32_t kind = mo & 7u;
-            if (kind == M_NOP) continue;
             pt_slices_evolve<NQ, RM>(s, v, kind, (mo & 8u) != 0);
             if (kind == M_CNOT) pt_slices_clean<NQ, RM>(s, v, qa, qb, n_removed, fault, log, rem_pos, outside);
         }
