@@ -281,6 +281,19 @@ int qg_sample_actions(const void *logits_dev, int logits_dtype, uint64_t ld, uin
 int qg_gae(const float *rewards_dev, const float *values_dev, const uint8_t *dones_dev, const float *last_values_dev, float gamma,
            float gae_lambda, size_t n_steps, uint64_t batch, float *advantages_dev, float *returns_dev, void *stream);
 
+/* The policy's first layer computed straight from the resident bit-packed state (no dense observation
+ * is written or read): out[e, n] = act(sum_k obs[e, k] * W[n, k] + bias[n]) in bf16, obs = Env::observe
+ * densified and flattened as in qg_vec_observe_dense_as -- the Linear(prod(obs_shape) -> hidden) that opens
+ * the reference's policy network (rl/configs.py:531-607; examples/models/ *.pt).  TILE-layout handles only
+ * (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32; QG_ERR_UNSUPPORTED otherwise); hidden % 64 == 0.
+ * qg_vec_pack_embedding re-orders W ([hidden, ld] of f32 / bf16, ld >= obs_rows*obs_cols) into the k order
+ * the kernel's in-register bit expansion produces (qg_vec_embed_packed_bytes bytes; repeat after every
+ * optimiser step); qg_vec_embed runs the layer: bias_dev f32 [hidden] or NULL, relu != 0 applies max(0, .),
+ * out_dev bf16 [batch, ld_out], 16-byte aligned, ld_out >= hidden and a multiple of 8. */
+size_t qg_vec_embed_packed_bytes(const qg_vec *v, uint32_t hidden);
+int qg_vec_pack_embedding(const qg_vec *v, const void *weight_dev, int weight_dtype, uint64_t ld, uint32_t hidden, void *packed_dev, void *stream);
+int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint32_t hidden, int relu, void *out_dev, uint64_t ld_out, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Scalar environment: the `Env` trait method for method (clifford.rs:285-382).
  * Every call synchronises; this flavour exists for API parity, not for speed.

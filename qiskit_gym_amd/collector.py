@@ -85,6 +85,33 @@ def expand_packed(packed: torch.Tensor, cols: int, dtype: torch.dtype, out: Opti
     return out
 
 
+def pack_embedding(env: VecEnv, weight: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """First-layer weight [hidden, rows*cols] (f32 / bf16) in the k order `embed` consumes (`qg_vec_pack_embedding`);
+    repack after every optimiser step (pass `out` to rewrite the same buffer: graph-safe)."""
+    if weight.dim() != 2 or weight.stride(1) != 1:
+        raise ValueError("weight must be [hidden, obs_size] with unit column stride")
+    L = _lib.load()
+    hidden = weight.shape[0]
+    nbytes = L.qg_vec_embed_packed_bytes(env._h, hidden)
+    if nbytes == 0:
+        raise ValueError("embed needs a TILE-layout env (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32) and hidden % 64 == 0")
+    if out is None:
+        out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=weight.device)
+    _lib.check(L.qg_vec_pack_embedding(env._h, weight.data_ptr(), _DT[weight.dtype], weight.stride(0), hidden, out.data_ptr(), _stream_ptr()))
+    return out
+
+
+def embed(env: VecEnv, packed: torch.Tensor, bias: Optional[torch.Tensor], hidden: int, relu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(obs @ W.T + bias) in bf16 [B, hidden], computed from the env's resident bit-packed state (`qg_vec_embed`)."""
+    if out is None:
+        out = torch.empty((env.batch, hidden), dtype=torch.bfloat16, device=env.device)
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
+        raise ValueError("bias must be a contiguous f32 vector")
+    _lib.check(_lib.load().qg_vec_embed(env._h, packed.data_ptr(), bias.data_ptr() if bias is not None else None, hidden, int(relu), out.data_ptr(),
+                                        out.stride(0), _stream_ptr()))
+    return out
+
+
 class BasicPolicy(nn.Module):
     def __init__(self, obs_size: int, num_actions: int, embedding_size: int = 512, common: int = 256):
         super().__init__()

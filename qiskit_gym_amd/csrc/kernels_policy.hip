@@ -1,0 +1,397 @@
+// kernels_policy.hip -- the policy's first layer computed straight from the resident bit-packed state
+// ("policy forward consuming packed obs directly").
+//
+// The reference's policy (twisterl.nn.BasicPolicy as configured by rl/configs.py:531-607; checkpoint
+// shapes in examples/models/*.pt) starts with Linear(prod(obs_shape) -> 512) on the flattened dense
+// {0,1} observation.  A collector that materialises that observation in bf16 writes and re-reads
+// 2 KiB per env per step for 128 B of information (CliffordEnv 16q), and the GEMM behind it streams
+// both operands through LDS.  Here the A operand never exists in memory:
+//
+//   h[e][n] = act( sum_k obs[e][k] * W[n][k] + b[n] ),   obs[e][row * D + col] = bit `col` of row `row`
+//
+//   * obs bits come from the TILE layout (kernels_qm.hip) 16 bytes per lane at a time and become MFMA A
+//     fragments in registers.  A bf16 with a single exponent bit set is a power of two (bit 14: 2, bit 13:
+//     2^-63, bit 12: 2^-95, bit 11: 2^-111), so the four VGPRs of a fragment are `rotr(word, t) & mask_j`
+//     with mask_j = 0x40004000 >> j: five VALU ops per fragment, no table, no LDS.  The weights are packed
+//     once into the k order those rotations yield, element j pre-multiplied by 2^0 / 2^64 / 2^96 / 2^112
+//     (exact in bf16), so every product is exactly 2 W and the factor 2 leaves in the epilogue.
+//   * a workgroup owns ONE 64-column slab of W for its whole life: [64][32 * R] bf16 <= 128 KiB, loaded
+//     into LDS once (global_load_lds), already in fragment order (lane-linear ds_read_b128, conflict-free).
+//     The main loop has no barrier and no global->LDS traffic; block b takes slab b % n_slabs, so the
+//     blocks that share an XCD's L2 share a slab.
+//   * a wave computes 64 envs x 64 columns per pass: per k-step of 16, two B fragments from LDS, two A
+//     fragments from registers, four v_mfma_f32_32x32x16_bf16; two waves per SIMD.  What limits the loop is
+//     the SIMD's issue port (an MFMA holds it for 8 of its 32 cycles, a VALU op for 4), so everything
+//     beside the MFMAs is kept to ~4 VALU ops per MFMA: the expansion above, pass-invariant addressing with
+//     immediate offsets, the first MFMA of a pass taking C = 0 instead of a cleared accumulator.
+//   * epilogue: x 0.5 + bias (one fma), optional ReLU, packed bf16 conversion, then a 4x4 transpose over
+//     the lane quad (DPP) so that a lane holds 8 adjacent outputs of one row: 16-byte stores, 128 contiguous
+//     bytes per row.  The stores are deferred and leave one at a time under the next pass's groups -- a burst
+//     of stores at every pass end (all workgroups reach it together) stalls the bit loads queued behind it.
+//
+// Numerics: products are exact, accumulation is the MFMA's f32 chain; the test compares against an f64
+// reference within bf16 output rounding and pins the k permutation with integer data.  |W| >= 2^16 saturates
+// in the packed form (2^112 W must stay finite in bf16).
+#include <hip/hip_bf16.h>
+
+#include "device_common.hpp"
+#include "qgym_host.hpp"
+
+namespace qg {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+constexpr uint32_t EMB_SLAB = 64;       // output columns per workgroup
+constexpr uint32_t EMB_MA = 2;          // 32-env MFMA row tiles per wave
+constexpr uint32_t EMB_WAVES = 8;       // waves per workgroup (two per SIMD)
+constexpr uint32_t EMB_WAVE_ENVS = 32 * EMB_MA;
+constexpr uint32_t EMB_BLOCK_ENVS = EMB_WAVES * EMB_WAVE_ENVS;
+constexpr uint32_t EMB_THREADS = 64 * EMB_WAVES;
+
+// matrix row of TILE slot `slot` (kernels_qm.hip: X-type row j = slot 2j, Z-type row N+j = slot 2j+1), or -1
+__host__ __device__ inline int32_t emb_slot_row(uint32_t slot, uint32_t N, bool has_z) {
+    if (!has_z) return slot < N ? (int32_t)slot : -1;
+    const uint32_t j = slot >> 1;
+    if (j >= N) return -1;
+    return (int32_t)((slot & 1u) ? N + j : j);
+}
+
+// k-steps of a packed slab: 8 per 16-byte group of the env, groups padded to an even count (the kernel's
+// bit buffers alternate between two register sets)
+__host__ __device__ inline uint32_t emb_groups(uint32_t R) { return ((R / 4u) + 1u) & ~1u; }
+__host__ __device__ inline uint32_t emb_ksteps(uint32_t R) { return 8u * emb_groups(R); }
+
+// Packed weights: [slab][k-step s < emb_ksteps(R)][nb < 2][lane < 64][e < 8] bf16.  Lane (c = lane & 31, h = lane >> 5)
+// element e = 2j + half of k-step s multiplies bit ((half ? 30 : 14) - j + 8 (s & 1) + 4h) mod 32 of slot s >> 1,
+// carries the factor 2^(128 - (128 >> j)) (the kernel's A element for it is 2^((128 >> j) - 127)) and belongs to
+// output column slab * 64 + 2c + nb.
+template <typename WT>
+__global__ __launch_bounds__(256) void pack_embed_kernel(const WT *w, uint64_t ld, uint32_t hidden, uint32_t R, uint32_t N, uint32_t D,
+                                                         uint32_t has_z, __hip_bfloat16 *out) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t KS = emb_ksteps(R);
+    const uint64_t total = (uint64_t)(hidden / EMB_SLAB) * KS * 2 * 64 * 8;
+    if (idx >= total) return;
+    const uint32_t e = (uint32_t)idx & 7u, lane = (uint32_t)(idx >> 3) & 63u, nb = (uint32_t)(idx >> 9) & 1u;
+    const uint64_t ss = idx >> 10;
+    const uint32_t s = (uint32_t)(ss % KS), slab = (uint32_t)(ss / KS);
+    const uint32_t c = lane & 31u, h = lane >> 5, j = e >> 1, half = e & 1u;
+    const uint32_t pos = ((half ? 30u : 14u) - j + 8u * (s & 1u) + 4u * h) & 31u;
+    const int32_t row = (s >> 1) < R ? emb_slot_row(s >> 1, N, has_z != 0) : -1;  // k-steps past 2R pad the slab to an even group count
+    const uint32_t n = slab * EMB_SLAB + 2u * c + nb;
+    float v = 0.0f;
+    if (row >= 0 && pos < D) {
+        v = (float)w[(uint64_t)n * ld + (uint64_t)row * D + pos];
+        v *= __uint_as_float((127u + 128u - (128u >> j)) << 23);  // 2^(128 - (128 >> j)): 1, 2^64, 2^96, 2^112
+        const float lim = 3.3895313892515355e38f;                   // largest finite bf16
+        v = v > lim ? lim : v < -lim ? -lim : v;
+    }
+    out[idx] = __float2bfloat16(v);
+}
+
+struct EmbedArgs {
+    const uint4 *state;     // TILE layout
+    const uint4 *wp;        // packed weights
+    const float *bias;      // [hidden] f32 or null
+    uint32_t *out;          // [B][ld_out / 2] bf16 pairs
+    uint64_t B;
+    uint64_t ld_out;        // elements per env row of out
+    uint32_t n_slabs;
+    uint32_t relu;
+};
+
+// A fragment (8 bf16 for this lane's row and k-half) from a row word: see the header comment
+__device__ __forceinline__ bf16x8 emb_expand(uint32_t w, uint32_t sh) {
+    const uint32_t t = __builtin_amdgcn_alignbit(w, w, sh);
+    u32x4 v;
+    v.x = t & 0x40004000u;
+    v.y = t & 0x20002000u;
+    v.z = t & 0x10001000u;
+    v.w = t & 0x08000800u;
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// 2x2 transpose step of the epilogue: lanes l and l ^ m (m = 1: DPP quad_perm [1,0,3,2] = 0xB1; m = 2: [2,3,0,1] = 0x4E)
+// exchange so that the lane with bit m clear ends with {a, partner's a} and the other with {partner's b, b}
+template <int CTRL>
+__device__ __forceinline__ void emb_quad_swap(uint32_t &a, uint32_t &b, bool upper) {
+    const uint32_t x = upper ? a : b;
+    const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false);
+    a = upper ? y : a;
+    b = upper ? b : y;
+}
+
+struct EmbWave {
+    f32x16 acc[EMB_MA][2];
+    bf16x8 a_c[EMB_MA], b_c[2];
+};
+
+// One group of a pass (8 k-steps = one 16-byte group of every env of the wave's row tiles).  `cur` holds the
+// group's bits, `nxt` receives the following group's (of this pass or of the next one): its loads are issued
+// first and consumed only by the last phase, which expands the first word of `nxt`.  `after_loads` issues the
+// deferred output stores of the previous pass that belong to this group.  Software pipeline: while the MFMAs
+// of k-step s issue, the B fragments of s + 1 are read from LDS and its A fragments are expanded into a second
+// register set.  FIRST: the pass starts here, the accumulators start from C = 0.
+template <bool FIRST, typename F>
+__device__ __forceinline__ void emb_group(EmbWave &w, const uint4 (&cur)[EMB_MA], uint4 (&nxt)[EMB_MA], const uint4 *const (&pn)[EMB_MA],
+                                          uint32_t pn_off, const uint4 *bl, uint32_t wrap, const uint32_t (&sh)[2], F &&after_loads) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (uint32_t i = 0; i < EMB_MA; ++i) nxt[i] = pn[i][pn_off];
+    after_loads();
+#pragma unroll
+    for (uint32_t ss = 0; ss < 8; ++ss) {
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t sn = ss + 1, compn = (sn >> 1) & 3u, spn = sn & 1u;
+        bf16x8 a_n[EMB_MA], b_n[2];
+        if (ss < 7) {
+            b_n[0] = __builtin_bit_cast(bf16x8, bl[(sn * 2u + 0u) * 64u]);
+            b_n[1] = __builtin_bit_cast(bf16x8, bl[(sn * 2u + 1u) * 64u]);
+#pragma unroll
+            for (uint32_t i = 0; i < EMB_MA; ++i) {
+                const uint32_t word = compn == 0 ? cur[i].x : compn == 1 ? cur[i].y : compn == 2 ? cur[i].z : cur[i].w;
+                a_n[i] = emb_expand(word, sh[spn]);
+            }
+        } else {  // the next group's first k-step (k-step 0 again after the last group)
+            b_n[0] = __builtin_bit_cast(bf16x8, (bl - wrap)[(8u * 2u + 0u) * 64u]);
+            b_n[1] = __builtin_bit_cast(bf16x8, (bl - wrap)[(8u * 2u + 1u) * 64u]);
+#pragma unroll
+            for (uint32_t i = 0; i < EMB_MA; ++i) a_n[i] = emb_expand(nxt[i].x, sh[0]);
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < EMB_MA; ++i) {
+            if (FIRST && ss == 0) {
+                const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                w.acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.a_c[i], w.b_c[0], zero, 0, 0, 0);
+                w.acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.a_c[i], w.b_c[1], zero, 0, 0, 0);
+            } else {
+                w.acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.a_c[i], w.b_c[0], w.acc[i][0], 0, 0, 0);
+                w.acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.a_c[i], w.b_c[1], w.acc[i][1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the two LDS reads first
+#pragma unroll
+        for (uint32_t m = 0; m < 2 * EMB_MA; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // a share of the next k-step's expansion
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < EMB_MA; ++i) w.a_c[i] = a_n[i];
+        w.b_c[0] = b_n[0];
+        w.b_c[1] = b_n[1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// G = 16-byte groups per env (R / 4); the slab holds GP = G rounded up to even groups (the padding group has
+// zero weights and re-reads group G - 1's bits).  The pass loop is unrolled over the groups, so bit-load offsets
+// are immediates and which deferred store goes with which group is a compile-time fact.
+template <uint32_t G>
+__global__ __launch_bounds__(EMB_THREADS, 1) void embed_bits_kernel(EmbedArgs a) {
+    extern __shared__ uint4 emb_lds[];  // the slab: [8 GP k-steps][2][64 lanes] x 16 B
+    constexpr uint32_t GP = (G + 1u) & ~1u;
+    constexpr uint32_t NQ = EMB_MA * 4u;  // output quads (16 B per lane) per pass
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t slab = blockIdx.x % a.n_slabs, mgroup = blockIdx.x / a.n_slabs, n_mgroups = gridDim.x / a.n_slabs;
+    constexpr uint32_t group_vec = 8u * 2u * 64u;      // uint4 per group of 8 k-steps
+    constexpr uint32_t slab_vec = GP * group_vec;      // uint4 per slab
+    {   // the slab goes global -> LDS without passing through registers: 1 KiB per wave instruction, lane-linear
+        const uint4 *src = a.wp + (uint64_t)slab * slab_vec;
+        for (uint32_t c = wave * 64u; c < slab_vec; c += EMB_THREADS)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + c + lane),
+                                             (__attribute__((address_space(3))) void *)(emb_lds + c), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    const uint32_t r = lane & 31u, h = lane >> 5;
+    const uint32_t sh[2] = {4u * h, 8u + 4u * h};
+    const uint32_t n0 = slab * EMB_SLAB + 2u * r;
+    const float bias0 = a.bias ? a.bias[n0] : 0.0f, bias1 = a.bias ? a.bias[n0 + 1] : 0.0f;
+    const uint64_t pass_stride = (uint64_t)n_mgroups * EMB_BLOCK_ENVS;
+
+    uint64_t env0 = (uint64_t)mgroup * EMB_BLOCK_ENVS + (uint64_t)wave * EMB_WAVE_ENVS;  // the pass being computed
+    if (env0 >= a.B) return;  // wave-uniform; no barrier below
+    // group 0 of a pass for row tile i, as this lane reads it; later groups are immediate offsets from it
+    auto point = [&](uint64_t e0, const uint4 *(&p)[EMB_MA]) {
+#pragma unroll
+        for (uint32_t i = 0; i < EMB_MA; ++i) {
+            uint64_t env = e0 + 32u * i + r;
+            env = env < a.B ? env : a.B - 1;  // tail: duplicate the last env, its rows are not stored
+            p[i] = a.state + (env >> 6) * (uint64_t)(G * 64u) + (env & 63u);
+        }
+    };
+    const uint4 *pc[EMB_MA], *pnx[EMB_MA];  // this pass, next pass (past the last pass: this pass again, the data is not used)
+    point(env0, pc);
+    EmbWave w;
+    uint4 bufa[EMB_MA], bufb[EMB_MA];
+#pragma unroll
+    for (uint32_t i = 0; i < EMB_MA; ++i) bufa[i] = pc[i][0];
+#pragma unroll
+    for (uint32_t i = 0; i < EMB_MA; ++i) w.a_c[i] = emb_expand(bufa[i].x, sh[0]);
+    w.b_c[0] = __builtin_bit_cast(bf16x8, emb_lds[lane]);
+    w.b_c[1] = __builtin_bit_cast(bf16x8, emb_lds[64u + lane]);
+
+    // outputs of the finished pass wait here (see the header comment)
+    uint4 pend[NQ];
+    uint32_t pend_rows = 0;  // rows of the pending pass that exist (0: nothing pending)
+    const uint64_t ldw = a.ld_out >> 1;  // dwords per output row
+    const uint32_t lane_row = (lane & 3u) + 4u * h;
+    uint32_t *const out_lane = a.out + ((slab * EMB_SLAB + 8u * (r >> 2)) >> 1) + (uint64_t)lane_row * ldw;
+    uint32_t *pend_ptr = out_lane;
+    auto store_quad = [&](uint32_t qi) {  // quad qi = (row tile i, register group j): row 32i + 8j + (lane & 3) + 4h of the pass
+        const uint32_t row0 = 32u * (qi >> 2) + 8u * (qi & 3u);
+        if (lane_row + row0 < pend_rows) *reinterpret_cast<uint4 *>(pend_ptr + (uint64_t)row0 * ldw) = pend[qi];
+    };
+
+    for (;;) {  // one pass per trip
+        point(env0 + pass_stride < a.B ? env0 + pass_stride : env0, pnx);
+#pragma unroll
+        for (uint32_t g = 0; g < GP; ++g) {
+            auto stores = [&]() {
+#pragma unroll
+                for (uint32_t qi = 0; qi < NQ; ++qi)
+                    if (qi * GP / NQ == g) store_quad(qi);
+            };
+            constexpr uint32_t none = 0u;
+            const uint32_t gn = g + 1u < GP ? (g + 1u < G ? g + 1u : G - 1u) : 0u;  // the group fetched under this one
+            const uint4 *const pn[EMB_MA] = {g + 1u < GP ? pc[0] : pnx[0], g + 1u < GP ? pc[1] : pnx[1]};
+            if (g & 1u) emb_group<false>(w, bufb, bufa, pn, gn * 64u, emb_lds + g * group_vec + lane, g + 1u < GP ? none : slab_vec, sh, stores);
+            else if (g == 0) emb_group<true>(w, bufa, bufb, pn, gn * 64u, emb_lds + g * group_vec + lane, none, sh, stores);
+            else emb_group<false>(w, bufa, bufb, pn, gn * 64u, emb_lds + g * group_vec + lane, none, sh, stores);
+        }
+        // The pass is complete: x 0.5 + bias, ReLU, bf16.  C layout: column = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5),
+        // so a lane holds one column pair (one dword) of 16 rows.  A 4x4 transpose over the lane quad (two DPP
+        // stages) turns four dwords = four rows x one column pair into one row x four column pairs.
+#pragma unroll
+        for (uint32_t i = 0; i < EMB_MA; ++i) {
+#pragma unroll
+            for (uint32_t q = 0; q < 16; ++q) {
+                w.acc[i][0][q] = __builtin_fmaf(w.acc[i][0][q], 0.5f, bias0);  // x 0.5 is exact: one rounding either way
+                w.acc[i][1][q] = __builtin_fmaf(w.acc[i][1][q], 0.5f, bias1);
+            }
+        }
+        if (a.relu) {
+#pragma unroll
+            for (uint32_t i = 0; i < EMB_MA; ++i) {
+#pragma unroll
+                for (uint32_t q = 0; q < 16; ++q) {
+                    w.acc[i][0][q] = __builtin_amdgcn_fmed3f(w.acc[i][0][q], 0.0f, __builtin_inff());  // max(x, 0) in one op
+                    w.acc[i][1][q] = __builtin_amdgcn_fmed3f(w.acc[i][1][q], 0.0f, __builtin_inff());
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < EMB_MA; ++i) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                uint32_t d[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const f32x2 v = {w.acc[i][0][4u * j + k], w.acc[i][1][4u * j + k]};
+                    d[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+                }
+                emb_quad_swap<0xB1>(d[0], d[1], (lane & 1u) != 0);  // lanes l ^ 1
+                emb_quad_swap<0xB1>(d[2], d[3], (lane & 1u) != 0);
+                emb_quad_swap<0x4E>(d[0], d[2], (lane & 2u) != 0);  // lanes l ^ 2
+                emb_quad_swap<0x4E>(d[1], d[3], (lane & 2u) != 0);
+                // now d[k] = the dword of quad lane k for row (lane & 3): columns 8 (r >> 2) + 2k, + 1 of this slab
+                pend[4u * i + j] = make_uint4(d[0], d[1], d[2], d[3]);
+            }
+        }
+        pend_rows = a.B - env0 < EMB_WAVE_ENVS ? (uint32_t)(a.B - env0) : EMB_WAVE_ENVS;
+        pend_ptr = out_lane + env0 * ldw;
+        env0 += pass_stride;
+        if (env0 >= a.B) break;
+#pragma unroll
+        for (uint32_t i = 0; i < EMB_MA; ++i) pc[i] = pnx[i];
+    }
+#pragma unroll
+    for (uint32_t qi = 0; qi < NQ; ++qi) store_quad(qi);
+}
+
+}  // namespace qg
+
+using namespace qg;
+
+extern "C" {
+
+size_t qg_vec_embed_packed_bytes(const qg_vec *v, uint32_t hidden) {
+    if (!v || v->layout != LAYOUT_TILE || hidden == 0 || hidden % EMB_SLAB) return 0;
+    const uint32_t R = v->has_z ? 2 * v->nxp : v->nxp;
+    return (size_t)hidden * 16u * emb_ksteps(R) * 2u;
+}
+
+int qg_vec_pack_embedding(const qg_vec *v, const void *weight_dev, int weight_dtype, uint64_t ld, uint32_t hidden, void *packed_dev, void *stream) {
+    if (!v || !weight_dev || !packed_dev) return set_error(QG_ERR_INVALID, "null argument");
+    if (v->layout != LAYOUT_TILE)
+        return set_error(QG_ERR_UNSUPPORTED, "the bit-consuming first layer needs the TILE layout (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32)");
+    if (hidden == 0 || hidden % EMB_SLAB) return set_error(QG_ERR_INVALID, "hidden size must be a multiple of %u", EMB_SLAB);
+    if (ld < (uint64_t)v->D * v->D) return set_error(QG_ERR_INVALID, "weight rows are shorter than the observation (%u x %u)", v->D, v->D);
+    HIP_TRY(hipSetDevice(v->device));
+    const uint32_t R = v->has_z ? 2 * v->nxp : v->nxp;
+    const uint64_t total = (uint64_t)hidden * 16u * emb_ksteps(R);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    __hip_bfloat16 *out = reinterpret_cast<__hip_bfloat16 *>(packed_dev);
+    switch (weight_dtype) {
+    case QG_DT_F32:
+        hipLaunchKernelGGL(pack_embed_kernel<float>, grid, block, 0, s, reinterpret_cast<const float *>(weight_dev), ld, hidden, R, v->N, v->D, (uint32_t)v->has_z, out);
+        break;
+    case QG_DT_BF16:
+        hipLaunchKernelGGL(pack_embed_kernel<__hip_bfloat16>, grid, block, 0, s, reinterpret_cast<const __hip_bfloat16 *>(weight_dev), ld, hidden, R, v->N, v->D,
+                           (uint32_t)v->has_z, out);
+        break;
+    default: return set_error(QG_ERR_INVALID, "weight dtype must be f32 or bf16");
+    }
+    HIP_TRY(hipGetLastError());
+    return QG_OK;
+}
+
+int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint32_t hidden, int relu, void *out_dev, uint64_t ld_out, void *stream) {
+    if (!v || !packed_dev || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
+    if (v->layout != LAYOUT_TILE)
+        return set_error(QG_ERR_UNSUPPORTED, "the bit-consuming first layer needs the TILE layout (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32)");
+    if (hidden == 0 || hidden % EMB_SLAB) return set_error(QG_ERR_INVALID, "hidden size must be a multiple of %u", EMB_SLAB);
+    if (ld_out < hidden || (ld_out & 7u) || (reinterpret_cast<uintptr_t>(out_dev) & 15u))
+        return set_error(QG_ERR_INVALID, "the output must be 16-byte aligned with a row stride that is a multiple of 8 elements");
+    HIP_TRY(hipSetDevice(v->device));
+    const uint32_t R = v->has_z ? 2 * v->nxp : v->nxp;
+    EmbedArgs a;
+    a.state = reinterpret_cast<const uint4 *>(v->state);
+    a.wp = reinterpret_cast<const uint4 *>(packed_dev);
+    a.bias = bias_dev;
+    a.out = reinterpret_cast<uint32_t *>(out_dev);
+    a.B = v->B;
+    a.ld_out = ld_out;
+    a.n_slabs = hidden / EMB_SLAB;
+    a.relu = relu ? 1u : 0u;
+    const uint32_t G = R / 4;
+    const size_t lds = (size_t)emb_groups(R) * 8u * 2u * 64u * 16u;  // <= 128 KiB (R <= 32)
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, v->device);
+    const uint64_t env_blocks = (v->B + EMB_BLOCK_ENVS - 1) / EMB_BLOCK_ENVS;
+    uint32_t mgroups = (uint32_t)((uint32_t)cus / a.n_slabs);
+    if (mgroups == 0) mgroups = 1;
+    if (mgroups > env_blocks) mgroups = (uint32_t)env_blocks;
+    const dim3 grid(mgroups * a.n_slabs), block(EMB_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+#define QG_EMB_CASE(GG)                                                                                                       \
+    case GG:                                                                                                                  \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(embed_bits_kernel<GG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(embed_bits_kernel<GG>, grid, block, lds, s, a);                                                     \
+        break;
+    switch (G) {
+        QG_EMB_CASE(2) QG_EMB_CASE(3) QG_EMB_CASE(4) QG_EMB_CASE(5) QG_EMB_CASE(6) QG_EMB_CASE(7) QG_EMB_CASE(8)
+    default: return set_error(QG_ERR_UNSUPPORTED, "unexpected row-group count %u", G);
+    }
+#undef QG_EMB_CASE
+    HIP_TRY(hipGetLastError());
+    return QG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+"""The bit-consuming first policy layer (qg_vec_embed) against a dense reference computed from
+Env::observe.  Integer data pins the k permutation of the packed weights exactly; random data checks
+the f32 accumulation within bf16 output rounding (tolerance stated below)."""
+import numpy as np
+import pytest
+import torch
+
+from qiskit_gym_amd import _lib
+from qiskit_gym_amd.collector import embed, pack_embedding
+from qiskit_gym_amd.vec import VecEnv
+from util import line_gateset
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # kind, qubits, batch, hidden
+    ("clifford", 16, 1000, 128),
+    ("clifford", 16, 4096, 512),
+    ("clifford", 5, 700, 64),
+    ("clifford", 9, 63, 192),
+    ("linear_function", 12, 1, 64),
+    ("linear_function", 32, 1500, 128),
+    ("linear_function", 17, 513, 64),
+]
+
+
+def _env(kind, n, B, seed):
+    gs = line_gateset(kind, n)
+    env = VecEnv(kind, n, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=64)
+    env.reset(seed)
+    return env
+
+
+@pytest.mark.parametrize("kind,n,B,hidden", CASES)
+def test_embed_integer_weights_exact(kind, n, B, hidden):
+    env = _env(kind, n, B, 11)
+    obs = env.observe().to(torch.float64).flatten(1)  # [B, D*D]
+    K = obs.shape[1]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    # +-1 entries, at most 200 per output: every partial sum is an integer below 256, exact in bf16
+    w = torch.zeros((hidden, K), dtype=torch.float32)
+    for r in range(hidden):
+        idx = torch.randperm(K, generator=g)[: min(K, 200)]
+        w[r, idx] = (torch.randint(0, 2, (idx.numel(),), generator=g) * 2 - 1).float()
+    bias = torch.randint(-8, 9, (hidden,), generator=g).float()
+    wd, bd = w.cuda(), bias.cuda()
+    for wt in (wd, wd.to(torch.bfloat16)):
+        packed = pack_embedding(env, wt)
+        for relu in (False, True):
+            out = embed(env, packed, bd, hidden, relu=relu)
+            ref = obs @ wd.double().t() + bd.double()
+            if relu:
+                ref = ref.clamp_min(0)
+            assert torch.equal(out.double(), ref), f"{kind} {n}q: mismatch in {(out.double() != ref).sum().item()} entries"
+    out = embed(env, packed, None, hidden, relu=False)
+    assert torch.equal(out.double(), obs @ wd.double().t())
+    env.sync()
+
+
+@pytest.mark.parametrize("kind,n,B,hidden", CASES[:2] + CASES[5:6])
+def test_embed_random_weights(kind, n, B, hidden):
+    env = _env(kind, n, B, 3)
+    obs = env.observe().to(torch.float64).flatten(1)
+    K = obs.shape[1]
+    g = torch.Generator(device="cpu").manual_seed(9)
+    w = (torch.randn((hidden, K), generator=g) * 0.05).to(torch.bfloat16).cuda()
+    bias = torch.randn(hidden, generator=g).cuda()
+    out = embed(env, pack_embedding(env, w), bias, hidden, relu=True)
+    ref = (obs @ w.double().t() + bias.double()).clamp_min(0)
+    # f32 accumulation of exact products (|error| <~ 1e-6 * sum|w|) then one bf16 rounding (2^-9 relative)
+    err = (out.double() - ref).abs()
+    assert bool((err <= ref.abs() * 2.0**-8 + 1e-4).all()), f"max error {err.max().item()}"
+    # a strided output (the layer may write into a wider activation buffer)
+    wide = torch.zeros((B, hidden + 64), dtype=torch.bfloat16, device="cuda")
+    embed(env, pack_embedding(env, w), bias, hidden, relu=True, out=wide[:, :hidden])
+    assert torch.equal(wide[:, :hidden], out) and not bool(wide[:, hidden:].any())
+    env.sync()
+
+
+def test_embed_follows_the_state():
+    """The layer reads the live tiles: after a step it sees the new observation."""
+    env = _env("clifford", 16, 2048, 1)
+    w = torch.randint(-1, 2, (64, 1024), generator=torch.Generator().manual_seed(2)).float()
+    w[:, 200:] = 0  # few nonzeros per output: exact in bf16
+    w = w.cuda()
+    packed = pack_embedding(env, w)
+    for t in range(4):
+        acts = torch.randint(0, env.num_actions(), (2048,), device="cuda", dtype=torch.int32)
+        env.step(acts)
+        ref = env.observe().double().flatten(1) @ w.double().t()
+        assert torch.equal(embed(env, packed, None, 64, relu=False).double(), ref)
+    env.sync()
+
+
+def test_embed_unsupported_layouts():
+    gs = line_gateset("clifford", 20)
+    env = VecEnv("clifford", 20, gs, 64, add_inverts=False, add_perms=False, track_solution=False)
+    with pytest.raises((ValueError, _lib.QGymError)):
+        pack_embedding(env, torch.zeros((64, 1600), device="cuda"))
+    env16 = _env("clifford", 16, 64, 1)
+    with pytest.raises((ValueError, _lib.QGymError)):
+        pack_embedding(env16, torch.zeros((100, 1024), device="cuda"))  # hidden % 64 != 0

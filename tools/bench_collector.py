@@ -9,7 +9,10 @@ from qiskit_gym_amd.collector import BasicPolicy, RolloutCollector
 from qiskit_gym_amd.vec import VecEnv
 from util import line_gateset
 
+ONLY = os.environ.get("ONLY")  # e.g. ONLY=65536 to run the large batch only (profiling)
 for B, store, graph in ((1024, "packed", False), (1024, "packed", True), (8192, "packed", False), (8192, "packed", True), (65536, "dense", False), (65536, "packed", False), (65536, "packed", True)):
+    if ONLY and (B != int(ONLY) or store != "packed" or graph):
+        continue
     gs = line_gateset("clifford", 16)
     env = VecEnv("clifford", 16, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=int(os.environ.get("DIFF", "32")))
     col = RolloutCollector(env, BasicPolicy(1024, len(gs)), dtype=torch.bfloat16, seed=1, store_obs=store, use_graph=graph)
