@@ -291,7 +291,7 @@ int qg_gae(const float *rewards_dev, const float *values_dev, const uint8_t *don
  * optimiser step); qg_vec_embed runs the layer: bias_dev f32 [hidden] or NULL, relu != 0 applies max(0, .),
  * out_dev bf16 [batch, ld_out], 16-byte aligned, ld_out >= hidden and a multiple of 8. */
 size_t qg_vec_embed_packed_bytes(const qg_vec *v, uint32_t hidden);
-int qg_vec_pack_embedding(const qg_vec *v, const void *weight_dev, int weight_dtype, uint64_t ld, uint32_t hidden, void *packed_dev, void *stream);
+int qg_vec_pack_embedding(qg_vec *v, const void *weight_dev, int weight_dtype, uint64_t ld, uint32_t hidden, void *packed_dev, void *stream);
 int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint32_t hidden, int relu, void *out_dev, uint64_t ld_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------

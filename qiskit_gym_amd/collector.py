@@ -186,7 +186,7 @@ class RolloutCollector:
     and samples with counter n; both modes therefore produce the same trajectories."""
 
     def __init__(self, env: VecEnv, policy: nn.Module, dtype: torch.dtype = torch.bfloat16, seed: int = 0, gamma: float = 0.995,
-                 gae_lambda: float = 0.995, store_obs: str = "dense", use_graph: bool = False):
+                 gae_lambda: float = 0.995, store_obs: str = "dense", use_graph: bool = False, use_bit_embedding: bool = True):
         self.env = env
         self.policy = policy.to(device=env.device, dtype=dtype)
         self.dtype = dtype
@@ -204,9 +204,17 @@ class RolloutCollector:
         self.clock = torch.zeros(1, dtype=torch.int64, device=env.device)  # collector steps taken so far
         env.set_clock(self.clock)
         self._heads = None
+        self._embed = None  # (packed first-layer weight, f32 bias): the first layer reads the env's bits directly
         if isinstance(self.policy, BasicPolicy):
             w, b, A = self.policy.fused_heads()
             self._heads = (w, b, A)
+            emb = self.policy.embeddings
+            if use_bit_embedding and dtype == torch.bfloat16 and emb.out_features % 64 == 0 and emb.in_features == self.obs_size:
+                try:
+                    self._embed = (pack_embedding(env, emb.weight), emb.bias.detach().float().contiguous())
+                except (ValueError, _lib.QGymError):
+                    self._embed = None  # layouts without the bit-consuming kernel keep the dense first layer
+        self._h1 = None
         self._graph = None
         self._graph_T = 0
         self._graph_ro: Optional[Rollout] = None
@@ -229,14 +237,18 @@ class RolloutCollector:
                        returns=torch.empty((T, B), **f32), obs_packed=self.store_obs == "packed", obs_cols=env.obs_shape_[1])
 
     def _observe(self, ro: Rollout, t: int):
-        """Observation of the current state into row t of the rollout and, as `dtype`, into the policy input."""
+        """Observation of the current state into row t of the rollout and, as `dtype`, into the policy input
+        (not needed when the first layer consumes the bits directly)."""
         env = self.env
         if ro.obs_packed:
             env.observe_packed(out=ro.obs[t])
-            env.observe_as(self.dtype, out=self._x)
+            if self._embed is None:
+                env.observe_as(self.dtype, out=self._x)
         else:
             env.observe(out=ro.obs[t].view(env.batch, *env.obs_shape_))
-            if env.env_kind == "pauli":
+            if self._embed is not None:
+                pass
+            elif env.env_kind == "pauli":
                 # PauliEnv.observe() with add_perms draws a permutation (pauli.rs:657-662): observe once
                 _lib.check(_lib.load().qg_widen_dense(ro.obs[t].data_ptr(), ro.obs[t].numel(), self._x.data_ptr(), _DT[self.dtype], _stream_ptr()))
             else:
@@ -252,12 +264,20 @@ class RolloutCollector:
         w[A].copy_(pol.value_head.weight[0])
         b[:A].copy_(pol.policy_head.bias)
         b[A : A + 1].copy_(pol.value_head.bias)
+        if self._embed is not None:
+            pack_embedding(self.env, pol.embeddings.weight, out=self._embed[0])
+            self._embed[1].copy_(pol.embeddings.bias)
 
     def _trunk(self) -> torch.Tensor:
         """Fused-head forward of `self._x`: [B, pad8(A + 1)], column A is the value."""
         pol = self.policy
         w, b, _ = self._heads
-        h = _linear_relu(self._x, pol.embeddings.weight, pol.embeddings.bias)
+        if self._embed is not None:
+            if self._h1 is None:
+                self._h1 = torch.empty((self.env.batch, pol.embeddings.out_features), dtype=self.dtype, device=self.env.device)
+            h = embed(self.env, self._embed[0], self._embed[1], pol.embeddings.out_features, relu=True, out=self._h1)
+        else:
+            h = _linear_relu(self._x, pol.embeddings.weight, pol.embeddings.bias)
         h = _linear_relu(h, pol.common.weight, pol.common.bias)
         return torch.addmm(b, h, w.t())
 
@@ -272,7 +292,8 @@ class RolloutCollector:
         ro.values[t].copy_(value)
 
     def _value_of_current_state(self) -> torch.Tensor:
-        self.env.observe_as(self.dtype, out=self._x)
+        if self._embed is None:
+            self.env.observe_as(self.dtype, out=self._x)
         if self._heads is not None:
             return self._trunk()[:, self._heads[2]].float()
         return self.policy(self._x)[1].float()

@@ -98,6 +98,7 @@ struct EmbedArgs {
     const uint4 *wp;        // packed weights
     const float *bias;      // [hidden] f32 or null
     uint32_t *out;          // [B][ld_out / 2] bf16 pairs
+    uint4 *dump;            // 64 x 16 B that nobody reads: where the lanes of rows past B (and the "nothing pending yet" case) store
     uint64_t B;
     uint64_t ld_out;        // elements per env row of out
     uint32_t n_slabs;
@@ -243,9 +244,14 @@ __global__ __launch_bounds__(EMB_THREADS, 1) void embed_bits_kernel(EmbedArgs a)
     const uint32_t lane_row = (lane & 3u) + 4u * h;
     uint32_t *const out_lane = a.out + ((slab * EMB_SLAB + 8u * (r >> 2)) >> 1) + (uint64_t)lane_row * ldw;
     uint32_t *pend_ptr = out_lane;
+    // Every store is unconditional (rows that do not exist go to the dump): behind a branch the compiler could not
+    // count it and would make each wait for a group's bit loads also wait for the store issued after them.
+    uint4 *const dump = a.dump + lane;
     auto store_quad = [&](uint32_t qi) {  // quad qi = (row tile i, register group j): row 32i + 8j + (lane & 3) + 4h of the pass
         const uint32_t row0 = 32u * (qi >> 2) + 8u * (qi & 3u);
-        if (lane_row + row0 < pend_rows) *reinterpret_cast<uint4 *>(pend_ptr + (uint64_t)row0 * ldw) = pend[qi];
+        uint4 *dst = reinterpret_cast<uint4 *>(pend_ptr + (uint64_t)row0 * ldw);
+        dst = lane_row + row0 < pend_rows ? dst : dump;
+        *dst = pend[qi];
     };
 
     for (;;) {  // one pass per trip
@@ -326,7 +332,7 @@ size_t qg_vec_embed_packed_bytes(const qg_vec *v, uint32_t hidden) {
     return (size_t)hidden * 16u * emb_ksteps(R) * 2u;
 }
 
-int qg_vec_pack_embedding(const qg_vec *v, const void *weight_dev, int weight_dtype, uint64_t ld, uint32_t hidden, void *packed_dev, void *stream) {
+int qg_vec_pack_embedding(qg_vec *v, const void *weight_dev, int weight_dtype, uint64_t ld, uint32_t hidden, void *packed_dev, void *stream) {
     if (!v || !weight_dev || !packed_dev) return set_error(QG_ERR_INVALID, "null argument");
     if (v->layout != LAYOUT_TILE)
         return set_error(QG_ERR_UNSUPPORTED, "the bit-consuming first layer needs the TILE layout (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32)");
@@ -334,6 +340,7 @@ int qg_vec_pack_embedding(const qg_vec *v, const void *weight_dev, int weight_dt
     if (ld < (uint64_t)v->D * v->D) return set_error(QG_ERR_INVALID, "weight rows are shorter than the observation (%u x %u)", v->D, v->D);
     HIP_TRY(hipSetDevice(v->device));
     const uint32_t R = v->has_z ? 2 * v->nxp : v->nxp;
+    if (!v->embed_dump) HIP_TRY(hipMalloc(&v->embed_dump, 1024));  // see EmbedArgs::dump
     const uint64_t total = (uint64_t)hidden * 16u * emb_ksteps(R);
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
     hipStream_t s = (hipStream_t)stream;
@@ -366,6 +373,8 @@ int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint3
     a.wp = reinterpret_cast<const uint4 *>(packed_dev);
     a.bias = bias_dev;
     a.out = reinterpret_cast<uint32_t *>(out_dev);
+    if (!v->embed_dump) return set_error(QG_ERR_INVALID, "qg_vec_pack_embedding must run on this handle first");
+    a.dump = reinterpret_cast<uint4 *>(v->embed_dump);
     a.B = v->B;
     a.ld_out = ld_out;
     a.n_slabs = hidden / EMB_SLAB;

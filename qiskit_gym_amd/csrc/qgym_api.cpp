@@ -223,7 +223,7 @@ static int vec_free_buffers(qg_vec *v) {
     void *ptrs[] = {v->state, v->own_depth ? v->depth : nullptr, v->own_reward ? v->reward : nullptr,
                     v->own_done ? v->done : nullptr, v->own_success ? v->success : nullptr, v->inverted, v->error, v->sol,
                     v->sol_len, v->layers, v->d_gates, v->d_descs, v->scratch, v->rot, v->pmeta, v->d_prog,
-                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad, v->done_list, v->d_rowops};
+                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad, v->done_list, v->d_rowops, v->embed_dump};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &g : v->graphs) {

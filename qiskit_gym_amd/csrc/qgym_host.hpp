@@ -81,6 +81,7 @@ struct qg_vec {
     uint32_t *d_rowops = nullptr;       // TILE: gate table as pairs of row operations on slots (cooperative reset kernel)
     uint32_t *done_list = nullptr;      // reset_done: [B] indices of finished envs + {length, reader ticket} at [B], [B + 1]
     uint32_t *d_nonsymp = nullptr;      // device word behind InitArgs::nonsymp_flag
+    void *embed_dump = nullptr;         // qg_vec_embed: 1 KiB nobody reads (kernels_policy.hip), allocated by qg_vec_pack_embedding
     bool maybe_nonsymplectic = false;   // CliffordEnv + add_inverts: some env may need the Gauss-Jordan inversion
     bool own_reward = true, own_done = true, own_success = true, own_depth = true;
 

@@ -11,8 +11,8 @@ from collect_ref import gae_f32  # noqa: E402
 from util import f32_bits, line_gateset, rng_actions  # noqa: E402
 
 
-@pytest.mark.parametrize("store_obs", ["dense", "packed"])
-def test_collector_trajectories_replay_on_the_oracle(store_obs):
+@pytest.mark.parametrize("store_obs,dtype_name", [("dense", "float32"), ("packed", "float32"), ("packed", "bfloat16"), ("dense", "bfloat16")])
+def test_collector_trajectories_replay_on_the_oracle(store_obs, dtype_name):
     from qiskit_gym_amd.collector import BasicPolicy, RolloutCollector
     from qiskit_gym_amd.vec import VecEnv
 
@@ -23,7 +23,11 @@ def test_collector_trajectories_replay_on_the_oracle(store_obs):
     env = VecEnv("clifford", n, gs, B, **cfg)
     torch.manual_seed(0)
     pol = BasicPolicy(4 * n * n, A, embedding_size=64, common=32)
-    col = RolloutCollector(env, pol, dtype=torch.float32, seed=77, gamma=0.99, gae_lambda=0.9, store_obs=store_obs)
+    dtype = getattr(torch, dtype_name)
+    col = RolloutCollector(env, pol, dtype=dtype, seed=77, gamma=0.99, gae_lambda=0.9, store_obs=store_obs)
+    # in bf16 the first layer reads the env's bit-packed state directly (qg_vec_embed), no dense policy input exists
+    assert (col._embed is not None) == (dtype == torch.bfloat16)
+    tol = 1e-4 if dtype == torch.float32 else 6e-2  # bf16 activations: 2^-8 relative per layer
     ro = col.collect(T)
     torch.cuda.synchronize()
     env.sync()
@@ -48,10 +52,10 @@ def test_collector_trajectories_replay_on_the_oracle(store_obs):
     assert col.steps_done == T
     assert torch.isfinite(ro.logp).all() and torch.isfinite(ro.values).all() and (ro.logp <= 0).all() and (ro.entropy >= 0).all()
     # the policy input the collector built is the observation; the sampled log-probs are the policy's
-    logits, value = col.policy(torch.from_numpy(obs[T - 1]).cuda().float())
+    logits, value = col.policy.float()(torch.from_numpy(obs[T - 1]).cuda().float())
     lsm = torch.log_softmax(logits.float(), dim=-1)
-    torch.testing.assert_close(ro.logp[T - 1], lsm.gather(1, ro.actions[T - 1].unsqueeze(1)).squeeze(1), atol=1e-4, rtol=0)
-    torch.testing.assert_close(ro.values[T - 1], value.float(), atol=1e-4, rtol=0)
+    torch.testing.assert_close(ro.logp[T - 1], lsm.gather(1, ro.actions[T - 1].unsqueeze(1)).squeeze(1), atol=tol, rtol=0)
+    torch.testing.assert_close(ro.values[T - 1], value.float(), atol=tol, rtol=0)
     # GAE over the rollout, bootstrapped with the value of the state after the last step
     want_adv, want_ret = gae_f32(rew, ro.values.cpu().numpy(), done, ro.last_values.cpu().numpy(), 0.99, 0.9)
     np.testing.assert_array_equal(f32_bits(ro.advantages.cpu().numpy()), f32_bits(want_adv))
@@ -126,3 +130,31 @@ def test_graph_replays_collect_the_same_rollouts_as_eager_calls(kind, n, kw):
     # successive rollouts differ (the clock advanced)
     assert not torch.equal(rollouts[True][1]["actions"], rollouts[True][2]["actions"])
     assert sum(int(r["dones"].sum()) for r in rollouts[True]) > B
+
+
+def test_graph_replay_with_the_bit_consuming_first_layer():
+    """bf16 policy on a TILE-layout env: the captured collection launches qg_vec_embed instead of observe + GEMM,
+    and a replay after an in-place parameter update uses the repacked weights."""
+    from qiskit_gym_amd.collector import BasicPolicy, RolloutCollector
+    from qiskit_gym_amd.vec import VecEnv
+
+    B, T = 256, 5
+    gs = line_gateset("clifford", 6)
+    env = VecEnv("clifford", 6, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=3)
+    torch.manual_seed(5)
+    pol = BasicPolicy(144, len(gs), embedding_size=128, common=64)
+    col = RolloutCollector(env, pol, dtype=torch.bfloat16, seed=9, store_obs="packed", use_graph=True)
+    assert col._embed is not None
+    for call in range(3):
+        ro = col.collect(T)
+        torch.cuda.synchronize()
+        obs = ro.dense_obs(torch.float32)[T - 1]
+        logits, value = col.policy(obs.to(torch.bfloat16))
+        lsm = torch.log_softmax(logits.float(), dim=-1)
+        torch.testing.assert_close(ro.logp[T - 1], lsm.gather(1, ro.actions[T - 1].unsqueeze(1)).squeeze(1), atol=6e-2, rtol=0)
+        torch.testing.assert_close(ro.values[T - 1], value.float(), atol=6e-2, rtol=0)
+        with torch.no_grad():  # an optimiser step, in place: the next replay must see it (heads refreshed, first layer repacked)
+            for prm in col.policy.parameters():
+                prm.mul_(0.5)
+    env.sync()
+    assert col.steps_done == 3 * T
