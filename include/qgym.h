@@ -294,6 +294,20 @@ size_t qg_vec_embed_packed_bytes(const qg_vec *v, uint32_t hidden);
 int qg_vec_pack_embedding(qg_vec *v, const void *weight_dev, int weight_dtype, uint64_t ld, uint32_t hidden, void *packed_dev, void *stream);
 int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint32_t hidden, int relu, void *out_dev, uint64_t ld_out, void *stream);
 
+/* The policy's last layer and the categorical draw in one kernel: logits[e, a] = sum_k h[e, k] W[a, k] + b[a] stay in
+ * registers and go straight into the exponential race of qg_sample_actions (same counter RNG, hash and tie rule, so
+ * the same seed / counter / clock give the same draw for the same logits); outputs as there, values_dev[e] = the value
+ * head W[value_row] . h[e] + b[value_row].  h_dev: bf16 [batch, ld_h], 16-byte aligned, ld_h % 8 == 0.  Limits
+ * (qg_policy_head_packed_bytes returns 0 outside them): num_actions <= 190, in_features % 64 == 0, <= 512, packed head
+ * <= 144 KiB.  qg_policy_pack_head re-orders W ([rows, ld] f32 / bf16) and the bias ([rows], same dtype, or NULL)
+ * into MFMA fragment order: rows 0..num_actions-1 are the actions, row value_row (>= 0, any index) the value head. */
+size_t qg_policy_head_packed_bytes(uint32_t num_actions, uint32_t in_features);
+int qg_policy_pack_head(const void *weight_dev, const void *bias_dev, int dtype, uint64_t ld, uint32_t in_features, uint32_t num_actions,
+                        int32_t value_row, void *packed_dev, void *stream);
+int qg_policy_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, uint32_t in_features, const void *packed_dev, uint32_t num_actions,
+                          uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev, int action_dtype, float *logp_dev,
+                          float *entropy_dev, float *values_dev, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Scalar environment: the `Env` trait method for method (clifford.rs:285-382).
  * Every call synchronises; this flavour exists for API parity, not for speed.

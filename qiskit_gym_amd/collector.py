@@ -112,6 +112,40 @@ def embed(env: VecEnv, packed: torch.Tensor, bias: Optional[torch.Tensor], hidde
     return out
 
 
+def pack_head(weight: torch.Tensor, bias: Optional[torch.Tensor], num_actions: int, value_row: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Last-layer weight [rows, in_features] (+ bias [rows]; f32 or bf16, same dtype) in the order `head_sample` consumes:
+    rows 0..num_actions-1 are the actions, row `value_row` the value head (`qg_policy_pack_head`)."""
+    L = _lib.load()
+    nbytes = L.qg_policy_head_packed_bytes(num_actions, weight.shape[1])
+    if nbytes == 0:
+        raise ValueError("fused head needs num_actions <= 190 and in_features % 64 == 0, <= 512")
+    if weight.stride(1) != 1 or (bias is not None and (bias.dtype != weight.dtype or not bias.is_contiguous())):
+        raise ValueError("weight must have unit column stride; bias contiguous and of the same dtype")
+    if out is None:
+        out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=weight.device)
+    _lib.check(L.qg_policy_pack_head(weight.data_ptr(), bias.data_ptr() if bias is not None else None, _DT[weight.dtype], weight.stride(0), weight.shape[1],
+                                     int(num_actions), int(value_row), out.data_ptr(), _stream_ptr()))
+    return out
+
+
+def head_sample(h: torch.Tensor, packed: torch.Tensor, num_actions: int, seed: int, counter: int, actions: Optional[torch.Tensor] = None,
+                logp: Optional[torch.Tensor] = None, entropy: Optional[torch.Tensor] = None, values: Optional[torch.Tensor] = None,
+                clock: Optional[torch.Tensor] = None):
+    """Last layer + categorical draw in one kernel (`qg_policy_head_sample`): h bf16 [B, in_features] -> (actions, logp, entropy, values)."""
+    if h.dim() != 2 or h.dtype != torch.bfloat16 or h.stride(1) != 1:
+        raise ValueError("h must be bf16 [B, in_features] with unit column stride")
+    B, dev = h.shape[0], h.device
+    actions = torch.empty(B, dtype=torch.int64, device=dev) if actions is None else actions
+    logp = torch.empty(B, dtype=torch.float32, device=dev) if logp is None else logp
+    entropy = torch.empty(B, dtype=torch.float32, device=dev) if entropy is None else entropy
+    values = torch.empty(B, dtype=torch.float32, device=dev) if values is None else values
+    act_dt = {torch.int32: _lib.ACT_I32, torch.int64: _lib.ACT_I64}[actions.dtype]
+    _lib.check(_lib.load().qg_policy_head_sample(h.data_ptr(), h.stride(0), B, h.shape[1], packed.data_ptr(), int(num_actions), int(seed) & (2**64 - 1),
+                                                 int(counter), clock.data_ptr() if clock is not None else None, actions.data_ptr(), act_dt,
+                                                 logp.data_ptr(), entropy.data_ptr(), values.data_ptr(), _stream_ptr()))
+    return actions, logp, entropy, values
+
+
 class BasicPolicy(nn.Module):
     def __init__(self, obs_size: int, num_actions: int, embedding_size: int = 512, common: int = 256):
         super().__init__()
@@ -186,7 +220,8 @@ class RolloutCollector:
     and samples with counter n; both modes therefore produce the same trajectories."""
 
     def __init__(self, env: VecEnv, policy: nn.Module, dtype: torch.dtype = torch.bfloat16, seed: int = 0, gamma: float = 0.995,
-                 gae_lambda: float = 0.995, store_obs: str = "dense", use_graph: bool = False, use_bit_embedding: bool = True):
+                 gae_lambda: float = 0.995, store_obs: str = "dense", use_graph: bool = False, use_bit_embedding: bool = True,
+                 use_fused_head: bool = True):
         self.env = env
         self.policy = policy.to(device=env.device, dtype=dtype)
         self.dtype = dtype
@@ -215,6 +250,15 @@ class RolloutCollector:
                 except (ValueError, _lib.QGymError):
                     self._embed = None  # layouts without the bit-consuming kernel keep the dense first layer
         self._h1 = None
+        self._head = None  # packed last layer for the fused head + sampling kernel (bf16 BasicPolicy within its limits)
+        if self._heads is not None and dtype == torch.bfloat16 and use_fused_head:
+            w, b, A = self._heads
+            try:
+                self._head = pack_head(w, b, A, A)
+                self._scratch_actions = torch.empty(env.batch, dtype=torch.int64, device=env.device)
+                self._scratch_f32 = torch.empty((3, env.batch), dtype=torch.float32, device=env.device)
+            except ValueError:
+                self._head = None
         self._graph = None
         self._graph_T = 0
         self._graph_ro: Optional[Rollout] = None
@@ -267,21 +311,30 @@ class RolloutCollector:
         if self._embed is not None:
             pack_embedding(self.env, pol.embeddings.weight, out=self._embed[0])
             self._embed[1].copy_(pol.embeddings.bias)
+        if self._head is not None:
+            pack_head(w, b, A, A, out=self._head)
 
-    def _trunk(self) -> torch.Tensor:
-        """Fused-head forward of `self._x`: [B, pad8(A + 1)], column A is the value."""
+    def _body_layers(self) -> torch.Tensor:
+        """The two hidden layers: [B, common] activations."""
         pol = self.policy
-        w, b, _ = self._heads
         if self._embed is not None:
             if self._h1 is None:
                 self._h1 = torch.empty((self.env.batch, pol.embeddings.out_features), dtype=self.dtype, device=self.env.device)
             h = embed(self.env, self._embed[0], self._embed[1], pol.embeddings.out_features, relu=True, out=self._h1)
         else:
             h = _linear_relu(self._x, pol.embeddings.weight, pol.embeddings.bias)
-        h = _linear_relu(h, pol.common.weight, pol.common.bias)
-        return torch.addmm(b, h, w.t())
+        return _linear_relu(h, pol.common.weight, pol.common.bias)
+
+    def _trunk(self) -> torch.Tensor:
+        """Fused-head forward of the current observation: [B, pad8(A + 1)], column A is the value."""
+        w, b, _ = self._heads
+        return torch.addmm(b, self._body_layers(), w.t())
 
     def _forward_sample(self, ro: Rollout, t: int):
+        if self._head is not None:  # last layer + draw in one kernel, the logits never reach memory
+            head_sample(self._body_layers(), self._head, self._heads[2], self.seed, t, actions=ro.actions[t], logp=ro.logp[t],
+                        entropy=ro.entropy[t], values=ro.values[t], clock=self.clock)
+            return
         if self._heads is not None:
             A = self._heads[2]
             sample_actions(self._trunk(), self.seed, t, num_actions=A, value_col=A, actions=ro.actions[t], logp=ro.logp[t],
@@ -294,6 +347,10 @@ class RolloutCollector:
     def _value_of_current_state(self) -> torch.Tensor:
         if self._embed is None:
             self.env.observe_as(self.dtype, out=self._x)
+        if self._head is not None:  # the fused kernel's value output (its draw is discarded)
+            head_sample(self._body_layers(), self._head, self._heads[2], self.seed, 0, actions=self._scratch_actions, logp=self._scratch_f32[0],
+                        entropy=self._scratch_f32[1], values=self._scratch_f32[2])
+            return self._scratch_f32[2]
         if self._heads is not None:
             return self._trunk()[:, self._heads[2]].float()
         return self.policy(self._x)[1].float()

@@ -320,6 +320,174 @@ __global__ __launch_bounds__(EMB_THREADS, 1) void embed_bits_kernel(EmbedArgs a)
     for (uint32_t qi = 0; qi < NQ; ++qi) store_quad(qi);
 }
 
+
+// =================================================================================================
+// Policy head + sampling in one kernel: logits = h W^T + b never leave the registers.
+//
+// The collector's last layer is Linear(256 -> num_actions) plus the value head (rl/configs.py:531-607), then a
+// categorical draw per env.  As separate steps (hipBLASLt GEMM on a 171-column output, then qg_sample_actions
+// re-reading the logits) they cost 21 + 26 us at 65 536 envs for 6 GFLOP.  Here the product is computed TRANSPOSED,
+// logits^T = W h^T: the MFMA's A operand is a 32-action tile of W (from LDS, fragment order), the B operand 32
+// envs of h (16 B per lane straight from global memory), so in the C layout a lane holds 16 actions per tile OF ITS
+// OWN env (column = lane & 31 = env, row = action).  Max, sum of exponentials, entropy and the exponential race
+// (the very draws of qg_sample_actions: same counter RNG, same hash, same tie rule) then run down the lane's
+// registers without cross-lane traffic; the two lane halves, which hold complementary actions, meet once.
+// The bias rides in an extra k-step (A = {bias_hi, bias_lo, 0...}, B = {1, 1, 0...}), padding rows carry bias
+// -1e30 (exp -> 0, never win), the value head sits in the last padded row.
+// =================================================================================================
+constexpr uint32_t HEAD_WAVES = 8;
+constexpr float HEAD_PAD_BIAS = -1.0e30f;
+
+// Packed head: [k-step s <= K/16][tile t][lane][8] bf16; lane (r, h) element e of k-step s < K/16 = W[row(32t + r)][16s + 8h + e];
+// k-step K/16: element 0 / 1 of the h = 0 lanes = bias hi / lo.  row(p) = p for p < A, value_row for p = 32 tiles - 1, else padding.
+template <typename WT>
+__global__ __launch_bounds__(256) void pack_head_kernel(const WT *w, const WT *bias, uint64_t ld, uint32_t K, uint32_t A, int32_t value_row,
+                                                        uint32_t tiles, __hip_bfloat16 *out) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ks = K / 16u;
+    const uint64_t total = (uint64_t)(ks + 1u) * tiles * 64u * 8u;
+    if (idx >= total) return;
+    const uint32_t e = (uint32_t)idx & 7u, lane = (uint32_t)(idx >> 3) & 63u;
+    const uint32_t st = (uint32_t)(idx >> 9), t = st % tiles, s = st / tiles;
+    const uint32_t r = lane & 31u, h = lane >> 5, p = 32u * t + r;
+    const int32_t src = p < A ? (int32_t)p : (p == 32u * tiles - 1u ? value_row : -1);
+    float v = 0.0f;
+    if (s < ks) {
+        if (src >= 0) v = (float)w[(uint64_t)src * ld + 16u * s + 8u * h + e];
+    } else if (h == 0 && e < 2) {
+        const float b = src >= 0 ? (bias ? (float)bias[src] : 0.0f) : HEAD_PAD_BIAS;
+        const float hi = __bfloat162float(__float2bfloat16(b));
+        v = e == 0 ? hi : b - hi;
+    }
+    out[idx] = __float2bfloat16(v);
+}
+
+struct HeadArgs {
+    const uint4 *h;        // [B][ld_h] bf16 activations
+    const uint4 *wp;       // packed head
+    void *actions;
+    float *logp, *entropy, *values;
+    const uint64_t *clock;
+    uint64_t ld_h;         // elements per row of h
+    uint64_t B, seed, counter;
+    uint32_t K, A;
+    int32_t act64;
+};
+
+__device__ __forceinline__ float head_xhalf(float x) { return __shfl_xor(x, 32, 64); }
+
+template <uint32_t TILES>
+__global__ __launch_bounds__(64 * HEAD_WAVES, 1) void head_sample_kernel(HeadArgs a) {
+    extern __shared__ uint4 head_lds[];  // packed head: [(K/16 + 1)][TILES][64]
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t ks = a.K / 16u;
+    const uint32_t total_vec = (ks + 1u) * TILES * 64u;
+    for (uint32_t c = wave * 64u; c < total_vec; c += 64u * HEAD_WAVES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.wp + c + lane),
+                                         (__attribute__((address_space(3))) void *)(head_lds + c), 16, 0, 0);
+    const uint32_t c = lane & 31u, h = lane >> 5;
+    const uint64_t n_tiles = (a.B + 31u) / 32u;
+    const uint64_t row_vec = a.ld_h / 8u;  // uint4 per row of h
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const float INF = __builtin_huge_valf();
+    for (uint64_t tile = (uint64_t)blockIdx.x * HEAD_WAVES + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * HEAD_WAVES) {
+        const uint64_t env_raw = tile * 32u + c;
+        const bool live = env_raw < a.B;
+        const uint64_t env = live ? env_raw : a.B - 1;
+        const uint4 *hrow = a.h + env * row_vec + h;  // k-step s: 16 B at element 16 s + 8 h
+        f32x16 acc[TILES];
+#pragma unroll
+        for (uint32_t t = 0; t < TILES; ++t)
+#pragma unroll
+            for (uint32_t q = 0; q < 16; ++q) acc[t][q] = 0.0f;
+        // four k-steps per trip, the next trip's activations in flight meanwhile
+        uint4 bq[4], bn[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) bq[j] = hrow[2u * j];
+        for (uint32_t s0 = 0; s0 < ks; s0 += 4u) {
+            const uint32_t sn = s0 + 4u < ks ? s0 + 4u : s0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) bn[j] = hrow[2u * (sn + j)];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, bq[j]);
+                const uint4 *al = head_lds + (uint64_t)(s0 + j) * (TILES * 64u) + lane;
+#pragma unroll
+                for (uint32_t t = 0; t < TILES; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[t * 64u]), bf, acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) bq[j] = bn[j];
+        }
+        {   // the bias k-step: B = {1, 1, 0, ...} on the k-half-0 lanes
+            const uint4 ones = make_uint4(h == 0 ? 0x3F803F80u : 0u, 0u, 0u, 0u);
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, ones);
+            const uint4 *al = head_lds + (uint64_t)ks * (TILES * 64u) + lane;
+#pragma unroll
+            for (uint32_t t = 0; t < TILES; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[t * 64u]), bf, acc[t], 0, 0, 0);
+        }
+        // acc[t][q] = logit of action 32 t + (q & 3) + 8 (q >> 2) + 4 h for env `env`; the last padded row is the value head
+        const float value = acc[TILES - 1][15];  // meaningful on the h = 1 lanes
+        if (h == 1) acc[TILES - 1][15] = HEAD_PAD_BIAS;
+        float m = -INF;
+#pragma unroll
+        for (uint32_t t = 0; t < TILES; ++t)
+#pragma unroll
+            for (uint32_t q = 0; q < 16; ++q) m = fmaxf(m, acc[t][q]);
+        m = fmaxf(m, head_xhalf(m));
+        const uint64_t base = rng_draw(a.seed, env, a.counter + clock_of(a.clock));
+        const uint32_t blo = (uint32_t)base, xb = (uint32_t)(base >> 32) + 4u * h * 0x9E3779B9u;  // hash input of this lane half's action 0
+        float best_q = INF, best_d = 0.0f, ssum = 0.0f, wsum = 0.0f;
+        uint32_t best_a = 0xFFFFFFFFu;
+#pragma unroll
+        for (uint32_t t = 0; t < TILES; ++t) {
+#pragma unroll
+            for (uint32_t q = 0; q < 16; ++q) {
+                const uint32_t act = 32u * t + (q & 3u) + 8u * (q >> 2) + 4u * h;
+                const float d = acc[t][q] - m;
+                const float ex = __expf(d);
+                ssum += ex;
+                wsum = __builtin_fmaf(ex, d, wsum);
+                uint32_t x = xb + (32u * t + (q & 3u) + 8u * (q >> 2)) * 0x9E3779B9u;  // sample_uniform(base, act) (kernels_collect.hip)
+                x ^= x >> 16;
+                x *= 0x7FEB352Du;
+                x ^= blo;
+                x ^= x >> 15;
+                x *= 0x846CA68Bu;
+                x ^= x >> 16;
+                const float u = ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f);
+                const float qv = -__logf(u) * __builtin_amdgcn_rcpf(ex);  // padding rows: ex = 0, q = inf, never wins
+                const bool take = qv < best_q;  // ascending action order within the lane: ties keep the lower index
+                best_q = take ? qv : best_q;
+                best_a = take ? act : best_a;
+                best_d = take ? d : best_d;
+            }
+        }
+        {   // the other lane half holds the other actions of this env
+            const float oq = head_xhalf(best_q), od = head_xhalf(best_d);
+            const uint32_t oa = __shfl_xor(best_a, 32, 64);
+            ssum += head_xhalf(ssum);
+            wsum += head_xhalf(wsum);
+            const bool take = oa != 0xFFFFFFFFu && (best_a == 0xFFFFFFFFu || oq < best_q || (oq == best_q && oa < best_a));
+            best_q = take ? oq : best_q;
+            best_a = take ? oa : best_a;
+            best_d = take ? od : best_d;
+        }
+        const float v_other = head_xhalf(value);
+        if (live && h == 0) {
+            const int64_t act = best_a == 0xFFFFFFFFu ? 0 : (int64_t)best_a;
+            if (a.act64) reinterpret_cast<int64_t *>(a.actions)[env] = act;
+            else reinterpret_cast<int32_t *>(a.actions)[env] = (int32_t)act;
+            const float log_s = logf(ssum);
+            if (a.logp) a.logp[env] = best_d - log_s;
+            if (a.entropy) a.entropy[env] = log_s - wsum / ssum;
+            if (a.values) a.values[env] = v_other;
+        }
+    }
+}
+
 }  // namespace qg
 
 using namespace qg;
@@ -399,6 +567,85 @@ int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint3
     default: return set_error(QG_ERR_UNSUPPORTED, "unexpected row-group count %u", G);
     }
 #undef QG_EMB_CASE
+    HIP_TRY(hipGetLastError());
+    return QG_OK;
+}
+
+size_t qg_policy_head_packed_bytes(uint32_t num_actions, uint32_t in_features) {
+    const uint32_t tiles = (num_actions + 1u + 31u) / 32u;
+    if (num_actions == 0 || tiles > 6 || in_features == 0 || in_features % 64u || in_features > 512u) return 0;
+    const size_t bytes = (size_t)(in_features / 16u + 1u) * tiles * 64u * 16u;
+    return bytes <= 144u * 1024u ? bytes : 0;
+}
+
+int qg_policy_pack_head(const void *weight_dev, const void *bias_dev, int dtype, uint64_t ld, uint32_t in_features, uint32_t num_actions,
+                        int32_t value_row, void *packed_dev, void *stream) {
+    if (!weight_dev || !packed_dev) return set_error(QG_ERR_INVALID, "null argument");
+    if (qg_policy_head_packed_bytes(num_actions, in_features) == 0)
+        return set_error(QG_ERR_UNSUPPORTED, "fused head: num_actions <= 190, in_features a multiple of 64 and <= 512, packed head <= 144 KiB");
+    if (ld < in_features) return set_error(QG_ERR_INVALID, "weight rows are shorter than in_features");
+    const uint32_t tiles = (num_actions + 1u + 31u) / 32u;
+    const uint64_t total = (uint64_t)(in_features / 16u + 1u) * tiles * 64u * 8u;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    __hip_bfloat16 *out = reinterpret_cast<__hip_bfloat16 *>(packed_dev);
+    switch (dtype) {
+    case QG_DT_F32:
+        hipLaunchKernelGGL(pack_head_kernel<float>, grid, block, 0, s, reinterpret_cast<const float *>(weight_dev), reinterpret_cast<const float *>(bias_dev), ld,
+                           in_features, num_actions, value_row, tiles, out);
+        break;
+    case QG_DT_BF16:
+        hipLaunchKernelGGL(pack_head_kernel<__hip_bfloat16>, grid, block, 0, s, reinterpret_cast<const __hip_bfloat16 *>(weight_dev),
+                           reinterpret_cast<const __hip_bfloat16 *>(bias_dev), ld, in_features, num_actions, value_row, tiles, out);
+        break;
+    default: return set_error(QG_ERR_INVALID, "weight dtype must be f32 or bf16");
+    }
+    HIP_TRY(hipGetLastError());
+    return QG_OK;
+}
+
+int qg_policy_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, uint32_t in_features, const void *packed_dev, uint32_t num_actions,
+                          uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev, int action_dtype, float *logp_dev,
+                          float *entropy_dev, float *values_dev, void *stream) {
+    if (!h_dev || !packed_dev || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
+    const size_t lds = qg_policy_head_packed_bytes(num_actions, in_features);
+    if (lds == 0) return set_error(QG_ERR_UNSUPPORTED, "fused head: num_actions <= 190, in_features a multiple of 64 and <= 512, packed head <= 144 KiB");
+    if (ld_h < in_features || (ld_h & 7u) || (reinterpret_cast<uintptr_t>(h_dev) & 15u))
+        return set_error(QG_ERR_INVALID, "activations must be 16-byte aligned bf16 rows with a stride that is a multiple of 8");
+    if (action_dtype != QG_ACT_I32 && action_dtype != QG_ACT_I64) return set_error(QG_ERR_INVALID, "bad action dtype");
+    if (batch == 0) return QG_OK;
+    HeadArgs a;
+    a.h = reinterpret_cast<const uint4 *>(h_dev);
+    a.wp = reinterpret_cast<const uint4 *>(packed_dev);
+    a.actions = actions_dev;
+    a.logp = logp_dev;
+    a.entropy = entropy_dev;
+    a.values = values_dev;
+    a.clock = clock_dev;
+    a.ld_h = ld_h;
+    a.B = batch;
+    a.seed = seed ^ 0x73616D70ull;  // the stream of qg_sample_actions
+    a.counter = counter;
+    a.K = in_features;
+    a.A = num_actions;
+    a.act64 = action_dtype == QG_ACT_I64;
+    const uint32_t tiles = (num_actions + 1u + 31u) / 32u;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint64_t env_tiles = (batch + 31u) / 32u, want = (env_tiles + HEAD_WAVES - 1) / HEAD_WAVES;
+    const dim3 grid((unsigned)(want < (uint64_t)cus ? want : (uint64_t)cus)), block(64 * HEAD_WAVES);
+    hipStream_t s = (hipStream_t)stream;
+#define QG_HEAD_CASE(TT)                                                                                                      \
+    case TT:                                                                                                                  \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(head_sample_kernel<TT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(head_sample_kernel<TT>, grid, block, lds, s, a);                                                   \
+        break;
+    switch (tiles) {
+        QG_HEAD_CASE(1) QG_HEAD_CASE(2) QG_HEAD_CASE(3) QG_HEAD_CASE(4) QG_HEAD_CASE(5) QG_HEAD_CASE(6)
+    default: return set_error(QG_ERR_UNSUPPORTED, "too many actions for the fused head");
+    }
+#undef QG_HEAD_CASE
     HIP_TRY(hipGetLastError());
     return QG_OK;
 }

@@ -144,3 +144,60 @@ def test_gae_is_bit_exact(T, B, with_last):
     want_adv, want_ret = gae_f32(r, v, d, lv, 0.995, 0.95)
     np.testing.assert_array_equal(f32_bits(adv.cpu().numpy()), f32_bits(want_adv))
     np.testing.assert_array_equal(f32_bits(ret.cpu().numpy()), f32_bits(want_ret))
+
+
+@pytest.mark.parametrize("A,K,B", [(170, 256, 3001), (12, 64, 500), (190, 128, 777), (33, 512, 64), (1, 64, 40)])
+def test_head_sample_is_the_race_on_its_own_logits(A, K, B):
+    """qg_policy_head_sample = last layer + qg_sample_actions in one kernel: the action is the winner of the same
+    exponential race on logits h W^T + b (f64 reference; bias carried as two bf16 terms), and log-prob / entropy /
+    value are those of that row."""
+    from qiskit_gym_amd.collector import head_sample, pack_head
+
+    seed, counter = 99, 5
+    g = torch.Generator(device="cuda")
+    g.manual_seed(A * 1000 + K)
+    h = (torch.randn((B, K), device="cuda", generator=g)).clamp_min(0).to(torch.bfloat16)
+    w = (torch.randn((A + 3, K), device="cuda", generator=g) * (2.0 / K**0.5)).to(torch.bfloat16)
+    b = torch.randn(A + 3, device="cuda", generator=g).to(torch.bfloat16)
+    value_row = A + 1  # any row of the matrix may be the value head
+    packed = pack_head(w, b, A, value_row)
+    acts, logp, ent, vals = head_sample(h, packed, A, seed, counter)
+    torch.cuda.synchronize()
+    full = (h.double() @ w.double().t() + b.double()).cpu().numpy()
+    logits = full[:, :A]
+    keys = race_keys(logits, sample_uniforms(seed, B, counter, A))
+    order = np.sort(keys, axis=1)
+    margin = order[:, 1] - order[:, 0] if A > 1 else np.full(B, np.inf)
+    got = acts.cpu().numpy()
+    clear = margin > 1e-3  # f32 MFMA accumulation vs f64: keys this close may swap
+    assert clear.mean() > 0.98
+    np.testing.assert_array_equal(got[clear], keys.argmin(axis=1)[clear])
+    assert ((got >= 0) & (got < A)).all()
+    lsm = log_softmax(logits)
+    np.testing.assert_allclose(logp.cpu().numpy(), lsm[np.arange(B), got], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(ent.cpu().numpy(), -(np.exp(lsm) * lsm).sum(axis=1), rtol=0, atol=2e-4)
+    np.testing.assert_allclose(vals.cpu().numpy(), full[:, value_row], rtol=0, atol=2e-4)
+    # f32 weights pack to the same thing as their bf16 rounding; int32 actions; reproducible; the counter matters
+    a32 = torch.empty(B, dtype=torch.int32, device="cuda")
+    head_sample(h, pack_head(w.float(), b.float(), A, value_row), A, seed, counter, actions=a32)
+    assert torch.equal(a32.long(), acts)
+    other, *_ = head_sample(h, packed, A, seed, counter + 1)
+    if A > 1:
+        assert not torch.equal(other, acts)
+
+
+def test_head_sample_follows_softmax():
+    """200k draws from one 6-way distribution through the fused head: chi-square against softmax."""
+    from qiskit_gym_amd.collector import head_sample, pack_head
+
+    B, K = 200_000, 64
+    row = torch.tensor([0.3, -1.2, 2.0, 0.0, 1.1, -3.0], device="cuda")
+    w = torch.zeros((7, K), device="cuda")
+    w[:6, 0] = row  # h = e_0: logits = row exactly
+    h = torch.zeros((B, K), dtype=torch.bfloat16, device="cuda")
+    h[:, 0] = 1.0
+    acts, *_ = head_sample(h, pack_head(w, None, 6, 6), 6, 42, 3)
+    counts = np.bincount(acts.cpu().numpy(), minlength=6).astype(np.float64)
+    p = torch.softmax(row.to(torch.bfloat16).double(), 0).cpu().numpy()
+    chi2 = ((counts - B * p) ** 2 / (B * p)).sum()
+    assert chi2 < 30.0, (chi2, counts, B * p)
