@@ -138,7 +138,7 @@ struct EmbWave {
 // of k-step s issue, the B fragments of s + 1 are read from LDS and its A fragments are expanded into a second
 // register set.  FIRST: the pass starts here, the accumulators start from C = 0.
 template <bool FIRST, typename F>
-__device__ __forceinline__ void emb_group(EmbWave &w, const uint4 (&cur)[EMB_MA], uint4 (&nxt)[EMB_MA], const uint4 *const (&pn)[EMB_MA],
+__device__ __forceinline__ void emb_group(EmbWave &w, const uint4 (&cur)[EMB_MA], uint4 (&nxt)[EMB_MA], const uint4 *(&pn)[EMB_MA],
                                           uint32_t pn_off, const uint4 *bl, uint32_t wrap, const uint32_t (&sh)[2], F &&after_loads) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -265,7 +265,9 @@ __global__ __launch_bounds__(EMB_THREADS, 1) void embed_bits_kernel(EmbedArgs a)
             };
             constexpr uint32_t none = 0u;
             const uint32_t gn = g + 1u < GP ? (g + 1u < G ? g + 1u : G - 1u) : 0u;  // the group fetched under this one
-            const uint4 *const pn[EMB_MA] = {g + 1u < GP ? pc[0] : pnx[0], g + 1u < GP ? pc[1] : pnx[1]};
+            const uint4 *pn[EMB_MA];
+#pragma unroll
+            for (uint32_t i = 0; i < EMB_MA; ++i) pn[i] = g + 1u < GP ? pc[i] : pnx[i];
             if (g & 1u) emb_group<false>(w, bufb, bufa, pn, gn * 64u, emb_lds + g * group_vec + lane, g + 1u < GP ? none : slab_vec, sh, stores);
             else if (g == 0) emb_group<true>(w, bufa, bufb, pn, gn * 64u, emb_lds + g * group_vec + lane, none, sh, stores);
             else emb_group<false>(w, bufa, bufb, pn, gn * 64u, emb_lds + g * group_vec + lane, none, sh, stores);
