@@ -19,5 +19,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
     # keep the step kernel's dispatches only (the file is large): header + rows of the dominant kernel
     if [ -n "$F" ]; then (head -1 "$F"; grep "qm_step1_kernel<16, true, false>" "$F") > "$OUT/pmc_$C.csv"; fi
 done
+# 4. the same kernel at 2^20 envs (kernel duration >> launch boundary): the kernel-trace average and bench.py's own
+#    per-launch figure agree there, which is the check that the 65 536-env gap is the profiler's per-dispatch serialisation
+cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/qg_prof/big -o bench --output-format csv -- python3 "$ROOT/bench.py" --envs 1048576 --steps 512 --warmup 64 --no-cpu-baseline --no-parity > "$OUT/bench_2p20_under_rocprof.json" 2> "$OUT/bench_2p20.err"
+cp /tmp/qg_prof/big/*kernel_stats.csv "$OUT/bench_2p20_kernel_stats.csv" 2>/dev/null
+cd "$ROOT" && python3 bench.py --envs 1048576 --steps 512 --warmup 64 --no-cpu-baseline --no-parity > "$OUT/bench_2p20.json" 2>> "$OUT/bench_2p20.err"
 cd "$ROOT" && python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 ls -la "$OUT"
