@@ -24,7 +24,7 @@ def test_collector_trajectories_replay_on_the_oracle(store_obs, dtype_name):
     torch.manual_seed(0)
     pol = BasicPolicy(4 * n * n, A, embedding_size=64, common=32)
     dtype = getattr(torch, dtype_name)
-    col = RolloutCollector(env, pol, dtype=dtype, seed=77, gamma=0.99, gae_lambda=0.9, store_obs=store_obs)
+    col = RolloutCollector(env, pol, dtype=dtype, seed=77, gamma=0.99, gae_lambda=0.9, store_obs=store_obs, use_bit_embedding=True, use_fused_head=True)
     # in bf16 the first layer reads the env's bit-packed state directly (qg_vec_embed), no dense policy input exists
     assert (col._embed is not None) == (dtype == torch.bfloat16)
     tol = 1e-4 if dtype == torch.float32 else 6e-2  # bf16 activations: 2^-8 relative per layer
@@ -143,7 +143,7 @@ def test_graph_replay_with_the_bit_consuming_first_layer():
     env = VecEnv("clifford", 6, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=3)
     torch.manual_seed(5)
     pol = BasicPolicy(144, len(gs), embedding_size=128, common=64)
-    col = RolloutCollector(env, pol, dtype=torch.bfloat16, seed=9, store_obs="packed", use_graph=True)
+    col = RolloutCollector(env, pol, dtype=torch.bfloat16, seed=9, store_obs="packed", use_graph=True, use_bit_embedding=True, use_fused_head=True)
     assert col._embed is not None
     for call in range(3):
         ro = col.collect(T)
