@@ -13,9 +13,11 @@
  *
  * PARITY PINNING: the reference cannot be compiled or imported here (no Rust toolchain, PyO3
  * module absent).  The oracle is pinned against the known-answer data the
- * reference ships (examples/intro.ipynb recorded outputs, examples/models/ JSON) -- see
- * tests/golden/ -- for gateset ordering, LinearFunction/Permutation/Clifford state transitions
- * and is_final.  Behaviour that depends on third-party crates absent from /root/reference
+ * reference ships (examples/intro.ipynb recorded outputs, examples/models/ JSON, and the three
+ * trained policies examples/models/ *.pt) -- see tests/golden/ -- for gateset ordering,
+ * LinearFunction/Permutation/Clifford state transitions and is_final; the trained policies, run
+ * greedily, solve random targets on this oracle (and on the HIP path) and fail on an env that
+ * differs in observation layout, action order or one gate's semantics (tests/test_reference_policies.py).  Behaviour that depends on third-party crates absent from /root/reference
  * (petgraph 0.6.5 `retain_nodes`/`remove_node` swap-remove order, nalgebra 0.33.2 `from_vec`
  * + `transpose`, twisterl 0.5.1 `Env` trait) is restated from their published algorithms and
  * is "parity unpinned": no reference test or fixture exercises it.

@@ -7,6 +7,8 @@ reference source text is copied):
 
   * examples/intro.ipynb  cells 3, 7, 10, 11, 12, 16, 24, 29, 35 (recorded outputs)
   * examples/models/{perm_square_3x3,lf_5_line,clifford_3q_custom}.json (env configs)
+  * examples/models/{perm_square_3x3,lf_5_line,clifford_3q_custom}.pt   (the trained policies the reference ships:
+    plain state dicts of tensors, read with torch.load(weights_only=True) and stored as float16 .npz under policies/)
 
 The reference has no tests; these notebook transcripts are the only
 executable-derived vectors that exist for this path.
@@ -43,7 +45,23 @@ def parse_gate_list(text):
     return [[name, [int(a), int(b)]] for name, a, b in re.findall(r"\('(\w+)', \((\d+), (\d+)\)\)", text)]
 
 
+def convert_policies():
+    """The reference's trained BasicPolicy checkpoints (embeddings / common.0 / action.0 / value.0, weight + bias) as
+    float16 arrays.  They are the strongest known-answer data the reference holds for this path: a policy trained
+    against the reference's env solves random targets only on an env with the same observation layout, action order,
+    gate semantics and solved test (tests/test_reference_policies.py)."""
+    import numpy as np
+    import torch
+
+    os.makedirs(os.path.join(OUT, "policies"), exist_ok=True)
+    for name in ("perm_square_3x3", "lf_5_line", "clifford_3q_custom"):
+        sd = torch.load(os.path.join(REF, "examples/models", name + ".pt"), map_location="cpu", weights_only=True)
+        arrays = {k.replace(".", "_"): v.numpy().astype(np.float16) for k, v in sd.items()}
+        np.savez_compressed(os.path.join(OUT, "policies", name + ".npz"), **arrays)
+
+
 def main():
+    convert_policies()
     nb = json.load(open(os.path.join(REF, "examples/intro.ipynb")))
 
     # ---- gateset orderings -------------------------------------------------------------
