@@ -125,3 +125,37 @@ def test_reference_clifford_policy_through_the_bit_consuming_first_layer():
         solved |= env.success.bool()
     env.sync()
     assert float(solved.float().mean()) >= 0.97
+
+
+@pytest.mark.parametrize("name", ["clifford_3q_custom", "lf_5_line"])
+def test_reference_value_heads_agree_with_the_reward_scheme(name):
+    """Soft evidence for the reward constants (metrics.rs:135-146 with the default weights: 0.0101 per CX): the trained
+    value head predicts the discounted return (gamma = 0.995) of the greedy rollout under the oracle's rewards to within
+    0.02 for states one to three gates from solved -- it would sit ~0.006 higher per CX under the older scheme the
+    notebook's printed rewards come from.  (The permutation checkpoint's value head does not
+    track the current SWAP penalty of 0.0303 and is left out.)"""
+    cfg, gateset, w = load(name)
+    A = len(gateset)
+
+    def value(o):
+        h = np.maximum(o @ w["embeddings_weight"].T + w["embeddings_bias"], 0)
+        h = np.maximum(h @ w["common_0_weight"].T + w["common_0_bias"], 0)
+        return (h @ w["value_0_weight"].T + w["value_0_bias"]).item()
+
+    for scramble in (1, 2, 3):
+        rng = np.random.default_rng(scramble)
+        vs, gs = [], []
+        for _ in range(60):
+            env = OracleEnv(MODELS[name], cfg["num_qubits"], gateset, add_inverts=0, add_perms=0, track_solution=0, difficulty=scramble)
+            env.reset_with(rng.integers(0, A, size=scramble))
+            if env.success():
+                continue
+            vs.append(value(env.dense_obs().reshape(-1).astype(np.float32)))
+            ret, disc, t = 0.0, 1.0, 0
+            while not env.success() and t < 20:
+                env.step(int(greedy(w, env.dense_obs().reshape(-1).astype(np.float32))))
+                ret += disc * env.reward()
+                disc *= 0.995
+                t += 1
+            gs.append(ret)
+        assert abs(np.mean(vs) - np.mean(gs)) < 0.02, (name, scramble, np.mean(vs), np.mean(gs))
