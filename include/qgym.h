@@ -302,11 +302,22 @@ int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint3
  * <= 144 KiB.  qg_policy_pack_head re-orders W ([rows, ld] f32 / bf16) and the bias ([rows], same dtype, or NULL)
  * into MFMA fragment order: rows 0..num_actions-1 are the actions, row value_row (>= 0, any index) the value head. */
 size_t qg_policy_head_packed_bytes(uint32_t num_actions, uint32_t in_features);
+/* after_mid != 0: pack for qg_policy_mid_head_sample (whose head fragments come out of an accumulator tile in a permuted k order) */
 int qg_policy_pack_head(const void *weight_dev, const void *bias_dev, int dtype, uint64_t ld, uint32_t in_features, uint32_t num_actions,
-                        int32_t value_row, void *packed_dev, void *stream);
+                        int32_t value_row, int after_mid, void *packed_dev, void *stream);
 int qg_policy_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, uint32_t in_features, const void *packed_dev, uint32_t num_actions,
                           uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev, int action_dtype, float *logp_dev,
                           float *entropy_dev, float *values_dev, void *stream);
+/* The layer before the head as well: h2 = relu(h W2^T + b2) (mid_features = 256 outputs, in_features % 32 == 0, <= 2048) feeds the head
+ * from registers -- with qg_vec_embed in front, the reference's default policy (rl/configs.py:531-607) runs forward and samples
+ * without a tensor library and without writing an observation, h2 or logits.  qg_policy_pack_mid packs W2 [mid_features, ld] / b2;
+ * the head must be packed with after_mid = 1. */
+size_t qg_policy_mid_packed_bytes(uint32_t in_features, uint32_t mid_features);
+int qg_policy_pack_mid(const void *weight_dev, const void *bias_dev, int dtype, uint64_t ld, uint32_t in_features, uint32_t mid_features,
+                       void *packed_dev, void *stream);
+int qg_policy_mid_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
+                              const void *packed_head_dev, uint32_t num_actions, uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev,
+                              int action_dtype, float *logp_dev, float *entropy_dev, float *values_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Scalar environment: the `Env` trait method for method (clifford.rs:285-382).

@@ -112,9 +112,10 @@ def embed(env: VecEnv, packed: torch.Tensor, bias: Optional[torch.Tensor], hidde
     return out
 
 
-def pack_head(weight: torch.Tensor, bias: Optional[torch.Tensor], num_actions: int, value_row: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Last-layer weight [rows, in_features] (+ bias [rows]; f32 or bf16, same dtype) in the order `head_sample` consumes:
-    rows 0..num_actions-1 are the actions, row `value_row` the value head (`qg_policy_pack_head`)."""
+def pack_head(weight: torch.Tensor, bias: Optional[torch.Tensor], num_actions: int, value_row: int, out: Optional[torch.Tensor] = None,
+              after_mid: bool = False) -> torch.Tensor:
+    """Last-layer weight [rows, in_features] (+ bias [rows]; f32 or bf16, same dtype) in the order `head_sample` (or, with
+    after_mid, `mid_head_sample`) consumes: rows 0..num_actions-1 are the actions, row `value_row` the value head (`qg_policy_pack_head`)."""
     L = _lib.load()
     nbytes = L.qg_policy_head_packed_bytes(num_actions, weight.shape[1])
     if nbytes == 0:
@@ -124,8 +125,41 @@ def pack_head(weight: torch.Tensor, bias: Optional[torch.Tensor], num_actions: i
     if out is None:
         out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=weight.device)
     _lib.check(L.qg_policy_pack_head(weight.data_ptr(), bias.data_ptr() if bias is not None else None, _DT[weight.dtype], weight.stride(0), weight.shape[1],
-                                     int(num_actions), int(value_row), out.data_ptr(), _stream_ptr()))
+                                     int(num_actions), int(value_row), int(after_mid), out.data_ptr(), _stream_ptr()))
     return out
+
+
+def pack_mid(weight: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Middle-layer weight [256, in_features] (+ bias) in the order `mid_head_sample` consumes (`qg_policy_pack_mid`)."""
+    L = _lib.load()
+    nbytes = L.qg_policy_mid_packed_bytes(weight.shape[1], weight.shape[0])
+    if nbytes == 0:
+        raise ValueError("fused middle layer needs 256 output features and in_features % 32 == 0, <= 2048")
+    if weight.stride(1) != 1 or (bias is not None and (bias.dtype != weight.dtype or not bias.is_contiguous())):
+        raise ValueError("weight must have unit column stride; bias contiguous and of the same dtype")
+    if out is None:
+        out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=weight.device)
+    _lib.check(L.qg_policy_pack_mid(weight.data_ptr(), bias.data_ptr() if bias is not None else None, _DT[weight.dtype], weight.stride(0), weight.shape[1],
+                                    weight.shape[0], out.data_ptr(), _stream_ptr()))
+    return out
+
+
+def mid_head_sample(h: torch.Tensor, packed_mid: torch.Tensor, mid_features: int, packed_head: torch.Tensor, num_actions: int, seed: int, counter: int,
+                    actions: Optional[torch.Tensor] = None, logp: Optional[torch.Tensor] = None, entropy: Optional[torch.Tensor] = None,
+                    values: Optional[torch.Tensor] = None, clock: Optional[torch.Tensor] = None):
+    """relu(h W2^T + b2) -> last layer -> categorical draw in one kernel (`qg_policy_mid_head_sample`); the head packed with after_mid=True."""
+    if h.dim() != 2 or h.dtype != torch.bfloat16 or h.stride(1) != 1:
+        raise ValueError("h must be bf16 [B, in_features] with unit column stride")
+    B, dev = h.shape[0], h.device
+    actions = torch.empty(B, dtype=torch.int64, device=dev) if actions is None else actions
+    logp = torch.empty(B, dtype=torch.float32, device=dev) if logp is None else logp
+    entropy = torch.empty(B, dtype=torch.float32, device=dev) if entropy is None else entropy
+    values = torch.empty(B, dtype=torch.float32, device=dev) if values is None else values
+    act_dt = {torch.int32: _lib.ACT_I32, torch.int64: _lib.ACT_I64}[actions.dtype]
+    _lib.check(_lib.load().qg_policy_mid_head_sample(h.data_ptr(), h.stride(0), B, h.shape[1], packed_mid.data_ptr(), int(mid_features), packed_head.data_ptr(),
+                                                     int(num_actions), int(seed) & (2**64 - 1), int(counter), clock.data_ptr() if clock is not None else None,
+                                                     actions.data_ptr(), act_dt, logp.data_ptr(), entropy.data_ptr(), values.data_ptr(), _stream_ptr()))
+    return actions, logp, entropy, values
 
 
 def head_sample(h: torch.Tensor, packed: torch.Tensor, num_actions: int, seed: int, counter: int, actions: Optional[torch.Tensor] = None,
@@ -257,14 +291,19 @@ class RolloutCollector:
                     self._embed = None  # layouts without the bit-consuming kernel keep the dense first layer
         self._h1 = None
         self._head = None  # packed last layer for the fused head + sampling kernel (bf16 BasicPolicy within its limits)
+        self._mid = None   # packed middle layer: then middle layer + head + sampling are ONE kernel and only the first layer stays outside
         if self._heads is not None and dtype == torch.bfloat16 and use_fused_head:
             w, b, A = self._heads
             try:
-                self._head = pack_head(w, b, A, A)
+                try:
+                    self._mid = pack_mid(self.policy.common.weight, self.policy.common.bias)
+                except ValueError:
+                    self._mid = None
+                self._head = pack_head(w, b, A, A, after_mid=self._mid is not None)
                 self._scratch_actions = torch.empty(env.batch, dtype=torch.int64, device=env.device)
                 self._scratch_f32 = torch.empty((3, env.batch), dtype=torch.float32, device=env.device)
             except ValueError:
-                self._head = None
+                self._head = self._mid = None
         self._graph = None
         self._graph_T = 0
         self._graph_ro: Optional[Rollout] = None
@@ -318,18 +357,31 @@ class RolloutCollector:
             pack_embedding(self.env, pol.embeddings.weight, out=self._embed[0])
             self._embed[1].copy_(pol.embeddings.bias)
         if self._head is not None:
-            pack_head(w, b, A, A, out=self._head)
+            pack_head(w, b, A, A, out=self._head, after_mid=self._mid is not None)
+        if self._mid is not None:
+            pack_mid(pol.common.weight, pol.common.bias, out=self._mid)
 
-    def _body_layers(self) -> torch.Tensor:
-        """The two hidden layers: [B, common] activations."""
+    def _first_layer(self) -> torch.Tensor:
         pol = self.policy
         if self._embed is not None:
             if self._h1 is None:
                 self._h1 = torch.empty((self.env.batch, pol.embeddings.out_features), dtype=self.dtype, device=self.env.device)
-            h = embed(self.env, self._embed[0], self._embed[1], pol.embeddings.out_features, relu=True, out=self._h1)
+            return embed(self.env, self._embed[0], self._embed[1], pol.embeddings.out_features, relu=True, out=self._h1)
+        return _linear_relu(self._x, pol.embeddings.weight, pol.embeddings.bias)
+
+    def _fused_tail(self, counter: int, actions, logp, entropy, values, clock):
+        """Everything after the first layer in one kernel (or, without the packed middle layer, GEMM + head kernel)."""
+        A = self._heads[2]
+        if self._mid is not None:
+            mid_head_sample(self._first_layer(), self._mid, self.policy.common.out_features, self._head, A, self.seed, counter, actions=actions, logp=logp,
+                            entropy=entropy, values=values, clock=clock)
         else:
-            h = _linear_relu(self._x, pol.embeddings.weight, pol.embeddings.bias)
-        return _linear_relu(h, pol.common.weight, pol.common.bias)
+            head_sample(self._body_layers(), self._head, A, self.seed, counter, actions=actions, logp=logp, entropy=entropy, values=values, clock=clock)
+
+    def _body_layers(self) -> torch.Tensor:
+        """The two hidden layers: [B, common] activations."""
+        pol = self.policy
+        return _linear_relu(self._first_layer(), pol.common.weight, pol.common.bias)
 
     def _trunk(self) -> torch.Tensor:
         """Fused-head forward of the current observation: [B, pad8(A + 1)], column A is the value."""
@@ -337,9 +389,8 @@ class RolloutCollector:
         return torch.addmm(b, self._body_layers(), w.t())
 
     def _forward_sample(self, ro: Rollout, t: int):
-        if self._head is not None:  # last layer + draw in one kernel, the logits never reach memory
-            head_sample(self._body_layers(), self._head, self._heads[2], self.seed, t, actions=ro.actions[t], logp=ro.logp[t],
-                        entropy=ro.entropy[t], values=ro.values[t], clock=self.clock)
+        if self._head is not None:  # (middle layer +) last layer + draw in one kernel, h2 / the logits never reach memory
+            self._fused_tail(t, ro.actions[t], ro.logp[t], ro.entropy[t], ro.values[t], self.clock)
             return
         if self._heads is not None:
             A = self._heads[2]
@@ -354,8 +405,7 @@ class RolloutCollector:
         if self._embed is None:
             self.env.observe_as(self.dtype, out=self._x)
         if self._head is not None:  # the fused kernel's value output (its draw is discarded)
-            head_sample(self._body_layers(), self._head, self._heads[2], self.seed, 0, actions=self._scratch_actions, logp=self._scratch_f32[0],
-                        entropy=self._scratch_f32[1], values=self._scratch_f32[2])
+            self._fused_tail(0, self._scratch_actions, self._scratch_f32[0], self._scratch_f32[1], self._scratch_f32[2], None)
             return self._scratch_f32[2]
         if self._heads is not None:
             return self._trunk()[:, self._heads[2]].float()

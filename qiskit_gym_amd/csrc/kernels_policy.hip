@@ -342,12 +342,14 @@ constexpr float HEAD_PAD_BIAS = -1.0e30f;
 
 // Packed head: [k-step s <= K/16][tile t][lane][8] bf16; lane (r, h) element e of k-step s < K/16 = W[row(32t + r)][16s + 8h + e];
 // k-step K/16: element 0 / 1 of the h = 0 lanes = bias hi / lo.  row(p) = p for p < A, value_row for p = 32 tiles - 1, else padding.
+// xorder: the k order of a fragment built from an MFMA accumulator tile (mid_head_sample_kernel): element e of lane half h in
+// k-step s is feature 32 (s >> 1) + 16 (s & 1) + 8 (e >> 2) + 4 h + (e & 3).  ks_total >= K/16 + 1 k-steps are written (zeros past the bias step).
 template <typename WT>
 __global__ __launch_bounds__(256) void pack_head_kernel(const WT *w, const WT *bias, uint64_t ld, uint32_t K, uint32_t A, int32_t value_row,
-                                                        uint32_t tiles, __hip_bfloat16 *out) {
+                                                        uint32_t tiles, uint32_t xorder, uint32_t ks_total, __hip_bfloat16 *out) {
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t ks = K / 16u;
-    const uint64_t total = (uint64_t)(ks + 1u) * tiles * 64u * 8u;
+    const uint64_t total = (uint64_t)ks_total * tiles * 64u * 8u;
     if (idx >= total) return;
     const uint32_t e = (uint32_t)idx & 7u, lane = (uint32_t)(idx >> 3) & 63u;
     const uint32_t st = (uint32_t)(idx >> 9), t = st % tiles, s = st / tiles;
@@ -355,8 +357,9 @@ __global__ __launch_bounds__(256) void pack_head_kernel(const WT *w, const WT *b
     const int32_t src = p < A ? (int32_t)p : (p == 32u * tiles - 1u ? value_row : -1);
     float v = 0.0f;
     if (s < ks) {
-        if (src >= 0) v = (float)w[(uint64_t)src * ld + 16u * s + 8u * h + e];
-    } else if (h == 0 && e < 2) {
+        const uint32_t k = xorder ? 32u * (s >> 1) + 16u * (s & 1u) + 8u * (e >> 2) + 4u * h + (e & 3u) : 16u * s + 8u * h + e;
+        if (src >= 0) v = (float)w[(uint64_t)src * ld + k];
+    } else if (s == ks && h == 0 && e < 2) {
         const float b = src >= 0 ? (bias ? (float)bias[src] : 0.0f) : HEAD_PAD_BIAS;
         const float hi = __bfloat162float(__float2bfloat16(b));
         v = e == 0 ? hi : b - hi;
@@ -378,6 +381,70 @@ struct HeadArgs {
 
 __device__ __forceinline__ float head_xhalf(float x) { return __shfl_xor(x, 32, 64); }
 
+// The draw from register-resident logits: acc[t][q] = logit of action 32 t + (q & 3) + 8 (q >> 2) + 4 h of env `env` (C layout of the
+// transposed product), the last padded row is the value head.  Same race as qg_sample_actions (kernels_collect.hip).
+template <uint32_t TILES>
+__device__ __forceinline__ void head_draw(f32x16 (&acc)[TILES], const HeadArgs &a, uint64_t env, bool live, uint32_t h) {
+    const float INF = __builtin_huge_valf();
+    // acc[t][q] = logit of action 32 t + (q & 3) + 8 (q >> 2) + 4 h for env `env`; the last padded row is the value head
+    const float value = acc[TILES - 1][15];  // meaningful on the h = 1 lanes
+    if (h == 1) acc[TILES - 1][15] = HEAD_PAD_BIAS;
+    float m = -INF;
+#pragma unroll
+    for (uint32_t t = 0; t < TILES; ++t)
+#pragma unroll
+        for (uint32_t q = 0; q < 16; ++q) m = fmaxf(m, acc[t][q]);
+    m = fmaxf(m, head_xhalf(m));
+    const uint64_t base = rng_draw(a.seed, env, a.counter + clock_of(a.clock));
+    const uint32_t blo = (uint32_t)base, xb = (uint32_t)(base >> 32) + 4u * h * 0x9E3779B9u;  // hash input of this lane half's action 0
+    float best_q = INF, best_d = 0.0f, ssum = 0.0f, wsum = 0.0f;
+    uint32_t best_a = 0xFFFFFFFFu;
+#pragma unroll
+    for (uint32_t t = 0; t < TILES; ++t) {
+#pragma unroll
+        for (uint32_t q = 0; q < 16; ++q) {
+            const uint32_t act = 32u * t + (q & 3u) + 8u * (q >> 2) + 4u * h;
+            const float d = acc[t][q] - m;
+            const float ex = __expf(d);
+            ssum += ex;
+            wsum = __builtin_fmaf(ex, d, wsum);
+            uint32_t x = xb + (32u * t + (q & 3u) + 8u * (q >> 2)) * 0x9E3779B9u;  // sample_uniform(base, act) (kernels_collect.hip)
+            x ^= x >> 16;
+            x *= 0x7FEB352Du;
+            x ^= blo;
+            x ^= x >> 15;
+            x *= 0x846CA68Bu;
+            x ^= x >> 16;
+            const float u = ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f);
+            const float qv = -__logf(u) * __builtin_amdgcn_rcpf(ex);  // padding rows: ex = 0, q = inf, never wins
+            const bool take = qv < best_q;  // ascending action order within the lane: ties keep the lower index
+            best_q = take ? qv : best_q;
+            best_a = take ? act : best_a;
+            best_d = take ? d : best_d;
+        }
+    }
+    {   // the other lane half holds the other actions of this env
+        const float oq = head_xhalf(best_q), od = head_xhalf(best_d);
+        const uint32_t oa = __shfl_xor(best_a, 32, 64);
+        ssum += head_xhalf(ssum);
+        wsum += head_xhalf(wsum);
+        const bool take = oa != 0xFFFFFFFFu && (best_a == 0xFFFFFFFFu || oq < best_q || (oq == best_q && oa < best_a));
+        best_q = take ? oq : best_q;
+        best_a = take ? oa : best_a;
+        best_d = take ? od : best_d;
+    }
+    const float v_other = head_xhalf(value);
+    if (live && h == 0) {
+        const int64_t act = best_a == 0xFFFFFFFFu ? 0 : (int64_t)best_a;
+        if (a.act64) reinterpret_cast<int64_t *>(a.actions)[env] = act;
+        else reinterpret_cast<int32_t *>(a.actions)[env] = (int32_t)act;
+        const float log_s = logf(ssum);
+        if (a.logp) a.logp[env] = best_d - log_s;
+        if (a.entropy) a.entropy[env] = log_s - wsum / ssum;
+        if (a.values) a.values[env] = v_other;
+    }
+}
+
 template <uint32_t TILES>
 __global__ __launch_bounds__(64 * HEAD_WAVES, 1) void head_sample_kernel(HeadArgs a) {
     extern __shared__ uint4 head_lds[];  // packed head: [(K/16 + 1)][TILES][64]
@@ -392,7 +459,6 @@ __global__ __launch_bounds__(64 * HEAD_WAVES, 1) void head_sample_kernel(HeadArg
     const uint64_t row_vec = a.ld_h / 8u;  // uint4 per row of h
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const float INF = __builtin_huge_valf();
     for (uint64_t tile = (uint64_t)blockIdx.x * HEAD_WAVES + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * HEAD_WAVES) {
         const uint64_t env_raw = tile * 32u + c;
         const bool live = env_raw < a.B;
@@ -430,63 +496,129 @@ __global__ __launch_bounds__(64 * HEAD_WAVES, 1) void head_sample_kernel(HeadArg
             for (uint32_t t = 0; t < TILES; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[t * 64u]), bf, acc[t], 0, 0, 0);
         }
-        // acc[t][q] = logit of action 32 t + (q & 3) + 8 (q >> 2) + 4 h for env `env`; the last padded row is the value head
-        const float value = acc[TILES - 1][15];  // meaningful on the h = 1 lanes
-        if (h == 1) acc[TILES - 1][15] = HEAD_PAD_BIAS;
-        float m = -INF;
+        head_draw<TILES>(acc, a, env, live, h);
+    }
+}
+
+
+// =================================================================================================
+// Middle layer + head + draw in one kernel: h2 = relu(h1 W2^T + b2) never leaves the registers either.
+//
+// Both products are computed transposed.  X = W2 h1^T: A operand = a 32-feature tile of W2 (LDS), B operand = 32 envs of
+// h1 (16 B per lane from global memory); the accumulator tile X[t] then has its 32 features in the registers and the
+// env on the lane -- exactly what the head's B operand needs, because the head sums over the features (the guide's
+// "accumulator tile as the next MFMA's operand": registers 8s..8s+7 packed to bf16 are the fragment of k-step 2t + s,
+// in a permuted k order that the head's packed weights follow, `xorder` above).  W2 (256 x 512 bf16 = 256 KiB) does
+// not fit beside the head: it streams through two 16 KiB LDS buffers, two k-steps per chunk, shared by the
+// workgroup's 8 waves (one barrier per chunk); the head (<= 102 KiB) stays resident.  Biases ride in extra k-steps.
+// =================================================================================================
+constexpr uint32_t MID_FT = 8;        // 32-feature tiles of the middle layer (256 features)
+constexpr uint32_t MID_CHUNK = 2;     // k-steps per streamed chunk
+
+struct MidHeadArgs {
+    HeadArgs head;         // head.h = h1, head.ld_h its stride, head.K = features of the middle layer (256), head.wp = packed head (xorder)
+    const uint4 *w2p;      // packed middle layer: [K1/16 + 2 k-steps][MID_FT][64]
+    uint32_t K1;           // in_features of the middle layer
+};
+
+template <uint32_t TILES>
+__global__ __launch_bounds__(64 * HEAD_WAVES, 1) void mid_head_sample_kernel(MidHeadArgs ma) {
+    extern __shared__ uint4 mh_lds[];  // [head: (K2/16 + 1) x TILES x 64][2 chunk buffers: MID_CHUNK x MID_FT x 64]
+    const HeadArgs &a = ma.head;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t ks2 = a.K / 16u;                       // head k-steps (= 2 MID_FT)
+    const uint32_t head_vec = (ks2 + 1u) * TILES * 64u;
+    constexpr uint32_t chunk_vec = MID_CHUNK * MID_FT * 64u;
+    uint4 *const cbuf = mh_lds + head_vec;
+    const uint32_t n_chunks = ma.K1 / (16u * MID_CHUNK) + 1u;  // the last chunk is {bias k-step, zero k-step}
+    for (uint32_t c = wave * 64u; c < head_vec; c += 64u * HEAD_WAVES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.wp + c + lane),
+                                         (__attribute__((address_space(3))) void *)(mh_lds + c), 16, 0, 0);
+    auto stage = [&](uint32_t chunk) {  // chunk -> buffer chunk & 1: 16 KiB = 2 wave-instructions per wave
+        const uint4 *src = ma.w2p + (uint64_t)chunk * chunk_vec;
+        uint4 *dst = cbuf + (chunk & 1u) * chunk_vec;
+        for (uint32_t c = wave * 64u; c < chunk_vec; c += 64u * HEAD_WAVES)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + c + lane),
+                                             (__attribute__((address_space(3))) void *)(dst + c), 16, 0, 0);
+    };
+    const uint32_t c = lane & 31u, h = lane >> 5;
+    const uint64_t n_tiles = (a.B + 31u) / 32u;
+    const uint64_t row_vec = a.ld_h / 8u;
+    const uint64_t tiles_per_trip = (uint64_t)gridDim.x * HEAD_WAVES;
+    const uint4 ones = make_uint4(h == 0 ? 0x3F803F80u : 0u, 0u, 0u, 0u), zeros = make_uint4(0u, 0u, 0u, 0u);
+    // every wave of the workgroup takes part in every trip (the chunk barriers): waves past the last tile compute on a clamped env
+    for (uint64_t tile0 = (uint64_t)blockIdx.x * HEAD_WAVES; tile0 < n_tiles; tile0 += tiles_per_trip) {
+        const uint64_t env_raw = (tile0 + wave) * 32u + c;
+        const bool live = env_raw < a.B;
+        const uint64_t env = live ? env_raw : a.B - 1;
+        const uint4 *hrow = a.h + env * row_vec + h;
+        stage(0);
+        uint4 bq[MID_CHUNK], bn[MID_CHUNK];
+#pragma unroll
+        for (uint32_t j = 0; j < MID_CHUNK; ++j) bq[j] = hrow[2u * j];
+        f32x16 x[MID_FT];
+#pragma unroll
+        for (uint32_t t = 0; t < MID_FT; ++t)
+#pragma unroll
+            for (uint32_t q = 0; q < 16; ++q) x[t][q] = 0.0f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (uint32_t ch = 0; ch < n_chunks; ++ch) {
+            if (ch + 1u < n_chunks) {
+                stage(ch + 1u);  // its buffer was last read in chunk ch - 1, which every wave left through the barrier below
+                if (ch + 2u < n_chunks) {
+#pragma unroll
+                    for (uint32_t j = 0; j < MID_CHUNK; ++j) bn[j] = hrow[2u * ((ch + 1u) * MID_CHUNK + j)];
+                } else {
+                    bn[0] = ones;
+                    bn[1] = zeros;
+                }
+            }
+            const uint4 *al = cbuf + (ch & 1u) * chunk_vec + lane;
+#pragma unroll
+            for (uint32_t j = 0; j < MID_CHUNK; ++j) {
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, bq[j]);
+#pragma unroll
+                for (uint32_t t = 0; t < MID_FT; ++t)
+                    x[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[(j * MID_FT + t) * 64u]), bf, x[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < MID_CHUNK; ++j) bq[j] = bn[j];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        // ReLU, bf16, and the tiles become the head's B fragments: registers 8s..8s+7 of tile t = k-step 2t + s
+        f32x16 acc[TILES];
 #pragma unroll
         for (uint32_t t = 0; t < TILES; ++t)
 #pragma unroll
-            for (uint32_t q = 0; q < 16; ++q) m = fmaxf(m, acc[t][q]);
-        m = fmaxf(m, head_xhalf(m));
-        const uint64_t base = rng_draw(a.seed, env, a.counter + clock_of(a.clock));
-        const uint32_t blo = (uint32_t)base, xb = (uint32_t)(base >> 32) + 4u * h * 0x9E3779B9u;  // hash input of this lane half's action 0
-        float best_q = INF, best_d = 0.0f, ssum = 0.0f, wsum = 0.0f;
-        uint32_t best_a = 0xFFFFFFFFu;
+            for (uint32_t q = 0; q < 16; ++q) acc[t][q] = 0.0f;
 #pragma unroll
-        for (uint32_t t = 0; t < TILES; ++t) {
+        for (uint32_t t = 0; t < MID_FT; ++t) {
 #pragma unroll
-            for (uint32_t q = 0; q < 16; ++q) {
-                const uint32_t act = 32u * t + (q & 3u) + 8u * (q >> 2) + 4u * h;
-                const float d = acc[t][q] - m;
-                const float ex = __expf(d);
-                ssum += ex;
-                wsum = __builtin_fmaf(ex, d, wsum);
-                uint32_t x = xb + (32u * t + (q & 3u) + 8u * (q >> 2)) * 0x9E3779B9u;  // sample_uniform(base, act) (kernels_collect.hip)
-                x ^= x >> 16;
-                x *= 0x7FEB352Du;
-                x ^= blo;
-                x ^= x >> 15;
-                x *= 0x846CA68Bu;
-                x ^= x >> 16;
-                const float u = ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f);
-                const float qv = -__logf(u) * __builtin_amdgcn_rcpf(ex);  // padding rows: ex = 0, q = inf, never wins
-                const bool take = qv < best_q;  // ascending action order within the lane: ties keep the lower index
-                best_q = take ? qv : best_q;
-                best_a = take ? act : best_a;
-                best_d = take ? d : best_d;
+            for (uint32_t s = 0; s < 2; ++s) {
+                u32x4 f;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const f32x2 v = {__builtin_amdgcn_fmed3f(x[t][8u * s + 2u * j], 0.0f, __builtin_inff()),
+                                     __builtin_amdgcn_fmed3f(x[t][8u * s + 2u * j + 1u], 0.0f, __builtin_inff())};
+                    f[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+                }
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, f);
+                const uint4 *al = mh_lds + (uint64_t)(2u * t + s) * (TILES * 64u) + lane;
+#pragma unroll
+                for (uint32_t tt = 0; tt < TILES; ++tt)
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[tt * 64u]), bf, acc[tt], 0, 0, 0);
             }
         }
-        {   // the other lane half holds the other actions of this env
-            const float oq = head_xhalf(best_q), od = head_xhalf(best_d);
-            const uint32_t oa = __shfl_xor(best_a, 32, 64);
-            ssum += head_xhalf(ssum);
-            wsum += head_xhalf(wsum);
-            const bool take = oa != 0xFFFFFFFFu && (best_a == 0xFFFFFFFFu || oq < best_q || (oq == best_q && oa < best_a));
-            best_q = take ? oq : best_q;
-            best_a = take ? oa : best_a;
-            best_d = take ? od : best_d;
+        {   // the head's bias k-step
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, ones);
+            const uint4 *al = mh_lds + (uint64_t)ks2 * (TILES * 64u) + lane;
+#pragma unroll
+            for (uint32_t tt = 0; tt < TILES; ++tt)
+                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[tt * 64u]), bf, acc[tt], 0, 0, 0);
         }
-        const float v_other = head_xhalf(value);
-        if (live && h == 0) {
-            const int64_t act = best_a == 0xFFFFFFFFu ? 0 : (int64_t)best_a;
-            if (a.act64) reinterpret_cast<int64_t *>(a.actions)[env] = act;
-            else reinterpret_cast<int32_t *>(a.actions)[env] = (int32_t)act;
-            const float log_s = logf(ssum);
-            if (a.logp) a.logp[env] = best_d - log_s;
-            if (a.entropy) a.entropy[env] = log_s - wsum / ssum;
-            if (a.values) a.values[env] = v_other;
-        }
+        head_draw<TILES>(acc, a, env, live, h);
     }
 }
 
@@ -580,30 +712,49 @@ size_t qg_policy_head_packed_bytes(uint32_t num_actions, uint32_t in_features) {
     return bytes <= 144u * 1024u ? bytes : 0;
 }
 
-int qg_policy_pack_head(const void *weight_dev, const void *bias_dev, int dtype, uint64_t ld, uint32_t in_features, uint32_t num_actions,
-                        int32_t value_row, void *packed_dev, void *stream) {
-    if (!weight_dev || !packed_dev) return set_error(QG_ERR_INVALID, "null argument");
-    if (qg_policy_head_packed_bytes(num_actions, in_features) == 0)
-        return set_error(QG_ERR_UNSUPPORTED, "fused head: num_actions <= 190, in_features a multiple of 64 and <= 512, packed head <= 144 KiB");
-    if (ld < in_features) return set_error(QG_ERR_INVALID, "weight rows are shorter than in_features");
-    const uint32_t tiles = (num_actions + 1u + 31u) / 32u;
-    const uint64_t total = (uint64_t)(in_features / 16u + 1u) * tiles * 64u * 8u;
+static int pack_rows_impl(const void *weight_dev, const void *bias_dev, int dtype, uint64_t ld, uint32_t in_features, uint32_t rows,
+                          int32_t value_row, uint32_t tiles, uint32_t xorder, uint32_t ks_total, void *packed_dev, hipStream_t s) {
+    const uint64_t total = (uint64_t)ks_total * tiles * 64u * 8u;
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    hipStream_t s = (hipStream_t)stream;
     __hip_bfloat16 *out = reinterpret_cast<__hip_bfloat16 *>(packed_dev);
     switch (dtype) {
     case QG_DT_F32:
         hipLaunchKernelGGL(pack_head_kernel<float>, grid, block, 0, s, reinterpret_cast<const float *>(weight_dev), reinterpret_cast<const float *>(bias_dev), ld,
-                           in_features, num_actions, value_row, tiles, out);
+                           in_features, rows, value_row, tiles, xorder, ks_total, out);
         break;
     case QG_DT_BF16:
         hipLaunchKernelGGL(pack_head_kernel<__hip_bfloat16>, grid, block, 0, s, reinterpret_cast<const __hip_bfloat16 *>(weight_dev),
-                           reinterpret_cast<const __hip_bfloat16 *>(bias_dev), ld, in_features, num_actions, value_row, tiles, out);
+                           reinterpret_cast<const __hip_bfloat16 *>(bias_dev), ld, in_features, rows, value_row, tiles, xorder, ks_total, out);
         break;
     default: return set_error(QG_ERR_INVALID, "weight dtype must be f32 or bf16");
     }
     HIP_TRY(hipGetLastError());
     return QG_OK;
+}
+
+int qg_policy_pack_head(const void *weight_dev, const void *bias_dev, int dtype, uint64_t ld, uint32_t in_features, uint32_t num_actions,
+                        int32_t value_row, int after_mid, void *packed_dev, void *stream) {
+    if (!weight_dev || !packed_dev) return set_error(QG_ERR_INVALID, "null argument");
+    if (qg_policy_head_packed_bytes(num_actions, in_features) == 0)
+        return set_error(QG_ERR_UNSUPPORTED, "fused head: num_actions <= 190, in_features a multiple of 64 and <= 512, packed head <= 144 KiB");
+    if (ld < in_features) return set_error(QG_ERR_INVALID, "weight rows are shorter than in_features");
+    const uint32_t tiles = (num_actions + 1u + 31u) / 32u;
+    return pack_rows_impl(weight_dev, bias_dev, dtype, ld, in_features, num_actions, value_row, tiles, after_mid ? 1u : 0u, in_features / 16u + 1u, packed_dev,
+                          (hipStream_t)stream);
+}
+
+size_t qg_policy_mid_packed_bytes(uint32_t in_features, uint32_t mid_features) {
+    if (mid_features != 32u * MID_FT || in_features == 0 || in_features % (16u * MID_CHUNK) || in_features > 2048u) return 0;
+    return (size_t)(in_features / 16u + MID_CHUNK) * MID_FT * 64u * 16u;
+}
+
+int qg_policy_pack_mid(const void *weight_dev, const void *bias_dev, int dtype, uint64_t ld, uint32_t in_features, uint32_t mid_features,
+                       void *packed_dev, void *stream) {
+    if (!weight_dev || !packed_dev) return set_error(QG_ERR_INVALID, "null argument");
+    if (qg_policy_mid_packed_bytes(in_features, mid_features) == 0)
+        return set_error(QG_ERR_UNSUPPORTED, "fused middle layer: 256 output features, in_features a multiple of 32 and <= 2048");
+    if (ld < in_features) return set_error(QG_ERR_INVALID, "weight rows are shorter than in_features");
+    return pack_rows_impl(weight_dev, bias_dev, dtype, ld, in_features, mid_features, -1, MID_FT, 0u, in_features / 16u + MID_CHUNK, packed_dev, (hipStream_t)stream);
 }
 
 int qg_policy_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, uint32_t in_features, const void *packed_dev, uint32_t num_actions,
@@ -648,6 +799,58 @@ int qg_policy_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, uint
     default: return set_error(QG_ERR_UNSUPPORTED, "too many actions for the fused head");
     }
 #undef QG_HEAD_CASE
+    HIP_TRY(hipGetLastError());
+    return QG_OK;
+}
+
+int qg_policy_mid_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
+                              const void *packed_head_dev, uint32_t num_actions, uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev,
+                              int action_dtype, float *logp_dev, float *entropy_dev, float *values_dev, void *stream) {
+    if (!h_dev || !packed_mid_dev || !packed_head_dev || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
+    const size_t head_bytes = qg_policy_head_packed_bytes(num_actions, mid_features);
+    if (head_bytes == 0 || qg_policy_mid_packed_bytes(in_features, mid_features) == 0)
+        return set_error(QG_ERR_UNSUPPORTED, "fused middle layer + head: 256 middle features, in_features a multiple of 32, num_actions <= 190");
+    const size_t lds = head_bytes + 2u * MID_CHUNK * MID_FT * 64u * 16u;
+    if (lds > 160u * 1024u) return set_error(QG_ERR_UNSUPPORTED, "fused middle layer + head: the packed head does not fit beside the stream buffers");
+    if (ld_h < in_features || (ld_h & 7u) || (reinterpret_cast<uintptr_t>(h_dev) & 15u))
+        return set_error(QG_ERR_INVALID, "activations must be 16-byte aligned bf16 rows with a stride that is a multiple of 8");
+    if (action_dtype != QG_ACT_I32 && action_dtype != QG_ACT_I64) return set_error(QG_ERR_INVALID, "bad action dtype");
+    if (batch == 0) return QG_OK;
+    MidHeadArgs m;
+    HeadArgs &a = m.head;
+    a.h = reinterpret_cast<const uint4 *>(h_dev);
+    a.wp = reinterpret_cast<const uint4 *>(packed_head_dev);
+    a.actions = actions_dev;
+    a.logp = logp_dev;
+    a.entropy = entropy_dev;
+    a.values = values_dev;
+    a.clock = clock_dev;
+    a.ld_h = ld_h;
+    a.B = batch;
+    a.seed = seed ^ 0x73616D70ull;
+    a.counter = counter;
+    a.K = mid_features;
+    a.A = num_actions;
+    a.act64 = action_dtype == QG_ACT_I64;
+    m.w2p = reinterpret_cast<const uint4 *>(packed_mid_dev);
+    m.K1 = in_features;
+    const uint32_t tiles = (num_actions + 1u + 31u) / 32u;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint64_t env_tiles = (batch + 31u) / 32u, want = (env_tiles + HEAD_WAVES - 1) / HEAD_WAVES;
+    const dim3 grid((unsigned)(want < (uint64_t)cus ? want : (uint64_t)cus)), block(64 * HEAD_WAVES);
+    hipStream_t s = (hipStream_t)stream;
+#define QG_MH_CASE(TT)                                                                                                        \
+    case TT:                                                                                                                  \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mid_head_sample_kernel<TT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(mid_head_sample_kernel<TT>, grid, block, lds, s, m);                                               \
+        break;
+    switch (tiles) {
+        QG_MH_CASE(1) QG_MH_CASE(2) QG_MH_CASE(3) QG_MH_CASE(4) QG_MH_CASE(5) QG_MH_CASE(6)
+    default: return set_error(QG_ERR_UNSUPPORTED, "too many actions for the fused head");
+    }
+#undef QG_MH_CASE
     HIP_TRY(hipGetLastError());
     return QG_OK;
 }

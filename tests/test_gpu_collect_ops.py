@@ -201,3 +201,72 @@ def test_head_sample_follows_softmax():
     p = torch.softmax(row.to(torch.bfloat16).double(), 0).cpu().numpy()
     chi2 = ((counts - B * p) ** 2 / (B * p)).sum()
     assert chi2 < 30.0, (chi2, counts, B * p)
+
+
+@pytest.mark.parametrize("A,K1,B", [(170, 512, 2500), (12, 64, 300), (190, 1024, 257), (40, 96, 64)])
+def test_mid_head_sample_on_integer_data_is_exact(A, K1, B):
+    """qg_policy_mid_head_sample = relu(h W2^T + b2) -> head -> draw, everything in registers.  Small-integer weights keep
+    every intermediate exactly representable (h2 <= 256 in bf16), which pins the fragment k orders: the draw must be
+    the race winner on the exact logits, log-prob / entropy / value to f32 round-off."""
+    from qiskit_gym_amd.collector import mid_head_sample, pack_head, pack_mid
+
+    seed, counter, F = 5, 11, 256
+    g = torch.Generator(device="cuda")
+    g.manual_seed(A + K1)
+    h1 = torch.randint(0, 3, (B, K1), device="cuda", generator=g).to(torch.bfloat16)
+    w2 = torch.zeros((F, K1), device="cuda")
+    for r in range(F):  # <= 24 entries of +-1 per feature: |h2| <= 48 + bias
+        idx = torch.randperm(K1, device="cuda", generator=g)[:24]
+        w2[r, idx] = (torch.randint(0, 2, (idx.numel(),), device="cuda", generator=g) * 2 - 1).float()
+    b2 = torch.randint(-4, 5, (F,), device="cuda", generator=g).float()
+    w3 = torch.zeros((A + 2, F), device="cuda")
+    for r in range(A + 2):
+        idx = torch.randperm(F, device="cuda", generator=g)[:6]
+        w3[r, idx] = (torch.randint(0, 2, (idx.numel(),), device="cuda", generator=g) * 2 - 1).float() * 0.125
+    b3 = torch.randint(-3, 4, (A + 2,), device="cuda", generator=g).float() * 0.25
+    value_row = A + 1
+    acts, logp, ent, vals = mid_head_sample(h1, pack_mid(w2, b2), F, pack_head(w3, b3, A, value_row, after_mid=True), A, seed, counter)
+    torch.cuda.synchronize()
+    h2 = torch.relu(h1.double() @ w2.double().t() + b2.double())
+    assert float(h2.max()) <= 256
+    full = (h2 @ w3.double().t() + b3.double()).cpu().numpy()
+    logits = full[:, :A]
+    keys = race_keys(logits, sample_uniforms(seed, B, counter, A))
+    order = np.sort(keys, axis=1)
+    margin = order[:, 1] - order[:, 0]
+    got = acts.cpu().numpy()
+    clear = margin > 1e-4
+    assert clear.mean() > 0.99
+    np.testing.assert_array_equal(got[clear], keys.argmin(axis=1)[clear])
+    lsm = log_softmax(logits)
+    np.testing.assert_allclose(logp.cpu().numpy(), lsm[np.arange(B), got], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(ent.cpu().numpy(), -(np.exp(lsm) * lsm).sum(axis=1), rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(vals.cpu().numpy(), full[:, value_row].astype(np.float32))
+
+
+def test_mid_head_sample_random_weights():
+    """Random bf16 weights: against an f64 reference that rounds h2 to bf16 like the kernel does."""
+    from qiskit_gym_amd.collector import mid_head_sample, pack_head, pack_mid
+
+    A, K1, F, B = 170, 512, 256, 4000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    h1 = torch.randn((B, K1), device="cuda", generator=g).clamp_min(0).to(torch.bfloat16)
+    w2 = (torch.randn((F, K1), device="cuda", generator=g) * (2.0 / K1) ** 0.5).to(torch.bfloat16)
+    b2 = (torch.randn(F, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    w3 = (torch.randn((A + 1, F), device="cuda", generator=g) * (2.0 / F) ** 0.5).to(torch.bfloat16)
+    b3 = (torch.randn(A + 1, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    acts, logp, ent, vals = mid_head_sample(h1, pack_mid(w2, b2), F, pack_head(w3, b3, A, A, after_mid=True), A, 1, 2)
+    torch.cuda.synchronize()
+    h2 = torch.relu(h1.double() @ w2.double().t() + b2.double()).to(torch.bfloat16).double()
+    full = (h2 @ w3.double().t() + b3.double()).cpu().numpy()
+    logits = full[:, :A]
+    keys = race_keys(logits, sample_uniforms(1, B, 2, A))
+    order = np.sort(keys, axis=1)
+    clear = (order[:, 1] - order[:, 0]) > 5e-2  # an h2 element on a bf16 rounding boundary moves a logit by ~1e-3
+    got = acts.cpu().numpy()
+    assert clear.mean() > 0.85
+    np.testing.assert_array_equal(got[clear], keys.argmin(axis=1)[clear])
+    lsm = log_softmax(logits)
+    np.testing.assert_allclose(logp.cpu().numpy(), lsm[np.arange(B), got], rtol=0, atol=2e-2)
+    np.testing.assert_allclose(vals.cpu().numpy(), full[:, A], rtol=0, atol=2e-2)
