@@ -249,11 +249,12 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     for (uint32_t i = sl; i < a.A; i += 16) {
         if (mrow && !mrow[i]) continue;
         const float d = logit_to_float<LT>(row[i]) - m;
-        // hardware exp2 / log2 / rcp (1 ulp each): the race only needs its winner, the sums feed a log-prob quoted to 1e-5
-        const float ex = __expf(d);
+        // raw hardware exp2 / log2 / rcp (1 ulp each): the race only needs its winner (log2 instead of ln scales every key by the
+        // same constant), the sums feed a log-prob quoted to 1e-5
+        const float ex = __builtin_amdgcn_exp2f(d * 1.44269504088896340736f);
         ssum += ex;
         wsum += ex * d;
-        const float q = -__logf(sample_uniform(base, i)) * __builtin_amdgcn_rcpf(ex);  // ex == 0 (logit far below the max): q = inf, never wins
+        const float q = -__builtin_amdgcn_logf(sample_uniform(base, i)) * __builtin_amdgcn_rcpf(ex);  // ex == 0 (logit far below the max): q = inf, never wins
         if (q < best_q || best_a == 0xFFFFFFFFu) {
             best_q = q;
             best_a = i;

@@ -405,7 +405,7 @@ __device__ __forceinline__ void head_draw(f32x16 (&acc)[TILES], const HeadArgs &
         for (uint32_t q = 0; q < 16; ++q) {
             const uint32_t act = 32u * t + (q & 3u) + 8u * (q >> 2) + 4u * h;
             const float d = acc[t][q] - m;
-            const float ex = __expf(d);
+            const float ex = __builtin_amdgcn_exp2f(d * 1.44269504088896340736f);  // raw v_exp_f32: d <= 0, a flushed tiny result is 0 either way
             ssum += ex;
             wsum = __builtin_fmaf(ex, d, wsum);
             uint32_t x = xb + (32u * t + (q & 3u) + 8u * (q >> 2)) * 0x9E3779B9u;  // sample_uniform(base, act) (kernels_collect.hip)
@@ -415,8 +415,10 @@ __device__ __forceinline__ void head_draw(f32x16 (&acc)[TILES], const HeadArgs &
             x ^= x >> 15;
             x *= 0x846CA68Bu;
             x ^= x >> 16;
-            const float u = ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f);
-            const float qv = -__logf(u) * __builtin_amdgcn_rcpf(ex);  // padding rows: ex = 0, q = inf, never wins
+            // u = ((x >> 9) + 0.5) 2^-23, built as (1 + (x >> 9) 2^-23) - (1 - 2^-24): both steps exact, bit-identical to sample_uniform
+            const float u = __uint_as_float((x >> 9) | 0x3F800000u) - 0.99999994039535522461f;
+            // the race compares -log(u) / ex; log2 instead of ln scales every key by the same positive constant
+            const float qv = -__builtin_amdgcn_logf(u) * __builtin_amdgcn_rcpf(ex);  // padding rows: ex = 0, q = inf, never wins
             const bool take = qv < best_q;  // ascending action order within the lane: ties keep the lower index
             best_q = take ? qv : best_q;
             best_a = take ? act : best_a;
