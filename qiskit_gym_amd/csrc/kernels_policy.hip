@@ -510,12 +510,18 @@ __global__ __launch_bounds__(64 * HEAD_WAVES, 1) void head_sample_kernel(HeadArg
 // h1 (16 B per lane from global memory); the accumulator tile X[t] then has its 32 features in the registers and the
 // env on the lane -- exactly what the head's B operand needs, because the head sums over the features (the guide's
 // "accumulator tile as the next MFMA's operand": registers 8s..8s+7 packed to bf16 are the fragment of k-step 2t + s,
-// in a permuted k order that the head's packed weights follow, `xorder` above).  W2 (256 x 512 bf16 = 256 KiB) does
-// not fit beside the head: it streams through two 16 KiB LDS buffers, two k-steps per chunk, shared by the
-// workgroup's 8 waves (one barrier per chunk); the head (<= 102 KiB) stays resident.  Biases ride in extra k-steps.
+// in a permuted k order that the head's packed weights follow, `xorder` above).  Biases ride in extra k-steps.
+//
+// Nothing is LDS-resident: W2 (256 KiB) and then the head (<= 102 KiB) stream through two 16 KiB buffers in chunks of
+// 16 fragments, shared by the workgroup's 4 waves (one barrier per chunk).  With 32 KiB of LDS and one wave per SIMD a
+// CU holds two workgroups (39 -> 36 us at 65 536 envs against one 8-wave workgroup with the head resident; starting the
+// second workgroup of a CU one MFMA phase late, so that its MFMAs would run under the first one's draw, measured no gain).
 // =================================================================================================
 constexpr uint32_t MID_FT = 8;        // 32-feature tiles of the middle layer (256 features)
-constexpr uint32_t MID_CHUNK = 2;     // k-steps per streamed chunk
+constexpr uint32_t MID_CHUNK = 2;     // k-steps of W2 per streamed chunk: MID_CHUNK * MID_FT = 16 fragments of 1 KiB
+constexpr uint32_t MH_WAVES = 4;
+constexpr uint32_t MH_CHUNK_FRAGS = MID_CHUNK * MID_FT;
+constexpr uint32_t MH_CHUNK_VEC = MH_CHUNK_FRAGS * 64u;  // uint4 per chunk
 
 struct MidHeadArgs {
     HeadArgs head;         // head.h = h1, head.ld_h its stride, head.K = features of the middle layer (256), head.wp = packed head (xorder)
@@ -524,32 +530,32 @@ struct MidHeadArgs {
 };
 
 template <uint32_t TILES>
-__global__ __launch_bounds__(64 * HEAD_WAVES, 1) void mid_head_sample_kernel(MidHeadArgs ma) {
-    extern __shared__ uint4 mh_lds[];  // [head: (K2/16 + 1) x TILES x 64][2 chunk buffers: MID_CHUNK x MID_FT x 64]
+__global__ __launch_bounds__(64 * MH_WAVES, 2) void mid_head_sample_kernel(MidHeadArgs ma) {
+    __shared__ uint4 cbuf[2 * MH_CHUNK_VEC];
     const HeadArgs &a = ma.head;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t ks2 = a.K / 16u;                       // head k-steps (= 2 MID_FT)
-    const uint32_t head_vec = (ks2 + 1u) * TILES * 64u;
-    constexpr uint32_t chunk_vec = MID_CHUNK * MID_FT * 64u;
-    uint4 *const cbuf = mh_lds + head_vec;
-    const uint32_t n_chunks = ma.K1 / (16u * MID_CHUNK) + 1u;  // the last chunk is {bias k-step, zero k-step}
-    for (uint32_t c = wave * 64u; c < head_vec; c += 64u * HEAD_WAVES)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.wp + c + lane),
-                                         (__attribute__((address_space(3))) void *)(mh_lds + c), 16, 0, 0);
-    auto stage = [&](uint32_t chunk) {  // chunk -> buffer chunk & 1: 16 KiB = 2 wave-instructions per wave
-        const uint4 *src = ma.w2p + (uint64_t)chunk * chunk_vec;
-        uint4 *dst = cbuf + (chunk & 1u) * chunk_vec;
-        for (uint32_t c = wave * 64u; c < chunk_vec; c += 64u * HEAD_WAVES)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + c + lane),
-                                             (__attribute__((address_space(3))) void *)(dst + c), 16, 0, 0);
+    constexpr uint32_t HEAD_FRAGS = (2u * MID_FT + 1u) * TILES;                       // k-steps 0..16 (16 = bias) x action tiles
+    constexpr uint32_t HEAD_CHUNKS = (HEAD_FRAGS + MH_CHUNK_FRAGS - 1u) / MH_CHUNK_FRAGS;
+    const uint32_t n2 = ma.K1 / (16u * MID_CHUNK) + 1u;                               // W2 chunks; the last is {bias k-step, zero k-step}
+    auto stage = [&](uint32_t sidx) {  // stream chunk sidx -> buffer sidx & 1 (4 wave-instructions per wave)
+        const uint4 *src = sidx < n2 ? ma.w2p + (uint64_t)sidx * MH_CHUNK_VEC : a.wp + (uint64_t)(sidx - n2) * MH_CHUNK_VEC;
+        uint4 *dst = cbuf + (sidx & 1u) * MH_CHUNK_VEC;
+#pragma unroll
+        for (uint32_t c = 0; c < MH_CHUNK_VEC; c += 64u * MH_WAVES)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + c + wave * 64u + lane),
+                                             (__attribute__((address_space(3))) void *)(dst + c + wave * 64u), 16, 0, 0);
+    };
+    auto landed = [&]() {  // every wave's pieces of the chunk in flight have landed and every wave is done with the other buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     };
     const uint32_t c = lane & 31u, h = lane >> 5;
     const uint64_t n_tiles = (a.B + 31u) / 32u;
     const uint64_t row_vec = a.ld_h / 8u;
-    const uint64_t tiles_per_trip = (uint64_t)gridDim.x * HEAD_WAVES;
+    const uint64_t tiles_per_trip = (uint64_t)gridDim.x * MH_WAVES;
     const uint4 ones = make_uint4(h == 0 ? 0x3F803F80u : 0u, 0u, 0u, 0u), zeros = make_uint4(0u, 0u, 0u, 0u);
     // every wave of the workgroup takes part in every trip (the chunk barriers): waves past the last tile compute on a clamped env
-    for (uint64_t tile0 = (uint64_t)blockIdx.x * HEAD_WAVES; tile0 < n_tiles; tile0 += tiles_per_trip) {
+    for (uint64_t tile0 = (uint64_t)blockIdx.x * MH_WAVES; tile0 < n_tiles; tile0 += tiles_per_trip) {
         const uint64_t env_raw = (tile0 + wave) * 32u + c;
         const bool live = env_raw < a.B;
         const uint64_t env = live ? env_raw : a.B - 1;
@@ -563,20 +569,17 @@ __global__ __launch_bounds__(64 * HEAD_WAVES, 1) void mid_head_sample_kernel(Mid
         for (uint32_t t = 0; t < MID_FT; ++t)
 #pragma unroll
             for (uint32_t q = 0; q < 16; ++q) x[t][q] = 0.0f;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (uint32_t ch = 0; ch < n_chunks; ++ch) {
-            if (ch + 1u < n_chunks) {
-                stage(ch + 1u);  // its buffer was last read in chunk ch - 1, which every wave left through the barrier below
-                if (ch + 2u < n_chunks) {
+        landed();
+        for (uint32_t ch = 0; ch < n2; ++ch) {
+            stage(ch + 1u);  // W2's next chunk, or the head's first; its buffer was last read in chunk ch - 1, which every wave has left
+            if (ch + 2u < n2) {
 #pragma unroll
-                    for (uint32_t j = 0; j < MID_CHUNK; ++j) bn[j] = hrow[2u * ((ch + 1u) * MID_CHUNK + j)];
-                } else {
-                    bn[0] = ones;
-                    bn[1] = zeros;
-                }
+                for (uint32_t j = 0; j < MID_CHUNK; ++j) bn[j] = hrow[2u * ((ch + 1u) * MID_CHUNK + j)];
+            } else {
+                bn[0] = ones;
+                bn[1] = zeros;
             }
-            const uint4 *al = cbuf + (ch & 1u) * chunk_vec + lane;
+            const uint4 *al = cbuf + (ch & 1u) * MH_CHUNK_VEC + lane;
 #pragma unroll
             for (uint32_t j = 0; j < MID_CHUNK; ++j) {
                 const bf16x8 bf = __builtin_bit_cast(bf16x8, bq[j]);
@@ -586,15 +589,10 @@ __global__ __launch_bounds__(64 * HEAD_WAVES, 1) void mid_head_sample_kernel(Mid
             }
 #pragma unroll
             for (uint32_t j = 0; j < MID_CHUNK; ++j) bq[j] = bn[j];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            landed();
         }
-        // ReLU, bf16, and the tiles become the head's B fragments: registers 8s..8s+7 of tile t = k-step 2t + s
-        f32x16 acc[TILES];
-#pragma unroll
-        for (uint32_t t = 0; t < TILES; ++t)
-#pragma unroll
-            for (uint32_t q = 0; q < 16; ++q) acc[t][q] = 0.0f;
+        // ReLU, bf16: the tiles become the head's B fragments, registers 8s..8s+7 of tile t = k-step 2t + s; k-step 16 = bias
+        bf16x8 hb[2u * MID_FT + 1u];
 #pragma unroll
         for (uint32_t t = 0; t < MID_FT; ++t) {
 #pragma unroll
@@ -606,19 +604,27 @@ __global__ __launch_bounds__(64 * HEAD_WAVES, 1) void mid_head_sample_kernel(Mid
                                      __builtin_amdgcn_fmed3f(x[t][8u * s + 2u * j + 1u], 0.0f, __builtin_inff())};
                     f[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
                 }
-                const bf16x8 bf = __builtin_bit_cast(bf16x8, f);
-                const uint4 *al = mh_lds + (uint64_t)(2u * t + s) * (TILES * 64u) + lane;
-#pragma unroll
-                for (uint32_t tt = 0; tt < TILES; ++tt)
-                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[tt * 64u]), bf, acc[tt], 0, 0, 0);
+                hb[2u * t + s] = __builtin_bit_cast(bf16x8, f);
             }
         }
-        {   // the head's bias k-step
-            const bf16x8 bf = __builtin_bit_cast(bf16x8, ones);
-            const uint4 *al = mh_lds + (uint64_t)ks2 * (TILES * 64u) + lane;
+        hb[2u * MID_FT] = __builtin_bit_cast(bf16x8, ones);
+        f32x16 acc[TILES];
 #pragma unroll
-            for (uint32_t tt = 0; tt < TILES; ++tt)
-                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[tt * 64u]), bf, acc[tt], 0, 0, 0);
+        for (uint32_t t = 0; t < TILES; ++t)
+#pragma unroll
+            for (uint32_t q = 0; q < 16; ++q) acc[t][q] = 0.0f;
+        // the head: fragment f = k-step (f / TILES) x action tile (f % TILES), 16 fragments per streamed chunk
+#pragma unroll
+        for (uint32_t hc = 0; hc < HEAD_CHUNKS; ++hc) {
+            if (hc + 1u < HEAD_CHUNKS) stage(n2 + hc + 1u);
+            const uint4 *al = cbuf + ((n2 + hc) & 1u) * MH_CHUNK_VEC + lane;
+#pragma unroll
+            for (uint32_t i = 0; i < MH_CHUNK_FRAGS; ++i) {
+                const uint32_t f = hc * MH_CHUNK_FRAGS + i;
+                if (f < HEAD_FRAGS)
+                    acc[f % TILES] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i * 64u]), hb[f / TILES], acc[f % TILES], 0, 0, 0);
+            }
+            landed();  // after the last chunk: every wave is done with both buffers before the next trip stages chunk 0
         }
         head_draw<TILES>(acc, a, env, live, h);
     }
@@ -711,7 +717,8 @@ size_t qg_policy_head_packed_bytes(uint32_t num_actions, uint32_t in_features) {
     const uint32_t tiles = (num_actions + 1u + 31u) / 32u;
     if (num_actions == 0 || tiles > 6 || in_features == 0 || in_features % 64u || in_features > 512u) return 0;
     const size_t bytes = (size_t)(in_features / 16u + 1u) * tiles * 64u * 16u;
-    return bytes <= 144u * 1024u ? bytes : 0;
+    if (bytes > 144u * 1024u) return 0;
+    return (bytes + 16383u) / 16384u * 16384u;  // whole 16 KiB chunks: qg_policy_mid_head_sample streams the head through LDS in such pieces
 }
 
 static int pack_rows_impl(const void *weight_dev, const void *bias_dev, int dtype, uint64_t ld, uint32_t in_features, uint32_t rows,
@@ -809,11 +816,8 @@ int qg_policy_mid_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, 
                               const void *packed_head_dev, uint32_t num_actions, uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev,
                               int action_dtype, float *logp_dev, float *entropy_dev, float *values_dev, void *stream) {
     if (!h_dev || !packed_mid_dev || !packed_head_dev || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
-    const size_t head_bytes = qg_policy_head_packed_bytes(num_actions, mid_features);
-    if (head_bytes == 0 || qg_policy_mid_packed_bytes(in_features, mid_features) == 0)
+    if (qg_policy_head_packed_bytes(num_actions, mid_features) == 0 || qg_policy_mid_packed_bytes(in_features, mid_features) == 0)
         return set_error(QG_ERR_UNSUPPORTED, "fused middle layer + head: 256 middle features, in_features a multiple of 32, num_actions <= 190");
-    const size_t lds = head_bytes + 2u * MID_CHUNK * MID_FT * 64u * 16u;
-    if (lds > 160u * 1024u) return set_error(QG_ERR_UNSUPPORTED, "fused middle layer + head: the packed head does not fit beside the stream buffers");
     if (ld_h < in_features || (ld_h & 7u) || (reinterpret_cast<uintptr_t>(h_dev) & 15u))
         return set_error(QG_ERR_INVALID, "activations must be 16-byte aligned bf16 rows with a stride that is a multiple of 8");
     if (action_dtype != QG_ACT_I32 && action_dtype != QG_ACT_I64) return set_error(QG_ERR_INVALID, "bad action dtype");
@@ -840,14 +844,12 @@ int qg_policy_mid_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, 
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const uint64_t env_tiles = (batch + 31u) / 32u, want = (env_tiles + HEAD_WAVES - 1) / HEAD_WAVES;
-    const dim3 grid((unsigned)(want < (uint64_t)cus ? want : (uint64_t)cus)), block(64 * HEAD_WAVES);
+    const uint64_t env_tiles = (batch + 31u) / 32u, want = (env_tiles + MH_WAVES - 1) / MH_WAVES;
+    const uint64_t resident = 2ull * (uint64_t)cus;  // two workgroups per CU (32 KiB of LDS and 256 registers x 4 waves each)
+    const dim3 grid((unsigned)(want < resident ? want : resident)), block(64 * MH_WAVES);
     hipStream_t s = (hipStream_t)stream;
-#define QG_MH_CASE(TT)                                                                                                        \
-    case TT:                                                                                                                  \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mid_head_sample_kernel<TT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(mid_head_sample_kernel<TT>, grid, block, lds, s, m);                                               \
-        break;
+#define QG_MH_CASE(TT)                                                        \
+    case TT: hipLaunchKernelGGL(mid_head_sample_kernel<TT>, grid, block, 0, s, m); break;
     switch (tiles) {
         QG_MH_CASE(1) QG_MH_CASE(2) QG_MH_CASE(3) QG_MH_CASE(4) QG_MH_CASE(5) QG_MH_CASE(6)
     default: return set_error(QG_ERR_UNSUPPORTED, "too many actions for the fused head");
