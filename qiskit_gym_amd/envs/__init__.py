@@ -15,6 +15,10 @@ def __getattr__(name):  # lazy: the env classes need the built library only when
         from . import gyms as synthesis
 
         return getattr(synthesis, name)
+    if name == "VecGym":
+        from .vector import VecGym
+
+        return VecGym
     if name == "RawEnv":
         from .raw import RawEnv
 

@@ -64,6 +64,12 @@ class BaseSynthesisEnv:
         cfg.update(overrides)
         return VecEnv(self.env_kind, self.config["num_qubits"], self.config["gateset"], batch, device=device, **cfg)
 
+    def vec_gym(self, num_envs: int, seed: int = 0, device=None, **overrides):
+        """`gymnasium.vector`-shaped front end over `vec(num_envs)` with same-step autoreset (envs/vector.py)."""
+        from .vector import VecGym
+
+        return VecGym(self.vec(num_envs, device=device, **overrides), seed=seed)
+
     def build_circuit_from_solution(self, actions: List[int], input=None):
         from qiskit import QuantumCircuit  # optional dependency
 

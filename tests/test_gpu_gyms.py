@@ -71,3 +71,41 @@ def test_vec_twin_and_defaults():
     p.set_state(state)
     obs, r, term, trunc, info = p.step(0)
     assert obs.shape == (6, 11)
+
+
+@pytest.mark.parametrize("cls,n", [(LinearFunctionGym, 5), (CliffordGym, 4), (PermutationGym, 6)])
+def test_vec_gym_autoreset_replays_on_the_oracle(cls, n):
+    """The gymnasium.vector-shaped front end: same-step autoreset on the device; every returned tensor replayed on
+    per-env CPU oracle copies (episode k of the handle is scrambled with seed + 0x9E3779B9 (k + 1))."""
+    from oracle import OracleEnv
+    from util import f32_bits, rng_actions
+
+    B, T, diff, seed = 96, 40, 3, 5
+    env = cls.from_coupling_map(line_edges(n, True), add_inverts=False, add_perms=False, difficulty=diff, depth_slope=2)
+    venv = env.vec_gym(B, seed=seed, track_solution=False)
+    gs, A = env.config["gateset"], len(env.config["gateset"])
+    assert venv.num_envs == B and venv.single_action_space.n == A and venv.single_observation_space.shape == tuple(env.observation_space.shape)
+    ora = [OracleEnv(env.env_kind, n, gs, add_inverts=0, add_perms=0, track_solution=0, difficulty=diff, depth_slope=2) for _ in range(B)]
+    episode = 1
+    draws = rng_actions((seed + 0x9E3779B9 * episode) & (2**64 - 1), B, diff, A)
+    for e, o in enumerate(ora):
+        o.reset_with(draws[:, e])
+    obs, info = venv.reset()
+    assert info == {} and obs.dtype == torch.int8
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    ended = 0
+    for t in range(T):
+        np.testing.assert_array_equal(obs.cpu().numpy().reshape(B, -1), np.stack([o.dense_obs().reshape(-1) for o in ora]), err_msg=f"t={t}")
+        acts = torch.randint(0, A, (B,), device="cuda", dtype=torch.int32, generator=gen)
+        obs, reward, terminated, truncated, _ = venv.step(acts)
+        episode += 1
+        draws = rng_actions((seed + 0x9E3779B9 * episode) & (2**64 - 1), B, diff, A)
+        r, te, tr = reward.cpu().numpy(), terminated.cpu().numpy(), truncated.cpu().numpy()
+        for e, o in enumerate(ora):
+            o.step(int(acts[e]))
+            assert o.reward_bits() == int(f32_bits(r[e])) and bool(te[e]) == o.success() and bool(tr[e]) == (o.is_final() and not o.success()), (t, e)
+            if o.is_final():
+                o.reset_with(draws[:, e])
+                ended += 1
+    assert ended > B  # several episodes per env
+    venv.venv.sync()
