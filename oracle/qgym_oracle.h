@@ -17,10 +17,12 @@
  * trained policies examples/models/ *.pt) -- see tests/golden/ -- for gateset ordering,
  * LinearFunction/Permutation/Clifford state transitions and is_final; the trained policies, run
  * greedily, solve random targets on this oracle (and on the HIP path) and fail on an env that
- * differs in observation layout, action order or one gate's semantics (tests/test_reference_policies.py).  Behaviour that depends on third-party crates absent from /root/reference
- * (petgraph 0.6.5 `retain_nodes`/`remove_node` swap-remove order, nalgebra 0.33.2 `from_vec`
- * + `transpose`, twisterl 0.5.1 `Env` trait) is restated from their published algorithms and
- * is "parity unpinned": no reference test or fixture exercises it.
+ * differs in observation layout, action order or one gate's semantics (tests/test_reference_policies.py).
+ * PauliEnv, for which the reference ships no data at all, is pinned to physics through the reference's Python
+ * encode / decode contract (envs/synthesis.py:316-512) restated on explicit unitaries: encoded circuits, solved by
+ * replaying their gates, decode to circuits with the same unitary (tests/test_pauli_physics.py).  Still "parity
+ * unpinned": the order of the observation's rotation columns (petgraph 0.6.5 `retain_nodes`/`remove_node`
+ * swap-remove re-indexing, restated from the crate's published algorithm) and twisterl 0.5.1's `Env` trait.
  *
  * Randomness: the reference draws from rand::thread_rng() (unseedable).  The oracle takes every
  * random draw as an explicit argument: reset scramble actions, the add_inverts coin, the Pauli
