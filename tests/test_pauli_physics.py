@@ -218,3 +218,40 @@ def test_hip_path_solutions_reproduce_the_encoded_unitary():
         solved, dec = replay(hip_env, n, circ)
         assert solved, circ
         assert same_up_to_phase(unitary(circ, n), unitary(dec, n)), (circ, dec)
+
+
+# ---- CliffordEnv: the same construction without rotations (envs/synthesis.py:206-209 `get_state`: Clifford(circuit).adjoint()
+# tableau without the phase column, transposed); all eight gate kinds, replayed in circuit order, no qubit exchange ----------
+def clifford_state(circ, n):
+    v = unitary(circ, n).conj().T
+    rows = [xz_bits(label_of(v @ op1(pm, i, n) @ v.conj().T, n), n) for pm in (X, Z) for i in range(n)]
+    return np.array(rows).T.flatten().tolist()
+
+
+def _clifford_case(env_factory, rng):
+    n = int(rng.integers(2, 4))
+    gs = line_gateset("clifford", n)
+    names = [(a.lower(), tuple(b)) for a, b in gs]
+    circ = [names[a] for a in rng.integers(0, len(names), size=rng.integers(1, 14))]
+    env = env_factory(n, gs)
+    env.set_state(clifford_state(circ, n))
+    for g in circ:
+        env.step(names.index(g))
+    assert env.success(), circ
+    # and the logged solution is that circuit
+    assert [names[a] for a in env.solution()] == circ
+
+
+def test_clifford_env_gates_are_the_physical_gates():
+    rng = np.random.default_rng(3)
+    for _ in range(150):
+        _clifford_case(lambda n, gs: OracleEnv("clifford", n, gs, add_inverts=0, add_perms=0, track_solution=1, difficulty=1), rng)
+
+
+@pytest.mark.gpu
+def test_clifford_env_gates_are_the_physical_gates_on_the_hip_path():
+    from qiskit_gym_amd.envs import RawEnv
+
+    rng = np.random.default_rng(4)
+    for _ in range(40):
+        _clifford_case(lambda n, gs: RawEnv("clifford", n, gs, add_inverts=False, add_perms=False, track_solution=True, difficulty=1), rng)
