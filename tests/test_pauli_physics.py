@@ -255,3 +255,58 @@ def test_clifford_env_gates_are_the_physical_gates_on_the_hip_path():
     rng = np.random.default_rng(4)
     for _ in range(40):
         _clifford_case(lambda n, gs: RawEnv("clifford", n, gs, add_inverts=False, add_perms=False, track_solution=True, difficulty=1), rng)
+
+
+# ---- add_inverts (clifford.rs:262-270, 334-340, 376-381): the state may be replaced by its inverse after any step, later actions
+# go to `solution_inv`, and solution() = solution ++ reverse(solution_inv) must still synthesise the target.  The reference's own
+# trained 3-qubit policy (tests/golden/policies, trained with add_inverts on) does the solving; coins are injected. -------------
+def is_pauli_up_to_phase(m, n):
+    for chars in itertools.product("IXYZ", repeat=n):
+        p = np.array([[1]], dtype=complex)
+        for ch in chars:
+            p = np.kron(p, P1[ch])
+        if abs(abs(np.trace(p.conj().T @ m)) - 2 ** n) < 1e-6:
+            return True
+    return False
+
+
+def _inverts_case(env_factory, rng, step):
+    from test_reference_policies import greedy, load
+
+    cfg, gateset, w = load("clifford_3q_custom")
+    n = 3
+    names = [(a.lower(), tuple(b)) for a, b in gateset]
+    target = [names[a] for a in rng.integers(0, len(names), size=rng.integers(4, 16))]
+    env = env_factory(n, gateset)
+    env.set_state(clifford_state(target, n))
+    flips = 0
+    for _ in range(96):
+        if env.success():
+            break
+        obs = np.zeros(36, dtype=np.float32)
+        obs[np.asarray(env.observe(), dtype=np.int64)] = 1
+        coin = int(rng.integers(0, 2))
+        flips += coin
+        step(env, int(greedy(w, obs)), coin)
+    assert env.success(), target
+    synth = [names[a] for a in env.solution()]
+    # equal as Cliffords without phases (the reference's check, intro.ipynb cell 37): U(synth)^dagger U(target) is a Pauli
+    assert is_pauli_up_to_phase(unitary(synth, n).conj().T @ unitary(target, n), n), (target, synth)
+    return flips
+
+
+def test_add_inverts_solutions_synthesise_the_target():
+    rng = np.random.default_rng(8)
+    flips = sum(_inverts_case(lambda n, gs: OracleEnv("clifford", n, gs, add_inverts=1, add_perms=0, track_solution=1, difficulty=1),
+                              rng, lambda env, a, c: env.step(a, c)) for _ in range(80))
+    assert flips > 100  # the coin did fire
+
+
+@pytest.mark.gpu
+def test_add_inverts_solutions_synthesise_the_target_on_the_hip_path():
+    from qiskit_gym_amd.envs import RawEnv
+
+    rng = np.random.default_rng(9)
+    flips = sum(_inverts_case(lambda n, gs: RawEnv("clifford", n, gs, add_inverts=True, add_perms=False, track_solution=True, difficulty=1),
+                              rng, lambda env, a, c: env.step(a, coin=c)) for _ in range(30))
+    assert flips > 30
