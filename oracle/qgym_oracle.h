@@ -20,7 +20,7 @@
  * differs in observation layout, action order or one gate's semantics (tests/test_reference_policies.py).
  * PauliEnv, for which the reference ships no data at all, is pinned to physics through the reference's Python
  * encode / decode contract (envs/synthesis.py:316-512) restated on explicit unitaries: encoded circuits, solved by
- * replaying their gates, decode to circuits with the same unitary (tests/test_pauli_physics.py).  Still "parity
+ * replaying their gates, decode to circuits with the same unitary (tests/test_physics.py).  Still "parity
  * unpinned": the order of the observation's rotation columns (petgraph 0.6.5 `retain_nodes`/`remove_node`
  * swap-remove re-indexing, restated from the crate's published algorithm) and twisterl 0.5.1's `Env` trait.
  *
