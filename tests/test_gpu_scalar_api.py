@@ -141,3 +141,54 @@ def test_twists_match_symmetry_rules():
     assert len(obs_perms) == 1 and obs_perms[0] == list(range(36))
     env = RawEnv("clifford", 3, cg, add_inverts=False, add_perms=False)
     assert env.twists() == ([], [])
+
+
+@pytest.mark.parametrize("kind,n,edges", [("linear_function", 4, "line"), ("clifford", 4, "line"), ("clifford", 4, "ring"), ("permutation", 5, "line")])
+def test_twists_are_symmetries_of_the_dynamics(kind, n, edges):
+    """Env::twists (symmetry.rs:115-361): every (obs_perm, act_perm) pair must commute with stepping -- relabel the
+    observation with obs_perm, the action with act_perm, and the relabelled env does the relabelled thing, with the same
+    reward.  twisterl, which applies the twists, is absent from the reference tree; the convention under which the pairs
+    are symmetries is obs'[obs_perm[i]] = obs[i] with action act_perm[a] (for the involutions of a line the direction does not
+    matter; the rotations of a ring tell the two apart).  One convention must work for every twist, state and action."""
+    from qiskit_gym_amd.envs.gateset import gateset_from_coupling_map, line_edges
+    from util import ALLOWED
+
+    e = line_edges(n, True)
+    if edges == "ring":
+        e = e + [(n - 1, 0), (0, n - 1)]
+    gs = gateset_from_coupling_map(e, None, ALLOWED[kind])[1]
+    env = RawEnv(kind, n, gs, add_inverts=False, add_perms=True, track_solution=False, difficulty=6)
+    obs_perms, act_perms = env.twists()
+    assert len(obs_perms) == len(act_perms) >= 2 and sorted(obs_perms[0]) == list(range(len(obs_perms[0])))
+    size = len(obs_perms[0])
+
+    def dense(e_):
+        d = np.zeros(size, dtype=np.int64)
+        d[np.asarray(e_.observe(), dtype=np.int64)] = 1
+        return d
+
+    def state_of(d):  # set_state wire format: the dense 0/1 matrix (Clifford / LinearFunction) or the permutation itself
+        return d.reshape(n, n).argmax(axis=1).tolist() if kind == "permutation" else d.tolist()
+
+    rng = np.random.default_rng(n)
+    twin = RawEnv(kind, n, gs, add_inverts=False, add_perms=True, track_solution=False, difficulty=6)
+    for trial in range(12):
+        env.reset(100 + trial)
+        for k, (op, ap) in enumerate(zip(obs_perms, act_perms)):
+            d = dense(env)
+            op = np.asarray(op)
+
+            def relabel(x):
+                y = np.zeros_like(x)
+                y[op] = x
+                return y
+
+            twin.set_state(state_of(relabel(d)))
+            assert dense(twin).tolist() == relabel(d).tolist()
+            a = int(rng.integers(0, len(gs)))
+            probe = env.clone()
+            probe.step(a)
+            twin.step(ap[a])
+            assert dense(twin).tolist() == relabel(dense(probe)).tolist(), (kind, k, a)
+            # same gate cost (the solved bonus may differ: set_state gives the twin max_depth, not the probe's depth)
+            assert twin.success() == probe.success()
