@@ -298,7 +298,7 @@ int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint3
  * registers and go straight into the exponential race of qg_sample_actions (same counter RNG, hash and tie rule, so
  * the same seed / counter / clock give the same draw for the same logits); outputs as there, values_dev[e] = the value
  * head W[value_row] . h[e] + b[value_row].  h_dev: bf16 [batch, ld_h], 16-byte aligned, ld_h % 8 == 0.  Limits
- * (qg_policy_head_packed_bytes returns 0 outside them): num_actions <= 190, in_features % 64 == 0, <= 512, packed head
+ * (qg_policy_head_packed_bytes returns 0 outside them): num_actions <= 222, in_features % 64 == 0, <= 512, packed head
  * <= 144 KiB.  qg_policy_pack_head re-orders W ([rows, ld] f32 / bf16) and the bias ([rows], same dtype, or NULL)
  * into MFMA fragment order: rows 0..num_actions-1 are the actions, row value_row (>= 0, any index) the value head. */
 size_t qg_policy_head_packed_bytes(uint32_t num_actions, uint32_t in_features);

@@ -119,7 +119,7 @@ def pack_head(weight: torch.Tensor, bias: Optional[torch.Tensor], num_actions: i
     L = _lib.load()
     nbytes = L.qg_policy_head_packed_bytes(num_actions, weight.shape[1])
     if nbytes == 0:
-        raise ValueError("fused head needs num_actions <= 190 and in_features % 64 == 0, <= 512")
+        raise ValueError("fused head needs num_actions <= 222 and in_features % 64 == 0, <= 512")
     if weight.stride(1) != 1 or (bias is not None and (bias.dtype != weight.dtype or not bias.is_contiguous())):
         raise ValueError("weight must have unit column stride; bias contiguous and of the same dtype")
     if out is None:

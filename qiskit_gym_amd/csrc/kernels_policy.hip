@@ -715,7 +715,7 @@ int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint3
 
 size_t qg_policy_head_packed_bytes(uint32_t num_actions, uint32_t in_features) {
     const uint32_t tiles = (num_actions + 1u + 31u) / 32u;
-    if (num_actions == 0 || tiles > 6 || in_features == 0 || in_features % 64u || in_features > 512u) return 0;
+    if (num_actions == 0 || tiles > 7 || in_features == 0 || in_features % 64u || in_features > 512u) return 0;
     const size_t bytes = (size_t)(in_features / 16u + 1u) * tiles * 64u * 16u;
     if (bytes > 144u * 1024u) return 0;
     return (bytes + 16383u) / 16384u * 16384u;  // whole 16 KiB chunks: qg_policy_mid_head_sample streams the head through LDS in such pieces
@@ -745,7 +745,7 @@ int qg_policy_pack_head(const void *weight_dev, const void *bias_dev, int dtype,
                         int32_t value_row, int after_mid, void *packed_dev, void *stream) {
     if (!weight_dev || !packed_dev) return set_error(QG_ERR_INVALID, "null argument");
     if (qg_policy_head_packed_bytes(num_actions, in_features) == 0)
-        return set_error(QG_ERR_UNSUPPORTED, "fused head: num_actions <= 190, in_features a multiple of 64 and <= 512, packed head <= 144 KiB");
+        return set_error(QG_ERR_UNSUPPORTED, "fused head: num_actions <= 222, in_features a multiple of 64 and <= 512, packed head <= 144 KiB");
     if (ld < in_features) return set_error(QG_ERR_INVALID, "weight rows are shorter than in_features");
     const uint32_t tiles = (num_actions + 1u + 31u) / 32u;
     return pack_rows_impl(weight_dev, bias_dev, dtype, ld, in_features, num_actions, value_row, tiles, after_mid ? 1u : 0u, in_features / 16u + 1u, packed_dev,
@@ -771,7 +771,7 @@ int qg_policy_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, uint
                           float *entropy_dev, float *values_dev, void *stream) {
     if (!h_dev || !packed_dev || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
     const size_t lds = qg_policy_head_packed_bytes(num_actions, in_features);
-    if (lds == 0) return set_error(QG_ERR_UNSUPPORTED, "fused head: num_actions <= 190, in_features a multiple of 64 and <= 512, packed head <= 144 KiB");
+    if (lds == 0) return set_error(QG_ERR_UNSUPPORTED, "fused head: num_actions <= 222, in_features a multiple of 64 and <= 512, packed head <= 144 KiB");
     if (ld_h < in_features || (ld_h & 7u) || (reinterpret_cast<uintptr_t>(h_dev) & 15u))
         return set_error(QG_ERR_INVALID, "activations must be 16-byte aligned bf16 rows with a stride that is a multiple of 8");
     if (action_dtype != QG_ACT_I32 && action_dtype != QG_ACT_I64) return set_error(QG_ERR_INVALID, "bad action dtype");
@@ -804,7 +804,7 @@ int qg_policy_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, uint
         hipLaunchKernelGGL(head_sample_kernel<TT>, grid, block, lds, s, a);                                                   \
         break;
     switch (tiles) {
-        QG_HEAD_CASE(1) QG_HEAD_CASE(2) QG_HEAD_CASE(3) QG_HEAD_CASE(4) QG_HEAD_CASE(5) QG_HEAD_CASE(6)
+        QG_HEAD_CASE(1) QG_HEAD_CASE(2) QG_HEAD_CASE(3) QG_HEAD_CASE(4) QG_HEAD_CASE(5) QG_HEAD_CASE(6) QG_HEAD_CASE(7)
     default: return set_error(QG_ERR_UNSUPPORTED, "too many actions for the fused head");
     }
 #undef QG_HEAD_CASE
@@ -817,7 +817,7 @@ int qg_policy_mid_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, 
                               int action_dtype, float *logp_dev, float *entropy_dev, float *values_dev, void *stream) {
     if (!h_dev || !packed_mid_dev || !packed_head_dev || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
     if (qg_policy_head_packed_bytes(num_actions, mid_features) == 0 || qg_policy_mid_packed_bytes(in_features, mid_features) == 0)
-        return set_error(QG_ERR_UNSUPPORTED, "fused middle layer + head: 256 middle features, in_features a multiple of 32, num_actions <= 190");
+        return set_error(QG_ERR_UNSUPPORTED, "fused middle layer + head: 256 middle features, in_features a multiple of 32, num_actions <= 222");
     if (ld_h < in_features || (ld_h & 7u) || (reinterpret_cast<uintptr_t>(h_dev) & 15u))
         return set_error(QG_ERR_INVALID, "activations must be 16-byte aligned bf16 rows with a stride that is a multiple of 8");
     if (action_dtype != QG_ACT_I32 && action_dtype != QG_ACT_I64) return set_error(QG_ERR_INVALID, "bad action dtype");
@@ -851,7 +851,7 @@ int qg_policy_mid_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, 
 #define QG_MH_CASE(TT)                                                        \
     case TT: hipLaunchKernelGGL(mid_head_sample_kernel<TT>, grid, block, 0, s, m); break;
     switch (tiles) {
-        QG_MH_CASE(1) QG_MH_CASE(2) QG_MH_CASE(3) QG_MH_CASE(4) QG_MH_CASE(5) QG_MH_CASE(6)
+        QG_MH_CASE(1) QG_MH_CASE(2) QG_MH_CASE(3) QG_MH_CASE(4) QG_MH_CASE(5) QG_MH_CASE(6) QG_MH_CASE(7)
     default: return set_error(QG_ERR_UNSUPPORTED, "too many actions for the fused head");
     }
 #undef QG_MH_CASE

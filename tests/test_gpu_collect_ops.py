@@ -146,7 +146,7 @@ def test_gae_is_bit_exact(T, B, with_last):
     np.testing.assert_array_equal(f32_bits(ret.cpu().numpy()), f32_bits(want_ret))
 
 
-@pytest.mark.parametrize("A,K,B", [(170, 256, 3001), (12, 64, 500), (190, 128, 777), (33, 512, 64), (1, 64, 40)])
+@pytest.mark.parametrize("A,K,B", [(170, 256, 3001), (12, 64, 500), (190, 128, 777), (33, 512, 64), (1, 64, 40), (214, 256, 1000), (222, 64, 90)])
 def test_head_sample_is_the_race_on_its_own_logits(A, K, B):
     """qg_policy_head_sample = last layer + qg_sample_actions in one kernel: the action is the winner of the same
     exponential race on logits h W^T + b (f64 reference; bias carried as two bf16 terms), and log-prob / entropy /
@@ -203,7 +203,7 @@ def test_head_sample_follows_softmax():
     assert chi2 < 30.0, (chi2, counts, B * p)
 
 
-@pytest.mark.parametrize("A,K1,B", [(170, 512, 2500), (12, 64, 300), (190, 1024, 257), (40, 96, 64)])
+@pytest.mark.parametrize("A,K1,B", [(170, 512, 2500), (12, 64, 300), (190, 1024, 257), (40, 96, 64), (214, 512, 1000), (222, 128, 70)])
 def test_mid_head_sample_on_integer_data_is_exact(A, K1, B):
     """qg_policy_mid_head_sample = relu(h W2^T + b2) -> head -> draw, everything in registers.  Small-integer weights keep
     every intermediate exactly representable (h2 <= 256 in bf16), which pins the fragment k orders: the draw must be
