@@ -241,8 +241,8 @@ class RolloutCollector:
     """Steps `env` for T steps under `policy`, resetting finished episodes on the device.
 
     store_obs: "dense" keeps the int8 observation of every step (the Gym adapter's format);
-    "packed" keeps the bit-packed rows (8x smaller for CliffordGym; `Rollout.dense_obs` expands them
-    on demand; not available for PauliGym, whose observation has no packed form).
+    "packed" keeps the bit-packed rows (8x smaller for CliffordGym, one 64-bit word per observation row for
+    PauliGym; `Rollout.dense_obs` expands them on demand).
 
     use_graph: capture the whole T-step collection (every env kernel, the policy GEMMs, sampling,
     GAE) into one hipGraph on the first call and replay it afterwards -- one host call per rollout
@@ -265,8 +265,8 @@ class RolloutCollector:
         self.obs_size = r * c
         if store_obs not in ("dense", "packed"):
             raise ValueError("store_obs must be 'dense' or 'packed'")
-        if store_obs == "packed" and env.env_kind == "pauli":
-            raise ValueError("PauliGym observations have no packed form")
+        if store_obs == "packed" and env.env_kind == "pauli" and env.obs_shape_[1] > 64:
+            raise ValueError("PauliGym observations wider than 64 columns have no packed form")
         self.store_obs = store_obs
         self.use_graph = bool(use_graph)
         self._x = torch.empty((env.batch, self.obs_size), dtype=dtype, device=env.device)  # policy input
@@ -331,7 +331,12 @@ class RolloutCollector:
         env = self.env
         if ro.obs_packed:
             env.observe_packed(out=ro.obs[t])
-            if self._embed is None:
+            if self._embed is not None:
+                pass
+            elif env.env_kind == "pauli":
+                # PauliEnv.observe() with add_perms draws a permutation (pauli.rs:657-662): observe once, expand the stored row words
+                expand_packed(ro.obs[t], env.obs_shape_[1], self.dtype, out=self._x.view(env.batch, *env.obs_shape_))
+            else:
                 env.observe_as(self.dtype, out=self._x)
         else:
             env.observe(out=ro.obs[t].view(env.batch, *env.obs_shape_))

@@ -1373,6 +1373,25 @@ hipError_t ptile_export(const qg_vec *v, const ObsArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// PauliEnv::observe as one 64-bit word per observation row (bit c = column c: the tableau's 2N columns, then the active rotations'
+// columns; pauli.rs:411-485) -- the packed form of the [2N, 2N + max_rotations] observation, 8 bytes per row instead of cols
+hipError_t ptile_observe_words(qg_vec *v, void *out_dev, hipStream_t s) {
+    ObsArgs a;
+    memset(&a, 0, sizeof a);
+    a.state = v->state;
+    a.B = v->B;
+    a.N = v->N;
+    a.D = 2 * v->N;
+    a.obs_rows = 2 * v->N;
+    a.obs_cols = 2 * v->N + (uint32_t)std::max(v->cfg.max_rotations, 1);
+    a.format = QG_FMT_U8;
+    if (!a.B) return hipSuccess;
+    PTObsArgs pa;
+    fill_obs(v, a, pa);
+    hipLaunchKernelGGL(ptile_rowwords_kernel, dim3(grid_for(a.B * 2ull * a.N / 2, 256)), dim3(256), 0, s, pa, reinterpret_cast<uint64_t *>(out_dev));
+    return hipGetLastError();
+}
+
 hipError_t ptile_observe_typed(qg_vec *v, void *out_dev, int out_dtype, hipStream_t s) {
     ObsArgs a;
     memset(&a, 0, sizeof a);

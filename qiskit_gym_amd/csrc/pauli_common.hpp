@@ -44,5 +44,6 @@ hipError_t ptile_step(const qg_vec *v, const StepArgs &a, hipStream_t s);
 hipError_t ptile_export(const qg_vec *v, const ObsArgs &a, hipStream_t s);
 // observe() as a dense tensor of `out_dtype` (obs_cols <= 64): row words, then expand_rows
 hipError_t ptile_observe_typed(qg_vec *v, void *out_dev, int out_dtype, hipStream_t s);
+hipError_t ptile_observe_words(qg_vec *v, void *out_dev, hipStream_t s);
 
 }  // namespace qg

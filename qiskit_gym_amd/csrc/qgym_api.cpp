@@ -921,7 +921,17 @@ int qg_vec_pauli_num_perms(const qg_vec *v) { return v ? (int)v->n_perms : -1; }
 int qg_vec_observe_packed(qg_vec *v, void *out_dev, void *stream) {
     if (!v || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(v->device));
-    if (v->layout == LAYOUT_PAULI) return set_error(QG_ERR_UNSUPPORTED, "packed observation of PauliEnv: use observe_dense");
+    if (v->layout == LAYOUT_PAULI) {
+        const uint32_t cols = 2 * v->N + (uint32_t)std::max(v->cfg.max_rotations, 1);
+        if (!v->pauli_tile || cols > 64u)
+            return set_error(QG_ERR_UNSUPPORTED, "packed observation of PauliEnv needs the thread-per-env family and at most 64 observation columns: use observe_dense");
+        v->perm_draw = true;  // PauliEnv::observe draws a new qubit permutation (pauli.rs:657-662)
+        const hipError_t e = ptile_observe_words(v, out_dev, (hipStream_t)stream);
+        v->perm_draw = false;
+        v->observe_counter += 1;
+        HIP_TRY(e);
+        return QG_OK;
+    }
     const bool rows = v->layout == LAYOUT_ROWS32 || v->layout == LAYOUT_ROWS64;
     const size_t word = v->layout == LAYOUT_ROWS64 ? 8 : 4;
     if (rows && v->stride_bytes == (size_t)v->D * word) {  // no padding: the resident state is the packed observation

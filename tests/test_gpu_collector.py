@@ -90,8 +90,15 @@ def test_collector_runs_pauli_and_generic_policies():
     env.sync()
     assert ro.obs.shape == (T, B, rows * cols) and ro.dones.sum() > 0
     assert torch.isfinite(ro.advantages).all() and ro.last_values is None
-    with pytest.raises(ValueError):
-        RolloutCollector(env, Tiny(), store_obs="packed")
+    # the packed form of the PauliGym observation (one 64-bit word per row) stores the same observations
+    env2 = VecEnv("pauli", n, gs, B, add_perms=False, track_solution=False, max_rotations=3, difficulty=4, depth_slope=1)
+    torch.manual_seed(1)
+    col2 = RolloutCollector(env2, Tiny(), dtype=torch.float32, seed=3, store_obs="packed")
+    ro2 = col2.collect(T)
+    torch.cuda.synchronize()
+    env2.sync()
+    assert ro2.obs_packed and ro2.obs.shape == (T, B, rows) and ro2.obs.dtype == torch.int64
+    assert torch.equal(ro2.dense_obs(torch.int8), ro.obs) and torch.equal(ro2.actions, ro.actions) and torch.equal(ro2.rewards, ro.rewards)
 
 
 

@@ -13,7 +13,7 @@ B = int(os.environ.get("B", "65536"))
 gs = line_gateset("pauli", 20)
 env = VecEnv("pauli", 20, gs, B, add_perms=False, track_solution=False, max_rotations=5, difficulty=int(os.environ.get("DIFF", "16")))
 r, c = env.obs_shape_
-col = RolloutCollector(env, BasicPolicy(r * c, len(gs)), dtype=torch.bfloat16, seed=1, store_obs="dense")
+col = RolloutCollector(env, BasicPolicy(r * c, len(gs)), dtype=torch.bfloat16, seed=1, store_obs=os.environ.get("STORE", "packed"))
 T = 16
 ro = col.collect(T)
 torch.cuda.synchronize()
