@@ -214,7 +214,10 @@ int qg_vec_rollout_ring(qg_vec *v, const void *actions_dev, int action_dtype, si
 /* Env::observe for every env, densified the way the Gym adapter does it (adapters.py:50-54):
  * out_dev[e * obs_rows*obs_cols + r*obs_cols + c] in {0,1}, int8. */
 int qg_vec_observe_dense(qg_vec *v, int8_t *out_dev, void *stream);
-/* Bit-packed observation in QG_FMT_PACKED layout (what the multi-GPU all-gather moves). */
+/* Bit-packed observation in QG_FMT_PACKED layout (what the multi-GPU all-gather moves): qg_vec_info.packed_words_per_env
+ * words of packed_word_bytes per env, one word per observation row, bit c = column c.  PauliEnv (thread-per-env family,
+ * at most 64 observation columns): one 64-bit word per row of the [2N, 2N + max_rotations] observation; the call counts
+ * as one Env::observe, i.e. it draws the add_perms permutation like qg_vec_observe_dense does. */
 int qg_vec_observe_packed(qg_vec *v, void *out_dev, void *stream);
 /* Env::masks (clifford.rs:349-351): out_dev[e*num_actions + a] = !success[e] */
 int qg_vec_masks(qg_vec *v, uint8_t *out_dev, void *stream);
