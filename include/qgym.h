@@ -263,7 +263,7 @@ int qg_vec_observe_dense_as(qg_vec *v, void *out_dev, int out_dtype, void *strea
  * column c; 1: PermutationEnv, the byte is the set column) -> out_dev[row * cols + c]. */
 int qg_expand_packed(const void *packed_dev, int word_bytes, uint64_t n_rows, uint32_t cols, void *out_dev, int out_dtype, void *stream);
 /* The int8 {0,1} observation of qg_vec_observe_dense (n_elems entries) in another dtype -- for
- * PauliEnv, whose observation has no packed form and whose observe() may draw a permutation, so it
+ * a PauliEnv observation taken once (observe() may draw a permutation) that has no row-word form, so it
  * is taken once and widened. */
 int qg_widen_dense(const int8_t *obs_dev, uint64_t n_elems, void *out_dev, int out_dtype, void *stream);
 /* One categorical draw per env from softmax(logits[e, 0:num_actions]) by an exponential race on

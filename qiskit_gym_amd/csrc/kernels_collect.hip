@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void expand_elems_kernel(const void *packed, i
     out[gid] = bit ? one : (T)0;
 }
 
-// dense int8 {0,1} -> dense dtype (PauliEnv, whose observation has no packed form): 16 input
+// dense int8 {0,1} -> dense dtype (PauliEnv families / widths without the row-word form): 16 input
 // bytes per thread
 template <int ES>
 __global__ __launch_bounds__(256) void widen01_kernel(const uint8_t *in, uint64_t n, void *out, uint32_t one) {
@@ -342,7 +342,7 @@ int qg_vec_observe_dense_as(qg_vec *v, void *out_dev, int out_dtype, void *strea
         HIP_TRY(e);
         return QG_OK;
     }
-    if (v->layout == LAYOUT_PAULI) {  // no packed form: int8 observation, then widen
+    if (v->layout == LAYOUT_PAULI) {  // lane-group family or more than 64 columns: int8 observation, then widen
         rc = ensure_scratch_public(v, v->B * obs);
         if (rc != QG_OK) return rc;
         rc = qg_vec_observe_dense(v, reinterpret_cast<int8_t *>(v->scratch), stream);
