@@ -46,7 +46,7 @@ def obs_times(env, reps=50):
     r, c = env.obs_shape_
     bufs = {"int8": env.observe(), "bf16": env.observe_as(torch.bfloat16)}
     calls = {"int8": lambda: env.observe(out=bufs["int8"]), "bf16": lambda: env.observe_as(torch.bfloat16, out=bufs["bf16"])}
-    if env.env_kind != "pauli":
+    if env.env_kind != "pauli" or c <= 64:
         bufs["packed"] = env.observe_packed()
         calls["packed"] = lambda: env.observe_packed(out=bufs["packed"])
     for name, fn in calls.items():
