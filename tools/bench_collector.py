@@ -25,5 +25,11 @@ for B, store, graph in ((1024, "packed", False), (1024, "packed", True), (8192, 
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     env.sync()
+    done_rate = float(ro.dones.float().mean())
+    del col, env, ro  # the next configuration starts from an empty allocator (graph pools of earlier ones otherwise stall its first collections)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
     print(f"B={B} obs stored {store}{' hipGraph' if graph else ''}: {3 * T * B / dt:.3e} env-steps/s with the policy in the loop ({dt / (3 * T) * 1e6:.0f} us per step), "
-          f"success rate in last rollout {float(ro.dones.float().mean()):.3f} done/step")
+          f"success rate in last rollout {done_rate:.3f} done/step")
