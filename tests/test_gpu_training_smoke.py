@@ -20,3 +20,13 @@ def test_ppo_on_collector_rollouts_learns_to_synthesise():
     start, end = sum(history[:3]) / 3, sum(history[-3:]) / 3
     assert start < 0.15, history[:3]          # an untrained policy rarely solves a 5-gate scramble in 10 steps
     assert end > 0.4 and end > 4 * start, (start, end)
+
+
+def test_ppo_learns_with_the_policy_layer_kernels_in_the_loop():
+    """CliffordGym 3q, bf16 collection on qg_vec_embed + qg_policy_mid_head_sample (weights re-packed from the f32 master
+    copy before every collection), f32 torch update: the solve rate must still go up."""
+    from ppo_linear_function import train
+
+    history = train(qubits=3, difficulty=4, envs=4096, horizon=10, iters=30, env_kind="clifford", bf16=True, log=lambda *_: None)
+    start, end = sum(history[:3]) / 3, sum(history[-3:]) / 3
+    assert end > 0.3 and end > 2 * start, (start, end, history)
