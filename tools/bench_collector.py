@@ -15,7 +15,9 @@ for B, store, graph in ((1024, "packed", False), (1024, "packed", True), (8192, 
         continue
     gs = line_gateset("clifford", 16)
     env = VecEnv("clifford", 16, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=int(os.environ.get("DIFF", "32")))
-    col = RolloutCollector(env, BasicPolicy(1024, len(gs)), dtype=torch.bfloat16, seed=1, store_obs=store, use_graph=graph)
+    fused = {"1": True, "0": False}.get(os.environ.get("FUSED", ""), None)  # FUSED=1 / 0 forces the policy-layer kernels on / off
+    col = RolloutCollector(env, BasicPolicy(1024, len(gs)), dtype=torch.bfloat16, seed=1, store_obs=store, use_graph=graph,
+                           use_bit_embedding=fused, use_fused_head=fused)
     T = 32
     ro = col.collect(T)
     torch.cuda.synchronize()
