@@ -672,6 +672,49 @@ __global__ __launch_bounds__(256) void qm_export_kernel(ObsArgs a, uint32_t nxp,
     }
 }
 
+// Packed observation (QG_FMT_PACKED with no padding between envs: out_stride == D): a wave turns one tile -- 64 envs, slots interleaved
+// per lane -- into the 64 * D contiguous row words of those envs.  Both sides are coalesced (1 KiB tile loads, 1 KiB stores when D % 4 == 0);
+// the transposition goes through LDS with a row pitch of D + 1 words (D is even for CliffordEnv: conflict-free across the lanes).
+__global__ __launch_bounds__(256) void qm_pack_kernel(ObsArgs a, uint32_t nxp, uint32_t has_z) {
+    __shared__ uint32_t lds[4][64 * 33];  // D <= 32 in this layout (uint32 rows)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t tile_idx = (uint64_t)blockIdx.x * 4u + wave;
+    const uint32_t R = has_z ? 2 * nxp : nxp, G = R / 4, D = a.D, pitch = D + 1u;
+    const uint64_t n_tiles = (a.B + 63u) / 64u;
+    uint32_t *my = lds[wave];
+    if (tile_idx < n_tiles) {
+        const uint4 *tile = reinterpret_cast<const uint4 *>(a.state) + tile_idx * (uint64_t)(G * 64);
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint4 v = tile[g * 64 + lane];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c) {
+                const uint32_t slot = 4u * g + c;
+                int32_t row;
+                if (has_z) row = (slot >> 1) < a.N ? (int32_t)((slot & 1u) ? a.N + (slot >> 1) : (slot >> 1)) : -1;
+                else row = slot < a.N ? (int32_t)slot : -1;
+                if (row >= 0) my[lane * pitch + (uint32_t)row] = w[c];
+            }
+        }
+    }
+    __syncthreads();
+    if (tile_idx >= n_tiles) return;
+    const uint64_t env0 = tile_idx * 64u;
+    const uint32_t envs = a.B - env0 < 64u ? (uint32_t)(a.B - env0) : 64u;
+    uint32_t *out = reinterpret_cast<uint32_t *>(a.out) + env0 * D;
+    if ((D & 3u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {
+        const uint32_t n4 = envs * D / 4u;
+        for (uint32_t i = lane; i < n4; i += 64u) {
+            const uint32_t e = (4u * i) / D, r = (4u * i) % D;
+            const uint32_t *p = my + e * pitch + r;
+            reinterpret_cast<uint4 *>(out)[i] = make_uint4(p[0], p[1], p[2], p[3]);
+        }
+    } else {
+        const uint32_t n = envs * D;
+        for (uint32_t i = lane; i < n; i += 64u) out[i] = my[(i / D) * pitch + (i % D)];
+    }
+}
+
 // Dense int8 observation for D == 32 (CliffordEnv N = 16): one lane expands one packed row into
 // 32 bytes (two 16 B stores); a wave writes 2 KiB contiguously.
 __global__ __launch_bounds__(256) void qm_dense32_kernel(ObsArgs a) {
@@ -774,6 +817,10 @@ hipError_t qm_export(const ObsArgs &a, uint32_t nxp, bool has_z, hipStream_t s) 
     if (!a.B) return hipSuccess;
     if (has_z && a.N == 16 && a.format == QG_FMT_U8 && a.out_stride == 1024 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
         hipLaunchKernelGGL(qm_dense32_kernel, dim3(grid_for(a.B * 32ull, 256)), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
+    if (a.format == QG_FMT_PACKED && a.out_stride == a.D && a.D <= 32 && (reinterpret_cast<uintptr_t>(a.out) & 3) == 0) {
+        hipLaunchKernelGGL(qm_pack_kernel, dim3((unsigned)((a.B + 255) / 256)), dim3(256), 0, s, a, nxp, has_z ? 1u : 0u);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(qm_export_kernel, dim3(grid_for(a.B * a.D, 256)), dim3(256), 0, s, a, nxp, has_z ? 1u : 0u);
