@@ -29,4 +29,4 @@ def test_ppo_learns_with_the_policy_layer_kernels_in_the_loop():
 
     history = train(qubits=3, difficulty=4, envs=4096, horizon=10, iters=30, env_kind="clifford", bf16=True, log=lambda *_: None)
     start, end = sum(history[:3]) / 3, sum(history[-3:]) / 3
-    assert end > 0.3 and end > 2 * start, (start, end, history)
+    assert end > 0.2 and end > 10 * start, (start, end, history)  # seed 0: 0.008 -> 0.37 (deterministic kernels; margin for library GEMM choices)
