@@ -22,6 +22,7 @@ CASES = [  # kind, qubits, batch, hidden
     ("linear_function", 17, 513, 64),
     ("linear_function", 27, 300, 64),   # 7 row groups (padded to 8 in the slab)
     ("clifford", 3, 200, 64),           # 2 row groups
+    ("clifford", 16, 2048, 1024),       # 16 column slabs
 ]
 
 
