@@ -182,12 +182,27 @@ __device__ inline uint32_t qm_cols_from_slots(uint32_t w, uint32_t N, uint32_t n
     return (w & xm) | (((w >> nxp) & xm) << N);
 }
 
-// in-register 32x32 bit-matrix transpose (a[r] bit c <-> a[c] bit r)
+// in-register 32x32 bit-matrix transpose (a[r] bit c <-> a[c] bit r): five butterfly stages; the two coarse ones exchange whole
+// bytes, which v_perm_b32 does in one instruction per output word instead of the three of the shift / mask / xor form
 __device__ inline void qm_transpose32(uint32_t (&a)[32]) {
 #pragma unroll
-    for (int st = 0; st < 5; ++st) {
+    for (int k = 0; k < 16; ++k) {  // stage 16: high halfword of a[k] <-> low halfword of a[k + 16]
+        const uint32_t lo = a[k], hi = a[k + 16];
+        a[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        a[k + 16] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {  // stage 8: odd bytes of a[k] <-> even bytes of a[k + 8]
+        if ((k & 8) == 0) {
+            const uint32_t lo = a[k], hi = a[k + 8];
+            a[k] = __builtin_amdgcn_perm(hi, lo, 0x06020400u);
+            a[k + 8] = __builtin_amdgcn_perm(hi, lo, 0x07030501u);
+        }
+    }
+#pragma unroll
+    for (int st = 2; st < 5; ++st) {
         const int j = 16 >> st;
-        const uint32_t m = st == 0 ? 0x0000FFFFu : st == 1 ? 0x00FF00FFu : st == 2 ? 0x0F0F0F0Fu : st == 3 ? 0x33333333u : 0x55555555u;
+        const uint32_t m = st == 2 ? 0x0F0F0F0Fu : st == 3 ? 0x33333333u : 0x55555555u;
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
             if ((k & j) == 0) {
