@@ -28,6 +28,8 @@
 // combinations of themselves given by the 4x4 bit matrix M (H, S, SX, CX, CZ, SWAP and "no gate"
 // are all of this form).  Per-lane row selection is a compare + conditional-move sweep over the
 // register file, the identity test an xor/or sweep.
+#include <cstdlib>
+
 #include "device_common.hpp"
 
 namespace qg {
@@ -561,6 +563,104 @@ __global__ __launch_bounds__(256) void qm_step1_kernel(StepArgs a) {
     if (FEAT && fault) atomicOr(&a.error[env], fault);
 }
 
+// Fused rollout on LDS-resident rows (T steps per launch, plain configuration: no add_inverts, no solution log, default
+// weights).  The register-resident fused kernel pays ~300 VALU instructions per env-step for select trees over 32 row
+// registers; here the env's rows live in LDS as [slot][lane] (one column per lane: any per-lane slot is conflict-free), so a
+// gate is four dynamic-index LDS reads, the 4x4 GF(2) mix and four writes, and `solved` is the incremental mask of the
+// one-step kernel.  Actions and gate entries of the next four steps are fetched ahead of the dependent LDS chain.
+template <int NXP, bool HAS_Z, bool ACT64>
+__global__ __launch_bounds__(256) void qm_fused_lds_kernel(StepArgs a) {
+    using Rows = QmRows<NXP, HAS_Z>;
+    __shared__ uint32_t lds_rows[4][Rows::R][QG_WAVE];
+    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    if (env >= a.B) return;  // no cross-lane operation and no barrier below
+    uint32_t (*rows)[QG_WAVE] = lds_rows[threadIdx.x >> 6];
+    uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Rows::G * 64);
+    uint32_t bad;
+    {
+        Rows s;
+        qm_load<NXP, HAS_Z>(tile, lane, s);
+        bad = qm_badmask<NXP, HAS_Z>(s, a.N);
+#pragma unroll
+        for (int k = 0; k < Rows::R; ++k) rows[k][lane] = s.r[k];
+    }
+    int32_t depth = a.depth[env];
+    const uint32_t zb = 1u << a.N;
+    float reward = 0.0f;
+    bool solved = bad == 0;
+    // two-stage prefetch, four steps per stage: while batch k is applied, the gate entries of batch k + 1 are in flight (their
+    // actions arrived during batch k - 1) and so are the actions of batch k + 2 -- nothing on the LDS chain waits for global memory
+    // every load is unconditional (clamped index, result selected afterwards): behind a branch the compiler waits for each load
+    // before issuing the next one, which serialises eight memory round trips per four steps
+    auto load_act = [&](uint32_t t) -> int64_t {
+        const uint64_t i = (uint64_t)(t < a.T ? t : a.T - 1u) * a.B + env;
+        const int64_t v = ACT64 ? reinterpret_cast<const int64_t *>(a.actions)[i] : (int64_t) reinterpret_cast<const int32_t *>(a.actions)[i];
+        return t < a.T ? v : -1;
+    };
+    auto load_gate = [&](int64_t act, GateEntry &g) {
+        const bool ok = act >= 0 && act < (int64_t)a.num_actions;  // gateset.get(action) (clifford.rs:324)
+        const GateEntry e = a.gates[ok ? act : 0];
+        g.ops = ok ? e.ops : (QM_IDENTITY << 10);
+        g.penalty = ok ? e.penalty : 0.0f;
+    };
+    auto step = [&](uint32_t t, const GateEntry &g) {
+        if (t >= a.T) return;
+        const uint32_t q0 = g.ops & 31u, q1 = (g.ops >> 5) & 31u, m = (g.ops >> 10) & 0xFFFFu;
+        if (m != QM_IDENTITY) {
+            const uint32_t sx0 = HAS_Z ? 2u * q0 : q0, sx1 = HAS_Z ? 2u * q1 : q1;
+            const uint32_t x0 = rows[sx0][lane], x1 = rows[sx1][lane];
+            const uint32_t z0 = HAS_Z ? rows[sx0 + 1u][lane] : 0u, z1 = HAS_Z ? rows[sx1 + 1u][lane] : 0u;
+            auto mix = [&](uint32_t k) -> uint32_t {  // out_k = xor_i M[k][i] * in_i
+                const uint32_t b = m >> (4 * k);
+                uint32_t o = ((0u - (b & 1u)) & x0) ^ ((0u - ((b >> 2) & 1u)) & x1);
+                if (HAS_Z) o ^= ((0u - ((b >> 1) & 1u)) & z0) ^ ((0u - ((b >> 3) & 1u)) & z1);
+                return o;
+            };
+            const uint32_t nx0 = mix(0), nx1 = mix(2), nz0 = HAS_Z ? mix(1) : 0u, nz1 = HAS_Z ? mix(3) : 0u;
+            // q1's rows first, then q0's (q0's value wins when q0 == q1, as in qm_apply)
+            rows[sx1][lane] = nx1;
+            if (HAS_Z) rows[sx1 + 1u][lane] = nz1;
+            rows[sx0][lane] = nx0;
+            if (HAS_Z) rows[sx0 + 1u][lane] = nz0;
+            const uint32_t b1 = (uint32_t)(nx1 != (1u << q1) || (HAS_Z && nz1 != (zb << q1)));
+            const uint32_t b0 = (uint32_t)(nx0 != (1u << q0) || (HAS_Z && nz0 != (zb << q0)));
+            bad = (bad & ~(1u << q1)) | (b1 << q1);
+            bad = (bad & ~(1u << q0)) | (b0 << q0);
+        }
+        depth = depth > 0 ? depth - 1 : 0;  // clifford.rs:342
+        solved = bad == 0;                   // clifford.rs:344
+        const float achieved = solved ? 1.0f : 0.0f;
+        reward = achieved - g.penalty;       // clifford.rs:345-346
+        if (a.rewards_seq) a.rewards_seq[(uint64_t)t * a.B + env] = reward;
+        if (a.dones_seq) a.dones_seq[(uint64_t)t * a.B + env] = (uint8_t)(depth == 0 || solved);
+    };
+    GateEntry cur[4], nxt[4];
+    int64_t acts[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) load_gate(load_act(k), cur[k]);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) acts[k] = load_act(4 + k);
+    for (uint32_t t = 0; t < a.T; t += 4) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) load_gate(acts[k], nxt[k]);      // batch t + 4
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) acts[k] = load_act(t + 8 + k);   // batch t + 8
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) step(t + k, cur[k]);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) cur[k] = nxt[k];
+    }
+#pragma unroll
+    for (int g = 0; g < Rows::G; ++g)
+        tile[g * 64 + lane] = make_uint4(rows[4 * g][lane], rows[4 * g + 1][lane], rows[4 * g + 2][lane], rows[4 * g + 3][lane]);
+    a.depth[env] = depth;
+    a.reward[env] = reward;
+    a.done[env] = (uint8_t)(depth == 0 || solved);  // is_final (clifford.rs:353)
+    a.success[env] = (uint8_t)solved;
+    if (a.bad) a.bad[env] = bad;
+}
+
 // slot of matrix row `row`
 __device__ inline uint32_t qm_slot(uint32_t row, uint32_t N, uint32_t nxp, bool has_z) {
     (void)nxp;
@@ -785,6 +885,14 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
         if (!HAS_Z || (a.flags & F_GJ)) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true, false>), grid, block, 0, s, a);
         return hipGetLastError();
+    }
+    if (!feat && seq && a.T > 1 && !getenv("QGYM_FUSED_REGS")) {  // plain fused rollout (QGYM_FUSED_REGS=1: the register-resident form, for A/B timing)
+        if (a.num_actions == 0) { /* an empty gateset has no table to read: the register-resident kernel below handles it */
+        } else {
+            if (a.flags & F_ACT64) hipLaunchKernelGGL((qm_fused_lds_kernel<NXP, HAS_Z, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((qm_fused_lds_kernel<NXP, HAS_Z, false>), grid, block, 0, s, a);
+            return hipGetLastError();
+        }
     }
     if (feat && seq) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true>), grid, block, 0, s, a);
     else if (feat) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, false>), grid, block, 0, s, a);
