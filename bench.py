@@ -312,7 +312,8 @@ def main():
             f1.record(stream)
         torch.cuda.synchronize()
         fms = f0.elapsed_time(f1)
-        fused = {"value": B * FT * 8 / (fms * 1e-3), "unit": "env-steps/s", "steps_per_launch": FT}
+        fused = {"value": B * FT * 8 / (fms * 1e-3), "unit": "env-steps/s", "steps_per_launch": FT,
+                 "kernel": "qg::qm_fused_lds_kernel<16, true, false> (rows resident in LDS; actions known up front)"}
 
     # ---- the same step kernel at 2^20 envs: where the launch boundary (1.6 us) stops dominating -----
     large = None
