@@ -559,6 +559,98 @@ __global__ __launch_bounds__(256) void q64_export_kernel(ObsArgs a, uint32_t ns,
 
 static inline unsigned grid_for(uint64_t threads, unsigned block) { return (unsigned)((threads + block - 1) / block); }
 
+// Fused rollout on LDS-resident rows: the uint64 counterpart of qm_fused_lds_kernel (kernels_qm.hip) -- one wave per workgroup,
+// rows as [slot][lane] (NS x 512 B <= 32 KiB), a gate = four dynamic-index 64-bit LDS reads, the 4x4 GF(2) mix, four writes; the
+// incremental 64-bit `bad` mask gives `solved`; actions and gate entries two batches of four steps ahead, all loads unconditional.
+template <int NS, bool HAS_Z, bool ACT64>
+__global__ __launch_bounds__(64) void q64_fused_lds_kernel(StepArgs a) {
+    __shared__ uint64_t rows[NS][QG_WAVE];
+    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    if (env >= a.B) return;  // no cross-lane operation and no barrier below
+    uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Q64Rows<NS>::G * 64);
+    uint64_t bad;
+    {
+        Q64Rows<NS> s;
+        q64_load<NS>(tile, lane, s);
+        bad = q64_badmask<NS, HAS_Z>(s, a.N);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) rows[k][lane] = s.r[k];
+    }
+    int32_t depth = a.depth[env];
+    const uint64_t zb = 1ull << a.N;
+    float reward = 0.0f;
+    bool solved = bad == 0;
+    auto load_act = [&](uint32_t t) -> int64_t {
+        const uint64_t i = (uint64_t)(t < a.T ? t : a.T - 1u) * a.B + env;
+        const int64_t v = ACT64 ? reinterpret_cast<const int64_t *>(a.actions)[i] : (int64_t) reinterpret_cast<const int32_t *>(a.actions)[i];
+        return t < a.T ? v : -1;
+    };
+    auto load_gate = [&](int64_t act, GateEntry &g) {
+        const bool ok = act >= 0 && act < (int64_t)a.num_actions;  // gateset.get(action) (clifford.rs:324)
+        const GateEntry e = a.gates[ok ? act : 0];
+        g.ops = ok ? e.ops : (Q64_IDENTITY << 12);
+        g.penalty = ok ? e.penalty : 0.0f;
+    };
+    auto step = [&](uint32_t t, const GateEntry &g) {
+        if (t >= a.T) return;
+        const uint32_t q0 = g.ops & 63u, q1 = (g.ops >> 6) & 63u, m = (g.ops >> 12) & 0xFFFFu;
+        if (m != Q64_IDENTITY) {
+            const uint32_t sx0 = HAS_Z ? 2u * q0 : q0, sx1 = HAS_Z ? 2u * q1 : q1;
+            const uint64_t x0 = rows[sx0][lane], x1 = rows[sx1][lane];
+            const uint64_t z0 = HAS_Z ? rows[sx0 + 1u][lane] : 0ull, z1 = HAS_Z ? rows[sx1 + 1u][lane] : 0ull;
+            auto mix = [&](uint32_t k) -> uint64_t {
+                const uint32_t b = m >> (4 * k);
+                uint64_t o = ((0ull - (uint64_t)(b & 1u)) & x0) ^ ((0ull - (uint64_t)((b >> 2) & 1u)) & x1);
+                if (HAS_Z) o ^= ((0ull - (uint64_t)((b >> 1) & 1u)) & z0) ^ ((0ull - (uint64_t)((b >> 3) & 1u)) & z1);
+                return o;
+            };
+            const uint64_t nx0 = mix(0), nx1 = mix(2), nz0 = HAS_Z ? mix(1) : 0ull, nz1 = HAS_Z ? mix(3) : 0ull;
+            // q1's rows first, then q0's (q0's value wins when q0 == q1, as in q64_apply)
+            rows[sx1][lane] = nx1;
+            if (HAS_Z) rows[sx1 + 1u][lane] = nz1;
+            rows[sx0][lane] = nx0;
+            if (HAS_Z) rows[sx0 + 1u][lane] = nz0;
+            const uint64_t b1 = (uint64_t)(nx1 != (1ull << q1) || (HAS_Z && nz1 != (zb << q1)));
+            const uint64_t b0 = (uint64_t)(nx0 != (1ull << q0) || (HAS_Z && nz0 != (zb << q0)));
+            bad = (bad & ~(1ull << q1)) | (b1 << q1);
+            bad = (bad & ~(1ull << q0)) | (b0 << q0);
+        }
+        depth = depth > 0 ? depth - 1 : 0;  // clifford.rs:342
+        solved = bad == 0;                   // clifford.rs:344
+        const float achieved = solved ? 1.0f : 0.0f;
+        reward = achieved - g.penalty;       // clifford.rs:345-346
+        if (a.rewards_seq) a.rewards_seq[(uint64_t)t * a.B + env] = reward;
+        if (a.dones_seq) a.dones_seq[(uint64_t)t * a.B + env] = (uint8_t)(depth == 0 || solved);
+    };
+    GateEntry cur[4], nxt[4];
+    int64_t acts[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) load_gate(load_act(k), cur[k]);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) acts[k] = load_act(4 + k);
+    for (uint32_t t = 0; t < a.T; t += 4) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) load_gate(acts[k], nxt[k]);      // batch t + 4
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) acts[k] = load_act(t + 8 + k);   // batch t + 8
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) step(t + k, cur[k]);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) cur[k] = nxt[k];
+    }
+#pragma unroll
+    for (int g = 0; g < Q64Rows<NS>::G; ++g) {
+        const uint64_t r0 = rows[2 * g][lane], r1 = rows[2 * g + 1][lane];
+        tile[g * 64 + lane] = make_uint4((uint32_t)r0, (uint32_t)(r0 >> 32), (uint32_t)r1, (uint32_t)(r1 >> 32));
+    }
+    a.depth[env] = depth;
+    a.reward[env] = reward;
+    a.done[env] = (uint8_t)(depth == 0 || solved);
+    a.success[env] = (uint8_t)solved;
+    if (a.bad) reinterpret_cast<uint64_t *>(a.bad)[env] = bad;
+}
+
 template <int NS, bool HAS_Z>
 static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
     const dim3 grid(grid_for(a.B, 256)), block(256);
@@ -566,6 +658,12 @@ static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
     if (a.bad && a.T == 1 && !(a.flags & F_INVERTS)) {  // the env.step() path
         if (a.flags & (F_TRACK | F_LAYERS)) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, false>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
+    if (a.T > 1 && !(a.flags & (F_TRACK | F_LAYERS | F_INVERTS)) && a.num_actions) {  // plain fused rollout: rows in LDS, one wave per workgroup
+        const dim3 g1(grid_for(a.B, 64)), b1(64);
+        if (a.flags & F_ACT64) hipLaunchKernelGGL((q64_fused_lds_kernel<NS, HAS_Z, true>), g1, b1, 0, s, a);
+        else hipLaunchKernelGGL((q64_fused_lds_kernel<NS, HAS_Z, false>), g1, b1, 0, s, a);
         return hipGetLastError();
     }
     if constexpr (HAS_Z) {

@@ -110,16 +110,22 @@ def test_layer_weighted_rewards(kind, n):
         _compare_step(ov, gv, rng.integers(0, A, size=200), label=f"t={t}")
 
 
-def test_rollout_graph_and_fused_match_single_steps():
-    gateset = line_gateset("clifford", 16)
+@pytest.mark.parametrize("kind,n,adt", [("clifford", 16, "int64"), ("clifford", 5, "int32"), ("clifford", 20, "int32"), ("clifford", 32, "int64"),
+                                        ("linear_function", 12, "int32"), ("linear_function", 40, "int64"), ("linear_function", 64, "int32")])
+def test_rollout_graph_and_fused_match_single_steps(kind, n, adt):
+    """qg_vec_rollout as a replayed graph of single steps and as one fused launch (rows resident in LDS) against per-step oracle
+    calls: TILE and TILE64 layouts, both action dtypes, a step count that is not a multiple of the prefetch batch, and some
+    out-of-range actions (a no-op for the state that still consumes depth, clifford.rs:324,342)."""
+    gateset = line_gateset(kind, n)
     A = len(gateset)
-    B, T = 2048, 16
-    ov, gv = make_pair("clifford", 16, gateset, B, add_inverts=False, add_perms=False, track_solution=False)
-    from qiskit_gym_amd.vec import VecEnv
-
-    rng = np.random.default_rng(7)
+    B, T = 1000, 19
+    ov, gv = make_pair(kind, n, gateset, B, add_inverts=False, add_perms=False, track_solution=False)
+    tdt = getattr(torch, adt)
+    rng = np.random.default_rng(7 + n)
     draws = rng.integers(0, A, size=(64, B))
     acts = rng.integers(0, A, size=(T, B))
+    acts[rng.random((T, B)) < 0.03] = A        # invalid: one past the end
+    acts[rng.random((T, B)) < 0.02] = -1       # invalid: negative
     rew_o = np.zeros((T, B), np.float32)
     fin_o = np.zeros((T, B), np.uint8)
     ov.proto.difficulty = 64
@@ -129,22 +135,30 @@ def test_rollout_graph_and_fused_match_single_steps():
     for t in range(T):
         r, s, f, d = ov.step(acts[t])
         rew_o[t], fin_o[t] = r, f
-    want_state = ov.get_state(1024)
+    want_state = ov.get_state(4 * n * n if kind == "clifford" else n * n)
     for fused in (False, True):
         gv.difficulty = 64
         gv.reset_with(_dev(draws, torch.int32))
         rew = torch.zeros((T, B), dtype=torch.float32, device="cuda")
         fin = torch.zeros((T, B), dtype=torch.uint8, device="cuda")
-        gv.rollout(_dev(acts, torch.int64), fused=fused, rewards_out=rew, dones_out=fin)
+        gv.rollout(_dev(acts, tdt), fused=fused, rewards_out=rew, dones_out=fin)
         gv.sync()
         np.testing.assert_array_equal(f32_bits(rew.cpu().numpy()), f32_bits(rew_o))
         np.testing.assert_array_equal(fin.cpu().numpy(), fin_o)
         np.testing.assert_array_equal(gv.get_state("i64").cpu().numpy(), want_state)
         if not fused:  # replay the cached graph once more from the same start
             gv.reset_with(_dev(draws, torch.int32))
-            gv.rollout(_dev(acts, torch.int64), fused=False, rewards_out=rew, dones_out=fin)
+            gv.rollout(_dev(acts, tdt), fused=False, rewards_out=rew, dones_out=fin)
             gv.sync()
             np.testing.assert_array_equal(gv.get_state("i64").cpu().numpy(), want_state)
+    # one more step on both sides: success / depth / is_final carried out of the fused launch are the oracle's
+    last = rng.integers(0, A, size=B)
+    r, s, f, d = ov.step(last)
+    gv.step(_dev(last, torch.int32))
+    gv.sync()
+    np.testing.assert_array_equal(gv.success.cpu().numpy(), s)
+    np.testing.assert_array_equal(gv.depth.cpu().numpy(), d)
+    np.testing.assert_array_equal(f32_bits(gv.reward.cpu().numpy()), f32_bits(r))
 
 
 def test_device_reset_matches_replayed_draws():
