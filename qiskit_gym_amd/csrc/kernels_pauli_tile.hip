@@ -642,6 +642,8 @@ __global__ __launch_bounds__(256) void ptile_step1_kernel(PTArgs pa) {
     const StepArgs &a = pa.s;
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
+    asm volatile("" ::"s"(pa.prog), "s"(pa.n_perms));
     if (env >= a.B) return;
     const uint32_t N = a.N;
     char *tile = L::tile(a.state, env);
@@ -774,6 +776,8 @@ __global__ __launch_bounds__(256) void ptile_step1c_kernel(PTArgs pa) {
     const StepArgs &a = pa.s;
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
+    asm volatile("" ::"s"(pa.prog), "s"(pa.n_perms));
     if (env >= a.B) return;
     const uint32_t N = a.N;
     char *tile = L::tile(a.state, env);

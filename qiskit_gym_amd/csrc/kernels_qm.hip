@@ -500,6 +500,7 @@ __global__ __launch_bounds__(256) void qm_step1_kernel(StepArgs a) {
     using Rows = QmRows<NXP, HAS_Z>;
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
     if (env >= a.B) return;
     uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Rows::G * 64);
     const int64_t act = load_action(a.actions, env, a.flags & F_ACT64);

@@ -371,6 +371,7 @@ template <int NS, bool HAS_Z, bool FEAT>
 __global__ __launch_bounds__(256) void q64_step1_kernel(StepArgs a) {
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
     if (env >= a.B) return;
     uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Q64Rows<NS>::G * 64);
     uint64_t *badp = reinterpret_cast<uint64_t *>(a.bad) + env;

@@ -70,6 +70,7 @@ __device__ inline uint64_t perm_invert(uint64_t s, uint32_t N) {  // permutation
 template <bool PERM>
 __global__ __launch_bounds__(256) void word_step_kernel(StepArgs a) {
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
     if (env >= a.B) return;
     const bool act64 = a.flags & F_ACT64;
     uint64_t *sp = reinterpret_cast<uint64_t *>(a.state) + env;
