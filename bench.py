@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the CPU-oracle replay of the timed run")
+    ap.add_argument("--no-large-batch", action="store_true", help="skip the 2^20-env leg (profiling runs: keeps the kernel statistics to one batch size)")
     ap.add_argument("--no-gather", action="store_true", help="N>1 diagnostics: skip the per-step all-gather")
     ap.add_argument("--gather-every", type=int, default=CHUNK,
                     help="N>1: all-gather the packed observation every this many steps (1 = after every step)")
@@ -317,7 +318,7 @@ def main():
 
     # ---- the same step kernel at 2^20 envs: where the launch boundary (1.6 us) stops dominating -----
     large = None
-    if not multi and B == ENVS_PER_GPU:
+    if not multi and B == ENVS_PER_GPU and not args.no_large_batch:
         LB = 1 << 20
         big = VecEnv("clifford", n, gateset, LB, add_inverts=False, add_perms=False, track_solution=False, difficulty=SCRAMBLE)
         bacts = torch.randint(0, A, (RING, LB), dtype=torch.int32, device=dev, generator=gen)

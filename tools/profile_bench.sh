@@ -11,10 +11,10 @@ OUT="$ROOT/gpurun_out/prof"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/qg_prof && mkdir -p /tmp/qg_prof
-rocprofv3 --kernel-trace --stats -d /tmp/qg_prof/stats -o bench --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-parity > "$OUT/stats_run.log" 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/qg_prof/stats -o bench --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-parity --no-large-batch > "$OUT/stats_run.log" 2>&1
 cp /tmp/qg_prof/stats/*kernel_stats.csv "$OUT/bench_kernel_stats.csv" 2>/dev/null
 for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --kernel-trace -d /tmp/qg_prof/$C -o pmc --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-parity --steps 512 --warmup 64 > "$OUT/pmc_$C.log" 2>&1
+    rocprofv3 --pmc $C --kernel-trace -d /tmp/qg_prof/$C -o pmc --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-parity --no-large-batch --steps 512 --warmup 64 > "$OUT/pmc_$C.log" 2>&1
     F=$(ls /tmp/qg_prof/$C/*counter_collection.csv 2>/dev/null | head -1)
     # keep the step kernel's dispatches only (the file is large): header + rows of the dominant kernel
     if [ -n "$F" ]; then (head -1 "$F"; grep "qm_step1_kernel<16, true, false>" "$F") > "$OUT/pmc_$C.csv"; fi
