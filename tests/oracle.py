@@ -17,7 +17,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
-_LIB_PATH = os.path.join(ORACLE_DIR, "libqgym_oracle.so")
+# QGYM_ORACLE_ASAN=1 (with LD_PRELOAD=$(gcc -print-file-name=libasan.so)): run the CPU tests on the address/UB-sanitizer build
+_LIB_NAME = "libqgym_oracle_asan.so" if os.environ.get("QGYM_ORACLE_ASAN") else "libqgym_oracle.so"
+_LIB_PATH = os.path.join(ORACLE_DIR, _LIB_NAME)
 
 GATE_KINDS = {"h": 0, "s": 1, "sdg": 2, "sx": 3, "sxdg": 4, "cx": 5, "cz": 6, "swap": 7}
 ENV_KINDS = {"permutation": 0, "linear_function": 1, "clifford": 2, "pauli": 3}
@@ -58,7 +60,7 @@ def build(force: bool = False) -> str:
         or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))
     )
     if stale:
-        subprocess.run(["make", "-C", ORACLE_DIR, "libqgym_oracle.so"], check=True, capture_output=True)
+        subprocess.run(["make", "-C", ORACLE_DIR, _LIB_NAME], check=True, capture_output=True)
     return _LIB_PATH
 
 
