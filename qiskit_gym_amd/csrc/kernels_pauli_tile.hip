@@ -911,6 +911,126 @@ __global__ __launch_bounds__(256) void ptile_step1c_kernel(PTArgs pa) {
     if (fault) atomicOr(&a.error[env], fault);
 }
 
+// Fused rollout on the compact layout (T steps per launch; plain configuration: no solution log, default weights, no
+// action permutation).  The dense fused kernel keeps all 2N rows in VGPRs and pays select trees over them for every gate;
+// here the wave's tile is copied verbatim into LDS (its [group][lane] form is bank-conflict-free for per-lane groups: 12- and
+// 8-byte lane strides), every step is the one-step kernel's gather / mix / scatter against LDS, and the DAG bookkeeping,
+// phase and weight planes stay in registers for the whole rollout.  Actions are fetched two steps ahead and the gate
+// program one step ahead with unconditional (clamped) loads, so the per-step chain never waits for global memory.
+template <int NQ, int RM>
+__global__ __launch_bounds__(64) void ptile_fused1c_kernel(PTArgs pa) {
+    using L = PTLayout<NQ, RM>;
+    static_assert(L::COMPACT && RM == 8, "compact layout only");
+    constexpr uint32_t VEC = L::TILE_BYTES / 16u;  // uint4 per tile, a multiple of 64
+    static_assert(L::TILE_BYTES % 1024u == 0, "tile = whole 1 KiB groups");
+    __shared__ uint4 lds_tile[VEC];
+    const StepArgs &a = pa.s;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t env = (uint64_t)blockIdx.x * QG_WAVE + lane;
+    uint4 *gtile = reinterpret_cast<uint4 *>(L::tile(a.state, (uint64_t)blockIdx.x * QG_WAVE));
+#pragma unroll 4
+    for (uint32_t i = 0; i < VEC; i += QG_WAVE) lds_tile[i + lane] = gtile[i + lane];
+    __syncthreads();
+    char *tile = reinterpret_cast<char *>(lds_tile);
+    const uint32_t N = a.N;
+
+    if (env < a.B) {
+        const bool act64 = a.flags & F_ACT64;
+        PTState<NQ, RM> s;  // rpred / phases / bookkeeping only
+        const uint4 m0 = *L::meta(tile, lane);
+        const uint2 pv = *L::rotgroup(tile, lane, 6), pw0 = *L::rotgroup(tile, lane, 7);
+        int32_t depth = a.depth[env];
+        s.alive = m0.x & 0xFFFFu;
+        s.count = m0.x >> 16;
+        s.bad = m0.y;
+        s.order = (uint64_t)m0.z | ((uint64_t)m0.w << 32);
+#pragma unroll
+        for (int k = 0; k < RM; ++k) s.rpred[k] = ((k < 4 ? pv.x : pv.y) >> (8 * (k & 3))) & 0xFFu;
+        s.plo = pw0.x & 0xFFu;
+        s.phi = (pw0.x >> 8) & 0xFFu;
+        uint32_t w[5] = {(pw0.x >> 16) & 0xFFu, pw0.x >> 24, pw0.y & 0xFFu, (pw0.y >> 8) & 0xFFu, (pw0.y >> 16) & 0xFFu};
+        uint32_t fault = 0;
+        bool solved = false;
+        float reward = 0.0f;
+
+        auto fetch = [&](uint32_t t) { return load_action(a.actions, (uint64_t)(t < a.T ? t : a.T - 1u) * a.B + env, act64); };
+        struct Decoded { uint64_t prog; float penalty; bool in_range; };
+        auto decode = [&](int64_t act) {
+            Decoded d;
+            d.in_range = act >= 0 && act < (int64_t)a.num_actions;  // pauli.rs:601
+            const int64_t i = d.in_range ? act : 0;
+            d.prog = pa.prog[i];
+            d.penalty = a.gates[i].penalty;
+            return d;
+        };
+        Decoded nxt = decode(fetch(0));
+        int64_t act1 = fetch(1);
+        for (uint32_t t = 0; t < a.T; ++t) {
+            const Decoded cur = nxt;
+            const int64_t act2 = fetch(t + 2u);
+            nxt = decode(act1);
+            act1 = act2;
+            const uint64_t prog = cur.prog;
+            const float penalty = cur.in_range ? cur.penalty : 0.0f;
+            const uint32_t qa = (uint32_t)prog & 31u, qb = (uint32_t)(prog >> 5) & 31u, m = (uint32_t)(prog >> 10) & 0xFFFFu;
+            uint32_t n_removed = 0;
+            uint64_t rem_pos[(RM + 7) / 8] = {};
+            if (cur.in_range) {
+                uint64_t xa, za, xb, zb, n[4];
+                L::load_qubit(tile, lane, qa, xa, za);
+                L::load_qubit(tile, lane, qb, xb, zb);
+                const uint32_t two = qa != qb;
+                const uint32_t sva = *L::xz(tile, lane, qa), svb = *L::xz(tile, lane, qb);
+                pt_mix(m, xa, za, xb, zb, n);
+                if (two) L::store_qubit(tile, lane, qb, n[2], n[3]);
+                L::store_qubit(tile, lane, qa, n[0], n[1]);
+                s.bad = pt_bad_update(s.bad, N, qa, qb, n);
+                PTSlices<RM> v;
+                v.xa = sva & 0xFFu;
+                v.za = sva >> 8;
+                v.xb = two ? svb & 0xFFu : 0u;
+                v.zb = two ? svb >> 8 : 0u;
+                planes_sub(w, v.xa | v.za);  // weights outside {qa, qb}
+                planes_sub(w, v.xb | v.zb);
+                const uint32_t hi = w[1] | w[2] | w[3] | w[4];
+                v.b0 = ~(w[0] | hi) & 0xFFu;
+                v.b1 = w[0] & ~hi & 0xFFu;
+                const PTSlices<RM> v0 = v;
+#pragma unroll
+                for (uint32_t k = 0; k < 3; ++k) {  // PauliNetwork::act (pauli_network.rs:225-260)
+                    const uint32_t mo = (uint32_t)(prog >> (26 + 4 * k)) & 15u;
+                    const uint32_t kind = mo & 7u;
+                    pt_slices_evolve<NQ, RM>(s, v, kind, (mo & 8u) != 0);
+                    if (kind == M_CNOT)
+                        pt_slices_clean<NQ, RM>(s, v, qa, qb, n_removed, fault, nullptr, rem_pos, [](uint32_t, uint32_t &ox, uint32_t &oz) { ox = oz = 0; });
+                }
+                planes_add(w, v.xa | v.za);
+                planes_add(w, v.xb | v.zb);
+                if ((v.xa ^ v0.xa) | (v.za ^ v0.za)) *L::xz(tile, lane, qa) = (uint16_t)(v.xa | (v.za << 8));
+                if ((v.xb ^ v0.xb) | (v.zb ^ v0.zb)) *L::xz(tile, lane, qb) = (uint16_t)(v.xb | (v.zb << 8));
+            }
+            depth = depth > 0 ? depth - 1 : 0;  // pauli.rs:630
+            solved = pt_solved<NQ, RM>(s);
+            const float achieved = solved ? 1.0f : 0.0f;
+            const float tmp = achieved - penalty;
+            const float bonus = a.pauli_layer_reward * (float)n_removed;
+            reward = tmp + bonus;  // pauli.rs:634
+            if (a.rewards_seq) a.rewards_seq[(uint64_t)t * a.B + env] = reward;
+            if (a.dones_seq) a.dones_seq[(uint64_t)t * a.B + env] = (uint8_t)(depth == 0 || solved);
+        }
+        *L::rotgroup(tile, lane, 7) = make_uint2((s.plo & 0xFFu) | ((s.phi & 0xFFu) << 8) | (w[0] << 16) | (w[1] << 24), w[2] | (w[3] << 8) | (w[4] << 16));
+        *L::meta(tile, lane) = make_uint4(s.alive | (s.count << 16), s.bad, (uint32_t)s.order, (uint32_t)(s.order >> 32));
+        a.depth[env] = depth;
+        a.reward[env] = reward;
+        a.done[env] = (uint8_t)(depth == 0 || solved);
+        a.success[env] = (uint8_t)solved;
+        if (fault) atomicOr(&a.error[env], fault);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (uint32_t i = 0; i < VEC; i += QG_WAVE) gtile[i + lane] = lds_tile[i + lane];
+}
+
 // after a host upload: optional initial clean (PauliEnv::reset, pauli.rs:576), then the scalar
 // resets of set_state (pauli.rs:544-551) / reset (pauli.rs:578-585)
 template <int NQ, int RM>
@@ -1296,6 +1416,9 @@ static hipError_t pt_launch_step(const PTArgs &pa, hipStream_t s) {
             if (feat) hipLaunchKernelGGL((ptile_step1_kernel<NQ, RM, true>), grid, block, 0, s, pa);
             else hipLaunchKernelGGL((ptile_step1_kernel<NQ, RM, false>), grid, block, 0, s, pa);
         }
+    } else if (!feat && !dense_only && !pa.n_perms && PTLayout<NQ, RM>::COMPACT && !getenv("QGYM_FUSED_REGS")) {
+        if constexpr (PTLayout<NQ, RM>::COMPACT)
+            hipLaunchKernelGGL((ptile_fused1c_kernel<NQ, RM>), dim3(grid_for(pa.s.B, QG_WAVE)), dim3(QG_WAVE), 0, s, pa);
     } else if (feat) {
         hipLaunchKernelGGL((ptile_step_kernel<NQ, RM, true>), grid, block, 0, s, pa);
     } else {

@@ -142,6 +142,61 @@ def test_pauli_set_state_wire_format_and_fused_rollout():
     np.testing.assert_array_equal(gv.observe().cpu().numpy(), np.stack([o.dense_obs() for o in envs]))
 
 
+@pytest.mark.parametrize("n,batch,max_rot,act_dtype", [(4, 130, 5, "int32"), (20, 64, 5, "int64"), (24, 70, 6, "int32"), (20, 200, 12, "int32")])
+def test_pauli_fused_rollout_matches_the_oracle_step_by_step(n, batch, max_rot, act_dtype):
+    """T steps in one launch (compact layout: the tile lives in LDS for the rollout; max_rot 12: the dense register kernel): per-step
+    rewards and episode ends, the final observation / state, and a one-step launch afterwards (the bookkeeping the fused kernel
+    wrote back must be what the one-step kernel expects), with out-of-range actions in the mix and a ragged last tile."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    gateset = line_gateset("pauli", n)
+    A = len(gateset)
+    pairs = [g[1] for g in gateset if g[0] == "CX"]
+    cfg = dict(add_perms=False, track_solution=False, max_rotations=max_rot, max_depth=40, difficulty=9)
+    rng = np.random.default_rng(300 + n + max_rot)
+    gv = VecEnv("pauli", n, gateset, batch, **cfg)
+    envs = [OracleEnv("pauli", n, gateset, **{k: int(v) for k, v in cfg.items()}) for _ in range(batch)]
+    tabs, labs = [], []
+    for e in range(batch):
+        # short scrambles and light rotations: some episodes finish (and keep being stepped) inside the rollout
+        t = random_tableau(rng, n, int(rng.integers(0, 6)), pairs)
+        l = random_labels(rng, n, int(rng.integers(0, max_rot + 3)), max_weight=min(3, n))
+        envs[e].pauli_reset_from(t, l)
+        tabs.append(t)
+        labs.append(l)
+    gv.pauli_reset_from(np.stack(tabs), labs)
+    T = 48  # runs past max_depth: depth saturates at 0
+    acts = rng.integers(0, A, size=(T, batch))
+    acts[5, ::3] = A
+    acts[17, 1::4] = -1
+    acts[40:, ::2] = rng.integers(0, min(A, 2 * n), size=acts[40:, ::2].shape)  # one-qubit gates
+    rew = torch.zeros((T, batch), dtype=torch.float32, device="cuda")
+    fin = torch.zeros((T, batch), dtype=torch.uint8, device="cuda")
+    gv.rollout(torch.as_tensor(acts, device="cuda", dtype=getattr(torch, act_dtype)), fused=True, rewards_out=rew, dones_out=fin)
+    gv.sync()
+    want_r = np.zeros((T, batch), np.uint32)
+    want_f = np.zeros((T, batch), np.uint8)
+    for t in range(T):
+        for e, o in enumerate(envs):
+            o.step(int(acts[t, e]))
+            want_r[t, e] = o.reward_bits()
+            want_f[t, e] = o.is_final()
+    np.testing.assert_array_equal(f32_bits(rew.cpu().numpy()), want_r)
+    np.testing.assert_array_equal(fin.cpu().numpy(), want_f)
+    np.testing.assert_array_equal(gv.success.cpu().numpy(), [int(o.success()) for o in envs])
+    np.testing.assert_array_equal(gv.depth.cpu().numpy(), [o.depth() for o in envs])
+    np.testing.assert_array_equal(gv.observe().cpu().numpy(), np.stack([o.dense_obs() for o in envs]))
+    np.testing.assert_array_equal(gv.get_state("i64").cpu().numpy(), np.stack([o.get_state() for o in envs]))
+    for k in range(6):  # one-step launches on what the fused kernel left behind
+        last = rng.integers(0, A, size=batch)
+        for o, a in zip(envs, last):
+            o.step(int(a))
+        gv.step(torch.as_tensor(last, device="cuda", dtype=torch.int32))
+    gv.sync()
+    np.testing.assert_array_equal(f32_bits(gv.reward.cpu().numpy()), np.array([o.reward_bits() for o in envs], dtype=np.uint32))
+    np.testing.assert_array_equal(gv.observe().cpu().numpy(), np.stack([o.dense_obs() for o in envs]))
+
+
 def test_pauli_add_perms_observe_and_action_unpermute():
     """add_perms=True: observe() permutes qubits by a drawn coupling-map automorphism and the next
     step() un-permutes the action with it (reference pauli.rs:594-599, 653-665)."""
