@@ -297,6 +297,18 @@ size_t qg_vec_embed_packed_bytes(const qg_vec *v, uint32_t hidden);
 int qg_vec_pack_embedding(qg_vec *v, const void *weight_dev, int weight_dtype, uint64_t ld, uint32_t hidden, void *packed_dev, void *stream);
 int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint32_t hidden, int relu, void *out_dev, uint64_t ld_out, void *stream);
 
+/* The same first layer from packed observation WORDS instead of a handle's resident state: words_dev = [batch, rows] uint64,
+ * bit c of word r = observation entry (r, c) -- what qg_vec_observe_packed writes for handles with 64-bit row words (PauliEnv:
+ * 2N rows of 2N + max_rotations columns; CliffordEnv N > 16; LinearFunctionEnv N > 32), a packed rollout buffer, or another
+ * rank's all-gathered shard, so the learner side never unpacks either.  rows even, cols <= 64, hidden % 128 == 0
+ * (qg_policy_embed_words_packed_bytes returns 0 otherwise); W is [hidden, ld] with ld >= rows*cols, k = r*cols + c as in
+ * qg_vec_observe_dense_as; words 16-byte aligned; output as qg_vec_embed.  The weights stream through LDS, so K is not limited. */
+size_t qg_policy_embed_words_packed_bytes(uint32_t rows, uint32_t cols, uint32_t hidden);
+int qg_policy_pack_embed_words(const void *weight_dev, int weight_dtype, uint64_t ld, uint32_t rows, uint32_t cols, uint32_t hidden, void *packed_dev,
+                               void *stream);
+int qg_policy_embed_words(const uint64_t *words_dev, uint64_t batch, uint32_t rows, uint32_t cols, const void *packed_dev, const float *bias_dev,
+                          uint32_t hidden, int relu, void *out_dev, uint64_t ld_out, void *stream);
+
 /* The policy's last layer and the categorical draw in one kernel: logits[e, a] = sum_k h[e, k] W[a, k] + b[a] stay in
  * registers and go straight into the exponential race of qg_sample_actions (same counter RNG, hash and tie rule, so
  * the same seed / counter / clock give the same draw for the same logits); outputs as there, values_dev[e] = the value

@@ -112,6 +112,37 @@ def embed(env: VecEnv, packed: torch.Tensor, bias: Optional[torch.Tensor], hidde
     return out
 
 
+def pack_embed_words(weight: torch.Tensor, rows: int, cols: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """First-layer weight [hidden, rows*cols] (f32 / bf16) in the order `embed_words` consumes (`qg_policy_pack_embed_words`)."""
+    if weight.dim() != 2 or weight.stride(1) != 1:
+        raise ValueError("weight must be [hidden, rows*cols] with unit column stride")
+    L = _lib.load()
+    nbytes = L.qg_policy_embed_words_packed_bytes(int(rows), int(cols), weight.shape[0])
+    if nbytes == 0:
+        raise ValueError("embed_words needs an even number of rows, cols <= 64 and hidden % 128 == 0")
+    if out is None:
+        out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=weight.device)
+    _lib.check(L.qg_policy_pack_embed_words(weight.data_ptr(), _DT[weight.dtype], weight.stride(0), int(rows), int(cols), weight.shape[0], out.data_ptr(),
+                                            _stream_ptr()))
+    return out
+
+
+def embed_words(words: torch.Tensor, cols: int, packed: torch.Tensor, bias: Optional[torch.Tensor], hidden: int, relu: bool = True,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(obs @ W.T + bias) in bf16 [B, hidden] from packed observation rows [B, rows] int64 (`VecEnv.observe_packed` of a handle with
+    64-bit row words, a packed rollout buffer, a gathered shard): `qg_policy_embed_words`."""
+    if words.dim() != 2 or words.dtype != torch.int64 or not words.is_contiguous():
+        raise ValueError("words must be a contiguous int64 [B, rows] tensor")
+    B, rows = words.shape
+    if out is None:
+        out = torch.empty((B, hidden), dtype=torch.bfloat16, device=words.device)
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
+        raise ValueError("bias must be a contiguous f32 vector")
+    _lib.check(_lib.load().qg_policy_embed_words(words.data_ptr(), B, rows, int(cols), packed.data_ptr(), bias.data_ptr() if bias is not None else None, hidden,
+                                                 int(relu), out.data_ptr(), out.stride(0), _stream_ptr()))
+    return out
+
+
 def pack_head(weight: torch.Tensor, bias: Optional[torch.Tensor], num_actions: int, value_row: int, out: Optional[torch.Tensor] = None,
               after_mid: bool = False) -> torch.Tensor:
     """Last-layer weight [rows, in_features] (+ bias [rows]; f32 or bf16, same dtype) in the order `head_sample` (or, with
@@ -289,6 +320,16 @@ class RolloutCollector:
                     self._embed = (pack_embedding(env, emb.weight), emb.bias.detach().float().contiguous())
                 except (ValueError, _lib.QGymError):
                     self._embed = None  # layouts without the bit-consuming kernel keep the dense first layer
+        # layouts the TILE kernel does not cover (PauliEnv, CliffordEnv N > 16, ...): the same first layer from the packed observation
+        # words the rollout stores anyway (64-bit row words, even row count)
+        self._embed_words = None
+        self._cur_words = None
+        if (self._embed is None and use_bit_embedding and isinstance(self.policy, BasicPolicy) and dtype == torch.bfloat16 and store_obs == "packed"
+                and env.packed_word_bytes == 8 and env.packed_words_per_env == r and self.policy.embeddings.in_features == self.obs_size):
+            try:
+                self._embed_words = (pack_embed_words(self.policy.embeddings.weight, r, c), self.policy.embeddings.bias.detach().float().contiguous())
+            except ValueError:
+                self._embed_words = None
         self._h1 = None
         self._head = None  # packed last layer for the fused head + sampling kernel (bf16 BasicPolicy within its limits)
         self._mid = None   # packed middle layer: then middle layer + head + sampling are ONE kernel and only the first layer stays outside
@@ -333,6 +374,8 @@ class RolloutCollector:
             env.observe_packed(out=ro.obs[t])
             if self._embed is not None:
                 pass
+            elif self._embed_words is not None:
+                self._cur_words = ro.obs[t]
             elif env.env_kind == "pauli":
                 # PauliEnv.observe() with add_perms draws a permutation (pauli.rs:657-662): observe once, expand the stored row words
                 expand_packed(ro.obs[t], env.obs_shape_[1], self.dtype, out=self._x.view(env.batch, *env.obs_shape_))
@@ -361,6 +404,9 @@ class RolloutCollector:
         if self._embed is not None:
             pack_embedding(self.env, pol.embeddings.weight, out=self._embed[0])
             self._embed[1].copy_(pol.embeddings.bias)
+        if self._embed_words is not None:
+            pack_embed_words(pol.embeddings.weight, *self.env.obs_shape_, out=self._embed_words[0])
+            self._embed_words[1].copy_(pol.embeddings.bias)
         if self._head is not None:
             pack_head(w, b, A, A, out=self._head, after_mid=self._mid is not None)
         if self._mid is not None:
@@ -372,6 +418,11 @@ class RolloutCollector:
             if self._h1 is None:
                 self._h1 = torch.empty((self.env.batch, pol.embeddings.out_features), dtype=self.dtype, device=self.env.device)
             return embed(self.env, self._embed[0], self._embed[1], pol.embeddings.out_features, relu=True, out=self._h1)
+        if self._embed_words is not None:
+            if self._h1 is None:
+                self._h1 = torch.empty((self.env.batch, pol.embeddings.out_features), dtype=self.dtype, device=self.env.device)
+            return embed_words(self._cur_words, self.env.obs_shape_[1], self._embed_words[0], self._embed_words[1], pol.embeddings.out_features, relu=True,
+                               out=self._h1)
         return _linear_relu(self._x, pol.embeddings.weight, pol.embeddings.bias)
 
     def _fused_tail(self, counter: int, actions, logp, entropy, values, clock):
@@ -407,7 +458,11 @@ class RolloutCollector:
         ro.values[t].copy_(value)
 
     def _value_of_current_state(self) -> torch.Tensor:
-        if self._embed is None:
+        if self._embed_words is not None:
+            if getattr(self, "_words_scratch", None) is None:
+                self._words_scratch = torch.empty((self.env.batch, self.env.packed_words_per_env), dtype=torch.int64, device=self.env.device)
+            self._cur_words = self.env.observe_packed(out=self._words_scratch)
+        elif self._embed is None:
             self.env.observe_as(self.dtype, out=self._x)
         if self._head is not None:  # the fused kernel's value output (its draw is discarded)
             self._fused_tail(0, self._scratch_actions, self._scratch_f32[0], self._scratch_f32[1], self._scratch_f32[2], None)

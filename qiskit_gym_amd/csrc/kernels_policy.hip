@@ -630,6 +630,222 @@ __global__ __launch_bounds__(64 * MH_WAVES, 2) void mid_head_sample_kernel(MidHe
     }
 }
 
+
+// =================================================================================================
+// First layer from packed observation WORDS: any env kind, any rank's shard.
+//
+// embed_bits_kernel above reads the resident TILE layout and keeps a whole 64-column weight slab in LDS, which caps K
+// at 1024.  The packed observation every layout exports (qg_vec_observe_packed: one 64-bit word per observation row --
+// PauliEnv 2N rows of 2N + max_rotations columns, CliffordEnv N > 16, and what the multi-GPU all-gather moves) has
+// K = 64 * rows bit positions, of which only `cols` per row carry weights.  Same bit trick for the A operand (a lane
+// loads 16 B = two rows of its env and expands them in registers), but the weights stream: a workgroup of 4 waves owns
+// 256 envs x 128 output columns, the packed weights of one 16-byte group (KPG k-steps x 4 fragments = KPG x 4 KiB)
+// arrive per chunk through two LDS buffers (global_load_lds, one barrier per chunk), every A fragment feeds four
+// B fragments (8 MFMAs per k-step per wave for 2 expansions), two workgroups per CU.  Only k-steps that can hold
+// weights exist: a row's low word takes two, its high word two (cols > 48), one (32 < cols <= 48: the <= 16 valid
+// bits are first moved to bits 0..7 / 16..23, which one rotation covers for both lane halves) or none (cols <= 32).
+// =================================================================================================
+constexpr uint32_t EW_WAVES = 4;
+constexpr uint32_t EW_MA = 2;                       // 32-env row tiles per wave
+constexpr uint32_t EW_NB = 4;                       // B fragments per k-step: 2 slabs of 64 columns x 2
+constexpr uint32_t EW_COLS = 32u * EW_NB;           // output columns per workgroup
+constexpr uint32_t EW_BLOCK_ENVS = EW_WAVES * 32u * EW_MA;
+
+__host__ __device__ inline uint32_t ew_kpg(uint32_t cols) { return cols <= 32u ? 4u : cols <= 48u ? 6u : 8u; }  // k-steps per 16-byte group (two rows)
+
+// k-step s of a group: which of the group's four 32-bit words {row0 lo, row0 hi, row1 lo, row1 hi} and which rotation:
+// 0 / 1 = the two phases of embed_bits_kernel (bits {11..18, 27..31, 0..2} / {3..10, 19..26}), 2 = the compressed high word
+__host__ __device__ inline void ew_kstep(uint32_t kpg, uint32_t s, uint32_t &word, uint32_t &mode) {
+    if (kpg == 8u) { word = s >> 1; mode = s & 1u; }
+    else if (kpg == 4u) { word = (s >> 1) * 2u; mode = s & 1u; }
+    else { const uint32_t r = s / 3u, k = s % 3u; word = 2u * r + (k == 2u ? 1u : 0u); mode = k == 2u ? 2u : k; }
+}
+
+// Packed weights: [column tile of 128][group g < rows / 2][k-step s < KPG][fragment f < 4][lane][e < 8] bf16.  Fragment f of
+// column tile ct holds, for lane (c = lane & 31, h = lane >> 5), output column ct * 128 + 64 (f >> 1) + 2 c + (f & 1); element
+// e = 2 j + half multiplies the observation bit the kernel's A element (j, half) of that k-step is built from.
+template <typename WT>
+__global__ __launch_bounds__(256) void pack_embed_words_kernel(const WT *w, uint64_t ld, uint32_t hidden, uint32_t rows, uint32_t cols, __hip_bfloat16 *out) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t kpg = ew_kpg(cols), G = rows / 2u;
+    const uint64_t total = (uint64_t)(hidden / EW_COLS) * G * kpg * EW_NB * 64u * 8u;
+    if (idx >= total) return;
+    const uint32_t e = (uint32_t)idx & 7u, lane = (uint32_t)(idx >> 3) & 63u, f = (uint32_t)(idx >> 9) & 3u;
+    uint64_t rest = idx >> 11;
+    const uint32_t s = (uint32_t)(rest % kpg);
+    rest /= kpg;
+    const uint32_t g = (uint32_t)(rest % G), ct = (uint32_t)(rest / G);
+    const uint32_t c = lane & 31u, h = lane >> 5, j = e >> 1, half = e & 1u;
+    uint32_t word, mode;
+    ew_kstep(kpg, s, word, mode);
+    uint32_t pos;
+    if (mode < 2u) {
+        pos = ((half ? 30u : 14u) - j + 8u * mode + 4u * h) & 31u;
+    } else {
+        const uint32_t pp = ((half ? 30u : 14u) - j + 21u + 4u * h) & 31u;  // 0..7 or 16..23 of the compressed word
+        pos = pp < 8u ? pp : pp - 8u;
+    }
+    const uint32_t row = 2u * g + (word >> 1), col = 32u * (word & 1u) + pos;
+    const uint32_t n = ct * EW_COLS + 64u * (f >> 1) + 2u * c + (f & 1u);
+    float v = 0.0f;
+    if (col < cols) {
+        v = (float)w[(uint64_t)n * ld + (uint64_t)row * cols + col];
+        v *= __uint_as_float((127u + 128u - (128u >> j)) << 23);  // see pack_embed_kernel
+        const float lim = 3.3895313892515355e38f;
+        v = v > lim ? lim : v < -lim ? -lim : v;
+    }
+    out[idx] = __float2bfloat16(v);
+}
+
+struct EmbedWordsArgs {
+    const uint4 *words;     // [B][groups] 16-byte groups = [B][rows] uint64
+    const uint4 *wp;        // packed weights
+    const float *bias;      // [hidden] f32 or null
+    uint32_t *out;          // [B][ld_out / 2] bf16 pairs
+    uint64_t B;
+    uint64_t ld_out;        // elements per env row of out
+    uint32_t groups;        // rows / 2
+    uint32_t n_ctiles;      // hidden / 128
+    uint32_t relu;
+};
+
+template <uint32_t KPG>
+__global__ __launch_bounds__(64 * EW_WAVES, 2) void embed_words_kernel(EmbedWordsArgs a) {
+    constexpr uint32_t CHUNK_VEC = KPG * EW_NB * 64u;  // uint4 per streamed chunk
+    __shared__ uint4 cbuf[2 * CHUNK_VEC];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t ct = blockIdx.x % a.n_ctiles;
+    const uint64_t etile = blockIdx.x / a.n_ctiles;
+    const uint32_t G = a.groups;
+    const uint4 *wsrc = a.wp + (uint64_t)ct * G * CHUNK_VEC;
+    auto stage = [&](uint32_t g) {  // chunk g -> buffer g & 1
+        const uint4 *src = wsrc + (uint64_t)g * CHUNK_VEC;
+        uint4 *dst = cbuf + (g & 1u) * CHUNK_VEC;
+#pragma unroll
+        for (uint32_t c = 0; c < CHUNK_VEC; c += 64u * EW_WAVES)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + c + wave * 64u + lane),
+                                             (__attribute__((address_space(3))) void *)(dst + c + wave * 64u), 16, 0, 0);
+    };
+    auto landed = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    const uint32_t r = lane & 31u, h = lane >> 5;
+    const uint32_t shA = 4u * h, shB = 8u + 4u * h, shS = 21u + 4u * h;
+    const uint64_t env0 = etile * EW_BLOCK_ENVS + (uint64_t)wave * (32u * EW_MA);
+    const uint4 *pw[EW_MA];
+#pragma unroll
+    for (uint32_t i = 0; i < EW_MA; ++i) {
+        uint64_t env = env0 + 32u * i + r;
+        env = env < a.B ? env : a.B - 1;  // waves / rows past the batch compute on the last env (every wave takes part in the barriers)
+        pw[i] = a.words + env * G;
+    }
+    f32x16 acc[EW_MA][EW_NB];
+#pragma unroll
+    for (uint32_t i = 0; i < EW_MA; ++i)
+#pragma unroll
+        for (uint32_t f = 0; f < EW_NB; ++f)
+#pragma unroll
+            for (uint32_t q = 0; q < 16; ++q) acc[i][f][q] = 0.0f;
+    stage(0);
+    uint4 cur[EW_MA], nxt[EW_MA];
+#pragma unroll
+    for (uint32_t i = 0; i < EW_MA; ++i) cur[i] = pw[i][0];
+    landed();
+    // A fragments of k-step s of the group held in `wds`
+    auto expand = [&](const uint4 (&wds)[EW_MA], uint32_t s, bf16x8 (&af)[EW_MA]) {
+        uint32_t word, mode;
+        ew_kstep(KPG, s, word, mode);
+#pragma unroll
+        for (uint32_t i = 0; i < EW_MA; ++i) {
+            uint32_t wv = word == 0 ? wds[i].x : word == 1 ? wds[i].y : word == 2 ? wds[i].z : wds[i].w;
+            if (mode == 2u) wv = (wv & 0xFFu) | ((wv << 8) & 0xFF0000u);  // bits 8..15 -> 16..23
+            af[i] = emb_expand(wv, mode == 0u ? shA : mode == 1u ? shB : shS);
+        }
+    };
+    // Software pipeline inside a chunk: while the 8 MFMAs of k-step s issue, the 4 B fragments of s + 1 are read from LDS and its
+    // A fragments expanded into the other register set.  The chunk's first k-step is fetched right after the barrier.
+    bf16x8 af[2][EW_MA], bfr[2][EW_NB];
+    {
+        const uint4 *bl = cbuf + lane;
+#pragma unroll
+        for (uint32_t f = 0; f < EW_NB; ++f) bfr[0][f] = __builtin_bit_cast(bf16x8, bl[f * 64u]);
+        expand(cur, 0, af[0]);
+    }
+    for (uint32_t g = 0; g < G; ++g) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1u < G) stage(g + 1u);  // its buffer was last read in chunk g - 1, which every wave has left
+        const uint32_t gn = g + 1u < G ? g + 1u : g;
+#pragma unroll
+        for (uint32_t i = 0; i < EW_MA; ++i) nxt[i] = pw[i][gn];
+        const uint4 *bl = cbuf + (g & 1u) * CHUNK_VEC + lane;
+#pragma unroll
+        for (uint32_t s = 0; s < KPG; ++s) {
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t c = s & 1u, n = c ^ 1u;
+            if (s + 1u < KPG) {
+#pragma unroll
+                for (uint32_t f = 0; f < EW_NB; ++f) bfr[n][f] = __builtin_bit_cast(bf16x8, bl[((s + 1u) * EW_NB + f) * 64u]);
+                expand(cur, s + 1u, af[n]);
+            }
+#pragma unroll
+            for (uint32_t f = 0; f < EW_NB; ++f)
+#pragma unroll
+                for (uint32_t i = 0; i < EW_MA; ++i) acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][i], bfr[c][f], acc[i][f], 0, 0, 0);
+            if (s + 1u < KPG) {
+                __builtin_amdgcn_sched_group_barrier(0x100, EW_NB, 0);  // the LDS reads first
+#pragma unroll
+                for (uint32_t m = 0; m < EW_NB * EW_MA; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // a share of the next k-step's expansion
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (uint32_t i = 0; i < EW_MA; ++i) cur[i] = nxt[i];
+        landed();
+        {   // KPG is even: the next chunk starts in register set 0 again
+            const uint4 *bn = cbuf + ((g + 1u) & 1u) * CHUNK_VEC + lane;
+#pragma unroll
+            for (uint32_t f = 0; f < EW_NB; ++f) bfr[0][f] = __builtin_bit_cast(bf16x8, bn[f * 64u]);
+            expand(cur, 0, af[0]);
+        }
+    }
+    // epilogue as in embed_bits_kernel: x 0.5 + bias, ReLU, bf16, 4x4 transpose over the lane quad, 16-byte stores
+    const uint64_t ldw = a.ld_out >> 1;
+    const uint32_t lane_row = (lane & 3u) + 4u * h;
+#pragma unroll
+    for (uint32_t sl = 0; sl < EW_NB / 2u; ++sl) {
+        const uint32_t n0 = ct * EW_COLS + 64u * sl + 2u * r;
+        const float bias0 = a.bias ? a.bias[n0] : 0.0f, bias1 = a.bias ? a.bias[n0 + 1] : 0.0f;
+        uint32_t *const out_lane = a.out + ((ct * EW_COLS + 64u * sl + 8u * (r >> 2)) >> 1);
+#pragma unroll
+        for (uint32_t i = 0; i < EW_MA; ++i) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                uint32_t d[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    float v0 = __builtin_fmaf(acc[i][2u * sl][4u * j + k], 0.5f, bias0), v1 = __builtin_fmaf(acc[i][2u * sl + 1u][4u * j + k], 0.5f, bias1);
+                    if (a.relu) {
+                        v0 = __builtin_amdgcn_fmed3f(v0, 0.0f, __builtin_inff());
+                        v1 = __builtin_amdgcn_fmed3f(v1, 0.0f, __builtin_inff());
+                    }
+                    const f32x2 v = {v0, v1};
+                    d[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+                }
+                emb_quad_swap<0xB1>(d[0], d[1], (lane & 1u) != 0);
+                emb_quad_swap<0xB1>(d[2], d[3], (lane & 1u) != 0);
+                emb_quad_swap<0x4E>(d[0], d[2], (lane & 2u) != 0);
+                emb_quad_swap<0x4E>(d[1], d[3], (lane & 2u) != 0);
+                const uint64_t row = env0 + 32u * i + 8u * j + lane_row;
+                if (row < a.B) *reinterpret_cast<uint4 *>(out_lane + row * ldw) = make_uint4(d[0], d[1], d[2], d[3]);
+            }
+        }
+    }
+}
+
 }  // namespace qg
 
 using namespace qg;
@@ -709,6 +925,67 @@ int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint3
     default: return set_error(QG_ERR_UNSUPPORTED, "unexpected row-group count %u", G);
     }
 #undef QG_EMB_CASE
+    HIP_TRY(hipGetLastError());
+    return QG_OK;
+}
+
+size_t qg_policy_embed_words_packed_bytes(uint32_t rows, uint32_t cols, uint32_t hidden) {
+    if (rows == 0 || (rows & 1u) || cols == 0 || cols > 64u || hidden == 0 || hidden % EW_COLS) return 0;
+    return (size_t)(hidden / EW_COLS) * (rows / 2u) * ew_kpg(cols) * EW_NB * 64u * 16u;
+}
+
+int qg_policy_pack_embed_words(const void *weight_dev, int weight_dtype, uint64_t ld, uint32_t rows, uint32_t cols, uint32_t hidden, void *packed_dev,
+                               void *stream) {
+    if (!weight_dev || !packed_dev) return set_error(QG_ERR_INVALID, "null argument");
+    const size_t bytes = qg_policy_embed_words_packed_bytes(rows, cols, hidden);
+    if (bytes == 0) return set_error(QG_ERR_UNSUPPORTED, "first layer from packed words: an even number of rows, <= 64 columns, hidden a multiple of %u", EW_COLS);
+    if (ld < (uint64_t)rows * cols) return set_error(QG_ERR_INVALID, "weight rows are shorter than the observation (%u x %u)", rows, cols);
+    const uint64_t total = bytes / 2u;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    __hip_bfloat16 *out = reinterpret_cast<__hip_bfloat16 *>(packed_dev);
+    switch (weight_dtype) {
+    case QG_DT_F32:
+        hipLaunchKernelGGL(pack_embed_words_kernel<float>, grid, block, 0, s, reinterpret_cast<const float *>(weight_dev), ld, hidden, rows, cols, out);
+        break;
+    case QG_DT_BF16:
+        hipLaunchKernelGGL(pack_embed_words_kernel<__hip_bfloat16>, grid, block, 0, s, reinterpret_cast<const __hip_bfloat16 *>(weight_dev), ld, hidden, rows, cols,
+                           out);
+        break;
+    default: return set_error(QG_ERR_INVALID, "weight dtype must be f32 or bf16");
+    }
+    HIP_TRY(hipGetLastError());
+    return QG_OK;
+}
+
+int qg_policy_embed_words(const uint64_t *words_dev, uint64_t batch, uint32_t rows, uint32_t cols, const void *packed_dev, const float *bias_dev,
+                          uint32_t hidden, int relu, void *out_dev, uint64_t ld_out, void *stream) {
+    if (!words_dev || !packed_dev || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
+    if (qg_policy_embed_words_packed_bytes(rows, cols, hidden) == 0)
+        return set_error(QG_ERR_UNSUPPORTED, "first layer from packed words: an even number of rows, <= 64 columns, hidden a multiple of %u", EW_COLS);
+    if ((reinterpret_cast<uintptr_t>(words_dev) & 15u)) return set_error(QG_ERR_INVALID, "the packed words must be 16-byte aligned");
+    if (ld_out < hidden || (ld_out & 7u) || (reinterpret_cast<uintptr_t>(out_dev) & 15u))
+        return set_error(QG_ERR_INVALID, "the output must be 16-byte aligned with a row stride that is a multiple of 8 elements");
+    if (batch == 0) return QG_OK;
+    EmbedWordsArgs a;
+    a.words = reinterpret_cast<const uint4 *>(words_dev);
+    a.wp = reinterpret_cast<const uint4 *>(packed_dev);
+    a.bias = bias_dev;
+    a.out = reinterpret_cast<uint32_t *>(out_dev);
+    a.B = batch;
+    a.ld_out = ld_out;
+    a.groups = rows / 2u;
+    a.n_ctiles = hidden / EW_COLS;
+    a.relu = relu ? 1u : 0u;
+    const uint64_t etiles = (batch + EW_BLOCK_ENVS - 1) / EW_BLOCK_ENVS;
+    if (etiles * a.n_ctiles > 0x7FFFFFFFull) return set_error(QG_ERR_UNSUPPORTED, "batch too large for one launch");
+    const dim3 grid((unsigned)(etiles * a.n_ctiles)), block(64 * EW_WAVES);
+    hipStream_t s = (hipStream_t)stream;
+    switch (ew_kpg(cols)) {
+    case 4: hipLaunchKernelGGL(embed_words_kernel<4>, grid, block, 0, s, a); break;
+    case 6: hipLaunchKernelGGL(embed_words_kernel<6>, grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL(embed_words_kernel<8>, grid, block, 0, s, a); break;
+    }
     HIP_TRY(hipGetLastError());
     return QG_OK;
 }

@@ -165,3 +165,37 @@ def test_graph_replay_with_the_bit_consuming_first_layer():
                 prm.mul_(0.5)
     env.sync()
     assert col.steps_done == 3 * T
+
+
+@pytest.mark.parametrize("kind,n,kw,use_graph", [("pauli", 6, dict(max_rotations=4, depth_slope=1), False), ("pauli", 6, dict(max_rotations=4, depth_slope=1), True),
+                                                 ("clifford", 18, dict(add_inverts=False), True)])
+def test_first_layer_from_the_packed_observation_words(kind, n, kw, use_graph):
+    """bf16 BasicPolicy on an env whose packed observation is one 64-bit word per row (PauliGym, CliffordGym N > 16): the collector stores
+    the words and feeds them straight to qg_policy_embed_words -- no dense observation exists.  log-probs / values must match the torch
+    policy on the re-expanded stored observation, also after an in-place parameter update (repacked weights)."""
+    from qiskit_gym_amd.collector import BasicPolicy, RolloutCollector
+    from qiskit_gym_amd.vec import VecEnv
+
+    B, T = 300, 5
+    gs = line_gateset(kind, n)
+    env = VecEnv(kind, n, gs, B, add_perms=False, track_solution=False, difficulty=3, **kw)
+    rows, cols = env.obs_shape_
+    torch.manual_seed(5)
+    pol = BasicPolicy(rows * cols, len(gs), embedding_size=128, common=64)
+    col = RolloutCollector(env, pol, dtype=torch.bfloat16, seed=9, store_obs="packed", use_graph=use_graph, use_bit_embedding=True, use_fused_head=True)
+    assert col._embed is None and col._embed_words is not None
+    for call in range(3):
+        ro = col.collect(T)
+        torch.cuda.synchronize()
+        assert ro.obs.dtype == torch.int64 and ro.obs.shape == (T, B, rows)
+        for t in (0, T - 1):
+            obs = ro.dense_obs(torch.float32)[t]
+            logits, value = col.policy(obs.to(torch.bfloat16))
+            lsm = torch.log_softmax(logits.float(), dim=-1)
+            torch.testing.assert_close(ro.logp[t], lsm.gather(1, ro.actions[t].unsqueeze(1)).squeeze(1), atol=6e-2, rtol=0)
+            torch.testing.assert_close(ro.values[t], value.float(), atol=6e-2, rtol=0)
+        with torch.no_grad():
+            for prm in col.policy.parameters():
+                prm.mul_(0.5)
+    env.sync()
+    assert col.steps_done == 3 * T

@@ -1,0 +1,128 @@
+"""The first policy layer from packed observation words (qg_policy_embed_words) against a dense reference.  Synthetic words
+exercise every bit position of every column count class (cols <= 32: no high word, <= 48: compressed high word, <= 64: full);
+integer weights pin the k permutation exactly; real PauliGym / 20-qubit CliffordGym observations check the env-side contract
+(observe_packed's words vs the dense observation)."""
+import numpy as np
+import pytest
+import torch
+
+from qiskit_gym_amd.collector import embed_words, pack_embed_words
+from qiskit_gym_amd.vec import VecEnv
+from util import line_gateset
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # rows, cols, batch, hidden
+    (40, 45, 1000, 128),   # PauliGym 20q, max_rotations 5
+    (40, 45, 257, 512),
+    (8, 9, 70, 128),       # cols <= 32
+    (10, 32, 300, 128),
+    (12, 33, 64, 128),
+    (6, 48, 1, 256),
+    (40, 49, 513, 128),    # cols > 48: full high word
+    (64, 64, 700, 128),    # CliffordGym 32q
+    (2, 64, 256, 128),
+]
+
+
+def _dense(words, cols):
+    bits = (words.unsqueeze(-1) >> torch.arange(cols, device=words.device)) & 1  # [B, rows, cols]
+    return bits.to(torch.float64).flatten(1)
+
+
+def _int_weights(hidden, K, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    w = torch.zeros((hidden, K), dtype=torch.float32)
+    for r in range(hidden):
+        idx = torch.randperm(K, generator=g)[: min(K, 200)]
+        w[r, idx] = (torch.randint(0, 2, (idx.numel(),), generator=g) * 2 - 1).float()
+    return w, torch.randint(-8, 9, (hidden,), generator=g).float()
+
+
+@pytest.mark.parametrize("rows,cols,B,hidden", SHAPES)
+def test_embed_words_integer_weights_exact(rows, cols, B, hidden):
+    g = torch.Generator(device="cpu").manual_seed(rows * 100 + cols)
+    words = torch.randint(-(2**63), 2**63 - 1, (B, rows), generator=g, dtype=torch.int64)
+    words[0] = -1  # every bit set, the ones past `cols` included: they must carry no weight
+    if cols < 64:
+        words[1:] &= (1 << cols) - 1
+    words = words.cuda()
+    obs = _dense(words, cols)
+    w, bias = _int_weights(hidden, rows * cols, 5)
+    wd, bd = w.cuda(), bias.cuda()
+    for wt in (wd, wd.to(torch.bfloat16)):
+        packed = pack_embed_words(wt, rows, cols)
+        for relu in (False, True):
+            out = embed_words(words, cols, packed, bd, hidden, relu=relu)
+            ref = obs @ wd.double().t() + bd.double()
+            if relu:
+                ref = ref.clamp_min(0)
+            assert torch.equal(out.double(), ref), f"{rows}x{cols}: mismatch in {(out.double() != ref).sum().item()} entries"
+    assert torch.equal(embed_words(words, cols, packed, None, hidden, relu=False).double(), obs @ wd.double().t())
+    torch.cuda.synchronize()
+
+
+def test_embed_words_single_weight_probes():
+    """One non-zero weight at a time: output n must equal exactly that observation bit (pins (row, col) -> k for all positions)."""
+    rows, cols, B, hidden = 4, 45, 64, 128
+    g = torch.Generator(device="cpu").manual_seed(1)
+    words = (torch.randint(0, 2**45, (B, rows), generator=g, dtype=torch.int64)).cuda()
+    obs = _dense(words, cols)
+    K = rows * cols
+    for base in range(0, K, hidden):
+        w = torch.zeros((hidden, K), dtype=torch.float32)
+        for n in range(hidden):
+            if base + n < K:
+                w[n, base + n] = 3.0
+        out = embed_words(words, cols, pack_embed_words(w.cuda(), rows, cols), None, hidden, relu=False)
+        want = torch.zeros((B, hidden), dtype=torch.float64, device="cuda")
+        m = min(hidden, K - base)
+        want[:, :m] = 3.0 * obs[:, base : base + m]
+        assert torch.equal(out.double(), want), base
+
+
+@pytest.mark.parametrize("rows,cols,B,hidden", SHAPES[:2] + SHAPES[7:8])
+def test_embed_words_random_weights(rows, cols, B, hidden):
+    g = torch.Generator(device="cpu").manual_seed(9)
+    words = torch.randint(0, 2**62, (B, rows), generator=g, dtype=torch.int64)
+    if cols < 64:
+        words &= (1 << cols) - 1
+    words = words.cuda()
+    obs = _dense(words, cols)
+    w = (torch.randn((hidden, rows * cols), generator=g) * 0.05).to(torch.bfloat16).cuda()
+    bias = torch.randn(hidden, generator=g).cuda()
+    out = embed_words(words, cols, pack_embed_words(w, rows, cols), bias, hidden, relu=True)
+    ref = (obs @ w.double().t() + bias.double()).clamp_min(0)
+    # f32 accumulation of exact products then one bf16 rounding (2^-9 relative)
+    err = (out.double() - ref).abs()
+    assert bool((err <= ref.abs() * 2.0**-8 + 1e-4).all()), f"max error {err.max().item()}"
+    wide = torch.zeros((B, hidden + 64), dtype=torch.bfloat16, device="cuda")
+    embed_words(words, cols, pack_embed_words(w, rows, cols), bias, hidden, relu=True, out=wide[:, :hidden])
+    assert torch.equal(wide[:, :hidden], out) and not bool(wide[:, hidden:].any())
+
+
+@pytest.mark.parametrize("kind,n,cfg", [("pauli", 20, dict(max_rotations=5)), ("pauli", 6, dict(max_rotations=8, final_pauli_layers=8)), ("clifford", 20, {})])
+def test_embed_words_on_env_observations(kind, n, cfg):
+    B, hidden = 700, 128
+    gs = line_gateset(kind, n)
+    env = VecEnv(kind, n, gs, B, add_perms=False, track_solution=False, difficulty=40, **cfg)
+    env.reset(4)
+    A = env.num_actions()
+    for t in range(6):
+        env.step(torch.randint(0, A, (B,), device="cuda", dtype=torch.int32))
+    rows, cols = env.obs_shape_
+    obs = env.observe().to(torch.float64).flatten(1)
+    words = env.observe_packed()
+    assert words.dtype == torch.int64 and words.shape == (B, rows)
+    w, bias = _int_weights(hidden, rows * cols, 8)
+    out = embed_words(words, cols, pack_embed_words(w.cuda(), rows, cols), bias.cuda(), hidden, relu=False)
+    assert torch.equal(out.double(), obs @ w.cuda().double().t() + bias.cuda().double())
+    env.sync()
+
+
+def test_embed_words_limits():
+    w = torch.zeros((128, 5 * 9), device="cuda")
+    with pytest.raises(ValueError):
+        pack_embed_words(w, 5, 9)  # odd row count
+    with pytest.raises(ValueError):
+        pack_embed_words(torch.zeros((64, 8 * 9), device="cuda"), 8, 9)  # hidden not a multiple of 128
