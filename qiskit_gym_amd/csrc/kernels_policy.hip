@@ -793,11 +793,14 @@ __global__ __launch_bounds__(64 * EW_WAVES, 2) void embed_words_kernel(EmbedWord
 #pragma unroll
                 for (uint32_t i = 0; i < EW_MA; ++i) acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][i], bfr[c][f], acc[i][f], 0, 0, 0);
             if (s + 1u < KPG) {
-                __builtin_amdgcn_sched_group_barrier(0x100, EW_NB, 0);  // the LDS reads first
+                // the first MFMA goes ahead of the next k-step's LDS reads: the wait for this k-step's fragments (read a whole k-step ago)
+                // then finds no younger LDS read outstanding -- with the reads first the compiler's lgkmcnt(0) also waits for those
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, EW_NB, 0);
 #pragma unroll
-                for (uint32_t m = 0; m < EW_NB * EW_MA; ++m) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                for (uint32_t m = 1; m < EW_NB * EW_MA; ++m) {
                     __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // a share of the next k-step's expansion
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
                 }
             }
         }
