@@ -55,6 +55,8 @@ class BatchedSynthesis:
     def _vec(self, batch: int, track_solution: bool) -> VecEnv:
         key = (batch, track_solution)
         if key not in self._vecs:
+            for k in [k for k in self._vecs if k[1] == track_solution]:  # one batch size at a time: the handles own device memory
+                self._vecs.pop(k).close()
             self._vecs[key] = self.env.vec(batch, device=self.device, add_inverts=False, add_perms=False, track_solution=track_solution)
             self._policy = self._policy.to(device=self._vecs[key].device, dtype=self.dtype)
         return self._vecs[key]

@@ -13,11 +13,13 @@ ONLY = os.environ.get("ONLY")  # e.g. ONLY=65536 to run the large batch only (pr
 for B, store, graph in ((1024, "packed", False), (1024, "packed", True), (8192, "packed", False), (8192, "packed", True), (65536, "dense", False), (65536, "packed", False), (65536, "packed", True)):
     if ONLY and (B != int(ONLY) or store != "packed" or graph):
         continue
-    gs = line_gateset("clifford", 16)
-    env = VecEnv("clifford", 16, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=int(os.environ.get("DIFF", "32")))
+    NQ = int(os.environ.get("QUBITS", "16"))  # > 16: 64-bit row words, the first layer reads the packed observation (qg_policy_embed_words)
+    gs = line_gateset("clifford", NQ)
+    env = VecEnv("clifford", NQ, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=int(os.environ.get("DIFF", "32")))
     fused = {"1": True, "0": False}.get(os.environ.get("FUSED", ""), None)  # FUSED=1 / 0 forces the policy-layer kernels on / off
-    col = RolloutCollector(env, BasicPolicy(1024, len(gs)), dtype=torch.bfloat16, seed=1, store_obs=store, use_graph=graph,
-                           use_bit_embedding=fused, use_fused_head=fused)
+    embed = {"1": True, "0": False}.get(os.environ.get("EMBED", ""), fused)  # EMBED=0: library GEMM for the first layer only
+    col = RolloutCollector(env, BasicPolicy(4 * NQ * NQ, len(gs)), dtype=torch.bfloat16, seed=1, store_obs=store, use_graph=graph,
+                           use_bit_embedding=embed, use_fused_head=fused)
     T = 32
     ro = col.collect(T)
     torch.cuda.synchronize()
@@ -33,5 +35,5 @@ for B, store, graph in ((1024, "packed", False), (1024, "packed", True), (8192, 
     gc.collect()
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
-    print(f"B={B} obs stored {store}{' hipGraph' if graph else ''}: {3 * T * B / dt:.3e} env-steps/s with the policy in the loop ({dt / (3 * T) * 1e6:.0f} us per step), "
+    print(f"CliffordGym {NQ}q B={B} obs stored {store}{' hipGraph' if graph else ''}: {3 * T * B / dt:.3e} env-steps/s with the policy in the loop ({dt / (3 * T) * 1e6:.0f} us per step), "
           f"success rate in last rollout {done_rate:.3f} done/step")
