@@ -9,6 +9,7 @@ this script only shows that the collector's rollouts are what a learner needs.
 
     python examples/ppo_linear_function.py [--qubits 4] [--difficulty 5] [--iters 30]
     python examples/ppo_linear_function.py --env clifford --bf16      # CliffordGym, collection on the policy-layer kernels
+    python examples/ppo_linear_function.py --env pauli --qubits 3 --bf16   # PauliGym: targets generated on the device, first layer from the packed observation words
 
 With --bf16 the learner keeps f32 master weights and the collector a bf16 copy (refreshed, i.e. re-packed for
 qg_vec_embed / qg_policy_mid_head_sample, before every collection): the forward pass and the draw of the collection
@@ -24,15 +25,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from qiskit_gym_amd.collector import BasicPolicy, RolloutCollector
-from qiskit_gym_amd.envs import CliffordGym, LinearFunctionGym
+from qiskit_gym_amd.envs import CliffordGym, LinearFunctionGym, PauliGym
 
 
 def train(qubits=4, difficulty=5, envs=4096, horizon=12, iters=30, epochs=4, minibatches=4, lr=3e-4, clip=0.1, vf_coef=0.5,
           ent_coef=0.01, seed=0, log=print, env_kind="linear_function", bf16=False):
     torch.manual_seed(seed)
     edges = [(i, i + 1) for i in range(qubits - 1)] + [(i + 1, i) for i in range(qubits - 1)]
-    cls = {"linear_function": LinearFunctionGym, "clifford": CliffordGym}[env_kind]
-    gym = cls.from_coupling_map(edges, difficulty=difficulty, add_inverts=False, add_perms=False)
+    cls = {"linear_function": LinearFunctionGym, "clifford": CliffordGym, "pauli": PauliGym}[env_kind]
+    gym = cls.from_coupling_map(edges, difficulty=difficulty, add_inverts=False, add_perms=False)  # (PauliGym has no add_inverts: filtered out)
     env = gym.vec(batch=envs, track_solution=False)
     rows, cols = env.obs_shape_
     if bf16:  # the default policy shape: both policy-layer kernels apply (hidden 512 % 64 == 0, middle layer 256)
@@ -87,7 +88,7 @@ if __name__ == "__main__":
     ap.add_argument("--difficulty", type=int, default=5)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--envs", type=int, default=4096)
-    ap.add_argument("--env", default="linear_function", choices=["linear_function", "clifford"])
+    ap.add_argument("--env", default="linear_function", choices=["linear_function", "clifford", "pauli"])
     ap.add_argument("--bf16", action="store_true")
     a = ap.parse_args()
     train(qubits=a.qubits, difficulty=a.difficulty, iters=a.iters, envs=a.envs, env_kind=a.env, bf16=a.bf16)

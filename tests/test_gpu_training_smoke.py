@@ -30,3 +30,13 @@ def test_ppo_learns_with_the_policy_layer_kernels_in_the_loop():
     history = train(qubits=3, difficulty=4, envs=4096, horizon=10, iters=30, env_kind="clifford", bf16=True, log=lambda *_: None)
     start, end = sum(history[:3]) / 3, sum(history[-3:]) / 3
     assert end > 0.2 and end > 10 * start, (start, end, history)  # seed 0: 0.008 -> 0.37 (deterministic kernels; margin for library GEMM choices)
+
+
+def test_ppo_learns_paulinetwork_synthesis_from_device_generated_targets():
+    """PauliGym 3q: targets from the device-side generator (reset_done), observation words -> qg_policy_embed_words ->
+    qg_policy_mid_head_sample -> step, f32 torch update.  Seed 0: 2 % -> 70 % solved within 24 iterations."""
+    from ppo_linear_function import train
+
+    history = train(qubits=3, difficulty=3, envs=4096, horizon=12, iters=24, env_kind="pauli", bf16=True, log=lambda *_: None)
+    start, end = sum(history[:3]) / 3, sum(history[-3:]) / 3
+    assert start < 0.1 and end > 0.3 and end > 5 * start, (start, end, history)
