@@ -29,7 +29,7 @@ from qiskit_gym_amd.envs import CliffordGym, LinearFunctionGym, PauliGym
 
 
 def train(qubits=4, difficulty=5, envs=4096, horizon=12, iters=30, epochs=4, minibatches=4, lr=3e-4, clip=0.1, vf_coef=0.5,
-          ent_coef=0.01, seed=0, log=print, env_kind="linear_function", bf16=False):
+          ent_coef=0.01, seed=0, log=print, env_kind="linear_function", bf16=False, return_policy=False):
     torch.manual_seed(seed)
     edges = [(i, i + 1) for i in range(qubits - 1)] + [(i + 1, i) for i in range(qubits - 1)]
     cls = {"linear_function": LinearFunctionGym, "clifford": CliffordGym, "pauli": PauliGym}[env_kind]
@@ -79,7 +79,7 @@ def train(qubits=4, difficulty=5, envs=4096, horizon=12, iters=30, epochs=4, min
         log(f"iter {it:3d}: {int(ends.sum()):6d} episodes, solved {rate:6.1%}, mean reward/step {float(ro.rewards.mean()):+.4f}, "
             f"{T * B / (time.perf_counter() - t0):.2e} env-steps/s incl. update")
     env.sync()
-    return history
+    return (history, gym, policy) if return_policy else history
 
 
 if __name__ == "__main__":

@@ -135,3 +135,42 @@ def test_pauli_solutions_carry_the_released_rotations():
         assert env.success() and env.solution() == sol
         checked += any(a >= 0x80000000 for a in sol)
     assert checked >= 1  # at least one solution released a rotation
+
+
+def test_pauli_train_then_synthesise_end_to_end():
+    """PauliGym 3q: a policy trained for a few seconds on device-generated targets (examples/ppo_linear_function.py) then drives
+    BatchedSynthesis on targets drawn by the oracle's restatement of the reference's generator and handed over through get_state's wire format;
+    every solution must reproduce the oracle's solution log and leave the oracle env solved."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from ppo_linear_function import train
+    from qiskit_gym_amd.synthesis import BatchedSynthesis
+
+    history, gym, policy = train(qubits=3, difficulty=3, envs=4096, horizon=12, iters=30, env_kind="pauli", bf16=True, log=lambda *_: None, return_policy=True)
+    assert history[-1] > 0.5, history
+    n, gs = gym.config["num_qubits"], gym.config["gateset"]
+    cfgk = {k: gym.config[k] for k in ("max_rotations", "max_depth", "depth_slope", "difficulty")}
+    raw, states = [], []
+    for k in range(40):
+        env = OracleEnv("pauli", n, gs, add_perms=0, track_solution=1, **cfgk)
+        env.pauli_reset_seeded(977, k)  # the oracle's restatement of PauliEnv::reset's target generator (pauli.rs:54-271): the training distribution
+        t = env.get_state()[: 4 * n * n].reshape(2 * n, 2 * n)
+        rots = []
+        for i in env.active_rotations():
+            x, z, _, _ = env.rotation(i)
+            rots.append("".join("IXZY"[int(x[q]) + 2 * int(z[q])] for q in range(n)))
+        raw.append((t, rots))
+        states.append(gym.get_state((t, rots)))
+    syn = BatchedSynthesis(gym, policy.float(), seed=2)
+    sols = syn.solve(states, num_searches=64)
+    assert sum(s is not None for s in sols) >= 32, syn.last_stats
+    for (t, rots), sol in zip(raw, sols):
+        if sol is None:
+            continue
+        env = OracleEnv("pauli", n, gs, add_perms=0, track_solution=1, **cfgk)
+        env.pauli_reset_from(t, rots)
+        for a in sol:
+            if a < 0x80000000:
+                env.step(int(a))
+        assert env.success() and env.solution() == sol
