@@ -126,3 +126,26 @@ def test_embed_words_limits():
         pack_embed_words(w, 5, 9)  # odd row count
     with pytest.raises(ValueError):
         pack_embed_words(torch.zeros((64, 8 * 9), device="cuda"), 8, 9)  # hidden not a multiple of 128
+
+
+def test_gathered_clifford16_shards_feed_the_first_layer_directly():
+    """BASELINE config 3 / 4: the packed observation the ranks all-gather is [B, 32] 32-bit row words; viewed as [B, 16] 64-bit words it is
+    the same row-major bit string (32 x 32 = 16 x 64), so the learner side runs qg_policy_embed_words on the gathered buffer as it is --
+    and gets what qg_vec_embed computes from the resident state on the owning rank."""
+    from qiskit_gym_amd.collector import embed, pack_embedding
+
+    B, hidden = 1500, 128
+    gs = line_gateset("clifford", 16)
+    env = VecEnv("clifford", 16, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=64)
+    env.reset(3)
+    packed_obs = env.observe_packed()
+    assert packed_obs.dtype == torch.int32 and packed_obs.shape == (B, 32)
+    words = packed_obs.view(torch.int64)
+    assert words.shape == (B, 16)
+    obs = env.observe().to(torch.float64).flatten(1)
+    w, bias = _int_weights(hidden, 1024, 12)
+    wd, bd = w.cuda(), bias.cuda()
+    out = embed_words(words, 64, pack_embed_words(wd, 16, 64), bd, hidden, relu=True)
+    assert torch.equal(out.double(), (obs @ wd.double().t() + bd.double()).clamp_min(0))
+    assert torch.equal(out, embed(env, pack_embedding(env, wd), bd, hidden, relu=True))
+    env.sync()
