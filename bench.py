@@ -197,10 +197,20 @@ def main():
 
         # double-buffered, host-mediated hand-over to a side stream (see OverlappedGather: a stream-to-stream
         # event wait would slow every later graph replay on the step stream by ~40 %)
-        gatherer = OverlappedGather((B, 32), torch.int32, dev)
+        # one flat int32 shard per rank carries everything SURVEY 8e lists for the learner: the packed observation [B, 32], the f32
+        # rewards [B] and is_final / success [B] bytes each -- one collective instead of four
+        SHARD_WORDS = B * 32 + B + 2 * ((B + 3) // 4)
+        gatherer = OverlappedGather((SHARD_WORDS,), torch.int32, dev)
+
+        def fill_shard(buf):
+            env.observe_packed(out=buf[: B * 32].view(B, 32))
+            buf[B * 32 : B * 33].copy_(env.reward.view(torch.int32))
+            flags = buf[B * 33 :].view(torch.uint8)
+            flags[:B].copy_(env.done)
+            flags[4 * ((B + 3) // 4) : 4 * ((B + 3) // 4) + B].copy_(env.success)
 
         def snapshot_and_gather():
-            gatherer.submit(lambda buf: env.observe_packed(out=buf))
+            gatherer.submit(fill_shard)
 
         flush_gathers = gatherer.flush
 
@@ -373,7 +383,7 @@ def main():
                 "launch": "one step kernel per env.step(); chunks of %d launches replayed from a hipGraph" % CHUNK
                 if not multi else "one step kernel per env.step() (hipGraph chunks); no collective inside step",
                 "collective": None if not multi or args.no_gather else
-                f"RCCL all_gather_into_tensor of the bit-packed observation (8 MiB/rank) every {args.gather_every} steps, side stream, overlapped",
+                f"RCCL all_gather_into_tensor of one shard per rank (bit-packed observation 8 MiB + rewards + is_final / success flags) every {args.gather_every} steps, side stream, overlapped",
             },
             "roofline": {
                 "bound": "hbm",
