@@ -199,15 +199,12 @@ def main():
         # event wait would slow every later graph replay on the step stream by ~40 %)
         # one flat int32 shard per rank carries everything SURVEY 8e lists for the learner: the packed observation [B, 32], the f32
         # rewards [B] and is_final / success [B] bytes each -- one collective instead of four
-        SHARD_WORDS = B * 32 + B + 2 * ((B + 3) // 4)
-        gatherer = OverlappedGather((SHARD_WORDS,), torch.int32, dev)
+        from qiskit_gym_amd.distributed import fill_learner_shard, learner_shard_words
+
+        gatherer = OverlappedGather((learner_shard_words(B, 32),), torch.int32, dev)
 
         def fill_shard(buf):
-            env.observe_packed(out=buf[: B * 32].view(B, 32))
-            buf[B * 32 : B * 33].copy_(env.reward.view(torch.int32))
-            flags = buf[B * 33 :].view(torch.uint8)
-            flags[:B].copy_(env.done)
-            flags[4 * ((B + 3) // 4) : 4 * ((B + 3) // 4) + B].copy_(env.success)
+            fill_learner_shard(buf, B, 32, lambda view: env.observe_packed(out=view), env.reward, env.done, env.success)
 
         def snapshot_and_gather():
             gatherer.submit(fill_shard)

@@ -43,6 +43,35 @@ def all_gather_observation(local: torch.Tensor, out: Optional[torch.Tensor] = No
     return out
 
 
+def learner_shard_words(batch: int, obs_words: int) -> int:
+    """int32 words of one rank's hand-over shard: packed observation [batch, obs_words], f32 rewards [batch], `is_final` and
+    `success` bytes [batch] each (SURVEY.md 8e's three gathers as one flat buffer, every section 4-byte aligned)."""
+    return batch * obs_words + batch + 2 * ((batch + 3) // 4)
+
+
+def fill_learner_shard(buf: torch.Tensor, batch: int, obs_words: int, write_obs: Callable[[torch.Tensor], None], reward: torch.Tensor,
+                       done: torch.Tensor, success: torch.Tensor):
+    """Fill one rank's flat int32 shard in place: `write_obs(view)` writes the packed observation into its [batch, obs_words] view."""
+    pad = 4 * ((batch + 3) // 4)
+    write_obs(buf[: batch * obs_words].view(batch, obs_words))
+    buf[batch * obs_words : batch * (obs_words + 1)].copy_(reward.view(torch.int32))
+    flags = buf[batch * (obs_words + 1) :].view(torch.uint8)
+    flags[:batch].copy_(done)
+    flags[pad : pad + batch].copy_(success)
+
+
+def split_learner_shards(gathered: torch.Tensor, world: int, batch: int, obs_words: int):
+    """The all-gathered `[world * learner_shard_words]` buffer -> (obs [world*batch, obs_words] int32, reward [world*batch] f32,
+    done, success [world*batch] uint8), rank order = env order."""
+    n = learner_shard_words(batch, obs_words)
+    pad = 4 * ((batch + 3) // 4)
+    g = gathered.view(world, n)
+    obs = g[:, : batch * obs_words].reshape(world * batch, obs_words)
+    reward = g[:, batch * obs_words : batch * (obs_words + 1)].contiguous().view(torch.float32).reshape(-1)
+    flags = g[:, batch * (obs_words + 1) :].contiguous().view(torch.uint8).view(world, -1)
+    return obs, reward, flags[:, :batch].reshape(-1), flags[:, pad : pad + batch].reshape(-1)
+
+
 class OverlappedGather:
     """Double-buffered all-gather of a per-rank snapshot that overlaps with the work enqueued after it.
 

@@ -10,7 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from qiskit_gym_amd.distributed import OverlappedGather, all_gather_observation, local_actions, shard_range, unpack_rows_u32
+from qiskit_gym_amd.distributed import (OverlappedGather, all_gather_observation, fill_learner_shard, learner_shard_words, local_actions,
+                                        shard_range, split_learner_shards, unpack_rows_u32)
 
 
 def test_shard_ranges_partition_the_batch():
@@ -64,6 +65,17 @@ def _worker(rank, world, port, per_rank, d, result_q):
                 ok = ok and torch.equal(og.latest(), full + (k - 1))
         og.flush()
         ok = ok and torch.equal(og.latest(), full + 4)
+        # the flat hand-over shard bench.py gathers: packed observation + rewards + is_final / success flags in one collective
+        g = torch.Generator().manual_seed(99)
+        rew_full = torch.randn(total, generator=g)
+        done_full = torch.randint(0, 2, (total,), generator=g, dtype=torch.uint8)
+        succ_full = torch.randint(0, 2, (total,), generator=g, dtype=torch.uint8)
+        sl = slice(start, start + count)
+        sg = OverlappedGather((learner_shard_words(per_rank, d),), torch.int32, "cpu")
+        sg.submit(lambda buf: fill_learner_shard(buf, per_rank, d, lambda view: view.copy_(local), rew_full[sl], done_full[sl], succ_full[sl]))
+        sg.flush()
+        obs_g, rew_g, done_g, succ_g = split_learner_shards(sg.latest(), world, per_rank, d)
+        ok = ok and torch.equal(obs_g, full) and torch.equal(rew_g, rew_full) and torch.equal(done_g, done_full) and torch.equal(succ_g, succ_full)
         # max-over-ranks timing reduction used by bench.py
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -78,7 +90,7 @@ def test_all_gather_of_packed_observations_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 96, 32, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 97, 32, q)) for r in range(world)]  # 97: the flag sections of the shard need padding
     for p in procs:
         p.start()
     for p in procs:
