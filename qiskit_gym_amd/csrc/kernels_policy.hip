@@ -709,22 +709,28 @@ struct EmbedWordsArgs {
     uint32_t relu;
 };
 
-template <uint32_t KPG>
-__global__ __launch_bounds__(64 * EW_WAVES, 2) void embed_words_kernel(EmbedWordsArgs a) {
-    constexpr uint32_t CHUNK_VEC = KPG * EW_NB * 64u;  // uint4 per streamed chunk
+// NB = B fragments per k-step the workgroup computes: 4 (the packed column tile of 128) or 2 (one 64-column half of it: twice the
+// workgroups, for batches that would otherwise leave CUs idle; the packed weights are the same, the half's fragments are picked while staging).
+template <uint32_t KPG, uint32_t NB>
+__global__ __launch_bounds__(64 * EW_WAVES, NB == 2 ? 3 : 2) void embed_words_kernel(EmbedWordsArgs a) {
+    constexpr uint32_t CHUNK_VEC = KPG * NB * 64u;  // uint4 per streamed chunk
     __shared__ uint4 cbuf[2 * CHUNK_VEC];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t ct = blockIdx.x % a.n_ctiles;
-    const uint64_t etile = blockIdx.x / a.n_ctiles;
+    const uint32_t n_tiles_c = a.n_ctiles * (EW_NB / NB);  // column tiles of 32 NB
+    const uint32_t ct = blockIdx.x % n_tiles_c;
+    const uint64_t etile = blockIdx.x / n_tiles_c;
     const uint32_t G = a.groups;
-    const uint4 *wsrc = a.wp + (uint64_t)ct * G * CHUNK_VEC;
-    auto stage = [&](uint32_t g) {  // chunk g -> buffer g & 1
-        const uint4 *src = wsrc + (uint64_t)g * CHUNK_VEC;
+    const uint32_t first_frag = NB == EW_NB ? 0u : (ct % (EW_NB / NB)) * NB;  // this workgroup's fragments inside the packed k-step
+    const uint4 *wsrc = a.wp + (uint64_t)(ct / (EW_NB / NB)) * G * (KPG * EW_NB * 64u);
+    auto stage = [&](uint32_t g) {  // chunk g -> buffer g & 1, one fragment (1 KiB) per wave instruction
+        const uint4 *src = wsrc + (uint64_t)g * (KPG * EW_NB * 64u);
         uint4 *dst = cbuf + (g & 1u) * CHUNK_VEC;
 #pragma unroll
-        for (uint32_t c = 0; c < CHUNK_VEC; c += 64u * EW_WAVES)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + c + wave * 64u + lane),
-                                             (__attribute__((address_space(3))) void *)(dst + c + wave * 64u), 16, 0, 0);
+        for (uint32_t j0 = 0; j0 < KPG * NB; j0 += EW_WAVES) {
+            const uint32_t j = j0 + wave, ks = j / NB, f = j % NB;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (ks * EW_NB + first_frag + f) * 64u + lane),
+                                             (__attribute__((address_space(3))) void *)(dst + j * 64u), 16, 0, 0);
+        }
     };
     auto landed = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -740,11 +746,11 @@ __global__ __launch_bounds__(64 * EW_WAVES, 2) void embed_words_kernel(EmbedWord
         env = env < a.B ? env : a.B - 1;  // waves / rows past the batch compute on the last env (every wave takes part in the barriers)
         pw[i] = a.words + env * G;
     }
-    f32x16 acc[EW_MA][EW_NB];
+    f32x16 acc[EW_MA][NB];
 #pragma unroll
     for (uint32_t i = 0; i < EW_MA; ++i)
 #pragma unroll
-        for (uint32_t f = 0; f < EW_NB; ++f)
+        for (uint32_t f = 0; f < NB; ++f)
 #pragma unroll
             for (uint32_t q = 0; q < 16; ++q) acc[i][f][q] = 0.0f;
     stage(0);
@@ -765,11 +771,11 @@ __global__ __launch_bounds__(64 * EW_WAVES, 2) void embed_words_kernel(EmbedWord
     };
     // Software pipeline inside a chunk: while the 8 MFMAs of k-step s issue, the 4 B fragments of s + 1 are read from LDS and its
     // A fragments expanded into the other register set.  The chunk's first k-step is fetched right after the barrier.
-    bf16x8 af[2][EW_MA], bfr[2][EW_NB];
+    bf16x8 af[2][EW_MA], bfr[2][NB];
     {
         const uint4 *bl = cbuf + lane;
 #pragma unroll
-        for (uint32_t f = 0; f < EW_NB; ++f) bfr[0][f] = __builtin_bit_cast(bf16x8, bl[f * 64u]);
+        for (uint32_t f = 0; f < NB; ++f) bfr[0][f] = __builtin_bit_cast(bf16x8, bl[f * 64u]);
         expand(cur, 0, af[0]);
     }
     for (uint32_t g = 0; g < G; ++g) {
@@ -785,21 +791,21 @@ __global__ __launch_bounds__(64 * EW_WAVES, 2) void embed_words_kernel(EmbedWord
             const uint32_t c = s & 1u, n = c ^ 1u;
             if (s + 1u < KPG) {
 #pragma unroll
-                for (uint32_t f = 0; f < EW_NB; ++f) bfr[n][f] = __builtin_bit_cast(bf16x8, bl[((s + 1u) * EW_NB + f) * 64u]);
+                for (uint32_t f = 0; f < NB; ++f) bfr[n][f] = __builtin_bit_cast(bf16x8, bl[((s + 1u) * NB + f) * 64u]);
                 expand(cur, s + 1u, af[n]);
             }
 #pragma unroll
-            for (uint32_t f = 0; f < EW_NB; ++f)
+            for (uint32_t f = 0; f < NB; ++f)
 #pragma unroll
                 for (uint32_t i = 0; i < EW_MA; ++i) acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][i], bfr[c][f], acc[i][f], 0, 0, 0);
             if (s + 1u < KPG) {
                 // the first MFMA goes ahead of the next k-step's LDS reads: the wait for this k-step's fragments (read a whole k-step ago)
                 // then finds no younger LDS read outstanding -- with the reads first the compiler's lgkmcnt(0) also waits for those
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, EW_NB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
 #pragma unroll
-                for (uint32_t m = 1; m < EW_NB * EW_MA; ++m) {
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // a share of the next k-step's expansion
+                for (uint32_t m = 1; m < NB * EW_MA; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, NB == 2 ? 4 : 2, 0);  // a share of the next k-step's expansion
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
                 }
             }
@@ -811,7 +817,7 @@ __global__ __launch_bounds__(64 * EW_WAVES, 2) void embed_words_kernel(EmbedWord
         {   // KPG is even: the next chunk starts in register set 0 again
             const uint4 *bn = cbuf + ((g + 1u) & 1u) * CHUNK_VEC + lane;
 #pragma unroll
-            for (uint32_t f = 0; f < EW_NB; ++f) bfr[0][f] = __builtin_bit_cast(bf16x8, bn[f * 64u]);
+            for (uint32_t f = 0; f < NB; ++f) bfr[0][f] = __builtin_bit_cast(bf16x8, bn[f * 64u]);
             expand(cur, 0, af[0]);
         }
     }
@@ -819,10 +825,10 @@ __global__ __launch_bounds__(64 * EW_WAVES, 2) void embed_words_kernel(EmbedWord
     const uint64_t ldw = a.ld_out >> 1;
     const uint32_t lane_row = (lane & 3u) + 4u * h;
 #pragma unroll
-    for (uint32_t sl = 0; sl < EW_NB / 2u; ++sl) {
-        const uint32_t n0 = ct * EW_COLS + 64u * sl + 2u * r;
+    for (uint32_t sl = 0; sl < NB / 2u; ++sl) {
+        const uint32_t n0 = ct * (32u * NB) + 64u * sl + 2u * r;
         const float bias0 = a.bias ? a.bias[n0] : 0.0f, bias1 = a.bias ? a.bias[n0 + 1] : 0.0f;
-        uint32_t *const out_lane = a.out + ((ct * EW_COLS + 64u * sl + 8u * (r >> 2)) >> 1);
+        uint32_t *const out_lane = a.out + ((ct * (32u * NB) + 64u * sl + 8u * (r >> 2)) >> 1);
 #pragma unroll
         for (uint32_t i = 0; i < EW_MA; ++i) {
 #pragma unroll
@@ -984,10 +990,19 @@ int qg_policy_embed_words(const uint64_t *words_dev, uint64_t batch, uint32_t ro
     if (etiles * a.n_ctiles > 0x7FFFFFFFull) return set_error(QG_ERR_UNSUPPORTED, "batch too large for one launch");
     const dim3 grid((unsigned)(etiles * a.n_ctiles)), block(64 * EW_WAVES);
     hipStream_t s = (hipStream_t)stream;
-    switch (ew_kpg(cols)) {
-    case 4: hipLaunchKernelGGL(embed_words_kernel<4>, grid, block, 0, s, a); break;
-    case 6: hipLaunchKernelGGL(embed_words_kernel<6>, grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL(embed_words_kernel<8>, grid, block, 0, s, a); break;
+    // 64-column workgroup tiles while 128-column ones would not give every CU its two workgroups
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const bool narrow = etiles * a.n_ctiles < 2ull * (uint64_t)cus;
+    const dim3 ngrid((unsigned)(etiles * a.n_ctiles * 2u));
+    switch (ew_kpg(cols) * 10u + (narrow ? 2u : 4u)) {
+    case 42: hipLaunchKernelGGL((embed_words_kernel<4, 2>), ngrid, block, 0, s, a); break;
+    case 44: hipLaunchKernelGGL((embed_words_kernel<4, 4>), grid, block, 0, s, a); break;
+    case 62: hipLaunchKernelGGL((embed_words_kernel<6, 2>), ngrid, block, 0, s, a); break;
+    case 64: hipLaunchKernelGGL((embed_words_kernel<6, 4>), grid, block, 0, s, a); break;
+    case 82: hipLaunchKernelGGL((embed_words_kernel<8, 2>), ngrid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((embed_words_kernel<8, 4>), grid, block, 0, s, a); break;
     }
     HIP_TRY(hipGetLastError());
     return QG_OK;

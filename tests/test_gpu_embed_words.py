@@ -22,6 +22,8 @@ SHAPES = [  # rows, cols, batch, hidden
     (40, 49, 513, 128),    # cols > 48: full high word
     (64, 64, 700, 128),    # CliffordGym 32q
     (2, 64, 256, 128),
+    (40, 45, 33000, 512),  # enough tiles for the 128-column workgroup shape (smaller launches use 64-column tiles)
+    (6, 64, 70000, 256),
 ]
 
 
