@@ -116,8 +116,19 @@ def parity_replay(gateset, seed, ids, ring_actions, trace, snap):
         "depth": bool(np.array_equal(snap["depth"], d)),
         "observation": bool(np.array_equal(snap["obs"].reshape(len(ids), -1), ov.observe_dense())),
     }
+    import hashlib
+
+    def digest(obs, reward, success, depth):  # SHA-256 over the final (state, reward bits, success, depth) streams
+        h = hashlib.sha256()
+        for arr in (np.asarray(obs, dtype=np.uint8), f32_bits(reward).astype(np.uint32), np.asarray(success, dtype=np.uint8), np.asarray(depth, dtype=np.int32)):
+            h.update(np.ascontiguousarray(arr).tobytes())
+        return h.hexdigest()
+
+    sha_gpu = digest(snap["obs"].reshape(len(ids), -1), snap["reward"], snap["success"], snap["depth"])
+    sha_cpu = digest(ov.observe_dense(), r, s, d)
+    ok["sha256"] = sha_gpu == sha_cpu
     return {"envs": int(len(ids)), "steps_replayed": len(trace), "checked": sorted(ok), "bit_exact": all(ok.values()),
-            "mismatch": [k for k, v in ok.items() if not v]}
+            "mismatch": [k for k, v in ok.items() if not v], "sha256_hip": sha_gpu, "sha256_oracle": sha_cpu}
 
 
 def main():
