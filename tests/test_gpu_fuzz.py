@@ -1,9 +1,11 @@
+import os
 """Randomised parity: arbitrary gatesets (any of the eight gate kinds on any qubit pair, repeated
 gates, two-qubit gates on equal qubits, gates an env ignores), random option / weight / depth
 combinations and batch sizes, stepped against the CPU oracle.  Every case is seeded."""
 import numpy as np
 import pytest
 
+SEED_OFFSET = int(os.environ.get("QGYM_FUZZ_SEED_OFFSET", "0"))  # soak runs: shift every case to fresh seeds
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
@@ -62,6 +64,7 @@ def _case(seed):
 
 @pytest.mark.parametrize("seed", range(150))
 def test_random_gatesets_and_options(seed):
+    seed += SEED_OFFSET
     rng, kind, n, gs, cfg, batch = _case(seed)
     A = len(gs)
     ov, gv = make_pair(kind, n, gs, batch, **cfg)
@@ -96,6 +99,7 @@ def test_random_gatesets_and_options(seed):
 def test_random_pauli_networks(seed):
     from qiskit_gym_amd.vec import VecEnv
 
+    seed += SEED_OFFSET
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.choice([2, 3, 5, 8, 13, 20, 24, 25, 32]))
     gs = random_gateset(rng, n, int(rng.integers(2, 36)), allow_equal=False)
@@ -133,6 +137,20 @@ def test_random_pauli_networks(seed):
         np.testing.assert_array_equal(f32_bits(gv.reward.cpu().numpy()), np.array([o.reward_bits() for o in envs], dtype=np.uint32), err_msg=f"reward t={t} {label}")
         np.testing.assert_array_equal(gv.done.cpu().numpy(), [int(o.is_final()) for o in envs], err_msg=f"final t={t} {label}")
         np.testing.assert_array_equal(gv.depth.cpu().numpy(), [o.depth() for o in envs], err_msg=f"depth t={t} {label}")
+    if not cfg["track_solution"]:  # a fused rollout on top (T steps in one launch: LDS-resident tile on the compact layout, registers otherwise)
+        T = 10
+        acts = rng.integers(-1, len(gs) + 1, size=(T, batch))
+        rew = torch.zeros((T, batch), dtype=torch.float32, device="cuda")
+        fin = torch.zeros((T, batch), dtype=torch.uint8, device="cuda")
+        gv.rollout(torch.as_tensor(acts, device="cuda", dtype=torch.int32), fused=True, rewards_out=rew, dones_out=fin)
+        gv.sync()
+        want_r, want_f = np.zeros((T, batch), np.uint32), np.zeros((T, batch), np.uint8)
+        for t in range(T):
+            for e, o in enumerate(envs):
+                o.step(int(acts[t, e]))
+                want_r[t, e], want_f[t, e] = o.reward_bits(), o.is_final()
+        np.testing.assert_array_equal(f32_bits(rew.cpu().numpy()), want_r, err_msg=f"fused rewards {label}")
+        np.testing.assert_array_equal(fin.cpu().numpy(), want_f, err_msg=f"fused finals {label}")
     np.testing.assert_array_equal(gv.observe().cpu().numpy(), np.stack([o.dense_obs() for o in envs]), err_msg=f"obs {label}")
     np.testing.assert_array_equal(gv.get_state("i64").cpu().numpy(), np.stack([o.get_state() for o in envs]), err_msg=f"state {label}")
     if cfg["track_solution"]:
