@@ -21,7 +21,8 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-from .collector import BasicPolicy, sample_actions
+from . import _lib
+from .collector import BasicPolicy, embed, mid_head_sample, pack_embedding, pack_head, pack_mid, sample_actions
 from .envs.gyms import ROTATION_MARKER
 from .vec import VecEnv
 
@@ -50,7 +51,24 @@ class BatchedSynthesis:
         self.device = device
         self._policy = policy
         self._vecs: Dict[tuple, VecEnv] = {}
+        self._packed = None  # (vec, packed first layer, its f32 bias, packed middle layer, packed head): the policy-layer kernels' operands
         self.last_stats: dict = {}
+
+    def _kernels(self, vec: VecEnv):
+        """Operands of the two policy-layer kernels (qg_vec_embed, qg_policy_mid_head_sample: bf16 products, f32 accumulation) when the
+        policy has the default shape and the env a TILE layout; None otherwise (the torch forward is used)."""
+        if self._packed is not None and self._packed[0] is vec:
+            return self._packed
+        pol = self._policy
+        if not isinstance(pol, BasicPolicy):
+            return None
+        try:
+            w, b, A = pol.fused_heads()
+            self._packed = (vec, pack_embedding(vec, pol.embeddings.weight), pol.embeddings.bias.detach().float().contiguous(),
+                            pack_mid(pol.common.weight, pol.common.bias), pack_head(w, b, A, A, after_mid=True))
+        except (ValueError, _lib.QGymError):
+            self._packed = None
+        return self._packed
 
     def _vec(self, batch: int, track_solution: bool) -> VecEnv:
         key = (batch, track_solution)
@@ -79,8 +97,10 @@ class BatchedSynthesis:
             vec.set_state(np.repeat(np.asarray(states, dtype=np.int64), repeat, axis=0), fmt="i64")
 
     @torch.no_grad()
-    def solve(self, states: Sequence[Sequence[int]], deterministic: bool = False, num_searches: int = 100) -> List[Optional[List[int]]]:
-        """One entry per target: `Env::solution()` of the best successful search, or None (rl/synthesis.py:121-126)."""
+    def solve(self, states: Sequence[Sequence[int]], deterministic: bool = False, num_searches: int = 100, fast: Optional[bool] = None) -> List[Optional[List[int]]]:
+        """One entry per target: `Env::solution()` of the best successful search, or None (rl/synthesis.py:121-126).
+        fast: run the sampled searches' forward pass and draw on the policy-layer kernels (bf16 products; default: when they apply and the
+        batch has at least 4 096 envs); solutions are valid either way -- the env decides what solves a target, the policy only proposes."""
         M = len(states)
         if M == 0:
             return []
@@ -95,13 +115,28 @@ class BatchedSynthesis:
         ret = torch.zeros(B, dtype=torch.float32, device=dev)
         parked = torch.full((B,), A, dtype=torch.int32, device=dev)  # out of range: no gate (clifford.rs:324)
         steps = 0
+        kern = None
+        if not deterministic and fast is not False and (fast or B >= 4096):
+            kern = self._kernels(vec)
+            if fast and kern is None:
+                raise ValueError("fast=True needs a BasicPolicy of the default shape on a TILE-layout env (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32)")
+        if kern is not None:
+            pol = self._policy
+            h1 = torch.empty((B, pol.embeddings.out_features), dtype=torch.bfloat16, device=dev)
+            act = torch.empty(B, dtype=torch.int32, device=dev)
+            scratch = torch.empty((3, B), dtype=torch.float32, device=dev)
+        self.last_stats = {"kernels": kern is not None}
         for t in range(T):
-            x = vec.observe_as(self.dtype)
-            logits = self._policy(x)[0]
-            if deterministic:
-                act = logits.argmax(dim=1).to(torch.int32)
+            if kern is not None:
+                embed(vec, kern[1], kern[2], h1.shape[1], relu=True, out=h1)
+                mid_head_sample(h1, kern[3], pol.common.out_features, kern[4], A, self.seed, t, actions=act, logp=scratch[0], entropy=scratch[1], values=scratch[2])
             else:
-                act = sample_actions(logits.contiguous(), self.seed, t)[0].to(torch.int32)
+                x = vec.observe_as(self.dtype)
+                logits = self._policy(x)[0]
+                if deterministic:
+                    act = logits.argmax(dim=1).to(torch.int32)
+                else:
+                    act = sample_actions(logits.contiguous(), self.seed, t)[0].to(torch.int32)
             actions[t] = torch.where(finished, parked, act)
             vec.step(actions[t])
             live = ~finished
@@ -119,8 +154,8 @@ class BatchedSynthesis:
         lengths = solved_at[idx].cpu().numpy()
         found = ok.any(dim=1).cpu().numpy()
         win = actions[:steps, idx].t().contiguous()  # [M, steps]
-        self.last_stats = {"targets": M, "searches": S, "steps": steps, "solved": int(found.sum()),
-                           "searches_solved": float(ok.float().mean()), "mean_gates": float(lengths[found].mean()) if found.any() else 0.0}
+        self.last_stats.update({"targets": M, "searches": S, "steps": steps, "solved": int(found.sum()),
+                           "searches_solved": float(ok.float().mean()), "mean_gates": float(lengths[found].mean()) if found.any() else 0.0})
         if vec.env_kind != "pauli":
             w = win.cpu().numpy()
             return [w[m, : lengths[m]].tolist() if found[m] else None for m in range(M)]

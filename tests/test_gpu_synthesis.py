@@ -174,3 +174,20 @@ def test_pauli_train_then_synthesise_end_to_end():
             if a < 0x80000000:
                 env.step(int(a))
         assert env.success() and env.solution() == sol
+
+
+def test_searches_on_the_policy_layer_kernels():
+    """fast=True: the sampled searches' forward pass and draw run on qg_vec_embed + qg_policy_mid_head_sample (bf16 products) instead of
+    torch; the reference's trained Clifford policy still solves every target and the oracle confirms each solution."""
+    kind, cfg, gateset, syn = make("clifford_3q_custom")
+    tg = targets(kind, cfg, gateset, 64, 24, 7)
+    sols = syn.solve(tg, num_searches=64, fast=True)
+    assert syn.last_stats["kernels"] and sum(s is not None for s in sols) >= 0.97 * len(tg), syn.last_stats
+    for state, sol in zip(tg, sols):
+        if sol is not None:
+            env = replay(kind, cfg, gateset, state, sol)
+            assert env.success() and env.solution() == sol
+    assert sols == syn.solve(tg, num_searches=64, fast=True)  # same seed, same draws
+    kind, cfg, gateset, syn = make("lf_5_line")  # one-word layout: the kernels do not apply
+    with pytest.raises(ValueError):
+        syn.solve(targets(kind, cfg, gateset, 4, 8, 1), num_searches=8, fast=True)

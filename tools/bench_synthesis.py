@@ -34,5 +34,5 @@ for name, M, S in (("clifford_3q_custom", 1024, 64), ("lf_5_line", 1024, 64), ("
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     st = syn.last_stats
-    print(f"{name}: {M} targets x {S} searches: {dt * 1e3:.1f} ms ({dt / M * 1e6:.1f} us per target), solved {st['solved']}/{M}, "
+    print(f"{name}{' (policy-layer kernels)' if st.get('kernels') else ''}: {M} targets x {S} searches: {dt * 1e3:.1f} ms ({dt / M * 1e6:.1f} us per target), solved {st['solved']}/{M}, "
           f"{st['searches_solved']:.1%} of searches, mean gates {st['mean_gates']:.1f}, {st['steps']} steps", flush=True)
