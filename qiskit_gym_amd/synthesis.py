@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .collector import BasicPolicy, embed, mid_head_sample, pack_embedding, pack_head, pack_mid, sample_actions
+from .collector import BasicPolicy, embed, embed_words, mid_head_sample, pack_embed_words, pack_embedding, pack_head, pack_mid, sample_actions
 from .envs.gyms import ROTATION_MARKER
 from .vec import VecEnv
 
@@ -56,7 +56,7 @@ class BatchedSynthesis:
 
     def _kernels(self, vec: VecEnv):
         """Operands of the two policy-layer kernels (qg_vec_embed, qg_policy_mid_head_sample: bf16 products, f32 accumulation) when the
-        policy has the default shape and the env a TILE layout; None otherwise (the torch forward is used)."""
+        policy has the default shape and the env a TILE layout or 64-bit observation words; None otherwise (the torch forward is used)."""
         if self._packed is not None and self._packed[0] is vec:
             return self._packed
         pol = self._policy
@@ -64,8 +64,16 @@ class BatchedSynthesis:
             return None
         try:
             w, b, A = pol.fused_heads()
-            self._packed = (vec, pack_embedding(vec, pol.embeddings.weight), pol.embeddings.bias.detach().float().contiguous(),
-                            pack_mid(pol.common.weight, pol.common.bias), pack_head(w, b, A, A, after_mid=True))
+            try:
+                first = pack_embedding(vec, pol.embeddings.weight)  # TILE layout: the first layer reads the resident state
+                words = False
+            except (ValueError, _lib.QGymError):
+                if vec.packed_word_bytes != 8 or vec.packed_words_per_env != vec.obs_shape_[0]:
+                    raise
+                first = pack_embed_words(pol.embeddings.weight, *vec.obs_shape_)  # 64-bit row words (PauliEnv, wide CliffordEnv): qg_policy_embed_words
+                words = True
+            self._packed = (vec, first, pol.embeddings.bias.detach().float().contiguous(), pack_mid(pol.common.weight, pol.common.bias),
+                            pack_head(w, b, A, A, after_mid=True), words)
         except (ValueError, _lib.QGymError):
             self._packed = None
         return self._packed
@@ -119,16 +127,20 @@ class BatchedSynthesis:
         if not deterministic and fast is not False and (fast or B >= 4096):
             kern = self._kernels(vec)
             if fast and kern is None:
-                raise ValueError("fast=True needs a BasicPolicy of the default shape on a TILE-layout env (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32)")
+                raise ValueError("fast=True needs a BasicPolicy of the default shape and an env whose state or packed observation the first-layer kernels read")
         if kern is not None:
             pol = self._policy
             h1 = torch.empty((B, pol.embeddings.out_features), dtype=torch.bfloat16, device=dev)
             act = torch.empty(B, dtype=torch.int32, device=dev)
             scratch = torch.empty((3, B), dtype=torch.float32, device=dev)
+            words_buf = torch.empty((B, vec.packed_words_per_env), dtype=torch.int64, device=dev) if kern[5] else None
         self.last_stats = {"kernels": kern is not None}
         for t in range(T):
             if kern is not None:
-                embed(vec, kern[1], kern[2], h1.shape[1], relu=True, out=h1)
+                if kern[5]:
+                    embed_words(vec.observe_packed(out=words_buf), vec.obs_shape_[1], kern[1], kern[2], h1.shape[1], relu=True, out=h1)
+                else:
+                    embed(vec, kern[1], kern[2], h1.shape[1], relu=True, out=h1)
                 mid_head_sample(h1, kern[3], pol.common.out_features, kern[4], A, self.seed, t, actions=act, logp=scratch[0], entropy=scratch[1], values=scratch[2])
             else:
                 x = vec.observe_as(self.dtype)

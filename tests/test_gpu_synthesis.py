@@ -163,8 +163,11 @@ def test_pauli_train_then_synthesise_end_to_end():
         raw.append((t, rots))
         states.append(gym.get_state((t, rots)))
     syn = BatchedSynthesis(gym, policy.float(), seed=2)
-    sols = syn.solve(states, num_searches=64)
-    assert sum(s is not None for s in sols) >= 32, syn.last_stats
+    fast = syn.solve(states, num_searches=64, fast=True)  # first layer from the packed observation words (qg_policy_embed_words)
+    assert syn.last_stats["kernels"] and sum(s is not None for s in fast) >= 32, syn.last_stats
+    sols = syn.solve(states, num_searches=64, fast=False)
+    assert not syn.last_stats["kernels"] and sum(s is not None for s in sols) >= 32, syn.last_stats
+    sols = [a if a is not None else b for a, b in zip(fast, sols)]  # every solution of either path goes to the oracle below
     for (t, rots), sol in zip(raw, sols):
         if sol is None:
             continue
