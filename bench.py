@@ -334,28 +334,29 @@ def main():
         fused = {"value": B * FT * 8 / (fms * 1e-3), "unit": "env-steps/s", "steps_per_launch": FT,
                  "kernel": "qg::qm_fused_lds_kernel<16, true, false> (rows resident in LDS; actions known up front)"}
 
-    # ---- the same step kernel at 2^20 envs: where the launch boundary (1.6 us) stops dominating -----
+    # ---- the same step kernel at 2^18 and 2^20 envs: where the launch boundary (1.6 us) stops dominating -----
     large = None
     if not multi and B == ENVS_PER_GPU and not args.no_large_batch:
-        LB = 1 << 20
-        big = VecEnv("clifford", n, gateset, LB, add_inverts=False, add_perms=False, track_solution=False, difficulty=SCRAMBLE)
-        bacts = torch.randint(0, A, (RING, LB), dtype=torch.int32, device=dev, generator=gen)
-        with torch.cuda.stream(stream):
-            big.reset(seed)
-            big.rollout_ring(bacts, CHUNK)
-            torch.cuda.synchronize()
-            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            b0.record(stream)
-            for _ in range(2):
+        sizes = []
+        for LB in (1 << 18, 1 << 20):
+            big = VecEnv("clifford", n, gateset, LB, add_inverts=False, add_perms=False, track_solution=False, difficulty=SCRAMBLE)
+            bacts = torch.randint(0, A, (RING, LB), dtype=torch.int32, device=dev, generator=gen)
+            with torch.cuda.stream(stream):
+                big.reset(seed)
                 big.rollout_ring(bacts, CHUNK)
-            b1.record(stream)
-        torch.cuda.synchronize()
-        big.sync()
-        lus = b0.elapsed_time(b1) * 1e3 / (2 * CHUNK)
-        lgb = ALGO_BYTES_PER_STEP * LB / (lus * 1e-6) / 1e9
-        large = {"envs": LB, "launch_us": lus, "achieved": lgb, "unit": "GB/s", "frac": lgb / HBM_PEAK_GBS,
-                 "note": "same kernel and layout, 16x the batch: per-launch time is kernel time, not launch boundary"}
-        del big, bacts
+                torch.cuda.synchronize()
+                b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                b0.record(stream)
+                for _ in range(2):
+                    big.rollout_ring(bacts, CHUNK)
+                b1.record(stream)
+            torch.cuda.synchronize()
+            big.sync()
+            lus = b0.elapsed_time(b1) * 1e3 / (2 * CHUNK)
+            lgb = ALGO_BYTES_PER_STEP * LB / (lus * 1e-6) / 1e9
+            sizes.append({"envs": LB, "launch_us": lus, "achieved": lgb, "unit": "GB/s", "frac": lgb / HBM_PEAK_GBS})
+            del big, bacts
+        large = dict(sizes[-1], note="same kernel and layout, 16x the batch: per-launch time is kernel time, not launch boundary", by_batch=sizes)
 
     out = None
     if rank == 0:
