@@ -35,6 +35,26 @@ def decode_pauli_solution(encoded_solution: List[int]) -> List[Tuple[str, int, i
     return result
 
 
+def pauli_solution_operations(solution: List[int], gateset, rotation_params=None) -> List[Tuple[str, Tuple[int, ...], object]]:
+    """A PauliGym solution as circuit operations in order, without qiskit: `(name, qubits, parameter)`.
+    Gates come from the gateset -- CX with its qubits REVERSED, because PauliNetwork::cnot uses the opposite convention to the gateset's
+    (control, target) (reference envs/synthesis.py:489-497) -- and a released rotation `(axis, qubit, index, sign)` becomes
+    `("rx" | "ry" | "rz", (qubit,), sign * rotation_params[index])`, or `(index, sign)` when no parameters are given (:498-504)."""
+    ops = []
+    for kind, a1, a2, a3 in decode_pauli_solution(solution):
+        if kind == "gate":
+            name, args = gateset[a1]
+            args = tuple(int(q) for q in args)
+            ops.append((name.lower(), args[::-1] if name.lower() == "cx" else args, None))
+        elif rotation_params is None:
+            ops.append((kind, (a1,), (a2, a3)))
+        elif a2 < len(rotation_params):
+            ops.append((kind, (a1,), a3 * rotation_params[a2]))
+        else:
+            raise ValueError("too few rotation parameters stored for this solution")
+    return ops
+
+
 class BaseSynthesisEnv:
     cls_name: str
     allowed_gates: List[str]
@@ -168,15 +188,46 @@ class PauliGym(GymFrontEnd, BaseSynthesisEnv):
                          metrics_weights=metrics_weights, add_perms=add_perms, pauli_layer_reward=pauli_layer_reward,
                          track_solution=track_solution)
         object.__setattr__(self, "_rotation_params", [])
+        object.__setattr__(self, "_original_circuit", None)
+
+    @staticmethod
+    def _parse_circuit(circuit):
+        """QuantumCircuit -> (Clifford, rotation labels, rotation angles) (reference envs/synthesis.py:316-364; needs qiskit): Clifford gates
+        compose onto a running Clifford, an rx / ry / rz becomes the single-qubit Pauli evolved through it (adjoint label) plus its angle."""
+        from qiskit.quantum_info import Clifford, Pauli
+
+        n = circuit.num_qubits
+        clifford = Clifford(np.eye(2 * n, dtype=bool))
+        labels, params = [], []
+        for inst in circuit.data:
+            name = inst.operation.name.lower()
+            qubits = [circuit.find_bit(q).index for q in inst.qubits]
+            if name in ("rx", "ry", "rz"):
+                chars = ["I"] * n
+                chars[n - 1 - qubits[0]] = name[1].upper()
+                labels.append(Pauli("".join(chars)).evolve(clifford).adjoint().to_label())
+                params.extend(inst.operation.params)
+            else:
+                clifford = clifford.compose(inst.operation, qubits)
+        return clifford, labels, params
 
     def get_state(self, input, rotations: List[str] = None):
-        """`(tableau, rotations)` -> the set_state wire format
-        [rot_count, tableau..., len, chars, ...] (reference envs/synthesis.py:451-461)."""
+        """`(tableau, rotations)` (or, with qiskit, a Clifford / a QuantumCircuit with rotations) -> the set_state wire format
+        [rot_count, tableau..., len, chars, ...] (reference envs/synthesis.py:413-464)."""
+        object.__setattr__(self, "_rotation_params", [])
+        object.__setattr__(self, "_original_circuit", None)
         if isinstance(input, tuple):
-            tableau, rotations = input
+            tableau, rotations = input  # a Clifford given in a tuple is taken as it is (already the adjoint)
+        elif hasattr(input, "data") and hasattr(input, "num_qubits") and not hasattr(input, "tableau"):  # QuantumCircuit
+            clifford, rotations, params = self._parse_circuit(input)
+            object.__setattr__(self, "_rotation_params", list(params))
+            object.__setattr__(self, "_original_circuit", input)
+            tableau = clifford.adjoint()
+        elif hasattr(input, "adjoint") and hasattr(input, "tableau"):  # a raw qiskit Clifford: the state holds its adjoint
+            tableau = input.adjoint()
         else:
             tableau = input
-        if hasattr(tableau, "tableau"):  # qiskit Clifford, already in adjoint form for tuple input
+        if hasattr(tableau, "tableau"):
             tableau = tableau.tableau[:, :-1].T
         rotations = list(rotations or [])
         state = [len(rotations)] + _tableau_state(tableau)
@@ -184,6 +235,32 @@ class PauliGym(GymFrontEnd, BaseSynthesisEnv):
             state.append(len(rot))
             state.extend(ord(c) for c in rot)
         return state
+
+    def solution_operations(self, actions: List[int]):
+        """The decoded solution as `(name, qubits, parameter)` operations (no qiskit needed): `pauli_solution_operations`."""
+        return pauli_solution_operations(actions, self.config["gateset"], self._rotation_params or None)
+
+    def build_circuit_from_solution(self, actions: List[int], input=None):
+        """Gates + released rotations as a QuantumCircuit, followed by the Clifford that corrects the Pauli phases when the original
+        circuit is known (reference envs/synthesis.py:466-518; needs qiskit)."""
+        from qiskit import QuantumCircuit
+        from qiskit.quantum_info import Clifford
+
+        qc = QuantumCircuit(self.config["num_qubits"])
+        for name, qubits, param in pauli_solution_operations(actions, self.config["gateset"], self._rotation_params):
+            if param is None:
+                getattr(qc, name)(*qubits)
+            else:
+                getattr(qc, name)(param, qubits[0])
+        original = input if (hasattr(input, "data") and hasattr(input, "num_qubits") and not hasattr(input, "tableau")) else self._original_circuit
+        if original is not None:
+            rest = qc.inverse().compose(original)
+            only_clifford = QuantumCircuit.copy_empty_like(rest)
+            for g in rest:
+                if g.operation.name not in ("rx", "ry", "rz"):
+                    only_clifford.append(g.operation, g.qubits)
+            qc = qc.compose(Clifford(only_clifford).to_circuit())
+        return qc
 
 
 SYNTH_ENVS = {

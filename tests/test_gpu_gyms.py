@@ -109,3 +109,25 @@ def test_vec_gym_autoreset_replays_on_the_oracle(cls, n):
                 ended += 1
     assert ended > B  # several episodes per env
     venv.venv.sync()
+
+
+def test_pauli_solution_operations_decode_gates_and_rotations():
+    """The qiskit-free decoder of a PauliGym solution (reference envs/synthesis.py:466-512): CX comes out with its qubits reversed, a released
+    rotation as (axis, qubit, sign * angle); checked on a target the env solves in two steps."""
+    from qiskit_gym_amd.envs import PauliGym
+    from qiskit_gym_amd.envs.gyms import pauli_solution_operations
+
+    gs = [("H", (0,)), ("CX", (0, 1)), ("S", (1,))]
+    gym = PauliGym(2, gs, max_rotations=2, add_perms=False)
+    # identity tableau, one rotation Z(x)Z: the CX maps it onto a single qubit, and the `clean` that follows the cnot releases it
+    state = gym.get_state((np.eye(4, dtype=np.uint8), ["ZZ"]))
+    gym._raw_env.set_state(state)
+    gym._raw_env.step(1)
+    sol = gym._raw_env.solution()
+    ops = gym.solution_operations(sol)
+    assert len(ops) == 2 and ops[0] == ("cx", (1, 0), None)
+    name, (q,), (index, sign) = ops[1]
+    assert name == "rz" and q in (0, 1) and index == 0 and sign in (1, -1)
+    assert pauli_solution_operations(sol, gs, [0.25]) == [("cx", (1, 0), None), ("rz", (q,), sign * 0.25)]
+    with pytest.raises(ValueError):
+        pauli_solution_operations(sol, gs, [])
