@@ -103,6 +103,11 @@ class BaseSynthesisEnv:
         return synth_circuit
 
 
+def _is_qiskit_object(x) -> bool:
+    """QuantumCircuit / Clifford (anything that is not a plain matrix, list or tuple) -- without importing qiskit."""
+    return not isinstance(x, (np.ndarray, list, tuple)) and (hasattr(x, "adjoint") or hasattr(x, "num_qubits"))
+
+
 def _tableau_state(x) -> List[int]:
     return np.asarray(x).astype(int).flatten().tolist()
 
@@ -121,7 +126,7 @@ class CliffordGym(GymFrontEnd, BaseSynthesisEnv):
     def get_state(self, input):
         """QuantumCircuit / qiskit Clifford -> adjoint tableau without the phase column, transposed
         (reference envs/synthesis.py:206-209); a 2N x 2N 0/1 matrix is passed through."""
-        if hasattr(input, "adjoint") or hasattr(input, "data"):
+        if _is_qiskit_object(input):
             from qiskit import QuantumCircuit
             from qiskit.quantum_info import Clifford
 
@@ -129,6 +134,29 @@ class CliffordGym(GymFrontEnd, BaseSynthesisEnv):
                 input = Clifford(input)
             return input.adjoint().tableau[:, :-1].T.flatten().astype(int).tolist()
         return _tableau_state(input)
+
+    def post_process_synthesis(self, synth_circuit, input):
+        """The synthesised gates fix the tableau, not the Pauli phases: add the X / Y / Z layer that does, and return the circuit of the
+        input itself rather than of its inverse (reference envs/synthesis.py:161-176, 210-217; needs qiskit).  Matrix inputs carry no phases:
+        the circuit is returned as built."""
+        if not _is_qiskit_object(input):
+            return synth_circuit
+        from qiskit import QuantumCircuit
+        from qiskit.quantum_info import Clifford
+
+        inverse = synth_circuit.inverse()
+        target = Clifford(input) if isinstance(input, QuantumCircuit) else input
+        rest = Clifford(inverse).compose(target)
+        paulis = QuantumCircuit(rest.num_qubits)
+        for q in range(rest.num_qubits):
+            stab, destab = rest.stab_phase[q], rest.destab_phase[q]
+            if destab and stab:
+                paulis.y(q)
+            elif stab:
+                paulis.x(q)
+            elif destab:
+                paulis.z(q)
+        return paulis.compose(inverse).inverse()
 
 
 class LinearFunctionGym(GymFrontEnd, BaseSynthesisEnv):
@@ -143,7 +171,7 @@ class LinearFunctionGym(GymFrontEnd, BaseSynthesisEnv):
                          track_solution=track_solution)
 
     def get_state(self, input):
-        if hasattr(input, "data") or hasattr(input, "linear"):  # reference envs/synthesis.py:254-258
+        if _is_qiskit_object(input) or hasattr(input, "linear"):  # reference envs/synthesis.py:254-258
             from qiskit.circuit.library.generalized_gates import LinearFunction
             from qiskit.quantum_info import Clifford
 

@@ -131,3 +131,20 @@ def test_pauli_solution_operations_decode_gates_and_rotations():
     assert pauli_solution_operations(sol, gs, [0.25]) == [("cx", (1, 0), None), ("rz", (q,), sign * 0.25)]
     with pytest.raises(ValueError):
         pauli_solution_operations(sol, gs, [])
+
+
+def test_get_state_takes_plain_matrices_without_qiskit():
+    """numpy matrices / nested lists go straight into the wire format (qiskit objects need qiskit, which is optional)."""
+    c = CliffordGym.from_coupling_map(line_edges(2), add_inverts=False, add_perms=False)
+    m = np.eye(4, dtype=np.uint8)
+    m[[0, 2]] = m[[2, 0]]  # H on qubit 0: rows X0 <-> Z0
+    assert c.get_state(m) == m.astype(int).flatten().tolist() == c.get_state(m.tolist())
+    c._raw_env.set_state(c.get_state(m))
+    c._raw_env.step(0)  # H(0)
+    assert c._raw_env.success()
+    lf = LinearFunctionGym.from_coupling_map(line_edges(3), add_inverts=False, add_perms=False)
+    a = np.array([[1, 0, 0], [1, 1, 0], [0, 0, 1]])
+    assert lf.get_state(a) == a.flatten().tolist()
+    qc = c.build_circuit_from_solution  # building circuits needs qiskit
+    with pytest.raises(ImportError):
+        qc([0], m)
