@@ -13,6 +13,14 @@ reads (`qg_vec_observe_dense_as`), actions / log-probs / entropy / values come o
 kernel (`qg_sample_actions`), rewards and episode ends are written by the step kernel into row t of
 the rollout, and GAE(lambda) runs as one kernel over the finished [T, B] rollout (`qg_gae`).
 
+For the reference's default policy shape in bf16 (and batches of a few thousand envs or more) the forward
+pass needs no tensor library and no observation at all:
+
+    reset_done -> [packed observation for the rollout] -> first layer from the bits -> middle layer + head + draw -> step
+
+`qg_vec_embed` reads the resident TILE-layout state, `qg_policy_embed_words` the packed observation words of every
+other layout (PauliEnv, wide CliffordEnv), `qg_policy_mid_head_sample` does the rest in one kernel.
+
 `BasicPolicy` mirrors the shape of the reference's default policy network (`twisterl.nn.BasicPolicy`
 as configured by `BasicPolicyConfig`, `rl/configs.py:531-607`; checkpoint shapes in
 `examples/models/*.pt`): Linear(prod(obs_shape) -> 512) -> ReLU -> Linear(512 -> 256) -> ReLU ->
