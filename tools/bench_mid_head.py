@@ -1,4 +1,6 @@
-"""Time qg_policy_mid_head_sample (middle layer + head + draw) on random activations.  Run on the GPU box."""
+"""Time qg_policy_mid_head_sample (middle layer + head + draw) on random activations.  Run on the GPU box.
+ISOLATE=1 puts another kernel (a 64 MB fill) between the launches and subtracts its time: back-to-back launches of the same kernel overlap their
+tails, which flatters variants that are slower inside the collector."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,10 +16,24 @@ for B, A in ((65536, 170), (65536, 214), (8192, 170)):
     pm, ph = pack_mid(w2, b2), pack_head(wh, bh, A, A, after_mid=True)
     outs = mid_head_sample(h, pm, 256, ph, A, 1, 0)
     torch.cuda.synchronize()
+    iso = os.environ.get("ISOLATE") == "1"
+    pad = torch.empty(16 << 20, dtype=torch.float32, device="cuda")
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fill_us = 0.0
+    if iso:
+        pad.fill_(1.0)
+        torch.cuda.synchronize()
+        a.record()
+        for i in range(20):
+            pad.fill_(float(i))
+        b.record()
+        torch.cuda.synchronize()
+        fill_us = a.elapsed_time(b) / 20 * 1e3
     a.record()
     for i in range(20):
         mid_head_sample(h, pm, 256, ph, A, 1, i, actions=outs[0], logp=outs[1], entropy=outs[2], values=outs[3])
+        if iso:
+            pad.fill_(float(i))
     b.record()
     torch.cuda.synchronize()
-    print(f"mid_head_sample {B} envs, {A} actions: {a.elapsed_time(b) / 20 * 1e3:.1f} us", flush=True)
+    print(f"mid_head_sample {B} envs, {A} actions{' (isolated launches)' if iso else ''}: {a.elapsed_time(b) / 20 * 1e3 - fill_us:.1f} us", flush=True)
