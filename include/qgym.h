@@ -186,6 +186,17 @@ int qg_stream_wait_stream(void *waiter_stream, void *producer_stream);
  * `observe_index`.  A caller that replays graphs sets them to the position inside the graph so
  * that eager and replayed launches draw alike (effective counter = this + the device clock). */
 int qg_vec_set_counters(qg_vec *v, uint64_t step_index, uint64_t observe_index);
+/* Seed of the handle's own counter-RNG streams: the add_inverts coin (clifford.rs:266 `gen_bool(0.5)`) and PauliEnv's
+ * observe() permutation draw (pauli.rs:657-662), when they are not supplied by the caller.  Handles start with one fixed
+ * seed (reproducible runs); a host that wants the reference's thread_rng behaviour -- independent streams per env object
+ * and per clone -- gives every handle its own seed. */
+int qg_vec_set_seed(qg_vec *v, uint64_t seed);
+/* Global index of this handle's env 0 in every counter-RNG draw (reset scramble, coins, PauliEnv targets and permutations):
+ * env e draws as env `first_env + e`.  A handle that holds the shard [first_env, first_env + batch) of a larger batch --
+ * one rank of a multi-GPU job, SURVEY 8e: GPU g owns envs [g*B/G, (g+1)*B/G) -- then draws exactly what the unsharded
+ * batch would, so a sharded run is bit-identical to the single-GPU run of the whole batch.  Default 0. */
+int qg_vec_set_env_base(qg_vec *v, uint64_t first_env);
+uint64_t qg_vec_get_env_base(const qg_vec *v);
 /* Same as qg_vec_reset, with the draws supplied: actions_dev[t*B + e], t < n_draws (int32). */
 int qg_vec_reset_with(qg_vec *v, const int32_t *actions_dev, size_t n_draws, void *stream);
 
@@ -342,6 +353,8 @@ typedef struct qg_env qg_env;
 
 int qg_env_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, int device, qg_env **out);
 int qg_env_clone(const qg_env *e, qg_env **out); /* Env: DynClone */
+/* seed of the env's own RNG streams (see qg_vec_set_seed); a clone starts with its source's seed and counters */
+int qg_env_set_seed(qg_env *e, uint64_t seed);
 void qg_env_destroy(qg_env *e);
 int64_t qg_env_num_actions(const qg_env *e);
 int qg_env_obs_shape(const qg_env *e, int64_t out[2]);

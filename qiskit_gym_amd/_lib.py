@@ -76,7 +76,7 @@ class QGymError(RuntimeError):
 EXPORTED_SYMBOLS = [
     "qg_config_default", "qg_last_error", "qg_abi_version", "qg_device_count", "qg_gate_parse",
     "qg_vec_create", "qg_vec_destroy", "qg_vec_get_info", "qg_vec_bind_outputs", "qg_vec_set_difficulty", "qg_vec_get_difficulty",
-    "qg_vec_set_state", "qg_vec_get_state", "qg_vec_reset", "qg_vec_reset_done", "qg_vec_set_clock", "qg_stream_wait_stream", "qg_vec_set_counters", "qg_vec_reset_with", "qg_vec_step", "qg_vec_rollout", "qg_vec_rollout_ring",
+    "qg_vec_set_state", "qg_vec_get_state", "qg_vec_reset", "qg_vec_reset_done", "qg_vec_set_clock", "qg_stream_wait_stream", "qg_vec_set_counters", "qg_vec_set_seed", "qg_vec_set_env_base", "qg_vec_get_env_base", "qg_vec_reset_with", "qg_vec_step", "qg_vec_rollout", "qg_vec_rollout_ring",
     "qg_vec_observe_dense", "qg_vec_observe_packed", "qg_vec_masks", "qg_vec_pauli_reset_from", "qg_vec_pauli_observe_dense", "qg_vec_pauli_num_perms", "qg_vec_sync",
     "qg_vec_solution",
     "qg_vec_observe_dense_as", "qg_expand_packed", "qg_widen_dense", "qg_sample_actions", "qg_gae",
@@ -84,7 +84,7 @@ EXPORTED_SYMBOLS = [
     "qg_policy_embed_words_packed_bytes", "qg_policy_pack_embed_words", "qg_policy_embed_words",
     "qg_policy_head_packed_bytes", "qg_policy_pack_head", "qg_policy_head_sample",
     "qg_policy_mid_packed_bytes", "qg_policy_pack_mid", "qg_policy_mid_head_sample",
-    "qg_env_create", "qg_env_clone", "qg_env_destroy", "qg_env_num_actions", "qg_env_obs_shape",
+    "qg_env_create", "qg_env_clone", "qg_env_set_seed", "qg_env_destroy", "qg_env_num_actions", "qg_env_obs_shape",
     "qg_env_set_difficulty", "qg_env_get_difficulty", "qg_env_set_state", "qg_env_reset", "qg_env_step",
     "qg_env_step_coin", "qg_env_masks", "qg_env_is_final", "qg_env_reward", "qg_env_success", "qg_env_observe",
     "qg_env_track_solution", "qg_env_solution", "qg_env_twists",
@@ -149,6 +149,11 @@ def load():
     L.qg_widen_dense.argtypes = [vp, u64, vp, C.c_int, vp]
     L.qg_vec_set_clock.argtypes = [vp, vp]
     L.qg_vec_set_counters.argtypes = [vp, u64, u64]
+    L.qg_vec_set_seed.argtypes = [vp, u64]
+    L.qg_vec_set_env_base.argtypes = [vp, u64]
+    L.qg_vec_get_env_base.argtypes = [vp]
+    L.qg_vec_get_env_base.restype = u64
+    L.qg_env_set_seed.argtypes = [vp, u64]
     L.qg_stream_wait_stream.argtypes = [vp, vp]
     L.qg_gae.argtypes = [vp, vp, vp, vp, C.c_float, C.c_float, sz, u64, vp, vp, vp]
     L.qg_vec_embed_packed_bytes.argtypes = [vp, C.c_uint32]

@@ -105,7 +105,7 @@ def pack_embedding(env: VecEnv, weight: torch.Tensor, out: Optional[torch.Tensor
         raise ValueError("embed needs a TILE-layout env (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32) and hidden % 64 == 0")
     if out is None:
         out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=weight.device)
-    _lib.check(L.qg_vec_pack_embedding(env._h, weight.data_ptr(), _DT[weight.dtype], weight.stride(0), hidden, out.data_ptr(), _stream_ptr()))
+    _lib.check(L.qg_vec_pack_embedding(env._h, weight.data_ptr(), _DT[weight.dtype], weight.stride(0), hidden, out.data_ptr(), env._stream()))
     return out
 
 
@@ -116,7 +116,7 @@ def embed(env: VecEnv, packed: torch.Tensor, bias: Optional[torch.Tensor], hidde
     if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
         raise ValueError("bias must be a contiguous f32 vector")
     _lib.check(_lib.load().qg_vec_embed(env._h, packed.data_ptr(), bias.data_ptr() if bias is not None else None, hidden, int(relu), out.data_ptr(),
-                                        out.stride(0), _stream_ptr()))
+                                        out.stride(0), env._stream()))
     return out
 
 

@@ -54,7 +54,7 @@ __device__ inline void scramble_flat(W (*rows)[QG_WAVE], uint32_t L, const InitA
     const uint64_t seed = init_seed(a);
     auto draw = [&](uint32_t t) -> uint32_t {
         if (t >= a.n_draws) return 0u;
-        const int64_t act = a.actions ? (int64_t)a.actions[(uint64_t)t * a.B + env] : (int64_t)rng_action(seed, env, t, a.num_actions);
+        const int64_t act = a.actions ? (int64_t)a.actions[(uint64_t)t * a.B + env] : (int64_t)rng_action(seed, a.env_base + env, t, a.num_actions);
         return (act >= 0 && act < (int64_t)a.num_actions) ? a.rowops[act] : 0u;
     };
     auto gate = [&](uint32_t o) {
@@ -89,7 +89,7 @@ __device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds,
     for (uint32_t c0 = 0; c0 < a.n_draws; c0 += CH) {
         const uint32_t len = a.n_draws - c0 < CH ? a.n_draws - c0 : CH;
         for (uint32_t k = sl; k < CH; k += S)  // the tail of the last chunk is padded with "no gate"
-            ops[k] = k < len ? a.rowops[rng_action(seed, env, c0 + k, a.num_actions)] : 0u;
+            ops[k] = k < len ? a.rowops[rng_action(seed, a.env_base + env, c0 + k, a.num_actions)] : 0u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (sl < 2) {

@@ -332,9 +332,9 @@ int qg_vec_observe_dense_as(qg_vec *v, void *out_dev, int out_dtype, void *strea
     qg_vec_info info;
     int rc = qg_vec_get_info(v, &info);
     if (rc != QG_OK) return rc;
-    HIP_TRY(hipSetDevice(v->device));
+    QG_ON_DEVICE(v);
     const uint64_t obs = (uint64_t)info.obs_rows * info.obs_cols;
-    if (v->layout == LAYOUT_PAULI && v->pauli_tile && (uint32_t)info.obs_cols <= 64u) {
+    if (v->layout == LAYOUT_PAULI && (uint32_t)info.obs_cols <= 64u) {
         v->perm_draw = true;  // PauliEnv::observe draws a new qubit permutation (pauli.rs:657-662)
         const hipError_t e = ptile_observe_typed(v, out_dev, out_dtype, (hipStream_t)stream);
         v->perm_draw = false;

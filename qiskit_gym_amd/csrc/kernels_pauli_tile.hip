@@ -1,6 +1,6 @@
 // kernels_pauli_tile.hip -- PauliEnv, thread-per-env ("PTILE" layout).  The default PauliEnv path.
 //
-// Reference semantics (same as kernels_pauli.hip, the lane-group family it replaces by default):
+// Reference semantics:
 //   PauliEnv::step / observe / reset tail     rust/src/envs/pauli.rs:588-635, 411-485, 573-585
 //   PauliNetwork::{act,cnot,h,s,sx,clean_and_return_with_phases,solved}   rust/src/pauli/pauli_network.rs:139-260
 //   Pauli::{evolve_h,evolve_s,evolve_cx,evolve_sx,phase}                  rust/src/pauli/pauli.rs:83-133
@@ -8,7 +8,7 @@
 //   petgraph 0.6.5 Graph::retain_nodes / remove_node (reverse visit + Vec::swap_remove): third
 //   party, restated from its published source (fixes the observation's rotation-column order).
 //
-// Why: the lane-group kernel spends ~200 wave-instructions per env-step (32 lanes per env).  Here a
+// Why thread-per-env: a lane-group form (32 lanes per env) spends ~200 wave-instructions per env-step.  Here a
 // lane owns a whole env -- 2N tableau rows as uint64 plus <= RM rotation records in VGPRs -- so a
 // wave instruction advances 64 envs and nothing crosses lanes.
 //
@@ -1076,6 +1076,7 @@ struct PTObsArgs {
     uint32_t n_perms, draw;
     uint64_t seed, counter;
     const uint64_t *clock;
+    uint64_t env_base;  // qg_vec_set_env_base
 };
 // the two observation rows qubit `q` of one env owns: tableau rows q and N + q (2N bits each, qubit-permuted
 // when add_perms) in wx / wz, and the active rotations' bits for those rows (DAG node order,
@@ -1093,7 +1094,7 @@ __device__ inline void ptile_obs_qubit(const PTObsArgs &pa, uint64_t env, uint32
         uint32_t pi;
         if (pa.draw) {  // `rng.gen_range(0..qubit_perms.len())` (pauli.rs:660), made reproducible
             pi = pa.perm_in ? (uint32_t)pa.perm_in[env] % pa.n_perms
-                            : (uint32_t)__umul64hi(rng_draw(pa.seed ^ 0x7065726Dull, env, pa.counter + clock_of(pa.clock)), (uint64_t)pa.n_perms);
+                            : (uint32_t)__umul64hi(rng_draw(pa.seed ^ 0x7065726Dull, pa.env_base + env, pa.counter + clock_of(pa.clock)), (uint64_t)pa.n_perms);
             if (q == 0) pa.perm_idx[env] = pi;  // current_perm_idx.store (pauli.rs:661)
         } else {
             pi = pa.perm_idx[env];
@@ -1191,7 +1192,7 @@ __global__ __launch_bounds__(256) void ptile_export_kernel(PTObsArgs pa) {
 // PauliEnv::reset on the device (pauli.rs:554-586): the random target generator
 // (get_pauli_under_diff / generate_paulis_with_difficulty / random_clifford_tableau, pauli.rs:115-271)
 // one env per lane, every draw from the counter-RNG stream rng_draw(seed ^ 0x7061756C, env, k),
-// k = 0, 1, 2, ... -- the stream the host generator (kernels_pauli.hip) and the tests use -- followed
+// k = 0, 1, 2, ... -- the stream the oracle-side tests replay -- followed
 // by the initial clean and the scalar resets.  Coupling-graph tables come from the host.
 // ------------------------------------------------------------------------------------------------
 struct PTGenArgs {
@@ -1236,7 +1237,7 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
     const uint32_t lane = (uint32_t)(env & (QG_WAVE - 1)), L = threadIdx.x & (QG_WAVE - 1);
     const uint32_t N = a.N;
     char *tile = PTLayout<NQ, RM>::tile(a.state, env);
-    PTStream rng{(ga.seed + QG_CLOCK_SEED_STRIDE * clock_of(a.clock)) ^ 0x7061756Cull, env, 0};
+    PTStream rng{(ga.seed + QG_CLOCK_SEED_STRIDE * clock_of(a.clock)) ^ 0x7061756Cull, a.env_base + env, 0};
     PTState<NQ, RM> s;
 #pragma unroll
     for (int k = 0; k < RM; ++k) s.rx[k] = s.rz[k] = s.rpred[k] = 0;
@@ -1406,9 +1407,8 @@ static void fill_pt_args(const qg_vec *v, const StepArgs &a, PTArgs &pa) {
 template <int NQ, int RM>
 static hipError_t pt_launch_step(const PTArgs &pa, hipStream_t s) {
     const dim3 grid(grid_for(pa.s.B, 256)), block(256);
-    static const bool dense_only = getenv("QGYM_PTILE_DENSE") != nullptr;  // development switch: always hold the tableau in registers
     const bool feat = pa.s.flags & (F_TRACK | F_LAYERS);
-    if (pa.s.T == 1 && !dense_only) {
+    if (pa.s.T == 1) {
         if constexpr (PTLayout<NQ, RM>::COMPACT) {
             if (feat) hipLaunchKernelGGL((ptile_step1c_kernel<NQ, RM, true>), grid, block, 0, s, pa);
             else hipLaunchKernelGGL((ptile_step1c_kernel<NQ, RM, false>), grid, block, 0, s, pa);
@@ -1416,7 +1416,7 @@ static hipError_t pt_launch_step(const PTArgs &pa, hipStream_t s) {
             if (feat) hipLaunchKernelGGL((ptile_step1_kernel<NQ, RM, true>), grid, block, 0, s, pa);
             else hipLaunchKernelGGL((ptile_step1_kernel<NQ, RM, false>), grid, block, 0, s, pa);
         }
-    } else if (!feat && !dense_only && !pa.n_perms && PTLayout<NQ, RM>::COMPACT && !getenv("QGYM_FUSED_REGS")) {
+    } else if (!feat && !pa.n_perms && PTLayout<NQ, RM>::COMPACT) {
         if constexpr (PTLayout<NQ, RM>::COMPACT)
             hipLaunchKernelGGL((ptile_fused1c_kernel<NQ, RM>), dim3(grid_for(pa.s.B, QG_WAVE)), dim3(QG_WAVE), 0, s, pa);
     } else if (feat) {
@@ -1475,6 +1475,7 @@ static void fill_obs(const qg_vec *v, const ObsArgs &a, PTObsArgs &pa) {
     pa.seed = v->coin_seed;
     pa.counter = v->observe_counter;
     pa.clock = v->clock_dev;
+    pa.env_base = v->env_base;
 }
 
 // dense observation in `out_dtype`: row words into the handle's scratch, then the write-bound expansion
@@ -1610,6 +1611,7 @@ int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s) 
     ga.n_cx = v->gen_ncx;
     ga.seed = seed;
     a.clock = v->clock_dev;
+    a.env_base = v->env_base;
     ga.difficulty = (uint32_t)v->difficulty;
     ga.pauli_difficulty = (uint32_t)(v->difficulty / std::max(v->cfg.pauli_diff_scale, 1));  // pauli.rs:557,392
     ga.max_paulis = v->rmax_generate;

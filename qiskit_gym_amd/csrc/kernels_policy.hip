@@ -873,7 +873,7 @@ int qg_vec_pack_embedding(qg_vec *v, const void *weight_dev, int weight_dtype, u
         return set_error(QG_ERR_UNSUPPORTED, "the bit-consuming first layer needs the TILE layout (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32)");
     if (hidden == 0 || hidden % EMB_SLAB) return set_error(QG_ERR_INVALID, "hidden size must be a multiple of %u", EMB_SLAB);
     if (ld < (uint64_t)v->D * v->D) return set_error(QG_ERR_INVALID, "weight rows are shorter than the observation (%u x %u)", v->D, v->D);
-    HIP_TRY(hipSetDevice(v->device));
+    QG_ON_DEVICE(v);
     const uint32_t R = v->has_z ? 2 * v->nxp : v->nxp;
     if (!v->embed_dump) HIP_TRY(hipMalloc(&v->embed_dump, 1024));  // see EmbedArgs::dump
     const uint64_t total = (uint64_t)hidden * 16u * emb_ksteps(R);
@@ -901,7 +901,7 @@ int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint3
     if (hidden == 0 || hidden % EMB_SLAB) return set_error(QG_ERR_INVALID, "hidden size must be a multiple of %u", EMB_SLAB);
     if (ld_out < hidden || (ld_out & 7u) || (reinterpret_cast<uintptr_t>(out_dev) & 15u))
         return set_error(QG_ERR_INVALID, "the output must be 16-byte aligned with a row stride that is a multiple of 8 elements");
-    HIP_TRY(hipSetDevice(v->device));
+    QG_ON_DEVICE(v);
     const uint32_t R = v->has_z ? 2 * v->nxp : v->nxp;
     EmbedArgs a;
     a.state = reinterpret_cast<const uint4 *>(v->state);

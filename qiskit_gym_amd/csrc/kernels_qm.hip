@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
         depth = depth > 0 ? depth - 1 : 0;          // clifford.rs:342
         if constexpr (INV) {                        // maybe_random_invert (clifford.rs:262-270, linear_function.rs:227-235)
             const uint32_t coin = a.coins ? a.coins[(uint64_t)t * a.B + env]
-                                          : (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, env, step_clock(a) + t) >> 63);
+                                          : (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, a.env_base + env, step_clock(a) + t) >> 63);
             if (coin & 1u) {
                 bool fast = false;
                 if constexpr (HAS_Z) {
@@ -887,7 +887,7 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
         else hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true, false>), grid, block, 0, s, a);
         return hipGetLastError();
     }
-    if (!feat && seq && a.T > 1 && !getenv("QGYM_FUSED_REGS")) {  // plain fused rollout (QGYM_FUSED_REGS=1: the register-resident form, for A/B timing)
+    if (!feat && seq && a.T > 1) {  // plain fused rollout
         if (a.num_actions == 0) { /* an empty gateset has no table to read: the register-resident kernel below handles it */
         } else {
             if (a.flags & F_ACT64) hipLaunchKernelGGL((qm_fused_lds_kernel<NXP, HAS_Z, true>), grid, block, 0, s, a);

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void q64_step_kernel(StepArgs a) {
         depth = depth > 0 ? depth - 1 : 0;  // clifford.rs:342
         if constexpr (INV && HAS_Z) {        // maybe_random_invert (clifford.rs:262-270)
             const uint32_t coin = a.coins ? a.coins[(uint64_t)t * a.B + env]
-                                          : (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, env, step_clock(a) + t) >> 63);
+                                          : (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, a.env_base + env, step_clock(a) + t) >> 63);
             if (coin & 1u) {
                 if (iflags & Q64_FLAG_SYMPLECTIC) {
                     q64_symplectic_inverse<NS>(s, a.N);

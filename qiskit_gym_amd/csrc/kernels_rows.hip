@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void rows_step_kernel(StepArgs a) {
 
         if (a.flags & F_INVERTS) {  // maybe_random_invert (clifford.rs:262-270)
             uint32_t coin = a.coins ? a.coins[(uint64_t)t * a.B + env]
-                                    : (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, env, step_clock(a) + t) >> 63);
+                                    : (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, a.env_base + env, step_clock(a) + t) >> 63);
             coin = valid ? (coin & 1u) : 0u;
             if (__any((int)coin)) {
                 W m[RPL], v[RPL];
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void rows_init_kernel(InitArgs a) {
     } else if (a.mode == 2) {  // reset (clifford.rs:306-316): `difficulty` uniform draws, state only
         for (uint32_t t = 0; t < a.n_draws; ++t) {
             int64_t act = a.actions ? (int64_t)a.actions[(uint64_t)t * a.B + env]
-                                    : (int64_t)rng_action(init_seed(a), env, t, a.num_actions);
+                                    : (int64_t)rng_action(init_seed(a), a.env_base + env, t, a.num_actions);
             uint32_t ops = (act >= 0 && act < (int64_t)a.num_actions) ? a.gates[act].ops : 0u;
             apply_ops<W>(r, ops, lie, base);
         }

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void word_step_kernel(StepArgs a) {
         depth = depth > 0 ? depth - 1 : 0;
         if (a.flags & F_INVERTS) {
             uint32_t coin = a.coins ? a.coins[(uint64_t)t * a.B + env]
-                                    : (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, env, step_clock(a) + t) >> 63);
+                                    : (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, a.env_base + env, step_clock(a) + t) >> 63);
             if (coin & 1u) {
                 if (PERM) {
                     s = perm_invert(s, a.N);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void word_init_kernel(InitArgs a) {
     } else if (a.mode == 2) {
         for (uint32_t t = 0; t < a.n_draws; ++t) {
             int64_t act = a.actions ? (int64_t)a.actions[(uint64_t)t * a.B + env]
-                                    : (int64_t)rng_action(init_seed(a), env, t, a.num_actions);
+                                    : (int64_t)rng_action(init_seed(a), a.env_base + env, t, a.num_actions);
             uint32_t ops = (act >= 0 && act < (int64_t)a.num_actions) ? a.gates[act].ops : 0u;
             s = PERM ? perm_apply(s, ops) : lf8_apply(s, ops);
         }

@@ -222,7 +222,7 @@ int qg_gate_parse(const char *name_in, const int64_t *idx, size_t n, qg_gate *ou
 static int vec_free_buffers(qg_vec *v) {
     void *ptrs[] = {v->state, v->own_depth ? v->depth : nullptr, v->own_reward ? v->reward : nullptr,
                     v->own_done ? v->done : nullptr, v->own_success ? v->success : nullptr, v->inverted, v->error, v->sol,
-                    v->sol_len, v->layers, v->d_gates, v->d_descs, v->scratch, v->rot, v->pmeta, v->d_prog,
+                    v->sol_len, v->layers, v->d_gates, v->d_descs, v->scratch, v->d_prog,
                     v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad, v->done_list, v->d_rowops, v->embed_dump};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -256,6 +256,7 @@ static void fill_init_args(const qg_vec *v, InitArgs &a) {
     a.log2L = v->log2L;
     a.num_actions = (uint32_t)v->gates.size();
     a.clock = v->clock_dev;
+    a.env_base = v->env_base;
     a.bad = v->bad;
     a.rowops = v->d_rowops;
     a.check_symplectic = ((v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) && (v->flags & F_INVERTS)) ? 1u : 0u;
@@ -291,6 +292,7 @@ static void fill_step_args(const qg_vec *v, StepArgs &a) {
     a.seed = v->coin_seed;
     a.step_index = v->step_index;
     a.clock = v->clock_dev;
+    a.env_base = v->env_base;
     a.bad = v->bad;
     a.D = v->D;
     a.N = v->N;
@@ -340,7 +342,11 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     int ndev = qg_device_count();
     if (ndev <= 0) return set_error(QG_ERR_DEVICE, "no HIP device visible: libqgym has no CPU fallback");
     if (device < 0 || device >= ndev) return set_error(QG_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
-    HIP_TRY(hipSetDevice(device));
+    qg::DeviceGuard guard(device);  // the caller's current device is restored on return
+    if (guard.err != hipSuccess) {
+        (void)hipGetLastError();
+        return set_error(QG_ERR_DEVICE, "cannot select device %d: %s", device, hipGetErrorString(guard.err));
+    }
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -392,7 +398,7 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     // Gauss-Jordan over that many register-resident rows is slower than the lane-group ROWS
     // kernels' (measured at N = 32: 72 vs 46 us per step), and CliffordEnv has the transpose form
     const bool tile_ok = !inverts || cfg->env_kind == QG_CLIFFORD || N <= 16;
-    if (v->layout == LAYOUT_ROWS32 && tile_ok && getenv("QGYM_FORCE_ROWS") == nullptr) {
+    if (v->layout == LAYOUT_ROWS32 && tile_ok) {
         v->layout = LAYOUT_TILE;
         v->nxp = (N + 3u) & ~3u;
         v->has_z = cfg->env_kind == QG_CLIFFORD;
@@ -400,7 +406,7 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
         v->stride_bytes = 0;
         v->state_bytes = ((batch + 63) / 64) * R * 256;
     }
-    if (v->layout == LAYOUT_ROWS64 && tile_ok && getenv("QGYM_FORCE_ROWS") == nullptr) {
+    if (v->layout == LAYOUT_ROWS64 && tile_ok) {
         v->layout = LAYOUT_TILE64;  // uint64 rows, thread per env (kernels_qm64.hip)
         v->has_z = cfg->env_kind == QG_CLIFFORD;
         v->nxp = v->has_z ? 2u * ((N + 3u) & ~3u) : ((N + 7u) & ~7u);  // row slots per env
@@ -461,11 +467,10 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     HIP_TRY_V(hipMalloc(&p->done, batch));
     HIP_TRY_V(hipMalloc(&p->success, batch));
     HIP_TRY_V(hipMalloc(&p->inverted, batch));
-    // TILE / TILE64 layouts without add_inverts: the one-step kernel keeps `solved` as a per-env mask (QGYM_TILE_DENSE=1:
-    // development switch that keeps every step on the register-resident kernel)
-    if ((v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) && !(v->flags & F_INVERTS) && !getenv("QGYM_TILE_DENSE"))
+    // TILE / TILE64 layouts without add_inverts: the one-step kernel keeps `solved` as a per-env mask
+    if ((v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) && !(v->flags & F_INVERTS))
         HIP_TRY_V(hipMalloc(&p->bad, (v->layout == LAYOUT_TILE64 ? sizeof(uint64_t) : sizeof(uint32_t)) * batch));
-    if (v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64 || (v->layout == LAYOUT_PAULI && v->pauli_tile)) {
+    if (v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_PAULI) {
         HIP_TRY_V(hipMalloc(&p->done_list, sizeof(uint32_t) * (batch + 2)));
         HIP_TRY_V(hipMemset(p->done_list + batch, 0, 2 * sizeof(uint32_t)));
     }
@@ -524,9 +529,11 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
 
 void qg_vec_destroy(qg_vec *v) {
     if (!v) return;
-    (void)hipSetDevice(v->device);
-    (void)hipDeviceSynchronize();
-    vec_free_buffers(v);
+    {
+        qg::DeviceGuard guard(v->device);
+        (void)hipDeviceSynchronize();
+        vec_free_buffers(v);
+    }
     delete v;
 }
 
@@ -568,7 +575,7 @@ static void drop_graphs(qg_vec *v) {
 
 int qg_vec_bind_outputs(qg_vec *v, float *reward_dev, uint8_t *done_dev, uint8_t *success_dev, int32_t *depth_dev) {
     if (!v) return set_error(QG_ERR_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(v->device));
+    QG_ON_DEVICE(v);
     HIP_TRY(hipDeviceSynchronize());
     drop_graphs(v);  // cached graphs have the old pointers baked in
     auto rebind = [&](auto *&cur, auto *ext, bool &own, size_t bytes) -> int {
@@ -608,7 +615,7 @@ static size_t format_min_elems(const qg_vec *v, int format) {
 int qg_vec_set_state(qg_vec *v, const void *states, int format, size_t stride, int on_device, void *stream) {
     if (!v || !states) return set_error(QG_ERR_INVALID, "null argument");
     if (format < QG_FMT_I64 || format > QG_FMT_PACKED) return set_error(QG_ERR_INVALID, "unknown state format %d", format);
-    HIP_TRY(hipSetDevice(v->device));
+    QG_ON_DEVICE(v);
     hipStream_t s = (hipStream_t)stream;
     if (v->layout == LAYOUT_PAULI) return pauli_set_state(v, states, format, stride, on_device, s);
     if (stride < format_min_elems(v, format))
@@ -679,7 +686,7 @@ int qg_vec_get_state(qg_vec *v, void *out, int format, size_t stride, int on_dev
     if (!v || !out) return set_error(QG_ERR_INVALID, "null argument");
     if (format < QG_FMT_I64 || format > QG_FMT_PACKED) return set_error(QG_ERR_INVALID, "unknown state format %d", format);
     if (stride < format_min_elems(v, format)) return set_error(QG_ERR_INVALID, "get_state: stride too small");
-    HIP_TRY(hipSetDevice(v->device));
+    QG_ON_DEVICE(v);
     hipStream_t s = (hipStream_t)stream;
     void *dst = out;
     size_t bytes = format_elem_bytes(v, format) * stride * v->B;
@@ -702,12 +709,8 @@ int qg_vec_get_state(qg_vec *v, void *out, int format, size_t stride, int on_dev
 }
 
 static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint64_t seed, hipStream_t s, bool only_done = false) {
-    HIP_TRY(hipSetDevice(v->device));
-    if (only_done && v->layout == LAYOUT_PAULI) {
-        if (!v->pauli_tile)
-            return set_error(QG_ERR_UNSUPPORTED, "the lane-group PauliEnv family generates targets on the host: reset the whole batch with qg_vec_reset");
-        return ptile_reset_seeded(v, seed, true, s);
-    }
+    QG_ON_DEVICE(v);
+    if (only_done && v->layout == LAYOUT_PAULI) return ptile_reset_seeded(v, seed, true, s);
     if (v->layout == LAYOUT_PAULI) {
         if (actions_dev) return set_error(QG_ERR_UNSUPPORTED, "PauliEnv reset draws a whole target, not `difficulty` actions: use qg_vec_reset(seed) or qg_vec_pauli_reset_from");
         return pauli_reset_seeded(v, seed, s);
@@ -738,9 +741,7 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
 
 int qg_vec_set_clock(qg_vec *v, const uint64_t *clock_dev) {
     if (!v) return set_error(QG_ERR_INVALID, "null argument");
-    if (clock_dev && v->layout == LAYOUT_PAULI && !v->pauli_tile)
-        return set_error(QG_ERR_UNSUPPORTED, "the lane-group PauliEnv family generates targets on the host and cannot follow a device clock");
-    HIP_TRY(hipSetDevice(v->device));
+    QG_ON_DEVICE(v);
     HIP_TRY(hipDeviceSynchronize());
     v->clock_dev = clock_dev;
     // cached rollout graphs bake the old pointer in
@@ -753,11 +754,15 @@ int qg_vec_set_clock(qg_vec *v, const uint64_t *clock_dev) {
 }
 
 int qg_stream_wait_stream(void *waiter, void *producer) {
-    // one pooled event per thread: device-scope only (no system fence), no timing
-    static thread_local hipEvent_t ev = nullptr;
-    if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence));
-    HIP_TRY(hipEventRecord(ev, (hipStream_t)producer));
-    HIP_TRY(hipStreamWaitEvent((hipStream_t)waiter, ev, 0));
+    // one pooled event per thread and device (an event belongs to the device it was created on): device-scope only
+    // (no system fence), no timing.  Both streams must belong to the calling thread's current device.
+    static thread_local hipEvent_t evs[64] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return set_error(QG_ERR_INVALID, "device index %d out of range", dev);
+    if (!evs[dev]) HIP_TRY(hipEventCreateWithFlags(&evs[dev], hipEventDisableTiming | hipEventDisableSystemFence));
+    HIP_TRY(hipEventRecord(evs[dev], (hipStream_t)producer));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)waiter, evs[dev], 0));
     return QG_OK;
 }
 
@@ -767,6 +772,24 @@ int qg_vec_set_counters(qg_vec *v, uint64_t step_index, uint64_t observe_index) 
     v->observe_counter = observe_index;
     return QG_OK;
 }
+
+int qg_vec_set_seed(qg_vec *v, uint64_t seed) {
+    if (!v) return set_error(QG_ERR_INVALID, "null argument");
+    if (seed != v->coin_seed) {
+        QG_ON_DEVICE(v);
+        HIP_TRY(hipDeviceSynchronize());
+        drop_graphs(v);  // the seed is a baked-in kernel argument of captured launches
+        v->coin_seed = seed;
+    }
+    return QG_OK;
+}
+
+int qg_vec_set_env_base(qg_vec *v, uint64_t first_env) {
+    if (!v) return set_error(QG_ERR_INVALID, "null argument");
+    v->env_base = first_env;  // cached graphs are keyed by it
+    return QG_OK;
+}
+uint64_t qg_vec_get_env_base(const qg_vec *v) { return v ? v->env_base : 0; }
 
 int qg_vec_reset(qg_vec *v, uint64_t seed, void *stream) {
     if (!v) return set_error(QG_ERR_INVALID, "null argument");
@@ -788,7 +811,7 @@ int qg_vec_reset_with(qg_vec *v, const int32_t *actions_dev, size_t n_draws, voi
 int qg_vec_step(qg_vec *v, const void *actions_dev, int action_dtype, const uint8_t *coins_dev, void *stream) {
     if (!v || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
     if (action_dtype != QG_ACT_I32 && action_dtype != QG_ACT_I64) return set_error(QG_ERR_INVALID, "bad action dtype");
-    HIP_TRY(hipSetDevice(v->device));
+    QG_ON_DEVICE(v);
     StepArgs a;
     fill_step_args(v, a);
     a.actions = actions_dev;
@@ -818,7 +841,7 @@ static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, si
     if (action_dtype != QG_ACT_I32 && action_dtype != QG_ACT_I64) return set_error(QG_ERR_INVALID, "bad action dtype");
     if (T == 0) return QG_OK;
     if (T > 0x7fffffffu) return set_error(QG_ERR_INVALID, "too many steps");
-    HIP_TRY(hipSetDevice(v->device));
+    QG_ON_DEVICE(v);
     hipStream_t s = (hipStream_t)stream;
     StepArgs a;
     fill_step_args(v, a);
@@ -859,7 +882,7 @@ static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, si
         v->step_index += T;
         return QG_OK;
     }
-    GraphKey key{actions_dev, coins_dev, rewards_dev, dones_dev, T, action_dtype, period};
+    GraphKey key{actions_dev, coins_dev, rewards_dev, dones_dev, T, action_dtype, period, a.flags, v->env_base};
     CachedGraph *cg = nullptr;
     for (auto &g : v->graphs)
         if (g.key == key) cg = &g;
@@ -890,7 +913,7 @@ static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, si
 }
 
 static int observe_dense_impl(qg_vec *v, int8_t *out_dev, const int32_t *perm_idx_dev, void *stream) {
-    HIP_TRY(hipSetDevice(v->device));
+    QG_ON_DEVICE(v);
     ObsArgs oa;
     qg_vec_info info;
     qg_vec_get_info(v, &info);
@@ -920,11 +943,11 @@ int qg_vec_pauli_num_perms(const qg_vec *v) { return v ? (int)v->n_perms : -1; }
 
 int qg_vec_observe_packed(qg_vec *v, void *out_dev, void *stream) {
     if (!v || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(v->device));
+    QG_ON_DEVICE(v);
     if (v->layout == LAYOUT_PAULI) {
         const uint32_t cols = 2 * v->N + (uint32_t)std::max(v->cfg.max_rotations, 1);
-        if (!v->pauli_tile || cols > 64u)
-            return set_error(QG_ERR_UNSUPPORTED, "packed observation of PauliEnv needs the thread-per-env family and at most 64 observation columns: use observe_dense");
+        if (cols > 64u)
+            return set_error(QG_ERR_UNSUPPORTED, "packed observation of PauliEnv needs at most 64 observation columns: use observe_dense");
         v->perm_draw = true;  // PauliEnv::observe draws a new qubit permutation (pauli.rs:657-662)
         const hipError_t e = ptile_observe_words(v, out_dev, (hipStream_t)stream);
         v->perm_draw = false;
@@ -946,7 +969,7 @@ int qg_vec_observe_packed(qg_vec *v, void *out_dev, void *stream) {
 
 int qg_vec_masks(qg_vec *v, uint8_t *out_dev, void *stream) {
     if (!v || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(v->device));
+    QG_ON_DEVICE(v);
     HIP_TRY(masks_fill(v->success, out_dev, v->B, (uint32_t)v->gates.size(), (hipStream_t)stream));
     return QG_OK;
 }
@@ -954,13 +977,13 @@ int qg_vec_masks(qg_vec *v, uint8_t *out_dev, void *stream) {
 int qg_vec_pauli_reset_from(qg_vec *v, const uint8_t *tableaus, const char *labels, const int32_t *n_rot, void *stream) {
     if (!v || !tableaus || !n_rot) return set_error(QG_ERR_INVALID, "null argument");
     if (v->layout != LAYOUT_PAULI) return set_error(QG_ERR_INVALID, "not a PauliEnv batch");
-    HIP_TRY(hipSetDevice(v->device));
+    QG_ON_DEVICE(v);
     return pauli_reset_from(v, tableaus, labels, n_rot, (hipStream_t)stream);
 }
 
 int qg_vec_sync(qg_vec *v, void *stream) {
     if (!v) return set_error(QG_ERR_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(v->device));
+    QG_ON_DEVICE(v);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     std::vector<uint32_t> err(v->B);
     HIP_TRY(hipMemcpy(err.data(), v->error, sizeof(uint32_t) * v->B, hipMemcpyDeviceToHost));
@@ -979,7 +1002,7 @@ int64_t qg_vec_solution(qg_vec *v, uint64_t env, uint64_t *out, size_t cap) {
     if (!v) return set_error(QG_ERR_INVALID, "null argument");
     if (env >= v->B) return set_error(QG_ERR_INVALID, "env index out of range");
     if (!v->cfg.track_solution) return 0;
-    if (hipSetDevice(v->device) != hipSuccess) return set_error(QG_ERR_DEVICE, "hipSetDevice failed");
+    QG_ON_DEVICE(v);
     int32_t len[2];
     std::vector<uint32_t> row(v->sol_cap);
     if (hipMemcpy(len, v->sol_len + env * 2, sizeof len, hipMemcpyDeviceToHost) != hipSuccess ||

@@ -207,8 +207,6 @@ int qg_env_clone(const qg_env *e, qg_env **out) {  // Env: DynClone -- deep copy
         {d->sol_len, s->sol_len, 8},
         {d->sol, s->sol, (size_t)s->sol_cap * 4},
         {d->layers, s->layers, (size_t)s->layers_len * 4},
-        {d->rot, s->rot, (size_t)s->rmax * 16},
-        {d->pmeta, s->pmeta, s->pmeta ? (size_t)16 : 0},
         {d->bad, s->bad, s->layout == LAYOUT_TILE64 ? (size_t)8 : (size_t)4},  // incremental solved mask of the one-step kernels
         {d->perm_idx, s->perm_idx, (size_t)4},                                 // PauliEnv current_perm_idx (pauli.rs:661)
     };
@@ -221,6 +219,8 @@ int qg_env_clone(const qg_env *e, qg_env **out) {  // Env: DynClone -- deep copy
     *out = c;
     return QG_OK;
 }
+
+int qg_env_set_seed(qg_env *e, uint64_t seed) { return e ? qg_vec_set_seed(e->v, seed) : set_error(QG_ERR_INVALID, "null argument"); }
 
 int64_t qg_env_num_actions(const qg_env *e) { return e ? (int64_t)e->v->gates.size() : -1; }
 

@@ -18,9 +18,11 @@ struct GraphKey {
     size_t T;
     int dtype;
     size_t period;
+    uint32_t flags;     // effective StepArgs::flags: they pick the kernel variant (e.g. F_GJ follows maybe_nonsymplectic)
+    uint64_t env_base;  // baked into the captured launches like every other kernel argument
     bool operator==(const GraphKey &o) const {
         return actions == o.actions && coins == o.coins && rewards == o.rewards && dones == o.dones && T == o.T &&
-               dtype == o.dtype && period == o.period;
+               dtype == o.dtype && period == o.period && flags == o.flags && env_base == o.env_base;
     }
 };
 struct CachedGraph {
@@ -41,6 +43,31 @@ int set_error(int code, const char *fmt, ...);
         }                                                                                          \
     } while (0)
 
+// Every C entry point works on its handle's GPU and leaves the calling thread's current device as it found it.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define QG_ON_DEVICE(v)                                                                            \
+    qg::DeviceGuard _qg_guard((v)->device);                                                        \
+    if (_qg_guard.err != hipSuccess) {                                                             \
+        (void)hipGetLastError();                                                                   \
+        return qg::set_error(QG_ERR_DEVICE, "cannot select device %d: %s", (v)->device, hipGetErrorString(_qg_guard.err)); \
+    }
+
 }  // namespace qg
 
 struct qg_vec {
@@ -58,6 +85,7 @@ struct qg_vec {
     int64_t difficulty = 1;
     uint64_t coin_seed = 0;
     uint64_t step_index = 0;
+    uint64_t env_base = 0;  // qg_vec_set_env_base: global index of env 0 in every counter-RNG draw (a shard of a larger batch)
     const uint64_t *clock_dev = nullptr;  // qg_vec_set_clock (not owned)
 
     // device buffers
@@ -85,13 +113,10 @@ struct qg_vec {
     bool maybe_nonsymplectic = false;   // CliffordEnv + add_inverts: some env may need the Gauss-Jordan inversion
     bool own_reward = true, own_done = true, own_success = true, own_depth = true;
 
-    // PauliEnv (kernels_pauli.hip)
-    void *rot = nullptr;     // [B][rmax] 16-byte rotation records
-    void *pmeta = nullptr;   // [B] per-env rotation bookkeeping (alive mask, node order, count)
-    void *d_prog = nullptr;  // [num_actions] micro-programs
+    // PauliEnv (pauli_host.cpp, kernels_pauli_tile.hip)
+    void *d_prog = nullptr;  // [num_actions] per-action programs (tableau map + micro-ops)
     uint32_t rmax = 0;
     uint32_t rmax_generate = 0;
-    bool pauli_tile = false;     // thread-per-env PTILE family (kernels_pauli_tile.hip)
     uint32_t pt_nq = 0, pt_rm = 0;
     void *d_gen_tables = nullptr;  // PTILE target generator: coupling-graph distance tables
     uint32_t gen_nd = 0, gen_ncx = 0, gen_off[4] = {0, 0, 0, 0};  // final_pauli_layers: most rotations reset() generates
@@ -112,7 +137,7 @@ namespace qg {
 int ensure_scratch_public(qg_vec *v, size_t bytes);
 void compute_qubit_and_action_perms(uint32_t N, const std::vector<qg_gate> &gates, std::vector<std::vector<int64_t>> &qubit_perms,
                                     std::vector<std::vector<int64_t>> &act_perms);
-// PauliEnv host hooks (kernels_pauli.hip)
+// PauliEnv host hooks (pauli_host.cpp)
 int pauli_plan(qg_vec *v);
 int pauli_alloc(qg_vec *v);
 int pauli_init_identity(qg_vec *v, hipStream_t s);

@@ -33,7 +33,7 @@ namespace qg {
 //   type 0 = none, 1 = dst ^= src, 2 = swap(dst, src).
 // The host guarantees the two operations touch disjoint rows (clifford.rs:111-133: CX, CZ and
 // SWAP with distinct qubits always do), so they commute.
-// For PauliEnv `ops` holds the micro-program instead (see kernels_pauli.hip).
+// For PauliEnv the per-action program lives in its own table (kernels_pauli_tile.hip).
 struct GateEntry {
     uint32_t ops;
     float penalty;  // metrics-weighted penalty of this action (metrics.rs:135-146), f32
@@ -109,6 +109,7 @@ struct StepArgs {
     float pauli_layer_reward;
     uint32_t max_rotations;
     const uint64_t *clock;    // device clock added to every RNG counter (qg_vec_set_clock), or null
+    uint64_t env_base;        // global index of env 0 in the counter RNG (qg_vec_set_env_base)
     uint32_t *bad;            // TILE (uint32) / TILE64 (uint64) per-env mask: bit j = qubit j's rows / row j differ from the identity's; or null
 };
 
@@ -156,6 +157,7 @@ struct InitArgs {
     uint32_t *list_count;      // [2]: length, reader ticket (device_common.hpp list_count_take)
     uint32_t coop;             // list mode with RNG draws: the 16-lanes-per-env scramble kernel handles small lists
     const uint32_t *rowops;    // TILE layout: per action two row operations (make_op, slot indices) for that kernel
+    uint64_t env_base;         // global index of env 0 in the counter RNG (qg_vec_set_env_base)
 };
 
 // A handle may be given a device-resident clock (qg_vec_set_clock).  Launches replayed from a

@@ -11,6 +11,8 @@ optionally the inversion coin, so runs are reproducible.
 from __future__ import annotations
 
 import ctypes as C
+import itertools
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -19,16 +21,31 @@ from .. import _lib
 from .gateset import parse_gateset
 
 
+_MASK64 = 2**64 - 1
+_PROCESS_ENTROPY = int.from_bytes(os.urandom(8), "little")  # differs per process, like thread_rng's OS seeding
+_INSTANCE_COUNTER = itertools.count(1)
+
+
+def _fresh_seed() -> int:
+    """A seed no other env object of any process shares: per-process OS entropy mixed with a process-wide counter."""
+    return (_PROCESS_ENTROPY ^ (0x9E3779B97F4A7C15 * next(_INSTANCE_COUNTER)) ^ int.from_bytes(os.urandom(8), "little")) & _MASK64
+
+
 class RawEnv:
+    """`seed=None` (default): the env draws like the reference's `thread_rng` (clifford.rs:266,307; pauli.rs:657) -- every
+    object, and every clone, has its own unpredictable stream.  `seed=int`: reproducible streams (tests, parity runs)."""
+
     def __init__(self, env_kind: str, num_qubits: int, gateset: Sequence, device: int = 0,
-                 metrics_weights: Optional[dict] = None, _handle=None, **config):
+                 metrics_weights: Optional[dict] = None, seed: Optional[int] = None, _handle=None, **config):
         self._L = _lib.load()
         self.env_kind = env_kind
         self.num_qubits = int(num_qubits)
         self.gateset = [(g[0], tuple(int(q) for q in g[1])) for g in gateset]
         self._reset_counter = 0
+        self._seed = _fresh_seed() if seed is None else int(seed) & _MASK64
         if _handle is not None:
             self._h = _handle
+            _lib.check(self._L.qg_env_set_seed(self._h, self._seed))
             return
         cfg = _lib.make_config(env_kind, num_qubits, metrics_weights=metrics_weights,
                                **{k: (int(v) if isinstance(v, bool) else v) for k, v in config.items()})
@@ -36,6 +53,7 @@ class RawEnv:
         h = C.c_void_p()
         _lib.check(self._L.qg_env_create(C.byref(cfg), gates, len(self.gateset), int(device), C.byref(h)))
         self._h = h
+        _lib.check(self._L.qg_env_set_seed(self._h, self._seed))
 
     def __del__(self):
         try:
@@ -45,10 +63,12 @@ class RawEnv:
         except Exception:
             pass
 
-    def clone(self) -> "RawEnv":
+    def clone(self, seed: Optional[int] = None) -> "RawEnv":
+        """Deep copy of the state (Env: DynClone).  The clone's FUTURE random draws (reset scramble, add_inverts coins,
+        PauliEnv permutations) are its own, as with the reference's thread_rng, unless `seed` pins them."""
         h = C.c_void_p()
         _lib.check(self._L.qg_env_clone(self._h, C.byref(h)))
-        return RawEnv(self.env_kind, self.num_qubits, self.gateset, _handle=h)
+        return RawEnv(self.env_kind, self.num_qubits, self.gateset, seed=seed, _handle=h)
 
     # ---- the Env trait (clifford.rs:285-382) --------------------------------------------------
     def num_actions(self) -> int:
@@ -72,9 +92,9 @@ class RawEnv:
         _lib.check(self._L.qg_env_set_state(self._h, a.ctypes.data_as(C.POINTER(C.c_int64)), a.size))
 
     def reset(self, seed: Optional[int] = None):
-        if seed is None:  # successive resets of one env draw different scrambles, like the reference
+        if seed is None:  # successive resets of one env, and resets of different envs / clones, draw different scrambles
             self._reset_counter += 1
-            seed = 0x9E3779B97F4A7C15 * self._reset_counter
+            seed = self._seed ^ (0x9E3779B97F4A7C15 * self._reset_counter)
         _lib.check(self._L.qg_env_reset(self._h, int(seed) & (2**64 - 1)))
 
     def step(self, action: int, coin: Optional[int] = None):

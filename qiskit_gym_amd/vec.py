@@ -17,15 +17,17 @@ from . import _lib
 from .envs.gateset import parse_gateset
 
 
-def _stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream_ptr(device=None) -> int:
+    """Current torch stream of `device` (default: the current device) -- for the handle-free C entry points, which work on
+    the calling thread's current HIP device.  Handle-bound calls use `VecEnv._stream()`."""
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 class VecEnv:
     """`batch` copies of one env kind (`"clifford" | "linear_function" | "permutation" | "pauli"`)."""
 
     def __init__(self, env_kind: str, num_qubits: int, gateset: Sequence, batch: int, device: int | None = None,
-                 metrics_weights: dict | None = None, **config):
+                 metrics_weights: dict | None = None, seed: int | None = None, env_base: int = 0, **config):
         if not torch.cuda.is_available():
             raise RuntimeError("qiskit_gym_amd.VecEnv needs a ROCm GPU (MI355X / gfx950); there is no CPU fallback")
         self._L = _lib.load()
@@ -42,6 +44,10 @@ class VecEnv:
             _lib.check(self._L.qg_vec_create(C.byref(self._cfg), self._gates, len(self.gateset), self.batch,
                                              self.device_index, C.byref(h)))
         self._h = h
+        if seed is not None:  # the handle's own RNG streams (add_inverts coins, PauliEnv observe permutations)
+            _lib.check(self._L.qg_vec_set_seed(self._h, int(seed) & (2**64 - 1)))
+        if env_base:
+            self.set_env_base(env_base)
         info = _lib.QGVecInfo()
         _lib.check(self._L.qg_vec_get_info(self._h, C.byref(info)))
         self.num_actions_ = info.num_actions
@@ -55,6 +61,10 @@ class VecEnv:
         self.depth = torch.empty(self.batch, dtype=torch.int32, device=self.device)
         _lib.check(self._L.qg_vec_bind_outputs(self._h, self.reward.data_ptr(), self.done.data_ptr(),
                                                self.success.data_ptr(), self.depth.data_ptr()))
+
+    def _stream(self) -> int:
+        """The current torch stream of THIS env's device (not of whatever device happens to be current)."""
+        return torch.cuda.current_stream(self.device).cuda_stream
 
     def close(self):
         if getattr(self, "_h", None):
@@ -82,19 +92,32 @@ class VecEnv:
     def difficulty(self, d: int):
         _lib.check(self._L.qg_vec_set_difficulty(self._h, int(d)))
 
+    def set_env_base(self, first_env: int):
+        """This batch is the shard [first_env, first_env + batch) of a larger one: every counter-RNG draw of env e is made
+        as env first_env + e, so a sharded (multi-GPU) run equals the unsharded run of the whole batch."""
+        _lib.check(self._L.qg_vec_set_env_base(self._h, int(first_env)))
+
     def set_state(self, states, fmt: str = "i64"):
         """states: [B, n] tensor/array in the trait's `Vec<i64>` wire format (`fmt="i64"`), dense
         0/1 bytes (`"u8"`) or bit-packed rows (`"packed"`)."""
         code = {"i64": _lib.FMT_I64, "u8": _lib.FMT_U8, "packed": _lib.FMT_PACKED}[fmt]
         if isinstance(states, torch.Tensor) and states.is_cuda:
+            if states.device != self.device:
+                raise ValueError("set_state: the tensor must live on the env's device")
+            size = {"i64": 8, "u8": 1}.get(fmt, self.packed_word_bytes)
+            ok = {8: (torch.int64, torch.uint64), 4: (torch.int32, torch.uint32), 1: (torch.uint8, torch.int8)}[size]
+            if states.dtype not in ok:
+                raise TypeError(f"set_state(fmt={fmt!r}): a device tensor must have {size}-byte integer elements, got {states.dtype}")
+            if states.numel() % self.batch:
+                raise ValueError(f"set_state: {states.numel()} elements do not divide into {self.batch} envs")
             t = states.contiguous().view(self.batch, -1)
-            _lib.check(self._L.qg_vec_set_state(self._h, t.data_ptr(), code, t.shape[1], 1, _stream_ptr()))
+            _lib.check(self._L.qg_vec_set_state(self._h, t.data_ptr(), code, t.shape[1], 1, self._stream()))
             return
         dt = {"i64": np.int64, "u8": np.uint8}.get(fmt)
         if dt is None:
             dt = {1: np.uint8, 4: np.uint32, 8: np.uint64}[self.packed_word_bytes]
         a = np.ascontiguousarray(np.asarray(states.cpu() if isinstance(states, torch.Tensor) else states, dtype=dt)).reshape(self.batch, -1)
-        _lib.check(self._L.qg_vec_set_state(self._h, a.ctypes.data, code, a.shape[1], 0, _stream_ptr()))
+        _lib.check(self._L.qg_vec_set_state(self._h, a.ctypes.data, code, a.shape[1], 0, self._stream()))
 
     def get_state(self, fmt: str = "i64") -> torch.Tensor:
         code = {"i64": _lib.FMT_I64, "u8": _lib.FMT_U8, "packed": _lib.FMT_PACKED}[fmt]
@@ -109,15 +132,15 @@ class VecEnv:
         if dt is None:
             dt = {1: torch.uint8, 4: torch.int32, 8: torch.int64}[self.packed_word_bytes]
         out = torch.empty((self.batch, n), dtype=dt, device=self.device)
-        _lib.check(self._L.qg_vec_get_state(self._h, out.data_ptr(), code, n, 1, _stream_ptr()))
+        _lib.check(self._L.qg_vec_get_state(self._h, out.data_ptr(), code, n, 1, self._stream()))
         return out
 
     def reset(self, seed: int = 0):
-        _lib.check(self._L.qg_vec_reset(self._h, int(seed) & (2**64 - 1), _stream_ptr()))
+        _lib.check(self._L.qg_vec_reset(self._h, int(seed) & (2**64 - 1), self._stream()))
 
     def reset_done(self, seed: int):
         """reset() only the envs whose episode is over (`done` set); stream-ordered, no host sync."""
-        _lib.check(self._L.qg_vec_reset_done(self._h, int(seed) & (2**64 - 1), _stream_ptr()))
+        _lib.check(self._L.qg_vec_reset_done(self._h, int(seed) & (2**64 - 1), self._stream()))
 
     def set_clock(self, clock: Optional[torch.Tensor]):
         """Attach (or detach with None) a device clock: an int64 [1] tensor on this device that every
@@ -135,11 +158,13 @@ class VecEnv:
     def reset_with(self, actions: torch.Tensor):
         """actions: int32 [difficulty, B] scramble draws (the reference's reset() RNG made explicit)."""
         a = actions.to(device=self.device, dtype=torch.int32).contiguous().view(-1, self.batch)
-        _lib.check(self._L.qg_vec_reset_with(self._h, a.data_ptr(), a.shape[0], _stream_ptr()))
+        _lib.check(self._L.qg_vec_reset_with(self._h, a.data_ptr(), a.shape[0], self._stream()))
 
     def _act(self, actions: torch.Tensor) -> Tuple[int, int]:
         if actions.device != self.device:
             raise ValueError("actions must live on the env's device")
+        if actions.dim() == 0 or actions.shape[-1] != self.batch:
+            raise ValueError(f"actions must be [..., {self.batch}] (one per env), got {tuple(actions.shape)}")
         if actions.dtype == torch.int32:
             return actions.data_ptr(), _lib.ACT_I32
         if actions.dtype == torch.int64:
@@ -149,12 +174,16 @@ class VecEnv:
     def step(self, actions: torch.Tensor, coins: Optional[torch.Tensor] = None):
         """One env.step() for every env: one kernel launch.  Returns (reward, done) views."""
         actions = actions.contiguous()
+        if actions.numel() != self.batch:
+            raise ValueError(f"step: one action per env ({self.batch}), got {tuple(actions.shape)}")
         ptr, dt = self._act(actions)
         cp = None
         if coins is not None:
             coins = coins.to(device=self.device, dtype=torch.uint8).contiguous()
+            if coins.numel() != self.batch:
+                raise ValueError("step: one coin per env")
             cp = coins.data_ptr()
-        _lib.check(self._L.qg_vec_step(self._h, ptr, dt, cp, _stream_ptr()))
+        _lib.check(self._L.qg_vec_step(self._h, ptr, dt, cp, self._stream()))
         return self.reward, self.done
 
     def rollout(self, actions: torch.Tensor, fused: bool = False, coins: Optional[torch.Tensor] = None,
@@ -162,22 +191,31 @@ class VecEnv:
         """actions [T, B].  fused=False: T single-step launches replayed from a hipGraph;
         fused=True: one launch with the state held in registers across the T steps."""
         actions = actions.contiguous()
+        if actions.dim() != 2:
+            raise ValueError(f"rollout: actions must be [T, {self.batch}], got {tuple(actions.shape)}")
         T = actions.shape[0]
         ptr, dt = self._act(actions)
+        if coins is not None and coins.numel() != T * self.batch:
+            raise ValueError("rollout: coins must be [T, B]")
+        for name, t, size in (("rewards_out", rewards_out, 4), ("dones_out", dones_out, 1)):
+            if t is not None and (t.device != self.device or t.numel() != T * self.batch or t.element_size() != size or not t.is_contiguous()):
+                raise ValueError(f"rollout: {name} must be a contiguous [T, B] tensor of {size}-byte elements on the env's device")
         cp = None
         if coins is not None:
             coins = coins.to(device=self.device, dtype=torch.uint8).contiguous()
             cp = coins.data_ptr()
         rp = rewards_out.data_ptr() if rewards_out is not None else None
         dp = dones_out.data_ptr() if dones_out is not None else None
-        _lib.check(self._L.qg_vec_rollout(self._h, ptr, dt, T, cp, rp, dp, 1 if fused else 0, _stream_ptr()))
+        _lib.check(self._L.qg_vec_rollout(self._h, ptr, dt, T, cp, rp, dp, 1 if fused else 0, self._stream()))
         return self.reward, self.done
 
     def rollout_ring(self, actions: torch.Tensor, n_steps: int):
         """n_steps single-step launches (one cached hipGraph); step t uses actions[t % len(actions)]."""
         actions = actions.contiguous()
+        if actions.dim() != 2:
+            raise ValueError(f"rollout_ring: actions must be [period, {self.batch}], got {tuple(actions.shape)}")
         ptr, dt = self._act(actions)
-        _lib.check(self._L.qg_vec_rollout_ring(self._h, ptr, dt, int(n_steps), actions.shape[0], _stream_ptr()))
+        _lib.check(self._L.qg_vec_rollout_ring(self._h, ptr, dt, int(n_steps), actions.shape[0], self._stream()))
         return self.reward, self.done
 
     def observe(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -185,7 +223,7 @@ class VecEnv:
         r, c = self.obs_shape_
         if out is None:
             out = torch.empty((self.batch, r, c), dtype=torch.int8, device=self.device)
-        _lib.check(self._L.qg_vec_observe_dense(self._h, out.data_ptr(), _stream_ptr()))
+        _lib.check(self._L.qg_vec_observe_dense(self._h, out.data_ptr(), self._stream()))
         return out
 
     _DTYPES = {torch.int8: _lib.QG_DT_I8, torch.float32: _lib.QG_DT_F32, torch.bfloat16: _lib.QG_DT_BF16, torch.float16: _lib.QG_DT_F16}
@@ -197,7 +235,7 @@ class VecEnv:
             out = torch.empty((self.batch, r * c), dtype=dtype, device=self.device)
         if out.dtype != dtype or out.numel() != self.batch * r * c or not out.is_contiguous():
             raise ValueError("observe_as: `out` must be a contiguous [B, rows*cols] tensor of the requested dtype")
-        _lib.check(self._L.qg_vec_observe_dense_as(self._h, out.data_ptr(), self._DTYPES[dtype], _stream_ptr()))
+        _lib.check(self._L.qg_vec_observe_dense_as(self._h, out.data_ptr(), self._DTYPES[dtype], self._stream()))
         return out
 
     def pauli_observe(self, perm_idx: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -209,7 +247,7 @@ class VecEnv:
         if perm_idx is not None:
             perm_idx = perm_idx.to(device=self.device, dtype=torch.int32).contiguous()
             pp = perm_idx.data_ptr()
-        _lib.check(self._L.qg_vec_pauli_observe_dense(self._h, out.data_ptr(), pp, _stream_ptr()))
+        _lib.check(self._L.qg_vec_pauli_observe_dense(self._h, out.data_ptr(), pp, self._stream()))
         return out
 
     def pauli_num_perms(self) -> int:
@@ -220,23 +258,23 @@ class VecEnv:
         dt = {1: torch.uint8, 4: torch.int32, 8: torch.int64}[self.packed_word_bytes]
         if out is None:
             out = torch.empty((self.batch, self.packed_words_per_env), dtype=dt, device=self.device)
-        _lib.check(self._L.qg_vec_observe_packed(self._h, out.data_ptr(), _stream_ptr()))
+        _lib.check(self._L.qg_vec_observe_packed(self._h, out.data_ptr(), self._stream()))
         return out
 
     def masks(self) -> torch.Tensor:
         out = torch.empty((self.batch, self.num_actions_), dtype=torch.uint8, device=self.device)
-        _lib.check(self._L.qg_vec_masks(self._h, out.data_ptr(), _stream_ptr()))
+        _lib.check(self._L.qg_vec_masks(self._h, out.data_ptr(), self._stream()))
         return out
 
     def pauli_reset_from(self, tableaus: np.ndarray, labels: Sequence[Sequence[str]]):
         t = np.ascontiguousarray(np.asarray(tableaus, dtype=np.uint8).reshape(self.batch, -1))
         n_rot = np.ascontiguousarray(np.array([len(l) for l in labels], dtype=np.int32))
         blob = "".join("".join(l) for l in labels).encode()
-        _lib.check(self._L.qg_vec_pauli_reset_from(self._h, t.ctypes.data, blob, n_rot.ctypes.data, _stream_ptr()))
+        _lib.check(self._L.qg_vec_pauli_reset_from(self._h, t.ctypes.data, blob, n_rot.ctypes.data, self._stream()))
 
     def sync(self):
         """Wait for the current stream and raise if any env hit a fault the reference panics on."""
-        _lib.check(self._L.qg_vec_sync(self._h, _stream_ptr()))
+        _lib.check(self._L.qg_vec_sync(self._h, self._stream()))
 
     def solution(self, env: int):
         n = self._L.qg_vec_solution(self._h, env, None, 0)
