@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the batched env.step() hot path on MI355X.
 
-Workload (BASELINE.json metric; BASELINE.md section 3 config 3): CliffordGym, 16 qubits, line-16
+Workload (BASELINE.json metric; SURVEY.md 8d config 3 / config 4): CliffordGym, 16 qubits, line-16
 bidirectional coupling map, all 8 gate kinds (170 actions), 65 536 envs per GPU, start = identity
 scrambled by 256 uniform random actions, then uniform random actions, add_inverts=False,
 add_perms=False, track_solution=False, default metric weights, free-running (no reset inside the
@@ -12,22 +12,37 @@ resident in HBM.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank owns 65 536 envs
-(weak scaling); env.step needs no collective.  The exchange BASELINE.json's north_star names --
-the observation handed back to the learner -- is an all-gather of the bit-packed observation
-(8 MiB per rank) on a side stream, double buffered and overlapped with the following steps, once
-per rollout segment (--gather-every, default 256 steps; 1 = after every step, which is link-bound
-at >= 55 us per step against a 4 us step).
+N > 1: one rank per GPU over RCCL.  Started by the driver through torch.distributed.run (WORLD_SIZE set), or, when
+it is not, bench.py itself starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
+process before this process has touched a GPU, and relays rank 0's JSON line.  Fewer visible GPUs than N is an
+error.  Rank r owns envs [r * 65 536, (r + 1) * 65 536) of ONE batch of N * 65 536 envs (weak scaling): every
+counter-RNG draw and every action is a function of the global env id (qg_vec_set_env_base), so the sharded run
+is bit-identical to the unsharded one.  env.step needs no collective.  The exchange BASELINE.json's north_star
+names -- the observation handed back to the learner -- is an all-gather of one flat shard per rank (bit-packed
+observation 8 MiB + rewards + is_final / success flags) on a side stream, double buffered and overlapped with
+the following steps, once per rollout segment of min(--gather-every, K) steps, so the timed region always
+contains at least one collective; the per-step cadence (SURVEY.md 8e's literal "one all-gather per step",
+link-bound at >= 55 us against a 3 us step) is measured beside it and printed too.
 
 Prints one JSON line on rank 0.
 """
 from __future__ import annotations
 
-import argparse
-import json
 import os
-import sys
-import time
+
+# the CPU-baseline leg pins its OpenMP threads; the OpenMP runtime reads these when it is first loaded (and then binds the
+# main thread to its first place, so the CPUs this process may use are counted before that)
+NPROC = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "threads")
+
+import argparse  # noqa: E402
+import csv  # noqa: E402
+import json  # noqa: E402
+import socket  # noqa: E402
+import subprocess  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -39,10 +54,17 @@ import torch  # noqa: E402
 NUM_QUBITS = 16
 ENVS_PER_GPU = 65536
 SCRAMBLE = 256
-CHUNK = 256  # steps per hipGraph replay (single-GPU path)
+CHUNK = 256  # most steps one hipGraph replay holds
 RING = 16    # pre-sampled action buffers the steps cycle through (a policy rewrites ONE buffer per step)
+OBS_WORDS = 2 * NUM_QUBITS  # packed observation: one 32-bit word per tableau row
 ALGO_BYTES_PER_STEP = 160  # 128 B state read + 16 B touched rows + 16 B scalars
+# what the one-step kernel has to move per env: two 16-byte row groups read and (at most) written back,
+# action 4 R, depth 4 R + 4 W, bad mask 4 R + 4 W (written when it changes), reward 4 W, done / success 1 W each; the 8-byte gate
+# entry comes from a 1.4 KB table that stays cache resident
+NEEDED_BYTES_PER_STEP = 2 * 16 + 2 * 16 + 4 + 8 + 8 + 4 + 2
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+KERNEL = "qg::qm_step1_kernel<16, true, false>"
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
 
 
 def build_gateset():
@@ -52,71 +74,115 @@ def build_gateset():
     return gateset_from_coupling_map(line_edges(NUM_QUBITS, True), None, kinds)
 
 
-def cpu_baseline(gateset, seed: int, budget_s: float = 12.0):
-    """Time the CPU oracle (a C port of the reference's scalar Rust path, one env object per env,
-    OpenMP over envs like twisterl's rayon-over-clones) on this box's host cores."""
+def global_actions(seed: int, total_envs: int, num_actions: int) -> torch.Tensor:
+    """The ring of pre-sampled action buffers of the WHOLE batch, [RING, total_envs] int32 on the host: a function of
+    (seed, global env id) only, so every rank takes its slice of the same tensor."""
+    gen = torch.Generator()
+    gen.manual_seed(seed)
+    return torch.randint(0, num_actions, (RING, total_envs), dtype=torch.int32, generator=gen)
+
+
+def cpu_quota():
+    """CPUs this container may use at once (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
+
+
+def cpu_baseline(gateset, seed: int, budget_s: float = 2.0, repeats: int = 5):
+    """Time the CPU oracle (a C port of the reference's scalar Rust path, one env object per env, OpenMP over envs like
+    twisterl's rayon-over-clones) on this box's host cores: the configuration's own 65 536 envs, on ONE core and on ALL
+    cores the process may run on, threads pinned (OMP_PROC_BIND=close), median of `repeats` timed repeats each."""
     from oracle import OracleEnv, OracleVec
 
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    B = 16384
+    nproc = NPROC
+    B = ENVS_PER_GPU
     A = len(gateset)
     proto = OracleEnv("clifford", NUM_QUBITS, gateset, add_inverts=0, add_perms=0, track_solution=0, difficulty=SCRAMBLE)
     ov = OracleVec(proto, B)
     rng = np.random.default_rng(seed)
     ov.reset_with(rng.integers(0, A, size=(SCRAMBLE, B)))
     acts = rng.integers(0, A, size=(32, B)).astype(np.int32)
-    for t in range(8):  # warm-up: thread pool, first-touch, allocator
-        ov.step_only(acts[t], threads=min(avail, 8))
-    # the box may expose more hardware threads than it lets one container run: pick the thread
-    # count that actually delivers the most steps/s and report that count as `cores`
-    best = (0.0, 1)
-    cand = sorted({c for c in (1, 2, 4, 8, 16, 32, 64, 128, 256) if c <= avail} | {min(avail, 256)})
-    for c in cand:
-        ov.step_only(acts[0], threads=c)
+
+    def measure(threads: int):
+        for t in range(4):  # warm-up: thread pool, first touch
+            ov.step_only(acts[t], threads=threads)
         t0 = time.perf_counter()
-        for t in range(4):
-            ov.step_only(acts[t], threads=c)
-        rate = 4 * B / (time.perf_counter() - t0)
-        if rate > best[0]:
-            best = (rate, c)
-    cores = best[1]
-    per_step = B / best[0]
-    n_steps = int(max(8, min(2_000_000, budget_s / max(per_step, 1e-6))))
-    t0 = time.perf_counter()
-    for t in range(n_steps):
-        ov.step_only(acts[t % 32], threads=cores)
-    dt = time.perf_counter() - t0
+        ov.step_only(acts[4], threads=threads)
+        one = max(time.perf_counter() - t0, 1e-6)
+        n_steps = int(max(4, min(100_000, budget_s / one)))
+        for t in range(max(4, n_steps // 4)):  # untimed: the first passes after a thread-count change run slow
+            ov.step_only(acts[t % 32], threads=threads)
+        rates = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            for t in range(n_steps):
+                ov.step_only(acts[t % 32], threads=threads)
+            rates.append(B * n_steps / (time.perf_counter() - t0))
+        return float(np.median(rates)), [float(r) for r in rates], n_steps
+
+    quota = cpu_quota()
+    threads = nproc if quota is None else max(1, min(nproc, int(quota + 0.5)))  # never more threads than CPUs the container may run
+    one_core, one_core_runs, n1 = measure(1)
+    all_core, all_core_runs, nall = measure(threads)
     return {
-        "value": B * n_steps / dt,
+        "value": all_core,
         "unit": "env-steps/s",
-        "cores": cores,
+        "cores": threads,
         "kind": "port",
-        "sample": f"CliffordGym 16q, {B} envs x {n_steps} steps ({dt:.1f} s), C port of the reference scalar path "
-                  f"(byte-per-entry state, per-env objects), OpenMP over envs on {cores} threads",
+        "sample": f"CliffordGym 16q, {B} envs x {nall} steps per repeat, median of {repeats} repeats; C port of the reference scalar "
+                  f"path (byte-per-entry state, per-env objects, gcc -O3), OpenMP static over envs, threads pinned (OMP_PROC_BIND=close)",
+        "repeats": all_core_runs,
+        "one_core": {"value": one_core, "cores": 1, "repeats": one_core_runs, "steps_per_repeat": n1},
+        "nproc": nproc,
+        "cpu_quota": quota,
     }
 
 
-def parity_replay(gateset, seed, ids, ring_actions, trace, snap):
-    """Replay the run the GPU just did -- same seed, same scramble draws, same action buffers in the
-    same order -- on the CPU oracle for the sampled envs, and compare everything env.step() produces
-    (reward bits, success, is_final, depth, dense observation) after the last timed step."""
+def oracle_replay(gateset, seed, global_ids, ring_actions, trace):
+    """The run the GPU did -- same seed, same scramble draws (functions of the GLOBAL env id), same action buffers in the same
+    order -- on the CPU oracle for the sampled envs.  Returns the oracle batch and the outputs of its last step."""
     from oracle import OracleEnv, OracleVec
-    from util import f32_bits, rng_actions
+    from util import rng_actions
 
     proto = OracleEnv("clifford", NUM_QUBITS, gateset, add_inverts=0, add_perms=0, track_solution=0, difficulty=SCRAMBLE)
-    ov = OracleVec(proto, len(ids))
-    ov.reset_with(rng_actions(seed, ids, SCRAMBLE, len(gateset)))
-    r = s = f = d = None
+    ov = OracleVec(proto, len(global_ids))
+    ov.reset_with(rng_actions(seed, global_ids, SCRAMBLE, len(gateset)))
+    last = (None, None, None, None)
     for ring_idx in trace:
-        r, s, f, d = ov.step(ring_actions[ring_idx])
+        last = ov.step(ring_actions[ring_idx])
+    return ov, last
+
+
+def pack_rows_u32(dense: np.ndarray) -> np.ndarray:
+    """dense [n, 32, 32] of {0,1} -> packed [n, 32] uint32, bit c of word r = entry (r, c) (QG_FMT_PACKED)."""
+    w = (dense.astype(np.uint64) << np.arange(dense.shape[2], dtype=np.uint64)).sum(axis=2)
+    return w.astype(np.uint32)
+
+
+def parity_replay(gateset, seed, global_ids, ring_actions, trace, snap):
+    """Compare everything env.step() produces (reward bits, success, is_final, depth, dense observation) after the last timed step."""
+    import hashlib
+
+    from util import f32_bits
+
+    ov, (r, s, f, d) = oracle_replay(gateset, seed, global_ids, ring_actions, trace)
+    n = len(global_ids)
     ok = {
         "reward_bits": bool(np.array_equal(f32_bits(snap["reward"]), f32_bits(r))),
         "success": bool(np.array_equal(snap["success"], s)),
         "is_final": bool(np.array_equal(snap["done"], f)),
         "depth": bool(np.array_equal(snap["depth"], d)),
-        "observation": bool(np.array_equal(snap["obs"].reshape(len(ids), -1), ov.observe_dense())),
+        "observation": bool(np.array_equal(snap["obs"].reshape(n, -1), ov.observe_dense())),
     }
-    import hashlib
 
     def digest(obs, reward, success, depth):  # SURVEY.md 8d: SHA-256 over the final (state, reward bits, success, depth) streams
         h = hashlib.sha256()
@@ -124,11 +190,90 @@ def parity_replay(gateset, seed, ids, ring_actions, trace, snap):
             h.update(np.ascontiguousarray(arr).tobytes())
         return h.hexdigest()
 
-    sha_gpu = digest(snap["obs"].reshape(len(ids), -1), snap["reward"], snap["success"], snap["depth"])
+    sha_gpu = digest(snap["obs"].reshape(n, -1), snap["reward"], snap["success"], snap["depth"])
     sha_cpu = digest(ov.observe_dense(), r, s, d)
     ok["sha256"] = sha_gpu == sha_cpu
-    return {"envs": int(len(ids)), "steps_replayed": len(trace), "checked": sorted(ok), "bit_exact": all(ok.values()),
+    return {"envs": int(n), "steps_replayed": len(trace), "checked": sorted(ok), "bit_exact": all(ok.values()),
             "mismatch": [k for k, v in ok.items() if not v], "sha256_hip": sha_gpu, "sha256_oracle": sha_cpu}
+
+
+def gathered_parity(gateset, seed, global_ids, ring_actions, trace, shard):
+    """The learner-side view: the sampled envs' slice of the all-gathered shard (packed observation words, reward, is_final, success)
+    against the oracle replayed up to the step the snapshot was taken at."""
+    from util import f32_bits
+
+    ov, (r, s, f, _) = oracle_replay(gateset, seed, global_ids, ring_actions, trace)
+    n = len(global_ids)
+    want_obs = pack_rows_u32(ov.observe_dense().reshape(n, 2 * NUM_QUBITS, 2 * NUM_QUBITS))
+    ok = {
+        "packed_observation": bool(np.array_equal(shard["obs"].view(np.uint32), want_obs)),
+        "reward_bits": bool(np.array_equal(f32_bits(shard["reward"]), f32_bits(r))),
+        "is_final": bool(np.array_equal(shard["done"], f)),
+        "success": bool(np.array_equal(shard["success"], s)),
+    }
+    return {"envs": int(n), "steps_replayed": len(trace), "checked": sorted(ok), "bit_exact": all(ok.values()),
+            "mismatch": [k for k, v in ok.items() if not v]}
+
+
+def rocprof_kernel_avg_us(envs: int):
+    """Average duration of the step kernel in the committed rocprofv3 --kernel-trace --stats summary of this command
+    (profiles/r02/, tools/profile_bench.sh), or None.  The statistics hold one batch size (profiling runs pass --no-large-batch)."""
+    path = os.path.join(PROFILE_DIR, "bench_kernel_stats.csv" if envs == ENVS_PER_GPU else f"bench_{envs}_kernel_stats.csv")
+    try:
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if KERNEL.split("::", 1)[1] in row["Name"]:
+                    return {"avg_us": float(row["AverageNs"]) / 1e3, "min_us": float(row["MinNs"]) / 1e3, "calls": int(row["Calls"]),
+                            "source": os.path.relpath(path, ROOT)}
+    except Exception:
+        return None
+    return None
+
+
+def pmc_traffic(envs: int):
+    """HBM bytes per launch of the step kernel from the committed PMC passes (tools/profile_bench.sh + tools/pmc_traffic.py:
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), or None."""
+    path = os.path.join(PROFILE_DIR, "traffic.json")
+    try:
+        t = json.load(open(path))
+        e = t["by_envs"][str(envs)]
+        return {"bytes_per_launch": e["bytes_per_launch"], "fetch_bytes": e["fetch_bytes"], "write_bytes": e["write_bytes"],
+                "source": os.path.relpath(path, ROOT)}
+    except Exception:
+        return None
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n: int, argv) -> int:
+    """Start n ranks of this script under torch.distributed.run as a child process and relay rank 0's JSON line.  Runs before this
+    process has made any HIP / torch.cuda call other than counting devices (a process that has touched the GPU must not be re-exec'd)."""
+    visible = torch.cuda.device_count()  # counting does not initialise the GPU
+    if visible < n:
+        print(f"bench.py: --gpus {n} requested but only {visible} GPU(s) are visible; refusing to run fewer ranks and report them as {n}",
+              file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in res.stdout.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+    if res.returncode != 0 or line is None:
+        sys.stderr.write(res.stdout[-4000:])
+        print(f"bench.py: the {n}-rank child run failed (exit code {res.returncode})", file=sys.stderr)
+        return res.returncode or 1
+    print(line, flush=True)
+    return 0
 
 
 def main():
@@ -138,16 +283,31 @@ def main():
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the CPU-oracle replay of the timed run")
-    ap.add_argument("--no-large-batch", action="store_true", help="skip the 2^20-env leg (profiling runs: keeps the kernel statistics to one batch size)")
-    ap.add_argument("--no-gather", action="store_true", help="N>1 diagnostics: skip the per-step all-gather")
+    ap.add_argument("--no-large-batch", action="store_true", help="skip the 2^18 / 2^20 / 2^22-env legs (profiling runs: keeps the kernel statistics to one batch size)")
+    ap.add_argument("--no-default-config", action="store_true", help="skip the reference-default (add_inverts=True, track_solution=True) leg")
+    ap.add_argument("--no-gather", action="store_true", help="N>1 diagnostics: step only, no all-gather")
     ap.add_argument("--gather-every", type=int, default=CHUNK,
-                    help="N>1: all-gather the packed observation every this many steps (1 = after every step)")
+                    help="N>1: all-gather the learner shard every min(this, --steps) steps (1 = after every step)")
     ap.add_argument("--envs", type=int, default=ENVS_PER_GPU,
-                    help="diagnostics: envs per GPU (the metric is quoted at the default 65 536; profiles/ uses 2^20 to show where the "
+                    help="diagnostics: envs per GPU (the metric is quoted at the default 65 536; profiles/ uses larger batches to show where the "
                          "launch boundary stops mattering)")
     ap.add_argument("--force-multi", action="store_true",
-                    help="diagnostics: run the multi-GPU code path (RCCL init, side-stream all-gather) even with one rank")
+                    help="diagnostics: run the multi-GPU code path (RCCL init, side-stream all-gather) on ONE rank")
+    ap.add_argument("--shard", type=str, default=None,
+                    help="with --force-multi: R/W = be rank R of a W-rank job for every env id (env base R * envs, actions of that slice)")
+    ap.add_argument("--dump-gathered", type=str, default=None,
+                    help="rank 0: write a strided sample of this rank's part of the last all-gathered shard, with what an oracle replay needs, to this .npz")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.gather_every < 1:
+        ap.error("--gpus, --steps, --gather-every must be positive and --warmup non-negative")
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1 and not args.force_multi:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(world_env) if world_env is not None else 1
+    if world != args.gpus and not args.force_multi:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree", file=sys.stderr)
+        sys.exit(2)
 
     # stdout carries exactly one JSON line: libraries that print to the C-level stdout (RCCL's version
     # banner) are sent to stderr, our line goes to a private duplicate of the original descriptor
@@ -157,111 +317,129 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if local_rank >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} has LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
+        sys.exit(2)
     dist = None
     multi = world > 1 or args.force_multi
     if multi:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != world:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, expected {world}")
     else:
         torch.cuda.set_device(0)
     n_gpus = world
     dev = torch.device("cuda", torch.cuda.current_device())
 
+    from qiskit_gym_amd.distributed import shard_range
     from qiskit_gym_amd.vec import VecEnv
 
     n, gateset = build_gateset()
     A = len(gateset)
     B = args.envs
-    seed = 0x5EED0003 + rank
-    env = VecEnv("clifford", n, gateset, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=SCRAMBLE)
+    # which slice of which batch this rank steps: rank r of W owns envs [r * B, (r + 1) * B) of a batch of W * B
+    shard_rank, shard_world = rank, world
+    if args.shard:
+        if not args.force_multi or world != 1:
+            raise SystemExit("bench.py: --shard needs --force-multi on one rank")
+        shard_rank, shard_world = (int(x) for x in args.shard.split("/"))
+    total_envs = B * shard_world
+    env_base, count = shard_range(total_envs, shard_rank, shard_world)
+    assert count == B
+    seed = 0x5EED0003 if shard_world == 1 else 0x5EED0004  # seed = 0x5EED0000 + config (3: one GPU, 4: the sharded batch)
+    env = VecEnv("clifford", n, gateset, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=SCRAMBLE, env_base=env_base)
     stream = torch.cuda.Stream(device=dev)
     K, W = args.steps, args.warmup
 
+    host_actions = global_actions(seed, total_envs, A)[:, env_base:env_base + B].contiguous()
+    actions = host_actions.to(dev)
     gen = torch.Generator(device=dev)
-    gen.manual_seed(seed)
-    actions = torch.randint(0, A, (RING, B), dtype=torch.int32, device=dev, generator=gen)
+    gen.manual_seed(seed + 17)
 
     ring_trace = []  # which action buffer every step since the last reset used (for the oracle replay)
+    launches = []    # how the steps since the last reset were issued (config.launch)
 
-    def run_steps_single(nsteps: int):
-        """nsteps env.step() launches: whole chunks replay a cached hipGraph of CHUNK launches."""
+    def issue(nsteps: int):
+        """nsteps env.step() launches of the resident batch: chunks of <= CHUNK single-step launches, each chunk one replay of a cached
+        hipGraph (the same launches, results and memory traffic as that many qg_vec_step calls, without their host cost)."""
         done = 0
-        while nsteps - done >= CHUNK:
-            env.rollout_ring(actions, CHUNK)
-            ring_trace.extend(i % RING for i in range(CHUNK))
-            done += CHUNK
-        for t in range(nsteps - done):
-            env.step(actions[t % RING])
-            ring_trace.append(t % RING)
+        while done < nsteps:
+            c = min(CHUNK, nsteps - done)
+            if c >= 2:
+                env.rollout_ring(actions, c)
+                launches.append(("graph", c))
+            else:
+                env.step(actions[0])
+                launches.append(("eager", 1))
+            ring_trace.extend(i % RING for i in range(c))
+            done += c
 
-    # ---- multi-GPU: step + all-gather of the packed observation, double buffered -------------
+    # ---- multi-GPU: step + all-gather of the learner shard, double buffered -------------------
+    gather_every = min(args.gather_every, K)
+    gather_log = {"submitted": 0}
     if multi:
-        from qiskit_gym_amd.distributed import OverlappedGather
+        from qiskit_gym_amd.distributed import OverlappedGather, fill_learner_shard, learner_shard_words, split_learner_shards
 
         # double-buffered, host-mediated hand-over to a side stream (see OverlappedGather: a stream-to-stream
         # event wait would slow every later graph replay on the step stream by ~40 %)
         # one flat int32 shard per rank carries everything SURVEY 8e lists for the learner: the packed observation [B, 32], the f32
         # rewards [B] and is_final / success [B] bytes each -- one collective instead of four
-        from qiskit_gym_amd.distributed import fill_learner_shard, learner_shard_words
-
-        gatherer = OverlappedGather((learner_shard_words(B, 32),), torch.int32, dev)
+        gatherer = OverlappedGather((learner_shard_words(B, OBS_WORDS),), torch.int32, dev)
 
         def fill_shard(buf):
-            fill_learner_shard(buf, B, 32, lambda view: env.observe_packed(out=view), env.reward, env.done, env.success)
+            fill_learner_shard(buf, B, OBS_WORDS, lambda view: env.observe_packed(out=view), env.reward, env.done, env.success)
 
         def snapshot_and_gather():
             gatherer.submit(fill_shard)
+            gather_log["submitted"] += 1
+            gather_log["trace_len"] = len(ring_trace)
 
-        flush_gathers = gatherer.flush
-
-        def run_steps_multi(nsteps: int):
-            """Each rank steps its own shard (no collective inside step).  Every `gather_every` steps the
-            bit-packed observation is snapshotted and all-gathered on the side stream, double buffered,
-            overlapping the steps that follow."""
-            G = args.gather_every
+        def run_steps(nsteps: int):
+            """Each rank steps its own shard (no collective inside step).  Every `gather_every` steps the learner shard is snapshotted
+            and all-gathered on the side stream, double buffered, overlapping the steps that follow."""
             done = 0
             while done < nsteps:
-                n = min(G, nsteps - done)
-                if n >= 8:
-                    env.rollout_ring(actions, n)  # cached hipGraph of n single-step launches
-                    ring_trace.extend(i % RING for i in range(n))
-                else:
-                    for t in range(n):
-                        env.step(actions[(done + t) % RING])
-                        ring_trace.append((done + t) % RING)
-                done += n
-                if not args.no_gather and n == G:
+                c = min(gather_every, nsteps - done)
+                issue(c)
+                done += c
+                if not args.no_gather and c == gather_every:
                     snapshot_and_gather()
-            flush_gathers()
-
-        run_steps = run_steps_multi
+            if not args.no_gather:
+                gatherer.flush()
     else:
-        run_steps = run_steps_single
+        run_steps = issue
 
     with torch.cuda.stream(stream):
         env.reset(seed)
-        run_steps(CHUNK)  # builds and caches the rollout graph (setup, not a step)
+        run_steps(K)  # builds and caches every graph the timed region replays (setup, not a step)
+        if W:
+            run_steps(W)
         if multi and not args.no_gather:  # communicator set-up and first-use kernel loads of RCCL (setup, not a step)
             snapshot_and_gather()
             snapshot_and_gather()
-            flush_gathers()
+            gatherer.flush()
         env.reset(seed)
         ring_trace.clear()
-        run_steps(W)  # untimed warmup steps
+        launches.clear()
+        gather_log["submitted"] = 0
+        if W:
+            run_steps(W)  # untimed warmup steps
+        launches.clear()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    gathers_before = gather_log["submitted"]
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
     with torch.cuda.stream(stream):
         ev0.record(stream)
         run_steps(K)
@@ -275,12 +453,14 @@ def main():
         elapsed = float(tt.item())
     env.sync()  # raises if any env faulted
     stream_ms = ev0.elapsed_time(ev1)
+    timed_launches = list(launches)
+    gathers_timed = gather_log["submitted"] - gathers_before
 
     # ---- snapshot of a sample of envs right after the timed steps, for the oracle replay -------
-    snap = None
+    snap = gshard = None
+    ids = np.arange(0, B, 64)
+    idx = torch.as_tensor(ids, device=dev)
     if rank == 0 and not args.no_parity:
-        ids = np.arange(0, B, 64)
-        idx = torch.as_tensor(ids, device=dev)
         with torch.cuda.stream(stream):
             snap = {
                 "obs": env.observe()[idx].cpu().numpy(),
@@ -290,9 +470,66 @@ def main():
                 "depth": env.depth[idx].cpu().numpy(),
             }
         snap_trace = list(ring_trace)
-        snap_actions = actions[:, idx].cpu().numpy()
+    snap_actions = host_actions[:, ids].numpy()
+    if multi and rank == 0 and not args.no_gather and gatherer.latest() is not None:
+        # this rank's own part of the last all-gathered buffer, as the learner would read it
+        g_obs, g_rew, g_done, g_succ = split_learner_shards(gatherer.latest(), world, B, OBS_WORDS)
+        lo = rank * B
+        gshard = {"obs": g_obs[lo:lo + B][idx].cpu().numpy(), "reward": g_rew[lo:lo + B][idx].cpu().numpy(),
+                  "done": g_done[lo:lo + B][idx].cpu().numpy(), "success": g_succ[lo:lo + B][idx].cpu().numpy(),
+                  "trace": ring_trace[:gather_log["trace_len"]]}
+        if args.dump_gathered:
+            np.savez(args.dump_gathered, global_ids=env_base + ids, actions=snap_actions, seed=np.uint64(seed), scramble=SCRAMBLE,
+                     trace=np.asarray(gshard["trace"], dtype=np.int64), obs=gshard["obs"], reward=gshard["reward"], done=gshard["done"],
+                     success=gshard["success"], total_envs=total_envs, env_base=env_base)
 
-    # ---- roofline leg: duration of the step kernel itself, HIP events around single launches --
+    # ---- collective cadences, beside the timed region (N > 1 or --force-multi) -------------------
+    cadence = None
+    if multi and not args.no_gather:
+        def timed(fn, reps):
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            t = time.perf_counter()
+            with torch.cuda.stream(stream):
+                for _ in range(reps):
+                    fn()
+                gatherer.flush()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item()) / reps
+
+        def step_and_gather():
+            env.step(actions[0])
+            snapshot_and_gather()
+
+        per_step = timed(step_and_gather, 64)       # SURVEY 8e's literal cadence: one all-gather per env.step()
+        gather_only = timed(snapshot_and_gather, 16)  # snapshot + collective alone, nothing to overlap with
+        cadence = {
+            "per_step_gather_us": per_step * 1e6,
+            "per_step_gather_value": B * n_gpus / per_step,
+            "segment_gather_us": gather_only * 1e6,
+            "segment_steps": gather_every,
+            "shard_bytes_per_rank": 4 * learner_shard_words(B, OBS_WORDS),
+        }
+
+    # ---- roofline leg: duration of the step kernel, HIP events on the stream the kernel is launched on --------
+    # (1) the timed region itself: events around the K timed launches (what `achieved` uses)
+    timed_region_us = stream_ms * 1e3 / K
+    # (2) steady-state launch period inside one hipGraph of CHUNK launches (no host in the loop)
+    with torch.cuda.stream(stream):
+        env.rollout_ring(actions, CHUNK)
+        torch.cuda.synchronize()
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record(stream)
+        for _ in range(4):
+            env.rollout_ring(actions, CHUNK)
+        g1.record(stream)
+    torch.cuda.synchronize()
+    graph_period_us = g0.elapsed_time(g1) * 1e3 / (4 * CHUNK)
+    # (3) one eager launch between two events
     reps = 200
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
     stops = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
@@ -302,21 +539,14 @@ def main():
             env.step(actions[i % RING])
             stops[i].record(stream)
     torch.cuda.synchronize()
-    per_launch_us = sorted(s.elapsed_time(e) * 1e3 for s, e in zip(starts, stops))
-    single_launch_us = float(np.median(per_launch_us))
-    b2b_us = stream_ms * 1e3 / K  # back-to-back launches incl. the inter-kernel boundary
-    kernel_us = min(single_launch_us, b2b_us)
+    eager_event_us = float(np.median(sorted(s.elapsed_time(e) * 1e3 for s, e in zip(starts, stops))))
     algo_bytes = ALGO_BYTES_PER_STEP * B
-    achieved = algo_bytes / (kernel_us * 1e-6) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and B == ENVS_PER_GPU:  # the PMC passes were collected at the metric's batch size
-        try:
-            traffic = json.load(open(tpath)).get("clifford_step_bytes_per_launch")
-        except Exception:
-            traffic = None
+    needed_bytes = NEEDED_BYTES_PER_STEP * B
+    achieved = algo_bytes / (timed_region_us * 1e-6) / 1e9
+    rocprof = rocprof_kernel_avg_us(B)
+    traffic = pmc_traffic(B)
 
-    # ---- fused rollout (state in registers across steps), reported beside the headline --------
+    # ---- fused rollout (state in LDS across steps), reported beside the headline --------
     fused = None
     if not multi:
         FT = 128
@@ -334,40 +564,80 @@ def main():
         fused = {"value": B * FT * 8 / (fms * 1e-3), "unit": "env-steps/s", "steps_per_launch": FT,
                  "kernel": "qg::qm_fused_lds_kernel<16, true, false> (rows resident in LDS; actions known up front)"}
 
-    # ---- the same step kernel at 2^18 and 2^20 envs: where the launch boundary (1.6 us) stops dominating -----
+    def graph_period(venv, acts, replays=2):
+        with torch.cuda.stream(stream):
+            venv.rollout_ring(acts, CHUNK)
+            torch.cuda.synchronize()
+            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b0.record(stream)
+            for _ in range(replays):
+                venv.rollout_ring(acts, CHUNK)
+            b1.record(stream)
+        torch.cuda.synchronize()
+        venv.sync()
+        return b0.elapsed_time(b1) * 1e3 / (replays * CHUNK)
+
+    # ---- the reference's DEFAULT configuration (envs/synthesis.py:182-204: add_inverts=True, track_solution=True) -------
+    default_cfg = None
+    if not multi and B == ENVS_PER_GPU and not args.no_default_config:
+        DT = 128  # = max_depth (envs/synthesis.py:188): what one episode, and its solution log, can hold
+        denv = VecEnv("clifford", n, gateset, B, add_inverts=True, add_perms=False, track_solution=True, difficulty=SCRAMBLE)
+        coins = torch.randint(0, 2, (DT, B), dtype=torch.uint8, device=dev, generator=gen)
+        dacts = torch.randint(0, A, (DT, B), dtype=torch.int32, device=dev, generator=gen)
+        dms = 0.0
+        with torch.cuda.stream(stream):
+            denv.reset(seed)
+            denv.rollout(dacts, coins=coins)  # builds the graph
+            for _ in range(4):
+                denv.reset(seed)  # a new episode: the log is empty again (not timed)
+                d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                d0.record(stream)
+                denv.rollout(dacts, coins=coins)
+                d1.record(stream)
+                torch.cuda.synchronize()
+                dms += d0.elapsed_time(d1)
+        denv.sync()
+        dus = dms * 1e3 / (4 * DT)
+        default_cfg = {"us_per_step": dus, "value": B / (dus * 1e-6), "unit": "env-steps/s",
+                       "config": "add_inverts=True (coin per env per step), track_solution=True, otherwise the headline workload; "
+                                 f"episodes of {DT} steps, each one hipGraph of {DT} launches, coins given"}
+        del denv, coins, dacts
+
+    # ---- the same step kernel at larger batches: where the launch boundary (1.6 us) stops dominating, and beyond the Infinity Cache -----
     large = None
     if not multi and B == ENVS_PER_GPU and not args.no_large_batch:
         sizes = []
-        for LB in (1 << 18, 1 << 20):
+        for LB in (1 << 18, 1 << 20, 1 << 22):
             big = VecEnv("clifford", n, gateset, LB, add_inverts=False, add_perms=False, track_solution=False, difficulty=SCRAMBLE)
             bacts = torch.randint(0, A, (RING, LB), dtype=torch.int32, device=dev, generator=gen)
             with torch.cuda.stream(stream):
                 big.reset(seed)
-                big.rollout_ring(bacts, CHUNK)
-                torch.cuda.synchronize()
-                b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                b0.record(stream)
-                for _ in range(2):
-                    big.rollout_ring(bacts, CHUNK)
-                b1.record(stream)
-            torch.cuda.synchronize()
-            big.sync()
-            lus = b0.elapsed_time(b1) * 1e3 / (2 * CHUNK)
+            lus = graph_period(big, bacts)
             lgb = ALGO_BYTES_PER_STEP * LB / (lus * 1e-6) / 1e9
-            sizes.append({"envs": LB, "launch_us": lus, "achieved": lgb, "unit": "GB/s", "frac": lgb / HBM_PEAK_GBS})
+            sizes.append({"envs": LB, "launch_us": lus, "achieved": lgb, "unit": "GB/s", "frac": lgb / HBM_PEAK_GBS,
+                          "state_MiB": LB * 128 / 2**20, "rocprof": rocprof_kernel_avg_us(LB), "traffic": pmc_traffic(LB)})
             del big, bacts
-        large = dict(sizes[-1], note="same kernel and layout, 16x the batch: per-launch time is kernel time, not launch boundary", by_batch=sizes)
+        large = {"note": "same kernel and layout at 4x / 16x / 64x the batch: per-launch time is kernel time, not launch boundary; "
+                         "2^22 envs = 512 MiB of state, beyond the 256 MiB Infinity Cache", "by_batch": sizes}
 
-    out = None
     if rank == 0:
         cpu = None
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only
+        if not args.no_cpu_baseline and world == 1 and not args.force_multi:  # the CPU leg runs at N = 1 only
             cpu = cpu_baseline(gateset, seed)
         parity = None
         if snap is not None:
-            parity = parity_replay(gateset, seed, ids, snap_actions, snap_trace, snap)
+            parity = parity_replay(gateset, seed, env_base + ids, snap_actions, snap_trace, snap)
             if not parity["bit_exact"]:
                 raise SystemExit(f"bench.py: GPU run differs from the CPU oracle replay: {parity}")
+            if gshard is not None:
+                parity["gathered_shard"] = gathered_parity(gateset, seed, env_base + ids, snap_actions, gshard["trace"], gshard)
+                if not parity["gathered_shard"]["bit_exact"]:
+                    raise SystemExit(f"bench.py: the all-gathered shard differs from the CPU oracle replay: {parity['gathered_shard']}")
+        graphs = [c for kind, c in timed_launches if kind == "graph"]
+        eager = sum(c for kind, c in timed_launches if kind == "eager")
+        launch_desc = ("one step kernel per env.step(); the %d timed steps = %s%s" % (
+            K, " + ".join(f"{graphs.count(c)} x hipGraph of {c} launches" for c in sorted(set(graphs), reverse=True)) or "no graph",
+            f" + {eager} eager launch(es)" if eager else ""))
         total_steps = B * K * n_gpus
         out = {
             "metric": f"env-steps/sec (whole node), CliffordGym 16q x {B} envs/GPU; bit-exact vs CPU",
@@ -389,28 +659,50 @@ def main():
                             "add_inverts=False, add_perms=False, track_solution=False, default weights, free-running",
                 "envs_per_gpu": B,
                 "total_envs": B * n_gpus,
-                "launch": "one step kernel per env.step(); chunks of %d launches replayed from a hipGraph" % CHUNK
-                if not multi else "one step kernel per env.step() (hipGraph chunks); no collective inside step",
-                "collective": None if not multi or args.no_gather else
-                f"RCCL all_gather_into_tensor of one shard per rank (bit-packed observation 8 MiB + rewards + is_final / success flags) every {args.gather_every} steps, side stream, overlapped",
+                "ranks_seen": dist.get_world_size() if dist is not None else 1,
+                "env_ids_of_rank0": [env_base, env_base + B],
+                "partition": f"rank r owns envs [r * {B}, (r + 1) * {B}) of one batch of {total_envs}; seeds and actions are functions of the global env id",
+                "launch": launch_desc,
+                "collective": None if not multi or args.no_gather else {
+                    "what": "RCCL all_gather_into_tensor of one flat shard per rank (bit-packed observation + f32 rewards + is_final / success flags), "
+                            "side stream, double buffered, overlapped with the following steps",
+                    "every_steps": gather_every,
+                    "collectives_in_timed_region": gathers_timed,
+                    **(cadence or {}),
+                },
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "qg::qm_step1_kernel<16, true, false>",
+                "kernel": KERNEL,
                 "kernel_resources": "256 threads/block, 1 wave/SIMD at 65 536 envs; no LDS; thread per env",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "clock": "HIP events on the launch stream around the K timed steps (kernel_us_timed_region): launch period, i.e. kernel + launch boundary",
+                "traffic": traffic["bytes_per_launch"] if traffic else None,
+                "traffic_detail": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes,
-                "launch_us": kernel_us,
-                "launch_us_single_event_pair": single_launch_us,
-                "launch_us_back_to_back": b2b_us,
+                "bytes_needed_per_launch": needed_bytes,
+                "bytes_per_env": {"survey_8d": ALGO_BYTES_PER_STEP, "needed": NEEDED_BYTES_PER_STEP,
+                                  "pmc": traffic["bytes_per_launch"] / B if traffic else None},
+                "traffic_over_needed": traffic["bytes_per_launch"] / needed_bytes if traffic else None,
+                "kernel_us_timed_region": timed_region_us,
+                "kernel_us_graph_period": graph_period_us,
+                "kernel_us_eager_event": eager_event_us,
+                "kernel_us_rocprof_avg": rocprof["avg_us"] if rocprof else None,
+                "rocprof": dict(rocprof, frac=algo_bytes / (rocprof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof else None,
+                "frac_by_clock": {
+                    "timed_region": achieved / HBM_PEAK_GBS,
+                    "graph_period": algo_bytes / (graph_period_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    "eager_event": algo_bytes / (eager_event_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    "rocprof_avg": algo_bytes / (rocprof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS if rocprof else None,
+                },
             },
             "cpu_baseline": cpu,
             "parity": parity,
             "fused_rollout": fused,
+            "default_config": default_cfg,
             "large_batch": large,
         }
         print(json.dumps(out), file=json_out, flush=True)

@@ -129,3 +129,20 @@ int main(void) {
                     f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.startswith("ok"), (out.returncode, out.stdout, out.stderr)
+
+
+def test_bench_refuses_more_gpus_than_visible_and_mismatched_world_size():
+    """bench.py --gpus N starts N ranks itself (or checks the launcher's WORLD_SIZE); it never runs fewer ranks and reports N."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1), "--steps", "20", "--warmup", "5"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 2 and "visible" in res.stderr and "metric" not in res.stdout
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], capture_output=True, text=True,
+                         env=dict(env, WORLD_SIZE="2"), timeout=300)
+    assert res.returncode == 2 and "disagree" in res.stderr

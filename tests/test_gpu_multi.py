@@ -1,0 +1,110 @@
+"""The multi-GPU leg as far as one GPU can show it (BASELINE config 4: 524 288 envs = 8 shards of 65 536):
+a shard stepped with an env base is bit-identical to its slice of the whole batch, and bench.py's RCCL path -- one rank
+standing in for rank 3 of 8 -- hands the learner a gathered shard that matches the CPU oracle for those env ids."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import OracleEnv, OracleVec
+from util import f32_bits, line_gateset, rng_actions
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("kind,n,cfg", [
+    ("clifford", 16, dict(add_inverts=False, add_perms=False, track_solution=False, difficulty=40)),
+    ("clifford", 6, dict(add_inverts=True, add_perms=False, track_solution=True, difficulty=12)),   # counter-RNG coins
+    ("linear_function", 8, dict(add_inverts=True, add_perms=False, track_solution=False, difficulty=20)),
+    ("linear_function", 24, dict(add_inverts=True, add_perms=False, track_solution=False, difficulty=20)),  # lane-group kernels
+    ("permutation", 9, dict(add_inverts=True, add_perms=False, track_solution=False, difficulty=10)),
+    ("clifford", 24, dict(add_inverts=False, add_perms=False, track_solution=False, difficulty=30)),
+    ("pauli", 6, dict(add_perms=True, track_solution=False, difficulty=48, pauli_diff_scale=8)),      # target generator + observe() permutations
+])
+def test_shard_with_env_base_equals_its_slice_of_the_whole_batch(kind, n, cfg):
+    from qiskit_gym_amd.vec import VecEnv
+
+    gs = line_gateset(kind, n)
+    A = len(gs)
+    per, world, r = 192, 4, 2
+    whole = VecEnv(kind, n, gs, per * world, **cfg)
+    shard = VecEnv(kind, n, gs, per, env_base=r * per, **cfg)
+    sl = slice(r * per, (r + 1) * per)
+    whole.reset(77)
+    shard.reset(77)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for t in range(12):
+        if kind == "pauli":
+            assert torch.equal(whole.observe()[sl], shard.observe())  # draws one permutation per env from the counter RNG
+        acts = torch.randint(0, A, (per * world,), dtype=torch.int32, device="cuda", generator=g)
+        whole.step(acts)
+        shard.step(acts[sl].contiguous())
+        assert torch.equal(whole.reward[sl].view(torch.int32), shard.reward.view(torch.int32)), (kind, t)
+        assert torch.equal(whole.done[sl], shard.done) and torch.equal(whole.success[sl], shard.success)
+    whole.sync()
+    shard.sync()
+    if kind == "pauli":
+        assert torch.equal(whole.get_state("i64")[sl], shard.get_state("i64"))
+    else:
+        assert torch.equal(whole.get_state("packed")[sl], shard.get_state("packed"))
+    # auto-reset of finished episodes draws by global env id too
+    whole.reset_done(123)
+    shard.reset_done(123)
+    assert torch.equal(whole.depth[sl], shard.depth)
+    fmt = "i64" if kind == "pauli" else "packed"
+    assert torch.equal(whole.get_state(fmt)[sl], shard.get_state(fmt))
+
+
+def _run_bench(*flags, timeout=600):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_rccl_path_gathered_shard_3_of_8_matches_oracle(tmp_path):
+    """BASELINE config 4's shape on the hardware there is: one rank runs bench.py's multi-GPU path (process group, side-stream
+    all-gather of the flat learner shard, --steps 20 so the driver's arguments put a collective inside the timed region) as
+    rank 3 of 8, i.e. env ids [196 608, 262 144).  The gathered packed observation, rewards and flags of a strided sample are
+    replayed here on the oracle, independently of bench.py's own check."""
+    dump = str(tmp_path / "gathered.npz")
+    res = _run_bench("--force-multi", "--shard", "3/8", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-large-batch",
+                     "--no-default-config", "--dump-gathered", dump)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    cfg = line["config"]
+    assert cfg["ranks_seen"] == 1 and line["n_gpus"] == 1
+    assert cfg["env_ids_of_rank0"] == [3 * 65536, 4 * 65536] and cfg["total_envs"] == 65536
+    assert cfg["collective"]["collectives_in_timed_region"] >= 1 and cfg["collective"]["every_steps"] == 20
+    assert cfg["collective"]["per_step_gather_us"] > 0 and cfg["collective"]["segment_gather_us"] > 0
+    assert line["parity"]["bit_exact"] and line["parity"]["gathered_shard"]["bit_exact"]
+    assert "hipGraph of 20 launches" in cfg["launch"]
+
+    d = np.load(dump)
+    ids = d["global_ids"]
+    assert ids.min() >= 3 * 65536 and ids.max() < 4 * 65536 and int(d["total_envs"]) == 8 * 65536
+    gs = line_gateset("clifford", 16)
+    proto = OracleEnv("clifford", 16, gs, add_inverts=0, add_perms=0, track_solution=0, difficulty=int(d["scramble"]))
+    ov = OracleVec(proto, len(ids))
+    ov.reset_with(rng_actions(int(d["seed"]), ids, int(d["scramble"]), len(gs)))
+    r = s = f = None
+    assert len(d["trace"]) == 5 + 20  # warmup + the one timed segment
+    for ring_idx in d["trace"]:
+        r, s, f, _ = ov.step(d["actions"][ring_idx])
+    dense = ov.observe_dense().reshape(len(ids), 32, 32).astype(np.uint64)
+    want = (dense << np.arange(32, dtype=np.uint64)).sum(axis=2).astype(np.uint32)
+    assert np.array_equal(d["obs"].view(np.uint32), want)
+    assert np.array_equal(f32_bits(d["reward"]), f32_bits(r))
+    assert np.array_equal(d["done"], f) and np.array_equal(d["success"], s)
+
+
+def test_bench_gpus_flag_fails_loudly_without_that_many_gpus():
+    n = torch.cuda.device_count() + 1
+    res = _run_bench("--gpus", str(n), "--steps", "20", "--warmup", "5", timeout=120)
+    assert res.returncode != 0 and "visible" in res.stderr
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]

@@ -1,35 +1,105 @@
-"""rocprofv3 PMC passes of bench.py (tools/profile_bench.sh) -> profiles/traffic.json.
+"""rocprofv3 PMC passes of tools/profile_bench.sh -> profiles/r02/traffic.json (and the kernel-stats files copied beside it).
 
-HBM bytes per launch of the step kernel = 2 x FETCH_SIZE + WRITE_SIZE (both reported in KiB):
-MI355X_MICROARCH.md's HBM section: on gfx950 FETCH_SIZE counts half the bytes of a 16 B/lane read,
-WRITE_SIZE is taken as is."""
-import csv, json, os, statistics, sys
+HBM bytes per launch of a step kernel = 2 x FETCH_SIZE + WRITE_SIZE (both reported in KiB): MI355X_MICROARCH.md's HBM
+section -- on gfx950 FETCH_SIZE counts half the bytes of a 16 B/lane read, WRITE_SIZE is taken as is; each counter is
+collected in its own pass (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2: they do not fit one pass)."""
+import csv
+import glob
+import itertools
+import json
+import os
+import shutil
+import statistics
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof")
-KERNEL = "qm_step1_kernel<16, true, false>"
-B, ALGO = 65536, 160
+dst = os.path.join(ROOT, "profiles", "r02")
+os.makedirs(dst, exist_ok=True)
+
+# run name -> (kernel substring, envs, SURVEY 8(d) bytes per env-step, bytes the kernel must move per env-step)
+RUNS = {
+    "bench": ("qm_step1_kernel<16, true, false>", 65536, 160, 90),
+    "C3_1048576": ("qm_step1_kernel<16, true, false>", 1048576, 160, 90),
+    "C3_4194304": ("qm_step1_kernel<16, true, false>", 4194304, 160, 90),
+    "C3d": ("qm_step_kernel<16, true, true, true, true, false>", 65536, 160, 160),
+    "C2": ("word_step_kernel<false>", 8192, 32, 32),
+    "C5": ("ptile_step1c_kernel<20, 8, false>", 65536, 494, None),
+}
 
 
-def read(counter):
+def read(run, counter, kernel, envs):
+    path = os.path.join(src, f"pmc_{run}_{counter}.csv")
     vals = []
-    with open(os.path.join(src, f"pmc_{counter}.csv")) as f:
+    if not os.path.exists(path):
+        return vals
+    with open(path) as f:
         for row in csv.DictReader(f):
-            if KERNEL in row["Kernel_Name"] and row["Counter_Name"] == counter and int(row["Grid_Size"]) == B:
+            if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter and int(row["Grid_Size"]) >= envs:
                 vals.append(float(row["Counter_Value"]))
     return vals
 
 
-fetch, write = read("FETCH_SIZE"), read("WRITE_SIZE")
-out = {
-    "kernel": f"qg::{KERNEL} (CliffordGym 16q x {B} envs, one env.step())",
-    "command": "tools/profile_bench.sh: rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline --no-parity --steps 512 --warmup 64 (one pass per counter)",
-    "FETCH_SIZE_KB_per_launch": statistics.mean(fetch),
-    "WRITE_SIZE_KB_per_launch": statistics.mean(write),
-    "correction": "MI355X_MICROARCH.md (HBM): FETCH_SIZE doubled on gfx950, WRITE_SIZE as is; both in KiB",
-    "clifford_step_bytes_per_launch": (2 * statistics.mean(fetch) + statistics.mean(write)) * 1024,
-    "algorithmic_bytes_per_launch": ALGO * B,
-    "raw": {n: {"dispatches": len(v), "mean": statistics.mean(v), "min": min(v), "max": max(v)} for n, v in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write))},
-}
-json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
-print(json.dumps(out, indent=1))
+def stats(run, kernel):
+    path = os.path.join(src, f"{run}_kernel_stats.csv")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if kernel in row["Name"]:
+                return {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3, "min_us": float(row["MinNs"]) / 1e3,
+                        "max_us": float(row["MaxNs"]) / 1e3}
+    return None
+
+
+out = {"method": "tools/profile_bench.sh: rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 <bench.py | tools/run_config.py ...>, "
+                 "one pass per counter; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md HBM section: FETCH_SIZE doubled on gfx950, "
+                 "WRITE_SIZE as is, both in KiB); mean over the step kernel's dispatches",
+       "by_envs": {}, "configs": {}}
+for run, (kernel, envs, algo, needed) in RUNS.items():
+    fetch, write = read(run, "FETCH_SIZE", kernel, envs), read(run, "WRITE_SIZE", kernel, envs)
+    if not fetch or not write:
+        continue
+    fb, wb = 2 * statistics.mean(fetch) * 1024, statistics.mean(write) * 1024
+    st = stats(run, kernel)
+    live = None
+    lp = os.path.join(src, f"{run}_live.json")
+    if os.path.exists(lp):
+        try:
+            live = json.loads(open(lp).read().strip().splitlines()[-1])
+        except Exception:
+            live = None
+    e = {"kernel": "qg::" + kernel, "envs": envs, "fetch_bytes": fb, "write_bytes": wb, "bytes_per_launch": fb + wb,
+         "bytes_per_env": (fb + wb) / envs, "fetch_per_env": fb / envs, "write_per_env": wb / envs,
+         "survey_8d_bytes_per_env": algo, "needed_bytes_per_env": needed,
+         "dispatches": {"FETCH_SIZE": len(fetch), "WRITE_SIZE": len(write)},
+         "raw_KiB": {"FETCH_SIZE": {"mean": statistics.mean(fetch), "min": min(fetch), "max": max(fetch)},
+                     "WRITE_SIZE": {"mean": statistics.mean(write), "min": min(write), "max": max(write)}},
+         "rocprof_kernel_stats": st, "live": live}
+    if st:
+        e["rocprof_GBs_algorithmic"] = algo * envs / st["avg_us"] / 1e3
+        e["rocprof_frac_algorithmic"] = e["rocprof_GBs_algorithmic"] / 8000
+        e["rocprof_GBs_moved"] = (fb + wb) / st["avg_us"] / 1e3
+        e["rocprof_frac_moved"] = e["rocprof_GBs_moved"] / 8000
+    out["configs"][run] = e
+    if kernel.startswith("qm_step1_kernel"):
+        out["by_envs"][str(envs)] = e
+json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+copied = []
+for f in glob.glob(os.path.join(src, "*kernel_stats.csv")):
+    name = os.path.basename(f)
+    name = {"C3_1048576_kernel_stats.csv": "bench_1048576_kernel_stats.csv", "C3_4194304_kernel_stats.csv": "bench_4194304_kernel_stats.csv"}.get(name, name)
+    shutil.copy(f, os.path.join(dst, name))
+    copied.append(name)
+for f in glob.glob(os.path.join(src, "pmc_*_SIZE.csv")):  # first 40 dispatches of each PMC pass as evidence (the full files are large)
+    with open(f) as fh:
+        head = list(itertools.islice(fh, 41))
+    open(os.path.join(dst, os.path.basename(f).replace(".csv", "_first40.csv")), "w").writelines(head)
+for f in ("bench_n1.json", "bench_driver_args.json", "bench_under_rocprof.json"):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+print(json.dumps({k: {"B/env": round(v["bytes_per_env"], 1), "fetch": round(v["fetch_per_env"], 1), "write": round(v["write_per_env"], 1),
+                      "rocprof_avg_us": v["rocprof_kernel_stats"]["avg_us"] if v["rocprof_kernel_stats"] else None,
+                      "frac_moved": round(v.get("rocprof_frac_moved", 0), 3), "frac_8d": round(v.get("rocprof_frac_algorithmic", 0), 3)}
+                  for k, v in out["configs"].items()}, indent=1))
+print("copied:", sorted(copied))

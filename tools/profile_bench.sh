@@ -1,28 +1,49 @@
 #!/bin/bash
-# Profiles of the bench.py command on the GPU box (run through gpurun from the repo root):
-#   1. rocprofv3 --kernel-trace --stats            -> gpurun_out/prof/bench_kernel_stats.csv
-#   2. rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (one pass per counter, kernel trace only)
-#                                                   -> gpurun_out/prof/pmc_<COUNTER>.csv
-#   3. bench.py itself                              -> gpurun_out/prof/bench_n1.json
-# tools/pmc_traffic.py turns (2) into profiles/traffic.json; copy what should be judged into profiles/.
+# Round-2 profiles (run through gpurun from the repo root; results land in gpurun_out/prof, tools/pmc_traffic.py turns them
+# into what is committed under profiles/r02/):
+#   1. rocprofv3 --kernel-trace --stats of the bench.py command the driver runs       -> bench_kernel_stats.csv
+#   2. --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (one per counter, kernel trace only) of the same kernel at 65 536 envs
+#   3. kernel stats + PMC passes of every other configuration's step kernel: C2 (word_step_kernel), C5 (ptile_step1c_kernel),
+#      C3 at 2^20 and 2^22 envs (beyond the Infinity Cache), C3 with the reference-default options
+# Each rocprofv3 command has the program itself after `--` (python3 <script>), never a shell or env wrapper.
 set -u
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$ROOT/gpurun_out/prof"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/qg_prof && mkdir -p /tmp/qg_prof
-rocprofv3 --kernel-trace --stats -d /tmp/qg_prof/stats -o bench --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-parity --no-large-batch > "$OUT/stats_run.log" 2>&1
+BENCH_ARGS="--gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-large-batch --no-default-config"
+echo "== bench.py kernel stats" && date
+rocprofv3 --kernel-trace --stats -d /tmp/qg_prof/stats -o bench --output-format csv -- python3 "$ROOT/bench.py" $BENCH_ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats_run.log"
 cp /tmp/qg_prof/stats/*kernel_stats.csv "$OUT/bench_kernel_stats.csv" 2>/dev/null
+pmc_pass() {  # name, counter, script args...
+    local name="$1" counter="$2"; shift 2
+    rocprofv3 --pmc "$counter" --kernel-trace -d "/tmp/qg_prof/${name}_$counter" -o pmc --output-format csv -- python3 "$@" > "$OUT/pmc_${name}_$counter.log" 2>&1
+    local F
+    F=$(ls /tmp/qg_prof/${name}_$counter/*counter_collection.csv 2>/dev/null | head -1)
+    # keep the step kernels' dispatches only (the files are large): header + rows of *_step* kernels
+    if [ -n "$F" ]; then (head -1 "$F"; grep -E "step1?c?_kernel" "$F") > "$OUT/pmc_${name}_$counter.csv"; fi
+}
+stats_pass() {  # name, script args...
+    local name="$1"; shift
+    rocprofv3 --kernel-trace --stats -d "/tmp/qg_prof/${name}_stats" -o run --output-format csv -- python3 "$@" > "$OUT/${name}_under_rocprof.json" 2> "$OUT/${name}_stats.log"
+    cp /tmp/qg_prof/${name}_stats/*kernel_stats.csv "$OUT/${name}_kernel_stats.csv" 2>/dev/null
+}
 for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --kernel-trace -d /tmp/qg_prof/$C -o pmc --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-parity --no-large-batch --steps 512 --warmup 64 > "$OUT/pmc_$C.log" 2>&1
-    F=$(ls /tmp/qg_prof/$C/*counter_collection.csv 2>/dev/null | head -1)
-    # keep the step kernel's dispatches only (the file is large): header + rows of the dominant kernel
-    if [ -n "$F" ]; then (head -1 "$F"; grep "qm_step1_kernel<16, true, false>" "$F") > "$OUT/pmc_$C.csv"; fi
+    echo "== bench.py pmc $C" && date
+    pmc_pass bench $C "$ROOT/bench.py" --gpus 1 --steps 512 --warmup 64 --no-cpu-baseline --no-parity --no-large-batch --no-default-config
 done
-# 4. the same kernel at 2^20 envs (kernel duration >> launch boundary): the kernel-trace average and bench.py's own
-#    per-launch figure agree there, which is the check that the 65 536-env gap is the profiler's per-dispatch serialisation
-cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/qg_prof/big -o bench --output-format csv -- python3 "$ROOT/bench.py" --envs 1048576 --steps 512 --warmup 64 --no-cpu-baseline --no-parity > "$OUT/bench_2p20_under_rocprof.json" 2> "$OUT/bench_2p20.err"
-cp /tmp/qg_prof/big/*kernel_stats.csv "$OUT/bench_2p20_kernel_stats.csv" 2>/dev/null
-cd "$ROOT" && python3 bench.py --envs 1048576 --steps 512 --warmup 64 --no-cpu-baseline --no-parity > "$OUT/bench_2p20.json" 2>> "$OUT/bench_2p20.err"
+for CFG in "C2" "C5" "C3d" "C3 --envs 1048576" "C3 --envs 4194304"; do
+    set -- $CFG
+    NAME=$(echo "$CFG" | tr -d ' -' | sed 's/envs/_/')
+    echo "== run_config $CFG ($NAME)" && date
+    python3 "$ROOT/tools/run_config.py" --config "$@" > "$OUT/${NAME}_live.json" 2> "$OUT/${NAME}_live.err"
+    stats_pass "$NAME" "$ROOT/tools/run_config.py" --config "$@" --steps 512
+    for C in FETCH_SIZE WRITE_SIZE; do
+        pmc_pass "$NAME" $C "$ROOT/tools/run_config.py" --config "$@" --steps 256
+    done
+done
+echo "== bench.py plain" && date
+cd "$ROOT" && python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_args.json" 2> "$OUT/bench_driver_args.err"
 cd "$ROOT" && python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 ls -la "$OUT"
