@@ -645,7 +645,7 @@ struct og_env {
     og_counts metrics_values;
     float w[4];
     float reward_value;
-    int add_inverts, track_solution, inverted;
+    int add_inverts, track_solution, inverted, add_perms;
     og_vecu solution, solution_inv;
     /* Pauli */
     size_t max_rotations, pauli_diff_scale, final_pauli_layers;
@@ -700,6 +700,7 @@ og_env *og_env_new(int32_t kind, const og_config *c, const og_gate *gates, size_
     e->w[3] = c->w_n_gates;
     e->add_inverts = c->add_inverts != 0;
     e->track_solution = c->track_solution != 0;
+    e->add_perms = c->add_perms != 0;
     metrics_init(&e->metrics, e->n);
     e->metrics_values = metrics_snapshot(&e->metrics);
     e->depth = 1; /* clifford.rs:228, linear_function.rs:204, permutation.rs:78, pauli.rs:384 */
@@ -733,6 +734,17 @@ og_env *og_env_new(int32_t kind, const og_config *c, const og_gate *gates, size_
         net_new(&e->net, e->n, id, "", 0); /* pauli.rs:355-356 */
         e->has_net = 1;
         free(id);
+        if (e->add_perms) { /* pauli.rs:374-378: compute_qubit_perms only when enabled */
+            const int64_t np = og_qubit_perms(e->n, e->gates, e->n_gates, NULL, NULL);
+            if (np > 0) {
+                int64_t *qp = (int64_t *)malloc(sizeof(int64_t) * (size_t)np * (e->n ? e->n : 1));
+                int64_t *ap = (int64_t *)malloc(sizeof(int64_t) * (size_t)np * (e->n_gates ? e->n_gates : 1));
+                og_qubit_perms(e->n, e->gates, e->n_gates, qp, ap);
+                og_pauli_set_perms(e, qp, ap, (size_t)np);
+                free(qp);
+                free(ap);
+            }
+        }
         break;
     }
     }
@@ -779,6 +791,11 @@ void og_env_free(og_env *e) {
     free(e->qubit_perms);
     free(e->act_perms);
     free(e);
+}
+
+int64_t og_env_twists(const og_env *e, int64_t *obs_out, int64_t *act_out) {
+    if (!e->add_perms) return 0; /* clifford.rs:218-222, linear_function.rs:194-198, permutation.rs:67-71 */
+    return og_twists(e->kind, e->n, e->gates, e->n_gates, obs_out, act_out);
 }
 
 static int env_solved(const og_env *e) {

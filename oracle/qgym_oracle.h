@@ -56,7 +56,7 @@ typedef struct {
     /* metrics.rs:150-166 */
     float w_n_cnots, w_n_layers_cnots, w_n_layers, w_n_gates;
     int32_t add_inverts;
-    int32_t add_perms; /* twists are host-side data; the oracle only needs it for PauliEnv perms */
+    int32_t add_perms; /* twists (symmetry.rs) for Env::twists; PauliEnv: its internal qubit / action permutations */
     int32_t track_solution;
     /* PauliEnv only (pauli.rs:340-409) */
     int32_t max_rotations;
@@ -100,6 +100,15 @@ size_t og_env_observe(og_env *e, int64_t *out, size_t cap, size_t perm_idx);
 int og_env_track_solution(const og_env *e);
 size_t og_env_solution(const og_env *e, uint64_t *out, size_t cap);
 
+/* twists(): (obs_perms, act_perms) (clifford.rs:370-372; empty when add_perms is off, clifford.rs:218-222; always empty for
+ * PauliEnv, pauli.rs:675-679).  Returns the number of twists; obs_out[n][prod(obs_shape)], act_out[n][num_actions] when non-NULL. */
+int64_t og_env_twists(const og_env *e, int64_t *obs_out, int64_t *act_out);
+/* The constructor-time computations behind it (rust/src/envs/symmetry.rs, restated in qgym_oracle_symmetry.c):
+ * compute_twists_square / compute_twists_clifford (symmetry.rs:297-303) by env kind ... */
+int64_t og_twists(int32_t env_kind, size_t num_qubits, const og_gate *gates, size_t n_gates, int64_t *obs_out, int64_t *act_out);
+/* ... and compute_qubit_perms (symmetry.rs:307-361): qubit_out[n][num_qubits], act_out[n][n_gates] */
+int64_t og_qubit_perms(size_t num_qubits, const og_gate *gates, size_t n_gates, int64_t *qubit_out, int64_t *act_out);
+
 /* --- white-box accessors used by the parity tests --- */
 size_t og_env_depth(const og_env *e);
 int og_env_inverted(const og_env *e);
@@ -117,7 +126,7 @@ int og_pauli_reset_from(og_env *e, const uint8_t *tableau, const char *labels, s
 /* The whole of PauliEnv::reset (pauli.rs:554-586) including the random target generator
  * (pauli.rs:54-271), every draw taken from the counter RNG stream of (seed, env_index). */
 int og_pauli_reset_seeded(og_env *e, uint64_t seed, uint64_t env_index);
-/* Install qubit/action permutations (symmetry.rs:307-361 output) for add_perms runs. */
+/* Replace the qubit/action permutations the constructor computed (pauli.rs:374-378) by explicit ones. */
 int og_pauli_set_perms(og_env *e, const int64_t *qubit_perms, const int64_t *act_perms, size_t n_perms);
 /* Active rotations in DAG node order (pauli_network.rs:176-181); returns count. */
 size_t og_pauli_active_rotations(const og_env *e, int64_t *out, size_t cap);

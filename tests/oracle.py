@@ -52,12 +52,11 @@ class OGConfig(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc if the .so is missing or stale."""
-    src = os.path.join(ORACLE_DIR, "qgym_oracle.c")
-    hdr = os.path.join(ORACLE_DIR, "qgym_oracle.h")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("qgym_oracle.c", "qgym_oracle_symmetry.c", "qgym_oracle.h", "Makefile")]
     stale = (
         force
         or not os.path.exists(_LIB_PATH)
-        or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))
+        or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
     )
     if stale:
         subprocess.run(["make", "-C", ORACLE_DIR, _LIB_NAME], check=True, capture_output=True)
@@ -118,6 +117,12 @@ def lib():
     L.og_vec_new.restype = vp
     L.og_vec_new.argtypes = [vp, sz]
     L.og_vec_free.argtypes = [vp]
+    L.og_env_twists.restype = C.c_int64
+    L.og_env_twists.argtypes = [vp, i64p, i64p]
+    L.og_twists.restype = C.c_int64
+    L.og_twists.argtypes = [C.c_int32, sz, C.POINTER(OGGate), sz, i64p, i64p]
+    L.og_qubit_perms.restype = C.c_int64
+    L.og_qubit_perms.argtypes = [sz, C.POINTER(OGGate), sz, i64p, i64p]
     L.og_vec_env.restype = vp
     L.og_vec_env.argtypes = [vp, sz]
     L.og_vec_set_state.argtypes = [vp, i64p, sz]
@@ -257,6 +262,17 @@ class OracleEnv:
         return [int(x) for x in buf[:n]]
 
     # --- white box ---
+    def twists(self) -> Tuple[List[List[int]], List[List[int]]]:
+        """Env::twists (clifford.rs:370-372): (obs_perms, act_perms)."""
+        n = int(lib().og_env_twists(self._h, None, None))
+        if n == 0:
+            return [], []
+        r, c = self.obs_shape()
+        ob = np.zeros((n, r * c), dtype=np.int64)
+        ab = np.zeros((n, max(self.num_actions(), 1)), dtype=np.int64)
+        lib().og_env_twists(self._h, _ptr(ob, C.c_int64), _ptr(ab, C.c_int64))
+        return ob.tolist(), ab[:, : self.num_actions()].tolist()
+
     def depth(self) -> int:
         return lib().og_env_depth(self._h)
 
@@ -372,3 +388,13 @@ class OracleVec:
         if lib().og_vec_get_state(self._h, _ptr(out, C.c_int64), per_env) != 0:
             raise OracleError(lib().og_last_error().decode())
         return out
+
+
+def qubit_perms(num_qubits: int, gateset) -> Tuple[List[List[int]], List[List[int]]]:
+    """compute_qubit_perms (symmetry.rs:307-361): (qubit_perms, act_perms)."""
+    gates = make_gates(gateset)
+    n = int(lib().og_qubit_perms(num_qubits, gates, len(gateset), None, None))
+    qp = np.zeros((max(n, 1), max(num_qubits, 1)), dtype=np.int64)
+    ap = np.zeros((max(n, 1), max(len(gateset), 1)), dtype=np.int64)
+    lib().og_qubit_perms(num_qubits, gates, len(gateset), _ptr(qp, C.c_int64), _ptr(ap, C.c_int64))
+    return qp[:n, :num_qubits].tolist(), ap[:n, : len(gateset)].tolist()

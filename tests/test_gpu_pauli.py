@@ -206,26 +206,13 @@ def test_pauli_add_perms_observe_and_action_unpermute():
     gateset = line_gateset("pauli", n)
     A = len(gateset)
     pairs = [g[1] for g in gateset if g[0] == "CX"]
-    # automorphisms of the 4-line, sorted: identity, reversal (symmetry.rs:115-176)
-    qperms = [list(range(n)), list(range(n - 1, -1, -1))]
-    index = {}
-    for i, (name, qs) in enumerate(gateset):
-        index[(name, tuple(sorted(qs)) if name == "SWAP" else tuple(qs))] = i  # later wins (symmetry.rs:217-223)
-    aperms = []
-    for p in qperms:
-        row = []
-        for name, qs in gateset:
-            m = tuple(p[q] for q in qs)
-            row.append(index[(name, tuple(sorted(m)) if name == "SWAP" else m)])
-        aperms.append(row)
     cfg = dict(add_perms=True, track_solution=True, max_rotations=4, max_depth=64)
     rng = np.random.default_rng(21)
     gv = VecEnv("pauli", n, gateset, batch, **cfg)
     assert gv.pauli_num_perms() == 2
     envs = [OracleEnv("pauli", n, gateset, **{k: int(v) for k, v in cfg.items()}) for _ in range(batch)]
     tabs, labs = [], []
-    for o in envs:
-        o.pauli_set_perms(qperms, aperms)
+    for o in envs:  # each oracle env computes its own permutations (pauli.rs:374-378; oracle/qgym_oracle_symmetry.c)
         t = random_tableau(rng, n, 10, pairs)
         l = random_labels(rng, n, int(rng.integers(0, 5)), 3)
         o.pauli_reset_from(t, l)
