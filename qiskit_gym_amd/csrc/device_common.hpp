@@ -115,10 +115,29 @@ __device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds,
 template <typename W, int R>
 constexpr size_t scramble_coop_lds_bytes(int waves) { return (size_t)waves * (QG_WAVE / QG_COOP_LANES) * (R * sizeof(W) + 64 * sizeof(uint32_t)); }
 
-// Solution-log word of an action (clifford.rs:334-340 pushes the action verbatim, valid or not):
-// the log is 32-bit, so anything a `usize` action could hold beyond 2^32 - 2 -- and a negative
-// int64, which `as usize` turns into 2^64 - 1 -- saturates to 0xFFFFFFFF (read back as UINT64_MAX).
+// Solution log (StepArgs::sol): entry `slot` of env e lives at sol[slot * B + e] -- step-major, so the one entry every env appends
+// per step is a coalesced store (the env-major form costs a 64-byte line per 4-byte entry: +7.5 us per step at 262 144 envs).
+__device__ inline uint32_t &sol_at(const StepArgs &a, uint64_t env, uint32_t slot) { return a.sol[(uint64_t)slot * a.B + env]; }
+// a window of one env's log, indexable like an array (PauliEnv logs several entries per step)
+struct SolLog {
+    uint32_t *p;
+    uint64_t stride;
+    __device__ uint32_t &operator[](uint32_t i) const { return p[(uint64_t)i * stride]; }
+    __device__ explicit operator bool() const { return p != nullptr; }
+};
+
+// Solution-log word of an action (clifford.rs:334-340 pushes the action verbatim, valid or not).
+// PauliEnv: 32 bits (bit 31 is the reference's own ROTATION_MARKER, pauli.rs:698-716), so anything a `usize` action could hold beyond
+// 2^32 - 2 -- and a negative int64, which `as usize` turns into 2^64 - 1 -- saturates to 0xFFFFFFFF (read back as UINT64_MAX).
 __device__ inline uint32_t sol_word(int64_t act) { return (act < 0 || act > 0xFFFFFFFEll) ? 0xFFFFFFFFu : (uint32_t)act; }
+// Clifford / LinearFunction / Permutation: entries are kept in the order they were pushed, slot = solution.len() + solution_inv.len(), with
+// bit 31 = "pushed to solution_inv" (clifford.rs:335-339); envs that were reset together then append to the SAME slot, which makes the
+// store coalesced whatever their coin histories were (separate front / back lists drift apart per env: one 128-byte line per 4-byte
+// entry, +4.4 us per step at 262 144 envs).  The action keeps 31 bits: beyond 2^31 - 2 it saturates to 0x7FFFFFFF (read back as UINT64_MAX).
+__device__ inline uint32_t sol_word_framed(int64_t act, bool inverted_frame) {
+    const uint32_t w = (act < 0 || act > 0x7FFFFFFEll) ? 0x7FFFFFFFu : (uint32_t)act;
+    return w | ((uint32_t)inverted_frame << 31);
+}
 
 // Dense {0,1} elements from packed bits: one 16-byte chunk = 16 / ES elements of ES bytes each.
 // `one`: the bit pattern of 1 in the output dtype (int8 1, bf16 0x3F80, f16 0x3C00, f32 0x3F800000)

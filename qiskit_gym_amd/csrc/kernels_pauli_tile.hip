@@ -330,7 +330,7 @@ __device__ inline uint32_t pt_evolve(PTState<NQ, RM> &s, uint32_t kind, uint32_t
 
 // clean_and_return_with_phases (pauli_network.rs:139-165).  `log`: solution-log sink or null.
 template <int NQ, int RM>
-__device__ inline void pt_clean(PTState<NQ, RM> &s, uint32_t &n_removed, uint32_t &fault, uint32_t *log, uint64_t (&rem_pos)[(RM + 7) / 8]) {
+__device__ inline void pt_clean(PTState<NQ, RM> &s, uint32_t &n_removed, uint32_t &fault, SolLog log, uint64_t (&rem_pos)[(RM + 7) / 8]) {
     uint32_t trivial = 0, zero_w = 0;  // weights do not change while cleaning (:79-93)
 #pragma unroll
     for (int k = 0; k < RM; ++k) {
@@ -451,9 +451,9 @@ __global__ __launch_bounds__(256) void ptile_step_kernel(PTArgs pa) {
         uint64_t rem_pos[(RM + 7) / 8];
 #pragma unroll
         for (int i = 0; i < (RM + 7) / 8; ++i) rem_pos[i] = 0;
-        uint32_t *log = nullptr;
+        SolLog log{nullptr, 0};
         if (FEAT && (a.flags & F_TRACK) && in_range && (uint32_t)sol_n + 1u + (uint32_t)s.count <= a.sol_cap)
-            log = a.sol + env * a.sol_cap + (uint32_t)sol_n + 1u;  // slot sol_n is the gate itself
+            log = SolLog{&sol_at(a, env, (uint32_t)sol_n + 1u), a.B};  // slot sol_n is the gate itself
 
         if (in_range) {
             const uint32_t alive_at_gate = s.alive;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void ptile_step_kernel(PTArgs pa) {
 
         if (FEAT && (a.flags & F_TRACK) && in_range) {  // pauli.rs:612-626
             if (log) {
-                a.sol[env * a.sol_cap + (uint32_t)sol_n] = sol_word(act);
+                sol_at(a, env, (uint32_t)sol_n) = sol_word(act);
                 // phase_mult is read after the whole gate has been applied (pauli.rs:618)
 #pragma unroll
                 for (int k = 0; k < RM; ++k) {
@@ -578,7 +578,7 @@ __device__ inline void pt_slices_evolve(PTState<NQ, RM> &s, PTSlices<RM> &v, uin
 // `outside(k, rx, rz)`: rotation k's masks with bits qa / qb cleared (only the solution log asks)
 template <int NQ, int RM, typename Outside>
 __device__ inline void pt_slices_clean(PTState<NQ, RM> &s, const PTSlices<RM> &v, uint32_t qa, uint32_t qb, uint32_t &n_removed, uint32_t &fault,
-                                       uint32_t *log, uint64_t (&rem_pos)[(RM + 7) / 8], Outside outside) {
+                                       SolLog log, uint64_t (&rem_pos)[(RM + 7) / 8], Outside outside) {
     const uint32_t sa = v.xa | v.za, sb = v.xb | v.zb;  // weights do not change while cleaning (:79-93)
     const uint32_t trivial = (v.b0 & ~(sa & sb)) | (v.b1 & ~(sa | sb)), zero_w = v.b0 & ~(sa | sb);
     for (;;) {
@@ -674,9 +674,9 @@ __global__ __launch_bounds__(256) void ptile_step1_kernel(PTArgs pa) {
     uint64_t rem_pos[(RM + 7) / 8];
 #pragma unroll
     for (int i = 0; i < (RM + 7) / 8; ++i) rem_pos[i] = 0;
-    uint32_t *log = nullptr;
+    SolLog log{nullptr, 0};
     if (FEAT && (a.flags & F_TRACK) && in_range && (uint32_t)sol_n + 1u + (uint32_t)s.count <= a.sol_cap)
-        log = a.sol + env * a.sol_cap + (uint32_t)sol_n + 1u;  // slot sol_n is the gate itself
+        log = SolLog{&sol_at(a, env, (uint32_t)sol_n + 1u), a.B};  // slot sol_n is the gate itself
 
     if (in_range) {
         uint64_t xa, za, xb, zb, n[4];
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void ptile_step1_kernel(PTArgs pa) {
 
     if (FEAT && (a.flags & F_TRACK) && in_range) {  // pauli.rs:612-626
         if (log) {
-            a.sol[env * a.sol_cap + (uint32_t)sol_n] = sol_word(act);
+            sol_at(a, env, (uint32_t)sol_n) = sol_word(act);
 #pragma unroll
             for (int k = 0; k < RM; ++k) {  // phase_mult is read after the whole gate has been applied (pauli.rs:618)
                 const uint32_t pos = (uint32_t)(rem_pos[k / 8] >> (8 * (k % 8))) & 0xFFu;
@@ -819,9 +819,9 @@ __global__ __launch_bounds__(256) void ptile_step1c_kernel(PTArgs pa) {
     uint64_t rem_pos[(RM + 7) / 8];
 #pragma unroll
     for (int i = 0; i < (RM + 7) / 8; ++i) rem_pos[i] = 0;
-    uint32_t *log = nullptr;
+    SolLog log{nullptr, 0};
     if (FEAT && (a.flags & F_TRACK) && in_range && (uint32_t)sol_n + 1u + (uint32_t)s.count <= a.sol_cap)
-        log = a.sol + env * a.sol_cap + (uint32_t)sol_n + 1u;  // slot sol_n is the gate itself
+        log = SolLog{&sol_at(a, env, (uint32_t)sol_n + 1u), a.B};  // slot sol_n is the gate itself
 
     // rotation k's masks outside {qa, qb}, from the transposed bytes (solution log only: a removal is rare)
     auto outside = [&](uint32_t k, uint32_t &ox, uint32_t &oz) {
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void ptile_step1c_kernel(PTArgs pa) {
 
     if (FEAT && (a.flags & F_TRACK) && in_range) {  // pauli.rs:612-626
         if (log) {
-            a.sol[env * a.sol_cap + (uint32_t)sol_n] = sol_word(act);
+            sol_at(a, env, (uint32_t)sol_n) = sol_word(act);
 #pragma unroll
             for (int k = 0; k < RM; ++k) {  // phase_mult is read after the whole gate has been applied (pauli.rs:618)
                 const uint32_t pos = (uint32_t)(rem_pos[k / 8] >> (8 * (k % 8))) & 0xFFu;
@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(64) void ptile_fused1c_kernel(PTArgs pa) {
                     const uint32_t kind = mo & 7u;
                     pt_slices_evolve<NQ, RM>(s, v, kind, (mo & 8u) != 0);
                     if (kind == M_CNOT)
-                        pt_slices_clean<NQ, RM>(s, v, qa, qb, n_removed, fault, nullptr, rem_pos, [](uint32_t, uint32_t &ox, uint32_t &oz) { ox = oz = 0; });
+                        pt_slices_clean<NQ, RM>(s, v, qa, qb, n_removed, fault, SolLog{nullptr, 0}, rem_pos, [](uint32_t, uint32_t &ox, uint32_t &oz) { ox = oz = 0; });
                 }
                 planes_add(w, v.xa | v.za);
                 planes_add(w, v.xb | v.zb);
@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(256) void ptile_init_kernel(PTArgs pa) {
     uint64_t rem_pos[(RM + 7) / 8];
 #pragma unroll
     for (int i = 0; i < (RM + 7) / 8; ++i) rem_pos[i] = 0;
-    if (pa.do_clean) pt_clean<NQ, RM>(s, n_removed, fault, nullptr, rem_pos);
+    if (pa.do_clean) pt_clean<NQ, RM>(s, n_removed, fault, SolLog{nullptr, 0}, rem_pos);
     s.bad = pt_badmask<NQ, RM>(s, a.N);
     const bool solved = pt_solved<NQ, RM>(s);
     pt_store_meta<NQ, RM>(tile, lane, s);
@@ -1351,7 +1351,7 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
     uint64_t rem_pos[(RM + 7) / 8];
 #pragma unroll
     for (int i = 0; i < (RM + 7) / 8; ++i) rem_pos[i] = 0;
-    pt_clean<NQ, RM>(s, n_removed, fault, nullptr, rem_pos);
+    pt_clean<NQ, RM>(s, n_removed, fault, SolLog{nullptr, 0}, rem_pos);
     const bool solved = pt_solved<NQ, RM>(s);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) PTLayout<NQ, RM>::store_qubit(tile, lane, q, s.X[q], s.Z[q]);

@@ -406,10 +406,12 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
 
         dirty |= qm_apply<NXP, HAS_Z>(s, g.ops);  // apply_gate_to_state (clifford.rs:331)
 
-        if (FEAT && (a.flags & F_TRACK)) {  // clifford.rs:334-340: the inverse-frame list grows from the back
+        if (FEAT && (a.flags & F_TRACK)) {  // clifford.rs:334-340: entries in push order, bit 31 = pushed to solution_inv
             if ((uint32_t)(sol_n + sol_b) < a.sol_cap) {
-                if (INV && (iflags & QM_FLAG_INVERTED)) a.sol[env * a.sol_cap + a.sol_cap - 1 - (uint32_t)sol_b++] = sol_word(act);
-                else a.sol[env * a.sol_cap + (uint32_t)sol_n++] = sol_word(act);
+                const bool inv_frame = INV && (iflags & QM_FLAG_INVERTED);
+                sol_at(a, env, (uint32_t)(sol_n + sol_b)) = sol_word_framed(act, inv_frame);
+                if (inv_frame) ++sol_b;
+                else ++sol_n;
             } else {
                 fault |= 8u;
             }
@@ -462,6 +464,193 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
     if (INV) a.inverted[env] = (uint8_t)iflags;
     if ((FEAT || INV) && fault) atomicOr(&a.error[env], fault);
     if (a.bad) a.bad[env] = qm_badmask<NXP, HAS_Z>(s, a.N);  // the one-step kernel may run next
+}
+
+// ------------------------------------------------------------------------------------------
+// The reference-default env.step() (add_inverts = true, clifford.rs:262-270,334-340): TWO lanes per env.
+//
+// Why: this step is instruction-bound, not memory-bound (apply the gate, and on half of the lanes -- the coin is per env --
+// a 32x32 bit transpose).  At 65 536 envs a thread-per-env kernel is ONE wave per SIMD, and one wave alone issues a
+// vector instruction every 4 cycles where two waves issue one every 2 (MI355X_MICROARCH.md, cycle constants): splitting an env
+// over a lane pair halves the instructions per lane AND doubles the issue rate.  Lane h of the pair owns qubits 8h .. 8h+7: the
+// rows {X[q], Z[q]} = groups 4h .. 4h+3 of the tile, 16 row words.
+//
+// The inverse of a symplectic M is Omega M^T Omega (see above).  Index rows and columns by v = 16 t + q (t = 0: X, 1: Z):
+// inv[v][v'] = M[v' ^ 16][v ^ 16], i.e. inv[v] = rot16(T[v ^ 16]) with T the plain 32x32 transpose.  The transpose is five
+// butterfly stages, one per index bit, in any order: bit 3 of v is the lane (stage 8 = one DPP exchange with the partner lane +
+// one v_perm_b32 per word), bits 0-2 and bit 4 pair words of the same lane; stage 16 is fused with the rot16 and the v ^ 16
+// renaming into one v_perm_b32 per word.  ~150 instructions per lane instead of ~600 per env.
+// States that are not known to be symplectic (set_state of an arbitrary matrix) keep the thread-per-env Gauss-Jordan variant.
+// ------------------------------------------------------------------------------------------
+__device__ inline uint32_t qm_pair_swap(uint32_t v) {  // the partner lane's value (lanes 2e, 2e+1): DPP quad_perm [1, 0, 3, 2]
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+}
+
+template <int NXP, bool FEAT>
+__global__ __launch_bounds__(256) void qm_inv2_kernel(StepArgs a) {
+    constexpr int G = NXP / 2;  // 16-byte groups per env (two qubits each)
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t env = tid >> 1;
+    const uint32_t h = (uint32_t)tid & 1u;
+    QG_PREFETCH_STEP_ARGS(a);
+    if (env >= a.B) return;  // whole lane pairs leave together
+    const uint32_t N = a.N;
+    uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(G * 64) + (env & 63u);
+    // every load that does not depend on another one is issued here, the rows first (the longest transfers), so that the whole
+    // kernel pays two memory round trips: this batch, and the gate entry behind the action
+    uint4 grp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        grp[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (k < G && (h == 0 || k + 4 < G)) grp[k] = tile[(uint32_t)(4 * h + k) * 64u];
+    }
+    int32_t depth = a.depth[env];
+    uint32_t iflags = a.inverted[env];
+    uint32_t coin = a.coins ? a.coins[env] : 0u;
+    int32_t sol_n = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2] : 0;
+    int32_t sol_b = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2 + 1] : 0;
+    const int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
+    const bool in_range = act >= 0 && act < (int64_t)a.num_actions;  // gateset.get(action) (clifford.rs:324)
+    GateEntry g = a.gates[in_range ? act : 0];  // unconditional (clamped) load: nothing else waits behind a branch
+    if (!in_range) g = GateEntry{QM_IDENTITY << 10, 0.0f};
+    if (!a.coins) coin = (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, a.env_base + env, step_clock(a)) >> 63);  // runs under the loads
+    // this lane's 8 qubits: xs[j] = X row of qubit 8h + j, zs[j] = its Z row (stored words: bit c = logical column c)
+    uint32_t xs[8], zs[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        xs[2 * k] = grp[k].x; zs[2 * k] = grp[k].y; xs[2 * k + 1] = grp[k].z; zs[2 * k + 1] = grp[k].w;
+    }
+    uint32_t fault = 0;
+    float penalty = g.penalty;
+    if (FEAT && (a.flags & F_LAYERS) && in_range && h == 0) penalty = layers_penalty(a.layers + env * (2 * N + 2), N, a.descs[act], a.w);
+
+    // ---- apply_gate_to_state (clifford.rs:331): the 4x4 GF(2) map on {X[q0], Z[q0], X[q1], Z[q1]} --------------------------
+    uint32_t dirty = 0;  // this lane's groups that changed (bit k: group 4h + k)
+    {
+        const uint32_t q0 = g.ops & 31u, q1 = (g.ops >> 5) & 31u, m = (g.ops >> 10) & 0xFFFFu;
+        const bool own0 = (q0 >> 3) == h, own1 = (q1 >> 3) == h;
+        uint32_t x0 = own0 ? tree_select<8>(xs, q0 & 7u) : 0u, z0 = own0 ? tree_select<8>(zs, q0 & 7u) : 0u;
+        uint32_t x1 = own1 ? tree_select<8>(xs, q1 & 7u) : 0u, z1 = own1 ? tree_select<8>(zs, q1 & 7u) : 0u;
+        x0 |= qm_pair_swap(x0); z0 |= qm_pair_swap(z0);  // the lane that does not own the qubit contributes zero
+        x1 |= qm_pair_swap(x1); z1 |= qm_pair_swap(z1);
+        auto mix = [&](uint32_t k) -> uint32_t {  // out_k = xor_i M[k][i] * in_i
+            const uint32_t b = m >> (4 * k);
+            return ((0u - (b & 1u)) & x0) ^ ((0u - ((b >> 1) & 1u)) & z0) ^ ((0u - ((b >> 2) & 1u)) & x1) ^ ((0u - ((b >> 3) & 1u)) & z1);
+        };
+        const uint32_t nx0 = mix(0), nz0 = mix(1), nx1 = mix(2), nz1 = mix(3);
+        if (m != QM_IDENTITY) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {  // q1's rows first, then q0's (q0's value wins when q0 == q1, as in qm_apply)
+                const bool h1 = own1 && (q1 & 7u) == (uint32_t)j, h0 = own0 && (q0 & 7u) == (uint32_t)j;
+                uint32_t vx = xs[j], vz = zs[j];
+                vx = h1 ? nx1 : vx; vz = h1 ? nz1 : vz;
+                vx = h0 ? nx0 : vx; vz = h0 ? nz0 : vz;
+                xs[j] = vx; zs[j] = vz;
+            }
+            if (own0) dirty |= 1u << ((q0 & 7u) >> 1);
+            if (own1) dirty |= 1u << ((q1 & 7u) >> 1);
+        }
+    }
+
+    if (FEAT && (a.flags & F_TRACK) && h == 0) {  // clifford.rs:334-340: entries in push order, bit 31 = pushed to solution_inv
+        if ((uint32_t)(sol_n + sol_b) < a.sol_cap) {
+            const bool inv_frame = iflags & QM_FLAG_INVERTED;
+            sol_at(a, env, (uint32_t)(sol_n + sol_b)) = sol_word_framed(act, inv_frame);
+            if (inv_frame) ++sol_b;
+            else ++sol_n;
+        } else {
+            fault |= 8u;
+        }
+    }
+    depth = depth > 0 ? depth - 1 : 0;  // clifford.rs:342
+
+    // ---- maybe_random_invert (clifford.rs:262-270) ----------------------------------------------------------------------------
+    if (coin & 1u) {  // both lanes of a pair take the same branch
+        if (iflags & QM_FLAG_SYMPLECTIC) {
+            uint32_t w[16];  // local index i = 8 t + j  <->  v = 16 t + 8 h + j
+            const uint32_t xm = N >= 16 ? 0xFFFFu : ((1u << N) - 1u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                w[j] = xs[j];
+                w[8 + j] = zs[j];
+            }
+            if (N < 16) {  // logical Z columns N .. 2N-1 move to bit positions 16 .. 16+N-1
+#pragma unroll
+                for (int i = 0; i < 16; ++i) w[i] = (w[i] & xm) | (((w[i] >> N) & xm) << 16);
+            }
+            // stages 4, 2, 1: word pairs (i, i + d) of this lane
+#pragma unroll
+            for (int st = 0; st < 3; ++st) {
+                const int d = 4 >> st;
+                const uint32_t mlo = st == 0 ? 0x0F0F0F0Fu : st == 1 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if ((i & d) == 0) {
+                        const uint32_t lo = w[i], hi = w[i + d];
+                        w[i] = (lo & mlo) | ((hi & mlo) << d);
+                        w[i + d] = ((lo >> d) & mlo) | (hi & ~mlo);
+                    }
+                }
+            }
+            // stage 8: the partner lane holds the other word of every pair; byte 1 / 3 of the low word <-> byte 0 / 2 of the high word
+            const uint32_t sel8 = h ? 0x03070105u : 0x06020400u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) w[i] = __builtin_amdgcn_perm(qm_pair_swap(w[i]), w[i], sel8);
+            // stage 16 + Omega: inv[v] = rot16(T[v ^ 16])
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t lo = w[j], hi = w[8 + j];
+                w[j] = __builtin_amdgcn_perm(hi, lo, 0x03020706u);      // {hi.hi16, lo.hi16}
+                w[8 + j] = __builtin_amdgcn_perm(hi, lo, 0x01000504u);  // {hi.lo16, lo.lo16}
+            }
+            if (N < 16) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) w[i] = (w[i] & xm) | (((w[i] >> 16) & xm) << N);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xs[j] = w[j];
+                zs[j] = w[8 + j];
+            }
+            iflags ^= QM_FLAG_INVERTED;
+            dirty = 0xFu;
+        } else {
+            fault |= QG_FAULT_BAD_STATE;  // unreachable: the host launches the Gauss-Jordan variant whenever such an env may exist
+        }
+    }
+
+    // ---- solved (clifford.rs:344), reward (:345-346) ----------------------------------------------------------------------------
+    uint32_t diff = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t q = 8u * h + (uint32_t)j;
+        const bool real = q < N;
+        diff |= xs[j] ^ (real ? 1u << q : 0u);
+        diff |= zs[j] ^ (real ? (1u << N) << q : 0u);
+    }
+    diff |= qm_pair_swap(diff);
+    const bool solved = diff == 0;
+    const float achieved = solved ? 1.0f : 0.0f;
+    const float reward = achieved - penalty;
+
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (((dirty >> k) & 1u) && k < G && (h == 0 || k + 4 < G))
+            tile[(uint32_t)(4 * h + k) * 64u] = make_uint4(xs[2 * k], zs[2 * k], xs[2 * k + 1], zs[2 * k + 1]);
+    if (h == 0) {
+        if (a.rewards_seq) a.rewards_seq[env] = reward;
+        if (a.dones_seq) a.dones_seq[env] = (uint8_t)(depth == 0 || solved);
+        a.depth[env] = depth;
+        a.reward[env] = reward;
+        a.done[env] = (uint8_t)(depth == 0 || solved);  // is_final (clifford.rs:353)
+        a.success[env] = (uint8_t)solved;
+        if (FEAT && (a.flags & F_TRACK)) {
+            a.sol_len[env * 2] = sol_n;
+            a.sol_len[env * 2 + 1] = sol_b;
+        }
+        a.inverted[env] = (uint8_t)iflags;
+        if (fault) atomicOr(&a.error[env], fault);
+    }
 }
 
 // One step per launch without holding the matrix (the env.step() path without add_inverts).  A gate
@@ -546,7 +735,7 @@ __global__ __launch_bounds__(256) void qm_step1_kernel(StepArgs a) {
         }
     }
     if (FEAT && (a.flags & F_TRACK)) {  // clifford.rs:334-340
-        if ((uint32_t)sol_n < a.sol_cap) a.sol[env * a.sol_cap + (uint32_t)sol_n++] = sol_word(act);
+        if ((uint32_t)sol_n < a.sol_cap) sol_at(a, env, (uint32_t)sol_n++) = sol_word_framed(act, false);
         else fault |= 8u;
     }
     depth = depth > 0 ? depth - 1 : 0;  // clifford.rs:342
@@ -882,7 +1071,16 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
         else hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, false>), grid, block, 0, s, a);
         return hipGetLastError();
     }
-    if (a.flags & F_INVERTS) {  // the inversion variants always carry FEAT and SEQ
+    if (a.flags & F_INVERTS) {
+        if constexpr (HAS_Z && NXP <= 16) {
+            if (!(a.flags & F_GJ) && a.T == 1) {  // every env symplectic, one step per launch: two lanes per env
+                const dim3 grid2(grid_for(2 * a.B, 256));
+                if (feat) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true>), grid2, block, 0, s, a);
+                else hipLaunchKernelGGL((qm_inv2_kernel<NXP, false>), grid2, block, 0, s, a);
+                return hipGetLastError();
+            }
+        }
+        // the thread-per-env inversion variants always carry FEAT and SEQ
         if (!HAS_Z || (a.flags & F_GJ)) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true, false>), grid, block, 0, s, a);
         return hipGetLastError();

@@ -315,8 +315,10 @@ __global__ __launch_bounds__(256) void q64_step_kernel(StepArgs a) {
         dirty |= q64_apply<NS, HAS_Z>(s, g.ops);  // clifford.rs:331
         if (EXTRA && (a.flags & F_TRACK)) {  // clifford.rs:334-340
             if ((uint32_t)(sol_n + sol_b) < a.sol_cap) {
-                if (INV && (iflags & Q64_FLAG_INVERTED)) a.sol[env * a.sol_cap + a.sol_cap - 1 - (uint32_t)sol_b++] = sol_word(act);
-                else a.sol[env * a.sol_cap + (uint32_t)sol_n++] = sol_word(act);
+                const bool inv_frame = INV && (iflags & Q64_FLAG_INVERTED);
+                sol_at(a, env, (uint32_t)(sol_n + sol_b)) = sol_word_framed(act, inv_frame);
+                if (inv_frame) ++sol_b;
+                else ++sol_n;
             } else {
                 fault |= 8u;
             }
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(256) void q64_step1_kernel(StepArgs a) {
         }
     }
     if (FEAT && (a.flags & F_TRACK)) {  // clifford.rs:334-340
-        if ((uint32_t)sol_n < a.sol_cap) a.sol[env * a.sol_cap + (uint32_t)sol_n++] = sol_word(act);
+        if ((uint32_t)sol_n < a.sol_cap) sol_at(a, env, (uint32_t)sol_n++) = sol_word_framed(act, false);
         else fault |= 8u;
     }
     depth = depth > 0 ? depth - 1 : 0;  // clifford.rs:342

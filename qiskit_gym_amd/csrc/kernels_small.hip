@@ -98,8 +98,7 @@ __global__ __launch_bounds__(256) void word_step_kernel(StepArgs a) {
         if ((a.flags & F_TRACK) && (!PERM || in_range)) {
             int32_t nf = a.sol_len[env * 2], nb = a.sol_len[env * 2 + 1];
             if ((uint32_t)(nf + nb) < a.sol_cap) {
-                uint32_t pos = inverted ? a.sol_cap - 1 - (uint32_t)nb : (uint32_t)nf;
-                a.sol[env * a.sol_cap + pos] = sol_word(act);
+                sol_at(a, env, (uint32_t)(nf + nb)) = sol_word_framed(act, inverted);
                 a.sol_len[env * 2 + (inverted ? 1 : 0)] = (inverted ? nb : nf) + 1;
             } else {
                 fault |= 8u;

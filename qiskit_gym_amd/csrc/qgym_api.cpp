@@ -1005,19 +1005,31 @@ int64_t qg_vec_solution(qg_vec *v, uint64_t env, uint64_t *out, size_t cap) {
     QG_ON_DEVICE(v);
     int32_t len[2];
     std::vector<uint32_t> row(v->sol_cap);
+    // the log is step-major (entry `slot` of env e at sol[slot * B + e]): one env's entries are a strided column
     if (hipMemcpy(len, v->sol_len + env * 2, sizeof len, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(row.data(), v->sol + env * v->sol_cap, sizeof(uint32_t) * v->sol_cap, hipMemcpyDeviceToHost) != hipSuccess) {
+        hipMemcpy2D(row.data(), sizeof(uint32_t), v->sol + env, sizeof(uint32_t) * v->B, sizeof(uint32_t), v->sol_cap, hipMemcpyDeviceToHost) != hipSuccess) {
         (void)hipGetLastError();
         return set_error(QG_ERR_DEVICE, "solution copy failed");
     }
-    // solution ++ reverse(solution_inv) (clifford.rs:376-381): the inverse-frame pushes were
-    // written from the back of the row, so reading the tail forwards is the reversed list.
-    auto widen = [](uint32_t w) { return w == 0xFFFFFFFFu ? ~0ull : (uint64_t)w; };  // saturated invalid action
     size_t n = 0;
-    for (int32_t i = 0; i < len[0]; ++i, ++n)
-        if (n < cap && out) out[n] = widen(row[i]);
-    for (uint32_t i = v->sol_cap - (uint32_t)len[1]; i < v->sol_cap; ++i, ++n)
-        if (n < cap && out) out[n] = widen(row[i]);
+    if (v->layout == LAYOUT_PAULI) {  // one list (pauli.rs:685-719); 32-bit entries
+        for (int32_t i = 0; i < len[0]; ++i, ++n)
+            if (n < cap && out) out[n] = row[i] == 0xFFFFFFFFu ? ~0ull : (uint64_t)row[i];  // saturated invalid action
+        return (int64_t)n;
+    }
+    // solution ++ reverse(solution_inv) (clifford.rs:376-381).  The log holds the pushes in order, bit 31 = pushed to solution_inv.
+    auto widen = [](uint32_t w) { return (w & 0x7FFFFFFFu) == 0x7FFFFFFFu ? ~0ull : (uint64_t)(w & 0x7FFFFFFFu); };
+    const uint32_t total = (uint32_t)std::min<int64_t>((int64_t)len[0] + len[1], v->sol_cap);
+    for (uint32_t i = 0; i < total; ++i)
+        if (!(row[i] >> 31)) {
+            if (n < cap && out) out[n] = widen(row[i]);
+            ++n;
+        }
+    for (uint32_t i = total; i-- > 0;)
+        if (row[i] >> 31) {
+            if (n < cap && out) out[n] = widen(row[i]);
+            ++n;
+        }
     return (int64_t)n;
 }
 

@@ -90,7 +90,7 @@ struct StepArgs {
     uint8_t *success;
     uint8_t *inverted;
     uint32_t *error;
-    uint32_t *sol;            // [B][sol_cap] solution log (front: solution, back: solution_inv)
+    uint32_t *sol;            // [sol_cap][B] solution log, step-major (slots from the front: solution, from the back: solution_inv)
     int32_t *sol_len;         // [B][2]
     int32_t *layers;          // F_LAYERS: [B][2N + 2] last_gates, last_cxs, then (n_layers, n_layers_cnots)
     float *rewards_seq;       // [T][B] or null

@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--envs", type=int, default=None)
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--chunk", type=int, default=128)
+    ap.add_argument("--no-track", action="store_true", help="C3d: add_inverts only (no solution log)")
+    ap.add_argument("--coin", default="rand", choices=["rand", "0", "1"], help="C3d: the inversion coins (ablation: never / always invert)")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
@@ -52,8 +54,10 @@ def main():
         if c == "C3":
             env = VecEnv("clifford", 16, gs, B, difficulty=256, **plain)
         else:
-            env = VecEnv("clifford", 16, gs, B, difficulty=256, add_inverts=True, add_perms=False, track_solution=True, max_depth=args.chunk)
+            env = VecEnv("clifford", 16, gs, B, difficulty=256, add_inverts=True, add_perms=False, track_solution=not args.no_track, max_depth=args.chunk)
             coins = torch.randint(0, 2, (args.chunk, B), dtype=torch.uint8, device=dev)
+            if args.coin != "rand":
+                coins.fill_(int(args.coin))
         env.reset(0x5EED0003)
     else:
         from test_gpu_pauli import random_labels, random_tableau
