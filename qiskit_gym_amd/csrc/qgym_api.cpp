@@ -268,6 +268,7 @@ static hipError_t launch_init(const qg_vec *v, const InitArgs &a, hipStream_t s)
     case LAYOUT_ROWS64: return rows_init(a, true, s);
     case LAYOUT_LF8: return lf8_init(a, s);
     case LAYOUT_PERM: return perm_init(a, s);
+    case LAYOUT_PERMB: return permb_init(a, v->nxp, v->d_descs, s);
     case LAYOUT_TILE: return qm_init(a, v->nxp, v->has_z, s);
     case LAYOUT_TILE64: return q64_init(a, v->nxp, v->has_z, s);
     default: return hipErrorInvalidValue;
@@ -315,6 +316,7 @@ static hipError_t launch_step(const qg_vec *v, const StepArgs &a, hipStream_t s)
     case LAYOUT_ROWS64: return rows_step(a, true, s);
     case LAYOUT_LF8: return lf8_step(a, a.T > 1, s);
     case LAYOUT_PERM: return perm_step(a, a.T > 1, s);
+    case LAYOUT_PERMB: return permb_step(a, v->nxp, s);
     case LAYOUT_PAULI: return pauli_step(v, a, s);
     case LAYOUT_TILE: return qm_step(a, v->nxp, v->has_z, s);
     case LAYOUT_TILE64: return q64_step(a, v->nxp, v->has_z, s);
@@ -363,10 +365,17 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
 
     switch (cfg->env_kind) {
     case QG_PERMUTATION:
-        if (N > 16) return set_error(QG_ERR_UNSUPPORTED, "PermutationEnv: N <= 16 supported (nibble-packed), got %u", N);
-        v->layout = LAYOUT_PERM;
+        if (N > 256) return set_error(QG_ERR_UNSUPPORTED, "PermutationEnv: N <= 256 supported (one byte per entry), got %u", N);
         v->D = N;
-        v->stride_bytes = 8;
+        if (N <= 16) {  // one uint64 of nibbles per env
+            v->layout = LAYOUT_PERM;
+            v->stride_bytes = 8;
+        } else {  // one byte per entry, tiles of 64 envs (kernels_perm.hip)
+            v->layout = LAYOUT_PERMB;
+            v->nxp = (N + 15u) / 16u;
+            v->stride_bytes = 0;
+            v->state_bytes = ((batch + 63) / 64) * (size_t)v->nxp * 1024;
+        }
         break;
     case QG_LINEAR_FUNCTION:
         v->D = N;
@@ -470,6 +479,7 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     // TILE / TILE64 layouts without add_inverts: the one-step kernel keeps `solved` as a per-env mask
     if ((v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) && !(v->flags & F_INVERTS))
         HIP_TRY_V(hipMalloc(&p->bad, (v->layout == LAYOUT_TILE64 ? sizeof(uint64_t) : sizeof(uint32_t)) * batch));
+    if (v->layout == LAYOUT_PERMB) HIP_TRY_V(hipMalloc(&p->bad, sizeof(uint32_t) * batch));  // number of entries with state[i] != i
     if (v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_PAULI) {
         HIP_TRY_V(hipMalloc(&p->done_list, sizeof(uint32_t) * (batch + 2)));
         HIP_TRY_V(hipMemset(p->done_list + batch, 0, 2 * sizeof(uint32_t)));
@@ -553,7 +563,7 @@ int qg_vec_get_info(const qg_vec *v, qg_vec_info *o) {
     }
     o->device = v->device;
     o->batch = v->B;
-    o->packed_word_bytes = v->layout == LAYOUT_PERM ? 1 : ((v->layout == LAYOUT_ROWS64 || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_PAULI) ? 8 : 4);
+    o->packed_word_bytes = (v->layout == LAYOUT_PERM || v->layout == LAYOUT_PERMB) ? 1 : ((v->layout == LAYOUT_ROWS64 || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_PAULI) ? 8 : 4);
     o->packed_words_per_env = v->D;
     o->packed_env_stride_bytes = v->stride_bytes;
     o->state_dev = v->state;
@@ -604,10 +614,10 @@ int64_t qg_vec_get_difficulty(const qg_vec *v) { return v ? v->difficulty : -1; 
 static size_t format_elem_bytes(const qg_vec *v, int format) {
     if (format == QG_FMT_I64) return 8;
     if (format == QG_FMT_U8) return 1;
-    return v->layout == LAYOUT_PERM ? 1 : ((v->layout == LAYOUT_ROWS64 || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_PAULI) ? 8 : 4);
+    return (v->layout == LAYOUT_PERM || v->layout == LAYOUT_PERMB) ? 1 : ((v->layout == LAYOUT_ROWS64 || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_PAULI) ? 8 : 4);
 }
 static size_t format_min_elems(const qg_vec *v, int format) {
-    if (v->layout == LAYOUT_PERM) return v->N;
+    if (v->layout == LAYOUT_PERM || v->layout == LAYOUT_PERMB) return v->N;
     if (format == QG_FMT_PACKED) return v->D;
     return (size_t)v->D * v->D;
 }
@@ -659,6 +669,7 @@ static hipError_t launch_export(const qg_vec *v, const ObsArgs &a, hipStream_t s
     case LAYOUT_ROWS64: return rows_export(a, true, s);
     case LAYOUT_LF8: return lf8_export(a, s);
     case LAYOUT_PERM: return perm_export(a, s);
+    case LAYOUT_PERMB: return permb_export(a, v->nxp, s);
     case LAYOUT_PAULI: return pauli_export(v, a, s);
     case LAYOUT_TILE: return qm_export(a, v->nxp, v->has_z, s);
     case LAYOUT_TILE64: return q64_export(a, v->nxp, v->has_z, s);

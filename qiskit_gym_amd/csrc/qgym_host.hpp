@@ -8,7 +8,7 @@
 
 namespace qg {
 
-enum Layout { LAYOUT_ROWS32 = 0, LAYOUT_ROWS64 = 1, LAYOUT_LF8 = 2, LAYOUT_PERM = 3, LAYOUT_PAULI = 4, LAYOUT_TILE = 5, LAYOUT_TILE64 = 6 };
+enum Layout { LAYOUT_ROWS32 = 0, LAYOUT_ROWS64 = 1, LAYOUT_LF8 = 2, LAYOUT_PERM = 3, LAYOUT_PAULI = 4, LAYOUT_TILE = 5, LAYOUT_TILE64 = 6, LAYOUT_PERMB = 7 };
 
 struct GraphKey {
     const void *actions;
@@ -79,7 +79,7 @@ struct qg_vec {
     qg::Layout layout = qg::LAYOUT_ROWS32;
     size_t stride_bytes = 0;   // per-env stride (0 for the tiled layout)
     size_t state_bytes = 0;    // total resident state size
-    uint32_t nxp = 0;          // TILE layout: X-row slots per env (N rounded up to 4)
+    uint32_t nxp = 0;          // TILE layout: X-row slots per env (N rounded up to 4); PERMB layout: 16-byte groups per env
     bool has_z = false;        // TILE layout: Z-type rows present (CliffordEnv)
     uint32_t flags = 0;
     int64_t difficulty = 1;

@@ -16,6 +16,7 @@
 //    LinearFunctionEnv 32<N<=64 without add_inverts -- see kernels_qm64.hip.
 //  LF8 layout   (LinearFunctionEnv N<=8): one uint64 per env, byte r = row r.
 //  PERM layout  (PermutationEnv N<=16): one uint64 per env, nibble i = state[i].
+//  PERMB layout (PermutationEnv 16<N<=256): one byte per entry, tiles of 64 envs x ceil(N/16) groups of 1 KiB -- see kernels_perm.hip.
 //  PAULI layout (PauliEnv N<=32): lane q owns qubit q's tableau rows {X row q, Z row N+q} as two
 //    uint64 (16 B), 32 lanes per env; rotations are 16-byte records {x mask, z mask, phase,
 //    predecessor mask}, RMAX per env, owned by lanes 0..RMAX-1.
@@ -201,6 +202,10 @@ hipError_t lf8_export(const ObsArgs &a, hipStream_t s);
 hipError_t perm_step(const StepArgs &a, bool fused, hipStream_t s);
 hipError_t perm_init(const InitArgs &a, hipStream_t s);
 hipError_t perm_export(const ObsArgs &a, hipStream_t s);
+// PermutationEnv with more than 16 qubits: one byte per entry, `ng` 16-byte groups per env (kernels_perm.hip)
+hipError_t permb_step(const StepArgs &a, uint32_t ng, hipStream_t s);
+hipError_t permb_init(const InitArgs &a, uint32_t ng, const uint32_t *descs, hipStream_t s);
+hipError_t permb_export(const ObsArgs &a, uint32_t ng, hipStream_t s);
 
 // dense {0,1} tensor of `out_dtype` (qg_dtype) from rows packed one per word (kernels_collect.hip)
 hipError_t expand_rows(const void *words_dev, int word_bytes, uint64_t n_rows, uint32_t cols, void *out_dev, int out_dtype, hipStream_t s);

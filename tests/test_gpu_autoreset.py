@@ -10,11 +10,12 @@ from util import f32_bits, grid_gateset, line_gateset, rng_actions  # noqa: E402
 
 
 @pytest.mark.parametrize("kind,n,inverts", [("clifford", 16, False), ("clifford", 5, True), ("linear_function", 8, False),
-                                            ("linear_function", 12, True), ("permutation", 9, False)])
+                                            ("linear_function", 12, True), ("permutation", 9, False), ("permutation", 25, True)])
 def test_reset_done_only_touches_finished_episodes(kind, n, inverts):
     from qiskit_gym_amd.vec import VecEnv
 
-    gs = grid_gateset("permutation", 3, 3) if kind == "permutation" else line_gateset(kind, n)
+    side = int(round(n ** 0.5))
+    gs = grid_gateset("permutation", side, side) if kind == "permutation" else line_gateset(kind, n)
     A, B, diff = len(gs), 333, 3
     cfg = dict(add_inverts=inverts, add_perms=False, track_solution=True, difficulty=diff, depth_slope=2, max_depth=128)
     gv = VecEnv(kind, n, gs, B, **cfg)

@@ -105,8 +105,8 @@ def test_limits_fail_loudly():
         VecEnv("clifford", 33, line_gateset("clifford", 33), 4)
     with pytest.raises(QGymError, match="N <= 64"):
         VecEnv("linear_function", 65, line_gateset("linear_function", 65), 4)
-    with pytest.raises(QGymError, match="N <= 16"):
-        VecEnv("permutation", 17, [("SWAP", (0, 16))], 4)
+    with pytest.raises(QGymError, match="N <= 256"):
+        VecEnv("permutation", 257, [("SWAP", (0, 256))], 4)
     with pytest.raises(QGymError, match="rotations"):
         VecEnv("pauli", 4, line_gateset("pauli", 4), 4, max_rotations=17)
     with pytest.raises(QGymError, match="out of range"):

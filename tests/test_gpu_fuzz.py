@@ -20,7 +20,7 @@ KINDS_2Q = ["CX", "CZ", "SWAP"]
 SIZES = {
     "clifford": [1, 2, 3, 7, 8, 9, 12, 16, 17, 24, 32],
     "linear_function": [1, 2, 5, 8, 9, 13, 16, 17, 32, 33, 50, 64],
-    "permutation": [1, 2, 6, 9, 16],
+    "permutation": [1, 2, 6, 9, 16, 17, 31, 32, 33, 64, 100, 200],
 }
 
 

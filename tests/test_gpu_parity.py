@@ -56,6 +56,10 @@ CASES = [
     ("linear_function", 40, lambda: line_gateset("linear_function", 40), 65),  # uint64 rows
     ("permutation", 9, lambda: grid_gateset("permutation", 3, 3), 128),
     ("permutation", 16, lambda: grid_gateset("permutation", 4, 4), 100),
+    ("permutation", 27, lambda: grid_gateset("permutation", 3, 9), 130),   # byte-per-entry layout (more than 16 qubits)
+    ("permutation", 64, lambda: grid_gateset("permutation", 8, 8), 70),
+    ("permutation", 127, lambda: line_gateset("permutation", 127), 65),    # an Eagle-sized register
+    ("permutation", 256, lambda: line_gateset("permutation", 256), 33),
 ]
 
 
@@ -98,9 +102,9 @@ def test_step_parity_with_inverts_and_solution(kind, n, gs, batch):
         assert gv.solution(e) == ov.env(e).solution(), e
 
 
-@pytest.mark.parametrize("kind,n", [("clifford", 16), ("clifford", 4), ("linear_function", 8), ("linear_function", 12), ("permutation", 9)])
+@pytest.mark.parametrize("kind,n", [("clifford", 16), ("clifford", 4), ("linear_function", 8), ("linear_function", 12), ("permutation", 9), ("permutation", 36)])
 def test_layer_weighted_rewards(kind, n):
-    gateset = line_gateset(kind, n) if kind != "permutation" else grid_gateset("permutation", 3, 3)
+    gateset = line_gateset(kind, n) if kind != "permutation" else grid_gateset("permutation", 3 if n == 9 else 6, 3 if n == 9 else 6)
     A = len(gateset)
     w = {"n_cnots": 0.02, "n_layers_cnots": 0.3, "n_layers": 0.07, "n_gates": 0.0005}
     ov, gv = make_pair(kind, n, gateset, 200, add_inverts=False, add_perms=False, track_solution=False, metrics_weights=w)
@@ -111,7 +115,8 @@ def test_layer_weighted_rewards(kind, n):
 
 
 @pytest.mark.parametrize("kind,n,adt", [("clifford", 16, "int64"), ("clifford", 5, "int32"), ("clifford", 20, "int32"), ("clifford", 32, "int64"),
-                                        ("linear_function", 12, "int32"), ("linear_function", 40, "int64"), ("linear_function", 64, "int32")])
+                                        ("linear_function", 12, "int32"), ("linear_function", 40, "int64"), ("linear_function", 64, "int32"),
+                                        ("permutation", 12, "int32"), ("permutation", 50, "int64")])
 def test_rollout_graph_and_fused_match_single_steps(kind, n, adt):
     """qg_vec_rollout as a replayed graph of single steps and as one fused launch (rows resident in LDS) against per-step oracle
     calls: TILE and TILE64 layouts, both action dtypes, a step count that is not a multiple of the prefetch batch, and some
@@ -135,7 +140,7 @@ def test_rollout_graph_and_fused_match_single_steps(kind, n, adt):
     for t in range(T):
         r, s, f, d = ov.step(acts[t])
         rew_o[t], fin_o[t] = r, f
-    want_state = ov.get_state(4 * n * n if kind == "clifford" else n * n)
+    want_state = ov.get_state(_per_env(kind, n))
     for fused in (False, True):
         gv.difficulty = 64
         gv.reset_with(_dev(draws, torch.int32))
