@@ -103,6 +103,33 @@ __device__ inline uint64_t tree_select64(const uint64_t (&t)[n], uint32_t q) {
 }
 __device__ inline uint32_t pnib(uint64_t order, uint32_t i) { return (uint32_t)(order >> (4 * i)) & 0xFu; }
 
+// DAG node order (petgraph NodeIndex -> rotation index): up to 16 rotations as nibbles of one uint64 (the memory format of the one- and
+// two-group layouts below), up to 32 as bytes of four
+template <int RM>
+struct PTOrder {
+    uint64_t w;
+    __device__ inline uint32_t get(uint32_t i) const { return (uint32_t)(w >> (4 * i)) & 0xFu; }
+    __device__ inline void set(uint32_t i, uint32_t v) { w = (w & ~(0xFull << (4 * i))) | ((uint64_t)v << (4 * i)); }
+    __device__ inline void clear() { w = 0; }
+    __device__ inline bool operator!=(const PTOrder &o) const { return w != o.w; }
+};
+template <>
+struct PTOrder<32> {
+    uint64_t w[4];
+    __device__ inline uint32_t get(uint32_t i) const {  // i may be a per-lane value: word select, then shift
+        const uint32_t k = i >> 3;
+        const uint64_t x = k == 0 ? w[0] : k == 1 ? w[1] : k == 2 ? w[2] : w[3];
+        return (uint32_t)(x >> (8 * (i & 7u))) & 0xFFu;
+    }
+    __device__ inline void set(uint32_t i, uint32_t v) {
+        const uint32_t k = i >> 3, sh = 8 * (i & 7u);
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) w[j] = k == j ? (w[j] & ~(0xFFull << sh)) | ((uint64_t)v << sh) : w[j];
+    }
+    __device__ inline void clear() { w[0] = w[1] = w[2] = w[3] = 0; }
+    __device__ inline bool operator!=(const PTOrder &o) const { return ((w[0] ^ o.w[0]) | (w[1] ^ o.w[1]) | (w[2] ^ o.w[2]) | (w[3] ^ o.w[3])) != 0; }
+};
+
 template <int NQ, int RM>
 struct PTState {
     uint64_t X[NQ], Z[NQ];
@@ -110,7 +137,7 @@ struct PTState {
     uint32_t plo, phi;  // phase bit-planes: phase of rotation k = ((phi >> k) & 1) * 2 + ((plo >> k) & 1)
     uint32_t alive, count;
     uint32_t bad;  // bit q: rows X[q] / Z[q] differ from the identity tableau's
-    uint64_t order;
+    PTOrder<RM> order;
 };
 
 template <int NQ, int RM>
@@ -118,7 +145,8 @@ struct PTLayout {
     static constexpr bool COMPACT = NQ <= 24 && RM == 8;
     static constexpr uint32_t QB = COMPACT ? 768u : 1024u;   // bytes of one qubit group
     static constexpr uint32_t RB = COMPACT ? 512u : 1024u;   // bytes of one rotation group
-    static constexpr uint32_t TILE_BYTES = NQ * QB + RM * RB + 1024u;
+    static constexpr uint32_t META_GROUPS = RM > 16 ? 3u : 1u;  // > 16 rotations: {alive, count, bad}, then 32 order bytes in two groups
+    static constexpr uint32_t TILE_BYTES = NQ * QB + RM * RB + META_GROUPS * 1024u;
     static __device__ inline char *tile(void *state, uint64_t env) { return reinterpret_cast<char *>(state) + (env >> 6) * (uint64_t)TILE_BYTES; }
 
     static __device__ inline void load_qubit(const char *t, uint32_t lane, uint32_t q, uint64_t &X, uint64_t &Z) {
@@ -156,13 +184,38 @@ struct PTLayout {
         if constexpr (COMPACT) *reinterpret_cast<uint2 *>(t + NQ * QB + k * RB + lane * 8u) = make_uint2(x | (pred << 24), z | (ph << 24));
         else *reinterpret_cast<uint4 *>(t + NQ * QB + k * RB + lane * 16u) = make_uint4(x, z, ph, pred);
     }
-    static __device__ inline uint4 *meta(char *t, uint32_t lane) { return reinterpret_cast<uint4 *>(t + NQ * QB + RM * RB + lane * 16u); }
+    static __device__ inline uint4 *meta(char *t, uint32_t lane, uint32_t g = 0) {
+        return reinterpret_cast<uint4 *>(t + NQ * QB + RM * RB + g * 1024u + lane * 16u);
+    }
     // compact layout: the transposed rotation region (see the file header)
     static __device__ inline uint16_t *xz(char *t, uint32_t lane, uint32_t q) {
         return reinterpret_cast<uint16_t *>(t + NQ * QB + (q >> 2) * RB + lane * 8u + (q & 3u) * 2u);
     }
     static __device__ inline uint2 *rotgroup(char *t, uint32_t lane, uint32_t g) { return reinterpret_cast<uint2 *>(t + NQ * QB + g * RB + lane * 8u); }
 };
+
+// DAG bookkeeping: {alive | count << 16, bad, order as 16 nibbles} in one group, or (more than 16 rotations) {alive, count, bad, -}
+// followed by the 32 order bytes in two groups
+template <int NQ, int RM>
+__device__ inline void pt_load_meta(char *t, uint32_t lane, PTState<NQ, RM> &s) {
+    using L = PTLayout<NQ, RM>;
+    const uint4 m = *L::meta(t, lane);
+    if constexpr (RM > 16) {
+        const uint4 o0 = *L::meta(t, lane, 1), o1 = *L::meta(t, lane, 2);
+        s.alive = m.x;
+        s.count = m.y;
+        s.bad = m.z;
+        s.order.w[0] = (uint64_t)o0.x | ((uint64_t)o0.y << 32);
+        s.order.w[1] = (uint64_t)o0.z | ((uint64_t)o0.w << 32);
+        s.order.w[2] = (uint64_t)o1.x | ((uint64_t)o1.y << 32);
+        s.order.w[3] = (uint64_t)o1.z | ((uint64_t)o1.w << 32);
+    } else {
+        s.alive = m.x & 0xFFFFu;
+        s.count = m.x >> 16;
+        s.bad = m.y;
+        s.order.w = (uint64_t)m.z | ((uint64_t)m.w << 32);
+    }
+}
 
 // rotations and bookkeeping (dense kernels; the compact layout's transposed rotation bytes are turned back
 // into one (x, z) mask pair per rotation here)
@@ -204,11 +257,7 @@ __device__ inline void pt_load_rotations(const char *tile, uint32_t lane, PTStat
             s.phi |= ((ph >> 1) & 1u) << k;
         }
     }
-    const uint4 m = *L::meta(t, lane);
-    s.alive = m.x & 0xFFFFu;
-    s.count = m.x >> 16;
-    s.bad = m.y;
-    s.order = (uint64_t)m.z | ((uint64_t)m.w << 32);
+    pt_load_meta<NQ, RM>(t, lane, s);
 }
 template <int NQ, int RM>
 __device__ inline void pt_load(const char *tile, uint32_t lane, PTState<NQ, RM> &s) {
@@ -260,7 +309,14 @@ __device__ inline void pt_store_rotations(char *tile, uint32_t lane, const PTSta
 }
 template <int NQ, int RM>
 __device__ inline void pt_store_meta(char *tile, uint32_t lane, const PTState<NQ, RM> &s) {
-    *PTLayout<NQ, RM>::meta(tile, lane) = make_uint4(s.alive | (s.count << 16), s.bad, (uint32_t)s.order, (uint32_t)(s.order >> 32));
+    using L = PTLayout<NQ, RM>;
+    if constexpr (RM > 16) {
+        *L::meta(tile, lane) = make_uint4(s.alive, s.count, s.bad, 0u);
+        *L::meta(tile, lane, 1) = make_uint4((uint32_t)s.order.w[0], (uint32_t)(s.order.w[0] >> 32), (uint32_t)s.order.w[1], (uint32_t)(s.order.w[1] >> 32));
+        *L::meta(tile, lane, 2) = make_uint4((uint32_t)s.order.w[2], (uint32_t)(s.order.w[2] >> 32), (uint32_t)s.order.w[3], (uint32_t)(s.order.w[3] >> 32));
+    } else {
+        *L::meta(tile, lane) = make_uint4(s.alive | (s.count << 16), s.bad, (uint32_t)s.order.w, (uint32_t)(s.order.w >> 32));
+    }
 }
 
 // the gate's composite tableau map on {X[qa], Z[qa], X[qb], Z[qb]}: out[k] = xor of the inputs bit 4k+i of m selects
@@ -351,14 +407,14 @@ __device__ inline void pt_clean(PTState<NQ, RM> &s, uint32_t &n_removed, uint32_
         // removals are reported in DAG node order within a pass (:146-152)
         uint32_t dpos = 0;  // bit i: DAG node i is removed in this pass
 #pragma unroll
-        for (int i = 0; i < RM; ++i) dpos |= (((uint32_t)i < s.count) ? ((doomed >> pnib(s.order, i)) & 1u) : 0u) << i;
+        for (int i = 0; i < RM; ++i) dpos |= (((uint32_t)i < s.count) ? ((doomed >> s.order.get(i)) & 1u) : 0u) << i;
         if (log) {
 #pragma unroll
             for (int k = 0; k < RM; ++k) {
                 if ((doomed >> k) & 1u) {
                     uint32_t pos = 0;
 #pragma unroll
-                    for (int i = 0; i < RM; ++i) pos = (pnib(s.order, i) == (uint32_t)k && (uint32_t)i < s.count) ? (uint32_t)i : pos;
+                    for (int i = 0; i < RM; ++i) pos = (s.order.get(i) == (uint32_t)k && (uint32_t)i < s.count) ? (uint32_t)i : pos;
                     const uint32_t seq = n_removed + (uint32_t)__popc(dpos & ((1u << pos) - 1u));
                     const uint32_t sup = s.rx[k] | s.rz[k];
                     const uint32_t qb = (uint32_t)__ffs((int)sup) - 1u;  // which_qubit / which_axis (:95-137)
@@ -374,8 +430,7 @@ __device__ inline void pt_clean(PTState<NQ, RM> &s, uint32_t &n_removed, uint32_
 #pragma unroll
         for (int i = RM - 1; i >= 0; --i) {
             if ((uint32_t)i < s.count && ((dpos >> i) & 1u)) {
-                const uint64_t last = (uint64_t)pnib(s.order, s.count - 1);
-                s.order = (s.order & ~(0xFull << (4 * i))) | (last << (4 * i));
+                s.order.set((uint32_t)i, s.order.get(s.count - 1));
                 s.count -= 1;
             }
         }
@@ -425,7 +480,7 @@ __global__ __launch_bounds__(256) void ptile_step_kernel(PTArgs pa) {
     int32_t depth = a.depth[env];
     int32_t sol_n = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2] : 0;
     const uint32_t alive0 = s.alive, count0 = s.count, bad0 = s.bad;
-    const uint64_t order0 = s.order;
+    const PTOrder<RM> order0 = s.order;
     uint32_t touched_rot = 0;   // rotations whose record changed while they were alive
     uint32_t dirty_q = 0;       // qubits whose tableau rows changed
     bool solved = false;
@@ -593,14 +648,14 @@ __device__ inline void pt_slices_clean(PTState<NQ, RM> &s, const PTSlices<RM> &v
         if (!doomed) break;
         uint32_t dpos = 0;  // bit i: DAG node i is removed in this pass (removals are reported in node order, :146-152)
 #pragma unroll
-        for (int i = 0; i < RM; ++i) dpos |= (((uint32_t)i < s.count) ? ((doomed >> pnib(s.order, i)) & 1u) : 0u) << i;
+        for (int i = 0; i < RM; ++i) dpos |= (((uint32_t)i < s.count) ? ((doomed >> s.order.get(i)) & 1u) : 0u) << i;
         if (log) {
 #pragma unroll
             for (int k = 0; k < RM; ++k) {
                 if ((doomed >> k) & 1u) {
                     uint32_t pos = 0;
 #pragma unroll
-                    for (int i = 0; i < RM; ++i) pos = (pnib(s.order, i) == (uint32_t)k && (uint32_t)i < s.count) ? (uint32_t)i : pos;
+                    for (int i = 0; i < RM; ++i) pos = (s.order.get(i) == (uint32_t)k && (uint32_t)i < s.count) ? (uint32_t)i : pos;
                     const uint32_t seq = n_removed + (uint32_t)__popc(dpos & ((1u << pos) - 1u));
                     // which_qubit / which_axis (:95-137): the single support qubit is outside {qa, qb} (b1), qa or qb
                     uint32_t q, bx, bz;
@@ -625,8 +680,7 @@ __device__ inline void pt_slices_clean(PTState<NQ, RM> &s, const PTSlices<RM> &v
 #pragma unroll
         for (int i = RM - 1; i >= 0; --i) {  // retain_nodes: visit NodeIndex high -> low, swap_remove each doomed node (:160-161)
             if ((uint32_t)i < s.count && ((dpos >> i) & 1u)) {
-                const uint64_t last = (uint64_t)pnib(s.order, s.count - 1);
-                s.order = (s.order & ~(0xFull << (4 * i))) | (last << (4 * i));
+                s.order.set((uint32_t)i, s.order.get(s.count - 1));
                 s.count -= 1;
             }
         }
@@ -654,7 +708,7 @@ __global__ __launch_bounds__(256) void ptile_step1_kernel(PTArgs pa) {
     int32_t depth = a.depth[env];
     int32_t sol_n = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2] : 0;
     const uint32_t alive0 = s.alive, count0 = s.count, bad0 = s.bad;
-    const uint64_t order0 = s.order;
+    const PTOrder<RM> order0 = s.order;
     uint32_t touched_rot = 0, fault = 0;
 
     if (pa.n_perms) {  // actual_action = act_perms[current_perm_idx][action] (pauli.rs:594-599)
@@ -793,7 +847,7 @@ __global__ __launch_bounds__(256) void ptile_step1c_kernel(PTArgs pa) {
     s.alive = m0.x & 0xFFFFu;
     s.count = m0.x >> 16;
     s.bad = m0.y;
-    s.order = (uint64_t)m0.z | ((uint64_t)m0.w << 32);
+    s.order.w = (uint64_t)m0.z | ((uint64_t)m0.w << 32);
 #pragma unroll
     for (int k = 0; k < RM; ++k) s.rpred[k] = ((k < 4 ? pv.x : pv.y) >> (8 * (k & 3))) & 0xFFu;
     s.plo = pw0.x & 0xFFu;
@@ -901,7 +955,7 @@ __global__ __launch_bounds__(256) void ptile_step1c_kernel(PTArgs pa) {
     if (a.dones_seq) a.dones_seq[env] = (uint8_t)(depth == 0 || solved);
     const uint2 pw = make_uint2((s.plo & 0xFFu) | ((s.phi & 0xFFu) << 8) | (w[0] << 16) | (w[1] << 24), w[2] | (w[3] << 8) | (w[4] << 16));
     if (pw.x != pw0.x || pw.y != pw0.y) *L::rotgroup(tile, lane, 7) = pw;
-    const uint4 m1 = make_uint4(s.alive | (s.count << 16), s.bad, (uint32_t)s.order, (uint32_t)(s.order >> 32));
+    const uint4 m1 = make_uint4(s.alive | (s.count << 16), s.bad, (uint32_t)s.order.w, (uint32_t)(s.order.w >> 32));
     if (m1.x != m0.x || m1.y != m0.y || m1.z != m0.z || m1.w != m0.w) *L::meta(tile, lane) = m1;
     a.depth[env] = depth;
     a.reward[env] = reward;
@@ -943,7 +997,7 @@ __global__ __launch_bounds__(64) void ptile_fused1c_kernel(PTArgs pa) {
         s.alive = m0.x & 0xFFFFu;
         s.count = m0.x >> 16;
         s.bad = m0.y;
-        s.order = (uint64_t)m0.z | ((uint64_t)m0.w << 32);
+        s.order.w = (uint64_t)m0.z | ((uint64_t)m0.w << 32);
 #pragma unroll
         for (int k = 0; k < RM; ++k) s.rpred[k] = ((k < 4 ? pv.x : pv.y) >> (8 * (k & 3))) & 0xFFu;
         s.plo = pw0.x & 0xFFu;
@@ -1019,7 +1073,7 @@ __global__ __launch_bounds__(64) void ptile_fused1c_kernel(PTArgs pa) {
             if (a.dones_seq) a.dones_seq[(uint64_t)t * a.B + env] = (uint8_t)(depth == 0 || solved);
         }
         *L::rotgroup(tile, lane, 7) = make_uint2((s.plo & 0xFFu) | ((s.phi & 0xFFu) << 8) | (w[0] << 16) | (w[1] << 24), w[2] | (w[3] << 8) | (w[4] << 16));
-        *L::meta(tile, lane) = make_uint4(s.alive | (s.count << 16), s.bad, (uint32_t)s.order, (uint32_t)(s.order >> 32));
+        *L::meta(tile, lane) = make_uint4(s.alive | (s.count << 16), s.bad, (uint32_t)s.order.w, (uint32_t)(s.order.w >> 32));
         a.depth[env] = depth;
         a.reward[env] = reward;
         a.done[env] = (uint8_t)(depth == 0 || solved);
@@ -1088,7 +1142,7 @@ __device__ inline void ptile_obs_qubit(const PTObsArgs &pa, uint64_t env, uint32
     const uint32_t cols = a.obs_cols, lane = (uint32_t)(env & 63);
     const bool compact = pa.nq <= 24 && pa.rm == 8;  // PTLayout::COMPACT
     const uint32_t QB = compact ? 768u : 1024u, RB = compact ? 512u : 1024u;
-    const char *tile = reinterpret_cast<const char *>(a.state) + (env >> 6) * (uint64_t)(pa.nq * QB + pa.rm * RB + 1024u);
+    const char *tile = reinterpret_cast<const char *>(a.state) + (env >> 6) * (uint64_t)(pa.nq * QB + pa.rm * RB + (pa.rm > 16 ? 3072u : 1024u));
     const uint8_t *perm = nullptr;
     if (pa.n_perms && cols > D && a.format != QG_FMT_PACKED) {
         uint32_t pi;
@@ -1123,19 +1177,23 @@ __device__ inline void ptile_obs_qubit(const PTObsArgs &pa, uint64_t env, uint32
     }
     ex = ez = 0;
     if (want_extra && cols > D) {
-        const uint4 m = *reinterpret_cast<const uint4 *>(tile + pa.nq * QB + pa.rm * RB + lane * 16u);
+        const char *mt = tile + pa.nq * QB + pa.rm * RB;  // DAG bookkeeping (pt_load_meta)
+        const uint4 m = *reinterpret_cast<const uint4 *>(mt + lane * 16u);
         const uint64_t order = (uint64_t)m.z | ((uint64_t)m.w << 32);
-        const uint32_t count = m.x >> 16, shown = count < pa.max_rot ? count : pa.max_rot;
+        const uint32_t count = pa.rm > 16 ? m.y : m.x >> 16, shown = count < pa.max_rot ? count : pa.max_rot;
+        auto node = [&](uint32_t i) -> uint32_t {  // rotation held by DAG node i
+            return pa.rm > 16 ? (uint32_t) reinterpret_cast<const uint8_t *>(mt + 1024u * (1u + (i >> 4)) + lane * 16u)[i & 15u] : pnib(order, i);
+        };
         if (compact) {  // transposed rotation bytes: bit k of xs / zs = rotation k at this qubit
             const uint32_t v = *reinterpret_cast<const uint16_t *>(tile + pa.nq * QB + (sq >> 2) * RB + lane * 8u + (sq & 3u) * 2u);
             for (uint32_t i = 0; i < shown; ++i) {
-                const uint32_t k = pnib(order, i);
+                const uint32_t k = node(i);
                 ex |= ((v >> k) & 1u) << i;
                 ez |= ((v >> (8 + k)) & 1u) << i;
             }
         } else {
             for (uint32_t i = 0; i < shown; ++i) {
-                const uint4 r = *reinterpret_cast<const uint4 *>(tile + pa.nq * QB + pnib(order, i) * RB + lane * 16u);
+                const uint4 r = *reinterpret_cast<const uint4 *>(tile + pa.nq * QB + node(i) * RB + lane * 16u);
                 ex |= ((r.x >> sq) & 1u) << i;
                 ez |= ((r.y >> sq) & 1u) << i;
             }
@@ -1306,12 +1364,13 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
         const uint32_t cost = difficulty - budget, dec = cost > 1 ? cost : 1;
         remaining = remaining > dec ? remaining - dec : 0;
     }
-    s.alive = (1u << n_lab) - 1u;  // n_lab <= RM <= 16
+    s.alive = (uint32_t)((1ull << n_lab) - 1ull);  // n_lab <= RM <= 32
     s.count = n_lab;
     s.bad = 0;  // the scramble below starts from the identity and keeps `bad` current
-    s.order = 0;
+    s.order.clear();
 #pragma unroll
-    for (int k = 0; k < RM; ++k) s.order |= ((uint32_t)k < n_lab) ? ((uint64_t)k << (4 * k)) : 0ull;
+    for (int k = 0; k < RM; ++k)
+        if ((uint32_t)k < n_lab) s.order.set((uint32_t)k, (uint32_t)k);
 
     // random_clifford_tableau (pauli.rs:220-271): H / S / CX row operations on the identity
     // (row q = X[q], row N + q = Z[q]; LDS slot NQ + q holds Z[q])
@@ -1379,10 +1438,11 @@ static inline unsigned grid_for(uint64_t threads, unsigned block) { return (unsi
 
 int ptile_plan(qg_vec *v) {
     v->pt_nq = (v->N + 3u) & ~3u;
-    v->pt_rm = v->rmax <= 8 ? 8u : 16u;
+    v->pt_rm = v->rmax <= 8 ? 8u : v->rmax <= 16 ? 16u : 32u;
     v->stride_bytes = 0;
     const bool compact = v->pt_nq <= 24 && v->pt_rm == 8;  // PTLayout::COMPACT
-    v->state_bytes = ((v->B + 63) / 64) * ((size_t)v->pt_nq * (compact ? 768 : 1024) + (size_t)v->pt_rm * (compact ? 512 : 1024) + 1024);
+    v->state_bytes = ((v->B + 63) / 64) * ((size_t)v->pt_nq * (compact ? 768 : 1024) + (size_t)v->pt_rm * (compact ? 512 : 1024) +
+                                           (v->pt_rm > 16 ? 3072 : 1024));  // PTLayout::TILE_BYTES
     return QG_OK;
 }
 
@@ -1450,6 +1510,14 @@ static hipError_t pt_launch_init(const PTArgs &pa, hipStream_t s) {
     case 2816: return FN<28, 16>(pa, s);                 \
     case 3208: return FN<32, 8>(pa, s);                  \
     case 3216: return FN<32, 16>(pa, s);                 \
+    case 432: return FN<4, 32>(pa, s);                   \
+    case 832: return FN<8, 32>(pa, s);                   \
+    case 1232: return FN<12, 32>(pa, s);                 \
+    case 1632: return FN<16, 32>(pa, s);                 \
+    case 2032: return FN<20, 32>(pa, s);                 \
+    case 2432: return FN<24, 32>(pa, s);                 \
+    case 2832: return FN<28, 32>(pa, s);                 \
+    case 3232: return FN<32, 32>(pa, s);                 \
     }                                                    \
     return hipErrorInvalidValue;
 
@@ -1632,7 +1700,7 @@ int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s) 
 int ptile_upload(qg_vec *v, const HostNet &h, bool do_clean, int32_t depth_value, hipStream_t s) {
     const uint32_t N = v->N, NQ = v->pt_nq, RM = v->pt_rm;
     const bool compact = NQ <= 24 && RM == 8;  // PTLayout::COMPACT
-    const size_t QB = compact ? 768 : 1024, RB = compact ? 512 : 1024, tile_bytes = NQ * QB + RM * RB + 1024;
+    const size_t QB = compact ? 768 : 1024, RB = compact ? 512 : 1024, tile_bytes = NQ * QB + RM * RB + (RM > 16 ? 3072 : 1024);
     std::vector<uint8_t> img(v->state_bytes, 0);
     for (uint64_t e = 0; e < v->B; ++e) {
         uint8_t *tile = img.data() + (e >> 6) * tile_bytes;
@@ -1674,8 +1742,18 @@ int ptile_upload(qg_vec *v, const HostNet &h, bool do_clean, int32_t depth_value
             }
         }
         const PauliMeta &m = h.meta[e];
-        uint32_t g[4] = {m.alive | (m.count << 16), 0u /* bad: the init kernel computes it */, (uint32_t)m.order, (uint32_t)(m.order >> 32)};
-        memcpy(tile + NQ * QB + RM * RB + lane * 16, g, 16);
+        uint8_t *mt = tile + NQ * QB + RM * RB;
+        if (RM > 16) {  // {alive, count, bad (the init kernel computes it), -}, then the 32 order bytes
+            const uint32_t g[4] = {m.alive, m.count, 0u, 0u};
+            memcpy(mt + lane * 16, g, 16);
+            memcpy(mt + 1024 + lane * 16, m.order, 16);
+            memcpy(mt + 2048 + lane * 16, m.order + 16, 16);
+        } else {
+            uint64_t nib = 0;
+            for (uint32_t k = 0; k < 16; ++k) nib |= (uint64_t)(m.order[k] & 0xFu) << (4 * k);
+            const uint32_t g[4] = {m.alive | (m.count << 16), 0u /* bad: the init kernel computes it */, (uint32_t)nib, (uint32_t)(nib >> 32)};
+            memcpy(mt + lane * 16, g, 16);
+        }
     }
     HIP_TRY(hipMemcpyAsync(v->state, img.data(), v->state_bytes, hipMemcpyHostToDevice, s));
     StepArgs a;

@@ -9,14 +9,13 @@
 
 namespace qg {
 
-#define PAULI_RMAX 16u
+#define PAULI_RMAX 32u
 
-struct PauliMeta {
-    uint32_t alive;  // bit k: rotation k still in the DAG
-    uint32_t count;  // number of DAG nodes
-    uint64_t order;  // nibble i = rotation index held by DAG node i (petgraph NodeIndex order)
+struct PauliMeta {  // host-side staging record (the device layout is kernels_pauli_tile.hip's)
+    uint32_t alive;             // bit k: rotation k still in the DAG
+    uint32_t count;             // number of DAG nodes
+    uint8_t order[PAULI_RMAX];  // order[i] = rotation index held by DAG node i (petgraph NodeIndex order)
 };
-static_assert(sizeof(PauliMeta) == 16, "PauliMeta must be 16 bytes");
 
 struct PauliRot {
     uint32_t x, z;   // base_x / base_z bit q = qubit q (reference pauli/pauli.rs:41-42)

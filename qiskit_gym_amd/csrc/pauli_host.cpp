@@ -98,7 +98,7 @@ static bool anticommute(const PauliRot &a, const PauliRot &b) { return (__builti
 static void host_net_init(const qg_vec *v, HostNet &h) {
     h.tab.assign((size_t)v->B * v->N * 2, 0);
     h.rot.assign((size_t)v->B * v->rmax, PauliRot{0, 0, 0, 0});
-    h.meta.assign(v->B, PauliMeta{0, 0, 0});
+    h.meta.assign(v->B, PauliMeta{});
 }
 // PauliNetwork::new (pauli_network.rs:37-77) for env e
 static int host_net_build(const qg_vec *v, HostNet &h, uint64_t e, const uint8_t *tableau_rowmajor,
@@ -124,8 +124,8 @@ static int host_net_build(const qg_vec *v, HostNet &h, uint64_t e, const uint8_t
     PauliMeta &m = h.meta[e];
     m.alive = R >= 32 ? ~0u : ((1u << R) - 1u);
     m.count = (uint32_t)R;
-    m.order = 0;
-    for (size_t k = 0; k < R; ++k) m.order |= (uint64_t)k << (4 * k);
+    memset(m.order, 0, sizeof m.order);
+    for (size_t k = 0; k < R; ++k) m.order[k] = (uint8_t)k;
     return QG_OK;
 }
 

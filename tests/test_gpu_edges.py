@@ -67,21 +67,22 @@ def test_empty_gateset_steps_are_noops_and_reset_panics():
         gv.reset(1)
 
 
-def test_pauli_maximum_size_32_qubits_16_rotations():
+@pytest.mark.parametrize("rot", [16, 32])
+def test_pauli_maximum_size_32_qubits(rot):
     from qiskit_gym_amd.vec import VecEnv
 
     n, B = 32, 40
     gs = line_gateset("pauli", n)
     A = len(gs)
     pairs = [g[1] for g in gs if g[0] == "CX"]
-    cfg = dict(add_perms=False, track_solution=True, max_rotations=16, final_pauli_layers=16, max_depth=64)
+    cfg = dict(add_perms=False, track_solution=True, max_rotations=rot, final_pauli_layers=rot, max_depth=64)
     rng = np.random.default_rng(9)
     gv = VecEnv("pauli", n, gs, B, **cfg)
     envs = [OracleEnv("pauli", n, gs, **{k: int(v) for k, v in cfg.items()}) for _ in range(B)]
     tabs, labs = [], []
     for o in envs:
         t = random_tableau(rng, n, 40, pairs)
-        l = random_labels(rng, n, 16, 3)
+        l = random_labels(rng, n, rot, 3)
         o.pauli_reset_from(t, l)
         tabs.append(t)
         labs.append(l)
@@ -108,7 +109,7 @@ def test_limits_fail_loudly():
     with pytest.raises(QGymError, match="N <= 256"):
         VecEnv("permutation", 257, [("SWAP", (0, 256))], 4)
     with pytest.raises(QGymError, match="rotations"):
-        VecEnv("pauli", 4, line_gateset("pauli", 4), 4, max_rotations=17)
+        VecEnv("pauli", 4, line_gateset("pauli", 4), 4, max_rotations=33)
     with pytest.raises(QGymError, match="out of range"):
         VecEnv("clifford", 3, [("H", (3,))], 4)
     with pytest.raises(QGymError, match="batch"):

@@ -104,8 +104,8 @@ def test_random_pauli_networks(seed):
     n = int(rng.choice([2, 3, 5, 8, 13, 20, 24, 25, 32]))
     gs = random_gateset(rng, n, int(rng.integers(2, 36)), allow_equal=False)
     pairs = [g[1] for g in gs if len(g[1]) == 2] or [(0, 1)]
-    max_rot = int(rng.integers(1, 9))
-    final_layers = None if rng.random() < 0.5 else int(rng.integers(1, 17))
+    max_rot = int(rng.integers(1, 9)) if rng.random() < 0.7 else int(rng.integers(9, 31))  # > 16 rotations: the 32-rotation kernels
+    final_layers = None if rng.random() < 0.5 else int(rng.integers(1, 33))
     rmax = final_layers if final_layers is not None else max_rot + 2
     cfg = dict(add_perms=False, track_solution=bool(rng.integers(2)), max_rotations=max_rot, max_depth=int(rng.integers(4, 80)),
                difficulty=int(rng.integers(1, 20)), pauli_layer_reward=float(np.float32(rng.random() * 0.05)))

@@ -40,7 +40,7 @@ def random_labels(rng, n, count, max_weight=4):
     return out
 
 
-@pytest.mark.parametrize("n,batch,max_rot,final_layers", [(4, 96, 5, None), (20, 64, 5, None), (3, 130, 2, 6), (6, 50, 8, 12)])
+@pytest.mark.parametrize("n,batch,max_rot,final_layers", [(4, 96, 5, None), (20, 64, 5, None), (3, 130, 2, 6), (6, 50, 8, 12), (5, 70, 20, 28), (20, 64, 24, 30)])
 def test_pauli_step_parity(n, batch, max_rot, final_layers):
     from qiskit_gym_amd.vec import VecEnv
 
@@ -235,15 +235,15 @@ def test_pauli_add_perms_observe_and_action_unpermute():
         assert gv.solution(e) == envs[e].solution()  # the log holds the un-permuted (actual) actions
 
 
-@pytest.mark.parametrize("n,difficulty,scale", [(6, 40, 4), (20, 96, 16), (4, 3, 8)])
-def test_pauli_reset_generates_the_replayed_target(n, difficulty, scale):
+@pytest.mark.parametrize("n,difficulty,scale,max_rot", [(6, 40, 4, 5), (20, 96, 16, 5), (4, 3, 8, 5), (10, 400, 1, 26)])
+def test_pauli_reset_generates_the_replayed_target(n, difficulty, scale, max_rot):
     """qg_vec_reset(seed) on a PauliEnv batch = PauliEnv::reset with its target generator
     (reference pauli.rs:54-271, 554-586) on the documented counter-RNG stream."""
     from qiskit_gym_amd.vec import VecEnv
 
     gateset = line_gateset("pauli", n)
     batch = 48
-    cfg = dict(add_perms=False, track_solution=False, max_rotations=5, difficulty=difficulty, pauli_diff_scale=scale)
+    cfg = dict(add_perms=False, track_solution=False, max_rotations=max_rot, difficulty=difficulty, pauli_diff_scale=scale)
     gv = VecEnv("pauli", n, gateset, batch, **cfg)
     gv.reset(seed=0xC0FFEE)
     gv.sync()
@@ -256,9 +256,11 @@ def test_pauli_reset_generates_the_replayed_target(n, difficulty, scale):
     np.testing.assert_array_equal(gv.depth.cpu().numpy(), [o.depth() for o in envs])
     np.testing.assert_array_equal(gv.success.cpu().numpy(), [int(o.success()) for o in envs])
     assert any(o.active_rotations() for o in envs) or difficulty // scale == 0
+    if max_rot > 16:
+        assert max(len(o.active_rotations()) for o in envs) > 16  # the generator filled more than the 16-rotation kernels hold
     # and the scalar Gym front-end can reset a PauliGym
     from qiskit_gym_amd.envs import PauliGym
 
     g = PauliGym.from_coupling_map([(i, i + 1) for i in range(n - 1)] + [(i + 1, i) for i in range(n - 1)], difficulty=difficulty, add_perms=False)
     obs, info = g.reset(seed=3)
-    assert obs.shape == (2 * n, 2 * n + 5) and obs.dtype == np.int8
+    assert obs.shape == (2 * n, 2 * n + 5) and obs.dtype == np.int8  # PauliGym's own default max_rotations
