@@ -22,7 +22,7 @@ RUNS = {
     "bench": ("qm_step1_kernel<16, true, false>", 65536, 160, 90),
     "C3_1048576": ("qm_step1_kernel<16, true, false>", 1048576, 160, 90),
     "C3_4194304": ("qm_step1_kernel<16, true, false>", 4194304, 160, 90),
-    "C3d": ("qm_step_kernel<16, true, true, true, true, false>", 65536, 160, 160),
+    "C3d": ("qm_inv2_kernel<16, true>", 2 * 65536, 160, 160),  # two lanes per env: Grid_Size is 2 x envs
     "C2": ("word_step_kernel<false>", 8192, 32, 32),
     "C5": ("ptile_step1c_kernel<20, 8, false>", 65536, 494, None),
 }
@@ -69,6 +69,8 @@ for run, (kernel, envs, algo, needed) in RUNS.items():
             live = json.loads(open(lp).read().strip().splitlines()[-1])
         except Exception:
             live = None
+    if run == "C3d":
+        envs //= 2
     e = {"kernel": "qg::" + kernel, "envs": envs, "fetch_bytes": fb, "write_bytes": wb, "bytes_per_launch": fb + wb,
          "bytes_per_env": (fb + wb) / envs, "fetch_per_env": fb / envs, "write_per_env": wb / envs,
          "survey_8d_bytes_per_env": algo, "needed_bytes_per_env": needed,

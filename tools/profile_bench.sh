@@ -22,7 +22,7 @@ pmc_pass() {  # name, counter, script args...
     local F
     F=$(ls /tmp/qg_prof/${name}_$counter/*counter_collection.csv 2>/dev/null | head -1)
     # keep the step kernels' dispatches only (the files are large): header + rows of *_step* kernels
-    if [ -n "$F" ]; then (head -1 "$F"; grep -E "step1?c?_kernel" "$F") > "$OUT/pmc_${name}_$counter.csv"; fi
+    if [ -n "$F" ]; then (head -1 "$F"; grep -E "step1?c?_kernel|inv2_kernel" "$F") > "$OUT/pmc_${name}_$counter.csv"; fi
 }
 stats_pass() {  # name, script args...
     local name="$1"; shift

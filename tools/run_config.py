@@ -24,7 +24,7 @@ from util import grid_gateset, line_gateset
 
 ALGO = {"C1": 32, "C2": 32, "C3": 160, "C3d": 160, "C5": 494}  # SURVEY.md 8(d), bytes per env-step
 KERNELS = {"C1": "word_step_kernel<true>", "C2": "word_step_kernel<false>", "C3": "qm_step1_kernel<16, true, false>",
-           "C3d": "qm_step_kernel<16, true, true, true, true, false>", "C5": "ptile_step1c_kernel<20, 8, false>"}
+           "C3d": "qm_inv2_kernel<16, true>", "C5": "ptile_step1c_kernel<20, 8, false>"}
 
 
 def main():
