@@ -344,6 +344,15 @@ int qg_policy_pack_mid(const void *weight_dev, const void *bias_dev, int dtype, 
 int qg_policy_mid_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
                               const void *packed_head_dev, uint32_t num_actions, uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev,
                               int action_dtype, float *logp_dev, float *entropy_dev, float *values_dev, void *stream);
+/* The same kernel followed, in the same launch, by Env::step of handle `v` with the action it drew (the lane that holds an env's draw
+ * gathers / scatters that env's rows like qg_vec_step does: same results, one launch less per collection step), and by the compaction of
+ * the envs whose episode ended with this step: the next qg_vec_reset_done finds its list ready and launches only the reset itself.
+ * batch, num_actions, the device clock and the env outputs are the handle's; rewards_dev / dones_dev: per-step outputs as in
+ * qg_vec_rollout (may be NULL).  TILE-layout handles without add_inverts (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32);
+ * QG_ERR_UNSUPPORTED otherwise. */
+int qg_vec_mid_head_sample_step(qg_vec *v, const void *h_dev, uint64_t ld_h, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
+                                const void *packed_head_dev, uint64_t seed, uint64_t counter, void *actions_dev, int action_dtype, float *logp_dev,
+                                float *entropy_dev, float *values_dev, float *rewards_dev, uint8_t *dones_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Scalar environment: the `Env` trait method for method (clifford.rs:285-382).

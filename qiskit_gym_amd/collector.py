@@ -201,6 +201,23 @@ def mid_head_sample(h: torch.Tensor, packed_mid: torch.Tensor, mid_features: int
     return actions, logp, entropy, values
 
 
+def mid_head_sample_step(env: VecEnv, h: torch.Tensor, packed_mid: torch.Tensor, mid_features: int, packed_head: torch.Tensor, seed: int, counter: int,
+                         actions: torch.Tensor, logp: torch.Tensor, entropy: torch.Tensor, values: torch.Tensor,
+                         rewards: Optional[torch.Tensor] = None, dones: Optional[torch.Tensor] = None):
+    """`mid_head_sample` followed, in the same launch, by `env.step(actions)` and by the compaction of the finished envs for the next
+    `env.reset_done` (`qg_vec_mid_head_sample_step`): same draws, same env results, two launches less per collection step.  The env's
+    device clock (`env.set_clock`) is the sampling clock."""
+    if h.dim() != 2 or h.dtype != torch.bfloat16 or h.stride(1) != 1 or h.shape[0] != env.batch:
+        raise ValueError("h must be bf16 [env.batch, in_features] with unit column stride")
+    act_dt = {torch.int32: _lib.ACT_I32, torch.int64: _lib.ACT_I64}[actions.dtype]
+    _lib.check(_lib.load().qg_vec_mid_head_sample_step(env._h, h.data_ptr(), h.stride(0), h.shape[1], packed_mid.data_ptr(), int(mid_features),
+                                                       packed_head.data_ptr(), int(seed) & (2**64 - 1), int(counter), actions.data_ptr(), act_dt,
+                                                       logp.data_ptr(), entropy.data_ptr(), values.data_ptr(),
+                                                       rewards.data_ptr() if rewards is not None else None,
+                                                       dones.data_ptr() if dones is not None else None, env._stream()))
+    return actions, logp, entropy, values
+
+
 def head_sample(h: torch.Tensor, packed: torch.Tensor, num_actions: int, seed: int, counter: int, actions: Optional[torch.Tensor] = None,
                 logp: Optional[torch.Tensor] = None, entropy: Optional[torch.Tensor] = None, values: Optional[torch.Tensor] = None,
                 clock: Optional[torch.Tensor] = None):
@@ -294,7 +311,7 @@ class RolloutCollector:
 
     def __init__(self, env: VecEnv, policy: nn.Module, dtype: torch.dtype = torch.bfloat16, seed: int = 0, gamma: float = 0.995,
                  gae_lambda: float = 0.995, store_obs: str = "dense", use_graph: bool = False, use_bit_embedding: Optional[bool] = None,
-                 use_fused_head: Optional[bool] = None):
+                 use_fused_head: Optional[bool] = None, use_fused_step: Optional[bool] = None):
         self.env = env
         self.policy = policy.to(device=env.device, dtype=dtype)
         self.dtype = dtype
@@ -353,6 +370,10 @@ class RolloutCollector:
                 self._scratch_f32 = torch.empty((3, env.batch), dtype=torch.float32, device=env.device)
             except ValueError:
                 self._head = self._mid = None
+        # sampling, env.step and the compaction of finished envs in ONE launch (qg_vec_mid_head_sample_step): TILE-layout envs without add_inverts
+        can_fuse_step = (self._mid is not None and env.env_kind in ("clifford", "linear_function") and not env.config.get("add_inverts", True)
+                         and ((env.env_kind == "clifford" and env.num_qubits <= 16) or (env.env_kind == "linear_function" and 8 < env.num_qubits <= 32)))
+        self._fused_step = can_fuse_step if use_fused_step is None else bool(use_fused_step) and can_fuse_step
         self._graph = None
         self._graph_T = 0
         self._graph_ro: Optional[Rollout] = None
@@ -489,6 +510,10 @@ class RolloutCollector:
             env.reset_done(self.seed + 0x9E3779B9 * (t + 1))
             self._observe(ro, t)
             # masks() is all-true for a live env (clifford.rs:349-351), so sampling needs no mask
+            if self._fused_step:  # first layer, then middle layer + head + draw + env.step + done compaction in one kernel
+                mid_head_sample_step(env, self._first_layer(), self._mid, self.policy.common.out_features, self._head, self.seed, t, ro.actions[t],
+                                     ro.logp[t], ro.entropy[t], ro.values[t], rewards=ro.rewards[t], dones=ro.dones[t])
+                continue
             self._forward_sample(ro, t)
             env.rollout(ro.actions[t : t + 1], rewards_out=ro.rewards[t : t + 1], dones_out=ro.dones[t : t + 1])
         # bootstrap value of the state after the last step (masked by `dones` where the episode ended)

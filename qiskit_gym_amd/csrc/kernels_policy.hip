@@ -34,8 +34,11 @@
 // in the packed form (2^112 W must stay finite in bf16).
 #include <hip/hip_bf16.h>
 
+#include <cstring>
+
 #include "device_common.hpp"
 #include "qgym_host.hpp"
+#include "qm_step1.hpp"
 
 namespace qg {
 
@@ -384,7 +387,7 @@ __device__ __forceinline__ float head_xhalf(float x) { return __shfl_xor(x, 32, 
 // The draw from register-resident logits: acc[t][q] = logit of action 32 t + (q & 3) + 8 (q >> 2) + 4 h of env `env` (C layout of the
 // transposed product), the last padded row is the value head.  Same race as qg_sample_actions (kernels_collect.hip).
 template <uint32_t TILES>
-__device__ __forceinline__ void head_draw(f32x16 (&acc)[TILES], const HeadArgs &a, uint64_t env, bool live, uint32_t h) {
+__device__ __forceinline__ int64_t head_draw(f32x16 (&acc)[TILES], const HeadArgs &a, uint64_t env, bool live, uint32_t h) {
     const float INF = __builtin_huge_valf();
     // acc[t][q] = logit of action 32 t + (q & 3) + 8 (q >> 2) + 4 h for env `env`; the last padded row is the value head
     const float value = acc[TILES - 1][15];  // meaningful on the h = 1 lanes
@@ -436,8 +439,8 @@ __device__ __forceinline__ void head_draw(f32x16 (&acc)[TILES], const HeadArgs &
         best_d = take ? od : best_d;
     }
     const float v_other = head_xhalf(value);
+    const int64_t act = best_a == 0xFFFFFFFFu ? 0 : (int64_t)best_a;  // the env's action on both lane halves
     if (live && h == 0) {
-        const int64_t act = best_a == 0xFFFFFFFFu ? 0 : (int64_t)best_a;
         if (a.act64) reinterpret_cast<int64_t *>(a.actions)[env] = act;
         else reinterpret_cast<int32_t *>(a.actions)[env] = (int32_t)act;
         const float log_s = logf(ssum);
@@ -445,6 +448,7 @@ __device__ __forceinline__ void head_draw(f32x16 (&acc)[TILES], const HeadArgs &
         if (a.entropy) a.entropy[env] = log_s - wsum / ssum;
         if (a.values) a.values[env] = v_other;
     }
+    return act;
 }
 
 template <uint32_t TILES>
@@ -527,6 +531,12 @@ struct MidHeadArgs {
     HeadArgs head;         // head.h = h1, head.ld_h its stride, head.K = features of the middle layer (256), head.wp = packed head (xorder)
     const uint4 *w2p;      // packed middle layer: [K1/16 + 2 k-steps][MID_FT][64]
     uint32_t K1;           // in_features of the middle layer
+    // qg_vec_mid_head_sample_step: Env::step with the drawn action in the same launch (TILE layout, no add_inverts), and the indices
+    // of the envs whose episode ended appended to the handle's list for the next qg_vec_reset_done.  step.state == nullptr: draw only.
+    StepArgs step;
+    uint32_t step_groups;  // 16-byte groups per env of the TILE layout
+    uint32_t step_has_z;
+    uint32_t *done_list, *done_count;
 };
 
 template <uint32_t TILES>
@@ -626,7 +636,21 @@ __global__ __launch_bounds__(64 * MH_WAVES, 2) void mid_head_sample_kernel(MidHe
             }
             landed();  // after the last chunk: every wave is done with both buffers before the next trip stages chunk 0
         }
-        head_draw<TILES>(acc, a, env, live, h);
+        const int64_t act = head_draw<TILES>(acc, a, env, live, h);
+        if (ma.step.state) {  // wave-uniform
+            bool fin = false;
+            if (live && h == 0)
+                fin = ma.step_has_z ? qm_step1_body<true, true>(ma.step, ma.step_groups, env, act) : qm_step1_body<false, true>(ma.step, ma.step_groups, env, act);
+            // compact_done (kernels_rows.hip) for this wave's 32 envs: one atomic per wave with a finished env
+            const uint64_t m = __ballot(fin);
+            if (m) {
+                const uint32_t first = (uint32_t)__ffsll((long long)m) - 1u;
+                uint32_t base = 0;
+                if (lane == first) base = atomicAdd(ma.done_count, (uint32_t)__popcll(m));
+                base = __shfl(base, first);
+                if (fin) ma.done_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)env;
+            }
+        }
     }
 }
 
@@ -1107,9 +1131,10 @@ int qg_policy_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, uint
     return QG_OK;
 }
 
-int qg_policy_mid_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
-                              const void *packed_head_dev, uint32_t num_actions, uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev,
-                              int action_dtype, float *logp_dev, float *entropy_dev, float *values_dev, void *stream) {
+static int mid_head_impl(const void *h_dev, uint64_t ld_h, uint64_t batch, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
+                         const void *packed_head_dev, uint32_t num_actions, uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev,
+                         int action_dtype, float *logp_dev, float *entropy_dev, float *values_dev, qg_vec *step_of, float *step_rewards,
+                         uint8_t *step_dones, void *stream) {
     if (!h_dev || !packed_mid_dev || !packed_head_dev || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
     if (qg_policy_head_packed_bytes(num_actions, mid_features) == 0 || qg_policy_mid_packed_bytes(in_features, mid_features) == 0)
         return set_error(QG_ERR_UNSUPPORTED, "fused middle layer + head: 256 middle features, in_features a multiple of 32, num_actions <= 222");
@@ -1135,6 +1160,20 @@ int qg_policy_mid_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, 
     a.act64 = action_dtype == QG_ACT_I64;
     m.w2p = reinterpret_cast<const uint4 *>(packed_mid_dev);
     m.K1 = in_features;
+    if (step_of) {  // Env::step with the drawn action in the same launch
+        qg_vec *v = step_of;
+        fill_step_args_public(v, m.step);
+        m.step.rewards_seq = step_rewards;
+        m.step.dones_seq = step_dones;
+        m.step_groups = (v->has_z ? 2u * v->nxp : v->nxp) / 4u;
+        m.step_has_z = v->has_z ? 1u : 0u;
+        m.done_list = v->done_list;
+        m.done_count = v->done_list + v->B;
+    } else {
+        m.step = StepArgs{};
+        m.step_groups = m.step_has_z = 0;
+        m.done_list = m.done_count = nullptr;
+    }
     const uint32_t tiles = (num_actions + 1u + 31u) / 32u;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
@@ -1151,6 +1190,30 @@ int qg_policy_mid_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, 
     }
 #undef QG_MH_CASE
     HIP_TRY(hipGetLastError());
+    return QG_OK;
+}
+
+int qg_policy_mid_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
+                              const void *packed_head_dev, uint32_t num_actions, uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev,
+                              int action_dtype, float *logp_dev, float *entropy_dev, float *values_dev, void *stream) {
+    return mid_head_impl(h_dev, ld_h, batch, in_features, packed_mid_dev, mid_features, packed_head_dev, num_actions, seed, counter, clock_dev, actions_dev,
+                         action_dtype, logp_dev, entropy_dev, values_dev, nullptr, nullptr, nullptr, stream);
+}
+
+int qg_vec_mid_head_sample_step(qg_vec *v, const void *h_dev, uint64_t ld_h, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
+                                const void *packed_head_dev, uint64_t seed, uint64_t counter, void *actions_dev, int action_dtype, float *logp_dev,
+                                float *entropy_dev, float *values_dev, float *rewards_dev, uint8_t *dones_dev, void *stream) {
+    if (!v) return set_error(QG_ERR_INVALID, "null argument");
+    if (v->layout != LAYOUT_TILE || (v->flags & F_INVERTS) || !v->bad || !v->done_list)
+        return set_error(QG_ERR_UNSUPPORTED, "the sampling kernel steps TILE-layout handles without add_inverts (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32)");
+    QG_ON_DEVICE(v);
+    if (v->done_list_fresh)  // a list nobody consumed (no qg_vec_reset_done since the last fused step): start it again
+        HIP_TRY(hipMemsetAsync(v->done_list + v->B, 0, 2 * sizeof(uint32_t), (hipStream_t)stream));
+    const int rc = mid_head_impl(h_dev, ld_h, v->B, in_features, packed_mid_dev, mid_features, packed_head_dev, (uint32_t)v->gates.size(), seed, counter,
+                                 v->clock_dev, actions_dev, action_dtype, logp_dev, entropy_dev, values_dev, v, rewards_dev, dones_dev, stream);
+    if (rc != QG_OK) return rc;
+    v->done_list_fresh = true;
+    v->step_index += 1;
     return QG_OK;
 }
 

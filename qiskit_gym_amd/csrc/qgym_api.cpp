@@ -237,6 +237,16 @@ static int vec_free_buffers(qg_vec *v) {
 
 static int ensure_scratch(qg_vec *v, size_t bytes) { return qg::ensure_scratch_public(v, bytes); }
 
+// The list of finished envs that qg_vec_mid_head_sample_step leaves for qg_vec_reset_done describes the `done` flags of that step only:
+// anything else that changes the flags first drops it (and re-zeroes its counter, which only the list's consumer would have done).
+static int drop_done_list(qg_vec *v, hipStream_t s) {
+    if (v->done_list_fresh) {
+        HIP_TRY(hipMemsetAsync(v->done_list + v->B, 0, 2 * sizeof(uint32_t), s));
+        v->done_list_fresh = false;
+    }
+    return QG_OK;
+}
+
 static void fill_init_args(const qg_vec *v, InitArgs &a) {
     memset(&a, 0, sizeof a);
     a.state = v->state;
@@ -627,6 +637,7 @@ int qg_vec_set_state(qg_vec *v, const void *states, int format, size_t stride, i
     if (format < QG_FMT_I64 || format > QG_FMT_PACKED) return set_error(QG_ERR_INVALID, "unknown state format %d", format);
     QG_ON_DEVICE(v);
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = drop_done_list(v, s)) return rc;
     if (v->layout == LAYOUT_PAULI) return pauli_set_state(v, states, format, stride, on_device, s);
     if (stride < format_min_elems(v, format))
         return set_error(QG_ERR_INVALID, "set_state: %zu elements per env, need %zu (the reference would index out of bounds)",
@@ -721,6 +732,8 @@ int qg_vec_get_state(qg_vec *v, void *out, int format, size_t stride, int on_dev
 
 static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint64_t seed, hipStream_t s, bool only_done = false) {
     QG_ON_DEVICE(v);
+    if (!only_done)
+        if (int rc = drop_done_list(v, s)) return rc;
     if (only_done && v->layout == LAYOUT_PAULI) return ptile_reset_seeded(v, seed, true, s);
     if (v->layout == LAYOUT_PAULI) {
         if (actions_dev) return set_error(QG_ERR_UNSUPPORTED, "PauliEnv reset draws a whole target, not `difficulty` actions: use qg_vec_reset(seed) or qg_vec_pauli_reset_from");
@@ -737,8 +750,9 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
     ia.only_done = only_done ? 1u : 0u;
     if (only_done && v->done_list) {
         // few, scattered finished envs: pack their indices first so that the scramble runs in full waves
-        // instead of in every wave that holds one finished env
-        HIP_TRY(compact_done(v->done, v->B, v->done_list, v->done_list + v->B, s));
+        // instead of in every wave that holds one finished env (the sampling + step kernel has already done it: done_list_fresh)
+        if (!v->done_list_fresh) HIP_TRY(compact_done(v->done, v->B, v->done_list, v->done_list + v->B, s));
+        v->done_list_fresh = false;
         ia.list = v->done_list;
         ia.list_count = v->done_list + v->B;
         ia.coop = (!actions_dev && v->B >= 64 && v->d_rowops) ? 1u : 0u;
@@ -823,6 +837,7 @@ int qg_vec_step(qg_vec *v, const void *actions_dev, int action_dtype, const uint
     if (!v || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
     if (action_dtype != QG_ACT_I32 && action_dtype != QG_ACT_I64) return set_error(QG_ERR_INVALID, "bad action dtype");
     QG_ON_DEVICE(v);
+    if (int rc = drop_done_list(v, (hipStream_t)stream)) return rc;
     StepArgs a;
     fill_step_args(v, a);
     a.actions = actions_dev;
@@ -854,6 +869,7 @@ static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, si
     if (T > 0x7fffffffu) return set_error(QG_ERR_INVALID, "too many steps");
     QG_ON_DEVICE(v);
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = drop_done_list(v, s)) return rc;
     StepArgs a;
     fill_step_args(v, a);
     a.actions = actions_dev;
@@ -1045,3 +1061,7 @@ int64_t qg_vec_solution(qg_vec *v, uint64_t env, uint64_t *out, size_t cap) {
 }
 
 }  // extern "C"
+
+namespace qg {
+void fill_step_args_public(const qg_vec *v, StepArgs &a) { fill_step_args(v, a); }
+}  // namespace qg

@@ -108,6 +108,7 @@ struct qg_vec {
     uint32_t *bad = nullptr;            // TILE / TILE64 without add_inverts: per-env "differs from identity" mask (one-step kernels)
     uint32_t *d_rowops = nullptr;       // TILE: gate table as pairs of row operations on slots (cooperative reset kernel)
     uint32_t *done_list = nullptr;      // reset_done: [B] indices of finished envs + {length, reader ticket} at [B], [B + 1]
+    bool done_list_fresh = false;       // the list already holds the finished envs (written by the step that ended them: qg_vec_mid_head_sample_step)
     uint32_t *d_nonsymp = nullptr;      // device word behind InitArgs::nonsymp_flag
     void *embed_dump = nullptr;         // qg_vec_embed: 1 KiB nobody reads (kernels_policy.hip), allocated by qg_vec_pack_embedding
     bool maybe_nonsymplectic = false;   // CliffordEnv + add_inverts: some env may need the Gauss-Jordan inversion
@@ -135,6 +136,7 @@ struct qg_vec {
 
 namespace qg {
 int ensure_scratch_public(qg_vec *v, size_t bytes);
+void fill_step_args_public(const qg_vec *v, StepArgs &a);
 void compute_qubit_and_action_perms(uint32_t N, const std::vector<qg_gate> &gates, std::vector<std::vector<int64_t>> &qubit_perms,
                                     std::vector<std::vector<int64_t>> &act_perms);
 // PauliEnv host hooks (pauli_host.cpp)

@@ -37,6 +37,7 @@ class VecEnv:
         self.device_index = torch.cuda.current_device() if device is None else int(device)
         self.device = torch.device("cuda", self.device_index)
         self.batch = int(batch)
+        self.config = dict(config)  # the constructor options as given (reference defaults where absent)
         self._cfg = _lib.make_config(env_kind, num_qubits, metrics_weights=metrics_weights, **config)
         self._gates = _lib.make_gates(parse_gateset(self.gateset))
         h = C.c_void_p()

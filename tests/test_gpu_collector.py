@@ -199,3 +199,49 @@ def test_first_layer_from_the_packed_observation_words(kind, n, kw, use_graph):
                 prm.mul_(0.5)
     env.sync()
     assert col.steps_done == 3 * T
+
+
+@pytest.mark.parametrize("kind,n,use_graph", [("clifford", 5, False), ("clifford", 16, True), ("linear_function", 12, False)])
+def test_sampling_kernel_that_also_steps_the_env_equals_the_separate_launches(kind, n, use_graph):
+    """qg_vec_mid_head_sample_step: middle layer + head + draw + Env::step + compaction of the finished envs in one launch.  Same
+    trajectories, bit for bit, as the sampling kernel followed by qg_vec_step and a reset_done that compacts for itself -- and the
+    trajectories replay on the oracle (auto-resets included: the list the kernel leaves is the list reset_done would have built)."""
+    from qiskit_gym_amd.collector import BasicPolicy, RolloutCollector
+    from qiskit_gym_amd.vec import VecEnv
+
+    B, T, diff = 1000, 12, 2
+    gs = line_gateset(kind, n)
+    A = len(gs)
+    cfg = dict(add_inverts=False, add_perms=False, track_solution=False, difficulty=diff)
+    obs_size = 4 * n * n if kind == "clifford" else n * n
+    runs = []
+    for fused in (True, False):
+        env = VecEnv(kind, n, gs, B, **cfg)
+        torch.manual_seed(3)
+        pol = BasicPolicy(obs_size, A, embedding_size=128, common=256)  # the fused tail needs the reference's 256 middle features
+        col = RolloutCollector(env, pol, dtype=torch.bfloat16, seed=5, store_obs="packed", use_graph=use_graph, use_bit_embedding=True,
+                               use_fused_head=True, use_fused_step=fused)
+        assert col._mid is not None and col._fused_step == fused
+        got = []
+        for call in range(2):
+            ro = col.collect(T)
+            torch.cuda.synchronize()
+            got.append({k: getattr(ro, k).clone() for k in ("obs", "actions", "logp", "values", "rewards", "dones", "advantages")})
+        env.sync()
+        runs.append((got, env.get_state("packed").clone(), env.depth.clone()))
+    for call in range(2):
+        for k in runs[0][0][call]:
+            assert torch.equal(runs[0][0][call][k], runs[1][0][call][k]), (call, k)
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    # oracle replay of the fused run's first collection
+    ro = runs[0][0][0]
+    acts, rew, done = ro["actions"].cpu().numpy(), ro["rewards"].cpu().numpy(), ro["dones"].cpu().numpy()
+    envs = [OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()}) for _ in range(0, B, 7)]
+    for t in range(T):
+        draws = rng_actions((5 + 0x9E3779B9 * (t + 1)) & (2**64 - 1), B, diff, A)
+        for i, o in enumerate(envs):
+            e = 7 * i
+            if o.is_final():
+                o.reset_with(draws[:, e])
+            o.step(int(acts[t, e]))
+            assert o.reward_bits() == int(f32_bits(rew[t, e])) and int(o.is_final()) == int(done[t, e]), (t, e)

@@ -10,7 +10,7 @@ from qiskit_gym_amd.vec import VecEnv
 from util import line_gateset
 
 ONLY = os.environ.get("ONLY")  # e.g. ONLY=65536 to run the large batch only (profiling)
-for B, store, graph in ((1024, "packed", False), (1024, "packed", True), (8192, "packed", False), (8192, "packed", True), (65536, "dense", False), (65536, "packed", False), (65536, "packed", True)):
+for B, store, graph in ((1024, "packed", False), (1024, "packed", True), (4096, "packed", True), (8192, "packed", False), (8192, "packed", True), (65536, "dense", False), (65536, "packed", False), (65536, "packed", True)):
     if ONLY and (B != int(ONLY) or store != "packed" or graph):
         continue
     NQ = int(os.environ.get("QUBITS", "16"))  # > 16: 64-bit row words, the first layer reads the packed observation (qg_policy_embed_words)
@@ -18,8 +18,9 @@ for B, store, graph in ((1024, "packed", False), (1024, "packed", True), (8192, 
     env = VecEnv("clifford", NQ, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=int(os.environ.get("DIFF", "32")))
     fused = {"1": True, "0": False}.get(os.environ.get("FUSED", ""), None)  # FUSED=1 / 0 forces the policy-layer kernels on / off
     embed = {"1": True, "0": False}.get(os.environ.get("EMBED", ""), fused)  # EMBED=0: library GEMM for the first layer only
+    fstep = {"1": True, "0": False}.get(os.environ.get("FSTEP", ""), None)  # FSTEP=0: sampling kernel, then qg_vec_step (A/B of the fused launch)
     col = RolloutCollector(env, BasicPolicy(4 * NQ * NQ, len(gs)), dtype=torch.bfloat16, seed=1, store_obs=store, use_graph=graph,
-                           use_bit_embedding=embed, use_fused_head=fused)
+                           use_bit_embedding=embed, use_fused_head=fused, use_fused_step=fstep)
     T = 32
     ro = col.collect(T)
     torch.cuda.synchronize()
@@ -35,5 +36,5 @@ for B, store, graph in ((1024, "packed", False), (1024, "packed", True), (8192, 
     gc.collect()
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
-    print(f"CliffordGym {NQ}q B={B} obs stored {store}{' hipGraph' if graph else ''}: {3 * T * B / dt:.3e} env-steps/s with the policy in the loop ({dt / (3 * T) * 1e6:.0f} us per step), "
+    print(f"CliffordGym {NQ}q B={B} obs stored {store}{' hipGraph' if graph else ''}{' FSTEP=' + os.environ['FSTEP'] if 'FSTEP' in os.environ else ''}: {3 * T * B / dt:.3e} env-steps/s with the policy in the loop ({dt / (3 * T) * 1e6:.0f} us per step), "
           f"success rate in last rollout {done_rate:.3f} done/step")
