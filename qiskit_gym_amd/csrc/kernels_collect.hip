@@ -117,6 +117,39 @@ __global__ __launch_bounds__(256) void widen01_kernel(const uint8_t *in, uint64_
     }
 }
 
+// Env::masks (clifford.rs:349-351)
+__global__ __launch_bounds__(256) void masks_kernel(const uint8_t *success, uint8_t *out, uint64_t total, uint32_t A) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < total) out[gid] = success[gid / A] ? 0 : 1;
+}
+// Indices of the finished envs, packed (qg_vec_reset_done): a wave ballots its `done` flags, one lane
+// reserves that many slots of `list` with an atomic add, every done lane writes its env index at its
+// prefix.  The order across waves is arbitrary -- every env's reset depends on (seed, env) only.
+__global__ __launch_bounds__(256) void compact_done_kernel(const uint8_t *done, uint64_t B, uint32_t *list, uint32_t *count) {
+    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    const bool d = env < B && done[env];
+    const uint64_t m = __ballot(d);
+    if (!m) return;
+    uint32_t base = 0;
+    if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (d) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)env;
+}
+// `count` must be zero on entry: the last kernel that consumes the list zeroes it again (list_count_take)
+hipError_t compact_done(const uint8_t *done, uint64_t B, uint32_t *list, uint32_t *count, hipStream_t s) {
+    hipLaunchKernelGGL(compact_done_kernel, dim3(blocks_for(B, 256)), dim3(256), 0, s, done, B, list, count);
+    return hipGetLastError();
+}
+
+hipError_t masks_fill(const uint8_t *success, uint8_t *out, uint64_t B, uint32_t A, hipStream_t s) {
+    const uint64_t total = B * A;
+    if (!total) return hipSuccess;
+    hipLaunchKernelGGL(masks_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, success, out, total, A);
+    return hipGetLastError();
+}
+
+
 static bool dtype_info(int dtype, uint32_t &elem_size, uint32_t &one) {
     switch (dtype) {
     case QG_DT_I8: elem_size = 1; one = 1u; return true;

@@ -274,8 +274,7 @@ static void fill_init_args(const qg_vec *v, InitArgs &a) {
 
 static hipError_t launch_init(const qg_vec *v, const InitArgs &a, hipStream_t s) {
     switch (v->layout) {
-    case LAYOUT_ROWS32: return rows_init(a, false, s);
-    case LAYOUT_ROWS64: return rows_init(a, true, s);
+    case LAYOUT_LFD: return lfd_init(a, v->w64, v->nxp, v->d_descs, s);
     case LAYOUT_LF8: return lf8_init(a, s);
     case LAYOUT_PERM: return perm_init(a, s);
     case LAYOUT_PERMB: return permb_init(a, v->nxp, v->d_descs, s);
@@ -322,8 +321,7 @@ static void fill_step_args(const qg_vec *v, StepArgs &a) {
 
 static hipError_t launch_step(const qg_vec *v, const StepArgs &a, hipStream_t s) {
     switch (v->layout) {
-    case LAYOUT_ROWS32: return rows_step(a, false, s);
-    case LAYOUT_ROWS64: return rows_step(a, true, s);
+    case LAYOUT_LFD: return lfd_step(a, v->w64, v->nxp, s);
     case LAYOUT_LF8: return lf8_step(a, a.T > 1, s);
     case LAYOUT_PERM: return perm_step(a, a.T > 1, s);
     case LAYOUT_PERMB: return permb_step(a, v->nxp, s);
@@ -389,20 +387,15 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
         break;
     case QG_LINEAR_FUNCTION:
         v->D = N;
+        if (N > 64) return set_error(QG_ERR_UNSUPPORTED, "LinearFunctionEnv: N <= 64 supported, got %u", N);
         if (N <= 8) {
             v->layout = LAYOUT_LF8;
             v->stride_bytes = 8;
-        } else if (N <= 64) {
-            v->layout = N <= 32 ? LAYOUT_ROWS32 : LAYOUT_ROWS64;
-        } else {
-            return set_error(QG_ERR_UNSUPPORTED, "LinearFunctionEnv: N <= 64 supported, got %u", N);
         }
         break;
     case QG_CLIFFORD:
         v->D = 2 * N;
-        if (N <= 16) v->layout = LAYOUT_ROWS32;
-        else if (N <= 32) v->layout = LAYOUT_ROWS64;
-        else return set_error(QG_ERR_UNSUPPORTED, "CliffordEnv: N <= 32 supported, got %u", N);
+        if (N > 32) return set_error(QG_ERR_UNSUPPORTED, "CliffordEnv: N <= 32 supported, got %u", N);
         break;
     case QG_PAULI:
         v->D = 2 * N;
@@ -411,13 +404,16 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     default: return set_error(QG_ERR_INVALID, "unknown env_kind %d", cfg->env_kind);
     }
     const bool inverts = cfg->add_inverts && cfg->env_kind != QG_PAULI;
-    // thread-per-env TILE layout for matrices of <= 32 rows (the hot path); the inversion path
-    // (add_inverts) lives in the lane-group ROWS kernels
-    // thread-per-env layouts for everything but LinearFunction inversion beyond 16 rows: a general
-    // Gauss-Jordan over that many register-resident rows is slower than the lane-group ROWS
-    // kernels' (measured at N = 32: 72 vs 46 us per step), and CliffordEnv has the transpose form
-    const bool tile_ok = !inverts || cfg->env_kind == QG_CLIFFORD || N <= 16;
-    if (v->layout == LAYOUT_ROWS32 && tile_ok) {
+    if (v->layout == LAYOUT_NONE && cfg->env_kind == QG_LINEAR_FUNCTION && inverts) {
+        // the matrix and its inverse side by side: inversion is a role swap (kernels_lfd.hip)
+        v->layout = LAYOUT_LFD;
+        v->w64 = N > 32;
+        const uint32_t rpg = v->w64 ? 2u : 4u;
+        v->nxp = (N + rpg - 1u) / rpg;  // groups per matrix
+        v->stride_bytes = 0;
+        v->state_bytes = ((batch + 63) / 64) * (size_t)2 * v->nxp * 1024;
+    }
+    if (v->layout == LAYOUT_NONE && v->D <= 32) {  // thread-per-env TILE layout, uint32 rows (kernels_qm.hip): the hot path
         v->layout = LAYOUT_TILE;
         v->nxp = (N + 3u) & ~3u;
         v->has_z = cfg->env_kind == QG_CLIFFORD;
@@ -425,17 +421,12 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
         v->stride_bytes = 0;
         v->state_bytes = ((batch + 63) / 64) * R * 256;
     }
-    if (v->layout == LAYOUT_ROWS64 && tile_ok) {
-        v->layout = LAYOUT_TILE64;  // uint64 rows, thread per env (kernels_qm64.hip)
+    if (v->layout == LAYOUT_NONE) {  // uint64 rows, thread per env (kernels_qm64.hip)
+        v->layout = LAYOUT_TILE64;
         v->has_z = cfg->env_kind == QG_CLIFFORD;
         v->nxp = v->has_z ? 2u * ((N + 3u) & ~3u) : ((N + 7u) & ~7u);  // row slots per env
         v->stride_bytes = 0;
         v->state_bytes = ((batch + 63) / 64) * (size_t)v->nxp * 512;
-    }
-    if (v->layout == LAYOUT_ROWS32 || v->layout == LAYOUT_ROWS64) {
-        const uint32_t rpl = v->layout == LAYOUT_ROWS32 ? 4 : 2;
-        v->log2L = pow2ceil_log2((v->D + rpl - 1) / rpl);
-        v->stride_bytes = (size_t)16 << v->log2L;
     }
 
     // behaviour flags
@@ -490,6 +481,7 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     if ((v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) && !(v->flags & F_INVERTS))
         HIP_TRY_V(hipMalloc(&p->bad, (v->layout == LAYOUT_TILE64 ? sizeof(uint64_t) : sizeof(uint32_t)) * batch));
     if (v->layout == LAYOUT_PERMB) HIP_TRY_V(hipMalloc(&p->bad, sizeof(uint32_t) * batch));  // number of entries with state[i] != i
+    if (v->layout == LAYOUT_LFD) HIP_TRY_V(hipMalloc(&p->bad, 2 * sizeof(uint64_t) * batch));  // row masks of the state's and the inverse's region
     if (v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_PAULI) {
         HIP_TRY_V(hipMalloc(&p->done_list, sizeof(uint32_t) * (batch + 2)));
         HIP_TRY_V(hipMemset(p->done_list + batch, 0, 2 * sizeof(uint32_t)));
@@ -573,7 +565,7 @@ int qg_vec_get_info(const qg_vec *v, qg_vec_info *o) {
     }
     o->device = v->device;
     o->batch = v->B;
-    o->packed_word_bytes = (v->layout == LAYOUT_PERM || v->layout == LAYOUT_PERMB) ? 1 : ((v->layout == LAYOUT_ROWS64 || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_PAULI) ? 8 : 4);
+    o->packed_word_bytes = (v->layout == LAYOUT_PERM || v->layout == LAYOUT_PERMB) ? 1 : ((v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_PAULI || (v->layout == LAYOUT_LFD && v->w64)) ? 8 : 4);
     o->packed_words_per_env = v->D;
     o->packed_env_stride_bytes = v->stride_bytes;
     o->state_dev = v->state;
@@ -624,7 +616,7 @@ int64_t qg_vec_get_difficulty(const qg_vec *v) { return v ? v->difficulty : -1; 
 static size_t format_elem_bytes(const qg_vec *v, int format) {
     if (format == QG_FMT_I64) return 8;
     if (format == QG_FMT_U8) return 1;
-    return (v->layout == LAYOUT_PERM || v->layout == LAYOUT_PERMB) ? 1 : ((v->layout == LAYOUT_ROWS64 || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_PAULI) ? 8 : 4);
+    return (v->layout == LAYOUT_PERM || v->layout == LAYOUT_PERMB) ? 1 : ((v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_PAULI || (v->layout == LAYOUT_LFD && v->w64)) ? 8 : 4);
 }
 static size_t format_min_elems(const qg_vec *v, int format) {
     if (v->layout == LAYOUT_PERM || v->layout == LAYOUT_PERMB) return v->N;
@@ -676,8 +668,7 @@ int qg_vec_set_state(qg_vec *v, const void *states, int format, size_t stride, i
 
 static hipError_t launch_export(const qg_vec *v, const ObsArgs &a, hipStream_t s) {
     switch (v->layout) {
-    case LAYOUT_ROWS32: return rows_export(a, false, s);
-    case LAYOUT_ROWS64: return rows_export(a, true, s);
+    case LAYOUT_LFD: return lfd_export(a, v->w64, v->nxp, v->inverted, s);
     case LAYOUT_LF8: return lf8_export(a, s);
     case LAYOUT_PERM: return perm_export(a, s);
     case LAYOUT_PERMB: return permb_export(a, v->nxp, s);
@@ -877,6 +868,7 @@ static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, si
     a.rewards_seq = rewards_dev;
     a.dones_seq = dones_dev;
     if (action_dtype == QG_ACT_I64) a.flags |= F_ACT64;
+    if (v->layout == LAYOUT_LFD) fused = 0;  // its step kernel spreads an env over four lanes; T steps = T launches (one graph)
     if (fused) {
         if (period != T) return set_error(QG_ERR_INVALID, "fused rollouts read actions[t] for every t");
         a.T = (uint32_t)T;
@@ -980,12 +972,6 @@ int qg_vec_observe_packed(qg_vec *v, void *out_dev, void *stream) {
         v->perm_draw = false;
         v->observe_counter += 1;
         HIP_TRY(e);
-        return QG_OK;
-    }
-    const bool rows = v->layout == LAYOUT_ROWS32 || v->layout == LAYOUT_ROWS64;
-    const size_t word = v->layout == LAYOUT_ROWS64 ? 8 : 4;
-    if (rows && v->stride_bytes == (size_t)v->D * word) {  // no padding: the resident state is the packed observation
-        HIP_TRY(hipMemcpyAsync(out_dev, v->state, v->stride_bytes * v->B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
         return QG_OK;
     }
     ObsArgs oa;

@@ -8,7 +8,7 @@
 
 namespace qg {
 
-enum Layout { LAYOUT_ROWS32 = 0, LAYOUT_ROWS64 = 1, LAYOUT_LF8 = 2, LAYOUT_PERM = 3, LAYOUT_PAULI = 4, LAYOUT_TILE = 5, LAYOUT_TILE64 = 6, LAYOUT_PERMB = 7 };
+enum Layout { LAYOUT_NONE = 0, LAYOUT_LF8 = 2, LAYOUT_PERM = 3, LAYOUT_PAULI = 4, LAYOUT_TILE = 5, LAYOUT_TILE64 = 6, LAYOUT_PERMB = 7, LAYOUT_LFD = 8 };
 
 struct GraphKey {
     const void *actions;
@@ -76,11 +76,12 @@ struct qg_vec {
     uint64_t B = 0;
     uint32_t N = 0, D = 0, log2L = 0;
     int device = 0;
-    qg::Layout layout = qg::LAYOUT_ROWS32;
+    qg::Layout layout = qg::LAYOUT_NONE;
     size_t stride_bytes = 0;   // per-env stride (0 for the tiled layout)
     size_t state_bytes = 0;    // total resident state size
     uint32_t nxp = 0;          // TILE layout: X-row slots per env (N rounded up to 4); PERMB layout: 16-byte groups per env
     bool has_z = false;        // TILE layout: Z-type rows present (CliffordEnv)
+    bool w64 = false;          // LFD layout: uint64 rows (N > 32); nxp = groups per region
     uint32_t flags = 0;
     int64_t difficulty = 1;
     uint64_t coin_seed = 0;

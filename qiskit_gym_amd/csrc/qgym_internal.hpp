@@ -2,18 +2,13 @@
 //
 // Resident state layouts (also documented in DESIGN.md section 3):
 //
-//  ROWS layout  (CliffordEnv any N<=32, LinearFunctionEnv N>8): the GF(2) matrix of one env is D
-//    rows (D = 2N Clifford, N LinearFunction) in the reference's row order, one machine word per
-//    row (uint32 when D<=32, else uint64), bit c = entry (r, c).  A lane owns 16 contiguous bytes
-//    (RPL = 4 uint32 rows or 2 uint64 rows); an env is L = pow2ceil(ceil(D/RPL)) lanes, padded
-//    with zero rows, so env e starts at byte e*L*16 and a wavefront's load is one fully
-//    coalesced 1 KiB transaction covering 64/L envs.  CliffordEnv N=16: D=32, L=8, 128 B/env,
-//    no padding -- the resident state IS the packed observation.
-//  TILE layout (CliffordEnv N<=16 and LinearFunctionEnv 8<N<=32 without add_inverts; the hot
+//  TILE layout (CliffordEnv N<=16, LinearFunctionEnv 8<N<=32 without add_inverts; the hot
 //    path): thread-per-env, envs in tiles of 64, each tile = R/4 row groups of 1 KiB holding one
 //    uint4 (4 row slots) per lane -- see kernels_qm.hip.
 //  TILE64 layout: the same with uint64 rows (two per 16-byte group) for CliffordEnv 16<N<=32 and
 //    LinearFunctionEnv 32<N<=64 without add_inverts -- see kernels_qm64.hip.
+//  LFD layout  (LinearFunctionEnv 8<N<=64 with add_inverts): the matrix AND its inverse, inversion = a role swap -- see
+//    kernels_lfd.hip.
 //  LF8 layout   (LinearFunctionEnv N<=8): one uint64 per env, byte r = row r.
 //  PERM layout  (PermutationEnv N<=16): one uint64 per env, nibble i = state[i].
 //  PERMB layout (PermutationEnv 16<N<=256): one byte per entry, tiles of 64 envs x ceil(N/16) groups of 1 KiB -- see kernels_perm.hip.
@@ -180,9 +175,10 @@ struct ObsArgs {
 };
 
 // launchers (one translation unit per layout)
-hipError_t rows_step(const StepArgs &a, bool word64, hipStream_t s);
-hipError_t rows_init(const InitArgs &a, bool word64, hipStream_t s);
-hipError_t rows_export(const ObsArgs &a, bool word64, hipStream_t s);
+// LinearFunctionEnv with add_inverts, 8 < N <= 64: state and inverse side by side, `rg` 16-byte groups per matrix (kernels_lfd.hip)
+hipError_t lfd_step(const StepArgs &a, bool w64, uint32_t rg, hipStream_t s);
+hipError_t lfd_init(const InitArgs &a, bool w64, uint32_t rg, const uint32_t *descs, hipStream_t s);
+hipError_t lfd_export(const ObsArgs &a, bool w64, uint32_t rg, const uint8_t *inverted, hipStream_t s);
 
 hipError_t qm_step(const StepArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
 hipError_t qm_init(const InitArgs &a, uint32_t nxp, bool has_z, hipStream_t s);

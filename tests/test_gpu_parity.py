@@ -241,3 +241,63 @@ def test_inverts_on_arbitrary_invertible_states(n):
     _compare_state(ov, gv, D * D, "end")
     for e in (0, 1, B - 1):
         assert gv.solution(e) == ov.env(e).solution()
+
+
+@pytest.mark.parametrize("n", [9, 12, 32, 33, 50, 64])
+def test_linear_function_inverts_from_arbitrary_states(n):
+    """LinearFunctionEnv with add_inverts keeps the matrix AND its inverse (kernels_lfd.hip): set_state of random invertible matrices
+    (the one place a Gauss-Jordan runs), then steps with coins -- every inversion is a role swap and must equal the oracle's
+    Gauss-Jordan inverse bit for bit; all set_state formats; get_state / packed observation read the region that is the state."""
+    gateset = line_gateset("linear_function", n)
+    A = len(gateset)
+    B = 130
+    ov, gv = make_pair("linear_function", n, gateset, B, add_inverts=True, add_perms=False, track_solution=True, max_depth=64)
+    rng = np.random.default_rng(n)
+    mats = np.zeros((B, n, n), dtype=np.int64)
+    for e in range(B):  # random products of elementary row operations on the identity: invertible, dense
+        m = np.eye(n, dtype=np.int64)
+        for _ in range(4 * n):
+            i, j = rng.choice(n, size=2, replace=False)
+            m[i] ^= m[j]
+        mats[e] = m[rng.permutation(n)]
+    for fmt in ("i64", "u8", "packed"):
+        ov.set_state(mats.reshape(B, -1))
+        if fmt == "i64":
+            gv.set_state(mats.reshape(B, -1), "i64")
+        elif fmt == "u8":
+            gv.set_state(mats.reshape(B, -1).astype(np.uint8), "u8")
+        else:
+            words = (mats.astype(np.uint64) << np.arange(n, dtype=np.uint64)).sum(axis=2)
+            gv.set_state(words.astype(np.uint32 if n <= 32 else np.uint64), "packed")
+        for t in range(12):
+            acts = rng.integers(0, A, size=B)
+            coins = rng.integers(0, 2, size=B)
+            _compare_step(ov, gv, acts, coins, label=f"{fmt} t={t}")
+        _compare_state(ov, gv, n * n, f"end {fmt}")
+        dense = ov.observe_dense().reshape(B, n, n).astype(np.uint64)
+        want = (dense << np.arange(n, dtype=np.uint64)).sum(axis=2)
+        got = gv.observe_packed().cpu().numpy()
+        np.testing.assert_array_equal(got.view(np.uint32 if n <= 32 else np.uint64), want.astype(np.uint32 if n <= 32 else np.uint64))
+    for e in (0, B - 1):
+        assert gv.solution(e) == ov.env(e).solution()
+
+
+@pytest.mark.parametrize("n", [12, 40])
+def test_linear_function_singular_state_faults_at_the_first_inversion(n):
+    """The reference's `inverse().expect(...)` panics when maybe_random_invert fires on a singular matrix (linear_function.rs:132-134),
+    not at set_state: stepping with coin = 0 is fine, the first coin = 1 raises."""
+    from qiskit_gym_amd._lib import QGymError
+
+    gateset = line_gateset("linear_function", n)
+    ov, gv = make_pair("linear_function", n, gateset, 6, add_inverts=True, add_perms=False, track_solution=False)
+    m = np.eye(n, dtype=np.int64)
+    m[n - 1] = m[0]  # two equal rows
+    st = np.broadcast_to(m.reshape(1, -1), (6, n * n)).copy()
+    ov.set_state(st)
+    gv.set_state(st, "i64")
+    for t in range(3):
+        _compare_step(ov, gv, np.full(6, t % len(gateset)), np.zeros(6, dtype=np.int64), label=f"t={t}")
+    gv.sync()
+    gv.step(_dev(np.zeros(6), torch.int32), _dev(np.array([0, 1, 0, 0, 1, 0]), torch.uint8))
+    with pytest.raises(QGymError, match="singular"):
+        gv.sync()

@@ -22,9 +22,9 @@ import torch
 from qiskit_gym_amd.vec import VecEnv
 from util import grid_gateset, line_gateset
 
-ALGO = {"C1": 32, "C2": 32, "C3": 160, "C3d": 160, "C5": 494}  # SURVEY.md 8(d), bytes per env-step
+ALGO = {"C1": 32, "C2": 32, "C3": 160, "C3d": 160, "C5": 494, "LFd": 0}  # SURVEY.md 8(d), bytes per env-step
 KERNELS = {"C1": "word_step_kernel<true>", "C2": "word_step_kernel<false>", "C3": "qm_step1_kernel<16, true, false>",
-           "C3d": "qm_inv2_kernel<16, true>", "C5": "ptile_step1c_kernel<20, 8, false>"}
+           "C3d": "qm_inv2_kernel<16, true>", "C5": "ptile_step1c_kernel<20, 8, false>", "LFd": "lfd_step_kernel"}
 
 
 def main():
@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--envs", type=int, default=None)
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--chunk", type=int, default=128)
+    ap.add_argument("--qubits", type=int, default=32, help="LFd: LinearFunctionGym with the reference defaults at this many qubits")
     ap.add_argument("--no-track", action="store_true", help="C3d: add_inverts only (no solution log)")
     ap.add_argument("--coin", default="rand", choices=["rand", "0", "1"], help="C3d: the inversion coins (ablation: never / always invert)")
     args = ap.parse_args()
@@ -48,6 +49,13 @@ def main():
     elif c == "C2":
         gs, B = line_gateset("linear_function", 8), args.envs or 8192
         env = VecEnv("linear_function", 8, gs, B, difficulty=64, **plain)
+        env.reset(0x5EED0002)
+    elif c == "LFd":
+        gs, B = line_gateset("linear_function", args.qubits), args.envs or 65536
+        env = VecEnv("linear_function", args.qubits, gs, B, difficulty=64, add_inverts=True, add_perms=False, track_solution=not args.no_track, max_depth=args.chunk)
+        coins = torch.randint(0, 2, (args.chunk, B), dtype=torch.uint8, device=dev)
+        if args.coin != "rand":
+            coins.fill_(int(args.coin))
         env.reset(0x5EED0002)
     elif c in ("C3", "C3d"):
         gs, B = line_gateset("clifford", 16), args.envs or 65536
