@@ -988,18 +988,19 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
         return hipGetLastError();
     }
     if (a.flags & F_INVERTS) {
-        if constexpr (HAS_Z && NXP <= 16) {
+        if constexpr (HAS_Z && NXP <= 16) {  // CliffordEnv (LinearFunctionEnv with add_inverts lives in kernels_lfd.hip)
             if (!(a.flags & F_GJ) && a.T == 1) {  // every env symplectic, one step per launch: two lanes per env
                 const dim3 grid2(grid_for(2 * a.B, 256));
                 if (feat) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true>), grid2, block, 0, s, a);
                 else hipLaunchKernelGGL((qm_inv2_kernel<NXP, false>), grid2, block, 0, s, a);
                 return hipGetLastError();
             }
+            // the thread-per-env inversion variants (fused rollouts, states not known to be symplectic) always carry FEAT and SEQ
+            if (a.flags & F_GJ) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true, false>), grid, block, 0, s, a);
+            return hipGetLastError();
         }
-        // the thread-per-env inversion variants always carry FEAT and SEQ
-        if (!HAS_Z || (a.flags & F_GJ)) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true, false>), grid, block, 0, s, a);
-        return hipGetLastError();
+        return hipErrorInvalidValue;
     }
     if (!feat && seq && a.T > 1) {  // plain fused rollout
         if (a.num_actions == 0) { /* an empty gateset has no table to read: the register-resident kernel below handles it */
