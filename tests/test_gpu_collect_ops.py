@@ -203,7 +203,8 @@ def test_head_sample_follows_softmax():
     assert chi2 < 30.0, (chi2, counts, B * p)
 
 
-@pytest.mark.parametrize("A,K1,B", [(170, 512, 2500), (12, 64, 300), (190, 1024, 257), (40, 96, 64), (214, 512, 1000), (222, 128, 70)])
+@pytest.mark.parametrize("A,K1,B", [(170, 512, 2500), (12, 64, 300), (190, 1024, 257), (40, 96, 64), (214, 512, 1000), (222, 128, 70),
+                                    (170, 512, 40000)])  # up to 32 768 envs the launch streams 64 KiB chunks, beyond 16 KiB ones: both forms
 def test_mid_head_sample_on_integer_data_is_exact(A, K1, B):
     """qg_policy_mid_head_sample = relu(h W2^T + b2) -> head -> draw, everything in registers.  Small-integer weights keep
     every intermediate exactly representable (h2 <= 256 in bf16), which pins the fragment k orders: the draw must be

@@ -148,3 +148,38 @@ def test_get_state_takes_plain_matrices_without_qiskit():
     qc = c.build_circuit_from_solution  # building circuits needs qiskit
     with pytest.raises(ImportError):
         qc([0], m)
+
+
+# IBM's 27-qubit heavy-hex coupling map (Falcon): the "normal qiskit-gym use" a 16-qubit limit rejected
+HEAVY_HEX_27 = [(0, 1), (1, 2), (1, 4), (2, 3), (3, 5), (4, 7), (5, 8), (6, 7), (7, 10), (8, 9), (8, 11), (10, 12), (11, 14), (12, 13), (12, 15),
+                (13, 14), (14, 16), (15, 18), (16, 19), (17, 18), (18, 21), (19, 20), (19, 22), (21, 23), (22, 25), (23, 24), (24, 25), (25, 26)]
+
+
+def test_permutation_gym_on_a_27_qubit_heavy_hex_device():
+    """PermutationGym.from_coupling_map on a 27-qubit heavy-hex map with the reference's defaults (add_inverts, add_perms,
+    track_solution): the Gym 5-tuple, the observation, twists and the solution against the oracle, a whole episode long."""
+    from oracle import OracleEnv
+
+    env = PermutationGym.from_coupling_map(HEAVY_HEX_27, difficulty=12)
+    assert env.observation_space.shape == (27, 27) and env.num_actions() == 28
+    gs = [(n, tuple(q)) for n, q in env.config["gateset"]]
+    assert all(n == "SWAP" for n, _ in gs)
+    ora = OracleEnv("permutation", 27, gs, difficulty=12)
+    assert env.twists() == tuple(ora.twists())
+    assert len(env.twists()[0]) == 2  # the identity and the lattice's half turn q -> 26 - q
+    rng = np.random.default_rng(27)
+    target = rng.permutation(27).tolist()
+    env.set_state(target)
+    ora.set_state(target)
+    raw = env._raw_env
+    for t in range(40):
+        a, coin = int(rng.integers(28)), int(rng.integers(2))
+        raw.step(a, coin)
+        ora.step(a, coin)
+        assert raw.observe() == ora.observe() and raw.is_final() == ora.is_final()
+        assert np.float32(raw.reward()).view(np.uint32) == ora.reward_bits()
+    assert raw.solution() == ora.solution()
+    obs, info = env.reset(seed=5)
+    assert obs.shape == (27, 27) and (obs.sum(axis=1) == 1).all() and (obs.sum(axis=0) == 1).all()
+    obs, reward, terminated, truncated, info = env.step(3)
+    assert obs.dtype == np.int8 and truncated is False
