@@ -205,7 +205,6 @@ __global__ __launch_bounds__(256) void permb_init_kernel(InitArgs a, uint32_t ng
     if (env >= a.B) return;
     if (a.only_done && !a.done[env]) return;  // qg_vec_reset_done
     uint32_t *img = permb_lds;
-    const uint32_t nb16 = 16u * ng;
     for (uint32_t d = 0; d < 4u * ng; ++d) img[d * lanes + l] = (4u * d) | ((4u * d + 1u) << 8) | ((4u * d + 2u) << 16) | ((4u * d + 3u) << 24);  // identity (permutation.rs:77)
     uint32_t fault = 0;
     if (a.mode == 1) {  // set_state (permutation.rs:168-173): state[i] = x as usize
@@ -232,7 +231,6 @@ __global__ __launch_bounds__(256) void permb_init_kernel(InitArgs a, uint32_t ng
             }
         }
     }
-    (void)nb16;
     if (a.mode == 1) {  // a state that is not a permutation (an entry twice) has no inverse and breaks the fixed-point count: flag it
         for (uint32_t i = 0; i < a.N && !(fault & QG_FAULT_BAD_STATE); ++i) {
             const uint32_t v = lds_get_byte(img, lanes, l, i);

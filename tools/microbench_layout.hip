@@ -107,6 +107,17 @@ __global__ __launch_bounds__(256) void step(Args a) {
         for (int k = 0; k < 8; ++k)
             if (MODE == 5 || g0 == (uint32_t)k || g1 == (uint32_t)k) tile[k * 64 + lane] = r[k];
         finish(a, env, depth, bad, acc);
+    } else if (MODE == 8) {  // TILE32: groups of four qubits, 32 B per lane: [tile][group 0..3][lane][2 x uint4] -- whole 32-byte sectors written
+        uint4 *tile = a.state + (uint64_t)(env >> 6) * 512u;
+        const uint32_t h0 = g0 >> 1, h1 = g1 >> 1;
+        uint4 a0 = tile[(h0 * 64 + lane) * 2], a1 = tile[(h0 * 64 + lane) * 2 + 1];
+        uint4 b0 = a0, b1 = a1;
+        if (h1 != h0) { b0 = tile[(h1 * 64 + lane) * 2]; b1 = tile[(h1 * 64 + lane) * 2 + 1]; }
+        a0.x ^= b1.y; b1.z ^= a0.w; a1.y ^= b0.x;
+        tile[(h0 * 64 + lane) * 2] = a0;
+        tile[(h0 * 64 + lane) * 2 + 1] = a1;
+        if (h1 != h0) { tile[(h1 * 64 + lane) * 2] = b0; tile[(h1 * 64 + lane) * 2 + 1] = b1; }
+        finish(a, env, depth, bad, a0.x ^ b1.z);
     } else if (MODE == 6) {  // mode 0 without any row access: the scalar arrays alone
         finish(a, env, depth, bad, g0 ^ g1);
     } else if (MODE == 7) {  // mode 0, reads only
@@ -200,6 +211,7 @@ int main(int argc, char **argv) {
         run<5>(a, s, "TILE, whole tile read and written");
         run<6>(a, s, "scalar arrays only");
         run<7>(a, s, "TILE, 16-byte gathers, no row writes");
+        run<8>(a, s, "TILE32: 4-qubit groups, 32 B per lane");
         CK(hipFree(a.state)); CK(hipFree(dact)); CK(hipFree(dg)); CK(hipFree(a.depth)); CK(hipFree(a.bad)); CK(hipFree(a.reward)); CK(hipFree(a.done)); CK(hipFree(a.success));
     }
     return 0;
