@@ -79,11 +79,12 @@ def test_constructor_state_clone_and_inverts():
 
 
 @pytest.mark.parametrize("kind,n,inverts", [("clifford", 5, False), ("clifford", 20, False), ("linear_function", 12, False),
-                                            ("linear_function", 40, False), ("clifford", 4, True), ("permutation", 9, False), ("pauli", 4, False)])
+                                            ("linear_function", 40, False), ("clifford", 4, True), ("permutation", 9, False), ("pauli", 4, False),
+                                            ("linear_function", 20, True), ("linear_function", 50, True), ("permutation", 30, True), ("clifford", 20, True)])
 def test_clone_mid_episode_continues_like_the_original(kind, n, inverts):
     """Env: DynClone -- a clone taken mid-episode carries every piece of resident state (including the
     incremental solved mask of the one-step kernels) and then evolves independently."""
-    gs = grid_gateset("permutation", 3, 3) if kind == "permutation" else line_gateset(kind, n)
+    gs = grid_gateset("permutation", 3, 3) if (kind == "permutation" and n == 9) else line_gateset(kind, n)
     kw = dict(add_perms=False, difficulty=6)
     if kind != "pauli":
         kw["add_inverts"] = inverts
@@ -99,15 +100,16 @@ def test_clone_mid_episode_continues_like_the_original(kind, n, inverts):
         env.set_state(start)  # the same scrambled state through the trait's own entry point
         ora.set_state(start)
     for t in range(3):
-        a = int(rng.integers(len(gs)))
-        env.step(a, 0) if kind != "pauli" else env.step(a)
-        ora.step(a, 0)
+        a, coin = int(rng.integers(len(gs))), int(rng.integers(2)) if inverts else 0
+        env.step(a, coin) if kind != "pauli" else env.step(a)
+        ora.step(a, coin)
     twin, ora_twin = env.clone(), ora.clone()
     for t in range(10):
         a, b = int(rng.integers(len(gs))), int(rng.integers(len(gs)))
         for e, o, act in ((env, ora, a), (twin, ora_twin, b)):
-            e.step(act, 0) if kind != "pauli" else e.step(act)
-            o.step(act, 0)
+            coin = int(rng.integers(2)) if inverts else 0  # an inversion: transpose (Clifford), role swap (LinearFunction), scatter (Permutation)
+            e.step(act, coin) if kind != "pauli" else e.step(act)
+            o.step(act, coin)
             assert e.observe() == o.observe(), (kind, t)
             assert np.float32(e.reward()).view(np.uint32) == o.reward_bits(), (kind, t)
             assert e.success() == o.success() and e.is_final() == o.is_final()
