@@ -163,75 +163,116 @@ __device__ inline uint4 expand_chunk(uint32_t bits, uint32_t one) {
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// MetricsTracker with running maxima instead of HashSets (metrics.rs:83-123).
-// `lay` = this env's record: last_gates[N], last_cxs[N], n_layers, n_layers_cnots (int32 each;
-// last_* start at -1).  |layers| == max(last_gates)+1 and |cnot_layers| == max(last_cxs)+1
-// because every inserted layer index is one more than an index already present (or 0).
+struct LayerRec {
+    int32_t *p;
+    __device__ int32_t &operator[](uint32_t i) const { return p[(size_t)i * 64]; }
+};
+__device__ inline LayerRec layer_rec(int32_t *layers, uint64_t env, uint32_t len) {
+    return LayerRec{layers + (env >> 6) * 64 * len + (env & 63)};
+}
 struct LayerDelta {
     int dc, dlc, dl, dg;
 };
-__device__ inline void layers_single(int32_t *lay, uint32_t N, uint32_t t, LayerDelta &d) {
+// The tracker entries one gate can touch, held in registers: every micro-op of a gate (metrics.rs:64-81: CX -> cx(c, t); SWAP -> three cx on
+// the same pair; CZ -> single(t), cx(c, t), single(t); one-qubit gates -> single(q)) reads and writes the layer indices of its own <= 2
+// qubits and the two running maxima only, so the record is gathered once, updated in registers and scattered once -- no store -> load
+// round trips through memory between the micro-ops (that chain cost 5 us per step of 65 536 envs).
+struct LayerRegs {
+    int32_t g[2], c[2];  // last_gates / last_cxs of q0 (index 0) and q1 (index 1)
+    int32_t nl, nlc;     // |layers|, |cnot_layers| as running maxima
+};
+__device__ inline void layers_single(LayerRegs &r, uint32_t N, uint32_t t, uint32_t ti, LayerDelta &d) {  // ti: t is q0 (0) or q1 (1)
     if (t >= N) return;  // metrics.rs:84-86
     d.dg += 1;
-    int32_t gl = lay[t] + 1;
-    lay[t] = gl;
-    int32_t nl = lay[2 * N];
-    if (gl + 1 > nl) {
-        d.dl += gl + 1 - nl;
-        lay[2 * N] = gl + 1;
+    const int32_t gl = r.g[ti] + 1;
+    r.g[ti] = gl;
+    if (gl + 1 > r.nl) {
+        d.dl += gl + 1 - r.nl;
+        r.nl = gl + 1;
     }
 }
-__device__ inline void layers_cx(int32_t *lay, uint32_t N, uint32_t c, uint32_t t, LayerDelta &d) {
+__device__ inline void layers_cx(LayerRegs &r, uint32_t N, uint32_t c, uint32_t t, LayerDelta &d) {  // the pair is always {q0, q1}
     if (c == t || c >= N || t >= N) return;  // metrics.rs:98-103
     d.dc += 1;
     d.dg += 1;
-    int32_t a = lay[c], b = lay[t];
-    int32_t gl = (a > b ? a : b) + 1;
-    lay[c] = gl;
-    lay[t] = gl;
-    int32_t nl = lay[2 * N];
-    if (gl + 1 > nl) {
-        d.dl += gl + 1 - nl;
-        lay[2 * N] = gl + 1;
+    const int32_t gl = (r.g[0] > r.g[1] ? r.g[0] : r.g[1]) + 1;
+    r.g[0] = r.g[1] = gl;
+    if (gl + 1 > r.nl) {
+        d.dl += gl + 1 - r.nl;
+        r.nl = gl + 1;
     }
-    a = lay[N + c];
-    b = lay[N + t];
-    int32_t cl = (a > b ? a : b) + 1;
-    lay[N + c] = cl;
-    lay[N + t] = cl;
-    int32_t nlc = lay[2 * N + 1];
-    if (cl + 1 > nlc) {
-        d.dlc += cl + 1 - nlc;
-        lay[2 * N + 1] = cl + 1;
+    const int32_t cl = (r.c[0] > r.c[1] ? r.c[0] : r.c[1]) + 1;
+    r.c[0] = r.c[1] = cl;
+    if (cl + 1 > r.nlc) {
+        d.dlc += cl + 1 - r.nlc;
+        r.nlc = cl + 1;
     }
 }
 // metrics.rs:64-81 + 135-146: apply the gate to the tracker, return the f32 penalty.
 // (This translation unit is compiled with -ffp-contract=off: no fused multiply-add.)
-__device__ inline float layers_penalty(int32_t *lay, uint32_t N, uint32_t desc, const float w[4]) {
-    uint32_t kind = desc & 0xFFu, q0 = (desc >> 8) & 0xFFu, q1 = (desc >> 16) & 0xFFu;
+// `lay` = this env's record: last_gates[N], last_cxs[N], n_layers, n_layers_cnots (int32 each; last_* start at -1), held like the state:
+// tiles of 64 envs, entry-major, so the 64 lanes of a wave touch at most 2N + 2 rows of 256 B instead of 64 separate records.
+// |layers| == max(last_gates)+1 and |cnot_layers| == max(last_cxs)+1 because every inserted layer index is one more than an index
+// already present (or 0): running maxima instead of the reference's HashSets (metrics.rs:83-123).
+// Split in two so that a step kernel can issue the tracker's loads together with its state loads (one memory round trip, not two):
+// layers_begin gathers, layers_commit updates in registers, scatters what changed and returns the penalty.
+struct LayerTxn {
+    LayerRec lay;
+    LayerRegs r;
+    uint32_t N, desc;
+};
+__device__ inline LayerTxn layers_begin(const LayerRec lay, uint32_t N, uint32_t desc) {
+    const uint32_t kind = desc & 0xFFu, q0 = (desc >> 8) & 0xFFu;
+    const uint32_t q1 = kind >= QG_CX ? (desc >> 16) & 0xFFu : q0;
+    const uint32_t i0 = q0 < N ? q0 : 0u, i1 = q1 < N ? q1 : 0u;  // out-of-range qubits are never applied (the guards above); keep the loads in bounds
+    LayerTxn t;
+    t.lay = lay; t.N = N; t.desc = desc;
+    t.r.g[0] = lay[i0]; t.r.g[1] = lay[i1];
+    t.r.c[0] = lay[N + i0]; t.r.c[1] = lay[N + i1];
+    t.r.nl = lay[2 * N]; t.r.nlc = lay[2 * N + 1];
+    return t;
+}
+__device__ inline float layers_commit(const LayerTxn &t, const float w[4]) {
+    const LayerRec lay = t.lay;
+    const uint32_t N = t.N, kind = t.desc & 0xFFu, q0 = (t.desc >> 8) & 0xFFu;
+    const bool two = kind >= QG_CX;
+    const uint32_t q1 = two ? (t.desc >> 16) & 0xFFu : q0;
+    const LayerRegs r0 = t.r;
+    LayerRegs r = t.r;
     LayerDelta d = {0, 0, 0, 0};
     switch (kind) {
-    case QG_CX: layers_cx(lay, N, q0, q1, d); break;
+    case QG_CX: layers_cx(r, N, q0, q1, d); break;
     case QG_SWAP:
-        layers_cx(lay, N, q0, q1, d);
-        layers_cx(lay, N, q1, q0, d);
-        layers_cx(lay, N, q0, q1, d);
+        layers_cx(r, N, q0, q1, d);
+        layers_cx(r, N, q1, q0, d);
+        layers_cx(r, N, q0, q1, d);
         break;
-    case QG_CZ:
-        layers_single(lay, N, q1, d);
-        layers_cx(lay, N, q0, q1, d);
-        layers_single(lay, N, q1, d);
+    case QG_CZ:  // with q0 == q1 only the two single(t) act, on q1's registers
+        layers_single(r, N, q1, 1, d);
+        layers_cx(r, N, q0, q1, d);
+        layers_single(r, N, q1, 1, d);
         break;
-    default: layers_single(lay, N, q0, d); break;
+    default: layers_single(r, N, q0, 0, d); break;
     }
-    float t0 = w[0] * (float)d.dc;
-    float t1 = w[1] * (float)d.dlc;
-    float t2 = w[2] * (float)d.dl;
-    float t3 = w[3] * (float)d.dg;
+    // q0's entries first, q1's second: when both are the same qubit (a two-qubit gate on one qubit) q1's registers hold the truth
+    if (r.g[0] != r0.g[0] && q0 < N && q0 != q1) lay[q0] = r.g[0];
+    if (r.c[0] != r0.c[0] && q0 < N && q0 != q1) lay[N + q0] = r.c[0];
+    if (!two && r.g[0] != r0.g[0] && q0 < N) lay[q0] = r.g[0];
+    if (two && r.g[1] != r0.g[1] && q1 < N) lay[q1] = r.g[1];
+    if (two && r.c[1] != r0.c[1] && q1 < N) lay[N + q1] = r.c[1];
+    if (r.nl != r0.nl) lay[2 * N] = r.nl;
+    if (r.nlc != r0.nlc) lay[2 * N + 1] = r.nlc;
+    const float t0 = w[0] * (float)d.dc;
+    const float t1 = w[1] * (float)d.dlc;
+    const float t2 = w[2] * (float)d.dl;
+    const float t3 = w[3] * (float)d.dg;
     float s = t0 + t1;
     s = s + t2;
     s = s + t3;
     return s;
+}
+__device__ inline float layers_penalty(const LayerRec lay, uint32_t N, uint32_t desc, const float w[4]) {
+    return layers_commit(layers_begin(lay, N, desc), w);
 }
 
 }  // namespace qg

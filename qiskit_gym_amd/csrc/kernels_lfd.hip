@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void lfd_step_kernel(StepArgs a, uint32_t RG) 
     const uint32_t desc = a.descs[ai];
     float penalty = in_range ? a.gates[ai].penalty : 0.0f;
     if (!a.coins) coin = (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, a.env_base + env, step_clock(a)) >> 63);
-    if ((a.flags & F_LAYERS) && in_range && j == 0) penalty = layers_penalty(a.layers + env * (2 * N + 2), N, desc, a.w);
+    if ((a.flags & F_LAYERS) && in_range && j == 0) penalty = layers_penalty(layer_rec(a.layers, env, 2 * N + 2), N, desc, a.w);
     const uint32_t kind = desc & 0xFFu, q0 = (desc >> 8) & 0xFFu, q1 = (desc >> 16) & 0xFFu;
     const bool is_cx = in_range && kind == QG_CX && q0 != q1, is_swap = in_range && kind == QG_SWAP && q0 != q1;  // other kinds: ignored (:241)
     uint32_t fault = 0;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64) void lfd_init_kernel(InitArgs a, uint32_t RG, c
     a.sol_len[env * 2] = 0;
     a.sol_len[env * 2 + 1] = 0;
     if (a.layers) {
-        int32_t *lay = a.layers + env * a.layers_len;
+        const LayerRec lay = layer_rec(a.layers, env, a.layers_len);
         for (uint32_t i = 0; i + 2 < a.layers_len; ++i) lay[i] = -1;
         lay[a.layers_len - 2] = 0;
         lay[a.layers_len - 1] = 0;

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void ptile_step_kernel(PTArgs pa) {
         if (in_range) {
             prog = pa.prog[act];
             penalty = a.gates[act].penalty;
-            if (FEAT && (a.flags & F_LAYERS)) penalty = layers_penalty(a.layers + env * (2 * N + 2), N, a.descs[act], a.w);
+            if (FEAT && (a.flags & F_LAYERS)) penalty = layers_penalty(layer_rec(a.layers, env, 2 * N + 2), N, a.descs[act], a.w);
         }
         const uint32_t qa = (uint32_t)prog & 31u, qb = (uint32_t)(prog >> 5) & 31u, m = (uint32_t)(prog >> 10) & 0xFFFFu;
         uint32_t n_removed = 0;
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256) void ptile_step1_kernel(PTArgs pa) {
     if (in_range) {
         prog = pa.prog[act];
         penalty = a.gates[act].penalty;
-        if (FEAT && (a.flags & F_LAYERS)) penalty = layers_penalty(a.layers + env * (2 * N + 2), N, a.descs[act], a.w);
+        if (FEAT && (a.flags & F_LAYERS)) penalty = layers_penalty(layer_rec(a.layers, env, 2 * N + 2), N, a.descs[act], a.w);
     }
     const uint32_t qa = (uint32_t)prog & 31u, qb = (uint32_t)(prog >> 5) & 31u, m = (uint32_t)(prog >> 10) & 0xFFFFu;
     uint32_t n_removed = 0;
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(256) void ptile_step1c_kernel(PTArgs pa) {
     if (in_range) {
         prog = pa.prog[act];
         penalty = a.gates[act].penalty;
-        if (FEAT && (a.flags & F_LAYERS)) penalty = layers_penalty(a.layers + env * (2 * N + 2), N, a.descs[act], a.w);
+        if (FEAT && (a.flags & F_LAYERS)) penalty = layers_penalty(layer_rec(a.layers, env, 2 * N + 2), N, a.descs[act], a.w);
     }
     const uint32_t qa = (uint32_t)prog & 31u, qb = (uint32_t)(prog >> 5) & 31u, m = (uint32_t)(prog >> 10) & 0xFFFFu;
     uint32_t n_removed = 0;
@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(256) void ptile_init_kernel(PTArgs pa) {
     a.sol_len[env * 2] = 0;
     a.sol_len[env * 2 + 1] = 0;
     if (a.layers) {
-        int32_t *lay = a.layers + env * (2 * a.N + 2);
+        const LayerRec lay = layer_rec(a.layers, env, (2 * a.N + 2));
         for (uint32_t i = 0; i < 2 * a.N; ++i) lay[i] = -1;
         lay[2 * a.N] = 0;
         lay[2 * a.N + 1] = 0;
@@ -1425,7 +1425,7 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
     a.sol_len[env * 2] = 0;
     a.sol_len[env * 2 + 1] = 0;
     if (a.layers) {
-        int32_t *lay = a.layers + env * (2 * N + 2);
+        const LayerRec lay = layer_rec(a.layers, env, (2 * N + 2));
         for (uint32_t i = 0; i < 2 * N; ++i) lay[i] = -1;
         lay[2 * N] = 0;
         lay[2 * N + 1] = 0;

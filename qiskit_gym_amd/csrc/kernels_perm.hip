@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void permb_step1_kernel(StepArgs a, uint32_t n
     if (in_range) {
         penalty = a.gates[act].penalty;
         const uint32_t desc = a.descs[act];
-        if (a.flags & F_LAYERS) penalty = layers_penalty(a.layers + env * (2 * a.N + 2), a.N, desc, a.w);
+        if (a.flags & F_LAYERS) penalty = layers_penalty(layer_rec(a.layers, env, 2 * a.N + 2), a.N, desc, a.w);
         uint32_t q0, q1;
         if (permb_is_swap(desc, q0, q1)) {  // permutation.rs:110-114
             uint8_t *p0 = permb_byte(a.state, env, ng, q0), *p1 = permb_byte(a.state, env, ng, q1);
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void permb_step_kernel(StepArgs a, uint32_t ng
         if (in_range) {
             penalty = a.gates[act].penalty;
             const uint32_t desc = a.descs[act];
-            if (a.flags & F_LAYERS) penalty = layers_penalty(a.layers + env * (2 * a.N + 2), a.N, desc, a.w);
+            if (a.flags & F_LAYERS) penalty = layers_penalty(layer_rec(a.layers, env, 2 * a.N + 2), a.N, desc, a.w);
             uint32_t q0, q1;
             if (permb_is_swap(desc, q0, q1)) {
                 const uint32_t v0 = lds_get_byte(cur, lanes, l, q0), v1 = lds_get_byte(cur, lanes, l, q1);
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void permb_init_kernel(InitArgs a, uint32_t ng
     a.sol_len[env * 2] = 0;
     a.sol_len[env * 2 + 1] = 0;
     if (a.layers) {
-        int32_t *lay = a.layers + env * a.layers_len;
+        const LayerRec lay = layer_rec(a.layers, env, a.layers_len);
         for (uint32_t i = 0; i + 2 < a.layers_len; ++i) lay[i] = -1;
         lay[a.layers_len - 2] = 0;
         lay[a.layers_len - 1] = 0;

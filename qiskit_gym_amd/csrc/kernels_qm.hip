@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
         if (in_range) g = a.gates[act];
         float penalty = g.penalty;
         if (FEAT && (a.flags & F_LAYERS) && in_range)
-            penalty = layers_penalty(a.layers + env * (2 * a.N + 2), a.N, a.descs[act], a.w);
+            penalty = layers_penalty(layer_rec(a.layers, env, 2 * a.N + 2), a.N, a.descs[act], a.w);
 
         dirty |= qm_apply<NXP, HAS_Z>(s, g.ops);  // apply_gate_to_state (clifford.rs:331)
 
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void qm_inv2_kernel(StepArgs a) {
     }
     uint32_t fault = 0;
     float penalty = g.penalty;
-    if (FEAT && (a.flags & F_LAYERS) && in_range && h == 0) penalty = layers_penalty(a.layers + env * (2 * N + 2), N, a.descs[act], a.w);
+    if (FEAT && (a.flags & F_LAYERS) && in_range && h == 0) penalty = layers_penalty(layer_rec(a.layers, env, 2 * N + 2), N, a.descs[act], a.w);
 
     // ---- apply_gate_to_state (clifford.rs:331): the 4x4 GF(2) map on {X[q0], Z[q0], X[q1], Z[q1]} --------------------------
     uint32_t dirty = 0;  // this lane's groups that changed (bit k: group 4h + k)
@@ -801,7 +801,7 @@ __device__ inline void qm_init_finish(const InitArgs &a, uint64_t env, const QmR
     a.sol_len[env * 2] = 0;
     a.sol_len[env * 2 + 1] = 0;
     if (a.layers) {
-        int32_t *lay = a.layers + env * a.layers_len;
+        const LayerRec lay = layer_rec(a.layers, env, a.layers_len);
         for (uint32_t i = 0; i + 2 < a.layers_len; ++i) lay[i] = -1;
         lay[a.layers_len - 2] = 0;
         lay[a.layers_len - 1] = 0;

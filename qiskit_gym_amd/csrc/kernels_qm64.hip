@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void q64_step_kernel(StepArgs a) {
         GateEntry g = {Q64_IDENTITY << 12, 0.0f};
         if (in_range) g = a.gates[act];
         float penalty = g.penalty;
-        if (EXTRA && (a.flags & F_LAYERS) && in_range) penalty = layers_penalty(a.layers + env * (2 * a.N + 2), a.N, a.descs[act], a.w);
+        if (EXTRA && (a.flags & F_LAYERS) && in_range) penalty = layers_penalty(layer_rec(a.layers, env, 2 * a.N + 2), a.N, a.descs[act], a.w);
         dirty |= q64_apply<NS, HAS_Z>(s, g.ops);  // clifford.rs:331
         if (EXTRA && (a.flags & F_TRACK)) {  // clifford.rs:334-340
             if ((uint32_t)(sol_n + sol_b) < a.sol_cap) {
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void q64_step1_kernel(StepArgs a) {
     if (in_range) {
         const GateEntry g = a.gates[act];
         penalty = g.penalty;
-        if (FEAT && (a.flags & F_LAYERS)) penalty = layers_penalty(a.layers + env * (2 * a.N + 2), a.N, a.descs[act], a.w);
+        if (FEAT && (a.flags & F_LAYERS)) penalty = layers_penalty(layer_rec(a.layers, env, 2 * a.N + 2), a.N, a.descs[act], a.w);
         const uint32_t q0 = g.ops & 63u, q1 = (g.ops >> 6) & 63u, m = (g.ops >> 12) & 0xFFFFu;
         if (m != Q64_IDENTITY) {
             constexpr uint32_t gsh = HAS_Z ? 0u : 1u;
@@ -474,7 +474,7 @@ __device__ inline void q64_init_finish(const InitArgs &a, uint64_t env, const Q6
     a.sol_len[env * 2] = 0;
     a.sol_len[env * 2 + 1] = 0;
     if (a.layers) {
-        int32_t *lay = a.layers + env * a.layers_len;
+        const LayerRec lay = layer_rec(a.layers, env, a.layers_len);
         for (uint32_t i = 0; i + 2 < a.layers_len; ++i) lay[i] = -1;
         lay[a.layers_len - 2] = 0;
         lay[a.layers_len - 1] = 0;

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void word_step_kernel(StepArgs a) {
         if (in_range) g = a.gates[act];
         float penalty = g.penalty;
         if ((a.flags & F_LAYERS) && in_range)
-            penalty = layers_penalty(a.layers + env * (2 * a.N + 2), a.N, a.descs[act], a.w);
+            penalty = layers_penalty(layer_rec(a.layers, env, 2 * a.N + 2), a.N, a.descs[act], a.w);
         s = PERM ? perm_apply(s, g.ops) : lf8_apply(s, g.ops);
 
         // solution push: Permutation only for a valid action (permutation.rs:210-216),
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void word_init_kernel(InitArgs a) {
     a.sol_len[env * 2] = 0;
     a.sol_len[env * 2 + 1] = 0;
     if (a.layers) {
-        int32_t *lay = a.layers + env * a.layers_len;
+        const LayerRec lay = layer_rec(a.layers, env, a.layers_len);
         for (uint32_t i = 0; i + 2 < a.layers_len; ++i) lay[i] = -1;
         lay[a.layers_len - 2] = 0;
         lay[a.layers_len - 1] = 0;

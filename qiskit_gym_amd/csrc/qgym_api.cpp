@@ -496,7 +496,7 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     }
     if (layers) {
         p->layers_len = 2 * N + 2;
-        HIP_TRY_V(hipMalloc(&p->layers, sizeof(int32_t) * (size_t)p->layers_len * batch));
+        HIP_TRY_V(hipMalloc(&p->layers, sizeof(int32_t) * (size_t)p->layers_len * (((size_t)batch + 63) & ~(size_t)63)));  // tiles of 64 envs (layer_rec)
     }
     HIP_TRY_V(hipMalloc(&p->d_gates, sizeof(GateEntry) * table.size()));
     HIP_TRY_V(hipMalloc(&p->d_descs, sizeof(uint32_t) * descs.size()));

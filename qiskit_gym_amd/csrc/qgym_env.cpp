@@ -206,7 +206,7 @@ int qg_env_clone(const qg_env *e, qg_env **out) {  // Env: DynClone -- deep copy
         {d->error, s->error, 4},
         {d->sol_len, s->sol_len, 8},
         {d->sol, s->sol, (size_t)s->sol_cap * 4},
-        {d->layers, s->layers, (size_t)s->layers_len * 4},
+        {d->layers, s->layers, (size_t)s->layers_len * 4 * 64},  // the env's tile (layer_rec)
         {d->bad, s->bad, s->layout == LAYOUT_LFD ? (size_t)16 : s->layout == LAYOUT_TILE64 ? (size_t)8 : (size_t)4},  // incremental solved masks
         {d->perm_idx, s->perm_idx, (size_t)4},                                 // PauliEnv current_perm_idx (pauli.rs:661)
     };

@@ -88,7 +88,7 @@ struct StepArgs {
     uint32_t *error;
     uint32_t *sol;            // [sol_cap][B] solution log, step-major (slots from the front: solution, from the back: solution_inv)
     int32_t *sol_len;         // [B][2]
-    int32_t *layers;          // F_LAYERS: [B][2N + 2] last_gates, last_cxs, then (n_layers, n_layers_cnots)
+    int32_t *layers;          // F_LAYERS: [B/64][2N + 2][64] last_gates, last_cxs, then (n_layers, n_layers_cnots) (layer_rec)
     float *rewards_seq;       // [T][B] or null
     uint8_t *dones_seq;       // [T][B] or null
     uint64_t B;

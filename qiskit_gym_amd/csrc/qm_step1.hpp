@@ -50,7 +50,9 @@ __device__ inline bool qm_step1_body(const StepArgs &a, uint32_t G, uint64_t env
     if (in_range) {
         const GateEntry g = a.gates[act];
         penalty = g.penalty;
-        if (FEAT && (a.flags & F_LAYERS)) penalty = layers_penalty(a.layers + env * (2 * a.N + 2), a.N, a.descs[act], a.w);
+        const bool layered = FEAT && (a.flags & F_LAYERS);
+        LayerTxn lt;
+        if (layered) lt = layers_begin(layer_rec(a.layers, env, 2 * a.N + 2), a.N, a.descs[act]);  // its loads fly with the state's
         const uint32_t q0 = g.ops & 31u, q1 = (g.ops >> 5) & 31u, m = (g.ops >> 10) & 0xFFFFu;
         if (m != QM_IDENTITY) {  // "no gate" (e.g. a two-qubit gate on equal qubits) changes nothing
             constexpr uint32_t gsh = HAS_Z ? 1u : 2u;
@@ -81,6 +83,7 @@ __device__ inline bool qm_step1_body(const StepArgs &a, uint32_t G, uint64_t env
             bad = (bad & ~(1u << q1)) | (b1 << q1);
             bad = (bad & ~(1u << q0)) | (b0 << q0);
         }
+        if (layered) penalty = layers_commit(lt, a.w);
     }
     if (FEAT && (a.flags & F_TRACK)) {  // clifford.rs:334-340
         if ((uint32_t)sol_n < a.sol_cap) sol_at(a, env, (uint32_t)sol_n++) = sol_word_framed(act, false);
