@@ -328,12 +328,13 @@ class RolloutCollector:
         self._x = torch.empty((env.batch, self.obs_size), dtype=dtype, device=env.device)  # policy input
         self.clock = torch.zeros(1, dtype=torch.int64, device=env.device)  # collector steps taken so far
         env.set_clock(self.clock)
-        # the two policy-layer kernels fill LDS with a weight slab per workgroup: worth it from a few thousand envs on
-        # (B = 1 024: 50 us per step with them, 43 us with the library GEMMs; B = 8 192: 62 against 66)
+        # the policy-layer kernels at every batch size: below ~ 4 096 envs the launches take their small-batch shapes (a 32-env tile per
+        # wave / workgroup, weight fragments straight from L2: CliffordGym 16q x 1 024 envs 33 us per step against 42 us on library GEMMs)
+        words_auto = use_bit_embedding is None and env.batch < 4096  # the first layer from packed WORDS has no small-batch shape: library GEMM there
         if use_bit_embedding is None:
-            use_bit_embedding = env.batch >= 4096
+            use_bit_embedding = True
         if use_fused_head is None:
-            use_fused_head = env.batch >= 4096
+            use_fused_head = True
         self._heads = None
         self._embed = None  # (packed first-layer weight, f32 bias): the first layer reads the env's bits directly
         if isinstance(self.policy, BasicPolicy):
@@ -349,7 +350,7 @@ class RolloutCollector:
         # words the rollout stores anyway (64-bit row words, even row count)
         self._embed_words = None
         self._cur_words = None
-        if (self._embed is None and use_bit_embedding and isinstance(self.policy, BasicPolicy) and dtype == torch.bfloat16 and store_obs == "packed"
+        if (self._embed is None and use_bit_embedding and not words_auto and isinstance(self.policy, BasicPolicy) and dtype == torch.bfloat16 and store_obs == "packed"
                 and env.packed_word_bytes == 8 and env.packed_words_per_env == r and self.policy.embeddings.in_features == self.obs_size):
             try:
                 self._embed_words = (pack_embed_words(self.policy.embeddings.weight, r, c), self.policy.embeddings.bias.detach().float().contiguous())

@@ -326,6 +326,72 @@ __global__ __launch_bounds__(EMB_THREADS, 1) void embed_bits_kernel(EmbedArgs a)
 }
 
 
+// Small batches (the reference collects 1 024 episodes at a time, rl/configs.py:134): embed_bits_kernel's workgroup passes 512 envs under
+// a 64-column slab it first loads into LDS, so 1 024 envs are 16 workgroups x 256 MFMAs per wave -- 14 us on 16 CUs.  Here a wave owns
+// one tile of 32 envs x one slab and takes the slab's fragments from L2 straight into registers (the packed layout is fragment order:
+// 1 KiB per wave load, one group of 8 k-steps ahead); the four waves of a workgroup share the slab (their loads meet in the CU's
+// vector cache) on four env tiles.  Same packed weights, same expansion, same k order: bit-identical activations.
+constexpr uint32_t EMS_WAVES = 4;
+
+template <uint32_t G>
+__global__ __launch_bounds__(64 * EMS_WAVES) void embed_small_kernel(EmbedArgs a) {
+    constexpr uint32_t GP = (G + 1u) & ~1u;
+    constexpr uint32_t slab_vec = GP * 8u * 2u * 64u;  // uint4 per slab (the padding group of an odd G has zero weights: skipped)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t slab = blockIdx.x % a.n_slabs;
+    const uint64_t tile = (uint64_t)(blockIdx.x / a.n_slabs) * EMS_WAVES + wave;
+    if (tile * 32u >= a.B) return;  // wave-uniform; no barrier below
+    const uint32_t r = lane & 31u, h = lane >> 5;
+    const uint32_t sh[2] = {4u * h, 8u + 4u * h};
+    uint64_t env = tile * 32u + r;
+    env = env < a.B ? env : a.B - 1;  // tail: duplicate the last env, its rows are not stored
+    const uint4 *ps = a.state + (env >> 6) * (uint64_t)(G * 64u) + (env & 63u);
+    const uint4 *pw = a.wp + (uint64_t)slab * slab_vec + lane;  // fragment (k-step s, nb) = pw[(2 s + nb) * 64]
+    uint4 bits[G], wb[2][8][2];
+    auto fetch = [&](uint32_t g, uint4 (&b)[8][2]) {
+#pragma unroll
+        for (uint32_t ss = 0; ss < 8; ++ss) {
+            b[ss][0] = pw[((8u * g + ss) * 2u + 0u) * 64u];
+            b[ss][1] = pw[((8u * g + ss) * 2u + 1u) * 64u];
+        }
+    };
+    fetch(0, wb[0]);
+#pragma unroll
+    for (uint32_t g = 0; g < G; ++g) bits[g] = ps[g * 64u];
+    const uint32_t n0 = slab * EMB_SLAB + 2u * r;
+    const float bias0 = a.bias ? a.bias[n0] : 0.0f, bias1 = a.bias ? a.bias[n0 + 1] : 0.0f;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (uint32_t q = 0; q < 16; ++q) acc0[q] = acc1[q] = 0.0f;
+#pragma unroll
+    for (uint32_t g = 0; g < G; ++g) {
+        if (g + 1u < G) fetch(g + 1u, wb[(g + 1u) & 1u]);
+#pragma unroll
+        for (uint32_t ss = 0; ss < 8; ++ss) {
+            const uint32_t comp = ss >> 1;
+            const uint32_t word = comp == 0 ? bits[g].x : comp == 1 ? bits[g].y : comp == 2 ? bits[g].z : bits[g].w;
+            const bf16x8 af = emb_expand(word, sh[ss & 1u]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, wb[g & 1u][ss][0]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, wb[g & 1u][ss][1]), acc1, 0, 0, 0);
+        }
+    }
+    // x 0.5 + bias (exact scaling: one rounding), ReLU, bf16; C layout: column pair of this slab = lane & 31, env row = (q & 3) + 8 (q >> 2) + 4 h
+    const uint64_t ldw = a.ld_out >> 1;  // dwords per output row
+    uint32_t *out = a.out + slab * (EMB_SLAB / 2u) + r;
+#pragma unroll
+    for (uint32_t q = 0; q < 16; ++q) {
+        float v0 = __builtin_fmaf(acc0[q], 0.5f, bias0), v1 = __builtin_fmaf(acc1[q], 0.5f, bias1);
+        if (a.relu) {
+            v0 = __builtin_amdgcn_fmed3f(v0, 0.0f, __builtin_inff());
+            v1 = __builtin_amdgcn_fmed3f(v1, 0.0f, __builtin_inff());
+        }
+        const f32x2 v = {v0, v1};
+        const uint64_t e = tile * 32u + (q & 3u) + 8u * (q >> 2) + 4u * h;
+        if (e < a.B) out[e * ldw] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    }
+}
+
+
 // =================================================================================================
 // Policy head + sampling in one kernel: logits = h W^T + b never leave the registers.
 //
@@ -383,6 +449,35 @@ struct HeadArgs {
 };
 
 __device__ __forceinline__ float head_xhalf(float x) { return __shfl_xor(x, 32, 64); }
+
+// One logit of the draw as a function (mid_head_small_kernel; head_draw below spells the same operations out in its loop, whose
+// register allocation the big kernels are tuned around): softmax terms relative to the env's maximum m and the exponential race of
+// qg_sample_actions (kernels_collect.hip).
+struct DrawLane {
+    float best_q = __builtin_huge_valf(), best_d = 0.0f, ssum = 0.0f, wsum = 0.0f;
+    uint32_t best_a = 0xFFFFFFFFu;
+};
+__device__ __forceinline__ void draw_logit(DrawLane &r, float logit, float m, uint32_t act, uint32_t bhi, uint32_t blo) {
+    const float d = logit - m;
+    const float ex = __builtin_amdgcn_exp2f(d * 1.44269504088896340736f);  // raw v_exp_f32: d <= 0, a flushed tiny result is 0 either way
+    r.ssum += ex;
+    r.wsum = __builtin_fmaf(ex, d, r.wsum);
+    uint32_t x = bhi + act * 0x9E3779B9u;  // sample_uniform(base, act) (kernels_collect.hip)
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= blo;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    // u = ((x >> 9) + 0.5) 2^-23, built as (1 + (x >> 9) 2^-23) - (1 - 2^-24): both steps exact, bit-identical to sample_uniform
+    const float u = __uint_as_float((x >> 9) | 0x3F800000u) - 0.99999994039535522461f;
+    // the race compares -log(u) / ex; log2 instead of ln scales every key by the same positive constant
+    const float qv = -__builtin_amdgcn_logf(u) * __builtin_amdgcn_rcpf(ex);  // padding rows: ex = 0, q = inf, never wins
+    const bool take = qv < r.best_q;  // ascending action order within the lane: ties keep the lower index
+    r.best_q = take ? qv : r.best_q;
+    r.best_a = take ? act : r.best_a;
+    r.best_d = take ? d : r.best_d;
+}
 
 // The draw from register-resident logits: acc[t][q] = logit of action 32 t + (q & 3) + 8 (q >> 2) + 4 h of env `env` (C layout of the
 // transposed product), the last padded row is the value head.  Same race as qg_sample_actions (kernels_collect.hip).
@@ -650,6 +745,200 @@ __global__ __launch_bounds__(64 * MH_WAVES, 2) void mid_head_sample_kernel(MidHe
                 base = __shfl(base, first);
                 if (fin) ma.done_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)env;
             }
+        }
+    }
+}
+
+
+// Small batches (the reference collects 1 024 episodes at a time, rl/configs.py:134): mid_head_sample_kernel gives a workgroup 128 envs
+// and lets it stream all 358 KB of weights, so 1 024 envs occupy 8 CUs for 23 us.  Here a workgroup's four waves share ONE tile of 32
+// envs: wave w multiplies feature tiles 2w, 2w + 1 of the middle layer and action tiles w, w + 4 of the head, so nobody shares a
+// weight fragment and each goes from L2 straight into registers (the packed layouts are already in fragment order: 1 KiB per wave
+// load), 8 k-steps ahead.  h2 crosses the waves through 16 KiB of LDS, the draw runs on a quarter of the logits per wave with the
+// env's maximum and the partial sums / race winners exchanged through LDS, wave 0 finishes (and steps the env).  Same packed weights,
+// same k order, same keys: actions are those of mid_head_sample_kernel; logp / entropy sum their terms in another order.
+constexpr uint32_t MHS_WAVES = 4;
+constexpr uint32_t MHS_GROUP = 8;  // k-steps per register group of the middle layer (two groups in flight)
+
+template <uint32_t TILES>
+__global__ __launch_bounds__(64 * MHS_WAVES, 1) void mid_head_small_kernel(MidHeadArgs ma) {
+    static_assert(MID_FT == 2 * MHS_WAVES && TILES <= 2 * MHS_WAVES, "two feature tiles and <= two action tiles per wave");
+    __shared__ uint4 hbuf[2u * MID_FT * 64u];       // h2 as the head's B fragments, k-step major
+    __shared__ float xmax[MHS_WAVES][32];
+    __shared__ float part[MHS_WAVES][6][32];         // ssum, wsum, best_q, best_d, best_a, value
+    const HeadArgs &a = ma.head;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t c = lane & 31u, h = lane >> 5;
+    const uint64_t env_raw = (uint64_t)blockIdx.x * 32u + c;
+    const bool live = env_raw < a.B;
+    const uint64_t env = live ? env_raw : a.B - 1;
+    const uint4 *hrow = a.h + env * (a.ld_h / 8u) + h;
+    const uint4 ones = make_uint4(h == 0 ? 0x3F803F80u : 0u, 0u, 0u, 0u);
+    const uint32_t ks1 = ma.K1 / 16u;  // real k-steps of the middle layer (a multiple of MHS_GROUP: the launcher checks), then the bias k-step
+    // ---- middle layer: x[i] = feature tile 2 wave + i ----
+    const uint4 *wa = ma.w2p + (2u * wave) * 64u + lane;  // fragment (k-step s, tile 2 wave + i) = wa[(s * MID_FT + i) * 64]
+    f32x16 x[2];
+#pragma unroll
+    for (uint32_t i = 0; i < 2; ++i)
+#pragma unroll
+        for (uint32_t q = 0; q < 16; ++q) x[i][q] = 0.0f;
+    uint4 fa[2][MHS_GROUP][2], fb[2][MHS_GROUP];
+    auto fetch = [&](uint32_t s0, uint4 (&A)[MHS_GROUP][2], uint4 (&Bv)[MHS_GROUP]) {
+#pragma unroll
+        for (uint32_t j = 0; j < MHS_GROUP; ++j) {
+            Bv[j] = hrow[2u * (s0 + j)];
+            A[j][0] = wa[((s0 + j) * MID_FT) * 64u];
+            A[j][1] = wa[((s0 + j) * MID_FT + 1u) * 64u];
+        }
+    };
+    auto multiply = [&](const uint4 (&A)[MHS_GROUP][2], const uint4 (&Bv)[MHS_GROUP]) {
+#pragma unroll
+        for (uint32_t j = 0; j < MHS_GROUP; ++j) {
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, Bv[j]);
+            x[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[j][0]), bf, x[0], 0, 0, 0);
+            x[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[j][1]), bf, x[1], 0, 0, 0);
+        }
+    };
+    fetch(0, fa[0], fb[0]);
+    const uint4 bias0 = wa[(ks1 * MID_FT) * 64u], bias1 = wa[(ks1 * MID_FT + 1u) * 64u];
+    for (uint32_t s0 = 0; s0 < ks1; s0 += 2u * MHS_GROUP) {  // two groups per trip: the register buffers are indexed statically
+        if (s0 + MHS_GROUP < ks1) fetch(s0 + MHS_GROUP, fa[1], fb[1]);
+        multiply(fa[0], fb[0]);
+        if (s0 + MHS_GROUP < ks1) {
+            if (s0 + 2u * MHS_GROUP < ks1) fetch(s0 + 2u * MHS_GROUP, fa[0], fb[0]);
+            multiply(fa[1], fb[1]);
+        }
+    }
+    // ---- the head's weights for this wave's action tiles (wave, wave + 4), all 17 k-steps, on their way during the epilogue of the middle layer ----
+    const bool two = wave + MHS_WAVES < TILES, any = wave < TILES;  // wave-uniform
+    const uint4 *wh = a.wp + wave * 64u + lane;  // fragment (k-step s, tile wave + 4 i) = wh[(s * TILES + 4 i) * 64]
+    uint4 ha[2u * MID_FT + 1u][2];
+#pragma unroll
+    for (uint32_t s = 0; s <= 2u * MID_FT; ++s) {
+        ha[s][0] = any ? wh[(s * TILES) * 64u] : make_uint4(0u, 0u, 0u, 0u);
+        ha[s][1] = two ? wh[(s * TILES + MHS_WAVES) * 64u] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    {   // bias k-step of the middle layer: B = {1, 1, 0, ...} on the k-half-0 lanes
+        const bf16x8 bf = __builtin_bit_cast(bf16x8, ones);
+        x[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bias0), bf, x[0], 0, 0, 0);
+        x[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bias1), bf, x[1], 0, 0, 0);
+    }
+    // ReLU, bf16: registers 8s..8s+7 of feature tile t = the head's k-step 2t + s (mid_head_sample_kernel)
+#pragma unroll
+    for (uint32_t i = 0; i < 2; ++i) {
+#pragma unroll
+        for (uint32_t sft = 0; sft < 2; ++sft) {
+            u32x4 f;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const f32x2 v = {__builtin_amdgcn_fmed3f(x[i][8u * sft + 2u * j], 0.0f, __builtin_inff()),
+                                 __builtin_amdgcn_fmed3f(x[i][8u * sft + 2u * j + 1u], 0.0f, __builtin_inff())};
+                f[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+            }
+            hbuf[(2u * (2u * wave + i) + sft) * 64u + lane] = __builtin_bit_cast(uint4, f);
+        }
+    }
+    __syncthreads();
+    // ---- head: acc[i] = action tile wave + 4 i ----
+    f32x16 acc[2];
+#pragma unroll
+    for (uint32_t i = 0; i < 2; ++i)
+#pragma unroll
+        for (uint32_t q = 0; q < 16; ++q) acc[i][q] = 0.0f;
+    if (any) {
+#pragma unroll
+        for (uint32_t s = 0; s <= 2u * MID_FT; ++s) {
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, s < 2u * MID_FT ? hbuf[s * 64u + lane] : ones);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ha[s][0]), bf, acc[0], 0, 0, 0);
+            if (two) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ha[s][1]), bf, acc[1], 0, 0, 0);
+        }
+    }
+    // ---- draw: this wave's logits are acc[i][q] = action 32 (wave + 4 i) + (q & 3) + 8 (q >> 2) + 4 h of env c ----
+    const float INF = __builtin_huge_valf();
+    constexpr uint32_t VW = (TILES - 1u) % MHS_WAVES, VI = (TILES - 1u) / MHS_WAVES;  // the value head: last row of the last tile (h = 1, q = 15)
+    float value = 0.0f;
+    if (wave == VW) {
+        value = acc[VI][15];
+        if (h == 1) acc[VI][15] = HEAD_PAD_BIAS;
+    }
+    float m = -INF;
+    if (any) {
+#pragma unroll
+        for (uint32_t q = 0; q < 16; ++q) m = fmaxf(m, acc[0][q]);
+        if (two) {
+#pragma unroll
+            for (uint32_t q = 0; q < 16; ++q) m = fmaxf(m, acc[1][q]);
+        }
+    }
+    m = fmaxf(m, head_xhalf(m));
+    if (h == 0) xmax[wave][c] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(xmax[0][c], xmax[1][c]), fmaxf(xmax[2][c], xmax[3][c]));
+    const uint64_t base = rng_draw(a.seed, env, a.counter + clock_of(a.clock));
+    const uint32_t blo = (uint32_t)base, bhi = (uint32_t)(base >> 32);
+    DrawLane r;
+    if (any) {
+#pragma unroll
+        for (uint32_t q = 0; q < 16; ++q) draw_logit(r, acc[0][q], m, 32u * wave + (q & 3u) + 8u * (q >> 2) + 4u * h, bhi, blo);
+        if (two) {
+#pragma unroll
+            for (uint32_t q = 0; q < 16; ++q) draw_logit(r, acc[1][q], m, 32u * (wave + MHS_WAVES) + (q & 3u) + 8u * (q >> 2) + 4u * h, bhi, blo);
+        }
+    }
+    {   // the other lane half holds the other actions of these tiles
+        const float oq = head_xhalf(r.best_q), od = head_xhalf(r.best_d);
+        const uint32_t oa = __shfl_xor(r.best_a, 32, 64);
+        r.ssum += head_xhalf(r.ssum);
+        r.wsum += head_xhalf(r.wsum);
+        const bool take = oa != 0xFFFFFFFFu && (r.best_a == 0xFFFFFFFFu || oq < r.best_q || (oq == r.best_q && oa < r.best_a));
+        r.best_q = take ? oq : r.best_q;
+        r.best_a = take ? oa : r.best_a;
+        r.best_d = take ? od : r.best_d;
+    }
+    const float v_other = head_xhalf(value);
+    if (h == 0) {
+        part[wave][0][c] = r.ssum;
+        part[wave][1][c] = r.wsum;
+        part[wave][2][c] = r.best_q;
+        part[wave][3][c] = r.best_d;
+        part[wave][4][c] = __uint_as_float(r.best_a);
+        if (wave == VW) part[0][5][c] = v_other;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    float ssum = 0.0f, wsum = 0.0f, best_q = INF, best_d = 0.0f;
+    uint32_t best_a = 0xFFFFFFFFu;
+#pragma unroll
+    for (uint32_t w = 0; w < MHS_WAVES; ++w) {  // ascending action tiles within a wave, ties across waves by the lower index
+        ssum += part[w][0][c];
+        wsum += part[w][1][c];
+        const float oq = part[w][2][c], od = part[w][3][c];
+        const uint32_t oa = __float_as_uint(part[w][4][c]);
+        const bool take = oa != 0xFFFFFFFFu && (best_a == 0xFFFFFFFFu || oq < best_q || (oq == best_q && oa < best_a));
+        best_q = take ? oq : best_q;
+        best_a = take ? oa : best_a;
+        best_d = take ? od : best_d;
+    }
+    const int64_t act = best_a == 0xFFFFFFFFu ? 0 : (int64_t)best_a;
+    if (live && h == 0) {
+        if (a.act64) reinterpret_cast<int64_t *>(a.actions)[env] = act;
+        else reinterpret_cast<int32_t *>(a.actions)[env] = (int32_t)act;
+        const float log_s = logf(ssum);
+        if (a.logp) a.logp[env] = best_d - log_s;
+        if (a.entropy) a.entropy[env] = log_s - wsum / ssum;
+        if (a.values) a.values[env] = part[0][5][c];
+    }
+    if (ma.step.state) {  // wave-uniform
+        bool fin = false;
+        if (live && h == 0)
+            fin = ma.step_has_z ? qm_step1_body<true, true>(ma.step, ma.step_groups, env, act) : qm_step1_body<false, true>(ma.step, ma.step_groups, env, act);
+        const uint64_t mk = __ballot(fin);
+        if (mk) {
+            const uint32_t first = (uint32_t)__ffsll((long long)mk) - 1u;
+            uint32_t basei = 0;
+            if (lane == first) basei = atomicAdd(ma.done_count, (uint32_t)__popcll(mk));
+            basei = __shfl(basei, first);
+            if (fin) ma.done_list[basei + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = (uint32_t)env;
         }
     }
 }
@@ -942,12 +1231,25 @@ int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint3
     const size_t lds = (size_t)emb_groups(R) * 8u * 2u * 64u * 16u;  // <= 128 KiB (R <= 32)
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, v->device);
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t env_tiles = (v->B + 31u) / 32u;
+    if (env_tiles * a.n_slabs <= (uint64_t)EMS_WAVES * (uint64_t)cus) {  // at most one workgroup per CU of embed_small_kernel: too few envs for 512-env passes
+        const dim3 grid((unsigned)(((env_tiles + EMS_WAVES - 1) / EMS_WAVES) * a.n_slabs)), block(64 * EMS_WAVES);
+#define QG_EMS_CASE(GG)                                                           \
+    case GG: hipLaunchKernelGGL(embed_small_kernel<GG>, grid, block, 0, s, a); break;
+        switch (G) {
+            QG_EMS_CASE(2) QG_EMS_CASE(3) QG_EMS_CASE(4) QG_EMS_CASE(5) QG_EMS_CASE(6) QG_EMS_CASE(7) QG_EMS_CASE(8)
+        default: return set_error(QG_ERR_UNSUPPORTED, "unexpected row-group count %u", G);
+        }
+#undef QG_EMS_CASE
+        HIP_TRY(hipGetLastError());
+        return QG_OK;
+    }
     const uint64_t env_blocks = (v->B + EMB_BLOCK_ENVS - 1) / EMB_BLOCK_ENVS;
     uint32_t mgroups = (uint32_t)((uint32_t)cus / a.n_slabs);
     if (mgroups == 0) mgroups = 1;
     if (mgroups > env_blocks) mgroups = (uint32_t)env_blocks;
     const dim3 grid(mgroups * a.n_slabs), block(EMB_THREADS);
-    hipStream_t s = (hipStream_t)stream;
 #define QG_EMB_CASE(GG)                                                                                                       \
     case GG:                                                                                                                  \
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(embed_bits_kernel<GG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -1179,9 +1481,24 @@ static int mid_head_impl(const void *h_dev, uint64_t ld_h, uint64_t batch, uint3
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint64_t env_tiles = (batch + 31u) / 32u, want = (env_tiles + MH_WAVES - 1) / MH_WAVES;
+    hipStream_t s = (hipStream_t)stream;
+    // up to one workgroup per CU of mid_head_small_kernel (a tile of 32 envs each): the batch is too small to fill the chip with
+    // mid_head_sample_kernel's 128-env workgroups
+    const bool small = env_tiles <= (uint64_t)cus && in_features % (16u * MHS_GROUP) == 0;
+    if (small) {
+        const dim3 grid((unsigned)env_tiles), block(64 * MHS_WAVES);
+#define QG_MHS_CASE(TT)                                                        \
+    case TT: hipLaunchKernelGGL(mid_head_small_kernel<TT>, grid, block, 0, s, m); break;
+        switch (tiles) {
+            QG_MHS_CASE(1) QG_MHS_CASE(2) QG_MHS_CASE(3) QG_MHS_CASE(4) QG_MHS_CASE(5) QG_MHS_CASE(6) QG_MHS_CASE(7)
+        default: return set_error(QG_ERR_UNSUPPORTED, "too many actions for the fused head");
+        }
+#undef QG_MHS_CASE
+        HIP_TRY(hipGetLastError());
+        return QG_OK;
+    }
     const uint64_t resident = 2ull * (uint64_t)cus;  // two workgroups per CU (32 KiB of LDS and 256 registers x 4 waves each)
     const dim3 grid((unsigned)(want < resident ? want : resident)), block(64 * MH_WAVES);
-    hipStream_t s = (hipStream_t)stream;
 #define QG_MH_CASE(TT)                                                        \
     case TT: hipLaunchKernelGGL(mid_head_sample_kernel<TT>, grid, block, 0, s, m); break;
     switch (tiles) {

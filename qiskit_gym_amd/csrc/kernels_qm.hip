@@ -905,8 +905,13 @@ __global__ __launch_bounds__(256) void qm_pack_kernel(ObsArgs a, uint32_t nxp, u
     uint32_t *my = lds[wave];
     if (tile_idx < n_tiles) {
         const uint4 *tile = reinterpret_cast<const uint4 *>(a.state) + tile_idx * (uint64_t)(G * 64);
-        for (uint32_t g = 0; g < G; ++g) {
-            const uint4 v = tile[g * 64 + lane];
+        uint4 vs[8];  // R <= 32 slots: all groups in flight at once (a loop over a run-time G waits for each load in turn)
+#pragma unroll
+        for (uint32_t g = 0; g < 8; ++g) vs[g] = g < G ? tile[g * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (uint32_t g = 0; g < 8; ++g) {
+            if (g >= G) break;
+            const uint4 v = vs[g];
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (uint32_t c = 0; c < 4; ++c) {

@@ -204,7 +204,7 @@ def test_head_sample_follows_softmax():
 
 
 @pytest.mark.parametrize("A,K1,B", [(170, 512, 2500), (12, 64, 300), (190, 1024, 257), (40, 96, 64), (214, 512, 1000), (222, 128, 70),
-                                    (170, 512, 40000)])  # up to 32 768 envs the launch streams 64 KiB chunks, beyond 16 KiB ones: both forms
+                                    (170, 512, 40000), (170, 512, 8192), (97, 256, 33)])  # <= 8 192 envs and in_features % 128 == 0: mid_head_small_kernel
 def test_mid_head_sample_on_integer_data_is_exact(A, K1, B):
     """qg_policy_mid_head_sample = relu(h W2^T + b2) -> head -> draw, everything in registers.  Small-integer weights keep
     every intermediate exactly representable (h2 <= 256 in bf16), which pins the fragment k orders: the draw must be
@@ -243,6 +243,30 @@ def test_mid_head_sample_on_integer_data_is_exact(A, K1, B):
     np.testing.assert_allclose(logp.cpu().numpy(), lsm[np.arange(B), got], rtol=0, atol=3e-5)
     np.testing.assert_allclose(ent.cpu().numpy(), -(np.exp(lsm) * lsm).sum(axis=1), rtol=0, atol=1e-4)
     np.testing.assert_array_equal(vals.cpu().numpy(), full[:, value_row].astype(np.float32))
+
+
+def test_mid_head_sample_small_and_large_batch_kernels_draw_the_same_actions():
+    """Up to 8 192 envs (one 32-env workgroup per CU) the launch takes mid_head_small_kernel, beyond mid_head_sample_kernel: same
+    weights, same k order, same race keys -- identical actions and values for the same env ids; log-prob / entropy sum in another order."""
+    from qiskit_gym_amd.collector import mid_head_sample, pack_head, pack_mid
+
+    A, K1, F, B = 170, 512, 256, 8192 + 2048
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    h1 = torch.randn((B, K1), device="cuda", generator=g).clamp_min(0).to(torch.bfloat16)
+    w2 = (torch.randn((F, K1), device="cuda", generator=g) * (2.0 / K1) ** 0.5).to(torch.bfloat16)
+    b2 = (torch.randn(F, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    w3 = (torch.randn((A + 1, F), device="cuda", generator=g) * (2.0 / F) ** 0.5).to(torch.bfloat16)
+    b3 = (torch.randn(A + 1, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    pm, ph = pack_mid(w2, b2), pack_head(w3, b3, A, A, after_mid=True)
+    big = mid_head_sample(h1, pm, F, ph, A, 7, 3)
+    for n in (8192, 1024, 77):
+        small = mid_head_sample(h1[:n].contiguous(), pm, F, ph, A, 7, 3)
+        torch.cuda.synchronize()
+        assert torch.equal(small[0], big[0][:n])
+        assert torch.equal(small[3], big[3][:n])
+        torch.testing.assert_close(small[1], big[1][:n], rtol=0, atol=2e-6)
+        torch.testing.assert_close(small[2], big[2][:n], rtol=0, atol=2e-6)
 
 
 def test_mid_head_sample_random_weights():

@@ -23,6 +23,11 @@ CASES = [  # kind, qubits, batch, hidden
     ("linear_function", 27, 300, 64),   # 7 row groups (padded to 8 in the slab)
     ("clifford", 3, 200, 64),           # 2 row groups
     ("clifford", 16, 2048, 1024),       # 16 column slabs
+    # up to 4 x CUs (env tile, slab) pairs the launch takes embed_small_kernel; beyond, embed_bits_kernel's 512-env passes
+    ("clifford", 16, 9000, 128),
+    ("linear_function", 27, 20001, 64),
+    ("clifford", 5, 40000, 64),
+    ("clifford", 16, 4097, 512),
 ]
 
 

@@ -6,7 +6,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qiskit_gym_amd.collector import mid_head_sample, pack_head, pack_mid
 
-for B, A in ((65536, 170), (65536, 214), (8192, 170)):
+for B, A in ((65536, 170), (65536, 214), (8192, 170), (4096, 170), (2048, 170), (1024, 170), (256, 170)):
     g = torch.Generator(device="cpu").manual_seed(1)
     h = torch.randn((B, 512), generator=g).relu().to(torch.bfloat16).cuda()
     w2 = (torch.randn((256, 512), generator=g) * 0.05).to(torch.bfloat16).cuda()
