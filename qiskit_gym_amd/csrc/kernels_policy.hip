@@ -736,7 +736,7 @@ __global__ __launch_bounds__(64 * MH_WAVES, 2) void mid_head_sample_kernel(MidHe
             bool fin = false;
             if (live && h == 0)
                 fin = ma.step_has_z ? qm_step1_body<true, true>(ma.step, ma.step_groups, env, act) : qm_step1_body<false, true>(ma.step, ma.step_groups, env, act);
-            // compact_done (kernels_rows.hip) for this wave's 32 envs: one atomic per wave with a finished env
+            // compact_done (kernels_collect.hip) for this wave's 32 envs: one atomic per wave with a finished env
             const uint64_t m = __ballot(fin);
             if (m) {
                 const uint32_t first = (uint32_t)__ffsll((long long)m) - 1u;
@@ -754,15 +754,25 @@ __global__ __launch_bounds__(64 * MH_WAVES, 2) void mid_head_sample_kernel(MidHe
 // and lets it stream all 358 KB of weights, so 1 024 envs occupy 8 CUs for 23 us.  Here a workgroup's four waves share ONE tile of 32
 // envs: wave w multiplies feature tiles 2w, 2w + 1 of the middle layer and action tiles w, w + 4 of the head, so nobody shares a
 // weight fragment and each goes from L2 straight into registers (the packed layouts are already in fragment order: 1 KiB per wave
-// load), 8 k-steps ahead.  h2 crosses the waves through 16 KiB of LDS, the draw runs on a quarter of the logits per wave with the
+// load), three groups of 8 k-steps ahead; the tile's activations are loaded once and shared through LDS.  h2 crosses the waves through 16 KiB of LDS, the draw runs on a quarter of the logits per wave with the
 // env's maximum and the partial sums / race winners exchanged through LDS, wave 0 finishes (and steps the env).  Same packed weights,
 // same k order, same keys: actions are those of mid_head_sample_kernel; logp / entropy sum their terms in another order.
 constexpr uint32_t MHS_WAVES = 4;
-constexpr uint32_t MHS_GROUP = 8;  // k-steps per register group of the middle layer (two groups in flight)
+constexpr uint32_t MHS_GROUP = 8;   // k-steps per register group of the middle layer
+constexpr uint32_t MHS_KMAX = 64;   // k-steps of activations the workgroup keeps in LDS (in_features <= 1024)
+
+// Workgroup barrier for data exchanged through LDS only: __syncthreads() fences every address space, which also drains the vector-memory
+// counter and with it the weight fragments requested ahead.
+__device__ __forceinline__ void mhs_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 template <uint32_t TILES>
 __global__ __launch_bounds__(64 * MHS_WAVES, 1) void mid_head_small_kernel(MidHeadArgs ma) {
     static_assert(MID_FT == 2 * MHS_WAVES && TILES <= 2 * MHS_WAVES, "two feature tiles and <= two action tiles per wave");
+    __shared__ uint4 bbuf[MHS_KMAX * 64u];          // the tile's activations as B fragments, k-step major: loaded once, read by all four waves
     __shared__ uint4 hbuf[2u * MID_FT * 64u];       // h2 as the head's B fragments, k-step major
     __shared__ float xmax[MHS_WAVES][32];
     __shared__ float part[MHS_WAVES][6][32];         // ssum, wsum, best_q, best_d, best_a, value
@@ -774,7 +784,8 @@ __global__ __launch_bounds__(64 * MHS_WAVES, 1) void mid_head_small_kernel(MidHe
     const uint64_t env = live ? env_raw : a.B - 1;
     const uint4 *hrow = a.h + env * (a.ld_h / 8u) + h;
     const uint4 ones = make_uint4(h == 0 ? 0x3F803F80u : 0u, 0u, 0u, 0u);
-    const uint32_t ks1 = ma.K1 / 16u;  // real k-steps of the middle layer (a multiple of MHS_GROUP: the launcher checks), then the bias k-step
+    const uint32_t ks1 = ma.K1 / 16u;  // real k-steps of the middle layer (a multiple of MHS_GROUP, <= MHS_KMAX: the launcher checks), then the bias k-step
+    const uint32_t ng = ks1 / MHS_GROUP;
     // ---- middle layer: x[i] = feature tile 2 wave + i ----
     const uint4 *wa = ma.w2p + (2u * wave) * 64u + lane;  // fragment (k-step s, tile 2 wave + i) = wa[(s * MID_FT + i) * 64]
     f32x16 x[2];
@@ -782,34 +793,40 @@ __global__ __launch_bounds__(64 * MHS_WAVES, 1) void mid_head_small_kernel(MidHe
     for (uint32_t i = 0; i < 2; ++i)
 #pragma unroll
         for (uint32_t q = 0; q < 16; ++q) x[i][q] = 0.0f;
-    uint4 fa[2][MHS_GROUP][2], fb[2][MHS_GROUP];
-    auto fetch = [&](uint32_t s0, uint4 (&A)[MHS_GROUP][2], uint4 (&Bv)[MHS_GROUP]) {
+    uint4 fa[3][MHS_GROUP][2];  // three groups of weight fragments in flight
+    auto fetch = [&](uint32_t g, uint4 (&A)[MHS_GROUP][2]) {
 #pragma unroll
         for (uint32_t j = 0; j < MHS_GROUP; ++j) {
-            Bv[j] = hrow[2u * (s0 + j)];
-            A[j][0] = wa[((s0 + j) * MID_FT) * 64u];
-            A[j][1] = wa[((s0 + j) * MID_FT + 1u) * 64u];
+            A[j][0] = wa[((g * MHS_GROUP + j) * MID_FT) * 64u];
+            A[j][1] = wa[((g * MHS_GROUP + j) * MID_FT + 1u) * 64u];
         }
     };
-    auto multiply = [&](const uint4 (&A)[MHS_GROUP][2], const uint4 (&Bv)[MHS_GROUP]) {
+    auto multiply = [&](uint32_t g, const uint4 (&A)[MHS_GROUP][2]) {
 #pragma unroll
         for (uint32_t j = 0; j < MHS_GROUP; ++j) {
-            const bf16x8 bf = __builtin_bit_cast(bf16x8, Bv[j]);
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, bbuf[(g * MHS_GROUP + j) * 64u + lane]);
             x[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[j][0]), bf, x[0], 0, 0, 0);
             x[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[j][1]), bf, x[1], 0, 0, 0);
         }
     };
-    fetch(0, fa[0], fb[0]);
-    const uint4 bias0 = wa[(ks1 * MID_FT) * 64u], bias1 = wa[(ks1 * MID_FT + 1u) * 64u];
-    for (uint32_t s0 = 0; s0 < ks1; s0 += 2u * MHS_GROUP) {  // two groups per trip: the register buffers are indexed statically
-        if (s0 + MHS_GROUP < ks1) fetch(s0 + MHS_GROUP, fa[1], fb[1]);
-        multiply(fa[0], fb[0]);
-        if (s0 + MHS_GROUP < ks1) {
-            if (s0 + 2u * MHS_GROUP < ks1) fetch(s0 + 2u * MHS_GROUP, fa[0], fb[0]);
-            multiply(fa[1], fb[1]);
+    fetch(0, fa[0]);
+    if (1u < ng) fetch(1, fa[1]);
+    if (2u < ng) fetch(2, fa[2]);
+    // the activations: wave w brings groups w, w + 4 (<= 2 x 8 k-steps, 16 B per lane each) and parks them in LDS for all four waves.
+    // Requested after the weights: vector memory returns in order, so once they are here so are the three weight groups -- everything
+    // the workgroup can have in flight is in flight from the first instruction on (the limit is what a CU's memory path delivers).
+#pragma unroll
+    for (uint32_t i = 0; i < 2; ++i) {
+        const uint32_t g = wave + MHS_WAVES * i;
+        if (g < ng) {
+#pragma unroll
+            for (uint32_t j = 0; j < MHS_GROUP; ++j) bbuf[(g * MHS_GROUP + j) * 64u + lane] = hrow[2u * (g * MHS_GROUP + j)];
         }
     }
-    // ---- the head's weights for this wave's action tiles (wave, wave + 4), all 17 k-steps, on their way during the epilogue of the middle layer ----
+    mhs_lds_barrier();
+    const uint4 bias0 = wa[(ks1 * MID_FT) * 64u], bias1 = wa[(ks1 * MID_FT + 1u) * 64u];
+    // ---- the head's weights for this wave's action tiles (wave, wave + 4), all 17 k-steps: requested behind the
+    // activations, they arrive while the middle layer multiplies ----
     const bool two = wave + MHS_WAVES < TILES, any = wave < TILES;  // wave-uniform
     const uint4 *wh = a.wp + wave * 64u + lane;  // fragment (k-step s, tile wave + 4 i) = wh[(s * TILES + 4 i) * 64]
     uint4 ha[2u * MID_FT + 1u][2];
@@ -817,6 +834,18 @@ __global__ __launch_bounds__(64 * MHS_WAVES, 1) void mid_head_small_kernel(MidHe
     for (uint32_t s = 0; s <= 2u * MID_FT; ++s) {
         ha[s][0] = any ? wh[(s * TILES) * 64u] : make_uint4(0u, 0u, 0u, 0u);
         ha[s][1] = two ? wh[(s * TILES + MHS_WAVES) * 64u] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    for (uint32_t g0 = 0; g0 < ng; g0 += 3u) {  // three groups per trip: the register buffers are indexed statically
+        multiply(g0, fa[0]);
+        if (g0 + 3u < ng) fetch(g0 + 3u, fa[0]);
+        if (g0 + 1u < ng) {
+            multiply(g0 + 1u, fa[1]);
+            if (g0 + 4u < ng) fetch(g0 + 4u, fa[1]);
+        }
+        if (g0 + 2u < ng) {
+            multiply(g0 + 2u, fa[2]);
+            if (g0 + 5u < ng) fetch(g0 + 5u, fa[2]);
+        }
     }
     {   // bias k-step of the middle layer: B = {1, 1, 0, ...} on the k-half-0 lanes
         const bf16x8 bf = __builtin_bit_cast(bf16x8, ones);
@@ -838,7 +867,7 @@ __global__ __launch_bounds__(64 * MHS_WAVES, 1) void mid_head_small_kernel(MidHe
             hbuf[(2u * (2u * wave + i) + sft) * 64u + lane] = __builtin_bit_cast(uint4, f);
         }
     }
-    __syncthreads();
+    mhs_lds_barrier();  // the head's fragments stay in flight
     // ---- head: acc[i] = action tile wave + 4 i ----
     f32x16 acc[2];
 #pragma unroll
@@ -1484,7 +1513,7 @@ static int mid_head_impl(const void *h_dev, uint64_t ld_h, uint64_t batch, uint3
     hipStream_t s = (hipStream_t)stream;
     // up to one workgroup per CU of mid_head_small_kernel (a tile of 32 envs each): the batch is too small to fill the chip with
     // mid_head_sample_kernel's 128-env workgroups
-    const bool small = env_tiles <= (uint64_t)cus && in_features % (16u * MHS_GROUP) == 0;
+    const bool small = env_tiles <= (uint64_t)cus && in_features % (16u * MHS_GROUP) == 0 && in_features <= 16u * MHS_KMAX;
     if (small) {
         const dim3 grid((unsigned)env_tiles), block(64 * MHS_WAVES);
 #define QG_MHS_CASE(TT)                                                        \
