@@ -307,6 +307,11 @@ int qg_gae(const float *rewards_dev, const float *values_dev, const uint8_t *don
 size_t qg_vec_embed_packed_bytes(const qg_vec *v, uint32_t hidden);
 int qg_vec_pack_embedding(qg_vec *v, const void *weight_dev, int weight_dtype, uint64_t ld, uint32_t hidden, void *packed_dev, void *stream);
 int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint32_t hidden, int relu, void *out_dev, uint64_t ld_out, void *stream);
+/* qg_vec_observe_packed(v, obs_packed_dev, stream) and qg_vec_embed(...) of the same state: the observation a rollout stores and the
+ * first layer of the policy that acts on it.  One launch for small batches (the layer's kernel holds the bits it would export), the
+ * two launches otherwise; results are those of the two calls. */
+int qg_vec_embed_observe(qg_vec *v, const void *packed_dev, const float *bias_dev, uint32_t hidden, int relu, void *out_dev, uint64_t ld_out,
+                         void *obs_packed_dev, void *stream);
 
 /* The same first layer from packed observation WORDS instead of a handle's resident state: words_dev = [batch, rows] uint64,
  * bit c of word r = observation entry (r, c) -- what qg_vec_observe_packed writes for handles with 64-bit row words (PauliEnv:

@@ -80,7 +80,7 @@ EXPORTED_SYMBOLS = [
     "qg_vec_observe_dense", "qg_vec_observe_packed", "qg_vec_masks", "qg_vec_pauli_reset_from", "qg_vec_pauli_observe_dense", "qg_vec_pauli_num_perms", "qg_vec_sync",
     "qg_vec_solution",
     "qg_vec_observe_dense_as", "qg_expand_packed", "qg_widen_dense", "qg_sample_actions", "qg_gae",
-    "qg_vec_embed_packed_bytes", "qg_vec_pack_embedding", "qg_vec_embed",
+    "qg_vec_embed_packed_bytes", "qg_vec_pack_embedding", "qg_vec_embed", "qg_vec_embed_observe",
     "qg_policy_embed_words_packed_bytes", "qg_policy_pack_embed_words", "qg_policy_embed_words",
     "qg_policy_head_packed_bytes", "qg_policy_pack_head", "qg_policy_head_sample",
     "qg_policy_mid_packed_bytes", "qg_policy_pack_mid", "qg_policy_mid_head_sample", "qg_vec_mid_head_sample_step",
@@ -160,6 +160,7 @@ def load():
     L.qg_vec_embed_packed_bytes.restype = sz
     L.qg_vec_pack_embedding.argtypes = [vp, vp, C.c_int, u64, C.c_uint32, vp, vp]
     L.qg_vec_embed.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp, u64, vp]
+    L.qg_vec_embed_observe.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp, u64, vp, vp]
     L.qg_policy_embed_words_packed_bytes.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     L.qg_policy_embed_words_packed_bytes.restype = sz
     L.qg_policy_pack_embed_words.argtypes = [vp, C.c_int, u64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]

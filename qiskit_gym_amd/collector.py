@@ -109,14 +109,24 @@ def pack_embedding(env: VecEnv, weight: torch.Tensor, out: Optional[torch.Tensor
     return out
 
 
-def embed(env: VecEnv, packed: torch.Tensor, bias: Optional[torch.Tensor], hidden: int, relu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """act(obs @ W.T + bias) in bf16 [B, hidden], computed from the env's resident bit-packed state (`qg_vec_embed`)."""
+def embed(env: VecEnv, packed: torch.Tensor, bias: Optional[torch.Tensor], hidden: int, relu: bool = True, out: Optional[torch.Tensor] = None,
+          obs_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(obs @ W.T + bias) in bf16 [B, hidden], computed from the env's resident bit-packed state (`qg_vec_embed`).  `obs_out`: also
+    `env.observe_packed(out=obs_out)` of the same state (`qg_vec_embed_observe`: one launch for small batches)."""
     if out is None:
         out = torch.empty((env.batch, hidden), dtype=torch.bfloat16, device=env.device)
     if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
         raise ValueError("bias must be a contiguous f32 vector")
-    _lib.check(_lib.load().qg_vec_embed(env._h, packed.data_ptr(), bias.data_ptr() if bias is not None else None, hidden, int(relu), out.data_ptr(),
-                                        out.stride(0), env._stream()))
+    L = _lib.load()
+    if obs_out is not None:
+        if (not obs_out.is_contiguous() or obs_out.numel() != env.batch * env.packed_words_per_env or obs_out.element_size() != env.packed_word_bytes
+                or obs_out.device != out.device):
+            raise ValueError("obs_out must be a contiguous [batch, packed_words_per_env] tensor of the env's packed word type on its device")
+        _lib.check(L.qg_vec_embed_observe(env._h, packed.data_ptr(), bias.data_ptr() if bias is not None else None, hidden, int(relu), out.data_ptr(),
+                                          out.stride(0), obs_out.data_ptr(), env._stream()))
+        return out
+    _lib.check(L.qg_vec_embed(env._h, packed.data_ptr(), bias.data_ptr() if bias is not None else None, hidden, int(relu), out.data_ptr(),
+                              out.stride(0), env._stream()))
     return out
 
 
@@ -329,7 +339,7 @@ class RolloutCollector:
         self.clock = torch.zeros(1, dtype=torch.int64, device=env.device)  # collector steps taken so far
         env.set_clock(self.clock)
         # the policy-layer kernels at every batch size: below ~ 4 096 envs the launches take their small-batch shapes (a 32-env tile per
-        # wave / workgroup, weight fragments straight from L2: CliffordGym 16q x 1 024 envs 27 us per step against 42 us on library GEMMs)
+        # wave / workgroup, weight fragments straight from L2: CliffordGym 16q x 1 024 envs 24 us per step against 42 us on library GEMMs)
         words_auto = use_bit_embedding is None and env.batch < 4096  # the first layer from packed WORDS has no small-batch shape: library GEMM there
         if use_bit_embedding is None:
             use_bit_embedding = True
@@ -357,6 +367,7 @@ class RolloutCollector:
             except ValueError:
                 self._embed_words = None
         self._h1 = None
+        self._obs_row = None  # the rollout row the next first-layer launch also fills with the packed observation
         self._head = None  # packed last layer for the fused head + sampling kernel (bf16 BasicPolicy within its limits)
         self._mid = None   # packed middle layer: then middle layer + head + sampling are ONE kernel and only the first layer stays outside
         if self._heads is not None and dtype == torch.bfloat16 and use_fused_head:
@@ -401,10 +412,11 @@ class RolloutCollector:
         (not needed when the first layer consumes the bits directly)."""
         env = self.env
         if ro.obs_packed:
-            env.observe_packed(out=ro.obs[t])
             if self._embed is not None:
-                pass
-            elif self._embed_words is not None:
+                self._obs_row = ro.obs[t]  # written by the first layer's launch (qg_vec_embed_observe)
+                return
+            env.observe_packed(out=ro.obs[t])
+            if self._embed_words is not None:
                 self._cur_words = ro.obs[t]
             elif env.env_kind == "pauli":
                 # PauliEnv.observe() with add_perms draws a permutation (pauli.rs:657-662): observe once, expand the stored row words
@@ -447,7 +459,8 @@ class RolloutCollector:
         if self._embed is not None:
             if self._h1 is None:
                 self._h1 = torch.empty((self.env.batch, pol.embeddings.out_features), dtype=self.dtype, device=self.env.device)
-            return embed(self.env, self._embed[0], self._embed[1], pol.embeddings.out_features, relu=True, out=self._h1)
+            obs_row, self._obs_row = self._obs_row, None
+            return embed(self.env, self._embed[0], self._embed[1], pol.embeddings.out_features, relu=True, out=self._h1, obs_out=obs_row)
         if self._embed_words is not None:
             if self._h1 is None:
                 self._h1 = torch.empty((self.env.batch, pol.embeddings.out_features), dtype=self.dtype, device=self.env.device)

@@ -106,6 +106,8 @@ struct EmbedArgs {
     uint64_t ld_out;        // elements per env row of out
     uint32_t n_slabs;
     uint32_t relu;
+    uint32_t *obs;          // embed_small_kernel: also the packed observation [B][D] (what qg_vec_observe_packed writes), or null
+    uint32_t N, D, has_z;
 };
 
 // A fragment (8 bf16 for this lane's row and k-half) from a row word: see the header comment
@@ -360,6 +362,37 @@ __global__ __launch_bounds__(64 * EMS_WAVES) void embed_small_kernel(EmbedArgs a
     for (uint32_t g = 0; g < G; ++g) bits[g] = ps[g * 64u];
     const uint32_t n0 = slab * EMB_SLAB + 2u * r;
     const float bias0 = a.bias ? a.bias[n0] : 0.0f, bias1 = a.bias ? a.bias[n0 + 1] : 0.0f;
+    if (a.obs && slab == 0 && tile * 32u + r < a.B) {
+        // The rollout's packed observation from the bits this wave holds anyway (qm_pack_kernel's rows: CliffordEnv X-type row j = slot
+        // 2j, Z-type row N + j = slot 2j + 1; LinearFunctionEnv row j = slot j).  Both lane halves hold the env: half h writes the
+        // X (h = 0) / Z (h = 1) rows, or the even / odd groups of a LinearFunctionEnv.
+        uint32_t *o = a.obs + (tile * 32u + r) * (uint64_t)a.D;
+        if (a.has_z) {
+            uint32_t *oh = o + (h ? a.N : 0u);
+            if ((a.N & 3u) == 0) {  // whole 16-byte stores (the buffer is 16-byte aligned: the launcher checks)
+#pragma unroll
+                for (uint32_t g = 0; g + 1u < G; g += 2u)
+                    if (2u * g < a.N)
+                        *reinterpret_cast<uint4 *>(oh + 2u * g) = h ? make_uint4(bits[g].y, bits[g].w, bits[g + 1u].y, bits[g + 1u].w)
+                                                                    : make_uint4(bits[g].x, bits[g].z, bits[g + 1u].x, bits[g + 1u].z);
+            } else {
+#pragma unroll
+                for (uint32_t g = 0; g < G; ++g) {
+                    if (2u * g < a.N) oh[2u * g] = h ? bits[g].y : bits[g].x;
+                    if (2u * g + 1u < a.N) oh[2u * g + 1u] = h ? bits[g].w : bits[g].z;
+                }
+            }
+        } else {
+#pragma unroll
+            for (uint32_t g = 0; g < G; ++g) {
+                if ((g & 1u) != h) continue;
+                const uint32_t w[4] = {bits[g].x, bits[g].y, bits[g].z, bits[g].w};
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k)
+                    if (4u * g + k < a.N) o[4u * g + k] = w[k];
+            }
+        }
+    }
     f32x16 acc0, acc1;
 #pragma unroll
     for (uint32_t q = 0; q < 16; ++q) acc0[q] = acc1[q] = 0.0f;
@@ -1236,7 +1269,8 @@ int qg_vec_pack_embedding(qg_vec *v, const void *weight_dev, int weight_dtype, u
     return QG_OK;
 }
 
-int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint32_t hidden, int relu, void *out_dev, uint64_t ld_out, void *stream) {
+static int embed_impl(qg_vec *v, const void *packed_dev, const float *bias_dev, uint32_t hidden, int relu, void *out_dev, uint64_t ld_out, void *obs_dev,
+                      void *stream) {
     if (!v || !packed_dev || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
     if (v->layout != LAYOUT_TILE)
         return set_error(QG_ERR_UNSUPPORTED, "the bit-consuming first layer needs the TILE layout (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32)");
@@ -1256,13 +1290,22 @@ int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint3
     a.ld_out = ld_out;
     a.n_slabs = hidden / EMB_SLAB;
     a.relu = relu ? 1u : 0u;
+    a.obs = nullptr;
+    a.N = v->N;
+    a.D = v->has_z ? 2u * v->N : v->N;
+    a.has_z = v->has_z ? 1u : 0u;
     const uint32_t G = R / 4;
     const size_t lds = (size_t)emb_groups(R) * 8u * 2u * 64u * 16u;  // <= 128 KiB (R <= 32)
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, v->device);
     hipStream_t s = (hipStream_t)stream;
     const uint64_t env_tiles = (v->B + 31u) / 32u;
-    if (env_tiles * a.n_slabs <= (uint64_t)EMS_WAVES * (uint64_t)cus) {  // at most one workgroup per CU of embed_small_kernel: too few envs for 512-env passes
+    const bool small = env_tiles * a.n_slabs <= (uint64_t)EMS_WAVES * (uint64_t)cus;  // at most one workgroup per CU of embed_small_kernel: too few envs for 512-env passes
+    if (obs_dev) {
+        if (small && (reinterpret_cast<uintptr_t>(obs_dev) & 15u) == 0) a.obs = reinterpret_cast<uint32_t *>(obs_dev);  // written by the same launch
+        else if (const int rc = qg_vec_observe_packed(v, obs_dev, stream)) return rc;
+    }
+    if (small) {
         const dim3 grid((unsigned)(((env_tiles + EMS_WAVES - 1) / EMS_WAVES) * a.n_slabs)), block(64 * EMS_WAVES);
 #define QG_EMS_CASE(GG)                                                           \
     case GG: hipLaunchKernelGGL(embed_small_kernel<GG>, grid, block, 0, s, a); break;
@@ -1291,6 +1334,16 @@ int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint3
 #undef QG_EMB_CASE
     HIP_TRY(hipGetLastError());
     return QG_OK;
+}
+
+int qg_vec_embed(qg_vec *v, const void *packed_dev, const float *bias_dev, uint32_t hidden, int relu, void *out_dev, uint64_t ld_out, void *stream) {
+    return embed_impl(v, packed_dev, bias_dev, hidden, relu, out_dev, ld_out, nullptr, stream);
+}
+
+int qg_vec_embed_observe(qg_vec *v, const void *packed_dev, const float *bias_dev, uint32_t hidden, int relu, void *out_dev, uint64_t ld_out,
+                         void *obs_packed_dev, void *stream) {
+    if (!obs_packed_dev) return set_error(QG_ERR_INVALID, "null argument");
+    return embed_impl(v, packed_dev, bias_dev, hidden, relu, out_dev, ld_out, obs_packed_dev, stream);
 }
 
 size_t qg_policy_embed_words_packed_bytes(uint32_t rows, uint32_t cols, uint32_t hidden) {

@@ -84,6 +84,26 @@ def test_embed_random_weights(kind, n, B, hidden):
     env.sync()
 
 
+@pytest.mark.parametrize("kind,n,B", [("clifford", 16, 1000), ("clifford", 5, 700), ("clifford", 12, 33), ("clifford", 9, 4096), ("linear_function", 12, 64),
+                                      ("linear_function", 27, 300), ("linear_function", 32, 1500), ("clifford", 16, 9000), ("linear_function", 17, 20001)])
+def test_embed_observe_also_writes_the_packed_observation(kind, n, B):
+    """qg_vec_embed_observe = observe_packed + embed of the same state (small batches: the layer's kernel writes both)."""
+    env = _env(kind, n, B, 21)
+    K = env.obs_shape_[0] * env.obs_shape_[1]
+    w = torch.randint(-1, 2, (64, K), generator=torch.Generator().manual_seed(4)).float()
+    w[:, 150:] = 0  # few nonzeros per output: exact in bf16
+    packed = pack_embedding(env, w.cuda())
+    want_obs = env.observe_packed()
+    want = embed(env, packed, None, 64, relu=False)
+    obs = torch.full_like(want_obs, -1)
+    got = embed(env, packed, None, 64, relu=False, obs_out=obs)
+    assert torch.equal(got, want)
+    assert torch.equal(obs, want_obs)
+    with pytest.raises(ValueError):
+        embed(env, packed, None, 64, relu=False, obs_out=obs[:, :-1])
+    env.sync()
+
+
 def test_embed_follows_the_state():
     """The layer reads the live tiles: after a step it sees the new observation."""
     env = _env("clifford", 16, 2048, 1)
