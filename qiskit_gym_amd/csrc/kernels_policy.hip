@@ -329,40 +329,42 @@ __global__ __launch_bounds__(EMB_THREADS, 1) void embed_bits_kernel(EmbedArgs a)
 
 
 // Small batches (the reference collects 1 024 episodes at a time, rl/configs.py:134): embed_bits_kernel's workgroup passes 512 envs under
-// a 64-column slab it first loads into LDS, so 1 024 envs are 16 workgroups x 256 MFMAs per wave -- 14 us on 16 CUs.  Here a wave owns
-// one tile of 32 envs x one slab and takes the slab's fragments from L2 straight into registers (the packed layout is fragment order:
-// 1 KiB per wave load, one group of 8 k-steps ahead); the four waves of a workgroup share the slab (their loads meet in the CU's
-// vector cache) on four env tiles.  Same packed weights, same expansion, same k order: bit-identical activations.
-constexpr uint32_t EMS_WAVES = 4;
+// a 64-column slab it first loads into LDS, so 1 024 envs are 16 workgroups x 256 MFMAs per wave -- 14 us on 16 CUs.  Here two waves
+// own one tile of 32 envs x one slab, one per column of the slab's column pairs, and take their fragments from L2 straight into
+// registers (the packed layout is fragment order: 1 KiB per wave load, EMS_AHEAD groups of 8 k-steps in flight).  What bounds these
+// launches is the bytes a CU pulls, so a tile gets a workgroup -- and a CU -- of its own while the chip has enough of them.
+// Same packed weights, same expansion, same k order: bit-identical activations.
+constexpr uint32_t EMS_TILES = 4;   // env tiles per workgroup when one tile each would not fit a workgroup per CU
+constexpr uint32_t EMS_AHEAD = 4;   // groups of 8 weight fragments in flight per wave
 
-template <uint32_t G>
-__global__ __launch_bounds__(64 * EMS_WAVES) void embed_small_kernel(EmbedArgs a) {
+// TILES env tiles per workgroup, two waves per tile: one per column of the slab's column pairs
+template <uint32_t G, uint32_t TILES>
+__global__ __launch_bounds__(128 * TILES) void embed_small_kernel(EmbedArgs a) {
     constexpr uint32_t GP = (G + 1u) & ~1u;
     constexpr uint32_t slab_vec = GP * 8u * 2u * 64u;  // uint4 per slab (the padding group of an odd G has zero weights: skipped)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t slab = blockIdx.x % a.n_slabs;
-    const uint64_t tile = (uint64_t)(blockIdx.x / a.n_slabs) * EMS_WAVES + wave;
+    const uint32_t nb = wave & 1u;  // this wave's column of every pair: 2 c + nb
+    const uint64_t tile = (uint64_t)(blockIdx.x / a.n_slabs) * TILES + (wave >> 1);
     if (tile * 32u >= a.B) return;  // wave-uniform; no barrier below
     const uint32_t r = lane & 31u, h = lane >> 5;
     const uint32_t sh[2] = {4u * h, 8u + 4u * h};
     uint64_t env = tile * 32u + r;
     env = env < a.B ? env : a.B - 1;  // tail: duplicate the last env, its rows are not stored
     const uint4 *ps = a.state + (env >> 6) * (uint64_t)(G * 64u) + (env & 63u);
-    const uint4 *pw = a.wp + (uint64_t)slab * slab_vec + lane;  // fragment (k-step s, nb) = pw[(2 s + nb) * 64]
-    uint4 bits[G], wb[2][8][2];
-    auto fetch = [&](uint32_t g, uint4 (&b)[8][2]) {
+    const uint4 *pw = a.wp + (uint64_t)slab * slab_vec + nb * 64u + lane;  // fragment (k-step s, nb) = pw[2 s * 64]
+    uint4 bits[G], wb[EMS_AHEAD][8];
+    auto fetch = [&](uint32_t g, uint4 (&b)[8]) {
 #pragma unroll
-        for (uint32_t ss = 0; ss < 8; ++ss) {
-            b[ss][0] = pw[((8u * g + ss) * 2u + 0u) * 64u];
-            b[ss][1] = pw[((8u * g + ss) * 2u + 1u) * 64u];
-        }
+        for (uint32_t ss = 0; ss < 8; ++ss) b[ss] = pw[((8u * g + ss) * 2u) * 64u];
     };
-    fetch(0, wb[0]);
+#pragma unroll
+    for (uint32_t g = 0; g + 1u < EMS_AHEAD && g < G; ++g) fetch(g, wb[g]);
 #pragma unroll
     for (uint32_t g = 0; g < G; ++g) bits[g] = ps[g * 64u];
-    const uint32_t n0 = slab * EMB_SLAB + 2u * r;
-    const float bias0 = a.bias ? a.bias[n0] : 0.0f, bias1 = a.bias ? a.bias[n0 + 1] : 0.0f;
-    if (a.obs && slab == 0 && tile * 32u + r < a.B) {
+    const uint32_t n0 = slab * EMB_SLAB + 2u * r + nb;
+    const float bias0 = a.bias ? a.bias[n0] : 0.0f;
+    if (a.obs && slab == 0 && nb == 0 && tile * 32u + r < a.B) {
         // The rollout's packed observation from the bits this wave holds anyway (qm_pack_kernel's rows: CliffordEnv X-type row j = slot
         // 2j, Z-type row N + j = slot 2j + 1; LinearFunctionEnv row j = slot j).  Both lane halves hold the env: half h writes the
         // X (h = 0) / Z (h = 1) rows, or the even / odd groups of a LinearFunctionEnv.
@@ -393,34 +395,28 @@ __global__ __launch_bounds__(64 * EMS_WAVES) void embed_small_kernel(EmbedArgs a
             }
         }
     }
-    f32x16 acc0, acc1;
+    f32x16 acc0;
 #pragma unroll
-    for (uint32_t q = 0; q < 16; ++q) acc0[q] = acc1[q] = 0.0f;
+    for (uint32_t q = 0; q < 16; ++q) acc0[q] = 0.0f;
 #pragma unroll
     for (uint32_t g = 0; g < G; ++g) {
-        if (g + 1u < G) fetch(g + 1u, wb[(g + 1u) & 1u]);
+        if (g + EMS_AHEAD - 1u < G) fetch(g + EMS_AHEAD - 1u, wb[(g + EMS_AHEAD - 1u) % EMS_AHEAD]);
 #pragma unroll
         for (uint32_t ss = 0; ss < 8; ++ss) {
             const uint32_t comp = ss >> 1;
             const uint32_t word = comp == 0 ? bits[g].x : comp == 1 ? bits[g].y : comp == 2 ? bits[g].z : bits[g].w;
             const bf16x8 af = emb_expand(word, sh[ss & 1u]);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, wb[g & 1u][ss][0]), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, wb[g & 1u][ss][1]), acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, wb[g % EMS_AHEAD][ss]), acc0, 0, 0, 0);
         }
     }
-    // x 0.5 + bias (exact scaling: one rounding), ReLU, bf16; C layout: column pair of this slab = lane & 31, env row = (q & 3) + 8 (q >> 2) + 4 h
-    const uint64_t ldw = a.ld_out >> 1;  // dwords per output row
-    uint32_t *out = a.out + slab * (EMB_SLAB / 2u) + r;
+    // x 0.5 + bias (exact scaling: one rounding), ReLU, bf16; C layout: column 2 (lane & 31) + nb of this slab, env row = (q & 3) + 8 (q >> 2) + 4 h
+    __hip_bfloat16 *out = reinterpret_cast<__hip_bfloat16 *>(a.out) + n0;
 #pragma unroll
     for (uint32_t q = 0; q < 16; ++q) {
-        float v0 = __builtin_fmaf(acc0[q], 0.5f, bias0), v1 = __builtin_fmaf(acc1[q], 0.5f, bias1);
-        if (a.relu) {
-            v0 = __builtin_amdgcn_fmed3f(v0, 0.0f, __builtin_inff());
-            v1 = __builtin_amdgcn_fmed3f(v1, 0.0f, __builtin_inff());
-        }
-        const f32x2 v = {v0, v1};
+        float v0 = __builtin_fmaf(acc0[q], 0.5f, bias0);
+        if (a.relu) v0 = __builtin_amdgcn_fmed3f(v0, 0.0f, __builtin_inff());
         const uint64_t e = tile * 32u + (q & 3u) + 8u * (q >> 2) + 4u * h;
-        if (e < a.B) out[e * ldw] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        if (e < a.B) out[e * a.ld_out] = __float2bfloat16(v0);
     }
 }
 
@@ -1300,15 +1296,22 @@ static int embed_impl(qg_vec *v, const void *packed_dev, const float *bias_dev, 
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, v->device);
     hipStream_t s = (hipStream_t)stream;
     const uint64_t env_tiles = (v->B + 31u) / 32u;
-    const bool small = env_tiles * a.n_slabs <= (uint64_t)EMS_WAVES * (uint64_t)cus;  // at most one workgroup per CU of embed_small_kernel: too few envs for 512-env passes
+    const bool small = env_tiles * a.n_slabs <= (uint64_t)EMS_TILES * (uint64_t)cus;  // at most one workgroup per CU of embed_small_kernel: too few envs for 512-env passes
     if (obs_dev) {
         if (small && (reinterpret_cast<uintptr_t>(obs_dev) & 15u) == 0) a.obs = reinterpret_cast<uint32_t *>(obs_dev);  // written by the same launch
         else if (const int rc = qg_vec_observe_packed(v, obs_dev, stream)) return rc;
     }
     if (small) {
-        const dim3 grid((unsigned)(((env_tiles + EMS_WAVES - 1) / EMS_WAVES) * a.n_slabs)), block(64 * EMS_WAVES);
+        // one env tile per workgroup while that leaves every workgroup a CU of its own (each wave then pulls its half slab, 64 KiB, and
+        // nobody else's); otherwise four tiles under a slab (their loads meet in the CU's vector cache)
+        const bool one = env_tiles * a.n_slabs <= (uint64_t)cus;
+        const uint32_t tiles_wg = one ? 1u : EMS_TILES;
+        const dim3 grid((unsigned)(((env_tiles + tiles_wg - 1) / tiles_wg) * a.n_slabs)), block(128 * tiles_wg);
 #define QG_EMS_CASE(GG)                                                           \
-    case GG: hipLaunchKernelGGL(embed_small_kernel<GG>, grid, block, 0, s, a); break;
+    case GG:                                                                      \
+        if (one) hipLaunchKernelGGL((embed_small_kernel<GG, 1>), grid, block, 0, s, a);      \
+        else hipLaunchKernelGGL((embed_small_kernel<GG, EMS_TILES>), grid, block, 0, s, a);  \
+        break;
         switch (G) {
             QG_EMS_CASE(2) QG_EMS_CASE(3) QG_EMS_CASE(4) QG_EMS_CASE(5) QG_EMS_CASE(6) QG_EMS_CASE(7) QG_EMS_CASE(8)
         default: return set_error(QG_ERR_UNSUPPORTED, "unexpected row-group count %u", G);
