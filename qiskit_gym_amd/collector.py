@@ -339,8 +339,8 @@ class RolloutCollector:
         self.clock = torch.zeros(1, dtype=torch.int64, device=env.device)  # collector steps taken so far
         env.set_clock(self.clock)
         # the policy-layer kernels at every batch size: below ~ 4 096 envs the launches take their small-batch shapes (a 32-env tile per
-        # wave / workgroup, weight fragments straight from L2: CliffordGym 16q x 1 024 envs 21 us per step against 42 us on library GEMMs)
-        words_auto = use_bit_embedding is None and env.batch < 4096  # the first layer from packed WORDS has no small-batch shape: library GEMM there
+        # wave / workgroup, weight fragments straight from L2: CliffordGym 16q x 1 024 envs 21 us per step against 42 us on library GEMMs,
+        # PauliGym 20q 36 against 44)
         if use_bit_embedding is None:
             use_bit_embedding = True
         if use_fused_head is None:
@@ -360,7 +360,7 @@ class RolloutCollector:
         # words the rollout stores anyway (64-bit row words, even row count)
         self._embed_words = None
         self._cur_words = None
-        if (self._embed is None and use_bit_embedding and not words_auto and isinstance(self.policy, BasicPolicy) and dtype == torch.bfloat16 and store_obs == "packed"
+        if (self._embed is None and use_bit_embedding and isinstance(self.policy, BasicPolicy) and dtype == torch.bfloat16 and store_obs == "packed"
                 and env.packed_word_bytes == 8 and env.packed_words_per_env == r and self.policy.embeddings.in_features == self.obs_size):
             try:
                 self._embed_words = (pack_embed_words(self.policy.embeddings.weight, r, c), self.policy.embeddings.bias.detach().float().contiguous())

@@ -1226,6 +1226,72 @@ __global__ __launch_bounds__(64 * EW_WAVES, NB == 2 ? 3 : 2) void embed_words_ke
     }
 }
 
+// Small batches: embed_words_kernel's workgroup takes 256 (NB = 4) or 128 envs under a 128- or 64-column tile whose weights stream
+// through LDS, so 1 024 PauliGym envs occupy a few dozen CUs for 16 us.  As in embed_small_kernel a wave here owns one tile of 32 envs
+// and ONE of the four fragment columns of a 128-column tile, and takes its fragments (1 KiB each, the packed layout is fragment order)
+// from L2 straight into registers, EWS_AHEAD 16-byte groups ahead; the two waves of a workgroup share the env tile (and a CU) and take
+// fragments f and f + 1 of a column-tile half.  Same packed weights, same expansion, same k order: bit-identical activations.
+constexpr uint32_t EWS_AHEAD = 4;  // groups (KPG fragments + one 16-byte word group each) in flight per wave
+
+template <uint32_t KPG>
+__global__ __launch_bounds__(128) void embed_words_small_kernel(EmbedWordsArgs a) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t per_tile = a.n_ctiles * 2u;  // workgroups per env tile: (column tile, half)
+    const uint32_t ch = blockIdx.x % per_tile, ct = ch >> 1, f = (ch & 1u) * 2u + wave;  // this wave's fragment of every k-step
+    const uint64_t tile = blockIdx.x / per_tile;
+    const uint32_t G = a.groups;
+    const uint32_t r = lane & 31u, h = lane >> 5;
+    const uint32_t shA = 4u * h, shB = 8u + 4u * h, shS = 21u + 4u * h;
+    uint64_t env = tile * 32u + r;
+    env = env < a.B ? env : a.B - 1;  // rows past the batch compute on the last env and are not stored
+    const uint4 *pw = a.words + env * G;
+    const uint4 *wf = a.wp + (uint64_t)ct * G * (KPG * EW_NB * 64u) + f * 64u + lane;  // fragment (group g, k-step s) = wf[(g * KPG + s) * EW_NB * 64]
+    uint4 wds[EWS_AHEAD], wb[EWS_AHEAD][KPG];
+    auto fetch = [&](uint32_t g, uint32_t slot) {
+        wds[slot] = pw[g];
+#pragma unroll
+        for (uint32_t s = 0; s < KPG; ++s) wb[slot][s] = wf[(uint64_t)(g * KPG + s) * (EW_NB * 64u)];
+    };
+    f32x16 acc;
+#pragma unroll
+    for (uint32_t q = 0; q < 16; ++q) acc[q] = 0.0f;
+    auto multiply = [&](uint32_t slot) {
+#pragma unroll
+        for (uint32_t s = 0; s < KPG; ++s) {
+            uint32_t word, mode;
+            ew_kstep(KPG, s, word, mode);
+            uint32_t wv = word == 0 ? wds[slot].x : word == 1 ? wds[slot].y : word == 2 ? wds[slot].z : wds[slot].w;
+            if (mode == 2u) wv = (wv & 0xFFu) | ((wv << 8) & 0xFF0000u);  // bits 8..15 -> 16..23 (embed_words_kernel)
+            const bf16x8 af = emb_expand(wv, mode == 0u ? shA : mode == 1u ? shB : shS);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, wb[slot][s]), acc, 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (uint32_t g = 0; g + 1u < EWS_AHEAD; ++g)
+        if (g < G) fetch(g, g);
+    for (uint32_t g0 = 0; g0 < G; g0 += EWS_AHEAD) {  // EWS_AHEAD groups per trip: the register ring is indexed statically
+#pragma unroll
+        for (uint32_t k = 0; k < EWS_AHEAD; ++k) {
+            const uint32_t g = g0 + k;
+            if (g < G) {
+                if (g + EWS_AHEAD - 1u < G) fetch(g + EWS_AHEAD - 1u, (k + EWS_AHEAD - 1u) % EWS_AHEAD);
+                multiply(k);
+            }
+        }
+    }
+    // x 0.5 + bias, ReLU, bf16; C layout: column ct * 128 + 64 (f >> 1) + 2 (lane & 31) + (f & 1), env row = (q & 3) + 8 (q >> 2) + 4 h
+    const uint32_t n0 = ct * EW_COLS + 64u * (f >> 1) + 2u * r + (f & 1u);
+    const float bias0 = a.bias ? a.bias[n0] : 0.0f;
+    __hip_bfloat16 *out = reinterpret_cast<__hip_bfloat16 *>(a.out) + n0;
+#pragma unroll
+    for (uint32_t q = 0; q < 16; ++q) {
+        float v0 = __builtin_fmaf(acc[q], 0.5f, bias0);
+        if (a.relu) v0 = __builtin_amdgcn_fmed3f(v0, 0.0f, __builtin_inff());
+        const uint64_t e = tile * 32u + (q & 3u) + 8u * (q >> 2) + 4u * h;
+        if (e < a.B) out[e * a.ld_out] = __float2bfloat16(v0);
+    }
+}
+
 }  // namespace qg
 
 using namespace qg;
@@ -1405,6 +1471,17 @@ int qg_policy_embed_words(const uint64_t *words_dev, uint64_t batch, uint32_t ro
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint64_t small_wgs = ((batch + 31u) / 32u) * a.n_ctiles * 2u;
+    if (small_wgs <= 2ull * (uint64_t)cus) {  // at most two workgroups of embed_words_small_kernel per CU (PauliGym 20q collector: 36 against 41 us per step at 1 024 envs, 39 against 42 at 2 048; 46 against 45 at 4 096)
+        const dim3 sgrid((unsigned)small_wgs), sblock(128);
+        switch (ew_kpg(cols)) {
+        case 4: hipLaunchKernelGGL(embed_words_small_kernel<4>, sgrid, sblock, 0, s, a); break;
+        case 6: hipLaunchKernelGGL(embed_words_small_kernel<6>, sgrid, sblock, 0, s, a); break;
+        default: hipLaunchKernelGGL(embed_words_small_kernel<8>, sgrid, sblock, 0, s, a); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return QG_OK;
+    }
     const bool narrow = etiles * a.n_ctiles < 2ull * (uint64_t)cus;
     const dim3 ngrid((unsigned)(etiles * a.n_ctiles * 2u));
     switch (ew_kpg(cols) * 10u + (narrow ? 2u : 4u)) {

@@ -24,6 +24,10 @@ SHAPES = [  # rows, cols, batch, hidden
     (2, 64, 256, 128),
     (40, 45, 33000, 512),  # enough tiles for the 128-column workgroup shape (smaller launches use 64-column tiles)
     (6, 64, 70000, 256),
+    # launches small enough to give every (32-env tile, half column tile) workgroup a CU take embed_words_small_kernel (most rows above);
+    # these two are past that and still below the 128-column shape: the 64-column tiles
+    (40, 45, 9000, 256),
+    (8, 9, 17000, 128),
 ]
 
 

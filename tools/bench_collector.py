@@ -10,7 +10,7 @@ from qiskit_gym_amd.vec import VecEnv
 from util import line_gateset
 
 ONLY = os.environ.get("ONLY")  # e.g. ONLY=65536 to run the large batch only (profiling)
-for B, store, graph in ((1024, "packed", False), (1024, "packed", True), (2048, "packed", True), (4096, "packed", True), (8192, "packed", False), (8192, "packed", True), (65536, "dense", False), (65536, "packed", False), (65536, "packed", True)):
+for B, store, graph in ((1024, "packed", False), (1024, "packed", True), (2048, "packed", True), (4096, "packed", True), (8192, "packed", False), (8192, "packed", True), (16384, "packed", True), (32768, "packed", True), (65536, "dense", False), (65536, "packed", False), (65536, "packed", True)):
     if ONLY and (B != int(ONLY) or store != "packed" or graph):
         continue
     if os.environ.get("GRAPH") == "1" and not graph:  # GRAPH=1: the hipGraph configurations only (small-batch A/Bs)
