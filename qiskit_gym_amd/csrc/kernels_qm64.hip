@@ -366,6 +366,192 @@ __global__ __launch_bounds__(256) void q64_step_kernel(StepArgs a) {
     if (a.bad) reinterpret_cast<uint64_t *>(a.bad)[env] = q64_badmask<NS, HAS_Z>(s, a.N);  // the one-step kernel may run next
 }
 
+// ------------------------------------------------------------------------------------------
+// The reference-default step (add_inverts, one step per launch, every env symplectic) with TWO lanes per env, as qm_inv2_kernel does
+// for N <= 16: q64_step_kernel above is ~5 800 instructions per env at one wave per SIMD (64 x 64 transpose in 64-bit words, the
+// column shuffles into and out of "slot space", select trees over 64 rows).  Here lane h of a pair holds the X-type (h = 0) or
+// Z-type (h = 1) rows of all qubits, each as two 32-bit words {lo = X columns, hi = Z columns}: the matrix is four 32 x 32 blocks
+// [A B; C D] (lane 0: A | B, lane 1: C | D), always padded to 32 qubits with identity rows (the inverse of diag(M, 1) is
+// diag(M^-1, 1)), so that
+//     M^-1 = Omega M^T Omega:   X row i = {lo = D^T_i, hi = B^T_i},   Z row i = {lo = C^T_i, hi = A^T_i}
+// is two 32 x 32 transposes in each lane's own registers (32-bit operations) and ONE exchange of 32 words with the partner lane
+// (DPP quad_perm [1, 0, 3, 2]); the gate's 4 x 4 GF(2) map needs the partner's two rows (4 DPP moves).
+// ------------------------------------------------------------------------------------------
+__device__ inline uint32_t q64_pair_swap(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }
+
+template <int n>
+__device__ inline uint32_t q64_tree_select32(const uint32_t (&t)[n], uint32_t q) {
+    if constexpr (n == 1) {
+        return t[0];
+    } else {
+        constexpr int m = (n + 1) / 2;
+        uint32_t u[m];
+        const uint32_t mb = 0u - (q & 1u);
+#pragma unroll
+        for (int k = 0; k < m; ++k) u[k] = (2 * k + 1 < n) ? ((t[2 * k + 1] & mb) | (t[2 * k] & ~mb)) : t[2 * k];
+        return q64_tree_select32<m>(u, q >> 1);
+    }
+}
+
+__device__ inline void q64_transpose32(uint32_t (&w)[32]) {
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int d = 16 >> st;
+        const uint32_t m = st == 0 ? 0x0000FFFFu : st == 1 ? 0x00FF00FFu : st == 2 ? 0x0F0F0F0Fu : st == 3 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if ((i & d) == 0) {
+                const uint32_t lo = w[i], hi = w[i + d];
+                w[i] = (lo & m) | ((hi & m) << d);
+                w[i + d] = ((lo >> d) & m) | (hi & ~m);
+            }
+        }
+    }
+}
+
+// NQ = qubit slots in memory (NS / 2 = N rounded up to 4)
+template <int NQ, bool FEAT>
+__global__ __launch_bounds__(256) void q64_inv2_kernel(StepArgs a) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t env = tid >> 1;
+    const uint32_t h = (uint32_t)tid & 1u;
+    QG_PREFETCH_STEP_ARGS(a);
+    if (env >= a.B) return;  // whole lane pairs leave together
+    const uint32_t N = a.N;
+    // group q = {X row of qubit q, Z row of qubit q} (two uint64): this lane's half of it
+    uint2 *rows = reinterpret_cast<uint2 *>(reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(NQ * 64) + (env & 63u)) + h;
+    uint2 raw[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) raw[q] = rows[(uint32_t)q * 128u];  // 64 uint4 = 128 uint2 per group
+    int32_t depth = a.depth[env];
+    uint32_t iflags = a.inverted[env];
+    uint32_t coin = a.coins ? a.coins[env] : 0u;
+    int32_t sol_n = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2] : 0;
+    int32_t sol_b = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2 + 1] : 0;
+    const int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
+    const bool in_range = act >= 0 && act < (int64_t)a.num_actions;  // gateset.get(action) (clifford.rs:324)
+    GateEntry g = a.gates[in_range ? act : 0];  // unconditional (clamped) load: nothing else waits behind a branch
+    if (!in_range) g = GateEntry{Q64_IDENTITY << 12, 0.0f};
+    if (!a.coins) coin = (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, a.env_base + env, step_clock(a)) >> 63);  // runs under the loads
+    // block form: stored word = X columns | Z columns << N; rows of the padding qubits N .. 31 are the identity's
+    uint32_t lo[32], hi[32];
+    const uint32_t xm = N >= 32 ? 0xFFFFFFFFu : ((1u << N) - 1u);
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        uint32_t l = h ? 0u : 1u << q, u = h ? 1u << q : 0u;
+        if (q < NQ) {
+            const uint64_t w = (uint64_t)raw[q].x | ((uint64_t)raw[q].y << 32);
+            const bool real = (uint32_t)q < N;
+            l = real ? (uint32_t)w & xm : l;
+            u = real ? (uint32_t)(w >> N) & xm : u;
+        }
+        lo[q] = l;
+        hi[q] = u;
+    }
+    uint32_t fault = 0;
+    float penalty = g.penalty;
+    if (FEAT && (a.flags & F_LAYERS) && in_range && h == 0) penalty = layers_penalty(layer_rec(a.layers, env, 2 * N + 2), N, a.descs[act], a.w);
+
+    // ---- apply_gate_to_state (clifford.rs:331): the 4x4 GF(2) map on {X[q0], Z[q0], X[q1], Z[q1]}; this lane makes its own type's two rows ----
+    uint32_t dirty = 0;  // qubits whose rows changed
+    {
+        const uint32_t q0 = g.ops & 63u, q1 = (g.ops >> 6) & 63u, m = (g.ops >> 12) & 0xFFFFu;
+        const uint32_t o0l = q64_tree_select32<32>(lo, q0), o0h = q64_tree_select32<32>(hi, q0);
+        const uint32_t o1l = q64_tree_select32<32>(lo, q1), o1h = q64_tree_select32<32>(hi, q1);
+        const uint32_t p0l = q64_pair_swap(o0l), p0h = q64_pair_swap(o0h), p1l = q64_pair_swap(o1l), p1h = q64_pair_swap(o1h);
+        // inputs in the order X0, Z0, X1, Z1: the X rows are lane 0's
+        const uint32_t x0l = h ? p0l : o0l, x0h = h ? p0h : o0h, z0l = h ? o0l : p0l, z0h = h ? o0h : p0h;
+        const uint32_t x1l = h ? p1l : o1l, x1h = h ? p1h : o1h, z1l = h ? o1l : p1l, z1h = h ? o1h : p1h;
+        auto mix = [&](uint32_t k, uint32_t &ol, uint32_t &oh) {  // out_k = xor_i M[k][i] * in_i
+            const uint32_t b = m >> (4 * k);
+            const uint32_t s0 = 0u - (b & 1u), s1 = 0u - ((b >> 1) & 1u), s2 = 0u - ((b >> 2) & 1u), s3 = 0u - ((b >> 3) & 1u);
+            ol = (s0 & x0l) ^ (s1 & z0l) ^ (s2 & x1l) ^ (s3 & z1l);
+            oh = (s0 & x0h) ^ (s1 & z0h) ^ (s2 & x1h) ^ (s3 & z1h);
+        };
+        uint32_t n0l, n0h, n1l, n1h;
+        mix(h, n0l, n0h);       // X[q0] (k = 0) or Z[q0] (k = 1)
+        mix(2u + h, n1l, n1h);  // X[q1] (k = 2) or Z[q1] (k = 3)
+        if (m != Q64_IDENTITY) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {  // q1's rows first, then q0's (q0's value wins when q0 == q1, as in q64_apply)
+                const bool h1 = q1 == (uint32_t)j, h0 = q0 == (uint32_t)j;
+                uint32_t vl = lo[j], vh = hi[j];
+                vl = h1 ? n1l : vl; vh = h1 ? n1h : vh;
+                vl = h0 ? n0l : vl; vh = h0 ? n0h : vh;
+                lo[j] = vl; hi[j] = vh;
+            }
+            dirty = (1u << q0) | (1u << q1);
+        }
+    }
+
+    if (FEAT && (a.flags & F_TRACK) && h == 0) {  // clifford.rs:334-340: entries in push order, bit 31 = pushed to solution_inv
+        if ((uint32_t)(sol_n + sol_b) < a.sol_cap) {
+            const bool inv_frame = iflags & Q64_FLAG_INVERTED;
+            sol_at(a, env, (uint32_t)(sol_n + sol_b)) = sol_word_framed(act, inv_frame);
+            if (inv_frame) ++sol_b;
+            else ++sol_n;
+        } else {
+            fault |= 8u;
+        }
+    }
+    depth = depth > 0 ? depth - 1 : 0;  // clifford.rs:342
+
+    // ---- maybe_random_invert (clifford.rs:262-270) ----------------------------------------------------------------------------
+    if (coin & 1u) {  // both lanes of a pair take the same branch
+        if (iflags & Q64_FLAG_SYMPLECTIC) {
+            q64_transpose32(lo);  // lane 0: A^T, lane 1: C^T
+            q64_transpose32(hi);  // lane 0: B^T, lane 1: D^T
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const uint32_t got = q64_pair_swap(h ? hi[i] : lo[i]);  // lane 0 receives D^T, lane 1 receives A^T
+                const uint32_t nl = h ? lo[i] : got, nh = h ? got : hi[i];
+                lo[i] = nl;
+                hi[i] = nh;
+            }
+            iflags ^= Q64_FLAG_INVERTED;
+            dirty = 0xFFFFFFFFu;
+        } else {
+            fault |= QG_FAULT_BAD_STATE;  // unreachable: the host launches the Gauss-Jordan variant whenever such an env may exist
+        }
+    }
+
+    // ---- solved (clifford.rs:344), the per-qubit mask the one-step kernel keeps, reward (:345-346) --------------------------------
+    uint32_t bad = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const bool real = (uint32_t)q < N;
+        const uint32_t wl = h ? 0u : 1u << q, wh = h ? 1u << q : 0u;
+        bad |= (uint32_t)(real && (lo[q] != wl || hi[q] != wh)) << q;
+    }
+    bad |= q64_pair_swap(bad);
+    const bool solved = bad == 0;
+    const float achieved = solved ? 1.0f : 0.0f;
+    const float reward = achieved - penalty;
+
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (((dirty >> q) & 1u) && (uint32_t)q < N) {
+            const uint64_t w = (uint64_t)lo[q] | ((uint64_t)hi[q] << N);
+            rows[(uint32_t)q * 128u] = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+        }
+    }
+    if (h == 0) {
+        if (a.rewards_seq) a.rewards_seq[env] = reward;
+        if (a.dones_seq) a.dones_seq[env] = (uint8_t)(depth == 0 || solved);
+        a.depth[env] = depth;
+        a.reward[env] = reward;
+        a.done[env] = (uint8_t)(depth == 0 || solved);  // is_final (clifford.rs:353)
+        a.success[env] = (uint8_t)solved;
+        if (FEAT && (a.flags & F_TRACK)) {
+            a.sol_len[env * 2] = sol_n;
+            a.sol_len[env * 2 + 1] = sol_b;
+        }
+        a.inverted[env] = (uint8_t)iflags;
+        if (fault) atomicOr(&a.error[env], fault);
+        if (a.bad) reinterpret_cast<uint64_t *>(a.bad)[env] = (uint64_t)bad;  // the one-step kernel may run next
+    }
+}
+
 // One step per launch without holding the matrix (see qm_step1_kernel in kernels_qm.hip): the gate's
 // <= 2 groups ({X[q], Z[q]} of a qubit for CliffordEnv, a row pair for LinearFunctionEnv) are gathered
 // and scattered at per-lane addresses, `solved` comes from the incrementally kept 64-bit `bad` mask.
@@ -671,6 +857,12 @@ static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
     }
     if constexpr (HAS_Z) {
         if (a.flags & F_INVERTS) {
+            if (!(a.flags & F_GJ) && a.T == 1) {  // every env symplectic, one step per launch: two lanes per env
+                const dim3 grid2(grid_for(2 * a.B, 256));
+                if (a.flags & (F_TRACK | F_LAYERS)) hipLaunchKernelGGL((q64_inv2_kernel<NS / 2, true>), grid2, block, 0, s, a);
+                else hipLaunchKernelGGL((q64_inv2_kernel<NS / 2, false>), grid2, block, 0, s, a);
+                return hipGetLastError();
+            }
             if (a.flags & F_GJ) hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, true, true, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, true, true, false>), grid, block, 0, s, a);
             return hipGetLastError();
