@@ -1687,7 +1687,7 @@ int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s) 
     const int64_t d = (int64_t)v->cfg.depth_slope * v->difficulty;  // pauli.rs:578
     ga.depth_value = (int32_t)std::min<int64_t>(d, v->cfg.max_depth);
     ga.only_done = only_done ? 1u : 0u;
-    if (only_done && v->done_list) {  // pack the finished envs: full waves instead of one live lane in every wave
+    if (only_done && v->done_list && v->B > QG_COMPACT_MIN_ENVS) {  // pack the finished envs: full waves instead of one live lane in every wave
         HIP_TRY(compact_done(v->done, v->B, v->done_list, v->done_list + v->B, s));
         ga.list = v->done_list;
         ga.list_count = v->done_list + v->B;

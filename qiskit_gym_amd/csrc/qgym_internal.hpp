@@ -121,6 +121,11 @@ struct StepArgs {
 #define QG_PREFETCH_STEP_ARGS(a) ((void)0)
 #endif
 
+// PauliEnv's qg_vec_reset_done packs the finished envs' indices first (compact_done) only for batches above this: a small batch is a
+// handful of waves that all hold a finished env anyway, and the extra launch costs more than the generator saves (the other envs
+// always pack: their short lists go to the 16-lanes-per-env scramble, which is the faster one at any batch)
+constexpr uint64_t QG_COMPACT_MIN_ENVS = 4096;
+
 // state (re)initialisation
 struct InitArgs {
     void *state;

@@ -8,7 +8,7 @@ from util import grid_gateset, line_gateset
 
 for kind, n, diff in (("clifford", 16, 256), ("clifford", 16, 32), ("pauli", 20, 128), ("clifford", 32, 256), ("linear_function", 8, 64), ("permutation", 9, 16)):
     gs = grid_gateset("permutation", 3, 3) if kind == "permutation" else line_gateset(kind, n)
-    B = 65536
+    B = int(os.environ.get("B", "65536"))
     kw = dict(add_perms=False, track_solution=False, difficulty=diff)
     if kind != "pauli":
         kw["add_inverts"] = False
