@@ -298,8 +298,9 @@ int qg_gae(const float *rewards_dev, const float *values_dev, const uint8_t *don
 /* The policy's first layer computed straight from the resident bit-packed state (no dense observation
  * is written or read): out[e, n] = act(sum_k obs[e, k] * W[n, k] + bias[n]) in bf16, obs = Env::observe
  * densified and flattened as in qg_vec_observe_dense_as -- the Linear(prod(obs_shape) -> hidden) that opens
- * the reference's policy network (rl/configs.py:531-607; examples/models/ *.pt).  TILE-layout handles only
- * (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32; QG_ERR_UNSUPPORTED otherwise); hidden % 64 == 0.
+ * the reference's policy network (rl/configs.py:531-607; examples/models/ *.pt).  Handles whose rows are resident uint32
+ * words only (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32 with or without add_inverts; QG_ERR_UNSUPPORTED otherwise);
+ * hidden % 64 == 0.
  * qg_vec_pack_embedding re-orders W ([hidden, ld] of f32 / bf16, ld >= obs_rows*obs_cols) into the k order
  * the kernel's in-register bit expansion produces (qg_vec_embed_packed_bytes bytes; repeat after every
  * optimiser step); qg_vec_embed runs the layer: bias_dev f32 [hidden] or NULL, relu != 0 applies max(0, .),

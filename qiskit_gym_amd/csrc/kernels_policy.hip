@@ -108,6 +108,10 @@ struct EmbedArgs {
     uint32_t relu;
     uint32_t *obs;          // embed_small_kernel: also the packed observation [B][D] (what qg_vec_observe_packed writes), or null
     uint32_t N, D, has_z;
+    // LFD layout (LinearFunctionEnv with add_inverts, kernels_lfd.hip): a tile holds two regions of G groups, bit 0 of the env's
+    // `inverted` byte says which one is the state.  TILE layout: region == null, tile_groups == G.
+    const uint8_t *region;
+    uint32_t tile_groups;   // 16-byte groups per env in a tile
 };
 
 // A fragment (8 bf16 for this lane's row and k-half) from a row word: see the header comment
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(EMB_THREADS, 1) void embed_bits_kernel(EmbedArgs a)
         for (uint32_t i = 0; i < EMB_MA; ++i) {
             uint64_t env = e0 + 32u * i + r;
             env = env < a.B ? env : a.B - 1;  // tail: duplicate the last env, its rows are not stored
-            p[i] = a.state + (env >> 6) * (uint64_t)(G * 64u) + (env & 63u);
+            p[i] = a.state + (env >> 6) * (uint64_t)(a.tile_groups * 64u) + (env & 63u) + (a.region ? (a.region[env] & 1u) * (G * 64u) : 0u);
         }
     };
     const uint4 *pc[EMB_MA], *pnx[EMB_MA];  // this pass, next pass (past the last pass: this pass again, the data is not used)
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(128 * TILES) void embed_small_kernel(EmbedArgs a) {
     const uint32_t sh[2] = {4u * h, 8u + 4u * h};
     uint64_t env = tile * 32u + r;
     env = env < a.B ? env : a.B - 1;  // tail: duplicate the last env, its rows are not stored
-    const uint4 *ps = a.state + (env >> 6) * (uint64_t)(G * 64u) + (env & 63u);
+    const uint4 *ps = a.state + (env >> 6) * (uint64_t)(a.tile_groups * 64u) + (env & 63u) + (a.region ? (a.region[env] & 1u) * (G * 64u) : 0u);
     const uint4 *pw = a.wp + (uint64_t)slab * slab_vec + nb * 64u + lane;  // fragment (k-step s, nb) = pw[2 s * 64]
     uint4 bits[G], wb[EMS_AHEAD][8];
     auto fetch = [&](uint32_t g, uint4 (&b)[8]) {
@@ -1298,20 +1302,23 @@ using namespace qg;
 
 extern "C" {
 
+// Layouts whose resident rows are uint32 words in 16-byte groups of four, tiles of 64 envs: TILE, and LFD with N <= 32 (two regions per tile)
+static bool emb_layout(const qg_vec *v) { return v->layout == LAYOUT_TILE || (v->layout == LAYOUT_LFD && !v->w64); }
+static uint32_t emb_rows(const qg_vec *v) { return v->layout == LAYOUT_LFD ? 4u * v->nxp : (v->has_z ? 2 * v->nxp : v->nxp); }  // row slots per matrix
+#define QG_EMB_LAYOUTS "the bit-consuming first layer needs uint32 rows resident in tiles (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32)"
+
 size_t qg_vec_embed_packed_bytes(const qg_vec *v, uint32_t hidden) {
-    if (!v || v->layout != LAYOUT_TILE || hidden == 0 || hidden % EMB_SLAB) return 0;
-    const uint32_t R = v->has_z ? 2 * v->nxp : v->nxp;
-    return (size_t)hidden * 16u * emb_ksteps(R) * 2u;
+    if (!v || !emb_layout(v) || hidden == 0 || hidden % EMB_SLAB) return 0;
+    return (size_t)hidden * 16u * emb_ksteps(emb_rows(v)) * 2u;
 }
 
 int qg_vec_pack_embedding(qg_vec *v, const void *weight_dev, int weight_dtype, uint64_t ld, uint32_t hidden, void *packed_dev, void *stream) {
     if (!v || !weight_dev || !packed_dev) return set_error(QG_ERR_INVALID, "null argument");
-    if (v->layout != LAYOUT_TILE)
-        return set_error(QG_ERR_UNSUPPORTED, "the bit-consuming first layer needs the TILE layout (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32)");
+    if (!emb_layout(v)) return set_error(QG_ERR_UNSUPPORTED, QG_EMB_LAYOUTS);
     if (hidden == 0 || hidden % EMB_SLAB) return set_error(QG_ERR_INVALID, "hidden size must be a multiple of %u", EMB_SLAB);
     if (ld < (uint64_t)v->D * v->D) return set_error(QG_ERR_INVALID, "weight rows are shorter than the observation (%u x %u)", v->D, v->D);
     QG_ON_DEVICE(v);
-    const uint32_t R = v->has_z ? 2 * v->nxp : v->nxp;
+    const uint32_t R = emb_rows(v);
     if (!v->embed_dump) HIP_TRY(hipMalloc(&v->embed_dump, 1024));  // see EmbedArgs::dump
     const uint64_t total = (uint64_t)hidden * 16u * emb_ksteps(R);
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
@@ -1334,13 +1341,12 @@ int qg_vec_pack_embedding(qg_vec *v, const void *weight_dev, int weight_dtype, u
 static int embed_impl(qg_vec *v, const void *packed_dev, const float *bias_dev, uint32_t hidden, int relu, void *out_dev, uint64_t ld_out, void *obs_dev,
                       void *stream) {
     if (!v || !packed_dev || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
-    if (v->layout != LAYOUT_TILE)
-        return set_error(QG_ERR_UNSUPPORTED, "the bit-consuming first layer needs the TILE layout (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32)");
+    if (!emb_layout(v)) return set_error(QG_ERR_UNSUPPORTED, QG_EMB_LAYOUTS);
     if (hidden == 0 || hidden % EMB_SLAB) return set_error(QG_ERR_INVALID, "hidden size must be a multiple of %u", EMB_SLAB);
     if (ld_out < hidden || (ld_out & 7u) || (reinterpret_cast<uintptr_t>(out_dev) & 15u))
         return set_error(QG_ERR_INVALID, "the output must be 16-byte aligned with a row stride that is a multiple of 8 elements");
     QG_ON_DEVICE(v);
-    const uint32_t R = v->has_z ? 2 * v->nxp : v->nxp;
+    const uint32_t R = emb_rows(v);
     EmbedArgs a;
     a.state = reinterpret_cast<const uint4 *>(v->state);
     a.wp = reinterpret_cast<const uint4 *>(packed_dev);
@@ -1357,6 +1363,8 @@ static int embed_impl(qg_vec *v, const void *packed_dev, const float *bias_dev, 
     a.D = v->has_z ? 2u * v->N : v->N;
     a.has_z = v->has_z ? 1u : 0u;
     const uint32_t G = R / 4;
+    a.region = v->layout == LAYOUT_LFD ? v->inverted : nullptr;
+    a.tile_groups = v->layout == LAYOUT_LFD ? 2u * G : G;
     const size_t lds = (size_t)emb_groups(R) * 8u * 2u * 64u * 16u;  // <= 128 KiB (R <= 32)
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, v->device);

@@ -139,17 +139,19 @@ def test_graph_replays_collect_the_same_rollouts_as_eager_calls(kind, n, kw):
     assert sum(int(r["dones"].sum()) for r in rollouts[True]) > B
 
 
-def test_graph_replay_with_the_bit_consuming_first_layer():
-    """bf16 policy on a TILE-layout env: the captured collection launches qg_vec_embed instead of observe + GEMM,
-    and a replay after an in-place parameter update uses the repacked weights."""
+@pytest.mark.parametrize("kind,n,inverts,B", [("clifford", 6, False, 256), ("linear_function", 12, True, 256), ("linear_function", 12, True, 9000)])
+def test_graph_replay_with_the_bit_consuming_first_layer(kind, n, inverts, B):
+    """bf16 policy on an env whose rows are resident uint32 words (TILE layout; LinearFunctionEnv with add_inverts, the reference's
+    default: the dual layout): the captured collection launches qg_vec_embed instead of observe + GEMM, and a replay after an
+    in-place parameter update uses the repacked weights."""
     from qiskit_gym_amd.collector import BasicPolicy, RolloutCollector
     from qiskit_gym_amd.vec import VecEnv
 
-    B, T = 256, 5
-    gs = line_gateset("clifford", 6)
-    env = VecEnv("clifford", 6, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=3)
+    T = 5
+    gs = line_gateset(kind, n)
+    env = VecEnv(kind, n, gs, B, add_inverts=inverts, add_perms=False, track_solution=False, difficulty=3)
     torch.manual_seed(5)
-    pol = BasicPolicy(144, len(gs), embedding_size=128, common=64)
+    pol = BasicPolicy(env.obs_shape_[0] * env.obs_shape_[1], len(gs), embedding_size=128, common=64)
     col = RolloutCollector(env, pol, dtype=torch.bfloat16, seed=9, store_obs="packed", use_graph=True, use_bit_embedding=True, use_fused_head=True)
     assert col._embed is not None
     for call in range(3):

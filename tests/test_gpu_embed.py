@@ -104,6 +104,32 @@ def test_embed_observe_also_writes_the_packed_observation(kind, n, B):
     env.sync()
 
 
+@pytest.mark.parametrize("n,B", [(12, 1000), (16, 333), (27, 64), (32, 2500), (9, 9000), (20, 20001)])
+def test_embed_reads_the_dual_layout_of_linear_function_envs_with_inverts(n, B):
+    """LinearFunctionEnv with add_inverts (the reference default) keeps the matrix and its inverse side by side and a flag per env says
+    which is the state (kernels_lfd.hip): the first layer and the packed observation follow the flag, env by env."""
+    gs = line_gateset("linear_function", n)
+    env = VecEnv("linear_function", n, gs, B, add_inverts=True, add_perms=False, track_solution=False, difficulty=40)
+    env.reset(7)
+    g = torch.Generator(device="cuda").manual_seed(n)
+    for t in range(5):  # coins flip the flag of about half the envs per step
+        env.rollout(torch.randint(0, len(gs), (1, B), device="cuda", generator=g, dtype=torch.int32),
+                    coins=torch.randint(0, 2, (1, B), device="cuda", generator=g, dtype=torch.uint8))
+    K = n * n
+    w = torch.randint(-1, 2, (128, K), generator=torch.Generator().manual_seed(4)).float()
+    w[:, 180:] = 0  # few nonzeros per output: exact in bf16
+    bias = torch.randint(-8, 9, (128,), generator=torch.Generator().manual_seed(5)).float().cuda()
+    packed = pack_embedding(env, w.cuda())
+    ref = (env.observe().double().flatten(1) @ w.cuda().double().t() + bias.double()).clamp_min(0)
+    want_obs = env.observe_packed()
+    obs = torch.full_like(want_obs, -1)
+    got = embed(env, packed, bias, 128, relu=True, obs_out=obs)
+    assert torch.equal(got.double(), ref)
+    assert torch.equal(obs, want_obs)
+    assert torch.equal(embed(env, packed, bias, 128, relu=True).double(), ref)
+    env.sync()
+
+
 def test_embed_follows_the_state():
     """The layer reads the live tiles: after a step it sees the new observation."""
     env = _env("clifford", 16, 2048, 1)
