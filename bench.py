@@ -285,6 +285,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the CPU-oracle replay of the timed run")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the 2^18 / 2^20 / 2^22-env legs (profiling runs: keeps the kernel statistics to one batch size)")
     ap.add_argument("--no-default-config", action="store_true", help="skip the reference-default (add_inverts=True, track_solution=True) leg")
+    ap.add_argument("--no-collector", action="store_true", help="skip the policy-in-the-loop leg (SURVEY 8f-3: collection with the reference's default policy shape)")
     ap.add_argument("--no-gather", action="store_true", help="N>1 diagnostics: step only, no all-gather")
     ap.add_argument("--gather-every", type=int, default=CHUNK,
                     help="N>1: all-gather the learner shard every min(this, --steps) steps (1 = after every step)")
@@ -620,6 +621,30 @@ def main():
         large = {"note": "same kernel and layout at 4x / 16x / 64x the batch: per-launch time is kernel time, not launch boundary; "
                          "2^22 envs = 512 MiB of state, beyond the 256 MiB Infinity Cache", "by_batch": sizes}
 
+    # ---- with a policy in the loop: the reference's default network shape (rl/configs.py:531-607, bf16, random weights) forward +
+    # categorical draw + env.step() + auto-reset per collection step, everything on the GPU; informational, not the headline metric -----
+    collector = None
+    if not multi and B == ENVS_PER_GPU and not args.no_collector:
+        from qiskit_gym_amd.collector import BasicPolicy, RolloutCollector
+        rows = []
+        for CB in (1024, B):  # the reference's num_episodes (rl/configs.py:134) and the headline batch
+            cenv = VecEnv("clifford", n, gateset, CB, add_inverts=False, add_perms=False, track_solution=False, difficulty=32)
+            col = RolloutCollector(cenv, BasicPolicy(4 * n * n, A), dtype=torch.bfloat16, seed=1, store_obs="packed", use_graph=True)
+            CT = 32
+            col.collect(CT)  # eager pass + capture
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ro = col.collect(CT)
+            torch.cuda.synchronize()
+            cus = (time.perf_counter() - t0) / (3 * CT) * 1e6
+            cenv.sync()
+            rows.append({"envs": CB, "us_per_step": cus, "value": CB / (cus * 1e-6), "unit": "env-steps/s", "done_per_step": float(ro.dones.float().mean())})
+            del col, cenv, ro
+            torch.cuda.empty_cache()
+        collector = {"policy": f"BasicPolicy {4 * n * n}-512-256-{{{A}, 1}} bf16, random weights; packed observation stored per step; one hipGraph per 32-step collection",
+                     "clock": "host wall clock around 3 replays, device idle before and after", "by_batch": rows}
+
     if rank == 0:
         cpu = None
         if not args.no_cpu_baseline and world == 1 and not args.force_multi:  # the CPU leg runs at N = 1 only
@@ -704,6 +729,7 @@ def main():
             "fused_rollout": fused,
             "default_config": default_cfg,
             "large_batch": large,
+            "policy_in_loop": collector,
         }
         print(json.dumps(out), file=json_out, flush=True)
     if dist is not None:
