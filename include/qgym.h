@@ -359,6 +359,12 @@ int qg_policy_mid_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, 
 int qg_vec_mid_head_sample_step(qg_vec *v, const void *h_dev, uint64_t ld_h, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
                                 const void *packed_head_dev, uint64_t seed, uint64_t counter, void *actions_dev, int action_dtype, float *logp_dev,
                                 float *entropy_dev, float *values_dev, float *rewards_dev, uint8_t *dones_dev, void *stream);
+/* ... and by qg_vec_reset_done(v, reset_seed): the envs whose episode ended with this step start their next one (clifford.rs:306-318)
+ * before the call returns to the stream -- inside the same launch for small batches, as the reset's own launch otherwise; results are
+ * those of the two calls.  A collection loop that uses it needs no qg_vec_reset_done of its own after the first step. */
+int qg_vec_mid_head_sample_step_reset(qg_vec *v, const void *h_dev, uint64_t ld_h, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
+                                      const void *packed_head_dev, uint64_t seed, uint64_t counter, void *actions_dev, int action_dtype, float *logp_dev,
+                                      float *entropy_dev, float *values_dev, float *rewards_dev, uint8_t *dones_dev, uint64_t reset_seed, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Scalar environment: the `Env` trait method for method (clifford.rs:285-382).

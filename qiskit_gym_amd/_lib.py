@@ -83,7 +83,7 @@ EXPORTED_SYMBOLS = [
     "qg_vec_embed_packed_bytes", "qg_vec_pack_embedding", "qg_vec_embed", "qg_vec_embed_observe",
     "qg_policy_embed_words_packed_bytes", "qg_policy_pack_embed_words", "qg_policy_embed_words",
     "qg_policy_head_packed_bytes", "qg_policy_pack_head", "qg_policy_head_sample",
-    "qg_policy_mid_packed_bytes", "qg_policy_pack_mid", "qg_policy_mid_head_sample", "qg_vec_mid_head_sample_step",
+    "qg_policy_mid_packed_bytes", "qg_policy_pack_mid", "qg_policy_mid_head_sample", "qg_vec_mid_head_sample_step", "qg_vec_mid_head_sample_step_reset",
     "qg_env_create", "qg_env_clone", "qg_env_set_seed", "qg_env_destroy", "qg_env_num_actions", "qg_env_obs_shape",
     "qg_env_set_difficulty", "qg_env_get_difficulty", "qg_env_set_state", "qg_env_reset", "qg_env_step",
     "qg_env_step_coin", "qg_env_masks", "qg_env_is_final", "qg_env_reward", "qg_env_success", "qg_env_observe",
@@ -173,6 +173,7 @@ def load():
     L.qg_policy_pack_mid.argtypes = [vp, vp, C.c_int, u64, C.c_uint32, C.c_uint32, vp, vp]
     L.qg_policy_mid_head_sample.argtypes = [vp, u64, u64, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, u64, u64, vp, vp, C.c_int, vp, vp, vp, vp]
     L.qg_vec_mid_head_sample_step.argtypes = [vp, vp, u64, C.c_uint32, vp, C.c_uint32, vp, u64, u64, vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.qg_vec_mid_head_sample_step_reset.argtypes = [vp, vp, u64, C.c_uint32, vp, C.c_uint32, vp, u64, u64, vp, C.c_int, vp, vp, vp, vp, vp, u64, vp]
     L.qg_policy_head_sample.argtypes = [vp, u64, u64, C.c_uint32, vp, C.c_uint32, u64, u64, vp, vp, C.c_int, vp, vp, vp, vp]
     L.qg_env_create.argtypes = [C.POINTER(QGConfig), C.POINTER(QGGate), sz, C.c_int, C.POINTER(vp)]
     L.qg_env_clone.argtypes = [vp, C.POINTER(vp)]

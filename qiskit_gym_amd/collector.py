@@ -213,18 +213,21 @@ def mid_head_sample(h: torch.Tensor, packed_mid: torch.Tensor, mid_features: int
 
 def mid_head_sample_step(env: VecEnv, h: torch.Tensor, packed_mid: torch.Tensor, mid_features: int, packed_head: torch.Tensor, seed: int, counter: int,
                          actions: torch.Tensor, logp: torch.Tensor, entropy: torch.Tensor, values: torch.Tensor,
-                         rewards: Optional[torch.Tensor] = None, dones: Optional[torch.Tensor] = None):
+                         rewards: Optional[torch.Tensor] = None, dones: Optional[torch.Tensor] = None, reset_seed: Optional[int] = None):
     """`mid_head_sample` followed, in the same launch, by `env.step(actions)` and by the compaction of the finished envs for the next
     `env.reset_done` (`qg_vec_mid_head_sample_step`): same draws, same env results, two launches less per collection step.  The env's
-    device clock (`env.set_clock`) is the sampling clock."""
+    device clock (`env.set_clock`) is the sampling clock.  `reset_seed`: also `env.reset_done(reset_seed)` (`..._step_reset`: inside the
+    same launch for small batches)."""
     if h.dim() != 2 or h.dtype != torch.bfloat16 or h.stride(1) != 1 or h.shape[0] != env.batch:
         raise ValueError("h must be bf16 [env.batch, in_features] with unit column stride")
     act_dt = {torch.int32: _lib.ACT_I32, torch.int64: _lib.ACT_I64}[actions.dtype]
-    _lib.check(_lib.load().qg_vec_mid_head_sample_step(env._h, h.data_ptr(), h.stride(0), h.shape[1], packed_mid.data_ptr(), int(mid_features),
-                                                       packed_head.data_ptr(), int(seed) & (2**64 - 1), int(counter), actions.data_ptr(), act_dt,
-                                                       logp.data_ptr(), entropy.data_ptr(), values.data_ptr(),
-                                                       rewards.data_ptr() if rewards is not None else None,
-                                                       dones.data_ptr() if dones is not None else None, env._stream()))
+    args = (env._h, h.data_ptr(), h.stride(0), h.shape[1], packed_mid.data_ptr(), int(mid_features), packed_head.data_ptr(), int(seed) & (2**64 - 1),
+            int(counter), actions.data_ptr(), act_dt, logp.data_ptr(), entropy.data_ptr(), values.data_ptr(),
+            rewards.data_ptr() if rewards is not None else None, dones.data_ptr() if dones is not None else None)
+    if reset_seed is None:
+        _lib.check(_lib.load().qg_vec_mid_head_sample_step(*args, env._stream()))
+    else:
+        _lib.check(_lib.load().qg_vec_mid_head_sample_step_reset(*args, int(reset_seed) & (2**64 - 1), env._stream()))
     return actions, logp, entropy, values
 
 
@@ -339,7 +342,7 @@ class RolloutCollector:
         self.clock = torch.zeros(1, dtype=torch.int64, device=env.device)  # collector steps taken so far
         env.set_clock(self.clock)
         # the policy-layer kernels at every batch size: below ~ 4 096 envs the launches take their small-batch shapes (a 32-env tile per
-        # wave / workgroup, weight fragments straight from L2: CliffordGym 16q x 1 024 envs 21 us per step against 42 us on library GEMMs,
+        # wave / workgroup, weight fragments straight from L2: CliffordGym 16q x 1 024 envs 20 us per step against 42 us on library GEMMs,
         # PauliGym 20q 36 against 44)
         if use_bit_embedding is None:
             use_bit_embedding = True
@@ -521,12 +524,16 @@ class RolloutCollector:
             # finished episodes start over (reference: the collector calls reset() on a fresh clone);
             # the kernels add the device clock: effective seed = seed + 0x9E3779B9 * (clock + t + 1)
             env.set_counters(t, t)  # coin / permutation draws: counter t + clock, eager or replayed
-            env.reset_done(self.seed + 0x9E3779B9 * (t + 1))
+            if t == 0 or not self._fused_step:  # with the fused step the envs that finish in step t are reset by step t's own call
+                env.reset_done(self.seed + 0x9E3779B9 * (t + 1))
             self._observe(ro, t)
             # masks() is all-true for a live env (clifford.rs:349-351), so sampling needs no mask
-            if self._fused_step:  # first layer, then middle layer + head + draw + env.step + done compaction in one kernel
+            if self._fused_step:  # first layer; then middle layer + head + draw + env.step + reset of the finished envs in one call
+                # (the seed of step t + 1's reset_done; the device clock advances by T between collections, so the last step of a
+                # collection resets with what the next collection's first reset_done would use)
                 mid_head_sample_step(env, self._first_layer(), self._mid, self.policy.common.out_features, self._head, self.seed, t, ro.actions[t],
-                                     ro.logp[t], ro.entropy[t], ro.values[t], rewards=ro.rewards[t], dones=ro.dones[t])
+                                     ro.logp[t], ro.entropy[t], ro.values[t], rewards=ro.rewards[t], dones=ro.dones[t],
+                                     reset_seed=self.seed + 0x9E3779B9 * (t + 2))
                 continue
             self._forward_sample(ro, t)
             env.rollout(ro.actions[t : t + 1], rewards_out=ro.rewards[t : t + 1], dones_out=ro.dones[t : t + 1])

@@ -665,6 +665,9 @@ struct MidHeadArgs {
     uint32_t step_groups;  // 16-byte groups per env of the TILE layout
     uint32_t step_has_z;
     uint32_t *done_list, *done_count;
+    // auto-reset (mid_head_small_kernel): the envs whose episode ended in this step start the next one before the launch ends --
+    // qg_vec_reset_done(reset.seed) without its own launch.  reset.state == nullptr: no reset (the done list is appended instead).
+    InitArgs reset;
 };
 
 template <uint32_t TILES>
@@ -994,6 +997,54 @@ __global__ __launch_bounds__(64 * MHS_WAVES, 1) void mid_head_small_kernel(MidHe
         bool fin = false;
         if (live && h == 0)
             fin = ma.step_has_z ? qm_step1_body<true, true>(ma.step, ma.step_groups, env, act) : qm_step1_body<false, true>(ma.step, ma.step_groups, env, act);
+        if (ma.reset.state) {
+            // qg_vec_reset_done for this wave's finished envs (clifford.rs:306-318; qm_init_kernel's mode 2 + qm_init_finish, kernels_qm.hip):
+            // identity, `difficulty` random gates on LDS-resident rows ([slot][lane], scramble_flat), rows back to the tile, bookkeeping
+            // of a fresh episode.  No add_inverts here (the launcher checks), so there is no symplectic flag to keep.
+            if (fin) {
+                const InitArgs &ia = ma.reset;
+                uint32_t (*rows)[QG_WAVE] = reinterpret_cast<uint32_t (*)[QG_WAVE]>(bbuf);  // free since the middle layer; 4 G x 64 words
+                const uint32_t R = 4u * ma.step_groups, N = ia.N;
+                auto ident = [&](uint32_t k) -> uint32_t {
+                    const uint32_t j = ma.step_has_z ? k >> 1 : k;
+                    return j < N ? ((ma.step_has_z && (k & 1u)) ? (1u << N) << j : 1u << j) : 0u;
+                };
+                for (uint32_t k = 0; k < R; ++k) rows[k][lane] = ident(k);
+                scramble_flat<uint32_t>(rows, lane, ia, env);
+                uint4 *tile = reinterpret_cast<uint4 *>(ia.state) + (env >> 6) * (uint64_t)(ma.step_groups * 64u) + (env & 63u);
+                uint32_t bad = 0;
+                for (uint32_t g = 0; g < ma.step_groups; ++g) {
+                    const uint32_t w0 = rows[4u * g][lane], w1 = rows[4u * g + 1u][lane], w2 = rows[4u * g + 2u][lane], w3 = rows[4u * g + 3u][lane];
+                    tile[g * 64u] = make_uint4(w0, w1, w2, w3);
+                    if (ma.step_has_z) {  // bit j: qubit j's two rows differ from the identity's (qm_badmask)
+                        bad |= (uint32_t)(w0 != ident(4u * g) || w1 != ident(4u * g + 1u)) << (2u * g);
+                        bad |= (uint32_t)(w2 != ident(4u * g + 2u) || w3 != ident(4u * g + 3u)) << (2u * g + 1u);
+                    } else {
+                        bad |= (uint32_t)(w0 != ident(4u * g)) << (4u * g);
+                        bad |= (uint32_t)(w1 != ident(4u * g + 1u)) << (4u * g + 1u);
+                        bad |= (uint32_t)(w2 != ident(4u * g + 2u)) << (4u * g + 2u);
+                        bad |= (uint32_t)(w3 != ident(4u * g + 3u)) << (4u * g + 3u);
+                    }
+                }
+                const bool solved = bad == 0;
+                if (ia.bad) ia.bad[env] = bad;
+                ia.depth[env] = ia.depth_value;  // reset_internals (clifford.rs:272-283)
+                ia.success[env] = (uint8_t)solved;
+                ia.reward[env] = solved ? 1.0f : 0.0f;
+                ia.done[env] = (uint8_t)(ia.depth_value == 0 || solved);
+                ia.inverted[env] = 0;
+                ia.error[env] = 0;
+                ia.sol_len[env * 2] = 0;
+                ia.sol_len[env * 2 + 1] = 0;
+                if (ia.layers) {
+                    const LayerRec lay = layer_rec(ia.layers, env, ia.layers_len);
+                    for (uint32_t i = 0; i + 2 < ia.layers_len; ++i) lay[i] = -1;
+                    lay[ia.layers_len - 2] = 0;
+                    lay[ia.layers_len - 1] = 0;
+                }
+            }
+            return;
+        }
         const uint64_t mk = __ballot(fin);
         if (mk) {
             const uint32_t first = (uint32_t)__ffsll((long long)mk) - 1u;
@@ -1606,7 +1657,7 @@ int qg_policy_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, uint
 static int mid_head_impl(const void *h_dev, uint64_t ld_h, uint64_t batch, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
                          const void *packed_head_dev, uint32_t num_actions, uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev,
                          int action_dtype, float *logp_dev, float *entropy_dev, float *values_dev, qg_vec *step_of, float *step_rewards,
-                         uint8_t *step_dones, void *stream) {
+                         uint8_t *step_dones, const uint64_t *reset_seed, void *stream) {
     if (!h_dev || !packed_mid_dev || !packed_head_dev || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
     if (qg_policy_head_packed_bytes(num_actions, mid_features) == 0 || qg_policy_mid_packed_bytes(in_features, mid_features) == 0)
         return set_error(QG_ERR_UNSUPPORTED, "fused middle layer + head: 256 middle features, in_features a multiple of 32, num_actions <= 222");
@@ -1646,6 +1697,7 @@ static int mid_head_impl(const void *h_dev, uint64_t ld_h, uint64_t batch, uint3
         m.step_groups = m.step_has_z = 0;
         m.done_list = m.done_count = nullptr;
     }
+    m.reset = InitArgs{};
     const uint32_t tiles = (num_actions + 1u + 31u) / 32u;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
@@ -1655,6 +1707,12 @@ static int mid_head_impl(const void *h_dev, uint64_t ld_h, uint64_t batch, uint3
     // up to one workgroup per CU of mid_head_small_kernel (a tile of 32 envs each): the batch is too small to fill the chip with
     // mid_head_sample_kernel's 128-env workgroups
     const bool small = env_tiles <= (uint64_t)cus && in_features % (16u * MHS_GROUP) == 0 && in_features <= 16u * MHS_KMAX;
+    // the finished envs' indices are appended to the handle's list, unless the small kernel resets them itself
+    const bool reset_in_kernel = small && step_of && reset_seed;
+    if (reset_in_kernel) fill_reset_done_args_public(step_of, *reset_seed, m.reset);
+    else if (step_of && step_of->done_list_fresh)  // a list nobody consumed (no qg_vec_reset_done since the last fused step): start it again
+        HIP_TRY(hipMemsetAsync(step_of->done_list + step_of->B, 0, 2 * sizeof(uint32_t), s));
+    if (step_of) step_of->done_list_fresh = !reset_in_kernel;
     if (small) {
         const dim3 grid((unsigned)env_tiles), block(64 * MHS_WAVES);
 #define QG_MHS_CASE(TT)                                                        \
@@ -1684,24 +1742,39 @@ int qg_policy_mid_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, 
                               const void *packed_head_dev, uint32_t num_actions, uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev,
                               int action_dtype, float *logp_dev, float *entropy_dev, float *values_dev, void *stream) {
     return mid_head_impl(h_dev, ld_h, batch, in_features, packed_mid_dev, mid_features, packed_head_dev, num_actions, seed, counter, clock_dev, actions_dev,
-                         action_dtype, logp_dev, entropy_dev, values_dev, nullptr, nullptr, nullptr, stream);
+                         action_dtype, logp_dev, entropy_dev, values_dev, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+static int mid_head_step_impl(qg_vec *v, const void *h_dev, uint64_t ld_h, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
+                              const void *packed_head_dev, uint64_t seed, uint64_t counter, void *actions_dev, int action_dtype, float *logp_dev,
+                              float *entropy_dev, float *values_dev, float *rewards_dev, uint8_t *dones_dev, const uint64_t *reset_seed, void *stream) {
+    if (!v) return set_error(QG_ERR_INVALID, "null argument");
+    if (v->layout != LAYOUT_TILE || (v->flags & F_INVERTS) || !v->bad || !v->done_list)
+        return set_error(QG_ERR_UNSUPPORTED, "the sampling kernel steps TILE-layout handles without add_inverts (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32)");
+    if (reset_seed && v->gates.empty() && v->difficulty)  // Uniform::new(0, 0) panics in the reference
+        return set_error(QG_ERR_PANIC, "reset with an empty gateset (the reference panics in Uniform::new(0, 0))");
+    QG_ON_DEVICE(v);
+    const int rc = mid_head_impl(h_dev, ld_h, v->B, in_features, packed_mid_dev, mid_features, packed_head_dev, (uint32_t)v->gates.size(), seed, counter,
+                                 v->clock_dev, actions_dev, action_dtype, logp_dev, entropy_dev, values_dev, v, rewards_dev, dones_dev, reset_seed, stream);
+    if (rc != QG_OK) return rc;
+    v->step_index += 1;
+    // larger batches: the kernel left the list of finished envs, the reset is its own launch
+    if (reset_seed && v->done_list_fresh) return qg_vec_reset_done(v, *reset_seed, stream);
+    return QG_OK;
 }
 
 int qg_vec_mid_head_sample_step(qg_vec *v, const void *h_dev, uint64_t ld_h, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
                                 const void *packed_head_dev, uint64_t seed, uint64_t counter, void *actions_dev, int action_dtype, float *logp_dev,
                                 float *entropy_dev, float *values_dev, float *rewards_dev, uint8_t *dones_dev, void *stream) {
-    if (!v) return set_error(QG_ERR_INVALID, "null argument");
-    if (v->layout != LAYOUT_TILE || (v->flags & F_INVERTS) || !v->bad || !v->done_list)
-        return set_error(QG_ERR_UNSUPPORTED, "the sampling kernel steps TILE-layout handles without add_inverts (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32)");
-    QG_ON_DEVICE(v);
-    if (v->done_list_fresh)  // a list nobody consumed (no qg_vec_reset_done since the last fused step): start it again
-        HIP_TRY(hipMemsetAsync(v->done_list + v->B, 0, 2 * sizeof(uint32_t), (hipStream_t)stream));
-    const int rc = mid_head_impl(h_dev, ld_h, v->B, in_features, packed_mid_dev, mid_features, packed_head_dev, (uint32_t)v->gates.size(), seed, counter,
-                                 v->clock_dev, actions_dev, action_dtype, logp_dev, entropy_dev, values_dev, v, rewards_dev, dones_dev, stream);
-    if (rc != QG_OK) return rc;
-    v->done_list_fresh = true;
-    v->step_index += 1;
-    return QG_OK;
+    return mid_head_step_impl(v, h_dev, ld_h, in_features, packed_mid_dev, mid_features, packed_head_dev, seed, counter, actions_dev, action_dtype, logp_dev,
+                              entropy_dev, values_dev, rewards_dev, dones_dev, nullptr, stream);
+}
+
+int qg_vec_mid_head_sample_step_reset(qg_vec *v, const void *h_dev, uint64_t ld_h, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
+                                      const void *packed_head_dev, uint64_t seed, uint64_t counter, void *actions_dev, int action_dtype, float *logp_dev,
+                                      float *entropy_dev, float *values_dev, float *rewards_dev, uint8_t *dones_dev, uint64_t reset_seed, void *stream) {
+    return mid_head_step_impl(v, h_dev, ld_h, in_features, packed_mid_dev, mid_features, packed_head_dev, seed, counter, actions_dev, action_dtype, logp_dev,
+                              entropy_dev, values_dev, rewards_dev, dones_dev, &reset_seed, stream);
 }
 
 }  // extern "C"

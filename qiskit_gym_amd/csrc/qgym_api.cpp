@@ -1050,4 +1050,15 @@ int64_t qg_vec_solution(qg_vec *v, uint64_t env, uint64_t *out, size_t cap) {
 
 namespace qg {
 void fill_step_args_public(const qg_vec *v, StepArgs &a) { fill_step_args(v, a); }
+// InitArgs of qg_vec_reset_done(v, seed) without a list: what a kernel that resets finished envs itself needs (qg_vec_mid_head_sample_step)
+void fill_reset_done_args_public(const qg_vec *v, uint64_t seed, InitArgs &ia) {
+    fill_init_args(v, ia);
+    ia.mode = 2;
+    ia.n_draws = (uint32_t)v->difficulty;
+    ia.seed = seed;
+    ia.only_done = 1u;
+    const int64_t d = (int64_t)v->cfg.depth_slope * v->difficulty;  // clifford.rs:317
+    ia.depth_value = (int32_t)std::min<int64_t>(d, v->cfg.max_depth);
+}
+int reset_done_public(qg_vec *v, uint64_t seed, void *stream) { return qg_vec_reset_done(v, seed, stream); }
 }  // namespace qg

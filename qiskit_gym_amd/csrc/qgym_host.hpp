@@ -138,6 +138,7 @@ struct qg_vec {
 namespace qg {
 int ensure_scratch_public(qg_vec *v, size_t bytes);
 void fill_step_args_public(const qg_vec *v, StepArgs &a);
+void fill_reset_done_args_public(const qg_vec *v, uint64_t seed, InitArgs &ia);
 void compute_qubit_and_action_perms(uint32_t N, const std::vector<qg_gate> &gates, std::vector<std::vector<int64_t>> &qubit_perms,
                                     std::vector<std::vector<int64_t>> &act_perms);
 // PauliEnv host hooks (pauli_host.cpp)

@@ -203,15 +203,16 @@ def test_first_layer_from_the_packed_observation_words(kind, n, kw, use_graph):
     assert col.steps_done == 3 * T
 
 
-@pytest.mark.parametrize("kind,n,use_graph", [("clifford", 5, False), ("clifford", 16, True), ("linear_function", 12, False)])
-def test_sampling_kernel_that_also_steps_the_env_equals_the_separate_launches(kind, n, use_graph):
-    """qg_vec_mid_head_sample_step: middle layer + head + draw + Env::step + compaction of the finished envs in one launch.  Same
-    trajectories, bit for bit, as the sampling kernel followed by qg_vec_step and a reset_done that compacts for itself -- and the
-    trajectories replay on the oracle (auto-resets included: the list the kernel leaves is the list reset_done would have built)."""
+@pytest.mark.parametrize("kind,n,use_graph,B", [("clifford", 5, False, 1000), ("clifford", 16, True, 1000), ("linear_function", 12, False, 1000),
+                                                 ("clifford", 5, True, 9000), ("linear_function", 20, False, 8193)])  # > 8 192 envs: the reset is its own launch
+def test_sampling_kernel_that_also_steps_the_env_equals_the_separate_launches(kind, n, use_graph, B):
+    """qg_vec_mid_head_sample_step_reset: middle layer + head + draw + Env::step + the reset of the envs that finished, in one call (one
+    launch for small batches).  Same trajectories, bit for bit, as the sampling kernel followed by qg_vec_step and a reset_done per step
+    -- and the trajectories replay on the oracle (auto-resets included)."""
     from qiskit_gym_amd.collector import BasicPolicy, RolloutCollector
     from qiskit_gym_amd.vec import VecEnv
 
-    B, T, diff = 1000, 12, 2
+    T, diff = 12, 2
     gs = line_gateset(kind, n)
     A = len(gs)
     cfg = dict(add_inverts=False, add_perms=False, track_solution=False, difficulty=diff)
@@ -229,6 +230,8 @@ def test_sampling_kernel_that_also_steps_the_env_equals_the_separate_launches(ki
             ro = col.collect(T)
             torch.cuda.synchronize()
             got.append({k: getattr(ro, k).clone() for k in ("obs", "actions", "logp", "values", "rewards", "dones", "advantages")})
+        if not fused:  # the fused call has already reset the envs that finished in the last step: what the next collection's first
+            env.reset_done(5 + 0x9E3779B9)  # reset_done (seed + phi * 1, on the clock both envs now share) is about to do here
         env.sync()
         runs.append((got, env.get_state("packed").clone(), env.depth.clone()))
     for call in range(2):
@@ -238,11 +241,12 @@ def test_sampling_kernel_that_also_steps_the_env_equals_the_separate_launches(ki
     # oracle replay of the fused run's first collection
     ro = runs[0][0][0]
     acts, rew, done = ro["actions"].cpu().numpy(), ro["rewards"].cpu().numpy(), ro["dones"].cpu().numpy()
-    envs = [OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()}) for _ in range(0, B, 7)]
+    stride = 7 if B <= 1000 else 61
+    envs = [OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()}) for _ in range(0, B, stride)]
     for t in range(T):
         draws = rng_actions((5 + 0x9E3779B9 * (t + 1)) & (2**64 - 1), B, diff, A)
         for i, o in enumerate(envs):
-            e = 7 * i
+            e = stride * i
             if o.is_final():
                 o.reset_with(draws[:, e])
             o.step(int(acts[t, e]))
