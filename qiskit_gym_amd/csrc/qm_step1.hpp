@@ -105,4 +105,195 @@ __device__ inline bool qm_step1_body(const StepArgs &a, uint32_t G, uint64_t env
     return depth == 0 || solved;
 }
 
+
+// ---- the reference-default step of CliffordEnv N <= 16 (add_inverts), two lanes per env: see kernels_qm.hip for the discussion ----
+#define QM_FLAG_INVERTED 1u
+#define QM_FLAG_SYMPLECTIC 2u
+
+// Balanced select tree: each level blends pairs with an all-ones/all-zeros lane mask, (hi & m) | (lo & ~m) = one v_bfi_b32; written
+// as bit arithmetic on purpose: a `b ? t[2k+1] : t[2k]` select gets folded by the compiler into a runtime-indexed (scratch) array read.
+template <int n>
+__device__ inline uint32_t tree_select(const uint32_t (&t)[n], uint32_t q) {
+    if constexpr (n == 1) {
+        return t[0];
+    } else {
+        constexpr int m = (n + 1) / 2;
+        uint32_t u[m];
+        const uint32_t mb = 0u - (q & 1u);
+#pragma unroll
+        for (int k = 0; k < m; ++k) u[k] = (2 * k + 1 < n) ? ((t[2 * k + 1] & mb) | (t[2 * k] & ~mb)) : t[2 * k];
+        return tree_select<m>(u, q >> 1);
+    }
+}
+
+__device__ inline uint32_t qm_pair_swap(uint32_t v) {  // the partner lane's value (lanes 2e, 2e+1): DPP quad_perm [1, 0, 3, 2]
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+}
+
+// GS: the env's 16-byte groups (two qubits each) as a compile-time constant, or 0: `groups` at run time (the policy kernel).
+// `env`, `h`: this lane's env and half (lanes 2e, 2e + 1 of a wave hold env e); `act`: the env's action, or null: load it from a.actions.
+// Returns is_final (on both lanes).
+template <int GS, bool FEAT>
+__device__ inline bool qm_inv2_body(const StepArgs &a, uint32_t groups, uint64_t env, uint32_t h, const int64_t *act_in) {
+    const int G = GS ? GS : (int)groups;
+    const uint32_t N = a.N;
+    uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(G * 64) + (env & 63u);
+    // every load that does not depend on another one is issued here, the rows first (the longest transfers), so that the whole
+    // kernel pays two memory round trips: this batch, and the gate entry behind the action
+    uint4 grp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        grp[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (k < G && (h == 0 || k + 4 < G)) grp[k] = tile[(uint32_t)(4 * h + k) * 64u];
+    }
+    int32_t depth = a.depth[env];
+    uint32_t iflags = a.inverted[env];
+    uint32_t coin = a.coins ? a.coins[env] : 0u;
+    int32_t sol_n = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2] : 0;
+    int32_t sol_b = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2 + 1] : 0;
+    const int64_t act = act_in ? *act_in : load_action(a.actions, env, a.flags & F_ACT64);
+    const bool in_range = act >= 0 && act < (int64_t)a.num_actions;  // gateset.get(action) (clifford.rs:324)
+    GateEntry g = a.gates[in_range ? act : 0];  // unconditional (clamped) load: nothing else waits behind a branch
+    if (!in_range) g = GateEntry{QM_IDENTITY << 10, 0.0f};
+    if (!a.coins) coin = (uint32_t)(rng_draw(a.seed ^ 0x636F696Eull, a.env_base + env, step_clock(a)) >> 63);  // runs under the loads
+    // this lane's 8 qubits: xs[j] = X row of qubit 8h + j, zs[j] = its Z row (stored words: bit c = logical column c)
+    uint32_t xs[8], zs[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        xs[2 * k] = grp[k].x; zs[2 * k] = grp[k].y; xs[2 * k + 1] = grp[k].z; zs[2 * k + 1] = grp[k].w;
+    }
+    uint32_t fault = 0;
+    float penalty = g.penalty;
+    if (FEAT && (a.flags & F_LAYERS) && in_range && h == 0) penalty = layers_penalty(layer_rec(a.layers, env, 2 * N + 2), N, a.descs[act], a.w);
+
+    // ---- apply_gate_to_state (clifford.rs:331): the 4x4 GF(2) map on {X[q0], Z[q0], X[q1], Z[q1]} --------------------------
+    uint32_t dirty = 0;  // this lane's groups that changed (bit k: group 4h + k)
+    {
+        const uint32_t q0 = g.ops & 31u, q1 = (g.ops >> 5) & 31u, m = (g.ops >> 10) & 0xFFFFu;
+        const bool own0 = (q0 >> 3) == h, own1 = (q1 >> 3) == h;
+        uint32_t x0 = own0 ? tree_select<8>(xs, q0 & 7u) : 0u, z0 = own0 ? tree_select<8>(zs, q0 & 7u) : 0u;
+        uint32_t x1 = own1 ? tree_select<8>(xs, q1 & 7u) : 0u, z1 = own1 ? tree_select<8>(zs, q1 & 7u) : 0u;
+        x0 |= qm_pair_swap(x0); z0 |= qm_pair_swap(z0);  // the lane that does not own the qubit contributes zero
+        x1 |= qm_pair_swap(x1); z1 |= qm_pair_swap(z1);
+        auto mix = [&](uint32_t k) -> uint32_t {  // out_k = xor_i M[k][i] * in_i
+            const uint32_t b = m >> (4 * k);
+            return ((0u - (b & 1u)) & x0) ^ ((0u - ((b >> 1) & 1u)) & z0) ^ ((0u - ((b >> 2) & 1u)) & x1) ^ ((0u - ((b >> 3) & 1u)) & z1);
+        };
+        const uint32_t nx0 = mix(0), nz0 = mix(1), nx1 = mix(2), nz1 = mix(3);
+        if (m != QM_IDENTITY) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {  // q1's rows first, then q0's (q0's value wins when q0 == q1, as in qm_apply)
+                const bool h1 = own1 && (q1 & 7u) == (uint32_t)j, h0 = own0 && (q0 & 7u) == (uint32_t)j;
+                uint32_t vx = xs[j], vz = zs[j];
+                vx = h1 ? nx1 : vx; vz = h1 ? nz1 : vz;
+                vx = h0 ? nx0 : vx; vz = h0 ? nz0 : vz;
+                xs[j] = vx; zs[j] = vz;
+            }
+            if (own0) dirty |= 1u << ((q0 & 7u) >> 1);
+            if (own1) dirty |= 1u << ((q1 & 7u) >> 1);
+        }
+    }
+
+    if (FEAT && (a.flags & F_TRACK) && h == 0) {  // clifford.rs:334-340: entries in push order, bit 31 = pushed to solution_inv
+        if ((uint32_t)(sol_n + sol_b) < a.sol_cap) {
+            const bool inv_frame = iflags & QM_FLAG_INVERTED;
+            sol_at(a, env, (uint32_t)(sol_n + sol_b)) = sol_word_framed(act, inv_frame);
+            if (inv_frame) ++sol_b;
+            else ++sol_n;
+        } else {
+            fault |= 8u;
+        }
+    }
+    depth = depth > 0 ? depth - 1 : 0;  // clifford.rs:342
+
+    // ---- maybe_random_invert (clifford.rs:262-270) ----------------------------------------------------------------------------
+    if (coin & 1u) {  // both lanes of a pair take the same branch
+        if (iflags & QM_FLAG_SYMPLECTIC) {
+            uint32_t w[16];  // local index i = 8 t + j  <->  v = 16 t + 8 h + j
+            const uint32_t xm = N >= 16 ? 0xFFFFu : ((1u << N) - 1u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                w[j] = xs[j];
+                w[8 + j] = zs[j];
+            }
+            if (N < 16) {  // logical Z columns N .. 2N-1 move to bit positions 16 .. 16+N-1
+#pragma unroll
+                for (int i = 0; i < 16; ++i) w[i] = (w[i] & xm) | (((w[i] >> N) & xm) << 16);
+            }
+            // stages 4, 2, 1: word pairs (i, i + d) of this lane
+#pragma unroll
+            for (int st = 0; st < 3; ++st) {
+                const int d = 4 >> st;
+                const uint32_t mlo = st == 0 ? 0x0F0F0F0Fu : st == 1 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if ((i & d) == 0) {
+                        const uint32_t lo = w[i], hi = w[i + d];
+                        w[i] = (lo & mlo) | ((hi & mlo) << d);
+                        w[i + d] = ((lo >> d) & mlo) | (hi & ~mlo);
+                    }
+                }
+            }
+            // stage 8: the partner lane holds the other word of every pair; byte 1 / 3 of the low word <-> byte 0 / 2 of the high word
+            const uint32_t sel8 = h ? 0x03070105u : 0x06020400u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) w[i] = __builtin_amdgcn_perm(qm_pair_swap(w[i]), w[i], sel8);
+            // stage 16 + Omega: inv[v] = rot16(T[v ^ 16])
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t lo = w[j], hi = w[8 + j];
+                w[j] = __builtin_amdgcn_perm(hi, lo, 0x03020706u);      // {hi.hi16, lo.hi16}
+                w[8 + j] = __builtin_amdgcn_perm(hi, lo, 0x01000504u);  // {hi.lo16, lo.lo16}
+            }
+            if (N < 16) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) w[i] = (w[i] & xm) | (((w[i] >> 16) & xm) << N);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xs[j] = w[j];
+                zs[j] = w[8 + j];
+            }
+            iflags ^= QM_FLAG_INVERTED;
+            dirty = 0xFu;
+        } else {
+            fault |= QG_FAULT_BAD_STATE;  // unreachable: the host launches the Gauss-Jordan variant whenever such an env may exist
+        }
+    }
+
+    // ---- solved (clifford.rs:344), reward (:345-346) ----------------------------------------------------------------------------
+    uint32_t diff = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t q = 8u * h + (uint32_t)j;
+        const bool real = q < N;
+        diff |= xs[j] ^ (real ? 1u << q : 0u);
+        diff |= zs[j] ^ (real ? (1u << N) << q : 0u);
+    }
+    diff |= qm_pair_swap(diff);
+    const bool solved = diff == 0;
+    const float achieved = solved ? 1.0f : 0.0f;
+    const float reward = achieved - penalty;
+
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (((dirty >> k) & 1u) && k < G && (h == 0 || k + 4 < G))
+            tile[(uint32_t)(4 * h + k) * 64u] = make_uint4(xs[2 * k], zs[2 * k], xs[2 * k + 1], zs[2 * k + 1]);
+    if (h == 0) {
+        if (a.rewards_seq) a.rewards_seq[env] = reward;
+        if (a.dones_seq) a.dones_seq[env] = (uint8_t)(depth == 0 || solved);
+        a.depth[env] = depth;
+        a.reward[env] = reward;
+        a.done[env] = (uint8_t)(depth == 0 || solved);  // is_final (clifford.rs:353)
+        a.success[env] = (uint8_t)solved;
+        if (FEAT && (a.flags & F_TRACK)) {
+            a.sol_len[env * 2] = sol_n;
+            a.sol_len[env * 2 + 1] = sol_b;
+        }
+        a.inverted[env] = (uint8_t)iflags;
+        if (fault) atomicOr(&a.error[env], fault);
+    }
+    return depth == 0 || solved;
+}
+
 }  // namespace qg
