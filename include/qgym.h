@@ -354,8 +354,10 @@ int qg_policy_mid_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, 
  * gathers / scatters that env's rows like qg_vec_step does: same results, one launch less per collection step), and by the compaction of
  * the envs whose episode ended with this step: the next qg_vec_reset_done finds its list ready and launches only the reset itself.
  * batch, num_actions, the device clock and the env outputs are the handle's; rewards_dev / dones_dev: per-step outputs as in
- * qg_vec_rollout (may be NULL).  TILE-layout handles without add_inverts (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32);
- * QG_ERR_UNSUPPORTED otherwise. */
+ * qg_vec_rollout (may be NULL).  TILE-layout handles (CliffordEnv N <= 16 with or without add_inverts -- the coin is the handle's counter
+ * RNG, as in qg_vec_step without coins; LinearFunctionEnv 8 < N <= 32 without add_inverts); QG_ERR_UNSUPPORTED otherwise.  Where the step
+ * cannot ride in the sampling kernel (add_inverts beyond the small-batch kernel, or a state that is not symplectic) the call issues
+ * the env's own step launch after it: same results. */
 int qg_vec_mid_head_sample_step(qg_vec *v, const void *h_dev, uint64_t ld_h, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
                                 const void *packed_head_dev, uint64_t seed, uint64_t counter, void *actions_dev, int action_dtype, float *logp_dev,
                                 float *entropy_dev, float *values_dev, float *rewards_dev, uint8_t *dones_dev, void *stream);

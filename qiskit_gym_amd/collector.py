@@ -385,9 +385,10 @@ class RolloutCollector:
                 self._scratch_f32 = torch.empty((3, env.batch), dtype=torch.float32, device=env.device)
             except ValueError:
                 self._head = self._mid = None
-        # sampling, env.step and the compaction of finished envs in ONE launch (qg_vec_mid_head_sample_step): TILE-layout envs without add_inverts
-        can_fuse_step = (self._mid is not None and env.env_kind in ("clifford", "linear_function") and not env.config.get("add_inverts", True)
-                         and ((env.env_kind == "clifford" and env.num_qubits <= 16) or (env.env_kind == "linear_function" and 8 < env.num_qubits <= 32)))
+        # sampling, env.step and the reset of the finished envs in ONE call (qg_vec_mid_head_sample_step_reset): TILE-layout envs
+        inverts = bool(env.config.get("add_inverts", True))
+        can_fuse_step = (self._mid is not None and ((env.env_kind == "clifford" and env.num_qubits <= 16)  # with add_inverts too (qm_inv2_body)
+                                                    or (env.env_kind == "linear_function" and 8 < env.num_qubits <= 32 and not inverts)))
         self._fused_step = can_fuse_step if use_fused_step is None else bool(use_fused_step) and can_fuse_step
         self._graph = None
         self._graph_T = 0

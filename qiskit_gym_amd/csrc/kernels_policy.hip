@@ -994,13 +994,23 @@ __global__ __launch_bounds__(64 * MHS_WAVES, 1) void mid_head_small_kernel(MidHe
         if (a.values) a.values[env] = part[0][5][c];
     }
     if (ma.step.state) {  // wave-uniform
+        // `fin` on ONE lane per env (renv): with add_inverts the step is qm_inv2_body's, two adjacent lanes per env, so the 32 envs
+        // move from lanes (c, c + 32) to lanes (2e, 2e + 1) first
         bool fin = false;
-        if (live && h == 0)
+        uint64_t renv = env;
+        if (ma.step.flags & F_INVERTS) {
+            const uint32_t e = lane >> 1;
+            const int64_t act2 = (int64_t)__shfl((int)act, (int)e);  // lanes 0 .. 31 hold the action of env c = lane
+            const uint64_t env2 = (uint64_t)blockIdx.x * 32u + e;
+            renv = env2;
+            if (env2 < a.B) fin = qm_inv2_body<0, true>(ma.step, ma.step_groups, env2, lane & 1u, &act2) && !(lane & 1u);
+        } else if (live && h == 0) {
             fin = ma.step_has_z ? qm_step1_body<true, true>(ma.step, ma.step_groups, env, act) : qm_step1_body<false, true>(ma.step, ma.step_groups, env, act);
+        }
         if (ma.reset.state) {
             // qg_vec_reset_done for this wave's finished envs (clifford.rs:306-318; qm_init_kernel's mode 2 + qm_init_finish, kernels_qm.hip):
             // identity, `difficulty` random gates on LDS-resident rows ([slot][lane], scramble_flat), rows back to the tile, bookkeeping
-            // of a fresh episode.  No add_inverts here (the launcher checks), so there is no symplectic flag to keep.
+            // of a fresh episode.
             if (fin) {
                 const InitArgs &ia = ma.reset;
                 uint32_t (*rows)[QG_WAVE] = reinterpret_cast<uint32_t (*)[QG_WAVE]>(bbuf);  // free since the middle layer; 4 G x 64 words
@@ -1010,8 +1020,8 @@ __global__ __launch_bounds__(64 * MHS_WAVES, 1) void mid_head_small_kernel(MidHe
                     return j < N ? ((ma.step_has_z && (k & 1u)) ? (1u << N) << j : 1u << j) : 0u;
                 };
                 for (uint32_t k = 0; k < R; ++k) rows[k][lane] = ident(k);
-                scramble_flat<uint32_t>(rows, lane, ia, env);
-                uint4 *tile = reinterpret_cast<uint4 *>(ia.state) + (env >> 6) * (uint64_t)(ma.step_groups * 64u) + (env & 63u);
+                scramble_flat<uint32_t>(rows, lane, ia, renv);
+                uint4 *tile = reinterpret_cast<uint4 *>(ia.state) + (renv >> 6) * (uint64_t)(ma.step_groups * 64u) + (renv & 63u);
                 uint32_t bad = 0;
                 for (uint32_t g = 0; g < ma.step_groups; ++g) {
                     const uint32_t w0 = rows[4u * g][lane], w1 = rows[4u * g + 1u][lane], w2 = rows[4u * g + 2u][lane], w3 = rows[4u * g + 3u][lane];
@@ -1027,17 +1037,17 @@ __global__ __launch_bounds__(64 * MHS_WAVES, 1) void mid_head_small_kernel(MidHe
                     }
                 }
                 const bool solved = bad == 0;
-                if (ia.bad) ia.bad[env] = bad;
-                ia.depth[env] = ia.depth_value;  // reset_internals (clifford.rs:272-283)
-                ia.success[env] = (uint8_t)solved;
-                ia.reward[env] = solved ? 1.0f : 0.0f;
-                ia.done[env] = (uint8_t)(ia.depth_value == 0 || solved);
-                ia.inverted[env] = 0;
-                ia.error[env] = 0;
-                ia.sol_len[env * 2] = 0;
-                ia.sol_len[env * 2 + 1] = 0;
+                if (ia.bad) ia.bad[renv] = bad;
+                ia.depth[renv] = ia.depth_value;  // reset_internals (clifford.rs:272-283)
+                ia.success[renv] = (uint8_t)solved;
+                ia.reward[renv] = solved ? 1.0f : 0.0f;
+                ia.done[renv] = (uint8_t)(ia.depth_value == 0 || solved);
+                ia.inverted[renv] = ia.check_symplectic ? (uint8_t)QM_FLAG_SYMPLECTIC : (uint8_t)0;  // identity + gates is symplectic (qm_init_finish)
+                ia.error[renv] = 0;
+                ia.sol_len[renv * 2] = 0;
+                ia.sol_len[renv * 2 + 1] = 0;
                 if (ia.layers) {
-                    const LayerRec lay = layer_rec(ia.layers, env, ia.layers_len);
+                    const LayerRec lay = layer_rec(ia.layers, renv, ia.layers_len);
                     for (uint32_t i = 0; i + 2 < ia.layers_len; ++i) lay[i] = -1;
                     lay[ia.layers_len - 2] = 0;
                     lay[ia.layers_len - 1] = 0;
@@ -1051,7 +1061,7 @@ __global__ __launch_bounds__(64 * MHS_WAVES, 1) void mid_head_small_kernel(MidHe
             uint32_t basei = 0;
             if (lane == first) basei = atomicAdd(ma.done_count, (uint32_t)__popcll(mk));
             basei = __shfl(basei, first);
-            if (fin) ma.done_list[basei + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = (uint32_t)env;
+            if (fin) ma.done_list[basei + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = (uint32_t)renv;
         }
     }
 }
@@ -1654,6 +1664,11 @@ int qg_policy_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, uint
     return QG_OK;
 }
 
+// up to one workgroup per CU of mid_head_small_kernel (a tile of 32 envs each)
+static bool mid_head_is_small(uint64_t batch, uint32_t in_features, int cus) {
+    return (batch + 31u) / 32u <= (uint64_t)cus && in_features % (16u * MHS_GROUP) == 0 && in_features <= 16u * MHS_KMAX;
+}
+
 static int mid_head_impl(const void *h_dev, uint64_t ld_h, uint64_t batch, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
                          const void *packed_head_dev, uint32_t num_actions, uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev,
                          int action_dtype, float *logp_dev, float *entropy_dev, float *values_dev, qg_vec *step_of, float *step_rewards,
@@ -1706,7 +1721,7 @@ static int mid_head_impl(const void *h_dev, uint64_t ld_h, uint64_t batch, uint3
     hipStream_t s = (hipStream_t)stream;
     // up to one workgroup per CU of mid_head_small_kernel (a tile of 32 envs each): the batch is too small to fill the chip with
     // mid_head_sample_kernel's 128-env workgroups
-    const bool small = env_tiles <= (uint64_t)cus && in_features % (16u * MHS_GROUP) == 0 && in_features <= 16u * MHS_KMAX;
+    const bool small = mid_head_is_small(batch, in_features, cus);
     // the finished envs' indices are appended to the handle's list, unless the small kernel resets them itself
     const bool reset_in_kernel = small && step_of && reset_seed;
     if (reset_in_kernel) fill_reset_done_args_public(step_of, *reset_seed, m.reset);
@@ -1749,11 +1764,23 @@ static int mid_head_step_impl(qg_vec *v, const void *h_dev, uint64_t ld_h, uint3
                               const void *packed_head_dev, uint64_t seed, uint64_t counter, void *actions_dev, int action_dtype, float *logp_dev,
                               float *entropy_dev, float *values_dev, float *rewards_dev, uint8_t *dones_dev, const uint64_t *reset_seed, void *stream) {
     if (!v) return set_error(QG_ERR_INVALID, "null argument");
-    if (v->layout != LAYOUT_TILE || (v->flags & F_INVERTS) || !v->bad || !v->done_list)
-        return set_error(QG_ERR_UNSUPPORTED, "the sampling kernel steps TILE-layout handles without add_inverts (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32)");
+    const bool inverts = v->flags & F_INVERTS;
+    if (v->layout != LAYOUT_TILE || (!inverts && !v->bad) || !v->done_list)
+        return set_error(QG_ERR_UNSUPPORTED, "the sampling kernel steps TILE-layout handles (CliffordEnv N <= 16; LinearFunctionEnv 8 < N <= 32 without add_inverts)");
     if (reset_seed && v->gates.empty() && v->difficulty)  // Uniform::new(0, 0) panics in the reference
         return set_error(QG_ERR_PANIC, "reset with an empty gateset (the reference panics in Uniform::new(0, 0))");
     QG_ON_DEVICE(v);
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, v->device);
+    // add_inverts (CliffordEnv's default): the step is the two-lanes-per-env kernel's, which the small-batch sampling kernel can run on its
+    // own lanes (qm_inv2_body) when every env is symplectic; otherwise the sampling kernel and the env's own step launch
+    if (inverts && !(mid_head_is_small(v->B, in_features, cus) && v->has_z && !v->maybe_nonsymplectic)) {
+        int rc = mid_head_impl(h_dev, ld_h, v->B, in_features, packed_mid_dev, mid_features, packed_head_dev, (uint32_t)v->gates.size(), seed, counter,
+                               v->clock_dev, actions_dev, action_dtype, logp_dev, entropy_dev, values_dev, nullptr, nullptr, nullptr, nullptr, stream);
+        if (rc == QG_OK) rc = qg_vec_rollout(v, actions_dev, action_dtype, 1, nullptr, rewards_dev, dones_dev, 0, stream);
+        if (rc == QG_OK && reset_seed) rc = qg_vec_reset_done(v, *reset_seed, stream);
+        return rc;
+    }
     const int rc = mid_head_impl(h_dev, ld_h, v->B, in_features, packed_mid_dev, mid_features, packed_head_dev, (uint32_t)v->gates.size(), seed, counter,
                                  v->clock_dev, actions_dev, action_dtype, logp_dev, entropy_dev, values_dev, v, rewards_dev, dones_dev, reset_seed, stream);
     if (rc != QG_OK) return rc;

@@ -203,9 +203,11 @@ def test_first_layer_from_the_packed_observation_words(kind, n, kw, use_graph):
     assert col.steps_done == 3 * T
 
 
-@pytest.mark.parametrize("kind,n,use_graph,B", [("clifford", 5, False, 1000), ("clifford", 16, True, 1000), ("linear_function", 12, False, 1000),
-                                                 ("clifford", 5, True, 9000), ("linear_function", 20, False, 8193)])  # > 8 192 envs: the reset is its own launch
-def test_sampling_kernel_that_also_steps_the_env_equals_the_separate_launches(kind, n, use_graph, B):
+@pytest.mark.parametrize("kind,n,use_graph,B,inverts", [("clifford", 5, False, 1000, False), ("clifford", 16, True, 1000, False), ("linear_function", 12, False, 1000, False),
+                                                         ("clifford", 5, True, 9000, False), ("linear_function", 20, False, 8193, False),  # > 8 192 envs: the reset is its own launch
+                                                         # add_inverts, the reference's default: the two-lanes-per-env step inside the small kernel; separate launches beyond
+                                                         ("clifford", 16, True, 1000, True), ("clifford", 7, False, 333, True), ("clifford", 12, True, 8200, True)])
+def test_sampling_kernel_that_also_steps_the_env_equals_the_separate_launches(kind, n, use_graph, B, inverts):
     """qg_vec_mid_head_sample_step_reset: middle layer + head + draw + Env::step + the reset of the envs that finished, in one call (one
     launch for small batches).  Same trajectories, bit for bit, as the sampling kernel followed by qg_vec_step and a reset_done per step
     -- and the trajectories replay on the oracle (auto-resets included)."""
@@ -215,7 +217,7 @@ def test_sampling_kernel_that_also_steps_the_env_equals_the_separate_launches(ki
     T, diff = 12, 2
     gs = line_gateset(kind, n)
     A = len(gs)
-    cfg = dict(add_inverts=False, add_perms=False, track_solution=False, difficulty=diff)
+    cfg = dict(add_inverts=inverts, add_perms=False, track_solution=inverts, difficulty=diff)  # with the solution log in the default configuration
     obs_size = 4 * n * n if kind == "clifford" else n * n
     runs = []
     for fused in (True, False):
@@ -245,9 +247,12 @@ def test_sampling_kernel_that_also_steps_the_env_equals_the_separate_launches(ki
     envs = [OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()}) for _ in range(0, B, stride)]
     for t in range(T):
         draws = rng_actions((5 + 0x9E3779B9 * (t + 1)) & (2**64 - 1), B, diff, A)
+        # add_inverts: the handle's counter RNG throws the coin of env e at step t (qgym_api.cpp: coin_seed; device_common: rng_draw(.., env, step + clock) >> 63)
+        from util import rng_draw
+        coins = (rng_draw(0x5EED0000C01F ^ 0x636F696E, np.arange(0, B, stride, dtype=np.uint64), t) >> np.uint64(63)).astype(np.int64)
         for i, o in enumerate(envs):
             e = stride * i
             if o.is_final():
                 o.reset_with(draws[:, e])
-            o.step(int(acts[t, e]))
+            o.step(int(acts[t, e]), int(coins[i]) if inverts else 0)
             assert o.reward_bits() == int(f32_bits(rew[t, e])) and int(o.is_final()) == int(done[t, e]), (t, e)

@@ -17,7 +17,8 @@ for B, store, graph in ((1024, "packed", False), (1024, "packed", True), (2048, 
         continue
     NQ = int(os.environ.get("QUBITS", "16"))  # > 16: 64-bit row words, the first layer reads the packed observation (qg_policy_embed_words)
     gs = line_gateset("clifford", NQ)
-    env = VecEnv("clifford", NQ, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=int(os.environ.get("DIFF", "32")))
+    dflt = os.environ.get("DEFAULTS") == "1"  # DEFAULTS=1: the reference's defaults add_inverts=True, track_solution=True
+    env = VecEnv("clifford", NQ, gs, B, add_inverts=dflt, add_perms=False, track_solution=dflt, difficulty=int(os.environ.get("DIFF", "32")))
     fused = {"1": True, "0": False}.get(os.environ.get("FUSED", ""), None)  # FUSED=1 / 0 forces the policy-layer kernels on / off
     embed = {"1": True, "0": False}.get(os.environ.get("EMBED", ""), fused)  # EMBED=0: library GEMM for the first layer only
     fstep = {"1": True, "0": False}.get(os.environ.get("FSTEP", ""), None)  # FSTEP=0: sampling kernel, then qg_vec_step (A/B of the fused launch)
