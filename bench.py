@@ -604,6 +604,43 @@ def main():
                                  f"episodes of {DT} steps, each one hipGraph of {DT} launches, coins given"}
         del denv, coins, dacts
 
+    # ---- SURVEY 8(d)'s auto-reset variant of the headline workload: qg_vec_reset_done after every step (finished episodes start over on the
+    # device: compaction of the finished envs + scramble from the identity), one captured graph of 128 x (step, reset_done) -----
+    auto_reset = None
+    if not multi and B == ENVS_PER_GPU and not args.no_default_config:
+        AT = 128
+        aenv = VecEnv("clifford", n, gateset, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=SCRAMBLE)
+        aacts = torch.randint(0, A, (AT, B), dtype=torch.int32, device=dev, generator=gen)
+        with torch.cuda.stream(stream):
+            aenv.reset(seed)
+
+            def episode():
+                for t in range(AT):
+                    aenv.set_counters(t, t)
+                    aenv.rollout(aacts[t : t + 1])
+                    aenv.reset_done(seed + 0x9E3779B9 * (t + 1))
+
+            episode()  # eager pass (allocations, kernel loads)
+            torch.cuda.synchronize()
+            ag = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ag, stream=stream):
+                episode()
+            torch.cuda.synchronize()
+            ag.replay()
+            torch.cuda.synchronize()
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record(stream)
+            for _ in range(4):
+                ag.replay()
+            a1.record(stream)
+        torch.cuda.synchronize()
+        aenv.sync()
+        aus = a0.elapsed_time(a1) * 1e3 / (4 * AT)
+        auto_reset = {"us_per_step": aus, "value": B / (aus * 1e-6), "unit": "env-steps/s", "finished_per_step": float(aenv.done.float().mean()),
+                      "config": f"the headline workload with qg_vec_reset_done after every step (episodes of depth min(depth_slope * difficulty, max_depth) = 128 "
+                                f"steps; every env finishes in the same step, so one step in 128 resets the whole batch); a captured graph of {AT} x (step, reset_done)"}
+        del ag, aenv, aacts
+
     # ---- the same step kernel at larger batches: where the launch boundary (1.6 us) stops dominating, and beyond the Infinity Cache -----
     large = None
     if not multi and B == ENVS_PER_GPU and not args.no_large_batch:
@@ -728,6 +765,7 @@ def main():
             "parity": parity,
             "fused_rollout": fused,
             "default_config": default_cfg,
+            "auto_reset": auto_reset,
             "large_batch": large,
             "policy_in_loop": collector,
         }

@@ -12,6 +12,18 @@ __device__ inline int64_t load_action(const void *actions, uint64_t idx, bool ac
                  : (int64_t) reinterpret_cast<const int32_t *>(actions)[idx];
 }
 
+// compact_done's job done by the kernel that finishes the envs: the wave's finished envs go to the list with one atomic per wave
+// (call from every lane still alive; `fin` on one lane per env)
+__device__ inline void done_list_append(uint32_t *list, uint32_t *count, bool fin, uint64_t env) {
+    const uint64_t m = __ballot(fin);
+    if (!m) return;
+    const uint32_t lane = __lane_id(), first = (uint32_t)__ffsll((long long)m) - 1u;
+    uint32_t base = 0;
+    if (lane == first) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = __shfl(base, first);
+    if (fin) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)env;
+}
+
 // Length of the compacted list of finished envs (compact_done), read by every thread of the LAST kernel
 // that consumes it; the last block to have read it zeroes the counter (and the ticket) for the next
 // qg_vec_reset_done.  counter[0] = length, counter[1] = blocks that have read it.  Call from all threads.

@@ -465,12 +465,14 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
 // renaming into one v_perm_b32 per word.  ~150 instructions per lane instead of ~600 per env.
 // States that are not known to be symplectic (set_state of an arbitrary matrix) keep the thread-per-env Gauss-Jordan variant.
 // ------------------------------------------------------------------------------------------
-template <int NXP, bool FEAT>
+template <int NXP, bool FEAT, bool LIST = false>
 __global__ __launch_bounds__(256) void qm_inv2_kernel(StepArgs a) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     QG_PREFETCH_STEP_ARGS(a);
     if ((tid >> 1) >= a.B) return;  // whole lane pairs leave together
-    qm_inv2_body<NXP / 2, FEAT>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr);  // qm_step1.hpp
+    const bool fin = qm_inv2_body<NXP / 2, FEAT>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr);  // qm_step1.hpp
+    if constexpr (LIST) done_list_append(a.done_list, a.done_count, fin && !(tid & 1u), tid >> 1);
+    else (void)fin;
 }
 
 // One step per launch without holding the matrix (the env.step() path without add_inverts).  A gate
@@ -479,14 +481,17 @@ __global__ __launch_bounds__(256) void qm_inv2_kernel(StepArgs a) {
 // incrementally kept `bad` mask (bit j: qubit j's rows / row j differ from the identity's).  ~3x fewer
 // instructions than the register-resident kernel, which at one wave per SIMD is what a step costs;
 // measured 3.77 -> 3.15 us per step at B = 65 536 and 34.9 -> 30.0 us at B = 2^20 (CliffordEnv 16q).
-template <int NXP, bool HAS_Z, bool FEAT>
+// LIST: also append the envs that finish to StepArgs::done_list (F_DONE_LIST; its own instantiation: the plain kernel's code stays as it is)
+template <int NXP, bool HAS_Z, bool FEAT, bool LIST = false>
 __global__ __launch_bounds__(256) void qm_step1_kernel(StepArgs a) {
     using Rows = QmRows<NXP, HAS_Z>;
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
     if (env >= a.B) return;
     const int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
-    qm_step1_body<HAS_Z, FEAT>(a, Rows::G, env, act);  // qm_step1.hpp
+    const bool fin = qm_step1_body<HAS_Z, FEAT>(a, Rows::G, env, act);  // qm_step1.hpp
+    if constexpr (LIST) done_list_append(a.done_list, a.done_count, fin, env);
+    else (void)fin;
 }
 
 // Fused rollout on LDS-resident rows (T steps per launch, plain configuration: no add_inverts, no solution log, default
@@ -808,7 +813,10 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
     const bool feat = a.flags & (F_TRACK | F_LAYERS);
     const bool seq = a.T != 1 || a.rewards_seq || a.dones_seq;
     if (a.bad && a.T == 1 && !(a.flags & F_INVERTS)) {  // the env.step() path
-        if (feat) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, true>), grid, block, 0, s, a);
+        const bool list = a.flags & F_DONE_LIST;
+        if (feat && list) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, true, true>), grid, block, 0, s, a);
+        else if (feat) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, true>), grid, block, 0, s, a);
+        else if (list) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, false, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, false>), grid, block, 0, s, a);
         return hipGetLastError();
     }
@@ -816,7 +824,10 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
         if constexpr (HAS_Z && NXP <= 16) {  // CliffordEnv (LinearFunctionEnv with add_inverts lives in kernels_lfd.hip)
             if (!(a.flags & F_GJ) && a.T == 1) {  // every env symplectic, one step per launch: two lanes per env
                 const dim3 grid2(grid_for(2 * a.B, 256));
-                if (feat) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true>), grid2, block, 0, s, a);
+                const bool list = a.flags & F_DONE_LIST;
+                if (feat && list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true, true>), grid2, block, 0, s, a);
+                else if (feat) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true>), grid2, block, 0, s, a);
+                else if (list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, false, true>), grid2, block, 0, s, a);
                 else hipLaunchKernelGGL((qm_inv2_kernel<NXP, false>), grid2, block, 0, s, a);
                 return hipGetLastError();
             }

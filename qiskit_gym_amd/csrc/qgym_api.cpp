@@ -744,6 +744,7 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
         // instead of in every wave that holds one finished env (the sampling + step kernel has already done it: done_list_fresh)
         if (!v->done_list_fresh) HIP_TRY(compact_done(v->done, v->B, v->done_list, v->done_list + v->B, s));
         v->done_list_fresh = false;
+        v->auto_list = true;
         ia.list = v->done_list;
         ia.list_count = v->done_list + v->B;
         ia.coop = (!actions_dev && v->B >= 64 && v->d_rowops) ? 1u : 0u;
@@ -824,18 +825,34 @@ int qg_vec_reset_with(qg_vec *v, const int32_t *actions_dev, size_t n_draws, voi
     return do_reset(v, actions_dev, n_draws, 0, (hipStream_t)stream);
 }
 
+// A handle on which qg_vec_reset_done is in use: a single step of the TILE one-step kernels (qm_step1_kernel, qm_inv2_kernel) leaves the
+// list of the envs it finished itself, and the reset that follows needs no compaction launch.
+static bool step_leaves_done_list(const qg_vec *v, StepArgs &a) {
+    const bool lists = v->auto_list && v->layout == LAYOUT_TILE && v->done_list &&
+                       ((v->flags & F_INVERTS) ? (v->has_z && v->nxp <= 16 && !v->maybe_nonsymplectic) : v->bad != nullptr);
+    if (lists) {
+        a.flags |= F_DONE_LIST;
+        a.done_list = v->done_list;
+        a.done_count = v->done_list + v->B;
+    }
+    return lists;
+}
+
 int qg_vec_step(qg_vec *v, const void *actions_dev, int action_dtype, const uint8_t *coins_dev, void *stream) {
     if (!v || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
     if (action_dtype != QG_ACT_I32 && action_dtype != QG_ACT_I64) return set_error(QG_ERR_INVALID, "bad action dtype");
     QG_ON_DEVICE(v);
+    if (v->done_list_fresh) v->auto_list = false;  // the last list was never consumed: this caller steps without qg_vec_reset_done
     if (int rc = drop_done_list(v, (hipStream_t)stream)) return rc;
     StepArgs a;
     fill_step_args(v, a);
+    const bool lists = step_leaves_done_list(v, a);
     a.actions = actions_dev;
     a.coins = coins_dev;
     if (action_dtype == QG_ACT_I64) a.flags |= F_ACT64;
     HIP_TRY(launch_step(v, a, (hipStream_t)stream));
     v->step_index += 1;
+    if (lists) v->done_list_fresh = true;
     return QG_OK;
 }
 
@@ -860,9 +877,11 @@ static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, si
     if (T > 0x7fffffffu) return set_error(QG_ERR_INVALID, "too many steps");
     QG_ON_DEVICE(v);
     hipStream_t s = (hipStream_t)stream;
+    if (v->done_list_fresh) v->auto_list = false;  // the last list was never consumed: this caller steps without qg_vec_reset_done
     if (int rc = drop_done_list(v, s)) return rc;
     StepArgs a;
     fill_step_args(v, a);
+    const bool lists = T == 1 && !fused && step_leaves_done_list(v, a);
     a.actions = actions_dev;
     a.coins = coins_dev;
     a.rewards_seq = rewards_dev;
@@ -899,6 +918,7 @@ static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, si
     if (cs != hipStreamCaptureStatusNone || rng_coins || T == 1) {
         HIP_TRY(enqueue_steps(s));
         v->step_index += T;
+        if (lists) v->done_list_fresh = true;
         return QG_OK;
     }
     GraphKey key{actions_dev, coins_dev, rewards_dev, dones_dev, T, action_dtype, period, a.flags, v->env_base};

@@ -109,6 +109,7 @@ struct qg_vec {
     uint32_t *bad = nullptr;            // TILE / TILE64 without add_inverts: per-env "differs from identity" mask (one-step kernels)
     uint32_t *d_rowops = nullptr;       // TILE: gate table as pairs of row operations on slots (cooperative reset kernel)
     uint32_t *done_list = nullptr;      // reset_done: [B] indices of finished envs + {length, reader ticket} at [B], [B + 1]
+    bool auto_list = false;             // qg_vec_reset_done is in use on this handle: single steps append the envs they finish to the list themselves
     bool done_list_fresh = false;       // the list already holds the finished envs (written by the step that ended them: qg_vec_mid_head_sample_step)
     uint32_t *d_nonsymp = nullptr;      // device word behind InitArgs::nonsymp_flag
     void *embed_dump = nullptr;         // qg_vec_embed: 1 KiB nobody reads (kernels_policy.hip), allocated by qg_vec_pack_embedding

@@ -52,7 +52,8 @@ enum : uint32_t {
     F_INVERTS = 1u << 1,   // add_inverts (clifford.rs:262-270)
     F_TRACK = 1u << 2,     // track_solution (clifford.rs:334-340)
     F_LAYERS = 1u << 3,    // non-zero n_layers / n_layers_cnots weights: track per-qubit layers
-    F_GJ = 1u << 4         // some env may hold a non-symplectic matrix: compile in the Gauss-Jordan inversion
+    F_GJ = 1u << 4,        // some env may hold a non-symplectic matrix: compile in the Gauss-Jordan inversion
+    F_DONE_LIST = 1u << 5  // the one-step kernel appends the envs that finish to StepArgs::done_list (qg_vec_reset_done follows: no compaction launch)
 };
 
 // counter RNG shared by host, device and the tests
@@ -107,6 +108,8 @@ struct StepArgs {
     const uint64_t *clock;    // device clock added to every RNG counter (qg_vec_set_clock), or null
     uint64_t env_base;        // global index of env 0 in the counter RNG (qg_vec_set_env_base)
     uint32_t *bad;            // TILE (uint32) / TILE64 (uint64) per-env mask: bit j = qubit j's rows / row j differ from the identity's; or null
+    uint32_t *done_list;      // F_DONE_LIST: [B] indices of the envs that finished in this step, then {length, reader ticket} (compact_done's format);
+    uint32_t *done_count;     // read only under that flag (the last fields of the block: other launches never touch their cache line)
 };
 
 // The argument block spans four 64-byte lines and the scalar cache is cold at every launch.  Left alone, the compiler fetches a field
