@@ -669,6 +669,7 @@ def main():
             col = RolloutCollector(cenv, BasicPolicy(4 * n * n, A), dtype=torch.bfloat16, seed=1, store_obs="packed", use_graph=True)
             CT = 32
             col.collect(CT)  # eager pass + capture
+            col.collect(CT)  # first replay (the graph's one-time upload: tens of ms now and then)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(3):

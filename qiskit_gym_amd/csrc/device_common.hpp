@@ -24,13 +24,22 @@ __device__ inline void done_list_append(uint32_t *list, uint32_t *count, bool fi
     if (fin) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)env;
 }
 
-// Length of the compacted list of finished envs (compact_done), read by every thread of the LAST kernel
-// that consumes it; the last block to have read it zeroes the counter (and the ticket) for the next
-// qg_vec_reset_done.  counter[0] = length, counter[1] = blocks that have read it.  Call from all threads.
-__device__ inline uint32_t list_count_take(uint32_t *counter) {
+#define QG_COOP_LANES 16  // lanes per env of the cooperative scramble (scramble_coop below)
+
+// Length of the compacted list of finished envs (compact_done), read by every thread of the LAST kernel that consumes it.  The last
+// block WITH WORK to have read it zeroes the counter (and the ticket) for the next qg_vec_reset_done: counter[0] = length, counter[1] =
+// blocks that have read it.  `coop_B`: 0, or the batch size when lists short enough (coop_takes) give an env 16 lanes instead of one --
+// the number of blocks with work follows from the length alone, so every block computes it.  A block without work takes no ticket (256
+// tickets on one address cost the launch 3.4 us); it may find the counter already zeroed and then sees an empty list, which for it is
+// the same thing.  An empty list needs neither tickets nor zeroing.  Call from all threads.
+__device__ inline uint32_t list_count_take(uint32_t *counter, uint64_t coop_B = 0) {
     const uint32_t count = counter[0];
+    if (count == 0) return 0;
+    const uint64_t threads = (coop_B && (uint64_t)count * QG_COOP_LANES * 2 <= coop_B) ? (uint64_t)count * QG_COOP_LANES : (uint64_t)count;
+    const uint32_t blocks = (uint32_t)((threads + blockDim.x - 1) / blockDim.x);
+    if (blockIdx.x >= blocks) return count;  // (this block's threads all lie past the list)
     __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(&counter[1], 1u) == gridDim.x - 1u) {
+    if (threadIdx.x == 0 && atomicAdd(&counter[1], 1u) == blocks - 1u) {
         counter[0] = 0;
         counter[1] = 0;
     }
@@ -45,7 +54,6 @@ __device__ inline uint32_t list_count_take(uint32_t *counter) {
 // indices), and the counter-RNG draws -- two splitmix64 rounds, ~300 cycles of 64-bit multiplies each --
 // are issued ahead of the dependent LDS chain.
 // ---------------------------------------------------------------------------------------------------
-#define QG_COOP_LANES 16
 // qg_vec_reset_done: lists of at most B / 32 finished envs take the 16-lanes-per-env path
 __device__ inline bool coop_takes(uint32_t count, uint64_t B) { return (uint64_t)count * QG_COOP_LANES * 2 <= B; }
 

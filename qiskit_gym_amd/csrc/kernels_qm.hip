@@ -642,8 +642,8 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t env = tid;
     if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
-        const uint32_t count = list_count_take(a.list_count);  // this kernel is the list's only reader
         constexpr bool coop_fits = scramble_coop_lds_bytes<uint32_t, Rows::R>(4) <= sizeof(lds_rows);
+        const uint32_t count = list_count_take(a.list_count, (coop_fits && a.coop) ? a.B : 0);  // this kernel is the list's only reader
         if (coop_fits && a.coop && coop_takes(count, a.B)) {  // few finished envs: 16 lanes each (count * 16 <= B / 2 threads)
             const uint32_t N = a.N;
             const uint32_t *rows = scramble_coop<uint32_t, Rows::R>(a, count, &lds_rows[0][0][0], env, [N](uint32_t k) -> uint32_t {

@@ -676,7 +676,7 @@ __global__ __launch_bounds__(64) void q64_init_kernel(InitArgs a) {
     uint64_t env = tid;
     Rows s;
     if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
-        const uint32_t count = list_count_take(a.list_count);  // this kernel is the list's only reader
+        const uint32_t count = list_count_take(a.list_count, a.coop ? a.B : 0);  // this kernel is the list's only reader
         if (a.coop && coop_takes(count, a.B)) {  // few finished envs: 16 lanes each
             const uint32_t N = a.N;
             const uint64_t *rows = scramble_coop<uint64_t, NS>(a, count, &lds_rows[0][0], env, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); });
