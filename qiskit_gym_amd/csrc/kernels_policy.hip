@@ -336,20 +336,20 @@ __global__ __launch_bounds__(EMB_THREADS, 1) void embed_bits_kernel(EmbedArgs a)
 // a 64-column slab it first loads into LDS, so 1 024 envs are 16 workgroups x 256 MFMAs per wave -- 14 us on 16 CUs.  Here two waves
 // own one tile of 32 envs x one slab, one per column of the slab's column pairs, and take their fragments from L2 straight into
 // registers (the packed layout is fragment order: 1 KiB per wave load, EMS_AHEAD groups of 8 k-steps in flight).  What bounds these
-// launches is the bytes a CU pulls, so a tile gets a workgroup -- and a CU -- of its own while the chip has enough of them.
+// launches is the bytes a CU pulls, so every (tile, slab) pair is a workgroup of its own and the launch spreads over all CUs.
 // Same packed weights, same expansion, same k order: bit-identical activations.
-constexpr uint32_t EMS_TILES = 4;   // env tiles per workgroup when one tile each would not fit a workgroup per CU
 constexpr uint32_t EMS_AHEAD = 4;   // groups of 8 weight fragments in flight per wave
+constexpr uint32_t EMS_WGS_PER_CU = 4;  // the launch takes this shape up to that many workgroups per CU
 
-// TILES env tiles per workgroup, two waves per tile: one per column of the slab's column pairs
-template <uint32_t G, uint32_t TILES>
-__global__ __launch_bounds__(128 * TILES) void embed_small_kernel(EmbedArgs a) {
+// one env tile per workgroup, two waves: one per column of the slab's column pairs
+template <uint32_t G>
+__global__ __launch_bounds__(128) void embed_small_kernel(EmbedArgs a) {
     constexpr uint32_t GP = (G + 1u) & ~1u;
     constexpr uint32_t slab_vec = GP * 8u * 2u * 64u;  // uint4 per slab (the padding group of an odd G has zero weights: skipped)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t slab = blockIdx.x % a.n_slabs;
     const uint32_t nb = wave & 1u;  // this wave's column of every pair: 2 c + nb
-    const uint64_t tile = (uint64_t)(blockIdx.x / a.n_slabs) * TILES + (wave >> 1);
+    const uint64_t tile = blockIdx.x / a.n_slabs;
     if (tile * 32u >= a.B) return;  // wave-uniform; no barrier below
     const uint32_t r = lane & 31u, h = lane >> 5;
     const uint32_t sh[2] = {4u * h, 8u + 4u * h};
@@ -1431,22 +1431,17 @@ static int embed_impl(qg_vec *v, const void *packed_dev, const float *bias_dev, 
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, v->device);
     hipStream_t s = (hipStream_t)stream;
     const uint64_t env_tiles = (v->B + 31u) / 32u;
-    const bool small = env_tiles * a.n_slabs <= (uint64_t)EMS_TILES * (uint64_t)cus;  // at most one workgroup per CU of embed_small_kernel: too few envs for 512-env passes
+    // (32-env tile, slab) workgroups of embed_small_kernel: too few envs for 512-env passes under an LDS-resident slab.  Measured inside the
+    // CliffordGym collector: 21 against 23 us per step at 2 048 envs (two workgroups per CU), equal at 4 096 (four), slower beyond.
+    const bool small = env_tiles * a.n_slabs <= (uint64_t)EMS_WGS_PER_CU * (uint64_t)cus;
     if (obs_dev) {
         if (small && (reinterpret_cast<uintptr_t>(obs_dev) & 15u) == 0) a.obs = reinterpret_cast<uint32_t *>(obs_dev);  // written by the same launch
         else if (const int rc = qg_vec_observe_packed(v, obs_dev, stream)) return rc;
     }
     if (small) {
-        // one env tile per workgroup while that leaves every workgroup a CU of its own (each wave then pulls its half slab, 64 KiB, and
-        // nobody else's); otherwise four tiles under a slab (their loads meet in the CU's vector cache)
-        const bool one = env_tiles * a.n_slabs <= (uint64_t)cus;
-        const uint32_t tiles_wg = one ? 1u : EMS_TILES;
-        const dim3 grid((unsigned)(((env_tiles + tiles_wg - 1) / tiles_wg) * a.n_slabs)), block(128 * tiles_wg);
+        const dim3 grid((unsigned)(env_tiles * a.n_slabs)), block(128);
 #define QG_EMS_CASE(GG)                                                           \
-    case GG:                                                                      \
-        if (one) hipLaunchKernelGGL((embed_small_kernel<GG, 1>), grid, block, 0, s, a);      \
-        else hipLaunchKernelGGL((embed_small_kernel<GG, EMS_TILES>), grid, block, 0, s, a);  \
-        break;
+    case GG: hipLaunchKernelGGL(embed_small_kernel<GG>, grid, block, 0, s, a); break;
         switch (G) {
             QG_EMS_CASE(2) QG_EMS_CASE(3) QG_EMS_CASE(4) QG_EMS_CASE(5) QG_EMS_CASE(6) QG_EMS_CASE(7) QG_EMS_CASE(8)
         default: return set_error(QG_ERR_UNSUPPORTED, "unexpected row-group count %u", G);
