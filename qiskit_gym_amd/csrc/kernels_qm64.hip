@@ -550,12 +550,14 @@ __global__ __launch_bounds__(256) void q64_inv2_kernel(StepArgs a) {
         if (fault) atomicOr(&a.error[env], fault);
         if (a.bad) reinterpret_cast<uint64_t *>(a.bad)[env] = (uint64_t)bad;  // the one-step kernel may run next
     }
+    if (a.flags & F_DONE_LIST) done_list_append(a.done_list, a.done_count, h == 0 && (depth == 0 || solved), env);
 }
 
 // One step per launch without holding the matrix (see qm_step1_kernel in kernels_qm.hip): the gate's
 // <= 2 groups ({X[q], Z[q]} of a qubit for CliffordEnv, a row pair for LinearFunctionEnv) are gathered
 // and scattered at per-lane addresses, `solved` comes from the incrementally kept 64-bit `bad` mask.
-template <int NS, bool HAS_Z, bool FEAT>
+// LIST: also append the envs that finish to StepArgs::done_list (F_DONE_LIST; its own instantiation: the plain kernel's code stays as it is)
+template <int NS, bool HAS_Z, bool FEAT, bool LIST = false>
 __global__ __launch_bounds__(256) void q64_step1_kernel(StepArgs a) {
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
@@ -632,6 +634,7 @@ __global__ __launch_bounds__(256) void q64_step1_kernel(StepArgs a) {
     a.success[env] = (uint8_t)solved;
     if (FEAT && (a.flags & F_TRACK)) a.sol_len[env * 2] = sol_n;
     if (FEAT && fault) atomicOr(&a.error[env], fault);
+    if constexpr (LIST) done_list_append(a.done_list, a.done_count, depth == 0 || solved, env);  // qg_vec_reset_done follows (qgym_api.cpp)
 }
 
 // the tail of set_state / reset for one env: rows to the tile, reset_internals (clifford.rs:272-283)
@@ -845,7 +848,10 @@ static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
     const dim3 grid(grid_for(a.B, 256)), block(256);
     const bool extra = (a.flags & (F_TRACK | F_LAYERS)) || a.T != 1 || a.rewards_seq || a.dones_seq;
     if (a.bad && a.T == 1 && !(a.flags & F_INVERTS)) {  // the env.step() path
-        if (a.flags & (F_TRACK | F_LAYERS)) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, true>), grid, block, 0, s, a);
+        const bool feat = a.flags & (F_TRACK | F_LAYERS), list = a.flags & F_DONE_LIST;
+        if (feat && list) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, true, true>), grid, block, 0, s, a);
+        else if (feat) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, true>), grid, block, 0, s, a);
+        else if (list) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, false, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, false>), grid, block, 0, s, a);
         return hipGetLastError();
     }

@@ -825,11 +825,12 @@ int qg_vec_reset_with(qg_vec *v, const int32_t *actions_dev, size_t n_draws, voi
     return do_reset(v, actions_dev, n_draws, 0, (hipStream_t)stream);
 }
 
-// A handle on which qg_vec_reset_done is in use: a single step of the TILE one-step kernels (qm_step1_kernel, qm_inv2_kernel) leaves the
-// list of the envs it finished itself, and the reset that follows needs no compaction launch.
+// A handle on which qg_vec_reset_done is in use: a single step of the TILE / TILE64 one-step kernels (qm_step1, qm_inv2, q64_step1, q64_inv2)
+// leaves the list of the envs it finished itself, and the reset that follows needs no compaction launch.
 static bool step_leaves_done_list(const qg_vec *v, StepArgs &a) {
-    const bool lists = v->auto_list && v->layout == LAYOUT_TILE && v->done_list &&
-                       ((v->flags & F_INVERTS) ? (v->has_z && v->nxp <= 16 && !v->maybe_nonsymplectic) : v->bad != nullptr);
+    const bool tile32 = v->layout == LAYOUT_TILE, tile64 = v->layout == LAYOUT_TILE64;  // qm_step1 / qm_inv2 (N <= 16), q64_step1 / q64_inv2
+    const bool lists = v->auto_list && (tile32 || tile64) && v->done_list &&
+                       ((v->flags & F_INVERTS) ? (v->has_z && (tile64 || v->nxp <= 16) && !v->maybe_nonsymplectic) : v->bad != nullptr);
     if (lists) {
         a.flags |= F_DONE_LIST;
         a.done_list = v->done_list;

@@ -10,7 +10,8 @@ from util import f32_bits, grid_gateset, line_gateset, rng_actions  # noqa: E402
 
 
 @pytest.mark.parametrize("kind,n,inverts", [("clifford", 16, False), ("clifford", 5, True), ("linear_function", 8, False),
-                                            ("linear_function", 12, True), ("permutation", 9, False), ("permutation", 25, True)])
+                                            ("linear_function", 12, True), ("permutation", 9, False), ("permutation", 25, True),
+                                            ("clifford", 20, False), ("clifford", 18, True), ("linear_function", 40, False)])  # 64-bit rows
 def test_reset_done_only_touches_finished_episodes(kind, n, inverts):
     from qiskit_gym_amd.vec import VecEnv
 
