@@ -12,7 +12,9 @@ resident in HBM.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1: one rank per GPU over RCCL.  Started by the driver through torch.distributed.run (WORLD_SIZE set), or, when
+N > 1: one rank per GPU; the data path is libqgym's own communicator (qg_comm_* of include/qgym.h: ncclAllGather of librccl.so.1
+called from C++, and the direct write into the peers' windows over xGMI) -- torch.distributed (gloo, CPU) only carries the control
+plane: the 128-byte communicator id, the barriers and the max-over-ranks of the elapsed time.  Started by the driver through torch.distributed.run (WORLD_SIZE set), or, when
 it is not, bench.py itself starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
 process before this process has touched a GPU, and relays rank 0's JSON line.  Fewer visible GPUs than N is an
 error.  Rank r owns envs [r * 65 536, (r + 1) * 65 536) of ONE batch of N * 65 536 envs (weak scaling): every
@@ -287,6 +289,7 @@ def main():
     ap.add_argument("--no-default-config", action="store_true", help="skip the reference-default (add_inverts=True, track_solution=True) leg")
     ap.add_argument("--no-collector", action="store_true", help="skip the policy-in-the-loop leg (SURVEY 8f-3: collection with the reference's default policy shape)")
     ap.add_argument("--no-gather", action="store_true", help="N>1 diagnostics: step only, no all-gather")
+    ap.add_argument("--no-p2p", action="store_true", help="N>1: skip the direct-write (hipIpc windows over xGMI) cadence leg")
     ap.add_argument("--gather-every", type=int, default=CHUNK,
                     help="N>1: all-gather the learner shard every min(this, --steps) steps (1 = after every step)")
     ap.add_argument("--envs", type=int, default=ENVS_PER_GPU,
@@ -322,6 +325,7 @@ def main():
         print(f"bench.py: rank {rank} has LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
         sys.exit(2)
     dist = None
+    comm = None
     multi = world > 1 or args.force_multi
     if multi:
         import torch.distributed as dist
@@ -331,10 +335,17 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: the control plane stays on loopback (the hostname may not resolve)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # control plane only (CPU tensors): id broadcast, barriers, max-over-ranks of the elapsed time
+        dist.init_process_group("gloo")
         if dist.get_world_size() != world:
             raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, expected {world}")
+        from qiskit_gym_amd.distributed import Communicator
+
+        uid = [Communicator.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = Communicator(rank, world, device=local_rank, unique_id=uid[0])  # ncclCommInitRank inside libqgym
     else:
         torch.cuda.set_device(0)
     n_gpus = world
@@ -387,21 +398,24 @@ def main():
     gather_every = min(args.gather_every, K)
     gather_log = {"submitted": 0}
     if multi:
-        from qiskit_gym_amd.distributed import OverlappedGather, fill_learner_shard, learner_shard_words, split_learner_shards
+        from qiskit_gym_amd.distributed import split_gathered
 
-        # double-buffered, host-mediated hand-over to a side stream (see OverlappedGather: a stream-to-stream
-        # event wait would slow every later graph replay on the step stream by ~40 %)
-        # one flat int32 shard per rank carries everything SURVEY 8e lists for the learner: the packed observation [B, 32], the f32
-        # rewards [B] and is_final / success [B] bytes each -- one collective instead of four
-        gatherer = OverlappedGather((learner_shard_words(B, OBS_WORDS),), torch.int32, dev)
-
-        def fill_shard(buf):
-            fill_learner_shard(buf, B, OBS_WORDS, lambda view: env.observe_packed(out=view), env.reward, env.done, env.success)
+        # double-buffered, host-mediated hand-over to the communicator's side stream, inside libqgym (qg_comm_gather_submit: a
+        # stream-to-stream event wait would slow every later graph replay on the step stream by ~40 %).  One flat shard per rank
+        # carries everything SURVEY 8e lists for the learner: the packed observation [B, 32], the f32 rewards [B] and is_final /
+        # success [B] bytes each -- one ncclAllGather instead of four
+        layout = env.shard_layout()
 
         def snapshot_and_gather():
-            gatherer.submit(fill_shard)
+            comm.submit(env)
             gather_log["submitted"] += 1
             gather_log["trace_len"] = len(ring_trace)
+
+        class _Flush:
+            flush = staticmethod(lambda: comm.flush())
+            latest = staticmethod(lambda: comm.latest())
+
+        gatherer = _Flush
 
         def run_steps(nsteps: int):
             """Each rank steps its own shard (no collective inside step).  Every `gather_every` steps the learner shard is snapshotted
@@ -449,7 +463,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     env.sync()  # raises if any env faulted
@@ -474,7 +488,7 @@ def main():
     snap_actions = host_actions[:, ids].numpy()
     if multi and rank == 0 and not args.no_gather and gatherer.latest() is not None:
         # this rank's own part of the last all-gathered buffer, as the learner would read it
-        g_obs, g_rew, g_done, g_succ = split_learner_shards(gatherer.latest(), world, B, OBS_WORDS)
+        g_obs, g_rew, g_done, g_succ = split_gathered(gatherer.latest(), layout, world, 4)
         lo = rank * B
         gshard = {"obs": g_obs[lo:lo + B][idx].cpu().numpy(), "reward": g_rew[lo:lo + B][idx].cpu().numpy(),
                   "done": g_done[lo:lo + B][idx].cpu().numpy(), "success": g_succ[lo:lo + B][idx].cpu().numpy(),
@@ -498,7 +512,7 @@ def main():
                 gatherer.flush()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item()) / reps
 
@@ -508,13 +522,60 @@ def main():
 
         per_step = timed(step_and_gather, 64)       # SURVEY 8e's literal cadence: one all-gather per env.step()
         gather_only = timed(snapshot_and_gather, 16)  # snapshot + collective alone, nothing to overlap with
+        inline_out = torch.empty(int(layout.bytes) * world, dtype=torch.uint8, device=dev)
+
+        def step_and_gather_in_stream():  # qg_vec_gather_learner_shard: pack + ncclAllGather on the step stream itself
+            env.step(actions[0])
+            comm.gather(env, out=inline_out)
+
+        in_stream = timed(step_and_gather_in_stream, 64)
         cadence = {
             "per_step_gather_us": per_step * 1e6,
             "per_step_gather_value": B * n_gpus / per_step,
+            "in_stream_gather_us": in_stream * 1e6,
             "segment_gather_us": gather_only * 1e6,
             "segment_steps": gather_every,
-            "shard_bytes_per_rank": 4 * learner_shard_words(B, OBS_WORDS),
+            "shard_bytes_per_rank": int(layout.bytes),
         }
+        # the direct write (SURVEY 5's follow-up): every rank copies its shard into a window in each peer's HBM over xGMI and raises
+        # a flag there; no collective library on the data path.  Measured beside the RCCL cadences, and checked against them.
+        if not args.no_p2p:
+            try:
+                comm.p2p_connect(int(layout.bytes))  # windows + hipIpc handle exchange over the communicator (collective)
+                p2p_view = [None]
+
+                def step_push_wait():
+                    env.step(actions[0])
+                    comm.push(env)
+                    p2p_view[0] = comm.wait()
+                    comm.release()
+
+                def push_wait():
+                    comm.push(env)
+                    p2p_view[0] = comm.wait()
+                    comm.release()
+
+                timed(step_push_wait, 4)  # first use
+                p2p_step = timed(step_push_wait, 64)
+                p2p_only = timed(push_wait, 16)
+                with torch.cuda.stream(stream):
+                    comm.push(env)
+                    view = comm.wait()
+                    direct = view.clone()
+                    comm.release()
+                    comm.gather(env, out=inline_out)
+                    comm.check()
+                same = bool(torch.equal(direct, inline_out))
+                cadence["direct_write"] = {"per_step_us": p2p_step * 1e6, "per_step_value": B * n_gpus / p2p_step, "push_wait_release_us": p2p_only * 1e6,
+                                           "equals_rccl_gather": same,
+                                           "what": "qg_vec_push_learner_shard + qg_comm_p2p_wait + qg_comm_p2p_release after every env.step(): the pack, "
+                                                   "one copy kernel writing into all ranks' hipIpc-mapped windows, per-source arrival flags"}
+                if not same:
+                    raise SystemExit("bench.py: the direct-write hand-over and the RCCL all-gather disagree")
+            except SystemExit:
+                raise
+            except Exception as exc:  # reported, not fatal: the RCCL path above is the measured default
+                cadence["direct_write"] = {"error": repr(exc)}
 
     # ---- roofline leg: duration of the step kernel, HIP events on the stream the kernel is launched on --------
     # (1) the timed region itself: events around the K timed launches (what `achieved` uses)
@@ -727,8 +788,9 @@ def main():
                 "partition": f"rank r owns envs [r * {B}, (r + 1) * {B}) of one batch of {total_envs}; seeds and actions are functions of the global env id",
                 "launch": launch_desc,
                 "collective": None if not multi or args.no_gather else {
-                    "what": "RCCL all_gather_into_tensor of one flat shard per rank (bit-packed observation + f32 rewards + is_final / success flags), "
-                            "side stream, double buffered, overlapped with the following steps",
+                    "what": "qg_comm_gather_submit (include/qgym.h): one flat shard per rank (bit-packed observation + f32 rewards + is_final / success flags) "
+                            "packed by libqgym and moved by ncclAllGather of librccl.so.1 called from libqgym, side stream, double buffered, "
+                            "overlapped with the following steps; torch.distributed (gloo) carries only the id, the barriers and the timing reduction",
                     "every_steps": gather_every,
                     "collectives_in_timed_region": gathers_timed,
                     **(cadence or {}),
@@ -772,7 +834,10 @@ def main():
         }
         print(json.dumps(out), file=json_out, flush=True)
     if dist is not None:
-        dist.barrier()
+        torch.cuda.synchronize()
+        dist.barrier()  # nobody unmaps a window or leaves the communicator while a peer may still use it
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

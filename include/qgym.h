@@ -369,6 +369,86 @@ int qg_vec_mid_head_sample_step_reset(qg_vec *v, const void *h_dev, uint64_t ld_
                                       float *entropy_dev, float *values_dev, float *rewards_dev, uint8_t *dones_dev, uint64_t reset_seed, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Multi-GPU hand-over (BASELINE.json north_star: "batches shard trivially over the 8 GPUs of one node with an RCCL all-gather
+ * over xGMI only for the observation tensor handed back to the learner").  One process (or thread) per GPU; rank r
+ * of W owns the contiguous env range [r*B, (r+1)*B) of one batch of W*B envs (qg_vec_set_env_base makes its draws those of the
+ * whole batch).  Env::step (clifford.rs:321-347) touches one env only, so stepping needs no exchange; what crosses GPUs is what
+ * the reference's collector reads from every env after a step -- Env::observe (clifford.rs:361-368), Env::reward (:355),
+ * Env::is_final (:353), Env::success (:357-359) -- as ONE flat shard per rank:
+ *
+ *   [ obs: B * packed_words_per_env * packed_word_bytes (qg_vec_observe_packed) | pad to 4 | reward: f32[B] |
+ *     is_final: u8[B] | pad to 4 | success: u8[B] | pad to 16 ]
+ *
+ * Two transports: ncclAllGather of librccl.so.1 (loaded on the first qg_comm_init, not a link-time dependency), and a direct
+ * write in which every rank copies its shard into a window in each peer's HBM over xGMI (hipIpc-shared, one link per peer) and
+ * raises a per-source flag -- no collective library on the data path.  A gathered buffer is W consecutive shards, rank order =
+ * env order.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct qg_comm qg_comm;
+#define QG_COMM_ID_BYTES 128   /* = NCCL_UNIQUE_ID_BYTES */
+#define QG_P2P_HANDLE_BYTES 64 /* = HIP_IPC_HANDLE_SIZE */
+#define QG_COMM_MAX_WORLD 16
+
+typedef struct {
+    uint64_t batch;          /* envs in the shard */
+    uint64_t bytes;          /* size of one rank's shard (multiple of 16) = stride between ranks in a gathered buffer */
+    uint64_t obs_offset;     /* 0 */
+    uint64_t obs_bytes;      /* batch * packed_words_per_env * packed_word_bytes */
+    uint64_t reward_offset;  /* f32[batch] */
+    uint64_t final_offset;   /* u8[batch]  Env::is_final */
+    uint64_t success_offset; /* u8[batch]  Env::success */
+} qg_shard_layout;
+
+/* Layout of one rank's shard for this handle (same for every rank that holds the same env kind and batch). */
+int qg_vec_learner_shard_layout(const qg_vec *v, qg_shard_layout *out);
+/* Write this handle's shard to shard_dev (qg_shard_layout.bytes, 16-byte aligned): two launches on `stream` (the packed
+ * observation as qg_vec_observe_packed writes it -- for a PauliEnv this counts as one observe() -- and the three per-env arrays). */
+int qg_vec_pack_learner_shard(qg_vec *v, void *shard_dev, void *stream);
+
+/* Rank 0 calls qg_comm_unique_id and hands the 128 bytes to every rank by whatever channel the host has (ncclGetUniqueId). */
+int qg_comm_unique_id(uint8_t id_out[QG_COMM_ID_BYTES]);
+/* Collective over all ranks: ncclCommInitRank on GPU `device`.  world == 1 is allowed. */
+int qg_comm_init(const uint8_t id[QG_COMM_ID_BYTES], int rank, int world, int device, qg_comm **out);
+/* A communicator without RCCL, for the direct-write transport only (handles are exchanged by the host: qg_comm_p2p_export /
+ * qg_comm_p2p_open).  Not collective. */
+int qg_comm_init_local(int rank, int world, int device, qg_comm **out);
+void qg_comm_destroy(qg_comm *c);
+int qg_comm_rank(const qg_comm *c);
+int qg_comm_world(const qg_comm *c);
+
+/* qg_vec_pack_learner_shard into a buffer of the communicator, then ncclAllGather of it into out_dev
+ * (world * qg_shard_layout.bytes), both on `stream`: stream-ordered after the steps enqueued before it. */
+int qg_vec_gather_learner_shard(qg_vec *v, qg_comm *c, void *out_dev, void *stream);
+/* The same, double buffered and overlapped with what `stream` does next: submit snapshots the shard on `stream` (the pack
+ * launches) and hands the PREVIOUS snapshot to ncclAllGather on the communicator's own stream; flush hands over the last one.  The
+ * hand-over goes through the host (wait for the snapshot's event, then enqueue the collective), not through a stream-to-stream
+ * event wait, which on ROCm 7 / MI355X slows every later hipGraph replay on the stepping stream by ~40 % (tools/gather_probe.py);
+ * the host therefore runs at most one snapshot ahead of the device.  latest waits for the most recently handed-over collective
+ * and returns its buffer (owned by the communicator, valid until two more submits), or NULL in *gathered_dev when none exists. */
+int qg_comm_gather_submit(qg_comm *c, qg_vec *v, void *stream);
+int qg_comm_gather_flush(qg_comm *c);
+int qg_comm_gather_latest(qg_comm *c, const void **gathered_dev);
+
+/* Direct write.  Set-up, once per communicator: every rank allocates its window (header + 2 parities x world x shard_bytes of
+ * uncached device memory), the hipIpc handles are exchanged, every rank maps the others' windows.  qg_comm_p2p_connect does all
+ * three over the communicator's RCCL (collective); without RCCL the host calls qg_comm_p2p_export on every rank, moves the
+ * QG_P2P_HANDLE_BYTES to every other rank itself (rank order) and calls qg_comm_p2p_open (a rank never opens its own handle). */
+int qg_comm_p2p_connect(qg_comm *c, uint64_t shard_bytes);
+int qg_comm_p2p_export(qg_comm *c, uint64_t shard_bytes, uint8_t handle_out[QG_P2P_HANDLE_BYTES]);
+int qg_comm_p2p_open(qg_comm *c, const uint8_t *handles /* [world][QG_P2P_HANDLE_BYTES] */);
+/* Epoch k (1, 2, ...; the k-th call on every rank): pack this handle's shard, copy it into slot `rank` of parity k & 1 of every
+ * rank's window (own included) and store k to the per-source arrival flag there; all on `stream`.  Before overwriting a parity
+ * the kernel waits (bounded) for that peer's release of epoch k - 2. */
+int qg_vec_push_learner_shard(qg_vec *v, qg_comm *c, void *stream);
+/* Enqueue on `stream` the wait for every rank's epoch-k arrival in this rank's window (k = the k-th call) and return the
+ * gathered buffer of that epoch (world * shard_bytes, inside the window): work enqueued on `stream` afterwards may read it. */
+int qg_comm_p2p_wait(qg_comm *c, const void **gathered_dev, void *stream);
+/* Enqueue on `stream` the release of the epoch last waited for: its parity may be overwritten by the push of epoch k + 2. */
+int qg_comm_p2p_release(qg_comm *c, void *stream);
+/* Synchronise `stream` and report a peer that did not arrive / release within the deadline (QG_ERR_DEVICE), else QG_OK. */
+int qg_comm_p2p_check(qg_comm *c, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Scalar environment: the `Env` trait method for method (clifford.rs:285-382).
  * Every call synchronises; this flavour exists for API parity, not for speed.
  * ---------------------------------------------------------------------------------------- */

@@ -65,6 +65,15 @@ class QGVecInfo(C.Structure):
     ]
 
 
+class QGShardLayout(C.Structure):
+    _fields_ = [("batch", C.c_uint64), ("bytes", C.c_uint64), ("obs_offset", C.c_uint64), ("obs_bytes", C.c_uint64),
+                ("reward_offset", C.c_uint64), ("final_offset", C.c_uint64), ("success_offset", C.c_uint64)]
+
+
+QG_COMM_ID_BYTES = 128
+QG_P2P_HANDLE_BYTES = 64
+
+
 class QGymError(RuntimeError):
     def __init__(self, status: int, message: str):
         super().__init__(f"libqgym status {status}: {message}")
@@ -84,6 +93,10 @@ EXPORTED_SYMBOLS = [
     "qg_policy_embed_words_packed_bytes", "qg_policy_pack_embed_words", "qg_policy_embed_words",
     "qg_policy_head_packed_bytes", "qg_policy_pack_head", "qg_policy_head_sample",
     "qg_policy_mid_packed_bytes", "qg_policy_pack_mid", "qg_policy_mid_head_sample", "qg_vec_mid_head_sample_step", "qg_vec_mid_head_sample_step_reset",
+    "qg_vec_learner_shard_layout", "qg_vec_pack_learner_shard", "qg_comm_unique_id", "qg_comm_init", "qg_comm_init_local", "qg_comm_destroy",
+    "qg_comm_rank", "qg_comm_world", "qg_vec_gather_learner_shard", "qg_comm_gather_submit", "qg_comm_gather_flush", "qg_comm_gather_latest",
+    "qg_comm_p2p_connect", "qg_comm_p2p_export", "qg_comm_p2p_open", "qg_vec_push_learner_shard", "qg_comm_p2p_wait", "qg_comm_p2p_release",
+    "qg_comm_p2p_check",
     "qg_env_create", "qg_env_clone", "qg_env_set_seed", "qg_env_destroy", "qg_env_num_actions", "qg_env_obs_shape",
     "qg_env_set_difficulty", "qg_env_get_difficulty", "qg_env_set_state", "qg_env_reset", "qg_env_step",
     "qg_env_step_coin", "qg_env_masks", "qg_env_is_final", "qg_env_reward", "qg_env_success", "qg_env_observe",
@@ -175,6 +188,26 @@ def load():
     L.qg_vec_mid_head_sample_step.argtypes = [vp, vp, u64, C.c_uint32, vp, C.c_uint32, vp, u64, u64, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.qg_vec_mid_head_sample_step_reset.argtypes = [vp, vp, u64, C.c_uint32, vp, C.c_uint32, vp, u64, u64, vp, C.c_int, vp, vp, vp, vp, vp, u64, vp]
     L.qg_policy_head_sample.argtypes = [vp, u64, u64, C.c_uint32, vp, C.c_uint32, u64, u64, vp, vp, C.c_int, vp, vp, vp, vp]
+    L.qg_vec_learner_shard_layout.argtypes = [vp, C.POINTER(QGShardLayout)]
+    L.qg_vec_pack_learner_shard.argtypes = [vp, vp, vp]
+    L.qg_comm_unique_id.argtypes = [vp]
+    L.qg_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.qg_comm_init_local.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.qg_comm_destroy.argtypes = [vp]
+    L.qg_comm_destroy.restype = None
+    L.qg_comm_rank.argtypes = [vp]
+    L.qg_comm_world.argtypes = [vp]
+    L.qg_vec_gather_learner_shard.argtypes = [vp, vp, vp, vp]
+    L.qg_comm_gather_submit.argtypes = [vp, vp, vp]
+    L.qg_comm_gather_flush.argtypes = [vp]
+    L.qg_comm_gather_latest.argtypes = [vp, C.POINTER(vp)]
+    L.qg_comm_p2p_connect.argtypes = [vp, u64]
+    L.qg_comm_p2p_export.argtypes = [vp, u64, vp]
+    L.qg_comm_p2p_open.argtypes = [vp, vp]
+    L.qg_vec_push_learner_shard.argtypes = [vp, vp, vp]
+    L.qg_comm_p2p_wait.argtypes = [vp, C.POINTER(vp), vp]
+    L.qg_comm_p2p_release.argtypes = [vp, vp]
+    L.qg_comm_p2p_check.argtypes = [vp, vp]
     L.qg_env_create.argtypes = [C.POINTER(QGConfig), C.POINTER(QGGate), sz, C.c_int, C.POINTER(vp)]
     L.qg_env_clone.argtypes = [vp, C.POINTER(vp)]
     L.qg_env_destroy.argtypes = [vp]

@@ -45,8 +45,9 @@ def all_gather_observation(local: torch.Tensor, out: Optional[torch.Tensor] = No
 
 def learner_shard_words(batch: int, obs_words: int) -> int:
     """int32 words of one rank's hand-over shard: packed observation [batch, obs_words], f32 rewards [batch], `is_final` and
-    `success` bytes [batch] each (SURVEY.md 8e's three gathers as one flat buffer, every section 4-byte aligned)."""
-    return batch * obs_words + batch + 2 * ((batch + 3) // 4)
+    `success` bytes [batch] each (SURVEY.md 8e's three gathers as one flat buffer, every section 4-byte aligned, the whole
+    shard padded to 16 bytes) -- `qg_shard_layout` of include/qgym.h for 32-bit observation words."""
+    return (batch * obs_words + batch + 2 * ((batch + 3) // 4) + 3) // 4 * 4
 
 
 def fill_learner_shard(buf: torch.Tensor, batch: int, obs_words: int, write_obs: Callable[[torch.Tensor], None], reward: torch.Tensor,
@@ -135,6 +136,145 @@ class OverlappedGather:
         if self.cuda:
             self.done[b].synchronize()
         return self.out[b]
+
+
+class _DeviceBytes:
+    """A device range owned by libqgym as a `__cuda_array_interface__` object (torch.as_tensor makes a view, no copy)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def split_gathered(gathered: torch.Tensor, layout, world: int, word_bytes: int = 4):
+    """`world` consecutive shards (uint8, `world * layout.bytes`) -> (obs [world*batch, words] of `word_bytes`-byte integers,
+    reward [world*batch] f32, is_final, success [world*batch] uint8), rank order = env order.  `layout`: VecEnv.shard_layout()."""
+    B = int(layout.batch)
+    g = gathered.view(torch.uint8).view(world, int(layout.bytes))
+    dt = {1: torch.uint8, 4: torch.int32, 8: torch.int64}[word_bytes]
+    obs = g[:, : int(layout.obs_bytes)].contiguous().view(dt).view(world * B, -1)
+    ro, fo, so = int(layout.reward_offset), int(layout.final_offset), int(layout.success_offset)
+    reward = g[:, ro : ro + 4 * B].contiguous().view(torch.float32).reshape(-1)
+    return obs, reward, g[:, fo : fo + B].reshape(-1), g[:, so : so + B].reshape(-1)
+
+
+class Communicator:
+    """`qg_comm` of include/qgym.h: the multi-GPU hand-over below Python -- RCCL's all-gather called from libqgym, or the
+    direct write into every peer's window over xGMI.  One per rank (process or thread), on the rank's GPU.
+
+    `unique_id`: the 128 bytes rank 0 got from `Communicator.unique_id()`, moved to every rank by the host's own control channel
+    (a file, a socket, a `torch.distributed` broadcast on gloo); `None` with `local=True` builds a communicator without RCCL, for
+    the direct-write transport with handles exchanged by the host."""
+
+    def __init__(self, rank: int, world: int, device: Optional[int] = None, unique_id: Optional[bytes] = None, local: bool = False):
+        import ctypes as C
+
+        from . import _lib
+
+        self._lib, self._C = _lib, C
+        self._L = _lib.load()
+        self.rank, self.world = int(rank), int(world)
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        h = C.c_void_p()
+        if local:
+            _lib.check(self._L.qg_comm_init_local(self.rank, self.world, self.device_index, C.byref(h)))
+        else:
+            if unique_id is None or len(unique_id) != _lib.QG_COMM_ID_BYTES:
+                raise ValueError("Communicator: pass the 128-byte id of Communicator.unique_id() (made on rank 0), or local=True")
+            buf = (C.c_uint8 * _lib.QG_COMM_ID_BYTES).from_buffer_copy(unique_id)
+            _lib.check(self._L.qg_comm_init(buf, self.rank, self.world, self.device_index, C.byref(h)))
+        self._h = h
+        self.shard_bytes = 0
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+
+        from . import _lib
+
+        buf = (C.c_uint8 * _lib.QG_COMM_ID_BYTES)()
+        _lib.check(_lib.load().qg_comm_unique_id(buf))
+        return bytes(buf)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.qg_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _view(self, ptr, nbytes: int) -> torch.Tensor:
+        return torch.as_tensor(_DeviceBytes(ptr, nbytes), device=self.device)
+
+    # ---- RCCL ---------------------------------------------------------------------------------------------------
+    def gather(self, env, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Pack `env`'s shard and ncclAllGather it on the current stream -> uint8 [world * shard bytes]."""
+        n = int(env.shard_layout().bytes) * self.world
+        if out is None:
+            out = torch.empty(n, dtype=torch.uint8, device=self.device)
+        if out.device != self.device or out.numel() * out.element_size() != n or not out.is_contiguous():
+            raise ValueError(f"gather: `out` must be a contiguous buffer of {n} bytes on the communicator's device")
+        self._lib.check(self._L.qg_vec_gather_learner_shard(env._h, self._h, out.data_ptr(), self._stream()))
+        return out
+
+    def submit(self, env):
+        """Snapshot `env`'s shard on the current stream; the previous snapshot goes to the all-gather on the side stream."""
+        self.shard_bytes = int(env.shard_layout().bytes)
+        self._lib.check(self._L.qg_comm_gather_submit(self._h, env._h, self._stream()))
+
+    def flush(self):
+        self._lib.check(self._L.qg_comm_gather_flush(self._h))
+
+    def latest(self) -> Optional[torch.Tensor]:
+        """The most recently gathered buffer (waits for its collective), or None.  A view into the communicator's memory."""
+        p = self._C.c_void_p()
+        self._lib.check(self._L.qg_comm_gather_latest(self._h, self._C.byref(p)))
+        return self._view(p.value, self.shard_bytes * self.world) if p.value else None
+
+    # ---- direct write -------------------------------------------------------------------------------------------
+    def p2p_connect(self, shard_bytes: int):
+        """Allocate the window, exchange the hipIpc handles over the communicator's RCCL, map the peers' windows (collective)."""
+        self.shard_bytes = int(shard_bytes)
+        self._lib.check(self._L.qg_comm_p2p_connect(self._h, self.shard_bytes))
+
+    def p2p_export(self, shard_bytes: int) -> bytes:
+        self.shard_bytes = int(shard_bytes)
+        buf = (self._C.c_uint8 * self._lib.QG_P2P_HANDLE_BYTES)()
+        self._lib.check(self._L.qg_comm_p2p_export(self._h, self.shard_bytes, buf))
+        return bytes(buf)
+
+    def p2p_open(self, handles):
+        """handles: the `world` exported handles in rank order (this rank's own entry is not opened)."""
+        blob = b"".join(handles)
+        if len(blob) != self.world * self._lib.QG_P2P_HANDLE_BYTES:
+            raise ValueError("p2p_open: one 64-byte handle per rank")
+        buf = (self._C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        self._lib.check(self._L.qg_comm_p2p_open(self._h, buf))
+
+    def push(self, env):
+        """Pack `env`'s shard and write it into every rank's window, then raise this rank's arrival flag there (current stream)."""
+        self._lib.check(self._L.qg_vec_push_learner_shard(env._h, self._h, self._stream()))
+
+    def wait(self) -> torch.Tensor:
+        """Enqueue the wait for every rank's shard of the next epoch; returns the gathered view (valid for work enqueued after this
+        call on the current stream, until `release`)."""
+        p = self._C.c_void_p()
+        self._lib.check(self._L.qg_comm_p2p_wait(self._h, self._C.byref(p), self._stream()))
+        return self._view(p.value, self.shard_bytes * self.world)
+
+    def release(self):
+        self._lib.check(self._L.qg_comm_p2p_release(self._h, self._stream()))
+
+    def check(self):
+        """Synchronise the current stream and raise if a peer missed a deadline."""
+        self._lib.check(self._L.qg_comm_p2p_check(self._h, self._stream()))
 
 
 def unpack_rows_u32(packed: torch.Tensor, dim: int) -> torch.Tensor:

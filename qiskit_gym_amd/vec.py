@@ -262,6 +262,22 @@ class VecEnv:
         _lib.check(self._L.qg_vec_observe_packed(self._h, out.data_ptr(), self._stream()))
         return out
 
+    def shard_layout(self) -> "_lib.QGShardLayout":
+        """Byte layout of this batch's learner shard: packed observation, f32 rewards, is_final and success bytes (qg_shard_layout)."""
+        lay = _lib.QGShardLayout()
+        _lib.check(self._L.qg_vec_learner_shard_layout(self._h, C.byref(lay)))
+        return lay
+
+    def pack_learner_shard(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """What the learner reads from every env after a step, as one flat uint8 buffer (`shard_layout()`)."""
+        lay = self.shard_layout()
+        if out is None:
+            out = torch.empty(lay.bytes, dtype=torch.uint8, device=self.device)
+        if out.device != self.device or out.numel() * out.element_size() != lay.bytes or not out.is_contiguous():
+            raise ValueError(f"pack_learner_shard: `out` must be a contiguous buffer of {lay.bytes} bytes on the env's device")
+        _lib.check(self._L.qg_vec_pack_learner_shard(self._h, out.data_ptr(), self._stream()))
+        return out
+
     def masks(self) -> torch.Tensor:
         out = torch.empty((self.batch, self.num_actions_), dtype=torch.uint8, device=self.device)
         _lib.check(self._L.qg_vec_masks(self._h, out.data_ptr(), self._stream()))
