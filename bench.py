@@ -254,9 +254,10 @@ def free_port() -> int:
 
 
 def launch_ranks(n: int, argv) -> int:
-    """Start n ranks of this script under torch.distributed.run as a child process and relay rank 0's JSON line.  Runs before this
-    process has made any HIP / torch.cuda call other than counting devices (a process that has touched the GPU must not be re-exec'd)."""
-    visible = torch.cuda.device_count()  # counting does not initialise the GPU
+    """Start n ranks of this script under torch.distributed.run as a CHILD process (subprocess.run) and relay rank 0's JSON line.  This
+    parent may already have touched the HIP runtime -- counting devices can initialise it -- which is exactly why the ranks are a fresh child
+    and never an exec of this process (a process that has touched the GPU must not be replaced by another program)."""
+    visible = torch.cuda.device_count()
     if visible < n:
         print(f"bench.py: --gpus {n} requested but only {visible} GPU(s) are visible; refusing to run fewer ranks and report them as {n}",
               file=sys.stderr)

@@ -130,7 +130,9 @@ typedef struct {
 
 #define QG_FAULT_SINGULAR 1u     /* inverse of a singular matrix requested (clifford.rs:155 panic) */
 #define QG_FAULT_ZERO_WEIGHT 2u  /* weight-0 rotation in the front layer (pauli_network.rs:114 unwrap) */
-#define QG_FAULT_BAD_STATE 4u    /* set_state produced an unusable state (e.g. non-permutation) */
+#define QG_FAULT_BAD_STATE 4u    /* set_state produced an unusable state: an out-of-range PermutationEnv entry (the reference indexes out
+                                    of bounds, permutation.rs:241-243), or -- with add_inverts only -- a repeated entry, which has no inverse;
+                                    without add_inverts a vector with repeated entries runs as in the reference (permutation.rs:168-173) */
 #define QG_FAULT_SOLUTION_OVERFLOW 8u /* track_solution: more entries than an episode can produce were logged (the
                                     log holds the max_depth steps an episode can last -- PauliEnv: plus one entry per
                                     rotation; the reference's Vec grows without bound when a caller keeps stepping a
@@ -208,6 +210,14 @@ int qg_vec_reset_with(qg_vec *v, const int32_t *actions_dev, size_t n_draws, voi
  * Results land in the resident reward/done/success/depth buffers (qg_vec_info). */
 int qg_vec_step(qg_vec *v, const void *actions_dev, int action_dtype, const uint8_t *coins_dev, void *stream);
 
+/* The same step with HOST buffers (batched flavour, host-pointer variant): actions_host[B] (and coins_host[B] or NULL) are
+ * copied to the device, the step runs, and reward / is_final / success are copied back into rewards_host f32[B], dones_host u8[B],
+ * success_host u8[B] (each may be NULL) -- all enqueued on `stream` with hipMemcpyAsync, nothing synchronises: with pinned buffers
+ * (hipHostMalloc / hipHostRegister) the call returns at once and the outputs are valid after qg_vec_sync(v, stream); pageable buffers
+ * work too (the runtime then stages the copies).  The input buffers must stay untouched until the stream has passed the call. */
+int qg_vec_step_host(qg_vec *v, const void *actions_host, int action_dtype, const uint8_t *coins_host, float *rewards_host, uint8_t *dones_host,
+                     uint8_t *success_host, void *stream);
+
 /* T consecutive steps.  actions_dev[t*B + e]; optional per-step outputs rewards_dev[t*B + e],
  * dones_dev[t*B + e] (NULL = only the final values in the resident buffers).
  *   fused == 0: T single-step launches replayed from a cached hipGraph (same results and same
@@ -230,6 +240,11 @@ int qg_vec_observe_dense(qg_vec *v, int8_t *out_dev, void *stream);
  * at most 64 observation columns): one 64-bit word per row of the [2N, 2N + max_rotations] observation; the call counts
  * as one Env::observe, i.e. it draws the add_perms permutation like qg_vec_observe_dense does. */
 int qg_vec_observe_packed(qg_vec *v, void *out_dev, void *stream);
+/* Host-pointer variants of the two calls above: the observation is written to a buffer of the handle and copied to out_host on `stream`
+ * (hipMemcpyAsync; valid after qg_vec_sync(v, stream), pinned memory for a truly asynchronous copy).  Sizes: B * obs_rows * obs_cols bytes,
+ * resp. B * packed_words_per_env * packed_word_bytes. */
+int qg_vec_observe_dense_host(qg_vec *v, int8_t *out_host, void *stream);
+int qg_vec_observe_packed_host(qg_vec *v, void *out_host, void *stream);
 /* Env::masks (clifford.rs:349-351): out_dev[e*num_actions + a] = !success[e] */
 int qg_vec_masks(qg_vec *v, uint8_t *out_dev, void *stream);
 

@@ -13,15 +13,17 @@ __device__ inline int64_t load_action(const void *actions, uint64_t idx, bool ac
 }
 
 // compact_done's job done by the kernel that finishes the envs: the wave's finished envs go to the list with one atomic per wave
-// (call from every lane still alive; `fin` on one lane per env)
-__device__ inline void done_list_append(uint32_t *list, uint32_t *count, bool fin, uint64_t env) {
+// (call from every lane still alive; `fin` on one lane per env).  The length must be zero when the kernel starts (qgym_api.cpp keeps it
+// so); an entry that would land past the list's `cap` = B slots is dropped rather than written.
+__device__ inline void done_list_append(uint32_t *list, uint32_t *count, bool fin, uint64_t env, uint64_t cap) {
     const uint64_t m = __ballot(fin);
     if (!m) return;
     const uint32_t lane = __lane_id(), first = (uint32_t)__ffsll((long long)m) - 1u;
     uint32_t base = 0;
     if (lane == first) base = atomicAdd(count, (uint32_t)__popcll(m));
     base = __shfl(base, first);
-    if (fin) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)env;
+    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (fin && slot < cap) list[slot] = (uint32_t)env;
 }
 
 #define QG_COOP_LANES 16  // lanes per env of the cooperative scramble (scramble_coop below)

@@ -136,8 +136,10 @@ __global__ __launch_bounds__(256) void compact_done_kernel(const uint8_t *done, 
     base = __shfl(base, __ffsll((long long)m) - 1);
     if (d) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)env;
 }
-// `count` must be zero on entry: the last kernel that consumes the list zeroes it again (list_count_take)
+// The length (and the reader ticket behind it) is zeroed right here, on the stream, whatever ran before: the host's idea of it is
+// stale as soon as a caller replays a graph that touches the list.  The last kernel that consumes the list zeroes it again (list_count_take).
 hipError_t compact_done(const uint8_t *done, uint64_t B, uint32_t *list, uint32_t *count, hipStream_t s) {
+    if (hipError_t e = hipMemsetAsync(count, 0, 2 * sizeof(uint32_t), s)) return e;
     hipLaunchKernelGGL(compact_done_kernel, dim3(blocks_for(B, 256)), dim3(256), 0, s, done, B, list, count);
     return hipGetLastError();
 }

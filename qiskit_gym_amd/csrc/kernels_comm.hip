@@ -26,6 +26,11 @@ __global__ __launch_bounds__(256) void shard_scalars_kernel(const float *__restr
                                                            const uint8_t *__restrict__ success, uint8_t *__restrict__ shard, ShardLayout lay) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= lay.batch) return;
+    if (e == 0) {  // the (at most 3 + 3 + 15) padding bytes are zero: a shard is a function of the env state, byte for byte
+        for (uint64_t i = lay.obs_bytes; i < lay.reward_offset; ++i) shard[i] = 0;
+        for (uint64_t i = lay.final_offset + lay.batch; i < lay.success_offset; ++i) shard[i] = 0;
+        for (uint64_t i = lay.success_offset + lay.batch; i < lay.bytes; ++i) shard[i] = 0;
+    }
     ((float *)(shard + lay.reward_offset))[e] = reward[e];
     shard[lay.final_offset + e] = done[e];
     shard[lay.success_offset + e] = success[e];

@@ -231,7 +231,10 @@ __global__ __launch_bounds__(256) void permb_init_kernel(InitArgs a, uint32_t ng
             }
         }
     }
-    if (a.mode == 1) {  // a state that is not a permutation (an entry twice) has no inverse and breaks the fixed-point count: flag it
+    // permutation.rs:168-173 stores the vector unvalidated, and step / observe / solved work on any vector of in-range entries (the count
+    // of non-fixed points is kept per swapped position).  Only inversion needs a permutation -- a repeated entry has no inverse and the
+    // count is no longer that of the inverse -- so such a state is a fault only with add_inverts (same rule in kernels_small.hip)
+    if (a.mode == 1 && a.inverts) {
         for (uint32_t i = 0; i < a.N && !(fault & QG_FAULT_BAD_STATE); ++i) {
             const uint32_t v = lds_get_byte(img, lanes, l, i);
             for (uint32_t j = i + 1; j < a.N; ++j)

@@ -477,6 +477,7 @@ struct HeadArgs {
     const uint64_t *clock;
     uint64_t ld_h;         // elements per row of h
     uint64_t B, seed, counter;
+    uint64_t env_base;     // global index of env 0 in the draw (the stepped handle's qg_vec_set_env_base; 0 without a handle)
     uint32_t K, A;
     int32_t act64;
 };
@@ -526,7 +527,7 @@ __device__ __forceinline__ int64_t head_draw(f32x16 (&acc)[TILES], const HeadArg
 #pragma unroll
         for (uint32_t q = 0; q < 16; ++q) m = fmaxf(m, acc[t][q]);
     m = fmaxf(m, head_xhalf(m));
-    const uint64_t base = rng_draw(a.seed, env, a.counter + clock_of(a.clock));
+    const uint64_t base = rng_draw(a.seed, a.env_base + env, a.counter + clock_of(a.clock));
     const uint32_t blo = (uint32_t)base, xb = (uint32_t)(base >> 32) + 4u * h * 0x9E3779B9u;  // hash input of this lane half's action 0
     float best_q = INF, best_d = 0.0f, ssum = 0.0f, wsum = 0.0f;
     uint32_t best_a = 0xFFFFFFFFu;
@@ -779,7 +780,8 @@ __global__ __launch_bounds__(64 * MH_WAVES, 2) void mid_head_sample_kernel(MidHe
                 uint32_t base = 0;
                 if (lane == first) base = atomicAdd(ma.done_count, (uint32_t)__popcll(m));
                 base = __shfl(base, first);
-                if (fin) ma.done_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)env;
+                const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (fin && slot < ma.step.B) ma.done_list[slot] = (uint32_t)env;
             }
         }
     }
@@ -939,7 +941,7 @@ __global__ __launch_bounds__(64 * MHS_WAVES, 1) void mid_head_small_kernel(MidHe
     if (h == 0) xmax[wave][c] = m;
     __syncthreads();
     m = fmaxf(fmaxf(xmax[0][c], xmax[1][c]), fmaxf(xmax[2][c], xmax[3][c]));
-    const uint64_t base = rng_draw(a.seed, env, a.counter + clock_of(a.clock));
+    const uint64_t base = rng_draw(a.seed, a.env_base + env, a.counter + clock_of(a.clock));
     const uint32_t blo = (uint32_t)base, bhi = (uint32_t)(base >> 32);
     DrawLane r;
     if (any) {
@@ -1061,7 +1063,8 @@ __global__ __launch_bounds__(64 * MHS_WAVES, 1) void mid_head_small_kernel(MidHe
             uint32_t basei = 0;
             if (lane == first) basei = atomicAdd(ma.done_count, (uint32_t)__popcll(mk));
             basei = __shfl(basei, first);
-            if (fin) ma.done_list[basei + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = (uint32_t)renv;
+            const uint32_t slot = basei + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+            if (fin && slot < ma.step.B) ma.done_list[slot] = (uint32_t)renv;
         }
     }
 }
@@ -1638,6 +1641,7 @@ int qg_policy_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, uint
     a.K = in_features;
     a.A = num_actions;
     a.act64 = action_dtype == QG_ACT_I64;
+    a.env_base = 0;
     const uint32_t tiles = (num_actions + 1u + 31u) / 32u;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
@@ -1667,7 +1671,7 @@ static bool mid_head_is_small(uint64_t batch, uint32_t in_features, int cus) {
 static int mid_head_impl(const void *h_dev, uint64_t ld_h, uint64_t batch, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
                          const void *packed_head_dev, uint32_t num_actions, uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev,
                          int action_dtype, float *logp_dev, float *entropy_dev, float *values_dev, qg_vec *step_of, float *step_rewards,
-                         uint8_t *step_dones, const uint64_t *reset_seed, void *stream) {
+                         uint8_t *step_dones, const uint64_t *reset_seed, uint64_t env_base, void *stream) {
     if (!h_dev || !packed_mid_dev || !packed_head_dev || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
     if (qg_policy_head_packed_bytes(num_actions, mid_features) == 0 || qg_policy_mid_packed_bytes(in_features, mid_features) == 0)
         return set_error(QG_ERR_UNSUPPORTED, "fused middle layer + head: 256 middle features, in_features a multiple of 32, num_actions <= 222");
@@ -1691,6 +1695,7 @@ static int mid_head_impl(const void *h_dev, uint64_t ld_h, uint64_t batch, uint3
     a.K = mid_features;
     a.A = num_actions;
     a.act64 = action_dtype == QG_ACT_I64;
+    a.env_base = env_base;  // a shard draws what its envs would draw in the unsharded batch (qg_vec_set_env_base of the stepped handle)
     m.w2p = reinterpret_cast<const uint4 *>(packed_mid_dev);
     m.K1 = in_features;
     if (step_of) {  // Env::step with the drawn action in the same launch
@@ -1719,10 +1724,11 @@ static int mid_head_impl(const void *h_dev, uint64_t ld_h, uint64_t batch, uint3
     const bool small = mid_head_is_small(batch, in_features, cus);
     // the finished envs' indices are appended to the handle's list, unless the small kernel resets them itself
     const bool reset_in_kernel = small && step_of && reset_seed;
+    bool trusted = false;
+    if (step_of) trusted = done_list_session(step_of, s);
     if (reset_in_kernel) fill_reset_done_args_public(step_of, *reset_seed, m.reset);
-    else if (step_of && step_of->done_list_fresh)  // a list nobody consumed (no qg_vec_reset_done since the last fused step): start it again
-        HIP_TRY(hipMemsetAsync(step_of->done_list + step_of->B, 0, 2 * sizeof(uint32_t), s));
-    if (step_of) step_of->done_list_fresh = !reset_in_kernel;
+    else if (step_of)  // the kernel appends the envs it finishes: the list's length is zero when it starts
+        if (int rc = done_list_before_append(step_of, s)) return rc;
     if (small) {
         const dim3 grid((unsigned)env_tiles), block(64 * MHS_WAVES);
 #define QG_MHS_CASE(TT)                                                        \
@@ -1733,6 +1739,7 @@ static int mid_head_impl(const void *h_dev, uint64_t ld_h, uint64_t batch, uint3
         }
 #undef QG_MHS_CASE
         HIP_TRY(hipGetLastError());
+        if (step_of && !reset_in_kernel) done_list_appended(step_of, trusted);
         return QG_OK;
     }
     const uint64_t resident = 2ull * (uint64_t)cus;  // two workgroups per CU (32 KiB of LDS and 256 registers x 4 waves each)
@@ -1745,6 +1752,7 @@ static int mid_head_impl(const void *h_dev, uint64_t ld_h, uint64_t batch, uint3
     }
 #undef QG_MH_CASE
     HIP_TRY(hipGetLastError());
+    if (step_of) done_list_appended(step_of, trusted);
     return QG_OK;
 }
 
@@ -1752,7 +1760,7 @@ int qg_policy_mid_head_sample(const void *h_dev, uint64_t ld_h, uint64_t batch, 
                               const void *packed_head_dev, uint32_t num_actions, uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev,
                               int action_dtype, float *logp_dev, float *entropy_dev, float *values_dev, void *stream) {
     return mid_head_impl(h_dev, ld_h, batch, in_features, packed_mid_dev, mid_features, packed_head_dev, num_actions, seed, counter, clock_dev, actions_dev,
-                         action_dtype, logp_dev, entropy_dev, values_dev, nullptr, nullptr, nullptr, nullptr, stream);
+                         action_dtype, logp_dev, entropy_dev, values_dev, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
 static int mid_head_step_impl(qg_vec *v, const void *h_dev, uint64_t ld_h, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
@@ -1771,17 +1779,17 @@ static int mid_head_step_impl(qg_vec *v, const void *h_dev, uint64_t ld_h, uint3
     // own lanes (qm_inv2_body) when every env is symplectic; otherwise the sampling kernel and the env's own step launch
     if (inverts && !(mid_head_is_small(v->B, in_features, cus) && v->has_z && !v->maybe_nonsymplectic)) {
         int rc = mid_head_impl(h_dev, ld_h, v->B, in_features, packed_mid_dev, mid_features, packed_head_dev, (uint32_t)v->gates.size(), seed, counter,
-                               v->clock_dev, actions_dev, action_dtype, logp_dev, entropy_dev, values_dev, nullptr, nullptr, nullptr, nullptr, stream);
+                               v->clock_dev, actions_dev, action_dtype, logp_dev, entropy_dev, values_dev, nullptr, nullptr, nullptr, nullptr, v->env_base, stream);
         if (rc == QG_OK) rc = qg_vec_rollout(v, actions_dev, action_dtype, 1, nullptr, rewards_dev, dones_dev, 0, stream);
         if (rc == QG_OK && reset_seed) rc = qg_vec_reset_done(v, *reset_seed, stream);
         return rc;
     }
     const int rc = mid_head_impl(h_dev, ld_h, v->B, in_features, packed_mid_dev, mid_features, packed_head_dev, (uint32_t)v->gates.size(), seed, counter,
-                                 v->clock_dev, actions_dev, action_dtype, logp_dev, entropy_dev, values_dev, v, rewards_dev, dones_dev, reset_seed, stream);
+                                 v->clock_dev, actions_dev, action_dtype, logp_dev, entropy_dev, values_dev, v, rewards_dev, dones_dev, reset_seed, v->env_base, stream);
     if (rc != QG_OK) return rc;
     v->step_index += 1;
     // larger batches: the kernel left the list of finished envs, the reset is its own launch
-    if (reset_seed && v->done_list_fresh) return qg_vec_reset_done(v, *reset_seed, stream);
+    if (reset_seed && !mid_head_is_small(v->B, in_features, cus)) return qg_vec_reset_done(v, *reset_seed, stream);
     return QG_OK;
 }
 

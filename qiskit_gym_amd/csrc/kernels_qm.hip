@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void qm_inv2_kernel(StepArgs a) {
     QG_PREFETCH_STEP_ARGS(a);
     if ((tid >> 1) >= a.B) return;  // whole lane pairs leave together
     const bool fin = qm_inv2_body<NXP / 2, FEAT>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr);  // qm_step1.hpp
-    if constexpr (LIST) done_list_append(a.done_list, a.done_count, fin && !(tid & 1u), tid >> 1);
+    if constexpr (LIST) done_list_append(a.done_list, a.done_count, fin && !(tid & 1u), tid >> 1, a.B);
     else (void)fin;
 }
 
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void qm_step1_kernel(StepArgs a) {
     if (env >= a.B) return;
     const int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
     const bool fin = qm_step1_body<HAS_Z, FEAT>(a, Rows::G, env, act);  // qm_step1.hpp
-    if constexpr (LIST) done_list_append(a.done_list, a.done_count, fin, env);
+    if constexpr (LIST) done_list_append(a.done_list, a.done_count, fin, env, a.B);
     else (void)fin;
 }
 

@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256) void q64_inv2_kernel(StepArgs a) {
         if (fault) atomicOr(&a.error[env], fault);
         if (a.bad) reinterpret_cast<uint64_t *>(a.bad)[env] = (uint64_t)bad;  // the one-step kernel may run next
     }
-    if (a.flags & F_DONE_LIST) done_list_append(a.done_list, a.done_count, h == 0 && (depth == 0 || solved), env);
+    if (a.flags & F_DONE_LIST) done_list_append(a.done_list, a.done_count, h == 0 && (depth == 0 || solved), env, a.B);
 }
 
 // One step per launch without holding the matrix (see qm_step1_kernel in kernels_qm.hip): the gate's
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void q64_step1_kernel(StepArgs a) {
     a.success[env] = (uint8_t)solved;
     if (FEAT && (a.flags & F_TRACK)) a.sol_len[env * 2] = sol_n;
     if (FEAT && fault) atomicOr(&a.error[env], fault);
-    if constexpr (LIST) done_list_append(a.done_list, a.done_count, depth == 0 || solved, env);  // qg_vec_reset_done follows (qgym_api.cpp)
+    if constexpr (LIST) done_list_append(a.done_list, a.done_count, depth == 0 || solved, env, a.B);  // qg_vec_reset_done follows (qgym_api.cpp)
 }
 
 // the tail of set_state / reset for one env: rows to the tile, reset_internals (clifford.rs:272-283)

@@ -158,6 +158,14 @@ __global__ __launch_bounds__(256) void word_init_kernel(InitArgs a) {
                 if (v < 0 || v >= (int64_t)a.N) { fault |= QG_FAULT_BAD_STATE; v = 0; }
                 s |= (uint64_t)v << (4 * i);
             }
+            if (a.inverts) {  // a repeated entry has no inverse (perm_invert): a fault with add_inverts only, like kernels_perm.hip
+                uint32_t seen = 0;
+                for (uint32_t i = 0; i < a.N; ++i) {
+                    const uint32_t bit = 1u << ((s >> (4 * i)) & 0xFull);
+                    if (seen & bit) fault |= QG_FAULT_BAD_STATE;
+                    seen |= bit;
+                }
+            }
         } else {  // linear_function.rs:279-283
             for (uint32_t r = 0; r < a.N; ++r) {
                 uint64_t w = 0;

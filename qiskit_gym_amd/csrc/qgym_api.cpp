@@ -223,7 +223,7 @@ static int vec_free_buffers(qg_vec *v) {
     void *ptrs[] = {v->state, v->own_depth ? v->depth : nullptr, v->own_reward ? v->reward : nullptr,
                     v->own_done ? v->done : nullptr, v->own_success ? v->success : nullptr, v->inverted, v->error, v->sol,
                     v->sol_len, v->layers, v->d_gates, v->d_descs, v->scratch, v->d_prog,
-                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad, v->done_list, v->d_rowops, v->embed_dump};
+                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad, v->done_list, v->d_rowops, v->embed_dump, v->host_in, v->host_obs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &g : v->graphs) {
@@ -237,12 +237,56 @@ static int vec_free_buffers(qg_vec *v) {
 
 static int ensure_scratch(qg_vec *v, size_t bytes) { return qg::ensure_scratch_public(v, bytes); }
 
-// The list of finished envs that qg_vec_mid_head_sample_step leaves for qg_vec_reset_done describes the `done` flags of that step only:
-// anything else that changes the flags first drops it (and re-zeroes its counter, which only the list's consumer would have done).
+}  // extern "C"
+namespace qg {
+// ---- the list of finished envs (done_list: [B] indices, then {length, reader ticket}) --------------------------------------------
+// Device-side facts: a LIST step kernel (and the sampling + step kernels) APPENDS to the list, so the length must be zero when it
+// starts; the reset kernel that consumes a list zeroes the length again (list_count_take); compact_done zeroes it itself.  What the
+// host knows about the length is exact only for launches it has enqueued eagerly, in order: anything captured into a caller's graph
+// runs later, any number of times, between whatever else the caller enqueues.  So the host's belief (done_list_fresh, list_zero_known)
+// is scoped to a SESSION -- one stream capture (its capture id), or eager execution on a handle none of whose list launches were
+// ever captured:
+//   * a new session starts with nothing known: its first appending launch is preceded by a memset of the length (captured with it),
+//     its first qg_vec_reset_done compacts the `done` flags itself;
+//   * once anything was captured (list_tainted), eager calls trust nothing: no LIST instantiations, every reset_done compacts;
+//   * inside a session the launches run in the order they were enqueued, so the belief is exact there.
+// Appends are clamped to the list's B entries on the device as well (done_list_append), so a misuse cannot write past the allocation.
+bool done_list_session(qg_vec *v, hipStream_t s) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    if (s) (void)hipStreamGetCaptureInfo(s, &cs, &id);
+    const uint64_t cur = cs == hipStreamCaptureStatusNone ? 0ull : (id ? (uint64_t)id : ~0ull);
+    if (cur != v->list_session) {
+        v->list_session = cur;
+        v->done_list_fresh = false;
+        v->list_zero_known = false;
+        if (cur) v->list_tainted = true;
+    }
+    return cur != 0 || !v->list_tainted;
+}
+
+// before a launch that appends: the length is zero when it runs
+int done_list_before_append(qg_vec *v, hipStream_t s) {
+    if (!v->list_zero_known || v->done_list_fresh) HIP_TRY(hipMemsetAsync(v->done_list + v->B, 0, 2 * sizeof(uint32_t), s));
+    v->done_list_fresh = false;
+    v->list_zero_known = true;
+    return QG_OK;
+}
+void done_list_appended(qg_vec *v, bool trusted) {
+    v->done_list_fresh = trusted;  // an untrusted list is never consumed: the next reset_done compacts
+    v->list_zero_known = false;
+}
+
+}  // namespace qg
+extern "C" {
+// A list describes the `done` flags of the step that wrote it only: anything else that changes the flags first drops it (and re-zeroes
+// its length, which only the list's consumer would have done).
 static int drop_done_list(qg_vec *v, hipStream_t s) {
+    (void)done_list_session(v, s);
     if (v->done_list_fresh) {
         HIP_TRY(hipMemsetAsync(v->done_list + v->B, 0, 2 * sizeof(uint32_t), s));
         v->done_list_fresh = false;
+        v->list_zero_known = true;
     }
     return QG_OK;
 }
@@ -269,6 +313,7 @@ static void fill_init_args(const qg_vec *v, InitArgs &a) {
     a.env_base = v->env_base;
     a.bad = v->bad;
     a.rowops = v->d_rowops;
+    a.inverts = (v->flags & F_INVERTS) ? 1u : 0u;
     a.check_symplectic = ((v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) && (v->flags & F_INVERTS)) ? 1u : 0u;
 }
 
@@ -723,6 +768,7 @@ int qg_vec_get_state(qg_vec *v, void *out, int format, size_t stride, int on_dev
 
 static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint64_t seed, hipStream_t s, bool only_done = false) {
     QG_ON_DEVICE(v);
+    const bool trusted = done_list_session(v, s);
     if (!only_done)
         if (int rc = drop_done_list(v, s)) return rc;
     if (only_done && v->layout == LAYOUT_PAULI) return ptile_reset_seeded(v, seed, true, s);
@@ -742,8 +788,9 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
     if (only_done && v->done_list) {
         // few, scattered finished envs: pack their indices first so that the scramble runs in full waves
         // instead of in every wave that holds one finished env (the sampling + step kernel has already done it: done_list_fresh)
-        if (!v->done_list_fresh) HIP_TRY(compact_done(v->done, v->B, v->done_list, v->done_list + v->B, s));
+        if (!(trusted && v->done_list_fresh)) HIP_TRY(compact_done(v->done, v->B, v->done_list, v->done_list + v->B, s));
         v->done_list_fresh = false;
+        v->list_zero_known = true;  // the reset kernel is the list's consumer: it zeroes the length (list_count_take)
         v->auto_list = true;
         ia.list = v->done_list;
         ia.list_count = v->done_list + v->B;
@@ -843,17 +890,36 @@ int qg_vec_step(qg_vec *v, const void *actions_dev, int action_dtype, const uint
     if (!v || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
     if (action_dtype != QG_ACT_I32 && action_dtype != QG_ACT_I64) return set_error(QG_ERR_INVALID, "bad action dtype");
     QG_ON_DEVICE(v);
+    const bool trusted = done_list_session(v, (hipStream_t)stream);
     if (v->done_list_fresh) v->auto_list = false;  // the last list was never consumed: this caller steps without qg_vec_reset_done
-    if (int rc = drop_done_list(v, (hipStream_t)stream)) return rc;
     StepArgs a;
     fill_step_args(v, a);
-    const bool lists = step_leaves_done_list(v, a);
+    const bool lists = trusted && step_leaves_done_list(v, a);
+    if (int rc = lists ? done_list_before_append(v, (hipStream_t)stream) : drop_done_list(v, (hipStream_t)stream)) return rc;
     a.actions = actions_dev;
     a.coins = coins_dev;
     if (action_dtype == QG_ACT_I64) a.flags |= F_ACT64;
     HIP_TRY(launch_step(v, a, (hipStream_t)stream));
     v->step_index += 1;
-    if (lists) v->done_list_fresh = true;
+    if (lists) done_list_appended(v, true);
+    return QG_OK;
+}
+
+int qg_vec_step_host(qg_vec *v, const void *actions_host, int action_dtype, const uint8_t *coins_host, float *rewards_host, uint8_t *dones_host,
+                     uint8_t *success_host, void *stream) {
+    if (!v || !actions_host) return set_error(QG_ERR_INVALID, "null argument");
+    if (action_dtype != QG_ACT_I32 && action_dtype != QG_ACT_I64) return set_error(QG_ERR_INVALID, "bad action dtype");
+    QG_ON_DEVICE(v);
+    hipStream_t s = (hipStream_t)stream;
+    if (!v->host_in) HIP_TRY(hipMalloc(&v->host_in, 9 * v->B));
+    const size_t act_bytes = (action_dtype == QG_ACT_I64 ? 8 : 4) * v->B;
+    uint8_t *coins_dev = coins_host ? (uint8_t *)v->host_in + 8 * v->B : nullptr;
+    HIP_TRY(hipMemcpyAsync(v->host_in, actions_host, act_bytes, hipMemcpyHostToDevice, s));
+    if (coins_host) HIP_TRY(hipMemcpyAsync(coins_dev, coins_host, v->B, hipMemcpyHostToDevice, s));
+    if (int rc = qg_vec_step(v, v->host_in, action_dtype, coins_dev, stream)) return rc;
+    if (rewards_host) HIP_TRY(hipMemcpyAsync(rewards_host, v->reward, sizeof(float) * v->B, hipMemcpyDeviceToHost, s));
+    if (dones_host) HIP_TRY(hipMemcpyAsync(dones_host, v->done, v->B, hipMemcpyDeviceToHost, s));
+    if (success_host) HIP_TRY(hipMemcpyAsync(success_host, v->success, v->B, hipMemcpyDeviceToHost, s));
     return QG_OK;
 }
 
@@ -878,11 +944,12 @@ static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, si
     if (T > 0x7fffffffu) return set_error(QG_ERR_INVALID, "too many steps");
     QG_ON_DEVICE(v);
     hipStream_t s = (hipStream_t)stream;
+    const bool trusted = done_list_session(v, s);
     if (v->done_list_fresh) v->auto_list = false;  // the last list was never consumed: this caller steps without qg_vec_reset_done
-    if (int rc = drop_done_list(v, s)) return rc;
     StepArgs a;
     fill_step_args(v, a);
-    const bool lists = T == 1 && !fused && step_leaves_done_list(v, a);
+    const bool lists = trusted && T == 1 && !fused && step_leaves_done_list(v, a);
+    if (int rc = lists ? done_list_before_append(v, s) : drop_done_list(v, s)) return rc;
     a.actions = actions_dev;
     a.coins = coins_dev;
     a.rewards_seq = rewards_dev;
@@ -919,7 +986,7 @@ static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, si
     if (cs != hipStreamCaptureStatusNone || rng_coins || T == 1) {
         HIP_TRY(enqueue_steps(s));
         v->step_index += T;
-        if (lists) v->done_list_fresh = true;
+        if (lists) done_list_appended(v, true);
         return QG_OK;
     }
     GraphKey key{actions_dev, coins_dev, rewards_dev, dones_dev, T, action_dtype, period, a.flags, v->env_base};
@@ -1000,6 +1067,29 @@ int qg_vec_observe_packed(qg_vec *v, void *out_dev, void *stream) {
     HIP_TRY(launch_export(v, oa, (hipStream_t)stream));
     return QG_OK;
 }
+
+static int observe_host(qg_vec *v, void *out_host, bool packed, void *stream) {
+    if (!v || !out_host) return set_error(QG_ERR_INVALID, "null argument");
+    QG_ON_DEVICE(v);
+    qg_vec_info info;
+    qg_vec_get_info(v, &info);
+    const size_t bytes = packed ? (size_t)v->B * info.packed_words_per_env * info.packed_word_bytes : (size_t)v->B * info.obs_rows * info.obs_cols;
+    if (v->host_obs_bytes < bytes) {
+        if (v->host_obs) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(v->host_obs));
+            v->host_obs = nullptr;
+            v->host_obs_bytes = 0;
+        }
+        HIP_TRY(hipMalloc(&v->host_obs, bytes));
+        v->host_obs_bytes = bytes;
+    }
+    if (int rc = packed ? qg_vec_observe_packed(v, v->host_obs, stream) : qg_vec_observe_dense(v, (int8_t *)v->host_obs, stream)) return rc;
+    HIP_TRY(hipMemcpyAsync(out_host, v->host_obs, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return QG_OK;
+}
+int qg_vec_observe_dense_host(qg_vec *v, int8_t *out_host, void *stream) { return observe_host(v, out_host, false, stream); }
+int qg_vec_observe_packed_host(qg_vec *v, void *out_host, void *stream) { return observe_host(v, out_host, true, stream); }
 
 int qg_vec_masks(qg_vec *v, uint8_t *out_dev, void *stream) {
     if (!v || !out_dev) return set_error(QG_ERR_INVALID, "null argument");

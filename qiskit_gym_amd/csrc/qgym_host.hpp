@@ -106,11 +106,17 @@ struct qg_vec {
     uint32_t layers_len = 0;
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    void *host_in = nullptr;            // qg_vec_step_host: device copies of the caller's actions [B] (8 bytes each) and coins [B]
+    void *host_obs = nullptr;           // qg_vec_observe_*_host: the observation before its copy to the caller's buffer
+    size_t host_obs_bytes = 0;
     uint32_t *bad = nullptr;            // TILE / TILE64 without add_inverts: per-env "differs from identity" mask (one-step kernels)
     uint32_t *d_rowops = nullptr;       // TILE: gate table as pairs of row operations on slots (cooperative reset kernel)
     uint32_t *done_list = nullptr;      // reset_done: [B] indices of finished envs + {length, reader ticket} at [B], [B + 1]
     bool auto_list = false;             // qg_vec_reset_done is in use on this handle: single steps append the envs they finish to the list themselves
-    bool done_list_fresh = false;       // the list already holds the finished envs (written by the step that ended them: qg_vec_mid_head_sample_step)
+    bool done_list_fresh = false;       // the list already holds the finished envs (written by the step that ended them); believed within the session only
+    bool list_zero_known = true;        // the list's length is known to be zero (creation, a memset, or its consumer ran) -- within the session
+    bool list_tainted = false;          // some launch that touches the list was captured into a caller's graph: eager calls trust nothing
+    uint64_t list_session = 0;          // 0 = eager execution, else the stream capture id the beliefs above belong to (qgym_api.cpp)
     uint32_t *d_nonsymp = nullptr;      // device word behind InitArgs::nonsymp_flag
     void *embed_dump = nullptr;         // qg_vec_embed: 1 KiB nobody reads (kernels_policy.hip), allocated by qg_vec_pack_embedding
     bool maybe_nonsymplectic = false;   // CliffordEnv + add_inverts: some env may need the Gauss-Jordan inversion
@@ -138,6 +144,10 @@ struct qg_vec {
 
 namespace qg {
 int ensure_scratch_public(qg_vec *v, size_t bytes);
+// done-list protocol (qgym_api.cpp): session scoping of the host's beliefs, zeroing before an appending launch
+bool done_list_session(qg_vec *v, hipStream_t s);
+int done_list_before_append(qg_vec *v, hipStream_t s);
+void done_list_appended(qg_vec *v, bool trusted);
 void fill_step_args_public(const qg_vec *v, StepArgs &a);
 void fill_reset_done_args_public(const qg_vec *v, uint64_t seed, InitArgs &ia);
 void compute_qubit_and_action_perms(uint32_t N, const std::vector<qg_gate> &gates, std::vector<std::vector<int64_t>> &qubit_perms,

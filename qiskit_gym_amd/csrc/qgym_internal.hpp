@@ -162,6 +162,7 @@ struct InitArgs {
     uint32_t coop;             // list mode with RNG draws: the 16-lanes-per-env scramble kernel handles small lists
     const uint32_t *rowops;    // TILE layout: per action two row operations (make_op, slot indices) for that kernel
     uint64_t env_base;         // global index of env 0 in the counter RNG (qg_vec_set_env_base)
+    uint32_t inverts;          // add_inverts is set (PermutationEnv set_state: a state with a repeated entry is a fault only then)
 };
 
 // A handle may be given a device-resident clock (qg_vec_set_clock).  Launches replayed from a

@@ -88,3 +88,81 @@ def test_pauli_reset_done_generates_fresh_targets_on_device():
     np.testing.assert_array_equal(gv.observe().cpu().numpy(), np.stack([o.dense_obs() for o in envs]))
     for e in (0, 11, B - 1):
         assert gv.solution(e) == envs[e].solution()
+
+
+def _twin(kind, n, B, **cfg):
+    from qiskit_gym_amd.vec import VecEnv
+
+    gs = line_gateset(kind, n)
+    return gs, VecEnv(kind, n, gs, B, **cfg), VecEnv(kind, n, gs, B, **cfg)
+
+
+def _same(a, b):
+    a.sync()
+    b.sync()
+    assert torch.equal(a.get_state("packed"), b.get_state("packed"))
+    assert torch.equal(a.depth, b.depth) and torch.equal(a.done, b.done) and torch.equal(a.reward.view(torch.int32), b.reward.view(torch.int32))
+
+
+@pytest.mark.parametrize("kind,n,inverts", [("clifford", 16, False), ("clifford", 16, True), ("clifford", 20, False)])
+def test_done_list_survives_graph_replays_of_single_steps(kind, n, inverts):
+    """The list of finished envs is a device-side fact: a single step captured into a caller's graph appends to it on EVERY replay, and the
+    host only sees the capture.  A graph of lone steps replayed many times, eager reset_done calls between replays, and a graph that opens
+    with reset_done must all behave like the same calls made eagerly on a twin handle (which never saw a capture)."""
+    B, diff = 2048, 2  # episodes of 4 steps: every replay finishes envs
+    cfg = dict(add_inverts=inverts, add_perms=False, track_solution=False, difficulty=diff)
+    gs, g, e = _twin(kind, n, B, **cfg)
+    A = len(gs)
+    gen = torch.Generator(device="cuda").manual_seed(12)
+    acts = torch.randint(0, A, (3, B), dtype=torch.int32, device="cuda", generator=gen)
+    coins = torch.randint(0, 2, (3, B), dtype=torch.uint8, device="cuda", generator=gen) if inverts else [None] * 3
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for h in (g, e):
+            h.reset(3)
+            h.step(acts[0], coins[0])
+            h.reset_done(50)  # from here on single steps leave the list of the envs they finish
+        # (1) lone steps in a graph, replayed 40 times: 40 x 3 steps append up to 120 x B entries unless every replay starts the list again
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            for t in range(3):
+                g.step(acts[t], coins[t])
+        for _ in range(40):
+            graph.replay()
+        for _ in range(40):
+            for t in range(3):
+                e.step(acts[t], coins[t])
+        _same(g, e)
+        # (2) eager reset_done after replays, then replay again, then eager reset_done: no stale or duplicated entries
+        for k in range(3):
+            g.reset_done(100 + k)
+            e.reset_done(100 + k)
+            _same(g, e)
+            graph.replay()
+            for t in range(3):
+                e.step(acts[t], coins[t])
+            _same(g, e)
+        # (3) a graph that opens with reset_done (the flags were set by launches outside it) and alternates step / reset_done
+        torch.cuda.synchronize()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, stream=stream):
+            for t in range(3):
+                g.reset_done(200 + t)
+                g.step(acts[t], coins[t])
+        for rep in range(5):
+            g2.replay()
+            for t in range(3):
+                e.reset_done(200 + t)
+                e.step(acts[t], coins[t])
+            _same(g, e)
+            if rep == 2:  # an eager whole-batch reset between replays
+                g.reset(9)
+                e.reset(9)
+        # (4) eager calls after captures still work (they trust nothing any more)
+        for t in range(3):
+            g.step(acts[t], coins[t])
+            g.reset_done(300 + t)
+            e.step(acts[t], coins[t])
+            e.reset_done(300 + t)
+        _same(g, e)

@@ -234,3 +234,107 @@ def test_c_program_runs_the_policy_loop_without_a_tensor_library(tmp_path):
             asum = (asum * 31 + a) & 0xFFFFFFFFFFFFFFFF
             rsum = (rsum * 31 + r) & 0xFFFFFFFFFFFFFFFF
         assert lines[t] == f"step {t} actions {asum} rewards {rsum}", (t, lines[t])
+
+
+HOST_PTR_SRC = r'''
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include "qgym.h"
+#define CHECK(x) do { int rc_ = (x); if (rc_ != QG_OK) { fprintf(stderr, "%s -> %d: %s\n", #x, rc_, qg_last_error()); return 10; } } while (0)
+#define HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #x, hipGetErrorString(e_)); return 11; } } while (0)
+enum { NQ = 12, B = 900, T = 7 };
+int main(void) {
+    static const qg_gate gates[] = { GATES };
+    const size_t n_gates = sizeof gates / sizeof gates[0];
+    qg_config cfg;
+    qg_vec *v = NULL;
+    qg_vec_info info;
+    hipStream_t s;
+    int64_t *act = NULL;      /* pinned */
+    uint8_t *coin = NULL, *done = NULL, *succ = NULL;
+    float *rew = NULL;
+    uint32_t *packed = NULL;
+    int8_t *dense = (int8_t *)malloc((size_t)B * 4 * NQ * NQ);   /* pageable on purpose */
+    int t, e, k;
+    qg_config_default(&cfg, QG_CLIFFORD, NQ);
+    cfg.add_perms = 0; cfg.track_solution = 0; cfg.difficulty = 9;   /* add_inverts stays on: the coins travel too */
+    CHECK(qg_vec_create(&cfg, gates, n_gates, B, 0, &v));
+    CHECK(qg_vec_get_info(v, &info));
+    HIP(hipStreamCreate(&s));
+    HIP(hipHostMalloc((void **)&act, sizeof(int64_t) * B * T, 0));
+    HIP(hipHostMalloc((void **)&coin, (size_t)B * T, 0));
+    HIP(hipHostMalloc((void **)&rew, sizeof(float) * B * T, 0));
+    HIP(hipHostMalloc((void **)&done, (size_t)B * T, 0));
+    HIP(hipHostMalloc((void **)&succ, (size_t)B * T, 0));
+    HIP(hipHostMalloc((void **)&packed, sizeof(uint32_t) * B * 2 * NQ, 0));
+    for (t = 0; t < T; ++t) for (e = 0; e < B; ++e) {
+        act[t * B + e] = (e * 5 + t * 11) % ((int)n_gates + 2) - 1;   /* includes -1 and n_gates: no gate, depth still decrements */
+        coin[t * B + e] = (uint8_t)((e * 3 + t) % 3 == 0);
+    }
+    CHECK(qg_vec_reset(v, 7, s));
+    for (t = 0; t < T; ++t)   /* nothing synchronises inside the loop */
+        CHECK(qg_vec_step_host(v, act + t * B, QG_ACT_I64, coin + t * B, rew + t * B, done + t * B, succ + t * B, s));
+    CHECK(qg_vec_observe_packed_host(v, packed, s));
+    CHECK(qg_vec_observe_dense_host(v, dense, s));
+    CHECK(qg_vec_sync(v, s));
+    for (t = 0; t < T; ++t) for (e = 0; e < B; ++e) {
+        uint32_t rb; memcpy(&rb, &rew[t * B + e], 4);
+        printf("r %u %u %u\n", rb, done[t * B + e], succ[t * B + e]);
+    }
+    for (e = 0; e < B; ++e) {
+        printf("o");
+        for (k = 0; k < 2 * NQ; ++k) {
+            uint32_t w = 0; int c;
+            for (c = 0; c < 2 * NQ; ++c) w |= (uint32_t)(dense[((size_t)e * 2 * NQ + k) * 2 * NQ + c] != 0) << c;
+            if (w != packed[e * 2 * NQ + k]) { fprintf(stderr, "dense and packed observation differ\n"); return 12; }
+            printf(" %u", w);
+        }
+        printf("\n");
+    }
+    qg_vec_destroy(v);
+    return 0;
+}
+'''
+
+
+def test_c_host_steps_with_host_pointers(tmp_path):
+    """qg_vec_step_host / qg_vec_observe_*_host (SURVEY 8b host-pointer variants): pinned actions and coins in, rewards and flags out, seven
+    steps enqueued back to back with no synchronisation, then both observation formats; compared with the oracle step by step."""
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    from oracle import OracleVec
+    from qiskit_gym_amd.envs.gateset import parse_gateset
+    from util import f32_bits, rng_actions
+
+    NQ, B, T = 12, 900, 7
+    gs = line_gateset("clifford", NQ)
+    A = len(gs)
+    src = HOST_PTR_SRC.replace("GATES", ", ".join("{%d, %d, %d}" % g for g in parse_gateset(gs)))
+    (tmp_path / "hp.c").write_text(src)
+    inc, libdir = os.path.join(ROOT, "include"), os.path.join(ROOT, "qiskit_gym_amd", "lib")
+    exe = tmp_path / "hp"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-I", inc, "-I", "/opt/rocm/include", str(tmp_path / "hp.c"), "-o", str(exe), "-L", libdir, "-lqgym",
+                    "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-2000:])
+    lines = out.stdout.splitlines()
+    rl = [ln.split() for ln in lines if ln.startswith("r ")]
+    ol = [ln.split() for ln in lines if ln.startswith("o ")]
+    assert len(rl) == B * T and len(ol) == B
+    proto = OracleEnv("clifford", NQ, gs, add_inverts=1, add_perms=0, track_solution=0, difficulty=9)
+    ov = OracleVec(proto, B)
+    ov.reset_with(rng_actions(7, B, 9, A))
+    e = np.arange(B)
+    for t in range(T):
+        acts = (e * 5 + t * 11) % (A + 2) - 1
+        coins = ((e * 3 + t) % 3 == 0).astype(np.uint8)
+        r, s, f, _ = ov.step(acts, coins)
+        got = np.array([[int(x) for x in row[1:]] for row in rl[t * B:(t + 1) * B]], dtype=np.int64)
+        assert np.array_equal(got[:, 0], f32_bits(r).astype(np.int64)), t
+        assert np.array_equal(got[:, 1], f) and np.array_equal(got[:, 2], s)
+    dense = ov.observe_dense().reshape(B, 2 * NQ, 2 * NQ).astype(np.uint64)
+    want = (dense << np.arange(2 * NQ, dtype=np.uint64)).sum(axis=2)
+    assert np.array_equal(np.array([[int(x) for x in row[1:]] for row in ol], dtype=np.uint64), want)

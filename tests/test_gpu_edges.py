@@ -226,3 +226,33 @@ def test_four_million_pauli_envs_index_arithmetic():
     np.testing.assert_array_equal(gv.observe_as(torch.float16)[idx].float().cpu().numpy().reshape(len(ids), rows, cols),
                                   np.stack([o.dense_obs() for o in envs]).astype(np.float32))
     gv.close()
+
+
+@pytest.mark.parametrize("n", [9, 25])  # nibble-packed and byte-per-entry layouts
+def test_permutation_set_state_with_repeated_entries_runs_like_the_reference(n):
+    """permutation.rs:168-173 stores the vector unvalidated; step / observe / solved work on any in-range vector.  Without add_inverts
+    such a state steps like the oracle's; with add_inverts it has no inverse, and both layouts report the fault at set_state."""
+    side = int(round(n ** 0.5))
+    gs = grid_gateset("permutation", side, side)
+    A, B = len(gs), 200
+    rng = np.random.default_rng(n)
+    states = np.stack([rng.permutation(n) for _ in range(B)]).astype(np.int64)
+    states[::2, 1] = states[::2, 0]  # every other env holds one entry twice
+    ov, gv = make_pair("permutation", n, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=4)
+    ov.set_state(states)
+    gv.set_state(states)
+    gv.sync()  # no fault
+    for t in range(12):
+        acts = rng.integers(0, A, size=B)
+        r, s, f, d = ov.step(acts)
+        gv.step(torch.as_tensor(acts, device="cuda", dtype=torch.int32))
+        gv.sync()
+        np.testing.assert_array_equal(f32_bits(gv.reward.cpu().numpy()), f32_bits(r))
+        np.testing.assert_array_equal(gv.success.cpu().numpy(), s)
+        np.testing.assert_array_equal(gv.observe().cpu().numpy().reshape(B, -1), ov.observe_dense())
+    from qiskit_gym_amd.vec import VecEnv
+
+    inv = VecEnv("permutation", n, gs, B, add_inverts=True, add_perms=False, track_solution=False, difficulty=4)
+    inv.set_state(states)
+    with pytest.raises(QGymError):
+        inv.sync()

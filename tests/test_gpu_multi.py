@@ -108,3 +108,43 @@ def test_bench_gpus_flag_fails_loudly_without_that_many_gpus():
     res = _run_bench("--gpus", str(n), "--steps", "20", "--warmup", "5", timeout=120)
     assert res.returncode != 0 and "visible" in res.stderr
     assert not [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]
+
+
+@pytest.mark.parametrize("inverts,per", [(False, 256), (False, 16384), (True, 256), (True, 16384)])  # small- and large-batch sampling kernels
+def test_sharded_policy_in_the_loop_draws_what_the_whole_batch_draws(inverts, per):
+    """The sampling + step call keys its action draw on the GLOBAL env id (qg_vec_set_env_base), like every env-side draw: one seed across
+    ranks, and rank r's actions, log-probs and env results are the slice [r * per, (r + 1) * per) of the unsharded batch's."""
+    from qiskit_gym_amd.collector import embed, mid_head_sample_step, pack_embedding, pack_head, pack_mid
+    from qiskit_gym_amd.vec import VecEnv
+
+    n, world, r, H1, H2 = 6, 2, 1, 512, 256
+    gs = line_gateset("clifford", n)
+    A = len(gs)
+    cfg = dict(add_inverts=inverts, add_perms=False, track_solution=False, difficulty=6)
+    whole = VecEnv("clifford", n, gs, per * world, seed=3, **cfg)
+    shard = VecEnv("clifford", n, gs, per, env_base=r * per, seed=3, **cfg)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    w1 = (torch.randn(H1, 4 * n * n, device="cuda", generator=g) * 0.2).to(torch.bfloat16)
+    w2 = (torch.randn(H2, H1, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    wh = (torch.randn(A + 1, H2, device="cuda", generator=g) * 0.2).to(torch.bfloat16)
+    pm, ph = pack_mid(w2, None), pack_head(wh, None, A, A, after_mid=True)
+    sl = slice(r * per, (r + 1) * per)
+    out = {}
+    for name, env in (("whole", whole), ("shard", shard)):
+        env.reset(21)
+        pe = pack_embedding(env, w1)
+        B = env.batch
+        acts = torch.empty(B, dtype=torch.int32, device="cuda")
+        logp, ent, val = (torch.empty(B, dtype=torch.float32, device="cuda") for _ in range(3))
+        trace = []
+        for t in range(4):
+            env.set_counters(t, t)
+            h = embed(env, pe, None, H1)
+            mid_head_sample_step(env, h, pm, H2, ph, 77, t, acts, logp, ent, val, reset_seed=500 + t)
+            trace.append((acts.clone(), logp.clone(), env.reward.clone(), env.done.clone()))
+        env.sync()
+        out[name] = (trace, env.get_state("packed"))
+    for (wa, wl, wr, wd), (sa, slp, sr, sd) in zip(out["whole"][0], out["shard"][0]):
+        assert torch.equal(wa[sl], sa) and torch.equal(wl[sl].view(torch.int32), slp.view(torch.int32))
+        assert torch.equal(wr[sl].view(torch.int32), sr.view(torch.int32)) and torch.equal(wd[sl], sd)
+    assert torch.equal(out["whole"][1][sl], out["shard"][1])
