@@ -84,22 +84,21 @@ def test_config3_clifford_16q_x65536():
 
 
 def test_config5_pauli_20q_x65536():
+    """SURVEY 8(d) config 5 as written: PauliGym 20q x 65 536, every env's target made ON THE DEVICE by reset(seed) (ptile_generate_kernel:
+    1-7 rotations over the coupling graph's distance classes + a tableau scrambled by `difficulty` = 256 gates, pauli.rs:54-271,554-586),
+    T = 128 steps (= max_depth); 517 sampled envs replayed on the oracle's og_pauli_reset_seeded: the generated target itself, every step's
+    reward bits and is_final, and the final observation."""
     from qiskit_gym_amd.vec import VecEnv
-    from test_gpu_pauli import random_labels, random_tableau
 
-    n, B, T = 20, 65536, 64
+    n, B, T, seed = 20, 65536, 128, 0x5EED0005
     gs = line_gateset("pauli", n)
     assert len(gs) == 214
     A = len(gs)
-    pairs = [g[1] for g in gs if g[0] == "CX"]
-    cfg = dict(add_perms=False, track_solution=False, max_rotations=5, difficulty=128)
-    rng = np.random.default_rng(5)
-    # 512 distinct targets tiled over the batch (target generation is host-side for now)
-    U = 512
-    tabs = [random_tableau(rng, n, 256, pairs) for _ in range(U)]
-    labs = [random_labels(rng, n, int(rng.integers(1, 8)), 4) for _ in range(U)]
+    cfg = dict(add_perms=False, track_solution=False, max_rotations=5, difficulty=256, pauli_diff_scale=8)
     gv = VecEnv("pauli", n, gs, B, **cfg)
-    gv.pauli_reset_from(np.stack([tabs[e % U] for e in range(B)]), [labs[e % U] for e in range(B)])
+    gv.reset(seed)
+    obs0 = gv.observe().cpu().numpy()
+    assert (gv.depth == 128).all()
     gen = torch.Generator(device="cuda")
     gen.manual_seed(55)
     acts = torch.randint(0, A, (T, B), dtype=torch.int32, device="cuda", generator=gen)
@@ -107,18 +106,142 @@ def test_config5_pauli_20q_x65536():
     fin = torch.empty((T, B), dtype=torch.uint8, device="cuda")
     gv.rollout(acts, fused=False, rewards_out=rew, dones_out=fin)
     gv.sync()
-    ids = np.arange(0, B, 509)
+    ids = np.arange(0, B, 127)
+    assert len(ids) >= 512
     acts_h, rew_h, fin_h = acts.cpu().numpy(), rew.cpu().numpy(), fin.cpu().numpy()
     obs = gv.observe().cpu().numpy()
+    n_rot = []
     for e in ids:
         o = OracleEnv("pauli", n, gs, **{k: int(v) for k, v in cfg.items()})
-        o.pauli_reset_from(tabs[e % U], labs[e % U])
+        o.pauli_reset_seeded(seed, int(e))
+        n_rot.append(len(o.active_rotations()))
+        np.testing.assert_array_equal(obs0[e], o.dense_obs(), err_msg=f"generated target of env {e}")
         for t in range(T):
             o.step(int(acts_h[t, e]))
             assert np.float32(rew_h[t, e]).view(np.uint32) == o.reward_bits(), (e, t)
             assert fin_h[t, e] == int(o.is_final()), (e, t)
         np.testing.assert_array_equal(obs[e], o.dense_obs(), err_msg=f"env {e}")
+    assert min(n_rot) >= 1 and max(n_rot) >= 6 and len(set(n_rot)) >= 5  # the 1-7 rotations per env SURVEY 8(d) names
     d_all, s_all, f_all = gv.depth.cpu().numpy(), gv.success.cpu().numpy(), gv.done.cpu().numpy()
     np.testing.assert_array_equal(f_all, ((d_all == 0) | (s_all == 1)).astype(np.uint8))
-    # envs that share a target and were given different actions diverge; identical inputs agree
-    assert (obs[0] != obs[U]).any() or (acts_h[:, 0] == acts_h[:, U]).all()
+    assert (d_all == 0).all()
+    # a second reset with another seed generates other targets; the same seed the same ones
+    gv.reset(seed)
+    np.testing.assert_array_equal(gv.observe().cpu().numpy()[ids], obs0[ids])
+    gv.reset(seed + 1)
+    assert (gv.observe().cpu().numpy()[ids] != obs0[ids]).any()
+
+
+def _coins(coin_seed, env_ids, step_index):
+    """The handle's counter-RNG coin of env e at step counter t (qm_step1.hpp: rng_draw(seed ^ "coin", env_base + env, t) >> 63)."""
+    from util import rng_draw
+
+    return (rng_draw(coin_seed ^ 0x636F696E, np.asarray(env_ids, dtype=np.uint64), step_index) >> np.uint64(63)).astype(np.uint8)
+
+
+@pytest.mark.parametrize("kind,n,B,scramble,per_env,stride", [
+    ("clifford", 16, 65536, 256, 1024, 128),        # config 3 with the reference's defaults: qm_inv2_kernel
+    ("linear_function", 8, 8192, 64, 64, 16),       # config 2 with the defaults: word_step_kernel with the byte-parallel Gauss-Jordan
+    ("linear_function", 16, 65536, 64, 256, 128),   # lfd_step_kernel (matrix + inverse, inversion = role swap)
+])
+def test_reference_default_configuration_at_full_size(kind, n, B, scramble, per_env, stride):
+    """The reference's DEFAULT options (envs/synthesis.py:182-204: add_inverts=True, track_solution=True) at BASELINE's batch sizes, the
+    coins thrown by the handle's counter RNG (clifford.rs:262-270 with the draw made explicit), T = 128 = max_depth so the solution log is
+    full: per-step reward bits / is_final, final state, depth and the `solution ++ rev(solution_inv)` list (clifford.rs:334-340,376-381) of a
+    strided sample against the oracle; is_final == (depth == 0 or success) over all envs."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    gs = line_gateset(kind, n)
+    A, T, seed, coin_seed = len(gs), 128, 0x5EED0003, 0xC0FFEE
+    cfg = dict(add_inverts=True, add_perms=False, track_solution=True, difficulty=scramble)
+    gv = VecEnv(kind, n, gs, B, seed=coin_seed, **cfg)
+    gv.reset(seed)
+    gv.set_counters(1000, 0)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    acts = torch.randint(-1, A + 1, (T, B), dtype=torch.int32, device="cuda", generator=gen)  # incl. the two kinds of "no gate"
+    rew = torch.empty((T, B), dtype=torch.float32, device="cuda")
+    fin = torch.empty((T, B), dtype=torch.uint8, device="cuda")
+    gv.rollout(acts, fused=False, rewards_out=rew, dones_out=fin)  # no coins given: the counter RNG
+    gv.sync()
+    ids = np.arange(0, B, stride)
+    proto = OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()})
+    ov = OracleVec(proto, len(ids))
+    ov.reset_with(rng_actions(seed, ids, scramble, A))
+    acts_h = acts.cpu().numpy()[:, ids]
+    rew_h, fin_h = rew.cpu().numpy()[:, ids], fin.cpu().numpy()[:, ids]
+    n_inv = 0
+    for t in range(T):
+        c = _coins(coin_seed, ids, 1000 + t)
+        n_inv += int(c.sum())
+        r, s, f, d = ov.step(acts_h[t], c)
+        np.testing.assert_array_equal(f32_bits(rew_h[t]), f32_bits(r), err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(fin_h[t], f, err_msg=f"is_final t={t}")
+    assert 0.4 < n_inv / (T * len(ids)) < 0.6
+    np.testing.assert_array_equal(gv.get_state("i64").cpu().numpy()[ids], ov.get_state(per_env))
+    np.testing.assert_array_equal(gv.depth.cpu().numpy()[ids], d)
+    np.testing.assert_array_equal(gv.observe().cpu().numpy().reshape(B, -1)[ids], ov.observe_dense())
+    for i in range(0, len(ids), 8):
+        assert gv.solution(int(ids[i])) == ov.env(i).solution(), f"solution of env {ids[i]}"
+    d_all, s_all, f_all = gv.depth.cpu().numpy(), gv.success.cpu().numpy(), gv.done.cpu().numpy()
+    np.testing.assert_array_equal(f_all, ((d_all == 0) | (s_all == 1)).astype(np.uint8))
+    gv.close()
+
+
+@pytest.mark.parametrize("kind,n,B,inverts", [("clifford", 16, 65536, False), ("clifford", 16, 65536, True), ("linear_function", 16, 65536, True)])
+def test_auto_reset_with_desynchronised_episodes_at_full_size(kind, n, B, inverts):
+    """SURVEY 8(d)'s auto-reset variant the way a collector sees it: episodes of L = 16 steps whose ends are spread evenly over time
+    (1/16 of the batch finishes per step), qg_vec_reset_done after every step, more than three episode boundaries per env -- every step's
+    reward bits / is_final / depth and the final state of a strided sample against an oracle replay (clifford.rs:306-319 for the reset).
+    The spread comes from Env::reset called at different times: during the first L steps class k = {env : env % L == k} is reset at step k
+    (its `done` flag -- caller-owned memory, qg_vec_bind_outputs -- is raised, then reset_done)."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    gs = line_gateset(kind, n)
+    A, diff = len(gs), 8
+    L, coin_seed = 2 * diff, 0xBEEF
+    cfg = dict(add_inverts=inverts, add_perms=False, track_solution=inverts, difficulty=diff)
+    gv = VecEnv(kind, n, gs, B, seed=coin_seed, **cfg)
+    ids = np.arange(0, B, 97)
+    envs = [OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()}) for _ in ids]
+
+    def oracle_reset(which, seed):
+        draws = rng_actions(seed, ids[which], diff, A)
+        for j, i in enumerate(which):
+            envs[i].reset_with(draws[:, j])
+
+    gv.reset(1)
+    oracle_reset(np.arange(len(ids)), 1)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    all_env = torch.arange(B, device="cuda")
+    finished = 0
+    for t in range(L + 3 * L + 5):
+        acts = torch.randint(0, A, (B,), dtype=torch.int32, device="cuda", generator=gen)
+        gv.set_counters(t, 0)
+        gv.step(acts)
+        gv.sync()
+        a_h = acts.cpu().numpy()[ids]
+        c = _coins(coin_seed, ids, t) if inverts else np.zeros(len(ids), dtype=np.uint8)
+        for i, o in enumerate(envs):
+            o.step(int(a_h[i]), int(c[i]))
+        np.testing.assert_array_equal(f32_bits(gv.reward.cpu().numpy()[ids]), np.array([o.reward_bits() for o in envs], dtype=np.uint32), err_msg=f"t={t}")
+        fin = gv.done.cpu().numpy()
+        np.testing.assert_array_equal(fin[ids], [int(o.is_final()) for o in envs], err_msg=f"t={t}")
+        np.testing.assert_array_equal(gv.depth.cpu().numpy()[ids], [o.depth() for o in envs])
+        if t >= L:
+            frac = fin.mean()
+            assert 0.04 < frac < 0.10, (t, frac)  # ~1/16 of the batch per step, not all at once
+            finished += int(fin.sum())
+        gv.reset_done(100 + t)
+        oracle_reset(np.nonzero(fin[ids])[0], 100 + t)
+        if t < L:  # Env::reset for class t at time t
+            gv.done[all_env % L == t] = 1
+            gv.reset_done(5000 + t)
+            oracle_reset(np.nonzero(ids % L == t)[0], 5000 + t)
+    assert finished >= 3 * B  # every env went through at least three more episode boundaries
+    gv.sync()
+    np.testing.assert_array_equal(gv.get_state("i64").cpu().numpy()[ids], np.stack([o.get_state() for o in envs]))
+    if inverts:
+        for i in range(0, len(ids), 16):
+            assert gv.solution(int(ids[i])) == envs[i].solution()
