@@ -65,8 +65,8 @@ ALGO_BYTES_PER_STEP = 160  # 128 B state read + 16 B touched row
 # entry comes from a 1.4 KB table that stays cache resident
 NEEDED_BYTES_PER_STEP = 2 * 16 + 2 * 16 + 4 + 8 + 8 + 4 + 2
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-KERNEL = "qg::qm_step1_kernel<16, true, false>"
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+KERNEL = "qg::qm_step1_kernel<16, true, false"  # prefix: the trailing template arguments (feature flags, done list) vary by call site
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
 
 
 def build_gateset():
@@ -217,19 +217,38 @@ def gathered_parity(gateset, seed, global_ids, ring_actions, trace, shard):
             "mismatch": [k for k, v in ok.items() if not v]}
 
 
-def rocprof_kernel_avg_us(envs: int):
+def rocprof_kernel_avg_us(envs: int, required: bool = False):
     """Average duration of the step kernel in the committed rocprofv3 --kernel-trace --stats summary of this command
-    (profiles/r02/, tools/profile_bench.sh), or None.  The statistics hold one batch size (profiling runs pass --no-large-batch)."""
+    (profiles/r03/, tools/profile_bench.sh).  The statistics hold one batch size (profiling runs pass --no-large-batch).  Every
+    instantiation of the kernel whose name starts with KERNEL counts (calls-weighted).  `required`: a missing file or kernel is an
+    error -- the line's roofline.frac is this figure -- unless the run IS the profiling run (--profiling-run)."""
     path = os.path.join(PROFILE_DIR, "bench_kernel_stats.csv" if envs == ENVS_PER_GPU else f"bench_{envs}_kernel_stats.csv")
+    want = KERNEL.split("::", 1)[1]
+    calls, total_ns, mins = 0, 0.0, []
     try:
         with open(path) as f:
             for row in csv.DictReader(f):
-                if KERNEL.split("::", 1)[1] in row["Name"]:
-                    return {"avg_us": float(row["AverageNs"]) / 1e3, "min_us": float(row["MinNs"]) / 1e3, "calls": int(row["Calls"]),
-                            "source": os.path.relpath(path, ROOT)}
-    except Exception:
-        return None
+                if want in row["Name"]:
+                    calls += int(row["Calls"])
+                    total_ns += float(row["AverageNs"]) * int(row["Calls"])
+                    mins.append(float(row["MinNs"]))
+    except OSError:
+        calls = 0
+    if calls:
+        return {"avg_us": total_ns / calls / 1e3, "min_us": min(mins) / 1e3, "calls": calls, "source": os.path.relpath(path, ROOT)}
+    if required:
+        raise SystemExit(f"bench.py: {os.path.relpath(path, ROOT)} does not hold a kernel named {want}*: re-run tools/profile_bench.sh on the "
+                         "current build and commit profiles/r03 (or pass --profiling-run)")
     return None
+
+
+def profiled_configs():
+    """profiles/r03/traffic.json: per configuration the step kernel's rocprofv3 average, the PMC bytes per env (separate FETCH_SIZE /
+    WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), the bytes it needs and both fractions of 8 TB/s."""
+    try:
+        return json.load(open(os.path.join(PROFILE_DIR, "traffic.json")))["configs"]
+    except Exception:
+        return {}
 
 
 def pmc_traffic(envs: int):
@@ -288,6 +307,10 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the CPU-oracle replay of the timed run")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the 2^18 / 2^20 / 2^22-env legs (profiling runs: keeps the kernel statistics to one batch size)")
     ap.add_argument("--no-default-config", action="store_true", help="skip the reference-default (add_inverts=True, track_solution=True) leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C2 / C5 / C3d legs (SURVEY 8d's other configurations)")
+    ap.add_argument("--profiling-run", action="store_true",
+                    help="this run produces profiles/r03 (tools/profile_bench.sh): the committed rocprofv3 summary is not required and roofline.frac falls "
+                         "back to the live clock")
     ap.add_argument("--no-collector", action="store_true", help="skip the policy-in-the-loop leg (SURVEY 8f-3: collection with the reference's default policy shape)")
     ap.add_argument("--no-gather", action="store_true", help="N>1 diagnostics: step only, no all-gather")
     ap.add_argument("--no-p2p", action="store_true", help="N>1: skip the direct-write (hipIpc windows over xGMI) cadence leg")
@@ -606,7 +629,7 @@ def main():
     algo_bytes = ALGO_BYTES_PER_STEP * B
     needed_bytes = NEEDED_BYTES_PER_STEP * B
     achieved = algo_bytes / (timed_region_us * 1e-6) / 1e9
-    rocprof = rocprof_kernel_avg_us(B)
+    rocprof = rocprof_kernel_avg_us(B, required=(rank == 0 and not args.profiling_run and B == ENVS_PER_GPU))
     traffic = pmc_traffic(B)
 
     # ---- fused rollout (state in LDS across steps), reported beside the headline --------
@@ -667,41 +690,114 @@ def main():
         del denv, coins, dacts
 
     # ---- SURVEY 8(d)'s auto-reset variant of the headline workload: qg_vec_reset_done after every step (finished episodes start over on the
-    # device: compaction of the finished envs + scramble from the identity), one captured graph of 128 x (step, reset_done) -----
+    # device: scramble from the identity), one captured graph of 128 x (step, reset_done).  Two episode schedules: "desynchronised" -- what a
+    # collector sees: episode ends spread evenly over time, 1/128 of the batch finishes in every step (Env::reset called for class
+    # env % 128 == k at warm-up step k) -- and "synchronised" (every env finishes in the same step, 127 of 128 reset_done calls find nothing) -----
     auto_reset = None
     if not multi and B == ENVS_PER_GPU and not args.no_default_config:
         AT = 128
-        aenv = VecEnv("clifford", n, gateset, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=SCRAMBLE)
-        aacts = torch.randint(0, A, (AT, B), dtype=torch.int32, device=dev, generator=gen)
-        with torch.cuda.stream(stream):
-            aenv.reset(seed)
+        legs = {}
+        for schedule in ("desynchronised", "synchronised"):
+            aenv = VecEnv("clifford", n, gateset, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=SCRAMBLE)
+            aacts = torch.randint(0, A, (AT, B), dtype=torch.int32, device=dev, generator=gen)
+            afin = torch.empty((AT, B), dtype=torch.uint8, device=dev)
+            with torch.cuda.stream(stream):
+                aenv.reset(seed)
+                if schedule == "desynchronised":
+                    cls = torch.arange(B, device=dev) % AT
+                    for k in range(AT):  # eager warm-up: spreads the episode ends (the done flags are caller-owned memory, qg_vec_bind_outputs)
+                        aenv.set_counters(k, k)
+                        aenv.step(aacts[k])
+                        aenv.reset_done(seed + 0x51ED * (k + 1))
+                        aenv.done[cls == k] = 1
+                        aenv.reset_done(seed + 0xA5A5 * (k + 1))
 
-            def episode():
-                for t in range(AT):
-                    aenv.set_counters(t, t)
-                    aenv.rollout(aacts[t : t + 1])
-                    aenv.reset_done(seed + 0x9E3779B9 * (t + 1))
+                def episode():
+                    for t in range(AT):
+                        aenv.set_counters(t, t)
+                        aenv.rollout(aacts[t : t + 1], dones_out=afin[t : t + 1])
+                        aenv.reset_done(seed + 0x9E3779B9 * (t + 1))
 
-            episode()  # eager pass (allocations, kernel loads)
-            torch.cuda.synchronize()
-            ag = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ag, stream=stream):
-                episode()
-            torch.cuda.synchronize()
-            ag.replay()
-            torch.cuda.synchronize()
-            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a0.record(stream)
-            for _ in range(4):
+                episode()  # eager pass (allocations, kernel loads)
+                torch.cuda.synchronize()
+                ag = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ag, stream=stream):
+                    episode()
+                torch.cuda.synchronize()
                 ag.replay()
-            a1.record(stream)
-        torch.cuda.synchronize()
-        aenv.sync()
-        aus = a0.elapsed_time(a1) * 1e3 / (4 * AT)
-        auto_reset = {"us_per_step": aus, "value": B / (aus * 1e-6), "unit": "env-steps/s", "finished_per_step": float(aenv.done.float().mean()),
-                      "config": f"the headline workload with qg_vec_reset_done after every step (episodes of depth min(depth_slope * difficulty, max_depth) = 128 "
-                                f"steps; every env finishes in the same step, so one step in 128 resets the whole batch); a captured graph of {AT} x (step, reset_done)"}
-        del ag, aenv, aacts
+                torch.cuda.synchronize()
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record(stream)
+                for _ in range(4):
+                    ag.replay()
+                a1.record(stream)
+            torch.cuda.synchronize()
+            aenv.sync()
+            aus = a0.elapsed_time(a1) * 1e3 / (4 * AT)
+            per_step = afin.float().mean(dim=1)
+            legs[schedule] = {"us_per_step": aus, "value": B / (aus * 1e-6), "unit": "env-steps/s", "finished_per_step": float(per_step.mean()),
+                              "finished_per_step_min_max": [float(per_step.min()), float(per_step.max())]}
+            del ag, aenv, aacts, afin
+        auto_reset = dict(legs["desynchronised"], synchronised=legs["synchronised"],
+                          config=f"the headline workload with qg_vec_reset_done after every step, episodes of min(depth_slope * difficulty, max_depth) = {AT} steps, "
+                                 f"a captured graph of {AT} x (step, reset_done) replayed 4 times; headline figures: episode ends spread evenly over time "
+                                 "(parity of this schedule: tests/test_gpu_fullsize.py::test_auto_reset_with_desynchronised_episodes_at_full_size)")
+
+    # ---- SURVEY 8(d)'s other configurations: live launch period (hipGraph of 128 single-step launches) beside the committed rocprofv3 / PMC
+    # figures of the same kernels (profiles/r03/traffic.json, tools/profile_bench.sh) -----
+    configs = None
+    if not multi and B == ENVS_PER_GPU and not args.no_configs:
+        from util import line_gateset
+
+        prof = profiled_configs()
+        configs = {}
+
+        def leg(name, venv, acts, coins=None):
+            with torch.cuda.stream(stream):
+                if coins is None:
+                    us = graph_period(venv, acts)
+                else:
+                    venv.rollout(acts, coins=coins)  # builds the graph
+                    tot = 0.0
+                    for _ in range(3):
+                        venv.reset(seed)  # a new episode: the solution log is empty again (not timed)
+                        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        c0.record(stream)
+                        venv.rollout(acts, coins=coins)
+                        c1.record(stream)
+                        torch.cuda.synchronize()
+                        tot += c0.elapsed_time(c1)
+                    venv.sync()
+                    us = tot * 1e3 / (3 * acts.shape[0])
+            p = prof.get(name) or {}
+            st = p.get("rocprof_kernel_stats") or {}
+            row = {"kernel": p.get("kernel"), "envs": venv.batch, "us_per_step": us, "value": venv.batch / (us * 1e-6), "unit": "env-steps/s",
+                   "rocprof_avg_us": st.get("avg_us"), "pmc_bytes_per_env": p.get("bytes_per_env"), "needed_bytes_per_env": p.get("needed_bytes_per_env"),
+                   "survey_8d_bytes_per_env": p.get("survey_8d_bytes_per_env"), "frac_moved": p.get("rocprof_frac_moved"),
+                   "frac_survey_8d": p.get("rocprof_frac_algorithmic"), "source": "profiles/r03/traffic.json" if p else None}
+            configs[name] = row
+
+        gs2 = line_gateset("linear_function", 8)
+        e2 = VecEnv("linear_function", 8, gs2, 8192, add_inverts=False, add_perms=False, track_solution=False, difficulty=64)
+        with torch.cuda.stream(stream):
+            e2.reset(0x5EED0002)
+        leg("C2", e2, torch.randint(0, len(gs2), (RING, 8192), dtype=torch.int32, device=dev, generator=gen))
+        del e2
+        gs5 = line_gateset("pauli", 20)
+        e5 = VecEnv("pauli", 20, gs5, B, add_perms=False, track_solution=False, max_rotations=5, difficulty=256, pauli_diff_scale=8)
+        with torch.cuda.stream(stream):
+            e5.reset(0x5EED0005)  # targets generated on the device: 1-7 rotations per env, tableau scrambled by 256 gates
+        leg("C5", e5, torch.randint(0, len(gs5), (RING, B), dtype=torch.int32, device=dev, generator=gen))
+        del e5
+        e3d = VecEnv("clifford", n, gateset, B, add_inverts=True, add_perms=False, track_solution=True, difficulty=SCRAMBLE)
+        with torch.cuda.stream(stream):
+            e3d.reset(seed)
+        leg("C3d", e3d, torch.randint(0, A, (128, B), dtype=torch.int32, device=dev, generator=gen),
+            coins=torch.randint(0, 2, (128, B), dtype=torch.uint8, device=dev, generator=gen))
+        del e3d
+        configs["note"] = ("C2 LinearFunctionGym 8q x 8 192, C5 PauliGym 20q x 65 536 (device-generated targets), C3d CliffordGym 16q x 65 536 with the "
+                           "reference's default add_inverts=True / track_solution=True; us_per_step is live (HIP events around hipGraph replays of "
+                           "single-step launches), the other columns are the committed rocprofv3 --kernel-trace --stats and --pmc passes of tools/run_config.py")
 
     # ---- the same step kernel at larger batches: where the launch boundary (1.6 us) stops dominating, and beyond the Infinity Cache -----
     large = None
@@ -801,11 +897,18 @@ def main():
                 "bound": "hbm",
                 "kernel": KERNEL,
                 "kernel_resources": "256 threads/block, 1 wave/SIMD at 65 536 envs; no LDS; thread per env",
-                "achieved": achieved,
+                # achieved / frac: SURVEY 8(d)'s algorithmic bytes per launch over the kernel's average duration in the committed rocprofv3
+                # --kernel-trace --stats summary of this command (profiles/r03/bench_kernel_stats.csv); the live clocks are in frac_by_clock.  A
+                # profiling run (no committed summary yet) falls back to the timed region's events
+                "achieved": (algo_bytes / (rocprof["avg_us"] * 1e-6) / 1e9) if rocprof else achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "clock": "HIP events on the launch stream around the K timed steps (kernel_us_timed_region): launch period, i.e. kernel + launch boundary",
+                "frac": ((algo_bytes / (rocprof["avg_us"] * 1e-6) / 1e9) if rocprof else achieved) / HBM_PEAK_GBS,
+                "clock": ("rocprofv3 --kernel-trace --stats average of the step kernel, " + rocprof["source"]) if rocprof else
+                         "HIP events on the launch stream around the K timed steps (no committed rocprofv3 summary: --profiling-run)",
+                "achieved_live": achieved,
+                "frac_live": achieved / HBM_PEAK_GBS,
+                "clock_live": "HIP events on the launch stream around the K timed steps (kernel_us_timed_region): launch period, i.e. kernel + launch boundary",
                 "traffic": traffic["bytes_per_launch"] if traffic else None,
                 "traffic_detail": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes,
@@ -830,6 +933,7 @@ def main():
             "fused_rollout": fused,
             "default_config": default_cfg,
             "auto_reset": auto_reset,
+            "configs": configs,
             "large_batch": large,
             "policy_in_loop": collector,
         }

@@ -1,4 +1,5 @@
-"""rocprofv3 PMC passes of tools/profile_bench.sh -> profiles/r02/traffic.json (and the kernel-stats files copied beside it).
+"""rocprofv3 PMC passes of tools/profile_bench.sh -> profiles/r03/traffic.json (and the kernel-stats files copied beside it).
+  python tools/pmc_traffic.py [src = gpurun_out/prof] [dst = profiles/r03]
 
 HBM bytes per launch of a step kernel = 2 x FETCH_SIZE + WRITE_SIZE (both reported in KiB): MI355X_MICROARCH.md's HBM
 section -- on gfx950 FETCH_SIZE counts half the bytes of a 16 B/lane read, WRITE_SIZE is taken as is; each counter is
@@ -14,17 +15,19 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof")
-dst = os.path.join(ROOT, "profiles", "r02")
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r03")
 os.makedirs(dst, exist_ok=True)
 
-# run name -> (kernel substring, envs, SURVEY 8(d) bytes per env-step, bytes the kernel must move per env-step)
+# run name -> (kernel name PREFIX -- trailing template arguments vary by call site --, envs, SURVEY 8(d) bytes per env-step, bytes the
+# kernel must move per env-step)
 RUNS = {
-    "bench": ("qm_step1_kernel<16, true, false>", 65536, 160, 90),
-    "C3_1048576": ("qm_step1_kernel<16, true, false>", 1048576, 160, 90),
-    "C3_4194304": ("qm_step1_kernel<16, true, false>", 4194304, 160, 90),
-    "C3d": ("qm_inv2_kernel<16, true>", 2 * 65536, 160, 160),  # two lanes per env: Grid_Size is 2 x envs
+    "bench": ("qm_step1_kernel<16, true, false", 65536, 160, 90),
+    "C3_1048576": ("qm_step1_kernel<16, true, false", 1048576, 160, 90),
+    "C3_4194304": ("qm_step1_kernel<16, true, false", 4194304, 160, 90),
+    "C3d": ("qm_inv2_kernel<16, true", 2 * 65536, 160, 160),  # two lanes per env: Grid_Size is 2 x envs
     "C2": ("word_step_kernel<false>", 8192, 32, 32),
-    "C5": ("ptile_step1c_kernel<20, 8, false>", 65536, 494, None),
+    # two 12-byte qubit records read and written, the 64-byte rotation block's touched 16-bit slices + bookkeeping, 22 B of scalars
+    "C5": ("ptile_step1c_kernel<20, 8", 65536, 494, 130),
 }
 
 
@@ -44,12 +47,17 @@ def stats(run, kernel):
     path = os.path.join(src, f"{run}_kernel_stats.csv")
     if not os.path.exists(path):
         return None
+    calls, total, mins, maxs = 0, 0.0, [], []
     with open(path) as f:
         for row in csv.DictReader(f):
-            if kernel in row["Name"]:
-                return {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3, "min_us": float(row["MinNs"]) / 1e3,
-                        "max_us": float(row["MaxNs"]) / 1e3}
-    return None
+            if kernel in row["Name"]:  # every instantiation with this prefix, calls-weighted
+                calls += int(row["Calls"])
+                total += float(row["AverageNs"]) * int(row["Calls"])
+                mins.append(float(row["MinNs"]))
+                maxs.append(float(row["MaxNs"]))
+    if not calls:
+        return None
+    return {"calls": calls, "avg_us": total / calls / 1e3, "min_us": min(mins) / 1e3, "max_us": max(maxs) / 1e3}
 
 
 out = {"method": "tools/profile_bench.sh: rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 <bench.py | tools/run_config.py ...>, "
@@ -71,18 +79,22 @@ for run, (kernel, envs, algo, needed) in RUNS.items():
             live = None
     if run == "C3d":
         envs //= 2
-    e = {"kernel": "qg::" + kernel, "envs": envs, "fetch_bytes": fb, "write_bytes": wb, "bytes_per_launch": fb + wb,
+    e = {"kernel": "qg::" + kernel + "...>", "envs": envs, "fetch_bytes": fb, "write_bytes": wb, "bytes_per_launch": fb + wb,
          "bytes_per_env": (fb + wb) / envs, "fetch_per_env": fb / envs, "write_per_env": wb / envs,
          "survey_8d_bytes_per_env": algo, "needed_bytes_per_env": needed,
          "dispatches": {"FETCH_SIZE": len(fetch), "WRITE_SIZE": len(write)},
          "raw_KiB": {"FETCH_SIZE": {"mean": statistics.mean(fetch), "min": min(fetch), "max": max(fetch)},
                      "WRITE_SIZE": {"mean": statistics.mean(write), "min": min(write), "max": max(write)}},
          "rocprof_kernel_stats": st, "live": live}
+    if needed:
+        e["traffic_over_needed"] = (fb + wb) / envs / needed
     if st:
         e["rocprof_GBs_algorithmic"] = algo * envs / st["avg_us"] / 1e3
         e["rocprof_frac_algorithmic"] = e["rocprof_GBs_algorithmic"] / 8000
         e["rocprof_GBs_moved"] = (fb + wb) / st["avg_us"] / 1e3
         e["rocprof_frac_moved"] = e["rocprof_GBs_moved"] / 8000
+        if needed:
+            e["rocprof_frac_needed"] = needed * envs / st["avg_us"] / 1e3 / 8000
     out["configs"][run] = e
     if kernel.startswith("qm_step1_kernel"):
         out["by_envs"][str(envs)] = e

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-2 profiles (run through gpurun from the repo root; results land in gpurun_out/prof, tools/pmc_traffic.py turns them
-# into what is committed under profiles/r02/):
+# Round-3 profiles (run through gpurun from the repo root; results land in gpurun_out/prof, tools/pmc_traffic.py turns them
+# into what is committed under profiles/r03/):
 #   1. rocprofv3 --kernel-trace --stats of the bench.py command the driver runs       -> bench_kernel_stats.csv
 #   2. --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (one per counter, kernel trace only) of the same kernel at 65 536 envs
 #   3. kernel stats + PMC passes of every other configuration's step kernel: C2 (word_step_kernel), C5 (ptile_step1c_kernel),
@@ -12,7 +12,7 @@ OUT="$ROOT/gpurun_out/prof"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/qg_prof && mkdir -p /tmp/qg_prof
-BENCH_ARGS="--gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-large-batch --no-default-config"
+BENCH_ARGS="--gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-large-batch --no-default-config --no-configs --no-collector --profiling-run"
 echo "== bench.py kernel stats" && date
 rocprofv3 --kernel-trace --stats -d /tmp/qg_prof/stats -o bench --output-format csv -- python3 "$ROOT/bench.py" $BENCH_ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats_run.log"
 cp /tmp/qg_prof/stats/*kernel_stats.csv "$OUT/bench_kernel_stats.csv" 2>/dev/null
@@ -31,7 +31,7 @@ stats_pass() {  # name, script args...
 }
 for C in FETCH_SIZE WRITE_SIZE; do
     echo "== bench.py pmc $C" && date
-    pmc_pass bench $C "$ROOT/bench.py" --gpus 1 --steps 512 --warmup 64 --no-cpu-baseline --no-parity --no-large-batch --no-default-config
+    pmc_pass bench $C "$ROOT/bench.py" --gpus 1 --steps 512 --warmup 64 --no-cpu-baseline --no-parity --no-large-batch --no-default-config --no-configs --no-collector --profiling-run
 done
 for CFG in "C2" "C5" "C3d" "C3 --envs 1048576" "C3 --envs 4194304"; do
     set -- $CFG
@@ -43,7 +43,11 @@ for CFG in "C2" "C5" "C3d" "C3 --envs 1048576" "C3 --envs 4194304"; do
         pmc_pass "$NAME" $C "$ROOT/tools/run_config.py" --config "$@" --steps 256
     done
 done
-echo "== bench.py plain" && date
-cd "$ROOT" && python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_args.json" 2> "$OUT/bench_driver_args.err"
-cd "$ROOT" && python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
-ls -la "$OUT"
+echo "== post-processing on the box: traffic.json + the files bench.py reads" && date
+mkdir -p "$OUT/r03"
+python3 "$ROOT/tools/pmc_traffic.py" "$OUT" "$OUT/r03" > "$OUT/pmc_traffic.log" 2>&1
+mkdir -p "$ROOT/profiles/r03" && cp "$OUT/r03/"* "$ROOT/profiles/r03/"   # the box's copy of the repo: bench.py below reads them
+echo "== bench.py plain (reads the summaries made above)" && date
+cd "$ROOT" && python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/r03/bench_driver_args.json" 2> "$OUT/bench_driver_args.err"
+cd "$ROOT" && python3 bench.py > "$OUT/r03/bench_n1.json" 2> "$OUT/bench_n1.err"
+ls -la "$OUT" "$OUT/r03"

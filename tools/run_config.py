@@ -23,8 +23,8 @@ from qiskit_gym_amd.vec import VecEnv
 from util import grid_gateset, line_gateset
 
 ALGO = {"C1": 32, "C2": 32, "C3": 160, "C3d": 160, "C5": 494, "LFd": 0}  # SURVEY.md 8(d), bytes per env-step
-KERNELS = {"C1": "word_step_kernel<true>", "C2": "word_step_kernel<false>", "C3": "qm_step1_kernel<16, true, false>",
-           "C3d": "qm_inv2_kernel<16, true>", "C5": "ptile_step1c_kernel<20, 8, false>", "LFd": "lfd_step_kernel"}
+KERNELS = {"C1": "word_step_kernel<true>", "C2": "word_step_kernel<false>", "C3": "qm_step1_kernel<16, true, false, *>",
+           "C3d": "qm_inv2_kernel<16, true, *>", "C5": "ptile_step1c_kernel<20, 8, *>", "LFd": "lfd_step_kernel"}
 
 
 def main():
@@ -67,18 +67,11 @@ def main():
             if args.coin != "rand":
                 coins.fill_(int(args.coin))
         env.reset(0x5EED0003)
-    else:
-        from test_gpu_pauli import random_labels, random_tableau
-
+    else:  # C5: every env's target generated on the device (1-7 rotations, tableau scrambled by 256 gates; tests/test_gpu_fullsize.py checks it)
         n, B = 20, args.envs or 65536
         gs = line_gateset("pauli", n)
-        pairs = [g[1] for g in gs if g[0] == "CX"]
-        rng = np.random.default_rng(5)
-        U = 256
-        tabs = [random_tableau(rng, n, 256, pairs) for _ in range(U)]
-        labs = [random_labels(rng, n, int(rng.integers(1, 8)), 4) for _ in range(U)]
-        env = VecEnv("pauli", n, gs, B, add_perms=False, track_solution=False, max_rotations=5, difficulty=128)
-        env.pauli_reset_from(np.stack([tabs[e % U] for e in range(B)]), [labs[e % U] for e in range(B)])
+        env = VecEnv("pauli", n, gs, B, add_perms=False, track_solution=False, max_rotations=5, difficulty=256, pauli_diff_scale=8)
+        env.reset(0x5EED0005)
     A = len(gs)
     T = args.chunk
     stream = torch.cuda.Stream(device=dev)
