@@ -34,14 +34,15 @@ __device__ inline void done_list_append(uint32_t *list, uint32_t *count, bool fi
 // the number of blocks with work follows from the length alone, so every block computes it.  A block without work takes no ticket (256
 // tickets on one address cost the launch 3.4 us); it may find the counter already zeroed and then sees an empty list, which for it is
 // the same thing.  An empty list needs neither tickets nor zeroing.  Call from all threads.
-__device__ inline uint32_t list_count_take(uint32_t *counter, uint64_t coop_B = 0) {
+__device__ inline uint32_t list_count_take(uint32_t *counter, uint64_t coop_B = 0, uint32_t coop_lanes = QG_COOP_LANES) {
     const uint32_t count = counter[0];
     if (count == 0) return 0;
-    const uint64_t threads = (coop_B && (uint64_t)count * QG_COOP_LANES * 2 <= coop_B) ? (uint64_t)count * QG_COOP_LANES : (uint64_t)count;
+    const uint64_t threads = (coop_B && (uint64_t)count * QG_COOP_LANES * 2 <= coop_B) ? (uint64_t)count * coop_lanes : (uint64_t)count;
     const uint32_t blocks = (uint32_t)((threads + blockDim.x - 1) / blockDim.x);
     if (blockIdx.x >= blocks) return count;  // (this block's threads all lie past the list)
     __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(&counter[1], 1u) == blocks - 1u) {
+    // the ticket waits for its atomic's answer: it rides on the block's LAST thread, whose wave has the least left to do in scramble_tree
+    if (threadIdx.x == blockDim.x - 1u && atomicAdd(&counter[1], 1u) == blocks - 1u) {
         counter[0] = 0;
         counter[1] = 0;
     }
@@ -134,6 +135,103 @@ __device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds,
     }
     return sl == 0 ? rows : nullptr;
 }
+// One WORKGROUP (four waves) per env, the matrix held by COLUMNS, the gate sequence cut in four.
+//
+// Columns: lane j keeps column j in slot order (bit s of `col` = entry (slot s, column j); uint32 rows: R <= 32 slots, <= 32 columns, the
+// upper half of each wave idles).  A row operation -- row[dst] ^= row[src], or the two rows trade places (clifford.rs:64-82) -- is then bit
+// arithmetic inside every lane's own word, and because a whole wave works on ONE env the gate is the same for all its lanes: its fields sit in
+// scalar registers, nothing crosses lanes and nothing touches LDS (three dependent vector instructions per row operation, no branch;
+// scramble_coop pays an LDS read -> write -> read round trip per operation).  The 64 draws of a chunk are made one per lane (two splitmix64
+// rounds each, all lanes at once) and handed to the wave by v_readlane.
+// Four waves: reset() is S = G_n ... G_1 S0 (S0 = the identity in slot order), a product of row-operation matrices, and matrix products
+// associate: wave w applies its quarter of the gates -- wave 0 to S0, the others to the R x R identity, giving P_w -- and the quarters are
+// multiplied in a two-level tree through LDS, (P3 P2) (P1 X0).  With columns on the lanes, column j of A B is A times column j of B:
+// the xor of A's columns s over the set bits s of the lane's own word -- A's 32 column words read from LDS, 64 vector instructions.
+// The dependent chain shrinks from n gates to n / 4 gates + two products (tools/microbench_scramble.hip: ~65 ns per gate, ~0.3 us per product).
+// Rows come back by ballot: row word of slot s = the lanes' bits s.  Returns true on the one lane (lane 0 of wave 0) that finishes the env.
+// `prod`: 4 x 32 words of LDS.  blockDim.x must be 256.
+constexpr uint32_t QG_TREE_THREADS = 256;
+constexpr uint32_t QG_TREE_MAX_ENVS = 1024;  // four waves per env: beyond ~1 000 envs the chip's SIMDs hold several of these waves each and issue slots,
+                                            // not the chain, set the time (65 536 envs, 3 % finished: 59 us against 56 for scramble_coop)
+// lists this short, of scrambles this long, go to scramble_tree (shorter chains do not repay the two products)
+__device__ __host__ inline bool tree_takes(uint32_t count, uint32_t n_draws, uint64_t B) {
+    return n_draws >= 64u && count <= QG_TREE_MAX_ENVS && (uint64_t)count * QG_COOP_LANES * 2 <= B;
+}
+template <int R>
+__device__ inline uint32_t gf2_cols_product(const uint32_t *a_cols, uint32_t b) {  // this lane's column of A B; a_cols[s] = column s of A
+    uint32_t acc = 0;
+#pragma unroll
+    for (int sl = 0; sl < R; ++sl) acc ^= a_cols[sl] & (uint32_t)__builtin_amdgcn_sbfe((int32_t)b, (uint32_t)sl, 1u);
+    return acc;
+}
+template <int R, typename Identity>
+__device__ inline bool scramble_tree(const InitArgs &a, uint32_t count, uint64_t &env, uint32_t (&rows_out)[R], uint32_t (*prod)[32], Identity identity) {
+    static_assert(R <= 32, "one uint32 of slots per column");
+    const uint64_t item = blockIdx.x;
+    if (item >= count) return false;  // whole workgroups leave together
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1), w = threadIdx.x >> 6;
+    env = a.list[item];
+    const uint32_t seg = (a.n_draws + 3u) / 4u, t0 = w * seg, t1 = (t0 + seg < a.n_draws) ? t0 + seg : a.n_draws;  // this wave's gates [t0, t1)
+    uint32_t col = 0;
+    if (lane < 32u) {
+        if (w == 0) {
+#pragma unroll
+            for (int sl = 0; sl < R; ++sl) col |= ((identity((uint32_t)sl) >> lane) & 1u) << sl;  // clifford.rs:307
+        } else {
+            col = lane < (uint32_t)R ? 1u << lane : 0u;
+        }
+    }
+    const uint64_t seed = init_seed(a);
+    // One row operation, branch-free: with b_src, b_dst the two bits as 0 / -1 (v_bfe_i32), x = b_src ^ (b_dst & swap) is what changes --
+    // xor: the source bit lands on dst; swap: both positions flip when the bits differ -- and `m` says where: bit dst (xor), bits dst
+    // and src (swap), nothing ("no gate").  src, dst, swap and m are wave-uniform: scalar registers.
+    auto rowop = [&](uint32_t src, uint32_t dst, int32_t swap, uint32_t m) {
+        const int32_t bs = __builtin_amdgcn_sbfe((int32_t)col, src, 1u), bd = __builtin_amdgcn_sbfe((int32_t)col, dst, 1u);
+        col ^= (uint32_t)(bs ^ (bd & swap)) & m;
+    };
+    auto mask_of = [](uint32_t op) -> uint32_t {  // per lane, for its own draw
+        const uint32_t type = (op >> 12) & 3u, dst = op & 63u, src = (op >> 6) & 63u;
+        return ((uint32_t)(type != OP_NONE) << dst) | ((uint32_t)(type == OP_SWAP) << src);
+    };
+    for (uint32_t c0 = t0; c0 < t1; c0 += 2u * QG_WAVE) {
+        uint32_t o[2], m0[2], m1[2];
+#pragma unroll
+        for (uint32_t j = 0; j < 2; ++j) {
+            const uint32_t t = c0 + j * QG_WAVE + lane;
+            o[j] = t < t1 ? a.rowops[rng_action(seed, a.env_base + env, t, a.num_actions)] : 0u;  // past the end: "no gate"
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 2; ++j) {
+            m0[j] = mask_of(o[j] & 0x3FFFu);
+            m1[j] = mask_of(o[j] >> 14);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 2; ++j) {
+            if (c0 + j * QG_WAVE >= t1) break;
+            const uint32_t left = t1 - (c0 + j * QG_WAVE);
+            const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)(left < QG_WAVE ? left : QG_WAVE));
+            for (uint32_t k = 0; k < len; ++k) {
+                const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)o[j], (int)k);
+                const uint32_t ga = (uint32_t)__builtin_amdgcn_readlane((int)m0[j], (int)k), gb = (uint32_t)__builtin_amdgcn_readlane((int)m1[j], (int)k);
+                // op = dst | src << 6 | type << 12, type in {0, 1, 2}: bit 13 says "swap" (OP_SWAP == 2)
+                rowop((g >> 6) & 63u, g & 63u, __builtin_amdgcn_sbfe((int32_t)g, 13u, 1u), ga);
+                rowop((g >> 20) & 63u, (g >> 14) & 63u, __builtin_amdgcn_sbfe((int32_t)g, 27u, 1u), gb);
+            }
+        }
+    }
+    // (P3 P2) (P1 X0): the odd waves publish their columns, the even ones multiply; then wave 2 publishes, wave 0 multiplies
+    if ((w & 1u) && lane < 32u) prod[w][lane] = col;
+    __syncthreads();
+    if (!(w & 1u)) col = gf2_cols_product<R>(prod[w + 1u], col);
+    if (w == 2u && lane < 32u) prod[2][lane] = col;
+    __syncthreads();
+    if (w != 0) return false;
+    col = gf2_cols_product<R>(prod[2], col);
+#pragma unroll
+    for (int sl = 0; sl < R; ++sl) rows_out[sl] = (uint32_t)__ballot((col >> sl) & 1u);
+    return lane == 0;
+}
+
 template <typename W, int R>
 constexpr size_t scramble_coop_lds_bytes(int waves) { return (size_t)waves * (QG_WAVE / QG_COOP_LANES) * (R * sizeof(W) + 64 * sizeof(uint32_t)); }
 

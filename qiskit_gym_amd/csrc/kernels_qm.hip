@@ -643,7 +643,19 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
     uint64_t env = tid;
     if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
         constexpr bool coop_fits = scramble_coop_lds_bytes<uint32_t, Rows::R>(4) <= sizeof(lds_rows);
-        const uint32_t count = list_count_take(a.list_count, (coop_fits && a.coop) ? a.B : 0);  // this kernel is the list's only reader
+        const bool tree = a.coop && tree_takes(a.list_count[0], a.n_draws, a.B);  // (a block past the list may see the count already zeroed: it has no work either way)
+        const uint32_t count = list_count_take(a.list_count, (coop_fits && a.coop) ? a.B : 0, tree ? QG_TREE_THREADS : QG_COOP_LANES);  // this kernel is the list's only reader
+        if (tree) {  // few finished envs, long scrambles: a workgroup each, the matrix by columns, the gate sequence cut in four (scramble_tree)
+            const uint32_t N = a.N;
+            Rows s;
+            if (!scramble_tree<Rows::R>(a, count, env, s.r, reinterpret_cast<uint32_t(*)[32]>(&lds_rows[0][0][0]), [N](uint32_t k) -> uint32_t {
+                    const uint32_t j = HAS_Z ? k >> 1 : k;
+                    return j < N ? ((HAS_Z && (k & 1u)) ? (1u << N) << j : 1u << j) : 0u;
+                }))
+                return;
+            qm_init_finish<NXP, HAS_Z>(a, env, s);
+            return;
+        }
         if (coop_fits && a.coop && coop_takes(count, a.B)) {  // few finished envs: 16 lanes each (count * 16 <= B / 2 threads)
             const uint32_t N = a.N;
             const uint32_t *rows = scramble_coop<uint32_t, Rows::R>(a, count, &lds_rows[0][0][0], env, [N](uint32_t k) -> uint32_t {
@@ -854,7 +866,14 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
 }
 template <int NXP, bool HAS_Z>
 static hipError_t launch_init(const InitArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL((qm_init_kernel<NXP, HAS_Z>), dim3(grid_for(a.B, 256)), dim3(256), 0, s, a);
+    // reset_done with a short list: scramble_tree gives each of up to min(QG_TREE_MAX_ENVS, B / 32) listed envs a workgroup (the workgroups
+    // past the list leave at once); every other path needs at most B threads
+    uint64_t threads = a.B;
+    if (a.list && a.coop && a.n_draws >= 64u) {
+        const uint64_t tree_blocks = a.B / 32u < QG_TREE_MAX_ENVS ? a.B / 32u : QG_TREE_MAX_ENVS;
+        if (tree_blocks * QG_TREE_THREADS > threads) threads = tree_blocks * QG_TREE_THREADS;
+    }
+    hipLaunchKernelGGL((qm_init_kernel<NXP, HAS_Z>), dim3(grid_for(threads, 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
