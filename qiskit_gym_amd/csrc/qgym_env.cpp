@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <set>
 #include <vector>
 
@@ -149,20 +150,75 @@ void compute_qubit_and_action_perms(uint32_t N, const std::vector<qg_gate> &gate
 
 }  // namespace qg
 
+// ---- scalar env ---------------------------------------------------------------------------------------------------------------
+// What a call costs is what crosses the host / device boundary, so a qg_env keeps that to one kernel launch and one stream
+// synchronisation per mutating call, and nothing at all per getter:
+//   * its own non-blocking stream: envs stepped from different host threads (twisterl's rayon workers) do not serialise on the null stream;
+//   * one pinned, device-mapped I/O block: the action and the coin are written there by the host and read by the step kernel in place;
+//     reward / is_final / success / depth are the handle's output arrays (qg_vec_bind_outputs) and live there too, so the kernel's results
+//     are in host memory when the stream has drained and reward() / is_final() / success() / masks() are plain loads; the dense
+//     observation lands in a second pinned buffer the same way;
+//   * clone() takes a finished env's handle from a pool when one with the same constructor arguments exists (twisterl clones the
+//     prototype once per episode): no allocation, no constructor launch -- the clone is a handful of device copies.
+struct EnvIO {  // pinned host memory, device-mapped
+    int64_t action;
+    uint8_t coin;
+    uint8_t pad0[7];
+    float reward;
+    uint8_t done, success, pad1[2];
+    int32_t depth;
+    uint32_t error;
+};
+
 struct qg_env {
     qg_vec *v = nullptr;
+    hipStream_t st = nullptr;
+    EnvIO *io = nullptr;      // host address
+    EnvIO *io_dev = nullptr;  // the same block as the device sees it
+    int8_t *obs = nullptr, *obs_dev = nullptr;  // pinned dense observation
+    size_t obs_bytes = 0;
     bool twists_done = false;
     std::vector<Perm> obs_perms, act_perms;
 };
 
-static int env_scalar_u8(const qg_env *e, const uint8_t *dev, uint8_t *out) {
-    if (hipMemcpy(out, dev, 1, hipMemcpyDeviceToHost) != hipSuccess) {
-        (void)hipGetLastError();
-        return set_error(QG_ERR_DEVICE, "device read failed");
+namespace {
+std::mutex g_pool_mutex;
+std::vector<qg_env *> g_pool;            // destroyed envs kept for the next clone
+constexpr size_t POOL_CAP = 4096;
+
+bool same_ctor(const qg_vec *a, const qg_vec *b) {
+    return a->device == b->device && memcmp(&a->cfg, &b->cfg, sizeof a->cfg) == 0 && a->gates.size() == b->gates.size() &&
+           (a->gates.empty() || memcmp(a->gates.data(), b->gates.data(), a->gates.size() * sizeof(qg_gate)) == 0);
+}
+
+void env_free(qg_env *e) {
+    if (!e) return;
+    if (e->v) {
+        qg::DeviceGuard guard(e->v->device);
+        if (e->st) (void)hipStreamSynchronize(e->st);
+        qg_vec_destroy(e->v);  // the output arrays are bound to the I/O block, which is released below
+        if (e->st) (void)hipStreamDestroy(e->st);
+        if (e->io) (void)hipHostFree(e->io);
+        if (e->obs) (void)hipHostFree(e->obs);
     }
-    (void)e;
+    delete e;
+}
+
+// stream drained; a fault the reference panics on becomes QG_ERR_PANIC (qg_vec_sync's rule, from the copy of the error word in the I/O block)
+int env_sync(qg_env *e) {
+    HIP_TRY(hipMemcpyAsync(&e->io->error, e->v->error, sizeof(uint32_t), hipMemcpyDeviceToHost, e->st));
+    HIP_TRY(hipStreamSynchronize(e->st));
+    const uint32_t err = e->io->error;
+    if (err) {
+        const char *what = (err & QG_FAULT_SINGULAR)      ? "singular matrix in inverse() (reference panics, clifford.rs:155)"
+                           : (err & QG_FAULT_ZERO_WEIGHT) ? "weight-0 rotation in the front layer (reference panics, pauli_network.rs:114)"
+                           : (err & QG_FAULT_BAD_STATE)   ? "set_state produced an unusable state"
+                                                          : "solution log overflow (QG_FAULT_SOLUTION_OVERFLOW)";
+        return set_error(QG_ERR_PANIC, "env 0: %s (fault bits 0x%x)", what, err);
+    }
     return QG_OK;
 }
+}  // namespace
 
 extern "C" {
 
@@ -174,34 +230,79 @@ int qg_env_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, in
     if (rc) return rc;
     qg_env *e = new qg_env();
     e->v = v;
+    auto fail = [&](int code) {
+        env_free(e);
+        return code;
+    };
+    QG_ON_DEVICE(v);
+#define HIP_TRY_E(expr)                                                                                          \
+    do {                                                                                                         \
+        hipError_t _e = (expr);                                                                                  \
+        if (_e != hipSuccess) {                                                                                  \
+            (void)hipGetLastError();                                                                             \
+            return fail(set_error(QG_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(_e)));                \
+        }                                                                                                        \
+    } while (0)
+    HIP_TRY_E(hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking));
+    HIP_TRY_E(hipHostMalloc((void **)&e->io, sizeof(EnvIO), hipHostMallocMapped));
+    memset(e->io, 0, sizeof(EnvIO));
+    HIP_TRY_E(hipHostGetDevicePointer((void **)&e->io_dev, e->io, 0));
+    qg_vec_info info;
+    qg_vec_get_info(v, &info);
+    e->obs_bytes = (size_t)info.obs_rows * info.obs_cols;
+    HIP_TRY_E(hipHostMalloc((void **)&e->obs, e->obs_bytes ? e->obs_bytes : 1, hipHostMallocMapped));
+    HIP_TRY_E(hipHostGetDevicePointer((void **)&e->obs_dev, e->obs, 0));
+#undef HIP_TRY_E
+    // the handle's per-env outputs live in the I/O block from here on (their constructor values are carried over)
+    // (the remaining depth stays in device memory: the step kernel reads and writes it, the trait has no getter for it)
+    rc = qg_vec_bind_outputs(v, &e->io_dev->reward, &e->io_dev->done, &e->io_dev->success, nullptr);
+    if (rc) return fail(rc);
     *out = e;
     return QG_OK;
 }
 
 void qg_env_destroy(qg_env *e) {
     if (!e) return;
-    qg_vec_destroy(e->v);
-    delete e;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        if (g_pool.size() < POOL_CAP) {  // kept for the next clone of an env built with the same arguments
+            g_pool.push_back(e);
+            return;
+        }
+    }
+    env_free(e);
 }
 
 int qg_env_clone(const qg_env *e, qg_env **out) {  // Env: DynClone -- deep copy of every resident buffer
     if (!e || !out) return set_error(QG_ERR_INVALID, "null argument");
+    *out = nullptr;
     qg_env *c = nullptr;
-    int rc = qg_env_create(&e->v->cfg, e->v->gates.data(), e->v->gates.size(), e->v->device, &c);
-    if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        for (size_t i = g_pool.size(); i-- > 0;)
+            if (same_ctor(g_pool[i]->v, e->v)) {
+                c = g_pool[i];
+                g_pool.erase(g_pool.begin() + (ptrdiff_t)i);
+                break;
+            }
+    }
+    if (!c) {
+        int rc = qg_env_create(&e->v->cfg, e->v->gates.data(), e->v->gates.size(), e->v->device, &c);
+        if (rc) return rc;
+    }
     const qg_vec *s = e->v;
     qg_vec *d = c->v;
+    QG_ON_DEVICE(d);
     d->difficulty = s->difficulty;
     d->step_index = s->step_index;
     d->coin_seed = s->coin_seed;
     d->maybe_nonsymplectic = s->maybe_nonsymplectic;
     d->observe_counter = s->observe_counter;
+    d->env_base = s->env_base;
+    d->auto_list = d->done_list_fresh = false;
     struct { void *dst; const void *src; size_t bytes; } copies[] = {
         {d->state, s->state, s->state_bytes},
         {d->depth, s->depth, 4},
-        {d->reward, s->reward, 4},
-        {d->done, s->done, 1},
-        {d->success, s->success, 1},
         {d->inverted, s->inverted, 1},
         {d->error, s->error, 4},
         {d->sol_len, s->sol_len, 8},
@@ -211,11 +312,24 @@ int qg_env_clone(const qg_env *e, qg_env **out) {  // Env: DynClone -- deep copy
         {d->perm_idx, s->perm_idx, (size_t)4},                                 // PauliEnv current_perm_idx (pauli.rs:661)
     };
     for (auto &cp : copies)
-        if (cp.dst && cp.src && cp.bytes && hipMemcpy(cp.dst, cp.src, cp.bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+        if (cp.dst && cp.src && cp.bytes && hipMemcpyAsync(cp.dst, cp.src, cp.bytes, hipMemcpyDeviceToDevice, c->st) != hipSuccess) {
             (void)hipGetLastError();
-            qg_env_destroy(c);
+            env_free(c);
             return set_error(QG_ERR_DEVICE, "clone copy failed");
         }
+    // reward / is_final / success / depth: host memory on both sides (the source is idle: every call on it has synchronised)
+    c->io->reward = e->io->reward;
+    c->io->done = e->io->done;
+    c->io->success = e->io->success;
+    c->io->error = e->io->error;
+    c->twists_done = false;
+    c->obs_perms.clear();
+    c->act_perms.clear();
+    if (hipStreamSynchronize(c->st) != hipSuccess) {
+        (void)hipGetLastError();
+        env_free(c);
+        return set_error(QG_ERR_DEVICE, "clone copy failed");
+    }
     *out = c;
     return QG_OK;
 }
@@ -240,33 +354,28 @@ int qg_env_set_state(qg_env *e, const int64_t *state, size_t n) {
     if (!e) return set_error(QG_ERR_INVALID, "null argument");
     if (n == 0 && e->v->layout == LAYOUT_PAULI) return QG_OK;  // pauli.rs:518-520
     if (!state) return set_error(QG_ERR_INVALID, "null argument");
-    int rc = qg_vec_set_state(e->v, state, QG_FMT_I64, n, 0, nullptr);
+    QG_ON_DEVICE(e->v);
+    int rc = qg_vec_set_state(e->v, state, QG_FMT_I64, n, 0, e->st);
     if (rc) return rc;
-    return qg_vec_sync(e->v, nullptr);
+    return env_sync(e);
 }
 
 int qg_env_reset(qg_env *e, uint64_t seed) {
     if (!e) return set_error(QG_ERR_INVALID, "null argument");
-    int rc = qg_vec_reset(e->v, seed, nullptr);
+    QG_ON_DEVICE(e->v);
+    int rc = qg_vec_reset(e->v, seed, e->st);
     if (rc) return rc;
-    return qg_vec_sync(e->v, nullptr);
+    return env_sync(e);
 }
 
 static int env_step(qg_env *e, int64_t action, const uint8_t *coin) {
     if (!e) return set_error(QG_ERR_INVALID, "null argument");
-    qg_vec *v = e->v;
-    int rc = ensure_scratch_public(v, 16);
+    QG_ON_DEVICE(e->v);
+    e->io->action = action;  // read in place by the step kernel
+    if (coin) e->io->coin = *coin;
+    int rc = qg_vec_step(e->v, &e->io_dev->action, QG_ACT_I64, coin ? &e->io_dev->coin : nullptr, e->st);
     if (rc) return rc;
-    int64_t *a_dev = reinterpret_cast<int64_t *>(v->scratch);
-    uint8_t *c_dev = reinterpret_cast<uint8_t *>(v->scratch) + 8;
-    if (hipMemcpy(a_dev, &action, 8, hipMemcpyHostToDevice) != hipSuccess ||
-        (coin && hipMemcpy(c_dev, coin, 1, hipMemcpyHostToDevice) != hipSuccess)) {
-        (void)hipGetLastError();
-        return set_error(QG_ERR_DEVICE, "action upload failed");
-    }
-    rc = qg_vec_step(v, a_dev, QG_ACT_I64, coin ? c_dev : nullptr, nullptr);
-    if (rc) return rc;
-    return qg_vec_sync(v, nullptr);
+    return env_sync(e);
 }
 int qg_env_step(qg_env *e, int64_t action) { return env_step(e, action, nullptr); }
 int qg_env_step_coin(qg_env *e, int64_t action, int coin) {
@@ -274,29 +383,13 @@ int qg_env_step_coin(qg_env *e, int64_t action, int coin) {
     return env_step(e, action, &c);
 }
 
-int qg_env_is_final(const qg_env *e) {
-    uint8_t x = 0;
-    if (!e || env_scalar_u8(e, e->v->done, &x)) return -1;
-    return x;
-}
-int qg_env_success(const qg_env *e) {
-    uint8_t x = 0;
-    if (!e || env_scalar_u8(e, e->v->success, &x)) return -1;
-    return x;
-}
-float qg_env_reward(const qg_env *e) {
-    float r = 0.0f;
-    if (!e || hipMemcpy(&r, e->v->reward, 4, hipMemcpyDeviceToHost) != hipSuccess) {
-        (void)hipGetLastError();
-        set_error(QG_ERR_DEVICE, "device read failed");
-        return 0.0f;
-    }
-    return r;
-}
+// the results of the last mutating call are in the I/O block (every such call drains the env's stream before it returns)
+int qg_env_is_final(const qg_env *e) { return e ? (int)e->io->done : -1; }
+int qg_env_success(const qg_env *e) { return e ? (int)e->io->success : -1; }
+float qg_env_reward(const qg_env *e) { return e ? e->io->reward : 0.0f; }
 int64_t qg_env_masks(const qg_env *e, uint8_t *out, size_t cap) {  // clifford.rs:349-351
     if (!e) return set_error(QG_ERR_INVALID, "null argument");
-    int s = qg_env_success(e);
-    if (s < 0) return QG_ERR_DEVICE;
+    const int s = e->io->success;
     const size_t n = e->v->gates.size();
     for (size_t i = 0; i < n && i < cap; ++i) out[i] = s ? 0 : 1;
     return (int64_t)n;
@@ -305,19 +398,15 @@ int64_t qg_env_masks(const qg_env *e, uint8_t *out, size_t cap) {  // clifford.r
 int64_t qg_env_observe(qg_env *e, int64_t *out, size_t cap) {
     if (!e) return set_error(QG_ERR_INVALID, "null argument");
     qg_vec *v = e->v;
-    qg_vec_info info;
-    qg_vec_get_info(v, &info);
-    const size_t n = (size_t)info.obs_rows * info.obs_cols;
-    int rc = ensure_scratch_public(v, n + 16);
+    QG_ON_DEVICE(v);
+    int rc = qg_vec_observe_dense(v, e->obs_dev, e->st);  // written straight into pinned host memory
     if (rc) return rc;
-    int8_t *dev = reinterpret_cast<int8_t *>(v->scratch) + 16;
-    rc = qg_vec_observe_dense(v, dev, nullptr);
-    if (rc) return rc;
-    std::vector<int8_t> host(n);
-    if (hipMemcpy(host.data(), dev, n, hipMemcpyDeviceToHost) != hipSuccess) {
+    if (hipStreamSynchronize(e->st) != hipSuccess) {
         (void)hipGetLastError();
-        return set_error(QG_ERR_DEVICE, "observation copy failed");
+        return set_error(QG_ERR_DEVICE, "observation failed");
     }
+    const size_t n = e->obs_bytes;
+    const int8_t *host = e->obs;
     int64_t cnt = 0;  // ascending flat indices of the set entries (clifford.rs:361-368)
     for (size_t i = 0; i < n; ++i)
         if (host[i]) {

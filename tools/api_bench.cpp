@@ -94,7 +94,12 @@ int main(int argc, char **argv) {
                 n_steps += k;
             }
         };
-        worker(0);  // warm-up (kernel loads, pools), not timed
+        {   // warm-up, not timed: kernel loads, and one pooled handle per thread (the first clone of a thread allocates; twisterl's workers
+            // live for the whole run, so the steady state is what a collection sees)
+            std::vector<std::thread> warm;
+            for (int t = 0; t < threads; ++t) warm.emplace_back(worker, t);
+            for (auto &t : warm) t.join();
+        }
         n_steps = 0;
         for (auto *v : {&t_clone, &t_reset, &t_loop}) std::fill(v->begin(), v->end(), 0.0);
         const double w0 = now();
