@@ -579,7 +579,10 @@ def main():
                     p2p_view[0] = comm.wait()
                     comm.release()
 
-                timed(step_push_wait, 4)  # first use
+                with torch.cuda.stream(stream):  # first use, checked at once: a peer that never arrives costs one deadline, not one per repetition
+                    step_push_wait()
+                    comm.check()
+                timed(step_push_wait, 4)
                 p2p_step = timed(step_push_wait, 64)
                 p2p_only = timed(push_wait, 16)
                 with torch.cuda.stream(stream):

@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void push_shard_kernel(PushArgs a) {
     if (threadIdx.x == 0) {
         // the parity buffer written now was last read in epoch - 2: the peer must have released it.  The copy proceeds either
         // way -- every block reaches the ticket below -- and the error word tells the host
-        const bool ok = a.epoch <= 2 || poll_at_least(a.local_ack + peer, a.epoch - 2, a.timeout_ticks);
+        // (once one block has run into the deadline the others do not wait it out again: a dead peer costs one timeout, not one per wave of blocks)
+        const bool ok = a.epoch <= 2 || (__hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & QG_COMM_ERR_ACK_TIMEOUT) ||
+                        poll_at_least(a.local_ack + peer, a.epoch - 2, a.timeout_ticks);
         if (!ok) atomicOr(a.error, QG_COMM_ERR_ACK_TIMEOUT);
     }
     __syncthreads();

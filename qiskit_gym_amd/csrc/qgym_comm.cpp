@@ -77,6 +77,7 @@ struct qg_comm {
 
     // all-gather: staged shard(s) and, for the overlapped form, the gathered buffers
     void *snap[2] = {nullptr, nullptr};
+    void *inline_snap = nullptr;  // qg_vec_gather_learner_shard's own staging (the overlapped form may have snap[] in flight)
     void *out[2] = {nullptr, nullptr};
     uint64_t shard_bytes = 0;  // what snap / out are sized for
     hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
@@ -115,13 +116,19 @@ int ensure_gather_buffers(qg_comm *c, uint64_t shard_bytes, bool outputs) {
             if (c->out[b]) HIP_TRY(hipFree(c->out[b]));
             c->snap[b] = c->out[b] = nullptr;
         }
+        if (c->inline_snap) HIP_TRY(hipFree(c->inline_snap));
+        c->inline_snap = nullptr;
         c->shard_bytes = shard_bytes;
         c->pending = c->latest = -1;
         c->submitted = 0;
     }
+    if (!outputs) {
+        if (!c->inline_snap) HIP_TRY(hipMalloc(&c->inline_snap, shard_bytes));
+        return QG_OK;
+    }
     for (int b = 0; b < 2; ++b) {
         if (!c->snap[b]) HIP_TRY(hipMalloc(&c->snap[b], shard_bytes));
-        if (outputs && !c->out[b]) HIP_TRY(hipMalloc(&c->out[b], shard_bytes * (uint64_t)c->world));
+        if (!c->out[b]) HIP_TRY(hipMalloc(&c->out[b], shard_bytes * (uint64_t)c->world));
     }
     return QG_OK;
 }
@@ -231,7 +238,7 @@ void qg_comm_destroy(qg_comm *c) {
         (void)hipDeviceSynchronize();
         for (int p = 0; p < c->world; ++p)
             if (c->opened[p] && c->peer[p]) (void)hipIpcCloseMemHandle(c->peer[p]);
-        for (void *p : {c->snap[0], c->snap[1], c->out[0], c->out[1], c->window, c->stage, (void *)c->ticket, (void *)c->error})
+        for (void *p : {c->snap[0], c->snap[1], c->inline_snap, c->out[0], c->out[1], c->window, c->stage, (void *)c->ticket, (void *)c->error})
             if (p) (void)hipFree(p);
         for (int b = 0; b < 2; ++b) {
             if (c->ready[b]) (void)hipEventDestroy(c->ready[b]);
@@ -255,8 +262,8 @@ int qg_vec_gather_learner_shard(qg_vec *v, qg_comm *c, void *out_dev, void *stre
     qg_shard_layout l;
     qg_vec_learner_shard_layout(v, &l);
     if (int rc = ensure_gather_buffers(c, l.bytes, false)) return rc;
-    if (int rc = qg_vec_pack_learner_shard(v, c->snap[0], stream)) return rc;
-    NCCL_TRY(rccl().AllGather(c->snap[0], out_dev, l.bytes, ncclInt8, c->nccl, (hipStream_t)stream));
+    if (int rc = qg_vec_pack_learner_shard(v, c->inline_snap, stream)) return rc;
+    NCCL_TRY(rccl().AllGather(c->inline_snap, out_dev, l.bytes, ncclInt8, c->nccl, (hipStream_t)stream));
     return QG_OK;
 }
 

@@ -175,7 +175,7 @@ struct qg_env {
     hipStream_t st = nullptr;
     EnvIO *io = nullptr;      // host address
     EnvIO *io_dev = nullptr;  // the same block as the device sees it
-    int8_t *obs = nullptr, *obs_dev = nullptr;  // pinned dense observation
+    int8_t *obs = nullptr, *obs_dev = nullptr;  // the dense observation, in the same pinned allocation behind the I/O block
     size_t obs_bytes = 0;
     bool twists_done = false;
     std::vector<Perm> obs_perms, act_perms;
@@ -184,7 +184,7 @@ struct qg_env {
 namespace {
 std::mutex g_pool_mutex;
 std::vector<qg_env *> g_pool;            // destroyed envs kept for the next clone
-constexpr size_t POOL_CAP = 4096;
+constexpr size_t POOL_CAP = 256;         // a few per host thread (rl/configs.py:135 num_cores = 32); beyond it destroy() frees
 
 bool same_ctor(const qg_vec *a, const qg_vec *b) {
     return a->device == b->device && memcmp(&a->cfg, &b->cfg, sizeof a->cfg) == 0 && a->gates.size() == b->gates.size() &&
@@ -198,8 +198,7 @@ void env_free(qg_env *e) {
         if (e->st) (void)hipStreamSynchronize(e->st);
         qg_vec_destroy(e->v);  // the output arrays are bound to the I/O block, which is released below
         if (e->st) (void)hipStreamDestroy(e->st);
-        if (e->io) (void)hipHostFree(e->io);
-        if (e->obs) (void)hipHostFree(e->obs);
+        if (e->io) (void)hipHostFree(e->io);  // the observation buffer lives in the same allocation
     }
     delete e;
 }
@@ -234,7 +233,11 @@ int qg_env_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, in
         env_free(e);
         return code;
     };
-    QG_ON_DEVICE(v);
+    qg::DeviceGuard guard(v->device);
+    if (guard.err != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(set_error(QG_ERR_DEVICE, "cannot select device %d: %s", v->device, hipGetErrorString(guard.err)));
+    }
 #define HIP_TRY_E(expr)                                                                                          \
     do {                                                                                                         \
         hipError_t _e = (expr);                                                                                  \
@@ -244,14 +247,15 @@ int qg_env_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, in
         }                                                                                                        \
     } while (0)
     HIP_TRY_E(hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking));
-    HIP_TRY_E(hipHostMalloc((void **)&e->io, sizeof(EnvIO), hipHostMallocMapped));
-    memset(e->io, 0, sizeof(EnvIO));
-    HIP_TRY_E(hipHostGetDevicePointer((void **)&e->io_dev, e->io, 0));
     qg_vec_info info;
     qg_vec_get_info(v, &info);
     e->obs_bytes = (size_t)info.obs_rows * info.obs_cols;
-    HIP_TRY_E(hipHostMalloc((void **)&e->obs, e->obs_bytes ? e->obs_bytes : 1, hipHostMallocMapped));
-    HIP_TRY_E(hipHostGetDevicePointer((void **)&e->obs_dev, e->obs, 0));
+    static_assert(sizeof(EnvIO) <= 64, "the observation starts 64 bytes into the pinned block");
+    HIP_TRY_E(hipHostMalloc((void **)&e->io, 64 + e->obs_bytes, hipHostMallocMapped));  // one pinned allocation per env
+    memset(e->io, 0, 64 + e->obs_bytes);
+    HIP_TRY_E(hipHostGetDevicePointer((void **)&e->io_dev, e->io, 0));
+    e->obs = reinterpret_cast<int8_t *>(e->io) + 64;
+    e->obs_dev = reinterpret_cast<int8_t *>(e->io_dev) + 64;
 #undef HIP_TRY_E
     // the handle's per-env outputs live in the I/O block from here on (their constructor values are carried over)
     // (the remaining depth stays in device memory: the step kernel reads and writes it, the trait has no getter for it)

@@ -24,7 +24,9 @@ RUNS = {
     "bench": ("qm_step1_kernel<16, true, false", 65536, 160, 90),
     "C3_1048576": ("qm_step1_kernel<16, true, false", 1048576, 160, 90),
     "C3_4194304": ("qm_step1_kernel<16, true, false", 4194304, 160, 90),
-    "C3d": ("qm_inv2_kernel<16, true", 2 * 65536, 160, 160),  # two lanes per env: Grid_Size is 2 x envs
+    # two lanes per env: Grid_Size is 2 x envs.  Needed: 128 B of state read; the envs whose coin fired (half) rewrite all 128 B, the others the
+    # gate's <= 2 groups (~24 B): 76 B on average; action 4, coin 1, depth 4 + 4, flags 1 + 1, log lengths 8 + 8, log entry 4, reward 4, done 1, success 1
+    "C3d": ("qm_inv2_kernel<16, true", 2 * 65536, 160, 245),
     "C2": ("word_step_kernel<false>", 8192, 32, 32),
     # two 12-byte qubit records read and written, the 64-byte rotation block's touched 16-bit slices + bookkeeping, 22 B of scalars
     "C5": ("ptile_step1c_kernel<20, 8", 65536, 494, 130),
