@@ -177,6 +177,9 @@ struct qg_env {
     EnvIO *io_dev = nullptr;  // the same block as the device sees it
     int8_t *obs = nullptr, *obs_dev = nullptr;  // the dense observation, in the same pinned allocation behind the I/O block
     size_t obs_bytes = 0;
+    bool obs_ahead = false;  // observe() is a pure function of the state (every env but PauliEnv with add_perms, whose observe() draws a
+                             // permutation per call, pauli.rs:653-665): the call that changes the state writes the next observation too
+    bool obs_valid = false;  // the pinned buffer holds the observation of the current state
     bool twists_done = false;
     std::vector<Perm> obs_perms, act_perms;
 };
@@ -203,8 +206,15 @@ void env_free(qg_env *e) {
     delete e;
 }
 
-// stream drained; a fault the reference panics on becomes QG_ERR_PANIC (qg_vec_sync's rule, from the copy of the error word in the I/O block)
+// stream drained; a fault the reference panics on becomes QG_ERR_PANIC (qg_vec_sync's rule, from the copy of the error word in the I/O block).
+// Called at the end of every call that changes the state: the next observe() is enqueued behind it first, so that the collection loop's
+// observe() / step() pair costs one stream synchronisation, not two.
 int env_sync(qg_env *e) {
+    e->obs_valid = false;
+    if (e->obs_ahead) {
+        if (int rc = qg_vec_observe_dense(e->v, e->obs_dev, e->st)) return rc;
+        e->obs_valid = true;
+    }
     HIP_TRY(hipMemcpyAsync(&e->io->error, e->v->error, sizeof(uint32_t), hipMemcpyDeviceToHost, e->st));
     HIP_TRY(hipStreamSynchronize(e->st));
     const uint32_t err = e->io->error;
@@ -257,6 +267,7 @@ int qg_env_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, in
     e->obs = reinterpret_cast<int8_t *>(e->io) + 64;
     e->obs_dev = reinterpret_cast<int8_t *>(e->io_dev) + 64;
 #undef HIP_TRY_E
+    e->obs_ahead = !(v->layout == LAYOUT_PAULI && v->n_perms > 0);
     // the handle's per-env outputs live in the I/O block from here on (their constructor values are carried over)
     // (the remaining depth stays in device memory: the step kernel reads and writes it, the trait has no getter for it)
     rc = qg_vec_bind_outputs(v, &e->io_dev->reward, &e->io_dev->done, &e->io_dev->success, nullptr);
@@ -326,6 +337,11 @@ int qg_env_clone(const qg_env *e, qg_env **out) {  // Env: DynClone -- deep copy
     c->io->done = e->io->done;
     c->io->success = e->io->success;
     c->io->error = e->io->error;
+    c->obs_valid = false;
+    if (c->obs_ahead && e->obs_valid) {  // the source's observation is the clone's
+        memcpy(c->obs, e->obs, e->obs_bytes);
+        c->obs_valid = true;
+    }
     c->twists_done = false;
     c->obs_perms.clear();
     c->act_perms.clear();
@@ -402,12 +418,15 @@ int64_t qg_env_masks(const qg_env *e, uint8_t *out, size_t cap) {  // clifford.r
 int64_t qg_env_observe(qg_env *e, int64_t *out, size_t cap) {
     if (!e) return set_error(QG_ERR_INVALID, "null argument");
     qg_vec *v = e->v;
-    QG_ON_DEVICE(v);
-    int rc = qg_vec_observe_dense(v, e->obs_dev, e->st);  // written straight into pinned host memory
-    if (rc) return rc;
-    if (hipStreamSynchronize(e->st) != hipSuccess) {
-        (void)hipGetLastError();
-        return set_error(QG_ERR_DEVICE, "observation failed");
+    if (!e->obs_valid) {  // PauliEnv with add_perms (a draw per call), or a state nobody has observed yet
+        QG_ON_DEVICE(v);
+        int rc = qg_vec_observe_dense(v, e->obs_dev, e->st);  // written straight into pinned host memory
+        if (rc) return rc;
+        if (hipStreamSynchronize(e->st) != hipSuccess) {
+            (void)hipGetLastError();
+            return set_error(QG_ERR_DEVICE, "observation failed");
+        }
+        e->obs_valid = e->obs_ahead;
     }
     const size_t n = e->obs_bytes;
     const int8_t *host = e->obs;
