@@ -1282,6 +1282,16 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
     // the tableau scramble runs on LDS-resident rows ([row][lane], conflict-free for any per-lane row): a
     // random CX / H / S is one or two row operations instead of a select sweep over 2N 64-bit registers
     __shared__ uint64_t lds_tab[2 * NQ][QG_WAVE];
+    // the scramble looks a CX pair up for most of its `difficulty` gates: from a copy in LDS, not from global memory behind the draw that picks it
+    // (a dependent global load per gate was most of this kernel: 256 gates x ~0.5 us).  Copied by the whole wave, before any lane leaves.
+    constexpr uint32_t CX_LDS = 1024;  // pairs (every ordered pair of 32 qubits is 992)
+    __shared__ uint8_t lds_cx[2 * CX_LDS];
+    const bool cx_in_lds = ga.n_cx <= CX_LDS;
+    if (cx_in_lds) {
+        for (uint32_t i = threadIdx.x; i < 2u * ga.n_cx; i += QG_WAVE) lds_cx[i] = ga.cx_pairs[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t env = tid;
     if (ga.list) {
@@ -1380,24 +1390,38 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
         lds_tab[NQ + j][L] = (uint32_t)j < N ? (1ull << N) << j : 0ull;
     }
     if (ga.difficulty != 0 && ga.n_cx != 0) {
-        for (uint32_t it = 0; it < ga.difficulty; ++it) {
-            const float r = rng.f32();
-            if (r > 0.3f) {  // CX: row q1 ^= row q0 ; row n+q0 ^= row n+q1
-                const uint32_t k = rng.range(ga.n_cx);
-                const uint32_t q0 = ga.cx_pairs[2 * k], q1 = ga.cx_pairs[2 * k + 1];
-                const uint64_t x0 = lds_tab[q0][L], z1 = lds_tab[NQ + q1][L];
-                lds_tab[q1][L] ^= x0;       // a CX(q, q) entry xors the rows into themselves: both become zero
-                lds_tab[NQ + q0][L] ^= z1;
-            } else if (r > 0.15f) {  // H: swap rows q, n+q
-                const uint32_t q = rng.range(N);
-                const uint64_t x = lds_tab[q][L], z = lds_tab[NQ + q][L];
-                lds_tab[q][L] = z;
-                lds_tab[NQ + q][L] = x;
-            } else {  // S: row n+q ^= row q
-                const uint32_t q = rng.range(N);
-                lds_tab[NQ + q][L] ^= lds_tab[q][L];
+        // gate `it` takes draws k0 + 2 it (kind) and k0 + 2 it + 1 (which pair / qubit) of the env's stream: the counter RNG makes every draw a
+        // function of its index, so four gates' draws are computed ahead of the dependent chain of LDS row operations
+        const uint64_t k0 = rng.k;
+        for (uint32_t it0 = 0; it0 < ga.difficulty; it0 += 4) {
+            uint64_t d1[4], d2[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                d1[j] = rng_draw(rng.seed, rng.env, k0 + 2ull * (it0 + j));
+                d2[j] = rng_draw(rng.seed, rng.env, k0 + 2ull * (it0 + j) + 1ull);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                if (it0 + j >= ga.difficulty) break;
+                const float r = (float)(d1[j] >> 40) * (1.0f / 16777216.0f);
+                if (r > 0.3f) {  // CX: row q1 ^= row q0 ; row n+q0 ^= row n+q1
+                    const uint32_t k = (uint32_t)__umul64hi(d2[j], (uint64_t)ga.n_cx);
+                    const uint32_t q0 = cx_in_lds ? lds_cx[2 * k] : ga.cx_pairs[2 * k], q1 = cx_in_lds ? lds_cx[2 * k + 1] : ga.cx_pairs[2 * k + 1];
+                    const uint64_t x0 = lds_tab[q0][L], z1 = lds_tab[NQ + q1][L];
+                    lds_tab[q1][L] ^= x0;       // a CX(q, q) entry xors the rows into themselves: both become zero
+                    lds_tab[NQ + q0][L] ^= z1;
+                } else if (r > 0.15f) {  // H: swap rows q, n+q
+                    const uint32_t q = (uint32_t)__umul64hi(d2[j], (uint64_t)N);
+                    const uint64_t x = lds_tab[q][L], z = lds_tab[NQ + q][L];
+                    lds_tab[q][L] = z;
+                    lds_tab[NQ + q][L] = x;
+                } else {  // S: row n+q ^= row q
+                    const uint32_t q = (uint32_t)__umul64hi(d2[j], (uint64_t)N);
+                    lds_tab[NQ + q][L] ^= lds_tab[q][L];
+                }
             }
         }
+        rng.k = k0 + 2ull * ga.difficulty;
     }
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
