@@ -166,3 +166,39 @@ def test_done_list_survives_graph_replays_of_single_steps(kind, n, inverts):
             e.step(acts[t], coins[t])
             e.reset_done(300 + t)
         _same(g, e)
+
+
+@pytest.mark.parametrize("kind,n,diff", [("clifford", 16, 256), ("clifford", 6, 101), ("clifford", 11, 64), ("linear_function", 20, 130), ("linear_function", 32, 67)])
+def test_reset_done_of_a_few_envs_with_long_scrambles_matches_the_oracle(kind, n, diff):
+    """Short lists of long scrambles take scramble_tree (a workgroup per env, the matrix by columns, the gate sequence cut in four and
+    multiplied back as GF(2) matrices): the state it leaves must be the oracle's identity + `difficulty` gates drawn by global env id, for
+    list lengths on both sides of its limits, with the other envs untouched."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    gs = line_gateset(kind, n)
+    A, B, base = len(gs), 8192, 1000
+    cfg = dict(add_inverts=False, add_perms=False, track_solution=False, difficulty=diff)
+    gv = VecEnv(kind, n, gs, B, env_base=base, **cfg)
+    gv.reset(7)
+    ref = gv.get_state("packed").clone()
+    rng = np.random.default_rng(diff)
+    for count in (1, 37, 256, 300):  # 256 = B / 32 is the longest list the short-list kernels take; 300 goes to the thread-per-env path
+        ids = np.sort(rng.choice(B, size=count, replace=False))
+        gv.done[:] = 0
+        gv.done[torch.as_tensor(ids, device="cuda")] = 1
+        seed = 9000 + count
+        gv.reset_done(seed)
+        gv.sync()
+        proto = OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()})
+        from oracle import OracleVec
+        ov = OracleVec(proto, count)
+        ov.reset_with(rng_actions(seed, base + ids, diff, A))
+        D = 2 * n if kind == "clifford" else n
+        got = gv.get_state("i64").cpu().numpy()
+        np.testing.assert_array_equal(got[ids], ov.get_state(D * D), err_msg=f"count={count}")
+        mask = np.ones(B, dtype=bool)
+        mask[ids] = False
+        packed = gv.get_state("packed")
+        assert torch.equal(packed[torch.as_tensor(mask, device="cuda")], ref[torch.as_tensor(mask, device="cuda")]), "a live env was touched"
+        ref = packed.clone()
+        assert (gv.depth.cpu().numpy()[ids] == min(2 * diff, 128)).all()  # clifford.rs:317
