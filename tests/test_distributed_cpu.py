@@ -106,3 +106,37 @@ def test_unpack_rows_matches_numpy():
     packed = (dense << np.arange(32, dtype=np.uint64)).sum(axis=2).astype(np.uint32).view(np.int32)
     got = unpack_rows_u32(torch.from_numpy(packed.copy()), 32).numpy()
     np.testing.assert_array_equal(got, dense.astype(np.int8))
+
+
+def test_split_gathered_follows_the_c_layout():
+    """`split_gathered` on a hand-built buffer laid out as include/qgym.h's qg_shard_layout says (sections 4-byte aligned, shard padded to
+    16 bytes), for a batch that needs every kind of padding and for 1- / 4- / 8-byte observation words; `learner_shard_words` agrees with it."""
+    from types import SimpleNamespace
+
+    from qiskit_gym_amd.distributed import split_gathered
+
+    rng = np.random.default_rng(3)
+    for batch, words, wb in ((97, 32, 4), (5, 9, 1), (130, 40, 8)):
+        world = 3
+        obs_bytes = batch * words * wb
+        ro = (obs_bytes + 3) // 4 * 4
+        fo = ro + 4 * batch
+        so = fo + (batch + 3) // 4 * 4
+        total = (so + batch + 15) // 16 * 16
+        lay = SimpleNamespace(batch=batch, bytes=total, obs_offset=0, obs_bytes=obs_bytes, reward_offset=ro, final_offset=fo, success_offset=so)
+        if wb == 4:
+            assert learner_shard_words(batch, words) * 4 == total
+        dt = {1: np.uint8, 4: np.int32, 8: np.int64}[wb]
+        obs = rng.integers(0, 100, size=(world, batch, words)).astype(dt)
+        rew = rng.standard_normal((world, batch)).astype(np.float32)
+        fin = rng.integers(0, 2, size=(world, batch)).astype(np.uint8)
+        suc = rng.integers(0, 2, size=(world, batch)).astype(np.uint8)
+        buf = np.zeros((world, total), dtype=np.uint8)
+        for r in range(world):
+            buf[r, :obs_bytes] = obs[r].view(np.uint8).reshape(-1)
+            buf[r, ro:ro + 4 * batch] = rew[r].view(np.uint8)
+            buf[r, fo:fo + batch] = fin[r]
+            buf[r, so:so + batch] = suc[r]
+        o, rw, f, s = split_gathered(torch.from_numpy(buf.reshape(-1)), lay, world, wb)
+        assert np.array_equal(o.numpy().view(dt), obs.reshape(world * batch, words))
+        assert np.array_equal(rw.numpy(), rew.reshape(-1)) and np.array_equal(f.numpy(), fin.reshape(-1)) and np.array_equal(s.numpy(), suc.reshape(-1))
