@@ -155,9 +155,9 @@ void compute_qubit_and_action_perms(uint32_t N, const std::vector<qg_gate> &gate
 // synchronisation per mutating call, and nothing at all per getter:
 //   * its own non-blocking stream: envs stepped from different host threads (twisterl's rayon workers) do not serialise on the null stream;
 //   * one pinned, device-mapped I/O block: the action and the coin are written there by the host and read by the step kernel in place;
-//     reward / is_final / success / depth are the handle's output arrays (qg_vec_bind_outputs) and live there too, so the kernel's results
-//     are in host memory when the stream has drained and reward() / is_final() / success() / masks() are plain loads; the dense
-//     observation lands in a second pinned buffer the same way;
+//     reward / is_final / success are the handle's output arrays (qg_vec_bind_outputs) and live there too, so the kernel's results are in
+//     host memory when the stream has drained and reward() / is_final() / success() / masks() are plain loads; the dense observation of
+//     the new state is written behind the I/O block by the same call (env_sync), so the loop's observe() is a scan of host memory;
 //   * clone() takes a finished env's handle from a pool when one with the same constructor arguments exists (twisterl clones the
 //     prototype once per episode): no allocation, no constructor launch -- the clone is a handful of device copies.
 struct EnvIO {  // pinned host memory, device-mapped
