@@ -171,6 +171,14 @@ int qg_vec_reset(qg_vec *v, uint64_t seed, void *stream);
  * Lets a GPU-resident collector run episode after episode without a host round trip; pass a
  * fresh seed per call (e.g. a step counter) so successive episodes of an env differ. */
 int qg_vec_reset_done(qg_vec *v, uint64_t seed, void *stream);
+/* Capturing these calls into a caller's hipGraph: once qg_vec_reset_done is in use on a handle, a single qg_vec_step (and the sampling +
+ * step calls) leaves the list of the envs it finished for the reset that follows, so that reset needs no compaction launch.  The list
+ * lives on the device and every launch that appends to it expects it empty; what the host believes about it only holds within one
+ * "session" -- one stream capture, or eager execution on a handle none of whose list launches was ever captured.  The library
+ * therefore (a) zeroes the list (a captured memset) before the first appending launch of every capture and compacts the `done` flags
+ * itself at the first qg_vec_reset_done of every capture, (b) after any capture, trusts no list in eager calls (they compact every
+ * time), and (c) bounds every append by the batch size on the device.  Any order of replays, eager steps and eager resets gives the
+ * results of the same calls made eagerly; the cheapest graph is the one that captures step and reset_done together. */
 /* Device clock for launches that are replayed from a captured hipGraph (kernel arguments, hence
  * seeds and RNG counters, are baked into a graph).  While set, every kernel of this handle adds
  * *clock_dev to its RNG counter: reset / reset_done draw with seed + 0x9E3779B9 * clock, the
