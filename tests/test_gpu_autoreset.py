@@ -202,3 +202,44 @@ def test_reset_done_of_a_few_envs_with_long_scrambles_matches_the_oracle(kind, n
         assert torch.equal(packed[torch.as_tensor(mask, device="cuda")], ref[torch.as_tensor(mask, device="cuda")]), "a live env was touched"
         ref = packed.clone()
         assert (gv.depth.cpu().numpy()[ids] == min(2 * diff, 128)).all()  # clifford.rs:317
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_reset_done_random_shapes_against_the_oracle(case):
+    """Random env kind / size / difficulty / batch / fraction of finished envs: whichever reset path the library picks (thread per env,
+    16 lanes per env, a workgroup per env with the product tree; 32- and 64-bit rows) must leave the oracle's state for the finished envs
+    and nothing else.  QGYM_FUZZ_SEED_OFFSET shifts the cases."""
+    import os
+
+    from oracle import OracleVec
+    from qiskit_gym_amd.vec import VecEnv
+
+    rng = np.random.default_rng(4242 + case + int(os.environ.get("QGYM_FUZZ_SEED_OFFSET", "0")))
+    kind = ["clifford", "linear_function"][int(rng.integers(0, 2))]
+    n = int(rng.integers(3, 33)) if kind == "clifford" else int(rng.integers(9, 65))
+    diff = int(rng.choice([1, 5, 40, 64, 65, 100, 200, 256]))
+    B = int(rng.choice([64, 1000, 4096, 20000]))
+    gs = line_gateset(kind, n)
+    A = len(gs)
+    cfg = dict(add_inverts=False, add_perms=False, track_solution=False, difficulty=diff)
+    base = int(rng.integers(0, 1 << 20))
+    gv = VecEnv(kind, n, gs, B, env_base=base, **cfg)
+    gv.reset(3)
+    D = 2 * n if kind == "clifford" else n
+    for rep in range(3):
+        frac = float(rng.choice([0.002, 0.02, 0.1, 0.6]))
+        count = max(1, min(B, int(B * frac)))
+        ids = np.sort(rng.choice(B, size=count, replace=False))
+        before = gv.get_state("packed").clone()
+        gv.done[:] = 0
+        gv.done[torch.as_tensor(ids, device="cuda")] = 1
+        seed = int(rng.integers(0, 1 << 40))
+        gv.reset_done(seed)
+        gv.sync()
+        ov = OracleVec(OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()}), count)
+        ov.reset_with(rng_actions(seed, base + ids, diff, A))
+        got = gv.get_state("i64").cpu().numpy()
+        np.testing.assert_array_equal(got[ids], ov.get_state(D * D), err_msg=f"{kind} {n}q diff {diff} B {B} count {count}")
+        mask = torch.ones(B, dtype=torch.bool, device="cuda")
+        mask[torch.as_tensor(ids, device="cuda")] = False
+        assert torch.equal(gv.get_state("packed")[mask], before[mask]), "a live env was touched"
