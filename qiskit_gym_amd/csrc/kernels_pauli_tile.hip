@@ -1292,6 +1292,19 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    // ... and so do the label generator's tables (distance classes and their qubit pairs): its loops walk them with dependent loads,
+    // ~1 us each from global memory, ~40 per rotation label (PauliGym 20q, 1 % of 65 536 envs finished: 162 -> see profiles/r03)
+    __shared__ uint32_t lds_dvals[32], lds_doff[33];
+    __shared__ uint8_t lds_pairs[2 * 496];  // N (N - 1) / 2 pairs, N <= 32
+    {
+        const uint32_t nd = ga.nd < 32u ? ga.nd : 32u;
+        for (uint32_t i = threadIdx.x; i < nd; i += QG_WAVE) lds_dvals[i] = ga.dvals[i];
+        for (uint32_t i = threadIdx.x; i <= nd; i += QG_WAVE) lds_doff[i] = ga.doff[i];
+        const uint32_t n_pairs = ga.doff[nd] < 496u ? ga.doff[nd] : 496u;
+        for (uint32_t i = threadIdx.x; i < 2u * n_pairs; i += QG_WAVE) lds_pairs[i] = ga.pairs[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t env = tid;
     if (ga.list) {
@@ -1316,29 +1329,29 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
     while (remaining > 0 && n_lab < ga.max_paulis) {
         const uint32_t difficulty = remaining;  // get_pauli_under_diff(remaining) (pauli.rs:115-188)
         uint32_t nvd = 0;
-        for (uint32_t i = 0; i < ga.nd; ++i) nvd += ga.dvals[i] <= difficulty;
+        for (uint32_t i = 0; i < ga.nd; ++i) nvd += lds_dvals[i] <= difficulty;
         if (nvd == 0) break;
         uint32_t inset = 0, budget = difficulty;
         uint32_t di = rng.range(nvd);
-        uint32_t d = ga.dvals[di];
-        uint32_t pick = ga.doff[di] + rng.range(ga.doff[di + 1] - ga.doff[di]);
-        inset |= (1u << ga.pairs[2 * pick]) | (1u << ga.pairs[2 * pick + 1]);
+        uint32_t d = lds_dvals[di];
+        uint32_t pick = lds_doff[di] + rng.range(lds_doff[di + 1] - lds_doff[di]);
+        inset |= (1u << lds_pairs[2 * pick]) | (1u << lds_pairs[2 * pick + 1]);
         budget = budget > d ? budget - d : 0;
         for (;;) {
             uint32_t nv2 = 0;
-            for (uint32_t i = 0; i < nvd; ++i) nv2 += ga.dvals[i] <= budget;
+            for (uint32_t i = 0; i < nvd; ++i) nv2 += lds_dvals[i] <= budget;
             if (budget == 0 || nv2 == 0 || (uint32_t)__popc(inset) >= N) break;
             if (rng.f32() <= ga.decay) break;  // continue with probability 1 - num_qubits_decay
             di = rng.range(nv2);
-            d = ga.dvals[di];
+            d = lds_dvals[di];
             uint32_t nc = 0;
-            for (uint32_t p = ga.doff[di]; p < ga.doff[di + 1]; ++p) nc += ((inset >> ga.pairs[2 * p]) | (inset >> ga.pairs[2 * p + 1])) & 1u;
+            for (uint32_t p = lds_doff[di]; p < lds_doff[di + 1]; ++p) nc += ((inset >> lds_pairs[2 * p]) | (inset >> lds_pairs[2 * p + 1])) & 1u;
             if (nc == 0) continue;
             uint32_t want = rng.range(nc);
-            for (uint32_t p = ga.doff[di]; p < ga.doff[di + 1]; ++p) {
-                if (((inset >> ga.pairs[2 * p]) | (inset >> ga.pairs[2 * p + 1])) & 1u) {
+            for (uint32_t p = lds_doff[di]; p < lds_doff[di + 1]; ++p) {
+                if (((inset >> lds_pairs[2 * p]) | (inset >> lds_pairs[2 * p + 1])) & 1u) {
                     if (want == 0) {
-                        inset |= (1u << ga.pairs[2 * p]) | (1u << ga.pairs[2 * p + 1]);
+                        inset |= (1u << lds_pairs[2 * p]) | (1u << lds_pairs[2 * p + 1]);
                         break;
                     }
                     --want;
