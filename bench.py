@@ -277,7 +277,7 @@ def launch_ranks(n: int, argv) -> int:
     parent may already have touched the HIP runtime -- counting devices can initialise it -- which is exactly why the ranks are a fresh child
     and never an exec of this process (a process that has touched the GPU must not be replaced by another program)."""
     visible = torch.cuda.device_count()
-    if visible < n:
+    if visible < n and "--ranks-share-gpu0" not in argv:
         print(f"bench.py: --gpus {n} requested but only {visible} GPU(s) are visible; refusing to run fewer ranks and report them as {n}",
               file=sys.stderr)
         return 2
@@ -314,6 +314,12 @@ def main():
     ap.add_argument("--no-collector", action="store_true", help="skip the policy-in-the-loop leg (SURVEY 8f-3: collection with the reference's default policy shape)")
     ap.add_argument("--no-gather", action="store_true", help="N>1 diagnostics: step only, no all-gather")
     ap.add_argument("--no-p2p", action="store_true", help="N>1: skip the direct-write (hipIpc windows over xGMI) cadence leg")
+    ap.add_argument("--handover", choices=["rccl", "direct"], default="rccl",
+                    help="N>1: transport of the learner shard inside the timed region: ncclAllGather called from libqgym on a side stream (default), or the "
+                         "direct write into every rank's hipIpc window (no RCCL at all: communicator handles travel over the control plane)")
+    ap.add_argument("--ranks-share-gpu0", action="store_true",
+                    help="diagnostics: every rank uses GPU 0 (a whole N-rank job -- control plane, sharding, hand-over, parity -- on a one-GPU box; needs "
+                         "--handover direct, RCCL refuses two ranks on one GPU)")
     ap.add_argument("--gather-every", type=int, default=CHUNK,
                     help="N>1: all-gather the learner shard every min(this, --steps) steps (1 = after every step)")
     ap.add_argument("--envs", type=int, default=ENVS_PER_GPU,
@@ -345,6 +351,10 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.ranks_share_gpu0:
+        if args.handover != "direct":
+            ap.error("--ranks-share-gpu0 needs --handover direct")
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         print(f"bench.py: rank {rank} has LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
         sys.exit(2)
@@ -367,9 +377,12 @@ def main():
             raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, expected {world}")
         from qiskit_gym_amd.distributed import Communicator
 
-        uid = [Communicator.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        comm = Communicator(rank, world, device=local_rank, unique_id=uid[0])  # ncclCommInitRank inside libqgym
+        if args.handover == "rccl":
+            uid = [Communicator.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = Communicator(rank, world, device=local_rank, unique_id=uid[0])  # ncclCommInitRank inside libqgym
+        else:
+            comm = Communicator(rank, world, device=local_rank, local=True)  # windows are connected below, once the shard size is known
     else:
         torch.cuda.set_device(0)
     n_gpus = world
@@ -432,14 +445,28 @@ def main():
         # success [B] bytes each -- one ncclAllGather instead of four
         layout = env.shard_layout()
 
+        direct = args.handover == "direct"
+        if direct:  # hipIpc handles over the control plane (gloo), then every rank maps every other rank's window
+            mine = comm.p2p_export(int(layout.bytes))
+            handles = [None] * world
+            dist.all_gather_object(handles, mine)
+            comm.p2p_open(handles)
+            dist.barrier()
+        direct_latest = [None]
+
         def snapshot_and_gather():
-            comm.submit(env)
+            if direct:  # pack + one copy kernel into all windows + flags, on the step stream; the view is copied out before the window is released
+                comm.push(env)
+                direct_latest[0] = comm.wait().clone()
+                comm.release()
+            else:
+                comm.submit(env)
             gather_log["submitted"] += 1
             gather_log["trace_len"] = len(ring_trace)
 
         class _Flush:
-            flush = staticmethod(lambda: comm.flush())
-            latest = staticmethod(lambda: comm.latest())
+            flush = staticmethod(lambda: None if direct else comm.flush())
+            latest = staticmethod(lambda: direct_latest[0] if direct else comm.latest())
 
         gatherer = _Flush
 
@@ -533,6 +560,12 @@ def main():
         gshard = {"obs": g_obs[lo:lo + B][idx].cpu().numpy(), "reward": g_rew[lo:lo + B][idx].cpu().numpy(),
                   "done": g_done[lo:lo + B][idx].cpu().numpy(), "success": g_succ[lo:lo + B][idx].cpu().numpy(),
                   "trace": ring_trace[:gather_log["trace_len"]]}
+        if world > 1:  # ... and the LAST rank's part, which only the hand-over can have brought here (its envs, its slice of the actions)
+            plo = (world - 1) * B
+            gshard["peer"] = {"obs": g_obs[plo:plo + B][idx].cpu().numpy(), "reward": g_rew[plo:plo + B][idx].cpu().numpy(),
+                              "done": g_done[plo:plo + B][idx].cpu().numpy(), "success": g_succ[plo:plo + B][idx].cpu().numpy(),
+                              "trace": gshard["trace"], "global_ids": plo + ids,
+                              "actions": global_actions(seed, total_envs, A)[:, plo:plo + B][:, ids].numpy()}
         if args.dump_gathered:
             np.savez(args.dump_gathered, global_ids=env_base + ids, actions=snap_actions, seed=np.uint64(seed), scramble=SCRAMBLE,
                      trace=np.asarray(gshard["trace"], dtype=np.int64), obs=gshard["obs"], reward=gshard["reward"], done=gshard["done"],
@@ -540,7 +573,10 @@ def main():
 
     # ---- collective cadences, beside the timed region (N > 1 or --force-multi) -------------------
     cadence = None
-    if multi and not args.no_gather:
+    if multi and not args.no_gather and args.handover == "direct":
+        with torch.cuda.stream(stream):
+            comm.check()  # a peer that missed a deadline during the run is an error, not a slow number
+    if multi and not args.no_gather and args.handover == "rccl":
         def timed(fn, reps):
             torch.cuda.synchronize()
             if dist is not None:
@@ -873,6 +909,11 @@ def main():
                 parity["gathered_shard"] = gathered_parity(gateset, seed, env_base + ids, snap_actions, gshard["trace"], gshard)
                 if not parity["gathered_shard"]["bit_exact"]:
                     raise SystemExit(f"bench.py: the all-gathered shard differs from the CPU oracle replay: {parity['gathered_shard']}")
+                if "peer" in gshard:
+                    pg = gshard["peer"]
+                    parity["gathered_shard_of_last_rank"] = gathered_parity(gateset, seed, pg["global_ids"], pg["actions"], pg["trace"], pg)
+                    if not parity["gathered_shard_of_last_rank"]["bit_exact"]:
+                        raise SystemExit(f"bench.py: the last rank's part of the gathered shard differs from the CPU oracle replay: {parity['gathered_shard_of_last_rank']}")
         graphs = [c for kind, c in timed_launches if kind == "graph"]
         eager = sum(c for kind, c in timed_launches if kind == "eager")
         launch_desc = ("one step kernel per env.step(); the %d timed steps = %s%s" % (
@@ -904,7 +945,10 @@ def main():
                 "partition": f"rank r owns envs [r * {B}, (r + 1) * {B}) of one batch of {total_envs}; seeds and actions are functions of the global env id",
                 "launch": launch_desc,
                 "collective": None if not multi or args.no_gather else {
-                    "what": "qg_comm_gather_submit (include/qgym.h): one flat shard per rank (bit-packed observation + f32 rewards + is_final / success flags) "
+                    "handover": args.handover,
+                    "what": "qg_vec_push_learner_shard + qg_comm_p2p_wait + qg_comm_p2p_release (include/qgym.h) on the step stream: the packed shard copied "
+                            "into every rank's hipIpc window, per-source arrival flags; handles exchanged over the control plane (gloo); no RCCL" if args.handover == "direct" else
+                            "qg_comm_gather_submit (include/qgym.h): one flat shard per rank (bit-packed observation + f32 rewards + is_final / success flags) "
                             "packed by libqgym and moved by ncclAllGather of librccl.so.1 called from libqgym, side stream, double buffered, "
                             "overlapped with the following steps; torch.distributed (gloo) carries only the id, the barriers and the timing reduction",
                     "every_steps": gather_every,

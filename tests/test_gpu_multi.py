@@ -148,3 +148,24 @@ def test_sharded_policy_in_the_loop_draws_what_the_whole_batch_draws(inverts, pe
         assert torch.equal(wa[sl], sa) and torch.equal(wl[sl].view(torch.int32), slp.view(torch.int32))
         assert torch.equal(wr[sl].view(torch.int32), sr.view(torch.int32)) and torch.equal(wd[sl], sd)
     assert torch.equal(out["whole"][1][sl], out["shard"][1])
+
+
+def test_bench_as_a_two_rank_job_on_one_gpu_with_the_direct_write_handover():
+    """A real N = 2 run of bench.py on the one GPU there is: two ranks under torch.distributed.run (gloo control plane, ids and barriers),
+    each stepping its shard of one 131 072-env batch, the learner shard handed over by the direct write into both ranks' hipIpc windows
+    inside the timed region; rank 0 replays its own part AND rank 1's part of what arrived on the oracle.  (RCCL refuses two ranks on one
+    GPU, so the collective transport itself stays a world-1 test: tests/test_gpu_comm.py.)"""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--handover", "direct", "--ranks-share-gpu0", "--steps", "20",
+                          "--warmup", "5", "--no-cpu-baseline", "--no-large-batch", "--no-default-config", "--no-configs", "--no-collector"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and cfg["ranks_seen"] == 2 and cfg["total_envs"] == 2 * 65536 and cfg["env_ids_of_rank0"] == [0, 65536]
+    assert cfg["collective"]["handover"] == "direct" and cfg["collective"]["collectives_in_timed_region"] >= 1
+    assert line["parity"]["bit_exact"] and line["parity"]["gathered_shard"]["bit_exact"]
+    assert line["parity"]["gathered_shard_of_last_rank"]["bit_exact"] and line["parity"]["gathered_shard_of_last_rank"]["envs"] == 1024
+    assert line["value"] > 1e9 and line["scaling"] == "weak"

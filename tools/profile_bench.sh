@@ -52,4 +52,5 @@ cd "$ROOT" && python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/r03/bench_
 cd "$ROOT" && python3 bench.py > "$OUT/r03/bench_n1.json" 2> "$OUT/bench_n1.err"
 echo "== the multi-GPU code path on one rank (qg_comm: RCCL + direct write cadences)" && date
 cd "$ROOT" && python3 bench.py --force-multi --shard 3/8 --steps 20 --warmup 5 --no-cpu-baseline --no-large-batch --no-default-config --no-configs --no-collector > "$OUT/r03/bench_force_multi_rank3of8.json" 2> "$OUT/bench_force_multi.err"
+cd "$ROOT" && python3 bench.py --gpus 2 --handover direct --ranks-share-gpu0 --steps 20 --warmup 5 --no-cpu-baseline --no-large-batch --no-default-config --no-configs --no-collector > "$OUT/r03/bench_two_ranks_one_gpu_direct.json" 2> "$OUT/bench_two_ranks.err"
 ls -la "$OUT" "$OUT/r03"
