@@ -232,6 +232,82 @@ __device__ inline bool scramble_tree(const InitArgs &a, uint32_t count, uint64_t
     return lane == 0;
 }
 
+// The same for 64-bit rows (TILE64: CliffordEnv 16 < N <= 32, LinearFunctionEnv 32 < N <= 64): R <= 64 slots in a uint64 per column, all
+// 64 lanes hold a column.  `prod`: 4 x 64 uint64 of LDS.  Called from its own kernel (q64_reset_tree_kernel), one workgroup per listed env.
+__device__ inline int64_t bit_mask64(uint64_t v, uint32_t off) { return (int64_t)(v << (63u - off)) >> 63; }  // bit `off` as 0 / -1
+template <int R>
+__device__ inline uint64_t gf2_cols_product64(const uint64_t *a_cols, uint64_t b) {
+    uint64_t acc = 0;
+#pragma unroll
+    for (int sl = 0; sl < R; ++sl) acc ^= a_cols[sl] & (uint64_t)bit_mask64(b, (uint32_t)sl);
+    return acc;
+}
+// Returns true on ALL lanes of wave 0, whose `col` is then the finished matrix by columns (the caller turns it into rows: 64 row words in
+// one lane's registers cost the caller 450 registers and scratch with CliffordEnv's finish, so q64_reset_tree_kernel keeps one row per lane).
+template <int R, typename Identity>
+__device__ inline bool scramble_tree64(const InitArgs &a, uint32_t count, uint64_t &env, uint64_t &col_out, uint64_t (*prod)[64], Identity identity) {
+    static_assert(R <= 64, "one uint64 of slots per column");
+    const uint64_t item = blockIdx.x;
+    if (item >= count) return false;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1), w = threadIdx.x >> 6;
+    env = a.list[item];
+    const uint32_t seg = (a.n_draws + 3u) / 4u, t0 = w * seg, t1 = (t0 + seg < a.n_draws) ? t0 + seg : a.n_draws;
+    uint64_t col = 0;
+    if (w == 0) {
+#pragma unroll
+        for (int sl = 0; sl < R; ++sl) col |= ((identity((uint32_t)sl) >> lane) & 1ull) << sl;  // clifford.rs:307
+    } else {
+        col = lane < (uint32_t)R ? 1ull << lane : 0ull;
+    }
+    const uint64_t seed = init_seed(a);
+    auto rowop = [&](uint32_t src, uint32_t dst, int64_t swap, uint64_t m) {
+        const int64_t bs = bit_mask64(col, src), bd = bit_mask64(col, dst);
+        col ^= (uint64_t)(bs ^ (bd & swap)) & m;
+    };
+    auto mask_of = [](uint32_t op) -> uint64_t {
+        const uint32_t type = (op >> 12) & 3u, dst = op & 63u, src = (op >> 6) & 63u;
+        return ((uint64_t)(type != OP_NONE) << dst) | ((uint64_t)(type == OP_SWAP) << src);
+    };
+    auto lane64 = [](uint64_t v, uint32_t k) -> uint64_t {
+        return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)k) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)k) << 32);
+    };
+    for (uint32_t c0 = t0; c0 < t1; c0 += 2u * QG_WAVE) {
+        uint32_t o[2];
+        uint64_t m0[2], m1[2];
+#pragma unroll
+        for (uint32_t j = 0; j < 2; ++j) {
+            const uint32_t t = c0 + j * QG_WAVE + lane;
+            o[j] = t < t1 ? a.rowops[rng_action(seed, a.env_base + env, t, a.num_actions)] : 0u;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 2; ++j) {
+            m0[j] = mask_of(o[j] & 0x3FFFu);
+            m1[j] = mask_of(o[j] >> 14);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 2; ++j) {
+            if (c0 + j * QG_WAVE >= t1) break;
+            const uint32_t left = t1 - (c0 + j * QG_WAVE);
+            const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)(left < QG_WAVE ? left : QG_WAVE));
+            for (uint32_t k = 0; k < len; ++k) {
+                const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)o[j], (int)k);
+                const uint64_t ga = lane64(m0[j], k), gb = lane64(m1[j], k);
+                // (the builtin's result is unsigned: through int32_t, so that "swap" widens to 64 ones, not 32)
+                rowop((g >> 6) & 63u, g & 63u, (int64_t)(int32_t)__builtin_amdgcn_sbfe((int32_t)g, 13u, 1u), ga);
+                rowop((g >> 20) & 63u, (g >> 14) & 63u, (int64_t)(int32_t)__builtin_amdgcn_sbfe((int32_t)g, 27u, 1u), gb);
+            }
+        }
+    }
+    if (w & 1u) prod[w][lane] = col;
+    __syncthreads();
+    if (!(w & 1u)) col = gf2_cols_product64<R>(prod[w + 1u], col);
+    if (w == 2u) prod[2][lane] = col;
+    __syncthreads();
+    if (w != 0) return false;
+    col_out = gf2_cols_product64<R>(prod[2], col);
+    return true;
+}
+
 template <typename W, int R>
 constexpr size_t scramble_coop_lds_bytes(int waves) { return (size_t)waves * (QG_WAVE / QG_COOP_LANES) * (R * sizeof(W) + 64 * sizeof(uint32_t)); }
 

@@ -878,8 +878,64 @@ static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
     else hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, false, false>), grid, block, 0, s, a);
     return hipGetLastError();
 }
+// qg_vec_reset_done with a short list of long scrambles (tree_takes): a workgroup per listed env, scramble_tree64.  Runs BEFORE q64_init_kernel
+// in the same call and consumes the list (the ticket of list_count_take zeroes it), so that the init kernel finds nothing to do; when the list
+// is too long or the scramble too short it leaves the list alone and the init kernel takes it as before.
+template <int NS, bool HAS_Z>
+__global__ __launch_bounds__(256) void q64_reset_tree_kernel(InitArgs a) {
+    __shared__ uint64_t prod[4][64];
+    if (!tree_takes(a.list_count[0], a.n_draws, a.B)) return;
+    const uint32_t count = list_count_take(a.list_count, a.B, QG_TREE_THREADS);
+    const uint32_t N = a.N;
+    uint64_t env = 0, col = 0;
+    if (!scramble_tree64<NS>(a, count, env, col, prod, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); })) return;
+    // q64_init_finish with the wave's 64 lanes: lane s takes the row of slot s (ballot of the columns' bits s), stores its 8 bytes of the
+    // env's tile and compares with the identity's; lane 0 writes the scalars (reset_internals, clifford.rs:272-283)
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    uint64_t myrow = 0;
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) {
+        const uint64_t r = (uint64_t)__ballot((col >> sl) & 1ull);
+        myrow = lane == (uint32_t)sl ? r : myrow;
+    }
+    const uint32_t le = (uint32_t)(env & (QG_WAVE - 1));
+    uint64_t *tile = reinterpret_cast<uint64_t *>(reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Q64Rows<NS>::G * 64));
+    if (lane < (uint32_t)NS) tile[((uint64_t)(lane >> 1) * 64 + le) * 2 + (lane & 1u)] = myrow;  // group lane / 2, the env's 16-byte piece, its low or high word
+    const uint64_t differs = (uint64_t)__ballot(lane < (uint32_t)NS && myrow != q64_identity_word<NS, HAS_Z>((int)lane, N));
+    if (lane != 0) return;
+    uint64_t bad = differs;
+    if constexpr (HAS_Z) {  // bit j: slot 2j or 2j + 1 differs
+        uint64_t t = (differs | (differs >> 1)) & 0x5555555555555555ull;
+        t = (t | (t >> 1)) & 0x3333333333333333ull;
+        t = (t | (t >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+        t = (t | (t >> 4)) & 0x00FF00FF00FF00FFull;
+        t = (t | (t >> 8)) & 0x0000FFFF0000FFFFull;
+        bad = (t | (t >> 16)) & 0x00000000FFFFFFFFull;
+    }
+    const bool solved = differs == 0;
+    if (a.bad) reinterpret_cast<uint64_t *>(a.bad)[env] = bad;
+    a.depth[env] = a.depth_value;
+    a.success[env] = (uint8_t)solved;
+    a.reward[env] = solved ? 1.0f : 0.0f;
+    a.done[env] = (uint8_t)(a.depth_value == 0 || solved);
+    a.inverted[env] = (uint8_t)((HAS_Z && a.check_symplectic) ? Q64_FLAG_SYMPLECTIC : 0u);  // identity + gates: symplectic (q64_init_finish, mode 2)
+    a.error[env] = 0;
+    a.sol_len[env * 2] = 0;
+    a.sol_len[env * 2 + 1] = 0;
+    if (a.layers) {
+        const LayerRec lay = layer_rec(a.layers, env, a.layers_len);
+        for (uint32_t i = 0; i + 2 < a.layers_len; ++i) lay[i] = -1;
+        lay[a.layers_len - 2] = 0;
+        lay[a.layers_len - 1] = 0;
+    }
+}
+
 template <int NS, bool HAS_Z>
 static hipError_t q64_launch_init(const InitArgs &a, hipStream_t s) {
+    if (a.list && a.coop && a.n_draws >= 64u) {
+        const uint64_t blocks = a.B / 32u < QG_TREE_MAX_ENVS ? a.B / 32u : QG_TREE_MAX_ENVS;
+        if (blocks) hipLaunchKernelGGL((q64_reset_tree_kernel<NS, HAS_Z>), dim3((unsigned)blocks), dim3(QG_TREE_THREADS), 0, s, a);
+    }
     hipLaunchKernelGGL((q64_init_kernel<NS, HAS_Z>), dim3(grid_for(a.B, 64)), dim3(64), 0, s, a);
     return hipGetLastError();
 }
