@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define QG_ABI_VERSION 1
+/* 2: + qg_comm_* / learner-shard entry points, qg_vec_step_host, qg_vec_observe_*_host (additions only: version-1 callers keep working) */
+#define QG_ABI_VERSION 2
 
 typedef enum {
     QG_OK = 0,
@@ -435,6 +436,8 @@ int qg_comm_init(const uint8_t id[QG_COMM_ID_BYTES], int rank, int world, int de
 /* A communicator without RCCL, for the direct-write transport only (handles are exchanged by the host: qg_comm_p2p_export /
  * qg_comm_p2p_open).  Not collective. */
 int qg_comm_init_local(int rank, int world, int device, qg_comm **out);
+/* With the direct-write transport, call it only when every rank is done with every window (a barrier of the host's own): peers write into this
+ * rank's window and this rank holds mappings of theirs. */
 void qg_comm_destroy(qg_comm *c);
 int qg_comm_rank(const qg_comm *c);
 int qg_comm_world(const qg_comm *c);

@@ -1,0 +1,34 @@
+"""The desynchronised auto-reset leg of bench.py on its own (CliffordGym 16q x 65 536, difficulty 256, 1/128 of the batch finishing per step),
+for rocprofv3 --kernel-trace --stats: what the step kernel with its done list and the reset kernel cost inside the captured graph."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from qiskit_gym_amd.vec import VecEnv
+from util import line_gateset
+
+gs = line_gateset("clifford", 16); B, AT, seed = 65536, 128, 7
+A = len(gs)
+env = VecEnv("clifford", 16, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=256)
+acts = torch.randint(0, A, (AT, B), dtype=torch.int32, device="cuda")
+stream = torch.cuda.Stream()
+with torch.cuda.stream(stream):
+    env.reset(seed)
+    cls = torch.arange(B, device="cuda") % AT
+    for k in range(AT):
+        env.set_counters(k, k); env.step(acts[k]); env.reset_done(seed + 0x51ED * (k + 1))
+        env.done[cls == k] = 1; env.reset_done(seed + 0xA5A5 * (k + 1))
+    def episode():
+        for t in range(AT):
+            env.set_counters(t, t); env.rollout(acts[t:t + 1]); env.reset_done(seed + 0x9E3779B9 * (t + 1))
+    episode(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=stream):
+        episode()
+    torch.cuda.synchronize(); g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(8): g.replay()
+    e1.record(stream)
+torch.cuda.synchronize(); env.sync()
+print(f"desynchronised auto-reset: {e0.elapsed_time(e1) * 1e3 / (8 * AT):.2f} us per (step + reset_done), {float(env.done.float().mean()) * 100:.2f} % finished per step")
