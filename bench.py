@@ -884,17 +884,19 @@ def main():
             col.collect(CT)  # eager pass + capture
             col.collect(CT)  # first replay (the graph's one-time upload: tens of ms now and then)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
+            per_replay = []
+            for _ in range(5):  # each replay timed on its own: a hipGraph launch now and then stalls for tens of ms (its upload), the median does not see it
+                t0 = time.perf_counter()
                 ro = col.collect(CT)
-            torch.cuda.synchronize()
-            cus = (time.perf_counter() - t0) / (3 * CT) * 1e6
+                torch.cuda.synchronize()
+                per_replay.append((time.perf_counter() - t0) / CT * 1e6)
+            cus = float(np.median(per_replay))
             cenv.sync()
             rows.append({"envs": CB, "us_per_step": cus, "value": CB / (cus * 1e-6), "unit": "env-steps/s", "done_per_step": float(ro.dones.float().mean())})
             del col, cenv, ro
             torch.cuda.empty_cache()
         collector = {"policy": f"BasicPolicy {4 * n * n}-512-256-{{{A}, 1}} bf16, random weights; packed observation stored per step; one hipGraph per 32-step collection",
-                     "clock": "host wall clock around 3 replays, device idle before and after", "by_batch": rows}
+                     "clock": "host wall clock around each of 5 replays (device idle before and after), median", "by_batch": rows}
 
     if rank == 0:
         cpu = None
