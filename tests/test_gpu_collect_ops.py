@@ -204,7 +204,11 @@ def test_head_sample_follows_softmax():
 
 
 @pytest.mark.parametrize("A,K1,B", [(170, 512, 2500), (12, 64, 300), (190, 1024, 257), (40, 96, 64), (214, 512, 1000), (222, 128, 70),
-                                    (170, 512, 40000), (170, 512, 8192), (97, 256, 33)])  # <= 8 192 envs and in_features % 128 == 0: mid_head_small_kernel
+                                    (170, 512, 40000), (170, 512, 8192), (97, 256, 33),
+                                    # more than one trip of mid_head_sample_kernel's grid (2 workgroups per CU x 4 waves x 32 envs = 65 536
+                                    # envs per trip on 256 CUs): exactly one trip, a ragged second one, 7 and 1 action tiles, three trips
+                                    (170, 512, 65536), (170, 512, 70001), (214, 512, 66000), (12, 512, 65600), (95, 512, 140000)])
+# <= 8 192 envs and in_features % 128 == 0: mid_head_small_kernel
 def test_mid_head_sample_on_integer_data_is_exact(A, K1, B):
     """qg_policy_mid_head_sample = relu(h W2^T + b2) -> head -> draw, everything in registers.  Small-integer weights keep
     every intermediate exactly representable (h2 <= 256 in bf16), which pins the fragment k orders: the draw must be

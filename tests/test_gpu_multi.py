@@ -110,14 +110,16 @@ def test_bench_gpus_flag_fails_loudly_without_that_many_gpus():
     assert not [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]
 
 
-@pytest.mark.parametrize("inverts,per", [(False, 256), (False, 16384), (True, 256), (True, 16384)])  # small- and large-batch sampling kernels
-def test_sharded_policy_in_the_loop_draws_what_the_whole_batch_draws(inverts, per):
+# small- and large-batch sampling kernels; world 5: the whole batch (81 920 envs) takes two trips of the large-batch kernel's grid, the
+# second one ragged, and the shard is its last fifth
+@pytest.mark.parametrize("inverts,per,world", [(False, 256, 2), (False, 16384, 2), (True, 256, 2), (True, 16384, 2), (False, 16384, 5)])
+def test_sharded_policy_in_the_loop_draws_what_the_whole_batch_draws(inverts, per, world):
     """The sampling + step call keys its action draw on the GLOBAL env id (qg_vec_set_env_base), like every env-side draw: one seed across
     ranks, and rank r's actions, log-probs and env results are the slice [r * per, (r + 1) * per) of the unsharded batch's."""
     from qiskit_gym_amd.collector import embed, mid_head_sample_step, pack_embedding, pack_head, pack_mid
     from qiskit_gym_amd.vec import VecEnv
 
-    n, world, r, H1, H2 = 6, 2, 1, 512, 256
+    n, r, H1, H2 = 6, world - 1, 512, 256
     gs = line_gateset("clifford", n)
     A = len(gs)
     cfg = dict(add_inverts=inverts, add_perms=False, track_solution=False, difficulty=6)
