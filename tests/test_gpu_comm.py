@@ -176,6 +176,19 @@ def _p2p_rank(rank, world, B, conn, result_q):
             ok = ok and th.equal(rew.view(th.int32), whole.reward.view(th.int32)) and th.equal(fin, whole.done) and th.equal(suc, whole.success)
         comm.check()
         shard.sync()
+        conn.send("stepped")
+        conn.recv()  # both ranks are through their T epochs
+        if rank == 0:
+            # a peer that never writes epoch T + 1: the wait gives up at its deadline (2 s of the device's wall clock), the stream drains, and
+            # the check names the cause -- a dead rank becomes an error on the host, not a hung GPU
+            comm.push(shard)
+            t0 = time.time()
+            comm.wait()
+            try:
+                comm.check()
+                ok = False
+            except RuntimeError as exc:
+                ok = ok and "did not arrive" in str(exc) and 1.5 < time.time() - t0 < 20.0
         conn.send("done")
         conn.recv()  # nobody unmaps a window a peer may still write
         comm.close()
@@ -187,7 +200,8 @@ def _p2p_rank(rank, world, B, conn, result_q):
 def test_direct_write_two_ranks_sharing_this_gpu():
     """Two processes, each a rank with its own shard, map each other's window (hipIpcGetMemHandle / hipIpcOpenMemHandle) and write
     their shards into both; every rank must read both shards, epoch after epoch, with no host synchronisation between the ranks
-    inside the loop (arrival flags and releases are the only ordering)."""
+    inside the loop (arrival flags and releases are the only ordering).  Then rank 1 stops: rank 0's next wait must end at its deadline
+    with an error the host can read."""
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
@@ -213,6 +227,9 @@ def test_direct_write_two_ranks_sharing_this_gpu():
         recv_all("opened")
         for r in range(world):
             pipes[r][0].send("go")
+        recv_all("stepped")
+        for r in range(world):
+            pipes[r][0].send("rank 1 stays silent for one epoch")
         recv_all("done")
         for r in range(world):
             pipes[r][0].send("bye")
