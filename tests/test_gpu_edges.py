@@ -256,3 +256,49 @@ def test_permutation_set_state_with_repeated_entries_runs_like_the_reference(n):
     inv.set_state(states)
     with pytest.raises(QGymError):
         inv.sync()
+
+
+@pytest.mark.parametrize("B,inverts,act64", [(1003, False, False), (1, True, True), (4096, True, False), (77, False, True)])
+def test_step_host_from_pinned_and_pageable_memory_equals_the_device_step(B, inverts, act64):
+    """qg_vec_step_host: pinned, device-mapped buffers take the zero-copy path (the step reads the actions in host memory, one kernel
+    writes reward / is_final / success there; ragged tails, a batch of one), pageable buffers the copies; both must equal qg_vec_step."""
+    from qiskit_gym_amd import _lib
+    from qiskit_gym_amd.vec import VecEnv
+
+    n, T = 7, 5
+    gs = line_gateset("clifford", n)
+    cfg = dict(add_inverts=inverts, add_perms=False, track_solution=False, difficulty=5)
+    ref, pin, page = (VecEnv("clifford", n, gs, B, seed=2, **cfg) for _ in range(3))
+    L = ref._L
+    rng = np.random.default_rng(B)
+    adt = np.int64 if act64 else np.int32
+    code = 1 if act64 else 0  # QG_ACT_I64 / QG_ACT_I32
+    for env in (ref, pin, page):
+        env.reset(11)
+    pinned = {k: torch.empty(B, dtype=dt).pin_memory() for k, dt in (("a", torch.int64 if act64 else torch.int32), ("c", torch.uint8), ("r", torch.float32),
+                                                                     ("d", torch.uint8), ("s", torch.uint8))}
+    for t in range(T):
+        acts = rng.integers(-1, len(gs) + 1, size=B).astype(adt)
+        coins = rng.integers(0, 2, size=B).astype(np.uint8)
+        ref.step(torch.as_tensor(acts, device="cuda"), torch.as_tensor(coins, device="cuda") if inverts else None)
+        ref.sync()
+        want = (ref.reward.cpu().numpy().view(np.uint32), ref.done.cpu().numpy(), ref.success.cpu().numpy())
+        # pinned
+        pinned["a"].numpy()[:] = acts
+        pinned["c"].numpy()[:] = coins
+        for k in "rds":
+            pinned[k].numpy()[:] = 0x55 if k != "r" else -1.0
+        _lib.check(L.qg_vec_step_host(pin._h, pinned["a"].data_ptr(), code, pinned["c"].data_ptr() if inverts else None, pinned["r"].data_ptr(),
+                                      pinned["d"].data_ptr(), pinned["s"].data_ptr(), pin._stream()))
+        pin.sync()
+        got = (pinned["r"].numpy().view(np.uint32), pinned["d"].numpy(), pinned["s"].numpy())
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g, w, err_msg=f"pinned, t={t}")
+        # pageable
+        r, d, s = np.full(B, -1.0, np.float32), np.full(B, 0x55, np.uint8), np.full(B, 0x55, np.uint8)
+        _lib.check(L.qg_vec_step_host(page._h, acts.ctypes.data, code, coins.ctypes.data if inverts else None, r.ctypes.data, d.ctypes.data, s.ctypes.data,
+                                      page._stream()))
+        page.sync()
+        for g, w in zip((r.view(np.uint32), d, s), want):
+            np.testing.assert_array_equal(g, w, err_msg=f"pageable, t={t}")
+    assert torch.equal(pin.get_state("packed"), ref.get_state("packed")) and torch.equal(page.get_state("packed"), ref.get_state("packed"))
