@@ -223,7 +223,10 @@ int qg_vec_step(qg_vec *v, const void *actions_dev, int action_dtype, const uint
  * copied to the device, the step runs, and reward / is_final / success are copied back into rewards_host f32[B], dones_host u8[B],
  * success_host u8[B] (each may be NULL) -- all enqueued on `stream` with hipMemcpyAsync, nothing synchronises: with pinned buffers
  * (hipHostMalloc / hipHostRegister) the call returns at once and the outputs are valid after qg_vec_sync(v, stream); pageable buffers
- * work too (the runtime then stages the copies).  The input buffers must stay untouched until the stream has passed the call. */
+ * work too (the runtime then stages the copies).  The input buffers must stay untouched until the stream has passed the call.
+ * When every buffer passed is pinned AND device-mapped (the default of hipHostMalloc; hipHostRegister with hipHostRegisterMapped) and the
+ * output buffers are 16-byte aligned, no copy is made at all: the step kernel reads actions / coins in host memory and one kernel writes
+ * the outputs there (same contract, a quarter of the time: tools/bench_step_host.py). */
 int qg_vec_step_host(qg_vec *v, const void *actions_host, int action_dtype, const uint8_t *coins_host, float *rewards_host, uint8_t *dones_host,
                      uint8_t *success_host, void *stream);
 
