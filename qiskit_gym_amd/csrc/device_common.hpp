@@ -26,6 +26,29 @@ __device__ inline void done_list_append(uint32_t *list, uint32_t *count, bool fi
     if (fin && slot < cap) list[slot] = (uint32_t)env;
 }
 
+// The same append for a whole workgroup of 256 threads (call from ALL of them): one atomic per workgroup with a finisher instead of one
+// per wave -- every append goes to one address, ~10 ns each, and they are the tail of the launch.
+__device__ inline void done_list_append_block(uint32_t *list, uint32_t *count, bool fin, uint64_t env, uint64_t cap) {
+    __shared__ uint32_t wave_count[4], wave_base[4];
+    const uint64_t m = __ballot(fin);
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    if (lane == 0) wave_count[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t c0 = wave_count[0], c1 = wave_count[1], c2 = wave_count[2], c3 = wave_count[3], total = c0 + c1 + c2 + c3;
+        const uint32_t base = total ? atomicAdd(count, total) : 0u;
+        wave_base[0] = base;
+        wave_base[1] = base + c0;
+        wave_base[2] = base + c0 + c1;
+        wave_base[3] = base + c0 + c1 + c2;
+    }
+    __syncthreads();
+    if (fin) {
+        const uint32_t slot = wave_base[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (slot < cap) list[slot] = (uint32_t)env;
+    }
+}
+
 #define QG_COOP_LANES 16  // lanes per env of the cooperative scramble (scramble_coop below)
 
 // Length of the compacted list of finished envs (compact_done), read by every thread of the LAST kernel that consumes it.  The last

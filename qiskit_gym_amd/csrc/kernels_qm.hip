@@ -469,10 +469,14 @@ template <int NXP, bool FEAT, bool LIST = false>
 __global__ __launch_bounds__(256) void qm_inv2_kernel(StepArgs a) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     QG_PREFETCH_STEP_ARGS(a);
-    if ((tid >> 1) >= a.B) return;  // whole lane pairs leave together
-    const bool fin = qm_inv2_body<NXP / 2, FEAT>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr);  // qm_step1.hpp
-    if constexpr (LIST) done_list_append(a.done_list, a.done_count, fin && !(tid & 1u), tid >> 1, a.B);
-    else (void)fin;
+    if constexpr (LIST) {  // every thread reaches the workgroup-wide append; whole lane pairs are in or out together
+        bool fin = false;
+        if ((tid >> 1) < a.B) fin = qm_inv2_body<NXP / 2, FEAT>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr);  // qm_step1.hpp
+        done_list_append_block(a.done_list, a.done_count, fin && !(tid & 1u), tid >> 1, a.B);
+    } else {
+        if ((tid >> 1) >= a.B) return;  // whole lane pairs leave together
+        (void)qm_inv2_body<NXP / 2, FEAT>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr);  // qm_step1.hpp
+    }
 }
 
 // One step per launch without holding the matrix (the env.step() path without add_inverts).  A gate
@@ -487,11 +491,15 @@ __global__ __launch_bounds__(256) void qm_step1_kernel(StepArgs a) {
     using Rows = QmRows<NXP, HAS_Z>;
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
-    if (env >= a.B) return;
-    const int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
-    const bool fin = qm_step1_body<HAS_Z, FEAT>(a, Rows::G, env, act);  // qm_step1.hpp
-    if constexpr (LIST) done_list_append(a.done_list, a.done_count, fin, env, a.B);
-    else (void)fin;
+    if constexpr (LIST) {  // every thread reaches the workgroup-wide append
+        bool fin = false;
+        if (env < a.B) fin = qm_step1_body<HAS_Z, FEAT>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64));
+        done_list_append_block(a.done_list, a.done_count, fin, env, a.B);
+    } else {
+        if (env >= a.B) return;
+        const int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
+        (void)qm_step1_body<HAS_Z, FEAT>(a, Rows::G, env, act);  // qm_step1.hpp
+    }
 }
 
 // Fused rollout on LDS-resident rows (T steps per launch, plain configuration: no add_inverts, no solution log, default
