@@ -245,3 +245,77 @@ def test_auto_reset_with_desynchronised_episodes_at_full_size(kind, n, B, invert
     if inverts:
         for i in range(0, len(ids), 16):
             assert gv.solution(int(ids[i])) == envs[i].solution()
+
+
+def test_config4_all_eight_shards_equal_the_whole_batch_x524288():
+    """BASELINE config 4 (CliffordGym 16q, 524 288 envs, 8 ranks x 65 536) on one GPU: the WHOLE batch as one handle against each of the
+    eight shards as its own handle with its env_base -- reset, 24 steps with auto-reset of finished episodes, then the learner shard every
+    rank would hand over (qg_vec_pack_learner_shard).  Concatenated in rank order the eight shards must be the whole batch's hand-over byte
+    for byte (what ncclAllGather / the direct write would assemble), and a strided sample of envs is replayed on the oracle."""
+    from qiskit_gym_amd.distributed import split_gathered
+    from qiskit_gym_amd.vec import VecEnv
+
+    n, per, world, T, seed, scramble = 16, 65536, 8, 24, 41, 7
+    gs = line_gateset("clifford", n)
+    A = len(gs)
+    cfg = dict(add_inverts=False, add_perms=False, track_solution=False, difficulty=scramble)
+    whole = VecEnv("clifford", n, gs, per * world, **cfg)
+    whole.reset(seed)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    acts = torch.randint(0, A, (T, per * world), dtype=torch.int32, device="cuda", generator=gen)
+    rew = torch.empty((T, per * world), dtype=torch.float32, device="cuda")
+    fin = torch.empty((T, per * world), dtype=torch.uint8, device="cuda")
+    for t in range(T):
+        whole.set_counters(t, t)
+        whole.step(acts[t])
+        rew[t].copy_(whole.reward)
+        fin[t].copy_(whole.done)
+        if t + 1 < T:
+            whole.reset_done(seed + 1000 * (t + 1))
+    whole.sync()
+    assert 0 < int(fin.sum()) < fin.numel()  # episodes do end inside the run (max_depth = 2 * difficulty), and not all at once
+    whole_state = whole.get_state("packed")
+    whole_shard = whole.pack_learner_shard()
+    w_obs, w_rew, w_fin, w_suc = split_gathered(whole_shard, whole.shard_layout(), 1, 4)
+    gathered = []
+    for r in range(world):
+        sl = slice(r * per, (r + 1) * per)
+        shard = VecEnv("clifford", n, gs, per, env_base=r * per, **cfg)
+        shard.reset(seed)
+        for t in range(T):
+            shard.set_counters(t, t)
+            shard.step(acts[t, sl].contiguous())
+            assert torch.equal(shard.reward.view(torch.int32), rew[t, sl].view(torch.int32)), (r, t)
+            assert torch.equal(shard.done, fin[t, sl]), (r, t)
+            if t + 1 < T:
+                shard.reset_done(seed + 1000 * (t + 1))
+        shard.sync()
+        assert torch.equal(shard.get_state("packed"), whole_state[sl]), r
+        gathered.append(shard.pack_learner_shard())
+        lay = shard.shard_layout()
+        shard.close()
+    g_obs, g_rew, g_fin, g_suc = split_gathered(torch.cat(gathered), lay, world, 4)
+    assert torch.equal(g_obs, w_obs) and torch.equal(g_rew.view(torch.int32), w_rew.view(torch.int32))
+    assert torch.equal(g_fin, w_fin) and torch.equal(g_suc, w_suc)
+    # the whole batch against the oracle on a sample: episode boundaries included (the reset's draws come from the counter RNG)
+    ids = np.arange(0, per * world, 4099)
+    envs = [OracleEnv("clifford", n, gs, **{k: int(v) for k, v in cfg.items()}) for _ in ids]
+
+    def oracle_reset(which, sd):
+        draws = rng_actions(sd, ids[which], scramble, A)
+        for j, i in enumerate(which):
+            envs[i].reset_with(draws[:, j])
+
+    oracle_reset(np.arange(len(ids)), seed)
+    acts_h, rew_h, fin_h = acts.cpu().numpy()[:, ids], rew.cpu().numpy()[:, ids], fin.cpu().numpy()[:, ids]
+    for t in range(T):
+        for i, o in enumerate(envs):
+            o.step(int(acts_h[t, i]), 0)
+        np.testing.assert_array_equal(f32_bits(rew_h[t]), np.array([o.reward_bits() for o in envs], dtype=np.uint32), err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(fin_h[t], [int(o.is_final()) for o in envs], err_msg=f"is_final t={t}")
+        if t + 1 < T:
+            done_ids = np.nonzero(fin_h[t])[0]
+            if len(done_ids):
+                oracle_reset(done_ids, seed + 1000 * (t + 1))
+    np.testing.assert_array_equal(whole.get_state("i64").cpu().numpy()[ids], np.stack([o.get_state() for o in envs]))
