@@ -137,7 +137,7 @@ def test_direct_write_world_1_epochs_match_oracle():
 
 
 def _p2p_rank(rank, world, B, conn, result_q):
-    """One of two processes on the SAME GPU: steps its shard, pushes it into both windows, checks what arrived from everybody."""
+    """One of `world` processes on the SAME GPU: steps its shard, pushes it into every window, checks what arrived from everybody."""
     import torch as th
 
     from qiskit_gym_amd.distributed import Communicator, split_gathered
@@ -197,15 +197,16 @@ def _p2p_rank(rank, world, B, conn, result_q):
         result_q.put((rank, False, repr(exc)))
 
 
-def test_direct_write_two_ranks_sharing_this_gpu():
-    """Two processes, each a rank with its own shard, map each other's window (hipIpcGetMemHandle / hipIpcOpenMemHandle) and write
-    their shards into both; every rank must read both shards, epoch after epoch, with no host synchronisation between the ranks
+@pytest.mark.parametrize("world", [2, 4])  # four ranks: every (rank + y) % world peer index, four arrival flags and releases per window
+def test_direct_write_ranks_sharing_this_gpu(world):
+    """`world` processes, each a rank with its own shard, map each other's window (hipIpcGetMemHandle / hipIpcOpenMemHandle) and write
+    their shards into all of them; every rank must read every shard, epoch after epoch, with no host synchronisation between the ranks
     inside the loop (arrival flags and releases are the only ordering).  Then rank 1 stops: rank 0's next wait must end at its deadline
     with an error the host can read."""
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
-    world, B = 2, 2048
+    B = 2048
     q = ctx.Queue()
     pipes = [ctx.Pipe() for _ in range(world)]
     procs = [ctx.Process(target=_p2p_rank, args=(r, world, B, pipes[r][1], q)) for r in range(world)]
