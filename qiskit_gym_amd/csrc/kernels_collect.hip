@@ -169,23 +169,33 @@ hipError_t step_outputs(const float *reward, const uint8_t *done, const uint8_t 
 }
 
 // qg_vec_sync: the OR of the per-env fault words in ONE word of pinned host memory -- a sync costs a launch and four bytes instead of a copy
-// of the whole array and a scan on the host (65 536 envs: 256 KiB per call).  One workgroup; its last thread standing writes the word.
-__global__ __launch_bounds__(1024) void fault_any_kernel(const uint32_t *__restrict__ error, uint64_t B, uint32_t *out_host) {
-    __shared__ uint32_t part[16];
+// of the whole array and a scan on the host (65 536 envs: 256 KiB per call).  Every workgroup ORs its share (16 bytes per load, grid stride)
+// into scratch[0]; the last one to finish (ticket scratch[1]) hands the word to the host and leaves both zero for the next call.
+__global__ __launch_bounds__(256) void fault_any_kernel(const uint32_t *__restrict__ error, uint64_t B, uint32_t *scratch, uint32_t *out_host) {
+    const uint64_t n4 = B / 4u, stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint4 *e4 = reinterpret_cast<const uint4 *>(error);
     uint32_t acc = 0;
-    for (uint64_t e = threadIdx.x; e < B; e += blockDim.x) acc |= error[e];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const uint4 q = e4[i];
+        acc |= (q.x | q.y) | (q.z | q.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (B & 3u)) acc |= error[n4 * 4u + threadIdx.x];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc |= __shfl_xor(acc, off, 64);
-    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = acc;
+    if ((threadIdx.x & 63u) == 0 && acc) atomicOr(&scratch[0], acc);
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t all = 0;
-        for (uint32_t w = 0; w < blockDim.x / 64u; ++w) all |= part[w];
-        *out_host = all;
+        __threadfence();
+        if (atomicAdd(&scratch[1], 1u) == gridDim.x - 1u) {
+            *out_host = atomicOr(&scratch[0], 0u);
+            scratch[0] = 0;
+            scratch[1] = 0;
+        }
     }
 }
-hipError_t fault_any(const uint32_t *error, uint64_t B, uint32_t *out_host, hipStream_t s) {
-    hipLaunchKernelGGL(fault_any_kernel, dim3(1), dim3(1024), 0, s, error, B, out_host);
+hipError_t fault_any(const uint32_t *error, uint64_t B, uint32_t *scratch, uint32_t *out_host, hipStream_t s) {
+    const uint64_t want = (B / 4u + 1023u) / 1024u;  // four loads of 16 bytes per thread
+    hipLaunchKernelGGL(fault_any_kernel, dim3((unsigned)(want < 1 ? 1 : want > 256 ? 256 : want)), dim3(256), 0, s, error, B, scratch, out_host);
     return hipGetLastError();
 }
 

@@ -223,7 +223,7 @@ static int vec_free_buffers(qg_vec *v) {
     void *ptrs[] = {v->state, v->own_depth ? v->depth : nullptr, v->own_reward ? v->reward : nullptr,
                     v->own_done ? v->done : nullptr, v->own_success ? v->success : nullptr, v->inverted, v->error, v->sol,
                     v->sol_len, v->layers, v->d_gates, v->d_descs, v->scratch, v->d_prog,
-                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad, v->done_list, v->d_rowops, v->embed_dump, v->host_in, v->host_obs};
+                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad, v->done_list, v->d_rowops, v->embed_dump, v->host_in, v->host_obs, v->fault_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &g : v->graphs) {
@@ -1132,8 +1132,12 @@ int qg_vec_sync(qg_vec *v, void *stream) {
     if (!v) return set_error(QG_ERR_INVALID, "null argument");
     QG_ON_DEVICE(v);
     if (!v->fault_word) HIP_TRY(hipHostMalloc((void **)&v->fault_word, sizeof(uint32_t), hipHostMallocMapped));
+    if (!v->fault_scratch) {
+        HIP_TRY(hipMalloc((void **)&v->fault_scratch, 2 * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(v->fault_scratch, 0, 2 * sizeof(uint32_t)));
+    }
     *v->fault_word = 0xFFFFFFFFu;  // whatever goes wrong below reads as "look at the array"
-    HIP_TRY(fault_any(v->error, v->B, v->fault_word, (hipStream_t)stream));
+    HIP_TRY(fault_any(v->error, v->B, v->fault_scratch, v->fault_word, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     if (*(volatile uint32_t *)v->fault_word == 0) return QG_OK;
     std::vector<uint32_t> err(v->B);

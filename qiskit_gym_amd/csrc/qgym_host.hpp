@@ -110,6 +110,7 @@ struct qg_vec {
     void *host_obs = nullptr;           // qg_vec_observe_*_host: the observation before its copy to the caller's buffer
     size_t host_obs_bytes = 0;
     uint32_t *fault_word = nullptr;     // qg_vec_sync: OR of error[], one pinned, device-mapped word the host reads after the stream has drained
+    uint32_t *fault_scratch = nullptr;  // its device-side accumulator and ticket (two words, zero between calls)
     uint32_t *bad = nullptr;            // TILE / TILE64 without add_inverts: per-env "differs from identity" mask (one-step kernels)
     uint32_t *d_rowops = nullptr;       // TILE: gate table as pairs of row operations on slots (cooperative reset kernel)
     uint32_t *done_list = nullptr;      // reset_done: [B] indices of finished envs + {length, reader ticket} at [B], [B + 1]

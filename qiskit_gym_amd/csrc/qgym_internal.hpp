@@ -216,7 +216,7 @@ hipError_t permb_export(const ObsArgs &a, uint32_t ng, hipStream_t s);
 hipError_t expand_rows(const void *words_dev, int word_bytes, uint64_t n_rows, uint32_t cols, void *out_dev, int out_dtype, hipStream_t s);
 hipError_t compact_done(const uint8_t *done, uint64_t B, uint32_t *list, uint32_t *count, hipStream_t s);
 hipError_t masks_fill(const uint8_t *success, uint8_t *out, uint64_t B, uint32_t num_actions, hipStream_t s);
-hipError_t fault_any(const uint32_t *error, uint64_t B, uint32_t *out_host, hipStream_t s);
+hipError_t fault_any(const uint32_t *error, uint64_t B, uint32_t *scratch, uint32_t *out_host, hipStream_t s);
 hipError_t step_outputs(const float *reward, const uint8_t *done, const uint8_t *success, float *rewards_out, uint8_t *dones_out, uint8_t *success_out,
                         uint64_t B, hipStream_t s);
 
