@@ -122,6 +122,27 @@ __global__ __launch_bounds__(256) void masks_kernel(const uint8_t *success, uint
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < total) out[gid] = success[gid / A] ? 0 : 1;
 }
+// the same, 16 bytes per thread (A >= 16: a chunk spans at most two envs; `out` 16-byte aligned): one byte per thread reaches 0.7 TB/s
+__global__ __launch_bounds__(256) void masks16_kernel(const uint8_t *__restrict__ success, uint8_t *__restrict__ out, uint64_t total, uint32_t A, uint64_t B) {
+    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16u;
+    if (g >= total) return;
+    const uint64_t env0 = g / A;
+    const uint32_t left = (uint32_t)((env0 + 1u) * A - g);  // bytes of this chunk that belong to env0 (>= 1)
+    const uint32_t m0 = success[env0] ? 0u : 1u, m1 = (env0 + 1u < B && success[env0 + 1u]) ? 0u : 1u;
+    uint32_t w[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) v |= ((4u * k + j) < left ? m0 : m1) << (8u * j);
+        w[k] = v;
+    }
+    if (g + 16u <= total) {
+        *reinterpret_cast<uint4 *>(out + g) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        for (uint32_t k = 0; g + k < total; ++k) out[g + k] = (uint8_t)(w[k >> 2] >> (8u * (k & 3u)));
+    }
+}
 // Indices of the finished envs, packed (qg_vec_reset_done): a wave ballots its `done` flags, one lane
 // reserves that many slots of `list` with an atomic add, every done lane writes its env index at its
 // prefix.  The order across waves is arbitrary -- every env's reset depends on (seed, env) only.
@@ -202,7 +223,10 @@ hipError_t fault_any(const uint32_t *error, uint64_t B, uint32_t *scratch, uint3
 hipError_t masks_fill(const uint8_t *success, uint8_t *out, uint64_t B, uint32_t A, hipStream_t s) {
     const uint64_t total = B * A;
     if (!total) return hipSuccess;
-    hipLaunchKernelGGL(masks_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, success, out, total, A);
+    if (A >= 16u && !(reinterpret_cast<uintptr_t>(out) & 15u))
+        hipLaunchKernelGGL(masks16_kernel, dim3(blocks_for((total + 15u) / 16u, 256)), dim3(256), 0, s, success, out, total, A, B);
+    else
+        hipLaunchKernelGGL(masks_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, success, out, total, A);
     return hipGetLastError();
 }
 

@@ -302,3 +302,54 @@ def test_step_host_from_pinned_and_pageable_memory_equals_the_device_step(B, inv
         for g, w in zip((r.view(np.uint32), d, s), want):
             np.testing.assert_array_equal(g, w, err_msg=f"pageable, t={t}")
     assert torch.equal(pin.get_state("packed"), ref.get_state("packed")) and torch.equal(page.get_state("packed"), ref.get_state("packed"))
+
+
+@pytest.mark.parametrize("kind,n,B", [("clifford", 16, 1003), ("clifford", 3, 77), ("linear_function", 5, 4096), ("clifford", 9, 1), ("permutation", 12, 333)])
+def test_masks_are_all_ones_except_for_solved_envs(kind, n, B):
+    """Env::masks (clifford.rs:349-351): every action allowed unless the env is solved -- exact for every (env, action) byte; action counts
+    above and below 16 (the 16-bytes-per-thread kernel and the byte kernel), ragged totals, a batch of one."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    gs = line_gateset(kind, n)
+    cfg = dict(add_perms=False, track_solution=False, difficulty=1)
+    if kind != "pauli":
+        cfg["add_inverts"] = False
+    env = VecEnv(kind, n, gs, B, **cfg)
+    env.reset(5)  # difficulty 1: one random gate per env, a good share of them is solved again after one more
+    g = torch.Generator(device="cuda").manual_seed(B)
+    env.step(torch.randint(0, len(gs), (B,), dtype=torch.int32, device="cuda", generator=g))
+    env.sync()
+    suc = env.success.cpu().numpy()
+    m = env.masks().cpu().numpy()
+    assert m.shape == (B, len(gs))
+    np.testing.assert_array_equal(m, np.repeat((suc == 0).astype(np.uint8)[:, None], len(gs), axis=1))
+    if B > 50:
+        assert 0 < suc.sum() < B
+
+
+@pytest.mark.parametrize("kind,n", [("clifford", 17), ("clifford", 24), ("clifford", 32), ("linear_function", 20), ("linear_function", 33), ("linear_function", 64)])
+def test_dense_observation_of_the_wide_layouts_equals_the_packed_rows(kind, n):
+    """observe() of the 64-bit-row and lane-group layouts goes packed rows -> expansion kernel: it must be the bits of observe_packed(), and
+    the oracle's observation on a sample."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    B = 517
+    gs = line_gateset(kind, n)
+    cfg = dict(add_inverts=(kind == "linear_function"), add_perms=False, track_solution=False, difficulty=3 * n)
+    ov, gv = make_pair(kind, n, gs, B, **cfg)
+    rng = np.random.default_rng(n)
+    draws = rng.integers(0, len(gs), size=(3 * n, B))
+    ov.reset_with(draws)
+    gv.reset_with(torch.as_tensor(draws, device="cuda", dtype=torch.int32))
+    for t in range(3):
+        acts = rng.integers(0, len(gs), size=B)
+        coins = rng.integers(0, 2, size=B) if cfg["add_inverts"] else None
+        ov.step(acts, coins)
+        gv.step(torch.as_tensor(acts, device="cuda", dtype=torch.int32), None if coins is None else torch.as_tensor(coins, device="cuda", dtype=torch.uint8))
+    gv.sync()
+    dense = gv.observe().cpu().numpy().reshape(B, -1)
+    np.testing.assert_array_equal(dense, ov.observe_dense())
+    rows = gv.observe_packed().cpu().numpy()
+    D = dense.shape[1] // rows.shape[1]
+    bits = ((rows.astype(np.uint64)[:, :, None] >> np.arange(D, dtype=np.uint64)) & 1).astype(np.int8).reshape(B, -1)
+    np.testing.assert_array_equal(dense, bits)
