@@ -311,6 +311,7 @@ def main():
     ap.add_argument("--profiling-run", action="store_true",
                     help="this run produces profiles/r03 (tools/profile_bench.sh): the committed rocprofv3 summary is not required and roofline.frac falls "
                          "back to the live clock")
+    ap.add_argument("--no-dense-obs", action="store_true", help="skip the observation-mode legs (SURVEY 8d: packed and dense observation after every step)")
     ap.add_argument("--no-collector", action="store_true", help="skip the policy-in-the-loop leg (SURVEY 8f-3: collection with the reference's default policy shape)")
     ap.add_argument("--no-gather", action="store_true", help="N>1 diagnostics: step only, no all-gather")
     ap.add_argument("--no-p2p", action="store_true", help="N>1: skip the direct-write (hipIpc windows over xGMI) cadence leg")
@@ -798,6 +799,104 @@ def main():
                                  f"a captured graph of {AT} x (step, reset_done) replayed 4 times; headline figures: episode ends spread evenly over time "
                                  "(parity of this schedule: tests/test_gpu_fullsize.py::test_auto_reset_with_desynchronised_episodes_at_full_size)")
 
+    # ---- SURVEY 8(d) "report both modes": the observation handed to the learner after EVERY step of the headline workload.  The Gym adapter
+    # returns the dense int8 [32, 32] matrix per env on every step() (adapters.py:50-54,62-72).  Four graphs of 128 steps each:
+    #   packed        step + qg_vec_observe_packed (the bit-packed [B, 32] row words in env-major order: what the all-gather moves)
+    #   dense         step + qg_vec_observe_dense  (8d's 1 184 B per env-step: a full 1 KiB rewrite per env)
+    #   dense_tracked step on a handle with qg_vec_track_dense: the step kernel itself rewrites the <= 4 rows its gate changed in a RESIDENT
+    #                 dense observation (same bytes in the tensor after every step, <= 128 of the 1 024 written)
+    #   dense_kernel  qg_vec_observe_dense alone (launch period): the HBM-write roofline of the rewrite kernel on the bytes it writes
+    obs_modes = None
+    if not multi and B == ENVS_PER_GPU and not args.no_dense_obs:
+        OT = 128
+        D2 = 4 * n * n  # dense bytes per env
+        oenv = VecEnv("clifford", n, gateset, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=SCRAMBLE)
+        tenv = VecEnv("clifford", n, gateset, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=SCRAMBLE)
+        obs_d = torch.empty((B, 2 * n, 2 * n), dtype=torch.int8, device=dev)
+        obs_p = torch.empty((B, 2 * n), dtype=torch.int32, device=dev)
+
+        def graph_of(body, replays=4):
+            with torch.cuda.stream(stream):
+                body()  # eager pass
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=stream):
+                    body()
+                torch.cuda.synchronize()
+                gr.replay()
+                torch.cuda.synchronize()
+                o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                o0.record(stream)
+                for _ in range(replays):
+                    gr.replay()
+                o1.record(stream)
+            torch.cuda.synchronize()
+            return o0.elapsed_time(o1) * 1e3 / (replays * OT)
+
+        def steps_with(env_, after):
+            def body():
+                for t in range(OT):
+                    env_.step(actions[t % RING])
+                    after()
+            return body
+
+        with torch.cuda.stream(stream):
+            oenv.reset(seed)
+            tenv.reset(seed)
+            tracked = tenv.track_dense()
+        us_packed = graph_of(steps_with(oenv, lambda: oenv.observe_packed(out=obs_p)))
+        us_dense = graph_of(steps_with(oenv, lambda: oenv.observe(out=obs_d)))
+        us_kernel = graph_of(lambda: [oenv.observe(out=obs_d) for _ in range(OT)])
+        us_tracked = graph_of(steps_with(tenv, lambda: None))
+        oenv.sync()
+        tenv.sync()
+        with torch.cuda.stream(stream):
+            oenv.observe_packed(out=obs_p)  # the packed words of the final state (the packed graph ran before the dense one)
+            same = bool(torch.equal(tracked, tenv.observe())) and bool(torch.equal(obs_d, oenv.observe()))
+        if not same:
+            raise SystemExit("bench.py: the tracked dense observation differs from a full rewrite of the same state")
+        # oracle check of a sample: oenv and tenv took the same steps from the same reset (eager pass + 6 replays of each graph)
+        obs_parity = None
+        if rank == 0 and not args.no_parity:
+            o_steps = 2 * 6 * OT  # oenv: two stepping graphs (eager pass + 5 replays each); tenv: one
+            t_steps = 6 * OT
+            sample = np.arange(0, B, 512)
+            acts_np = host_actions[:, sample].numpy()
+            ov_o, _ = oracle_replay(gateset, seed, env_base + sample, acts_np, [t % RING for t in range(OT)] * (o_steps // OT))
+            ov_t, _ = oracle_replay(gateset, seed, env_base + sample, acts_np, [t % RING for t in range(OT)] * (t_steps // OT))
+            sidx = torch.as_tensor(sample, device=dev)
+            ok_d = bool(np.array_equal(obs_d[sidx].cpu().numpy().reshape(len(sample), -1), ov_o.observe_dense()))
+            ok_t = bool(np.array_equal(tracked[sidx].cpu().numpy().reshape(len(sample), -1), ov_t.observe_dense()))
+            ok_p = bool(np.array_equal(obs_p[sidx].cpu().numpy().view(np.uint32), pack_rows_u32(ov_o.observe_dense().reshape(len(sample), 2 * n, 2 * n))))
+            obs_parity = {"envs": int(len(sample)), "dense_rewrite": ok_d, "dense_tracked": ok_t, "packed": ok_p, "bit_exact": ok_d and ok_t and ok_p}
+            if not obs_parity["bit_exact"]:
+                raise SystemExit(f"bench.py: observation modes differ from the CPU oracle replay: {obs_parity}")
+
+        def mode(us, bytes_per_env, what):
+            gbs = bytes_per_env * B / (us * 1e-6) / 1e9
+            return {"us_per_step": us, "value": B / (us * 1e-6), "unit": "env-steps/s", "bytes_per_env_step": bytes_per_env,
+                    "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}, "what": what}
+
+        obs_modes = {
+            "packed": mode(us_packed, ALGO_BYTES_PER_STEP + 2 * 4 * 2 * n,
+                           "step + qg_vec_observe_packed per step: 8d's 160 B + the env-major copy of the 32 row words (128 B read, 128 B written)"),
+            "dense": mode(us_dense, ALGO_BYTES_PER_STEP + D2, "step + qg_vec_observe_dense per step: SURVEY 8d's 1 184 B per env-step (full 1 KiB int8 rewrite)"),
+            "dense_tracked": dict(mode(us_tracked, ALGO_BYTES_PER_STEP + D2,
+                                       "qg_vec_track_dense: the step kernel rewrites the rows its gate changed in a resident dense observation; the tensor "
+                                       "holds the same bytes as after the full rewrite.  frac is quoted on 8d's 1 184 B, most of which this form does not "
+                                       "move (it may exceed 1); frac_moved on the bytes it has to move"),
+                                  bytes_moved_per_env_step=NEEDED_BYTES_PER_STEP + 64,
+                                  frac_moved=(NEEDED_BYTES_PER_STEP + 64) * B / (us_tracked * 1e-6) / 1e9 / HBM_PEAK_GBS),
+            "dense_kernel": {"kernel": "qg::qm_dense_stream_kernel<2>", "us_per_launch": us_kernel, "bytes_written_per_launch": D2 * B,
+                             "roofline": {"bound": "hbm", "achieved": D2 * B / (us_kernel * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": D2 * B / (us_kernel * 1e-6) / 1e9 / HBM_PEAK_GBS},
+                             "what": "launch period of qg_vec_observe_dense alone (hipGraph of 128 launches); written bytes only (it reads 128 B per env)"},
+            "parity": obs_parity,
+            "config": f"the headline workload, one observation after every step, hipGraphs of {OT} steps replayed 4 times; the average changed-row count of the "
+                      "170-action gateset is 1.98 rows of 32 B per step",
+        }
+        del oenv, tenv, obs_d, obs_p, tracked
+
     # ---- SURVEY 8(d)'s other configurations: live launch period (hipGraph of 128 single-step launches) beside the committed rocprofv3 / PMC
     # figures of the same kernels (profiles/r03/traffic.json, tools/profile_bench.sh) -----
     configs = None
@@ -998,6 +1097,7 @@ def main():
             "fused_rollout": fused,
             "default_config": default_cfg,
             "auto_reset": auto_reset,
+            "observation_modes": obs_modes,
             "configs": configs,
             "large_batch": large,
             "policy_in_loop": collector,

@@ -31,8 +31,9 @@
 extern "C" {
 #endif
 
-/* 2: + qg_comm_* / learner-shard entry points, qg_vec_step_host, qg_vec_observe_*_host (additions only: version-1 callers keep working) */
-#define QG_ABI_VERSION 2
+/* 2: + qg_comm_* / learner-shard entry points, qg_vec_step_host, qg_vec_observe_*_host (additions only: version-1 callers keep working)
+ * 3: + qg_vec_track_dense (additions only) */
+#define QG_ABI_VERSION 3
 
 typedef enum {
     QG_OK = 0,
@@ -247,6 +248,15 @@ int qg_vec_rollout_ring(qg_vec *v, const void *actions_dev, int action_dtype, si
 /* Env::observe for every env, densified the way the Gym adapter does it (adapters.py:50-54):
  * out_dev[e * obs_rows*obs_cols + r*obs_cols + c] in {0,1}, int8. */
 int qg_vec_observe_dense(qg_vec *v, int8_t *out_dev, void *stream);
+/* Keep the dense observation RESIDENT: from this call on, dense_dev[B * obs_rows * obs_cols] (caller-owned device memory, 16-byte aligned,
+ * alive until the handle is destroyed or the tracking is detached with dense_dev == NULL) always holds what qg_vec_observe_dense would
+ * write, in stream order after every call that changes states.  What the Gym adapter does after every step (adapters.py:62-72 calls
+ * `_full_obs`, :50-54) costs a full D * D-byte rewrite per env; a gate changes the rows of at most two qubits, so the one-step kernel
+ * rewrites just those rows (<= 4 rows of D bytes: 128 of CliffordEnv 16q's 1 024 bytes) in the launch that applies the gate.  Resets of
+ * finished envs (qg_vec_reset_done) rewrite those envs; launches that cannot track it (add_inverts, fused rollouts, the policy kernels)
+ * are followed by one full rewrite on the same stream.  Handles whose matrix has 16 or 32 rows held as 32-bit words (CliffordEnv
+ * N = 8, 16; LinearFunctionEnv N = 16, 32): QG_ERR_UNSUPPORTED otherwise.  Drop cached expectations: rollout graphs are keyed by it. */
+int qg_vec_track_dense(qg_vec *v, int8_t *dense_dev, void *stream);
 /* Bit-packed observation in QG_FMT_PACKED layout (what the multi-GPU all-gather moves): qg_vec_info.packed_words_per_env
  * words of packed_word_bytes per env, one word per observation row, bit c = column c.  PauliEnv (thread-per-env family,
  * at most 64 observation columns): one 64-bit word per row of the [2N, 2N + max_rotations] observation; the call counts

@@ -382,6 +382,23 @@ __device__ inline uint4 expand_chunk(uint32_t bits, uint32_t one) {
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// 16 bits -> 16 int8 {0,1} entries (adapters.py:50-54's dense observation).  A nibble times 0x204081 puts copies of it at bits 0, 7, 14
+// and 21 (they do not overlap: no carries), so the mask keeps bit k of the nibble in byte k: three full-rate instructions (bfe,
+// mul_u32_u24, and) per output word.
+__device__ inline uint4 expand16_i8(uint32_t bits) {
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = __umul24((bits >> (4 * k)) & 0xFu, 0x204081u) & 0x01010101u;
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+// row `row` of env `env` in the resident dense int8 observation [B][D][D], D = 16 * D16: 16 * D16 bytes at 16-byte alignment
+template <int D16>
+__device__ inline void dense_row_store(int8_t *dense, uint64_t env, uint32_t row, uint32_t w) {
+    uint4 *p = reinterpret_cast<uint4 *>(dense + (env * (16u * D16) + row) * (16u * D16));
+#pragma unroll
+    for (int k = 0; k < D16; ++k) p[k] = expand16_i8(w >> (16 * k));
+}
+
 struct LayerRec {
     int32_t *p;
     __device__ int32_t &operator[](uint32_t i) const { return p[(size_t)i * 64]; }

@@ -1788,6 +1788,8 @@ static int mid_head_step_impl(qg_vec *v, const void *h_dev, uint64_t ld_h, uint3
                                  v->clock_dev, actions_dev, action_dtype, logp_dev, entropy_dev, values_dev, v, rewards_dev, dones_dev, reset_seed, v->env_base, stream);
     if (rc != QG_OK) return rc;
     v->step_index += 1;
+    if (v->dense)  // qg_vec_track_dense: the sampling kernel's step does not write the dense observation (its policy reads the bits)
+        if (int rc2 = dense_refresh_public(v, (hipStream_t)stream)) return rc2;
     // larger batches: the kernel left the list of finished envs, the reset is its own launch
     if (reset_seed && !mid_head_is_small(v->B, in_features, cus)) return qg_vec_reset_done(v, *reset_seed, stream);
     return QG_OK;

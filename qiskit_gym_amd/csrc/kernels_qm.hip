@@ -486,19 +486,21 @@ __global__ __launch_bounds__(256) void qm_inv2_kernel(StepArgs a) {
 // instructions than the register-resident kernel, which at one wave per SIMD is what a step costs;
 // measured 3.77 -> 3.15 us per step at B = 65 536 and 34.9 -> 30.0 us at B = 2^20 (CliffordEnv 16q).
 // LIST: also append the envs that finish to StepArgs::done_list (F_DONE_LIST; its own instantiation: the plain kernel's code stays as it is)
-template <int NXP, bool HAS_Z, bool FEAT, bool LIST = false>
+// DENSE (qg_vec_track_dense, N == NXP, D % 16 == 0): the rows the gate rewrote also go to the resident dense int8 observation
+template <int NXP, bool HAS_Z, bool FEAT, bool LIST = false, bool DENSE = false>
 __global__ __launch_bounds__(256) void qm_step1_kernel(StepArgs a) {
     using Rows = QmRows<NXP, HAS_Z>;
+    constexpr int D16 = DENSE ? Rows::R / 16 : 0;
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
     if constexpr (LIST) {  // every thread reaches the workgroup-wide append
         bool fin = false;
-        if (env < a.B) fin = qm_step1_body<HAS_Z, FEAT>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64));
+        if (env < a.B) fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64));
         done_list_append_block(a.done_list, a.done_count, fin, env, a.B);
     } else {
         if (env >= a.B) return;
         const int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
-        (void)qm_step1_body<HAS_Z, FEAT>(a, Rows::G, env, act);  // qm_step1.hpp
+        (void)qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, act);  // qm_step1.hpp
     }
 }
 
@@ -616,6 +618,15 @@ __device__ inline void qm_init_finish(const InitArgs &a, uint64_t env, const QmR
 #pragma unroll
     for (int g = 0; g < Rows::G; ++g) tile[g * 64 + lane] = make_uint4(s.r[4 * g], s.r[4 * g + 1], s.r[4 * g + 2], s.r[4 * g + 3]);
     if (a.bad) a.bad[env] = qm_badmask<NXP, HAS_Z>(s, a.N);
+    if constexpr (Rows::R % 16 == 0) {  // qg_vec_track_dense, list resets (a few envs): the env's whole dense observation, row by row
+        if (a.dense) {
+#pragma unroll
+            for (int k = 0; k < Rows::R; ++k) {
+                const uint32_t row = HAS_Z ? ((k & 1) ? a.N + (k >> 1) : (k >> 1)) : (uint32_t)k;
+                dense_row_store<Rows::R / 16>(a.dense, env, row, s.r[k]);
+            }
+        }
+    }
     a.depth[env] = a.depth_value;  // reset_internals (clifford.rs:272-283)
     a.success[env] = (uint8_t)solved;
     a.reward[env] = solved ? 1.0f : 0.0f;
@@ -786,25 +797,46 @@ __global__ __launch_bounds__(256) void qm_pack_kernel(ObsArgs a, uint32_t nxp, u
     }
 }
 
-// Dense int8 observation for D == 32 (CliffordEnv N = 16): one lane expands one packed row into
-// 32 bytes (two 16 B stores); a wave writes 2 KiB contiguously.
-__global__ __launch_bounds__(256) void qm_dense32_kernel(ObsArgs a) {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // env * 32 + row
-    if (gid >= a.B * 32ull) return;
-    const uint64_t env = gid >> 5;
-    const uint32_t row = (uint32_t)gid & 31u;
-    const uint32_t slot = row < 16 ? 2 * row : 2 * (row - 16) + 1;  // X/Z interleaved slots
-    const uint32_t *tile = reinterpret_cast<const uint32_t *>(a.state) + (env >> 6) * (uint64_t)(32 * 64);
-    const uint32_t w = tile[((slot >> 2) * 64 + (uint32_t)(env & 63)) * 4 + (slot & 3)];
-    uint32_t o[8];
+// Dense int8 observation (adapters.py:50-54) for matrices of D = 16 * D16 rows without padding slots (CliffordEnv N = 8, 16;
+// LinearFunctionEnv N = 16, 32): HBM-write bound (D * D bytes per env against D * 4 read).  A wave owns a tile: its 64 envs' rows come
+// in with coalesced 1 KiB loads and are turned to [env][row] order in LDS (pitch D + 1 words: conflict-free both ways); then every
+// store instruction of the wave writes 1 KiB CONTIGUOUS bytes of the output (lane i owns 16-byte chunk i), the 64 * D * D bytes of
+// the tile front to back: 11.5 us at 65 536 envs (rocprofv3) = 5.8 TB/s of written bytes.  (The version before wrote two 16-byte pieces
+// 32 bytes apart per lane -- every store instruction spanned 2 KiB with holes: 17.6 us.  A workgroup per tile, 16 envs per wave, with
+// or without non-temporal stores, measured 1-1.6 us slower than a wave per tile.)
+template <int D16>
+__global__ __launch_bounds__(256) void qm_dense_stream_kernel(ObsArgs a, uint32_t has_z) {
+    constexpr uint32_t D = 16u * D16, G = D / 4u, PITCH = D + 1u, CPE = D * D16;  // CPE: 16-byte chunks per env
+    __shared__ uint32_t lds[4][64 * PITCH];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t n_tiles = (a.B + 63u) / 64u;
+    const uint64_t tile_idx = (uint64_t)blockIdx.x * 4u + wave;
+    if (tile_idx >= n_tiles) return;  // wave-private LDS, no workgroup barrier below
+    uint32_t *my = lds[wave];
+    const uint4 *tile = reinterpret_cast<const uint4 *>(a.state) + tile_idx * (uint64_t)(G * 64u);
+    uint4 vs[G];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const uint32_t nb = (w >> (4 * k)) & 0xFu;
-        o[k] = (nb & 1u) | ((nb & 2u) << 7) | ((nb & 4u) << 14) | ((nb & 8u) << 21);  // bit i -> byte i
+    for (uint32_t g = 0; g < G; ++g) vs[g] = tile[g * 64u + lane];
+#pragma unroll
+    for (uint32_t g = 0; g < G; ++g) {
+        const uint32_t w[4] = {vs[g].x, vs[g].y, vs[g].z, vs[g].w};
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) {
+            const uint32_t slot = 4u * g + c;
+            const uint32_t row = has_z ? ((slot & 1u) ? D / 2u + (slot >> 1) : (slot >> 1)) : slot;
+            my[lane * PITCH + row] = w[c];
+        }
     }
-    uint4 *out = reinterpret_cast<uint4 *>(reinterpret_cast<int8_t *>(a.out) + gid * 32ull);
-    out[0] = make_uint4(o[0], o[1], o[2], o[3]);
-    out[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    __builtin_amdgcn_wave_barrier();  // the LDS region is this wave's own: its writes are ordered before its reads (lgkmcnt), no s_barrier
+    const uint64_t env0 = tile_idx * 64u;
+    const uint32_t envs = a.B - env0 < 64u ? (uint32_t)(a.B - env0) : 64u;
+    uint4 *out = reinterpret_cast<uint4 *>(reinterpret_cast<int8_t *>(a.out) + env0 * (uint64_t)(D * D));
+    const uint32_t n_chunks = envs * CPE;
+#pragma unroll 8
+    for (uint32_t i = lane; i < n_chunks; i += 64u) {
+        const uint32_t e = i / CPE, r = (i % CPE) / D16, part = i % D16;
+        out[i] = expand16_i8(my[e * PITCH + r] >> (16u * part));
+    }
 }
 
 // Dense observation in the policy's dtype straight from the tiles: one thread per 16-byte output
@@ -834,6 +866,15 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
     const bool seq = a.T != 1 || a.rewards_seq || a.dones_seq;
     if (a.bad && a.T == 1 && !(a.flags & F_INVERTS)) {  // the env.step() path
         const bool list = a.flags & F_DONE_LIST;
+        if constexpr (QmRows<NXP, HAS_Z>::R % 16 == 0) {
+            if (a.dense) {  // qg_vec_track_dense (the host passes it for N == NXP only)
+                if (feat && list) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, true, true, true>), grid, block, 0, s, a);
+                else if (feat) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, true, false, true>), grid, block, 0, s, a);
+                else if (list) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, false, true, true>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, false, false, true>), grid, block, 0, s, a);
+                return hipGetLastError();
+            }
+        }
         if (feat && list) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, true, true>), grid, block, 0, s, a);
         else if (feat) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, true>), grid, block, 0, s, a);
         else if (list) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, false, true>), grid, block, 0, s, a);
@@ -917,8 +958,11 @@ hipError_t qm_init(const InitArgs &a, uint32_t nxp, bool has_z, hipStream_t s) {
 }
 hipError_t qm_export(const ObsArgs &a, uint32_t nxp, bool has_z, hipStream_t s) {
     if (!a.B) return hipSuccess;
-    if (has_z && a.N == 16 && a.format == QG_FMT_U8 && a.out_stride == 1024 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
-        hipLaunchKernelGGL(qm_dense32_kernel, dim3(grid_for(a.B * 32ull, 256)), dim3(256), 0, s, a);
+    const uint32_t R = has_z ? 2 * nxp : nxp;
+    if (a.format == QG_FMT_U8 && a.D == R && (a.D == 16 || a.D == 32) && a.out_stride == (uint64_t)a.D * a.D && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
+        const dim3 grid((unsigned)((a.B + 255) / 256)), block(256);  // a wave per tile of 64 envs
+        if (a.D == 32) hipLaunchKernelGGL(qm_dense_stream_kernel<2>, grid, block, 0, s, a, has_z ? 1u : 0u);
+        else hipLaunchKernelGGL(qm_dense_stream_kernel<1>, grid, block, 0, s, a, has_z ? 1u : 0u);
         return hipGetLastError();
     }
     if (a.format == QG_FMT_PACKED && a.out_stride == a.D && a.D <= 32 && (reinterpret_cast<uintptr_t>(a.out) & 3) == 0) {

@@ -378,6 +378,12 @@ static hipError_t launch_step(const qg_vec *v, const StepArgs &a, hipStream_t s)
     }
 }
 
+// qg_vec_track_dense.  The one-step kernel without add_inverts (qm_step1_kernel) rewrites the rows its gate changed in the same launch;
+// every other launch that changes states is followed by a full rewrite (dense_refresh), except resets of a list of finished envs, which
+// rewrite those envs' observations themselves.
+static bool dense_rides_in_step(const qg_vec *v) { return v->dense && v->layout == LAYOUT_TILE && v->bad && !(v->flags & F_INVERTS); }
+static int dense_refresh(qg_vec *v, hipStream_t s);
+
 int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, uint64_t batch, int device, qg_vec **out) {
     if (!cfg || !out || (!gates && n_gates)) return set_error(QG_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -701,6 +707,8 @@ int qg_vec_set_state(qg_vec *v, const void *states, int format, size_t stride, i
         ia.nonsymp_flag = v->d_nonsymp;
     }
     HIP_TRY(launch_init(v, ia, s));
+    if (v->dense)
+        if (int rc = dense_refresh(v, s)) return rc;
     if (ia.check_symplectic) {
         uint32_t flag = 0;
         HIP_TRY(hipMemcpyAsync(&flag, v->d_nonsymp, sizeof flag, hipMemcpyDeviceToHost, s));
@@ -796,11 +804,13 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
         ia.list = v->done_list;
         ia.list_count = v->done_list + v->B;
         ia.coop = (!actions_dev && v->B >= 64 && v->d_rowops) ? 1u : 0u;
+        if (v->layout == LAYOUT_TILE) ia.dense = v->dense;  // the listed envs' dense observations are rewritten by the reset itself
     }
     if (!only_done) v->maybe_nonsymplectic = false;  // identity + gates: every env is symplectic again
     int64_t d = (int64_t)v->cfg.depth_slope * v->difficulty;  // clifford.rs:317
     ia.depth_value = (int32_t)std::min<int64_t>(d, v->cfg.max_depth);
     HIP_TRY(launch_init(v, ia, s));
+    if (v->dense && !ia.dense) return dense_refresh(v, s);
     return QG_OK;
 }
 
@@ -900,9 +910,11 @@ int qg_vec_step(qg_vec *v, const void *actions_dev, int action_dtype, const uint
     a.actions = actions_dev;
     a.coins = coins_dev;
     if (action_dtype == QG_ACT_I64) a.flags |= F_ACT64;
+    if (dense_rides_in_step(v)) a.dense = v->dense;
     HIP_TRY(launch_step(v, a, (hipStream_t)stream));
     v->step_index += 1;
     if (lists) done_list_appended(v, true);
+    if (v->dense && !a.dense) return dense_refresh(v, (hipStream_t)stream);
     return QG_OK;
 }
 
@@ -979,11 +991,13 @@ static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, si
     a.dones_seq = dones_dev;
     if (action_dtype == QG_ACT_I64) a.flags |= F_ACT64;
     if (v->layout == LAYOUT_LFD) fused = 0;  // its step kernel spreads an env over four lanes; T steps = T launches (one graph)
+    if (dense_rides_in_step(v) && (!fused || T == 1)) a.dense = v->dense;  // single-step launches keep the tracked observation current themselves
     if (fused) {
         if (period != T) return set_error(QG_ERR_INVALID, "fused rollouts read actions[t] for every t");
         a.T = (uint32_t)T;
         HIP_TRY(launch_step(v, a, s));
         v->step_index += T;
+        if (v->dense && !a.dense) return dense_refresh(v, s);
         return QG_OK;
     }
     const size_t act_bytes = action_dtype == QG_ACT_I64 ? 8 : 4;
@@ -999,6 +1013,11 @@ static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, si
             hipError_t e = launch_step(v, b, st);
             if (e != hipSuccess) return e;
         }
+        if (v->dense && !a.dense) {  // kernels that do not track it (add_inverts, other layouts): one full rewrite after the last step
+            ObsArgs oa;
+            fill_obs_args(v, oa, v->dense, QG_FMT_U8, (size_t)v->D * v->D);
+            return launch_export(v, oa, st);
+        }
         return hipSuccess;
     };
     // A graph bakes kernel arguments in: the counter-RNG coin path changes per call, and a stream
@@ -1012,7 +1031,7 @@ static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, si
         if (lists) done_list_appended(v, true);
         return QG_OK;
     }
-    GraphKey key{actions_dev, coins_dev, rewards_dev, dones_dev, T, action_dtype, period, a.flags, v->env_base};
+    GraphKey key{actions_dev, coins_dev, rewards_dev, dones_dev, T, action_dtype, period, a.flags, v->env_base, v->dense};
     CachedGraph *cg = nullptr;
     for (auto &g : v->graphs)
         if (g.key == key) cg = &g;
@@ -1072,6 +1091,28 @@ static int observe_dense_impl(qg_vec *v, int8_t *out_dev, const int32_t *perm_id
 int qg_vec_observe_dense(qg_vec *v, int8_t *out_dev, void *stream) {
     if (!v || !out_dev) return set_error(QG_ERR_INVALID, "null argument");
     return observe_dense_impl(v, out_dev, nullptr, stream);
+}
+
+static int dense_refresh(qg_vec *v, hipStream_t s) {
+    ObsArgs oa;
+    fill_obs_args(v, oa, v->dense, QG_FMT_U8, (size_t)v->D * v->D);
+    HIP_TRY(launch_export(v, oa, s));
+    return QG_OK;
+}
+
+int qg_vec_track_dense(qg_vec *v, int8_t *dense_dev, void *stream) {
+    if (!v) return set_error(QG_ERR_INVALID, "null argument");
+    QG_ON_DEVICE(v);
+    if (!dense_dev) {
+        v->dense = nullptr;
+        return QG_OK;
+    }
+    const uint32_t R = v->has_z ? 2 * v->nxp : v->nxp;
+    if (v->layout != LAYOUT_TILE || v->D != R || (v->D != 16 && v->D != 32))
+        return set_error(QG_ERR_UNSUPPORTED, "track_dense: matrices of 16 or 32 rows held as 32-bit row words (CliffordEnv N = 8, 16; LinearFunctionEnv N = 16, 32)");
+    if ((uintptr_t)dense_dev & 15u) return set_error(QG_ERR_INVALID, "track_dense: the buffer must be 16-byte aligned");
+    v->dense = dense_dev;
+    return dense_refresh(v, (hipStream_t)stream);
 }
 
 int qg_vec_pauli_observe_dense(qg_vec *v, int8_t *out_dev, const int32_t *perm_idx_dev, void *stream) {
@@ -1203,6 +1244,7 @@ int64_t qg_vec_solution(qg_vec *v, uint64_t env, uint64_t *out, size_t cap) {
 
 namespace qg {
 void fill_step_args_public(const qg_vec *v, StepArgs &a) { fill_step_args(v, a); }
+int dense_refresh_public(qg_vec *v, hipStream_t s) { return dense_refresh(v, s); }
 // InitArgs of qg_vec_reset_done(v, seed) without a list: what a kernel that resets finished envs itself needs (qg_vec_mid_head_sample_step)
 void fill_reset_done_args_public(const qg_vec *v, uint64_t seed, InitArgs &ia) {
     fill_init_args(v, ia);

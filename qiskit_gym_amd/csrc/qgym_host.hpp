@@ -20,9 +20,10 @@ struct GraphKey {
     size_t period;
     uint32_t flags;     // effective StepArgs::flags: they pick the kernel variant (e.g. F_GJ follows maybe_nonsymplectic)
     uint64_t env_base;  // baked into the captured launches like every other kernel argument
+    const void *dense;  // qg_vec_track_dense: the tracked buffer (picks the DENSE kernel variant, and is baked in)
     bool operator==(const GraphKey &o) const {
         return actions == o.actions && coins == o.coins && rewards == o.rewards && dones == o.dones && T == o.T &&
-               dtype == o.dtype && period == o.period && flags == o.flags && env_base == o.env_base;
+               dtype == o.dtype && period == o.period && flags == o.flags && env_base == o.env_base && dense == o.dense;
     }
 };
 struct CachedGraph {
@@ -119,6 +120,7 @@ struct qg_vec {
     bool list_zero_known = true;        // the list's length is known to be zero (creation, a memset, or its consumer ran) -- within the session
     bool list_tainted = false;          // some launch that touches the list was captured into a caller's graph: eager calls trust nothing
     uint64_t list_session = 0;          // 0 = eager execution, else the stream capture id the beliefs above belong to (qgym_api.cpp)
+    int8_t *dense = nullptr;            // qg_vec_track_dense: caller-owned [B][rows][cols] int8 observation kept equal to observe_dense() of the state
     uint32_t *d_nonsymp = nullptr;      // device word behind InitArgs::nonsymp_flag
     void *embed_dump = nullptr;         // qg_vec_embed: 1 KiB nobody reads (kernels_policy.hip), allocated by qg_vec_pack_embedding
     bool maybe_nonsymplectic = false;   // CliffordEnv + add_inverts: some env may need the Gauss-Jordan inversion
@@ -151,6 +153,8 @@ bool done_list_session(qg_vec *v, hipStream_t s);
 int done_list_before_append(qg_vec *v, hipStream_t s);
 void done_list_appended(qg_vec *v, bool trusted);
 void fill_step_args_public(const qg_vec *v, StepArgs &a);
+// qg_vec_track_dense: rewrite the whole tracked observation from the state (after a launch that changed states without updating it)
+int dense_refresh_public(qg_vec *v, hipStream_t s);
 void fill_reset_done_args_public(const qg_vec *v, uint64_t seed, InitArgs &ia);
 void compute_qubit_and_action_perms(uint32_t N, const std::vector<qg_gate> &gates, std::vector<std::vector<int64_t>> &qubit_perms,
                                     std::vector<std::vector<int64_t>> &act_perms);

@@ -110,6 +110,8 @@ struct StepArgs {
     uint32_t *bad;            // TILE (uint32) / TILE64 (uint64) per-env mask: bit j = qubit j's rows / row j differ from the identity's; or null
     uint32_t *done_list;      // F_DONE_LIST: [B] indices of the envs that finished in this step, then {length, reader ticket} (compact_done's format);
     uint32_t *done_count;     // read only under that flag (the last fields of the block: other launches never touch their cache line)
+    int8_t *dense;            // qg_vec_track_dense: the resident dense int8 observation [B][D][D]; the DENSE instantiations of the one-step kernels
+                              // rewrite the rows their gate changed (read by those instantiations only)
 };
 
 // The argument block spans four 64-byte lines and the scalar cache is cold at every launch.  Left alone, the compiler fetches a field
@@ -163,6 +165,8 @@ struct InitArgs {
     const uint32_t *rowops;    // TILE layout: per action two row operations (make_op, slot indices) for that kernel
     uint64_t env_base;         // global index of env 0 in the counter RNG (qg_vec_set_env_base)
     uint32_t inverts;          // add_inverts is set (PermutationEnv set_state: a state with a repeated entry is a fault only then)
+    int8_t *dense;             // qg_vec_track_dense + a list of finished envs: the reset rewrites those envs' dense observation (else null: the host
+                               // refreshes the whole buffer after the launch)
 };
 
 // A handle may be given a device-resident clock (qg_vec_set_clock).  Launches replayed from a

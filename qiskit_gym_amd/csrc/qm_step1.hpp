@@ -37,7 +37,9 @@ __device__ inline void qm_group_put(uint32_t (&u)[4], uint32_t q, uint32_t x, ui
 // One env.step() of env `env` with action `act` (already loaded): gathers the gate's <= 2 row groups from the env's tile (G groups of
 // 1 KiB), applies the gate's 4x4 GF(2) map, scatters, updates the incremental solved mask, depth, reward, done, success (and the
 // solution log / layer metrics when FEAT).  Returns is_final.
-template <bool HAS_Z, bool FEAT>
+// D16 > 0 (qg_vec_track_dense; the matrix has D = 16 * D16 rows, no padding slots): the rows the gate rewrote also go to the env's
+// dense int8 observation -- <= 4 rows of D bytes instead of the D * D bytes a full qg_vec_observe_dense writes.
+template <bool HAS_Z, bool FEAT, int D16 = 0>
 __device__ inline bool qm_step1_body(const StepArgs &a, uint32_t G, uint64_t env, int64_t act) {
     const uint32_t lane = (uint32_t)env & (QG_WAVE - 1);
     uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(G * 64);
@@ -47,6 +49,7 @@ __device__ inline bool qm_step1_body(const StepArgs &a, uint32_t G, uint64_t env
     int32_t sol_n = (FEAT && (a.flags & F_TRACK)) ? a.sol_len[env * 2] : 0;
     const bool in_range = act >= 0 && act < (int64_t)a.num_actions;  // gateset.get(action) (clifford.rs:324)
     float penalty = 0.0f;
+    uint32_t drow[4] = {0, 0, 0, 0}, dword[4] = {0, 0, 0, 0}, dchg = 0;  // D16: the rows the gate changed (bit k of dchg: entry k)
     if (in_range) {
         const GateEntry g = a.gates[act];
         penalty = g.penalty;
@@ -77,6 +80,12 @@ __device__ inline bool qm_step1_body(const StepArgs &a, uint32_t G, uint64_t env
             qm_group_put<HAS_Z>(ua, q0, nx0, nz0);
             if (!same) tile[g1 * 64 + lane] = make_uint4(ub[0], ub[1], ub[2], ub[3]);
             tile[g0 * 64 + lane] = make_uint4(ua[0], ua[1], ua[2], ua[3]);
+            if constexpr (D16 > 0) {  // the rows that changed (S rewrites one of a qubit's two rows, CX two of four, ...): stored below
+                drow[0] = q0; dword[0] = nx0; dchg |= (uint32_t)(nx0 != x0);
+                drow[1] = a.N + q0; dword[1] = nz0; dchg |= (uint32_t)(HAS_Z && nz0 != z0) << 1;
+                drow[2] = q1; dword[2] = nx1; dchg |= (uint32_t)(q1 != q0 && nx1 != x1) << 2;
+                drow[3] = a.N + q1; dword[3] = nz1; dchg |= (uint32_t)(HAS_Z && q1 != q0 && nz1 != z1) << 3;
+            }
             const uint32_t zb = 1u << a.N;
             const uint32_t b1 = (uint32_t)(nx1 != (1u << q1) || (HAS_Z && nz1 != (zb << q1)));
             const uint32_t b0 = (uint32_t)(nx0 != (1u << q0) || (HAS_Z && nz0 != (zb << q0)));
@@ -84,6 +93,31 @@ __device__ inline bool qm_step1_body(const StepArgs &a, uint32_t G, uint64_t env
             bad = (bad & ~(1u << q0)) | (b0 << q0);
         }
         if (layered) penalty = layers_commit(lt, a.w);
+    }
+    // qg_vec_track_dense: matrix row r, column c of env e at dense[(e * D + r) * D + c] (clifford.rs:361-368, adapters.py:50-54)
+    if constexpr (D16 == 2) {
+        // The two lanes of a pair (2k, 2k + 1: neighbouring envs) write one 32-byte row together, 16 bytes each, so that a store
+        // instruction's lanes cover whole rows: per-lane rows (two 16-byte stores 16 bytes apart from ONE lane) measured 5.28 us per step at
+        // 65 536 envs, this form 4.83 (3.11 without the dense observation).  Every lane that runs this body reaches this point; a pair lane
+        // that does not (the batch's ragged end) reads as "no row": update_dpp keeps `old` = 0 for a disabled source lane.
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t mine = ((dchg >> k) & 1u) ? (drow[k] | 0x80000000u) : 0u;
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {  // quad_perm [0, 0, 2, 2] / [1, 1, 3, 3]: the even / odd lane's entry on both lanes of the pair
+                const uint32_t r = par ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xF5, 0xF, 0xF, false)
+                                       : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xA0, 0xF, 0xF, false);
+                const uint32_t w = par ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dword[k], 0xF5, 0xF, 0xF, false)
+                                       : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dword[k], 0xA0, 0xF, 0xF, false);
+                const uint64_t e = (env & ~1ull) | (uint64_t)par;
+                const uint32_t half = lane & 1u;
+                if (r >> 31) *reinterpret_cast<uint4 *>(a.dense + (e * 32u + (r & 31u)) * 32u + 16u * half) = expand16_i8(w >> (16u * half));
+            }
+        }
+    } else if constexpr (D16 == 1) {  // 16-byte rows: one store each
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((dchg >> k) & 1u) dense_row_store<1>(a.dense, env, drow[k], dword[k]);
     }
     if (FEAT && (a.flags & F_TRACK)) {  // clifford.rs:334-340
         if ((uint32_t)sol_n < a.sol_cap) sol_at(a, env, (uint32_t)sol_n++) = sol_word_framed(act, false);

@@ -71,6 +71,7 @@ class VecEnv:
         if getattr(self, "_h", None):
             self._L.qg_vec_destroy(self._h)
             self._h = None
+        self._dense = None
 
     def __del__(self):
         try:
@@ -226,6 +227,19 @@ class VecEnv:
             out = torch.empty((self.batch, r, c), dtype=torch.int8, device=self.device)
         _lib.check(self._L.qg_vec_observe_dense(self._h, out.data_ptr(), self._stream()))
         return out
+
+    def track_dense(self, enable: bool = True) -> Optional[torch.Tensor]:
+        """Keep the dense int8 observation [B, rows, cols] resident and current (`qg_vec_track_dense`): the returned tensor equals
+        `observe()` after every later call, in stream order; a step rewrites only the rows its gate changed.  `enable=False` detaches."""
+        if not enable:
+            _lib.check(self._L.qg_vec_track_dense(self._h, None, self._stream()))
+            self._dense = None
+            return None
+        r, c = self.obs_shape_
+        dense = torch.empty((self.batch, r, c), dtype=torch.int8, device=self.device)
+        _lib.check(self._L.qg_vec_track_dense(self._h, dense.data_ptr(), self._stream()))
+        self._dense = dense  # the handle writes into it until detached: keep it alive
+        return dense
 
     _DTYPES = {torch.int8: _lib.QG_DT_I8, torch.float32: _lib.QG_DT_F32, torch.bfloat16: _lib.QG_DT_BF16, torch.float16: _lib.QG_DT_F16}
 
