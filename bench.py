@@ -37,12 +37,16 @@ import os
 NPROC = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "threads")
+# multi-process GPU work on this pool needs dmabuf IPC (hipIpcGetMemHandle fails otherwise): set before anything can initialise HIP -- the
+# ranks may come from the driver's launcher, not from launch_ranks() below
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import argparse  # noqa: E402
 import csv  # noqa: E402
 import json  # noqa: E402
 import socket  # noqa: E402
 import subprocess  # noqa: E402
+import threading  # noqa: E402
 import sys  # noqa: E402
 import time  # noqa: E402
 
@@ -65,6 +69,8 @@ ALGO_BYTES_PER_STEP = 160  # 128 B state read + 16 B touched row
 # entry comes from a 1.4 KB table that stays cache resident
 NEEDED_BYTES_PER_STEP = 2 * 16 + 2 * 16 + 4 + 8 + 8 + 4 + 2
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+CONTROL_TIMEOUT_S = 90   # gloo control plane: a rank that never reaches a barrier costs its peers this long, not the driver's whole budget
+CADENCE_BUDGET_S = 240   # N > 1: wall-clock budget of the optional collective-cadence legs; past it the line is printed without them
 KERNEL = "qg::qm_step1_kernel<16, true, false"  # prefix: the trailing template arguments (feature flags, done list) vary by call site
 PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
 
@@ -373,7 +379,9 @@ def main():
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: the control plane stays on loopback (the hostname may not resolve)
         torch.cuda.set_device(local_rank)
         # control plane only (CPU tensors): id broadcast, barriers, max-over-ranks of the elapsed time
-        dist.init_process_group("gloo")
+        import datetime
+
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=CONTROL_TIMEOUT_S))
         if dist.get_world_size() != world:
             raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, expected {world}")
         from qiskit_gym_amd.distributed import Communicator
@@ -438,7 +446,7 @@ def main():
     gather_every = min(args.gather_every, K)
     gather_log = {"submitted": 0}
     if multi:
-        from qiskit_gym_amd.distributed import split_gathered
+        from qiskit_gym_amd.distributed import run_guarded_phases, split_gathered
 
         # double-buffered, host-mediated hand-over to the communicator's side stream, inside libqgym (qg_comm_gather_submit: a
         # stream-to-stream event wait would slow every later graph replay on the step stream by ~40 %).  One flat shard per rank
@@ -447,12 +455,34 @@ def main():
         layout = env.shard_layout()
 
         direct = args.handover == "direct"
-        if direct:  # hipIpc handles over the control plane (gloo), then every rank maps every other rank's window
-            mine = comm.p2p_export(int(layout.bytes))
-            handles = [None] * world
-            dist.all_gather_object(handles, mine)
-            comm.p2p_open(handles)
-            dist.barrier()
+        p2p_state = {"connected": False}
+
+        def connect_windows():
+            """hipIpc handles over the control plane (gloo), then every rank maps every other rank's window.  Each phase is local to a rank
+            and followed by a vote of all ranks: a rank whose hipIpcOpenMemHandle fails stops everybody at the same point (None = connected)."""
+            box = {}
+
+            def export():
+                box["mine"] = comm.p2p_export(int(layout.bytes))
+
+            def exchange():
+                box["handles"] = [None] * world
+                dist.all_gather_object(box["handles"], box["mine"])
+
+            def open_():
+                if os.environ.get("QG_BENCH_INJECT_P2P_OPEN_FAILURE") == str(rank):  # tests: this rank cannot map its peers
+                    raise RuntimeError("injected: hipIpcOpenMemHandle failed")
+                comm.p2p_open(box["handles"])
+
+            err = run_guarded_phases([("p2p_export", export), ("handle_exchange", exchange), ("p2p_open", open_)])
+            p2p_state["connected"] = err is None
+            return err
+
+        if direct:
+            err = connect_windows()
+            if err is not None:  # the transport the caller asked for does not exist: no headline number in this mode
+                print(f"bench.py: rank {rank}: --handover direct cannot be set up: {err}", file=sys.stderr)
+                sys.exit(3)
         direct_latest = [None]
 
         def snapshot_and_gather():
@@ -572,12 +602,17 @@ def main():
                      trace=np.asarray(gshard["trace"], dtype=np.int64), obs=gshard["obs"], reward=gshard["reward"], done=gshard["done"],
                      success=gshard["success"], total_envs=total_envs, env_base=env_base)
 
-    # ---- collective cadences, beside the timed region (N > 1 or --force-multi) -------------------
-    cadence = None
+    # ---- collective cadences, beside the timed region (N > 1 or --force-multi): run LAST, after everything the line needs has been
+    # measured, every phase followed by a vote of all ranks (run_guarded_phases) and the whole block under a wall-clock budget -- a rank that
+    # fails (or a peer that never shows up) costs these optional figures, never the headline line -------------------
     if multi and not args.no_gather and args.handover == "direct":
         with torch.cuda.stream(stream):
             comm.check()  # a peer that missed a deadline during the run is an error, not a slow number
-    if multi and not args.no_gather and args.handover == "rccl":
+
+    def collective_cadences():
+        if not (multi and not args.no_gather and args.handover == "rccl"):
+            return None
+
         def timed(fn, reps):
             torch.cuda.synchronize()
             if dist is not None:
@@ -597,29 +632,31 @@ def main():
             env.step(actions[0])
             snapshot_and_gather()
 
-        per_step = timed(step_and_gather, 64)       # SURVEY 8e's literal cadence: one all-gather per env.step()
-        gather_only = timed(snapshot_and_gather, 16)  # snapshot + collective alone, nothing to overlap with
+        cadence = {"segment_steps": gather_every, "shard_bytes_per_rank": int(layout.bytes)}
         inline_out = torch.empty(int(layout.bytes) * world, dtype=torch.uint8, device=dev)
 
         def step_and_gather_in_stream():  # qg_vec_gather_learner_shard: pack + ncclAllGather on the step stream itself
             env.step(actions[0])
             comm.gather(env, out=inline_out)
 
-        in_stream = timed(step_and_gather_in_stream, 64)
-        cadence = {
-            "per_step_gather_us": per_step * 1e6,
-            "per_step_gather_value": B * n_gpus / per_step,
-            "in_stream_gather_us": in_stream * 1e6,
-            "segment_gather_us": gather_only * 1e6,
-            "segment_steps": gather_every,
-            "shard_bytes_per_rank": int(layout.bytes),
-        }
+        def rccl_legs():
+            per_step = timed(step_and_gather, 64)       # SURVEY 8e's literal cadence: one all-gather per env.step()
+            gather_only = timed(snapshot_and_gather, 16)  # snapshot + collective alone, nothing to overlap with
+            in_stream = timed(step_and_gather_in_stream, 64)
+            cadence.update({"per_step_gather_us": per_step * 1e6, "per_step_gather_value": B * n_gpus / per_step,
+                            "in_stream_gather_us": in_stream * 1e6, "segment_gather_us": gather_only * 1e6})
+
+        err = run_guarded_phases([("rccl_cadences", rccl_legs)])
+        if err is not None:
+            cadence["error"] = err
+            return cadence
         # the direct write (SURVEY 5's follow-up): every rank copies its shard into a window in each peer's HBM over xGMI and raises
         # a flag there; no collective library on the data path.  Measured beside the RCCL cadences, and checked against them.
         if not args.no_p2p:
-            try:
-                comm.p2p_connect(int(layout.bytes))  # windows + hipIpc handle exchange over the communicator (collective)
+            err = connect_windows()
+            if err is None:
                 p2p_view = [None]
+                res = {}
 
                 def step_push_wait():
                     env.step(actions[0])
@@ -632,30 +669,37 @@ def main():
                     p2p_view[0] = comm.wait()
                     comm.release()
 
-                with torch.cuda.stream(stream):  # first use, checked at once: a peer that never arrives costs one deadline, not one per repetition
-                    step_push_wait()
-                    comm.check()
-                timed(step_push_wait, 4)
-                p2p_step = timed(step_push_wait, 64)
-                p2p_only = timed(push_wait, 16)
-                with torch.cuda.stream(stream):
-                    comm.push(env)
-                    view = comm.wait()
-                    direct = view.clone()
-                    comm.release()
-                    comm.gather(env, out=inline_out)
-                    comm.check()
-                same = bool(torch.equal(direct, inline_out))
-                cadence["direct_write"] = {"per_step_us": p2p_step * 1e6, "per_step_value": B * n_gpus / p2p_step, "push_wait_release_us": p2p_only * 1e6,
-                                           "equals_rccl_gather": same,
-                                           "what": "qg_vec_push_learner_shard + qg_comm_p2p_wait + qg_comm_p2p_release after every env.step(): the pack, "
-                                                   "one copy kernel writing into all ranks' hipIpc-mapped windows, per-source arrival flags"}
-                if not same:
-                    raise SystemExit("bench.py: the direct-write hand-over and the RCCL all-gather disagree")
-            except SystemExit:
-                raise
-            except Exception as exc:  # reported, not fatal: the RCCL path above is the measured default
-                cadence["direct_write"] = {"error": repr(exc)}
+                def first_epoch():  # first use, checked at once: a peer that never arrives costs one deadline, not one per repetition
+                    with torch.cuda.stream(stream):
+                        step_push_wait()
+                        comm.check()
+
+                def timed_legs():
+                    timed(step_push_wait, 4)
+                    res["p2p_step"] = timed(step_push_wait, 64)
+                    res["p2p_only"] = timed(push_wait, 16)
+
+                def compare():
+                    with torch.cuda.stream(stream):
+                        comm.push(env)
+                        view = comm.wait()
+                        direct_copy = view.clone()
+                        comm.release()
+                        comm.gather(env, out=inline_out)
+                        comm.check()
+                    res["same"] = bool(torch.equal(direct_copy, inline_out))
+                    if not res["same"]:
+                        raise RuntimeError("the direct-write hand-over and the RCCL all-gather disagree")
+
+                err = run_guarded_phases([("first_epoch", first_epoch), ("timed", timed_legs), ("equals_rccl_gather", compare)])
+                if err is None:
+                    cadence["direct_write"] = {"per_step_us": res["p2p_step"] * 1e6, "per_step_value": B * n_gpus / res["p2p_step"],
+                                               "push_wait_release_us": res["p2p_only"] * 1e6, "equals_rccl_gather": res["same"],
+                                               "what": "qg_vec_push_learner_shard + qg_comm_p2p_wait + qg_comm_p2p_release after every env.step(): the pack, "
+                                                       "one copy kernel writing into all ranks' hipIpc-mapped windows, per-source arrival flags"}
+            if err is not None:  # reported, not fatal: the RCCL path above is the measured default
+                cadence["direct_write"] = {"error": err}
+        return cadence
 
     # ---- roofline leg: duration of the step kernel, HIP events on the stream the kernel is launched on --------
     # (1) the timed region itself: events around the K timed launches (what `achieved` uses)
@@ -685,7 +729,7 @@ def main():
     algo_bytes = ALGO_BYTES_PER_STEP * B
     needed_bytes = NEEDED_BYTES_PER_STEP * B
     achieved = algo_bytes / (timed_region_us * 1e-6) / 1e9
-    rocprof = rocprof_kernel_avg_us(B, required=(rank == 0 and not args.profiling_run and B == ENVS_PER_GPU))
+    rocprof = rocprof_kernel_avg_us(B)  # the committed rocprofv3 summary of this command: reported beside the live clock, never required
     traffic = pmc_traffic(B)
 
     # ---- fused rollout (state in LDS across steps), reported beside the headline --------
@@ -1021,11 +1065,27 @@ def main():
             K, " + ".join(f"{graphs.count(c)} x hipGraph of {c} launches" for c in sorted(set(graphs), reverse=True)) or "no graph",
             f" + {eager} eager launch(es)" if eager else ""))
         total_steps = B * K * n_gpus
+        # the committed profile is evidence, not the measurement: it must agree with what this run measured (the rocprofv3 average
+        # brackets between the steady-state launch period and the eager launch's event time), or it is stale -- said, not fatal
+        rocprof_vs_live = None
+        if rocprof:
+            lo, hi = 0.75 * min(graph_period_us, timed_region_us), 1.35 * max(eager_event_us, timed_region_us)
+            rocprof_vs_live = dict(rocprof, frac=algo_bytes / (rocprof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                   agrees_with_live=bool(lo <= rocprof["avg_us"] <= hi), live_bracket_us=[lo, hi])
+            if not rocprof_vs_live["agrees_with_live"]:
+                print(f"bench.py: WARNING: {rocprof['source']} says {rocprof['avg_us']:.2f} us per launch, this run measured {graph_period_us:.2f} (graph period) .. "
+                      f"{eager_event_us:.2f} (eager launch): the committed profile is stale -- re-run tools/profile_bench.sh", file=sys.stderr)
+        shared = bool(args.ranks_share_gpu0 and world > 1)
         out = {
-            "metric": f"env-steps/sec (whole node), CliffordGym 16q x {B} envs/GPU; bit-exact vs CPU",
+            "metric": (f"env-steps/sec ({world} ranks time-sharing ONE GPU: a functional record of the multi-rank path, not a scaling number), "
+                       f"CliffordGym 16q x {B} envs/rank; bit-exact vs CPU") if shared else
+                      f"env-steps/sec (whole node), CliffordGym 16q x {B} envs/GPU; bit-exact vs CPU",
             "value": total_steps / elapsed,
             "unit": "env-steps/s",
-            "n_gpus": n_gpus,
+            "n_gpus": 1 if shared else n_gpus,  # distinct devices in use
+            "ranks": world,
+            "physical_gpus": 1 if shared else n_gpus,
+            "ranks_share_gpu0": shared,
             "steps": K,
             "warmup": W,
             "ms_per_step": elapsed * 1e3 / K,
@@ -1054,25 +1114,20 @@ def main():
                             "overlapped with the following steps; torch.distributed (gloo) carries only the id, the barriers and the timing reduction",
                     "every_steps": gather_every,
                     "collectives_in_timed_region": gathers_timed,
-                    **(cadence or {}),
                 },
             },
             "roofline": {
                 "bound": "hbm",
                 "kernel": KERNEL,
                 "kernel_resources": "256 threads/block, 1 wave/SIMD at 65 536 envs; no LDS; thread per env",
-                # achieved / frac: SURVEY 8(d)'s algorithmic bytes per launch over the kernel's average duration in the committed rocprofv3
-                # --kernel-trace --stats summary of this command (profiles/r03/bench_kernel_stats.csv); the live clocks are in frac_by_clock.  A
-                # profiling run (no committed summary yet) falls back to the timed region's events
-                "achieved": (algo_bytes / (rocprof["avg_us"] * 1e-6) / 1e9) if rocprof else achieved,
+                # achieved / frac: SURVEY 8(d)'s algorithmic bytes per launch over the step kernel's launch duration measured in THIS run: HIP
+                # events on the launch stream around the K timed steps.  The committed rocprofv3 --kernel-trace --stats average of the same
+                # command (tools/profile_bench.sh -> profiles/) is reported beside it with whether the two agree
+                "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": ((algo_bytes / (rocprof["avg_us"] * 1e-6) / 1e9) if rocprof else achieved) / HBM_PEAK_GBS,
-                "clock": ("rocprofv3 --kernel-trace --stats average of the step kernel, " + rocprof["source"]) if rocprof else
-                         "HIP events on the launch stream around the K timed steps (no committed rocprofv3 summary: --profiling-run)",
-                "achieved_live": achieved,
-                "frac_live": achieved / HBM_PEAK_GBS,
-                "clock_live": "HIP events on the launch stream around the K timed steps (kernel_us_timed_region): launch period, i.e. kernel + launch boundary",
+                "frac": achieved / HBM_PEAK_GBS,
+                "clock": "HIP events on the launch stream around the K timed steps of this run (kernel_us_timed_region): launch period = kernel + launch boundary",
                 "traffic": traffic["bytes_per_launch"] if traffic else None,
                 "traffic_detail": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes,
@@ -1083,13 +1138,12 @@ def main():
                 "kernel_us_timed_region": timed_region_us,
                 "kernel_us_graph_period": graph_period_us,
                 "kernel_us_eager_event": eager_event_us,
-                "kernel_us_rocprof_avg": rocprof["avg_us"] if rocprof else None,
-                "rocprof": dict(rocprof, frac=algo_bytes / (rocprof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof else None,
+                "rocprof_committed": rocprof_vs_live,
                 "frac_by_clock": {
                     "timed_region": achieved / HBM_PEAK_GBS,
                     "graph_period": algo_bytes / (graph_period_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                     "eager_event": algo_bytes / (eager_event_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                    "rocprof_avg": algo_bytes / (rocprof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS if rocprof else None,
+                    "rocprof_committed_avg": algo_bytes / (rocprof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS if rocprof else None,
                 },
             },
             "cpu_baseline": cpu,
@@ -1102,10 +1156,45 @@ def main():
             "large_batch": large,
             "policy_in_loop": collector,
         }
+    else:
+        out = None
+
+    # ---- the optional collective cadences (N > 1), last and under a watchdog: whatever happens in there, rank 0's line goes out -----
+    printed = threading.Event()
+
+    def emit(cadence):
+        if out is None or printed.is_set():
+            return
+        printed.set()
+        if out["config"]["collective"] is not None and cadence:
+            out["config"]["collective"].update(cadence)
         print(json.dumps(out), file=json_out, flush=True)
+
+    def out_of_time():
+        emit({"cadence_error": f"the collective-cadence legs did not finish within {CADENCE_BUDGET_S} s (a rank or a device-side wait is stuck); "
+                               "the line above them is complete"})
+        print(f"bench.py: rank {rank}: cadence legs exceeded {CADENCE_BUDGET_S} s, leaving", file=sys.stderr)
+        sys.stderr.flush()
+        os._exit(4)
+
+    cadence = None
+    if multi:
+        watchdog = threading.Timer(CADENCE_BUDGET_S, out_of_time)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            cadence = collective_cadences()
+        except Exception as exc:  # noqa: BLE001 -- optional legs: reported in the line
+            cadence = {"cadence_error": f"{type(exc).__name__}: {exc}"}
+    emit(cadence)
     if dist is not None:
-        torch.cuda.synchronize()
-        dist.barrier()  # nobody unmaps a window or leaves the communicator while a peer may still use it
+        try:
+            torch.cuda.synchronize()
+            dist.barrier()  # nobody unmaps a window or leaves the communicator while a peer may still use it
+        except Exception as exc:  # noqa: BLE001 -- a peer is gone: nothing left to protect
+            print(f"bench.py: rank {rank}: final barrier failed: {exc}", file=sys.stderr)
+            os._exit(5)
+        watchdog.cancel()
         if comm is not None:
             comm.close()
         dist.destroy_process_group()

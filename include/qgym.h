@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 /* 2: + qg_comm_* / learner-shard entry points, qg_vec_step_host, qg_vec_observe_*_host (additions only: version-1 callers keep working)
- * 3: + qg_vec_track_dense (additions only) */
+ * 3: + qg_vec_track_dense, qg_comm_p2p_reset (additions only) */
 #define QG_ABI_VERSION 3
 
 typedef enum {
@@ -484,8 +484,14 @@ int qg_vec_push_learner_shard(qg_vec *v, qg_comm *c, void *stream);
 int qg_comm_p2p_wait(qg_comm *c, const void **gathered_dev, void *stream);
 /* Enqueue on `stream` the release of the epoch last waited for: its parity may be overwritten by the push of epoch k + 2. */
 int qg_comm_p2p_release(qg_comm *c, void *stream);
-/* Synchronise `stream` and report a peer that did not arrive / release within the deadline (QG_ERR_DEVICE), else QG_OK. */
+/* Synchronise `stream` and report a peer that did not arrive / release within the deadline (QG_ERR_DEVICE), else QG_OK.
+ * Deadlines: a push whose target parity was not released in time SKIPS that peer (no copy, no arrival flag: the peer's wait runs into its
+ * own deadline rather than reading a torn shard) and raises a sticky error; while it is set, pushes write to nobody.  qg_comm_p2p_wait
+ * returns its pointer either way: a caller that may have lost a peer checks before it trusts an epoch. */
 int qg_comm_p2p_check(qg_comm *c, void *stream);
+/* Restart the direct-write transport after an error: call on EVERY rank between two barriers of the host's own (all streams drained, no
+ * push in flight anywhere).  Synchronises `stream`, clears the error word, this rank's window header and both epoch counters. */
+int qg_comm_p2p_reset(qg_comm *c, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Scalar environment: the `Env` trait method for method (clifford.rs:285-382).

@@ -64,15 +64,20 @@ __global__ __launch_bounds__(256) void push_shard_kernel(PushArgs a) {
     const uint32_t y = blockIdx.y;
     uint32_t peer = a.rank + y;
     if (peer >= a.world) peer -= a.world;
+    __shared__ uint32_t go;
     if (threadIdx.x == 0) {
-        // the parity buffer written now was last read in epoch - 2: the peer must have released it.  The copy proceeds either
-        // way -- every block reaches the ticket below -- and the error word tells the host
-        // (once one block has run into the deadline the others do not wait it out again: a dead peer costs one timeout, not one per wave of blocks)
-        const bool ok = a.epoch <= 2 || (__hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & QG_COMM_ERR_ACK_TIMEOUT) ||
-                        poll_at_least(a.local_ack + peer, a.epoch - 2, a.timeout_ticks);
-        if (!ok) atomicOr(a.error, QG_COMM_ERR_ACK_TIMEOUT);
+        // the parity buffer written now was last read in epoch - 2: the peer must have released it.  If it has not within the deadline,
+        // this peer's copy AND its arrival flag are skipped -- the buffer may still be read there -- and the error word is raised: the
+        // peer's wait then runs into its own deadline instead of reading a half-overwritten shard.  The error is sticky until the host
+        // calls qg_comm_p2p_reset: while it is set no push writes to any peer and nothing waits (a dead peer costs one timeout, not one
+        // per push and not one per wave of blocks).  Every block still reaches the ticket below.
+        const bool down = __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & QG_COMM_ERR_ACK_TIMEOUT;
+        const bool ok = !down && (a.epoch <= 2 || poll_at_least(a.local_ack + peer, a.epoch - 2, a.timeout_ticks));
+        if (!ok && !down) atomicOr(a.error, QG_COMM_ERR_ACK_TIMEOUT);
+        go = ok ? 1u : 0u;
     }
     __syncthreads();
+    const bool copy = go != 0u;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 *__restrict__ src = (const u32x4 *)a.src;
     u32x4 *__restrict__ dst = (u32x4 *)a.dst[peer];
@@ -81,21 +86,25 @@ __global__ __launch_bounds__(256) void push_shard_kernel(PushArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
-        if (i < a.n16) v[k] = src[i];
+        if (copy && i < a.n16) v[k] = src[i];
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
-        if (i < a.n16) __builtin_nontemporal_store(v[k], dst + i);
+        if (copy && i < a.n16) __builtin_nontemporal_store(v[k], dst + i);
     }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
+        uint32_t *skipped = a.ticket + COMM_MAX_WORLD + y;  // set by a block that skipped its chunk
+        if (!copy) atomicOr(skipped, 1u);
+        __threadfence();
         const uint32_t taken = atomicAdd(a.ticket + y, 1u);
         if (taken == gridDim.x - 1) {  // the last block of this peer: every chunk is visible system-wide
+            const bool whole = atomicExch(skipped, 0u) == 0u;
             a.ticket[y] = 0;
             __threadfence_system();
-            store_sys(a.arrive[peer] + a.rank, a.epoch);
+            if (whole) store_sys(a.arrive[peer] + a.rank, a.epoch);  // every chunk written: the shard has arrived
         }
     }
 }

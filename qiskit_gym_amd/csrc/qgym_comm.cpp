@@ -325,18 +325,34 @@ int qg_comm_p2p_export(qg_comm *c, uint64_t shard_bytes, uint8_t handle_out[QG_P
         c->window = nullptr;
         return set_error(QG_ERR_DEVICE, "cannot allocate the %llu-byte window: %s", (unsigned long long)window_bytes(c), hipGetErrorString(e));
     }
-    HIP_TRY(hipMemset(c->window, 0, COMM_HEADER_BYTES));
-    HIP_TRY(hipMalloc(&c->stage, shard_bytes));
-    HIP_TRY(hipMalloc(&c->ticket, sizeof(uint32_t) * COMM_MAX_WORLD));
-    HIP_TRY(hipMalloc(&c->error, sizeof(uint32_t)));
-    HIP_TRY(hipMemset(c->ticket, 0, sizeof(uint32_t) * COMM_MAX_WORLD));
-    HIP_TRY(hipMemset(c->error, 0, sizeof(uint32_t)));
-    HIP_TRY(hipDeviceSynchronize());
+    // a failure below leaves the communicator as it was before the call (no window: a retry starts over)
+    auto undo = [&](hipError_t err, const char *what) {
+        (void)hipGetLastError();
+        for (void **p : {(void **)&c->window, (void **)&c->stage, (void **)&c->ticket, (void **)&c->error}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
+        c->peer[c->rank] = nullptr;
+        return set_error(QG_ERR_DEVICE, "%s failed: %s", what, hipGetErrorString(err));
+    };
+#define P2P_TRY(expr)                                    \
+    do {                                                 \
+        hipError_t _e = (expr);                          \
+        if (_e != hipSuccess) return undo(_e, #expr);    \
+    } while (0)
+    P2P_TRY(hipMemset(c->window, 0, COMM_HEADER_BYTES));
+    P2P_TRY(hipMalloc(&c->stage, shard_bytes));
+    P2P_TRY(hipMalloc(&c->ticket, sizeof(uint32_t) * 2 * COMM_MAX_WORLD));  // per peer: block ticket, "a block skipped" flag
+    P2P_TRY(hipMalloc(&c->error, sizeof(uint32_t)));
+    P2P_TRY(hipMemset(c->ticket, 0, sizeof(uint32_t) * 2 * COMM_MAX_WORLD));
+    P2P_TRY(hipMemset(c->error, 0, sizeof(uint32_t)));
+    P2P_TRY(hipDeviceSynchronize());
     c->peer[c->rank] = c->window;
     static_assert(sizeof(hipIpcMemHandle_t) == QG_P2P_HANDLE_BYTES, "QG_P2P_HANDLE_BYTES must equal HIP_IPC_HANDLE_SIZE");
     hipIpcMemHandle_t h;
     memset(&h, 0, sizeof h);
-    if (c->world > 1) HIP_TRY(hipIpcGetMemHandle(&h, c->window));
+    if (c->world > 1) P2P_TRY(hipIpcGetMemHandle(&h, c->window));
+#undef P2P_TRY
     memcpy(handle_out, &h, sizeof h);
     return QG_OK;
 }
@@ -434,6 +450,20 @@ int qg_comm_p2p_release(qg_comm *c, void *stream) {
     a.world = (uint32_t)c->world;
     a.epoch = c->wait_epoch;
     HIP_TRY(release_window(a, (hipStream_t)stream));
+    return QG_OK;
+}
+
+int qg_comm_p2p_reset(qg_comm *c, void *stream) {
+    if (!c) return set_error(QG_ERR_INVALID, "null argument");
+    if (!c->window) return QG_OK;
+    QG_ON_DEVICE(c);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemset(c->window, 0, COMM_HEADER_BYTES));  // this rank's arrival flags and the releases stored here
+    HIP_TRY(hipMemset(c->ticket, 0, sizeof(uint32_t) * 2 * COMM_MAX_WORLD));
+    HIP_TRY(hipMemset(c->error, 0, sizeof(uint32_t)));
+    HIP_TRY(hipDeviceSynchronize());
+    c->push_epoch = 0;
+    c->wait_epoch = 0;
     return QG_OK;
 }
 

@@ -43,6 +43,37 @@ def all_gather_observation(local: torch.Tensor, out: Optional[torch.Tensor] = No
     return out
 
 
+def all_ranks_ok(ok: bool, group=None) -> bool:
+    """Collective vote over the control plane (CPU tensor: gloo): True when EVERY rank passed True."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
+def run_guarded_phases(phases, group=None) -> Optional[dict]:
+    """Run an OPTIONAL multi-rank leg (e.g. a measurement beside the headline) so that one rank's failure cannot strand the others.
+
+    `phases`: [(name, callable)].  A phase may fail on one rank only (mapping a peer's memory, a device-side deadline); after every
+    phase all ranks vote (`all_ranks_ok`), and at the first phase that did not pass everywhere EVERY rank stops there -- no rank goes on
+    into a barrier its peers never reach.  Returns None when all phases passed on all ranks, else
+    `{"error", "phase", "failed_on_this_rank"}` (plus `"control_plane"` when the vote itself failed: a peer died or the control plane's
+    timeout expired -- the group is then unusable and the caller should finish without further collectives)."""
+    for name, fn in phases:
+        err = None
+        try:
+            fn()
+        except Exception as exc:  # noqa: BLE001 -- whatever went wrong on this rank, the peers must hear of it
+            err = f"{type(exc).__name__}: {exc}"
+        try:
+            ok = all_ranks_ok(err is None, group)
+        except Exception as exc:  # noqa: BLE001
+            return {"error": err or "the vote after this phase failed", "phase": name, "failed_on_this_rank": err is not None,
+                    "control_plane": f"{type(exc).__name__}: {exc}"}
+        if not ok:
+            return {"error": err or "a peer rank failed in this phase", "phase": name, "failed_on_this_rank": err is not None}
+    return None
+
+
 def learner_shard_words(batch: int, obs_words: int) -> int:
     """int32 words of one rank's hand-over shard: packed observation [batch, obs_words], f32 rewards [batch], `is_final` and
     `success` bytes [batch] each (SURVEY.md 8e's three gathers as one flat buffer, every section 4-byte aligned, the whole
@@ -275,6 +306,10 @@ class Communicator:
     def check(self):
         """Synchronise the current stream and raise if a peer missed a deadline."""
         self._lib.check(self._L.qg_comm_p2p_check(self._h, self._stream()))
+
+    def p2p_reset(self):
+        """Restart the direct-write transport after an error (every rank, between two barriers of the host's own)."""
+        self._lib.check(self._L.qg_comm_p2p_reset(self._h, self._stream()))
 
 
 def unpack_rows_u32(packed: torch.Tensor, dim: int) -> torch.Tensor:

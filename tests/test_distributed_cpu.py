@@ -140,3 +140,89 @@ def test_split_gathered_follows_the_c_layout():
         o, rw, f, s = split_gathered(torch.from_numpy(buf.reshape(-1)), lay, world, wb)
         assert np.array_equal(o.numpy().view(dt), obs.reshape(world * batch, words))
         assert np.array_equal(rw.numpy(), rew.reshape(-1)) and np.array_equal(f.numpy(), fin.reshape(-1)) and np.array_equal(s.numpy(), suc.reshape(-1))
+
+
+def _guarded_worker(rank, world, port, scenario, result_q):
+    """bench.py's optional N > 1 legs run as voted phases (qiskit_gym_amd.distributed.run_guarded_phases): what every rank sees when one
+    rank's phase fails (scenario "open_fails": rank 1 cannot map its peer's window) or a rank disappears (scenario "rank_dies")."""
+    import datetime
+    import time
+
+    from qiskit_gym_amd.distributed import run_guarded_phases
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=8))
+    reached = []
+
+    def export():
+        reached.append("export")
+
+    def exchange():
+        got = [None] * world
+        dist.all_gather_object(got, f"handle-of-{rank}")
+        assert got == [f"handle-of-{r}" for r in range(world)]
+        reached.append("exchange")
+
+    def open_():
+        if scenario == "open_fails" and rank == 1:
+            raise RuntimeError("injected: hipIpcOpenMemHandle failed")
+        if scenario == "rank_dies" and rank == 1:
+            os._exit(0)  # no vote, no goodbye
+        reached.append("open")
+
+    def timed():  # holds a barrier: must never be entered by a subset of the ranks
+        dist.barrier()
+        reached.append("timed")
+
+    t0 = time.time()
+    err = run_guarded_phases([("p2p_export", export), ("handle_exchange", exchange), ("p2p_open", open_), ("timed", timed)])
+    elapsed = time.time() - t0
+    usable = None
+    if err is not None and "control_plane" not in err:  # a voted stop leaves the control plane intact: the run goes on to its final barrier
+        dist.barrier()
+        usable = True
+    result_q.put((rank, err, reached, elapsed, usable))
+    if err is None or "control_plane" not in err:
+        dist.destroy_process_group()
+
+
+def _run_guarded(scenario, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_guarded_worker, args=(r, world, port, scenario, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    expect = world - (1 if scenario == "rank_dies" else 0)
+    for _ in range(expect):
+        r = q.get(timeout=60)
+        out[r[0]] = r[1:]
+    for p in procs:
+        p.join(30)
+    return out
+
+
+def test_a_failed_phase_on_one_rank_stops_every_rank_at_the_same_phase():
+    out = _run_guarded("open_fails")
+    for rank in (0, 1):
+        err, reached, elapsed, usable = out[rank]
+        assert err is not None and err["phase"] == "p2p_open" and "timed" not in reached and usable
+        assert err["failed_on_this_rank"] == (rank == 1)
+        assert elapsed < 5.0, "a rank waited for a peer that had already failed"
+    assert "injected" in out[1][0]["error"] and "peer rank failed" in out[0][0]["error"]
+
+
+def test_all_phases_pass_when_nothing_fails():
+    out = _run_guarded("ok")
+    for rank in (0, 1):
+        err, reached, elapsed, usable = out[rank]
+        assert err is None and reached == ["export", "exchange", "open", "timed"]
+
+
+def test_a_vanished_rank_costs_the_control_plane_timeout_not_forever():
+    out = _run_guarded("rank_dies")
+    err, reached, elapsed, usable = out[0]
+    assert err is not None and err["phase"] == "p2p_open" and "control_plane" in err and "timed" not in reached
+    assert elapsed < 30.0

@@ -4,6 +4,7 @@ standing in for rank 3 of 8 -- hands the learner a gathered shard that matches t
 import json
 import os
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -60,10 +61,11 @@ def test_shard_with_env_base_equals_its_slice_of_the_whole_batch(kind, n, cfg):
     assert torch.equal(whole.get_state(fmt)[sl], shard.get_state(fmt))
 
 
-def _run_bench(*flags, timeout=600):
+def _run_bench(*flags, timeout=600, extra_env=None):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
+    env.update(extra_env or {})
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=timeout, env=env)
 
 
@@ -101,6 +103,19 @@ def test_bench_rccl_path_gathered_shard_3_of_8_matches_oracle(tmp_path):
     assert np.array_equal(d["obs"].view(np.uint32), want)
     assert np.array_equal(f32_bits(d["reward"]), f32_bits(r))
     assert np.array_equal(d["done"], f) and np.array_equal(d["success"], s)
+
+
+def test_bench_line_survives_a_failed_direct_write_leg():
+    """The optional direct-write cadence leg fails on this rank (its hipIpcOpenMemHandle, injected): the line still goes out, complete, with
+    the RCCL cadences measured and `direct_write: {error: ...}` naming the phase."""
+    res = _run_bench("--force-multi", "--shard", "3/8", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-large-batch",
+                     "--no-default-config", "--no-configs", "--no-collector", "--no-dense-obs", extra_env={"QG_BENCH_INJECT_P2P_OPEN_FAILURE": "0"})
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    col = line["config"]["collective"]
+    assert col["per_step_gather_us"] > 0 and line["parity"]["bit_exact"] and line["value"] > 1e7
+    assert col["direct_write"]["error"]["phase"] == "p2p_open" and col["direct_write"]["error"]["failed_on_this_rank"]
+    assert "injected" in col["direct_write"]["error"]["error"]
 
 
 def test_bench_gpus_flag_fails_loudly_without_that_many_gpus():
@@ -166,8 +181,25 @@ def test_bench_as_a_two_rank_job_on_one_gpu_with_the_direct_write_handover():
     assert res.returncode == 0, res.stderr[-3000:]
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')][-1])
     cfg = line["config"]
-    assert line["n_gpus"] == 2 and cfg["ranks_seen"] == 2 and cfg["total_envs"] == 2 * 65536 and cfg["env_ids_of_rank0"] == [0, 65536]
+    assert line["ranks"] == 2 and cfg["ranks_seen"] == 2 and cfg["total_envs"] == 2 * 65536 and cfg["env_ids_of_rank0"] == [0, 65536]
+    assert line["n_gpus"] == 1 and line["physical_gpus"] == 1 and line["ranks_share_gpu0"] and "ONE GPU" in line["metric"]  # said, not implied
     assert cfg["collective"]["handover"] == "direct" and cfg["collective"]["collectives_in_timed_region"] >= 1
     assert line["parity"]["bit_exact"] and line["parity"]["gathered_shard"]["bit_exact"]
     assert line["parity"]["gathered_shard_of_last_rank"]["bit_exact"] and line["parity"]["gathered_shard_of_last_rank"]["envs"] == 1024
     assert line["value"] > 1e7 and line["scaling"] == "weak"  # (two processes share one GPU: a functional run, its rate means nothing)
+
+
+def test_bench_two_ranks_with_one_rank_unable_to_map_its_peer_fails_fast_on_every_rank():
+    """--handover direct with rank 1's hipIpcOpenMemHandle failing (injected): the vote after the phase stops BOTH ranks there -- the run ends
+    within seconds with a non-zero exit code instead of one rank waiting in a barrier for the control plane's timeout."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["QG_BENCH_INJECT_P2P_OPEN_FAILURE"] = "1"
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--handover", "direct", "--ranks-share-gpu0", "--steps", "20",
+                          "--warmup", "5", "--no-cpu-baseline", "--no-large-batch", "--no-default-config", "--no-configs", "--no-collector"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode != 0
+    assert time.time() - t0 < 120, "a rank waited for a peer that had already failed"
+    assert "p2p_open" in res.stderr and "injected" in res.stderr
