@@ -279,6 +279,58 @@ static int expand_packed_impl(const void *packed_dev, int word_bytes, uint64_t n
     return QG_OK;
 }
 
+// ---- the trait's Vec<i64> wire format (Env::set_state / get_state, clifford.rs:299-304: D * D entries per env, > 0 means 1) ----------------
+// out: one thread per 16-byte chunk = two int64 entries of the flat [n_rows * cols] array; the row words are tiny and stay in cache, the
+// stores are wave-contiguous (1 KiB per instruction): 537 MB for CliffordEnv 16q x 65 536.  (The export kernels before wrote a row per
+// thread, entry by entry: 0.6 TB/s.)
+__global__ __launch_bounds__(256) void expand_i64_kernel(const void *packed, int word_bytes, uint64_t n_rows, uint32_t cols, int64_t *out) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = n_rows * cols, e0 = gid * 2u;
+    if (e0 >= total) return;
+    uint64_t row;
+    if (total <= 0xFFFFFFFFull) row = (uint32_t)e0 / cols;  // 32-bit division: the 64-bit one costs more than the rest of the thread
+    else row = e0 / cols;
+    const uint32_t c = (uint32_t)(e0 - row * cols);
+    auto word = [&](uint64_t r) -> uint64_t {
+        return word_bytes == 8 ? reinterpret_cast<const uint64_t *>(packed)[r] : (uint64_t) reinterpret_cast<const uint32_t *>(packed)[r];
+    };
+    const uint64_t w = word(row);
+    const uint64_t v0 = (w >> c) & 1ull;
+    if (e0 + 1 >= total) {  // the array's last entry (odd total)
+        out[e0] = (int64_t)v0;
+        return;
+    }
+    const uint64_t v1 = (c + 1u < cols) ? (w >> (c + 1u)) & 1ull : word(row + 1) & 1ull;
+    typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+    u64x2 v = {v0, v1};
+    *reinterpret_cast<u64x2 *>(out + e0) = v;
+}
+
+hipError_t expand_rows_i64(const void *words_dev, int word_bytes, uint64_t n_rows, uint32_t cols, int64_t *out_dev, hipStream_t s) {
+    if (!n_rows || !cols) return hipSuccess;
+    hipLaunchKernelGGL(expand_i64_kernel, dim3(blocks_for((n_rows * cols + 1) / 2, 256)), dim3(256), 0, s, words_dev, word_bytes, n_rows, cols, out_dev);
+    return hipGetLastError();
+}
+
+// in: the flat entry stream as a BIT stream (bit e of the stream = entry e > 0), 64 entries per wave instruction: lane l of the wave that
+// owns entries [64 i, 64 i + 64) loads entry 64 i + l (512 contiguous bytes of int64, 64 of uint8) and the wave's ballot IS stream word i.
+// The init kernels then cut their row words out of the stream (QG_FMT_BITS, bits_window): no thread walks a row of 8-byte entries.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_bitstream_kernel(const T *src, uint64_t n_entries, uint64_t *out) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool one = gid < n_entries && src[gid] > 0;  // whole waves reach the ballot
+    const uint64_t m = __ballot(one);
+    if ((threadIdx.x & 63u) == 0 && (gid >> 6) < (n_entries + 63u) / 64u) out[gid >> 6] = m;
+}
+
+hipError_t pack_bitstream(const void *src, int elem_bytes, uint64_t n_entries, uint64_t *out_words, hipStream_t s) {
+    if (!n_entries) return hipSuccess;
+    const unsigned grid = blocks_for((n_entries + 63u) / 64u * 64u, 256);
+    if (elem_bytes == 8) hipLaunchKernelGGL(pack_bitstream_kernel<int64_t>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const int64_t *>(src), n_entries, out_words);
+    else hipLaunchKernelGGL(pack_bitstream_kernel<int8_t>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const int8_t *>(src), n_entries, out_words);
+    return hipGetLastError();
+}
+
 hipError_t expand_rows(const void *words_dev, int word_bytes, uint64_t n_rows, uint32_t cols, void *out_dev, int out_dtype, hipStream_t s) {
     return expand_packed_impl(words_dev, word_bytes, n_rows, cols, out_dev, out_dtype, s) == QG_OK ? hipSuccess : hipErrorInvalidValue;
 }

@@ -209,6 +209,8 @@ __global__ __launch_bounds__(64) void lfd_init_kernel(InitArgs a, uint32_t RG, c
             if (a.format == QG_FMT_PACKED) {
                 w = reinterpret_cast<const W *>(a.src)[env * a.src_stride + r];
                 if (N < 8 * sizeof(W)) w &= ((W)1 << N) - 1;
+            } else if (a.format == QG_FMT_BITS) {  // the entry stream as bits (pack_bitstream)
+                w = (W)bits_window(reinterpret_cast<const uint64_t *>(a.src), env * a.src_stride + (uint64_t)r * N, N);
             } else if (a.format == QG_FMT_I64) {
                 const int64_t *p = reinterpret_cast<const int64_t *>(a.src) + env * a.src_stride + (uint64_t)r * N;
                 for (uint32_t c = 0; c < N; ++c) w |= (W)(p[c] > 0) << c;

@@ -707,6 +707,8 @@ __global__ __launch_bounds__(64) void q64_init_kernel(InitArgs a) {
                 if (a.format == QG_FMT_PACKED) {
                     w = reinterpret_cast<const uint64_t *>(a.src)[env * a.src_stride + row];
                     if (a.D < 64) w &= (1ull << a.D) - 1ull;
+                } else if (a.format == QG_FMT_BITS) {  // the entry stream as bits (pack_bitstream): i64 / u8 set_state at streaming rate
+                    w = bits_window(reinterpret_cast<const uint64_t *>(a.src), env * a.src_stride + (uint64_t)row * a.D, a.D);
                 } else if (a.format == QG_FMT_I64) {
                     const int64_t *p = reinterpret_cast<const int64_t *>(a.src) + env * a.src_stride + (uint64_t)row * a.D;
                     for (uint32_t c = 0; c < a.D; ++c) w |= (uint64_t)(p[c] > 0) << c;

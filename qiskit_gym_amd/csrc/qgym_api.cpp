@@ -687,11 +687,19 @@ int qg_vec_set_state(qg_vec *v, const void *states, int format, size_t stride, i
         return set_error(QG_ERR_INVALID, "set_state: %zu elements per env, need %zu (the reference would index out of bounds)",
                          stride, format_min_elems(v, format));
     const void *src = states;
-    if (!on_device) {
-        size_t bytes = format_elem_bytes(v, format) * stride * v->B;
-        int rc = ensure_scratch(v, bytes);
+    // entry formats (the trait's Vec<i64>, dense bytes) of the bit-matrix layouts: the flat entry stream becomes a bit stream first (64 entries
+    // per wave instruction, coalesced), the init kernel cuts its row words out of it -- no thread walks rows of 8-byte entries
+    // (a handful of envs -- the scalar qg_env_* handles are batches of one -- keep the single launch)
+    const bool as_bits = format != QG_FMT_PACKED && v->B >= QG_STREAM_MIN_ENVS && (v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_LFD);
+    const size_t in_bytes = format_elem_bytes(v, format) * stride * v->B;
+    const size_t staged = on_device ? 0 : (in_bytes + 15) & ~(size_t)15;
+    const size_t stream_words = as_bits ? (stride * v->B + 63) / 64 + 2 : 0;  // + the word bits_window may read past the end
+    if (staged + stream_words) {
+        int rc = ensure_scratch(v, staged + stream_words * sizeof(uint64_t));
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(v->scratch, states, bytes, hipMemcpyHostToDevice, s));
+    }
+    if (!on_device) {
+        HIP_TRY(hipMemcpyAsync(v->scratch, states, in_bytes, hipMemcpyHostToDevice, s));
         src = v->scratch;
     }
     InitArgs ia;
@@ -700,6 +708,13 @@ int qg_vec_set_state(qg_vec *v, const void *states, int format, size_t stride, i
     ia.src = src;
     ia.src_stride = stride;
     ia.format = (uint32_t)format;
+    if (as_bits) {
+        uint64_t *stream = reinterpret_cast<uint64_t *>((char *)v->scratch + staged);
+        HIP_TRY(hipMemsetAsync(stream + stream_words - 2, 0, 2 * sizeof(uint64_t), s));
+        HIP_TRY(pack_bitstream(src, (int)format_elem_bytes(v, format), (uint64_t)stride * v->B, stream, s));
+        ia.src = stream;
+        ia.format = QG_FMT_BITS;
+    }
     ia.depth_value = v->cfg.max_depth;  // clifford.rs:302
     if (ia.check_symplectic) {  // the init kernel reports whether any installed matrix is not symplectic
         if (!v->d_nonsymp) HIP_TRY(hipMalloc(&v->d_nonsymp, sizeof(uint32_t)));
@@ -757,17 +772,32 @@ int qg_vec_get_state(qg_vec *v, void *out, int format, size_t stride, int on_dev
     hipStream_t s = (hipStream_t)stream;
     void *dst = out;
     size_t bytes = format_elem_bytes(v, format) * stride * v->B;
-    if (!on_device) {
-        int rc = ensure_scratch(v, bytes);
+    // the trait's Vec<i64> of the bit-matrix layouts: the row words first (8 MiB for CliffordEnv 16q x 65 536), then one expansion kernel whose
+    // stores are wave-contiguous -- 537 MB at streaming rate (the export kernels' row-per-thread, entry-by-entry stores reached 0.6 TB/s)
+    qg_vec_info info;
+    qg_vec_get_info(v, &info);
+    const bool two_stage = format == QG_FMT_I64 && v->B >= QG_STREAM_MIN_ENVS && stride == (size_t)v->D * v->D && !((uintptr_t)out & 15u) &&
+                           (v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_LFD) && info.packed_words_per_env == v->D;
+    const size_t staged = on_device ? 0 : (bytes + 15) & ~(size_t)15;
+    const size_t words_bytes = two_stage ? (size_t)v->B * v->D * info.packed_word_bytes : 0;
+    if (staged + words_bytes) {
+        int rc = ensure_scratch(v, staged + words_bytes);
         if (rc) return rc;
-        dst = v->scratch;
     }
+    if (!on_device) dst = v->scratch;
     ObsArgs oa;
-    fill_obs_args(v, oa, dst, format, stride);
-    if (v->layout == LAYOUT_PAULI) {  // tableau only, square
-        oa.obs_cols = oa.obs_rows;
+    if (two_stage) {
+        void *words = (char *)v->scratch + staged;
+        fill_obs_args(v, oa, words, QG_FMT_PACKED, v->D);
+        HIP_TRY(launch_export(v, oa, s));
+        HIP_TRY(expand_rows_i64(words, (int)info.packed_word_bytes, v->B * (uint64_t)v->D, v->D, reinterpret_cast<int64_t *>(dst), s));
+    } else {
+        fill_obs_args(v, oa, dst, format, stride);
+        if (v->layout == LAYOUT_PAULI) {  // tableau only, square
+            oa.obs_cols = oa.obs_rows;
+        }
+        HIP_TRY(launch_export(v, oa, s));
     }
-    HIP_TRY(launch_export(v, oa, s));
     if (!on_device) {
         HIP_TRY(hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));

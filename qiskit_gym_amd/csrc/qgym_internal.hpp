@@ -130,6 +130,9 @@ struct StepArgs {
 // handful of waves that all hold a finished env anyway, and the extra launch costs more than the generator saves (the other envs
 // always pack: their short lists go to the 16-lanes-per-env scramble, which is the faster one at any batch)
 constexpr uint64_t QG_COMPACT_MIN_ENVS = 4096;
+// set_state / get_state in the entry formats (Vec<i64>, dense bytes) go through a bit stream / row words plus a streaming kernel from this
+// batch size on; below it (the scalar qg_env_* handles are batches of one) the single init / export launch is the cheaper one
+constexpr uint64_t QG_STREAM_MIN_ENVS = 64;
 
 // state (re)initialisation
 struct InitArgs {
@@ -187,6 +190,17 @@ struct ObsArgs {
     uint32_t obs_rows, obs_cols;
 };
 
+// internal set_state source format (never crosses the C ABI): InitArgs::src is a bit stream, bit e = entry e of the flat [B][D][D] array
+// (pack_bitstream, kernels_collect.hip); src_stride = D * D
+#define QG_FMT_BITS 3u
+// D <= 64 bits of the stream starting at bit `pos` (the word after the stream's last one must be readable: the host pads it)
+__device__ inline uint64_t bits_window(const uint64_t *bs, uint64_t pos, uint32_t D) {
+    const uint32_t sh = (uint32_t)pos & 63u;
+    const uint64_t lo = bs[pos >> 6], hi = bs[(pos >> 6) + 1];
+    const uint64_t w = sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+    return D >= 64u ? w : w & ((1ull << D) - 1ull);
+}
+
 // launchers (one translation unit per layout)
 // LinearFunctionEnv with add_inverts, 8 < N <= 64: state and inverse side by side, `rg` 16-byte groups per matrix (kernels_lfd.hip)
 hipError_t lfd_step(const StepArgs &a, bool w64, uint32_t rg, hipStream_t s);
@@ -218,6 +232,10 @@ hipError_t permb_export(const ObsArgs &a, uint32_t ng, hipStream_t s);
 
 // dense {0,1} tensor of `out_dtype` (qg_dtype) from rows packed one per word (kernels_collect.hip)
 hipError_t expand_rows(const void *words_dev, int word_bytes, uint64_t n_rows, uint32_t cols, void *out_dev, int out_dtype, hipStream_t s);
+// the trait's Vec<i64> wire format: [n_rows * cols] int64 {0, 1} entries from row words (get_state), and the flat entry stream (int64 / int8,
+// > 0 means 1) as a bit stream of 64-bit words for the init kernels' QG_FMT_BITS (set_state)
+hipError_t expand_rows_i64(const void *words_dev, int word_bytes, uint64_t n_rows, uint32_t cols, int64_t *out_dev, hipStream_t s);
+hipError_t pack_bitstream(const void *src, int elem_bytes, uint64_t n_entries, uint64_t *out_words, hipStream_t s);
 hipError_t compact_done(const uint8_t *done, uint64_t B, uint32_t *list, uint32_t *count, hipStream_t s);
 hipError_t masks_fill(const uint8_t *success, uint8_t *out, uint64_t B, uint32_t num_actions, hipStream_t s);
 hipError_t fault_any(const uint32_t *error, uint64_t B, uint32_t *scratch, uint32_t *out_host, hipStream_t s);

@@ -99,10 +99,13 @@ __device__ inline bool qm_step1_body(const StepArgs &a, uint32_t G, uint64_t env
         // The two lanes of a pair (2k, 2k + 1: neighbouring envs) write one 32-byte row together, 16 bytes each, so that a store
         // instruction's lanes cover whole rows: per-lane rows (two 16-byte stores 16 bytes apart from ONE lane) measured 5.28 us per step at
         // 65 536 envs, this form 4.83 (3.11 without the dense observation).  Every lane that runs this body reaches this point; a pair lane
-        // that does not (the batch's ragged end) reads as "no row": update_dpp keeps `old` = 0 for a disabled source lane.
+        // that does not (past the batch's odd end) reads as "no row" -- update_dpp keeps `old` = 0 for a disabled source lane -- and the
+        // env it leaves without a partner writes its rows alone.
+        const bool solo = (env ^ 1ull) >= a.B;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t mine = ((dchg >> k) & 1u) ? (drow[k] | 0x80000000u) : 0u;
+            if (solo && ((dchg >> k) & 1u)) dense_row_store<2>(a.dense, env, drow[k], dword[k]);
+            const uint32_t mine = (!solo && ((dchg >> k) & 1u)) ? (drow[k] | 0x80000000u) : 0u;
 #pragma unroll
             for (int par = 0; par < 2; ++par) {  // quad_perm [0, 0, 2, 2] / [1, 1, 3, 3]: the even / odd lane's entry on both lanes of the pair
                 const uint32_t r = par ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xF5, 0xF, 0xF, false)

@@ -24,8 +24,9 @@ for it in range(6):
     env.masks()
     if kind != "pauli":
         st = env.get_state("packed")
-        env.get_state("i64")
+        wire = env.get_state("i64")
         env.set_state(st, "packed")
+        env.set_state(wire, "i64")  # the trait's Vec<i64> (clifford.rs:299-304)
     else:
         env.get_state("i64")
     env.reset_done(it + 100)
