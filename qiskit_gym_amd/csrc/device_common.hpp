@@ -158,25 +158,31 @@ __device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds,
     }
     return sl == 0 ? rows : nullptr;
 }
-// One WORKGROUP (four waves) per env, the matrix held by COLUMNS, the gate sequence cut in four.
+// One WORKGROUP (four waves) per env, the matrix held by COLUMNS, the gate sequence cut in EIGHT.
 //
-// Columns: lane j keeps column j in slot order (bit s of `col` = entry (slot s, column j); uint32 rows: R <= 32 slots, <= 32 columns, the
-// upper half of each wave idles).  A row operation -- row[dst] ^= row[src], or the two rows trade places (clifford.rs:64-82) -- is then bit
-// arithmetic inside every lane's own word, and because a whole wave works on ONE env the gate is the same for all its lanes: its fields sit in
-// scalar registers, nothing crosses lanes and nothing touches LDS (three dependent vector instructions per row operation, no branch;
-// scramble_coop pays an LDS read -> write -> read round trip per operation).  The 64 draws of a chunk are made one per lane (two splitmix64
-// rounds each, all lanes at once) and handed to the wave by v_readlane.
-// Four waves: reset() is S = G_n ... G_1 S0 (S0 = the identity in slot order), a product of row-operation matrices, and matrix products
-// associate: wave w applies its quarter of the gates -- wave 0 to S0, the others to the R x R identity, giving P_w -- and the quarters are
-// multiplied in a two-level tree through LDS, (P3 P2) (P1 X0).  With columns on the lanes, column j of A B is A times column j of B:
-// the xor of A's columns s over the set bits s of the lane's own word -- A's 32 column words read from LDS, 64 vector instructions.
-// The dependent chain shrinks from n gates to n / 4 gates + two products (tools/microbench_scramble.hip: ~65 ns per gate, ~0.3 us per product).
+// Columns: lane j keeps column j in slot order (bit s of `col` = entry (slot s, column j); uint32 rows: R <= 32 slots, <= 32 columns).  A row
+// operation -- row[dst] ^= row[src], or the two rows trade places (clifford.rs:64-82) -- is then bit arithmetic inside every lane's own
+// word, as a parity test: t = col & test, col ^= -(popcount(t) & 1) & flip, with test = 1 << src, flip = 1 << dst for the xor and
+// test = flip = both bits for the swap ("no gate": both zero).  The lane that draws a gate (two splitmix64 rounds, all lanes at once)
+// decodes it into its four masks itself and parks them in LDS as one uint4; the serial loop reads them back (every lane of a half wave the
+// same address: a broadcast), four gates ahead of the dependent chain, and decodes nothing: five dependent vector instructions per row
+// operation, no scalar unit in the loop.  (Three v_readlane + scalar field extraction per gate measured 73 ns per gate, this form 38;
+// tools/microbench_scramble.hip.)
+// A 32-column matrix fills half a wave, so each wave runs TWO segments side by side -- lanes 0-31 and 32-63 read their own gate
+// stream -- which halves the chain again (24 ns per gate and wave).  reset() is S = G_n ... G_1 S0 (S0 = the identity in slot order), a
+// product of row-operation matrices, and matrix products associate: segment 0 applies its eighth of the gates to S0, the others to the
+// R x R identity, giving P_k, and the eighths are multiplied back in a three-level tree through LDS: inside each wave P_upper P_lower, then
+// (W3 W2) (W1 W0).  With columns on the lanes, column j of A B is A times column j of B: the xor of A's columns s over the set bits s of
+// the lane's own word -- A's 32 column words read from LDS, 64 vector instructions (~0.3 us).  The dependent chain is n / 8 gates + three
+// products (n = 256: 32 steps of ~45 ns instead of 64 gates of 73).
 // Rows come back by ballot: row word of slot s = the lanes' bits s.  Returns true on the one lane (lane 0 of wave 0) that finishes the env.
-// `prod`: 4 x 32 words of LDS.  blockDim.x must be 256.
+// `prod`: 4 x 32 words of LDS; `gates`: 4 x 64 uint4 of LDS (16-byte aligned); `table`: the row-operation table in LDS (the caller brings it
+// in while the list length is still in flight), or null: read a.rowops.  blockDim.x must be 256.
 constexpr uint32_t QG_TREE_THREADS = 256;
+constexpr uint32_t QG_TREE_TABLE_MAX = 1024;  // gatesets up to this many actions have their row-operation table in LDS
 constexpr uint32_t QG_TREE_MAX_ENVS = 1024;  // four waves per env: beyond ~1 000 envs the chip's SIMDs hold several of these waves each and issue slots,
                                             // not the chain, set the time (65 536 envs, 3 % finished: 59 us against 56 for scramble_coop)
-// lists this short, of scrambles this long, go to scramble_tree (shorter chains do not repay the two products)
+// lists this short, of scrambles this long, go to scramble_tree (shorter chains do not repay the products)
 __device__ __host__ inline bool tree_takes(uint32_t count, uint32_t n_draws, uint64_t B) {
     return n_draws >= 64u && count <= QG_TREE_MAX_ENVS && (uint64_t)count * QG_COOP_LANES * 2 <= B;
 }
@@ -187,71 +193,86 @@ __device__ inline uint32_t gf2_cols_product(const uint32_t *a_cols, uint32_t b) 
     for (int sl = 0; sl < R; ++sl) acc ^= a_cols[sl] & (uint32_t)__builtin_amdgcn_sbfe((int32_t)b, (uint32_t)sl, 1u);
     return acc;
 }
+// one row operation in the parity form (see above)
+__device__ inline void rowop_parity(uint32_t &col, uint32_t test, uint32_t flip) {
+    col ^= (uint32_t)__builtin_amdgcn_sbfe((int32_t)__builtin_popcount(col & test), 0u, 1u) & flip;
+}
+// the four masks {test0, flip0, test1, flip1} of a gate word (two row operations, make_op with slot indices, 14 bits each)
+__device__ inline uint4 rowop_masks(uint32_t o) {
+    auto half = [](uint32_t op, uint32_t &test, uint32_t &flip) {
+        const uint32_t type = (op >> 12) & 3u, bd = 1u << (op & 63u), bs = 1u << ((op >> 6) & 63u);
+        test = type == OP_NONE ? 0u : (type == OP_SWAP ? bs | bd : bs);
+        flip = type == OP_NONE ? 0u : (type == OP_SWAP ? bs | bd : bd);
+    };
+    uint4 r;
+    half(o & 0x3FFFu, r.x, r.y);
+    half(o >> 14, r.z, r.w);
+    return r;
+}
 template <int R, typename Identity>
-__device__ inline bool scramble_tree(const InitArgs &a, uint32_t count, uint64_t &env, uint32_t (&rows_out)[R], uint32_t (*prod)[32], Identity identity) {
+__device__ inline bool scramble_tree(const InitArgs &a, uint32_t count, uint64_t &env, uint32_t (&rows_out)[R], uint32_t (*prod)[32], uint4 (*gates)[QG_WAVE],
+                                     const uint32_t *table, Identity identity) {
     static_assert(R <= 32, "one uint32 of slots per column");
     const uint64_t item = blockIdx.x;
     if (item >= count) return false;  // whole workgroups leave together
-    const uint32_t lane = threadIdx.x & (QG_WAVE - 1), w = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1), w = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31u;
     env = a.list[item];
-    const uint32_t seg = (a.n_draws + 3u) / 4u, t0 = w * seg, t1 = (t0 + seg < a.n_draws) ? t0 + seg : a.n_draws;  // this wave's gates [t0, t1)
-    uint32_t col = 0;
-    if (lane < 32u) {
-        if (w == 0) {
+    // segment k = 2 w + half owns the gates [k seg, (k + 1) seg)
+    const uint32_t seg = (a.n_draws + 7u) / 8u, k = 2u * w + half;
+    const uint32_t t0 = k * seg < a.n_draws ? k * seg : a.n_draws, t1 = (t0 + seg < a.n_draws) ? t0 + seg : a.n_draws;
+    uint32_t col;
+    if (k == 0) {
+        col = 0;
 #pragma unroll
-            for (int sl = 0; sl < R; ++sl) col |= ((identity((uint32_t)sl) >> lane) & 1u) << sl;  // clifford.rs:307
-        } else {
-            col = lane < (uint32_t)R ? 1u << lane : 0u;
-        }
+        for (int sl = 0; sl < R; ++sl) col |= ((identity((uint32_t)sl) >> hl) & 1u) << sl;  // clifford.rs:307
+    } else {
+        col = hl < (uint32_t)R ? 1u << hl : 0u;
     }
     const uint64_t seed = init_seed(a);
-    // One row operation, branch-free: with b_src, b_dst the two bits as 0 / -1 (v_bfe_i32), x = b_src ^ (b_dst & swap) is what changes --
-    // xor: the source bit lands on dst; swap: both positions flip when the bits differ -- and `m` says where: bit dst (xor), bits dst
-    // and src (swap), nothing ("no gate").  src, dst, swap and m are wave-uniform: scalar registers.
-    auto rowop = [&](uint32_t src, uint32_t dst, int32_t swap, uint32_t m) {
-        const int32_t bs = __builtin_amdgcn_sbfe((int32_t)col, src, 1u), bd = __builtin_amdgcn_sbfe((int32_t)col, dst, 1u);
-        col ^= (uint32_t)(bs ^ (bd & swap)) & m;
-    };
-    auto mask_of = [](uint32_t op) -> uint32_t {  // per lane, for its own draw
-        const uint32_t type = (op >> 12) & 3u, dst = op & 63u, src = (op >> 6) & 63u;
-        return ((uint32_t)(type != OP_NONE) << dst) | ((uint32_t)(type == OP_SWAP) << src);
-    };
-    for (uint32_t c0 = t0; c0 < t1; c0 += 2u * QG_WAVE) {
-        uint32_t o[2], m0[2], m1[2];
-#pragma unroll
-        for (uint32_t j = 0; j < 2; ++j) {
-            const uint32_t t = c0 + j * QG_WAVE + lane;
-            o[j] = t < t1 ? a.rowops[rng_action(seed, a.env_base + env, t, a.num_actions)] : 0u;  // past the end: "no gate"
+    uint4 *mine = gates[w];
+    for (uint32_t c0 = 0; c0 < seg; c0 += 32u) {  // 32 gates per half wave and pass (seg <= 32 up to 256 draws: one pass)
+        const uint32_t t = t0 + c0 + hl;
+        uint32_t o = 0u;  // past the segment's end: "no gate" (all four masks zero)
+        if (t < t1) {
+            const uint32_t act = rng_action(seed, a.env_base + env, t, a.num_actions);
+            o = table ? table[act] : a.rowops[act];
         }
+        __builtin_amdgcn_wave_barrier();  // (the previous pass has read its masks)
+        mine[lane] = rowop_masks(o);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t left = seg - c0, steps = left < 32u ? left : 32u;  // wave-uniform (both halves walk `steps` gates; the tail is "no gate")
+        const uint4 *p = mine + 32u * half;
+        uint4 g[4];
 #pragma unroll
-        for (uint32_t j = 0; j < 2; ++j) {
-            m0[j] = mask_of(o[j] & 0x3FFFu);
-            m1[j] = mask_of(o[j] >> 14);
-        }
+        for (int q = 0; q < 4; ++q) g[q] = p[q];
+        for (uint32_t kk = 0; kk < steps; kk += 4u) {
+            uint4 nx[4];
 #pragma unroll
-        for (uint32_t j = 0; j < 2; ++j) {
-            if (c0 + j * QG_WAVE >= t1) break;
-            const uint32_t left = t1 - (c0 + j * QG_WAVE);
-            const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)(left < QG_WAVE ? left : QG_WAVE));
-            for (uint32_t k = 0; k < len; ++k) {
-                const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)o[j], (int)k);
-                const uint32_t ga = (uint32_t)__builtin_amdgcn_readlane((int)m0[j], (int)k), gb = (uint32_t)__builtin_amdgcn_readlane((int)m1[j], (int)k);
-                // op = dst | src << 6 | type << 12, type in {0, 1, 2}: bit 13 says "swap" (OP_SWAP == 2)
-                rowop((g >> 6) & 63u, g & 63u, __builtin_amdgcn_sbfe((int32_t)g, 13u, 1u), ga);
-                rowop((g >> 20) & 63u, (g >> 14) & 63u, __builtin_amdgcn_sbfe((int32_t)g, 27u, 1u), gb);
+            for (int q = 0; q < 4; ++q) nx[q] = p[(kk + 4u + q) & 31u];  // the next four gates fly while these four are applied
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // (entries past `steps` in the last group of four are past the segment's end: zero masks)
+                rowop_parity(col, g[q].x, g[q].y);
+                rowop_parity(col, g[q].z, g[q].w);
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] = nx[q];
         }
     }
-    // (P3 P2) (P1 X0): the odd waves publish their columns, the even ones multiply; then wave 2 publishes, wave 0 multiplies
-    if ((w & 1u) && lane < 32u) prod[w][lane] = col;
+    // P_upper P_lower inside the wave, then (W3 W2) (W1 W0): publish, multiply
+    if (half) prod[w][hl] = col;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (!half) col = gf2_cols_product<R>(prod[w], col);
+    if ((w & 1u) && !half) prod[w][hl] = col;  // (prod[w] is this wave's own: its reads above are ordered before this write)
     __syncthreads();
-    if (!(w & 1u)) col = gf2_cols_product<R>(prod[w + 1u], col);
-    if (w == 2u && lane < 32u) prod[2][lane] = col;
+    if (!(w & 1u) && !half) col = gf2_cols_product<R>(prod[w + 1u], col);
+    if (w == 2u && !half) prod[2][hl] = col;
     __syncthreads();
     if (w != 0) return false;
-    col = gf2_cols_product<R>(prod[2], col);
+    if (!half) col = gf2_cols_product<R>(prod[2], col);
 #pragma unroll
-    for (int sl = 0; sl < R; ++sl) rows_out[sl] = (uint32_t)__ballot((col >> sl) & 1u);
+    for (int sl = 0; sl < R; ++sl) rows_out[sl] = (uint32_t)__ballot(!half && ((col >> sl) & 1u));
     return lane == 0;
 }
 

@@ -1600,6 +1600,20 @@ hipError_t ptile_export(const qg_vec *v, const ObsArgs &a, hipStream_t s) {
     if (!a.B) return hipSuccess;
     if (a.format == QG_FMT_U8 && a.obs_cols <= 64u && a.out_stride == (uint64_t)a.obs_rows * a.obs_cols && (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0)
         return ptile_dense_via_words(const_cast<qg_vec *>(v), a, a.out, QG_DT_I8, s);  // the scratch buffer is a cache, not state
+    if (a.format == QG_FMT_I64 && a.B >= QG_STREAM_MIN_ENVS && a.obs_cols == 2 * a.N && a.out_stride == (uint64_t)a.obs_cols * a.obs_cols &&
+        (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0 && a.out != v->scratch) {
+        // get_state in the trait's Vec<i64> format (the tableau, pauli.rs:517-552): row words + the streaming expansion (qgym_api.cpp does the
+        // same for the other bit-matrix layouts); 839 MB for 20 qubits x 65 536 envs, which the row-per-thread kernel below writes at 1.8 TB/s
+        qg_vec *mv = const_cast<qg_vec *>(v);  // the scratch buffer is a cache, not state
+        const uint64_t n_rows = a.B * 2ull * a.N;
+        if (ensure_scratch_public(mv, n_rows * sizeof(uint64_t)) != QG_OK) return hipErrorOutOfMemory;
+        PTObsArgs pa;
+        fill_obs(v, a, pa);
+        hipLaunchKernelGGL(ptile_rowwords_kernel, dim3(grid_for(n_rows / 2, 256)), dim3(256), 0, s, pa, reinterpret_cast<uint64_t *>(mv->scratch));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        return expand_rows_i64(mv->scratch, 8, n_rows, a.obs_cols, reinterpret_cast<int64_t *>(a.out), s);
+    }
     PTObsArgs pa;
     fill_obs(v, a, pa);
     hipLaunchKernelGGL(ptile_export_kernel, dim3(grid_for(a.B * 2ull * a.N, 256)), dim3(256), 0, s, pa);

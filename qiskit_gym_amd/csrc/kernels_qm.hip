@@ -662,12 +662,21 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
     uint64_t env = tid;
     if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
         constexpr bool coop_fits = scramble_coop_lds_bytes<uint32_t, Rows::R>(4) <= sizeof(lds_rows);
+        // scramble_tree's LDS: the gates' masks, and the row-operation table, which comes in while the list length is still in flight (the
+        // draws then index LDS instead of paying a third dependent trip to memory)
+        __shared__ uint4 tree_gates[4][QG_WAVE];
+        __shared__ uint32_t tree_table[QG_TREE_TABLE_MAX];
+        const bool table_fits = a.coop && a.num_actions <= QG_TREE_TABLE_MAX;
+        if (table_fits)
+            for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) tree_table[i] = a.rowops[i];
         const bool tree = a.coop && tree_takes(a.list_count[0], a.n_draws, a.B);  // (a block past the list may see the count already zeroed: it has no work either way)
         const uint32_t count = list_count_take(a.list_count, (coop_fits && a.coop) ? a.B : 0, tree ? QG_TREE_THREADS : QG_COOP_LANES);  // this kernel is the list's only reader
-        if (tree) {  // few finished envs, long scrambles: a workgroup each, the matrix by columns, the gate sequence cut in four (scramble_tree)
+        if (tree) {  // few finished envs, long scrambles: a workgroup each, the matrix by columns, the gate sequence cut in eight (scramble_tree)
             const uint32_t N = a.N;
             Rows s;
-            if (!scramble_tree<Rows::R>(a, count, env, s.r, reinterpret_cast<uint32_t(*)[32]>(&lds_rows[0][0][0]), [N](uint32_t k) -> uint32_t {
+            __syncthreads();  // the table is in LDS
+            if (!scramble_tree<Rows::R>(a, count, env, s.r, reinterpret_cast<uint32_t(*)[32]>(&lds_rows[0][0][0]), tree_gates, table_fits ? tree_table : nullptr,
+                                        [N](uint32_t k) -> uint32_t {
                     const uint32_t j = HAS_Z ? k >> 1 : k;
                     return j < N ? ((HAS_Z && (k & 1u)) ? (1u << N) << j : 1u << j) : 0u;
                 }))

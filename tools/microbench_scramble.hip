@@ -70,6 +70,85 @@ __global__ __launch_bounds__(64) void k(const uint32_t *ops, uint32_t *out, int 
     out[(size_t)blockIdx.x * 64 + lane] = col;
 }
 
+// MODE 5..8: the row operation as a parity test -- t = col & test, col ^= -(popcount(t) & 1) & flip; xor: test = 1 << src, flip = 1 << dst;
+// swap: test = flip = both bits -- so a gate is four masks the drawing lane decodes itself, and nothing is decoded in the serial loop:
+//   5  four readlanes per gate
+//   7  the four masks of a gate parked in LDS as one uint4, read back by every lane (broadcast), four gates ahead of the chain
+//   8  the same with TWO gate streams per wave: lanes 0-31 and 32-63 each hold a 32-column matrix and read their own stream (n / 2 steps)
+__device__ inline void rowop_p(uint32_t &col, uint32_t test, uint32_t flip) {
+    const uint32_t t = col & test;
+    col ^= (uint32_t)__builtin_amdgcn_sbfe((int32_t)__builtin_popcount(t), 0u, 1u) & flip;
+}
+__device__ inline uint4 decode_p(uint32_t o) {
+    auto half = [](uint32_t op, uint32_t &test, uint32_t &flip) {
+        const uint32_t type = (op >> 12) & 3u, dst = op & 63u, src = (op >> 6) & 63u;
+        const uint32_t bs = 1u << src, bd = 1u << dst;
+        test = type == 0 ? 0u : (type == 2 ? bs | bd : bs);
+        flip = type == 0 ? 0u : (type == 2 ? bs | bd : bd);
+    };
+    uint4 r;
+    half(o & 0x3FFFu, r.x, r.y);
+    half(o >> 14, r.z, r.w);
+    return r;
+}
+template <int MODE>
+__global__ __launch_bounds__(64) void kp(const uint32_t *ops, uint32_t *out, int n) {
+    __shared__ uint4 lds[256];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t *my = ops + (size_t)blockIdx.x * 256;
+    uint32_t col = 1u << (lane & 31u);
+    uint4 d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        d[j] = decode_p(my[j * 64 + lane]);
+        lds[j * 64 + lane] = d[j];
+    }
+    __syncthreads();
+    if (MODE == 5) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            for (int kk = 0; kk < 64 && j * 64 + kk < n; ++kk) {
+                const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)d[j].x, kk), b = (uint32_t)__builtin_amdgcn_readlane((int)d[j].y, kk);
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)d[j].z, kk), e = (uint32_t)__builtin_amdgcn_readlane((int)d[j].w, kk);
+                rowop_p(col, a, b);
+                rowop_p(col, c, e);
+            }
+    } else {
+        // MODE 8: the upper half wave walks the second half of the stream
+        const int steps = MODE == 8 ? n / 2 : n;
+        const uint4 *p = lds + ((MODE == 8 && lane >= 32u) ? steps : 0);
+        uint4 g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = p[q];
+        for (int kk = 0; kk < steps; kk += 4) {
+            uint4 nx[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nx[q] = p[(kk + 4 + q) & 255];  // the next four gates fly while these four are applied
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                rowop_p(col, g[q].x, g[q].y);
+                rowop_p(col, g[q].z, g[q].w);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] = nx[q];
+        }
+    }
+    out[(size_t)blockIdx.x * 64 + lane] = col;
+}
+template <int MODE>
+static void runp(const char *name, const uint32_t *ops, uint32_t *out, int waves, int n) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kp<MODE>, dim3(waves), dim3(64), 0, 0, ops, out, n);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kp<MODE>, dim3(waves), dim3(64), 0, 0, ops, out, n);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("waves %5d gates %3d mode %d %-52s %8.2f us per launch  %6.1f ns per gate\n", waves, n, MODE, name, ms * 1e3 / 20, ms * 1e6 / 20 / n);
+}
+
 template <int MODE>
 static void run(const char *name, const uint32_t *ops, uint32_t *out, int waves, int n) {
     hipEvent_t e0, e1;
@@ -103,6 +182,9 @@ int main() {
             run<2>("LDS broadcast, vector decode", ops, out, waves, n);
             run<3>("constant gate (floor of the vector chain)", ops, out, waves, n);
             run<4>("global uniform load per gate", ops, out, waves, n);
+            runp<5>("parity form, 4 readlanes of pre-decoded masks", ops, out, waves, n);
+            runp<7>("parity form, masks from LDS (broadcast, 4 ahead)", ops, out, waves, n);
+            runp<8>("... two streams per wave (half waves)", ops, out, waves, n);
         }
     }
     return 0;
