@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 /* 2: + qg_comm_* / learner-shard entry points, qg_vec_step_host, qg_vec_observe_*_host (additions only: version-1 callers keep working)
- * 3: + qg_vec_track_dense, qg_comm_p2p_reset (additions only) */
+ * 3: + qg_vec_track_dense, qg_comm_p2p_reset, qg_plan_query (additions only) */
 #define QG_ABI_VERSION 3
 
 typedef enum {
@@ -492,6 +492,26 @@ int qg_comm_p2p_check(qg_comm *c, void *stream);
 /* Restart the direct-write transport after an error: call on EVERY rank between two barriers of the host's own (all streams drained, no
  * push in flight anywhere).  Synchronises `stream`, clears the error word, this rank's window header and both epoch counters. */
 int qg_comm_p2p_reset(qg_comm *c, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Which kernel would run.  The library picks a state layout and a kernel family from the env kind, the sizes and the options (DESIGN.md
+ * section 2); this query answers from the same decision functions the launch paths call (csrc/qgym_plan.hpp) and needs no GPU, so a test can
+ * pin the table.  `arg`: QG_PLAN_ROLLOUT_FUSED: number of steps T; QG_PLAN_RESET_DONE: length of the list of finished envs.
+ * `nonsymplectic` != 0: some env holds a state not known to be symplectic (set_state of an arbitrary matrix with add_inverts).
+ * name_out receives a short name ("TILE", "qm_step1_kernel", "scramble_tree", "qm_dense_stream_kernel", ...).  Returns QG_OK, or the status
+ * qg_vec_create would return for this configuration (QG_ERR_UNSUPPORTED beyond the limits).
+ * ---------------------------------------------------------------------------------------- */
+typedef enum {
+    QG_PLAN_LAYOUT = 0,         /* the resident state layout */
+    QG_PLAN_STEP = 1,           /* qg_vec_step */
+    QG_PLAN_ROLLOUT_FUSED = 2,  /* qg_vec_rollout(fused = 1) of `arg` steps */
+    QG_PLAN_RESET_DONE = 3,     /* qg_vec_reset_done with `arg` finished envs, cfg->difficulty draws each */
+    QG_PLAN_OBSERVE_DENSE = 4,  /* qg_vec_observe_dense into a 16-byte-aligned buffer */
+    QG_PLAN_OBSERVE_PACKED = 5, /* qg_vec_observe_packed */
+    QG_PLAN_STATE_I64 = 6,      /* qg_vec_get_state / set_state in QG_FMT_I64 */
+    QG_PLAN_TRACK_DENSE = 7     /* qg_vec_track_dense: "in-step", "refresh" (a full rewrite after every step) or unsupported */
+} qg_plan_op;
+int qg_plan_query(const qg_config *cfg, uint64_t batch, uint32_t num_actions, int op, uint64_t arg, int nonsymplectic, char *name_out, size_t cap);
 
 /* ------------------------------------------------------------------------------------------
  * Scalar environment: the `Env` trait method for method (clifford.rs:285-382).

@@ -96,7 +96,7 @@ EXPORTED_SYMBOLS = [
     "qg_vec_learner_shard_layout", "qg_vec_pack_learner_shard", "qg_comm_unique_id", "qg_comm_init", "qg_comm_init_local", "qg_comm_destroy",
     "qg_comm_rank", "qg_comm_world", "qg_vec_gather_learner_shard", "qg_comm_gather_submit", "qg_comm_gather_flush", "qg_comm_gather_latest",
     "qg_comm_p2p_connect", "qg_comm_p2p_export", "qg_comm_p2p_open", "qg_vec_push_learner_shard", "qg_comm_p2p_wait", "qg_comm_p2p_release",
-    "qg_comm_p2p_check", "qg_comm_p2p_reset",
+    "qg_comm_p2p_check", "qg_comm_p2p_reset", "qg_plan_query",
     "qg_env_create", "qg_env_clone", "qg_env_set_seed", "qg_env_destroy", "qg_env_num_actions", "qg_env_obs_shape",
     "qg_env_set_difficulty", "qg_env_get_difficulty", "qg_env_set_state", "qg_env_reset", "qg_env_step",
     "qg_env_step_coin", "qg_env_masks", "qg_env_is_final", "qg_env_reward", "qg_env_success", "qg_env_observe",
@@ -213,6 +213,7 @@ def load():
     L.qg_comm_p2p_release.argtypes = [vp, vp]
     L.qg_comm_p2p_check.argtypes = [vp, vp]
     L.qg_comm_p2p_reset.argtypes = [vp, vp]
+    L.qg_plan_query.argtypes = [C.POINTER(QGConfig), C.c_uint64, C.c_uint32, C.c_int, C.c_uint64, C.c_int, C.c_char_p, C.c_size_t]
     L.qg_env_create.argtypes = [C.POINTER(QGConfig), C.POINTER(QGGate), sz, C.c_int, C.POINTER(vp)]
     L.qg_env_clone.argtypes = [vp, C.POINTER(vp)]
     L.qg_env_destroy.argtypes = [vp]

@@ -2,6 +2,7 @@
 #pragma once
 
 #include "qgym_internal.hpp"
+#include "qgym_plan.hpp"
 
 namespace qg {
 
@@ -49,7 +50,7 @@ __device__ inline void done_list_append_block(uint32_t *list, uint32_t *count, b
     }
 }
 
-#define QG_COOP_LANES 16  // lanes per env of the cooperative scramble (scramble_coop below)
+#define QG_COOP_LANES qg::plan::COOP_LANES  // lanes per env of the cooperative scramble (scramble_coop below; qgym_plan.hpp)
 
 // Length of the compacted list of finished envs (compact_done), read by every thread of the LAST kernel that consumes it.  The last
 // block WITH WORK to have read it zeroes the counter (and the ticket) for the next qg_vec_reset_done: counter[0] = length, counter[1] =
@@ -80,8 +81,9 @@ __device__ inline uint32_t list_count_take(uint32_t *counter, uint64_t coop_B = 
 // indices), and the counter-RNG draws -- two splitmix64 rounds, ~300 cycles of 64-bit multiplies each --
 // are issued ahead of the dependent LDS chain.
 // ---------------------------------------------------------------------------------------------------
-// qg_vec_reset_done: lists of at most B / 32 finished envs take the 16-lanes-per-env path
-__device__ inline bool coop_takes(uint32_t count, uint64_t B) { return (uint64_t)count * QG_COOP_LANES * 2 <= B; }
+// qg_vec_reset_done: which of the three scrambles a list takes is decided in qgym_plan.hpp (list_reset_path)
+using plan::coop_takes;
+using plan::tree_takes;
 
 template <typename W>
 __device__ inline void lds_rowop(W *dst, W *src, uint32_t type) {
@@ -178,14 +180,9 @@ __device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds,
 // Rows come back by ballot: row word of slot s = the lanes' bits s.  Returns true on the one lane (lane 0 of wave 0) that finishes the env.
 // `prod`: 4 x 32 words of LDS; `gates`: 4 x 64 uint4 of LDS (16-byte aligned); `table`: the row-operation table in LDS (the caller brings it
 // in while the list length is still in flight), or null: read a.rowops.  blockDim.x must be 256.
-constexpr uint32_t QG_TREE_THREADS = 256;
+constexpr uint32_t QG_TREE_THREADS = plan::TREE_THREADS;
 constexpr uint32_t QG_TREE_TABLE_MAX = 1024;  // gatesets up to this many actions have their row-operation table in LDS
-constexpr uint32_t QG_TREE_MAX_ENVS = 1024;  // four waves per env: beyond ~1 000 envs the chip's SIMDs hold several of these waves each and issue slots,
-                                            // not the chain, set the time (65 536 envs, 3 % finished: 59 us against 56 for scramble_coop)
-// lists this short, of scrambles this long, go to scramble_tree (shorter chains do not repay the products)
-__device__ __host__ inline bool tree_takes(uint32_t count, uint32_t n_draws, uint64_t B) {
-    return n_draws >= 64u && count <= QG_TREE_MAX_ENVS && (uint64_t)count * QG_COOP_LANES * 2 <= B;
-}
+constexpr uint32_t QG_TREE_MAX_ENVS = plan::TREE_MAX_ENVS;
 template <int R>
 __device__ inline uint32_t gf2_cols_product(const uint32_t *a_cols, uint32_t b) {  // this lane's column of A B; a_cols[s] = column s of A
     uint32_t acc = 0;

@@ -1473,16 +1473,6 @@ static inline unsigned grid_for(uint64_t threads, unsigned block) { return (unsi
 
 // ---- host hooks ----------------------------------------------------------------------------------
 
-int ptile_plan(qg_vec *v) {
-    v->pt_nq = (v->N + 3u) & ~3u;
-    v->pt_rm = v->rmax <= 8 ? 8u : v->rmax <= 16 ? 16u : 32u;
-    v->stride_bytes = 0;
-    const bool compact = v->pt_nq <= 24 && v->pt_rm == 8;  // PTLayout::COMPACT
-    v->state_bytes = ((v->B + 63) / 64) * ((size_t)v->pt_nq * (compact ? 768 : 1024) + (size_t)v->pt_rm * (compact ? 512 : 1024) +
-                                           (v->pt_rm > 16 ? 3072 : 1024));  // PTLayout::TILE_BYTES
-    return QG_OK;
-}
-
 int ptile_alloc(qg_vec *v) {
     std::vector<uint64_t> prog(std::max<size_t>(v->gates.size(), 1));
     for (size_t i = 0; i < v->gates.size(); ++i) prog[i] = ptile_program(v->gates[i]);
@@ -1505,21 +1495,27 @@ template <int NQ, int RM>
 static hipError_t pt_launch_step(const PTArgs &pa, hipStream_t s) {
     const dim3 grid(grid_for(pa.s.B, 256)), block(256);
     const bool feat = pa.s.flags & (F_TRACK | F_LAYERS);
-    if (pa.s.T == 1) {
+    switch (plan::pauli_step_kernel_of(pa.s.flags, pa.s.T, PTLayout<NQ, RM>::COMPACT, pa.n_perms != 0)) {  // qgym_plan.hpp
+    case plan::SK_PTILE_STEP1C:
         if constexpr (PTLayout<NQ, RM>::COMPACT) {
             if (feat) hipLaunchKernelGGL((ptile_step1c_kernel<NQ, RM, true>), grid, block, 0, s, pa);
             else hipLaunchKernelGGL((ptile_step1c_kernel<NQ, RM, false>), grid, block, 0, s, pa);
-        } else {
+        }
+        break;
+    case plan::SK_PTILE_STEP1:
+        if constexpr (!PTLayout<NQ, RM>::COMPACT) {
             if (feat) hipLaunchKernelGGL((ptile_step1_kernel<NQ, RM, true>), grid, block, 0, s, pa);
             else hipLaunchKernelGGL((ptile_step1_kernel<NQ, RM, false>), grid, block, 0, s, pa);
         }
-    } else if (!feat && !pa.n_perms && PTLayout<NQ, RM>::COMPACT) {
+        break;
+    case plan::SK_PTILE_FUSED1C:
         if constexpr (PTLayout<NQ, RM>::COMPACT)
             hipLaunchKernelGGL((ptile_fused1c_kernel<NQ, RM>), dim3(grid_for(pa.s.B, QG_WAVE)), dim3(QG_WAVE), 0, s, pa);
-    } else if (feat) {
-        hipLaunchKernelGGL((ptile_step_kernel<NQ, RM, true>), grid, block, 0, s, pa);
-    } else {
-        hipLaunchKernelGGL((ptile_step_kernel<NQ, RM, false>), grid, block, 0, s, pa);
+        break;
+    default:
+        if (feat) hipLaunchKernelGGL((ptile_step_kernel<NQ, RM, true>), grid, block, 0, s, pa);
+        else hipLaunchKernelGGL((ptile_step_kernel<NQ, RM, false>), grid, block, 0, s, pa);
+        break;
     }
     return hipGetLastError();
 }

@@ -19,6 +19,7 @@
 //     image at index state[i] and the two images trade places.
 // HBM-bound: N R + <= 2 W bytes (one step) / 2 x roundup(N, 16) bytes (inversion) + 16 B of scalars per env-step.
 #include "device_common.hpp"
+#include "qgym_plan.hpp"
 
 namespace qg {
 
@@ -286,7 +287,7 @@ static unsigned permb_block(uint32_t ng, uint32_t images) {  // threads per bloc
 
 hipError_t permb_step(const StepArgs &a, const uint32_t ng, hipStream_t s) {
     if (!a.B) return hipSuccess;
-    if (a.T == 1 && !(a.flags & F_INVERTS) && a.bad) {
+    if (plan::permb_step_kernel_of(a.flags, a.T, a.bad != nullptr) == plan::SK_PERMB_STEP1) {  // qgym_plan.hpp
         hipLaunchKernelGGL(permb_step1_kernel, dim3(grid_for(a.B, 256)), dim3(256), 0, s, a, ng);
         return hipGetLastError();
     }

@@ -31,6 +31,7 @@
 #include <cstdlib>
 
 #include "device_common.hpp"
+#include "qgym_plan.hpp"
 #include "qm_step1.hpp"
 
 namespace qg {
@@ -662,6 +663,7 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
     uint64_t env = tid;
     if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
         constexpr bool coop_fits = scramble_coop_lds_bytes<uint32_t, Rows::R>(4) <= sizeof(lds_rows);
+        static_assert(coop_fits == plan::tile_coop_fits(Rows::R, 4), "qgym_plan.hpp must describe this kernel");
         // scramble_tree's LDS: the gates' masks, and the row-operation table, which comes in while the list length is still in flight (the
         // draws then index LDS instead of paying a third dependent trip to memory)
         __shared__ uint4 tree_gates[4][QG_WAVE];
@@ -669,7 +671,9 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
         const bool table_fits = a.coop && a.num_actions <= QG_TREE_TABLE_MAX;
         if (table_fits)
             for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) tree_table[i] = a.rowops[i];
-        const bool tree = a.coop && tree_takes(a.list_count[0], a.n_draws, a.B);  // (a block past the list may see the count already zeroed: it has no work either way)
+        // (a block past the list may see the count already zeroed: it has no work either way)
+        const plan::ResetPath path = plan::list_reset_path(a.list_count[0], a.n_draws, a.B, a.coop != 0, coop_fits);  // qgym_plan.hpp
+        const bool tree = path == plan::RP_TREE;
         const uint32_t count = list_count_take(a.list_count, (coop_fits && a.coop) ? a.B : 0, tree ? QG_TREE_THREADS : QG_COOP_LANES);  // this kernel is the list's only reader
         if (tree) {  // few finished envs, long scrambles: a workgroup each, the matrix by columns, the gate sequence cut in eight (scramble_tree)
             const uint32_t N = a.N;
@@ -684,7 +688,7 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
             qm_init_finish<NXP, HAS_Z>(a, env, s);
             return;
         }
-        if (coop_fits && a.coop && coop_takes(count, a.B)) {  // few finished envs: 16 lanes each (count * 16 <= B / 2 threads)
+        if (plan::list_reset_path(count, a.n_draws, a.B, a.coop != 0, coop_fits) == plan::RP_COOP) {  // few finished envs: 16 lanes each
             const uint32_t N = a.N;
             const uint32_t *rows = scramble_coop<uint32_t, Rows::R>(a, count, &lds_rows[0][0][0], env, [N](uint32_t k) -> uint32_t {
                 const uint32_t j = HAS_Z ? k >> 1 : k;
@@ -875,8 +879,9 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
     const dim3 grid(grid_for(a.B, 256)), block(256);  // 64- and 128-thread blocks measured no faster
     const bool feat = a.flags & (F_TRACK | F_LAYERS);
     const bool seq = a.T != 1 || a.rewards_seq || a.dones_seq;
-    if (a.bad && a.T == 1 && !(a.flags & F_INVERTS)) {  // the env.step() path
-        const bool list = a.flags & F_DONE_LIST;
+    const bool list = a.flags & F_DONE_LIST;
+    switch (plan::tile_step(a.flags, a.T, a.bad != nullptr, a.rewards_seq || a.dones_seq, a.num_actions, HAS_Z, NXP)) {  // qgym_plan.hpp
+    case plan::SK_QM_STEP1:  // the env.step() path
         if constexpr (QmRows<NXP, HAS_Z>::R % 16 == 0) {
             if (a.dense) {  // qg_vec_track_dense (the host passes it for N == NXP only)
                 if (feat && list) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, true, true, true>), grid, block, 0, s, a);
@@ -891,38 +896,40 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
         else if (list) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, false, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, false>), grid, block, 0, s, a);
         return hipGetLastError();
-    }
-    if (a.flags & F_INVERTS) {
-        if constexpr (HAS_Z && NXP <= 16) {  // CliffordEnv (LinearFunctionEnv with add_inverts lives in kernels_lfd.hip)
-            if (!(a.flags & F_GJ) && a.T == 1) {  // every env symplectic, one step per launch: two lanes per env
-                const dim3 grid2(grid_for(2 * a.B, 256));
-                const bool list = a.flags & F_DONE_LIST;
-                if (feat && list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true, true>), grid2, block, 0, s, a);
-                else if (feat) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true>), grid2, block, 0, s, a);
-                else if (list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, false, true>), grid2, block, 0, s, a);
-                else hipLaunchKernelGGL((qm_inv2_kernel<NXP, false>), grid2, block, 0, s, a);
-                return hipGetLastError();
-            }
-            // the thread-per-env inversion variants (fused rollouts, states not known to be symplectic) always carry FEAT and SEQ
-            if (a.flags & F_GJ) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true, false>), grid, block, 0, s, a);
+    case plan::SK_QM_INV2:  // CliffordEnv with add_inverts, every env symplectic, one step per launch: two lanes per env
+        if constexpr (HAS_Z && NXP <= 16) {
+            const dim3 grid2(grid_for(2 * a.B, 256));
+            if (feat && list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true, true>), grid2, block, 0, s, a);
+            else if (feat) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true>), grid2, block, 0, s, a);
+            else if (list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, false, true>), grid2, block, 0, s, a);
+            else hipLaunchKernelGGL((qm_inv2_kernel<NXP, false>), grid2, block, 0, s, a);
             return hipGetLastError();
         }
         return hipErrorInvalidValue;
-    }
-    if (!feat && seq && a.T > 1) {  // plain fused rollout
-        if (a.num_actions == 0) { /* an empty gateset has no table to read: the register-resident kernel below handles it */
-        } else {
-            if (a.flags & F_ACT64) hipLaunchKernelGGL((qm_fused_lds_kernel<NXP, HAS_Z, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((qm_fused_lds_kernel<NXP, HAS_Z, false>), grid, block, 0, s, a);
+    case plan::SK_QM_STEP_GJ:  // the thread-per-env inversion variants (fused rollouts, states not known to be symplectic) always carry FEAT and SEQ
+        if constexpr (HAS_Z && NXP <= 16) {
+            hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true, true>), grid, block, 0, s, a);
             return hipGetLastError();
         }
+        return hipErrorInvalidValue;
+    case plan::SK_QM_STEP_INV:
+        if constexpr (HAS_Z && NXP <= 16) {
+            hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true, true, false>), grid, block, 0, s, a);
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
+    case plan::SK_QM_FUSED_LDS:  // plain fused rollout (an empty gateset has no table to read: the register-resident kernel handles it)
+        if (a.flags & F_ACT64) hipLaunchKernelGGL((qm_fused_lds_kernel<NXP, HAS_Z, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((qm_fused_lds_kernel<NXP, HAS_Z, false>), grid, block, 0, s, a);
+        return hipGetLastError();
+    case plan::SK_QM_STEP:
+        if (feat && seq) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true>), grid, block, 0, s, a);
+        else if (feat) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, false>), grid, block, 0, s, a);
+        else if (seq) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, false, false>), grid, block, 0, s, a);
+        return hipGetLastError();
+    default: return hipErrorInvalidValue;
     }
-    if (feat && seq) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, true>), grid, block, 0, s, a);
-    else if (feat) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, true, false>), grid, block, 0, s, a);
-    else if (seq) hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, false, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((qm_step_kernel<NXP, HAS_Z, false, false>), grid, block, 0, s, a);
-    return hipGetLastError();
 }
 template <int NXP, bool HAS_Z>
 static hipError_t launch_init(const InitArgs &a, hipStream_t s) {
@@ -970,15 +977,18 @@ hipError_t qm_init(const InitArgs &a, uint32_t nxp, bool has_z, hipStream_t s) {
 hipError_t qm_export(const ObsArgs &a, uint32_t nxp, bool has_z, hipStream_t s) {
     if (!a.B) return hipSuccess;
     const uint32_t R = has_z ? 2 * nxp : nxp;
-    if (a.format == QG_FMT_U8 && a.D == R && (a.D == 16 || a.D == 32) && a.out_stride == (uint64_t)a.D * a.D && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(a.out);
+    switch (plan::tile_export(a.format, a.D, R, a.out_stride, (addr & 15) == 0, (addr & 3) == 0)) {  // qgym_plan.hpp
+    case plan::EK_DENSE_STREAM: {
         const dim3 grid((unsigned)((a.B + 255) / 256)), block(256);  // a wave per tile of 64 envs
         if (a.D == 32) hipLaunchKernelGGL(qm_dense_stream_kernel<2>, grid, block, 0, s, a, has_z ? 1u : 0u);
         else hipLaunchKernelGGL(qm_dense_stream_kernel<1>, grid, block, 0, s, a, has_z ? 1u : 0u);
         return hipGetLastError();
     }
-    if (a.format == QG_FMT_PACKED && a.out_stride == a.D && a.D <= 32 && (reinterpret_cast<uintptr_t>(a.out) & 3) == 0) {
+    case plan::EK_PACK:
         hipLaunchKernelGGL(qm_pack_kernel, dim3((unsigned)((a.B + 255) / 256)), dim3(256), 0, s, a, nxp, has_z ? 1u : 0u);
         return hipGetLastError();
+    default: break;
     }
     hipLaunchKernelGGL(qm_export_kernel, dim3(grid_for(a.B * a.D, 256)), dim3(256), 0, s, a, nxp, has_z ? 1u : 0u);
     return hipGetLastError();

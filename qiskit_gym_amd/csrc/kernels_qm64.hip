@@ -14,6 +14,7 @@
 // two.  LinearFunctionEnv: slot j = row j.  The lane-group ROWS kernels these shapes used before
 // are instruction-issue-bound (14-15 us per step, 140-220 us with inversion at B = 65 536).
 #include "device_common.hpp"
+#include "qgym_plan.hpp"
 
 namespace qg {
 
@@ -848,37 +849,47 @@ __global__ __launch_bounds__(64) void q64_fused_lds_kernel(StepArgs a) {
 template <int NS, bool HAS_Z>
 static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
     const dim3 grid(grid_for(a.B, 256)), block(256);
-    const bool extra = (a.flags & (F_TRACK | F_LAYERS)) || a.T != 1 || a.rewards_seq || a.dones_seq;
-    if (a.bad && a.T == 1 && !(a.flags & F_INVERTS)) {  // the env.step() path
-        const bool feat = a.flags & (F_TRACK | F_LAYERS), list = a.flags & F_DONE_LIST;
+    const bool feat = a.flags & (F_TRACK | F_LAYERS), list = a.flags & F_DONE_LIST;
+    const bool extra = feat || a.T != 1 || a.rewards_seq || a.dones_seq;
+    switch (plan::tile64_step(a.flags, a.T, a.bad != nullptr, a.rewards_seq || a.dones_seq, a.num_actions, HAS_Z)) {  // qgym_plan.hpp
+    case plan::SK_Q64_STEP1:  // the env.step() path
         if (feat && list) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, true, true>), grid, block, 0, s, a);
         else if (feat) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, true>), grid, block, 0, s, a);
         else if (list) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, false, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, false>), grid, block, 0, s, a);
         return hipGetLastError();
-    }
-    if (a.T > 1 && !(a.flags & (F_TRACK | F_LAYERS | F_INVERTS)) && a.num_actions) {  // plain fused rollout: rows in LDS, one wave per workgroup
+    case plan::SK_Q64_FUSED_LDS: {  // plain fused rollout: rows in LDS, one wave per workgroup
         const dim3 g1(grid_for(a.B, 64)), b1(64);
         if (a.flags & F_ACT64) hipLaunchKernelGGL((q64_fused_lds_kernel<NS, HAS_Z, true>), g1, b1, 0, s, a);
         else hipLaunchKernelGGL((q64_fused_lds_kernel<NS, HAS_Z, false>), g1, b1, 0, s, a);
         return hipGetLastError();
     }
-    if constexpr (HAS_Z) {
-        if (a.flags & F_INVERTS) {
-            if (!(a.flags & F_GJ) && a.T == 1) {  // every env symplectic, one step per launch: two lanes per env
-                const dim3 grid2(grid_for(2 * a.B, 256));
-                if (a.flags & (F_TRACK | F_LAYERS)) hipLaunchKernelGGL((q64_inv2_kernel<NS / 2, true>), grid2, block, 0, s, a);
-                else hipLaunchKernelGGL((q64_inv2_kernel<NS / 2, false>), grid2, block, 0, s, a);
-                return hipGetLastError();
-            }
-            if (a.flags & F_GJ) hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, true, true, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, true, true, false>), grid, block, 0, s, a);
+    case plan::SK_Q64_INV2:  // every env symplectic, one step per launch: two lanes per env
+        if constexpr (HAS_Z) {
+            const dim3 grid2(grid_for(2 * a.B, 256));
+            if (feat) hipLaunchKernelGGL((q64_inv2_kernel<NS / 2, true>), grid2, block, 0, s, a);
+            else hipLaunchKernelGGL((q64_inv2_kernel<NS / 2, false>), grid2, block, 0, s, a);
             return hipGetLastError();
         }
+        return hipErrorInvalidValue;
+    case plan::SK_Q64_STEP_GJ:
+        if constexpr (HAS_Z) {
+            hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, true, true, true>), grid, block, 0, s, a);
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
+    case plan::SK_Q64_STEP_INV:
+        if constexpr (HAS_Z) {
+            hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, true, true, false>), grid, block, 0, s, a);
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
+    case plan::SK_Q64_STEP:
+        if (extra) hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, false, false>), grid, block, 0, s, a);
+        return hipGetLastError();
+    default: return hipErrorInvalidValue;
     }
-    if (extra) hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, true, false>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((q64_step_kernel<NS, HAS_Z, false, false>), grid, block, 0, s, a);
-    return hipGetLastError();
 }
 // qg_vec_reset_done with a short list of long scrambles (tree_takes): a workgroup per listed env, scramble_tree64.  Runs BEFORE q64_init_kernel
 // in the same call and consumes the list (the ticket of list_count_take zeroes it), so that the init kernel finds nothing to do; when the list

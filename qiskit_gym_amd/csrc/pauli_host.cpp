@@ -18,21 +18,6 @@
 
 namespace qg {
 
-int pauli_plan(qg_vec *v) {
-    if (v->N > 32) return set_error(QG_ERR_UNSUPPORTED, "PauliEnv: N <= 32 supported, got %u", v->N);
-    const int max_rot = std::max(v->cfg.max_rotations, 1);  // pauli.rs:387
-    const int final_layers = v->cfg.final_pauli_layers >= 0 ? v->cfg.final_pauli_layers : v->cfg.max_rotations + 2;  // :760
-    const int rmax = std::max(max_rot, final_layers);
-    if (rmax > (int)PAULI_RMAX)
-        return set_error(QG_ERR_UNSUPPORTED, "PauliEnv: at most %u rotations per env supported (max_rotations=%d, final_pauli_layers=%d)",
-                         PAULI_RMAX, max_rot, final_layers);
-    v->rmax = (uint32_t)rmax;
-    v->rmax_generate = (uint32_t)final_layers;  // reset() generates at most final_pauli_layers rotations (pauli.rs:563)
-    v->cfg.max_rotations = max_rot;
-    v->stride_bytes = (size_t)16 * v->N;
-    return ptile_plan(v);
-}
-
 int pauli_alloc(qg_vec *v) {
     int rc = ptile_alloc(v);
     if (rc) return rc;

@@ -381,7 +381,21 @@ static hipError_t launch_step(const qg_vec *v, const StepArgs &a, hipStream_t s)
 // qg_vec_track_dense.  The one-step kernel without add_inverts (qm_step1_kernel) rewrites the rows its gate changed in the same launch;
 // every other launch that changes states is followed by a full rewrite (dense_refresh), except resets of a list of finished envs, which
 // rewrite those envs' observations themselves.
-static bool dense_rides_in_step(const qg_vec *v) { return v->dense && v->layout == LAYOUT_TILE && v->bad && !(v->flags & F_INVERTS); }
+static plan::HandlePlan plan_of(const qg_vec *v) {  // the handle's fields that the planner's predicates read
+    plan::HandlePlan hp;
+    hp.layout = v->layout;
+    hp.D = v->D;
+    hp.nxp = v->nxp;
+    hp.has_z = v->has_z;
+    hp.w64 = v->w64;
+    hp.flags = v->flags;
+    hp.has_bad = v->bad != nullptr;
+    hp.pt_nq = v->pt_nq;
+    hp.pt_rm = v->pt_rm;
+    hp.pauli_compact = v->pt_nq <= 24 && v->pt_rm == 8;
+    return hp;
+}
+static bool dense_rides_in_step(const qg_vec *v) { return v->dense && plan::dense_rides_in_step(plan_of(v)); }
 static int dense_refresh(qg_vec *v, hipStream_t s);
 
 int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, uint64_t batch, int device, qg_vec **out) {
@@ -423,70 +437,26 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     v->difficulty = cfg->difficulty;
     v->coin_seed = 0x5EED0000C01Full;
 
-    switch (cfg->env_kind) {
-    case QG_PERMUTATION:
-        if (N > 256) return set_error(QG_ERR_UNSUPPORTED, "PermutationEnv: N <= 256 supported (one byte per entry), got %u", N);
-        v->D = N;
-        if (N <= 16) {  // one uint64 of nibbles per env
-            v->layout = LAYOUT_PERM;
-            v->stride_bytes = 8;
-        } else {  // one byte per entry, tiles of 64 envs (kernels_perm.hip)
-            v->layout = LAYOUT_PERMB;
-            v->nxp = (N + 15u) / 16u;
-            v->stride_bytes = 0;
-            v->state_bytes = ((batch + 63) / 64) * (size_t)v->nxp * 1024;
-        }
-        break;
-    case QG_LINEAR_FUNCTION:
-        v->D = N;
-        if (N > 64) return set_error(QG_ERR_UNSUPPORTED, "LinearFunctionEnv: N <= 64 supported, got %u", N);
-        if (N <= 8) {
-            v->layout = LAYOUT_LF8;
-            v->stride_bytes = 8;
-        }
-        break;
-    case QG_CLIFFORD:
-        v->D = 2 * N;
-        if (N > 32) return set_error(QG_ERR_UNSUPPORTED, "CliffordEnv: N <= 32 supported, got %u", N);
-        break;
-    case QG_PAULI:
-        v->D = 2 * N;
-        v->layout = LAYOUT_PAULI;
-        break;
-    default: return set_error(QG_ERR_INVALID, "unknown env_kind %d", cfg->env_kind);
+    // layout, size class and behaviour flags: qgym_plan.hpp (the same function answers qg_plan_query without a GPU)
+    plan::HandlePlan hp;
+    const char *why = "";
+    if (int rc = plan::handle_plan(*cfg, batch, hp, why)) return set_error(rc, "%s (num_qubits = %u)", why, N);
+    v->layout = hp.layout;
+    v->D = hp.D;
+    v->nxp = hp.nxp;
+    v->has_z = hp.has_z;
+    v->w64 = hp.w64;
+    v->flags = hp.flags;
+    v->stride_bytes = hp.stride_bytes;
+    v->state_bytes = hp.state_bytes;
+    if (hp.layout == LAYOUT_PAULI) {
+        v->rmax = hp.rmax;
+        v->rmax_generate = hp.rmax_generate;
+        v->cfg.max_rotations = hp.max_rotations;
+        v->pt_nq = hp.pt_nq;
+        v->pt_rm = hp.pt_rm;
     }
-    const bool inverts = cfg->add_inverts && cfg->env_kind != QG_PAULI;
-    if (v->layout == LAYOUT_NONE && cfg->env_kind == QG_LINEAR_FUNCTION && inverts) {
-        // the matrix and its inverse side by side: inversion is a role swap (kernels_lfd.hip)
-        v->layout = LAYOUT_LFD;
-        v->w64 = N > 32;
-        const uint32_t rpg = v->w64 ? 2u : 4u;
-        v->nxp = (N + rpg - 1u) / rpg;  // groups per matrix
-        v->stride_bytes = 0;
-        v->state_bytes = ((batch + 63) / 64) * (size_t)2 * v->nxp * 1024;
-    }
-    if (v->layout == LAYOUT_NONE && v->D <= 32) {  // thread-per-env TILE layout, uint32 rows (kernels_qm.hip): the hot path
-        v->layout = LAYOUT_TILE;
-        v->nxp = (N + 3u) & ~3u;
-        v->has_z = cfg->env_kind == QG_CLIFFORD;
-        const size_t R = v->has_z ? 2 * v->nxp : v->nxp;
-        v->stride_bytes = 0;
-        v->state_bytes = ((batch + 63) / 64) * R * 256;
-    }
-    if (v->layout == LAYOUT_NONE) {  // uint64 rows, thread per env (kernels_qm64.hip)
-        v->layout = LAYOUT_TILE64;
-        v->has_z = cfg->env_kind == QG_CLIFFORD;
-        v->nxp = v->has_z ? 2u * ((N + 3u) & ~3u) : ((N + 7u) & ~7u);  // row slots per env
-        v->stride_bytes = 0;
-        v->state_bytes = ((batch + 63) / 64) * (size_t)v->nxp * 512;
-    }
-
-    // behaviour flags
-    v->flags = 0;
-    if (inverts) v->flags |= F_INVERTS;
-    if (cfg->track_solution) v->flags |= F_TRACK;
-    const bool layers = !(cfg->w_n_layers == 0.0f && cfg->w_n_layers_cnots == 0.0f);
-    if (layers) v->flags |= F_LAYERS;
+    const bool layers = v->flags & F_LAYERS;
 
     // gate table
     std::vector<GateEntry> table(std::max<size_t>(n_gates, 1));
@@ -517,11 +487,6 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
         }                                                                                          \
     } while (0)
 
-    if (v->layout == LAYOUT_PAULI) {
-        int rc = pauli_plan(p);
-        if (rc) return fail(rc);
-    }
-    if (!p->state_bytes) p->state_bytes = p->stride_bytes * batch;
     HIP_TRY_V(hipMalloc(&p->state, p->state_bytes));
     HIP_TRY_V(hipMemset(p->state, 0, p->state_bytes));
     HIP_TRY_V(hipMalloc(&p->depth, sizeof(int32_t) * batch));
@@ -529,12 +494,11 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     HIP_TRY_V(hipMalloc(&p->done, batch));
     HIP_TRY_V(hipMalloc(&p->success, batch));
     HIP_TRY_V(hipMalloc(&p->inverted, batch));
-    // TILE / TILE64 layouts without add_inverts: the one-step kernel keeps `solved` as a per-env mask
-    if ((v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) && !(v->flags & F_INVERTS))
-        HIP_TRY_V(hipMalloc(&p->bad, (v->layout == LAYOUT_TILE64 ? sizeof(uint64_t) : sizeof(uint32_t)) * batch));
-    if (v->layout == LAYOUT_PERMB) HIP_TRY_V(hipMalloc(&p->bad, sizeof(uint32_t) * batch));  // number of entries with state[i] != i
-    if (v->layout == LAYOUT_LFD) HIP_TRY_V(hipMalloc(&p->bad, 2 * sizeof(uint64_t) * batch));  // row masks of the state's and the inverse's region
-    if (v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_PAULI) {
+    // TILE / TILE64 layouts without add_inverts: the one-step kernel keeps `solved` as a per-env mask; PERMB: the number of entries with
+    // state[i] != i; LFD: row masks of the state's and the inverse's region
+    if (hp.has_bad)
+        HIP_TRY_V(hipMalloc(&p->bad, (v->layout == LAYOUT_LFD ? 2 * sizeof(uint64_t) : v->layout == LAYOUT_TILE64 ? sizeof(uint64_t) : sizeof(uint32_t)) * batch));
+    if (hp.has_done_list) {
         HIP_TRY_V(hipMalloc(&p->done_list, sizeof(uint32_t) * (batch + 2)));
         HIP_TRY_V(hipMemset(p->done_list + batch, 0, 2 * sizeof(uint32_t)));
     }
@@ -690,7 +654,7 @@ int qg_vec_set_state(qg_vec *v, const void *states, int format, size_t stride, i
     // entry formats (the trait's Vec<i64>, dense bytes) of the bit-matrix layouts: the flat entry stream becomes a bit stream first (64 entries
     // per wave instruction, coalesced), the init kernel cuts its row words out of it -- no thread walks rows of 8-byte entries
     // (a handful of envs -- the scalar qg_env_* handles are batches of one -- keep the single launch)
-    const bool as_bits = format != QG_FMT_PACKED && v->B >= QG_STREAM_MIN_ENVS && (v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_LFD);
+    const bool as_bits = format != QG_FMT_PACKED && plan::entry_formats_stream(v->layout, v->B);
     const size_t in_bytes = format_elem_bytes(v, format) * stride * v->B;
     const size_t staged = on_device ? 0 : (in_bytes + 15) & ~(size_t)15;
     const size_t stream_words = as_bits ? (stride * v->B + 63) / 64 + 2 : 0;  // + the word bits_window may read past the end
@@ -776,8 +740,8 @@ int qg_vec_get_state(qg_vec *v, void *out, int format, size_t stride, int on_dev
     // stores are wave-contiguous -- 537 MB at streaming rate (the export kernels' row-per-thread, entry-by-entry stores reached 0.6 TB/s)
     qg_vec_info info;
     qg_vec_get_info(v, &info);
-    const bool two_stage = format == QG_FMT_I64 && v->B >= QG_STREAM_MIN_ENVS && stride == (size_t)v->D * v->D && !((uintptr_t)out & 15u) &&
-                           (v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_LFD) && info.packed_words_per_env == v->D;
+    const bool two_stage = format == QG_FMT_I64 && plan::entry_formats_stream(v->layout, v->B) && stride == (size_t)v->D * v->D && !((uintptr_t)out & 15u) &&
+                           info.packed_words_per_env == v->D;
     const size_t staged = on_device ? 0 : (bytes + 15) & ~(size_t)15;
     const size_t words_bytes = two_stage ? (size_t)v->B * v->D * info.packed_word_bytes : 0;
     if (staged + words_bytes) {
@@ -833,7 +797,7 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
         v->auto_list = true;
         ia.list = v->done_list;
         ia.list_count = v->done_list + v->B;
-        ia.coop = (!actions_dev && v->B >= 64 && v->d_rowops) ? 1u : 0u;
+        ia.coop = plan::reset_coop_allowed(actions_dev != nullptr, v->B, v->d_rowops != nullptr) ? 1u : 0u;
         if (v->layout == LAYOUT_TILE) ia.dense = v->dense;  // the listed envs' dense observations are rewritten by the reset itself
     }
     if (!only_done) v->maybe_nonsymplectic = false;  // identity + gates: every env is symplectic again
@@ -1137,12 +1101,66 @@ int qg_vec_track_dense(qg_vec *v, int8_t *dense_dev, void *stream) {
         v->dense = nullptr;
         return QG_OK;
     }
-    const uint32_t R = v->has_z ? 2 * v->nxp : v->nxp;
-    if (v->layout != LAYOUT_TILE || v->D != R || (v->D != 16 && v->D != 32))
+    if (!plan::dense_trackable(plan_of(v)))
         return set_error(QG_ERR_UNSUPPORTED, "track_dense: matrices of 16 or 32 rows held as 32-bit row words (CliffordEnv N = 8, 16; LinearFunctionEnv N = 16, 32)");
     if ((uintptr_t)dense_dev & 15u) return set_error(QG_ERR_INVALID, "track_dense: the buffer must be 16-byte aligned");
     v->dense = dense_dev;
     return dense_refresh(v, (hipStream_t)stream);
+}
+
+int qg_plan_query(const qg_config *cfg, uint64_t batch, uint32_t num_actions, int op, uint64_t arg, int nonsymplectic, char *name_out, size_t cap) {
+    if (!cfg || !name_out || !cap) return set_error(QG_ERR_INVALID, "null argument");
+    if (cfg->num_qubits <= 0 || batch == 0) return set_error(QG_ERR_INVALID, "num_qubits and batch must be positive");
+    plan::HandlePlan hp;
+    const char *why = "";
+    if (int rc = plan::handle_plan(*cfg, batch, hp, why)) return set_error(rc, "%s", why);
+    const char *name = "(none)";
+    static const char *layouts[] = {"NONE", "?", "LF8", "PERM", "PAULI", "TILE", "TILE64", "PERMB", "LFD"};
+    const bool perms = cfg->env_kind == QG_PAULI && cfg->add_perms;  // (a PauliEnv whose coupling map has automorphisms)
+    const uint32_t R = hp.has_z ? 2 * hp.nxp : hp.nxp;
+    switch (op) {
+    case QG_PLAN_LAYOUT: name = hp.layout == LAYOUT_PAULI ? (hp.pauli_compact ? "PTILE-compact" : "PTILE") : layouts[hp.layout]; break;
+    case QG_PLAN_STEP: name = plan::step_kernel_name(plan::step_kernel_of(hp, 1, false, false, nonsymplectic != 0, num_actions, perms)); break;
+    case QG_PLAN_ROLLOUT_FUSED:
+        name = plan::step_kernel_name(plan::step_kernel_of(hp, (uint32_t)(arg ? arg : 1), true, true, nonsymplectic != 0, num_actions, perms));
+        break;
+    case QG_PLAN_RESET_DONE: {
+        const uint32_t draws = (uint32_t)cfg->difficulty, count = (uint32_t)arg;
+        if (hp.layout == LAYOUT_TILE) {
+            const bool coop = plan::reset_coop_allowed(false, batch, true);
+            name = plan::reset_path_name(plan::list_reset_path(count, draws, batch, coop, plan::tile_coop_fits(R, 4)));
+        } else if (hp.layout == LAYOUT_TILE64) {
+            const bool coop = plan::reset_coop_allowed(false, batch, true);
+            const plan::ResetPath rp = plan::list_reset_path(count, draws, batch, coop, true);
+            name = rp == plan::RP_TREE ? "scramble_tree64" : plan::reset_path_name(rp);
+        } else if (hp.layout == LAYOUT_PAULI) {
+            name = batch >= QG_COMPACT_MIN_ENVS ? "compact_done + ptile_generate_kernel" : "ptile_generate_kernel";
+        } else {
+            name = "init_kernel";
+        }
+        break;
+    }
+    case QG_PLAN_OBSERVE_DENSE:
+        if (hp.layout == LAYOUT_TILE) name = plan::export_kernel_name(plan::tile_export(QG_FMT_U8, hp.D, R, (uint64_t)hp.D * hp.D, true, true));
+        else if (hp.layout == LAYOUT_TILE64 || hp.layout == LAYOUT_LFD || hp.layout == LAYOUT_PAULI) name = plan::export_kernel_name(plan::EK_WORDS_THEN_EXPAND);
+        else name = plan::export_kernel_name(plan::EK_GENERIC);
+        break;
+    case QG_PLAN_OBSERVE_PACKED:
+        name = hp.layout == LAYOUT_TILE ? plan::export_kernel_name(plan::tile_export(QG_FMT_PACKED, hp.D, R, hp.D, true, true))
+               : hp.layout == LAYOUT_PAULI ? "ptile_rowwords_kernel" : plan::export_kernel_name(plan::EK_GENERIC);
+        break;
+    case QG_PLAN_STATE_I64:
+        name = (plan::entry_formats_stream(hp.layout, batch) || (hp.layout == LAYOUT_PAULI && batch >= QG_STREAM_MIN_ENVS)) ? "row words / bit stream + streaming kernel"
+                                                                                                                  : "init / export kernel";
+        break;
+    case QG_PLAN_TRACK_DENSE:
+        if (!plan::dense_trackable(hp)) return set_error(QG_ERR_UNSUPPORTED, "track_dense: matrices of 16 or 32 rows held as 32-bit row words");
+        name = plan::dense_rides_in_step(hp) ? "in-step" : "refresh";
+        break;
+    default: return set_error(QG_ERR_INVALID, "unknown plan op %d", op);
+    }
+    snprintf(name_out, cap, "%s", name);
+    return QG_OK;
 }
 
 int qg_vec_pauli_observe_dense(qg_vec *v, int8_t *out_dev, const int32_t *perm_idx_dev, void *stream) {

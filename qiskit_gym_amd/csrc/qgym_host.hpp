@@ -5,10 +5,9 @@
 #include <vector>
 
 #include "qgym_internal.hpp"
+#include "qgym_plan.hpp"
 
 namespace qg {
-
-enum Layout { LAYOUT_NONE = 0, LAYOUT_LF8 = 2, LAYOUT_PERM = 3, LAYOUT_PAULI = 4, LAYOUT_TILE = 5, LAYOUT_TILE64 = 6, LAYOUT_PERMB = 7, LAYOUT_LFD = 8 };
 
 struct GraphKey {
     const void *actions;
@@ -159,7 +158,6 @@ void fill_reset_done_args_public(const qg_vec *v, uint64_t seed, InitArgs &ia);
 void compute_qubit_and_action_perms(uint32_t N, const std::vector<qg_gate> &gates, std::vector<std::vector<int64_t>> &qubit_perms,
                                     std::vector<std::vector<int64_t>> &act_perms);
 // PauliEnv host hooks (pauli_host.cpp)
-int pauli_plan(qg_vec *v);
 int pauli_alloc(qg_vec *v);
 int pauli_init_identity(qg_vec *v, hipStream_t s);
 int pauli_set_state(qg_vec *v, const void *states, int format, size_t stride, int on_device, hipStream_t s);

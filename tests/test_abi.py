@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared
-    assert L.qg_abi_version() == 2
+    assert L.qg_abi_version() == 3
 
 
 def test_config_defaults_match_reference_constructors():
