@@ -671,8 +671,12 @@ struct MidHeadArgs {
     InitArgs reset;
 };
 
-template <uint32_t TILES>
-__global__ __launch_bounds__(64 * MH_WAVES, 2) void mid_head_sample_kernel(MidHeadArgs ma) {
+// TPW = env tiles per wave.  TPW = 1: two workgroups per CU (the second one's MFMA phase can run under the first one's draw).  TPW = 2: one
+// workgroup per CU whose waves carry two tiles each -- every weight fragment read from LDS feeds two MFMAs, and a tile pays half the chunk
+// barriers, staging instructions and LDS reads; the accumulators of both tiles (256 + 136 + 32 TILES registers at the widest point) need
+// the whole register file of a SIMD, i.e. one wave per SIMD.
+template <uint32_t TILES, uint32_t TPW>
+__global__ __launch_bounds__(64 * MH_WAVES, TPW == 1 ? 2 : 1) void mid_head_sample_kernel(MidHeadArgs ma) {
     __shared__ uint4 cbuf[2 * MH_CHUNK_VEC];
     const HeadArgs &a = ma.head;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -694,67 +698,90 @@ __global__ __launch_bounds__(64 * MH_WAVES, 2) void mid_head_sample_kernel(MidHe
     const uint32_t c = lane & 31u, h = lane >> 5;
     const uint64_t n_tiles = (a.B + 31u) / 32u;
     const uint64_t row_vec = a.ld_h / 8u;
-    const uint64_t tiles_per_trip = (uint64_t)gridDim.x * MH_WAVES;
+    const uint64_t tiles_per_trip = (uint64_t)gridDim.x * MH_WAVES * TPW;
     const uint4 ones = make_uint4(h == 0 ? 0x3F803F80u : 0u, 0u, 0u, 0u), zeros = make_uint4(0u, 0u, 0u, 0u);
     // every wave of the workgroup takes part in every trip (the chunk barriers): waves past the last tile compute on a clamped env
-    for (uint64_t tile0 = (uint64_t)blockIdx.x * MH_WAVES; tile0 < n_tiles; tile0 += tiles_per_trip) {
-        const uint64_t env_raw = (tile0 + wave) * 32u + c;
-        const bool live = env_raw < a.B;
-        const uint64_t env = live ? env_raw : a.B - 1;
-        const uint4 *hrow = a.h + env * row_vec + h;
+    for (uint64_t tile0 = (uint64_t)blockIdx.x * MH_WAVES * TPW; tile0 < n_tiles; tile0 += tiles_per_trip) {
+        bool live[TPW];
+        uint64_t env[TPW];
+        const uint4 *hrow[TPW];
+#pragma unroll
+        for (uint32_t p = 0; p < TPW; ++p) {
+            const uint64_t env_raw = (tile0 + wave * TPW + p) * 32u + c;
+            live[p] = env_raw < a.B;
+            env[p] = live[p] ? env_raw : a.B - 1;
+            hrow[p] = a.h + env[p] * row_vec + h;
+        }
         stage(0);
-        uint4 bq[MID_CHUNK], bn[MID_CHUNK];
+        uint4 bq[TPW][MID_CHUNK], bn[TPW][MID_CHUNK];
 #pragma unroll
-        for (uint32_t j = 0; j < MID_CHUNK; ++j) bq[j] = hrow[2u * j];
-        f32x16 x[MID_FT];
+        for (uint32_t p = 0; p < TPW; ++p)
 #pragma unroll
-        for (uint32_t t = 0; t < MID_FT; ++t)
+            for (uint32_t j = 0; j < MID_CHUNK; ++j) bq[p][j] = hrow[p][2u * j];
+        f32x16 x[TPW][MID_FT];
 #pragma unroll
-            for (uint32_t q = 0; q < 16; ++q) x[t][q] = 0.0f;
+        for (uint32_t p = 0; p < TPW; ++p)
+#pragma unroll
+            for (uint32_t t = 0; t < MID_FT; ++t)
+#pragma unroll
+                for (uint32_t q = 0; q < 16; ++q) x[p][t][q] = 0.0f;
         landed();
         for (uint32_t ch = 0; ch < n2; ++ch) {
             stage(ch + 1u);  // W2's next chunk, or the head's first; its buffer was last read in chunk ch - 1, which every wave has left
-            if (ch + 2u < n2) {
 #pragma unroll
-                for (uint32_t j = 0; j < MID_CHUNK; ++j) bn[j] = hrow[2u * ((ch + 1u) * MID_CHUNK + j)];
-            } else {
-                bn[0] = ones;
-                bn[1] = zeros;
+            for (uint32_t p = 0; p < TPW; ++p) {
+                if (ch + 2u < n2) {
+#pragma unroll
+                    for (uint32_t j = 0; j < MID_CHUNK; ++j) bn[p][j] = hrow[p][2u * ((ch + 1u) * MID_CHUNK + j)];
+                } else {
+                    bn[p][0] = ones;
+                    bn[p][1] = zeros;
+                }
             }
             const uint4 *al = cbuf + (ch & 1u) * MH_CHUNK_VEC + lane;
 #pragma unroll
             for (uint32_t j = 0; j < MID_CHUNK; ++j) {
-                const bf16x8 bf = __builtin_bit_cast(bf16x8, bq[j]);
 #pragma unroll
-                for (uint32_t t = 0; t < MID_FT; ++t)
-                    x[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[(j * MID_FT + t) * 64u]), bf, x[t], 0, 0, 0);
+                for (uint32_t t = 0; t < MID_FT; ++t) {
+                    const bf16x8 af = __builtin_bit_cast(bf16x8, al[(j * MID_FT + t) * 64u]);  // one LDS read, TPW MFMAs
+#pragma unroll
+                    for (uint32_t p = 0; p < TPW; ++p)
+                        x[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bq[p][j]), x[p][t], 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (uint32_t j = 0; j < MID_CHUNK; ++j) bq[j] = bn[j];
+            for (uint32_t p = 0; p < TPW; ++p)
+#pragma unroll
+                for (uint32_t j = 0; j < MID_CHUNK; ++j) bq[p][j] = bn[p][j];
             landed();
         }
         // ReLU, bf16: the tiles become the head's B fragments, registers 8s..8s+7 of tile t = k-step 2t + s; k-step 16 = bias
-        bf16x8 hb[2u * MID_FT + 1u];
+        bf16x8 hb[TPW][2u * MID_FT + 1u];
 #pragma unroll
-        for (uint32_t t = 0; t < MID_FT; ++t) {
+        for (uint32_t p = 0; p < TPW; ++p) {
 #pragma unroll
-            for (uint32_t s = 0; s < 2; ++s) {
-                u32x4 f;
+            for (uint32_t t = 0; t < MID_FT; ++t) {
 #pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {
-                    const f32x2 v = {__builtin_amdgcn_fmed3f(x[t][8u * s + 2u * j], 0.0f, __builtin_inff()),
-                                     __builtin_amdgcn_fmed3f(x[t][8u * s + 2u * j + 1u], 0.0f, __builtin_inff())};
-                    f[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+                for (uint32_t s = 0; s < 2; ++s) {
+                    u32x4 f;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        const f32x2 v = {__builtin_amdgcn_fmed3f(x[p][t][8u * s + 2u * j], 0.0f, __builtin_inff()),
+                                         __builtin_amdgcn_fmed3f(x[p][t][8u * s + 2u * j + 1u], 0.0f, __builtin_inff())};
+                        f[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+                    }
+                    hb[p][2u * t + s] = __builtin_bit_cast(bf16x8, f);
                 }
-                hb[2u * t + s] = __builtin_bit_cast(bf16x8, f);
             }
+            hb[p][2u * MID_FT] = __builtin_bit_cast(bf16x8, ones);
         }
-        hb[2u * MID_FT] = __builtin_bit_cast(bf16x8, ones);
-        f32x16 acc[TILES];
+        f32x16 acc[TPW][TILES];
 #pragma unroll
-        for (uint32_t t = 0; t < TILES; ++t)
+        for (uint32_t p = 0; p < TPW; ++p)
 #pragma unroll
-            for (uint32_t q = 0; q < 16; ++q) acc[t][q] = 0.0f;
+            for (uint32_t t = 0; t < TILES; ++t)
+#pragma unroll
+                for (uint32_t q = 0; q < 16; ++q) acc[p][t][q] = 0.0f;
         // the head: fragment f = k-step (f / TILES) x action tile (f % TILES), 16 fragments per streamed chunk
 #pragma unroll
         for (uint32_t hc = 0; hc < HEAD_CHUNKS; ++hc) {
@@ -763,25 +790,32 @@ __global__ __launch_bounds__(64 * MH_WAVES, 2) void mid_head_sample_kernel(MidHe
 #pragma unroll
             for (uint32_t i = 0; i < MH_CHUNK_FRAGS; ++i) {
                 const uint32_t f = hc * MH_CHUNK_FRAGS + i;
-                if (f < HEAD_FRAGS)
-                    acc[f % TILES] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i * 64u]), hb[f / TILES], acc[f % TILES], 0, 0, 0);
+                if (f < HEAD_FRAGS) {
+                    const bf16x8 af = __builtin_bit_cast(bf16x8, al[i * 64u]);
+#pragma unroll
+                    for (uint32_t p = 0; p < TPW; ++p)
+                        acc[p][f % TILES] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, hb[p][f / TILES], acc[p][f % TILES], 0, 0, 0);
+                }
             }
             landed();  // after the last chunk: every wave is done with both buffers before the next trip stages chunk 0
         }
-        const int64_t act = head_draw<TILES>(acc, a, env, live, h);
-        if (ma.step.state) {  // wave-uniform
-            bool fin = false;
-            if (live && h == 0)
-                fin = ma.step_has_z ? qm_step1_body<true, true>(ma.step, ma.step_groups, env, act) : qm_step1_body<false, true>(ma.step, ma.step_groups, env, act);
-            // compact_done (kernels_collect.hip) for this wave's 32 envs: one atomic per wave with a finished env
-            const uint64_t m = __ballot(fin);
-            if (m) {
-                const uint32_t first = (uint32_t)__ffsll((long long)m) - 1u;
-                uint32_t base = 0;
-                if (lane == first) base = atomicAdd(ma.done_count, (uint32_t)__popcll(m));
-                base = __shfl(base, first);
-                const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (fin && slot < ma.step.B) ma.done_list[slot] = (uint32_t)env;
+#pragma unroll
+        for (uint32_t p = 0; p < TPW; ++p) {
+            const int64_t act = head_draw<TILES>(acc[p], a, env[p], live[p], h);
+            if (ma.step.state) {  // wave-uniform
+                bool fin = false;
+                if (live[p] && h == 0)
+                    fin = ma.step_has_z ? qm_step1_body<true, true>(ma.step, ma.step_groups, env[p], act) : qm_step1_body<false, true>(ma.step, ma.step_groups, env[p], act);
+                // compact_done (kernels_collect.hip) for this wave's 32 envs: one atomic per wave with a finished env
+                const uint64_t m = __ballot(fin);
+                if (m) {
+                    const uint32_t first = (uint32_t)__ffsll((long long)m) - 1u;
+                    uint32_t base = 0;
+                    if (lane == first) base = atomicAdd(ma.done_count, (uint32_t)__popcll(m));
+                    base = __shfl(base, first);
+                    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (fin && slot < ma.step.B) ma.done_list[slot] = (uint32_t)env[p];
+                }
             }
         }
     }
@@ -1668,6 +1702,22 @@ static bool mid_head_is_small(uint64_t batch, uint32_t in_features, int cus) {
     return (batch + 31u) / 32u <= (uint64_t)cus && in_features % (16u * MHS_GROUP) == 0 && in_features <= 16u * MHS_KMAX;
 }
 
+// mid_head_sample_kernel with two env tiles per wave (one 256-env workgroup per CU): built and measured in round 4 -- bit-identical
+// (tests/test_gpu_collect_ops.py, test_gpu_collector.py) and 2.5x SLOWER (92.9 against 36.5 us at 65 536 envs; collector 159 against 104 us
+// per step): at one wave per SIMD nothing covers a chunk's memory round trip (every chunk ends in s_waitcnt vmcnt(0) + barrier with the
+// activation prefetch and the next chunk's staging in flight, and the 32 MFMAs of a chunk are shorter than that trip), and the two tiles'
+// accumulators (256 AGPRs + 256 VGPRs) leave the draw 266 spilled registers (profiles/r04/mid_head_two_tiles.txt).  Kept behind a
+// development build flag (tools/build_variant.sh two_tiles kernels_policy.hip -DQG_MID_HEAD_TWO_TILES); the product uses one tile per wave.
+static bool mid_head_two_tiles(uint64_t batch, int cus) {
+#ifdef QG_MID_HEAD_TWO_TILES
+    return batch >= 256ull * (uint64_t)cus;
+#else
+    (void)batch;
+    (void)cus;
+    return false;
+#endif
+}
+
 static int mid_head_impl(const void *h_dev, uint64_t ld_h, uint64_t batch, uint32_t in_features, const void *packed_mid_dev, uint32_t mid_features,
                          const void *packed_head_dev, uint32_t num_actions, uint64_t seed, uint64_t counter, const uint64_t *clock_dev, void *actions_dev,
                          int action_dtype, float *logp_dev, float *entropy_dev, float *values_dev, qg_vec *step_of, float *step_rewards,
@@ -1742,10 +1792,22 @@ static int mid_head_impl(const void *h_dev, uint64_t ld_h, uint64_t batch, uint3
         if (step_of && !reset_in_kernel) done_list_appended(step_of, trusted);
         return QG_OK;
     }
-    const uint64_t resident = 2ull * (uint64_t)cus;  // two workgroups per CU (32 KiB of LDS and 256 registers x 4 waves each)
-    const dim3 grid((unsigned)(want < resident ? want : resident)), block(64 * MH_WAVES);
-#define QG_MH_CASE(TT)                                                        \
-    case TT: hipLaunchKernelGGL(mid_head_sample_kernel<TT>, grid, block, 0, s, m); break;
+    // two tiles per wave (one workgroup of 256 envs per CU) once the batch gives every CU such a workgroup; below that, one tile per wave, two
+    // workgroups per CU (32 KiB of LDS and 256 registers x 4 waves each)
+    const bool two = mid_head_two_tiles(batch, cus);
+    const uint64_t per_wg = two ? 2ull * MH_WAVES : (uint64_t)MH_WAVES, want_wg = (env_tiles + per_wg - 1) / per_wg;
+    const uint64_t resident = two ? (uint64_t)cus : 2ull * (uint64_t)cus;
+    const dim3 grid((unsigned)(want_wg < resident ? want_wg : resident)), block(64 * MH_WAVES);
+#ifdef QG_MID_HEAD_TWO_TILES
+#define QG_MH_CASE(TT)                                                                                   \
+    case TT:                                                                                             \
+        if (two) hipLaunchKernelGGL((mid_head_sample_kernel<TT, 2>), grid, block, 0, s, m);              \
+        else hipLaunchKernelGGL((mid_head_sample_kernel<TT, 1>), grid, block, 0, s, m);                  \
+        break;
+#else
+#define QG_MH_CASE(TT)                                                                                   \
+    case TT: hipLaunchKernelGGL((mid_head_sample_kernel<TT, 1>), grid, block, 0, s, m); break;
+#endif
     switch (tiles) {
         QG_MH_CASE(1) QG_MH_CASE(2) QG_MH_CASE(3) QG_MH_CASE(4) QG_MH_CASE(5) QG_MH_CASE(6) QG_MH_CASE(7)
     default: return set_error(QG_ERR_UNSUPPORTED, "too many actions for the fused head");
