@@ -514,8 +514,12 @@ typedef enum {
 int qg_plan_query(const qg_config *cfg, uint64_t batch, uint32_t num_actions, int op, uint64_t arg, int nonsymplectic, char *name_out, size_t cap);
 
 /* ------------------------------------------------------------------------------------------
- * Scalar environment: the `Env` trait method for method (clifford.rs:285-382).
- * Every call synchronises; this flavour exists for API parity, not for speed.
+ * Scalar environment: the `Env` trait method for method (clifford.rs:285-382): a batch of one on the same kernels.  A call that changes the
+ * state costs one kernel launch and one stream synchronisation (its results land in a pinned block the getters read as plain loads); this
+ * flavour exists for API parity -- throughput comes from qg_vec_* (README: 4.6e4 env-steps/s per host thread against 1e10 batched).
+ * qg_env_destroy parks the handle (device buffers, stream, pinned block) in a process-wide pool for the next qg_env_clone of an env with
+ * the same constructor arguments -- at most 64 per configuration, 256 in all; beyond that it frees.  qg_env_pool_clear releases the pool
+ * (call it at teardown, or when a configuration will not be cloned again).
  * ---------------------------------------------------------------------------------------- */
 typedef struct qg_env qg_env;
 
@@ -524,6 +528,7 @@ int qg_env_clone(const qg_env *e, qg_env **out); /* Env: DynClone */
 /* seed of the env's own RNG streams (see qg_vec_set_seed); a clone starts with its source's seed and counters */
 int qg_env_set_seed(qg_env *e, uint64_t seed);
 void qg_env_destroy(qg_env *e);
+void qg_env_pool_clear(void);
 int64_t qg_env_num_actions(const qg_env *e);
 int qg_env_obs_shape(const qg_env *e, int64_t out[2]);
 int qg_env_set_difficulty(qg_env *e, int64_t d);

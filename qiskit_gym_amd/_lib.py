@@ -97,7 +97,7 @@ EXPORTED_SYMBOLS = [
     "qg_comm_rank", "qg_comm_world", "qg_vec_gather_learner_shard", "qg_comm_gather_submit", "qg_comm_gather_flush", "qg_comm_gather_latest",
     "qg_comm_p2p_connect", "qg_comm_p2p_export", "qg_comm_p2p_open", "qg_vec_push_learner_shard", "qg_comm_p2p_wait", "qg_comm_p2p_release",
     "qg_comm_p2p_check", "qg_comm_p2p_reset", "qg_plan_query",
-    "qg_env_create", "qg_env_clone", "qg_env_set_seed", "qg_env_destroy", "qg_env_num_actions", "qg_env_obs_shape",
+    "qg_env_create", "qg_env_clone", "qg_env_set_seed", "qg_env_destroy", "qg_env_pool_clear", "qg_env_num_actions", "qg_env_obs_shape",
     "qg_env_set_difficulty", "qg_env_get_difficulty", "qg_env_set_state", "qg_env_reset", "qg_env_step",
     "qg_env_step_coin", "qg_env_masks", "qg_env_is_final", "qg_env_reward", "qg_env_success", "qg_env_observe",
     "qg_env_track_solution", "qg_env_solution", "qg_env_twists",
@@ -218,6 +218,8 @@ def load():
     L.qg_env_clone.argtypes = [vp, C.POINTER(vp)]
     L.qg_env_destroy.argtypes = [vp]
     L.qg_env_destroy.restype = None
+    L.qg_env_pool_clear.argtypes = []
+    L.qg_env_pool_clear.restype = None
     L.qg_env_num_actions.argtypes = [vp]
     L.qg_env_num_actions.restype = i64
     L.qg_env_obs_shape.argtypes = [vp, C.POINTER(i64)]

@@ -538,6 +538,13 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
         if (rc) return fail(rc);
     }
 
+    // observe_dense of the 64-bit-row / lane-group / PauliEnv layouts goes through row words in the handle's scratch buffer: sized here, so
+    // that the call never allocates (it may be made inside a stream capture)
+    if (v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_LFD || v->layout == LAYOUT_PAULI) {
+        const size_t word = (v->layout == LAYOUT_LFD && !v->w64) ? 4 : 8;
+        int rc = ensure_scratch(p, (size_t)batch * v->D * word);
+        if (rc) return fail(rc);
+    }
     // constructor state: identity, depth 1, success, reward 1.0 (clifford.rs:214-245)
     if (v->layout == LAYOUT_PAULI) {
         int rc = pauli_init_identity(p, nullptr);
@@ -912,14 +919,23 @@ int qg_vec_step(qg_vec *v, const void *actions_dev, int action_dtype, const uint
     return QG_OK;
 }
 
-// the device's view of a pinned, mapped host pointer; nullptr for pageable memory (and for anything the runtime does not know)
-static void *mapped_view(const void *host_ptr) {
+// the device's view of `bytes` of pinned, mapped host memory; nullptr for pageable memory, for anything the runtime does not know, and for a
+// mapping that does not cover the whole range
+static void *mapped_view(const void *host_ptr, size_t bytes) {
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, host_ptr) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
-    return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
+    if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)at.devicePointer) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    const uintptr_t lo = (uintptr_t)at.devicePointer, end = (uintptr_t)base + size;
+    return (lo + bytes <= end) ? at.devicePointer : nullptr;
 }
 
 int qg_vec_step_host(qg_vec *v, const void *actions_host, int action_dtype, const uint8_t *coins_host, float *rewards_host, uint8_t *dones_host,
@@ -930,10 +946,14 @@ int qg_vec_step_host(qg_vec *v, const void *actions_host, int action_dtype, cons
     hipStream_t s = (hipStream_t)stream;
     {   // pinned, device-mapped buffers (hipHostMalloc / hipHostRegister): the step reads the actions where they are and one small kernel
         // writes the outputs where they go -- two launches, no copy engine (four copies of <= 256 KiB cost ~13 us of latency each)
-        void *act_m = mapped_view(actions_host), *coin_m = coins_host ? mapped_view(coins_host) : nullptr;
-        void *rew_m = rewards_host ? mapped_view(rewards_host) : nullptr, *done_m = dones_host ? mapped_view(dones_host) : nullptr,
-             *suc_m = success_host ? mapped_view(success_host) : nullptr;
-        const bool aligned = !(((uintptr_t)rew_m | (uintptr_t)done_m | (uintptr_t)suc_m) & 15u);
+        const size_t act_bytes_m = (action_dtype == QG_ACT_I64 ? 8 : 4) * v->B;
+        void *act_m = mapped_view(actions_host, act_bytes_m), *coin_m = coins_host ? mapped_view(coins_host, v->B) : nullptr;
+        void *rew_m = rewards_host ? mapped_view(rewards_host, sizeof(float) * v->B) : nullptr, *done_m = dones_host ? mapped_view(dones_host, v->B) : nullptr,
+             *suc_m = success_host ? mapped_view(success_host, v->B) : nullptr;
+        // step_outputs_kernel moves 16 bytes of rewards and 4 bytes of flags per thread: destinations AND sources (the handle's output arrays
+        // may be bound to caller memory of any alignment, qg_vec_bind_outputs) must allow it, else the copies below do the job
+        const bool aligned = !(((uintptr_t)rew_m | (uintptr_t)done_m | (uintptr_t)suc_m) & 15u) && !((uintptr_t)v->reward & 15u) &&
+                             !(((uintptr_t)v->done | (uintptr_t)v->success) & 3u);
         if (act_m && (!coins_host || coin_m) && (!rewards_host || rew_m) && (!dones_host || done_m) && (!success_host || suc_m) && aligned) {
             if (int rc = qg_vec_step(v, act_m, action_dtype, (const uint8_t *)coin_m, stream)) return rc;
             HIP_TRY(step_outputs(v->reward, v->done, v->success, (float *)rew_m, (uint8_t *)done_m, (uint8_t *)suc_m, v->B, s));

@@ -188,6 +188,8 @@ namespace {
 std::mutex g_pool_mutex;
 std::vector<qg_env *> g_pool;            // destroyed envs kept for the next clone
 constexpr size_t POOL_CAP = 256;         // a few per host thread (rl/configs.py:135 num_cores = 32); beyond it destroy() frees
+constexpr size_t POOL_CAP_PER_KEY = 64;  // ... and at most this many with the same constructor arguments (a trainer that destroys thousands of
+                                         // clones of one prototype does not push every other configuration's handles out, nor pin 256 of its own)
 
 bool same_ctor(const qg_vec *a, const qg_vec *b) {
     return a->device == b->device && memcmp(&a->cfg, &b->cfg, sizeof a->cfg) == 0 && a->gates.size() == b->gates.size() &&
@@ -280,12 +282,23 @@ void qg_env_destroy(qg_env *e) {
     if (!e) return;
     {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
-        if (g_pool.size() < POOL_CAP) {  // kept for the next clone of an env built with the same arguments
+        size_t same = 0;
+        for (const qg_env *p : g_pool) same += same_ctor(p->v, e->v) ? 1 : 0;
+        if (g_pool.size() < POOL_CAP && same < POOL_CAP_PER_KEY) {  // kept for the next clone of an env built with the same arguments
             g_pool.push_back(e);
             return;
         }
     }
     env_free(e);
+}
+
+void qg_env_pool_clear(void) {
+    std::vector<qg_env *> drained;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        drained.swap(g_pool);
+    }
+    for (qg_env *e : drained) env_free(e);
 }
 
 int qg_env_clone(const qg_env *e, qg_env **out) {  // Env: DynClone -- deep copy of every resident buffer
@@ -314,7 +327,20 @@ int qg_env_clone(const qg_env *e, qg_env **out) {  // Env: DynClone -- deep copy
     d->maybe_nonsymplectic = s->maybe_nonsymplectic;
     d->observe_counter = s->observe_counter;
     d->env_base = s->env_base;
+    // a handle from the pool carries its previous owner's host-side session state: everything a fresh handle starts with, it starts with
     d->auto_list = d->done_list_fresh = false;
+    d->list_zero_known = false;  // (unknown is always safe: the next appending launch zeroes the length first)
+    d->list_tainted = false;
+    d->list_session = 0;
+    d->perm_draw = false;
+    d->perm_in = nullptr;
+    d->clock_dev = s->clock_dev;
+    d->dense = nullptr;
+    for (auto &g : d->graphs) {  // cached rollout graphs have the previous owner's pointers and counters baked in
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    d->graphs.clear();
     struct { void *dst; const void *src; size_t bytes; } copies[] = {
         {d->state, s->state, s->state_bytes},
         {d->depth, s->depth, 4},

@@ -63,6 +63,11 @@ class RawEnv:
         except Exception:
             pass
 
+    @staticmethod
+    def release_pool():
+        """Free the handles that destroyed envs left in the process-wide clone pool (`qg_env_pool_clear`)."""
+        _lib.load().qg_env_pool_clear()
+
     def clone(self, seed: Optional[int] = None) -> "RawEnv":
         """Deep copy of the state (Env: DynClone).  The clone's FUTURE random draws (reset scramble, add_inverts coins,
         PauliEnv permutations) are its own, as with the reference's thread_rng, unless `seed` pins them."""

@@ -16,3 +16,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _release_scalar_env_pool():
+    """qg_env_destroy parks handles in a process-wide pool for the next clone; the suite hands them back at the end (qg_env_pool_clear)."""
+    yield
+    try:
+        from qiskit_gym_amd import _lib
+
+        if _lib._lib is not None:
+            _lib._lib.qg_env_pool_clear()
+    except Exception:
+        pass

@@ -194,3 +194,29 @@ def test_twists_are_symmetries_of_the_dynamics(kind, n, edges):
             assert dense(twin).tolist() == relabel(dense(probe)).tolist(), (kind, k, a)
             # same gate cost (the solved bonus may differ: set_state gives the twin max_depth, not the probe's depth)
             assert twin.success() == probe.success()
+
+
+def test_destroyed_envs_are_pooled_for_clones_and_the_pool_can_be_released():
+    """qg_env_destroy parks a handle for the next clone of the same configuration (<= 64 per configuration); a clone taken from the pool
+    starts from its source's state whatever its previous owner did, and qg_env_pool_clear hands everything back."""
+    from qiskit_gym_amd.envs.raw import RawEnv
+
+    gs = line_gateset("clifford", 4)
+    proto = RawEnv("clifford", 4, gs, add_inverts=False, add_perms=False, track_solution=True, difficulty=6, seed=3)
+    proto.reset()
+    scratch = [proto.clone() for _ in range(70)]
+    for i, c in enumerate(scratch):  # their previous lives differ
+        for a in range(i % 5):
+            c.step(a)
+    del scratch, c  # 70 destroyed handles: 64 parked, the rest freed
+    want = (proto.observe(), proto.reward(), proto.is_final(), proto.solution())
+    clones = [proto.clone() for _ in range(66)]  # 64 from the pool, two fresh
+    for c in clones:
+        assert (c.observe(), c.reward(), c.is_final(), c.solution()) == want
+        c.step(1)
+    proto.step(1)
+    assert clones[0].observe() == proto.observe() and clones[-1].observe() == proto.observe()
+    del clones
+    RawEnv.release_pool()
+    again = proto.clone()  # the pool is empty: a fresh handle, same answer
+    assert again.observe() == proto.observe()
