@@ -892,6 +892,25 @@ def main():
         us_dense = graph_of(steps_with(oenv, lambda: oenv.observe(out=obs_d)))
         us_kernel = graph_of(lambda: [oenv.observe(out=obs_d) for _ in range(OT)])
         us_tracked = graph_of(steps_with(tenv, lambda: None))
+        # ... and with the reference's default options (add_inverts=True, track_solution=True; coins given): the two-lanes-per-env step rewrites
+        # an env's whole observation when its coin inverts the matrix (half of the envs per step), the gate's rows otherwise
+        denv2 = VecEnv("clifford", n, gateset, B, add_inverts=True, add_perms=False, track_solution=True, difficulty=SCRAMBLE, max_depth=7 * OT)
+        dcoins = torch.randint(0, 2, (RING, B), dtype=torch.uint8, device=dev, generator=gen)
+        with torch.cuda.stream(stream):
+            denv2.reset(seed)
+            tracked2 = denv2.track_dense()
+
+        def default_steps():
+            for t in range(OT):
+                denv2.step(actions[t % RING], dcoins[t % RING])
+
+        us_tracked_default = graph_of(default_steps)
+        denv2.sync()
+        with torch.cuda.stream(stream):
+            same2 = bool(torch.equal(tracked2, denv2.observe()))
+        if not same2:
+            raise SystemExit("bench.py: the tracked dense observation (reference-default options) differs from a full rewrite of the same state")
+        del denv2, tracked2, dcoins
         oenv.sync()
         tenv.sync()
         with torch.cuda.stream(stream):
@@ -931,6 +950,10 @@ def main():
                                        "move (it may exceed 1); frac_moved on the bytes it has to move"),
                                   bytes_moved_per_env_step=NEEDED_BYTES_PER_STEP + 64,
                                   frac_moved=(NEEDED_BYTES_PER_STEP + 64) * B / (us_tracked * 1e-6) / 1e9 / HBM_PEAK_GBS),
+            "dense_tracked_reference_defaults": {
+                "us_per_step": us_tracked_default, "value": B / (us_tracked_default * 1e-6), "unit": "env-steps/s",
+                "what": "qg_vec_track_dense with add_inverts=True, track_solution=True (coins given): qm_inv2_kernel rewrites the whole env when its coin fires "
+                        "(wave-contiguous 1 KiB stores), the gate's rows otherwise; equals a full rewrite of the final state (checked)"},
             "dense_kernel": {"kernel": "qg::qm_dense_stream_kernel<2>", "us_per_launch": us_kernel, "bytes_written_per_launch": D2 * B,
                              "roofline": {"bound": "hbm", "achieved": D2 * B / (us_kernel * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": D2 * B / (us_kernel * 1e-6) / 1e9 / HBM_PEAK_GBS},

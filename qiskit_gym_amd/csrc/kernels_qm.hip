@@ -466,17 +466,21 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
 // renaming into one v_perm_b32 per word.  ~150 instructions per lane instead of ~600 per env.
 // States that are not known to be symplectic (set_state of an arbitrary matrix) keep the thread-per-env Gauss-Jordan variant.
 // ------------------------------------------------------------------------------------------
-template <int NXP, bool FEAT, bool LIST = false>
+template <int NXP, bool FEAT, bool LIST = false, bool DENSE = false>
 __global__ __launch_bounds__(256) void qm_inv2_kernel(StepArgs a) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t dense_rows[DENSE ? 4 : 1][DENSE ? 32 * 33 : 1];  // DENSE: the inverted envs' rows, [env of the wave][row], pitch 33
+    uint32_t *dl = DENSE ? dense_rows[threadIdx.x >> 6] : nullptr;
     QG_PREFETCH_STEP_ARGS(a);
-    if constexpr (LIST) {  // every thread reaches the workgroup-wide append; whole lane pairs are in or out together
+    bool whole = false;  // DENSE: this lane's env was inverted, its rows are parked in dl
+    if constexpr (LIST || DENSE) {  // every thread reaches the workgroup-wide append / the wave-wide rewrite; whole lane pairs are in or out together
         bool fin = false;
-        if ((tid >> 1) < a.B) fin = qm_inv2_body<NXP / 2, FEAT>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr);  // qm_step1.hpp
-        done_list_append_block(a.done_list, a.done_count, fin && !(tid & 1u), tid >> 1, a.B);
+        if ((tid >> 1) < a.B) fin = qm_inv2_body<NXP / 2, FEAT, DENSE>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr, dl, &whole);  // qm_step1.hpp
+        if constexpr (DENSE) qm_inv2_dense_flush(a.dense, dl, (tid - (threadIdx.x & 63u)) >> 1, whole);
+        if constexpr (LIST) done_list_append_block(a.done_list, a.done_count, fin && !(tid & 1u), tid >> 1, a.B);
     } else {
         if ((tid >> 1) >= a.B) return;  // whole lane pairs leave together
-        (void)qm_inv2_body<NXP / 2, FEAT>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr);  // qm_step1.hpp
+        (void)qm_inv2_body<NXP / 2, FEAT, DENSE>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr, dl, &whole);  // qm_step1.hpp
     }
 }
 
@@ -899,6 +903,15 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
     case plan::SK_QM_INV2:  // CliffordEnv with add_inverts, every env symplectic, one step per launch: two lanes per env
         if constexpr (HAS_Z && NXP <= 16) {
             const dim3 grid2(grid_for(2 * a.B, 256));
+            if constexpr (NXP == 16) {
+                if (a.dense) {  // qg_vec_track_dense (N = 16)
+                    if (feat && list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true, true, true>), grid2, block, 0, s, a);
+                    else if (feat) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true, false, true>), grid2, block, 0, s, a);
+                    else if (list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, false, true, true>), grid2, block, 0, s, a);
+                    else hipLaunchKernelGGL((qm_inv2_kernel<NXP, false, false, true>), grid2, block, 0, s, a);
+                    return hipGetLastError();
+                }
+            }
             if (feat && list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true, true>), grid2, block, 0, s, a);
             else if (feat) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true>), grid2, block, 0, s, a);
             else if (list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, false, true>), grid2, block, 0, s, a);

@@ -395,7 +395,12 @@ static plan::HandlePlan plan_of(const qg_vec *v) {  // the handle's fields that 
     hp.pauli_compact = v->pt_nq <= 24 && v->pt_rm == 8;
     return hp;
 }
-static bool dense_rides_in_step(const qg_vec *v) { return v->dense && plan::dense_rides_in_step(plan_of(v)); }
+// env.step() (one step per launch) of this handle keeps the tracked observation current itself
+static bool dense_rides_in_step(const qg_vec *v) {
+    if (!v->dense) return false;
+    const plan::HandlePlan hp = plan_of(v);
+    return plan::dense_in_kernel(hp, plan::step_kernel_of(hp, 1, false, false, v->maybe_nonsymplectic, (uint32_t)v->gates.size(), false));
+}
 static int dense_refresh(qg_vec *v, hipStream_t s);
 
 int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, uint64_t batch, int device, qg_vec **out) {

@@ -256,7 +256,14 @@ inline bool dense_trackable(const HandlePlan &p) {
     const uint32_t R = p.has_z ? 2 * p.nxp : p.nxp;
     return p.layout == LAYOUT_TILE && p.D == R && (p.D == 16 || p.D == 32);
 }
-inline bool dense_rides_in_step(const HandlePlan &p) { return dense_trackable(p) && p.has_bad && !(p.flags & F_INVERTS); }
+// ... which step kernels rewrite the rows they changed themselves: the one-step kernel without add_inverts, and CliffordEnv 16q's
+// two-lanes-per-env kernel (whole env when the coin inverted it); every other launch is followed by a full rewrite
+inline bool dense_in_kernel(const HandlePlan &p, StepKernel k) {
+    return dense_trackable(p) && (k == SK_QM_STEP1 || (k == SK_QM_INV2 && p.has_z && p.D == 32));
+}
+inline bool dense_rides_in_step(const HandlePlan &p) {  // env.step() on a handle whose states are known to be symplectic
+    return dense_in_kernel(p, step_kernel_of(p, 1, false, false, false, 1, false));
+}
 
 }  // namespace plan
 }  // namespace qg

@@ -143,6 +143,22 @@ __device__ inline bool qm_step1_body(const StepArgs &a, uint32_t G, uint64_t env
 }
 
 
+// qg_vec_track_dense with add_inverts (N = 16): the envs of this wave whose matrix was inverted in this step, one after the other -- every lane
+// writes its 16 bytes of the env's contiguous 1 KiB from the rows qm_inv2_body parked in `dense_lds` ([env of the wave][row], pitch 33).
+// Call from all 64 lanes; `env0` = the wave's first env, `whole` false on lanes without an env.
+__device__ inline void qm_inv2_dense_flush(int8_t *dense, const uint32_t *dense_lds, uint64_t env0, bool whole) {
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint64_t todo = __ballot(whole && !(lane & 1u));  // bit 2 * slot per inverted env of this wave
+    while (todo) {  // wave-uniform
+        const uint32_t sl = ((uint32_t)__ffsll((long long)todo) - 1u) >> 1;
+        todo &= todo - 1ull;
+        const uint32_t w = dense_lds[sl * 33u + (lane >> 1)];
+        reinterpret_cast<uint4 *>(dense + (env0 + sl) * 1024u)[lane] = expand16_i8(w >> (16u * (lane & 1u)));
+    }
+}
+
 // ---- the reference-default step of CliffordEnv N <= 16 (add_inverts), two lanes per env: see kernels_qm.hip for the discussion ----
 #define QM_FLAG_INVERTED 1u
 #define QM_FLAG_SYMPLECTIC 2u
@@ -170,8 +186,14 @@ __device__ inline uint32_t qm_pair_swap(uint32_t v) {  // the partner lane's val
 // GS: the env's 16-byte groups (two qubits each) as a compile-time constant, or 0: `groups` at run time (the policy kernel).
 // `env`, `h`: this lane's env and half (lanes 2e, 2e + 1 of a wave hold env e); `act`: the env's action, or null: load it from a.actions.
 // Returns is_final (on both lanes).
-template <int GS, bool FEAT>
-__device__ inline bool qm_inv2_body(const StepArgs &a, uint32_t groups, uint64_t env, uint32_t h, const int64_t *act_in) {
+// DENSE (qg_vec_track_dense, N = 16): `dense_lds` = 32 x 33 words of LDS owned by this wave; the env's dense int8 observation follows the step --
+// the whole 1 KiB when the coin inverted the matrix (the wave's inverted envs one after the other, every lane 16 bytes of a contiguous 1 KiB),
+// else the rows of the gate's qubits.
+// The whole-env part needs all 64 lanes of the wave: the body only parks the rows (and reports `whole`), the kernel calls qm_inv2_dense_flush
+// from EVERY lane afterwards, the ones past the batch's end included.
+template <int GS, bool FEAT, bool DENSE = false>
+__device__ inline bool qm_inv2_body(const StepArgs &a, uint32_t groups, uint64_t env, uint32_t h, const int64_t *act_in, uint32_t *dense_lds = nullptr,
+                                    bool *dense_whole = nullptr) {
     const int G = GS ? GS : (int)groups;
     const uint32_t N = a.N;
     uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(G * 64) + (env & 63u);
@@ -205,9 +227,9 @@ __device__ inline bool qm_inv2_body(const StepArgs &a, uint32_t groups, uint64_t
 
     // ---- apply_gate_to_state (clifford.rs:331): the 4x4 GF(2) map on {X[q0], Z[q0], X[q1], Z[q1]} --------------------------
     uint32_t dirty = 0;  // this lane's groups that changed (bit k: group 4h + k)
+    const uint32_t q0 = g.ops & 31u, q1 = (g.ops >> 5) & 31u, m = (g.ops >> 10) & 0xFFFFu;
+    const bool own0 = (q0 >> 3) == h, own1 = (q1 >> 3) == h;
     {
-        const uint32_t q0 = g.ops & 31u, q1 = (g.ops >> 5) & 31u, m = (g.ops >> 10) & 0xFFFFu;
-        const bool own0 = (q0 >> 3) == h, own1 = (q1 >> 3) == h;
         uint32_t x0 = own0 ? tree_select<8>(xs, q0 & 7u) : 0u, z0 = own0 ? tree_select<8>(zs, q0 & 7u) : 0u;
         uint32_t x1 = own1 ? tree_select<8>(xs, q1 & 7u) : 0u, z1 = own1 ? tree_select<8>(zs, q1 & 7u) : 0u;
         x0 |= qm_pair_swap(x0); z0 |= qm_pair_swap(z0);  // the lane that does not own the qubit contributes zero
@@ -316,6 +338,28 @@ __device__ inline bool qm_inv2_body(const StepArgs &a, uint32_t groups, uint64_t
     for (int k = 0; k < 4; ++k)
         if (((dirty >> k) & 1u) && k < G && (h == 0 || k + 4 < G))
             tile[(uint32_t)(4 * h + k) * 64u] = make_uint4(xs[2 * k], zs[2 * k], xs[2 * k + 1], zs[2 * k + 1]);
+    if constexpr (DENSE) {  // N = 16: matrix row r of env e at dense[(e * 32 + r) * 32] (clifford.rs:361-368, adapters.py:50-54)
+        const uint32_t lane = threadIdx.x & (QG_WAVE - 1), slot = lane >> 1;
+        const bool whole = dirty == 0xFu;  // the inversion rewrote every row (both lanes of the pair agree)
+        if (whole) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                dense_lds[slot * 33u + 8u * h + (uint32_t)j] = xs[j];
+                dense_lds[slot * 33u + 16u + 8u * h + (uint32_t)j] = zs[j];
+            }
+        }
+        *dense_whole = whole;
+        if (!whole && m != QM_IDENTITY) {  // the gate's rows only (this lane's share of them)
+            if (own0) {
+                dense_row_store<2>(a.dense, env, q0, tree_select<8>(xs, q0 & 7u));
+                dense_row_store<2>(a.dense, env, 16u + q0, tree_select<8>(zs, q0 & 7u));
+            }
+            if (own1 && q1 != q0) {
+                dense_row_store<2>(a.dense, env, q1, tree_select<8>(xs, q1 & 7u));
+                dense_row_store<2>(a.dense, env, 16u + q1, tree_select<8>(zs, q1 & 7u));
+            }
+        }
+    }
     if (h == 0) {
         if (a.rewards_seq) a.rewards_seq[env] = reward;
         if (a.dones_seq) a.dones_seq[env] = (uint8_t)(depth == 0 || solved);

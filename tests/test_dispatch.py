@@ -134,7 +134,8 @@ def test_observation_and_state_paths():
 
 def test_track_dense_modes():
     assert plan("clifford", 16, TRACK_DENSE, **PLAIN) == "in-step"
-    assert plan("clifford", 16, TRACK_DENSE, **DEFAULT) == "refresh"   # add_inverts: the two-lanes-per-env step is followed by a full rewrite
+    assert plan("clifford", 16, TRACK_DENSE, **DEFAULT) == "in-step"   # add_inverts: the two-lanes-per-env step rewrites the env when its coin fires
+    assert plan("clifford", 8, TRACK_DENSE, **DEFAULT) == "refresh"    # ... for 16 qubits only: other sizes get a full rewrite after the step
     assert plan("clifford", 8, TRACK_DENSE, **PLAIN) == "in-step"
     assert plan("linear_function", 32, TRACK_DENSE, **PLAIN) == "in-step"
     for kind, n in (("clifford", 5), ("clifford", 20), ("linear_function", 8), ("permutation", 9), ("pauli", 20)):

@@ -87,6 +87,50 @@ def test_tracked_dense_observation_follows_every_step(kind, n, track_solution):
     assert torch.equal(dense, before)
 
 
+@pytest.mark.parametrize("n,batch", [(16, 517), (16, 64), (8, 300)])
+def test_tracked_dense_observation_with_the_reference_default_options(n, batch):
+    """add_inverts=True, track_solution=True (envs/synthesis.py:182-204): CliffordEnv 16q's two-lanes-per-env step rewrites an env's whole
+    observation when its coin inverts the matrix and the gate's rows otherwise; 8 qubits: a full rewrite after every step.  Single steps with
+    given coins, a graph rollout, a fused rollout (Gauss-Jordan-free thread-per-env kernel + full rewrite), a non-symplectic set_state."""
+    gs = line_gateset("clifford", n)
+    A, B = len(gs), batch
+    ov, gv = make_pair("clifford", n, gs, B, add_inverts=True, add_perms=False, track_solution=True, difficulty=2 * n, max_depth=200)
+    rng = np.random.default_rng(n * B)
+    dense = gv.track_dense()
+
+    def check(label):
+        gv.sync()
+        np.testing.assert_array_equal(dense.cpu().numpy().reshape(B, -1), ov.observe_dense(), err_msg=label)
+
+    draws = rng.integers(0, A, size=(2 * n, B))
+    ov.reset_with(draws)
+    gv.reset_with(_dev(draws, torch.int32))
+    check("after reset_with")
+    for t in range(20):
+        acts = rng.integers(0, A, size=B)
+        coins = rng.integers(0, 2, size=B) if t % 5 else np.full(B, t % 2)  # all inverted / none inverted now and then
+        if t == 7:
+            acts[::6] = A + 1  # "no gate": nothing but the inversion changes the matrix
+        ov.step(acts, coins)
+        gv.step(_dev(acts, torch.int32), _dev(coins, torch.uint8))
+        check(f"step {t}")
+    for fused in (False, True):
+        T = 5
+        seq, cseq = rng.integers(0, A, size=(T, B)), rng.integers(0, 2, size=(T, B))
+        for t in range(T):
+            ov.step(seq[t], cseq[t])
+        gv.rollout(_dev(seq, torch.int32), fused=fused, coins=_dev(cseq, torch.uint8))
+        check(f"rollout fused={fused}")
+    # an arbitrary invertible (not symplectic) matrix: the Gauss-Jordan step kernel runs, followed by a full rewrite
+    st = ov.get_state(4 * n * n)
+    st[:, : 2 * n] = 0
+    st[:, 0] = 1
+    st[:, 1] = 1  # row 0 := e0 + e1: invertible with the other rows? keep it simple: only env 0 gets it, if its row 1 is not equal
+    ov.set_state(st)
+    gv.set_state(st, "i64")
+    check("after set_state")
+
+
 @pytest.mark.parametrize("inverts", [False, True])
 def test_tracked_dense_observation_across_auto_reset(inverts):
     """Episodes that end are re-scrambled by reset_done (a list of finished envs: the reset rewrites their observations itself; with
