@@ -72,7 +72,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 CONTROL_TIMEOUT_S = 90   # gloo control plane: a rank that never reaches a barrier costs its peers this long, not the driver's whole budget
 CADENCE_BUDGET_S = 240   # N > 1: wall-clock budget of the optional collective-cadence legs; past it the line is printed without them
 KERNEL = "qg::qm_step1_kernel<16, true, false"  # prefix: the trailing template arguments (feature flags, done list) vary by call site
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
 
 
 def build_gateset():
@@ -225,7 +225,7 @@ def gathered_parity(gateset, seed, global_ids, ring_actions, trace, shard):
 
 def rocprof_kernel_avg_us(envs: int, required: bool = False):
     """Average duration of the step kernel in the committed rocprofv3 --kernel-trace --stats summary of this command
-    (profiles/r03/, tools/profile_bench.sh).  The statistics hold one batch size (profiling runs pass --no-large-batch).  Every
+    (profiles/r04/, tools/profile_bench.sh).  The statistics hold one batch size (profiling runs pass --no-large-batch).  Every
     instantiation of the kernel whose name starts with KERNEL counts (calls-weighted).  `required`: a missing file or kernel is an
     error -- the line's roofline.frac is this figure -- unless the run IS the profiling run (--profiling-run)."""
     path = os.path.join(PROFILE_DIR, "bench_kernel_stats.csv" if envs == ENVS_PER_GPU else f"bench_{envs}_kernel_stats.csv")
@@ -244,12 +244,12 @@ def rocprof_kernel_avg_us(envs: int, required: bool = False):
         return {"avg_us": total_ns / calls / 1e3, "min_us": min(mins) / 1e3, "calls": calls, "source": os.path.relpath(path, ROOT)}
     if required:
         raise SystemExit(f"bench.py: {os.path.relpath(path, ROOT)} does not hold a kernel named {want}*: re-run tools/profile_bench.sh on the "
-                         "current build and commit profiles/r03 (or pass --profiling-run)")
+                         "current build and commit profiles/r04 (or pass --profiling-run)")
     return None
 
 
 def profiled_configs():
-    """profiles/r03/traffic.json: per configuration the step kernel's rocprofv3 average, the PMC bytes per env (separate FETCH_SIZE /
+    """profiles/r04/traffic.json: per configuration the step kernel's rocprofv3 average, the PMC bytes per env (separate FETCH_SIZE /
     WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), the bytes it needs and both fractions of 8 TB/s."""
     try:
         return json.load(open(os.path.join(PROFILE_DIR, "traffic.json")))["configs"]
@@ -315,7 +315,7 @@ def main():
     ap.add_argument("--no-default-config", action="store_true", help="skip the reference-default (add_inverts=True, track_solution=True) leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the C2 / C5 / C3d legs (SURVEY 8d's other configurations)")
     ap.add_argument("--profiling-run", action="store_true",
-                    help="this run produces profiles/r03 (tools/profile_bench.sh): the committed rocprofv3 summary is not required and roofline.frac falls "
+                    help="this run produces profiles/r04 (tools/profile_bench.sh): the committed rocprofv3 summary is not required and roofline.frac falls "
                          "back to the live clock")
     ap.add_argument("--no-dense-obs", action="store_true", help="skip the observation-mode legs (SURVEY 8d: packed and dense observation after every step)")
     ap.add_argument("--no-collector", action="store_true", help="skip the policy-in-the-loop leg (SURVEY 8f-3: collection with the reference's default policy shape)")
@@ -812,11 +812,13 @@ def main():
                         aenv.done[cls == k] = 1
                         aenv.reset_done(seed + 0xA5A5 * (k + 1))
 
-                def episode():
-                    for t in range(AT):
+                def episode():  # step, then AT - 1 x (reset_done, step) as qg_vec_reset_done_step -- one launch each -- and the last reset_done
+                    aenv.set_counters(0, 0)
+                    aenv.rollout(aacts[0:1], dones_out=afin[0:1])
+                    for t in range(1, AT):
                         aenv.set_counters(t, t)
-                        aenv.rollout(aacts[t : t + 1], dones_out=afin[t : t + 1])
-                        aenv.reset_done(seed + 0x9E3779B9 * (t + 1))
+                        aenv.reset_done_step(seed + 0x9E3779B9 * t, aacts[t], dones_out=afin[t])
+                    aenv.reset_done(seed + 0x9E3779B9 * AT)
 
                 episode()  # eager pass (allocations, kernel loads)
                 torch.cuda.synchronize()
@@ -839,7 +841,7 @@ def main():
                               "finished_per_step_min_max": [float(per_step.min()), float(per_step.max())]}
             del ag, aenv, aacts, afin
         auto_reset = dict(legs["desynchronised"], synchronised=legs["synchronised"],
-                          config=f"the headline workload with qg_vec_reset_done after every step, episodes of min(depth_slope * difficulty, max_depth) = {AT} steps, "
+                          config=f"the headline workload with qg_vec_reset_done after every step (the pair reset_done + next step issued as qg_vec_reset_done_step: one launch), episodes of min(depth_slope * difficulty, max_depth) = {AT} steps, "
                                  f"a captured graph of {AT} x (step, reset_done) replayed 4 times; headline figures: episode ends spread evenly over time "
                                  "(parity of this schedule: tests/test_gpu_fullsize.py::test_auto_reset_with_desynchronised_episodes_at_full_size)")
 
@@ -965,7 +967,7 @@ def main():
         del oenv, tenv, obs_d, obs_p, tracked
 
     # ---- SURVEY 8(d)'s other configurations: live launch period (hipGraph of 128 single-step launches) beside the committed rocprofv3 / PMC
-    # figures of the same kernels (profiles/r03/traffic.json, tools/profile_bench.sh) -----
+    # figures of the same kernels (profiles/r04/traffic.json, tools/profile_bench.sh) -----
     configs = None
     if not multi and B == ENVS_PER_GPU and not args.no_configs:
         from util import line_gateset
@@ -995,7 +997,7 @@ def main():
             row = {"kernel": p.get("kernel"), "envs": venv.batch, "us_per_step": us, "value": venv.batch / (us * 1e-6), "unit": "env-steps/s",
                    "rocprof_avg_us": st.get("avg_us"), "pmc_bytes_per_env": p.get("bytes_per_env"), "needed_bytes_per_env": p.get("needed_bytes_per_env"),
                    "survey_8d_bytes_per_env": p.get("survey_8d_bytes_per_env"), "frac_moved": p.get("rocprof_frac_moved"),
-                   "frac_survey_8d": p.get("rocprof_frac_algorithmic"), "source": "profiles/r03/traffic.json" if p else None}
+                   "frac_survey_8d": p.get("rocprof_frac_algorithmic"), "source": "profiles/r04/traffic.json" if p else None}
             configs[name] = row
 
         gs2 = line_gateset("linear_function", 8)

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 /* 2: + qg_comm_* / learner-shard entry points, qg_vec_step_host, qg_vec_observe_*_host (additions only: version-1 callers keep working)
- * 3: + qg_vec_track_dense, qg_comm_p2p_reset, qg_plan_query (additions only) */
+ * 3: + qg_vec_track_dense, qg_comm_p2p_reset, qg_plan_query, qg_vec_reset_done_step, qg_env_pool_clear (additions only) */
 #define QG_ABI_VERSION 3
 
 typedef enum {
@@ -173,6 +173,14 @@ int qg_vec_reset(qg_vec *v, uint64_t seed, void *stream);
  * Lets a GPU-resident collector run episode after episode without a host round trip; pass a
  * fresh seed per call (e.g. a step counter) so successive episodes of an env differ. */
 int qg_vec_reset_done(qg_vec *v, uint64_t seed, void *stream);
+/* qg_vec_reset_done(v, reset_seed) followed by qg_vec_step(v, actions_dev, ...) -- the auto-reset collection loop's pair of calls -- with the
+ * results of exactly those two calls (rewards_dev / dones_dev: optional per-step outputs as in qg_vec_rollout).  Handles whose env.step() is
+ * the one-step kernel of the 32-bit-row layout (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32, both without add_inverts) run the pair as
+ * ONE launch from the second call of a session on: the reset's workgroups (the finished envs' scrambles) and the step's workgroups (every
+ * other env) share the grid, and an env that was reset takes its first step on the lane that finished its scramble.  Everything else -- and
+ * the first call of a session, whose list has to be compacted from the flags -- is the two calls. */
+int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_dev, int action_dtype, const uint8_t *coins_dev, float *rewards_dev,
+                           uint8_t *dones_dev, void *stream);
 /* Capturing these calls into a caller's hipGraph: once qg_vec_reset_done is in use on a handle, a single qg_vec_step (and the sampling +
  * step calls) leaves the list of the envs it finished for the reset that follows, so that reset needs no compaction launch.  The list
  * lives on the device and every launch that appends to it expects it empty; what the host believes about it only holds within one

@@ -85,7 +85,7 @@ class QGymError(RuntimeError):
 EXPORTED_SYMBOLS = [
     "qg_config_default", "qg_last_error", "qg_abi_version", "qg_device_count", "qg_gate_parse",
     "qg_vec_create", "qg_vec_destroy", "qg_vec_get_info", "qg_vec_bind_outputs", "qg_vec_set_difficulty", "qg_vec_get_difficulty",
-    "qg_vec_set_state", "qg_vec_get_state", "qg_vec_reset", "qg_vec_reset_done", "qg_vec_set_clock", "qg_stream_wait_stream", "qg_vec_set_counters", "qg_vec_set_seed", "qg_vec_set_env_base", "qg_vec_get_env_base", "qg_vec_reset_with", "qg_vec_step", "qg_vec_step_host", "qg_vec_rollout", "qg_vec_rollout_ring",
+    "qg_vec_set_state", "qg_vec_get_state", "qg_vec_reset", "qg_vec_reset_done", "qg_vec_reset_done_step", "qg_vec_set_clock", "qg_stream_wait_stream", "qg_vec_set_counters", "qg_vec_set_seed", "qg_vec_set_env_base", "qg_vec_get_env_base", "qg_vec_reset_with", "qg_vec_step", "qg_vec_step_host", "qg_vec_rollout", "qg_vec_rollout_ring",
     "qg_vec_observe_dense", "qg_vec_track_dense", "qg_vec_observe_packed", "qg_vec_observe_dense_host", "qg_vec_observe_packed_host", "qg_vec_masks", "qg_vec_pauli_reset_from", "qg_vec_pauli_observe_dense", "qg_vec_pauli_num_perms", "qg_vec_sync",
     "qg_vec_solution",
     "qg_vec_observe_dense_as", "qg_expand_packed", "qg_widen_dense", "qg_sample_actions", "qg_gae",
@@ -152,6 +152,7 @@ def load():
     L.qg_vec_rollout_ring.argtypes = [vp, vp, C.c_int, sz, sz, vp]
     L.qg_vec_observe_dense.argtypes = [vp, vp, vp]
     L.qg_vec_track_dense.argtypes = [vp, vp, vp]
+    L.qg_vec_reset_done_step.argtypes = [vp, C.c_uint64, vp, C.c_int, vp, vp, vp, vp]
     L.qg_vec_observe_packed.argtypes = [vp, vp, vp]
     L.qg_vec_masks.argtypes = [vp, vp, vp]
     L.qg_vec_pauli_reset_from.argtypes = [vp, vp, C.c_char_p, vp, vp]

@@ -58,12 +58,13 @@ __device__ inline void done_list_append_block(uint32_t *list, uint32_t *count, b
 // the number of blocks with work follows from the length alone, so every block computes it.  A block without work takes no ticket (256
 // tickets on one address cost the launch 3.4 us); it may find the counter already zeroed and then sees an empty list, which for it is
 // the same thing.  An empty list needs neither tickets nor zeroing.  Call from all threads.
-__device__ inline uint32_t list_count_take(uint32_t *counter, uint64_t coop_B = 0, uint32_t coop_lanes = QG_COOP_LANES) {
+// `vblock`: this block's index among the blocks that consume the list (blockIdx.x, or less an offset when the kernel's grid starts with other work)
+__device__ inline uint32_t list_count_take(uint32_t *counter, uint64_t coop_B, uint32_t coop_lanes, uint32_t vblock) {
     const uint32_t count = counter[0];
     if (count == 0) return 0;
     const uint64_t threads = (coop_B && (uint64_t)count * QG_COOP_LANES * 2 <= coop_B) ? (uint64_t)count * coop_lanes : (uint64_t)count;
     const uint32_t blocks = (uint32_t)((threads + blockDim.x - 1) / blockDim.x);
-    if (blockIdx.x >= blocks) return count;  // (this block's threads all lie past the list)
+    if (vblock >= blocks) return count;  // (this block's threads all lie past the list)
     __syncthreads();
     // the ticket waits for its atomic's answer: it rides on the block's LAST thread, whose wave has the least left to do in scramble_tree
     if (threadIdx.x == blockDim.x - 1u && atomicAdd(&counter[1], 1u) == blocks - 1u) {
@@ -71,6 +72,9 @@ __device__ inline uint32_t list_count_take(uint32_t *counter, uint64_t coop_B = 
         counter[1] = 0;
     }
     return count;
+}
+__device__ inline uint32_t list_count_take(uint32_t *counter, uint64_t coop_B = 0, uint32_t coop_lanes = QG_COOP_LANES) {
+    return list_count_take(counter, coop_B, coop_lanes, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -123,9 +127,9 @@ __device__ inline void scramble_flat(W (*rows)[QG_WAVE], uint32_t L, const InitA
 // row operation each.  `lds`: R rows + 64 words per env, 64 / 16 envs per wave.  Returns the env's rows
 // on the one lane per env that has to finish it (its index in `env`), nullptr on every other lane.
 template <typename W, int R, typename Identity>
-__device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds, uint64_t &env, Identity identity) {
+__device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds, uint64_t &env, Identity identity, uint32_t vblock) {
     constexpr uint32_t S = QG_COOP_LANES, EPW = QG_WAVE / S, CH = 64, PER_ENV = R * sizeof(W) + CH * sizeof(uint32_t);
-    const uint64_t item = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / S;
+    const uint64_t item = ((uint64_t)vblock * blockDim.x + threadIdx.x) / S;
     if (item >= count) return nullptr;  // whole lane groups leave together
     const uint32_t sl = threadIdx.x & (S - 1), w = threadIdx.x >> 6, g = (threadIdx.x & (QG_WAVE - 1)) / S;
     env = a.list[item];
@@ -160,6 +164,10 @@ __device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds,
     }
     return sl == 0 ? rows : nullptr;
 }
+template <typename W, int R, typename Identity>
+__device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds, uint64_t &env, Identity identity) {
+    return scramble_coop<W, R>(a, count, lds, env, identity, blockIdx.x);
+}
 // One WORKGROUP (four waves) per env, the matrix held by COLUMNS, the gate sequence cut in EIGHT.
 //
 // Columns: lane j keeps column j in slot order (bit s of `col` = entry (slot s, column j); uint32 rows: R <= 32 slots, <= 32 columns).  A row
@@ -179,7 +187,7 @@ __device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds,
 // products (n = 256: 32 steps of ~45 ns instead of 64 gates of 73).
 // Rows come back by ballot: row word of slot s = the lanes' bits s.  Returns true on the one lane (lane 0 of wave 0) that finishes the env.
 // `prod`: 4 x 32 words of LDS; `gates`: 4 x 64 uint4 of LDS (16-byte aligned); `table`: the row-operation table in LDS (the caller brings it
-// in while the list length is still in flight), or null: read a.rowops.  blockDim.x must be 256.
+// in while the list length is still in flight), or null: read a.rowops; `env`: list[vblock], loaded by the caller.  blockDim.x must be 256.
 constexpr uint32_t QG_TREE_THREADS = plan::TREE_THREADS;
 constexpr uint32_t QG_TREE_TABLE_MAX = 1024;  // gatesets up to this many actions have their row-operation table in LDS
 constexpr uint32_t QG_TREE_MAX_ENVS = plan::TREE_MAX_ENVS;
@@ -208,12 +216,12 @@ __device__ inline uint4 rowop_masks(uint32_t o) {
 }
 template <int R, typename Identity>
 __device__ inline bool scramble_tree(const InitArgs &a, uint32_t count, uint64_t &env, uint32_t (&rows_out)[R], uint32_t (*prod)[32], uint4 (*gates)[QG_WAVE],
-                                     const uint32_t *table, Identity identity) {
+                                     const uint32_t *table, Identity identity, uint32_t vblock) {
     static_assert(R <= 32, "one uint32 of slots per column");
-    const uint64_t item = blockIdx.x;
+    const uint64_t item = vblock;
     if (item >= count) return false;  // whole workgroups leave together
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1), w = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31u;
-    env = a.list[item];
+    // (`env` comes in from the caller: list[item], requested before the list's length was known)
     // segment k = 2 w + half owns the gates [k seg, (k + 1) seg)
     const uint32_t seg = (a.n_draws + 7u) / 8u, k = 2u * w + half;
     const uint32_t t0 = k * seg < a.n_draws ? k * seg : a.n_draws, t1 = (t0 + seg < a.n_draws) ? t0 + seg : a.n_draws;

@@ -500,7 +500,10 @@ __global__ __launch_bounds__(256) void qm_step1_kernel(StepArgs a) {
     QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
     if constexpr (LIST) {  // every thread reaches the workgroup-wide append
         bool fin = false;
-        if (env < a.B) fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64));
+        if (env < a.B) {
+            fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64));
+            if (a.pend_out) a.pend_out[env] = (uint8_t)fin;  // what the next qg_vec_reset_done_step tests (qm_reset_step_kernel)
+        }
         done_list_append_block(a.done_list, a.done_count, fin, env, a.B);
     } else {
         if (env >= a.B) return;
@@ -657,14 +660,17 @@ __device__ inline void qm_init_finish(const InitArgs &a, uint64_t env, const QmR
     }
 }
 
+// set_state / reset / reset_done for the thread's env: the work of one workgroup of the init kernel.  `vblock`: the workgroup's index among the
+// workgroups doing this work.  Returns true on the threads that finished an env (`env`: which one) -- every thread of the full-batch
+// modes, one lane per env of the cooperative list scrambles.
 template <int NXP, bool HAS_Z>
-__global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
+__device__ __forceinline__ bool qm_init_block(const InitArgs &a, uint32_t vblock, uint64_t &env) {
     using Rows = QmRows<NXP, HAS_Z>;
     // reset scramble (device_common.hpp): the rows live in LDS (wave-private, [slot][lane]: conflict-free for
     // any per-lane slot), so a gate is dynamic-index reads and writes instead of a sweep over 32 registers
     __shared__ uint32_t lds_rows[4][Rows::R][QG_WAVE];
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t env = tid;
+    const uint64_t tid = (uint64_t)vblock * blockDim.x + threadIdx.x;
+    env = tid;
     if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
         constexpr bool coop_fits = scramble_coop_lds_bytes<uint32_t, Rows::R>(4) <= sizeof(lds_rows);
         static_assert(coop_fits == plan::tile_coop_fits(Rows::R, 4), "qgym_plan.hpp must describe this kernel");
@@ -675,41 +681,47 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
         const bool table_fits = a.coop && a.num_actions <= QG_TREE_TABLE_MAX;
         if (table_fits)
             for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) tree_table[i] = a.rowops[i];
+        // the entry this workgroup would scramble as a tree, requested before the list's length is known (any index below B is readable)
+        const uint32_t tree_env = a.coop ? a.list[vblock < a.B ? vblock : 0u] : 0u;
         // (a block past the list may see the count already zeroed: it has no work either way)
         const plan::ResetPath path = plan::list_reset_path(a.list_count[0], a.n_draws, a.B, a.coop != 0, coop_fits);  // qgym_plan.hpp
         const bool tree = path == plan::RP_TREE;
-        const uint32_t count = list_count_take(a.list_count, (coop_fits && a.coop) ? a.B : 0, tree ? QG_TREE_THREADS : QG_COOP_LANES);  // this kernel is the list's only reader
+        asm volatile("" ::"v"(tree_env));  // (keeps the entry's load up here, beside the length's: the compiler would sink it to its first use)
+        // this kernel is the list's only reader.  The barrier inside list_count_take (workgroups with work) is also the one that makes the table
+        // visible; it comes BEFORE the ticket, whose answer nobody waits for: a barrier after it made every workgroup wait its turn on the
+        // ticket's address (512 workgroups: the last one entered its scramble 6 us after the first)
+        const uint32_t count = list_count_take(a.list_count, (coop_fits && a.coop) ? a.B : 0, tree ? QG_TREE_THREADS : QG_COOP_LANES, vblock);
         if (tree) {  // few finished envs, long scrambles: a workgroup each, the matrix by columns, the gate sequence cut in eight (scramble_tree)
             const uint32_t N = a.N;
             Rows s;
-            __syncthreads();  // the table is in LDS
+            env = tree_env;
             if (!scramble_tree<Rows::R>(a, count, env, s.r, reinterpret_cast<uint32_t(*)[32]>(&lds_rows[0][0][0]), tree_gates, table_fits ? tree_table : nullptr,
                                         [N](uint32_t k) -> uint32_t {
                     const uint32_t j = HAS_Z ? k >> 1 : k;
                     return j < N ? ((HAS_Z && (k & 1u)) ? (1u << N) << j : 1u << j) : 0u;
-                }))
-                return;
+                }, vblock))
+                return false;
             qm_init_finish<NXP, HAS_Z>(a, env, s);
-            return;
+            return true;
         }
         if (plan::list_reset_path(count, a.n_draws, a.B, a.coop != 0, coop_fits) == plan::RP_COOP) {  // few finished envs: 16 lanes each
             const uint32_t N = a.N;
             const uint32_t *rows = scramble_coop<uint32_t, Rows::R>(a, count, &lds_rows[0][0][0], env, [N](uint32_t k) -> uint32_t {
                 const uint32_t j = HAS_Z ? k >> 1 : k;
                 return j < N ? ((HAS_Z && (k & 1u)) ? (1u << N) << j : 1u << j) : 0u;
-            });
-            if (!rows) return;
+            }, vblock);
+            if (!rows) return false;
             Rows s;
 #pragma unroll
             for (int k = 0; k < Rows::R; ++k) s.r[k] = rows[k];
             qm_init_finish<NXP, HAS_Z>(a, env, s);
-            return;
+            return true;
         }
-        if (tid >= count) return;
+        if (tid >= count) return false;
         env = a.list[tid];
     } else {
-        if (env >= a.B) return;
-        if (a.only_done && !a.done[env]) return;  // live episodes keep running
+        if (env >= a.B) return false;
+        if (a.only_done && !a.done[env]) return false;  // live episodes keep running
     }
     Rows s;
     qm_identity<NXP, HAS_Z>(s, a.N);
@@ -745,6 +757,55 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
         for (int sl = 0; sl < Rows::R; ++sl) s.r[sl] = rows[sl][L];
     }
     qm_init_finish<NXP, HAS_Z>(a, env, s);
+    return true;
+}
+
+
+template <int NXP, bool HAS_Z>
+__global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
+    uint64_t env;
+    (void)qm_init_block<NXP, HAS_Z>(a, blockIdx.x, env);
+}
+
+// qg_vec_reset_done followed by qg_vec_step in ONE launch (qg_vec_reset_done_step): the grid's first `reset_blocks` workgroups are the
+// reset's (qm_init_block on the list the PREVIOUS step left; they are the launch's long pole -- scramble, then the env's step on the lane
+// that finished it -- so they are dispatched first), the others step the envs whose episode goes on.  Nothing is handed over inside the launch: which envs are being reset is read from `pend_in`, the
+// is_final flags the previous step wrote for this purpose and nobody writes during this launch (the user-visible `done` array is written
+// by both halves); this launch writes `pend_out` and appends the envs that finish to the OTHER list.  Results are those of the two calls.
+struct ResetStepArgs {
+    InitArgs reset;
+    StepArgs step;
+    const uint8_t *pend_in;  // [B] is_final after the previous step: 1 = this env is on the reset's list
+    uint8_t *pend_out;       // [B] is_final after this step
+    uint32_t reset_blocks;
+};
+template <int NXP, bool HAS_Z, bool FEAT, bool DENSE>
+__global__ __launch_bounds__(256) void qm_reset_step_kernel(ResetStepArgs ra) {
+    using Rows = QmRows<NXP, HAS_Z>;
+    constexpr int D16 = DENSE ? Rows::R / 16 : 0;
+    const StepArgs &a = ra.step;
+    QG_PREFETCH_STEP_ARGS(a);  // (the reset's lanes reach their step late: its argument lines are requested now, not one miss after the other then)
+    if (blockIdx.x >= ra.reset_blocks) {
+        const uint64_t env = (uint64_t)(blockIdx.x - ra.reset_blocks) * blockDim.x + threadIdx.x;
+        bool fin = false;
+        if (env < a.B && !ra.pend_in[env]) {
+            // (the dense rows are written by lane pairs: a lane whose neighbour is being reset writes its rows alone)
+            const bool alone = D16 != 0 && (env ^ 1ull) < a.B && ra.pend_in[env ^ 1ull];
+            fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64), alone);
+            ra.pend_out[env] = (uint8_t)fin;
+        }
+        done_list_append_block(a.done_list, a.done_count, fin, env, a.B);
+        return;
+    }
+    uint64_t env;
+    if (!qm_init_block<NXP, HAS_Z>(ra.reset, blockIdx.x, env)) return;
+    // this lane has just written the env's fresh episode (state, depth, bad mask, log lengths): its first step, on the same lane
+    const bool fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64), true);
+    ra.pend_out[env] = (uint8_t)fin;
+    if (fin) {  // (rare: one atomic per env that is final again after its first step)
+        const uint32_t slot = atomicAdd(a.done_count, 1u);
+        if (slot < a.B) a.done_list[slot] = (uint32_t)env;
+    }
 }
 
 // export: one thread per (env, matrix row).  log2L carries NXP/4, flag bit 31 of D's companion
@@ -987,6 +1048,40 @@ hipError_t qm_init(const InitArgs &a, uint32_t nxp, bool has_z, hipStream_t s) {
     if (!a.B) return hipSuccess;
     QM_DISPATCH(launch_init, a)
 }
+template <int NXP, bool HAS_Z>
+static hipError_t launch_reset_step(const ResetStepArgs &ra, hipStream_t s) {
+    const InitArgs &ia = ra.reset;
+    uint64_t threads = ia.B;  // the reset's share of the grid: as launch_init sizes it
+    if (ia.list && ia.coop && ia.n_draws >= plan::TREE_MIN_DRAWS) {
+        const uint64_t tree_blocks = ia.B / 32u < QG_TREE_MAX_ENVS ? ia.B / 32u : QG_TREE_MAX_ENVS;
+        if (tree_blocks * QG_TREE_THREADS > threads) threads = tree_blocks * QG_TREE_THREADS;
+    }
+    ResetStepArgs rb = ra;
+    rb.reset_blocks = grid_for(threads, 256);
+    const dim3 grid(rb.reset_blocks + grid_for(ra.step.B, 256)), block(256);
+    const bool feat = ra.step.flags & (F_TRACK | F_LAYERS);
+    if constexpr (QmRows<NXP, HAS_Z>::R % 16 == 0) {
+        if (ra.step.dense) {
+            if (feat) hipLaunchKernelGGL((qm_reset_step_kernel<NXP, HAS_Z, true, true>), grid, block, 0, s, rb);
+            else hipLaunchKernelGGL((qm_reset_step_kernel<NXP, HAS_Z, false, true>), grid, block, 0, s, rb);
+            return hipGetLastError();
+        }
+    }
+    if (feat) hipLaunchKernelGGL((qm_reset_step_kernel<NXP, HAS_Z, true, false>), grid, block, 0, s, rb);
+    else hipLaunchKernelGGL((qm_reset_step_kernel<NXP, HAS_Z, false, false>), grid, block, 0, s, rb);
+    return hipGetLastError();
+}
+hipError_t qm_reset_step(const InitArgs &reset, const StepArgs &step, const uint8_t *pend_in, uint8_t *pend_out, uint32_t nxp, bool has_z, hipStream_t s) {
+    if (!step.B) return hipSuccess;
+    ResetStepArgs ra;
+    ra.reset = reset;
+    ra.step = step;
+    ra.pend_in = pend_in;
+    ra.pend_out = pend_out;
+    ra.reset_blocks = 0;  // (set by the launcher)
+    QM_DISPATCH(launch_reset_step, ra)
+}
+
 hipError_t qm_export(const ObsArgs &a, uint32_t nxp, bool has_z, hipStream_t s) {
     if (!a.B) return hipSuccess;
     const uint32_t R = has_z ? 2 * nxp : nxp;

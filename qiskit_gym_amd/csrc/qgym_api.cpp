@@ -223,7 +223,7 @@ static int vec_free_buffers(qg_vec *v) {
     void *ptrs[] = {v->state, v->own_depth ? v->depth : nullptr, v->own_reward ? v->reward : nullptr,
                     v->own_done ? v->done : nullptr, v->own_success ? v->success : nullptr, v->inverted, v->error, v->sol,
                     v->sol_len, v->layers, v->d_gates, v->d_descs, v->scratch, v->d_prog,
-                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad, v->done_list, v->d_rowops, v->embed_dump, v->host_in, v->host_obs, v->fault_scratch};
+                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad, v->done_list, v->done_list_alt, v->pend[0], v->pend[1], v->d_rowops, v->embed_dump, v->host_in, v->host_obs, v->fault_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &g : v->graphs) {
@@ -261,6 +261,8 @@ bool done_list_session(qg_vec *v, hipStream_t s) {
         v->list_session = cur;
         v->done_list_fresh = false;
         v->list_zero_known = false;
+        v->pend_fresh = false;
+        v->alt_zero_known = false;
         if (cur) v->list_tainted = true;
     }
     return cur != 0 || !v->list_tainted;
@@ -276,6 +278,17 @@ int done_list_before_append(qg_vec *v, hipStream_t s) {
 void done_list_appended(qg_vec *v, bool trusted) {
     v->done_list_fresh = trusted;  // an untrusted list is never consumed: the next reset_done compacts
     v->list_zero_known = false;
+    v->pend_fresh = false;  // (the step launches that also wrote the is_final array say so themselves: step_wrote_pend)
+}
+// a list-leaving step of a handle that can fuse reset_done + step also keeps is_final of every env (StepArgs::pend_out)
+static void step_writes_pend(const qg_vec *v, StepArgs &a) {
+    if (v->pend[0]) a.pend_out = v->pend[v->pend_cur ^ 1];
+}
+static void step_wrote_pend(qg_vec *v, const StepArgs &a, bool trusted) {
+    if (a.pend_out) {
+        v->pend_cur ^= 1;
+        v->pend_fresh = trusted;
+    }
 }
 
 }  // namespace qg
@@ -506,6 +519,14 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     if (hp.has_done_list) {
         HIP_TRY_V(hipMalloc(&p->done_list, sizeof(uint32_t) * (batch + 2)));
         HIP_TRY_V(hipMemset(p->done_list + batch, 0, 2 * sizeof(uint32_t)));
+    }
+    if (plan::reset_step_fusable(hp)) {  // qg_vec_reset_done_step in one launch: the second list and the two is_final arrays
+        HIP_TRY_V(hipMalloc(&p->done_list_alt, sizeof(uint32_t) * (batch + 2)));
+        HIP_TRY_V(hipMemset(p->done_list_alt + batch, 0, 2 * sizeof(uint32_t)));
+        for (auto &pp : p->pend) {
+            HIP_TRY_V(hipMalloc(&pp, batch));
+            HIP_TRY_V(hipMemset(pp, 0, batch));
+        }
     }
     HIP_TRY_V(hipMalloc(&p->error, sizeof(uint32_t) * batch));
     HIP_TRY_V(hipMalloc(&p->sol_len, sizeof(int32_t) * 2 * batch));
@@ -917,9 +938,13 @@ int qg_vec_step(qg_vec *v, const void *actions_dev, int action_dtype, const uint
     a.coins = coins_dev;
     if (action_dtype == QG_ACT_I64) a.flags |= F_ACT64;
     if (dense_rides_in_step(v)) a.dense = v->dense;
+    if (lists) step_writes_pend(v, a);
     HIP_TRY(launch_step(v, a, (hipStream_t)stream));
     v->step_index += 1;
-    if (lists) done_list_appended(v, true);
+    if (lists) {
+        done_list_appended(v, true);
+        step_wrote_pend(v, a, true);
+    }
     if (v->dense && !a.dense) return dense_refresh(v, (hipStream_t)stream);
     return QG_OK;
 }
@@ -980,6 +1005,59 @@ int qg_vec_step_host(qg_vec *v, const void *actions_host, int action_dtype, cons
 static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, size_t T, size_t period, const uint8_t *coins_dev,
                         float *rewards_dev, uint8_t *dones_dev, int fused, void *stream);
 
+int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_dev, int action_dtype, const uint8_t *coins_dev, float *rewards_dev,
+                           uint8_t *dones_dev, void *stream) {
+    if (!v || !actions_dev) return set_error(QG_ERR_INVALID, "null argument");
+    if (action_dtype != QG_ACT_I32 && action_dtype != QG_ACT_I64) return set_error(QG_ERR_INVALID, "bad action dtype");
+    QG_ON_DEVICE(v);
+    hipStream_t s = (hipStream_t)stream;
+    const bool trusted = done_list_session(v, s);
+    // one launch when the list of finished envs and their is_final flags were left by this handle's own previous step (same session) and the
+    // reset would take the list path with counter-RNG draws; otherwise the two calls, whose step leaves both for the next time
+    const bool fuse = v->pend[0] && trusted && v->done_list_fresh && v->pend_fresh && v->auto_list && !v->gates.empty() &&
+                      plan::reset_coop_allowed(false, v->B, v->d_rowops != nullptr);
+    if (!fuse) {
+        if (int rc = qg_vec_reset_done(v, reset_seed, stream)) return rc;
+        return rollout_impl(v, actions_dev, action_dtype, 1, 1, coins_dev, rewards_dev, dones_dev, 0, stream);
+    }
+    InitArgs ia;
+    fill_init_args(v, ia);
+    ia.mode = 2;
+    ia.n_draws = (uint32_t)v->difficulty;
+    ia.seed = reset_seed;
+    ia.only_done = 1u;
+    ia.list = v->done_list;
+    ia.list_count = v->done_list + v->B;
+    ia.coop = 1u;
+    ia.dense = v->dense;
+    ia.depth_value = (int32_t)std::min<int64_t>((int64_t)v->cfg.depth_slope * v->difficulty, v->cfg.max_depth);  // clifford.rs:317
+    StepArgs a;
+    fill_step_args(v, a);
+    a.actions = actions_dev;
+    a.coins = coins_dev;
+    a.rewards_seq = rewards_dev;
+    a.dones_seq = dones_dev;
+    if (action_dtype == QG_ACT_I64) a.flags |= F_ACT64;
+    a.flags |= F_DONE_LIST;  // the envs that finish in this step go to the OTHER list
+    a.done_list = v->done_list_alt;
+    a.done_count = v->done_list_alt + v->B;
+    if (!v->alt_zero_known) HIP_TRY(hipMemsetAsync(v->done_list_alt + v->B, 0, 2 * sizeof(uint32_t), s));
+    if (dense_rides_in_step(v)) a.dense = v->dense;
+    const uint8_t *pend_in = v->pend[v->pend_cur];
+    uint8_t *pend_out = v->pend[v->pend_cur ^ 1];
+    HIP_TRY(qm_reset_step(ia, a, pend_in, pend_out, v->nxp, v->has_z, s));
+    v->step_index += 1;
+    // the list just appended to is the current one; the one just consumed was zeroed by its last reader and is the next launch's target
+    std::swap(v->done_list, v->done_list_alt);
+    v->pend_cur ^= 1;
+    v->done_list_fresh = true;
+    v->pend_fresh = true;
+    v->list_zero_known = false;
+    v->alt_zero_known = true;
+    if (v->dense && !a.dense) return dense_refresh(v, s);
+    return QG_OK;
+}
+
 int qg_vec_rollout(qg_vec *v, const void *actions_dev, int action_dtype, size_t T, const uint8_t *coins_dev,
                    float *rewards_dev, uint8_t *dones_dev, int fused, void *stream) {
     return rollout_impl(v, actions_dev, action_dtype, T, T, coins_dev, rewards_dev, dones_dev, fused, stream);
@@ -1011,6 +1089,7 @@ static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, si
     if (action_dtype == QG_ACT_I64) a.flags |= F_ACT64;
     if (v->layout == LAYOUT_LFD) fused = 0;  // its step kernel spreads an env over four lanes; T steps = T launches (one graph)
     if (dense_rides_in_step(v) && (!fused || T == 1)) a.dense = v->dense;  // single-step launches keep the tracked observation current themselves
+    if (lists) step_writes_pend(v, a);
     if (fused) {
         if (period != T) return set_error(QG_ERR_INVALID, "fused rollouts read actions[t] for every t");
         a.T = (uint32_t)T;
@@ -1047,7 +1126,10 @@ static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, si
     if (cs != hipStreamCaptureStatusNone || rng_coins || T == 1) {
         HIP_TRY(enqueue_steps(s));
         v->step_index += T;
-        if (lists) done_list_appended(v, true);
+        if (lists) {
+            done_list_appended(v, true);
+            step_wrote_pend(v, a, true);
+        }
         return QG_OK;
     }
     GraphKey key{actions_dev, coins_dev, rewards_dev, dones_dev, T, action_dtype, period, a.flags, v->env_base, v->dense};

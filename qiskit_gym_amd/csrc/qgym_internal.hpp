@@ -112,6 +112,8 @@ struct StepArgs {
     uint32_t *done_count;     // read only under that flag (the last fields of the block: other launches never touch their cache line)
     int8_t *dense;            // qg_vec_track_dense: the resident dense int8 observation [B][D][D]; the DENSE instantiations of the one-step kernels
                               // rewrite the rows their gate changed (read by those instantiations only)
+    uint8_t *pend_out;        // F_DONE_LIST, TILE without add_inverts: is_final of every env after this step, for the membership test of the next
+                              // qg_vec_reset_done_step (null: not kept)
 };
 
 // The argument block spans four 64-byte lines and the scalar cache is cold at every launch.  Left alone, the compiler fetches a field
@@ -209,6 +211,8 @@ hipError_t lfd_export(const ObsArgs &a, bool w64, uint32_t rg, const uint8_t *in
 
 hipError_t qm_step(const StepArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
 hipError_t qm_init(const InitArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
+// qg_vec_reset_done (list in `reset`) + qg_vec_step (`step`, F_DONE_LIST: appends to ITS list) in one launch; pend_in / pend_out: StepArgs::pend_out
+hipError_t qm_reset_step(const InitArgs &reset, const StepArgs &step, const uint8_t *pend_in, uint8_t *pend_out, uint32_t nxp, bool has_z, hipStream_t s);
 hipError_t qm_export(const ObsArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
 // dense {0,1} observation in an element type of `elem_size` bytes whose 1 is the bit pattern `one`
 hipError_t qm_export_typed(const void *state, uint64_t B, uint32_t N, uint32_t D, uint32_t nxp, bool has_z, void *out, uint32_t elem_size,

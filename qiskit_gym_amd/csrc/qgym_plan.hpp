@@ -236,6 +236,9 @@ inline bool reset_coop_allowed(bool draws_given, uint64_t B, bool has_rowops) { 
 // scramble_coop's LDS (4 waves x 4 envs x (R rows + 64 gate words)) against the init kernel's row array (4 waves x R x 64 words)
 constexpr bool tile_coop_fits(uint32_t R, uint32_t word_bytes) { return 16ull * (R * word_bytes + 256ull) <= 4ull * R * 64ull * word_bytes; }
 
+// qg_vec_reset_done_step as ONE launch (qm_reset_step_kernel): handles whose env.step() is the one-step TILE kernel
+inline bool reset_step_fusable(const HandlePlan &p) { return p.layout == LAYOUT_TILE && p.has_bad && !(p.flags & F_INVERTS) && p.has_done_list; }
+
 // ---- observations / state export (TILE) ----------------------------------------------------------------------------------------------
 enum ExportKernel { EK_GENERIC = 0, EK_DENSE_STREAM, EK_PACK, EK_WORDS_THEN_EXPAND };
 inline const char *export_kernel_name(ExportKernel k) {

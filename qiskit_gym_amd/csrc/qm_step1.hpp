@@ -39,8 +39,10 @@ __device__ inline void qm_group_put(uint32_t (&u)[4], uint32_t q, uint32_t x, ui
 // solution log / layer metrics when FEAT).  Returns is_final.
 // D16 > 0 (qg_vec_track_dense; the matrix has D = 16 * D16 rows, no padding slots): the rows the gate rewrote also go to the env's
 // dense int8 observation -- <= 4 rows of D bytes instead of the D * D bytes a full qg_vec_observe_dense writes.
+// `alone`: the neighbouring lane does not run this body with the neighbouring env (the reset's lanes in qm_reset_step_kernel): the dense rows are
+// then written by this lane alone.
 template <bool HAS_Z, bool FEAT, int D16 = 0>
-__device__ inline bool qm_step1_body(const StepArgs &a, uint32_t G, uint64_t env, int64_t act) {
+__device__ inline bool qm_step1_body(const StepArgs &a, uint32_t G, uint64_t env, int64_t act, bool alone = false) {
     const uint32_t lane = (uint32_t)env & (QG_WAVE - 1);
     uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(G * 64);
     int32_t depth = a.depth[env];
@@ -101,7 +103,7 @@ __device__ inline bool qm_step1_body(const StepArgs &a, uint32_t G, uint64_t env
         // 65 536 envs, this form 4.83 (3.11 without the dense observation).  Every lane that runs this body reaches this point; a pair lane
         // that does not (past the batch's odd end) reads as "no row" -- update_dpp keeps `old` = 0 for a disabled source lane -- and the
         // env it leaves without a partner writes its rows alone.
-        const bool solo = (env ^ 1ull) >= a.B;
+        const bool solo = alone || (env ^ 1ull) >= a.B;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (solo && ((dchg >> k) & 1u)) dense_row_store<2>(a.dense, env, drow[k], dword[k]);

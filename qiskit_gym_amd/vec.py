@@ -144,6 +144,25 @@ class VecEnv:
         """reset() only the envs whose episode is over (`done` set); stream-ordered, no host sync."""
         _lib.check(self._L.qg_vec_reset_done(self._h, int(seed) & (2**64 - 1), self._stream()))
 
+    def reset_done_step(self, seed: int, actions: torch.Tensor, coins: Optional[torch.Tensor] = None,
+                        rewards_out: Optional[torch.Tensor] = None, dones_out: Optional[torch.Tensor] = None):
+        """`reset_done(seed)` then `step(actions)` -- same results -- as one launch where the layout allows it (`qg_vec_reset_done_step`)."""
+        actions = actions.contiguous()
+        if actions.numel() != self.batch:
+            raise ValueError(f"reset_done_step: one action per env ({self.batch}), got {tuple(actions.shape)}")
+        ptr, dt = self._act(actions)
+        cp = None
+        if coins is not None:
+            coins = coins.to(device=self.device, dtype=torch.uint8).contiguous()
+            cp = coins.data_ptr()
+        for name, t, size in (("rewards_out", rewards_out, 4), ("dones_out", dones_out, 1)):
+            if t is not None and (t.device != self.device or t.numel() != self.batch or t.element_size() != size or not t.is_contiguous()):
+                raise ValueError(f"reset_done_step: {name} must be a contiguous [B] tensor of {size}-byte elements on the env's device")
+        rp = rewards_out.data_ptr() if rewards_out is not None else None
+        dp = dones_out.data_ptr() if dones_out is not None else None
+        _lib.check(self._L.qg_vec_reset_done_step(self._h, int(seed) & (2**64 - 1), ptr, dt, cp, rp, dp, self._stream()))
+        return self.reward, self.done
+
     def set_clock(self, clock: Optional[torch.Tensor]):
         """Attach (or detach with None) a device clock: an int64 [1] tensor on this device that every
         RNG-driven kernel of the handle adds to its counter (`qg_vec_set_clock`) -- what lets a captured

@@ -243,3 +243,119 @@ def test_reset_done_random_shapes_against_the_oracle(case):
         mask = torch.ones(B, dtype=torch.bool, device="cuda")
         mask[torch.as_tensor(ids, device="cuda")] = False
         assert torch.equal(gv.get_state("packed")[mask], before[mask]), "a live env was touched"
+
+
+@pytest.mark.parametrize("kind,n,B,diff,track,dense", [
+    ("clifford", 16, 700, 3, False, False),      # short scrambles: the flat / cooperative list paths inside the fused launch
+    ("clifford", 16, 4096, 70, True, False),     # long scrambles, short lists: scramble_tree; solution log
+    ("clifford", 16, 4096, 70, False, True),     # ... with a resident dense observation kept current by both halves of the launch
+    ("clifford", 5, 333, 4, True, False),
+    ("linear_function", 12, 1000, 5, False, False),
+    ("linear_function", 32, 2048, 66, False, True),
+])
+def test_reset_done_step_in_one_launch_equals_the_two_calls(kind, n, B, diff, track, dense):
+    """qg_vec_reset_done_step (from its second call on: ONE launch whose grid holds the reset's and the step's workgroups) against
+    qg_vec_reset_done + qg_vec_step on a twin handle and against the oracle: rewards, flags, depth after every step, states, solution logs
+    and the tracked dense observation at the end; episodes end at different times (depth 2 * difficulty, or earlier on success)."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    gs = line_gateset(kind, n)
+    A = len(gs)
+    cfg = dict(add_inverts=False, add_perms=False, track_solution=track, difficulty=diff, depth_slope=1 if diff > 20 else 2, max_depth=128)
+    fused, twin = VecEnv(kind, n, gs, B, **cfg), VecEnv(kind, n, gs, B, **cfg)
+    envs = [OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()}) for _ in range(min(B, 400))]
+    dt = fused.track_dense() if dense else None
+    seed0 = 5
+    fused.reset(seed0)
+    twin.reset(seed0)
+    draws = rng_actions(seed0, len(envs), diff, A)
+    for e, o in enumerate(envs):
+        o.reset_with(draws[:, e])
+    rng = np.random.default_rng(B + diff)
+    resets = 0
+    if diff > 20:  # long episodes end together: spread the ends first (class env % 64 == k starts a new episode at prologue step k)
+        cls = torch.arange(B, device="cuda") % 64
+        for k in range(64):
+            acts = rng.integers(0, A, size=B)
+            ta = torch.as_tensor(acts, device="cuda", dtype=torch.int32)
+            seed = 100 + k
+            d2 = rng_actions(seed, len(envs), diff, A)
+            for h in (fused, twin):
+                h.step(ta)
+                h.reset_done(3)         # (consumes the step's own list: nobody is final yet)
+                h.done[cls == k] = 1    # the caller ends these episodes
+                h.reset_done(seed)      # (flags written by the caller: this one compacts)
+            for e, o in enumerate(envs):
+                o.step(int(acts[e]), 0)
+                if e % 64 == k:
+                    o.reset_with(d2[:, e])
+                    resets += 1
+    for t in range(3 * cfg["depth_slope"] * diff + 5 if diff <= 5 else 90):
+        seed = 900 + 7 * t
+        acts = rng.integers(0, A, size=B)
+        if t % 9 == 4:
+            acts[::5] = A + 1  # "no gate": still uses depth
+        done = twin.done.cpu().numpy().astype(bool)
+        ta = torch.as_tensor(acts, device="cuda", dtype=torch.int32)
+        fused.reset_done_step(seed, ta)
+        twin.reset_done(seed)
+        twin.step(ta)
+        d2 = rng_actions(seed, len(envs), diff, A)
+        for e, o in enumerate(envs):
+            if done[e]:
+                o.reset_with(d2[:, e])
+                resets += 1
+            o.step(int(acts[e]), 0)
+        fused.sync()
+        twin.sync()
+        assert torch.equal(fused.reward.view(torch.int32), twin.reward.view(torch.int32)), t
+        assert torch.equal(fused.done, twin.done) and torch.equal(fused.success, twin.success) and torch.equal(fused.depth, twin.depth), t
+        ne = len(envs)
+        np.testing.assert_array_equal(f32_bits(fused.reward.cpu().numpy()[:ne]), np.array([o.reward_bits() for o in envs], dtype=np.uint32), err_msg=f"t={t}")
+        np.testing.assert_array_equal(fused.depth.cpu().numpy()[:ne], [o.depth() for o in envs])
+    assert resets > 1.9 * len(envs)  # every env went through episode ends
+    assert torch.equal(fused.get_state("packed"), twin.get_state("packed"))
+    np.testing.assert_array_equal(fused.get_state("i64").cpu().numpy()[: len(envs)], np.stack([o.get_state() for o in envs]))
+    if track:
+        for e in (0, 3, len(envs) - 1):
+            assert fused.solution(e) == envs[e].solution() == twin.solution(e)
+    if dense:
+        assert torch.equal(dt, fused.observe())
+        np.testing.assert_array_equal(dt.cpu().numpy()[: len(envs)].reshape(len(envs), -1), np.stack([o.dense_obs() for o in envs]).reshape(len(envs), -1))
+
+
+def test_reset_done_step_inside_a_captured_graph_replays_like_eager_calls():
+    """A graph of 16 x reset_done_step (its first call compacts the list from the flags, the others are single launches) replayed three times
+    against the same calls made eagerly on a twin: the device-side lists and flag arrays of consecutive replays line up whatever the
+    graph's length (here even and odd)."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    gs = line_gateset("clifford", 16)
+    A, B = len(gs), 8192
+    for T in (16, 7):
+        cfg = dict(add_inverts=False, add_perms=False, track_solution=False, difficulty=3, depth_slope=2, max_depth=128)
+        g_env, twin = VecEnv("clifford", 16, gs, B, **cfg), VecEnv("clifford", 16, gs, B, **cfg)
+        acts = torch.randint(0, A, (T, B), dtype=torch.int32, device="cuda")
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            g_env.reset(1)
+            twin.reset(1)
+
+            def body(env):
+                for t in range(T):
+                    env.reset_done_step(40 + t, acts[t])
+
+            body(g_env)  # eager pass on both
+            body(twin)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                body(g_env)
+            for _ in range(3):
+                graph.replay()
+                body(twin)
+            torch.cuda.synchronize()
+        g_env.sync()
+        twin.sync()
+        assert torch.equal(g_env.get_state("packed"), twin.get_state("packed")), T
+        assert torch.equal(g_env.depth, twin.depth) and torch.equal(g_env.done, twin.done) and torch.equal(g_env.reward.view(torch.int32), twin.reward.view(torch.int32)), T

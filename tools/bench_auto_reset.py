@@ -4,6 +4,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
+if os.environ.get('QG_LIB'):
+    from qiskit_gym_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(os.environ['QG_LIB'])
 from qiskit_gym_amd.vec import VecEnv
 from util import line_gateset
 
@@ -18,9 +21,16 @@ with torch.cuda.stream(stream):
     for k in range(AT):
         env.set_counters(k, k); env.step(acts[k]); env.reset_done(seed + 0x51ED * (k + 1))
         env.done[cls == k] = 1; env.reset_done(seed + 0xA5A5 * (k + 1))
+    FUSED = os.environ.get("UNFUSED") != "1"
     def episode():
-        for t in range(AT):
-            env.set_counters(t, t); env.rollout(acts[t:t + 1]); env.reset_done(seed + 0x9E3779B9 * (t + 1))
+        if not FUSED:
+            for t in range(AT):
+                env.set_counters(t, t); env.rollout(acts[t:t + 1]); env.reset_done(seed + 0x9E3779B9 * (t + 1))
+            return
+        env.set_counters(0, 0); env.rollout(acts[0:1])
+        for t in range(1, AT):
+            env.set_counters(t, t); env.reset_done_step(seed + 0x9E3779B9 * t, acts[t])  # reset_done + step: one launch
+        env.reset_done(seed + 0x9E3779B9 * AT)
     episode(); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=stream):
@@ -31,4 +41,5 @@ with torch.cuda.stream(stream):
     for _ in range(8): g.replay()
     e1.record(stream)
 torch.cuda.synchronize(); env.sync()
+print(("one launch per (reset_done + step)" if FUSED else "two launches") + ": ", end="")
 print(f"desynchronised auto-reset: {e0.elapsed_time(e1) * 1e3 / (8 * AT):.2f} us per (step + reset_done), {100.0 / AT:.2f} % of the batch finishes per step")

@@ -1,5 +1,5 @@
-"""rocprofv3 PMC passes of tools/profile_bench.sh -> profiles/r03/traffic.json (and the kernel-stats files copied beside it).
-  python tools/pmc_traffic.py [src = gpurun_out/prof] [dst = profiles/r03]
+"""rocprofv3 PMC passes of tools/profile_bench.sh -> profiles/r04/traffic.json (and the kernel-stats files copied beside it).
+  python tools/pmc_traffic.py [src = gpurun_out/prof] [dst = profiles/r04]
 
 HBM bytes per launch of a step kernel = 2 x FETCH_SIZE + WRITE_SIZE (both reported in KiB): MI355X_MICROARCH.md's HBM
 section -- on gfx950 FETCH_SIZE counts half the bytes of a 16 B/lane read, WRITE_SIZE is taken as is; each counter is
@@ -15,7 +15,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof")
-dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r03")
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r04")
 os.makedirs(dst, exist_ok=True)
 
 # run name -> (kernel name PREFIX -- trailing template arguments vary by call site --, envs, SURVEY 8(d) bytes per env-step, bytes the
@@ -30,6 +30,12 @@ RUNS = {
     "C2": ("word_step_kernel<false>", 8192, 32, 32),
     # two 12-byte qubit records read and written, the 64-byte rotation block's touched 16-bit slices + bookkeeping, 22 B of scalars
     "C5": ("ptile_step1c_kernel<20, 8", 65536, 494, 130),
+    # SURVEY 8d's dense-observation mode (tools/bench_dense_obs.py): the full rewrite (1 KiB written, 128 B read per env), the step that keeps a
+    # resident dense observation current (8d counts 1 184 B; it has to move the step's 90 B + ~2 changed rows of 32 B), and the same with the
+    # reference-default options (two lanes per env: half of the envs rewrite 1 KiB, the others the gate's rows)
+    "dense": ("qm_dense_stream_kernel<2>", 65536, 1152, 1152),
+    "tracked": ("qm_step1_kernel<16, true, false, false, true>", 65536, 1184, 154),
+    "tracked_default": ("qm_inv2_kernel<16, false, false, true>", 2 * 65536, 1184, 245 + 512 + 48 - 20),  # (tools/bench_dense_obs.py --inverts keeps no solution log)
 }
 
 
@@ -79,7 +85,7 @@ for run, (kernel, envs, algo, needed) in RUNS.items():
             live = json.loads(open(lp).read().strip().splitlines()[-1])
         except Exception:
             live = None
-    if run == "C3d":
+    if run in ("C3d", "tracked_default"):
         envs //= 2
     e = {"kernel": "qg::" + kernel + "...>", "envs": envs, "fetch_bytes": fb, "write_bytes": wb, "bytes_per_launch": fb + wb,
          "bytes_per_env": (fb + wb) / envs, "fetch_per_env": fb / envs, "write_per_env": wb / envs,
@@ -98,7 +104,7 @@ for run, (kernel, envs, algo, needed) in RUNS.items():
         if needed:
             e["rocprof_frac_needed"] = needed * envs / st["avg_us"] / 1e3 / 8000
     out["configs"][run] = e
-    if kernel.startswith("qm_step1_kernel"):
+    if kernel.startswith("qm_step1_kernel") and run != "tracked":
         out["by_envs"][str(envs)] = e
 json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 copied = []

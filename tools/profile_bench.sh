@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-3 profiles (run through gpurun from the repo root; results land in gpurun_out/prof, tools/pmc_traffic.py turns them
-# into what is committed under profiles/r03/):
+# Round-4 profiles (run through gpurun from the repo root; results land in gpurun_out/prof, tools/pmc_traffic.py turns them
+# into what is committed under profiles/r04/):
 #   1. rocprofv3 --kernel-trace --stats of the bench.py command the driver runs       -> bench_kernel_stats.csv
 #   2. --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (one per counter, kernel trace only) of the same kernel at 65 536 envs
 #   3. kernel stats + PMC passes of every other configuration's step kernel: C2 (word_step_kernel), C5 (ptile_step1c_kernel),
@@ -12,7 +12,7 @@ OUT="$ROOT/gpurun_out/prof"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/qg_prof && mkdir -p /tmp/qg_prof
-BENCH_ARGS="--gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-large-batch --no-default-config --no-configs --no-collector --profiling-run"
+BENCH_ARGS="--gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-large-batch --no-default-config --no-configs --no-collector --no-dense-obs --profiling-run"
 echo "== bench.py kernel stats" && date
 rocprofv3 --kernel-trace --stats -d /tmp/qg_prof/stats -o bench --output-format csv -- python3 "$ROOT/bench.py" $BENCH_ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats_run.log"
 cp /tmp/qg_prof/stats/*kernel_stats.csv "$OUT/bench_kernel_stats.csv" 2>/dev/null
@@ -22,7 +22,7 @@ pmc_pass() {  # name, counter, script args...
     local F
     F=$(ls /tmp/qg_prof/${name}_$counter/*counter_collection.csv 2>/dev/null | head -1)
     # keep the step kernels' dispatches only (the files are large): header + rows of *_step* kernels
-    if [ -n "$F" ]; then (head -1 "$F"; grep -E "step1?c?_kernel|inv2_kernel" "$F") > "$OUT/pmc_${name}_$counter.csv"; fi
+    if [ -n "$F" ]; then (head -1 "$F"; grep -E "step1?c?_kernel|inv2_kernel|dense_stream_kernel" "$F") > "$OUT/pmc_${name}_$counter.csv"; fi
 }
 stats_pass() {  # name, script args...
     local name="$1"; shift
@@ -31,7 +31,7 @@ stats_pass() {  # name, script args...
 }
 for C in FETCH_SIZE WRITE_SIZE; do
     echo "== bench.py pmc $C" && date
-    pmc_pass bench $C "$ROOT/bench.py" --gpus 1 --steps 512 --warmup 64 --no-cpu-baseline --no-parity --no-large-batch --no-default-config --no-configs --no-collector --profiling-run
+    pmc_pass bench $C "$ROOT/bench.py" --gpus 1 --steps 512 --warmup 64 --no-cpu-baseline --no-parity --no-large-batch --no-default-config --no-configs --no-collector --no-dense-obs --profiling-run
 done
 for CFG in "C2" "C5" "C3d" "C3 --envs 1048576" "C3 --envs 4194304"; do
     set -- $CFG
@@ -43,14 +43,26 @@ for CFG in "C2" "C5" "C3d" "C3 --envs 1048576" "C3 --envs 4194304"; do
         pmc_pass "$NAME" $C "$ROOT/tools/run_config.py" --config "$@" --steps 256
     done
 done
+echo "== SURVEY 8d's dense-observation mode: full rewrite, tracked, tracked with the reference-default options" && date
+python3 "$ROOT/tools/bench_dense_obs.py" > "$OUT/dense_live.json" 2> "$OUT/dense_live.err"
+python3 "$ROOT/tools/bench_dense_obs.py" --inverts > "$OUT/dense_default_live.json" 2>> "$OUT/dense_live.err"
+for RUN in "dense --modes dense" "tracked --modes tracked" "tracked_default --modes tracked --inverts"; do
+    set -- $RUN
+    NAME=$1; shift
+    stats_pass "$NAME" "$ROOT/tools/bench_dense_obs.py" "$@"
+    for C in FETCH_SIZE WRITE_SIZE; do
+        pmc_pass "$NAME" $C "$ROOT/tools/bench_dense_obs.py" "$@" --replays 2
+    done
+done
 echo "== post-processing on the box: traffic.json + the files bench.py reads" && date
-mkdir -p "$OUT/r03"
-python3 "$ROOT/tools/pmc_traffic.py" "$OUT" "$OUT/r03" > "$OUT/pmc_traffic.log" 2>&1
-mkdir -p "$ROOT/profiles/r03" && cp "$OUT/r03/"* "$ROOT/profiles/r03/"   # the box's copy of the repo: bench.py below reads them
+mkdir -p "$OUT/r04"
+python3 "$ROOT/tools/pmc_traffic.py" "$OUT" "$OUT/r04" > "$OUT/pmc_traffic.log" 2>&1
+cp "$OUT/dense_live.json" "$OUT/dense_default_live.json" "$OUT/r04/" 2>/dev/null
+mkdir -p "$ROOT/profiles/r04" && cp "$OUT/r04/"* "$ROOT/profiles/r04/"   # the box's copy of the repo: bench.py below reads them
 echo "== bench.py plain (reads the summaries made above)" && date
-cd "$ROOT" && python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/r03/bench_driver_args.json" 2> "$OUT/bench_driver_args.err"
-cd "$ROOT" && python3 bench.py > "$OUT/r03/bench_n1.json" 2> "$OUT/bench_n1.err"
+cd "$ROOT" && python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/r04/bench_driver_args.json" 2> "$OUT/bench_driver_args.err"
+cd "$ROOT" && python3 bench.py > "$OUT/r04/bench_n1.json" 2> "$OUT/bench_n1.err"
 echo "== the multi-GPU code path on one rank (qg_comm: RCCL + direct write cadences)" && date
-cd "$ROOT" && python3 bench.py --force-multi --shard 3/8 --steps 20 --warmup 5 --no-cpu-baseline --no-large-batch --no-default-config --no-configs --no-collector > "$OUT/r03/bench_force_multi_rank3of8.json" 2> "$OUT/bench_force_multi.err"
-cd "$ROOT" && python3 bench.py --gpus 2 --handover direct --ranks-share-gpu0 --steps 20 --warmup 5 --no-cpu-baseline --no-large-batch --no-default-config --no-configs --no-collector > "$OUT/r03/bench_two_ranks_one_gpu_direct.json" 2> "$OUT/bench_two_ranks.err"
-ls -la "$OUT" "$OUT/r03"
+cd "$ROOT" && python3 bench.py --force-multi --shard 3/8 --steps 20 --warmup 5 --no-cpu-baseline --no-large-batch --no-default-config --no-configs --no-collector > "$OUT/r04/bench_force_multi_rank3of8.json" 2> "$OUT/bench_force_multi.err"
+cd "$ROOT" && python3 bench.py --gpus 2 --handover direct --ranks-share-gpu0 --steps 20 --warmup 5 --no-cpu-baseline --no-large-batch --no-default-config --no-configs --no-collector > "$OUT/r04/bench_two_ranks_one_gpu_direct.json" 2> "$OUT/bench_two_ranks.err"
+ls -la "$OUT" "$OUT/r04"
