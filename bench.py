@@ -639,10 +639,10 @@ def main():
             env.step(actions[0])
             comm.gather(env, out=inline_out)
 
-        def rccl_legs():
-            per_step = timed(step_and_gather, 64)       # SURVEY 8e's literal cadence: one all-gather per env.step()
-            gather_only = timed(snapshot_and_gather, 16)  # snapshot + collective alone, nothing to overlap with
-            in_stream = timed(step_and_gather_in_stream, 64)
+        def rccl_legs():  # medians of three batches each
+            per_step = float(np.median([timed(step_and_gather, 32) for _ in range(3)]))       # SURVEY 8e's literal cadence: one all-gather per env.step()
+            gather_only = float(np.median([timed(snapshot_and_gather, 16) for _ in range(3)]))  # snapshot + collective alone, nothing to overlap with
+            in_stream = float(np.median([timed(step_and_gather_in_stream, 32) for _ in range(3)]))
             cadence.update({"per_step_gather_us": per_step * 1e6, "per_step_gather_value": B * n_gpus / per_step,
                             "in_stream_gather_us": in_stream * 1e6, "segment_gather_us": gather_only * 1e6})
 
@@ -674,10 +674,10 @@ def main():
                         step_push_wait()
                         comm.check()
 
-                def timed_legs():
+                def timed_legs():  # median of three batches: now and then a launch stalls for tens of ms (as in the collector leg)
                     timed(step_push_wait, 4)
-                    res["p2p_step"] = timed(step_push_wait, 64)
-                    res["p2p_only"] = timed(push_wait, 16)
+                    res["p2p_step"] = float(np.median([timed(step_push_wait, 32) for _ in range(3)]))
+                    res["p2p_only"] = float(np.median([timed(push_wait, 16) for _ in range(3)]))
 
                 def compare():
                     with torch.cuda.stream(stream):

@@ -78,6 +78,12 @@ assert np.array_equal(rows, (dense << np.arange(2 * N, dtype=np.uint64)).sum(axi
 print("packed CPU model == oracle after 32 steps (states, reward bits, success, is_final, depth)")
 
 nproc = len(os.sched_getaffinity(0))
+try:  # never more threads than the container may run at once (cgroup v2 cpu.max), as bench.py's cpu_baseline
+    q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+    if q != "max":
+        nproc = max(1, min(nproc, int(float(q) / float(per) + 0.5)))
+except Exception:
+    pass
 
 
 def rate(fn, threads, budget=2.0):
