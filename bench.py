@@ -36,7 +36,7 @@ import os
 # main thread to its first place, so the CPUs this process may use are counted before that)
 NPROC = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "threads")
+os.environ.setdefault("OMP_PLACES", "cores")  # one thread per physical core: with "threads" 16 threads share 8 cores' SMT siblings (3.2e7 against 5.3e7 env-steps/s)
 # multi-process GPU work on this pool needs dmabuf IPC (hipIpcGetMemHandle fails otherwise): set before anything can initialise HIP -- the
 # ranks may come from the driver's launcher, not from launch_ranks() below
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -108,7 +108,7 @@ def cpu_quota():
 def cpu_baseline(gateset, seed: int, budget_s: float = 2.0, repeats: int = 5):
     """Time the CPU oracle (a C port of the reference's scalar Rust path, one env object per env, OpenMP over envs like
     twisterl's rayon-over-clones) on this box's host cores: the configuration's own 65 536 envs, on ONE core and on ALL
-    cores the process may run on, threads pinned (OMP_PROC_BIND=close), median of `repeats` timed repeats each."""
+    cores the process may run on, one pinned thread per physical core (OMP_PLACES=cores, OMP_PROC_BIND=close), median of `repeats` timed repeats each."""
     from oracle import OracleEnv, OracleVec
 
     nproc = NPROC
@@ -147,7 +147,7 @@ def cpu_baseline(gateset, seed: int, budget_s: float = 2.0, repeats: int = 5):
         "cores": threads,
         "kind": "port",
         "sample": f"CliffordGym 16q, {B} envs x {nall} steps per repeat, median of {repeats} repeats; C port of the reference scalar "
-                  f"path (byte-per-entry state, per-env objects, gcc -O3), OpenMP static over envs, threads pinned (OMP_PROC_BIND=close)",
+                  f"path (byte-per-entry state, per-env objects, gcc -O3), OpenMP static over envs, one thread per physical core (OMP_PLACES=cores, OMP_PROC_BIND=close)",
         "repeats": all_core_runs,
         "one_core": {"value": one_core, "cores": 1, "repeats": one_core_runs, "steps_per_repeat": n1},
         "nproc": nproc,
