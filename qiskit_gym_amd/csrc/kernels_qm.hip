@@ -919,6 +919,76 @@ __global__ __launch_bounds__(256) void qm_dense_stream_kernel(ObsArgs a, uint32_
     }
 }
 
+// The same for every other matrix size of the layout (D <= 32 rows, any N: CliffordEnv 3..15 qubits, LinearFunctionEnv 9..31): the tile's output
+// is still one contiguous run of 64 * D * D bytes, a lane still owns an aligned 16-byte chunk of it, but a chunk's bytes now cross rows and
+// envs: the lane walks (env, row, column) byte by byte from one division at its start.  (The row-per-thread export kernel wrote a byte per
+// store instruction: 0.6 TB/s.)
+__global__ __launch_bounds__(256) void qm_dense_stream_any_kernel(ObsArgs a, uint32_t nxp, uint32_t has_z) {
+    constexpr uint32_t PITCH = 33u;
+    __shared__ uint32_t lds[4][64 * PITCH];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t n_tiles = (a.B + 63u) / 64u;
+    const uint64_t tile_idx = (uint64_t)blockIdx.x * 4u + wave;
+    if (tile_idx >= n_tiles) return;  // wave-private LDS, no workgroup barrier below
+    uint32_t *my = lds[wave];
+    const uint32_t N = a.N, D = a.D, DD = D * D, R = has_z ? 2u * nxp : nxp, G = R / 4u;
+    const uint4 *tile = reinterpret_cast<const uint4 *>(a.state) + tile_idx * (uint64_t)(G * 64u);
+    uint4 vs[8];  // R <= 32 slots: all groups in flight at once
+#pragma unroll
+    for (uint32_t g = 0; g < 8; ++g) vs[g] = g < G ? tile[g * 64u + lane] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (uint32_t g = 0; g < 8; ++g) {
+        if (g >= G) break;
+        const uint32_t w[4] = {vs[g].x, vs[g].y, vs[g].z, vs[g].w};
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) {
+            const uint32_t slot = 4u * g + c, j = has_z ? slot >> 1 : slot;
+            if (j < N) my[lane * PITCH + ((has_z && (slot & 1u)) ? N + j : j)] = w[c];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t env0 = tile_idx * 64u;
+    const uint32_t envs = a.B - env0 < 64u ? (uint32_t)(a.B - env0) : 64u;
+    uint8_t *out = reinterpret_cast<uint8_t *>(a.out) + env0 * (uint64_t)DD;
+    const uint32_t n_bytes = envs * DD;
+    // (env, row, column) of the lane's first byte by division, once; every later chunk is 1 024 bytes further on: wave-uniform increments
+    uint32_t f = 16u * lane;
+    uint32_t e = f / DD, rem = f - e * DD, r = rem / D, c = rem - r * D;
+    const uint32_t adv_e = 1024u / DD, adv_rem = 1024u - adv_e * DD, adv_r = adv_rem / D, adv_c = adv_rem - adv_r * D;
+    for (; f < n_bytes; f += 1024u) {
+        // the chunk's 16 entries as bits: the rest of row r, then whole rows, then the head of a last one (D >= 3: at most six pieces)
+        uint32_t bits = 0, filled = 0, pe = e, pr = r, pc = c;
+        while (filled < 16u && pe < envs) {
+            const uint32_t take = (16u - filled) < (D - pc) ? (16u - filled) : (D - pc);
+            bits |= ((my[pe * PITCH + pr] >> pc) & ((1u << take) - 1u)) << filled;
+            filled += take;
+            pc = 0;
+            if (++pr == D) {
+                pr = 0;
+                ++pe;
+            }
+        }
+        const uint4 v = expand16_i8(bits);
+        if (n_bytes - f >= 16u) {
+            *reinterpret_cast<uint4 *>(out + f) = v;
+        } else {  // the ragged last tile's last, partial chunk
+            const uint32_t o[4] = {v.x, v.y, v.z, v.w};
+            for (uint32_t b = 0; b < n_bytes - f; ++b) out[f + b] = (uint8_t)(o[b >> 2] >> (8u * (b & 3u)));
+        }
+        c += adv_c;
+        if (c >= D) {
+            c -= D;
+            ++r;
+        }
+        r += adv_r;
+        if (r >= D) {
+            r -= D;
+            ++e;
+        }
+        e += adv_e;
+    }
+}
+
 // Dense observation in the policy's dtype straight from the tiles: one thread per 16-byte output
 // chunk (D % (16 / ES) == 0), so a wave's store is 1 KiB contiguous; the 4..16 threads that share a
 // row read the same resident word (cache hit).
@@ -1093,6 +1163,9 @@ hipError_t qm_export(const ObsArgs &a, uint32_t nxp, bool has_z, hipStream_t s) 
         else hipLaunchKernelGGL(qm_dense_stream_kernel<1>, grid, block, 0, s, a, has_z ? 1u : 0u);
         return hipGetLastError();
     }
+    case plan::EK_DENSE_STREAM_ANY:
+        hipLaunchKernelGGL(qm_dense_stream_any_kernel, dim3((unsigned)((a.B + 255) / 256)), dim3(256), 0, s, a, nxp, has_z ? 1u : 0u);
+        return hipGetLastError();
     case plan::EK_PACK:
         hipLaunchKernelGGL(qm_pack_kernel, dim3((unsigned)((a.B + 255) / 256)), dim3(256), 0, s, a, nxp, has_z ? 1u : 0u);
         return hipGetLastError();

@@ -240,13 +240,14 @@ constexpr bool tile_coop_fits(uint32_t R, uint32_t word_bytes) { return 16ull * 
 inline bool reset_step_fusable(const HandlePlan &p) { return p.layout == LAYOUT_TILE && p.has_bad && !(p.flags & F_INVERTS) && p.has_done_list; }
 
 // ---- observations / state export (TILE) ----------------------------------------------------------------------------------------------
-enum ExportKernel { EK_GENERIC = 0, EK_DENSE_STREAM, EK_PACK, EK_WORDS_THEN_EXPAND };
+enum ExportKernel { EK_GENERIC = 0, EK_DENSE_STREAM, EK_DENSE_STREAM_ANY, EK_PACK, EK_WORDS_THEN_EXPAND };
 inline const char *export_kernel_name(ExportKernel k) {
-    return k == EK_DENSE_STREAM ? "qm_dense_stream_kernel" : k == EK_PACK ? "qm_pack_kernel" : k == EK_WORDS_THEN_EXPAND ? "row words + expand" : "export_kernel";
+    return k == EK_DENSE_STREAM ? "qm_dense_stream_kernel" : k == EK_DENSE_STREAM_ANY ? "qm_dense_stream_any_kernel" : k == EK_PACK ? "qm_pack_kernel" : k == EK_WORDS_THEN_EXPAND ? "row words + expand" : "export_kernel";
 }
 // kernels_qm.hip qm_export: `R` = row slots of the layout (2 nxp with Z rows)
 inline ExportKernel tile_export(uint32_t format, uint32_t D, uint32_t R, uint64_t out_stride, bool aligned16, bool aligned4) {
     if (format == QG_FMT_U8 && D == R && (D == 16 || D == 32) && out_stride == (uint64_t)D * D && aligned16) return EK_DENSE_STREAM;
+    if (format == QG_FMT_U8 && D <= 32 && out_stride == (uint64_t)D * D && aligned16) return EK_DENSE_STREAM_ANY;  // any other size of the layout
     if (format == QG_FMT_PACKED && out_stride == D && D <= 32 && aligned4) return EK_PACK;
     return EK_GENERIC;
 }

@@ -117,8 +117,9 @@ def test_reset_done_paths(kind, n, batch, difficulty, count, want):
 def test_observation_and_state_paths():
     assert plan("clifford", 16, OBS_DENSE, **PLAIN) == "qm_dense_stream_kernel"
     assert plan("clifford", 8, OBS_DENSE, **PLAIN) == "qm_dense_stream_kernel"
-    assert plan("clifford", 5, OBS_DENSE, **PLAIN) == "export_kernel"          # 10 rows: no 16-byte chunks
-    assert plan("clifford", 12, OBS_DENSE, **PLAIN) == "export_kernel"
+    assert plan("clifford", 5, OBS_DENSE, **PLAIN) == "qm_dense_stream_any_kernel"   # 10 rows: 16-byte chunks cross rows and envs
+    assert plan("clifford", 12, OBS_DENSE, **PLAIN) == "qm_dense_stream_any_kernel"
+    assert plan("linear_function", 9, OBS_DENSE, **PLAIN) == "qm_dense_stream_any_kernel"
     assert plan("linear_function", 32, OBS_DENSE, **PLAIN) == "qm_dense_stream_kernel"
     assert plan("linear_function", 16, OBS_DENSE, **PLAIN) == "qm_dense_stream_kernel"
     assert plan("clifford", 24, OBS_DENSE, **PLAIN) == "row words + expand"

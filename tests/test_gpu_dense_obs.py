@@ -16,9 +16,10 @@ def _dev(a, dtype):
 
 
 TRACKED = [("clifford", 16), ("clifford", 8), ("linear_function", 16), ("linear_function", 32)]
+ANY_SIZE = [("clifford", 3), ("clifford", 5), ("clifford", 12), ("clifford", 15), ("linear_function", 9), ("linear_function", 13), ("linear_function", 31)]
 
 
-@pytest.mark.parametrize("kind,n", TRACKED)
+@pytest.mark.parametrize("kind,n", TRACKED + ANY_SIZE)
 @pytest.mark.parametrize("batch", [1, 63, 64, 1000])
 def test_streaming_dense_observation_matches_oracle(kind, n, batch):
     """qg_vec_observe_dense on the shapes the streaming kernel serves, ragged last tile included."""
