@@ -10,7 +10,7 @@ if os.environ.get('QG_LIB'):
 from qiskit_gym_amd.vec import VecEnv
 from util import line_gateset
 
-gs = line_gateset("clifford", 16); B, AT, seed = 65536, 128, 7
+gs = line_gateset("clifford", 16); B, AT, seed = int(os.environ.get("B", "65536")), 128, 7
 A = len(gs)
 env = VecEnv("clifford", 16, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=256)
 acts = torch.randint(0, A, (AT, B), dtype=torch.int32, device="cuda")
