@@ -185,7 +185,7 @@ __device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds,
 // (W3 W2) (W1 W0).  With columns on the lanes, column j of A B is A times column j of B: the xor of A's columns s over the set bits s of
 // the lane's own word -- A's 32 column words read from LDS, 64 vector instructions (~0.3 us).  The dependent chain is n / 8 gates + three
 // products (n = 256: 32 steps of ~45 ns instead of 64 gates of 73).
-// Rows come back by ballot: row word of slot s = the lanes' bits s.  Returns true on the one lane (lane 0 of wave 0) that finishes the env.
+// Rows come back by ballot: row word of slot s = the lanes' bits s, kept by lane s.  Returns true on the 64 lanes of wave 0, which finish the env together.
 // `prod`: 4 x 32 words of LDS; `gates`: 4 x 64 uint4 of LDS (16-byte aligned); `table`: the row-operation table in LDS (the caller brings it
 // in while the list length is still in flight), or null: read a.rowops; `env`: list[vblock], loaded by the caller.  blockDim.x must be 256.
 constexpr uint32_t QG_TREE_THREADS = plan::TREE_THREADS;
@@ -194,7 +194,7 @@ constexpr uint32_t QG_TREE_MAX_ENVS = plan::TREE_MAX_ENVS;
 template <int R>
 __device__ inline uint32_t gf2_cols_product(const uint32_t *a_cols, uint32_t b) {  // this lane's column of A B; a_cols[s] = column s of A
     uint32_t acc = 0;
-#pragma unroll
+#pragma unroll 8
     for (int sl = 0; sl < R; ++sl) acc ^= a_cols[sl] & (uint32_t)__builtin_amdgcn_sbfe((int32_t)b, (uint32_t)sl, 1u);
     return acc;
 }
@@ -215,7 +215,7 @@ __device__ inline uint4 rowop_masks(uint32_t o) {
     return r;
 }
 template <int R, typename Identity>
-__device__ inline bool scramble_tree(const InitArgs &a, uint32_t count, uint64_t &env, uint32_t (&rows_out)[R], uint32_t (*prod)[32], uint4 (*gates)[QG_WAVE],
+__device__ inline bool scramble_tree(const InitArgs &a, uint32_t count, uint64_t &env, uint32_t &row_out, uint32_t (*prod)[32], uint4 (*gates)[QG_WAVE],
                                      const uint32_t *table, Identity identity, uint32_t vblock) {
     static_assert(R <= 32, "one uint32 of slots per column");
     const uint64_t item = vblock;
@@ -228,7 +228,7 @@ __device__ inline bool scramble_tree(const InitArgs &a, uint32_t count, uint64_t
     uint32_t col;
     if (k == 0) {
         col = 0;
-#pragma unroll
+#pragma unroll 4
         for (int sl = 0; sl < R; ++sl) col |= ((identity((uint32_t)sl) >> hl) & 1u) << sl;  // clifford.rs:307
     } else {
         col = hl < (uint32_t)R ? 1u << hl : 0u;
@@ -276,9 +276,16 @@ __device__ inline bool scramble_tree(const InitArgs &a, uint32_t count, uint64_t
     __syncthreads();
     if (w != 0) return false;
     if (!half) col = gf2_cols_product<R>(prod[2], col);
-#pragma unroll
-    for (int sl = 0; sl < R; ++sl) rows_out[sl] = (uint32_t)__ballot(!half && ((col >> sl) & 1u));
-    return lane == 0;
+    // rows come back by ballot, ONE PER LANE: lane s keeps the row of slot s (R uniform row words in scalar registers cost the caller
+    // hundreds of spilled SGPRs and a one-lane finish of ~500 instructions; with a row per lane the finish is a handful of wave instructions)
+    uint32_t my_row = 0;
+#pragma unroll 8
+    for (int sl = 0; sl < R; ++sl) {
+        const uint32_t rw = (uint32_t)__ballot(!half && ((col >> sl) & 1u));
+        my_row = lane == (uint32_t)sl ? rw : my_row;
+    }
+    row_out = my_row;
+    return true;  // on all 64 lanes of wave 0
 }
 
 // The same for 64-bit rows (TILE64: CliffordEnv 16 < N <= 32, LinearFunctionEnv 32 < N <= 64): R <= 64 slots in a uint64 per column, all

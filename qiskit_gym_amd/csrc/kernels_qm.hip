@@ -660,6 +660,49 @@ __device__ inline void qm_init_finish(const InitArgs &a, uint64_t env, const QmR
     }
 }
 
+// qm_init_finish for a reset env whose rows sit one per lane (scramble_tree: lane s holds the row of slot s): called by the 64 lanes of a wave.
+// Lane s stores its 4 bytes of the tile (four lanes = one 16-byte group) and its row of the dense observation, the `bad` mask and `solved` come
+// from one ballot, lane 0 writes the scalars (reset_internals, clifford.rs:272-283; identity + gates is symplectic).
+template <int NXP, bool HAS_Z>
+__device__ inline void qm_init_finish_wave(const InitArgs &a, uint64_t env, uint32_t myrow) {
+    using Rows = QmRows<NXP, HAS_Z>;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1), le = (uint32_t)(env & (QG_WAVE - 1)), N = a.N;
+    uint32_t *tile = reinterpret_cast<uint32_t *>(reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Rows::G * 64));
+    const bool slot = lane < (uint32_t)Rows::R;
+    const uint32_t j = HAS_Z ? lane >> 1 : lane;  // the slot's qubit / row
+    const uint32_t ident = (slot && j < N) ? ((HAS_Z && (lane & 1u)) ? (1u << N) << j : 1u << j) : 0u;
+    if (slot) tile[((lane >> 2) * 64u + le) * 4u + (lane & 3u)] = myrow;
+    const uint64_t differs = __ballot(slot && myrow != ident);
+    if constexpr (Rows::R % 16 == 0) {  // qg_vec_track_dense: the env's whole dense observation, a row per lane
+        if (a.dense && slot) dense_row_store<Rows::R / 16>(a.dense, env, HAS_Z ? ((lane & 1u) ? N + j : j) : lane, myrow);
+    }
+    if (lane != 0) return;
+    uint32_t bad = (uint32_t)differs;
+    if constexpr (HAS_Z) {  // bit j: slot 2j or 2j + 1 differs
+        uint32_t t = (bad | (bad >> 1)) & 0x55555555u;
+        t = (t | (t >> 1)) & 0x33333333u;
+        t = (t | (t >> 2)) & 0x0F0F0F0Fu;
+        t = (t | (t >> 4)) & 0x00FF00FFu;
+        bad = (t | (t >> 8)) & 0x0000FFFFu;
+    }
+    const bool solved = differs == 0;
+    if (a.bad) a.bad[env] = bad;
+    a.depth[env] = a.depth_value;
+    a.success[env] = (uint8_t)solved;
+    a.reward[env] = solved ? 1.0f : 0.0f;
+    a.done[env] = (uint8_t)(a.depth_value == 0 || solved);
+    a.inverted[env] = (uint8_t)((HAS_Z && a.check_symplectic) ? QM_FLAG_SYMPLECTIC : 0u);
+    a.error[env] = 0;
+    a.sol_len[env * 2] = 0;
+    a.sol_len[env * 2 + 1] = 0;
+    if (a.layers) {
+        const LayerRec lay = layer_rec(a.layers, env, a.layers_len);
+        for (uint32_t i = 0; i + 2 < a.layers_len; ++i) lay[i] = -1;
+        lay[a.layers_len - 2] = 0;
+        lay[a.layers_len - 1] = 0;
+    }
+}
+
 // set_state / reset / reset_done for the thread's env: the work of one workgroup of the init kernel.  `vblock`: the workgroup's index among the
 // workgroups doing this work.  Returns true on the threads that finished an env (`env`: which one) -- every thread of the full-batch
 // modes, one lane per env of the cooperative list scrambles.
@@ -693,16 +736,16 @@ __device__ __forceinline__ bool qm_init_block(const InitArgs &a, uint32_t vblock
         const uint32_t count = list_count_take(a.list_count, (coop_fits && a.coop) ? a.B : 0, tree ? QG_TREE_THREADS : QG_COOP_LANES, vblock);
         if (tree) {  // few finished envs, long scrambles: a workgroup each, the matrix by columns, the gate sequence cut in eight (scramble_tree)
             const uint32_t N = a.N;
-            Rows s;
+            uint32_t myrow = 0;
             env = tree_env;
-            if (!scramble_tree<Rows::R>(a, count, env, s.r, reinterpret_cast<uint32_t(*)[32]>(&lds_rows[0][0][0]), tree_gates, table_fits ? tree_table : nullptr,
+            if (!scramble_tree<Rows::R>(a, count, env, myrow, reinterpret_cast<uint32_t(*)[32]>(&lds_rows[0][0][0]), tree_gates, table_fits ? tree_table : nullptr,
                                         [N](uint32_t k) -> uint32_t {
                     const uint32_t j = HAS_Z ? k >> 1 : k;
                     return j < N ? ((HAS_Z && (k & 1u)) ? (1u << N) << j : 1u << j) : 0u;
                 }, vblock))
                 return false;
-            qm_init_finish<NXP, HAS_Z>(a, env, s);
-            return true;
+            qm_init_finish_wave<NXP, HAS_Z>(a, env, myrow);  // the 64 lanes of wave 0
+            return (threadIdx.x & (QG_WAVE - 1)) == 0;
         }
         if (plan::list_reset_path(count, a.n_draws, a.B, a.coop != 0, coop_fits) == plan::RP_COOP) {  // few finished envs: 16 lanes each
             const uint32_t N = a.N;
