@@ -322,9 +322,37 @@ __global__ __launch_bounds__(256) void pack_bitstream_kernel(const T *src, uint6
     const uint64_t m = __ballot(one);
     if ((threadIdx.x & 63u) == 0 && (gid >> 6) < (n_entries + 63u) / 64u) out[gid >> 6] = m;
 }
+// int64 entries, 16 bytes per lane: lane l of the wave that owns entries [128 i, 128 i + 128) loads entries 128 i + 2 l and + 2 l + 1 (1 KiB per wave
+// instruction instead of 512 bytes); the two ballots are the even and the odd entries' bits, interleaved on the scalar unit into stream
+// words 2 i and 2 i + 1.  n_entries even and src 16-byte aligned (the launcher checks).
+__device__ inline uint64_t spread_bits32(uint64_t x) {  // bit k of the low word -> bit 2 k
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+__global__ __launch_bounds__(256) void pack_bitstream_i64x2_kernel(const int64_t *src, uint64_t n_entries, uint64_t *out) {
+    typedef int64_t i64x2 __attribute__((ext_vector_type(2)));
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, e0 = 2u * gid;
+    i64x2 v = {0, 0};
+    if (e0 < n_entries) v = reinterpret_cast<const i64x2 *>(src)[gid];  // (n_entries is even)
+    const uint64_t even = __ballot(v.x > 0), odd = __ballot(v.y > 0);
+    if ((threadIdx.x & 63u) == 0) {
+        const uint64_t w = gid >> 6, n_words = (n_entries + 63u) / 64u;  // this wave's entries: stream words 2 w and 2 w + 1
+        if (2u * w < n_words) out[2u * w] = spread_bits32(even & 0xFFFFFFFFull) | (spread_bits32(odd & 0xFFFFFFFFull) << 1);
+        if (2u * w + 1u < n_words) out[2u * w + 1u] = spread_bits32(even >> 32) | (spread_bits32(odd >> 32) << 1);
+    }
+}
 
 hipError_t pack_bitstream(const void *src, int elem_bytes, uint64_t n_entries, uint64_t *out_words, hipStream_t s) {
     if (!n_entries) return hipSuccess;
+    if (elem_bytes == 8 && !(n_entries & 1u) && !(reinterpret_cast<uintptr_t>(src) & 15u)) {
+        const unsigned grid = blocks_for((n_entries / 2u + 63u) / 64u * 64u, 256);
+        hipLaunchKernelGGL(pack_bitstream_i64x2_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const int64_t *>(src), n_entries, out_words);
+        return hipGetLastError();
+    }
     const unsigned grid = blocks_for((n_entries + 63u) / 64u * 64u, 256);
     if (elem_bytes == 8) hipLaunchKernelGGL(pack_bitstream_kernel<int64_t>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const int64_t *>(src), n_entries, out_words);
     else hipLaunchKernelGGL(pack_bitstream_kernel<int8_t>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const int8_t *>(src), n_entries, out_words);
