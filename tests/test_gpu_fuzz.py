@@ -156,3 +156,98 @@ def test_random_pauli_networks(seed):
     if cfg["track_solution"]:
         for e in {0, batch - 1}:
             assert gv.solution(e) == envs[e].solution(), (label, e)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_auto_reset_loops_with_tracked_observations(seed):
+    """Random interleavings of the calls a collection loop makes -- step, reset_done, reset_done_step (one launch), whole resets, rollouts --
+    on random gatesets and sizes of the 32-bit-row layout, with and without a tracked dense observation, against a twin handle that only uses
+    the plain calls (step + reset_done + observe) and, for the first envs, against the oracle: flags, depths, reward bits after every call,
+    states and observations at the end."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    seed += SEED_OFFSET + 5000
+    rng = np.random.default_rng(seed)
+    kind = ["clifford", "linear_function"][seed % 2]
+    n = int(rng.choice([3, 8, 12, 16] if kind == "clifford" else [9, 16, 24, 32]))
+    gs = random_gateset(rng, n, int(rng.integers(2, 30)), allow_equal=False)
+    A = len(gs)
+    B = int(rng.choice([64, 130, 257, 1024, 4096]))
+    diff = int(rng.choice([1, 2, 5, 70]))
+    cfg = dict(add_inverts=False, add_perms=False, track_solution=bool(rng.integers(2)), difficulty=diff, depth_slope=int(rng.integers(1, 3)),
+               max_depth=int(rng.integers(2, 9)))
+    a, twin = VecEnv(kind, n, gs, B, **cfg), VecEnv(kind, n, gs, B, **cfg)
+    trackable = (2 * n if kind == "clifford" else n) in (16, 32)
+    dense = a.track_dense() if trackable and rng.integers(2) else None
+    ne = min(B, 96)
+    envs = [OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()}) for _ in range(ne)]
+    label = f"seed={seed} {kind} n={n} A={A} B={B} {cfg} dense={dense is not None}"
+
+    def oracle_reset(seed_, only_done):
+        from util import rng_actions
+        d = rng_actions(seed_, ne, diff, A)
+        for e, o in enumerate(envs):
+            if not only_done or o.is_final():
+                o.reset_with(d[:, e])
+
+    def compare(what):
+        a.sync()
+        twin.sync()
+        assert torch.equal(a.reward.view(torch.int32), twin.reward.view(torch.int32)) and torch.equal(a.done, twin.done), (what, label)
+        assert torch.equal(a.depth, twin.depth) and torch.equal(a.success, twin.success), (what, label)
+        np.testing.assert_array_equal(f32_bits(a.reward.cpu().numpy()[:ne]), np.array([o.reward_bits() for o in envs], dtype=np.uint32), err_msg=f"{what} {label}")
+        np.testing.assert_array_equal(a.done.cpu().numpy()[:ne].astype(bool), [o.is_final() for o in envs], err_msg=f"{what} {label}")
+
+    a.reset(seed)
+    twin.reset(seed)
+    oracle_reset(seed, False)
+    for t in range(40):
+        op = int(rng.integers(10))
+        acts = rng.integers(-1, A + 1, size=B)
+        ta = torch.as_tensor(acts, device="cuda", dtype=torch.int64 if t % 2 else torch.int32)
+        s2 = int(rng.integers(1 << 30))
+        if op < 5:  # the collection loop's pair, as one call
+            a.reset_done_step(s2, ta)
+            twin.reset_done(s2)
+            twin.step(ta)
+            oracle_reset(s2, True)
+            for o, x in zip(envs, acts[:ne]):
+                o.step(int(x), 0)
+        elif op < 7:  # the two calls
+            for h in (a, twin):
+                h.reset_done(s2)
+                h.step(ta)
+            oracle_reset(s2, True)
+            for o, x in zip(envs, acts[:ne]):
+                o.step(int(x), 0)
+        elif op == 7:  # a plain step (finished envs keep stepping: the trait allows it) -- unless the log would overflow
+            if cfg["track_solution"]:
+                continue
+            for h in (a, twin):
+                h.step(ta)
+            for o, x in zip(envs, acts[:ne]):
+                o.step(int(x), 0)
+        elif op == 8:  # everybody starts over
+            for h in (a, twin):
+                h.reset(s2)
+            oracle_reset(s2, False)
+        else:  # a graph rollout of three steps after a reset_done
+            if cfg["track_solution"] and cfg["max_depth"] < 4:
+                continue
+            seq = rng.integers(0, A, size=(3, B))
+            tseq = torch.as_tensor(seq, device="cuda", dtype=torch.int32)
+            for h in (a, twin):
+                h.reset(s2)
+                h.rollout(tseq)
+            oracle_reset(s2, False)
+            for k in range(3):
+                for o, x in zip(envs, seq[k][:ne]):
+                    o.step(int(x), 0)
+        compare(f"t={t} op={op}")
+        if dense is not None:
+            assert torch.equal(dense, twin.observe()), (t, op, label)
+    assert torch.equal(a.get_state("packed"), twin.get_state("packed")), label
+    np.testing.assert_array_equal(a.get_state("i64").cpu().numpy()[:ne], np.stack([o.get_state() for o in envs]), err_msg=label)
+    if cfg["track_solution"]:
+        for e in (0, ne - 1):
+            assert a.solution(e) == envs[e].solution() == twin.solution(e), (label, e)
