@@ -300,58 +300,63 @@ __device__ inline uint64_t gf2_cols_product64(const uint64_t *a_cols, uint64_t b
 }
 // Returns true on ALL lanes of wave 0, whose `col` is then the finished matrix by columns (the caller turns it into rows: 64 row words in
 // one lane's registers cost the caller 450 registers and scratch with CliffordEnv's finish, so q64_reset_tree_kernel keeps one row per lane).
+// 64-bit counterparts of rowop_parity / rowop_masks
+__device__ inline void rowop_parity64(uint64_t &col, uint64_t test, uint64_t flip) {
+    col ^= (uint64_t)(0ll - (long long)(__builtin_popcountll(col & test) & 1)) & flip;
+}
+struct RowopMasks64 {
+    uint64_t t0, f0, t1, f1;
+};
+__device__ inline RowopMasks64 rowop_masks64(uint32_t o) {
+    auto half = [](uint32_t op, uint64_t &test, uint64_t &flip) {
+        const uint32_t type = (op >> 12) & 3u;
+        const uint64_t bd = 1ull << (op & 63u), bs = 1ull << ((op >> 6) & 63u);
+        test = type == OP_NONE ? 0ull : (type == OP_SWAP ? bs | bd : bs);
+        flip = type == OP_NONE ? 0ull : (type == OP_SWAP ? bs | bd : bd);
+    };
+    RowopMasks64 r;
+    half(o & 0x3FFFu, r.t0, r.f0);
+    half(o >> 14, r.t1, r.f1);
+    return r;
+}
+// `gates`: 4 x 64 RowopMasks64 of LDS (8 KiB): the drawing lane decodes its gate into the four parity-test masks, the serial loop reads them
+// back as a broadcast, two gates ahead (scramble_tree's scheme; a 64-column matrix fills the wave, so a wave runs one segment: four segments)
 template <int R, typename Identity>
-__device__ inline bool scramble_tree64(const InitArgs &a, uint32_t count, uint64_t &env, uint64_t &col_out, uint64_t (*prod)[64], Identity identity) {
+__device__ inline bool scramble_tree64(const InitArgs &a, uint32_t count, uint64_t &env, uint64_t &col_out, uint64_t (*prod)[64], RowopMasks64 (*gates)[QG_WAVE],
+                                       Identity identity) {
     static_assert(R <= 64, "one uint64 of slots per column");
     const uint64_t item = blockIdx.x;
     if (item >= count) return false;
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1), w = threadIdx.x >> 6;
     env = a.list[item];
-    const uint32_t seg = (a.n_draws + 3u) / 4u, t0 = w * seg, t1 = (t0 + seg < a.n_draws) ? t0 + seg : a.n_draws;
+    const uint32_t seg = (a.n_draws + 3u) / 4u, t0 = w * seg < a.n_draws ? w * seg : a.n_draws, t1 = (t0 + seg < a.n_draws) ? t0 + seg : a.n_draws;
     uint64_t col = 0;
     if (w == 0) {
-#pragma unroll
+#pragma unroll 8
         for (int sl = 0; sl < R; ++sl) col |= ((identity((uint32_t)sl) >> lane) & 1ull) << sl;  // clifford.rs:307
     } else {
         col = lane < (uint32_t)R ? 1ull << lane : 0ull;
     }
     const uint64_t seed = init_seed(a);
-    auto rowop = [&](uint32_t src, uint32_t dst, int64_t swap, uint64_t m) {
-        const int64_t bs = bit_mask64(col, src), bd = bit_mask64(col, dst);
-        col ^= (uint64_t)(bs ^ (bd & swap)) & m;
-    };
-    auto mask_of = [](uint32_t op) -> uint64_t {
-        const uint32_t type = (op >> 12) & 3u, dst = op & 63u, src = (op >> 6) & 63u;
-        return ((uint64_t)(type != OP_NONE) << dst) | ((uint64_t)(type == OP_SWAP) << src);
-    };
-    auto lane64 = [](uint64_t v, uint32_t k) -> uint64_t {
-        return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)k) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)k) << 32);
-    };
-    for (uint32_t c0 = t0; c0 < t1; c0 += 2u * QG_WAVE) {
-        uint32_t o[2];
-        uint64_t m0[2], m1[2];
+    RowopMasks64 *mine = gates[w];
+    for (uint32_t c0 = t0; c0 < t1; c0 += QG_WAVE) {  // 64 gates per pass
+        const uint32_t t = c0 + lane;
+        const uint32_t o = t < t1 ? a.rowops[rng_action(seed, a.env_base + env, t, a.num_actions)] : 0u;  // past the end: "no gate"
+        __builtin_amdgcn_wave_barrier();  // (the previous pass has read its masks)
+        mine[lane] = rowop_masks64(o);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t left = t1 - c0, steps = left < QG_WAVE ? left : QG_WAVE;
+        RowopMasks64 g[2] = {mine[0], mine[1]};
+        for (uint32_t kk = 0; kk < steps; kk += 2u) {
+            const RowopMasks64 n0 = mine[(kk + 2u) & 63u], n1 = mine[(kk + 3u) & 63u];  // the next two gates fly while these two are applied
 #pragma unroll
-        for (uint32_t j = 0; j < 2; ++j) {
-            const uint32_t t = c0 + j * QG_WAVE + lane;
-            o[j] = t < t1 ? a.rowops[rng_action(seed, a.env_base + env, t, a.num_actions)] : 0u;
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < 2; ++j) {
-            m0[j] = mask_of(o[j] & 0x3FFFu);
-            m1[j] = mask_of(o[j] >> 14);
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < 2; ++j) {
-            if (c0 + j * QG_WAVE >= t1) break;
-            const uint32_t left = t1 - (c0 + j * QG_WAVE);
-            const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)(left < QG_WAVE ? left : QG_WAVE));
-            for (uint32_t k = 0; k < len; ++k) {
-                const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)o[j], (int)k);
-                const uint64_t ga = lane64(m0[j], k), gb = lane64(m1[j], k);
-                // (the builtin's result is unsigned: through int32_t, so that "swap" widens to 64 ones, not 32)
-                rowop((g >> 6) & 63u, g & 63u, (int64_t)(int32_t)__builtin_amdgcn_sbfe((int32_t)g, 13u, 1u), ga);
-                rowop((g >> 20) & 63u, (g >> 14) & 63u, (int64_t)(int32_t)__builtin_amdgcn_sbfe((int32_t)g, 27u, 1u), gb);
+            for (int q = 0; q < 2; ++q) {  // (an entry past `steps` is past the segment's end: zero masks)
+                rowop_parity64(col, g[q].t0, g[q].f0);
+                rowop_parity64(col, g[q].t1, g[q].f1);
             }
+            g[0] = n0;
+            g[1] = n1;
         }
     }
     if (w & 1u) prod[w][lane] = col;

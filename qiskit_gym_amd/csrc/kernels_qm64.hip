@@ -897,11 +897,12 @@ static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
 template <int NS, bool HAS_Z>
 __global__ __launch_bounds__(256) void q64_reset_tree_kernel(InitArgs a) {
     __shared__ uint64_t prod[4][64];
+    __shared__ RowopMasks64 tree_gates[4][QG_WAVE];
     if (!tree_takes(a.list_count[0], a.n_draws, a.B)) return;
     const uint32_t count = list_count_take(a.list_count, a.B, QG_TREE_THREADS);
     const uint32_t N = a.N;
     uint64_t env = 0, col = 0;
-    if (!scramble_tree64<NS>(a, count, env, col, prod, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); })) return;
+    if (!scramble_tree64<NS>(a, count, env, col, prod, tree_gates, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); })) return;
     // q64_init_finish with the wave's 64 lanes: lane s takes the row of slot s (ballot of the columns' bits s), stores its 8 bytes of the
     // env's tile and compares with the identity's; lane 0 writes the scalars (reset_internals, clifford.rs:272-283)
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
