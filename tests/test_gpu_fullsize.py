@@ -247,6 +247,73 @@ def test_auto_reset_with_desynchronised_episodes_at_full_size(kind, n, B, invert
             assert gv.solution(int(ids[i])) == envs[i].solution()
 
 
+@pytest.mark.parametrize("diff,L", [(8, 16), (128, 128)])
+def test_one_launch_auto_reset_with_a_tracked_observation_at_full_size(diff, L):
+    """The headline workload as a collector that reads the dense observation runs it: CliffordGym 16q x 65 536, qg_vec_track_dense, and
+    qg_vec_reset_done_step (reset_done + step in one launch) after a first step, episode ends spread evenly over time (1 / L of the batch
+    per step: L = 128, difficulty 128 is bench.py's auto-reset leg -- 512 finishers per step, scramble_tree).  Reward bits, is_final, depth of
+    a strided sample against the oracle after every step; at the end the states, and the resident observation against a full rewrite and
+    against the oracle."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    kind, n, B = "clifford", 16, 65536
+    gs = line_gateset(kind, n)
+    A = len(gs)
+    cfg = dict(add_inverts=False, add_perms=False, track_solution=False, difficulty=diff, depth_slope=2 if diff == 8 else 1, max_depth=128)
+    gv = VecEnv(kind, n, gs, B, **cfg)
+    dense = gv.track_dense()
+    ids = np.arange(0, B, 197)
+    envs = [OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()}) for _ in ids]
+
+    def oracle_reset(which, seed):
+        draws = rng_actions(seed, ids[which], diff, A)
+        for j, i in enumerate(which):
+            envs[i].reset_with(draws[:, j])
+
+    gv.reset(1)
+    oracle_reset(np.arange(len(ids)), 1)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(11)
+    all_env = torch.arange(B, device="cuda")
+    for k in range(L):  # Env::reset for class k at time k (the caller raises the flags: these resets compact the list from them)
+        acts = torch.randint(0, A, (B,), dtype=torch.int32, device="cuda", generator=gen)
+        gv.step(acts)
+        fin = gv.done.cpu().numpy()
+        a_h = acts.cpu().numpy()[ids]
+        for i, o in enumerate(envs):
+            o.step(int(a_h[i]), 0)
+        gv.reset_done(100 + k)
+        oracle_reset(np.nonzero(fin[ids])[0], 100 + k)
+        gv.done[all_env % L == k] = 1
+        gv.reset_done(5000 + k)
+        oracle_reset(np.nonzero(ids % L == k)[0], 5000 + k)
+    finished = 0
+    acts = torch.randint(0, A, (B,), dtype=torch.int32, device="cuda", generator=gen)
+    gv.step(acts)  # leaves the list and the is_final flags for the one-launch pairs that follow
+    a_h = acts.cpu().numpy()[ids]
+    for i, o in enumerate(envs):
+        o.step(int(a_h[i]), 0)
+    for t in range(2 * L + 7):
+        fin = gv.done.cpu().numpy()
+        frac = fin.mean()
+        assert 0.4 / L < frac < 2.5 / L, (t, frac)
+        finished += int(fin.sum())
+        acts = torch.randint(0, A, (B,), dtype=torch.int32, device="cuda", generator=gen)
+        gv.reset_done_step(9000 + t, acts)
+        gv.sync()
+        oracle_reset(np.nonzero(fin[ids])[0], 9000 + t)
+        a_h = acts.cpu().numpy()[ids]
+        for i, o in enumerate(envs):
+            o.step(int(a_h[i]), 0)
+        np.testing.assert_array_equal(f32_bits(gv.reward.cpu().numpy()[ids]), np.array([o.reward_bits() for o in envs], dtype=np.uint32), err_msg=f"t={t}")
+        np.testing.assert_array_equal(gv.done.cpu().numpy()[ids], [int(o.is_final()) for o in envs], err_msg=f"t={t}")
+        np.testing.assert_array_equal(gv.depth.cpu().numpy()[ids], [o.depth() for o in envs])
+    assert finished >= 2 * B
+    np.testing.assert_array_equal(gv.get_state("i64").cpu().numpy()[ids], np.stack([o.get_state() for o in envs]))
+    assert torch.equal(dense, gv.observe())
+    np.testing.assert_array_equal(dense.cpu().numpy()[ids].reshape(len(ids), -1), np.stack([o.dense_obs() for o in envs]).reshape(len(ids), -1))
+
+
 def test_config4_all_eight_shards_equal_the_whole_batch_x524288():
     """BASELINE config 4 (CliffordGym 16q, 524 288 envs, 8 ranks x 65 536) on one GPU: the WHOLE batch as one handle against each of the
     eight shards as its own handle with its env_base -- reset, 24 steps with auto-reset of finished episodes, then the learner shard every
