@@ -707,7 +707,7 @@ __device__ inline void qm_init_finish_wave(const InitArgs &a, uint64_t env, uint
 // workgroups doing this work.  Returns true on the threads that finished an env (`env`: which one) -- every thread of the full-batch
 // modes, one lane per env of the cooperative list scrambles.
 template <int NXP, bool HAS_Z>
-__device__ __forceinline__ bool qm_init_block(const InitArgs &a, uint32_t vblock, uint64_t &env) {
+__device__ __forceinline__ bool qm_init_block_work(const InitArgs &a, uint32_t vblock, uint64_t &env, ListTicket &ticket) {
     using Rows = QmRows<NXP, HAS_Z>;
     // reset scramble (device_common.hpp): the rows live in LDS (wave-private, [slot][lane]: conflict-free for
     // any per-lane slot), so a gate is dynamic-index reads and writes instead of a sweep over 32 registers
@@ -733,7 +733,7 @@ __device__ __forceinline__ bool qm_init_block(const InitArgs &a, uint32_t vblock
         // this kernel is the list's only reader.  The barrier inside list_count_take (workgroups with work) is also the one that makes the table
         // visible; it comes BEFORE the ticket, whose answer nobody waits for: a barrier after it made every workgroup wait its turn on the
         // ticket's address (512 workgroups: the last one entered its scramble 6 us after the first)
-        const uint32_t count = list_count_take(a.list_count, (coop_fits && a.coop) ? a.B : 0, tree ? QG_TREE_THREADS : QG_COOP_LANES, vblock);
+        const uint32_t count = list_count_take(a.list_count, (coop_fits && a.coop) ? a.B : 0, tree ? QG_TREE_THREADS : QG_COOP_LANES, vblock, &ticket);
         if (tree) {  // few finished envs, long scrambles: a workgroup each, the matrix by columns, the gate sequence cut in eight (scramble_tree)
             const uint32_t N = a.N;
             uint32_t myrow = 0;
@@ -803,6 +803,14 @@ __device__ __forceinline__ bool qm_init_block(const InitArgs &a, uint32_t vblock
     return true;
 }
 
+
+template <int NXP, bool HAS_Z>
+__device__ __forceinline__ bool qm_init_block(const InitArgs &a, uint32_t vblock, uint64_t &env) {
+    ListTicket ticket;  // the list's reader ticket: taken at the start, answered by the end (device_common.hpp)
+    const bool finished = qm_init_block_work<NXP, HAS_Z>(a, vblock, env, ticket);
+    ticket.done();
+    return finished;
+}
 
 template <int NXP, bool HAS_Z>
 __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
