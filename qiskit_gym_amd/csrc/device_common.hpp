@@ -59,33 +59,28 @@ __device__ inline void done_list_append_block(uint32_t *list, uint32_t *count, b
 // tickets on one address cost the launch 3.4 us); it may find the counter already zeroed and then sees an empty list, which for it is
 // the same thing.  An empty list needs neither tickets nor zeroing.  Call from all threads.
 // `vblock`: this block's index among the blocks that consume the list (blockIdx.x, or less an offset when the kernel's grid starts with other work)
-// `later`: the ticket is taken here but its answer is looked at by ListTicket::done at the END of the workgroup's work.  All tickets go to
-// one address, ~12 ns each, one after the other: with 512 workgroups the last answer comes 6 us after the first, and a thread that compares
-// it right away stalls its wave -- and, at the next barrier, its workgroup -- for that long.
-struct ListTicket {
-    uint32_t *counter = nullptr;  // non-null on the one thread that holds a ticket
-    uint32_t answer = 0, blocks = 0;
-    __device__ void done() const {
-        if (counter && answer == blocks - 1u) {  // the last workgroup with work to have read the length
-            counter[0] = 0;
-            counter[1] = 0;
-        }
-    }
-};
-__device__ inline uint32_t list_count_take(uint32_t *counter, uint64_t coop_B, uint32_t coop_lanes, uint32_t vblock, ListTicket *later = nullptr) {
-    const uint32_t count = counter[0];
-    if (count == 0) return 0;
+// `zero_other`: no ticket at all -- the handle keeps a list that nobody reads or appends to during this launch (qgym_api.cpp: the lists rotate),
+// this launch zeroes THAT list's length for whoever appends to it next, and the list consumed here is left as it is.  All tickets go to one
+// address, ~12 ns each, one after the other: with 512 workgroups the last answer comes 6 us after the first, the wave that took the ticket
+// waits for it (the compiler compares the answer where the atomic is) and, at the next barrier, so does its workgroup.
+// `known`: the length, when the caller has loaded counter[0] already.
+__device__ inline uint32_t list_blocks(uint32_t count, uint64_t coop_B, uint32_t coop_lanes) {  // workgroups with work (blockDim.x: a power of two)
     const uint64_t threads = (coop_B && (uint64_t)count * QG_COOP_LANES * 2 <= coop_B) ? (uint64_t)count * coop_lanes : (uint64_t)count;
-    const uint32_t blocks = (uint32_t)((threads + blockDim.x - 1) / blockDim.x);
+    return (uint32_t)((threads + blockDim.x - 1u) >> (31u - (uint32_t)__builtin_clz(blockDim.x)));  // (a 64-bit division costs ~150 scalar instructions)
+}
+__device__ inline uint32_t list_count_take(uint32_t *counter, uint64_t coop_B, uint32_t coop_lanes, uint32_t vblock, uint32_t *zero_other = nullptr,
+                                           const uint32_t *known = nullptr) {
+    if (zero_other && vblock == 0 && threadIdx.x == 0) {
+        zero_other[0] = 0;
+        zero_other[1] = 0;
+    }
+    const uint32_t count = known ? *known : counter[0];
+    if (count == 0) return 0;
+    const uint32_t blocks = list_blocks(count, coop_B, coop_lanes);
     if (vblock >= blocks) return count;  // (this block's threads all lie past the list)
     __syncthreads();
-    if (threadIdx.x == blockDim.x - 1u) {
-        const uint32_t answer = atomicAdd(&counter[1], 1u);
-        if (later) {
-            later->counter = counter;
-            later->answer = answer;
-            later->blocks = blocks;
-        } else if (answer == blocks - 1u) {
+    if (!zero_other && threadIdx.x == blockDim.x - 1u) {
+        if (atomicAdd(&counter[1], 1u) == blocks - 1u) {
             counter[0] = 0;
             counter[1] = 0;
         }

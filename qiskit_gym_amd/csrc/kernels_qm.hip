@@ -707,7 +707,7 @@ __device__ inline void qm_init_finish_wave(const InitArgs &a, uint64_t env, uint
 // workgroups doing this work.  Returns true on the threads that finished an env (`env`: which one) -- every thread of the full-batch
 // modes, one lane per env of the cooperative list scrambles.
 template <int NXP, bool HAS_Z>
-__device__ __forceinline__ bool qm_init_block_work(const InitArgs &a, uint32_t vblock, uint64_t &env, ListTicket &ticket) {
+__device__ __forceinline__ bool qm_init_block(const InitArgs &a, uint32_t vblock, uint64_t &env) {
     using Rows = QmRows<NXP, HAS_Z>;
     // reset scramble (device_common.hpp): the rows live in LDS (wave-private, [slot][lane]: conflict-free for
     // any per-lane slot), so a gate is dynamic-index reads and writes instead of a sweep over 32 registers
@@ -722,18 +722,24 @@ __device__ __forceinline__ bool qm_init_block_work(const InitArgs &a, uint32_t v
         __shared__ uint4 tree_gates[4][QG_WAVE];
         __shared__ uint32_t tree_table[QG_TREE_TABLE_MAX];
         const bool table_fits = a.coop && a.num_actions <= QG_TREE_TABLE_MAX;
+        // three trips to memory, all in flight together: the list's length, the entry this workgroup would scramble as a tree (any index below B
+        // is readable) and the table.  The first two are uniform, and a uniform load is waited for where it is issued (the compiler moves its
+        // result to a scalar register at once) -- three round trips one after the other.  An index the compiler cannot see through makes them
+        // ordinary vector loads, the clobber keeps them up here, and their values become scalars after the table has been requested.
+        uint32_t opaque_zero;
+        asm("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+        const uint32_t count_v = a.list_count[opaque_zero];
+        const uint32_t entry_v = a.coop ? a.list[(vblock < a.B ? vblock : 0u) + opaque_zero] : 0u;
+        asm volatile("" ::: "memory");
         if (table_fits)
             for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) tree_table[i] = a.rowops[i];
-        // the entry this workgroup would scramble as a tree, requested before the list's length is known (any index below B is readable)
-        const uint32_t tree_env = a.coop ? a.list[vblock < a.B ? vblock : 0u] : 0u;
+        const uint32_t count_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)count_v);
+        const uint32_t tree_env = (uint32_t)__builtin_amdgcn_readfirstlane((int)entry_v);
         // (a block past the list may see the count already zeroed: it has no work either way)
-        const plan::ResetPath path = plan::list_reset_path(a.list_count[0], a.n_draws, a.B, a.coop != 0, coop_fits);  // qgym_plan.hpp
+        const plan::ResetPath path = plan::list_reset_path(count_now, a.n_draws, a.B, a.coop != 0, coop_fits);  // qgym_plan.hpp
         const bool tree = path == plan::RP_TREE;
-        asm volatile("" ::"v"(tree_env));  // (keeps the entry's load up here, beside the length's: the compiler would sink it to its first use)
-        // this kernel is the list's only reader.  The barrier inside list_count_take (workgroups with work) is also the one that makes the table
-        // visible; it comes BEFORE the ticket, whose answer nobody waits for: a barrier after it made every workgroup wait its turn on the
-        // ticket's address (512 workgroups: the last one entered its scramble 6 us after the first)
-        const uint32_t count = list_count_take(a.list_count, (coop_fits && a.coop) ? a.B : 0, tree ? QG_TREE_THREADS : QG_COOP_LANES, vblock, &ticket);
+        // this kernel is the list's only reader.  The barrier inside list_count_take (workgroups with work) is also the one that makes the table visible
+        const uint32_t count = list_count_take(a.list_count, (coop_fits && a.coop) ? a.B : 0, tree ? QG_TREE_THREADS : QG_COOP_LANES, vblock, a.zero_count, &count_now);
         if (tree) {  // few finished envs, long scrambles: a workgroup each, the matrix by columns, the gate sequence cut in eight (scramble_tree)
             const uint32_t N = a.N;
             uint32_t myrow = 0;
@@ -803,14 +809,6 @@ __device__ __forceinline__ bool qm_init_block_work(const InitArgs &a, uint32_t v
     return true;
 }
 
-
-template <int NXP, bool HAS_Z>
-__device__ __forceinline__ bool qm_init_block(const InitArgs &a, uint32_t vblock, uint64_t &env) {
-    ListTicket ticket;  // the list's reader ticket: taken at the start, answered by the end (device_common.hpp)
-    const bool finished = qm_init_block_work<NXP, HAS_Z>(a, vblock, env, ticket);
-    ticket.done();
-    return finished;
-}
 
 template <int NXP, bool HAS_Z>
 __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {

@@ -223,7 +223,7 @@ static int vec_free_buffers(qg_vec *v) {
     void *ptrs[] = {v->state, v->own_depth ? v->depth : nullptr, v->own_reward ? v->reward : nullptr,
                     v->own_done ? v->done : nullptr, v->own_success ? v->success : nullptr, v->inverted, v->error, v->sol,
                     v->sol_len, v->layers, v->d_gates, v->d_descs, v->scratch, v->d_prog,
-                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad, v->done_list, v->done_list_alt, v->pend[0], v->pend[1], v->d_rowops, v->embed_dump, v->host_in, v->host_obs, v->fault_scratch};
+                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad, v->done_list, v->done_list_alt, v->done_list_spare, v->pend[0], v->pend[1], v->d_rowops, v->embed_dump, v->host_in, v->host_obs, v->fault_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &g : v->graphs) {
@@ -519,6 +519,10 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     if (hp.has_done_list) {
         HIP_TRY_V(hipMalloc(&p->done_list, sizeof(uint32_t) * (batch + 2)));
         HIP_TRY_V(hipMemset(p->done_list + batch, 0, 2 * sizeof(uint32_t)));
+    }
+    if (hp.has_done_list && v->layout == LAYOUT_TILE) {  // the init kernel zeroes the idle list's length instead of taking reader tickets on its own
+        HIP_TRY_V(hipMalloc(&p->done_list_spare, sizeof(uint32_t) * (batch + 2)));
+        HIP_TRY_V(hipMemset(p->done_list_spare + batch, 0, 2 * sizeof(uint32_t)));
     }
     if (plan::reset_step_fusable(hp)) {  // qg_vec_reset_done_step in one launch: the second list and the two is_final arrays
         HIP_TRY_V(hipMalloc(&p->done_list_alt, sizeof(uint32_t) * (batch + 2)));
@@ -832,11 +836,13 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
         ia.list_count = v->done_list + v->B;
         ia.coop = plan::reset_coop_allowed(actions_dev != nullptr, v->B, v->d_rowops != nullptr) ? 1u : 0u;
         if (v->layout == LAYOUT_TILE) ia.dense = v->dense;  // the listed envs' dense observations are rewritten by the reset itself
+        if (v->done_list_spare) ia.zero_count = v->done_list_spare + v->B;
     }
     if (!only_done) v->maybe_nonsymplectic = false;  // identity + gates: every env is symplectic again
     int64_t d = (int64_t)v->cfg.depth_slope * v->difficulty;  // clifford.rs:317
     ia.depth_value = (int32_t)std::min<int64_t>(d, v->cfg.max_depth);
     HIP_TRY(launch_init(v, ia, s));
+    if (ia.zero_count) std::swap(v->done_list, v->done_list_spare);  // the list just zeroed is the one the next step appends to; the consumed one idles
     if (v->dense && !ia.dense) return dense_refresh(v, s);
     return QG_OK;
 }
@@ -1028,6 +1034,7 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     ia.only_done = 1u;
     ia.list = v->done_list;
     ia.list_count = v->done_list + v->B;
+    ia.zero_count = v->done_list_spare + v->B;
     ia.coop = 1u;
     ia.dense = v->dense;
     ia.depth_value = (int32_t)std::min<int64_t>((int64_t)v->cfg.depth_slope * v->difficulty, v->cfg.max_depth);  // clifford.rs:317
@@ -1047,8 +1054,9 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     uint8_t *pend_out = v->pend[v->pend_cur ^ 1];
     HIP_TRY(qm_reset_step(ia, a, pend_in, pend_out, v->nxp, v->has_z, s));
     v->step_index += 1;
-    // the list just appended to is the current one; the one just consumed was zeroed by its last reader and is the next launch's target
-    std::swap(v->done_list, v->done_list_alt);
+    // the list just appended to is the current one, the idle list (zeroed by this launch) is the next launch's target, the one just consumed idles
+    std::swap(v->done_list, v->done_list_alt);   // (current, alt, spare) <- (alt, spare, current)
+    std::swap(v->done_list_alt, v->done_list_spare);
     v->pend_cur ^= 1;
     v->done_list_fresh = true;
     v->pend_fresh = true;

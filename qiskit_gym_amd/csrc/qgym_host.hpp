@@ -117,6 +117,7 @@ struct qg_vec {
     // qg_vec_reset_done_step (TILE without add_inverts): the fused launch consumes done_list and appends to done_list_alt, then the two trade
     // places; pend[pend_cur] = is_final of every env as the last list-leaving step wrote it (the fused launch's membership test)
     uint32_t *done_list_alt = nullptr;
+    uint32_t *done_list_spare = nullptr;  // TILE: the list no launch in flight reads or appends to; the reset that consumes done_list zeroes this one's length, then they rotate
     uint8_t *pend[2] = {nullptr, nullptr};
     int pend_cur = 0;
     bool pend_fresh = false;            // pend[pend_cur] describes the list in done_list (believed within the session, like done_list_fresh)
