@@ -199,7 +199,12 @@ __device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds,
 // (W3 W2) (W1 W0).  With columns on the lanes, column j of A B is A times column j of B: the xor of A's columns s over the set bits s of
 // the lane's own word -- A's 32 column words read from LDS, 64 vector instructions (~0.3 us).  The dependent chain is n / 8 gates + three
 // products (n = 256: 32 steps of ~45 ns instead of 64 gates of 73).
-// Rows come back by ballot: row word of slot s = the lanes' bits s, kept by lane s.  Returns true on the 64 lanes of wave 0, which finish the env together.
+// The env needs ROWS (a row word per slot), the lanes hold columns -- so the tree computes the TRANSPOSE: S^T = S0^T G_1^T ... G_n^T, whose
+// column j is row j of S.  A segment's leaf is then its gates in REVERSE order, each transposed (the xor trades test and flip, the swap is its
+// own transpose), tree place p takes segment 7 - p, and the place that holds segment 0 multiplies S0^T on at the end of its chain (the xor of
+// S0's rows over the set bits of the lane's word).  No row has to be gathered from 32 lanes' bits afterwards (32 ballots on the wave
+// everything waits for), and S0 costs one half wave ~100 instructions instead of the long wave ~200.
+// Returns true on the 64 lanes of wave 0, which finish the env together: lane s < R holds the row of slot s.
 // `prod`: 4 x 32 words of LDS; `gates`: 4 x 64 uint4 of LDS (16-byte aligned); `table`: the row-operation table in LDS (the caller brings it
 // in while the list length is still in flight), or null: read a.rowops; `env`: list[vblock], loaded by the caller.  blockDim.x must be 256.
 constexpr uint32_t QG_TREE_THREADS = plan::TREE_THREADS;
@@ -217,9 +222,10 @@ __device__ inline void rowop_parity(uint32_t &col, uint32_t test, uint32_t flip)
     col ^= (uint32_t)__builtin_amdgcn_sbfe((int32_t)__builtin_popcount(col & test), 0u, 1u) & flip;
 }
 // the four masks {test0, flip0, test1, flip1} of a gate word (two row operations, make_op with slot indices, 14 bits each)
-__device__ inline uint4 rowop_masks(uint32_t o) {
-    auto half = [](uint32_t op, uint32_t &test, uint32_t &flip) {
-        const uint32_t type = (op >> 12) & 3u, bd = 1u << (op & 63u), bs = 1u << ((op >> 6) & 63u);
+// (`transposed`: the masks of the row operation's transpose -- row[src] ^= row[dst]; the swap is symmetric)
+__device__ inline uint4 rowop_masks(uint32_t o, bool transposed = false) {
+    auto half = [transposed](uint32_t op, uint32_t &test, uint32_t &flip) {
+        const uint32_t type = (op >> 12) & 3u, bd = 1u << ((op >> (transposed ? 6 : 0)) & 63u), bs = 1u << ((op >> (transposed ? 0 : 6)) & 63u);
         test = type == OP_NONE ? 0u : (type == OP_SWAP ? bs | bd : bs);
         flip = type == OP_NONE ? 0u : (type == OP_SWAP ? bs | bd : bd);
     };
@@ -236,28 +242,21 @@ __device__ inline bool scramble_tree(const InitArgs &a, uint32_t count, uint64_t
     if (item >= count) return false;  // whole workgroups leave together
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1), w = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31u;
     // (`env` comes in from the caller: list[item], requested before the list's length was known)
-    // segment k = 2 w + half owns the gates [k seg, (k + 1) seg)
-    const uint32_t seg = (a.n_draws + 7u) / 8u, k = 2u * w + half;
-    const uint32_t t0 = k * seg < a.n_draws ? k * seg : a.n_draws, t1 = (t0 + seg < a.n_draws) ? t0 + seg : a.n_draws;
-    uint32_t col;
-    if (k == 0) {
-        col = 0;
-#pragma unroll 4
-        for (int sl = 0; sl < R; ++sl) col |= ((identity((uint32_t)sl) >> hl) & 1u) << sl;  // clifford.rs:307
-    } else {
-        col = hl < (uint32_t)R ? 1u << hl : 0u;
-    }
+    // tree place p = 2 w + half holds segment k = 7 - p: the gates [k seg, (k + 1) seg), last one first, transposed
+    const uint32_t seg = (a.n_draws + 7u) / 8u, k = 7u - (2u * w + half);
+    const uint32_t t0 = k * seg < a.n_draws ? k * seg : a.n_draws, t1 = (t0 + seg < a.n_draws) ? t0 + seg : a.n_draws, len = t1 - t0;
+    uint32_t col = hl < (uint32_t)R ? 1u << hl : 0u;
     const uint64_t seed = init_seed(a);
     uint4 *mine = gates[w];
     for (uint32_t c0 = 0; c0 < seg; c0 += 32u) {  // 32 gates per half wave and pass (seg <= 32 up to 256 draws: one pass)
-        const uint32_t t = t0 + c0 + hl;
+        const uint32_t u = c0 + hl;  // the u-th gate this place applies: the segment's gate len - 1 - u
         uint32_t o = 0u;  // past the segment's end: "no gate" (all four masks zero)
-        if (t < t1) {
-            const uint32_t act = rng_action(seed, a.env_base + env, t, a.num_actions);
+        if (u < len) {
+            const uint32_t act = rng_action(seed, a.env_base + env, t0 + (len - 1u - u), a.num_actions);
             o = table ? table[act] : a.rowops[act];
         }
         __builtin_amdgcn_wave_barrier();  // (the previous pass has read its masks)
-        mine[lane] = rowop_masks(o);
+        mine[lane] = rowop_masks(o, true);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t left = seg - c0, steps = left < 32u ? left : 32u;  // wave-uniform (both halves walk `steps` gates; the tail is "no gate")
@@ -278,6 +277,12 @@ __device__ inline bool scramble_tree(const InitArgs &a, uint32_t count, uint64_t
             for (int q = 0; q < 4; ++q) g[q] = nx[q];
         }
     }
+    if (k == 0) {  // S0^T on the left (clifford.rs:307): the xor of S0's rows over the set bits of the word
+        uint32_t acc = 0;
+#pragma unroll 8
+        for (int sl = 0; sl < R; ++sl) acc ^= identity((uint32_t)sl) & (uint32_t)__builtin_amdgcn_sbfe((int32_t)col, (uint32_t)sl, 1u);
+        col = acc;
+    }
     // P_upper P_lower inside the wave, then (W3 W2) (W1 W0): publish, multiply
     if (half) prod[w][hl] = col;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -290,14 +295,8 @@ __device__ inline bool scramble_tree(const InitArgs &a, uint32_t count, uint64_t
     __syncthreads();
     if (w != 0) return false;
     if (!half) col = gf2_cols_product<R>(prod[2], col);
-    // rows come back by ballot, ONE PER LANE: lane s keeps the row of slot s (R uniform row words in scalar registers cost the caller
-    // hundreds of spilled SGPRs and a one-lane finish of ~500 instructions; with a row per lane the finish is a handful of wave instructions)
-    uint32_t my_row = 0;
-#pragma unroll 8
-    for (int sl = 0; sl < R; ++sl) {
-        const uint32_t rw = (uint32_t)__ballot(!half && ((col >> sl) & 1u));
-        my_row = lane == (uint32_t)sl ? rw : my_row;
-    }
+    // (the transpose's column hl IS the row of slot hl: lanes 0 .. R - 1 of the wave hold the env's rows, the upper half nothing)
+    const uint32_t my_row = half ? 0u : col;
     row_out = my_row;
     return true;  // on all 64 lanes of wave 0
 }
@@ -312,8 +311,8 @@ __device__ inline uint64_t gf2_cols_product64(const uint64_t *a_cols, uint64_t b
     for (int sl = 0; sl < R; ++sl) acc ^= a_cols[sl] & (uint64_t)bit_mask64(b, (uint32_t)sl);
     return acc;
 }
-// Returns true on ALL lanes of wave 0, whose `col` is then the finished matrix by columns (the caller turns it into rows: 64 row words in
-// one lane's registers cost the caller 450 registers and scratch with CliffordEnv's finish, so q64_reset_tree_kernel keeps one row per lane).
+// Returns true on ALL lanes of wave 0, whose `col_out` is then the env's ROW of slot `lane` (the tree runs on the transpose, see scramble_tree:
+// a row per lane is what q64_reset_tree_kernel's finish wants -- 64 row words in one lane's registers cost 450 registers and scratch).
 // 64-bit counterparts of rowop_parity / rowop_masks
 __device__ inline void rowop_parity64(uint64_t &col, uint64_t test, uint64_t flip) {
     col ^= (uint64_t)(0ll - (long long)(__builtin_popcountll(col & test) & 1)) & flip;
@@ -321,10 +320,10 @@ __device__ inline void rowop_parity64(uint64_t &col, uint64_t test, uint64_t fli
 struct RowopMasks64 {
     uint64_t t0, f0, t1, f1;
 };
-__device__ inline RowopMasks64 rowop_masks64(uint32_t o) {
-    auto half = [](uint32_t op, uint64_t &test, uint64_t &flip) {
+__device__ inline RowopMasks64 rowop_masks64(uint32_t o, bool transposed = false) {
+    auto half = [transposed](uint32_t op, uint64_t &test, uint64_t &flip) {
         const uint32_t type = (op >> 12) & 3u;
-        const uint64_t bd = 1ull << (op & 63u), bs = 1ull << ((op >> 6) & 63u);
+        const uint64_t bd = 1ull << ((op >> (transposed ? 6 : 0)) & 63u), bs = 1ull << ((op >> (transposed ? 0 : 6)) & 63u);
         test = type == OP_NONE ? 0ull : (type == OP_SWAP ? bs | bd : bs);
         flip = type == OP_NONE ? 0ull : (type == OP_SWAP ? bs | bd : bd);
     };
@@ -343,24 +342,21 @@ __device__ inline bool scramble_tree64(const InitArgs &a, uint32_t count, uint64
     if (item >= count) return false;
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1), w = threadIdx.x >> 6;
     env = a.list[item];
-    const uint32_t seg = (a.n_draws + 3u) / 4u, t0 = w * seg < a.n_draws ? w * seg : a.n_draws, t1 = (t0 + seg < a.n_draws) ? t0 + seg : a.n_draws;
-    uint64_t col = 0;
-    if (w == 0) {
-#pragma unroll 8
-        for (int sl = 0; sl < R; ++sl) col |= ((identity((uint32_t)sl) >> lane) & 1ull) << sl;  // clifford.rs:307
-    } else {
-        col = lane < (uint32_t)R ? 1ull << lane : 0ull;
-    }
+    // the transpose, as scramble_tree: tree place w holds segment k = 3 - w, its gates last one first and transposed; segment 0's place
+    // multiplies S0^T on at the end.  Lane s of wave 0 ends with the row of slot s.
+    const uint32_t seg = (a.n_draws + 3u) / 4u, k = 3u - w;
+    const uint32_t t0 = k * seg < a.n_draws ? k * seg : a.n_draws, t1 = (t0 + seg < a.n_draws) ? t0 + seg : a.n_draws, len = t1 - t0;
+    uint64_t col = lane < (uint32_t)R ? 1ull << lane : 0ull;
     const uint64_t seed = init_seed(a);
     RowopMasks64 *mine = gates[w];
-    for (uint32_t c0 = t0; c0 < t1; c0 += QG_WAVE) {  // 64 gates per pass
-        const uint32_t t = c0 + lane;
-        const uint32_t o = t < t1 ? a.rowops[rng_action(seed, a.env_base + env, t, a.num_actions)] : 0u;  // past the end: "no gate"
+    for (uint32_t c0 = 0; c0 < len; c0 += QG_WAVE) {  // 64 gates per pass
+        const uint32_t u = c0 + lane;  // the u-th gate this place applies: the segment's gate len - 1 - u
+        const uint32_t o = u < len ? a.rowops[rng_action(seed, a.env_base + env, t0 + (len - 1u - u), a.num_actions)] : 0u;  // past the end: "no gate"
         __builtin_amdgcn_wave_barrier();  // (the previous pass has read its masks)
-        mine[lane] = rowop_masks64(o);
+        mine[lane] = rowop_masks64(o, true);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint32_t left = t1 - c0, steps = left < QG_WAVE ? left : QG_WAVE;
+        const uint32_t left = len - c0, steps = left < QG_WAVE ? left : QG_WAVE;
         RowopMasks64 g[2] = {mine[0], mine[1]};
         for (uint32_t kk = 0; kk < steps; kk += 2u) {
             const RowopMasks64 n0 = mine[(kk + 2u) & 63u], n1 = mine[(kk + 3u) & 63u];  // the next two gates fly while these two are applied
@@ -372,6 +368,12 @@ __device__ inline bool scramble_tree64(const InitArgs &a, uint32_t count, uint64
             g[0] = n0;
             g[1] = n1;
         }
+    }
+    if (k == 0) {  // S0^T on the left (clifford.rs:307)
+        uint64_t acc = 0;
+#pragma unroll 8
+        for (int sl = 0; sl < R; ++sl) acc ^= identity((uint32_t)sl) & (uint64_t)bit_mask64(col, (uint32_t)sl);
+        col = acc;
     }
     if (w & 1u) prod[w][lane] = col;
     __syncthreads();

@@ -680,7 +680,9 @@ __global__ __launch_bounds__(64) void q64_init_kernel(InitArgs a) {
     uint64_t env = tid;
     Rows s;
     if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
-        const uint32_t count = list_count_take(a.list_count, a.coop ? a.B : 0);  // this kernel is the list's only reader
+        const uint32_t count = list_count_take(a.list_count, a.coop ? a.B : 0, QG_COOP_LANES, blockIdx.x, a.zero_count);
+        // (without reader tickets -- InitArgs::zero_count -- the list q64_reset_tree_kernel has taken is still there: the same test says so)
+        if (a.zero_count && a.coop && a.n_draws >= 64u && tree_takes(count, a.n_draws, a.B)) return;
         if (a.coop && coop_takes(count, a.B)) {  // few finished envs: 16 lanes each
             const uint32_t N = a.N;
             const uint64_t *rows = scramble_coop<uint64_t, NS>(a, count, &lds_rows[0][0], env, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); });
@@ -892,26 +894,22 @@ static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
     }
 }
 // qg_vec_reset_done with a short list of long scrambles (tree_takes): a workgroup per listed env, scramble_tree64.  Runs BEFORE q64_init_kernel
-// in the same call and consumes the list (the ticket of list_count_take zeroes it), so that the init kernel finds nothing to do; when the list
-// is too long or the scramble too short it leaves the list alone and the init kernel takes it as before.
+// in the same call and consumes the list (the ticket of list_count_take zeroes it, or -- no tickets, InitArgs::zero_count -- the init kernel applies
+// the same test), so that the init kernel finds nothing to do; when the list is too long or the scramble too short it leaves the list alone and the
+// init kernel takes it as before.
 template <int NS, bool HAS_Z>
 __global__ __launch_bounds__(256) void q64_reset_tree_kernel(InitArgs a) {
     __shared__ uint64_t prod[4][64];
     __shared__ RowopMasks64 tree_gates[4][QG_WAVE];
     if (!tree_takes(a.list_count[0], a.n_draws, a.B)) return;
-    const uint32_t count = list_count_take(a.list_count, a.B, QG_TREE_THREADS);
+    const uint32_t count = list_count_take(a.list_count, a.B, QG_TREE_THREADS, blockIdx.x, a.zero_count);
     const uint32_t N = a.N;
     uint64_t env = 0, col = 0;
     if (!scramble_tree64<NS>(a, count, env, col, prod, tree_gates, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); })) return;
-    // q64_init_finish with the wave's 64 lanes: lane s takes the row of slot s (ballot of the columns' bits s), stores its 8 bytes of the
+    // q64_init_finish with the wave's 64 lanes: lane s holds the row of slot s (scramble_tree64 runs on the transpose), stores its 8 bytes of the
     // env's tile and compares with the identity's; lane 0 writes the scalars (reset_internals, clifford.rs:272-283)
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
-    uint64_t myrow = 0;
-#pragma unroll
-    for (int sl = 0; sl < NS; ++sl) {
-        const uint64_t r = (uint64_t)__ballot((col >> sl) & 1ull);
-        myrow = lane == (uint32_t)sl ? r : myrow;
-    }
+    const uint64_t myrow = col;
     const uint32_t le = (uint32_t)(env & (QG_WAVE - 1));
     uint64_t *tile = reinterpret_cast<uint64_t *>(reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Q64Rows<NS>::G * 64));
     if (lane < (uint32_t)NS) tile[((uint64_t)(lane >> 1) * 64 + le) * 2 + (lane & 1u)] = myrow;  // group lane / 2, the env's 16-byte piece, its low or high word

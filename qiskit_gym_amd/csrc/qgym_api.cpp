@@ -520,7 +520,7 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
         HIP_TRY_V(hipMalloc(&p->done_list, sizeof(uint32_t) * (batch + 2)));
         HIP_TRY_V(hipMemset(p->done_list + batch, 0, 2 * sizeof(uint32_t)));
     }
-    if (hp.has_done_list && v->layout == LAYOUT_TILE) {  // the init kernel zeroes the idle list's length instead of taking reader tickets on its own
+    if (hp.has_done_list && (v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64)) {  // the init kernel zeroes the idle list's length instead of taking reader tickets on its own
         HIP_TRY_V(hipMalloc(&p->done_list_spare, sizeof(uint32_t) * (batch + 2)));
         HIP_TRY_V(hipMemset(p->done_list_spare + batch, 0, 2 * sizeof(uint32_t)));
     }
