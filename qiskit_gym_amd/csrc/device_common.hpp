@@ -217,6 +217,24 @@ __device__ inline uint32_t gf2_cols_product(const uint32_t *a_cols, uint32_t b) 
     for (int sl = 0; sl < R; ++sl) acc ^= a_cols[sl] & (uint32_t)__builtin_amdgcn_sbfe((int32_t)b, (uint32_t)sl, 1u);
     return acc;
 }
+// The same with BOTH halves of the wave at work (a 32-column matrix fills half a wave; an instruction costs the same with 32 lanes idle):
+// lanes hl and hl + 32 hold the same word b, half h sums the slots [h R/2, (h + 1) R/2), and the halves' partial columns are xor-ed across
+// with one v_permlane32_swap (gfx950): half the instructions of the one-half form.  Returns the column on both halves.
+__device__ inline uint32_t both_halves_xor(uint32_t v) {  // v of lane hl ^ v of lane hl + 32, on both
+    const auto sw = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // {lower half's value on both halves, upper half's on both}
+    return sw[0] ^ sw[1];
+}
+__device__ inline uint32_t lower_half_on_both(uint32_t v) { return __builtin_amdgcn_permlane32_swap(v, v, false, false)[0]; }
+template <int R>
+__device__ inline uint32_t gf2_cols_product_halves(const uint32_t *a_cols, uint32_t b, uint32_t half) {
+    constexpr int H = (R + 1) / 2;
+    const uint32_t *ac = a_cols + H * half;
+    const uint32_t bs = b >> (H * half);
+    uint32_t acc = 0;
+#pragma unroll 8
+    for (int i = 0; i < H; ++i) acc ^= (H + i < R || !half ? ac[i] : 0u) & (uint32_t)__builtin_amdgcn_sbfe((int32_t)bs, (uint32_t)i, 1u);
+    return both_halves_xor(acc);
+}
 // one row operation in the parity form (see above)
 __device__ inline void rowop_parity(uint32_t &col, uint32_t test, uint32_t flip) {
     col ^= (uint32_t)__builtin_amdgcn_sbfe((int32_t)__builtin_popcount(col & test), 0u, 1u) & flip;
@@ -284,17 +302,19 @@ __device__ inline bool scramble_tree(const InitArgs &a, uint32_t count, uint64_t
         col = acc;
     }
     // P_upper P_lower inside the wave, then (W3 W2) (W1 W0): publish, multiply
+    // (every product with both halves of the wave: gf2_cols_product_halves; from the first one on both halves hold the same column)
     if (half) prod[w][hl] = col;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (!half) col = gf2_cols_product<R>(prod[w], col);
-    if ((w & 1u) && !half) prod[w][hl] = col;  // (prod[w] is this wave's own: its reads above are ordered before this write)
+    col = gf2_cols_product_halves<R>(prod[w], lower_half_on_both(col), half);
+    __builtin_amdgcn_wave_barrier();  // (prod[w] is this wave's own: its reads above come before the write below)
+    if ((w & 1u) && !half) prod[w][hl] = col;
     __syncthreads();
-    if (!(w & 1u) && !half) col = gf2_cols_product<R>(prod[w + 1u], col);
+    if (!(w & 1u)) col = gf2_cols_product_halves<R>(prod[w + 1u], col, half);
     if (w == 2u && !half) prod[2][hl] = col;
     __syncthreads();
     if (w != 0) return false;
-    if (!half) col = gf2_cols_product<R>(prod[2], col);
+    col = gf2_cols_product_halves<R>(prod[2], col, half);
     // (the transpose's column hl IS the row of slot hl: lanes 0 .. R - 1 of the wave hold the env's rows, the upper half nothing)
     const uint32_t my_row = half ? 0u : col;
     row_out = my_row;
