@@ -354,24 +354,20 @@ __device__ inline RowopMasks64 rowop_masks64(uint32_t o, bool transposed = false
 }
 // `gates`: 4 x 64 RowopMasks64 of LDS (8 KiB): the drawing lane decodes its gate into the four parity-test masks, the serial loop reads them
 // back as a broadcast, two gates ahead (scramble_tree's scheme; a 64-column matrix fills the wave, so a wave runs one segment: four segments)
-template <int R, typename Identity>
-__device__ inline bool scramble_tree64(const InitArgs &a, uint32_t count, uint64_t &env, uint64_t &col_out, uint64_t (*prod)[64], RowopMasks64 (*gates)[QG_WAVE],
-                                       Identity identity) {
+// `op_of(t)`: the row-operation word of gate t (two make_op halves, slot indices), t < n_gates; call from all 256 threads of the workgroup.
+template <int R, typename Identity, typename OpOf>
+__device__ inline bool scramble_tree64_ops(uint32_t n_gates, uint64_t &col_out, uint64_t (*prod)[64], RowopMasks64 (*gates)[QG_WAVE], Identity identity, OpOf op_of) {
     static_assert(R <= 64, "one uint64 of slots per column");
-    const uint64_t item = blockIdx.x;
-    if (item >= count) return false;
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1), w = threadIdx.x >> 6;
-    env = a.list[item];
     // the transpose, as scramble_tree: tree place w holds segment k = 3 - w, its gates last one first and transposed; segment 0's place
     // multiplies S0^T on at the end.  Lane s of wave 0 ends with the row of slot s.
-    const uint32_t seg = (a.n_draws + 3u) / 4u, k = 3u - w;
-    const uint32_t t0 = k * seg < a.n_draws ? k * seg : a.n_draws, t1 = (t0 + seg < a.n_draws) ? t0 + seg : a.n_draws, len = t1 - t0;
+    const uint32_t seg = (n_gates + 3u) / 4u, k = 3u - w;
+    const uint32_t t0 = k * seg < n_gates ? k * seg : n_gates, t1 = (t0 + seg < n_gates) ? t0 + seg : n_gates, len = t1 - t0;
     uint64_t col = lane < (uint32_t)R ? 1ull << lane : 0ull;
-    const uint64_t seed = init_seed(a);
     RowopMasks64 *mine = gates[w];
     for (uint32_t c0 = 0; c0 < len; c0 += QG_WAVE) {  // 64 gates per pass
         const uint32_t u = c0 + lane;  // the u-th gate this place applies: the segment's gate len - 1 - u
-        const uint32_t o = u < len ? a.rowops[rng_action(seed, a.env_base + env, t0 + (len - 1u - u), a.num_actions)] : 0u;  // past the end: "no gate"
+        const uint32_t o = u < len ? op_of(t0 + (len - 1u - u)) : 0u;  // past the end: "no gate"
         __builtin_amdgcn_wave_barrier();  // (the previous pass has read its masks)
         mine[lane] = rowop_masks64(o, true);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -403,6 +399,18 @@ __device__ inline bool scramble_tree64(const InitArgs &a, uint32_t count, uint64
     if (w != 0) return false;
     col_out = gf2_cols_product64<R>(prod[2], col);
     return true;
+}
+template <int R, typename Identity>
+__device__ inline bool scramble_tree64(const InitArgs &a, uint32_t count, uint64_t &env, uint64_t &col_out, uint64_t (*prod)[64], RowopMasks64 (*gates)[QG_WAVE],
+                                       Identity identity) {
+    const uint64_t item = blockIdx.x;
+    if (item >= count) return false;
+    env = a.list[item];
+    const uint64_t seed = init_seed(a), e = a.env_base + env;
+    const uint32_t *rowops = a.rowops;
+    const uint32_t num_actions = a.num_actions;
+    return scramble_tree64_ops<R>(a.n_draws, col_out, prod, gates, identity,
+                                  [=](uint32_t t) -> uint32_t { return rowops[rng_action(seed, e, t, num_actions)]; });
 }
 
 template <typename W, int R>

@@ -1267,7 +1267,10 @@ struct PTGenArgs {
     uint32_t only_done;
     const uint32_t *list;  // only_done, compacted (compact_done): thread i regenerates env list[i]
     uint32_t *list_count;
+    uint32_t tree;         // ptile_reset_tree_kernel runs before ptile_generate_kernel and takes the lists pt_tree_takes says it takes
 };
+constexpr uint32_t PT_CX_LDS = plan::PAULI_CX_LDS;
+using plan::pauli_tree_takes;  // short lists of long scrambles: a workgroup per listed env (ptile_reset_tree_kernel), qgym_plan.hpp
 
 struct PTStream {
     uint64_t seed, env, k;
@@ -1276,82 +1279,60 @@ struct PTStream {
     __device__ float f32() { return (float)(next() >> 40) * (1.0f / 16777216.0f); }
 };
 
+// The generator's tables in LDS: the scramble looks a CX pair up for most of its `difficulty` gates -- from a copy in LDS, not from global memory
+// behind the draw that picks it (a dependent global load per gate was most of this kernel: 256 gates x ~0.5 us) -- and the label
+// generator's loops walk the distance classes and their qubit pairs with dependent loads, ~40 per rotation label.
+struct PTGenTables {
+    uint8_t cx[2 * PT_CX_LDS];
+    uint32_t dvals[32], doff[33];
+    uint8_t pairs[2 * 496];  // N (N - 1) / 2 pairs, N <= 32
+};
+// copied by the whole workgroup, before any lane leaves; the caller makes the copy visible (wave barrier / __syncthreads)
+__device__ inline bool pt_gen_tables_load(const PTGenArgs &ga, PTGenTables &t) {
+    const bool cx_in_lds = ga.n_cx <= PT_CX_LDS;
+    if (cx_in_lds)
+        for (uint32_t i = threadIdx.x; i < 2u * ga.n_cx; i += blockDim.x) t.cx[i] = ga.cx_pairs[i];
+    const uint32_t nd = ga.nd < 32u ? ga.nd : 32u;
+    for (uint32_t i = threadIdx.x; i < nd; i += blockDim.x) t.dvals[i] = ga.dvals[i];
+    for (uint32_t i = threadIdx.x; i <= nd; i += blockDim.x) t.doff[i] = ga.doff[i];
+    const uint32_t n_pairs = ga.doff[nd] < 496u ? ga.doff[nd] : 496u;
+    for (uint32_t i = threadIdx.x; i < 2u * n_pairs; i += blockDim.x) t.pairs[i] = ga.pairs[i];
+    return cx_in_lds;
+}
+
+// generate_paulis_with_difficulty (pauli.rs:191-213): the env's rotations, their DAG and phases into `s`; returns the number of labels
 template <int NQ, int RM>
-__global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
-    const StepArgs &a = ga.s;
-    // the tableau scramble runs on LDS-resident rows ([row][lane], conflict-free for any per-lane row): a
-    // random CX / H / S is one or two row operations instead of a select sweep over 2N 64-bit registers
-    __shared__ uint64_t lds_tab[2 * NQ][QG_WAVE];
-    // the scramble looks a CX pair up for most of its `difficulty` gates: from a copy in LDS, not from global memory behind the draw that picks it
-    // (a dependent global load per gate was most of this kernel: 256 gates x ~0.5 us).  Copied by the whole wave, before any lane leaves.
-    constexpr uint32_t CX_LDS = 1024;  // pairs (every ordered pair of 32 qubits is 992)
-    __shared__ uint8_t lds_cx[2 * CX_LDS];
-    const bool cx_in_lds = ga.n_cx <= CX_LDS;
-    if (cx_in_lds) {
-        for (uint32_t i = threadIdx.x; i < 2u * ga.n_cx; i += QG_WAVE) lds_cx[i] = ga.cx_pairs[i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    // ... and so do the label generator's tables (distance classes and their qubit pairs): its loops walk them with dependent loads,
-    // ~1 us each from global memory, ~40 per rotation label (PauliGym 20q, 1 % of 65 536 envs finished: 162 -> see profiles/r03)
-    __shared__ uint32_t lds_dvals[32], lds_doff[33];
-    __shared__ uint8_t lds_pairs[2 * 496];  // N (N - 1) / 2 pairs, N <= 32
-    {
-        const uint32_t nd = ga.nd < 32u ? ga.nd : 32u;
-        for (uint32_t i = threadIdx.x; i < nd; i += QG_WAVE) lds_dvals[i] = ga.dvals[i];
-        for (uint32_t i = threadIdx.x; i <= nd; i += QG_WAVE) lds_doff[i] = ga.doff[i];
-        const uint32_t n_pairs = ga.doff[nd] < 496u ? ga.doff[nd] : 496u;
-        for (uint32_t i = threadIdx.x; i < 2u * n_pairs; i += QG_WAVE) lds_pairs[i] = ga.pairs[i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t env = tid;
-    if (ga.list) {
-        const uint32_t count = list_count_take(ga.list_count);  // the list's only reader
-        if (tid >= count) return;
-        env = ga.list[tid];
-    } else {
-        if (env >= a.B) return;
-        if (ga.only_done && !a.done[env]) return;
-    }
-    const uint32_t lane = (uint32_t)(env & (QG_WAVE - 1)), L = threadIdx.x & (QG_WAVE - 1);
-    const uint32_t N = a.N;
-    char *tile = PTLayout<NQ, RM>::tile(a.state, env);
-    PTStream rng{(ga.seed + QG_CLOCK_SEED_STRIDE * clock_of(a.clock)) ^ 0x7061756Cull, a.env_base + env, 0};
-    PTState<NQ, RM> s;
+__device__ inline uint32_t pt_gen_labels(const PTGenArgs &ga, const PTGenTables &t, PTStream &rng, PTState<NQ, RM> &s, uint32_t N) {
 #pragma unroll
     for (int k = 0; k < RM; ++k) s.rx[k] = s.rz[k] = s.rpred[k] = 0;
     s.plo = s.phi = 0;
-
-    // generate_paulis_with_difficulty (pauli.rs:191-213)
     uint32_t n_lab = 0, remaining = ga.pauli_difficulty;
     while (remaining > 0 && n_lab < ga.max_paulis) {
         const uint32_t difficulty = remaining;  // get_pauli_under_diff(remaining) (pauli.rs:115-188)
         uint32_t nvd = 0;
-        for (uint32_t i = 0; i < ga.nd; ++i) nvd += lds_dvals[i] <= difficulty;
+        for (uint32_t i = 0; i < ga.nd; ++i) nvd += t.dvals[i] <= difficulty;
         if (nvd == 0) break;
         uint32_t inset = 0, budget = difficulty;
         uint32_t di = rng.range(nvd);
-        uint32_t d = lds_dvals[di];
-        uint32_t pick = lds_doff[di] + rng.range(lds_doff[di + 1] - lds_doff[di]);
-        inset |= (1u << lds_pairs[2 * pick]) | (1u << lds_pairs[2 * pick + 1]);
+        uint32_t d = t.dvals[di];
+        uint32_t pick = t.doff[di] + rng.range(t.doff[di + 1] - t.doff[di]);
+        inset |= (1u << t.pairs[2 * pick]) | (1u << t.pairs[2 * pick + 1]);
         budget = budget > d ? budget - d : 0;
         for (;;) {
             uint32_t nv2 = 0;
-            for (uint32_t i = 0; i < nvd; ++i) nv2 += lds_dvals[i] <= budget;
+            for (uint32_t i = 0; i < nvd; ++i) nv2 += t.dvals[i] <= budget;
             if (budget == 0 || nv2 == 0 || (uint32_t)__popc(inset) >= N) break;
             if (rng.f32() <= ga.decay) break;  // continue with probability 1 - num_qubits_decay
             di = rng.range(nv2);
-            d = lds_dvals[di];
+            d = t.dvals[di];
             uint32_t nc = 0;
-            for (uint32_t p = lds_doff[di]; p < lds_doff[di + 1]; ++p) nc += ((inset >> lds_pairs[2 * p]) | (inset >> lds_pairs[2 * p + 1])) & 1u;
+            for (uint32_t p = t.doff[di]; p < t.doff[di + 1]; ++p) nc += ((inset >> t.pairs[2 * p]) | (inset >> t.pairs[2 * p + 1])) & 1u;
             if (nc == 0) continue;
             uint32_t want = rng.range(nc);
-            for (uint32_t p = lds_doff[di]; p < lds_doff[di + 1]; ++p) {
-                if (((inset >> lds_pairs[2 * p]) | (inset >> lds_pairs[2 * p + 1])) & 1u) {
+            for (uint32_t p = t.doff[di]; p < t.doff[di + 1]; ++p) {
+                if (((inset >> t.pairs[2 * p]) | (inset >> t.pairs[2 * p + 1])) & 1u) {
                     if (want == 0) {
-                        inset |= (1u << lds_pairs[2 * p]) | (1u << lds_pairs[2 * p + 1]);
+                        inset |= (1u << t.pairs[2 * p]) | (1u << t.pairs[2 * p + 1]);
                         break;
                     }
                     --want;
@@ -1389,11 +1370,74 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
     }
     s.alive = (uint32_t)((1ull << n_lab) - 1ull);  // n_lab <= RM <= 32
     s.count = n_lab;
-    s.bad = 0;  // the scramble below starts from the identity and keeps `bad` current
+    s.bad = 0;  // the scramble starts from the identity and keeps `bad` current
     s.order.clear();
 #pragma unroll
     for (int k = 0; k < RM; ++k)
         if ((uint32_t)k < n_lab) s.order.set((uint32_t)k, (uint32_t)k);
+    return n_lab;
+}
+
+// what follows the scramble, on the lane that holds the env's tableau in s.X / s.Z: clean, store, bookkeeping (pauli.rs:576-585)
+template <int NQ, int RM>
+__device__ inline void pt_gen_finish(const PTGenArgs &ga, PTState<NQ, RM> &s, uint64_t env, uint32_t N) {
+    const StepArgs &a = ga.s;
+    const uint32_t lane = (uint32_t)(env & (QG_WAVE - 1));
+    char *tile = PTLayout<NQ, RM>::tile(a.state, env);
+    s.bad = pt_badmask<NQ, RM>(s, N);
+    uint32_t n_removed = 0, fault = 0;  // clean initially trivial rotations (pauli.rs:576)
+    uint64_t rem_pos[(RM + 7) / 8];
+#pragma unroll
+    for (int i = 0; i < (RM + 7) / 8; ++i) rem_pos[i] = 0;
+    pt_clean<NQ, RM>(s, n_removed, fault, SolLog{nullptr, 0}, rem_pos);
+    const bool solved = pt_solved<NQ, RM>(s);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) PTLayout<NQ, RM>::store_qubit(tile, lane, q, s.X[q], s.Z[q]);
+    pt_store_rotations<NQ, RM>(tile, lane, s, ~0u, ~0u, true);
+    pt_store_meta<NQ, RM>(tile, lane, s);
+    a.depth[env] = ga.depth_value;  // pauli.rs:578-585
+    a.success[env] = (uint8_t)solved;
+    a.reward[env] = solved ? 1.0f : 0.0f;
+    a.done[env] = (uint8_t)(ga.depth_value == 0 || solved);
+    a.inverted[env] = 0;
+    a.error[env] = fault;
+    a.sol_len[env * 2] = 0;
+    a.sol_len[env * 2 + 1] = 0;
+    if (a.layers) {
+        const LayerRec lay = layer_rec(a.layers, env, (2 * N + 2));
+        for (uint32_t i = 0; i < 2 * N; ++i) lay[i] = -1;
+        lay[2 * N] = 0;
+        lay[2 * N + 1] = 0;
+    }
+}
+
+template <int NQ, int RM>
+__global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
+    const StepArgs &a = ga.s;
+    // the tableau scramble runs on LDS-resident rows ([row][lane], conflict-free for any per-lane row): a
+    // random CX / H / S is one or two row operations instead of a select sweep over 2N 64-bit registers
+    __shared__ uint64_t lds_tab[2 * NQ][QG_WAVE];
+    __shared__ PTGenTables tb;
+    const bool cx_in_lds = pt_gen_tables_load(ga, tb);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t env = tid;
+    if (ga.list) {
+        // the list's only reader; compact_done re-initialises the length before every use, so nobody has to zero it here (no reader tickets)
+        const uint32_t count = ga.list_count[0];
+        if (ga.tree && pauli_tree_takes(count, ga.difficulty, a.B, ga.n_cx)) return;  // ptile_reset_tree_kernel has taken this list
+        if (tid >= count) return;
+        env = ga.list[tid];
+    } else {
+        if (env >= a.B) return;
+        if (ga.only_done && !a.done[env]) return;
+    }
+    const uint32_t L = threadIdx.x & (QG_WAVE - 1);
+    const uint32_t N = a.N;
+    PTStream rng{(ga.seed + QG_CLOCK_SEED_STRIDE * clock_of(a.clock)) ^ 0x7061756Cull, a.env_base + env, 0};
+    PTState<NQ, RM> s;
+    (void)pt_gen_labels<NQ, RM>(ga, tb, rng, s, N);
 
     // random_clifford_tableau (pauli.rs:220-271): H / S / CX row operations on the identity
     // (row q = X[q], row N + q = Z[q]; LDS slot NQ + q holds Z[q])
@@ -1419,7 +1463,7 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
                 const float r = (float)(d1[j] >> 40) * (1.0f / 16777216.0f);
                 if (r > 0.3f) {  // CX: row q1 ^= row q0 ; row n+q0 ^= row n+q1
                     const uint32_t k = (uint32_t)__umul64hi(d2[j], (uint64_t)ga.n_cx);
-                    const uint32_t q0 = cx_in_lds ? lds_cx[2 * k] : ga.cx_pairs[2 * k], q1 = cx_in_lds ? lds_cx[2 * k + 1] : ga.cx_pairs[2 * k + 1];
+                    const uint32_t q0 = cx_in_lds ? tb.cx[2 * k] : ga.cx_pairs[2 * k], q1 = cx_in_lds ? tb.cx[2 * k + 1] : ga.cx_pairs[2 * k + 1];
                     const uint64_t x0 = lds_tab[q0][L], z1 = lds_tab[NQ + q1][L];
                     lds_tab[q1][L] ^= x0;       // a CX(q, q) entry xors the rows into themselves: both become zero
                     lds_tab[NQ + q0][L] ^= z1;
@@ -1441,32 +1485,61 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
         s.X[j] = lds_tab[j][L];
         s.Z[j] = lds_tab[NQ + j][L];
     }
-    s.bad = pt_badmask<NQ, RM>(s, N);
+    pt_gen_finish<NQ, RM>(ga, s, env, N);
+}
 
-    uint32_t n_removed = 0, fault = 0;  // clean initially trivial rotations (pauli.rs:576)
-    uint64_t rem_pos[(RM + 7) / 8];
+// qg_vec_reset_done with a short list of long scrambles (pt_tree_takes): a workgroup per listed env.  A lane of the kernel above spends most
+// of its time on the scramble's 2 x `difficulty` draws (four 64-bit multiplies each) and on the dependent chain of row operations behind
+// them; here every thread draws ONE gate and the chain is cut in four and multiplied back (scramble_tree64_ops, device_common.hpp; the
+// tableau's 2 NQ <= 64 rows are the slots, X[q] = slot q, Z[q] = slot NQ + q).  The labels are generated by every thread alike (uniform
+// work: it costs what one lane costs, and tells everybody where the scramble's draws start); lane 0 of wave 0 takes the rows and finishes.
+template <int NQ, int RM>
+__global__ __launch_bounds__(256) void ptile_reset_tree_kernel(PTGenArgs ga) {
+    const StepArgs &a = ga.s;
+    constexpr int R = 2 * NQ;
+    __shared__ uint64_t prod[4][64];
+    __shared__ RowopMasks64 tree_gates[4][QG_WAVE];
+    __shared__ PTGenTables tb;
+    __shared__ uint64_t rows_out[64];
+    const uint32_t count = ga.list_count[0];
+    if (!pauli_tree_takes(count, ga.difficulty, a.B, ga.n_cx) || blockIdx.x >= count) return;  // (uniform per workgroup)
+    (void)pt_gen_tables_load(ga, tb);
+    __syncthreads();
+    const uint64_t env = ga.list[blockIdx.x];
+    const uint32_t N = a.N, lane = threadIdx.x & (QG_WAVE - 1);
+    PTStream rng{(ga.seed + QG_CLOCK_SEED_STRIDE * clock_of(a.clock)) ^ 0x7061756Cull, a.env_base + env, 0};
+    PTState<NQ, RM> s;
+    (void)pt_gen_labels<NQ, RM>(ga, tb, rng, s, N);
+    const uint64_t k0 = rng.k, seed = rng.seed, renv = rng.env;
+    const uint32_t n_cx = ga.n_cx;
+    const uint8_t *cx = tb.cx;
+    uint64_t row = 0;
+    const bool finisher = scramble_tree64_ops<R>(
+        ga.difficulty, row, prod, tree_gates,
+        [N](uint32_t k) -> uint64_t { const uint32_t j = k < (uint32_t)NQ ? k : k - (uint32_t)NQ; return j < N ? (k < (uint32_t)NQ ? 1ull << j : (1ull << N) << j) : 0ull; },
+        [=](uint32_t it) -> uint32_t {  // random_clifford_tableau's gate `it` as two row operations (pauli.rs:220-271)
+            const uint64_t d1 = rng_draw(seed, renv, k0 + 2ull * it), d2 = rng_draw(seed, renv, k0 + 2ull * it + 1ull);
+            const float r = (float)(d1 >> 40) * (1.0f / 16777216.0f);
+            if (r > 0.3f) {  // CX: row q1 ^= row q0 ; row n+q0 ^= row n+q1 (q0 == q1: a row xor-ed into itself is zero, in this form too)
+                const uint32_t k = (uint32_t)__umul64hi(d2, (uint64_t)n_cx);
+                const uint32_t q0 = cx[2 * k], q1 = cx[2 * k + 1];
+                return make_op(OP_XOR, q1, q0) | (make_op(OP_XOR, (uint32_t)NQ + q0, (uint32_t)NQ + q1) << 14);
+            }
+            const uint32_t q = (uint32_t)__umul64hi(d2, (uint64_t)N);
+            if (r > 0.15f) return make_op(OP_SWAP, q, (uint32_t)NQ + q);  // H: swap rows q, n+q
+            return make_op(OP_XOR, (uint32_t)NQ + q, q);                    // S: row n+q ^= row q
+        });
+    if (!finisher) return;  // wave 0 goes on: lane s holds the row of slot s
+    rows_out[lane] = row;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane != 0) return;
 #pragma unroll
-    for (int i = 0; i < (RM + 7) / 8; ++i) rem_pos[i] = 0;
-    pt_clean<NQ, RM>(s, n_removed, fault, SolLog{nullptr, 0}, rem_pos);
-    const bool solved = pt_solved<NQ, RM>(s);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) PTLayout<NQ, RM>::store_qubit(tile, lane, q, s.X[q], s.Z[q]);
-    pt_store_rotations<NQ, RM>(tile, lane, s, ~0u, ~0u, true);
-    pt_store_meta<NQ, RM>(tile, lane, s);
-    a.depth[env] = ga.depth_value;  // pauli.rs:578-585
-    a.success[env] = (uint8_t)solved;
-    a.reward[env] = solved ? 1.0f : 0.0f;
-    a.done[env] = (uint8_t)(ga.depth_value == 0 || solved);
-    a.inverted[env] = 0;
-    a.error[env] = fault;
-    a.sol_len[env * 2] = 0;
-    a.sol_len[env * 2 + 1] = 0;
-    if (a.layers) {
-        const LayerRec lay = layer_rec(a.layers, env, (2 * N + 2));
-        for (uint32_t i = 0; i < 2 * N; ++i) lay[i] = -1;
-        lay[2 * N] = 0;
-        lay[2 * N + 1] = 0;
+    for (int j = 0; j < NQ; ++j) {
+        s.X[j] = rows_out[j];
+        s.Z[j] = rows_out[NQ + j];
     }
+    pt_gen_finish<NQ, RM>(ga, s, env, N);
 }
 
 static inline unsigned grid_for(uint64_t threads, unsigned block) { return (unsigned)((threads + block - 1) / block); }
@@ -1652,6 +1725,10 @@ hipError_t ptile_observe_typed(qg_vec *v, void *out_dev, int out_dtype, hipStrea
 
 template <int NQ, int RM>
 static hipError_t pt_launch_generate(const PTGenArgs &pa, hipStream_t s) {
+    if (pa.tree) {  // up to B / 32 listed envs get a workgroup each; the workgroups past the list leave at once
+        const uint64_t blocks = pa.s.B / 32u;
+        hipLaunchKernelGGL((ptile_reset_tree_kernel<NQ, RM>), dim3((unsigned)blocks), dim3(plan::TREE_THREADS), 0, s, pa);
+    }
     hipLaunchKernelGGL((ptile_generate_kernel<NQ, RM>), dim3(grid_for(pa.s.B, 64)), dim3(64), 0, s, pa);
     return hipGetLastError();
 }
@@ -1738,6 +1815,7 @@ int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s) 
         HIP_TRY(compact_done(v->done, v->B, v->done_list, v->done_list + v->B, s));
         ga.list = v->done_list;
         ga.list_count = v->done_list + v->B;
+        ga.tree = (ga.difficulty >= plan::TREE_MIN_DRAWS && v->B / 32u >= 1u && pauli_tree_takes(1u, ga.difficulty, v->B, ga.n_cx)) ? 1u : 0u;
     }
     HIP_TRY(ptile_generate(v, ga, s));
     return QG_OK;

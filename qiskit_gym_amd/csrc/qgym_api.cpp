@@ -1249,7 +1249,10 @@ int qg_plan_query(const qg_config *cfg, uint64_t batch, uint32_t num_actions, in
             const plan::ResetPath rp = plan::list_reset_path(count, draws, batch, coop, true);
             name = rp == plan::RP_TREE ? "scramble_tree64" : plan::reset_path_name(rp);
         } else if (hp.layout == LAYOUT_PAULI) {
-            name = batch >= QG_COMPACT_MIN_ENVS ? "compact_done + ptile_generate_kernel" : "ptile_generate_kernel";
+            // (the gateset's CX count is not known here: a PauliEnv gateset is taken to hold at least one CX and at most num_actions of them)
+            name = batch > QG_COMPACT_MIN_ENVS ? (plan::pauli_tree_takes(count, draws, batch, (uint32_t)num_actions) ? "compact_done + ptile_reset_tree_kernel"
+                                                                                                                       : "compact_done + ptile_generate_kernel")
+                                               : "ptile_generate_kernel";
         } else {
             name = "init_kernel";
         }

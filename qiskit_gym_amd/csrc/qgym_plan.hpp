@@ -226,6 +226,13 @@ __host__ __device__ inline bool coop_takes(uint32_t count, uint64_t B) { return 
 __host__ __device__ inline bool tree_takes(uint32_t count, uint32_t n_draws, uint64_t B) {
     return n_draws >= TREE_MIN_DRAWS && count <= TREE_MAX_ENVS && coop_takes(count, B);
 }
+// PauliEnv (kernels_pauli_tile.hip): a workgroup per listed env (ptile_reset_tree_kernel) for lists up to B / 32 of scrambles this long.  No
+// TREE_MAX_ENVS here: the per-lane generator is so much slower (130 us against 50 at 1 % of 65 536 envs) that the tree wins all the way.
+// `n_cx`: CX gates in the gateset (the scramble draws from them; their table must fit the kernel's LDS copy).
+constexpr uint32_t PAULI_CX_LDS = 1024;  // pairs (every ordered pair of 32 qubits is 992)
+__host__ __device__ inline bool pauli_tree_takes(uint32_t count, uint32_t difficulty, uint64_t B, uint32_t n_cx) {
+    return n_cx != 0 && n_cx <= PAULI_CX_LDS && difficulty >= TREE_MIN_DRAWS && coop_takes(count, B);
+}
 // `coop`: the host allows the cooperative paths (RNG draws, a row-operation table, B >= 64: InitArgs::coop); `coop_fits`: scramble_coop's LDS fits
 __host__ __device__ inline ResetPath list_reset_path(uint32_t count, uint32_t n_draws, uint64_t B, bool coop, bool coop_fits) {
     if (coop && tree_takes(count, n_draws, B)) return RP_TREE;

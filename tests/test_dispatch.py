@@ -99,7 +99,10 @@ RESETS = [
     ("clifford", 24, B, 256, 512, "scramble_tree64"),
     ("clifford", 24, B, 256, 1500, "scramble_coop"),
     ("clifford", 24, B, 32, 4000, "scramble_flat"),
-    ("pauli", 20, B, 128, 512, "compact_done + ptile_generate_kernel"),
+    ("pauli", 20, B, 128, 512, "compact_done + ptile_reset_tree_kernel"),
+    ("pauli", 20, B, 128, B // 32, "compact_done + ptile_reset_tree_kernel"),
+    ("pauli", 20, B, 128, B // 32 + 1, "compact_done + ptile_generate_kernel"),
+    ("pauli", 20, B, 32, 512, "compact_done + ptile_generate_kernel"),
     ("pauli", 20, 4095, 128, 40, "ptile_generate_kernel"),
     ("linear_function", 8, B, 64, 512, "init_kernel"),
     ("permutation", 27, B, 64, 512, "init_kernel"),
