@@ -252,9 +252,12 @@ __device__ inline uint4 rowop_masks(uint32_t o, bool transposed = false) {
     half(o >> 14, r.z, r.w);
     return r;
 }
-template <int R, typename Identity>
+struct NoMid { __device__ void operator()() const {} };
+// `mid`: called by wave 0 between the chain and the products (the caller's loads for what follows the tree are issued there: by then their
+// addresses have arrived, and the products' time hides them)
+template <int R, typename Identity, typename Mid = NoMid>
 __device__ inline bool scramble_tree(const InitArgs &a, uint32_t count, uint64_t &env, uint32_t &row_out, uint32_t (*prod)[32], uint4 (*gates)[QG_WAVE],
-                                     const uint32_t *table, Identity identity, uint32_t vblock) {
+                                     const uint32_t *table, Identity identity, uint32_t vblock, Mid mid = Mid()) {
     static_assert(R <= 32, "one uint32 of slots per column");
     const uint64_t item = vblock;
     if (item >= count) return false;  // whole workgroups leave together
@@ -302,6 +305,7 @@ __device__ inline bool scramble_tree(const InitArgs &a, uint32_t count, uint64_t
         col = acc;
     }
     // P_upper P_lower inside the wave, then (W3 W2) (W1 W0): publish, multiply
+    if (w == 0) mid();
     // (every product with both halves of the wave: gf2_cols_product_halves; from the first one on both halves hold the same column)
     if (half) prod[w][hl] = col;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -703,11 +703,85 @@ __device__ inline void qm_init_finish_wave(const InitArgs &a, uint64_t env, uint
     }
 }
 
+// qm_init_finish_wave followed by the env's first step (qg_vec_reset_done_step, plain configuration: no solution log, no layer metrics), on
+// the wave that holds the fresh rows one per lane: the gate's four rows are read across the lanes (the action is uniform), mixed, and put
+// back before anything is stored, so the step costs no trip to memory for what the reset has just written -- as two calls the lane that
+// finished the reset loaded depth, mask, action, gate entry and row groups back, three dependent trips (1.4 us of the launch's 11).
+// `act`, `g`: the env's action and its gate entry (requested during the scramble).  Results are those of qm_init_finish_wave + qm_step1_body.
+// Returns is_final (on every lane).
+template <int NXP, bool HAS_Z>
+__device__ inline bool qm_init_finish_wave_step(const InitArgs &a, const StepArgs &sa, uint64_t env, uint32_t myrow, int64_t act, GateEntry g) {
+    using Rows = QmRows<NXP, HAS_Z>;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1), le = (uint32_t)(env & (QG_WAVE - 1)), N = a.N;
+    const bool in_range = act >= 0 && act < (int64_t)sa.num_actions;  // gateset.get(action) (clifford.rs:324)
+    const float penalty = in_range ? g.penalty : 0.0f;
+    const uint32_t q0 = g.ops & 31u, q1 = (g.ops >> 5) & 31u, m = (g.ops >> 10) & 0xFFFFu;
+    if (in_range && m != QM_IDENTITY) {  // (uniform) qm_step1_body's gate on rows held across the lanes
+        const uint32_t s0 = HAS_Z ? 2u * q0 : q0, s1 = HAS_Z ? 2u * q1 : q1;
+        const uint32_t x0 = (uint32_t)__shfl((int)myrow, (int)s0), x1 = (uint32_t)__shfl((int)myrow, (int)s1);
+        const uint32_t z0 = HAS_Z ? (uint32_t)__shfl((int)myrow, (int)(s0 + 1u)) : 0u, z1 = HAS_Z ? (uint32_t)__shfl((int)myrow, (int)(s1 + 1u)) : 0u;
+        auto mix = [&](uint32_t k) -> uint32_t {  // out_k = xor_i M[k][i] * in_i
+            const uint32_t b = m >> (4 * k);
+            uint32_t o = ((0u - (b & 1u)) & x0) ^ ((0u - ((b >> 2) & 1u)) & x1);
+            if (HAS_Z) o ^= ((0u - ((b >> 1) & 1u)) & z0) ^ ((0u - ((b >> 3) & 1u)) & z1);
+            return o;
+        };
+        const uint32_t nx0 = mix(0), nx1 = mix(2), nz0 = HAS_Z ? mix(1) : 0u, nz1 = HAS_Z ? mix(3) : 0u;
+        // q1's rows first, then q0's (q0's value wins when q0 == q1, as in qm_apply)
+        myrow = lane == s1 ? nx1 : myrow;
+        if (HAS_Z) myrow = lane == s1 + 1u ? nz1 : myrow;
+        myrow = lane == s0 ? nx0 : myrow;
+        if (HAS_Z) myrow = lane == s0 + 1u ? nz0 : myrow;
+    }
+    uint32_t *tile = reinterpret_cast<uint32_t *>(reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Rows::G * 64));
+    const bool slot = lane < (uint32_t)Rows::R;
+    const uint32_t j = HAS_Z ? lane >> 1 : lane;  // the slot's qubit / row
+    const uint32_t ident = (slot && j < N) ? ((HAS_Z && (lane & 1u)) ? (1u << N) << j : 1u << j) : 0u;
+    if (slot) tile[((lane >> 2) * 64u + le) * 4u + (lane & 3u)] = myrow;
+    const uint64_t differs = __ballot(slot && myrow != ident);
+    if constexpr (Rows::R % 16 == 0) {  // qg_vec_track_dense: the env's whole dense observation, a row per lane
+        if (a.dense && slot) dense_row_store<Rows::R / 16>(a.dense, env, HAS_Z ? ((lane & 1u) ? N + j : j) : lane, myrow);
+    }
+    const bool solved = differs == 0;                                   // clifford.rs:344
+    const int32_t depth = a.depth_value > 0 ? a.depth_value - 1 : 0;    // clifford.rs:317, 342
+    const bool fin = depth == 0 || solved;                              // clifford.rs:353
+    if (lane != 0) return fin;
+    uint32_t bad = (uint32_t)differs;
+    if constexpr (HAS_Z) {  // bit j: slot 2j or 2j + 1 differs
+        uint32_t t = (bad | (bad >> 1)) & 0x55555555u;
+        t = (t | (t >> 1)) & 0x33333333u;
+        t = (t | (t >> 2)) & 0x0F0F0F0Fu;
+        t = (t | (t >> 4)) & 0x00FF00FFu;
+        bad = (t | (t >> 8)) & 0x0000FFFFu;
+    }
+    const float reward = (solved ? 1.0f : 0.0f) - penalty;  // clifford.rs:345-346
+    if (sa.rewards_seq) sa.rewards_seq[env] = reward;
+    if (sa.dones_seq) sa.dones_seq[env] = (uint8_t)fin;
+    if (a.bad) a.bad[env] = bad;
+    a.depth[env] = depth;
+    a.success[env] = (uint8_t)solved;
+    a.reward[env] = reward;
+    a.done[env] = (uint8_t)fin;
+    a.inverted[env] = (uint8_t)((HAS_Z && a.check_symplectic) ? QM_FLAG_SYMPLECTIC : 0u);
+    a.error[env] = 0;
+    a.sol_len[env * 2] = 0;
+    a.sol_len[env * 2 + 1] = 0;
+    if (a.layers) {
+        const LayerRec lay = layer_rec(a.layers, env, a.layers_len);
+        for (uint32_t i = 0; i + 2 < a.layers_len; ++i) lay[i] = -1;
+        lay[a.layers_len - 2] = 0;
+        lay[a.layers_len - 1] = 0;
+    }
+    return fin;
+}
+
 // set_state / reset / reset_done for the thread's env: the work of one workgroup of the init kernel.  `vblock`: the workgroup's index among the
 // workgroups doing this work.  Returns true on the threads that finished an env (`env`: which one) -- every thread of the full-batch
 // modes, one lane per env of the cooperative list scrambles.
+// `sa` (qm_reset_step_kernel, plain configuration): the tree path also takes the env's first step (qm_init_finish_wave_step) and says so in
+// `stepped`, with is_final in `fin`; the other paths leave the step to the caller.
 template <int NXP, bool HAS_Z>
-__device__ __forceinline__ bool qm_init_block(const InitArgs &a, uint32_t vblock, uint64_t &env) {
+__device__ __forceinline__ bool qm_init_block(const InitArgs &a, uint32_t vblock, uint64_t &env, const StepArgs *sa = nullptr, bool *stepped = nullptr, bool *fin = nullptr) {
     using Rows = QmRows<NXP, HAS_Z>;
     // reset scramble (device_common.hpp): the rows live in LDS (wave-private, [slot][lane]: conflict-free for
     // any per-lane slot), so a gate is dynamic-index reads and writes instead of a sweep over 32 registers
@@ -744,13 +818,24 @@ __device__ __forceinline__ bool qm_init_block(const InitArgs &a, uint32_t vblock
             const uint32_t N = a.N;
             uint32_t myrow = 0;
             env = tree_env;
+            // the first step's action is requested now (a vector load: see above), its gate entry between the chain and the products
+            int64_t act = 0;
+            GateEntry ge{QM_IDENTITY << 10, 0.0f};
+            if (sa && vblock < count) act = load_action(sa->actions, (uint64_t)tree_env + opaque_zero, sa->flags & F_ACT64);
             if (!scramble_tree<Rows::R>(a, count, env, myrow, reinterpret_cast<uint32_t(*)[32]>(&lds_rows[0][0][0]), tree_gates, table_fits ? tree_table : nullptr,
                                         [N](uint32_t k) -> uint32_t {
                     const uint32_t j = HAS_Z ? k >> 1 : k;
                     return j < N ? ((HAS_Z && (k & 1u)) ? (1u << N) << j : 1u << j) : 0u;
-                }, vblock))
+                }, vblock, [&]() {
+                    if (sa && act >= 0 && act < (int64_t)sa->num_actions) ge = sa->gates[act];
+                }))
                 return false;
-            qm_init_finish_wave<NXP, HAS_Z>(a, env, myrow);  // the 64 lanes of wave 0
+            if (sa) {
+                *fin = qm_init_finish_wave_step<NXP, HAS_Z>(a, *sa, env, myrow, act, ge);  // the 64 lanes of wave 0
+                *stepped = true;
+            } else {
+                qm_init_finish_wave<NXP, HAS_Z>(a, env, myrow);  // the 64 lanes of wave 0
+            }
             return (threadIdx.x & (QG_WAVE - 1)) == 0;
         }
         if (plan::list_reset_path(count, a.n_draws, a.B, a.coop != 0, coop_fits) == plan::RP_COOP) {  // few finished envs: 16 lanes each
@@ -847,9 +932,11 @@ __global__ __launch_bounds__(256) void qm_reset_step_kernel(ResetStepArgs ra) {
         return;
     }
     uint64_t env;
-    if (!qm_init_block<NXP, HAS_Z>(ra.reset, blockIdx.x, env)) return;
-    // this lane has just written the env's fresh episode (state, depth, bad mask, log lengths): its first step, on the same lane
-    const bool fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64), true);
+    bool stepped = false, fin = false;
+    // (plain configuration: the tree's wave takes the env's first step on the rows it holds -- qm_init_finish_wave_step)
+    if (!qm_init_block<NXP, HAS_Z>(ra.reset, blockIdx.x, env, FEAT ? nullptr : &a, &stepped, &fin)) return;
+    // otherwise this lane has just written the env's fresh episode (state, depth, bad mask, log lengths): its first step, on the same lane
+    if (!stepped) fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64), true);
     ra.pend_out[env] = (uint8_t)fin;
     if (fin) {  // (rare: one atomic per env that is final again after its first step)
         const uint32_t slot = atomicAdd(a.done_count, 1u);
