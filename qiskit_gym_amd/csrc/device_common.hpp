@@ -54,30 +54,24 @@ __device__ inline void done_list_append_block(uint32_t *list, uint32_t *count, b
 
 // Length of the compacted list of finished envs (compact_done), read by every thread of the LAST kernel that consumes it.  The last
 // block WITH WORK to have read it zeroes the counter (and the ticket) for the next qg_vec_reset_done: counter[0] = length, counter[1] =
-// blocks that have read it.  `coop_B`: 0, or the batch size when lists short enough (coop_takes) give an env 16 lanes instead of one --
-// the number of blocks with work follows from the length alone, so every block computes it.  A block without work takes no ticket (256
-// tickets on one address cost the launch 3.4 us); it may find the counter already zeroed and then sees an empty list, which for it is
+// blocks that have read it.  The number of blocks with work follows from the length alone (and the path the length selects), so every block
+// computes it.  A block without work takes no ticket (256 tickets on one address cost the launch 3.4 us); it may find the counter already zeroed and then sees an empty list, which for it is
 // the same thing.  An empty list needs neither tickets nor zeroing.  Call from all threads.
 // `vblock`: this block's index among the blocks that consume the list (blockIdx.x, or less an offset when the kernel's grid starts with other work)
 // `zero_other`: no ticket at all -- the handle keeps a list that nobody reads or appends to during this launch (qgym_api.cpp: the lists rotate),
 // this launch zeroes THAT list's length for whoever appends to it next, and the list consumed here is left as it is.  All tickets go to one
 // address, ~12 ns each, one after the other: with 512 workgroups the last answer comes 6 us after the first, the wave that took the ticket
 // waits for it (the compiler compares the answer where the atomic is) and, at the next barrier, so does its workgroup.
-// `known`: the length, when the caller has loaded counter[0] already.
-__device__ inline uint32_t list_blocks(uint32_t count, uint64_t coop_B, uint32_t coop_lanes) {  // workgroups with work (blockDim.x: a power of two)
-    const uint64_t threads = (coop_B && (uint64_t)count * QG_COOP_LANES * 2 <= coop_B) ? (uint64_t)count * coop_lanes : (uint64_t)count;
-    return (uint32_t)((threads + blockDim.x - 1u) >> (31u - (uint32_t)__builtin_clz(blockDim.x)));  // (a 64-bit division costs ~150 scalar instructions)
-}
-__device__ inline uint32_t list_count_take(uint32_t *counter, uint64_t coop_B, uint32_t coop_lanes, uint32_t vblock, uint32_t *zero_other = nullptr,
-                                           const uint32_t *known = nullptr) {
+// `count`: the length (the caller has loaded counter[0]); `threads`: how many threads of the launch have work with a list this long (one per
+// env, 16 per env, a workgroup per env: the caller's path); returns `count`.
+__device__ inline uint32_t list_count_take(uint32_t *counter, uint32_t count, uint64_t threads, uint32_t vblock, uint32_t *zero_other = nullptr) {
     if (zero_other && vblock == 0 && threadIdx.x == 0) {
         zero_other[0] = 0;
         zero_other[1] = 0;
     }
-    const uint32_t count = known ? *known : counter[0];
     if (count == 0) return 0;
-    const uint32_t blocks = list_blocks(count, coop_B, coop_lanes);
-    if (vblock >= blocks) return count;  // (this block's threads all lie past the list)
+    const uint32_t blocks = (uint32_t)((threads + blockDim.x - 1u) >> (31u - (uint32_t)__builtin_clz(blockDim.x)));  // blockDim.x: a power of two (a 64-bit
+    if (vblock >= blocks) return count;  // (this block's threads all lie past the list)                               division costs ~150 scalar instructions)
     __syncthreads();
     if (!zero_other && threadIdx.x == blockDim.x - 1u) {
         if (atomicAdd(&counter[1], 1u) == blocks - 1u) {
@@ -86,9 +80,6 @@ __device__ inline uint32_t list_count_take(uint32_t *counter, uint64_t coop_B, u
         }
     }
     return count;
-}
-__device__ inline uint32_t list_count_take(uint32_t *counter, uint64_t coop_B = 0, uint32_t coop_lanes = QG_COOP_LANES) {
-    return list_count_take(counter, coop_B, coop_lanes, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -256,11 +247,9 @@ struct NoMid { __device__ void operator()() const {} };
 // `mid`: called by wave 0 between the chain and the products (the caller's loads for what follows the tree are issued there: by then their
 // addresses have arrived, and the products' time hides them)
 template <int R, typename Identity, typename Mid = NoMid>
-__device__ inline bool scramble_tree(const InitArgs &a, uint32_t count, uint64_t &env, uint32_t &row_out, uint32_t (*prod)[32], uint4 (*gates)[QG_WAVE],
-                                     const uint32_t *table, Identity identity, uint32_t vblock, Mid mid = Mid()) {
+__device__ inline bool scramble_tree(const InitArgs &a, uint64_t env, uint32_t &row_out, uint32_t (*prod)[32], uint4 (*gates)[QG_WAVE],
+                                     const uint32_t *table, Identity identity, Mid mid = Mid()) {
     static_assert(R <= 32, "one uint32 of slots per column");
-    const uint64_t item = vblock;
-    if (item >= count) return false;  // whole workgroups leave together
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1), w = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31u;
     // (`env` comes in from the caller: list[item], requested before the list's length was known)
     // tree place p = 2 w + half holds segment k = 7 - p: the gates [k seg, (k + 1) seg), last one first, transposed
@@ -405,11 +394,8 @@ __device__ inline bool scramble_tree64_ops(uint32_t n_gates, uint64_t &col_out, 
     return true;
 }
 template <int R, typename Identity>
-__device__ inline bool scramble_tree64(const InitArgs &a, uint32_t count, uint64_t &env, uint64_t &col_out, uint64_t (*prod)[64], RowopMasks64 (*gates)[QG_WAVE],
+__device__ inline bool scramble_tree64(const InitArgs &a, uint64_t env, uint64_t &col_out, uint64_t (*prod)[64], RowopMasks64 (*gates)[QG_WAVE],
                                        Identity identity) {
-    const uint64_t item = blockIdx.x;
-    if (item >= count) return false;
-    env = a.list[item];
     const uint64_t seed = init_seed(a), e = a.env_base + env;
     const uint32_t *rowops = a.rowops;
     const uint32_t num_actions = a.num_actions;

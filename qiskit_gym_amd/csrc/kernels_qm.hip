@@ -778,16 +778,19 @@ __device__ inline bool qm_init_finish_wave_step(const InitArgs &a, const StepArg
 // set_state / reset / reset_done for the thread's env: the work of one workgroup of the init kernel.  `vblock`: the workgroup's index among the
 // workgroups doing this work.  Returns true on the threads that finished an env (`env`: which one) -- every thread of the full-batch
 // modes, one lane per env of the cooperative list scrambles.
+// `after(env, stepped, fin)`: called on every lane that has finished an env (one lane per env on the list paths; a tree workgroup walks the
+// list in rounds -- entries vblock, vblock + tree_grid, ... -- so it may be called several times).
 // `sa` (qm_reset_step_kernel, plain configuration): the tree path also takes the env's first step (qm_init_finish_wave_step) and says so in
-// `stepped`, with is_final in `fin`; the other paths leave the step to the caller.
-template <int NXP, bool HAS_Z>
-__device__ __forceinline__ bool qm_init_block(const InitArgs &a, uint32_t vblock, uint64_t &env, const StepArgs *sa = nullptr, bool *stepped = nullptr, bool *fin = nullptr) {
+// `stepped`, with is_final in `fin`; the other paths leave the step to `after`.
+struct NoAfter { __device__ void operator()(uint64_t, bool, bool) const {} };
+template <int NXP, bool HAS_Z, typename After = NoAfter>
+__device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock, const StepArgs *sa = nullptr, After after = After()) {
     using Rows = QmRows<NXP, HAS_Z>;
     // reset scramble (device_common.hpp): the rows live in LDS (wave-private, [slot][lane]: conflict-free for
     // any per-lane slot), so a gate is dynamic-index reads and writes instead of a sweep over 32 registers
     __shared__ uint32_t lds_rows[4][Rows::R][QG_WAVE];
     const uint64_t tid = (uint64_t)vblock * blockDim.x + threadIdx.x;
-    env = tid;
+    uint64_t env = tid;
     if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
         constexpr bool coop_fits = scramble_coop_lds_bytes<uint32_t, Rows::R>(4) <= sizeof(lds_rows);
         static_assert(coop_fits == plan::tile_coop_fits(Rows::R, 4), "qgym_plan.hpp must describe this kernel");
@@ -813,49 +816,59 @@ __device__ __forceinline__ bool qm_init_block(const InitArgs &a, uint32_t vblock
         const plan::ResetPath path = plan::list_reset_path(count_now, a.n_draws, a.B, a.coop != 0, coop_fits);  // qgym_plan.hpp
         const bool tree = path == plan::RP_TREE;
         // this kernel is the list's only reader.  The barrier inside list_count_take (workgroups with work) is also the one that makes the table visible
-        const uint32_t count = list_count_take(a.list_count, (coop_fits && a.coop) ? a.B : 0, tree ? QG_TREE_THREADS : QG_COOP_LANES, vblock, a.zero_count, &count_now);
+        const uint64_t with_work = tree ? (uint64_t)(count_now < a.tree_grid ? count_now : a.tree_grid) * QG_TREE_THREADS
+                                        : (uint64_t)count_now * (path == plan::RP_COOP ? QG_COOP_LANES : 1u);
+        const uint32_t count = list_count_take(a.list_count, count_now, with_work, vblock, a.zero_count);
         if (tree) {  // few finished envs, long scrambles: a workgroup each, the matrix by columns, the gate sequence cut in eight (scramble_tree)
             const uint32_t N = a.N;
-            uint32_t myrow = 0;
-            env = tree_env;
-            // the first step's action is requested now (a vector load: see above), its gate entry between the chain and the products
-            int64_t act = 0;
-            GateEntry ge{QM_IDENTITY << 10, 0.0f};
-            if (sa && vblock < count) act = load_action(sa->actions, (uint64_t)tree_env + opaque_zero, sa->flags & F_ACT64);
-            if (!scramble_tree<Rows::R>(a, count, env, myrow, reinterpret_cast<uint32_t(*)[32]>(&lds_rows[0][0][0]), tree_gates, table_fits ? tree_table : nullptr,
-                                        [N](uint32_t k) -> uint32_t {
-                    const uint32_t j = HAS_Z ? k >> 1 : k;
-                    return j < N ? ((HAS_Z && (k & 1u)) ? (1u << N) << j : 1u << j) : 0u;
-                }, vblock, [&]() {
-                    if (sa && act >= 0 && act < (int64_t)sa->num_actions) ge = sa->gates[act];
-                }))
-                return false;
-            if (sa) {
-                *fin = qm_init_finish_wave_step<NXP, HAS_Z>(a, *sa, env, myrow, act, ge);  // the 64 lanes of wave 0
-                *stepped = true;
-            } else {
-                qm_init_finish_wave<NXP, HAS_Z>(a, env, myrow);  // the 64 lanes of wave 0
+            // entry vblock of the list, then vblock + tree_grid, ...: the launch has tree_grid workgroups for a list of any (tree) length.  (The first
+            // round straight-line, the later ones in a loop: as one loop the first round came out 0.3 us slower.)
+            auto round = [&](uint64_t e) __attribute__((always_inline)) {
+                uint32_t myrow = 0;
+                // the first step's action is requested now (a vector load: see above), its gate entry between the chain and the products
+                int64_t act = 0;
+                GateEntry ge{QM_IDENTITY << 10, 0.0f};
+                if (sa) act = load_action(sa->actions, e + opaque_zero, sa->flags & F_ACT64);
+                const bool finisher = scramble_tree<Rows::R>(a, e, myrow, reinterpret_cast<uint32_t(*)[32]>(&lds_rows[0][0][0]), tree_gates, table_fits ? tree_table : nullptr,
+                                                             [N](uint32_t k) -> uint32_t {
+                        const uint32_t j = HAS_Z ? k >> 1 : k;
+                        return j < N ? ((HAS_Z && (k & 1u)) ? (1u << N) << j : 1u << j) : 0u;
+                    }, [&]() {
+                        if (sa && act >= 0 && act < (int64_t)sa->num_actions) ge = sa->gates[act];
+                    });
+                if (!finisher) return;  // the 64 lanes of wave 0 go on
+                bool fin = false;
+                if (sa) fin = qm_init_finish_wave_step<NXP, HAS_Z>(a, *sa, e, myrow, act, ge);
+                else qm_init_finish_wave<NXP, HAS_Z>(a, e, myrow);
+                if ((threadIdx.x & (QG_WAVE - 1)) == 0) after(e, sa != nullptr, fin);
+            };
+            if (vblock >= count) return;
+            round(tree_env);
+            for (uint32_t item = vblock + a.tree_grid; item < count; item += a.tree_grid) {
+                __syncthreads();  // (the previous round's LDS has been read)
+                round(a.list[item]);
             }
-            return (threadIdx.x & (QG_WAVE - 1)) == 0;
+            return;
         }
-        if (plan::list_reset_path(count, a.n_draws, a.B, a.coop != 0, coop_fits) == plan::RP_COOP) {  // few finished envs: 16 lanes each
+        if (path == plan::RP_COOP) {  // few finished envs: 16 lanes each
             const uint32_t N = a.N;
             const uint32_t *rows = scramble_coop<uint32_t, Rows::R>(a, count, &lds_rows[0][0][0], env, [N](uint32_t k) -> uint32_t {
                 const uint32_t j = HAS_Z ? k >> 1 : k;
                 return j < N ? ((HAS_Z && (k & 1u)) ? (1u << N) << j : 1u << j) : 0u;
             }, vblock);
-            if (!rows) return false;
+            if (!rows) return;
             Rows s;
 #pragma unroll
             for (int k = 0; k < Rows::R; ++k) s.r[k] = rows[k];
             qm_init_finish<NXP, HAS_Z>(a, env, s);
-            return true;
+            after(env, false, false);
+            return;
         }
-        if (tid >= count) return false;
+        if (tid >= count) return;
         env = a.list[tid];
     } else {
-        if (env >= a.B) return false;
-        if (a.only_done && !a.done[env]) return false;  // live episodes keep running
+        if (env >= a.B) return;
+        if (a.only_done && !a.done[env]) return;  // live episodes keep running
     }
     Rows s;
     qm_identity<NXP, HAS_Z>(s, a.N);
@@ -891,14 +904,13 @@ __device__ __forceinline__ bool qm_init_block(const InitArgs &a, uint32_t vblock
         for (int sl = 0; sl < Rows::R; ++sl) s.r[sl] = rows[sl][L];
     }
     qm_init_finish<NXP, HAS_Z>(a, env, s);
-    return true;
+    after(env, false, false);
 }
 
 
 template <int NXP, bool HAS_Z>
 __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
-    uint64_t env;
-    (void)qm_init_block<NXP, HAS_Z>(a, blockIdx.x, env);
+    qm_init_block<NXP, HAS_Z>(a, blockIdx.x);
 }
 
 // qg_vec_reset_done followed by qg_vec_step in ONE launch (qg_vec_reset_done_step): the grid's first `reset_blocks` workgroups are the
@@ -931,17 +943,16 @@ __global__ __launch_bounds__(256) void qm_reset_step_kernel(ResetStepArgs ra) {
         done_list_append_block(a.done_list, a.done_count, fin, env, a.B);
         return;
     }
-    uint64_t env;
-    bool stepped = false, fin = false;
-    // (plain configuration: the tree's wave takes the env's first step on the rows it holds -- qm_init_finish_wave_step)
-    if (!qm_init_block<NXP, HAS_Z>(ra.reset, blockIdx.x, env, FEAT ? nullptr : &a, &stepped, &fin)) return;
-    // otherwise this lane has just written the env's fresh episode (state, depth, bad mask, log lengths): its first step, on the same lane
-    if (!stepped) fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64), true);
-    ra.pend_out[env] = (uint8_t)fin;
-    if (fin) {  // (rare: one atomic per env that is final again after its first step)
-        const uint32_t slot = atomicAdd(a.done_count, 1u);
-        if (slot < a.B) a.done_list[slot] = (uint32_t)env;
-    }
+    // (plain configuration: the tree's wave takes the env's first step on the rows it holds -- qm_init_finish_wave_step; otherwise the lane
+    // that has just written the env's fresh episode -- state, depth, bad mask, log lengths -- takes it, as qm_step1_body)
+    qm_init_block<NXP, HAS_Z>(ra.reset, blockIdx.x, FEAT ? nullptr : &a, [&](uint64_t env, bool stepped, bool fin) {
+        if (!stepped) fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64), true);
+        ra.pend_out[env] = (uint8_t)fin;
+        if (fin) {  // (rare: one atomic per env that is final again after its first step)
+            const uint32_t slot = atomicAdd(a.done_count, 1u);
+            if (slot < a.B) a.done_list[slot] = (uint32_t)env;
+        }
+    });
 }
 
 // export: one thread per (env, matrix row).  log2L carries NXP/4, flag bit 31 of D's companion
@@ -1213,11 +1224,11 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
 }
 template <int NXP, bool HAS_Z>
 static hipError_t launch_init(const InitArgs &a, hipStream_t s) {
-    // reset_done with a short list: scramble_tree gives each of up to min(QG_TREE_MAX_ENVS, B / 32) listed envs a workgroup (the workgroups
+    // reset_done with a short list: scramble_tree walks the list with InitArgs::tree_grid workgroups (the workgroups
     // past the list leave at once); every other path needs at most B threads
     uint64_t threads = a.B;
     if (a.list && a.coop && a.n_draws >= 64u) {
-        const uint64_t tree_blocks = a.B / 32u < QG_TREE_MAX_ENVS ? a.B / 32u : QG_TREE_MAX_ENVS;
+        const uint64_t tree_blocks = a.tree_grid;
         if (tree_blocks * QG_TREE_THREADS > threads) threads = tree_blocks * QG_TREE_THREADS;
     }
     hipLaunchKernelGGL((qm_init_kernel<NXP, HAS_Z>), dim3(grid_for(threads, 256)), dim3(256), 0, s, a);
@@ -1259,7 +1270,7 @@ static hipError_t launch_reset_step(const ResetStepArgs &ra, hipStream_t s) {
     const InitArgs &ia = ra.reset;
     uint64_t threads = ia.B;  // the reset's share of the grid: as launch_init sizes it
     if (ia.list && ia.coop && ia.n_draws >= plan::TREE_MIN_DRAWS) {
-        const uint64_t tree_blocks = ia.B / 32u < QG_TREE_MAX_ENVS ? ia.B / 32u : QG_TREE_MAX_ENVS;
+        const uint64_t tree_blocks = ia.tree_grid;
         if (tree_blocks * QG_TREE_THREADS > threads) threads = tree_blocks * QG_TREE_THREADS;
     }
     ResetStepArgs rb = ra;

@@ -680,9 +680,10 @@ __global__ __launch_bounds__(64) void q64_init_kernel(InitArgs a) {
     uint64_t env = tid;
     Rows s;
     if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
-        const uint32_t count = list_count_take(a.list_count, a.coop ? a.B : 0, QG_COOP_LANES, blockIdx.x, a.zero_count);
+        const uint32_t len = a.list_count[0];
+        const uint32_t count = list_count_take(a.list_count, len, (uint64_t)len * ((a.coop && coop_takes(len, a.B)) ? QG_COOP_LANES : 1u), blockIdx.x, a.zero_count);
         // (without reader tickets -- InitArgs::zero_count -- the list q64_reset_tree_kernel has taken is still there: the same test says so)
-        if (a.zero_count && a.coop && a.n_draws >= 64u && tree_takes(count, a.n_draws, a.B)) return;
+        if (a.zero_count && a.coop && a.n_draws >= 64u && tree_takes(count, a.n_draws)) return;
         if (a.coop && coop_takes(count, a.B)) {  // few finished envs: 16 lanes each
             const uint32_t N = a.N;
             const uint64_t *rows = scramble_coop<uint64_t, NS>(a, count, &lds_rows[0][0], env, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); });
@@ -901,51 +902,56 @@ template <int NS, bool HAS_Z>
 __global__ __launch_bounds__(256) void q64_reset_tree_kernel(InitArgs a) {
     __shared__ uint64_t prod[4][64];
     __shared__ RowopMasks64 tree_gates[4][QG_WAVE];
-    if (!tree_takes(a.list_count[0], a.n_draws, a.B)) return;
-    const uint32_t count = list_count_take(a.list_count, a.B, QG_TREE_THREADS, blockIdx.x, a.zero_count);
+    const uint32_t len = a.list_count[0];
+    if (!tree_takes(len, a.n_draws)) return;
+    const uint32_t count = list_count_take(a.list_count, len, (uint64_t)(len < gridDim.x ? len : gridDim.x) * QG_TREE_THREADS, blockIdx.x, a.zero_count);
     const uint32_t N = a.N;
-    uint64_t env = 0, col = 0;
-    if (!scramble_tree64<NS>(a, count, env, col, prod, tree_gates, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); })) return;
-    // q64_init_finish with the wave's 64 lanes: lane s holds the row of slot s (scramble_tree64 runs on the transpose), stores its 8 bytes of the
-    // env's tile and compares with the identity's; lane 0 writes the scalars (reset_internals, clifford.rs:272-283)
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
-    const uint64_t myrow = col;
-    const uint32_t le = (uint32_t)(env & (QG_WAVE - 1));
-    uint64_t *tile = reinterpret_cast<uint64_t *>(reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Q64Rows<NS>::G * 64));
-    if (lane < (uint32_t)NS) tile[((uint64_t)(lane >> 1) * 64 + le) * 2 + (lane & 1u)] = myrow;  // group lane / 2, the env's 16-byte piece, its low or high word
-    const uint64_t differs = (uint64_t)__ballot(lane < (uint32_t)NS && myrow != q64_identity_word<NS, HAS_Z>((int)lane, N));
-    if (lane != 0) return;
-    uint64_t bad = differs;
-    if constexpr (HAS_Z) {  // bit j: slot 2j or 2j + 1 differs
-        uint64_t t = (differs | (differs >> 1)) & 0x5555555555555555ull;
-        t = (t | (t >> 1)) & 0x3333333333333333ull;
-        t = (t | (t >> 2)) & 0x0F0F0F0F0F0F0F0Full;
-        t = (t | (t >> 4)) & 0x00FF00FF00FF00FFull;
-        t = (t | (t >> 8)) & 0x0000FFFF0000FFFFull;
-        bad = (t | (t >> 16)) & 0x00000000FFFFFFFFull;
-    }
-    const bool solved = differs == 0;
-    if (a.bad) reinterpret_cast<uint64_t *>(a.bad)[env] = bad;
-    a.depth[env] = a.depth_value;
-    a.success[env] = (uint8_t)solved;
-    a.reward[env] = solved ? 1.0f : 0.0f;
-    a.done[env] = (uint8_t)(a.depth_value == 0 || solved);
-    a.inverted[env] = (uint8_t)((HAS_Z && a.check_symplectic) ? Q64_FLAG_SYMPLECTIC : 0u);  // identity + gates: symplectic (q64_init_finish, mode 2)
-    a.error[env] = 0;
-    a.sol_len[env * 2] = 0;
-    a.sol_len[env * 2 + 1] = 0;
-    if (a.layers) {
-        const LayerRec lay = layer_rec(a.layers, env, a.layers_len);
-        for (uint32_t i = 0; i + 2 < a.layers_len; ++i) lay[i] = -1;
-        lay[a.layers_len - 2] = 0;
-        lay[a.layers_len - 1] = 0;
+    // entry blockIdx.x of the list, then + gridDim.x, ...: the launch has plan::tree_grid workgroups for a list of any (tree) length
+    for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+        if (item != blockIdx.x) __syncthreads();  // (the previous round's LDS has been read)
+        const uint64_t env = a.list[item];
+        uint64_t myrow = 0;
+        // q64_init_finish with the wave's 64 lanes: lane s holds the row of slot s (scramble_tree64 runs on the transpose), stores its 8 bytes of the
+        // env's tile and compares with the identity's; lane 0 writes the scalars (reset_internals, clifford.rs:272-283)
+        if (!scramble_tree64<NS>(a, env, myrow, prod, tree_gates, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); })) continue;
+        const uint32_t le = (uint32_t)(env & (QG_WAVE - 1));
+        uint64_t *tile = reinterpret_cast<uint64_t *>(reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Q64Rows<NS>::G * 64));
+        if (lane < (uint32_t)NS) tile[((uint64_t)(lane >> 1) * 64 + le) * 2 + (lane & 1u)] = myrow;  // group lane / 2, the env's 16-byte piece, its low or high word
+        const uint64_t differs = (uint64_t)__ballot(lane < (uint32_t)NS && myrow != q64_identity_word<NS, HAS_Z>((int)lane, N));
+        if (lane != 0) continue;
+        uint64_t bad = differs;
+        if constexpr (HAS_Z) {  // bit j: slot 2j or 2j + 1 differs
+            uint64_t t = (differs | (differs >> 1)) & 0x5555555555555555ull;
+            t = (t | (t >> 1)) & 0x3333333333333333ull;
+            t = (t | (t >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+            t = (t | (t >> 4)) & 0x00FF00FF00FF00FFull;
+            t = (t | (t >> 8)) & 0x0000FFFF0000FFFFull;
+            bad = (t | (t >> 16)) & 0x00000000FFFFFFFFull;
+        }
+        const bool solved = differs == 0;
+        if (a.bad) reinterpret_cast<uint64_t *>(a.bad)[env] = bad;
+        a.depth[env] = a.depth_value;
+        a.success[env] = (uint8_t)solved;
+        a.reward[env] = solved ? 1.0f : 0.0f;
+        a.done[env] = (uint8_t)(a.depth_value == 0 || solved);
+        a.inverted[env] = (uint8_t)((HAS_Z && a.check_symplectic) ? Q64_FLAG_SYMPLECTIC : 0u);  // identity + gates: symplectic (q64_init_finish, mode 2)
+        a.error[env] = 0;
+        a.sol_len[env * 2] = 0;
+        a.sol_len[env * 2 + 1] = 0;
+        if (a.layers) {
+            const LayerRec lay = layer_rec(a.layers, env, a.layers_len);
+            for (uint32_t i = 0; i + 2 < a.layers_len; ++i) lay[i] = -1;
+            lay[a.layers_len - 2] = 0;
+            lay[a.layers_len - 1] = 0;
+        }
     }
 }
 
 template <int NS, bool HAS_Z>
 static hipError_t q64_launch_init(const InitArgs &a, hipStream_t s) {
     if (a.list && a.coop && a.n_draws >= 64u) {
-        const uint64_t blocks = a.B / 32u < QG_TREE_MAX_ENVS ? a.B / 32u : QG_TREE_MAX_ENVS;
+        const uint64_t blocks = a.tree_grid;
         if (blocks) hipLaunchKernelGGL((q64_reset_tree_kernel<NS, HAS_Z>), dim3((unsigned)blocks), dim3(QG_TREE_THREADS), 0, s, a);
     }
     hipLaunchKernelGGL((q64_init_kernel<NS, HAS_Z>), dim3(grid_for(a.B, 64)), dim3(64), 0, s, a);

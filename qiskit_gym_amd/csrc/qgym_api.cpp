@@ -307,6 +307,7 @@ static int drop_done_list(qg_vec *v, hipStream_t s) {
 
 static void fill_init_args(const qg_vec *v, InitArgs &a) {
     memset(&a, 0, sizeof a);
+    a.tree_grid = plan::tree_grid(v->B);
     a.state = v->state;
     a.depth = v->depth;
     a.reward = v->reward;

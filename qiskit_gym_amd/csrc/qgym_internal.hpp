@@ -166,6 +166,7 @@ struct InitArgs {
     uint32_t *bad;             // see StepArgs::bad
     const uint32_t *list;      // reset_done, compacted: thread i resets env list[i], i < *list_count (or null: thread = env)
     uint32_t *list_count;      // [2]: length, reader ticket (device_common.hpp list_count_take)
+    uint32_t tree_grid;        // workgroups of this launch that walk a list as trees (plan::tree_grid), entry i on workgroup i mod tree_grid
     uint32_t *zero_count;      // [2] of ANOTHER list, idle during this launch, or null: zeroed here instead of a reader ticket on list_count (list_count_take)
     uint32_t coop;             // list mode with RNG draws: the 16-lanes-per-env scramble kernel handles small lists
     const uint32_t *rowops;    // TILE layout: per action two row operations (make_op, slot indices) for that kernel

@@ -217,15 +217,19 @@ enum ResetPath { RP_FLAT = 0, RP_COOP = 1, RP_TREE = 2 };
 inline const char *reset_path_name(ResetPath r) { return r == RP_TREE ? "scramble_tree" : r == RP_COOP ? "scramble_coop" : "scramble_flat"; }
 constexpr uint32_t COOP_LANES = 16;        // lanes per env of the cooperative scramble (scramble_coop)
 constexpr uint32_t TREE_THREADS = 256;     // one workgroup per env (scramble_tree)
-constexpr uint32_t TREE_MAX_ENVS = 1024;   // four waves per env: beyond ~1 000 envs the chip's SIMDs hold several of these waves each and issue slots,
-                                           // not the chain, set the time (65 536 envs, 3 % finished: 59 us against 56 for scramble_coop)
+constexpr uint32_t TREE_MAX_ENVS = 4096;   // four waves per env: the chip's SIMDs hold several of these waves each and issue slots, not the chain, set the time --
+                                           // CliffordGym 16q, 262 144 envs: 4 096 finished 41 us as trees, 8 192 finished 48 us with 16 lanes each (tools/bench_reset_fraction.py)
+constexpr uint32_t TREE_GRID = 1024;       // workgroups a launch sets aside for trees; a longer list is walked in rounds (a workgroup that finds no entry still runs the
+                                           // kernel's prologue: 2 048 of them instead of 1 024 cost qg_vec_reset_done_step 2.3 us per pair at 65 536 envs, 4 096 cost
+                                           // qg_vec_reset_done 3.5 us)
 constexpr uint32_t TREE_MIN_DRAWS = 64;    // shorter chains do not repay the products
 // lists of at most B / 32 finished envs take the 16-lanes-per-env path (count * 16 <= B / 2 threads)
 __host__ __device__ inline bool coop_takes(uint32_t count, uint64_t B) { return (uint64_t)count * COOP_LANES * 2 <= B; }
-// lists this short, of scrambles this long, go to scramble_tree
-__host__ __device__ inline bool tree_takes(uint32_t count, uint32_t n_draws, uint64_t B) {
-    return n_draws >= TREE_MIN_DRAWS && count <= TREE_MAX_ENVS && coop_takes(count, B);
-}
+// lists this short, of scrambles this long, go to scramble_tree: the one-lane-per-env form costs ~100 us whatever the list's length (its chain is
+// `difficulty` gates long), a tree 15 us + ~4.5 us per 1 000 envs
+__host__ __device__ inline bool tree_takes(uint32_t count, uint32_t n_draws) { return n_draws >= TREE_MIN_DRAWS && count <= TREE_MAX_ENVS; }
+// workgroups of the launch that walk the list as trees (InitArgs::tree_grid); B / 8 keeps the grid in proportion to a small batch
+inline uint32_t tree_grid(uint64_t B) { return (uint32_t)(B / 8u < TREE_GRID ? B / 8u : TREE_GRID); }
 // PauliEnv (kernels_pauli_tile.hip): a workgroup per listed env (ptile_reset_tree_kernel) for lists up to B / 32 of scrambles this long.  No
 // TREE_MAX_ENVS here: the per-lane generator is so much slower (130 us against 50 at 1 % of 65 536 envs) that the tree wins all the way.
 // `n_cx`: CX gates in the gateset (the scramble draws from them; their table must fit the kernel's LDS copy).
@@ -235,7 +239,7 @@ __host__ __device__ inline bool pauli_tree_takes(uint32_t count, uint32_t diffic
 }
 // `coop`: the host allows the cooperative paths (RNG draws, a row-operation table, B >= 64: InitArgs::coop); `coop_fits`: scramble_coop's LDS fits
 __host__ __device__ inline ResetPath list_reset_path(uint32_t count, uint32_t n_draws, uint64_t B, bool coop, bool coop_fits) {
-    if (coop && tree_takes(count, n_draws, B)) return RP_TREE;
+    if (coop && tree_takes(count, n_draws)) return RP_TREE;
     if (coop && coop_fits && coop_takes(count, B)) return RP_COOP;
     return RP_FLAT;
 }

@@ -84,20 +84,22 @@ def test_layer_weights_take_the_feature_kernels_and_an_empty_gateset_the_registe
 
 
 RESETS = [
-    # kind, qubits, batch, difficulty, finished envs -> which scramble resets them    (list_reset_path: tree <= 1 024 envs and >= 64 draws and
-    ("clifford", 16, B, 256, 512, "scramble_tree"),      #  count * 32 <= B; coop: count * 32 <= B; else one thread per env)
-    ("clifford", 16, B, 256, 1024, "scramble_tree"),
-    ("clifford", 16, B, 256, 1025, "scramble_coop"),
-    ("clifford", 16, B, 256, 2048, "scramble_coop"),
-    ("clifford", 16, B, 256, 2049, "scramble_flat"),
+    # kind, qubits, batch, difficulty, finished envs -> which scramble resets them    (list_reset_path: tree up to 4 096 envs of >= 64
+    ("clifford", 16, B, 256, 512, "scramble_tree"),      #  draws; 16 lanes per env: count * 32 <= B; else one thread per env)
+    ("clifford", 16, B, 256, 4096, "scramble_tree"),
+    ("clifford", 16, B, 256, 4097, "scramble_flat"),
+    ("clifford", 16, 4 * B, 256, 4096, "scramble_tree"),
+    ("clifford", 16, 4 * B, 256, 4097, "scramble_coop"),
+    ("clifford", 16, 4 * B, 256, 8192, "scramble_coop"),
+    ("clifford", 16, 4 * B, 256, 8193, "scramble_flat"),
     ("clifford", 16, B, 64, 512, "scramble_tree"),
     ("clifford", 16, B, 63, 512, "scramble_coop"),
-    ("clifford", 16, 1024, 256, 32, "scramble_tree"),
-    ("clifford", 16, 1024, 256, 33, "scramble_flat"),
+    ("clifford", 16, 1024, 256, 1024, "scramble_tree"),   # (walked in rounds by B / 8 workgroups)
     ("clifford", 16, 63, 256, 1, "scramble_flat"),        # batches below 64 envs never take the cooperative paths
     ("linear_function", 12, B, 256, 512, "scramble_tree"),
     ("clifford", 24, B, 256, 512, "scramble_tree64"),
-    ("clifford", 24, B, 256, 1500, "scramble_coop"),
+    ("clifford", 24, B, 256, 1500, "scramble_tree64"),
+    ("clifford", 24, 4 * B, 256, 6000, "scramble_coop"),
     ("clifford", 24, B, 32, 4000, "scramble_flat"),
     ("pauli", 20, B, 128, 512, "compact_done + ptile_reset_tree_kernel"),
     ("pauli", 20, B, 128, B // 32, "compact_done + ptile_reset_tree_kernel"),

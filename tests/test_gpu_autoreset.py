@@ -132,6 +132,46 @@ def test_pauli_reset_done_of_a_short_list_runs_as_a_tree_and_equals_the_per_lane
         assert int(a.depth[int(e)]) == o.depth() and bool(a.done[int(e)]) == o.is_final()
 
 
+@pytest.mark.parametrize("kind,n", [("clifford", 16), ("clifford", 20), ("linear_function", 12)])
+def test_reset_done_of_a_list_longer_than_the_tree_grid_is_walked_in_rounds(kind, n):
+    """Trees take lists up to 4 096 envs with min(1 024, B / 8) workgroups: a longer list is walked in rounds (entry i on workgroup i mod grid).
+    The same envs reset with even more finished beside them (beyond the trees' range: one lane per env) must come out identical -- a fresh
+    episode depends on (seed, env) only -- and a few are replayed on the oracle."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    B, listed_n, extra_n = 8192, 3000, 2500  # 3 000 -> three rounds of 1 024 workgroups; 5 500 -> not a tree
+    gs = line_gateset(kind, n)
+    cfg = dict(add_inverts=False, add_perms=False, track_solution=False, difficulty=80)
+    a, b = VecEnv(kind, n, gs, B, **cfg), VecEnv(kind, n, gs, B, **cfg)
+    a.reset(3)
+    b.reset(3)
+    rng = np.random.default_rng(n)
+    perm = rng.permutation(B)
+    listed, extra = np.sort(perm[:listed_n]), perm[listed_n:listed_n + extra_n]
+    before = a.get_state("packed").clone()
+    a.done.zero_()
+    b.done.zero_()
+    a.done[torch.as_tensor(listed, device="cuda")] = 1
+    b.done[torch.as_tensor(np.concatenate([listed, extra]), device="cuda")] = 1
+    a.reset_done(41)
+    b.reset_done(41)
+    a.sync()
+    b.sync()
+    sa, sb = a.get_state("packed"), b.get_state("packed")
+    li = torch.as_tensor(listed, device="cuda")
+    assert torch.equal(sa[li], sb[li])
+    for name in ("depth", "done", "success"):
+        assert torch.equal(getattr(a, name)[li], getattr(b, name)[li]), name
+    keep = torch.as_tensor(np.setdiff1d(np.arange(B), listed), device="cuda")
+    assert torch.equal(sa[keep], before[keep])  # live episodes are untouched
+    dense = a.observe()
+    draws = rng_actions(41, B, cfg["difficulty"], len(gs))
+    for e in (listed[0], listed[1024], listed[2048], listed[-1]):  # envs of every round
+        o = OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()})
+        o.reset_with(draws[:, int(e)])
+        np.testing.assert_array_equal(dense[int(e)].cpu().numpy(), o.dense_obs())
+
+
 def _twin(kind, n, B, **cfg):
     from qiskit_gym_amd.vec import VecEnv
 

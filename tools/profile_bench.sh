@@ -54,10 +54,17 @@ for RUN in "dense --modes dense" "tracked --modes tracked" "tracked_default --mo
         pmc_pass "$NAME" $C "$ROOT/tools/bench_dense_obs.py" "$@" --replays 2
     done
 done
+echo "== desynchronised auto-reset (one launch per pair, and two) and reset_done alone" && date
+stats_pass auto_reset "$ROOT/tools/bench_auto_reset.py"
+python3 "$ROOT/tools/bench_auto_reset.py" > "$OUT/auto_reset_live.txt" 2>&1
+B=32768 python3 "$ROOT/tools/bench_auto_reset.py" >> "$OUT/auto_reset_live.txt" 2>&1
+B=131072 python3 "$ROOT/tools/bench_auto_reset.py" >> "$OUT/auto_reset_live.txt" 2>&1
+UNFUSED=1 python3 "$ROOT/tools/bench_auto_reset.py" >> "$OUT/auto_reset_live.txt" 2>&1
+python3 "$ROOT/tools/bench_reset_done.py" > "$OUT/reset_done_live.txt" 2>&1
 echo "== post-processing on the box: traffic.json + the files bench.py reads" && date
 mkdir -p "$OUT/r04"
 python3 "$ROOT/tools/pmc_traffic.py" "$OUT" "$OUT/r04" > "$OUT/pmc_traffic.log" 2>&1
-cp "$OUT/dense_live.json" "$OUT/dense_default_live.json" "$OUT/r04/" 2>/dev/null
+cp "$OUT/dense_live.json" "$OUT/dense_default_live.json" "$OUT/auto_reset_live.txt" "$OUT/reset_done_live.txt" "$OUT/r04/" 2>/dev/null
 mkdir -p "$ROOT/profiles/r04" && cp "$OUT/r04/"* "$ROOT/profiles/r04/"   # the box's copy of the repo: bench.py below reads them
 echo "== bench.py plain (reads the summaries made above)" && date
 cd "$ROOT" && python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/r04/bench_driver_args.json" 2> "$OUT/bench_driver_args.err"
