@@ -200,7 +200,6 @@ __device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds,
 // in while the list length is still in flight), or null: read a.rowops; `env`: list[vblock], loaded by the caller.  blockDim.x must be 256.
 constexpr uint32_t QG_TREE_THREADS = plan::TREE_THREADS;
 constexpr uint32_t QG_TREE_TABLE_MAX = 1024;  // gatesets up to this many actions have their row-operation table in LDS
-constexpr uint32_t QG_TREE_MAX_ENVS = plan::TREE_MAX_ENVS;
 template <int R>
 __device__ inline uint32_t gf2_cols_product(const uint32_t *a_cols, uint32_t b) {  // this lane's column of A B; a_cols[s] = column s of A
     uint32_t acc = 0;
