@@ -1418,15 +1418,16 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
     // random CX / H / S is one or two row operations instead of a select sweep over 2N 64-bit registers
     __shared__ uint64_t lds_tab[2 * NQ][QG_WAVE];
     __shared__ PTGenTables tb;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // the list's only reader; compact_done re-initialises the length before every use, so nobody has to zero it here (no reader tickets)
+    const uint32_t count = ga.list ? ga.list_count[0] : 0u;
+    // (before the tables are brought in: most calls with a list leave here -- ptile_reset_tree_kernel has taken it, or the wave lies past it)
+    if (ga.list && ((ga.tree && pauli_tree_takes(count, ga.difficulty, a.B, ga.n_cx)) || (tid & ~(uint64_t)(QG_WAVE - 1)) >= count)) return;
     const bool cx_in_lds = pt_gen_tables_load(ga, tb);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t env = tid;
     if (ga.list) {
-        // the list's only reader; compact_done re-initialises the length before every use, so nobody has to zero it here (no reader tickets)
-        const uint32_t count = ga.list_count[0];
-        if (ga.tree && pauli_tree_takes(count, ga.difficulty, a.B, ga.n_cx)) return;  // ptile_reset_tree_kernel has taken this list
         if (tid >= count) return;
         env = ga.list[tid];
     } else {
