@@ -27,21 +27,41 @@ __device__ inline void done_list_append(uint32_t *list, uint32_t *count, bool fi
     if (fin && slot < cap) list[slot] = (uint32_t)env;
 }
 
-// The same append for a whole workgroup of 256 threads (call from ALL of them): one atomic per workgroup with a finisher instead of one
-// per wave -- every append goes to one address, ~10 ns each, and they are the tail of the launch.
+// The same append for a whole workgroup (call from ALL of its threads): one atomic per workgroup with a finisher instead of one per wave --
+// every append goes to one address, ~12 ns each, one after the other, and they are the tail of the launch.  WAVES = 4 (256 threads) or 16
+// (1 024 threads: the LIST step kernels, whose 64 workgroups at 65 536 envs take 64 turns instead of 256).
+template <int WAVES = 4>
 __device__ inline void done_list_append_block(uint32_t *list, uint32_t *count, bool fin, uint64_t env, uint64_t cap) {
-    __shared__ uint32_t wave_count[4], wave_base[4];
+    static_assert(WAVES == 4 || WAVES == 16, "256 or 1 024 threads");
+    __shared__ uint32_t wave_count[WAVES], wave_base[WAVES];
     const uint64_t m = __ballot(fin);
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
     if (lane == 0) wave_count[wave] = (uint32_t)__popcll(m);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t c0 = wave_count[0], c1 = wave_count[1], c2 = wave_count[2], c3 = wave_count[3], total = c0 + c1 + c2 + c3;
-        const uint32_t base = total ? atomicAdd(count, total) : 0u;
-        wave_base[0] = base;
-        wave_base[1] = base + c0;
-        wave_base[2] = base + c0 + c1;
-        wave_base[3] = base + c0 + c1 + c2;
+    if constexpr (WAVES == 4) {
+        if (threadIdx.x == 0) {
+            const uint32_t c0 = wave_count[0], c1 = wave_count[1], c2 = wave_count[2], c3 = wave_count[3], total = c0 + c1 + c2 + c3;
+            const uint32_t base = total ? atomicAdd(count, total) : 0u;
+            wave_base[0] = base;
+            wave_base[1] = base + c0;
+            wave_base[2] = base + c0 + c1;
+            wave_base[3] = base + c0 + c1 + c2;
+        }
+    } else {
+        if (threadIdx.x < 16u) {  // an exclusive prefix over the waves on the first 16 lanes, the total from lane 15
+            const uint32_t c = wave_count[threadIdx.x];
+            uint32_t incl = c;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 16);
+                if ((int)threadIdx.x >= off) incl += up;
+            }
+            const uint32_t total = (uint32_t)__shfl((int)incl, 15, 16);
+            uint32_t base = 0;
+            if (threadIdx.x == 0 && total) base = atomicAdd(count, total);
+            base = (uint32_t)__shfl((int)base, 0, 16);
+            wave_base[threadIdx.x] = base + incl - c;
+        }
     }
     __syncthreads();
     if (fin) {

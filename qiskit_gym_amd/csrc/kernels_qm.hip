@@ -492,8 +492,10 @@ __global__ __launch_bounds__(256) void qm_inv2_kernel(StepArgs a) {
 // measured 3.77 -> 3.15 us per step at B = 65 536 and 34.9 -> 30.0 us at B = 2^20 (CliffordEnv 16q).
 // LIST: also append the envs that finish to StepArgs::done_list (F_DONE_LIST; its own instantiation: the plain kernel's code stays as it is)
 // DENSE (qg_vec_track_dense, N == NXP, D % 16 == 0): the rows the gate rewrote also go to the resident dense int8 observation
+// (LIST: launched with QM_LIST_BLOCK threads per workgroup -- fewer, larger workgroups take fewer turns at the list's counter)
+constexpr unsigned QM_LIST_BLOCK = 1024;
 template <int NXP, bool HAS_Z, bool FEAT, bool LIST = false, bool DENSE = false>
-__global__ __launch_bounds__(256) void qm_step1_kernel(StepArgs a) {
+__global__ __launch_bounds__(LIST ? QM_LIST_BLOCK : 256) void qm_step1_kernel(StepArgs a) {
     using Rows = QmRows<NXP, HAS_Z>;
     constexpr int D16 = DENSE ? Rows::R / 16 : 0;
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(256) void qm_step1_kernel(StepArgs a) {
             fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64));
             if (a.pend_out) a.pend_out[env] = (uint8_t)fin;  // what the next qg_vec_reset_done_step tests (qm_reset_step_kernel)
         }
-        done_list_append_block(a.done_list, a.done_count, fin, env, a.B);
+        done_list_append_block<QM_LIST_BLOCK / 64>(a.done_list, a.done_count, fin, env, a.B);  // (every wave of the workgroup gets here, also past the batch's end)
     } else {
         if (env >= a.B) return;
         const int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
@@ -1163,21 +1165,23 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
     const bool seq = a.T != 1 || a.rewards_seq || a.dones_seq;
     const bool list = a.flags & F_DONE_LIST;
     switch (plan::tile_step(a.flags, a.T, a.bad != nullptr, a.rewards_seq || a.dones_seq, a.num_actions, HAS_Z, NXP)) {  // qgym_plan.hpp
-    case plan::SK_QM_STEP1:  // the env.step() path
+    case plan::SK_QM_STEP1: {  // the env.step() path
+        const dim3 lgrid(grid_for(a.B, QM_LIST_BLOCK)), lblock(QM_LIST_BLOCK);
         if constexpr (QmRows<NXP, HAS_Z>::R % 16 == 0) {
             if (a.dense) {  // qg_vec_track_dense (the host passes it for N == NXP only)
-                if (feat && list) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, true, true, true>), grid, block, 0, s, a);
+                if (feat && list) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, true, true, true>), lgrid, lblock, 0, s, a);
                 else if (feat) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, true, false, true>), grid, block, 0, s, a);
-                else if (list) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, false, true, true>), grid, block, 0, s, a);
+                else if (list) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, false, true, true>), lgrid, lblock, 0, s, a);
                 else hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, false, false, true>), grid, block, 0, s, a);
                 return hipGetLastError();
             }
         }
-        if (feat && list) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, true, true>), grid, block, 0, s, a);
+        if (feat && list) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, true, true>), lgrid, lblock, 0, s, a);
         else if (feat) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, true>), grid, block, 0, s, a);
-        else if (list) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, false, true>), grid, block, 0, s, a);
+        else if (list) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, false, true>), lgrid, lblock, 0, s, a);
         else hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, false>), grid, block, 0, s, a);
         return hipGetLastError();
+    }
     case plan::SK_QM_INV2:  // CliffordEnv with add_inverts, every env symplectic, one step per launch: two lanes per env
         if constexpr (HAS_Z && NXP <= 16) {
             const dim3 grid2(grid_for(2 * a.B, 256));
