@@ -466,10 +466,16 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
 // renaming into one v_perm_b32 per word.  ~150 instructions per lane instead of ~600 per env.
 // States that are not known to be symplectic (set_state of an arbitrary matrix) keep the thread-per-env Gauss-Jordan variant.
 // ------------------------------------------------------------------------------------------
+#ifndef QG_LIST_BLOCK
+#define QG_LIST_BLOCK 1024  // (256 for a development build of the former shape: tools/build_variant.sh -DQG_LIST_BLOCK=256)
+#endif
+constexpr unsigned QM_LIST_BLOCK = QG_LIST_BLOCK;
+// (LIST: QM_LIST_BLOCK threads per workgroup, as qm_step1_kernel<..., LIST> -- two lanes per env make 512 workgroups of 256 threads at 65 536 envs,
+// each with a turn at the list's counter)
 template <int NXP, bool FEAT, bool LIST = false, bool DENSE = false>
-__global__ __launch_bounds__(256) void qm_inv2_kernel(StepArgs a) {
+__global__ __launch_bounds__(LIST ? QM_LIST_BLOCK : 256) void qm_inv2_kernel(StepArgs a) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    __shared__ uint32_t dense_rows[DENSE ? 4 : 1][DENSE ? 32 * 33 : 1];  // DENSE: the inverted envs' rows, [env of the wave][row], pitch 33
+    __shared__ uint32_t dense_rows[DENSE ? (LIST ? QM_LIST_BLOCK / 64 : 4) : 1][DENSE ? 32 * 33 : 1];  // DENSE: the inverted envs' rows, [env of the wave][row], pitch 33
     uint32_t *dl = DENSE ? dense_rows[threadIdx.x >> 6] : nullptr;
     QG_PREFETCH_STEP_ARGS(a);
     bool whole = false;  // DENSE: this lane's env was inverted, its rows are parked in dl
@@ -477,7 +483,7 @@ __global__ __launch_bounds__(256) void qm_inv2_kernel(StepArgs a) {
         bool fin = false;
         if ((tid >> 1) < a.B) fin = qm_inv2_body<NXP / 2, FEAT, DENSE>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr, dl, &whole);  // qm_step1.hpp
         if constexpr (DENSE) qm_inv2_dense_flush(a.dense, dl, (tid - (threadIdx.x & 63u)) >> 1, whole);
-        if constexpr (LIST) done_list_append_block(a.done_list, a.done_count, fin && !(tid & 1u), tid >> 1, a.B);
+        if constexpr (LIST) done_list_append_block<QM_LIST_BLOCK / 64>(a.done_list, a.done_count, fin && !(tid & 1u), tid >> 1, a.B);
     } else {
         if ((tid >> 1) >= a.B) return;  // whole lane pairs leave together
         (void)qm_inv2_body<NXP / 2, FEAT, DENSE>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr, dl, &whole);  // qm_step1.hpp
@@ -493,7 +499,6 @@ __global__ __launch_bounds__(256) void qm_inv2_kernel(StepArgs a) {
 // LIST: also append the envs that finish to StepArgs::done_list (F_DONE_LIST; its own instantiation: the plain kernel's code stays as it is)
 // DENSE (qg_vec_track_dense, N == NXP, D % 16 == 0): the rows the gate rewrote also go to the resident dense int8 observation
 // (LIST: launched with QM_LIST_BLOCK threads per workgroup -- fewer, larger workgroups take fewer turns at the list's counter)
-constexpr unsigned QM_LIST_BLOCK = 1024;
 template <int NXP, bool HAS_Z, bool FEAT, bool LIST = false, bool DENSE = false>
 __global__ __launch_bounds__(LIST ? QM_LIST_BLOCK : 256) void qm_step1_kernel(StepArgs a) {
     using Rows = QmRows<NXP, HAS_Z>;
@@ -1184,19 +1189,19 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
     }
     case plan::SK_QM_INV2:  // CliffordEnv with add_inverts, every env symplectic, one step per launch: two lanes per env
         if constexpr (HAS_Z && NXP <= 16) {
-            const dim3 grid2(grid_for(2 * a.B, 256));
+            const dim3 grid2(grid_for(2 * a.B, 256)), lgrid2(grid_for(2 * a.B, QM_LIST_BLOCK)), lblock(QM_LIST_BLOCK);
             if constexpr (NXP == 16) {
                 if (a.dense) {  // qg_vec_track_dense (N = 16)
-                    if (feat && list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true, true, true>), grid2, block, 0, s, a);
+                    if (feat && list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true, true, true>), lgrid2, lblock, 0, s, a);
                     else if (feat) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true, false, true>), grid2, block, 0, s, a);
-                    else if (list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, false, true, true>), grid2, block, 0, s, a);
+                    else if (list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, false, true, true>), lgrid2, lblock, 0, s, a);
                     else hipLaunchKernelGGL((qm_inv2_kernel<NXP, false, false, true>), grid2, block, 0, s, a);
                     return hipGetLastError();
                 }
             }
-            if (feat && list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true, true>), grid2, block, 0, s, a);
+            if (feat && list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true, true>), lgrid2, lblock, 0, s, a);
             else if (feat) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true>), grid2, block, 0, s, a);
-            else if (list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, false, true>), grid2, block, 0, s, a);
+            else if (list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, false, true>), lgrid2, lblock, 0, s, a);
             else hipLaunchKernelGGL((qm_inv2_kernel<NXP, false>), grid2, block, 0, s, a);
             return hipGetLastError();
         }

@@ -12,7 +12,8 @@ from util import line_gateset
 
 gs = line_gateset("clifford", 16); B, AT, seed = int(os.environ.get("B", "65536")), 128, 7
 A = len(gs)
-env = VecEnv("clifford", 16, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=256)
+DEFAULTS = os.environ.get("DEFAULTS") == "1"  # the reference's default options: add_inverts + solution log (the pair is then two launches)
+env = VecEnv("clifford", 16, gs, B, add_inverts=DEFAULTS, add_perms=False, track_solution=DEFAULTS, difficulty=256)
 acts = torch.randint(0, A, (AT, B), dtype=torch.int32, device="cuda")
 stream = torch.cuda.Stream()
 with torch.cuda.stream(stream):
@@ -41,5 +42,5 @@ with torch.cuda.stream(stream):
     for _ in range(8): g.replay()
     e1.record(stream)
 torch.cuda.synchronize(); env.sync()
-print(("one launch per (reset_done + step)" if FUSED else "two launches") + ": ", end="")
+print(("one launch per (reset_done + step)" if FUSED and not DEFAULTS else "two launches") + (" [reference-default options]" if DEFAULTS else "") + ": ", end="")
 print(f"desynchronised auto-reset: {e0.elapsed_time(e1) * 1e3 / (8 * AT):.2f} us per (step + reset_done), {100.0 / AT:.2f} % of the batch finishes per step")
