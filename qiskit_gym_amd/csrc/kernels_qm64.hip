@@ -558,12 +558,9 @@ __global__ __launch_bounds__(256) void q64_inv2_kernel(StepArgs a) {
 // <= 2 groups ({X[q], Z[q]} of a qubit for CliffordEnv, a row pair for LinearFunctionEnv) are gathered
 // and scattered at per-lane addresses, `solved` comes from the incrementally kept 64-bit `bad` mask.
 // LIST: also append the envs that finish to StepArgs::done_list (F_DONE_LIST; its own instantiation: the plain kernel's code stays as it is)
-template <int NS, bool HAS_Z, bool FEAT, bool LIST = false>
-__global__ __launch_bounds__(256) void q64_step1_kernel(StepArgs a) {
-    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+template <int NS, bool HAS_Z, bool FEAT>
+__device__ __forceinline__ bool q64_step1_body(const StepArgs &a, uint64_t env) {  // returns is_final
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
-    QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
-    if (env >= a.B) return;
     uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Q64Rows<NS>::G * 64);
     uint64_t *badp = reinterpret_cast<uint64_t *>(a.bad) + env;
     const int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
@@ -635,7 +632,22 @@ __global__ __launch_bounds__(256) void q64_step1_kernel(StepArgs a) {
     a.success[env] = (uint8_t)solved;
     if (FEAT && (a.flags & F_TRACK)) a.sol_len[env * 2] = sol_n;
     if (FEAT && fault) atomicOr(&a.error[env], fault);
-    if constexpr (LIST) done_list_append(a.done_list, a.done_count, depth == 0 || solved, env, a.B);  // qg_vec_reset_done follows (qgym_api.cpp)
+    return depth == 0 || solved;
+}
+// (LIST: Q64_LIST_BLOCK threads per workgroup and one turn at the list's counter per workgroup -- done_list_append_block; a turn per wave with
+// a finished env was ~400 turns of ~12 ns at 65 536 envs)
+constexpr unsigned Q64_LIST_BLOCK = 1024;
+template <int NS, bool HAS_Z, bool FEAT, bool LIST = false>
+__global__ __launch_bounds__(LIST ? Q64_LIST_BLOCK : 256) void q64_step1_kernel(StepArgs a) {
+    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
+    if constexpr (LIST) {  // every thread reaches the workgroup-wide append; qg_vec_reset_done follows (qgym_api.cpp)
+        const bool fin = env < a.B && q64_step1_body<NS, HAS_Z, FEAT>(a, env);
+        done_list_append_block<Q64_LIST_BLOCK / 64>(a.done_list, a.done_count, fin, env, a.B);
+    } else {
+        if (env >= a.B) return;
+        (void)q64_step1_body<NS, HAS_Z, FEAT>(a, env);
+    }
 }
 
 // the tail of set_state / reset for one env: rows to the tile, reset_internals (clifford.rs:272-283)
@@ -856,9 +868,9 @@ static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
     const bool extra = feat || a.T != 1 || a.rewards_seq || a.dones_seq;
     switch (plan::tile64_step(a.flags, a.T, a.bad != nullptr, a.rewards_seq || a.dones_seq, a.num_actions, HAS_Z)) {  // qgym_plan.hpp
     case plan::SK_Q64_STEP1:  // the env.step() path
-        if (feat && list) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, true, true>), grid, block, 0, s, a);
+        if (feat && list) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, true, true>), dim3(grid_for(a.B, Q64_LIST_BLOCK)), dim3(Q64_LIST_BLOCK), 0, s, a);
         else if (feat) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, true>), grid, block, 0, s, a);
-        else if (list) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, false, true>), grid, block, 0, s, a);
+        else if (list) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, false, true>), dim3(grid_for(a.B, Q64_LIST_BLOCK)), dim3(Q64_LIST_BLOCK), 0, s, a);
         else hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, false>), grid, block, 0, s, a);
         return hipGetLastError();
     case plan::SK_Q64_FUSED_LDS: {  // plain fused rollout: rows in LDS, one wave per workgroup

@@ -10,10 +10,11 @@ if os.environ.get('QG_LIB'):
 from qiskit_gym_amd.vec import VecEnv
 from util import line_gateset
 
-gs = line_gateset("clifford", 16); B, AT, seed = int(os.environ.get("B", "65536")), 128, 7
+NQ = int(os.environ.get("N", "16"))  # > 16: 64-bit rows (no one-launch pair: two launches)
+gs = line_gateset("clifford", NQ); B, AT, seed = int(os.environ.get("B", "65536")), 128, 7
 A = len(gs)
 DEFAULTS = os.environ.get("DEFAULTS") == "1"  # the reference's default options: add_inverts + solution log (the pair is then two launches)
-env = VecEnv("clifford", 16, gs, B, add_inverts=DEFAULTS, add_perms=False, track_solution=DEFAULTS, difficulty=256)
+env = VecEnv("clifford", NQ, gs, B, add_inverts=DEFAULTS, add_perms=False, track_solution=DEFAULTS, difficulty=256)
 acts = torch.randint(0, A, (AT, B), dtype=torch.int32, device="cuda")
 stream = torch.cuda.Stream()
 with torch.cuda.stream(stream):
@@ -42,5 +43,5 @@ with torch.cuda.stream(stream):
     for _ in range(8): g.replay()
     e1.record(stream)
 torch.cuda.synchronize(); env.sync()
-print(("one launch per (reset_done + step)" if FUSED and not DEFAULTS else "two launches") + (" [reference-default options]" if DEFAULTS else "") + ": ", end="")
+print(("one launch per (reset_done + step)" if FUSED and not DEFAULTS and NQ <= 16 else "two launches") + (" [reference-default options]" if DEFAULTS else "") + (f" [{NQ} qubits]" if NQ != 16 else "") + ": ", end="")
 print(f"desynchronised auto-reset: {e0.elapsed_time(e1) * 1e3 / (8 * AT):.2f} us per (step + reset_done), {100.0 / AT:.2f} % of the batch finishes per step")
