@@ -406,6 +406,67 @@ def test_reset_done_step_in_one_launch_equals_the_two_calls(kind, n, B, diff, tr
         np.testing.assert_array_equal(dt.cpu().numpy()[: len(envs)].reshape(len(envs), -1), np.stack([o.dense_obs() for o in envs]).reshape(len(envs), -1))
 
 
+@pytest.mark.parametrize("n,B,diff,track,given_coins", [(16, 4096, 3, True, True), (16, 2048, 70, True, True), (9, 777, 4, False, True),
+                                                         (16, 4096, 3, True, False), (12, 8192, 70, False, False)])
+def test_reset_done_step_with_the_reference_default_options_equals_the_two_calls(n, B, diff, track, given_coins):
+    """CliffordEnv with add_inverts: qg_vec_reset_done_step (here the two launches behind one call: a one-launch form was built and measured
+    slower, EXPERIMENTS round 4) against reset_done + step on a twin and, with the coins given, against the oracle; with the handle's
+    counter-RNG coins against the twin alone."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    gs = line_gateset("clifford", n)
+    A = len(gs)
+    cfg = dict(add_inverts=True, add_perms=False, track_solution=track, difficulty=diff, depth_slope=1 if diff > 20 else 2, max_depth=128)
+    fused, twin = VecEnv("clifford", n, gs, B, **cfg), VecEnv("clifford", n, gs, B, **cfg)
+    envs = [OracleEnv("clifford", n, gs, **{k: int(v) for k, v in cfg.items()}) for _ in range(min(B, 300))] if given_coins else []
+    seed0 = 5
+    fused.reset(seed0)
+    twin.reset(seed0)
+    draws = rng_actions(seed0, max(len(envs), 1), diff, A)
+    for e, o in enumerate(envs):
+        o.reset_with(draws[:, e])
+    rng = np.random.default_rng(B + diff)
+    resets = 0
+    steps = 3 * cfg["depth_slope"] * diff + 5 if diff <= 5 else 2 * diff + 20
+    for t in range(steps):
+        seed = 900 + 7 * t
+        acts = rng.integers(0, A, size=B)
+        if t % 9 == 4:
+            acts[::5] = A + 1  # "no gate": still uses depth
+        coins = rng.integers(0, 2, size=B).astype(np.uint8)
+        done = twin.done.cpu().numpy().astype(bool)
+        ta = torch.as_tensor(acts, device="cuda", dtype=torch.int64 if t % 2 else torch.int32)
+        tc = torch.as_tensor(coins, device="cuda") if given_coins else None
+        fused.reset_done_step(seed, ta, tc)
+        twin.reset_done(seed)
+        twin.step(ta, tc)
+        if envs:
+            d2 = rng_actions(seed, len(envs), diff, A)
+            for e, o in enumerate(envs):
+                if done[e]:
+                    o.reset_with(d2[:, e])
+                    resets += 1
+                o.step(int(acts[e]), int(coins[e]))
+        fused.sync()
+        twin.sync()
+        assert torch.equal(fused.reward.view(torch.int32), twin.reward.view(torch.int32)), t
+        assert torch.equal(fused.done, twin.done) and torch.equal(fused.success, twin.success) and torch.equal(fused.depth, twin.depth), t
+        if envs:
+            ne = len(envs)
+            np.testing.assert_array_equal(f32_bits(fused.reward.cpu().numpy()[:ne]), np.array([o.reward_bits() for o in envs], dtype=np.uint32), err_msg=f"t={t}")
+            np.testing.assert_array_equal(fused.depth.cpu().numpy()[:ne], [o.depth() for o in envs])
+    if envs:
+        assert resets > len(envs)  # every env went through episode ends
+        np.testing.assert_array_equal(fused.get_state("i64").cpu().numpy()[: len(envs)], np.stack([o.get_state() for o in envs]))
+    assert torch.equal(fused.get_state("packed"), twin.get_state("packed"))
+    assert torch.equal(fused.inverted, twin.inverted) if hasattr(fused, "inverted") else True
+    if track:
+        for e in (0, 3, min(B, 300) - 1):
+            assert fused.solution(e) == twin.solution(e)
+            if envs:
+                assert fused.solution(e) == envs[e].solution()
+
+
 def test_reset_done_step_inside_a_captured_graph_replays_like_eager_calls():
     """A graph of 16 x reset_done_step (its first call compacts the list from the flags, the others are single launches) replayed three times
     against the same calls made eagerly on a twin: the device-side lists and flag arrays of consecutive replays line up whatever the
