@@ -797,13 +797,14 @@ def main():
     if not multi and B == ENVS_PER_GPU and not args.no_default_config:
         AT = 128
         legs = {}
-        for schedule in ("desynchronised", "synchronised"):
-            aenv = VecEnv("clifford", n, gateset, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=SCRAMBLE)
+        for schedule in ("desynchronised", "synchronised", "desynchronised_reference_defaults"):
+            ref_defaults = schedule.endswith("reference_defaults")  # add_inverts + solution log: the pair is two launches behind the one call
+            aenv = VecEnv("clifford", n, gateset, B, add_inverts=ref_defaults, add_perms=False, track_solution=ref_defaults, difficulty=SCRAMBLE)
             aacts = torch.randint(0, A, (AT, B), dtype=torch.int32, device=dev, generator=gen)
             afin = torch.empty((AT, B), dtype=torch.uint8, device=dev)
             with torch.cuda.stream(stream):
                 aenv.reset(seed)
-                if schedule == "desynchronised":
+                if schedule != "synchronised":
                     cls = torch.arange(B, device=dev) % AT
                     for k in range(AT):  # eager warm-up: spreads the episode ends (the done flags are caller-owned memory, qg_vec_bind_outputs)
                         aenv.set_counters(k, k)
@@ -840,7 +841,31 @@ def main():
             legs[schedule] = {"us_per_step": aus, "value": B / (aus * 1e-6), "unit": "env-steps/s", "finished_per_step": float(per_step.mean()),
                               "finished_per_step_min_max": [float(per_step.min()), float(per_step.max())]}
             del ag, aenv, aacts, afin
-        auto_reset = dict(legs["desynchronised"], synchronised=legs["synchronised"],
+        # ... and qg_vec_reset_done by itself where it is not a tree of row operations on a bit matrix: PauliGym 20q (config 5's env: a fresh target is
+        # generated on the device), 1 % of the batch finished, eager calls (memset + compaction + two kernels), median of 12
+        from util import line_gateset as _line_gateset  # (the gateset builder the configs leg below uses)
+
+        pg_n = 20
+        pg_gs = _line_gateset("pauli", pg_n)
+        penv = VecEnv("pauli", pg_n, pg_gs, B, add_perms=False, track_solution=False, difficulty=128)
+        with torch.cuda.stream(stream):
+            penv.reset(seed)
+            pmask = (torch.rand(B, device=dev, generator=gen) < 0.01).to(torch.uint8)
+            ptimes = []
+            for i in range(12):
+                penv.done.copy_(pmask)
+                p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                p0.record(stream)
+                penv.reset_done(seed + 100 + i)
+                p1.record(stream)
+                torch.cuda.synchronize()
+                ptimes.append(p0.elapsed_time(p1) * 1e3)
+        penv.sync()
+        legs["pauli_reset_done"] = {"us_per_call": sorted(ptimes)[len(ptimes) // 2], "finished": float(pmask.float().mean()),
+                                    "config": f"PauliGym {pg_n}q x {B} envs, difficulty 128, qg_vec_reset_done with 1 % of the batch finished, eager, median of 12"}
+        del penv
+        auto_reset = dict(legs["desynchronised"], synchronised=legs["synchronised"], reference_defaults=legs["desynchronised_reference_defaults"],
+                          pauli_reset_done=legs["pauli_reset_done"],
                           config=f"the headline workload with qg_vec_reset_done after every step (the pair reset_done + next step issued as qg_vec_reset_done_step: one launch), episodes of min(depth_slope * difficulty, max_depth) = {AT} steps, "
                                  f"a captured graph of {AT} x (step, reset_done) replayed 4 times; headline figures: episode ends spread evenly over time "
                                  "(parity of this schedule: tests/test_gpu_fullsize.py::test_auto_reset_with_desynchronised_episodes_at_full_size)")

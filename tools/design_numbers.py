@@ -79,7 +79,9 @@ if d:
     ar = d.get("auto_reset")
     if ar:
         out.append(f"* Auto-reset (step + `reset_done` per step, one hipGraph): desynchronised episodes ({ar['finished_per_step'] * 100:.2f} % of the batch finishes per step) "
-                   f"**{ar['us_per_step']:.1f} µs**, synchronised {ar['synchronised']['us_per_step']:.1f} µs.")
+                   f"**{ar['us_per_step']:.1f} µs**, synchronised {ar['synchronised']['us_per_step']:.1f} µs"
+                   + (f"; with the reference-default options (two launches per pair) {ar['reference_defaults']['us_per_step']:.1f} µs" if ar.get("reference_defaults") else "")
+                   + (f"; PauliGym 20q `reset_done` alone at 1 % finished, eager: {ar['pauli_reset_done']['us_per_call']:.0f} µs" if ar.get("pauli_reset_done") else "") + ".")
     om = d.get("observation_modes")
     if om:
         out.append(f"* Observation after every step (SURVEY 8d, both modes): packed {om['packed']['us_per_step']:.2f} µs per step; dense, full rewrite "
