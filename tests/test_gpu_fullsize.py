@@ -139,6 +139,36 @@ def _coins(coin_seed, env_ids, step_index):
     return (rng_draw(coin_seed ^ 0x636F696E, np.asarray(env_ids, dtype=np.uint64), step_index) >> np.uint64(63)).astype(np.uint8)
 
 
+def test_config5_pauli_reset_done_of_one_percent_at_full_size():
+    """Config 5's env in the auto-reset regime: 1 % of 65 536 PauliGym 20q envs finished -> qg_vec_reset_done generates their fresh targets with a
+    workgroup per env (ptile_reset_tree_kernel: the 256-gate tableau scramble one gate per thread).  Sampled finished envs against the oracle's
+    og_pauli_reset_seeded; every other env untouched."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    n, B, seed = 20, 65536, 0x5EED0005
+    gs = line_gateset("pauli", n)
+    cfg = dict(add_perms=False, track_solution=False, max_rotations=5, difficulty=256, pauli_diff_scale=8)
+    gv = VecEnv("pauli", n, gs, B, **cfg)
+    gv.reset(seed)
+    before = gv.observe().clone()
+    depth0 = gv.depth.clone()
+    rng = np.random.default_rng(5)
+    listed = np.sort(rng.choice(B, size=655, replace=False))
+    gv.done.zero_()
+    gv.done[torch.as_tensor(listed, device="cuda")] = 1
+    gv.reset_done(seed + 1)
+    gv.sync()
+    after = gv.observe()
+    keep = torch.ones(B, dtype=torch.bool, device="cuda")
+    keep[torch.as_tensor(listed, device="cuda")] = False
+    assert torch.equal(after[keep], before[keep]) and torch.equal(gv.depth[keep], depth0[keep])
+    for e in listed[::28]:  # 24 of them
+        o = OracleEnv("pauli", n, gs, **{k: int(v) for k, v in cfg.items()})
+        o.pauli_reset_seeded(seed + 1, int(e))
+        np.testing.assert_array_equal(after[int(e)].cpu().numpy(), o.dense_obs(), err_msg=f"env {e}")
+        assert int(gv.depth[int(e)]) == o.depth() and bool(gv.done[int(e)]) == o.is_final() and bool(gv.success[int(e)]) == o.success()
+
+
 @pytest.mark.parametrize("kind,n,B,scramble,per_env,stride", [
     ("clifford", 16, 65536, 256, 1024, 128),        # config 3 with the reference's defaults: qm_inv2_kernel
     ("linear_function", 8, 8192, 64, 64, 16),       # config 2 with the defaults: word_step_kernel with the byte-parallel Gauss-Jordan
