@@ -1272,9 +1272,14 @@ struct PTGenArgs {
 constexpr uint32_t PT_CX_LDS = plan::PAULI_CX_LDS;
 using plan::pauli_tree_takes;  // short lists of long scrambles: a workgroup per listed env (ptile_reset_tree_kernel), qgym_plan.hpp
 
+// `pre`: the stream's first `n_pre` draws computed ahead, one per thread, and parked in LDS (ptile_reset_tree_kernel): the label generator's draws
+// depend on each other through what they decide, two splitmix64 rounds each (~0.15 us) -- a counter RNG's draw k depends on k alone
 struct PTStream {
     uint64_t seed, env, k;
-    __device__ uint64_t next() { return rng_draw(seed, env, k++); }
+    const uint64_t *pre = nullptr;
+    uint32_t n_pre = 0;
+    __device__ uint64_t at(uint64_t i) const { return (pre && i < n_pre) ? pre[i] : rng_draw(seed, env, i); }  // draw i, the stream stays where it is
+    __device__ uint64_t next() { return at(k++); }
     __device__ uint32_t range(uint32_t n) { return (uint32_t)__umul64hi(next(), (uint64_t)n); }
     __device__ float f32() { return (float)(next() >> 40) * (1.0f / 16777216.0f); }
 };
@@ -1351,6 +1356,95 @@ __device__ inline uint32_t pt_gen_labels(const PTGenArgs &ga, const PTGenTables 
                 ys += ax == 1;
             }
         }
+        uint32_t pred = 0;  // PauliDag::new (pauli_dag.rs:35-41): edge to every earlier non-commuting rotation
+#pragma unroll
+        for (int k = 0; k < RM; ++k)
+            if ((uint32_t)k < n_lab) pred |= (uint32_t)((__popc(x & s.rz[k]) + __popc(z & s.rx[k])) & 1) << k;
+#pragma unroll
+        for (int k = 0; k < RM; ++k) {
+            const bool here = (uint32_t)k == n_lab;
+            s.rx[k] = here ? x : s.rx[k];
+            s.rz[k] = here ? z : s.rz[k];
+            s.rpred[k] = here ? pred : s.rpred[k];
+        }
+        s.plo |= (ys & 1u) << n_lab;  // base_phase = (0 + #Y) mod 4 (pauli.rs:73)
+        s.phi |= ((ys >> 1) & 1u) << n_lab;
+        n_lab += 1;
+        const uint32_t cost = difficulty - budget, dec = cost > 1 ? cost : 1;
+        remaining = remaining > dec ? remaining - dec : 0;
+    }
+    s.alive = (uint32_t)((1ull << n_lab) - 1ull);  // n_lab <= RM <= 32
+    s.count = n_lab;
+    s.bad = 0;  // the scramble starts from the identity and keeps `bad` current
+    s.order.clear();
+#pragma unroll
+    for (int k = 0; k < RM; ++k)
+        if ((uint32_t)k < n_lab) s.order.set((uint32_t)k, (uint32_t)k);
+    return n_lab;
+}
+
+// pt_gen_labels by the 64 lanes of ONE wave (ptile_reset_tree_kernel; all of them call it, converged): the same draws in the same order and
+// the same choices, but every walk over a table -- distance classes within a budget, the pairs of a class that touch the set, the axes of the
+// set's qubits -- is a ballot over the lanes instead of a loop of dependent LDS reads (~60 per added pair, 17 of the kernel's 31 us).
+template <int NQ, int RM>
+__device__ inline uint32_t pt_gen_labels_wave(const PTGenArgs &ga, const PTGenTables &t, PTStream &rng, PTState<NQ, RM> &s, uint32_t N) {
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    const uint32_t nd = ga.nd < 32u ? ga.nd : 32u;
+    const uint32_t my_dval = lane < nd ? t.dvals[lane] : 0xFFFFFFFFu;
+    auto classes_within = [&](uint32_t limit, uint32_t budget) -> uint32_t {  // #{i < limit : dvals[i] <= budget}
+        return (uint32_t)__popcll(__ballot(lane < limit && my_dval <= budget));
+    };
+#pragma unroll
+    for (int k = 0; k < RM; ++k) s.rx[k] = s.rz[k] = s.rpred[k] = 0;
+    s.plo = s.phi = 0;
+    uint32_t n_lab = 0, remaining = ga.pauli_difficulty;
+    while (remaining > 0 && n_lab < ga.max_paulis) {
+        const uint32_t difficulty = remaining;  // get_pauli_under_diff(remaining) (pauli.rs:115-188)
+        const uint32_t nvd = classes_within(nd, difficulty);
+        if (nvd == 0) break;
+        uint32_t inset = 0, budget = difficulty;
+        uint32_t di = rng.range(nvd);
+        uint32_t d = t.dvals[di];
+        const uint32_t pick = t.doff[di] + rng.range(t.doff[di + 1] - t.doff[di]);
+        inset |= (1u << t.pairs[2 * pick]) | (1u << t.pairs[2 * pick + 1]);
+        budget = budget > d ? budget - d : 0;
+        for (;;) {
+            const uint32_t nv2 = classes_within(nvd, budget);
+            if (budget == 0 || nv2 == 0 || (uint32_t)__popc(inset) >= N) break;
+            if (rng.f32() <= ga.decay) break;  // continue with probability 1 - num_qubits_decay
+            di = rng.range(nv2);
+            d = t.dvals[di];
+            const uint32_t p0 = t.doff[di], p1 = t.doff[di + 1];
+            auto touching = [&](uint32_t base) -> uint64_t {  // the class's pairs base .. base + 63 that touch the set, one per lane
+                const uint32_t p = base + lane;
+                return __ballot(p < p1 && (((inset >> t.pairs[2 * p]) | (inset >> t.pairs[2 * p + 1])) & 1u));
+            };
+            uint32_t nc = 0;
+            for (uint32_t base = p0; base < p1; base += QG_WAVE) nc += (uint32_t)__popcll(touching(base));
+            if (nc == 0) continue;
+            uint32_t want = rng.range(nc);
+            for (uint32_t base = p0; base < p1; base += QG_WAVE) {  // the want-th touching pair, in ascending order
+                const uint64_t m = touching(base);
+                const uint32_t here = (uint32_t)__popcll(m);
+                if (want < here) {
+                    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    const uint64_t sel = __ballot(((m >> lane) & 1ull) && rank == want);
+                    const uint32_t p = base + (uint32_t)__ffsll((long long)sel) - 1u;
+                    inset |= (1u << t.pairs[2 * p]) | (1u << t.pairs[2 * p + 1]);
+                    break;
+                }
+                want -= here;
+            }
+            budget = budget > d ? budget - d : 0;
+        }
+        // label: string index q carries the axis; Pauli::from_label reverses, so it is qubit N-1-q.  The set's qubits draw their axes in
+        // ascending order: qubit q takes draw k + (set qubits below q)
+        const bool mine = lane < N && ((inset >> lane) & 1u);
+        const uint32_t ax = mine ? (uint32_t)__umul64hi(rng.at(rng.k + (uint64_t)__popc(inset & ((1u << lane) - 1u))), 3ull) : 3u;  // "XYZ"
+        rng.k += (uint64_t)__popc(inset);
+        const uint32_t xq = (uint32_t)__ballot(mine && ax != 2u), zq = (uint32_t)__ballot(mine && ax != 0u);  // bit q
+        const uint32_t ys = (uint32_t)__popcll(__ballot(mine && ax == 1u));
+        const uint32_t x = __brev(xq) >> (32u - N), z = __brev(zq) >> (32u - N);  // bit N - 1 - q
         uint32_t pred = 0;  // PauliDag::new (pauli_dag.rs:35-41): edge to every earlier non-commuting rotation
 #pragma unroll
         for (int k = 0; k < RM; ++k)
@@ -1502,16 +1596,33 @@ __global__ __launch_bounds__(256) void ptile_reset_tree_kernel(PTGenArgs ga) {
     __shared__ RowopMasks64 tree_gates[4][QG_WAVE];
     __shared__ PTGenTables tb;
     __shared__ uint64_t rows_out[64];
+    __shared__ uint64_t pre_draws[QG_TREE_THREADS];
     const uint32_t count = ga.list_count[0];
     if (!pauli_tree_takes(count, ga.difficulty, a.B, ga.n_cx) || blockIdx.x >= count) return;  // (uniform per workgroup)
     (void)pt_gen_tables_load(ga, tb);
-    __syncthreads();
     const uint64_t env = ga.list[blockIdx.x];
     const uint32_t N = a.N, lane = threadIdx.x & (QG_WAVE - 1);
     PTStream rng{(ga.seed + QG_CLOCK_SEED_STRIDE * clock_of(a.clock)) ^ 0x7061756Cull, a.env_base + env, 0};
+    pre_draws[threadIdx.x] = rng_draw(rng.seed, rng.env, threadIdx.x);  // the label generator's draws, one per thread (it rarely needs more than 256)
+    __syncthreads();
+    rng.pre = pre_draws;
+    rng.n_pre = QG_TREE_THREADS;
+#if defined(QG_PT_STOP) && QG_PT_STOP == 1  // development: phase timing by truncation (tools/build_variant.sh)
+    return;
+#endif
     PTState<NQ, RM> s;
-    (void)pt_gen_labels<NQ, RM>(ga, tb, rng, s, N);
-    const uint64_t k0 = rng.k, seed = rng.seed, renv = rng.env;
+    // the labels on wave 0 alone (its lane 0 finishes the env; the others need only where the scramble's draws start): four waves walking the
+    // same tables kept each other waiting for LDS
+    __shared__ uint64_t k0_shared;
+    if (threadIdx.x < QG_WAVE) {
+        (void)pt_gen_labels_wave<NQ, RM>(ga, tb, rng, s, N);
+        if (threadIdx.x == 0) k0_shared = rng.k;
+    }
+    __syncthreads();
+    const uint64_t k0 = k0_shared, seed = rng.seed, renv = rng.env;
+#if defined(QG_PT_STOP) && QG_PT_STOP == 2
+    if (k0 != 0x123456789ull) return;
+#endif
     const uint32_t n_cx = ga.n_cx;
     const uint8_t *cx = tb.cx;
     uint64_t row = 0;
@@ -1531,6 +1642,9 @@ __global__ __launch_bounds__(256) void ptile_reset_tree_kernel(PTGenArgs ga) {
             return make_op(OP_XOR, (uint32_t)NQ + q, q);                    // S: row n+q ^= row q
         });
     if (!finisher) return;  // wave 0 goes on: lane s holds the row of slot s
+#if defined(QG_PT_STOP) && QG_PT_STOP == 3
+    if (row != 0x123456789ull) return;
+#endif
     rows_out[lane] = row;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

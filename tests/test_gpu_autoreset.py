@@ -90,15 +90,22 @@ def test_pauli_reset_done_generates_fresh_targets_on_device():
         assert gv.solution(e) == envs[e].solution()
 
 
-@pytest.mark.parametrize("n,max_rot", [(20, 8), (12, 4), (28, 16)])
-def test_pauli_reset_done_of_a_short_list_runs_as_a_tree_and_equals_the_per_lane_generator_and_the_oracle(n, max_rot):
+@pytest.mark.parametrize("n,max_rot,coupling", [(20, 8, "line"), (12, 4, "line"), (28, 16, "line"), (13, 8, "all"), (16, 8, "grid")])
+def test_pauli_reset_done_of_a_short_list_runs_as_a_tree_and_equals_the_per_lane_generator_and_the_oracle(n, max_rot, coupling):
     """A few finished envs of a large batch with a long tableau scramble: a workgroup per env (ptile_reset_tree_kernel: every thread draws one
     gate, the chain is cut in four and multiplied back).  A fresh target depends on (seed, env) only, so the same envs regenerated with many
     others finished too (the per-lane generator) must come out identical, and so must the oracle's."""
     from qiskit_gym_amd.vec import VecEnv
 
     B, few, many = 8192, 37, 900  # (lists are compacted above 4 096 envs)
-    gs = line_gateset("pauli", n)
+    if coupling == "all":  # one distance class of n (n - 1) / 2 = 78 pairs: more than a wave of lanes (the tree's label generator walks it in chunks)
+        from qiskit_gym_amd.envs.gateset import gateset_from_coupling_map
+        from util import ALLOWED
+        gs = gateset_from_coupling_map([(i, j) for i in range(n) for j in range(n) if i != j], None, ALLOWED["pauli"])[1]
+    elif coupling == "grid":
+        gs = grid_gateset("pauli", 4, 4, bidirectional=True)
+    else:
+        gs = line_gateset("pauli", n)
     cfg = dict(add_perms=False, track_solution=False, max_rotations=max_rot, difficulty=128, pauli_diff_scale=16, depth_slope=1, max_depth=200)
     a, b = VecEnv("pauli", n, gs, B, **cfg), VecEnv("pauli", n, gs, B, **cfg)
     a.reset(3)
