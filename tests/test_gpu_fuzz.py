@@ -158,6 +158,49 @@ def test_random_pauli_networks(seed):
             assert gv.solution(e) == envs[e].solution(), (label, e)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_pauli_reset_done_as_trees(seed):
+    """qg_vec_reset_done of PauliEnv on random sizes, couplings and generator settings: a short list of finished envs (a workgroup per env: the
+    label generator as ballots over a wave, the tableau scramble as a tree) against the same envs regenerated with many others finished beside
+    them (one lane per env: the serial generator) and, for a few, against the oracle."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    seed += SEED_OFFSET
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([4, 7, 12, 16, 20, 24, 27, 32]))
+    gs = random_gateset(rng, n, int(rng.integers(6, 60)), allow_equal=False)
+    if not any(g[0] == "CX" for g in gs):
+        gs.append(("CX", (0, 1)))  # the tableau scramble draws from the gateset's CX gates
+    max_rot = int(rng.choice([1, 3, 5, 8, 12, 20, 30]))
+    cfg = dict(add_perms=False, track_solution=False, max_rotations=max_rot, difficulty=int(rng.choice([64, 65, 100, 128, 200, 256])),
+               pauli_diff_scale=int(rng.choice([1, 4, 8, 16, 50])), num_qubits_decay=float(np.float32(rng.choice([0.0, 0.3, 0.5, 0.9]))), max_depth=300)
+    B = int(rng.choice([4160, 6000, 8192]))  # lists are compacted above 4 096 envs
+    few, many = int(rng.integers(1, B // 32 + 1)), B // 8
+    label = f"seed={seed} n={n} A={len(gs)} B={B} few={few} {cfg}"
+    a, b = VecEnv("pauli", n, gs, B, **cfg), VecEnv("pauli", n, gs, B, **cfg)
+    a.reset(seed)
+    b.reset(seed)
+    perm = rng.permutation(B)
+    listed, extra = np.sort(perm[:few]), perm[few:few + many]
+    for h, idx in ((a, listed), (b, np.concatenate([listed, extra]))):
+        h.done.zero_()
+        h.done[torch.as_tensor(idx, device="cuda")] = 1
+    a.reset_done(900 + seed)   # <= B / 32 finished: trees
+    b.reset_done(900 + seed)   # > B / 32: one lane per env
+    a.sync()
+    b.sync()
+    li = torch.as_tensor(listed, device="cuda")
+    oa, ob = a.observe(), b.observe()
+    assert torch.equal(oa[li], ob[li]), label
+    for name in ("depth", "done", "success"):
+        assert torch.equal(getattr(a, name)[li], getattr(b, name)[li]), (name, label)
+    assert torch.equal(a.reward[li].view(torch.int32), b.reward[li].view(torch.int32)), label
+    for e in listed[:3]:
+        o = OracleEnv("pauli", n, gs, **cfg)
+        o.pauli_reset_seeded(900 + seed, int(e))
+        np.testing.assert_array_equal(oa[int(e)].cpu().numpy(), o.dense_obs(), err_msg=label)
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_random_auto_reset_loops_with_tracked_observations(seed):
     """Random interleavings of the calls a collection loop makes -- step, reset_done, reset_done_step (one launch), whole resets, rollouts --
