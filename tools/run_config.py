@@ -18,6 +18,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
+if os.environ.get('QG_LIB'):  # development: a variant build
+    from qiskit_gym_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(os.environ['QG_LIB'])
 
 from qiskit_gym_amd.vec import VecEnv
 from util import grid_gateset, line_gateset
