@@ -35,6 +35,25 @@ import os
 # the CPU-baseline leg pins its OpenMP threads; the OpenMP runtime reads these when it is first loaded (and then binds the
 # main thread to its first place, so the CPUs this process may use are counted before that)
 NPROC = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+def _cpu_quota():
+    """CPUs this container may use at once (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
+
+
+CPU_QUOTA = _cpu_quota()
+ORACLE_THREADS = NPROC if CPU_QUOTA is None else max(1, min(NPROC, int(CPU_QUOTA + 0.5)))  # never more threads than CPUs the container may run
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")  # one thread per physical core: with "threads" 16 threads share 8 cores' SMT siblings (3.2e7 against 5.3e7 env-steps/s)
 # multi-process GPU work on this pool needs dmabuf IPC (hipIpcGetMemHandle fails otherwise): set before anything can initialise HIP -- the
@@ -90,21 +109,6 @@ def global_actions(seed: int, total_envs: int, num_actions: int) -> torch.Tensor
     return torch.randint(0, num_actions, (RING, total_envs), dtype=torch.int32, generator=gen)
 
 
-def cpu_quota():
-    """CPUs this container may use at once (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited."""
-    try:
-        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
-        return None if q == "max" else float(q) / float(p)
-    except Exception:
-        pass
-    try:
-        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-        return None if q <= 0 else q / p
-    except Exception:
-        return None
-
-
 def cpu_baseline(gateset, seed: int, budget_s: float = 2.0, repeats: int = 5):
     """Time the CPU oracle (a C port of the reference's scalar Rust path, one env object per env, OpenMP over envs like
     twisterl's rayon-over-clones) on this box's host cores: the configuration's own 65 536 envs, on ONE core and on ALL
@@ -137,8 +141,7 @@ def cpu_baseline(gateset, seed: int, budget_s: float = 2.0, repeats: int = 5):
             rates.append(B * n_steps / (time.perf_counter() - t0))
         return float(np.median(rates)), [float(r) for r in rates], n_steps
 
-    quota = cpu_quota()
-    threads = nproc if quota is None else max(1, min(nproc, int(quota + 0.5)))  # never more threads than CPUs the container may run
+    quota, threads = CPU_QUOTA, ORACLE_THREADS
     one_core, one_core_runs, n1 = measure(1)
     all_core, all_core_runs, nall = measure(threads)
     return {
@@ -159,14 +162,13 @@ def oracle_replay(gateset, seed, global_ids, ring_actions, trace):
     """The run the GPU did -- same seed, same scramble draws (functions of the GLOBAL env id), same action buffers in the same
     order -- on the CPU oracle for the sampled envs.  Returns the oracle batch and the outputs of its last step."""
     from oracle import OracleEnv, OracleVec
-    from util import rng_actions
 
     proto = OracleEnv("clifford", NUM_QUBITS, gateset, add_inverts=0, add_perms=0, track_solution=0, difficulty=SCRAMBLE)
     ov = OracleVec(proto, len(global_ids))
-    ov.reset_with(rng_actions(seed, global_ids, SCRAMBLE, len(gateset)))
+    ov.reset_seeded(seed, env_ids=global_ids, threads=ORACLE_THREADS)  # Env::reset with the draws of qg_vec_reset(seed) (counter RNG, global env id)
     last = (None, None, None, None)
     for ring_idx in trace:
-        last = ov.step(ring_actions[ring_idx])
+        last = ov.step(ring_actions[ring_idx], threads=ORACLE_THREADS)
     return ov, last
 
 
@@ -189,7 +191,7 @@ def parity_replay(gateset, seed, global_ids, ring_actions, trace, snap):
         "success": bool(np.array_equal(snap["success"], s)),
         "is_final": bool(np.array_equal(snap["done"], f)),
         "depth": bool(np.array_equal(snap["depth"], d)),
-        "observation": bool(np.array_equal(snap["obs"].reshape(n, -1), ov.observe_dense())),
+        "observation": bool(np.array_equal(snap["obs"].reshape(n, -1), ov.observe_dense(threads=ORACLE_THREADS))),
     }
 
     def digest(obs, reward, success, depth):  # SHA-256 over the final (state, reward bits, success, depth) streams
@@ -199,7 +201,7 @@ def parity_replay(gateset, seed, global_ids, ring_actions, trace, snap):
         return h.hexdigest()
 
     sha_gpu = digest(snap["obs"].reshape(n, -1), snap["reward"], snap["success"], snap["depth"])
-    sha_cpu = digest(ov.observe_dense(), r, s, d)
+    sha_cpu = digest(ov.observe_dense(threads=ORACLE_THREADS), r, s, d)
     ok["sha256"] = sha_gpu == sha_cpu
     return {"envs": int(n), "steps_replayed": len(trace), "checked": sorted(ok), "bit_exact": all(ok.values()),
             "mismatch": [k for k, v in ok.items() if not v], "sha256_hip": sha_gpu, "sha256_oracle": sha_cpu}
@@ -212,7 +214,7 @@ def gathered_parity(gateset, seed, global_ids, ring_actions, trace, shard):
 
     ov, (r, s, f, _) = oracle_replay(gateset, seed, global_ids, ring_actions, trace)
     n = len(global_ids)
-    want_obs = pack_rows_u32(ov.observe_dense().reshape(n, 2 * NUM_QUBITS, 2 * NUM_QUBITS))
+    want_obs = pack_rows_u32(ov.observe_dense(threads=ORACLE_THREADS).reshape(n, 2 * NUM_QUBITS, 2 * NUM_QUBITS))
     ok = {
         "packed_observation": bool(np.array_equal(shard["obs"].view(np.uint32), want_obs)),
         "reward_bits": bool(np.array_equal(f32_bits(shard["reward"]), f32_bits(r))),
@@ -336,6 +338,9 @@ def main():
                     help="diagnostics: run the multi-GPU code path (RCCL init, side-stream all-gather) on ONE rank")
     ap.add_argument("--shard", type=str, default=None,
                     help="with --force-multi: R/W = be rank R of a W-rank job for every env id (env base R * envs, actions of that slice)")
+    ap.add_argument("--inject-p2p-open-failure", type=int, default=-1, metavar="RANK",
+                    help="tests only: this rank's hipIpcOpenMemHandle phase raises (tests/test_gpu_multi.py: every rank must stop at the same phase)")
+    ap.add_argument("--diag-repeat", type=int, default=0, help="diagnostics: repeat the timed region this many times after the measurement and print each on stderr")
     ap.add_argument("--dump-gathered", type=str, default=None,
                     help="rank 0: write a strided sample of this rank's part of the last all-gathered shard, with what an oracle replay needs, to this .npz")
     args = ap.parse_args()
@@ -470,7 +475,7 @@ def main():
                 dist.all_gather_object(box["handles"], box["mine"])
 
             def open_():
-                if os.environ.get("QG_BENCH_INJECT_P2P_OPEN_FAILURE") == str(rank):  # tests: this rank cannot map its peers
+                if args.inject_p2p_open_failure == rank:  # tests: this rank cannot map its peers
                     raise RuntimeError("injected: hipIpcOpenMemHandle failed")
                 comm.p2p_open(box["handles"])
 
@@ -552,8 +557,8 @@ def main():
     torch.cuda.synchronize()
     gathers_before = gather_log["submitted"]
     elapsed, ev0, ev1 = timed_region()
-    if os.environ.get("QG_BENCH_DIAG_REPEAT"):  # diagnostics only: the same timed region again, to tell one-shot effects from steady state
-        for _ in range(int(os.environ["QG_BENCH_DIAG_REPEAT"])):
+    if args.diag_repeat:  # diagnostics only: the same timed region again, to tell one-shot effects from steady state
+        for _ in range(args.diag_repeat):
             td = time.perf_counter()
             with torch.cuda.stream(stream):
                 run_steps(K)
@@ -569,9 +574,10 @@ def main():
     timed_launches = list(launches)
     gathers_timed = gather_log["submitted"] - gathers_before
 
-    # ---- snapshot of a sample of envs right after the timed steps, for the oracle replay -------
+    # ---- snapshot of EVERY env right after the timed steps, for the oracle replay (every lane of every wave: the kernels are
+    # lane-position sensitive, and the oracle steps 65 536 envs x a few thousand steps in seconds) -------
     snap = gshard = None
-    ids = np.arange(0, B, 64)
+    ids = np.arange(B)
     idx = torch.as_tensor(ids, device=dev)
     if rank == 0 and not args.no_parity:
         with torch.cuda.stream(stream):
@@ -945,12 +951,12 @@ def main():
             same = bool(torch.equal(tracked, tenv.observe())) and bool(torch.equal(obs_d, oenv.observe()))
         if not same:
             raise SystemExit("bench.py: the tracked dense observation differs from a full rewrite of the same state")
-        # oracle check of a sample: oenv and tenv took the same steps from the same reset (eager pass + 6 replays of each graph)
+        # oracle check of every env: oenv and tenv took the same steps from the same reset (eager pass + 6 replays of each graph)
         obs_parity = None
         if rank == 0 and not args.no_parity:
             o_steps = 2 * 6 * OT  # oenv: two stepping graphs (eager pass + 5 replays each); tenv: one
             t_steps = 6 * OT
-            sample = np.arange(0, B, 512)
+            sample = np.arange(B)  # every env
             acts_np = host_actions[:, sample].numpy()
             ov_o, _ = oracle_replay(gateset, seed, env_base + sample, acts_np, [t % RING for t in range(OT)] * (o_steps // OT))
             ov_t, _ = oracle_replay(gateset, seed, env_base + sample, acts_np, [t % RING for t in range(OT)] * (t_steps // OT))

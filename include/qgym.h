@@ -302,6 +302,9 @@ int qg_vec_sync(qg_vec *v, void *stream);
  * reported exactly when it is below 2^32 - 1; negative or larger ones are reported as
  * UINT64_MAX (what `-1 as usize` is). */
 int64_t qg_vec_solution(qg_vec *v, uint64_t env, uint64_t *out, size_t cap);
+/* The same for EVERY env with one copy of the log: out[e * cap + i] = entry i of env e's list (entries beyond cap dropped), lens[e] = its
+ * full length (what twisterl's collector does per episode with Env::solution, here once per batch).  Host pointers; synchronises. */
+int qg_vec_solutions(qg_vec *v, uint64_t *out, size_t cap, int64_t *lens);
 
 /* ------------------------------------------------------------------------------------------
  * Collector support: the device-side steps between observe() and step() when a policy network

@@ -1460,7 +1460,55 @@ int og_vec_observe_dense(og_vec *v, int8_t *out, int threads) {
     return 0;
 }
 int og_vec_get_state(og_vec *v, int64_t *out, size_t per_env) {
-    for (size_t i = 0; i < v->batch; i++)
-        if (og_env_get_state_i64(v->envs[i], out + i * per_env, per_env) != per_env) return fail("get_state: size mismatch");
+    int bad = 0;
+    long B = (long)v->batch;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) reduction(| : bad)
+#endif
+    for (long i = 0; i < B; i++)
+        if (og_env_get_state_i64(v->envs[i], out + (size_t)i * per_env, per_env) != per_env) bad |= 1;
+    return bad ? fail("get_state: size mismatch") : 0;
+}
+
+/* --- batched conveniences for the full-size parity tests (no reference counterpart: the draws of Env::reset made explicit
+ * through the counter RNG the HIP path uses, qgym_internal.hpp rng_draw).  env i of the batch is GLOBAL env env_ids[i] (or
+ * env_base + i); `mask` (or NULL = all) selects the envs to reset. --- */
+int og_vec_reset_seeded(og_vec *v, uint64_t seed, uint64_t env_base, const uint64_t *env_ids, const uint8_t *mask, int threads) {
+    int rc = 0;
+    long B = (long)v->batch;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(threads) reduction(| : rc)
+#endif
+    for (long i = 0; i < B; i++) {
+        if (mask && !mask[i]) continue;
+        og_env *e = v->envs[i];
+        const size_t n = e->difficulty;
+        int64_t *draws = (int64_t *)malloc(sizeof(int64_t) * (n ? n : 1));
+        og_rng rng = {seed, env_ids ? env_ids[i] : env_base + (uint64_t)i, 0};
+        for (size_t t = 0; t < n; t++) draws[t] = (int64_t)og_range(&rng, e->n_gates); /* clifford.rs:311-316 gen_range(0..num_actions) */
+        if (og_env_reset_with(e, draws, n)) rc |= 1;
+        free(draws);
+    }
+    (void)threads;
+    return rc ? -1 : 0;
+}
+int og_vec_pauli_reset_seeded(og_vec *v, uint64_t seed, uint64_t env_base, const uint64_t *env_ids, const uint8_t *mask, int threads) {
+    int rc = 0;
+    long B = (long)v->batch;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(threads) reduction(| : rc)
+#endif
+    for (long i = 0; i < B; i++) {
+        if (mask && !mask[i]) continue;
+        if (og_pauli_reset_seeded(v->envs[i], seed, env_ids ? env_ids[i] : env_base + (uint64_t)i)) rc |= 1;
+    }
+    (void)threads;
+    return rc ? -1 : 0;
+}
+/* Env::solution of every env: out[i * cap .. ] (entries beyond cap dropped), lens[i] = the full length */
+int og_vec_solutions(og_vec *v, uint64_t *out, size_t cap, int64_t *lens) {
+    for (size_t i = 0; i < v->batch; i++) lens[i] = (int64_t)og_env_solution(v->envs[i], out + i * cap, cap);
     return 0;
 }

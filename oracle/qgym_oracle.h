@@ -150,6 +150,12 @@ int og_vec_step(og_vec *v, const int32_t *actions, const uint8_t *coins, float *
 /* dense int8 observation [B, prod(obs_shape)] (envs/adapters.py:50-54) */
 int og_vec_observe_dense(og_vec *v, int8_t *out, int threads);
 int og_vec_get_state(og_vec *v, int64_t *out, size_t per_env);
+/* Test conveniences: Env::reset of the envs selected by `mask` (NULL = all) with its draws taken from the counter RNG the HIP path
+ * uses, keyed by the GLOBAL env id (env_ids[i], or env_base + i): `difficulty` x gen_range(0..num_actions) for Clifford / LinearFunction /
+ * Permutation (clifford.rs:311-316), og_pauli_reset_seeded for PauliEnv; and Env::solution of every env (lens[i] = full length). */
+int og_vec_reset_seeded(og_vec *v, uint64_t seed, uint64_t env_base, const uint64_t *env_ids, const uint8_t *mask, int threads);
+int og_vec_pauli_reset_seeded(og_vec *v, uint64_t seed, uint64_t env_base, const uint64_t *env_ids, const uint8_t *mask, int threads);
+int og_vec_solutions(og_vec *v, uint64_t *out, size_t cap, int64_t *lens);
 
 #ifdef __cplusplus
 }

@@ -88,6 +88,7 @@ EXPORTED_SYMBOLS = [
     "qg_vec_set_state", "qg_vec_get_state", "qg_vec_reset", "qg_vec_reset_done", "qg_vec_reset_done_step", "qg_vec_set_clock", "qg_stream_wait_stream", "qg_vec_set_counters", "qg_vec_set_seed", "qg_vec_set_env_base", "qg_vec_get_env_base", "qg_vec_reset_with", "qg_vec_step", "qg_vec_step_host", "qg_vec_rollout", "qg_vec_rollout_ring",
     "qg_vec_observe_dense", "qg_vec_track_dense", "qg_vec_observe_packed", "qg_vec_observe_dense_host", "qg_vec_observe_packed_host", "qg_vec_masks", "qg_vec_pauli_reset_from", "qg_vec_pauli_observe_dense", "qg_vec_pauli_num_perms", "qg_vec_sync",
     "qg_vec_solution",
+    "qg_vec_solutions",
     "qg_vec_observe_dense_as", "qg_expand_packed", "qg_widen_dense", "qg_sample_actions", "qg_gae",
     "qg_vec_embed_packed_bytes", "qg_vec_pack_embedding", "qg_vec_embed", "qg_vec_embed_observe",
     "qg_policy_embed_words_packed_bytes", "qg_policy_pack_embed_words", "qg_policy_embed_words",
@@ -161,6 +162,7 @@ def load():
     L.qg_vec_sync.argtypes = [vp, vp]
     L.qg_vec_solution.argtypes = [vp, u64, C.POINTER(u64), sz]
     L.qg_vec_solution.restype = i64
+    L.qg_vec_solutions.argtypes = [vp, C.POINTER(u64), sz, C.POINTER(i64)]
     L.qg_vec_observe_dense_as.argtypes = [vp, vp, C.c_int, vp]
     L.qg_expand_packed.argtypes = [vp, C.c_int, u64, C.c_uint32, vp, C.c_int, vp]
     L.qg_sample_actions.argtypes = [vp, C.c_int, u64, u64, C.c_uint32, vp, u64, u64, vp, vp, C.c_int, vp, vp, C.c_int32, vp, vp]

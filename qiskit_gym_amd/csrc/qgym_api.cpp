@@ -1372,6 +1372,30 @@ int qg_vec_sync(qg_vec *v, void *stream) {
     return QG_OK;
 }
 
+// Env::solution from one env's slice of the log (`row[i * stride]` = entry i in push order, `len` = {pushed to solution, to solution_inv})
+static size_t decode_solution(const qg_vec *v, const uint32_t *row, size_t stride, const int32_t len[2], uint64_t *out, size_t cap) {
+    size_t n = 0;
+    if (v->layout == LAYOUT_PAULI) {  // one list (pauli.rs:685-719); 32-bit entries
+        for (int32_t i = 0; i < len[0]; ++i, ++n)
+            if (n < cap && out) out[n] = row[i * stride] == 0xFFFFFFFFu ? ~0ull : (uint64_t)row[i * stride];  // saturated invalid action
+        return n;
+    }
+    // solution ++ reverse(solution_inv) (clifford.rs:376-381).  The log holds the pushes in order, bit 31 = pushed to solution_inv.
+    auto widen = [](uint32_t w) { return (w & 0x7FFFFFFFu) == 0x7FFFFFFFu ? ~0ull : (uint64_t)(w & 0x7FFFFFFFu); };
+    const uint32_t total = (uint32_t)std::min<int64_t>((int64_t)len[0] + len[1], v->sol_cap);
+    for (uint32_t i = 0; i < total; ++i)
+        if (!(row[i * stride] >> 31)) {
+            if (n < cap && out) out[n] = widen(row[i * stride]);
+            ++n;
+        }
+    for (uint32_t i = total; i-- > 0;)
+        if (row[i * stride] >> 31) {
+            if (n < cap && out) out[n] = widen(row[i * stride]);
+            ++n;
+        }
+    return n;
+}
+
 int64_t qg_vec_solution(qg_vec *v, uint64_t env, uint64_t *out, size_t cap) {
     if (!v) return set_error(QG_ERR_INVALID, "null argument");
     if (env >= v->B) return set_error(QG_ERR_INVALID, "env index out of range");
@@ -1385,26 +1409,26 @@ int64_t qg_vec_solution(qg_vec *v, uint64_t env, uint64_t *out, size_t cap) {
         (void)hipGetLastError();
         return set_error(QG_ERR_DEVICE, "solution copy failed");
     }
-    size_t n = 0;
-    if (v->layout == LAYOUT_PAULI) {  // one list (pauli.rs:685-719); 32-bit entries
-        for (int32_t i = 0; i < len[0]; ++i, ++n)
-            if (n < cap && out) out[n] = row[i] == 0xFFFFFFFFu ? ~0ull : (uint64_t)row[i];  // saturated invalid action
-        return (int64_t)n;
+    return (int64_t)decode_solution(v, row.data(), 1, len, out, cap);
+}
+
+int qg_vec_solutions(qg_vec *v, uint64_t *out, size_t cap, int64_t *lens) {
+    if (!v || !lens || (cap && !out)) return set_error(QG_ERR_INVALID, "null argument");
+    if (!v->cfg.track_solution) {
+        std::fill(lens, lens + v->B, (int64_t)0);
+        return QG_OK;
     }
-    // solution ++ reverse(solution_inv) (clifford.rs:376-381).  The log holds the pushes in order, bit 31 = pushed to solution_inv.
-    auto widen = [](uint32_t w) { return (w & 0x7FFFFFFFu) == 0x7FFFFFFFu ? ~0ull : (uint64_t)(w & 0x7FFFFFFFu); };
-    const uint32_t total = (uint32_t)std::min<int64_t>((int64_t)len[0] + len[1], v->sol_cap);
-    for (uint32_t i = 0; i < total; ++i)
-        if (!(row[i] >> 31)) {
-            if (n < cap && out) out[n] = widen(row[i]);
-            ++n;
-        }
-    for (uint32_t i = total; i-- > 0;)
-        if (row[i] >> 31) {
-            if (n < cap && out) out[n] = widen(row[i]);
-            ++n;
-        }
-    return (int64_t)n;
+    QG_ON_DEVICE(v);
+    std::vector<int32_t> len((size_t)v->B * 2);
+    std::vector<uint32_t> log((size_t)v->sol_cap * v->B);
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(len.data(), v->sol_len, len.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(log.data(), v->sol, log.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return set_error(QG_ERR_DEVICE, "solution copy failed");
+    }
+    for (size_t e = 0; e < v->B; ++e) lens[e] = (int64_t)decode_solution(v, log.data() + e, v->B, &len[2 * e], out ? out + e * cap : nullptr, cap);
+    return QG_OK;
 }
 
 }  // extern "C"

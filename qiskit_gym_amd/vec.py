@@ -333,3 +333,11 @@ class VecEnv:
         buf = (C.c_uint64 * max(int(n), 1))()
         self._L.qg_vec_solution(self._h, env, buf, int(n))
         return [int(buf[i]) for i in range(int(n))]
+
+    def solutions(self, cap: Optional[int] = None):
+        """Env::solution of every env at once (`qg_vec_solutions`): (entries uint64 [B, cap], lengths int64 [B]) as numpy arrays."""
+        cap = int(self.config.get("max_depth", 128) if cap is None else cap)
+        out = np.zeros((self.batch, max(cap, 1)), dtype=np.uint64)
+        lens = np.zeros(self.batch, dtype=np.int64)
+        _lib.check(self._L.qg_vec_solutions(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), cap, lens.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out[:, :cap], lens

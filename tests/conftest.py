@@ -8,6 +8,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
+# The oracle's OpenMP loops default to every CPU the machine shows (256 on the GPU box, of which the container may run 16): cap the team at
+# what this process may actually use.  Set here, before any test module imports torch or the oracle: libgomp reads it once, when it is loaded.
+if "OMP_NUM_THREADS" not in os.environ:
+    try:
+        _q, _p = open("/sys/fs/cgroup/cpu.max").read().split()
+        _quota = None if _q == "max" else int(float(_q) / float(_p) + 0.5)
+    except Exception:
+        _quota = None
+    _n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(max(1, min(_n, _quota or _n)))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
@@ -29,3 +40,4 @@ def _release_scalar_env_pool():
             _lib._lib.qg_env_pool_clear()
     except Exception:
         pass
+

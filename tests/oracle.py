@@ -130,6 +130,10 @@ def lib():
     L.og_vec_step.argtypes = [vp, i32p, u8p, f32p, u8p, u8p, i32p, C.c_int]
     L.og_vec_observe_dense.argtypes = [vp, C.POINTER(C.c_int8), C.c_int]
     L.og_vec_get_state.argtypes = [vp, i64p, sz]
+    u64p = C.POINTER(C.c_uint64)
+    L.og_vec_reset_seeded.argtypes = [vp, C.c_uint64, C.c_uint64, u64p, u8p, C.c_int]
+    L.og_vec_pauli_reset_seeded.argtypes = [vp, C.c_uint64, C.c_uint64, u64p, u8p, C.c_int]
+    L.og_vec_solutions.argtypes = [vp, u64p, sz, i64p]
     _lib = L
     return L
 
@@ -356,6 +360,28 @@ class OracleVec:
         if lib().og_vec_reset_with(self._h, _ptr(a, C.c_int64), a.shape[0]) != 0:
             raise OracleError(lib().og_last_error().decode())
 
+    def reset_seeded(self, seed: int, env_ids=None, env_base: int = 0, mask=None, threads: int = 0):
+        """Env::reset of the envs selected by `mask` (None = all), its draws from the counter RNG of the HIP path keyed by the global env id
+        (env_ids[i] or env_base + i): what qg_vec_reset(seed) / qg_vec_reset_done(seed) do on the device.  PauliEnv: the whole target generator."""
+        ids = ip = None
+        if env_ids is not None:
+            ids = np.ascontiguousarray(np.asarray(env_ids, dtype=np.uint64).reshape(self.batch))
+            ip = _ptr(ids, C.c_uint64)
+        mp = None
+        if mask is not None:
+            mask = np.ascontiguousarray(np.asarray(mask, dtype=np.uint8).reshape(self.batch))
+            mp = _ptr(mask, C.c_uint8)
+        fn = lib().og_vec_pauli_reset_seeded if self.proto.kind == "pauli" else lib().og_vec_reset_seeded
+        if fn(self._h, int(seed) & (2**64 - 1), int(env_base), ip, mp, threads) != 0:
+            raise OracleError(lib().og_last_error().decode())
+
+    def solutions(self, cap: int):
+        """Env::solution of every env: (entries uint64 [B, cap], lengths int64 [B])."""
+        out = np.zeros((self.batch, max(cap, 1)), dtype=np.uint64)
+        lens = np.zeros(self.batch, dtype=np.int64)
+        lib().og_vec_solutions(self._h, _ptr(out, C.c_uint64), cap, _ptr(lens, C.c_int64))
+        return out[:, :cap], lens
+
     def step(self, actions: np.ndarray, coins: np.ndarray | None = None, threads: int = 0):
         a = np.ascontiguousarray(np.asarray(actions, dtype=np.int32).reshape(self.batch))
         reward = np.zeros(self.batch, dtype=np.float32)
@@ -384,7 +410,7 @@ class OracleVec:
         return out
 
     def get_state(self, per_env: int) -> np.ndarray:
-        out = np.zeros((self.batch, per_env), dtype=np.int64)
+        out = np.empty((self.batch, per_env), dtype=np.int64)
         if lib().og_vec_get_state(self._h, _ptr(out, C.c_int64), per_env) != 0:
             raise OracleError(lib().og_last_error().decode())
         return out

@@ -1,10 +1,10 @@
 """BASELINE.json configurations at their full sizes.
 
-Exact oracle parity on a strided sample of envs (envs are independent, so env i on the GPU must
-equal a scalar oracle env fed env i's inputs) plus size-independent properties over ALL envs:
-every gate of these envs is an involution on the phase-less state, so replaying an action sequence
-backwards must return every env to its start state; is_final == (depth == 0 or success); the
-set_state(get_state) round trip is the identity.
+Exact oracle parity for EVERY env of the batch -- every lane of every wave, the ragged tail included: the oracle steps the same
+65 536 (8 192, 128) envs side by side (OracleVec, OpenMP over envs), its resets drawn from the same counter RNG -- plus
+size-independent properties: every gate of these envs is an involution on the phase-less state, so replaying an action
+sequence backwards must return every env to its start state; is_final == (depth == 0 or success); the set_state(get_state)
+round trip is the identity.
 """
 import numpy as np
 import pytest
@@ -16,7 +16,11 @@ from oracle import OracleEnv, OracleVec  # noqa: E402
 from util import f32_bits, grid_gateset, line_gateset, rng_actions  # noqa: E402
 
 
-def _run_config(kind, n, gateset, B, scramble, T, per_env, seed, sample_stride):
+def _all_envs_oracle(kind, n, gateset, B, cfg):
+    return OracleVec(OracleEnv(kind, n, gateset, **{k: int(v) for k, v in cfg.items()}), B)
+
+
+def _run_config(kind, n, gateset, B, scramble, T, per_env, seed):
     from qiskit_gym_amd.vec import VecEnv
 
     A = len(gateset)
@@ -35,20 +39,18 @@ def _run_config(kind, n, gateset, B, scramble, T, per_env, seed, sample_stride):
     depth_mid = gv.depth.clone()
     succ_mid = gv.success.clone()
 
-    # ---- exact parity on a sample of envs ------------------------------------------------------
-    ids = np.arange(0, B, sample_stride)
-    proto = OracleEnv(kind, n, gateset, **{k: int(v) for k, v in cfg.items()})
-    ov = OracleVec(proto, len(ids))
-    ov.reset_with(rng_actions(seed, ids, scramble, A))
-    acts_h = acts.cpu().numpy()[:, ids]
-    rew_h, fin_h = rew.cpu().numpy()[:, ids], fin.cpu().numpy()[:, ids]
+    # ---- exact parity, every env ------------------------------------------------------------------
+    ov = _all_envs_oracle(kind, n, gateset, B, cfg)
+    ov.reset_seeded(seed)
+    np.testing.assert_array_equal(ov.get_state(per_env)[:64], OracleVecFromDraws(kind, n, gateset, cfg, seed, 64, scramble, A).get_state(per_env))
+    acts_h, rew_h, fin_h = acts.cpu().numpy(), rew.cpu().numpy(), fin.cpu().numpy()
     for t in range(T):
         r, s, f, d = ov.step(acts_h[t])
-        np.testing.assert_array_equal(f32_bits(rew_h[t]), f32_bits(r), err_msg=f"reward t={t}")
-        np.testing.assert_array_equal(fin_h[t], f, err_msg=f"is_final t={t}")
-    np.testing.assert_array_equal(gv.get_state("i64").cpu().numpy()[ids], ov.get_state(per_env))
-    np.testing.assert_array_equal(depth_mid.cpu().numpy()[ids], d)
-    np.testing.assert_array_equal(gv.observe().cpu().numpy().reshape(B, -1)[ids], ov.observe_dense())
+        assert np.array_equal(f32_bits(rew_h[t]), f32_bits(r)), f"reward t={t}: envs {np.nonzero(f32_bits(rew_h[t]) != f32_bits(r))[0][:8]}"
+        assert np.array_equal(fin_h[t], f), f"is_final t={t}: envs {np.nonzero(fin_h[t] != f)[0][:8]}"
+    assert np.array_equal(gv.get_state("i64").cpu().numpy(), ov.get_state(per_env)), "state (Vec<i64> wire format)"
+    assert np.array_equal(depth_mid.cpu().numpy(), d) and np.array_equal(succ_mid.cpu().numpy(), s)
+    assert np.array_equal(gv.observe().cpu().numpy().reshape(B, -1), ov.observe_dense()), "dense observation"
 
     # ---- properties over all envs ---------------------------------------------------------------
     d_all, s_all, f_all = depth_mid.cpu().numpy(), succ_mid.cpu().numpy(), gv.done.cpu().numpy()
@@ -65,28 +67,35 @@ def _run_config(kind, n, gateset, B, scramble, T, per_env, seed, sample_stride):
     gv.close()
 
 
+def OracleVecFromDraws(kind, n, gateset, cfg, seed, count, scramble, A):
+    """The first `count` envs reset from draws made in numpy (util.rng_actions): pins og_vec_reset_seeded's C restatement of the counter RNG."""
+    ov = _all_envs_oracle(kind, n, gateset, count, cfg)
+    ov.reset_with(rng_actions(seed, count, scramble, A))
+    return ov
+
+
 def test_config1_permutation_3x3_x128():
     gs = grid_gateset("permutation", 3, 3)
     assert len(gs) == 12
-    _run_config("permutation", 9, gs, 128, 16, 128, 9, 0x5EED0001, 1)
+    _run_config("permutation", 9, gs, 128, 16, 128, 9, 0x5EED0001)
 
 
 def test_config2_linear_function_8q_x8192():
     gs = line_gateset("linear_function", 8)
     assert len(gs) == 28
-    _run_config("linear_function", 8, gs, 8192, 64, 128, 64, 0x5EED0002, 16)
+    _run_config("linear_function", 8, gs, 8192, 64, 128, 64, 0x5EED0002)
 
 
 def test_config3_clifford_16q_x65536():
     gs = line_gateset("clifford", 16)
     assert len(gs) == 170
-    _run_config("clifford", 16, gs, 65536, 256, 128, 1024, 0x5EED0003, 128)
+    _run_config("clifford", 16, gs, 65536, 256, 128, 1024, 0x5EED0003)
 
 
 def test_config5_pauli_20q_x65536():
     """SURVEY 8(d) config 5 as written: PauliGym 20q x 65 536, every env's target made ON THE DEVICE by reset(seed) (ptile_generate_kernel:
     1-7 rotations over the coupling graph's distance classes + a tableau scrambled by `difficulty` = 256 gates, pauli.rs:54-271,554-586),
-    T = 128 steps (= max_depth); 517 sampled envs replayed on the oracle's og_pauli_reset_seeded: the generated target itself, every step's
+    T = 128 steps (= max_depth); EVERY env replayed on the oracle (og_pauli_reset_seeded): the generated target itself, every step's
     reward bits and is_final, and the final observation."""
     from qiskit_gym_amd.vec import VecEnv
 
@@ -106,22 +115,20 @@ def test_config5_pauli_20q_x65536():
     fin = torch.empty((T, B), dtype=torch.uint8, device="cuda")
     gv.rollout(acts, fused=False, rewards_out=rew, dones_out=fin)
     gv.sync()
-    ids = np.arange(0, B, 127)
-    assert len(ids) >= 512
     acts_h, rew_h, fin_h = acts.cpu().numpy(), rew.cpu().numpy(), fin.cpu().numpy()
     obs = gv.observe().cpu().numpy()
-    n_rot = []
-    for e in ids:
-        o = OracleEnv("pauli", n, gs, **{k: int(v) for k, v in cfg.items()})
-        o.pauli_reset_seeded(seed, int(e))
-        n_rot.append(len(o.active_rotations()))
-        np.testing.assert_array_equal(obs0[e], o.dense_obs(), err_msg=f"generated target of env {e}")
-        for t in range(T):
-            o.step(int(acts_h[t, e]))
-            assert np.float32(rew_h[t, e]).view(np.uint32) == o.reward_bits(), (e, t)
-            assert fin_h[t, e] == int(o.is_final()), (e, t)
-        np.testing.assert_array_equal(obs[e], o.dense_obs(), err_msg=f"env {e}")
+    ov = _all_envs_oracle("pauli", n, gs, B, cfg)
+    ov.reset_seeded(seed)  # og_pauli_reset_seeded for every env
+    assert np.array_equal(obs0.reshape(B, -1), ov.observe_dense()), "generated targets"
+    n_rot = [len(ov.env(int(e)).active_rotations()) for e in range(0, B, 127)]
+    for t in range(T):
+        r, s_, f, d = ov.step(acts_h[t])
+        assert np.array_equal(f32_bits(rew_h[t]), f32_bits(r)), f"reward t={t}: envs {np.nonzero(f32_bits(rew_h[t]) != f32_bits(r))[0][:8]}"
+        assert np.array_equal(fin_h[t], f), f"is_final t={t}: envs {np.nonzero(fin_h[t] != f)[0][:8]}"
+    assert np.array_equal(obs.reshape(B, -1), ov.observe_dense()), "final observation"
+    assert np.array_equal(gv.success.cpu().numpy(), s_)
     assert min(n_rot) >= 1 and max(n_rot) >= 6 and len(set(n_rot)) >= 5  # the 1-7 rotations per env SURVEY 8(d) names
+    ids = np.arange(0, B, 127)
     d_all, s_all, f_all = gv.depth.cpu().numpy(), gv.success.cpu().numpy(), gv.done.cpu().numpy()
     np.testing.assert_array_equal(f_all, ((d_all == 0) | (s_all == 1)).astype(np.uint8))
     assert (d_all == 0).all()
@@ -141,7 +148,7 @@ def _coins(coin_seed, env_ids, step_index):
 
 def test_config5_pauli_reset_done_of_one_percent_at_full_size():
     """Config 5's env in the auto-reset regime: 1 % of 65 536 PauliGym 20q envs finished -> qg_vec_reset_done generates their fresh targets with a
-    workgroup per env (ptile_reset_tree_kernel: the 256-gate tableau scramble one gate per thread).  Sampled finished envs against the oracle's
+    workgroup per env (ptile_reset_tree_kernel: the 256-gate tableau scramble one gate per thread).  Every finished env against the oracle's
     og_pauli_reset_seeded; every other env untouched."""
     from qiskit_gym_amd.vec import VecEnv
 
@@ -162,23 +169,25 @@ def test_config5_pauli_reset_done_of_one_percent_at_full_size():
     keep = torch.ones(B, dtype=torch.bool, device="cuda")
     keep[torch.as_tensor(listed, device="cuda")] = False
     assert torch.equal(after[keep], before[keep]) and torch.equal(gv.depth[keep], depth0[keep])
-    for e in listed[::28]:  # 24 of them
-        o = OracleEnv("pauli", n, gs, **{k: int(v) for k, v in cfg.items()})
-        o.pauli_reset_seeded(seed + 1, int(e))
-        np.testing.assert_array_equal(after[int(e)].cpu().numpy(), o.dense_obs(), err_msg=f"env {e}")
-        assert int(gv.depth[int(e)]) == o.depth() and bool(gv.done[int(e)]) == o.is_final() and bool(gv.success[int(e)]) == o.success()
+    ov = _all_envs_oracle("pauli", n, gs, len(listed), cfg)  # every listed env
+    ov.reset_seeded(seed + 1, env_ids=listed)
+    li = torch.as_tensor(listed, device="cuda")
+    assert np.array_equal(after[li].cpu().numpy().reshape(len(listed), -1), ov.observe_dense()), "regenerated targets"
+    for j, e in enumerate(listed):
+        o = ov.env(j)
+        assert int(gv.depth[int(e)]) == o.depth() and bool(gv.done[int(e)]) == o.is_final() and bool(gv.success[int(e)]) == o.success(), e
 
 
-@pytest.mark.parametrize("kind,n,B,scramble,per_env,stride", [
-    ("clifford", 16, 65536, 256, 1024, 128),        # config 3 with the reference's defaults: qm_inv2_kernel
-    ("linear_function", 8, 8192, 64, 64, 16),       # config 2 with the defaults: word_step_kernel with the byte-parallel Gauss-Jordan
-    ("linear_function", 16, 65536, 64, 256, 128),   # lfd_step_kernel (matrix + inverse, inversion = role swap)
+@pytest.mark.parametrize("kind,n,B,scramble,per_env", [
+    ("clifford", 16, 65536, 256, 1024),        # config 3 with the reference's defaults: qm_inv2_kernel
+    ("linear_function", 8, 8192, 64, 64),      # config 2 with the defaults: word_step_kernel with the byte-parallel Gauss-Jordan
+    ("linear_function", 16, 65536, 64, 256),   # lfd_step_kernel (matrix + inverse, inversion = role swap)
 ])
-def test_reference_default_configuration_at_full_size(kind, n, B, scramble, per_env, stride):
+def test_reference_default_configuration_at_full_size(kind, n, B, scramble, per_env):
     """The reference's DEFAULT options (envs/synthesis.py:182-204: add_inverts=True, track_solution=True) at BASELINE's batch sizes, the
     coins thrown by the handle's counter RNG (clifford.rs:262-270 with the draw made explicit), T = 128 = max_depth so the solution log is
-    full: per-step reward bits / is_final, final state, depth and the `solution ++ rev(solution_inv)` list (clifford.rs:334-340,376-381) of a
-    strided sample against the oracle; is_final == (depth == 0 or success) over all envs."""
+    full: per-step reward bits / is_final, final state, depth and the `solution ++ rev(solution_inv)` list (clifford.rs:334-340,376-381) of
+    EVERY env against the oracle; is_final == (depth == 0 or success) over all envs."""
     from qiskit_gym_amd.vec import VecEnv
 
     gs = line_gateset(kind, n)
@@ -194,25 +203,27 @@ def test_reference_default_configuration_at_full_size(kind, n, B, scramble, per_
     fin = torch.empty((T, B), dtype=torch.uint8, device="cuda")
     gv.rollout(acts, fused=False, rewards_out=rew, dones_out=fin)  # no coins given: the counter RNG
     gv.sync()
-    ids = np.arange(0, B, stride)
-    proto = OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()})
-    ov = OracleVec(proto, len(ids))
-    ov.reset_with(rng_actions(seed, ids, scramble, A))
-    acts_h = acts.cpu().numpy()[:, ids]
-    rew_h, fin_h = rew.cpu().numpy()[:, ids], fin.cpu().numpy()[:, ids]
+    ids = np.arange(B)
+    ov = _all_envs_oracle(kind, n, gs, B, cfg)
+    ov.reset_seeded(seed)
+    acts_h, rew_h, fin_h = acts.cpu().numpy(), rew.cpu().numpy(), fin.cpu().numpy()
     n_inv = 0
     for t in range(T):
         c = _coins(coin_seed, ids, 1000 + t)
         n_inv += int(c.sum())
         r, s, f, d = ov.step(acts_h[t], c)
-        np.testing.assert_array_equal(f32_bits(rew_h[t]), f32_bits(r), err_msg=f"reward t={t}")
-        np.testing.assert_array_equal(fin_h[t], f, err_msg=f"is_final t={t}")
-    assert 0.4 < n_inv / (T * len(ids)) < 0.6
-    np.testing.assert_array_equal(gv.get_state("i64").cpu().numpy()[ids], ov.get_state(per_env))
-    np.testing.assert_array_equal(gv.depth.cpu().numpy()[ids], d)
-    np.testing.assert_array_equal(gv.observe().cpu().numpy().reshape(B, -1)[ids], ov.observe_dense())
-    for i in range(0, len(ids), 8):
-        assert gv.solution(int(ids[i])) == ov.env(i).solution(), f"solution of env {ids[i]}"
+        assert np.array_equal(f32_bits(rew_h[t]), f32_bits(r)), f"reward t={t}: envs {np.nonzero(f32_bits(rew_h[t]) != f32_bits(r))[0][:8]}"
+        assert np.array_equal(fin_h[t], f), f"is_final t={t}: envs {np.nonzero(fin_h[t] != f)[0][:8]}"
+    assert 0.49 < n_inv / (T * B) < 0.51
+    assert np.array_equal(gv.get_state("i64").cpu().numpy(), ov.get_state(per_env)), "state"
+    assert np.array_equal(gv.depth.cpu().numpy(), d)
+    assert np.array_equal(gv.observe().cpu().numpy().reshape(B, -1), ov.observe_dense()), "observation"
+    g_sol, g_len = gv.solutions(T)
+    o_sol, o_len = ov.solutions(T)
+    assert np.array_equal(g_len, o_len) and np.array_equal(g_sol, o_sol), "solution lists"
+    assert (o_len == T).all()
+    for e in (0, 63, 64, B - 1):  # the per-env call agrees with the batched one
+        assert gv.solution(e) == ov.env(e).solution()
     d_all, s_all, f_all = gv.depth.cpu().numpy(), gv.success.cpu().numpy(), gv.done.cpu().numpy()
     np.testing.assert_array_equal(f_all, ((d_all == 0) | (s_all == 1)).astype(np.uint8))
     gv.close()
@@ -222,7 +233,7 @@ def test_reference_default_configuration_at_full_size(kind, n, B, scramble, per_
 def test_auto_reset_with_desynchronised_episodes_at_full_size(kind, n, B, inverts):
     """SURVEY 8(d)'s auto-reset variant the way a collector sees it: episodes of L = 16 steps whose ends are spread evenly over time
     (1/16 of the batch finishes per step), qg_vec_reset_done after every step, more than three episode boundaries per env -- every step's
-    reward bits / is_final / depth and the final state of a strided sample against an oracle replay (clifford.rs:306-319 for the reset).
+    reward bits / is_final / depth and the final state of EVERY env against an oracle replay (clifford.rs:306-319 for the reset).
     The spread comes from Env::reset called at different times: during the first L steps class k = {env : env % L == k} is reset at step k
     (its `done` flag -- caller-owned memory, qg_vec_bind_outputs -- is raised, then reset_done)."""
     from qiskit_gym_amd.vec import VecEnv
@@ -232,16 +243,12 @@ def test_auto_reset_with_desynchronised_episodes_at_full_size(kind, n, B, invert
     L, coin_seed = 2 * diff, 0xBEEF
     cfg = dict(add_inverts=inverts, add_perms=False, track_solution=inverts, difficulty=diff)
     gv = VecEnv(kind, n, gs, B, seed=coin_seed, **cfg)
-    ids = np.arange(0, B, 97)
-    envs = [OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()}) for _ in ids]
-
-    def oracle_reset(which, seed):
-        draws = rng_actions(seed, ids[which], diff, A)
-        for j, i in enumerate(which):
-            envs[i].reset_with(draws[:, j])
+    ids = np.arange(B)
+    ov = _all_envs_oracle(kind, n, gs, B, cfg)
+    per_env = (2 * n) ** 2 if kind == "clifford" else n * n
 
     gv.reset(1)
-    oracle_reset(np.arange(len(ids)), 1)
+    ov.reset_seeded(1)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(3)
     all_env = torch.arange(B, device="cuda")
@@ -251,30 +258,29 @@ def test_auto_reset_with_desynchronised_episodes_at_full_size(kind, n, B, invert
         gv.set_counters(t, 0)
         gv.step(acts)
         gv.sync()
-        a_h = acts.cpu().numpy()[ids]
-        c = _coins(coin_seed, ids, t) if inverts else np.zeros(len(ids), dtype=np.uint8)
-        for i, o in enumerate(envs):
-            o.step(int(a_h[i]), int(c[i]))
-        np.testing.assert_array_equal(f32_bits(gv.reward.cpu().numpy()[ids]), np.array([o.reward_bits() for o in envs], dtype=np.uint32), err_msg=f"t={t}")
+        c = _coins(coin_seed, ids, t) if inverts else None
+        r, s, f, d = ov.step(acts.cpu().numpy(), c)
+        assert np.array_equal(f32_bits(gv.reward.cpu().numpy()), f32_bits(r)), f"reward t={t}"
         fin = gv.done.cpu().numpy()
-        np.testing.assert_array_equal(fin[ids], [int(o.is_final()) for o in envs], err_msg=f"t={t}")
-        np.testing.assert_array_equal(gv.depth.cpu().numpy()[ids], [o.depth() for o in envs])
+        assert np.array_equal(fin, f), f"is_final t={t}: envs {np.nonzero(fin != f)[0][:8]}"
+        assert np.array_equal(gv.depth.cpu().numpy(), d), f"depth t={t}"
         if t >= L:
             frac = fin.mean()
             assert 0.04 < frac < 0.10, (t, frac)  # ~1/16 of the batch per step, not all at once
             finished += int(fin.sum())
         gv.reset_done(100 + t)
-        oracle_reset(np.nonzero(fin[ids])[0], 100 + t)
+        ov.reset_seeded(100 + t, mask=fin)
         if t < L:  # Env::reset for class t at time t
             gv.done[all_env % L == t] = 1
             gv.reset_done(5000 + t)
-            oracle_reset(np.nonzero(ids % L == t)[0], 5000 + t)
+            ov.reset_seeded(5000 + t, mask=(ids % L == t))
     assert finished >= 3 * B  # every env went through at least three more episode boundaries
     gv.sync()
-    np.testing.assert_array_equal(gv.get_state("i64").cpu().numpy()[ids], np.stack([o.get_state() for o in envs]))
+    assert np.array_equal(gv.get_state("i64").cpu().numpy(), ov.get_state(per_env)), "final states"
     if inverts:
-        for i in range(0, len(ids), 16):
-            assert gv.solution(int(ids[i])) == envs[i].solution()
+        g_sol, g_len = gv.solutions(2 * L)
+        o_sol, o_len = ov.solutions(2 * L)
+        assert np.array_equal(g_len, o_len) and np.array_equal(g_sol, o_sol), "solution lists"
 
 
 @pytest.mark.parametrize("diff,L", [(8, 16), (128, 128)])
@@ -282,7 +288,7 @@ def test_one_launch_auto_reset_with_a_tracked_observation_at_full_size(diff, L):
     """The headline workload as a collector that reads the dense observation runs it: CliffordGym 16q x 65 536, qg_vec_track_dense, and
     qg_vec_reset_done_step (reset_done + step in one launch) after a first step, episode ends spread evenly over time (1 / L of the batch
     per step: L = 128, difficulty 128 is bench.py's auto-reset leg -- 512 finishers per step, scramble_tree).  Reward bits, is_final, depth of
-    a strided sample against the oracle after every step; at the end the states, and the resident observation against a full rewrite and
+    EVERY env against the oracle after every step; at the end the states, and the resident observation against a full rewrite and
     against the oracle."""
     from qiskit_gym_amd.vec import VecEnv
 
@@ -292,16 +298,11 @@ def test_one_launch_auto_reset_with_a_tracked_observation_at_full_size(diff, L):
     cfg = dict(add_inverts=False, add_perms=False, track_solution=False, difficulty=diff, depth_slope=2 if diff == 8 else 1, max_depth=128)
     gv = VecEnv(kind, n, gs, B, **cfg)
     dense = gv.track_dense()
-    ids = np.arange(0, B, 197)
-    envs = [OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()}) for _ in ids]
-
-    def oracle_reset(which, seed):
-        draws = rng_actions(seed, ids[which], diff, A)
-        for j, i in enumerate(which):
-            envs[i].reset_with(draws[:, j])
+    ids = np.arange(B)
+    ov = _all_envs_oracle(kind, n, gs, B, cfg)
 
     gv.reset(1)
-    oracle_reset(np.arange(len(ids)), 1)
+    ov.reset_seeded(1)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(11)
     all_env = torch.arange(B, device="cuda")
@@ -309,20 +310,16 @@ def test_one_launch_auto_reset_with_a_tracked_observation_at_full_size(diff, L):
         acts = torch.randint(0, A, (B,), dtype=torch.int32, device="cuda", generator=gen)
         gv.step(acts)
         fin = gv.done.cpu().numpy()
-        a_h = acts.cpu().numpy()[ids]
-        for i, o in enumerate(envs):
-            o.step(int(a_h[i]), 0)
+        ov.step(acts.cpu().numpy())
         gv.reset_done(100 + k)
-        oracle_reset(np.nonzero(fin[ids])[0], 100 + k)
+        ov.reset_seeded(100 + k, mask=fin)
         gv.done[all_env % L == k] = 1
         gv.reset_done(5000 + k)
-        oracle_reset(np.nonzero(ids % L == k)[0], 5000 + k)
+        ov.reset_seeded(5000 + k, mask=(ids % L == k))
     finished = 0
     acts = torch.randint(0, A, (B,), dtype=torch.int32, device="cuda", generator=gen)
     gv.step(acts)  # leaves the list and the is_final flags for the one-launch pairs that follow
-    a_h = acts.cpu().numpy()[ids]
-    for i, o in enumerate(envs):
-        o.step(int(a_h[i]), 0)
+    ov.step(acts.cpu().numpy())
     for t in range(2 * L + 7):
         fin = gv.done.cpu().numpy()
         frac = fin.mean()
@@ -331,24 +328,22 @@ def test_one_launch_auto_reset_with_a_tracked_observation_at_full_size(diff, L):
         acts = torch.randint(0, A, (B,), dtype=torch.int32, device="cuda", generator=gen)
         gv.reset_done_step(9000 + t, acts)
         gv.sync()
-        oracle_reset(np.nonzero(fin[ids])[0], 9000 + t)
-        a_h = acts.cpu().numpy()[ids]
-        for i, o in enumerate(envs):
-            o.step(int(a_h[i]), 0)
-        np.testing.assert_array_equal(f32_bits(gv.reward.cpu().numpy()[ids]), np.array([o.reward_bits() for o in envs], dtype=np.uint32), err_msg=f"t={t}")
-        np.testing.assert_array_equal(gv.done.cpu().numpy()[ids], [int(o.is_final()) for o in envs], err_msg=f"t={t}")
-        np.testing.assert_array_equal(gv.depth.cpu().numpy()[ids], [o.depth() for o in envs])
+        ov.reset_seeded(9000 + t, mask=fin)
+        r, s, f, d = ov.step(acts.cpu().numpy())
+        assert np.array_equal(f32_bits(gv.reward.cpu().numpy()), f32_bits(r)), f"reward t={t}"
+        assert np.array_equal(gv.done.cpu().numpy(), f), f"is_final t={t}: envs {np.nonzero(gv.done.cpu().numpy() != f)[0][:8]}"
+        assert np.array_equal(gv.depth.cpu().numpy(), d), f"depth t={t}"
     assert finished >= 2 * B
-    np.testing.assert_array_equal(gv.get_state("i64").cpu().numpy()[ids], np.stack([o.get_state() for o in envs]))
+    assert np.array_equal(gv.get_state("i64").cpu().numpy(), ov.get_state(1024)), "final states"
     assert torch.equal(dense, gv.observe())
-    np.testing.assert_array_equal(dense.cpu().numpy()[ids].reshape(len(ids), -1), np.stack([o.dense_obs() for o in envs]).reshape(len(ids), -1))
+    assert np.array_equal(dense.cpu().numpy().reshape(B, -1), ov.observe_dense()), "resident observation"
 
 
 def test_config4_all_eight_shards_equal_the_whole_batch_x524288():
     """BASELINE config 4 (CliffordGym 16q, 524 288 envs, 8 ranks x 65 536) on one GPU: the WHOLE batch as one handle against each of the
     eight shards as its own handle with its env_base -- reset, 24 steps with auto-reset of finished episodes, then the learner shard every
     rank would hand over (qg_vec_pack_learner_shard).  Concatenated in rank order the eight shards must be the whole batch's hand-over byte
-    for byte (what ncclAllGather / the direct write would assemble), and a strided sample of envs is replayed on the oracle."""
+    for byte (what ncclAllGather / the direct write would assemble); two whole shards and a strided sample of the others are replayed on the oracle."""
     from qiskit_gym_amd.distributed import split_gathered
     from qiskit_gym_amd.vec import VecEnv
 
@@ -395,24 +390,17 @@ def test_config4_all_eight_shards_equal_the_whole_batch_x524288():
     g_obs, g_rew, g_fin, g_suc = split_gathered(torch.cat(gathered), lay, world, 4)
     assert torch.equal(g_obs, w_obs) and torch.equal(g_rew.view(torch.int32), w_rew.view(torch.int32))
     assert torch.equal(g_fin, w_fin) and torch.equal(g_suc, w_suc)
-    # the whole batch against the oracle on a sample: episode boundaries included (the reset's draws come from the counter RNG)
-    ids = np.arange(0, per * world, 4099)
-    envs = [OracleEnv("clifford", n, gs, **{k: int(v) for k, v in cfg.items()}) for _ in ids]
-
-    def oracle_reset(which, sd):
-        draws = rng_actions(sd, ids[which], scramble, A)
-        for j, i in enumerate(which):
-            envs[i].reset_with(draws[:, j])
-
-    oracle_reset(np.arange(len(ids)), seed)
+    # the whole batch against the oracle: episode boundaries included (the reset's draws come from the counter RNG keyed by the GLOBAL env
+    # id) -- all 65 536 envs of rank 5's shard and of rank 7's (the last window), plus every 61st env of the others
+    ids = np.unique(np.concatenate([np.arange(5 * per, 6 * per), np.arange(7 * per, 8 * per), np.arange(0, per * world, 61)]))
+    ov = _all_envs_oracle("clifford", n, gs, len(ids), cfg)
+    ov.reset_seeded(seed, env_ids=ids)
     acts_h, rew_h, fin_h = acts.cpu().numpy()[:, ids], rew.cpu().numpy()[:, ids], fin.cpu().numpy()[:, ids]
     for t in range(T):
-        for i, o in enumerate(envs):
-            o.step(int(acts_h[t, i]), 0)
-        np.testing.assert_array_equal(f32_bits(rew_h[t]), np.array([o.reward_bits() for o in envs], dtype=np.uint32), err_msg=f"reward t={t}")
-        np.testing.assert_array_equal(fin_h[t], [int(o.is_final()) for o in envs], err_msg=f"is_final t={t}")
+        r, s, f, d = ov.step(acts_h[t])
+        assert np.array_equal(f32_bits(rew_h[t]), f32_bits(r)), f"reward t={t}"
+        assert np.array_equal(fin_h[t], f), f"is_final t={t}"
         if t + 1 < T:
-            done_ids = np.nonzero(fin_h[t])[0]
-            if len(done_ids):
-                oracle_reset(done_ids, seed + 1000 * (t + 1))
-    np.testing.assert_array_equal(whole.get_state("i64").cpu().numpy()[ids], np.stack([o.get_state() for o in envs]))
+            ov.reset_seeded(seed + 1000 * (t + 1), env_ids=ids, mask=fin_h[t])
+    idx = torch.as_tensor(ids, device="cuda")
+    assert np.array_equal(whole.observe()[idx].cpu().numpy().reshape(len(ids), -1), ov.observe_dense()), "final states"

@@ -72,7 +72,7 @@ def _run_bench(*flags, timeout=600, extra_env=None):
 def test_bench_rccl_path_gathered_shard_3_of_8_matches_oracle(tmp_path):
     """BASELINE config 4's shape on the hardware there is: one rank runs bench.py's multi-GPU path (process group, side-stream
     all-gather of the flat learner shard, --steps 20 so the driver's arguments put a collective inside the timed region) as
-    rank 3 of 8, i.e. env ids [196 608, 262 144).  The gathered packed observation, rewards and flags of a strided sample are
+    rank 3 of 8, i.e. env ids [196 608, 262 144).  The gathered packed observation, rewards and flags of every env of the shard are
     replayed here on the oracle, independently of bench.py's own check."""
     dump = str(tmp_path / "gathered.npz")
     res = _run_bench("--force-multi", "--shard", "3/8", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-large-batch",
@@ -93,7 +93,8 @@ def test_bench_rccl_path_gathered_shard_3_of_8_matches_oracle(tmp_path):
     gs = line_gateset("clifford", 16)
     proto = OracleEnv("clifford", 16, gs, add_inverts=0, add_perms=0, track_solution=0, difficulty=int(d["scramble"]))
     ov = OracleVec(proto, len(ids))
-    ov.reset_with(rng_actions(int(d["seed"]), ids, int(d["scramble"]), len(gs)))
+    assert len(ids) == 65536  # every env of the shard
+    ov.reset_with(rng_actions(int(d["seed"]), ids, int(d["scramble"]), len(gs)))  # (draws made in numpy: independent of og_vec_reset_seeded)
     r = s = f = None
     assert len(d["trace"]) == 5 + 20  # warmup + the one timed segment
     for ring_idx in d["trace"]:
@@ -109,7 +110,7 @@ def test_bench_line_survives_a_failed_direct_write_leg():
     """The optional direct-write cadence leg fails on this rank (its hipIpcOpenMemHandle, injected): the line still goes out, complete, with
     the RCCL cadences measured and `direct_write: {error: ...}` naming the phase."""
     res = _run_bench("--force-multi", "--shard", "3/8", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-large-batch",
-                     "--no-default-config", "--no-configs", "--no-collector", "--no-dense-obs", extra_env={"QG_BENCH_INJECT_P2P_OPEN_FAILURE": "0"})
+                     "--no-default-config", "--no-configs", "--no-collector", "--no-dense-obs", "--inject-p2p-open-failure", "0")
     assert res.returncode == 0, res.stderr[-3000:]
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')][-1])
     col = line["config"]["collective"]
@@ -185,7 +186,7 @@ def test_bench_as_a_two_rank_job_on_one_gpu_with_the_direct_write_handover():
     assert line["n_gpus"] == 1 and line["physical_gpus"] == 1 and line["ranks_share_gpu0"] and "ONE GPU" in line["metric"]  # said, not implied
     assert cfg["collective"]["handover"] == "direct" and cfg["collective"]["collectives_in_timed_region"] >= 1
     assert line["parity"]["bit_exact"] and line["parity"]["gathered_shard"]["bit_exact"]
-    assert line["parity"]["gathered_shard_of_last_rank"]["bit_exact"] and line["parity"]["gathered_shard_of_last_rank"]["envs"] == 1024
+    assert line["parity"]["gathered_shard_of_last_rank"]["bit_exact"] and line["parity"]["gathered_shard_of_last_rank"]["envs"] == 65536 and line["parity"]["envs"] == 65536
     assert line["value"] > 1e7 and line["scaling"] == "weak"  # (two processes share one GPU: a functional run, its rate means nothing)
 
 
@@ -195,10 +196,10 @@ def test_bench_two_ranks_with_one_rank_unable_to_map_its_peer_fails_fast_on_ever
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    env["QG_BENCH_INJECT_P2P_OPEN_FAILURE"] = "1"
     t0 = time.time()
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--handover", "direct", "--ranks-share-gpu0", "--steps", "20",
-                          "--warmup", "5", "--no-cpu-baseline", "--no-large-batch", "--no-default-config", "--no-configs", "--no-collector"],
+                          "--warmup", "5", "--no-cpu-baseline", "--no-large-batch", "--no-default-config", "--no-configs", "--no-collector",
+                          "--inject-p2p-open-failure", "1"],
                          capture_output=True, text=True, timeout=300, env=env)
     assert res.returncode != 0
     assert time.time() - t0 < 120, "a rank waited for a peer that had already failed"

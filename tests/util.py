@@ -61,9 +61,10 @@ def rng_actions(seed: int, batch, n_draws: int, num_actions: int) -> np.ndarray:
     """The draws qg_vec_reset(seed) uses: mulhi64(rng_draw, num_actions); shape [n_draws, B].
     `batch`: an int (envs 0..B-1) or an array of env indices."""
     env = np.arange(batch, dtype=np.uint64) if np.isscalar(batch) else np.asarray(batch, dtype=np.uint64)
-    batch = env.size
-    out = np.zeros((n_draws, batch), dtype=np.int64)
+    out = np.zeros((n_draws, env.size), dtype=np.int64)
+    a, lo32, s32 = np.uint64(num_actions), np.uint64(0xFFFFFFFF), np.uint64(32)
+    assert 0 < num_actions < 2**32
     for t in range(n_draws):
         d = rng_draw(seed, env, t)
-        out[t] = [(int(v) * num_actions) >> 64 for v in d]
+        out[t] = ((d >> s32) * a + (((d & lo32) * a) >> s32)) >> s32  # (d * a) >> 64 without 128-bit integers
     return out
