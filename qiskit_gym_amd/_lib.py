@@ -89,6 +89,8 @@ EXPORTED_SYMBOLS = [
     "qg_vec_observe_dense", "qg_vec_track_dense", "qg_vec_observe_packed", "qg_vec_observe_dense_host", "qg_vec_observe_packed_host", "qg_vec_masks", "qg_vec_pauli_reset_from", "qg_vec_pauli_observe_dense", "qg_vec_pauli_num_perms", "qg_vec_sync",
     "qg_vec_solution",
     "qg_vec_solutions",
+    "qg_vec_set_kernel_clock",
+    "qg_kernel_clock_rate_khz",
     "qg_vec_observe_dense_as", "qg_expand_packed", "qg_widen_dense", "qg_sample_actions", "qg_gae",
     "qg_vec_embed_packed_bytes", "qg_vec_pack_embedding", "qg_vec_embed", "qg_vec_embed_observe",
     "qg_policy_embed_words_packed_bytes", "qg_policy_pack_embed_words", "qg_policy_embed_words",
@@ -163,6 +165,8 @@ def load():
     L.qg_vec_solution.argtypes = [vp, u64, C.POINTER(u64), sz]
     L.qg_vec_solution.restype = i64
     L.qg_vec_solutions.argtypes = [vp, C.POINTER(u64), sz, C.POINTER(i64)]
+    L.qg_vec_set_kernel_clock.argtypes = [vp, vp, sz]
+    L.qg_kernel_clock_rate_khz.argtypes = [C.c_int]
     L.qg_vec_observe_dense_as.argtypes = [vp, vp, C.c_int, vp]
     L.qg_expand_packed.argtypes = [vp, C.c_int, u64, C.c_uint32, vp, C.c_int, vp]
     L.qg_sample_actions.argtypes = [vp, C.c_int, u64, u64, C.c_uint32, vp, u64, u64, vp, vp, C.c_int, vp, vp, C.c_int32, vp, vp]

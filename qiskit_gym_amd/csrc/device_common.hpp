@@ -8,6 +8,31 @@ namespace qg {
 
 #define QG_WAVE 64
 
+// The kernel device clock (qg_vec_set_kernel_clock, include/qgym.h): how long a launch's waves were on the machine, measured by the waves
+// themselves -- profiler-independent.  The constant-rate counter (s_memrealtime, 100 MHz on gfx950) is read as the kernel's first
+// instruction by every wave (two SGPRs, no wait); with a slot, every wave waits for its own loads and stores at its end, reads the counter again
+// and one lane folds the pair into the launch's slot: slot[0] = min over waves of the entry stamp, slot[1] = max of the exit stamps.  Without a slot (every
+// ordinary launch) the cost is that one scalar instruction and a scalar branch.  Declare as the first statement of a kernel; the destructor runs
+// on every return path (min / max are idempotent, so diverged early returns of a ragged last wave are harmless).
+struct KernelClock {
+    unsigned long long *slot;
+    unsigned long long t0;
+    __device__ inline explicit KernelClock(unsigned long long *s) : slot(s), t0(wall_clock64()) {}
+    __device__ inline ~KernelClock() {
+        if (slot) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the wave's own stores have reached the L2 (gfx9: stores count in vmcnt)
+            const unsigned long long t1 = wall_clock64();
+            const unsigned long long m = __ballot(1);
+            if (__lane_id() == (unsigned)__ffsll((long long)m) - 1u) {
+                atomicMin(slot, t0);
+                atomicMax(slot + 1, t1);
+            }
+        }
+    }
+    KernelClock(const KernelClock &) = delete;
+    KernelClock &operator=(const KernelClock &) = delete;
+};
+
 __device__ inline int64_t load_action(const void *actions, uint64_t idx, bool act64) {
     return act64 ? reinterpret_cast<const int64_t *>(actions)[idx]
                  : (int64_t) reinterpret_cast<const int32_t *>(actions)[idx];

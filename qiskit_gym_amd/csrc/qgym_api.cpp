@@ -379,7 +379,15 @@ static void fill_step_args(const qg_vec *v, StepArgs &a) {
     a.max_rotations = (uint32_t)v->cfg.max_rotations;
 }
 
-static hipError_t launch_step(const qg_vec *v, const StepArgs &a, hipStream_t s) {
+// qg_vec_set_kernel_clock: the slot of the launch about to be enqueued (the k-th one after the call), or null
+static unsigned long long *kernel_clock_slot(const qg_vec *v) {
+    if (!v->kclk || v->kclk_next >= v->kclk_cap) return nullptr;
+    return v->kclk + 2 * (v->kclk_next++);
+}
+
+static hipError_t launch_step(const qg_vec *v, const StepArgs &a_in, hipStream_t s) {
+    StepArgs a = a_in;
+    a.kclk = kernel_clock_slot(v);
     switch (v->layout) {
     case LAYOUT_LFD: return lfd_step(a, v->w64, v->nxp, s);
     case LAYOUT_LF8: return lf8_step(a, a.T > 1, s);
@@ -737,7 +745,9 @@ int qg_vec_set_state(qg_vec *v, const void *states, int format, size_t stride, i
     return QG_OK;
 }
 
-static hipError_t launch_export(const qg_vec *v, const ObsArgs &a, hipStream_t s) {
+static hipError_t launch_export(const qg_vec *v, const ObsArgs &a_in, hipStream_t s) {
+    ObsArgs a = a_in;
+    a.kclk = kernel_clock_slot(v);
     switch (v->layout) {
     case LAYOUT_LFD: return lfd_export(a, v->w64, v->nxp, v->inverted, s);
     case LAYOUT_LF8: return lf8_export(a, s);
@@ -860,6 +870,24 @@ int qg_vec_set_clock(qg_vec *v, const uint64_t *clock_dev) {
     }
     v->graphs.clear();
     return QG_OK;
+}
+
+int qg_vec_set_kernel_clock(qg_vec *v, uint64_t *slots_dev, size_t n_slots) {
+    if (!v || (n_slots && !slots_dev)) return set_error(QG_ERR_INVALID, "null argument");
+    drop_graphs(v);  // cached rollout graphs carry the previous slots (or none) in their kernel arguments
+    v->kclk = n_slots ? reinterpret_cast<unsigned long long *>(slots_dev) : nullptr;
+    v->kclk_cap = n_slots;
+    v->kclk_next = 0;
+    return QG_OK;
+}
+
+int qg_kernel_clock_rate_khz(int device) {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return set_error(QG_ERR_DEVICE, "cannot read the wall clock rate of device %d", device);
+    }
+    return khz;
 }
 
 int qg_stream_wait_stream(void *waiter, void *producer) {
@@ -1053,6 +1081,7 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     if (dense_rides_in_step(v)) a.dense = v->dense;
     const uint8_t *pend_in = v->pend[v->pend_cur];
     uint8_t *pend_out = v->pend[v->pend_cur ^ 1];
+    a.kclk = kernel_clock_slot(v);
     HIP_TRY(qm_reset_step(ia, a, pend_in, pend_out, v->nxp, v->has_z, s));
     v->step_index += 1;
     // the list just appended to is the current one, the idle list (zeroed by this launch) is the next launch's target, the one just consumed idles

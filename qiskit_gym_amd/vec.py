@@ -322,6 +322,29 @@ class VecEnv:
         blob = "".join("".join(l) for l in labels).encode()
         _lib.check(self._L.qg_vec_pauli_reset_from(self._h, t.ctypes.data, blob, n_rot.ctypes.data, self._stream()))
 
+    def kernel_clock(self, n_slots: int) -> Optional[torch.Tensor]:
+        """Diagnostics (`qg_vec_set_kernel_clock`): the next `n_slots` step / observation launches stamp {first wave entry, last wave exit} device-clock
+        ticks into the returned uint64-as-int64 tensor [n_slots, 2] (initialised to {UINT64_MAX, 0}); `n_slots=0` detaches.  See `kernel_durations_us`."""
+        if n_slots <= 0:
+            _lib.check(self._L.qg_vec_set_kernel_clock(self._h, None, 0))
+            self._kclk = None
+            return None
+        slots = torch.empty((n_slots, 2), dtype=torch.int64, device=self.device)
+        slots[:, 0] = -1  # UINT64_MAX
+        slots[:, 1] = 0
+        _lib.check(self._L.qg_vec_set_kernel_clock(self._h, slots.data_ptr(), n_slots))
+        self._kclk = slots
+        return slots
+
+    def kernel_durations_us(self, slots: torch.Tensor) -> np.ndarray:
+        """exit - entry of every stamped slot of `kernel_clock`'s tensor, in microseconds (slots no launch stamped are left out)."""
+        rate = int(self._L.qg_kernel_clock_rate_khz(self.device_index))
+        if rate <= 0:
+            _lib.check(rate)
+        h = slots.cpu().numpy().view(np.uint64)
+        ok = h[:, 1] > 0
+        return (h[ok, 1] - h[ok, 0]).astype(np.float64) * 1e3 / rate
+
     def sync(self):
         """Wait for the current stream and raise if any env hit a fault the reference panics on."""
         _lib.check(self._L.qg_vec_sync(self._h, self._stream()))

@@ -1,0 +1,70 @@
+"""qg_vec_set_kernel_clock (include/qgym.h): the kernel's own waves stamp first entry / last exit of every launch on the device clock.
+The stamps must not change any result, every stamped launch must report a duration that fits inside the launch period the host sees,
+and launches past the last slot (or kernels without stamps) must leave their slots alone."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from util import line_gateset  # noqa: E402
+
+
+@pytest.mark.parametrize("kind,n,B,cfg", [
+    ("clifford", 16, 65536, dict(add_inverts=False, track_solution=False)),   # qm_step1_kernel (the headline)
+    ("clifford", 16, 4100, dict(add_inverts=True, track_solution=True)),      # qm_inv2_kernel, ragged last wave
+    ("linear_function", 8, 8192, dict(add_inverts=False, track_solution=False)),  # word_step_kernel
+    ("pauli", 20, 5000, dict(track_solution=False, max_rotations=5, pauli_diff_scale=8)),  # ptile_step1c_kernel
+    ("clifford", 24, 1000, dict(add_inverts=False, track_solution=False)),    # q64_step1_kernel
+    ("linear_function", 16, 3000, dict(add_inverts=True, track_solution=False)),  # lfd_step_kernel
+])
+def test_stamped_launches_report_durations_and_change_nothing(kind, n, B, cfg):
+    from qiskit_gym_amd.vec import VecEnv
+
+    gs = line_gateset(kind, n)
+    A, T = len(gs), 24
+    envs = [VecEnv(kind, n, gs, B, add_perms=False, difficulty=32, seed=9, **cfg) for _ in range(2)]
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    acts = torch.randint(0, A, (T, B), dtype=torch.int32, device="cuda", generator=gen)
+    for e in envs:
+        e.reset(4)
+    slots = envs[0].kernel_clock(T - 4)  # the last four launches have no slot
+    untouched = slots.clone()
+    t0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0[0].record()
+    envs[0].rollout(acts, fused=False)
+    t0[1].record()
+    envs[1].rollout(acts, fused=False)
+    for e in envs:
+        e.sync()
+    d = envs[0].kernel_durations_us(slots)
+    assert len(d) == T - 4, "every slotted launch stamps its slot"
+    assert (d > 0.3).all() and d.sum() < t0[0].elapsed_time(t0[1]) * 1e3, (d.min(), d.sum(), t0[0].elapsed_time(t0[1]) * 1e3)
+    h = slots.cpu().numpy().view(np.uint64)
+    assert (h[1:, 0] >= h[:-1, 1]).all(), "launches on one stream: each starts after the one before has finished"
+    fmt = "i64" if kind == "pauli" else "packed"
+    assert torch.equal(envs[0].get_state(fmt), envs[1].get_state(fmt))
+    assert torch.equal(envs[0].reward.view(torch.int32), envs[1].reward.view(torch.int32)) and torch.equal(envs[0].depth, envs[1].depth)
+    # detached: nothing is written any more
+    envs[0].kernel_clock(0)
+    before = slots.clone()
+    envs[0].step(acts[0])
+    envs[0].sync()
+    assert torch.equal(slots, before) and not torch.equal(slots, untouched)
+
+
+def test_dense_rewrite_is_stamped_and_reset_launches_leave_their_slot_alone():
+    from qiskit_gym_amd.vec import VecEnv
+
+    gs = line_gateset("clifford", 16)
+    env = VecEnv("clifford", 16, gs, 8192, add_inverts=False, add_perms=False, track_solution=False, difficulty=16)
+    env.reset(1)
+    slots = env.kernel_clock(3)
+    out = env.observe()          # slot 0: qm_dense_stream_kernel
+    env.reset(2)                 # (reset kernels take no slot)
+    env.observe(out=out)         # slot 1
+    env.sync()
+    d = env.kernel_durations_us(slots)
+    assert len(d) == 2 and (d > 0.3).all()
+    h = slots.cpu().numpy().view(np.uint64)
+    assert h[2, 0] == np.uint64(0xFFFFFFFFFFFFFFFF) and h[2, 1] == 0
