@@ -91,7 +91,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 CONTROL_TIMEOUT_S = 90   # gloo control plane: a rank that never reaches a barrier costs its peers this long, not the driver's whole budget
 CADENCE_BUDGET_S = 240   # N > 1: wall-clock budget of the optional collective-cadence legs; past it the line is printed without them
 KERNEL = "qg::qm_step1_kernel<16, true, false"  # prefix: the trailing template arguments (feature flags, done list) vary by call site
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r05")
 
 
 def build_gateset():
@@ -227,7 +227,7 @@ def gathered_parity(gateset, seed, global_ids, ring_actions, trace, shard):
 
 def rocprof_kernel_avg_us(envs: int, required: bool = False):
     """Average duration of the step kernel in the committed rocprofv3 --kernel-trace --stats summary of this command
-    (profiles/r04/, tools/profile_bench.sh).  The statistics hold one batch size (profiling runs pass --no-large-batch).  Every
+    (profiles/r05/, tools/profile_bench.sh).  The statistics hold one batch size (profiling runs pass --no-large-batch).  Every
     instantiation of the kernel whose name starts with KERNEL counts (calls-weighted).  `required`: a missing file or kernel is an
     error -- the line's roofline.frac is this figure -- unless the run IS the profiling run (--profiling-run)."""
     path = os.path.join(PROFILE_DIR, "bench_kernel_stats.csv" if envs == ENVS_PER_GPU else f"bench_{envs}_kernel_stats.csv")
@@ -246,12 +246,12 @@ def rocprof_kernel_avg_us(envs: int, required: bool = False):
         return {"avg_us": total_ns / calls / 1e3, "min_us": min(mins) / 1e3, "calls": calls, "source": os.path.relpath(path, ROOT)}
     if required:
         raise SystemExit(f"bench.py: {os.path.relpath(path, ROOT)} does not hold a kernel named {want}*: re-run tools/profile_bench.sh on the "
-                         "current build and commit profiles/r04 (or pass --profiling-run)")
+                         "current build and commit profiles/r05 (or pass --profiling-run)")
     return None
 
 
 def profiled_configs():
-    """profiles/r04/traffic.json: per configuration the step kernel's rocprofv3 average, the PMC bytes per env (separate FETCH_SIZE /
+    """profiles/r05/traffic.json: per configuration the step kernel's rocprofv3 average, the PMC bytes per env (separate FETCH_SIZE /
     WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), the bytes it needs and both fractions of 8 TB/s."""
     try:
         return json.load(open(os.path.join(PROFILE_DIR, "traffic.json")))["configs"]
@@ -317,7 +317,7 @@ def main():
     ap.add_argument("--no-default-config", action="store_true", help="skip the reference-default (add_inverts=True, track_solution=True) leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the C2 / C5 / C3d legs (SURVEY 8d's other configurations)")
     ap.add_argument("--profiling-run", action="store_true",
-                    help="this run produces profiles/r04 (tools/profile_bench.sh): the committed rocprofv3 summary is not required and roofline.frac falls "
+                    help="this run produces profiles/r05 (tools/profile_bench.sh): the committed rocprofv3 summary is not required and roofline.frac falls "
                          "back to the live clock")
     ap.add_argument("--no-dense-obs", action="store_true", help="skip the observation-mode legs (SURVEY 8d: packed and dense observation after every step)")
     ap.add_argument("--no-collector", action="store_true", help="skip the policy-in-the-loop leg (SURVEY 8f-3: collection with the reference's default policy shape)")
@@ -732,9 +732,28 @@ def main():
             stops[i].record(stream)
     torch.cuda.synchronize()
     eager_event_us = float(np.median(sorted(s.elapsed_time(e) * 1e3 for s, e in zip(starts, stops))))
+    # (4) the kernel's own clock (qg_vec_set_kernel_clock): every wave stamps its entry and -- after waiting for its loads and stores -- its exit on
+    # the device's constant-rate counter; a launch's duration = last exit - first entry.  No host, no profiler, no launch boundary: this is the
+    # duration roofline.achieved divides by.  One slot per launch of a CHUNK-launch graph, four replays.
+    kslots = env.kernel_clock(CHUNK)
+    kdurs = []
+    with torch.cuda.stream(stream):
+        env.rollout_ring(actions, CHUNK)  # a fresh graph: its launches carry their slots
+        for _ in range(4):
+            torch.cuda.synchronize()
+            kslots.zero_()
+            torch.cuda.synchronize()
+            env.rollout_ring(actions, CHUNK)
+            torch.cuda.synchronize()
+            kdurs.append(env.kernel_durations_us(kslots))
+    env.kernel_clock(0)
+    kdurs = np.concatenate(kdurs)
+    if kdurs.size != 4 * CHUNK:
+        raise SystemExit(f"bench.py: {kdurs.size} of {4 * CHUNK} step launches stamped the kernel clock")
+    device_clock_us = float(kdurs.mean())
     algo_bytes = ALGO_BYTES_PER_STEP * B
     needed_bytes = NEEDED_BYTES_PER_STEP * B
-    achieved = algo_bytes / (timed_region_us * 1e-6) / 1e9
+    achieved = algo_bytes / (device_clock_us * 1e-6) / 1e9
     rocprof = rocprof_kernel_avg_us(B)  # the committed rocprofv3 summary of this command: reported beside the live clock, never required
     traffic = pmc_traffic(B)
 
@@ -977,12 +996,12 @@ def main():
             "packed": mode(us_packed, ALGO_BYTES_PER_STEP + 2 * 4 * 2 * n,
                            "step + qg_vec_observe_packed per step: 8d's 160 B + the env-major copy of the 32 row words (128 B read, 128 B written)"),
             "dense": mode(us_dense, ALGO_BYTES_PER_STEP + D2, "step + qg_vec_observe_dense per step: SURVEY 8d's 1 184 B per env-step (full 1 KiB int8 rewrite)"),
-            "dense_tracked": dict(mode(us_tracked, ALGO_BYTES_PER_STEP + D2,
-                                       "qg_vec_track_dense: the step kernel rewrites the rows its gate changed in a resident dense observation; the tensor "
-                                       "holds the same bytes as after the full rewrite.  frac is quoted on 8d's 1 184 B, most of which this form does not "
-                                       "move (it may exceed 1); frac_moved on the bytes it has to move"),
-                                  bytes_moved_per_env_step=NEEDED_BYTES_PER_STEP + 64,
-                                  frac_moved=(NEEDED_BYTES_PER_STEP + 64) * B / (us_tracked * 1e-6) / 1e9 / HBM_PEAK_GBS),
+            "dense_tracked": {"us_per_step": us_tracked, "value": B / (us_tracked * 1e-6), "unit": "env-steps/s",
+                              "bytes_moved_per_env_step": NEEDED_BYTES_PER_STEP + 64,
+                              "frac_moved": (NEEDED_BYTES_PER_STEP + 64) * B / (us_tracked * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                              "what": "qg_vec_track_dense: the step kernel rewrites the rows its gate changed in a resident dense observation; the tensor "
+                                      "holds the same bytes as after the full rewrite.  No fraction on 8d's 1 184 B: this form does not move most of them; "
+                                      "frac_moved is on the bytes it has to move"},
             "dense_tracked_reference_defaults": {
                 "us_per_step": us_tracked_default, "value": B / (us_tracked_default * 1e-6), "unit": "env-steps/s",
                 "what": "qg_vec_track_dense with add_inverts=True, track_solution=True (coins given): qm_inv2_kernel rewrites the whole env when its coin fires "
@@ -998,7 +1017,7 @@ def main():
         del oenv, tenv, obs_d, obs_p, tracked
 
     # ---- SURVEY 8(d)'s other configurations: live launch period (hipGraph of 128 single-step launches) beside the committed rocprofv3 / PMC
-    # figures of the same kernels (profiles/r04/traffic.json, tools/profile_bench.sh) -----
+    # figures of the same kernels (profiles/r05/traffic.json, tools/profile_bench.sh) -----
     configs = None
     if not multi and B == ENVS_PER_GPU and not args.no_configs:
         from util import line_gateset
@@ -1028,7 +1047,7 @@ def main():
             row = {"kernel": p.get("kernel"), "envs": venv.batch, "us_per_step": us, "value": venv.batch / (us * 1e-6), "unit": "env-steps/s",
                    "rocprof_avg_us": st.get("avg_us"), "pmc_bytes_per_env": p.get("bytes_per_env"), "needed_bytes_per_env": p.get("needed_bytes_per_env"),
                    "survey_8d_bytes_per_env": p.get("survey_8d_bytes_per_env"), "frac_moved": p.get("rocprof_frac_moved"),
-                   "frac_survey_8d": p.get("rocprof_frac_algorithmic"), "source": "profiles/r04/traffic.json" if p else None}
+                   "frac_survey_8d": p.get("rocprof_frac_algorithmic"), "source": "profiles/r05/traffic.json" if p else None}
             configs[name] = row
 
         gs2 = line_gateset("linear_function", 8)
@@ -1176,14 +1195,20 @@ def main():
                 "bound": "hbm",
                 "kernel": KERNEL,
                 "kernel_resources": "256 threads/block, 1 wave/SIMD at 65 536 envs; no LDS; thread per env",
-                # achieved / frac: SURVEY 8(d)'s algorithmic bytes per launch over the step kernel's launch duration measured in THIS run: HIP
-                # events on the launch stream around the K timed steps.  The committed rocprofv3 --kernel-trace --stats average of the same
-                # command (tools/profile_bench.sh -> profiles/) is reported beside it with whether the two agree
+                # achieved / frac: SURVEY 8(d)'s algorithmic bytes per launch over the step kernel's DURATION ON THE DEVICE CLOCK measured in this run
+                # (qg_vec_set_kernel_clock: first wave entry -> last wave exit, stamped by the waves; mean of 4 x 256 launches).  The launch period
+                # (kernel + launch boundary: HIP events on the launch stream around the K timed steps -- what `value` counts) is beside it, and the
+                # committed rocprofv3 --kernel-trace --stats average of the same command (tools/profile_bench.sh -> profiles/)
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "clock": "HIP events on the launch stream around the K timed steps of this run (kernel_us_timed_region): launch period = kernel + launch boundary",
+                "clock": "kernel device clock (qg_vec_set_kernel_clock): last wave exit - first wave entry on the 100 MHz constant-rate counter, "
+                         "every wave waiting for its own loads and stores before its exit stamp; mean over 4 replays of a 256-launch hipGraph in this run",
+                "kernel_us_device_clock": {"mean": device_clock_us, "median": float(np.median(kdurs)), "min": float(kdurs.min()), "max": float(kdurs.max()),
+                                           "p10": float(np.percentile(kdurs, 10)), "p90": float(np.percentile(kdurs, 90)), "launches": int(kdurs.size)},
+                "launch_period_us": timed_region_us,
+                "frac_launch_period": algo_bytes / (timed_region_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "traffic": traffic["bytes_per_launch"] if traffic else None,
                 "traffic_detail": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes,
@@ -1196,7 +1221,8 @@ def main():
                 "kernel_us_eager_event": eager_event_us,
                 "rocprof_committed": rocprof_vs_live,
                 "frac_by_clock": {
-                    "timed_region": achieved / HBM_PEAK_GBS,
+                    "device_clock": achieved / HBM_PEAK_GBS,
+                    "timed_region": algo_bytes / (timed_region_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                     "graph_period": algo_bytes / (graph_period_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                     "eager_event": algo_bytes / (eager_event_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                     "rocprof_committed_avg": algo_bytes / (rocprof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS if rocprof else None,

@@ -293,14 +293,16 @@ int qg_vec_pauli_observe_dense(qg_vec *v, int8_t *out_dev, const int32_t *perm_i
 int qg_vec_pauli_num_perms(const qg_vec *v);
 
 /* Diagnostics: the kernel device clock -- how long a launch's waves were on the machine, measured by the waves themselves (no profiler, no host
- * clock).  slots_dev: n_slots x {uint64 first wave entry, uint64 last wave exit} in device memory, initialised by the caller to {UINT64_MAX, 0};
+ * clock).  slots_dev: n_slots x waves_per_slot records {uint64 entry, uint64 exit} in device memory (16-byte aligned), zeroed by the caller;
  * ticks of the device's constant-rate counter (qg_kernel_clock_rate_khz: 100 MHz on gfx950).  After the call the k-th step / observation kernel
- * launched through this handle (eager, or captured into a graph: a replay stamps the slots its launches were captured with) folds its waves'
- * stamps into slot k; launches past n_slots and kernels without stamps (reset, export and fused-rollout kernels) leave their slot untouched.
- * Stamped: the one-step kernels (qm_step1 / q64_step1 / qm_inv2 / q64_inv2 / word_step / lfd_step / ptile_step1c), qm_reset_step and the dense
- * observation rewrite (qm_dense_stream).  A wave with a slot waits for its own loads and stores before its exit stamp, so exit - entry covers
- * the memory traffic of the launch; a launch WITHOUT a slot pays one scalar instruction.  n_slots = 0 detaches.  Drops cached rollout graphs. */
-int qg_vec_set_kernel_clock(qg_vec *v, uint64_t *slots_dev, size_t n_slots);
+ * launched through this handle (eager, or captured into a graph: a replay stamps the slots its launches were captured with) has its wave w write
+ * record w of slot k (waves past waves_per_slot write nothing: size it to the largest grid, batch / 32 covers every stamped kernel); the launch's
+ * duration is max(exit) - min(entry) over the records with exit != 0.  Launches past n_slots and kernels without stamps (reset, export and
+ * fused-rollout kernels) leave their slot untouched.  Stamped: the one-step kernels (qm_step1 / q64_step1 / qm_inv2 / q64_inv2 / word_step /
+ * lfd_step / ptile_step1c), qm_reset_step and the dense observation rewrite (qm_dense_stream).  A wave with a slot waits for its own loads and
+ * stores before its exit stamp, so exit - entry covers the memory traffic of the launch; a launch WITHOUT a slot pays one scalar instruction.
+ * n_slots = 0 detaches.  Drops cached rollout graphs. */
+int qg_vec_set_kernel_clock(qg_vec *v, uint64_t *slots_dev, size_t n_slots, uint32_t waves_per_slot);
 /* ticks per millisecond of that counter on `device` (hipDeviceAttributeWallClockRate), or a negative status */
 int qg_kernel_clock_rate_khz(int device);
 

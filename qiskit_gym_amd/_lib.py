@@ -165,7 +165,7 @@ def load():
     L.qg_vec_solution.argtypes = [vp, u64, C.POINTER(u64), sz]
     L.qg_vec_solution.restype = i64
     L.qg_vec_solutions.argtypes = [vp, C.POINTER(u64), sz, C.POINTER(i64)]
-    L.qg_vec_set_kernel_clock.argtypes = [vp, vp, sz]
+    L.qg_vec_set_kernel_clock.argtypes = [vp, vp, sz, C.c_uint32]
     L.qg_kernel_clock_rate_khz.argtypes = [C.c_int]
     L.qg_vec_observe_dense_as.argtypes = [vp, vp, C.c_int, vp]
     L.qg_expand_packed.argtypes = [vp, C.c_int, u64, C.c_uint32, vp, C.c_int, vp]

@@ -11,22 +11,25 @@ namespace qg {
 // The kernel device clock (qg_vec_set_kernel_clock, include/qgym.h): how long a launch's waves were on the machine, measured by the waves
 // themselves -- profiler-independent.  The constant-rate counter (s_memrealtime, 100 MHz on gfx950) is read as the kernel's first
 // instruction by every wave (two SGPRs, no wait); with a slot, every wave waits for its own loads and stores at its end, reads the counter again
-// and one lane folds the pair into the launch's slot: slot[0] = min over waves of the entry stamp, slot[1] = max of the exit stamps.  Without a slot (every
-// ordinary launch) the cost is that one scalar instruction and a scalar branch.  Declare as the first statement of a kernel; the destructor runs
-// on every return path (min / max are idempotent, so diverged early returns of a ragged last wave are harmless).
+// and one lane stores the pair {entry, exit} into the wave's OWN record of the launch's slot (wave w of the grid -> record w; plain 16-byte stores to
+// distinct addresses: atomics folding 1 024 waves into one pair of words queue at one L2 channel for ~12 ns each, and every wave's exit stamp
+// waits for its stores behind them -- the headline kernel read 17 us that way).  The host takes min(entry) and max(exit) over the records.
+// Without a slot (every ordinary launch) the cost is that one scalar instruction and a scalar branch.  Declare as the first statement of a kernel;
+// the destructor runs on every return path (a ragged last wave whose lanes leave at different points writes its record more than once: the
+// last write, the latest exit, stays).
 struct KernelClock {
     unsigned long long *slot;
     unsigned long long t0;
-    __device__ inline explicit KernelClock(unsigned long long *s) : slot(s), t0(wall_clock64()) {}
+    uint32_t waves;
+    __device__ inline KernelClock(unsigned long long *s, uint32_t n) : slot(s), t0(wall_clock64()), waves(n) {}
     __device__ inline ~KernelClock() {
         if (slot) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the wave's own stores have reached the L2 (gfx9: stores count in vmcnt)
             const unsigned long long t1 = wall_clock64();
+            const uint32_t wave = blockIdx.x * ((blockDim.x + 63u) >> 6) + (threadIdx.x >> 6);
             const unsigned long long m = __ballot(1);
-            if (__lane_id() == (unsigned)__ffsll((long long)m) - 1u) {
-                atomicMin(slot, t0);
-                atomicMax(slot + 1, t1);
-            }
+            if (wave < waves && __lane_id() == (unsigned)__ffsll((long long)m) - 1u)
+                *reinterpret_cast<ulonglong2 *>(slot + 2ull * wave) = make_ulonglong2(t0, t1);
         }
     }
     KernelClock(const KernelClock &) = delete;

@@ -65,7 +65,7 @@ __device__ inline uint32_t lanes_or(uint32_t v) {  // OR over the L lanes of an 
 // ---- one env.step() per launch ---------------------------------------------------------------------------------------------------
 template <bool W64, int L, int GPL>
 __global__ __launch_bounds__(256) void lfd_step_kernel(StepArgs a, uint32_t RG) {
-    KernelClock kclk(a.kclk);  // device_common.hpp
+    KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
     using T = LfdT<W64>;
     using W = typename T::W;
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

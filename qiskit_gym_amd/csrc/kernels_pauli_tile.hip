@@ -825,7 +825,7 @@ __device__ inline void planes_add(uint32_t (&w)[5], uint32_t bits) {
 // loaded: per env the step reads two qubit records, two slice pairs and 32 bytes of bookkeeping.
 template <int NQ, int RM, bool FEAT>
 __global__ __launch_bounds__(256) void ptile_step1c_kernel(PTArgs pa) {
-    KernelClock kclk(pa.s.kclk);  // device_common.hpp
+    KernelClock kclk(pa.s.kclk, pa.s.kclk_waves);  // device_common.hpp
     using L = PTLayout<NQ, RM>;
     static_assert(L::COMPACT && RM == 8, "compact layout only");
     const StepArgs &a = pa.s;

@@ -474,7 +474,7 @@ constexpr unsigned QM_LIST_BLOCK = QG_LIST_BLOCK;
 // each with a turn at the list's counter)
 template <int NXP, bool FEAT, bool LIST = false, bool DENSE = false>
 __global__ __launch_bounds__(LIST ? QM_LIST_BLOCK : 256) void qm_inv2_kernel(StepArgs a) {
-    KernelClock kclk(a.kclk);  // device_common.hpp
+    KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ uint32_t dense_rows[DENSE ? (LIST ? QM_LIST_BLOCK / 64 : 4) : 1][DENSE ? 32 * 33 : 1];  // DENSE: the inverted envs' rows, [env of the wave][row], pitch 33
     uint32_t *dl = DENSE ? dense_rows[threadIdx.x >> 6] : nullptr;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(LIST ? QM_LIST_BLOCK : 256) void qm_inv2_kernel(Ste
 // (LIST: launched with QM_LIST_BLOCK threads per workgroup -- fewer, larger workgroups take fewer turns at the list's counter)
 template <int NXP, bool HAS_Z, bool FEAT, bool LIST = false, bool DENSE = false>
 __global__ __launch_bounds__(LIST ? QM_LIST_BLOCK : 256) void qm_step1_kernel(StepArgs a) {
-    KernelClock kclk(a.kclk);  // device_common.hpp
+    KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
     using Rows = QmRows<NXP, HAS_Z>;
     constexpr int D16 = DENSE ? Rows::R / 16 : 0;
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -936,7 +936,7 @@ struct ResetStepArgs {
 };
 template <int NXP, bool HAS_Z, bool FEAT, bool DENSE>
 __global__ __launch_bounds__(256) void qm_reset_step_kernel(ResetStepArgs ra) {
-    KernelClock kclk(ra.step.kclk);  // device_common.hpp
+    KernelClock kclk(ra.step.kclk, ra.step.kclk_waves);  // device_common.hpp
     using Rows = QmRows<NXP, HAS_Z>;
     constexpr int D16 = DENSE ? Rows::R / 16 : 0;
     const StepArgs &a = ra.step;
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(256) void qm_pack_kernel(ObsArgs a, uint32_t nxp, u
 // or without non-temporal stores, measured 1-1.6 us slower than a wave per tile.)
 template <int D16>
 __global__ __launch_bounds__(256) void qm_dense_stream_kernel(ObsArgs a, uint32_t has_z) {
-    KernelClock kclk(a.kclk);  // device_common.hpp
+    KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
     constexpr uint32_t D = 16u * D16, G = D / 4u, PITCH = D + 1u, CPE = D * D16;  // CPE: 16-byte chunks per env
     __shared__ uint32_t lds[4][64 * PITCH];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;

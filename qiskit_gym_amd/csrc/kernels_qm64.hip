@@ -413,7 +413,7 @@ __device__ inline void q64_transpose32(uint32_t (&w)[32]) {
 // NQ = qubit slots in memory (NS / 2 = N rounded up to 4)
 template <int NQ, bool FEAT>
 __global__ __launch_bounds__(256) void q64_inv2_kernel(StepArgs a) {
-    KernelClock kclk(a.kclk);  // device_common.hpp
+    KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t env = tid >> 1;
     const uint32_t h = (uint32_t)tid & 1u;
@@ -640,7 +640,7 @@ __device__ __forceinline__ bool q64_step1_body(const StepArgs &a, uint64_t env) 
 constexpr unsigned Q64_LIST_BLOCK = 1024;
 template <int NS, bool HAS_Z, bool FEAT, bool LIST = false>
 __global__ __launch_bounds__(LIST ? Q64_LIST_BLOCK : 256) void q64_step1_kernel(StepArgs a) {
-    KernelClock kclk(a.kclk);  // device_common.hpp
+    KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
     if constexpr (LIST) {  // every thread reaches the workgroup-wide append; qg_vec_reset_done follows (qgym_api.cpp)

@@ -69,7 +69,7 @@ __device__ inline uint64_t perm_invert(uint64_t s, uint32_t N) {  // permutation
 
 template <bool PERM>
 __global__ __launch_bounds__(256) void word_step_kernel(StepArgs a) {
-    KernelClock kclk(a.kclk);  // device_common.hpp
+    KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
     if (env >= a.B) return;

@@ -382,12 +382,13 @@ static void fill_step_args(const qg_vec *v, StepArgs &a) {
 // qg_vec_set_kernel_clock: the slot of the launch about to be enqueued (the k-th one after the call), or null
 static unsigned long long *kernel_clock_slot(const qg_vec *v) {
     if (!v->kclk || v->kclk_next >= v->kclk_cap) return nullptr;
-    return v->kclk + 2 * (v->kclk_next++);
+    return v->kclk + 2ull * v->kclk_waves * (v->kclk_next++);
 }
 
 static hipError_t launch_step(const qg_vec *v, const StepArgs &a_in, hipStream_t s) {
     StepArgs a = a_in;
     a.kclk = kernel_clock_slot(v);
+    a.kclk_waves = v->kclk_waves;
     switch (v->layout) {
     case LAYOUT_LFD: return lfd_step(a, v->w64, v->nxp, s);
     case LAYOUT_LF8: return lf8_step(a, a.T > 1, s);
@@ -748,6 +749,7 @@ int qg_vec_set_state(qg_vec *v, const void *states, int format, size_t stride, i
 static hipError_t launch_export(const qg_vec *v, const ObsArgs &a_in, hipStream_t s) {
     ObsArgs a = a_in;
     a.kclk = kernel_clock_slot(v);
+    a.kclk_waves = v->kclk_waves;
     switch (v->layout) {
     case LAYOUT_LFD: return lfd_export(a, v->w64, v->nxp, v->inverted, s);
     case LAYOUT_LF8: return lf8_export(a, s);
@@ -872,11 +874,13 @@ int qg_vec_set_clock(qg_vec *v, const uint64_t *clock_dev) {
     return QG_OK;
 }
 
-int qg_vec_set_kernel_clock(qg_vec *v, uint64_t *slots_dev, size_t n_slots) {
-    if (!v || (n_slots && !slots_dev)) return set_error(QG_ERR_INVALID, "null argument");
+int qg_vec_set_kernel_clock(qg_vec *v, uint64_t *slots_dev, size_t n_slots, uint32_t waves_per_slot) {
+    if (!v || (n_slots && (!slots_dev || !waves_per_slot))) return set_error(QG_ERR_INVALID, "null argument");
+    if ((uintptr_t)slots_dev & 15u) return set_error(QG_ERR_INVALID, "kernel clock slots must be 16-byte aligned");
     drop_graphs(v);  // cached rollout graphs carry the previous slots (or none) in their kernel arguments
     v->kclk = n_slots ? reinterpret_cast<unsigned long long *>(slots_dev) : nullptr;
     v->kclk_cap = n_slots;
+    v->kclk_waves = n_slots ? waves_per_slot : 0u;
     v->kclk_next = 0;
     return QG_OK;
 }
@@ -1082,6 +1086,7 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     const uint8_t *pend_in = v->pend[v->pend_cur];
     uint8_t *pend_out = v->pend[v->pend_cur ^ 1];
     a.kclk = kernel_clock_slot(v);
+    a.kclk_waves = v->kclk_waves;
     HIP_TRY(qm_reset_step(ia, a, pend_in, pend_out, v->nxp, v->has_z, s));
     v->step_index += 1;
     // the list just appended to is the current one, the idle list (zeroed by this launch) is the next launch's target, the one just consumed idles

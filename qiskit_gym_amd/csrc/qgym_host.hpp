@@ -88,9 +88,10 @@ struct qg_vec {
     uint64_t step_index = 0;
     uint64_t env_base = 0;  // qg_vec_set_env_base: global index of env 0 in every counter-RNG draw (a shard of a larger batch)
     const uint64_t *clock_dev = nullptr;  // qg_vec_set_clock (not owned)
-    // qg_vec_set_kernel_clock (not owned): [kclk_cap][2] device slots; the k-th step / observation launch after the call stamps slot k
+    // qg_vec_set_kernel_clock (not owned): [kclk_cap][kclk_waves][2] device words; the k-th step / observation launch after the call stamps slot k
     unsigned long long *kclk = nullptr;
     size_t kclk_cap = 0;
+    uint32_t kclk_waves = 0;
     mutable size_t kclk_next = 0;
 
     // device buffers

@@ -105,10 +105,11 @@ struct StepArgs {
     float w[4];               // MetricsWeights, F_LAYERS only
     float pauli_layer_reward;
     uint32_t max_rotations;
+    uint32_t kclk_waves;      // qg_vec_set_kernel_clock: wave records of this launch's slot
     const uint64_t *clock;    // device clock added to every RNG counter (qg_vec_set_clock), or null
     uint64_t env_base;        // global index of env 0 in the counter RNG (qg_vec_set_env_base)
     uint32_t *bad;            // TILE (uint32) / TILE64 (uint64) per-env mask: bit j = qubit j's rows / row j differ from the identity's; or null
-    unsigned long long *kclk; // qg_vec_set_kernel_clock: this launch's {first wave entry, last wave exit} slot (device_common.hpp KernelClock), or null
+    unsigned long long *kclk; // qg_vec_set_kernel_clock: this launch's slot -- kclk_waves records {entry, exit}, one per wave (device_common.hpp KernelClock) -- or null
     uint32_t *done_list;      // F_DONE_LIST: [B] indices of the envs that finished in this step, then {length, reader ticket} (compact_done's format);
     uint32_t *done_count;     // read only under that flag (the last fields of the block: other launches never touch their cache line)
     int8_t *dense;            // qg_vec_track_dense: the resident dense int8 observation [B][D][D]; the DENSE instantiations of the one-step kernels
@@ -194,7 +195,8 @@ struct ObsArgs {
     uint32_t D, N, log2L;
     uint32_t format;          // qg_state_format (U8 -> int8 dense, I64, PACKED)
     uint32_t obs_rows, obs_cols;
-    unsigned long long *kclk; // qg_vec_set_kernel_clock: this launch's slot, or null
+    unsigned long long *kclk; // qg_vec_set_kernel_clock: this launch's slot (kclk_waves wave records), or null
+    uint32_t kclk_waves;
 };
 
 // internal set_state source format (never crosses the C ABI): InitArgs::src is a bit stream, bit e = entry e of the flat [B][D][D] array

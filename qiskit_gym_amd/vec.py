@@ -323,27 +323,29 @@ class VecEnv:
         _lib.check(self._L.qg_vec_pauli_reset_from(self._h, t.ctypes.data, blob, n_rot.ctypes.data, self._stream()))
 
     def kernel_clock(self, n_slots: int) -> Optional[torch.Tensor]:
-        """Diagnostics (`qg_vec_set_kernel_clock`): the next `n_slots` step / observation launches stamp {first wave entry, last wave exit} device-clock
-        ticks into the returned uint64-as-int64 tensor [n_slots, 2] (initialised to {UINT64_MAX, 0}); `n_slots=0` detaches.  See `kernel_durations_us`."""
+        """Diagnostics (`qg_vec_set_kernel_clock`): the next `n_slots` step / observation launches have every wave write its {entry, exit} device-clock
+        ticks into the returned int64 tensor [n_slots, waves, 2] (zeroed); `n_slots=0` detaches.  See `kernel_durations_us`."""
         if n_slots <= 0:
-            _lib.check(self._L.qg_vec_set_kernel_clock(self._h, None, 0))
+            _lib.check(self._L.qg_vec_set_kernel_clock(self._h, None, 0, 0))
             self._kclk = None
             return None
-        slots = torch.empty((n_slots, 2), dtype=torch.int64, device=self.device)
-        slots[:, 0] = -1  # UINT64_MAX
-        slots[:, 1] = 0
-        _lib.check(self._L.qg_vec_set_kernel_clock(self._h, slots.data_ptr(), n_slots))
+        waves = max(1, (self.batch + 31) // 32)  # two lanes per env is the widest stamped grid
+        slots = torch.zeros((n_slots, waves, 2), dtype=torch.int64, device=self.device)
+        _lib.check(self._L.qg_vec_set_kernel_clock(self._h, slots.data_ptr(), n_slots, waves))
         self._kclk = slots
         return slots
 
     def kernel_durations_us(self, slots: torch.Tensor) -> np.ndarray:
-        """exit - entry of every stamped slot of `kernel_clock`'s tensor, in microseconds (slots no launch stamped are left out)."""
+        """Last wave exit - first wave entry of every stamped launch of `kernel_clock`'s tensor, in microseconds (slots no launch stamped are left out)."""
         rate = int(self._L.qg_kernel_clock_rate_khz(self.device_index))
         if rate <= 0:
             _lib.check(rate)
-        h = slots.cpu().numpy().view(np.uint64)
-        ok = h[:, 1] > 0
-        return (h[ok, 1] - h[ok, 0]).astype(np.float64) * 1e3 / rate
+        t0, t1 = slots[..., 0], slots[..., 1]
+        live = t1 != 0
+        first = torch.where(live, t0, torch.full_like(t0, torch.iinfo(torch.int64).max)).amin(dim=1)
+        last = t1.amax(dim=1)
+        ok = live.any(dim=1)
+        return ((last - first)[ok]).cpu().numpy().astype(np.float64) * 1e3 / rate
 
     def sync(self):
         """Wait for the current stream and raise if any env hit a fault the reference panics on."""

@@ -40,8 +40,11 @@ def test_stamped_launches_report_durations_and_change_nothing(kind, n, B, cfg):
     d = envs[0].kernel_durations_us(slots)
     assert len(d) == T - 4, "every slotted launch stamps its slot"
     assert (d > 0.3).all() and d.sum() < t0[0].elapsed_time(t0[1]) * 1e3, (d.min(), d.sum(), t0[0].elapsed_time(t0[1]) * 1e3)
-    h = slots.cpu().numpy().view(np.uint64)
-    assert (h[1:, 0] >= h[:-1, 1]).all(), "launches on one stream: each starts after the one before has finished"
+    live = slots[: T - 4, :, 1] != 0
+    first = torch.where(live, slots[: T - 4, :, 0], torch.full_like(slots[: T - 4, :, 0], 2**62)).amin(dim=1)
+    last = slots[: T - 4, :, 1].amax(dim=1)
+    assert bool((first[1:] >= last[:-1]).all()), "launches on one stream: each starts after the one before has finished"
+    assert int(live[0].sum()) >= (B + 63) // 64, "every wave of the grid writes its record"
     fmt = "i64" if kind == "pauli" else "packed"
     assert torch.equal(envs[0].get_state(fmt), envs[1].get_state(fmt))
     assert torch.equal(envs[0].reward.view(torch.int32), envs[1].reward.view(torch.int32)) and torch.equal(envs[0].depth, envs[1].depth)
@@ -66,5 +69,4 @@ def test_dense_rewrite_is_stamped_and_reset_launches_leave_their_slot_alone():
     env.sync()
     d = env.kernel_durations_us(slots)
     assert len(d) == 2 and (d > 0.3).all()
-    h = slots.cpu().numpy().view(np.uint64)
-    assert h[2, 0] == np.uint64(0xFFFFFFFFFFFFFFFF) and h[2, 1] == 0
+    assert not bool(slots[2].any())
