@@ -534,7 +534,8 @@ typedef enum {
     QG_PLAN_OBSERVE_DENSE = 4,  /* qg_vec_observe_dense into a 16-byte-aligned buffer */
     QG_PLAN_OBSERVE_PACKED = 5, /* qg_vec_observe_packed */
     QG_PLAN_STATE_I64 = 6,      /* qg_vec_get_state / set_state in QG_FMT_I64 */
-    QG_PLAN_TRACK_DENSE = 7     /* qg_vec_track_dense: "in-step", "refresh" (a full rewrite after every step) or unsupported */
+    QG_PLAN_TRACK_DENSE = 7,    /* qg_vec_track_dense: "in-step", "refresh" (a full rewrite after every step) or unsupported */
+    QG_PLAN_RESET_DONE_STEP = 8 /* qg_vec_reset_done_step: the one-launch kernel, or "two launches" */
 } qg_plan_op;
 int qg_plan_query(const qg_config *cfg, uint64_t batch, uint32_t num_actions, int op, uint64_t arg, int nonsymplectic, char *name_out, size_t cap);
 

@@ -67,18 +67,17 @@ __device__ inline uint64_t perm_invert(uint64_t s, uint32_t N) {  // permutation
     return inv;
 }
 
+// One env's step(s) (Env::step, linear_function.rs:302-328 / permutation.rs:194-225).  `fresh`: the env has just been reset in this launch
+// (word_reset_step_kernel): its state and depth come in registers -- `fresh_state`, `fresh_depth` -- instead of from memory, its `inverted` flag is
+// clear, and its state is stored whether or not the step changes it.
 template <bool PERM>
-__global__ __launch_bounds__(256) void word_step_kernel(StepArgs a) {
-    KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
-    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
-    if (env >= a.B) return;
+__device__ inline void word_step_body(const StepArgs &a, uint64_t env, bool fresh = false, uint64_t fresh_state = 0, int32_t fresh_depth = 0) {
     const bool act64 = a.flags & F_ACT64;
     uint64_t *sp = reinterpret_cast<uint64_t *>(a.state) + env;
-    uint64_t s = *sp;
-    const uint64_t s0 = s;
-    int32_t depth = a.depth[env];
-    uint32_t inverted = (a.flags & F_INVERTS) ? a.inverted[env] : 0u;
+    uint64_t s = fresh ? fresh_state : *sp;
+    const uint64_t s0 = fresh ? ~s : s;
+    int32_t depth = fresh ? fresh_depth : a.depth[env];
+    uint32_t inverted = ((a.flags & F_INVERTS) && !fresh) ? a.inverted[env] : 0u;
     const uint64_t ident = PERM ? perm_identity(a.N) : lf8_identity(a.N);
     bool solved = false;
     float reward = 0.0f;
@@ -142,13 +141,137 @@ __global__ __launch_bounds__(256) void word_step_kernel(StepArgs a) {
 }
 
 template <bool PERM>
+__global__ __launch_bounds__(256) void word_step_kernel(StepArgs a) {
+    KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
+    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
+    if (env >= a.B) return;
+    word_step_body<PERM>(a, env);
+}
+
+// ---- Env::reset of a few finished envs scattered over the batch (qg_vec_reset_done, qg_vec_reset_done_step) ---------------------------------
+// A scramble is `difficulty` row operations (position swaps) applied to the identity one after the other: a chain of dependent updates, each
+// behind a gate-table load -- 64 draws cost a lone lane ~30 us, whatever the other 63 lanes of its wave do.  The updates compose: for
+// LinearFunctionEnv a run of row operations IS the matrix E it makes of the identity, and a later run after an earlier one is the GF(2)
+// product E_later . E_earlier; for PermutationEnv a run of position swaps applied to x gives x[e[i]] where e is what the run makes of the
+// identity, so later after earlier is earlier[later[i]].  So a finished env is given 16 lanes: each applies its ceil(difficulty / 16)
+// consecutive draws to the identity (all its gate entries requested at once), and four rounds of products over the 16 lanes leave the
+// env's fresh state on all of them -- one memory round trip and ~300 instructions instead of `difficulty` dependent round trips.  A wave
+// takes four finished envs at a time.
+// E_hi . E_lo on byte-packed rows: row r = xor over c of hi[r][c] * (row c of lo)
+__device__ inline uint64_t lf8_mul(uint64_t hi, uint64_t lo) {
+    const uint32_t ones = 0x01010101u;
+    const uint32_t h0 = (uint32_t)hi, h1 = (uint32_t)(hi >> 32), l0 = (uint32_t)lo, l1 = (uint32_t)(lo >> 32);
+    uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < 8; ++c) {
+        const uint32_t row = __builtin_amdgcn_perm(0u, c < 4 ? l0 : l1, 0x01010101u * (c & 3u));  // row c of lo in every byte
+        const uint32_t m0 = (h0 >> c) & ones, m1 = (h1 >> c) & ones;                              // byte r = hi[r][c]
+        c0 ^= ((m0 << 8) - m0) & row;  // m * 255: 0xFF in the bytes of the rows that take row c
+        c1 ^= ((m1 << 8) - m1) & row;
+    }
+    return (uint64_t)c0 | ((uint64_t)c1 << 32);
+}
+// positions moved by `hi` after `lo`: out[i] = lo[hi[i]] (nibbles)
+__device__ inline uint64_t perm_compose(uint64_t hi, uint64_t lo, uint32_t N) {
+    uint64_t out = 0;
+    for (uint32_t i = 0; i < N; ++i) out |= ((lo >> (4u * (uint32_t)((hi >> (4u * i)) & 0xFull))) & 0xFull) << (4u * i);
+    return out;
+}
+constexpr uint32_t WORD_COOP_MAX = 8;  // finished envs per wave the 16-lane groups take (two passes); a fuller wave runs the per-lane chain
+
+// Bit l of `m` (wave-uniform): lane l's env starts over, its draws from the counter RNG.  Call from all 64 lanes; returns the env's fresh state
+// on the lanes of `m` (the identity elsewhere).  `env0`: the env of lane 0.
+template <bool PERM>
+__device__ inline uint64_t word_scramble_coop(const InitArgs &a, uint64_t env0, uint64_t m, uint64_t ident) {
+    const uint32_t lane = __lane_id(), grp = lane >> 4, j = lane & 15u;
+    const uint32_t per = (a.n_draws + 15u) >> 4;  // consecutive draws per lane
+    const uint64_t seed = init_seed(a);
+    const uint32_t my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));  // (on the lanes of m) which finished env of the wave this one is
+    uint64_t mine = ident, rest = m;
+    for (uint32_t pass = 0; rest; ++pass) {
+        uint32_t src = 64;  // the lane whose env this group scrambles: the grp-th set bit of `rest`
+#pragma unroll
+        for (uint32_t g = 0; g < 4; ++g) {
+            if (rest) {
+                if (g == grp) src = (uint32_t)__ffsll((long long)rest) - 1u;
+                rest &= rest - 1ull;
+            }
+        }
+        uint64_t s = ident;
+        if (src < 64u) {
+            const uint64_t e = a.env_base + env0 + src;
+            const uint32_t t0 = j * per, t1 = t0 + per < a.n_draws ? t0 + per : a.n_draws;
+            for (uint32_t t = t0; t < t1; t += 4u) {
+                uint32_t ops[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) ops[k] = t + k < t1 ? a.gates[rng_action(seed, e, t + k, a.num_actions)].ops : 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) s = PERM ? perm_apply(s, ops[k]) : lf8_apply(s, ops[k]);
+            }
+        }
+#pragma unroll
+        for (uint32_t d = 1; d < 16u; d <<= 1) {  // the lane with bit d set holds the LATER draws
+            const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)s, (int)d);
+            const uint64_t hi = (j & d) ? s : o, lo = (j & d) ? o : s;
+            s = PERM ? perm_compose(hi, lo, a.N) : lf8_mul(hi, lo);
+        }
+        const uint64_t got = (uint64_t)__shfl((unsigned long long)s, (int)((my_rank & 3u) << 4));  // from the group that took this lane's env
+        if (((m >> lane) & 1ull) && (my_rank >> 2) == pass) mine = got;
+    }
+    return mine;
+}
+
+// the per-lane chain (full resets, reset_with's given draws, waves full of finished envs): eight gate entries requested ahead of the updates
+template <bool PERM>
+__device__ inline uint64_t word_scramble_lane(const InitArgs &a, uint64_t env, uint64_t s) {
+    const uint64_t seed = init_seed(a);
+    for (uint32_t t = 0; t < a.n_draws; t += 8u) {
+        uint32_t ops[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            ops[k] = 0u;
+            if (t + k < a.n_draws) {
+                const int64_t act = a.actions ? (int64_t)a.actions[(uint64_t)(t + k) * a.B + env] : (int64_t)rng_action(seed, a.env_base + env, t + k, a.num_actions);
+                if (act >= 0 && act < (int64_t)a.num_actions) ops[k] = a.gates[act].ops;
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) s = PERM ? perm_apply(s, ops[k]) : lf8_apply(s, ops[k]);
+    }
+    return s;
+}
+
+// what Env::reset / set_state leave besides the state (reset_internals, linear_function.rs:245-256): log lengths, fault word, layer record
+__device__ inline void word_reset_bookkeeping(const InitArgs &a, uint64_t env, uint32_t fault) {
+    a.inverted[env] = 0;
+    a.error[env] = fault;
+    a.sol_len[env * 2] = 0;
+    a.sol_len[env * 2 + 1] = 0;
+    if (a.layers) {
+        const LayerRec lay = layer_rec(a.layers, env, a.layers_len);
+        for (uint32_t i = 0; i + 2 < a.layers_len; ++i) lay[i] = -1;
+        lay[a.layers_len - 2] = 0;
+        lay[a.layers_len - 1] = 0;
+    }
+}
+
+template <bool PERM>
 __global__ __launch_bounds__(256) void word_init_kernel(InitArgs a) {
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= a.B) return;
-    if (a.only_done && !a.done[env]) return;  // qg_vec_reset_done
+    const bool mine = env < a.B && !(a.only_done && !a.done[env]);  // (only_done: qg_vec_reset_done)
     const uint64_t ident = PERM ? perm_identity(a.N) : lf8_identity(a.N);
     uint64_t s = ident;
     uint32_t fault = 0;
+    bool scrambled = false;
+    if (a.mode == 2 && a.only_done && !a.actions) {  // (wave-uniform) a few finished envs per wave: 16 lanes each
+        const uint64_t m = __ballot(mine);
+        if (m && (uint32_t)__popcll(m) <= WORD_COOP_MAX) {
+            s = word_scramble_coop<PERM>(a, env - __lane_id(), m, ident);
+            scrambled = true;
+        }
+    }
+    if (!mine) return;
     if (a.mode == 1) {
         s = 0;
         if (PERM) {  // permutation.rs:168-173: state[i] = x as usize
@@ -182,13 +305,8 @@ __global__ __launch_bounds__(256) void word_init_kernel(InitArgs a) {
                 s |= w << (8 * r);
             }
         }
-    } else if (a.mode == 2) {
-        for (uint32_t t = 0; t < a.n_draws; ++t) {
-            int64_t act = a.actions ? (int64_t)a.actions[(uint64_t)t * a.B + env]
-                                    : (int64_t)rng_action(init_seed(a), a.env_base + env, t, a.num_actions);
-            uint32_t ops = (act >= 0 && act < (int64_t)a.num_actions) ? a.gates[act].ops : 0u;
-            s = PERM ? perm_apply(s, ops) : lf8_apply(s, ops);
-        }
+    } else if (a.mode == 2 && !scrambled) {
+        s = word_scramble_lane<PERM>(a, env, s);
     }
     const bool solved = (s == ident);
     reinterpret_cast<uint64_t *>(a.state)[env] = s;
@@ -196,16 +314,27 @@ __global__ __launch_bounds__(256) void word_init_kernel(InitArgs a) {
     a.success[env] = (uint8_t)solved;
     a.reward[env] = solved ? 1.0f : 0.0f;
     a.done[env] = (uint8_t)(a.depth_value == 0 || solved);
-    a.inverted[env] = 0;
-    a.error[env] = fault;
-    a.sol_len[env * 2] = 0;
-    a.sol_len[env * 2 + 1] = 0;
-    if (a.layers) {
-        const LayerRec lay = layer_rec(a.layers, env, a.layers_len);
-        for (uint32_t i = 0; i + 2 < a.layers_len; ++i) lay[i] = -1;
-        lay[a.layers_len - 2] = 0;
-        lay[a.layers_len - 1] = 0;
+    word_reset_bookkeeping(a, env, fault);
+}
+
+// qg_vec_reset_done_step in one launch: the envs whose episode is over (`done`, as the previous step left it) start over -- 16 lanes each, or the
+// per-lane chain in a wave full of them -- and then EVERY env takes its step; a fresh env's state and depth reach its step in registers.
+template <bool PERM>
+__global__ __launch_bounds__(256) void word_reset_step_kernel(InitArgs ia, StepArgs a) {
+    KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
+    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
+    const bool fin = env < a.B && ia.done[env];
+    const uint64_t m = __ballot(fin);
+    const uint64_t ident = PERM ? perm_identity(a.N) : lf8_identity(a.N);
+    uint64_t fresh = ident;
+    if (m) {  // (wave-uniform)
+        if ((uint32_t)__popcll(m) <= WORD_COOP_MAX) fresh = word_scramble_coop<PERM>(ia, env - __lane_id(), m, ident);
+        else if (fin) fresh = word_scramble_lane<PERM>(ia, env, ident);
     }
+    if (env >= a.B) return;
+    if (fin) word_reset_bookkeeping(ia, env, 0u);  // (read back by this same lane's step where the step reads them at all)
+    word_step_body<PERM>(a, env, fin, fresh, ia.depth_value);
 }
 
 template <bool PERM>
@@ -262,6 +391,12 @@ hipError_t lf8_init(const InitArgs &a, hipStream_t s) {
 hipError_t perm_init(const InitArgs &a, hipStream_t s) {
     if (!a.B) return hipSuccess;
     hipLaunchKernelGGL(word_init_kernel<true>, dim3(grid_for(a.B, 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t word_reset_step(const InitArgs &reset, const StepArgs &a, bool perm, hipStream_t s) {
+    if (!a.B) return hipSuccess;
+    if (perm) hipLaunchKernelGGL(word_reset_step_kernel<true>, dim3(grid_for(a.B, 256)), dim3(256), 0, s, reset, a);
+    else hipLaunchKernelGGL(word_reset_step_kernel<false>, dim3(grid_for(a.B, 256)), dim3(256), 0, s, reset, a);
     return hipGetLastError();
 }
 hipError_t lf8_export(const ObsArgs &a, hipStream_t s) {

@@ -1055,6 +1055,28 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     // reset would take the list path with counter-RNG draws; otherwise the two calls, whose step leaves both for the next time
     const bool fuse = v->pend[0] && trusted && v->done_list_fresh && v->pend_fresh && v->auto_list && !v->gates.empty() &&
                       plan::reset_coop_allowed(false, v->B, v->d_rowops != nullptr);
+    if (plan::reset_step_in_word_kernel(plan_of(v), v->gates.size())) {
+        // one uint64 per env: no list -- every wave tests its envs' is_final flags, resets the finished ones (16 lanes each) and steps all of them
+        InitArgs ia;
+        fill_init_args(v, ia);
+        ia.mode = 2;
+        ia.n_draws = (uint32_t)v->difficulty;
+        ia.seed = reset_seed;
+        ia.only_done = 1u;
+        ia.depth_value = (int32_t)std::min<int64_t>((int64_t)v->cfg.depth_slope * v->difficulty, v->cfg.max_depth);  // linear_function.rs:296
+        StepArgs a;
+        fill_step_args(v, a);
+        a.actions = actions_dev;
+        a.coins = coins_dev;
+        a.rewards_seq = rewards_dev;
+        a.dones_seq = dones_dev;
+        if (action_dtype == QG_ACT_I64) a.flags |= F_ACT64;
+        a.kclk = kernel_clock_slot(v);
+        a.kclk_waves = v->kclk_waves;
+        HIP_TRY(word_reset_step(ia, a, v->layout == LAYOUT_PERM, s));
+        v->step_index += 1;
+        return QG_OK;
+    }
     if (!fuse) {
         if (int rc = qg_vec_reset_done(v, reset_seed, stream)) return rc;
         return rollout_impl(v, actions_dev, action_dtype, 1, 1, coins_dev, rewards_dev, dones_dev, 0, stream);
@@ -1288,11 +1310,17 @@ int qg_plan_query(const qg_config *cfg, uint64_t batch, uint32_t num_actions, in
             name = batch > QG_COMPACT_MIN_ENVS ? (plan::pauli_tree_takes(count, draws, batch, (uint32_t)num_actions) ? "compact_done + ptile_reset_tree_kernel"
                                                                                                                        : "compact_done + ptile_generate_kernel")
                                                : "ptile_generate_kernel";
+        } else if (hp.layout == LAYOUT_LF8 || hp.layout == LAYOUT_PERM) {
+            name = "word_init_kernel";  // (decides per wave: 16 lanes per finished env up to 8 of them, the per-lane chain in a fuller wave)
         } else {
             name = "init_kernel";
         }
         break;
     }
+    case QG_PLAN_RESET_DONE_STEP:
+        name = plan::reset_step_fusable(hp) ? "qm_reset_step_kernel (after a list-leaving step)"
+               : plan::reset_step_in_word_kernel(hp, num_actions) ? "word_reset_step_kernel" : "two launches";
+        break;
     case QG_PLAN_OBSERVE_DENSE:
         if (hp.layout == LAYOUT_TILE) name = plan::export_kernel_name(plan::tile_export(QG_FMT_U8, hp.D, R, (uint64_t)hp.D * hp.D, true, true));
         else if (hp.layout == LAYOUT_TILE64 || hp.layout == LAYOUT_LFD || hp.layout == LAYOUT_PAULI) name = plan::export_kernel_name(plan::EK_WORDS_THEN_EXPAND);

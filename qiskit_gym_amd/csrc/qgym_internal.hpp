@@ -233,6 +233,8 @@ hipError_t lf8_step(const StepArgs &a, bool fused, hipStream_t s);
 hipError_t lf8_init(const InitArgs &a, hipStream_t s);
 hipError_t lf8_export(const ObsArgs &a, hipStream_t s);
 
+// LF8 / PERM: qg_vec_reset_done (counter-RNG draws) + qg_vec_step in one launch (kernels_small.hip word_reset_step_kernel)
+hipError_t word_reset_step(const InitArgs &reset, const StepArgs &step, bool perm, hipStream_t s);
 hipError_t perm_step(const StepArgs &a, bool fused, hipStream_t s);
 hipError_t perm_init(const InitArgs &a, hipStream_t s);
 hipError_t perm_export(const ObsArgs &a, hipStream_t s);

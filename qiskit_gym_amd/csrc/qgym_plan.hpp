@@ -250,6 +250,9 @@ constexpr bool tile_coop_fits(uint32_t R, uint32_t word_bytes) { return 16ull * 
 // qg_vec_reset_done_step as ONE launch (qm_reset_step_kernel): handles whose env.step() is the one-step TILE kernel
 inline bool reset_step_fusable(const HandlePlan &p) { return p.layout == LAYOUT_TILE && p.has_bad && !(p.flags & F_INVERTS) && p.has_done_list; }
 
+// ... and on the one-word layouts (word_reset_step_kernel: the wave tests its envs' is_final flags itself, no list)
+inline bool reset_step_in_word_kernel(const HandlePlan &p, size_t num_actions) { return (p.layout == LAYOUT_LF8 || p.layout == LAYOUT_PERM) && num_actions != 0; }
+
 // ---- observations / state export (TILE) ----------------------------------------------------------------------------------------------
 enum ExportKernel { EK_GENERIC = 0, EK_DENSE_STREAM, EK_DENSE_STREAM_ANY, EK_PACK, EK_WORDS_THEN_EXPAND };
 inline const char *export_kernel_name(ExportKernel k) {

@@ -8,7 +8,7 @@ import pytest
 
 from qiskit_gym_amd import _lib
 
-LAYOUT, STEP, FUSED, RESET_DONE, OBS_DENSE, OBS_PACKED, STATE_I64, TRACK_DENSE = range(8)
+LAYOUT, STEP, FUSED, RESET_DONE, OBS_DENSE, OBS_PACKED, STATE_I64, TRACK_DENSE, RESET_DONE_STEP = range(9)
 B = 65536
 
 
@@ -106,7 +106,8 @@ RESETS = [
     ("pauli", 20, B, 128, B // 32 + 1, "compact_done + ptile_generate_kernel"),
     ("pauli", 20, B, 32, 512, "compact_done + ptile_generate_kernel"),
     ("pauli", 20, 4095, 128, 40, "ptile_generate_kernel"),
-    ("linear_function", 8, B, 64, 512, "init_kernel"),
+    ("linear_function", 8, B, 64, 512, "word_init_kernel"),   # (16 lanes per finished env, decided per wave)
+    ("permutation", 9, B, 16, 512, "word_init_kernel"),
     ("permutation", 27, B, 64, 512, "init_kernel"),
 ]
 
@@ -117,6 +118,18 @@ def test_reset_done_paths(kind, n, batch, difficulty, count, want):
     if kind != "pauli":
         cfg["add_inverts"] = False
     assert plan(kind, n, RESET_DONE, batch=batch, arg=count, **cfg) == want
+
+
+def test_reset_done_step_in_one_launch():
+    """qg_vec_reset_done_step: which handles have a kernel that resets the finished envs and steps every env in ONE launch."""
+    assert plan("clifford", 16, RESET_DONE_STEP, **PLAIN).startswith("qm_reset_step_kernel")
+    assert plan("linear_function", 24, RESET_DONE_STEP, **PLAIN).startswith("qm_reset_step_kernel")
+    assert plan("linear_function", 8, RESET_DONE_STEP, num_actions=28, **PLAIN) == "word_reset_step_kernel"      # config 2's env
+    assert plan("linear_function", 8, RESET_DONE_STEP, num_actions=28, **DEFAULT) == "word_reset_step_kernel"    # ... with the reference's defaults
+    assert plan("permutation", 9, RESET_DONE_STEP, num_actions=12, **DEFAULT) == "word_reset_step_kernel"
+    assert plan("linear_function", 8, RESET_DONE_STEP, num_actions=0, **PLAIN) == "two launches"                  # (an empty gateset: reset is an error)
+    for kind, n, cfg in (("clifford", 16, DEFAULT), ("clifford", 24, PLAIN), ("linear_function", 24, DEFAULT), ("permutation", 27, PLAIN), ("pauli", 20, {})):
+        assert plan(kind, n, RESET_DONE_STEP, **cfg) == "two launches", (kind, n)
 
 
 def test_observation_and_state_paths():
