@@ -1269,6 +1269,7 @@ struct PTGenArgs {
     const uint32_t *list;  // only_done, compacted (compact_done): thread i regenerates env list[i]
     uint32_t *list_count;
     uint32_t tree;         // ptile_reset_tree_kernel runs before ptile_generate_kernel and takes the lists pt_tree_takes says it takes
+    unsigned long long *tree_kclk;  // qg_vec_set_kernel_clock: the tree launch's slot (the generate launch's is s.kclk)
 };
 constexpr uint32_t PT_CX_LDS = plan::PAULI_CX_LDS;
 using plan::pauli_tree_takes;  // short lists of long scrambles: a workgroup per listed env (ptile_reset_tree_kernel), qgym_plan.hpp
@@ -1508,6 +1509,7 @@ __device__ inline void pt_gen_finish(const PTGenArgs &ga, PTState<NQ, RM> &s, ui
 
 template <int NQ, int RM>
 __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
+    KernelClock kclk(ga.s.kclk, ga.s.kclk_waves);  // device_common.hpp
     const StepArgs &a = ga.s;
     // the tableau scramble runs on LDS-resident rows ([row][lane], conflict-free for any per-lane row): a
     // random CX / H / S is one or two row operations instead of a select sweep over 2N 64-bit registers
@@ -1591,6 +1593,7 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
 // work: it costs what one lane costs, and tells everybody where the scramble's draws start); lane 0 of wave 0 takes the rows and finishes.
 template <int NQ, int RM>
 __global__ __launch_bounds__(256) void ptile_reset_tree_kernel(PTGenArgs ga) {
+    KernelClock kclk(ga.tree_kclk, ga.s.kclk_waves);  // device_common.hpp
     const StepArgs &a = ga.s;
     constexpr int R = 2 * NQ;
     __shared__ uint64_t prod[4][64];
@@ -1933,6 +1936,9 @@ int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s) 
         ga.list_count = v->done_list + v->B;
         ga.tree = (ga.difficulty >= plan::TREE_MIN_DRAWS && v->B / 32u >= 1u && pauli_tree_takes(1u, ga.difficulty, v->B, ga.n_cx)) ? 1u : 0u;
     }
+    if (ga.tree) ga.tree_kclk = kernel_clock_slot_public(v);
+    a.kclk = kernel_clock_slot_public(v);
+    a.kclk_waves = v->kclk_waves;
     HIP_TRY(ptile_generate(v, ga, s));
     return QG_OK;
 }

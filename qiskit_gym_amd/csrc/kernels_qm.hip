@@ -919,6 +919,7 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
 
 template <int NXP, bool HAS_Z>
 __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
+    KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
     qm_init_block<NXP, HAS_Z>(a, blockIdx.x);
 }
 

@@ -178,7 +178,7 @@ __device__ inline uint64_t perm_compose(uint64_t hi, uint64_t lo, uint32_t N) {
     for (uint32_t i = 0; i < N; ++i) out |= ((lo >> (4u * (uint32_t)((hi >> (4u * i)) & 0xFull))) & 0xFull) << (4u * i);
     return out;
 }
-constexpr uint32_t WORD_COOP_MAX = 8;  // finished envs per wave the 16-lane groups take (two passes); a fuller wave runs the per-lane chain
+constexpr uint32_t WORD_COOP_MAX = 64;  // finished envs per wave the 16-lane groups take, four per pass (a threshold below 64 hands fuller waves to the per-lane chain)
 
 // Bit l of `m` (wave-uniform): lane l's env starts over, its draws from the counter RNG.  Call from all 64 lanes; returns the env's fresh state
 // on the lanes of `m` (the identity elsewhere).  `env0`: the env of lane 0.
@@ -258,6 +258,7 @@ __device__ inline void word_reset_bookkeeping(const InitArgs &a, uint64_t env, u
 
 template <bool PERM>
 __global__ __launch_bounds__(256) void word_init_kernel(InitArgs a) {
+    KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool mine = env < a.B && !(a.only_done && !a.done[env]);  // (only_done: qg_vec_reset_done)
     const uint64_t ident = PERM ? perm_identity(a.N) : lf8_identity(a.N);

@@ -305,6 +305,12 @@ static int drop_done_list(qg_vec *v, hipStream_t s) {
     return QG_OK;
 }
 
+// qg_vec_set_kernel_clock: the slot of the launch about to be enqueued (the k-th one after the call), or null
+static unsigned long long *kernel_clock_slot(const qg_vec *v) {
+    if (!v->kclk || v->kclk_next >= v->kclk_cap) return nullptr;
+    return v->kclk + 2ull * v->kclk_waves * (v->kclk_next++);
+}
+
 static void fill_init_args(const qg_vec *v, InitArgs &a) {
     memset(&a, 0, sizeof a);
     a.tree_grid = plan::tree_grid(v->B);
@@ -332,7 +338,10 @@ static void fill_init_args(const qg_vec *v, InitArgs &a) {
     a.check_symplectic = ((v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) && (v->flags & F_INVERTS)) ? 1u : 0u;
 }
 
-static hipError_t launch_init(const qg_vec *v, const InitArgs &a, hipStream_t s) {
+static hipError_t launch_init(const qg_vec *v, const InitArgs &a_in, hipStream_t s) {
+    InitArgs a = a_in;
+    a.kclk = kernel_clock_slot(v);
+    a.kclk_waves = v->kclk_waves;
     switch (v->layout) {
     case LAYOUT_LFD: return lfd_init(a, v->w64, v->nxp, v->d_descs, s);
     case LAYOUT_LF8: return lf8_init(a, s);
@@ -377,12 +386,6 @@ static void fill_step_args(const qg_vec *v, StepArgs &a) {
     a.w[3] = v->cfg.w_n_gates;
     a.pauli_layer_reward = v->cfg.pauli_layer_reward;
     a.max_rotations = (uint32_t)v->cfg.max_rotations;
-}
-
-// qg_vec_set_kernel_clock: the slot of the launch about to be enqueued (the k-th one after the call), or null
-static unsigned long long *kernel_clock_slot(const qg_vec *v) {
-    if (!v->kclk || v->kclk_next >= v->kclk_cap) return nullptr;
-    return v->kclk + 2ull * v->kclk_waves * (v->kclk_next++);
 }
 
 static hipError_t launch_step(const qg_vec *v, const StepArgs &a_in, hipStream_t s) {
@@ -1497,6 +1500,7 @@ int qg_vec_solutions(qg_vec *v, uint64_t *out, size_t cap, int64_t *lens) {
 
 namespace qg {
 void fill_step_args_public(const qg_vec *v, StepArgs &a) { fill_step_args(v, a); }
+unsigned long long *kernel_clock_slot_public(const qg_vec *v) { return kernel_clock_slot(v); }
 int dense_refresh_public(qg_vec *v, hipStream_t s) { return dense_refresh(v, s); }
 // InitArgs of qg_vec_reset_done(v, seed) without a list: what a kernel that resets finished envs itself needs (qg_vec_mid_head_sample_step)
 void fill_reset_done_args_public(const qg_vec *v, uint64_t seed, InitArgs &ia) {

@@ -165,6 +165,7 @@ bool done_list_session(qg_vec *v, hipStream_t s);
 int done_list_before_append(qg_vec *v, hipStream_t s);
 void done_list_appended(qg_vec *v, bool trusted);
 void fill_step_args_public(const qg_vec *v, StepArgs &a);
+unsigned long long *kernel_clock_slot_public(const qg_vec *v);  // qg_vec_set_kernel_clock: the slot of the launch about to be enqueued, or null
 // qg_vec_track_dense: rewrite the whole tracked observation from the state (after a launch that changed states without updating it)
 int dense_refresh_public(qg_vec *v, hipStream_t s);
 void fill_reset_done_args_public(const qg_vec *v, uint64_t seed, InitArgs &ia);

@@ -177,6 +177,8 @@ struct InitArgs {
     uint32_t inverts;          // add_inverts is set (PermutationEnv set_state: a state with a repeated entry is a fault only then)
     int8_t *dense;             // qg_vec_track_dense + a list of finished envs: the reset rewrites those envs' dense observation (else null: the host
                                // refreshes the whole buffer after the launch)
+    unsigned long long *kclk;  // qg_vec_set_kernel_clock: this launch's slot (kclk_waves wave records), or null
+    uint32_t kclk_waves;
 };
 
 // A handle may be given a device-resident clock (qg_vec_set_clock).  Launches replayed from a

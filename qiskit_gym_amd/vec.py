@@ -329,7 +329,7 @@ class VecEnv:
             _lib.check(self._L.qg_vec_set_kernel_clock(self._h, None, 0, 0))
             self._kclk = None
             return None
-        waves = max(1, (self.batch + 31) // 32)  # two lanes per env is the widest stamped grid
+        waves = max(8192, (self.batch + 7) // 8)  # the widest stamped grid: PauliEnv's reset trees, B / 32 workgroups of four waves
         slots = torch.zeros((n_slots, waves, 2), dtype=torch.int64, device=self.device)
         _lib.check(self._L.qg_vec_set_kernel_clock(self._h, slots.data_ptr(), n_slots, waves))
         self._kclk = slots

@@ -1,0 +1,53 @@
+"""qg_vec_reset_done / qg_vec_reset_done_step on the one-word layouts (LinearFunctionGym 8q = config 2's env, PermutationGym 3x3): eager call
+times by finished fraction, and the auto-reset pair (reset_done + step) as a captured graph against the plain step."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from qiskit_gym_amd.vec import VecEnv
+from util import grid_gateset, line_gateset
+
+T = 128
+for kind, n, diff, B in (("linear_function", 8, 64, 65536), ("linear_function", 8, 64, 8192), ("permutation", 9, 16, 65536)):
+    gs = grid_gateset("permutation", 3, 3) if kind == "permutation" else line_gateset(kind, n)
+    env = VecEnv(kind, n, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=diff)
+    env.reset(1)
+    for frac in (1.0, 0.5, 0.1, 0.03, 0.01, 0.0):
+        mask = (torch.rand(B, device="cuda") < frac).to(torch.uint8)
+        times = []
+        for i in range(12):
+            env.done.copy_(mask)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            env.reset_done(100 + i)
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) * 1e3)
+        times.sort()
+        print(f"{kind}{n} x {B} difficulty {diff:3d}: {frac * 100:5.1f} % done -> reset_done (eager) {times[len(times) // 2]:8.1f} us", flush=True)
+    # the pair in a graph: episodes of depth_slope * difficulty steps, ends spread over time by the scramble itself after a few episodes
+    acts = torch.randint(0, len(gs), (T, B), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.Stream()
+    for name, body in (("step only", lambda t: env.step(acts[t])), ("reset_done_step", lambda t: env.reset_done_step(1000 + t, acts[t])),
+                       ("reset_done + step (two calls)", lambda t: (env.reset_done(1000 + t), env.step(acts[t])))):
+        with torch.cuda.stream(stream):
+            for rep in range(3):
+                for t in range(T):
+                    body(t)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                for t in range(T):
+                    body(t)
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(4):
+                g.replay()
+            e1.record(stream)
+            torch.cuda.synchronize()
+        print(f"{kind}{n} x {B}: {name:32s} {e0.elapsed_time(e1) * 1e3 / (4 * T):6.2f} us per step (graph of {T}); finished per step {float(env.done.float().mean()):.4f}", flush=True)
+    env.sync()
+    env.close()
