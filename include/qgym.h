@@ -297,9 +297,10 @@ int qg_vec_pauli_num_perms(const qg_vec *v);
  * ticks of the device's constant-rate counter (qg_kernel_clock_rate_khz: 100 MHz on gfx950).  After the call the k-th step / observation kernel
  * launched through this handle (eager, or captured into a graph: a replay stamps the slots its launches were captured with) has its wave w write
  * record w of slot k (waves past waves_per_slot write nothing: size it to the largest grid, batch / 32 covers every stamped kernel); the launch's
- * duration is max(exit) - min(entry) over the records with exit != 0.  Launches past n_slots and kernels without stamps (reset, export and
- * fused-rollout kernels) leave their slot untouched.  Stamped: the one-step kernels (qm_step1 / q64_step1 / qm_inv2 / q64_inv2 / word_step /
- * lfd_step / ptile_step1c), qm_reset_step and the dense observation rewrite (qm_dense_stream).  A wave with a slot waits for its own loads and
+ * duration is max(exit) - min(entry) over the records with exit != 0.  Launches past n_slots and kernels without stamps (export and
+ * fused-rollout kernels, the 64-bit-row and lane-group resets) leave their slot untouched.  Stamped: the one-step kernels (qm_step1 / q64_step1 /
+ * qm_inv2 / q64_inv2 / word_step / lfd_step / ptile_step1c), the resets qm_init / word_init / ptile_generate / ptile_reset_tree (one slot each),
+ * qm_reset_step / word_reset_step and the dense observation rewrite (qm_dense_stream).  A wave with a slot waits for its own loads and
  * stores before its exit stamp, so exit - entry covers the memory traffic of the launch; a launch WITHOUT a slot pays one scalar instruction.
  * n_slots = 0 detaches.  Drops cached rollout graphs. */
 int qg_vec_set_kernel_clock(qg_vec *v, uint64_t *slots_dev, size_t n_slots, uint32_t waves_per_slot);

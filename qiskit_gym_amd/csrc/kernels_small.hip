@@ -178,7 +178,7 @@ __device__ inline uint64_t perm_compose(uint64_t hi, uint64_t lo, uint32_t N) {
     for (uint32_t i = 0; i < N; ++i) out |= ((lo >> (4u * (uint32_t)((hi >> (4u * i)) & 0xFull))) & 0xFull) << (4u * i);
     return out;
 }
-constexpr uint32_t WORD_COOP_MAX = 64;  // finished envs per wave the 16-lane groups take, four per pass (a threshold below 64 hands fuller waves to the per-lane chain)
+constexpr uint32_t WORD_COOP_MAX = 24;  // finished envs per wave the 16-lane groups take, four per pass (~1.8 us a pass); a fuller wave runs the per-lane chain (~15 us for 64 draws)
 
 // Bit l of `m` (wave-uniform): lane l's env starts over, its draws from the counter RNG.  Call from all 64 lanes; returns the env's fresh state
 // on the lanes of `m` (the identity elsewhere).  `env0`: the env of lane 0.

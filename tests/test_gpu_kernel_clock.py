@@ -56,17 +56,18 @@ def test_stamped_launches_report_durations_and_change_nothing(kind, n, B, cfg):
     assert torch.equal(slots, before) and not torch.equal(slots, untouched)
 
 
-def test_dense_rewrite_is_stamped_and_reset_launches_leave_their_slot_alone():
+def test_dense_rewrite_and_reset_launches_are_stamped_and_other_launches_leave_their_slot_alone():
     from qiskit_gym_amd.vec import VecEnv
 
     gs = line_gateset("clifford", 16)
     env = VecEnv("clifford", 16, gs, 8192, add_inverts=False, add_perms=False, track_solution=False, difficulty=16)
     env.reset(1)
-    slots = env.kernel_clock(3)
+    slots = env.kernel_clock(5)
     out = env.observe()          # slot 0: qm_dense_stream_kernel
-    env.reset(2)                 # (reset kernels take no slot)
-    env.observe(out=out)         # slot 1
+    env.reset(2)                 # slot 1: qm_init_kernel
+    env.observe(out=out)         # slot 2
+    env.get_state("i64")         # slot 3, taken by an export kernel without stamps
     env.sync()
     d = env.kernel_durations_us(slots)
-    assert len(d) == 2 and (d > 0.3).all()
-    assert not bool(slots[2].any())
+    assert len(d) == 3 and (d > 0.3).all()
+    assert bool(slots[:3].any(dim=2).any(dim=1).all()) and not bool(slots[3:].any())

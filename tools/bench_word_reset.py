@@ -25,20 +25,30 @@ for kind, n, diff, B in (("linear_function", 8, 64, 65536), ("linear_function", 
             times.append(e0.elapsed_time(e1) * 1e3)
         times.sort()
         print(f"{kind}{n} x {B} difficulty {diff:3d}: {frac * 100:5.1f} % done -> reset_done (eager) {times[len(times) // 2]:8.1f} us", flush=True)
-    # the pair in a graph: episodes of depth_slope * difficulty steps, ends spread over time by the scramble itself after a few episodes
+    # the pair in a graph, episode ends spread evenly over time as a collector sees them: class k = {env : env % L == k} is reset at warm-up step k
+    # (L = the episode length), so ~1 / L of the batch finishes in every step
+    L = min(2 * diff, 128)
     acts = torch.randint(0, len(gs), (T, B), dtype=torch.int32, device="cuda")
     stream = torch.cuda.Stream()
+    cls = torch.arange(B, device="cuda") % L
     for name, body in (("step only", lambda t: env.step(acts[t])), ("reset_done_step", lambda t: env.reset_done_step(1000 + t, acts[t])),
                        ("reset_done + step (two calls)", lambda t: (env.reset_done(1000 + t), env.step(acts[t])))):
         with torch.cuda.stream(stream):
-            for rep in range(3):
-                for t in range(T):
-                    body(t)
+            env.reset(5)
+            for k in range(L):
+                env.step(acts[k % T])
+                env.reset_done(7000 + k)
+                env.done[cls == k] = 1
+                env.reset_done(8000 + k)
+            for t in range(T):
+                body(t)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
+            fin = torch.zeros(T, device="cuda")
             with torch.cuda.graph(g, stream=stream):
                 for t in range(T):
                     body(t)
+                    fin[t] = env.done.float().mean()
             torch.cuda.synchronize()
             g.replay()
             torch.cuda.synchronize()
@@ -48,6 +58,7 @@ for kind, n, diff, B in (("linear_function", 8, 64, 65536), ("linear_function", 
                 g.replay()
             e1.record(stream)
             torch.cuda.synchronize()
-        print(f"{kind}{n} x {B}: {name:32s} {e0.elapsed_time(e1) * 1e3 / (4 * T):6.2f} us per step (graph of {T}); finished per step {float(env.done.float().mean()):.4f}", flush=True)
+        print(f"{kind}{n} x {B}: {name:32s} {e0.elapsed_time(e1) * 1e3 / (4 * T):6.2f} us per step (graph of {T}, incl. a mean() per step); finished per step "
+              f"{float(fin.mean()):.4f} [{float(fin.min()):.4f}, {float(fin.max()):.4f}]", flush=True)
     env.sync()
     env.close()
