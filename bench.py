@@ -820,17 +820,19 @@ def main():
     # env % 128 == k at warm-up step k) -- and "synchronised" (every env finishes in the same step, 127 of 128 reset_done calls find nothing) -----
     auto_reset = None
     if not multi and B == ENVS_PER_GPU and not args.no_default_config:
-        AT = 128
-        legs = {}
-        for schedule in ("desynchronised", "synchronised", "desynchronised_reference_defaults"):
-            ref_defaults = schedule.endswith("reference_defaults")  # add_inverts + solution log: the pair is two launches behind the one call
-            aenv = VecEnv("clifford", n, gateset, B, add_inverts=ref_defaults, add_perms=False, track_solution=ref_defaults, difficulty=SCRAMBLE)
-            aacts = torch.randint(0, A, (AT, B), dtype=torch.int32, device=dev, generator=gen)
-            afin = torch.empty((AT, B), dtype=torch.uint8, device=dev)
+        AT = 128  # = min(depth_slope * difficulty, max_depth) for every configuration below: the episode length
+
+        def auto_reset_leg(aenv, num_actions, spread=True):
+            """One captured graph of AT x (step, reset_done), the pair issued as qg_vec_reset_done_step (ONE launch where the layout has it: TILE without
+            add_inverts, LF8, PERM), replayed 4 times.  `spread`: Env::reset for class env % AT == k at warm-up step k, so 1 / AT of the batch finishes in
+            every step of the graph (what a collector sees); else every env finishes in the same step."""
+            nb = aenv.batch
+            aacts = torch.randint(0, num_actions, (AT, nb), dtype=torch.int32, device=dev, generator=gen)
+            afin = torch.empty((AT, nb), dtype=torch.uint8, device=dev)
             with torch.cuda.stream(stream):
                 aenv.reset(seed)
-                if schedule != "synchronised":
-                    cls = torch.arange(B, device=dev) % AT
+                if spread:
+                    cls = torch.arange(nb, device=dev) % AT
                     for k in range(AT):  # eager warm-up: spreads the episode ends (the done flags are caller-owned memory, qg_vec_bind_outputs)
                         aenv.set_counters(k, k)
                         aenv.step(aacts[k])
@@ -838,7 +840,7 @@ def main():
                         aenv.done[cls == k] = 1
                         aenv.reset_done(seed + 0xA5A5 * (k + 1))
 
-                def episode():  # step, then AT - 1 x (reset_done, step) as qg_vec_reset_done_step -- one launch each -- and the last reset_done
+                def episode():  # step, then AT - 1 x (reset_done, step) as qg_vec_reset_done_step, and the last reset_done
                     aenv.set_counters(0, 0)
                     aenv.rollout(aacts[0:1], dones_out=afin[0:1])
                     for t in range(1, AT):
@@ -863,15 +865,33 @@ def main():
             aenv.sync()
             aus = a0.elapsed_time(a1) * 1e3 / (4 * AT)
             per_step = afin.float().mean(dim=1)
-            legs[schedule] = {"us_per_step": aus, "value": B / (aus * 1e-6), "unit": "env-steps/s", "finished_per_step": float(per_step.mean()),
-                              "finished_per_step_min_max": [float(per_step.min()), float(per_step.max())]}
-            del ag, aenv, aacts, afin
-        # ... and qg_vec_reset_done by itself where it is not a tree of row operations on a bit matrix: PauliGym 20q (config 5's env: a fresh target is
-        # generated on the device), 1 % of the batch finished, eager calls (memset + compaction + two kernels), median of 12
+            return {"us_per_step": aus, "value": nb / (aus * 1e-6), "unit": "env-steps/s", "envs": nb, "finished_per_step": float(per_step.mean()),
+                    "finished_per_step_min_max": [float(per_step.min()), float(per_step.max())]}
+
         from util import line_gateset as _line_gateset  # (the gateset builder the configs leg below uses)
 
+        legs = {}
+        for schedule in ("desynchronised", "synchronised", "desynchronised_reference_defaults"):
+            ref_defaults = schedule.endswith("reference_defaults")  # add_inverts + solution log: the pair is two launches behind the one call
+            aenv = VecEnv("clifford", n, gateset, B, add_inverts=ref_defaults, add_perms=False, track_solution=ref_defaults, difficulty=SCRAMBLE)
+            legs[schedule] = auto_reset_leg(aenv, A, spread=schedule != "synchronised")
+            del aenv
+        # "an auto-reset variant reported separately" for the other configurations too, same schedule (episode ends spread evenly over time)
+        gs2a = _line_gateset("linear_function", 8)
+        for name, nb, kw in (("C2", 8192, dict(add_inverts=False, track_solution=False)), ("C2_x65536", B, dict(add_inverts=False, track_solution=False)),
+                             ("C2_reference_defaults", 8192, dict(add_inverts=True, track_solution=True))):
+            aenv = VecEnv("linear_function", 8, gs2a, nb, add_perms=False, difficulty=64, **kw)
+            legs[name] = dict(auto_reset_leg(aenv, len(gs2a)), config=f"LinearFunctionGym 8q x {nb}, difficulty 64, {kw}: word_reset_step_kernel (one launch per pair)")
+            del aenv
+        gs5a = _line_gateset("pauli", 20)
+        aenv = VecEnv("pauli", 20, gs5a, B, add_perms=False, track_solution=False, max_rotations=5, difficulty=256, pauli_diff_scale=8)
+        legs["C5"] = dict(auto_reset_leg(aenv, len(gs5a)), config=f"PauliGym 20q x {B}, difficulty 256 (targets regenerated on the device), compact_done + "
+                                                                  "ptile_reset_tree_kernel + ptile_generate_kernel + ptile_step1c_kernel per pair")
+        del aenv
+        # ... and qg_vec_reset_done by itself where it is not a tree of row operations on a bit matrix: PauliGym 20q (config 5's env: a fresh target is
+        # generated on the device), 1 % of the batch finished, eager calls (memset + compaction + two kernels), median of 12
         pg_n = 20
-        pg_gs = _line_gateset("pauli", pg_n)
+        pg_gs = gs5a
         penv = VecEnv("pauli", pg_n, pg_gs, B, add_perms=False, track_solution=False, difficulty=128)
         with torch.cuda.stream(stream):
             penv.reset(seed)
@@ -890,6 +910,7 @@ def main():
                                     "config": f"PauliGym {pg_n}q x {B} envs, difficulty 128, qg_vec_reset_done with 1 % of the batch finished, eager, median of 12"}
         del penv
         auto_reset = dict(legs["desynchronised"], synchronised=legs["synchronised"], reference_defaults=legs["desynchronised_reference_defaults"],
+                          C2=legs["C2"], C2_x65536=legs["C2_x65536"], C2_reference_defaults=legs["C2_reference_defaults"], C5=legs["C5"],
                           pauli_reset_done=legs["pauli_reset_done"],
                           config=f"the headline workload with qg_vec_reset_done after every step (the pair reset_done + next step issued as qg_vec_reset_done_step: one launch), episodes of min(depth_slope * difficulty, max_depth) = {AT} steps, "
                                  f"a captured graph of {AT} x (step, reset_done) replayed 4 times; headline figures: episode ends spread evenly over time "

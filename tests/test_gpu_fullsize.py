@@ -229,7 +229,8 @@ def test_reference_default_configuration_at_full_size(kind, n, B, scramble, per_
     gv.close()
 
 
-@pytest.mark.parametrize("kind,n,B,inverts", [("clifford", 16, 65536, False), ("clifford", 16, 65536, True), ("linear_function", 16, 65536, True)])
+@pytest.mark.parametrize("kind,n,B,inverts", [("clifford", 16, 65536, False), ("clifford", 16, 65536, True), ("linear_function", 16, 65536, True),
+                                              ("linear_function", 8, 8192, False), ("linear_function", 8, 65536, True)])  # config 2's env (one uint64 per env)
 def test_auto_reset_with_desynchronised_episodes_at_full_size(kind, n, B, inverts):
     """SURVEY 8(d)'s auto-reset variant the way a collector sees it: episodes of L = 16 steps whose ends are spread evenly over time
     (1/16 of the batch finishes per step), qg_vec_reset_done after every step, more than three episode boundaries per env -- every step's

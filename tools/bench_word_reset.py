@@ -31,8 +31,10 @@ for kind, n, diff, B in (("linear_function", 8, 64, 65536), ("linear_function", 
     acts = torch.randint(0, len(gs), (T, B), dtype=torch.int32, device="cuda")
     stream = torch.cuda.Stream()
     cls = torch.arange(B, device="cuda") % L
-    for name, body in (("step only", lambda t: env.step(acts[t])), ("reset_done_step", lambda t: env.reset_done_step(1000 + t, acts[t])),
-                       ("reset_done + step (two calls)", lambda t: (env.reset_done(1000 + t), env.step(acts[t])))):
+    fin = torch.zeros((T, B), dtype=torch.uint8, device="cuda")
+    for name, body in (("step only", lambda t: env.rollout(acts[t:t + 1], dones_out=fin[t:t + 1])),
+                       ("reset_done_step", lambda t: env.reset_done_step(1000 + t, acts[t], dones_out=fin[t])),
+                       ("reset_done + step (two calls)", lambda t: (env.reset_done(1000 + t), env.rollout(acts[t:t + 1], dones_out=fin[t:t + 1])))):
         with torch.cuda.stream(stream):
             env.reset(5)
             for k in range(L):
@@ -44,11 +46,9 @@ for kind, n, diff, B in (("linear_function", 8, 64, 65536), ("linear_function", 
                 body(t)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            fin = torch.zeros(T, device="cuda")
             with torch.cuda.graph(g, stream=stream):
                 for t in range(T):
                     body(t)
-                    fin[t] = env.done.float().mean()
             torch.cuda.synchronize()
             g.replay()
             torch.cuda.synchronize()
@@ -58,7 +58,8 @@ for kind, n, diff, B in (("linear_function", 8, 64, 65536), ("linear_function", 
                 g.replay()
             e1.record(stream)
             torch.cuda.synchronize()
-        print(f"{kind}{n} x {B}: {name:32s} {e0.elapsed_time(e1) * 1e3 / (4 * T):6.2f} us per step (graph of {T}, incl. a mean() per step); finished per step "
-              f"{float(fin.mean()):.4f} [{float(fin.min()):.4f}, {float(fin.max()):.4f}]", flush=True)
+        per = fin.float().mean(dim=1)
+        print(f"{kind}{n} x {B}: {name:32s} {e0.elapsed_time(e1) * 1e3 / (4 * T):6.2f} us per step (graph of {T}); finished per step "
+              f"{float(per.mean()):.4f} [{float(per.min()):.4f}, {float(per.max()):.4f}]", flush=True)
     env.sync()
     env.close()
