@@ -98,6 +98,74 @@ __device__ inline void done_list_append_block(uint32_t *list, uint32_t *count, b
     }
 }
 
+// The finished envs of a step as one bit each (StepArgs::done_mask): the wave's ballot, one 8-byte store per wave -- no counter, no atomics, nothing
+// to zero (every launch rewrites every word).  Call from every lane of every wave of a thread-per-env grid (`fin` false past the batch's end).
+__device__ inline void done_mask_store(uint64_t *mask, bool fin, uint64_t env) {
+    const uint64_t m = __ballot(fin);
+    if (__lane_id() == 0) mask[env >> 6] = m;
+}
+// ... of a two-lanes-per-env grid (`tid` = 2 env + half; `fin` on the even lane): a wave holds 32 envs, half a word
+__device__ inline void done_mask_store_pairs(uint64_t *mask, bool fin, uint64_t tid) {
+    uint64_t m = __ballot(fin && !(tid & 1ull));  // bit 2k: env k of the wave
+    m = (m | (m >> 1)) & 0x3333333333333333ull;
+    m = (m | (m >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    m = (m | (m >> 4)) & 0x00FF00FF00FF00FFull;
+    m = (m | (m >> 8)) & 0x0000FFFF0000FFFFull;
+    m = (m | (m >> 16)) & 0x00000000FFFFFFFFull;
+    if (__lane_id() == 0) reinterpret_cast<uint32_t *>(mask)[tid >> 6] = (uint32_t)m;
+}
+// The reader's side: every workgroup of the reset kernel counts the mask for itself (B / 64 words: 8 KB at 65 536 envs) -- thread t owns the words
+// [t c, (t + 1) c), c = ceil(words / 256) -- and finds "the i-th finished env" by a search over the 256 partial sums and a walk over one chunk.
+// done_mask_popc: this thread's share (its loads fly with whatever the caller issues next); done_mask_scan: call from all 256 threads, two
+// barriers, leaves part[t] = bits before thread t's chunk, part[256] = the total, which it returns; done_mask_nth: any thread, any i < total.
+__device__ inline uint32_t done_mask_popc(const uint64_t *mask, uint32_t words) {
+    const uint32_t chunk = (words + 255u) >> 8;
+    uint32_t n = 0;
+    for (uint32_t k = 0; k < chunk; ++k) {
+        const uint32_t w = threadIdx.x * chunk + k;
+        if (w < words) n += (uint32_t)__popcll(mask[w]);
+    }
+    return n;
+}
+__device__ inline uint32_t done_mask_scan(uint32_t mine, uint32_t *part /* LDS [257 + 4] */) {
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+        if ((int)lane >= off) incl += up;
+    }
+    if (lane == 63u) part[257u + wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; ++w) base += part[257u + w];
+    part[threadIdx.x + 1u] = base + incl;
+    if (threadIdx.x == 0) part[0] = 0;
+    __syncthreads();
+    return part[256];
+}
+__device__ inline uint32_t done_mask_nth(const uint64_t *mask, uint32_t words, const uint32_t *part, uint32_t i) {
+    uint32_t lo = 0, hi = 256;  // part[lo] <= i < part[hi]
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (part[mid] <= i) lo = mid;
+        else hi = mid;
+    }
+    const uint32_t chunk = (words + 255u) >> 8;
+    uint32_t rem = i - part[lo];
+    for (uint32_t k = 0; k < chunk; ++k) {
+        const uint32_t w = lo * chunk + k;
+        uint64_t m = w < words ? mask[w] : 0ull;
+        const uint32_t pc = (uint32_t)__popcll(m);
+        if (rem < pc) {
+            for (; rem; --rem) m &= m - 1ull;
+            return w * 64u + (uint32_t)__ffsll((long long)m) - 1u;
+        }
+        rem -= pc;
+    }
+    return 0u;  // (unreachable for i < total)
+}
+
 #define QG_COOP_LANES qg::plan::COOP_LANES  // lanes per env of the cooperative scramble (scramble_coop below; qgym_plan.hpp)
 
 // Length of the compacted list of finished envs (compact_done), read by every thread of the LAST kernel that consumes it.  The last
@@ -179,13 +247,17 @@ __device__ inline void scramble_flat(W (*rows)[QG_WAVE], uint32_t L, const InitA
 // spread over the 16 lanes and parked in LDS as row-op words; two lanes then apply them in lockstep, one
 // row operation each.  `lds`: R rows + 64 words per env, 64 / 16 envs per wave.  Returns the env's rows
 // on the one lane per env that has to finish it (its index in `env`), nullptr on every other lane.
-template <typename W, int R, typename Identity>
-__device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds, uint64_t &env, Identity identity, uint32_t vblock) {
+struct ListEntry {  // entry i of InitArgs::list (the default source of scramble_coop's envs)
+    const uint32_t *list;
+    __device__ uint32_t operator()(uint32_t i) const { return list[i]; }
+};
+template <typename W, int R, typename Identity, typename EnvOf>
+__device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds, uint64_t &env, Identity identity, uint32_t vblock, EnvOf env_of) {
     constexpr uint32_t S = QG_COOP_LANES, EPW = QG_WAVE / S, CH = 64, PER_ENV = R * sizeof(W) + CH * sizeof(uint32_t);
     const uint64_t item = ((uint64_t)vblock * blockDim.x + threadIdx.x) / S;
     if (item >= count) return nullptr;  // whole lane groups leave together
     const uint32_t sl = threadIdx.x & (S - 1), w = threadIdx.x >> 6, g = (threadIdx.x & (QG_WAVE - 1)) / S;
-    env = a.list[item];
+    env = env_of((uint32_t)item);
     char *base = reinterpret_cast<char *>(lds) + (size_t)(w * EPW + g) * PER_ENV;
     W *rows = reinterpret_cast<W *>(base);
     uint32_t *ops = reinterpret_cast<uint32_t *>(base + R * sizeof(W));
@@ -219,7 +291,7 @@ __device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds,
 }
 template <typename W, int R, typename Identity>
 __device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds, uint64_t &env, Identity identity) {
-    return scramble_coop<W, R>(a, count, lds, env, identity, blockIdx.x);
+    return scramble_coop<W, R>(a, count, lds, env, identity, blockIdx.x, ListEntry{a.list});
 }
 // One WORKGROUP (four waves) per env, the matrix held by COLUMNS, the gate sequence cut in EIGHT.
 //

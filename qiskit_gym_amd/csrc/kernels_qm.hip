@@ -466,25 +466,22 @@ __global__ __launch_bounds__(256) void qm_step_kernel(StepArgs a) {
 // renaming into one v_perm_b32 per word.  ~150 instructions per lane instead of ~600 per env.
 // States that are not known to be symplectic (set_state of an arbitrary matrix) keep the thread-per-env Gauss-Jordan variant.
 // ------------------------------------------------------------------------------------------
-#ifndef QG_LIST_BLOCK
-#define QG_LIST_BLOCK 1024  // (256 for a development build of the former shape: tools/build_variant.sh -DQG_LIST_BLOCK=256)
-#endif
-constexpr unsigned QM_LIST_BLOCK = QG_LIST_BLOCK;
-// (LIST: QM_LIST_BLOCK threads per workgroup, as qm_step1_kernel<..., LIST> -- two lanes per env make 512 workgroups of 256 threads at 65 536 envs,
-// each with a turn at the list's counter)
+// (LIST: the envs that finish are recorded for the qg_vec_reset_done that follows -- one bit per env, the wave's ballot stored as half a word of
+// StepArgs::done_mask; round 4 appended their indices to a list with one atomic per workgroup of 1 024 threads, which cost this kernel 4.2 us of
+// its 7.5: half of the CUs idle, the others with sixteen waves each)
 template <int NXP, bool FEAT, bool LIST = false, bool DENSE = false>
-__global__ __launch_bounds__(LIST ? QM_LIST_BLOCK : 256) void qm_inv2_kernel(StepArgs a) {
+__global__ __launch_bounds__(256) void qm_inv2_kernel(StepArgs a) {
     KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    __shared__ uint32_t dense_rows[DENSE ? (LIST ? QM_LIST_BLOCK / 64 : 4) : 1][DENSE ? 32 * 33 : 1];  // DENSE: the inverted envs' rows, [env of the wave][row], pitch 33
+    __shared__ uint32_t dense_rows[DENSE ? 4 : 1][DENSE ? 32 * 33 : 1];  // DENSE: the inverted envs' rows, [env of the wave][row], pitch 33
     uint32_t *dl = DENSE ? dense_rows[threadIdx.x >> 6] : nullptr;
     QG_PREFETCH_STEP_ARGS(a);
     bool whole = false;  // DENSE: this lane's env was inverted, its rows are parked in dl
-    if constexpr (LIST || DENSE) {  // every thread reaches the workgroup-wide append / the wave-wide rewrite; whole lane pairs are in or out together
+    if constexpr (LIST || DENSE) {  // every thread reaches the wave-wide ballot / rewrite; whole lane pairs are in or out together
         bool fin = false;
         if ((tid >> 1) < a.B) fin = qm_inv2_body<NXP / 2, FEAT, DENSE>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr, dl, &whole);  // qm_step1.hpp
         if constexpr (DENSE) qm_inv2_dense_flush(a.dense, dl, (tid - (threadIdx.x & 63u)) >> 1, whole);
-        if constexpr (LIST) done_list_append_block<QM_LIST_BLOCK / 64>(a.done_list, a.done_count, fin && !(tid & 1u), tid >> 1, a.B);
+        if constexpr (LIST) done_mask_store_pairs(a.done_mask, fin, tid);
     } else {
         if ((tid >> 1) >= a.B) return;  // whole lane pairs leave together
         (void)qm_inv2_body<NXP / 2, FEAT, DENSE>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr, dl, &whole);  // qm_step1.hpp
@@ -497,23 +494,19 @@ __global__ __launch_bounds__(LIST ? QM_LIST_BLOCK : 256) void qm_inv2_kernel(Ste
 // incrementally kept `bad` mask (bit j: qubit j's rows / row j differ from the identity's).  ~3x fewer
 // instructions than the register-resident kernel, which at one wave per SIMD is what a step costs;
 // measured 3.77 -> 3.15 us per step at B = 65 536 and 34.9 -> 30.0 us at B = 2^20 (CliffordEnv 16q).
-// LIST: also append the envs that finish to StepArgs::done_list (F_DONE_LIST; its own instantiation: the plain kernel's code stays as it is)
+// LIST: also record the envs that finish, one bit each in StepArgs::done_mask (F_DONE_LIST; its own instantiation: the plain kernel's code stays as it is)
 // DENSE (qg_vec_track_dense, N == NXP, D % 16 == 0): the rows the gate rewrote also go to the resident dense int8 observation
-// (LIST: launched with QM_LIST_BLOCK threads per workgroup -- fewer, larger workgroups take fewer turns at the list's counter)
 template <int NXP, bool HAS_Z, bool FEAT, bool LIST = false, bool DENSE = false>
-__global__ __launch_bounds__(LIST ? QM_LIST_BLOCK : 256) void qm_step1_kernel(StepArgs a) {
+__global__ __launch_bounds__(256) void qm_step1_kernel(StepArgs a) {
     KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
     using Rows = QmRows<NXP, HAS_Z>;
     constexpr int D16 = DENSE ? Rows::R / 16 : 0;
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
-    if constexpr (LIST) {  // every thread reaches the workgroup-wide append
+    if constexpr (LIST) {  // every thread reaches the wave's ballot
         bool fin = false;
-        if (env < a.B) {
-            fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64));
-            if (a.pend_out) a.pend_out[env] = (uint8_t)fin;  // what the next qg_vec_reset_done_step tests (qm_reset_step_kernel)
-        }
-        done_list_append_block<QM_LIST_BLOCK / 64>(a.done_list, a.done_count, fin, env, a.B);  // (every wave of the workgroup gets here, also past the batch's end)
+        if (env < a.B) fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64));
+        done_mask_store(a.done_mask, fin, env);
     } else {
         if (env >= a.B) return;
         const int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
@@ -816,11 +809,18 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
         asm("v_mov_b32 %0, 0" : "=v"(opaque_zero));
         const uint32_t count_v = a.list_count[opaque_zero];
         const uint32_t entry_v = a.coop ? a.list[(vblock < a.B ? vblock : 0u) + opaque_zero] : 0u;
+        // ... and, when the step before left its finishers as a mask (InitArgs::mask), this thread's share of the mask's words
+        __shared__ uint32_t mask_part[257 + 4];
+        const uint32_t my_bits = a.mask ? done_mask_popc(a.mask, a.mask_words) : 0u;
         asm volatile("" ::: "memory");
         if (table_fits)
             for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) tree_table[i] = a.rowops[i];
-        const uint32_t count_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)count_v);
-        const uint32_t tree_env = (uint32_t)__builtin_amdgcn_readfirstlane((int)entry_v);
+        const uint32_t mcount = a.mask ? done_mask_scan(my_bits, mask_part) : 0u;  // (two barriers: the table is visible after them too)
+        const uint32_t lcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)count_v);
+        const uint32_t count_now = mcount + lcount;
+        // the envs to reset: the mask's set bits in ascending order, then the list's entries
+        auto entry = [&](uint32_t i) -> uint32_t { return i < mcount ? done_mask_nth(a.mask, a.mask_words, mask_part, i) : a.list[i - mcount]; };
+        const uint32_t tree_env = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.mask ? (vblock < count_now ? entry(vblock) : 0u) : entry_v));
         // (a block past the list may see the count already zeroed: it has no work either way)
         const plan::ResetPath path = plan::list_reset_path(count_now, a.n_draws, a.B, a.coop != 0, coop_fits);  // qgym_plan.hpp
         const bool tree = path == plan::RP_TREE;
@@ -855,7 +855,7 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
             round(tree_env);
             for (uint32_t item = vblock + a.tree_grid; item < count; item += a.tree_grid) {
                 __syncthreads();  // (the previous round's LDS has been read)
-                round(a.list[item]);
+                round(entry(item));
             }
             return;
         }
@@ -864,7 +864,7 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
             const uint32_t *rows = scramble_coop<uint32_t, Rows::R>(a, count, &lds_rows[0][0][0], env, [N](uint32_t k) -> uint32_t {
                 const uint32_t j = HAS_Z ? k >> 1 : k;
                 return j < N ? ((HAS_Z && (k & 1u)) ? (1u << N) << j : 1u << j) : 0u;
-            }, vblock);
+            }, vblock, entry);
             if (!rows) return;
             Rows s;
 #pragma unroll
@@ -874,7 +874,7 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
             return;
         }
         if (tid >= count) return;
-        env = a.list[tid];
+        env = entry((uint32_t)tid);
     } else {
         if (env >= a.B) return;
         if (a.only_done && !a.done[env]) return;  // live episodes keep running
@@ -925,15 +925,15 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
 
 // qg_vec_reset_done followed by qg_vec_step in ONE launch (qg_vec_reset_done_step): the grid's first `reset_blocks` workgroups are the
 // reset's (qm_init_block on the list the PREVIOUS step left; they are the launch's long pole -- scramble, then the env's step on the lane
-// that finished it -- so they are dispatched first), the others step the envs whose episode goes on.  Nothing is handed over inside the launch: which envs are being reset is read from `pend_in`, the
-// is_final flags the previous step wrote for this purpose and nobody writes during this launch (the user-visible `done` array is written
-// by both halves); this launch writes `pend_out` and appends the envs that finish to the OTHER list.  Results are those of the two calls.
+// that finished it -- so they are dispatched first), the others step the envs whose episode goes on.  Nothing is handed over inside the launch: which envs are being reset is read from the mask of
+// is_final bits the previous step left and nobody writes during this launch (the user-visible `done` array is written
+// by both halves); this launch writes the OTHER mask, and a reset env that is final again after its first step goes to the OTHER list.  Results are
+// those of the two calls.
 struct ResetStepArgs {
-    InitArgs reset;
-    StepArgs step;
-    const uint8_t *pend_in;  // [B] is_final after the previous step: 1 = this env is on the reset's list
-    uint8_t *pend_out;       // [B] is_final after this step
+    InitArgs reset;          // reset.mask: the is_final bits the PREVIOUS step left (bit set = this env is being reset in this launch)
+    StepArgs step;           // step.done_mask: the bits this launch leaves (the other buffer)
     uint32_t reset_blocks;
+    uint32_t step_blocks;
 };
 template <int NXP, bool HAS_Z, bool FEAT, bool DENSE>
 __global__ __launch_bounds__(256) void qm_reset_step_kernel(ResetStepArgs ra) {
@@ -942,23 +942,22 @@ __global__ __launch_bounds__(256) void qm_reset_step_kernel(ResetStepArgs ra) {
     constexpr int D16 = DENSE ? Rows::R / 16 : 0;
     const StepArgs &a = ra.step;
     QG_PREFETCH_STEP_ARGS(a);  // (the reset's lanes reach their step late: its argument lines are requested now, not one miss after the other then)
-    if (blockIdx.x >= ra.reset_blocks) {
-        const uint64_t env = (uint64_t)(blockIdx.x - ra.reset_blocks) * blockDim.x + threadIdx.x;
+    if (blockIdx.x < ra.step_blocks) {  // the step workgroups come first in the grid: they are on the machine while the reset workgroups are still being dispatched
+        const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const uint64_t resets = env < a.B ? ra.reset.mask[env >> 6] : 0ull;  // (one word per wave)
         bool fin = false;
-        if (env < a.B && !ra.pend_in[env]) {
+        if (env < a.B && !((resets >> (env & 63u)) & 1ull)) {
             // (the dense rows are written by lane pairs: a lane whose neighbour is being reset writes its rows alone)
-            const bool alone = D16 != 0 && (env ^ 1ull) < a.B && ra.pend_in[env ^ 1ull];
+            const bool alone = D16 != 0 && ((resets >> ((env ^ 1ull) & 63u)) & 1ull);
             fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64), alone);
-            ra.pend_out[env] = (uint8_t)fin;
         }
-        done_list_append_block(a.done_list, a.done_count, fin, env, a.B);
+        done_mask_store(a.done_mask, fin, env);  // (an env being reset: bit clear -- if it is final again after its first step the reset's lane appends it to the list)
         return;
     }
     // (plain configuration: the tree's wave takes the env's first step on the rows it holds -- qm_init_finish_wave_step; otherwise the lane
     // that has just written the env's fresh episode -- state, depth, bad mask, log lengths -- takes it, as qm_step1_body)
-    qm_init_block<NXP, HAS_Z>(ra.reset, blockIdx.x, FEAT ? nullptr : &a, [&](uint64_t env, bool stepped, bool fin) {
+    qm_init_block<NXP, HAS_Z>(ra.reset, blockIdx.x - ra.step_blocks, FEAT ? nullptr : &a, [&](uint64_t env, bool stepped, bool fin) {
         if (!stepped) fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64), true);
-        ra.pend_out[env] = (uint8_t)fin;
         if (fin) {  // (rare: one atomic per env that is final again after its first step)
             const uint32_t slot = atomicAdd(a.done_count, 1u);
             if (slot < a.B) a.done_list[slot] = (uint32_t)env;
@@ -1176,7 +1175,7 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
     const bool list = a.flags & F_DONE_LIST;
     switch (plan::tile_step(a.flags, a.T, a.bad != nullptr, a.rewards_seq || a.dones_seq, a.num_actions, HAS_Z, NXP)) {  // qgym_plan.hpp
     case plan::SK_QM_STEP1: {  // the env.step() path
-        const dim3 lgrid(grid_for(a.B, QM_LIST_BLOCK)), lblock(QM_LIST_BLOCK);
+        const dim3 lgrid = grid, lblock = block;
         if constexpr (QmRows<NXP, HAS_Z>::R % 16 == 0) {
             if (a.dense) {  // qg_vec_track_dense (the host passes it for N == NXP only)
                 if (feat && list) hipLaunchKernelGGL((qm_step1_kernel<NXP, HAS_Z, true, true, true>), lgrid, lblock, 0, s, a);
@@ -1194,7 +1193,7 @@ static hipError_t launch_step(const StepArgs &a, hipStream_t s) {
     }
     case plan::SK_QM_INV2:  // CliffordEnv with add_inverts, every env symplectic, one step per launch: two lanes per env
         if constexpr (HAS_Z && NXP <= 16) {
-            const dim3 grid2(grid_for(2 * a.B, 256)), lgrid2(grid_for(2 * a.B, QM_LIST_BLOCK)), lblock(QM_LIST_BLOCK);
+            const dim3 grid2(grid_for(2 * a.B, 256)), lgrid2 = grid2, lblock = block;
             if constexpr (NXP == 16) {
                 if (a.dense) {  // qg_vec_track_dense (N = 16)
                     if (feat && list) hipLaunchKernelGGL((qm_inv2_kernel<NXP, true, true, true>), lgrid2, lblock, 0, s, a);
@@ -1289,7 +1288,8 @@ static hipError_t launch_reset_step(const ResetStepArgs &ra, hipStream_t s) {
     }
     ResetStepArgs rb = ra;
     rb.reset_blocks = grid_for(threads, 256);
-    const dim3 grid(rb.reset_blocks + grid_for(ra.step.B, 256)), block(256);
+    rb.step_blocks = grid_for(ra.step.B, 256);
+    const dim3 grid(rb.reset_blocks + rb.step_blocks), block(256);
     const bool feat = ra.step.flags & (F_TRACK | F_LAYERS);
     if constexpr (QmRows<NXP, HAS_Z>::R % 16 == 0) {
         if (ra.step.dense) {
@@ -1302,14 +1302,12 @@ static hipError_t launch_reset_step(const ResetStepArgs &ra, hipStream_t s) {
     else hipLaunchKernelGGL((qm_reset_step_kernel<NXP, HAS_Z, false, false>), grid, block, 0, s, rb);
     return hipGetLastError();
 }
-hipError_t qm_reset_step(const InitArgs &reset, const StepArgs &step, const uint8_t *pend_in, uint8_t *pend_out, uint32_t nxp, bool has_z, hipStream_t s) {
+hipError_t qm_reset_step(const InitArgs &reset, const StepArgs &step, uint32_t nxp, bool has_z, hipStream_t s) {
     if (!step.B) return hipSuccess;
     ResetStepArgs ra;
     ra.reset = reset;
     ra.step = step;
-    ra.pend_in = pend_in;
-    ra.pend_out = pend_out;
-    ra.reset_blocks = 0;  // (set by the launcher)
+    ra.reset_blocks = ra.step_blocks = 0;  // (set by the launcher)
     QM_DISPATCH(launch_reset_step, ra)
 }
 

@@ -223,7 +223,7 @@ static int vec_free_buffers(qg_vec *v) {
     void *ptrs[] = {v->state, v->own_depth ? v->depth : nullptr, v->own_reward ? v->reward : nullptr,
                     v->own_done ? v->done : nullptr, v->own_success ? v->success : nullptr, v->inverted, v->error, v->sol,
                     v->sol_len, v->layers, v->d_gates, v->d_descs, v->scratch, v->d_prog,
-                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad, v->done_list, v->done_list_alt, v->done_list_spare, v->pend[0], v->pend[1], v->d_rowops, v->embed_dump, v->host_in, v->host_obs, v->fault_scratch};
+                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad, v->done_list, v->done_list_alt, v->done_list_spare, v->done_mask[0], v->done_mask[1], v->d_rowops, v->embed_dump, v->host_in, v->host_obs, v->fault_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &g : v->graphs) {
@@ -261,7 +261,7 @@ bool done_list_session(qg_vec *v, hipStream_t s) {
         v->list_session = cur;
         v->done_list_fresh = false;
         v->list_zero_known = false;
-        v->pend_fresh = false;
+        v->mask_fresh = false;
         v->alt_zero_known = false;
         if (cur) v->list_tainted = true;
     }
@@ -272,22 +272,21 @@ bool done_list_session(qg_vec *v, hipStream_t s) {
 int done_list_before_append(qg_vec *v, hipStream_t s) {
     if (!v->list_zero_known || v->done_list_fresh) HIP_TRY(hipMemsetAsync(v->done_list + v->B, 0, 2 * sizeof(uint32_t), s));
     v->done_list_fresh = false;
+    v->mask_fresh = false;
     v->list_zero_known = true;
     return QG_OK;
 }
 void done_list_appended(qg_vec *v, bool trusted) {
     v->done_list_fresh = trusted;  // an untrusted list is never consumed: the next reset_done compacts
     v->list_zero_known = false;
-    v->pend_fresh = false;  // (the step launches that also wrote the is_final array say so themselves: step_wrote_pend)
+    v->mask_fresh = false;  // (the step launches that left their finishers as a mask say so themselves: step_wrote_mask)
 }
-// a list-leaving step of a handle that can fuse reset_done + step also keeps is_final of every env (StepArgs::pend_out)
-static void step_writes_pend(const qg_vec *v, StepArgs &a) {
-    if (v->pend[0]) a.pend_out = v->pend[v->pend_cur ^ 1];
-}
-static void step_wrote_pend(qg_vec *v, const StepArgs &a, bool trusted) {
-    if (a.pend_out) {
-        v->pend_cur ^= 1;
-        v->pend_fresh = trusted;
+// TILE: a list-leaving step writes the mask that is not the current one (and appends nothing: the list stays empty)
+static void step_wrote_mask(qg_vec *v, const StepArgs &a, bool trusted) {
+    if (a.done_mask) {
+        v->mask_cur ^= 1;
+        v->mask_fresh = trusted;
+        v->list_zero_known = true;  // (nothing was appended: the length is still the zero done_list_before_append made sure of)
     }
 }
 
@@ -298,10 +297,11 @@ extern "C" {
 static int drop_done_list(qg_vec *v, hipStream_t s) {
     (void)done_list_session(v, s);
     if (v->done_list_fresh) {
-        HIP_TRY(hipMemsetAsync(v->done_list + v->B, 0, 2 * sizeof(uint32_t), s));
+        if (!(v->mask_fresh && v->list_zero_known)) HIP_TRY(hipMemsetAsync(v->done_list + v->B, 0, 2 * sizeof(uint32_t), s));
         v->done_list_fresh = false;
         v->list_zero_known = true;
     }
+    v->mask_fresh = false;
     return QG_OK;
 }
 
@@ -537,12 +537,14 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
         HIP_TRY_V(hipMalloc(&p->done_list_spare, sizeof(uint32_t) * (batch + 2)));
         HIP_TRY_V(hipMemset(p->done_list_spare + batch, 0, 2 * sizeof(uint32_t)));
     }
-    if (plan::reset_step_fusable(hp)) {  // qg_vec_reset_done_step in one launch: the second list and the two is_final arrays
+    if (plan::reset_step_fusable(hp)) {  // qg_vec_reset_done_step in one launch: the second list
         HIP_TRY_V(hipMalloc(&p->done_list_alt, sizeof(uint32_t) * (batch + 2)));
         HIP_TRY_V(hipMemset(p->done_list_alt + batch, 0, 2 * sizeof(uint32_t)));
-        for (auto &pp : p->pend) {
-            HIP_TRY_V(hipMalloc(&pp, batch));
-            HIP_TRY_V(hipMemset(pp, 0, batch));
+    }
+    if (hp.has_done_list && v->layout == LAYOUT_TILE) {  // the finished envs of a step as one bit each (qm_step1 / qm_inv2 <LIST>)
+        for (auto &m : p->done_mask) {
+            HIP_TRY_V(hipMalloc(&m, sizeof(uint64_t) * ((batch + 63) / 64 + 1)));
+            HIP_TRY_V(hipMemset(m, 0, sizeof(uint64_t) * ((batch + 63) / 64 + 1)));
         }
     }
     HIP_TRY_V(hipMalloc(&p->error, sizeof(uint32_t) * batch));
@@ -844,12 +846,21 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
     if (only_done && v->done_list) {
         // few, scattered finished envs: pack their indices first so that the scramble runs in full waves
         // instead of in every wave that holds one finished env (the sampling + step kernel has already done it: done_list_fresh)
-        if (!(trusted && v->done_list_fresh)) HIP_TRY(compact_done(v->done, v->B, v->done_list, v->done_list + v->B, s));
+        const bool left_by_step = trusted && v->done_list_fresh;  // the step before recorded its finishers itself (a list, or TILE: bits + a list)
+        if (!left_by_step) {
+            HIP_TRY(compact_done(v->done, v->B, v->done_list, v->done_list + v->B, s));
+            v->mask_fresh = false;
+        }
         v->done_list_fresh = false;
         v->list_zero_known = true;  // the reset kernel is the list's consumer: it zeroes the length (list_count_take)
         v->auto_list = true;
         ia.list = v->done_list;
         ia.list_count = v->done_list + v->B;
+        if (left_by_step && v->mask_fresh && v->done_mask[0]) {  // TILE: the step before left its finishers as bits (the list holds what the fused launch added, if anything)
+            ia.mask = v->done_mask[v->mask_cur];
+            ia.mask_words = (uint32_t)((v->B + 63) / 64);
+        }
+        v->mask_fresh = false;
         ia.coop = plan::reset_coop_allowed(actions_dev != nullptr, v->B, v->d_rowops != nullptr) ? 1u : 0u;
         if (v->layout == LAYOUT_TILE) ia.dense = v->dense;  // the listed envs' dense observations are rewritten by the reset itself
         if (v->done_list_spare) ia.zero_count = v->done_list_spare + v->B;
@@ -962,6 +973,7 @@ static bool step_leaves_done_list(const qg_vec *v, StepArgs &a) {
         a.flags |= F_DONE_LIST;
         a.done_list = v->done_list;
         a.done_count = v->done_list + v->B;
+        if (tile32) a.done_mask = v->done_mask[v->mask_cur ^ 1];  // one bit per env instead of an append (the list stays empty)
     }
     return lists;
 }
@@ -980,12 +992,11 @@ int qg_vec_step(qg_vec *v, const void *actions_dev, int action_dtype, const uint
     a.coins = coins_dev;
     if (action_dtype == QG_ACT_I64) a.flags |= F_ACT64;
     if (dense_rides_in_step(v)) a.dense = v->dense;
-    if (lists) step_writes_pend(v, a);
     HIP_TRY(launch_step(v, a, (hipStream_t)stream));
     v->step_index += 1;
     if (lists) {
         done_list_appended(v, true);
-        step_wrote_pend(v, a, true);
+        step_wrote_mask(v, a, true);
     }
     if (v->dense && !a.dense) return dense_refresh(v, (hipStream_t)stream);
     return QG_OK;
@@ -1056,7 +1067,7 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     const bool trusted = done_list_session(v, s);
     // one launch when the list of finished envs and their is_final flags were left by this handle's own previous step (same session) and the
     // reset would take the list path with counter-RNG draws; otherwise the two calls, whose step leaves both for the next time
-    const bool fuse = v->pend[0] && trusted && v->done_list_fresh && v->pend_fresh && v->auto_list && !v->gates.empty() &&
+    const bool fuse = v->done_list_alt && v->done_mask[0] && trusted && v->done_list_fresh && v->mask_fresh && v->auto_list && !v->gates.empty() &&
                       plan::reset_coop_allowed(false, v->B, v->d_rowops != nullptr);
     if (plan::reset_step_in_word_kernel(plan_of(v), v->gates.size())) {
         // one uint64 per env: no list -- every wave tests its envs' is_final flags, resets the finished ones (16 lanes each) and steps all of them
@@ -1093,6 +1104,8 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     ia.list = v->done_list;
     ia.list_count = v->done_list + v->B;
     ia.zero_count = v->done_list_spare + v->B;
+    ia.mask = v->done_mask[v->mask_cur];  // the finishers of the step before: the reset's work, and the step workgroups' "not mine" test
+    ia.mask_words = (uint32_t)((v->B + 63) / 64);
     ia.coop = 1u;
     ia.dense = v->dense;
     ia.depth_value = (int32_t)std::min<int64_t>((int64_t)v->cfg.depth_slope * v->difficulty, v->cfg.max_depth);  // clifford.rs:317
@@ -1103,23 +1116,22 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     a.rewards_seq = rewards_dev;
     a.dones_seq = dones_dev;
     if (action_dtype == QG_ACT_I64) a.flags |= F_ACT64;
-    a.flags |= F_DONE_LIST;  // the envs that finish in this step go to the OTHER list
+    a.flags |= F_DONE_LIST;  // the envs that finish in this step go to the OTHER mask (a reset env that is final again after its first step: to the OTHER list)
     a.done_list = v->done_list_alt;
     a.done_count = v->done_list_alt + v->B;
+    a.done_mask = v->done_mask[v->mask_cur ^ 1];
     if (!v->alt_zero_known) HIP_TRY(hipMemsetAsync(v->done_list_alt + v->B, 0, 2 * sizeof(uint32_t), s));
     if (dense_rides_in_step(v)) a.dense = v->dense;
-    const uint8_t *pend_in = v->pend[v->pend_cur];
-    uint8_t *pend_out = v->pend[v->pend_cur ^ 1];
     a.kclk = kernel_clock_slot(v);
     a.kclk_waves = v->kclk_waves;
-    HIP_TRY(qm_reset_step(ia, a, pend_in, pend_out, v->nxp, v->has_z, s));
+    HIP_TRY(qm_reset_step(ia, a, v->nxp, v->has_z, s));
     v->step_index += 1;
     // the list just appended to is the current one, the idle list (zeroed by this launch) is the next launch's target, the one just consumed idles
     std::swap(v->done_list, v->done_list_alt);   // (current, alt, spare) <- (alt, spare, current)
     std::swap(v->done_list_alt, v->done_list_spare);
-    v->pend_cur ^= 1;
+    v->mask_cur ^= 1;
     v->done_list_fresh = true;
-    v->pend_fresh = true;
+    v->mask_fresh = true;
     v->list_zero_known = false;
     v->alt_zero_known = true;
     if (v->dense && !a.dense) return dense_refresh(v, s);
@@ -1157,7 +1169,6 @@ static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, si
     if (action_dtype == QG_ACT_I64) a.flags |= F_ACT64;
     if (v->layout == LAYOUT_LFD) fused = 0;  // its step kernel spreads an env over four lanes; T steps = T launches (one graph)
     if (dense_rides_in_step(v) && (!fused || T == 1)) a.dense = v->dense;  // single-step launches keep the tracked observation current themselves
-    if (lists) step_writes_pend(v, a);
     if (fused) {
         if (period != T) return set_error(QG_ERR_INVALID, "fused rollouts read actions[t] for every t");
         a.T = (uint32_t)T;
@@ -1196,7 +1207,7 @@ static int rollout_impl(qg_vec *v, const void *actions_dev, int action_dtype, si
         v->step_index += T;
         if (lists) {
             done_list_appended(v, true);
-            step_wrote_pend(v, a, true);
+            step_wrote_mask(v, a, true);
         }
         return QG_OK;
     }

@@ -328,7 +328,7 @@ int qg_env_clone(const qg_env *e, qg_env **out) {  // Env: DynClone -- deep copy
     d->observe_counter = s->observe_counter;
     d->env_base = s->env_base;
     // a handle from the pool carries its previous owner's host-side session state: everything a fresh handle starts with, it starts with
-    d->auto_list = d->done_list_fresh = false;
+    d->auto_list = d->done_list_fresh = d->mask_fresh = false;
     d->list_zero_known = false;  // (unknown is always safe: the next appending launch zeroes the length first)
     d->list_tainted = false;
     d->list_session = 0;

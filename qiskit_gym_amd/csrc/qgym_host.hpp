@@ -120,12 +120,15 @@ struct qg_vec {
     uint32_t *d_rowops = nullptr;       // TILE: gate table as pairs of row operations on slots (cooperative reset kernel)
     uint32_t *done_list = nullptr;      // reset_done: [B] indices of finished envs + {length, reader ticket} at [B], [B + 1]
     // qg_vec_reset_done_step (TILE without add_inverts): the fused launch consumes done_list and appends to done_list_alt, then the two trade
-    // places; pend[pend_cur] = is_final of every env as the last list-leaving step wrote it (the fused launch's membership test)
+    // places
     uint32_t *done_list_alt = nullptr;
     uint32_t *done_list_spare = nullptr;  // TILE: the list no launch in flight reads or appends to; the reset that consumes done_list zeroes this one's length, then they rotate
-    uint8_t *pend[2] = {nullptr, nullptr};
-    int pend_cur = 0;
-    bool pend_fresh = false;            // pend[pend_cur] describes the list in done_list (believed within the session, like done_list_fresh)
+    // TILE: the finished envs of a step as one bit per env (StepArgs::done_mask), two buffers -- a list-leaving step (or the fused reset + step
+    // launch, which reads the current one) writes the other one, then they trade places.  Nothing to zero: a launch rewrites every word.
+    uint64_t *done_mask[2] = {nullptr, nullptr};
+    int mask_cur = 0;
+    bool mask_fresh = false;            // done_mask[mask_cur] (+ the list in done_list: envs reset and final again inside the fused launch; else empty) holds
+                                        // the envs that are final, as the handle's own last step left them (believed within the session, like done_list_fresh)
     bool alt_zero_known = true;         // done_list_alt's length is known to be zero
     bool auto_list = false;             // qg_vec_reset_done is in use on this handle: single steps append the envs they finish to the list themselves
     bool done_list_fresh = false;       // the list already holds the finished envs (written by the step that ended them); believed within the session only

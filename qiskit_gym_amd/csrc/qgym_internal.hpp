@@ -53,7 +53,8 @@ enum : uint32_t {
     F_TRACK = 1u << 2,     // track_solution (clifford.rs:334-340)
     F_LAYERS = 1u << 3,    // non-zero n_layers / n_layers_cnots weights: track per-qubit layers
     F_GJ = 1u << 4,        // some env may hold a non-symplectic matrix: compile in the Gauss-Jordan inversion
-    F_DONE_LIST = 1u << 5  // the one-step kernel appends the envs that finish to StepArgs::done_list (qg_vec_reset_done follows: no compaction launch)
+    F_DONE_LIST = 1u << 5  // the one-step kernel records the envs that finish for the qg_vec_reset_done that follows (no compaction launch): TILE stores
+                           // one bit per env in StepArgs::done_mask, TILE64 and the sampling + step kernels append indices to StepArgs::done_list
 };
 
 // counter RNG shared by host, device and the tests
@@ -114,8 +115,8 @@ struct StepArgs {
     uint32_t *done_count;     // read only under that flag (the last fields of the block: other launches never touch their cache line)
     int8_t *dense;            // qg_vec_track_dense: the resident dense int8 observation [B][D][D]; the DENSE instantiations of the one-step kernels
                               // rewrite the rows their gate changed (read by those instantiations only)
-    uint8_t *pend_out;        // F_DONE_LIST, TILE without add_inverts: is_final of every env after this step, for the membership test of the next
-                              // qg_vec_reset_done_step (null: not kept)
+    uint64_t *done_mask;      // F_DONE_LIST, TILE: word w = is_final of envs 64 w .. 64 w + 63 after this step, every word rewritten by the launch (no
+                              // counter, nothing to zero: device_common.hpp done_mask_store); read by the next reset's workgroups (InitArgs::mask)
 };
 
 // The argument block spans four 64-byte lines and the scalar cache is cold at every launch.  Left alone, the compiler fetches a field
@@ -167,6 +168,8 @@ struct InitArgs {
     uint32_t *nonsymp_flag;    // set_state with add_inverts: or-ed to 1 when some env is not symplectic
     const uint64_t *clock;     // device clock: the scramble seed becomes seed + 0x9E3779B9 * clock (qg_vec_set_clock)
     uint32_t *bad;             // see StepArgs::bad
+    const uint64_t *mask;      // reset_done, TILE: the finished envs as the bits a step launch left (StepArgs::done_mask), mask_words words; the envs to
+    uint32_t mask_words;       // reset are the set bits in ascending order FOLLOWED by the list's entries (null: the list alone)
     const uint32_t *list;      // reset_done, compacted: thread i resets env list[i], i < *list_count (or null: thread = env)
     uint32_t *list_count;      // [2]: length, reader ticket (device_common.hpp list_count_take)
     uint32_t tree_grid;        // workgroups of this launch that walk a list as trees (plan::tree_grid), entry i on workgroup i mod tree_grid
@@ -220,8 +223,9 @@ hipError_t lfd_export(const ObsArgs &a, bool w64, uint32_t rg, const uint8_t *in
 
 hipError_t qm_step(const StepArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
 hipError_t qm_init(const InitArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
-// qg_vec_reset_done (list in `reset`) + qg_vec_step (`step`, F_DONE_LIST: appends to ITS list) in one launch; pend_in / pend_out: StepArgs::pend_out
-hipError_t qm_reset_step(const InitArgs &reset, const StepArgs &step, const uint8_t *pend_in, uint8_t *pend_out, uint32_t nxp, bool has_z, hipStream_t s);
+// qg_vec_reset_done (mask + list in `reset`) + qg_vec_step (`step`, F_DONE_LIST: writes ITS mask, a reset env that is final again after its first step
+// goes to ITS list) in one launch
+hipError_t qm_reset_step(const InitArgs &reset, const StepArgs &step, uint32_t nxp, bool has_z, hipStream_t s);
 hipError_t qm_export(const ObsArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
 // dense {0,1} observation in an element type of `elem_size` bytes whose 1 is the bit pattern `one`
 hipError_t qm_export_typed(const void *state, uint64_t B, uint32_t N, uint32_t D, uint32_t nxp, bool has_z, void *out, uint32_t elem_size,
