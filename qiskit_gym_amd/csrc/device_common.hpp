@@ -115,21 +115,43 @@ __device__ inline void done_mask_store_pairs(uint64_t *mask, bool fin, uint64_t 
     if (__lane_id() == 0) reinterpret_cast<uint32_t *>(mask)[tid >> 6] = (uint32_t)m;
 }
 // The reader's side: every workgroup of the reset kernel counts the mask for itself (B / 64 words: 8 KB at 65 536 envs) -- thread t owns the words
-// [t c, (t + 1) c), c = ceil(words / 256) -- and finds "the i-th finished env" by a search over the 256 partial sums and a walk over one chunk.
-// done_mask_popc: this thread's share (its loads fly with whatever the caller issues next); done_mask_scan: call from all 256 threads, two
-// barriers, leaves part[t] = bits before thread t's chunk, part[256] = the total, which it returns; done_mask_nth: any thread, any i < total.
-__device__ inline uint32_t done_mask_popc(const uint64_t *mask, uint32_t words) {
-    const uint32_t chunk = (words + 255u) >> 8;
-    uint32_t n = 0;
-    for (uint32_t k = 0; k < chunk; ++k) {
-        const uint32_t w = threadIdx.x * chunk + k;
-        if (w < words) n += (uint32_t)__popcll(mask[w]);
-    }
-    return n;
+// [t c, (t + 1) c), c = ceil(words / 256), and keeps them in registers when c <= 4 (batches up to 65 536 envs).
+//   done_mask_load   this thread's share (its loads fly with whatever the caller issues next); returns its set bits
+//   done_mask_scan   call from all 256 threads: two barriers; part[t] = bits before thread t's chunk, part[256] = the total, which it returns
+//   done_mask_find   "the i-th finished env" for an i that is the same on every thread of the workgroup (the tree path's entry): the thread whose
+//                    chunk holds it answers from its registers, one more barrier, no search
+//   done_mask_nth    the same for any thread and any i < total: a search over the 256 partial sums and a walk over one chunk
+struct DoneMaskShare {
+    uint64_t w[4];
+    uint32_t bits, before;
+};
+__device__ inline uint32_t done_mask_pick(uint64_t m, uint32_t r) {  // position of the r-th set bit (r < popcount)
+    for (; r; --r) m &= m - 1ull;
+    return (uint32_t)__ffsll((long long)m) - 1u;
 }
-__device__ inline uint32_t done_mask_scan(uint32_t mine, uint32_t *part /* LDS [257 + 4] */) {
+__device__ inline void done_mask_load(const uint64_t *mask, uint32_t words, DoneMaskShare &sh) {
+    const uint32_t chunk = (words + 255u) >> 8;
+    sh.bits = 0;
+    if (chunk <= 4u) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t w = threadIdx.x * chunk + k;
+            const bool mine = k < chunk && w < words;
+            const uint64_t v = mask[mine ? w : 0u];  // (an unconditional load: the four requests leave together)
+            sh.w[k] = mine ? v : 0ull;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) sh.bits += (uint32_t)__popcll(sh.w[k]);
+    } else {
+        for (uint32_t k = 0; k < chunk; ++k) {
+            const uint32_t w = threadIdx.x * chunk + k;
+            if (w < words) sh.bits += (uint32_t)__popcll(mask[w]);
+        }
+    }
+}
+__device__ inline uint32_t done_mask_scan(DoneMaskShare &sh, uint32_t *part /* LDS [257 + 5] */) {
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
-    uint32_t incl = mine;
+    uint32_t incl = sh.bits;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
@@ -139,6 +161,7 @@ __device__ inline uint32_t done_mask_scan(uint32_t mine, uint32_t *part /* LDS [
     __syncthreads();
     uint32_t base = 0;
     for (uint32_t w = 0; w < wave; ++w) base += part[257u + w];
+    sh.before = base + incl - sh.bits;
     part[threadIdx.x + 1u] = base + incl;
     if (threadIdx.x == 0) part[0] = 0;
     __syncthreads();
@@ -155,15 +178,32 @@ __device__ inline uint32_t done_mask_nth(const uint64_t *mask, uint32_t words, c
     uint32_t rem = i - part[lo];
     for (uint32_t k = 0; k < chunk; ++k) {
         const uint32_t w = lo * chunk + k;
-        uint64_t m = w < words ? mask[w] : 0ull;
+        const uint64_t m = w < words ? mask[w] : 0ull;
         const uint32_t pc = (uint32_t)__popcll(m);
-        if (rem < pc) {
-            for (; rem; --rem) m &= m - 1ull;
-            return w * 64u + (uint32_t)__ffsll((long long)m) - 1u;
-        }
+        if (rem < pc) return w * 64u + done_mask_pick(m, rem);
         rem -= pc;
     }
     return 0u;  // (unreachable for i < total)
+}
+__device__ inline uint32_t done_mask_find(const uint64_t *mask, uint32_t words, const DoneMaskShare &sh, uint32_t *part, uint32_t i) {
+    const uint32_t chunk = (words + 255u) >> 8;
+    if (chunk > 4u) return done_mask_nth(mask, words, part, i);
+    if (sh.before <= i && i < sh.before + sh.bits) {  // exactly one thread
+        uint32_t rem = i - sh.before, env = 0;
+        bool found = false;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t pc = (uint32_t)__popcll(sh.w[k]);
+            if (!found && rem < pc) {
+                env = (threadIdx.x * chunk + k) * 64u + done_mask_pick(sh.w[k], rem);
+                found = true;
+            }
+            rem -= found ? 0u : pc;
+        }
+        part[261] = env;
+    }
+    __syncthreads();
+    return part[261];
 }
 
 #define QG_COOP_LANES qg::plan::COOP_LANES  // lanes per env of the cooperative scramble (scramble_coop below; qgym_plan.hpp)

@@ -810,17 +810,17 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
         const uint32_t count_v = a.list_count[opaque_zero];
         const uint32_t entry_v = a.coop ? a.list[(vblock < a.B ? vblock : 0u) + opaque_zero] : 0u;
         // ... and, when the step before left its finishers as a mask (InitArgs::mask), this thread's share of the mask's words
-        __shared__ uint32_t mask_part[257 + 4];
-        const uint32_t my_bits = a.mask ? done_mask_popc(a.mask, a.mask_words) : 0u;
+        __shared__ uint32_t mask_part[257 + 5];
+        DoneMaskShare share;
+        if (a.mask) done_mask_load(a.mask, a.mask_words, share);
         asm volatile("" ::: "memory");
         if (table_fits)
             for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) tree_table[i] = a.rowops[i];
-        const uint32_t mcount = a.mask ? done_mask_scan(my_bits, mask_part) : 0u;  // (two barriers: the table is visible after them too)
+        const uint32_t mcount = a.mask ? done_mask_scan(share, mask_part) : 0u;  // (two barriers: the table is visible after them too)
         const uint32_t lcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)count_v);
         const uint32_t count_now = mcount + lcount;
         // the envs to reset: the mask's set bits in ascending order, then the list's entries
         auto entry = [&](uint32_t i) -> uint32_t { return i < mcount ? done_mask_nth(a.mask, a.mask_words, mask_part, i) : a.list[i - mcount]; };
-        const uint32_t tree_env = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.mask ? (vblock < count_now ? entry(vblock) : 0u) : entry_v));
         // (a block past the list may see the count already zeroed: it has no work either way)
         const plan::ResetPath path = plan::list_reset_path(count_now, a.n_draws, a.B, a.coop != 0, coop_fits);  // qgym_plan.hpp
         const bool tree = path == plan::RP_TREE;
@@ -852,7 +852,10 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
                 if ((threadIdx.x & (QG_WAVE - 1)) == 0) after(e, sa != nullptr, fin);
             };
             if (vblock >= count) return;
-            round(tree_env);
+            // (workgroup-uniform) the first entry: from the list's prefetched word, or from the thread that holds it in its share of the mask
+            const uint32_t first = !a.mask ? (uint32_t)__builtin_amdgcn_readfirstlane((int)entry_v)
+                                   : vblock < mcount ? done_mask_find(a.mask, a.mask_words, share, mask_part, vblock) : a.list[vblock - mcount];
+            round((uint32_t)__builtin_amdgcn_readfirstlane((int)first));
             for (uint32_t item = vblock + a.tree_grid; item < count; item += a.tree_grid) {
                 __syncthreads();  // (the previous round's LDS has been read)
                 round(entry(item));

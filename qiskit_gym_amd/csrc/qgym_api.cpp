@@ -542,9 +542,10 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
         HIP_TRY_V(hipMemset(p->done_list_alt + batch, 0, 2 * sizeof(uint32_t)));
     }
     if (hp.has_done_list && v->layout == LAYOUT_TILE) {  // the finished envs of a step as one bit each (qm_step1 / qm_inv2 <LIST>)
+        const size_t mask_bytes = sizeof(uint64_t) * 4 * ((batch + 255) / 256);  // every wave of the step grid stores its word: whole workgroups of 256 envs
         for (auto &m : p->done_mask) {
-            HIP_TRY_V(hipMalloc(&m, sizeof(uint64_t) * ((batch + 63) / 64 + 1)));
-            HIP_TRY_V(hipMemset(m, 0, sizeof(uint64_t) * ((batch + 63) / 64 + 1)));
+            HIP_TRY_V(hipMalloc(&m, mask_bytes));
+            HIP_TRY_V(hipMemset(m, 0, mask_bytes));
         }
     }
     HIP_TRY_V(hipMalloc(&p->error, sizeof(uint32_t) * batch));

@@ -56,7 +56,9 @@ for spread in (True, False):
     w = np.nonzero(live[k])[0]
     rel0, rel1 = (t0[k][w] - t0[k][w].min()) / 100.0, (t1[k][w] - t0[k][w].min()) / 100.0
     print(f"  launch {k}: {len(w)} waves stamped, wave ids {w.min()}..{w.max()}")
-    for name, sel in (("reset workgroups (wave id < 4096)", w < 4096), ("step workgroups (wave id >= 4096)", w >= 4096)):
+    nfin = int(round(float(B) / AT)) if spread else 0
+    for name, sel in (("step workgroups (first 256 of the grid)", w < 1024), (f"reset workgroups with work (the next {nfin})", (w >= 1024) & (w < 1024 + 4 * nfin)),
+                      ("reset workgroups without work", w >= 1024 + 4 * nfin)):
         if sel.any():
             print(f"    {name}: {int(sel.sum())} waves; entry min/median/max {rel0[sel].min():.2f} {np.median(rel0[sel]):.2f} {rel0[sel].max():.2f}; "
                   f"exit min/median/max {rel1[sel].min():.2f} {np.median(rel1[sel]):.2f} {rel1[sel].max():.2f}")
