@@ -99,53 +99,62 @@ __device__ inline void done_list_append_block(uint32_t *list, uint32_t *count, b
 }
 
 // The finished envs of a step as one bit each (StepArgs::done_mask): the wave's ballot, one 8-byte store per wave -- no counter, no atomics, nothing
-// to zero (every launch rewrites every word).  Call from every lane of every wave of a thread-per-env grid (`fin` false past the batch's end).
-__device__ inline void done_mask_store(uint64_t *mask, bool fin, uint64_t env) {
+// to zero (every launch rewrites every word) -- and, behind the words, one byte per 32 envs with the number of bits set there (`done_mask_counts`):
+// what the reader sums, an eighth of the words' bytes.  Call from every lane of every wave of a thread-per-env grid (`fin` false past the batch's end).
+// Layout of a mask buffer for a batch of B: W = 4 * ceil(B / 256) words, then 2 W count bytes.
+__host__ __device__ inline uint64_t done_mask_words(uint64_t B) { return 4ull * ((B + 255ull) / 256ull); }
+__host__ __device__ inline uint64_t done_mask_bytes(uint64_t B) { return done_mask_words(B) * 10ull; }
+__device__ inline uint8_t *done_mask_counts(uint64_t *mask, uint64_t B) { return reinterpret_cast<uint8_t *>(mask + done_mask_words(B)); }
+__device__ inline const uint8_t *done_mask_counts(const uint64_t *mask, uint64_t B) { return reinterpret_cast<const uint8_t *>(mask + done_mask_words(B)); }
+__device__ inline void done_mask_store(uint64_t *mask, uint64_t B, bool fin, uint64_t env) {
     const uint64_t m = __ballot(fin);
-    if (__lane_id() == 0) mask[env >> 6] = m;
+    if (__lane_id() == 0) {
+        mask[env >> 6] = m;
+        reinterpret_cast<uint16_t *>(done_mask_counts(mask, B))[env >> 6] = (uint16_t)((uint32_t)__popc((uint32_t)m) | ((uint32_t)__popc((uint32_t)(m >> 32)) << 8));
+    }
 }
-// ... of a two-lanes-per-env grid (`tid` = 2 env + half; `fin` on the even lane): a wave holds 32 envs, half a word
-__device__ inline void done_mask_store_pairs(uint64_t *mask, bool fin, uint64_t tid) {
+// ... of a two-lanes-per-env grid (`tid` = 2 env + half; `fin` on the even lane): a wave holds 32 envs, half a word and one count byte
+__device__ inline void done_mask_store_pairs(uint64_t *mask, uint64_t B, bool fin, uint64_t tid) {
     uint64_t m = __ballot(fin && !(tid & 1ull));  // bit 2k: env k of the wave
     m = (m | (m >> 1)) & 0x3333333333333333ull;
     m = (m | (m >> 2)) & 0x0F0F0F0F0F0F0F0Full;
     m = (m | (m >> 4)) & 0x00FF00FF00FF00FFull;
     m = (m | (m >> 8)) & 0x0000FFFF0000FFFFull;
     m = (m | (m >> 16)) & 0x00000000FFFFFFFFull;
-    if (__lane_id() == 0) reinterpret_cast<uint32_t *>(mask)[tid >> 6] = (uint32_t)m;
+    if (__lane_id() == 0) {
+        reinterpret_cast<uint32_t *>(mask)[tid >> 6] = (uint32_t)m;
+        done_mask_counts(mask, B)[tid >> 6] = (uint8_t)__popc((uint32_t)m);
+    }
 }
-// The reader's side: every workgroup of the reset kernel counts the mask for itself (B / 64 words: 8 KB at 65 536 envs) -- thread t owns the words
-// [t c, (t + 1) c), c = ceil(words / 256), and keeps them in registers when c <= 4 (batches up to 65 536 envs).
-//   done_mask_load   this thread's share (its loads fly with whatever the caller issues next); returns its set bits
+// The reader's side: every workgroup of the reset kernel sums the counts for itself (B / 32 bytes: 2 KB at 65 536 envs) -- thread t owns the words
+// [t c, (t + 1) c), c = ceil(words / 256), i.e. 2 c count bytes (one 8-byte load for batches up to 65 536 envs).
+//   done_mask_load   this thread's share of the counts (its load flies with whatever the caller issues next)
 //   done_mask_scan   call from all 256 threads: two barriers; part[t] = bits before thread t's chunk, part[256] = the total, which it returns
 //   done_mask_find   "the i-th finished env" for an i that is the same on every thread of the workgroup (the tree path's entry): the thread whose
-//                    chunk holds it answers from its registers, one more barrier, no search
-//   done_mask_nth    the same for any thread and any i < total: a search over the 256 partial sums and a walk over one chunk
+//                    chunk holds it loads its words and answers; one more barrier, no search
+//   done_mask_nth    the same for any thread and any i < total: a search over the 256 partial sums and a walk over one chunk's words
 struct DoneMaskShare {
-    uint64_t w[4];
     uint32_t bits, before;
 };
 __device__ inline uint32_t done_mask_pick(uint64_t m, uint32_t r) {  // position of the r-th set bit (r < popcount)
     for (; r; --r) m &= m - 1ull;
     return (uint32_t)__ffsll((long long)m) - 1u;
 }
-__device__ inline void done_mask_load(const uint64_t *mask, uint32_t words, DoneMaskShare &sh) {
+__device__ inline uint32_t byte_sum4(uint32_t x) { return (x * 0x01010101u) >> 24; }  // (each byte <= 32: no carry out of the top byte)
+__device__ inline void done_mask_load(const uint64_t *mask, uint64_t B, uint32_t words, DoneMaskShare &sh) {
     const uint32_t chunk = (words + 255u) >> 8;
+    const uint8_t *cnt = done_mask_counts(mask, B);
     sh.bits = 0;
-    if (chunk <= 4u) {
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const uint32_t w = threadIdx.x * chunk + k;
-            const bool mine = k < chunk && w < words;
-            const uint64_t v = mask[mine ? w : 0u];  // (an unconditional load: the four requests leave together)
-            sh.w[k] = mine ? v : 0ull;
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) sh.bits += (uint32_t)__popcll(sh.w[k]);
+    if (chunk == 4u) {  // 8 count bytes
+        const uint2 v = reinterpret_cast<const uint2 *>(cnt)[threadIdx.x];
+        sh.bits = byte_sum4(v.x) + byte_sum4(v.y);
     } else {
         for (uint32_t k = 0; k < chunk; ++k) {
             const uint32_t w = threadIdx.x * chunk + k;
-            if (w < words) sh.bits += (uint32_t)__popcll(mask[w]);
+            if (w < words) {
+                const uint32_t c2 = reinterpret_cast<const uint16_t *>(cnt)[w];
+                sh.bits += (c2 & 0xFFu) + (c2 >> 8);
+            }
         }
     }
 }
@@ -167,6 +176,35 @@ __device__ inline uint32_t done_mask_scan(DoneMaskShare &sh, uint32_t *part /* L
     __syncthreads();
     return part[256];
 }
+// the r-th set bit of the chunk of thread `t`
+__device__ inline uint32_t done_mask_in_chunk(const uint64_t *mask, uint32_t words, uint32_t t, uint32_t rem) {
+    const uint32_t chunk = (words + 255u) >> 8;
+    if (chunk == 4u) {  // the four words at once
+        const uint4 a = reinterpret_cast<const uint4 *>(mask)[2u * t], b = reinterpret_cast<const uint4 *>(mask)[2u * t + 1u];
+        const uint64_t w[4] = {(uint64_t)a.x | ((uint64_t)a.y << 32), (uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)b.x | ((uint64_t)b.y << 32),
+                               (uint64_t)b.z | ((uint64_t)b.w << 32)};
+        uint32_t env = 0;
+        bool found = false;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t pc = (uint32_t)__popcll(w[k]);
+            if (!found && rem < pc) {
+                env = (t * 4u + k) * 64u + done_mask_pick(w[k], rem);
+                found = true;
+            }
+            rem -= found ? 0u : pc;
+        }
+        return env;
+    }
+    for (uint32_t k = 0; k < chunk; ++k) {
+        const uint32_t w = t * chunk + k;
+        const uint64_t m = w < words ? mask[w] : 0ull;
+        const uint32_t pc = (uint32_t)__popcll(m);
+        if (rem < pc) return w * 64u + done_mask_pick(m, rem);
+        rem -= pc;
+    }
+    return 0u;  // (unreachable for rem < the chunk's bits)
+}
 __device__ inline uint32_t done_mask_nth(const uint64_t *mask, uint32_t words, const uint32_t *part, uint32_t i) {
     uint32_t lo = 0, hi = 256;  // part[lo] <= i < part[hi]
     while (hi - lo > 1u) {
@@ -174,34 +212,10 @@ __device__ inline uint32_t done_mask_nth(const uint64_t *mask, uint32_t words, c
         if (part[mid] <= i) lo = mid;
         else hi = mid;
     }
-    const uint32_t chunk = (words + 255u) >> 8;
-    uint32_t rem = i - part[lo];
-    for (uint32_t k = 0; k < chunk; ++k) {
-        const uint32_t w = lo * chunk + k;
-        const uint64_t m = w < words ? mask[w] : 0ull;
-        const uint32_t pc = (uint32_t)__popcll(m);
-        if (rem < pc) return w * 64u + done_mask_pick(m, rem);
-        rem -= pc;
-    }
-    return 0u;  // (unreachable for i < total)
+    return done_mask_in_chunk(mask, words, lo, i - part[lo]);
 }
 __device__ inline uint32_t done_mask_find(const uint64_t *mask, uint32_t words, const DoneMaskShare &sh, uint32_t *part, uint32_t i) {
-    const uint32_t chunk = (words + 255u) >> 8;
-    if (chunk > 4u) return done_mask_nth(mask, words, part, i);
-    if (sh.before <= i && i < sh.before + sh.bits) {  // exactly one thread
-        uint32_t rem = i - sh.before, env = 0;
-        bool found = false;
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const uint32_t pc = (uint32_t)__popcll(sh.w[k]);
-            if (!found && rem < pc) {
-                env = (threadIdx.x * chunk + k) * 64u + done_mask_pick(sh.w[k], rem);
-                found = true;
-            }
-            rem -= found ? 0u : pc;
-        }
-        part[261] = env;
-    }
+    if (sh.before <= i && i < sh.before + sh.bits) part[261] = done_mask_in_chunk(mask, words, threadIdx.x, i - sh.before);  // exactly one thread
     __syncthreads();
     return part[261];
 }

@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void qm_inv2_kernel(StepArgs a) {
         bool fin = false;
         if ((tid >> 1) < a.B) fin = qm_inv2_body<NXP / 2, FEAT, DENSE>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr, dl, &whole);  // qm_step1.hpp
         if constexpr (DENSE) qm_inv2_dense_flush(a.dense, dl, (tid - (threadIdx.x & 63u)) >> 1, whole);
-        if constexpr (LIST) done_mask_store_pairs(a.done_mask, fin, tid);
+        if constexpr (LIST) done_mask_store_pairs(a.done_mask, a.B, fin, tid);
     } else {
         if ((tid >> 1) >= a.B) return;  // whole lane pairs leave together
         (void)qm_inv2_body<NXP / 2, FEAT, DENSE>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr, dl, &whole);  // qm_step1.hpp
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void qm_step1_kernel(StepArgs a) {
     if constexpr (LIST) {  // every thread reaches the wave's ballot
         bool fin = false;
         if (env < a.B) fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64));
-        done_mask_store(a.done_mask, fin, env);
+        done_mask_store(a.done_mask, a.B, fin, env);
     } else {
         if (env >= a.B) return;
         const int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
@@ -812,7 +812,7 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
         // ... and, when the step before left its finishers as a mask (InitArgs::mask), this thread's share of the mask's words
         __shared__ uint32_t mask_part[257 + 5];
         DoneMaskShare share;
-        if (a.mask) done_mask_load(a.mask, a.mask_words, share);
+        if (a.mask) done_mask_load(a.mask, a.B, a.mask_words, share);
         asm volatile("" ::: "memory");
         if (table_fits)
             for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) tree_table[i] = a.rowops[i];
@@ -947,14 +947,22 @@ __global__ __launch_bounds__(256) void qm_reset_step_kernel(ResetStepArgs ra) {
     QG_PREFETCH_STEP_ARGS(a);  // (the reset's lanes reach their step late: its argument lines are requested now, not one miss after the other then)
     if (blockIdx.x < ra.step_blocks) {  // the step workgroups come first in the grid: they are on the machine while the reset workgroups are still being dispatched
         const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        const uint64_t resets = env < a.B ? ra.reset.mask[env >> 6] : 0ull;  // (one word per wave)
+        // which envs the reset workgroups are taking: the bits of the previous step's mask, and (rare) the entries of the list -- envs that were reset in
+        // the previous launch and final again after their first step, which that launch's reset lanes could only append
+        uint64_t resets = env < a.B ? ra.reset.mask[env >> 6] : 0ull;  // (one word per wave)
+        uint32_t relisted = ra.reset.list_count[0];
+        relisted = relisted < a.B ? relisted : (uint32_t)a.B;
+        for (uint32_t i = 0; i < relisted; ++i) {  // (wave-uniform)
+            const uint32_t e = ra.reset.list[i];
+            if ((e >> 6) == (uint32_t)(env >> 6)) resets |= 1ull << (e & 63u);
+        }
         bool fin = false;
         if (env < a.B && !((resets >> (env & 63u)) & 1ull)) {
             // (the dense rows are written by lane pairs: a lane whose neighbour is being reset writes its rows alone)
             const bool alone = D16 != 0 && ((resets >> ((env ^ 1ull) & 63u)) & 1ull);
             fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64), alone);
         }
-        done_mask_store(a.done_mask, fin, env);  // (an env being reset: bit clear -- if it is final again after its first step the reset's lane appends it to the list)
+        done_mask_store(a.done_mask, a.B, fin, env);  // (an env being reset: bit clear -- if it is final again after its first step the reset's lane appends it to the list)
         return;
     }
     // (plain configuration: the tree's wave takes the env's first step on the rows it holds -- qm_init_finish_wave_step; otherwise the lane

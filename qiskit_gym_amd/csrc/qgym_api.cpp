@@ -542,7 +542,7 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
         HIP_TRY_V(hipMemset(p->done_list_alt + batch, 0, 2 * sizeof(uint32_t)));
     }
     if (hp.has_done_list && v->layout == LAYOUT_TILE) {  // the finished envs of a step as one bit each (qm_step1 / qm_inv2 <LIST>)
-        const size_t mask_bytes = sizeof(uint64_t) * 4 * ((batch + 255) / 256);  // every wave of the step grid stores its word: whole workgroups of 256 envs
+        const size_t mask_bytes = 10 * 4 * ((batch + 255) / 256);  // device_common.hpp done_mask_bytes: a word per wave of the step grid (whole workgroups of 256 envs), then a count byte per 32 envs
         for (auto &m : p->done_mask) {
             HIP_TRY_V(hipMalloc(&m, mask_bytes));
             HIP_TRY_V(hipMemset(m, 0, mask_bytes));
@@ -859,7 +859,7 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
         ia.list_count = v->done_list + v->B;
         if (left_by_step && v->mask_fresh && v->done_mask[0]) {  // TILE: the step before left its finishers as bits (the list holds what the fused launch added, if anything)
             ia.mask = v->done_mask[v->mask_cur];
-            ia.mask_words = (uint32_t)((v->B + 63) / 64);
+            ia.mask_words = (uint32_t)(4 * ((v->B + 255) / 256));
         }
         v->mask_fresh = false;
         ia.coop = plan::reset_coop_allowed(actions_dev != nullptr, v->B, v->d_rowops != nullptr) ? 1u : 0u;
@@ -1106,7 +1106,7 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     ia.list_count = v->done_list + v->B;
     ia.zero_count = v->done_list_spare + v->B;
     ia.mask = v->done_mask[v->mask_cur];  // the finishers of the step before: the reset's work, and the step workgroups' "not mine" test
-    ia.mask_words = (uint32_t)((v->B + 63) / 64);
+    ia.mask_words = (uint32_t)(4 * ((v->B + 255) / 256));
     ia.coop = 1u;
     ia.dense = v->dense;
     ia.depth_value = (int32_t)std::min<int64_t>((int64_t)v->cfg.depth_slope * v->difficulty, v->cfg.max_depth);  // clifford.rs:317
