@@ -305,6 +305,7 @@ struct ListEntry {  // entry i of InitArgs::list (the default source of scramble
     const uint32_t *list;
     __device__ uint32_t operator()(uint32_t i) const { return list[i]; }
 };
+// (`env` is set on every lane of a group that has an entry, also on the lanes that get nullptr back)
 template <typename W, int R, typename Identity, typename EnvOf>
 __device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds, uint64_t &env, Identity identity, uint32_t vblock, EnvOf env_of) {
     constexpr uint32_t S = QG_COOP_LANES, EPW = QG_WAVE / S, CH = 64, PER_ENV = R * sizeof(W) + CH * sizeof(uint32_t);

@@ -248,7 +248,11 @@ inline bool reset_coop_allowed(bool draws_given, uint64_t B, bool has_rowops) { 
 constexpr bool tile_coop_fits(uint32_t R, uint32_t word_bytes) { return 16ull * (R * word_bytes + 256ull) <= 4ull * R * 64ull * word_bytes; }
 
 // qg_vec_reset_done_step as ONE launch (qm_reset_step_kernel): handles whose env.step() is the one-step TILE kernel
-inline bool reset_step_fusable(const HandlePlan &p) { return p.layout == LAYOUT_TILE && p.has_bad && !(p.flags & F_INVERTS) && p.has_done_list; }
+// ... and CliffordEnv N <= 16 with add_inverts (qm_reset_inv2_step_kernel: two lanes per env), while every env is known to be symplectic
+inline bool reset_step_fusable(const HandlePlan &p) {
+    if (p.layout != LAYOUT_TILE || !p.has_done_list) return false;
+    return (p.flags & F_INVERTS) ? (p.has_z && p.nxp <= 16) : p.has_bad;
+}
 
 // ... and on the one-word layouts (word_reset_step_kernel: the wave tests its envs' is_final flags itself, no list)
 inline bool reset_step_in_word_kernel(const HandlePlan &p, size_t num_actions) { return (p.layout == LAYOUT_LF8 || p.layout == LAYOUT_PERM) && num_actions != 0; }

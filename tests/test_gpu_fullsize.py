@@ -340,6 +340,63 @@ def test_one_launch_auto_reset_with_a_tracked_observation_at_full_size(diff, L):
     assert np.array_equal(dense.cpu().numpy().reshape(B, -1), ov.observe_dense()), "resident observation"
 
 
+def test_one_launch_auto_reset_with_the_reference_defaults_at_full_size():
+    """CliffordGym(...) as a user gets it (add_inverts=True, track_solution=True) at 65 536 envs in a collector's loop: qg_vec_reset_done_step after a first
+    step -- one launch per pair (qm_reset_inv2_step_kernel) -- with the coins from the handle's counter RNG, episode ends spread evenly over time
+    (1 / 32 of the batch per step).  Every env against the oracle after every step: reward bits, is_final, depth; states and solution lists at the end."""
+    from qiskit_gym_amd.vec import VecEnv
+
+    kind, n, B, diff, L, coin_seed = "clifford", 16, 65536, 64, 32, 0xFEED
+    gs = line_gateset(kind, n)
+    A = len(gs)
+    cfg = dict(add_inverts=True, add_perms=False, track_solution=True, difficulty=diff, depth_slope=1, max_depth=L)
+    gv = VecEnv(kind, n, gs, B, seed=coin_seed, **cfg)
+    ids = np.arange(B)
+    ov = _all_envs_oracle(kind, n, gs, B, cfg)
+    gv.reset(1)
+    ov.reset_seeded(1)
+    gen = torch.Generator(device="cuda").manual_seed(12)
+    all_env = torch.arange(B, device="cuda")
+    t = 0
+    for k in range(L):  # Env::reset for class k at time k
+        acts = torch.randint(0, A, (B,), dtype=torch.int32, device="cuda", generator=gen)
+        gv.set_counters(t, 0)
+        gv.step(acts)
+        fin = gv.done.cpu().numpy()
+        ov.step(acts.cpu().numpy(), _coins(coin_seed, ids, t))
+        t += 1
+        gv.reset_done(100 + k)
+        ov.reset_seeded(100 + k, mask=fin)
+        gv.done[all_env % L == k] = 1
+        gv.reset_done(5000 + k)
+        ov.reset_seeded(5000 + k, mask=(ids % L == k))
+    acts = torch.randint(0, A, (B,), dtype=torch.int32, device="cuda", generator=gen)
+    gv.set_counters(t, 0)
+    gv.step(acts)  # leaves its finishers for the one-launch pairs that follow
+    ov.step(acts.cpu().numpy(), _coins(coin_seed, ids, t))
+    t += 1
+    finished = 0
+    for k in range(2 * L + 5):
+        fin = gv.done.cpu().numpy()
+        assert 0.4 / L < fin.mean() < 2.5 / L, (k, fin.mean())
+        finished += int(fin.sum())
+        acts = torch.randint(0, A, (B,), dtype=torch.int32, device="cuda", generator=gen)
+        gv.set_counters(t, 0)
+        gv.reset_done_step(9000 + k, acts)
+        gv.sync()
+        ov.reset_seeded(9000 + k, mask=fin)
+        r, s, f, d = ov.step(acts.cpu().numpy(), _coins(coin_seed, ids, t))
+        t += 1
+        assert np.array_equal(f32_bits(gv.reward.cpu().numpy()), f32_bits(r)), f"reward k={k}"
+        assert np.array_equal(gv.done.cpu().numpy(), f), f"is_final k={k}: envs {np.nonzero(gv.done.cpu().numpy() != f)[0][:8]}"
+        assert np.array_equal(gv.depth.cpu().numpy(), d), f"depth k={k}"
+    assert finished >= 2 * B
+    assert np.array_equal(gv.get_state("i64").cpu().numpy(), ov.get_state(1024)), "final states"
+    g_sol, g_len = gv.solutions(L)
+    o_sol, o_len = ov.solutions(L)
+    assert np.array_equal(g_len, o_len) and np.array_equal(g_sol, o_sol), "solution lists"
+
+
 def test_config4_all_eight_shards_equal_the_whole_batch_x524288():
     """BASELINE config 4 (CliffordGym 16q, 524 288 envs, 8 ranks x 65 536) on one GPU: the WHOLE batch as one handle against each of the
     eight shards as its own handle with its env_base -- reset, 24 steps with auto-reset of finished episodes, then the learner shard every
