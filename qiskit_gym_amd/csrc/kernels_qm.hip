@@ -979,9 +979,23 @@ __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
 struct ResetStepArgs {
     InitArgs reset;          // reset.mask: the is_final bits the PREVIOUS step left (bit set = this env is being reset in this launch)
     StepArgs step;           // step.done_mask: the bits this launch leaves (the other buffer)
+    // the grid: [reset workgroups 0 .. first_reset) [step workgroups] [reset workgroups first_reset .. reset_blocks).  A list's work sits in its first
+    // workgroups: those go first (two per CU at 65 536 envs), the step workgroups take the slots beside them, and the reset workgroups that will most
+    // likely find no entry come last -- at three workgroups per CU (40 KB of LDS each) whatever is dispatched late waits for a slot
     uint32_t reset_blocks;
     uint32_t step_blocks;
+    uint32_t first_reset;
 };
+// this workgroup's role: true = a step workgroup (`index` among them), false = a reset workgroup (`index` = vblock)
+__device__ inline bool reset_step_role(const ResetStepArgs &ra, uint32_t &index) {
+    const uint32_t b = blockIdx.x;
+    if (b >= ra.first_reset && b < ra.first_reset + ra.step_blocks) {
+        index = b - ra.first_reset;
+        return true;
+    }
+    index = b < ra.first_reset ? b : b - ra.step_blocks;
+    return false;
+}
 template <int NXP, bool HAS_Z, bool FEAT, bool DENSE>
 __global__ __launch_bounds__(256) void qm_reset_step_kernel(ResetStepArgs ra) {
     KernelClock kclk(ra.step.kclk, ra.step.kclk_waves);  // device_common.hpp
@@ -989,8 +1003,9 @@ __global__ __launch_bounds__(256) void qm_reset_step_kernel(ResetStepArgs ra) {
     constexpr int D16 = DENSE ? Rows::R / 16 : 0;
     const StepArgs &a = ra.step;
     QG_PREFETCH_STEP_ARGS(a);  // (the reset's lanes reach their step late: its argument lines are requested now, not one miss after the other then)
-    if (blockIdx.x < ra.step_blocks) {  // the step workgroups come first in the grid: they are on the machine while the reset workgroups are still being dispatched
-        const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t role_index;
+    if (reset_step_role(ra, role_index)) {
+        const uint64_t env = (uint64_t)role_index * blockDim.x + threadIdx.x;
         // which envs the reset workgroups are taking: the bits of the previous step's mask, and (rare) the entries of the list -- envs that were reset in
         // the previous launch and final again after their first step, which that launch's reset lanes could only append
         uint64_t resets = env < a.B ? ra.reset.mask[env >> 6] : 0ull;  // (one word per wave)
@@ -1011,7 +1026,7 @@ __global__ __launch_bounds__(256) void qm_reset_step_kernel(ResetStepArgs ra) {
     }
     // (plain configuration: the tree's wave takes the env's first step on the rows it holds -- qm_init_finish_wave_step; otherwise the lane
     // that has just written the env's fresh episode -- state, depth, bad mask, log lengths -- takes it, as qm_step1_body)
-    qm_init_block<NXP, HAS_Z>(ra.reset, blockIdx.x - ra.step_blocks, FEAT ? nullptr : &a, [&](uint64_t env, bool stepped, bool fin) {
+    qm_init_block<NXP, HAS_Z>(ra.reset, role_index, FEAT ? nullptr : &a, [&](uint64_t env, bool stepped, bool fin) {
         if (!stepped) fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64), true);
         if (fin) {  // (rare: one atomic per env that is final again after its first step)
             const uint32_t slot = atomicAdd(a.done_count, 1u);
@@ -1028,8 +1043,9 @@ __global__ __launch_bounds__(256) void qm_reset_inv2_step_kernel(ResetStepArgs r
     KernelClock kclk(ra.step.kclk, ra.step.kclk_waves);  // device_common.hpp
     const StepArgs &a = ra.step;
     QG_PREFETCH_STEP_ARGS(a);
-    if (blockIdx.x < ra.step_blocks) {
-        const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, env = tid >> 1;
+    uint32_t role_index;
+    if (reset_step_role(ra, role_index)) {
+        const uint64_t tid = (uint64_t)role_index * blockDim.x + threadIdx.x, env = tid >> 1;
         uint64_t resets = env < a.B ? ra.reset.mask[env >> 6] : 0ull;  // (a wave's 32 envs share a word)
         uint32_t relisted = ra.reset.list_count[0];  // (see qm_reset_step_kernel)
         relisted = relisted < a.B ? relisted : (uint32_t)a.B;
@@ -1042,7 +1058,7 @@ __global__ __launch_bounds__(256) void qm_reset_inv2_step_kernel(ResetStepArgs r
         done_mask_store_pairs(a.done_mask, a.B, fin, tid);
         return;
     }
-    qm_init_block<NXP, true, true>(ra.reset, blockIdx.x - ra.step_blocks, nullptr, [&](uint64_t env, uint32_t h) {
+    qm_init_block<NXP, true, true>(ra.reset, role_index, nullptr, [&](uint64_t env, uint32_t h) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the fresh episode (written by this wave's lanes) is in memory before the pair reads it back
         const bool fin = qm_inv2_body<NXP / 2, FEAT, false>(a, NXP / 2, env, h, nullptr);
         if (fin && h == 0) {  // (rare: final again after its first step)
@@ -1375,6 +1391,7 @@ static hipError_t launch_reset_step(const ResetStepArgs &ra, hipStream_t s) {
     }
     ResetStepArgs rb = ra;
     rb.reset_blocks = grid_for(threads, 256);
+    rb.first_reset = rb.reset_blocks / 2;
     const bool feat = ra.step.flags & (F_TRACK | F_LAYERS);
     if (ra.step.flags & F_INVERTS) {  // the reference-default step: two lanes per env
         if constexpr (HAS_Z && NXP <= 16) {
@@ -1404,7 +1421,7 @@ hipError_t qm_reset_step(const InitArgs &reset, const StepArgs &step, uint32_t n
     ResetStepArgs ra;
     ra.reset = reset;
     ra.step = step;
-    ra.reset_blocks = ra.step_blocks = 0;  // (set by the launcher)
+    ra.reset_blocks = ra.step_blocks = ra.first_reset = 0;  // (set by the launcher)
     QM_DISPATCH(launch_reset_step, ra)
 }
 

@@ -11,8 +11,9 @@ from util import line_gateset
 AT, B = 128, 65536
 gs = line_gateset("clifford", 16)
 A = len(gs)
+INVERTS = "--inverts" in sys.argv
 for spread in (True, False):
-    env = VecEnv("clifford", 16, gs, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=256)
+    env = VecEnv("clifford", 16, gs, B, add_inverts=INVERTS, add_perms=False, track_solution=INVERTS, difficulty=256)
     stream = torch.cuda.Stream()
     gen = torch.Generator(device="cuda").manual_seed(3)
     acts = torch.randint(0, A, (AT, B), dtype=torch.int32, device="cuda", generator=gen)
@@ -57,8 +58,12 @@ for spread in (True, False):
     rel0, rel1 = (t0[k][w] - t0[k][w].min()) / 100.0, (t1[k][w] - t0[k][w].min()) / 100.0
     print(f"  launch {k}: {len(w)} waves stamped, wave ids {w.min()}..{w.max()}")
     nfin = int(round(float(B) / AT)) if spread else 0
-    for name, sel in (("step workgroups (first 256 of the grid)", w < 1024), (f"reset workgroups with work (the next {nfin})", (w >= 1024) & (w < 1024 + 4 * nfin)),
-                      ("reset workgroups without work", w >= 1024 + 4 * nfin)):
+    first_reset, step_blocks = 512, (512 if INVERTS else 256)  # the grid: [reset 0..511][step][reset 512..1023]
+    wg = w // 4
+    is_step = (wg >= first_reset) & (wg < first_reset + step_blocks)
+    vblock = np.where(wg < first_reset, wg, wg - step_blocks)
+    for name, sel in (("step workgroups", is_step), (f"reset workgroups with work (vblock < {nfin})", ~is_step & (vblock < nfin)),
+                      ("reset workgroups without work", ~is_step & (vblock >= nfin))):
         if sel.any():
             print(f"    {name}: {int(sel.sum())} waves; entry min/median/max {rel0[sel].min():.2f} {np.median(rel0[sel]):.2f} {rel0[sel].max():.2f}; "
                   f"exit min/median/max {rel1[sel].min():.2f} {np.median(rel1[sel]):.2f} {rel1[sel].max():.2f}")
