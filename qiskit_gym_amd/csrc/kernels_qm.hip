@@ -784,10 +784,8 @@ __device__ inline bool qm_init_finish_wave_step(const InitArgs &a, const StepArg
 // list in rounds -- entries vblock, vblock + tree_grid, ... -- so it may be called several times).
 // `sa` (qm_reset_step_kernel, plain configuration): the tree path also takes the env's first step (qm_init_finish_wave_step) and says so in
 // `stepped`, with is_final in `fin`; the other paths leave the step to `after`.
-// PAIR (qm_reset_inv2_step_kernel; list paths only): the env's first step is taken by TWO adjacent lanes (the reference-default step, qm_inv2_body): after a
-// reset env's fresh episode has been written, `after(env, h)` is called on an even lane (h = 0) and the odd lane next to it (h = 1), both active.
 struct NoAfter { __device__ void operator()(uint64_t, bool, bool) const {} };
-template <int NXP, bool HAS_Z, bool PAIR = false, typename After = NoAfter>
+template <int NXP, bool HAS_Z, typename After = NoAfter>
 __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock, const StepArgs *sa = nullptr, After after = After()) {
     using Rows = QmRows<NXP, HAS_Z>;
     // reset scramble (device_common.hpp): the rows live in LDS (wave-private, [slot][lane]: conflict-free for
@@ -821,6 +819,7 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
         const uint32_t mcount = a.mask ? done_mask_scan(share, mask_part) : 0u;  // (two barriers: the table is visible after them too)
         const uint32_t lcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)count_v);
         const uint32_t count_now = mcount + lcount;
+        if (a.count_out && vblock == 0 && threadIdx.x == 0) *a.count_out = count_now;  // (host memory: sizes the next launches' tree grid)
         // the envs to reset: the mask's set bits in ascending order, then the list's entries
         auto entry = [&](uint32_t i) -> uint32_t { return i < mcount ? done_mask_nth(a.mask, a.mask_words, mask_part, i) : a.list[i - mcount]; };
         // (a block past the list may see the count already zeroed: it has no work either way)
@@ -851,11 +850,7 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
                 bool fin = false;
                 if (sa) fin = qm_init_finish_wave_step<NXP, HAS_Z>(a, *sa, e, myrow, act, ge);
                 else qm_init_finish_wave<NXP, HAS_Z>(a, e, myrow);
-                if constexpr (PAIR) {
-                    if ((threadIdx.x & (QG_WAVE - 1)) < 2u) after(e, threadIdx.x & 1u);
-                } else {
-                    if ((threadIdx.x & (QG_WAVE - 1)) == 0) after(e, sa != nullptr, fin);
-                }
+                if ((threadIdx.x & (QG_WAVE - 1)) == 0) after(e, sa != nullptr, fin);
             };
             if (vblock >= count) return;
             // (workgroup-uniform) the first entry: from the list's prefetched word, or from the thread that holds it in its share of the mask
@@ -874,50 +869,12 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
                 const uint32_t j = HAS_Z ? k >> 1 : k;
                 return j < N ? ((HAS_Z && (k & 1u)) ? (1u << N) << j : 1u << j) : 0u;
             }, vblock, entry);
-            if constexpr (PAIR) {  // lanes 0 and 1 of every 16-lane group with an entry stay: lane 0 finishes the reset, then both take the step
-                const uint32_t sl = threadIdx.x & (QG_COOP_LANES - 1);
-                if (((uint64_t)vblock * blockDim.x + threadIdx.x) / QG_COOP_LANES >= count || sl >= 2u) return;
-                if (rows) {
-                    Rows s;
+            if (!rows) return;
+            Rows s;
 #pragma unroll
-                    for (int k = 0; k < Rows::R; ++k) s.r[k] = rows[k];
-                    qm_init_finish<NXP, HAS_Z>(a, env, s);
-                }
-                after(env, sl);
-                return;
-            } else {
-                if (!rows) return;
-                Rows s;
-#pragma unroll
-                for (int k = 0; k < Rows::R; ++k) s.r[k] = rows[k];
-                qm_init_finish<NXP, HAS_Z>(a, env, s);
-                after(env, false, false);
-                return;
-            }
-        }
-        if constexpr (PAIR) {  // one lane per env for the reset; then the wave's envs one after the other on lanes 0 and 1 (no lane leaves before that)
-            const bool has = tid < count;
-            if (!__ballot(has)) return;
-            const uint32_t mine = has ? entry((uint32_t)tid) : 0u;
-            if (has) {
-                Rows s;
-                qm_identity<NXP, HAS_Z>(s, a.N);
-                uint32_t(*rows)[QG_WAVE] = lds_rows[threadIdx.x >> 6];
-                const uint32_t L = threadIdx.x & (QG_WAVE - 1);
-#pragma unroll
-                for (int sl = 0; sl < Rows::R; ++sl) rows[sl][L] = s.r[sl];
-                scramble_flat<uint32_t>(rows, L, a, mine);
-#pragma unroll
-                for (int sl = 0; sl < Rows::R; ++sl) s.r[sl] = rows[sl][L];
-                qm_init_finish<NXP, HAS_Z>(a, mine, s);
-            }
-            uint64_t todo = __ballot(has);
-            while (todo) {  // (wave-uniform)
-                const int b = __ffsll((long long)todo) - 1;
-                todo &= todo - 1ull;
-                const uint32_t e = (uint32_t)__shfl((int)mine, b);
-                if ((threadIdx.x & (QG_WAVE - 1)) < 2u) after((uint64_t)e, threadIdx.x & 1u);
-            }
+            for (int k = 0; k < Rows::R; ++k) s.r[k] = rows[k];
+            qm_init_finish<NXP, HAS_Z>(a, env, s);
+            after(env, false, false);
             return;
         }
         if (tid >= count) return;
@@ -960,7 +917,7 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
         for (int sl = 0; sl < Rows::R; ++sl) s.r[sl] = rows[sl][L];
     }
     qm_init_finish<NXP, HAS_Z>(a, env, s);
-    if constexpr (!PAIR) after(env, false, false);  // (PAIR: the list paths above have returned; set_state and whole resets are not followed by a step)
+    after(env, false, false);
 }
 
 
@@ -1029,39 +986,6 @@ __global__ __launch_bounds__(256) void qm_reset_step_kernel(ResetStepArgs ra) {
     qm_init_block<NXP, HAS_Z>(ra.reset, role_index, FEAT ? nullptr : &a, [&](uint64_t env, bool stepped, bool fin) {
         if (!stepped) fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64), true);
         if (fin) {  // (rare: one atomic per env that is final again after its first step)
-            const uint32_t slot = atomicAdd(a.done_count, 1u);
-            if (slot < a.B) a.done_list[slot] = (uint32_t)env;
-        }
-    });
-}
-
-// The same with the reference's default options (add_inverts; CliffordEnv N <= 16, every env symplectic): the step workgroups run qm_inv2_body (two lanes
-// per env, 512 workgroups at 65 536 envs), a reset env's first step is taken by two adjacent lanes of the wave that has just written its fresh
-// episode (qm_init_block<PAIR>).  As two launches the pair cost 14.3 us (reset 6.5 + step 3.8 + two launch boundaries 4.0).
-template <int NXP, bool FEAT>
-__global__ __launch_bounds__(256) void qm_reset_inv2_step_kernel(ResetStepArgs ra) {
-    KernelClock kclk(ra.step.kclk, ra.step.kclk_waves);  // device_common.hpp
-    const StepArgs &a = ra.step;
-    QG_PREFETCH_STEP_ARGS(a);
-    uint32_t role_index;
-    if (reset_step_role(ra, role_index)) {
-        const uint64_t tid = (uint64_t)role_index * blockDim.x + threadIdx.x, env = tid >> 1;
-        uint64_t resets = env < a.B ? ra.reset.mask[env >> 6] : 0ull;  // (a wave's 32 envs share a word)
-        uint32_t relisted = ra.reset.list_count[0];  // (see qm_reset_step_kernel)
-        relisted = relisted < a.B ? relisted : (uint32_t)a.B;
-        for (uint32_t i = 0; i < relisted; ++i) {
-            const uint32_t e = ra.reset.list[i];
-            if ((e >> 6) == (uint32_t)(env >> 6)) resets |= 1ull << (e & 63u);
-        }
-        bool fin = false;
-        if (env < a.B && !((resets >> (env & 63u)) & 1ull)) fin = qm_inv2_body<NXP / 2, FEAT, false>(a, NXP / 2, env, (uint32_t)tid & 1u, nullptr);  // qm_step1.hpp
-        done_mask_store_pairs(a.done_mask, a.B, fin, tid);
-        return;
-    }
-    qm_init_block<NXP, true, true>(ra.reset, role_index, nullptr, [&](uint64_t env, uint32_t h) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the fresh episode (written by this wave's lanes) is in memory before the pair reads it back
-        const bool fin = qm_inv2_body<NXP / 2, FEAT, false>(a, NXP / 2, env, h, nullptr);
-        if (fin && h == 0) {  // (rare: final again after its first step)
             const uint32_t slot = atomicAdd(a.done_count, 1u);
             if (slot < a.B) a.done_list[slot] = (uint32_t)env;
         }
@@ -1393,16 +1317,7 @@ static hipError_t launch_reset_step(const ResetStepArgs &ra, hipStream_t s) {
     rb.reset_blocks = grid_for(threads, 256);
     rb.first_reset = rb.reset_blocks / 2;
     const bool feat = ra.step.flags & (F_TRACK | F_LAYERS);
-    if (ra.step.flags & F_INVERTS) {  // the reference-default step: two lanes per env
-        if constexpr (HAS_Z && NXP <= 16) {
-            rb.step_blocks = grid_for(2 * ra.step.B, 256);
-            const dim3 grid2(rb.reset_blocks + rb.step_blocks);
-            if (feat) hipLaunchKernelGGL((qm_reset_inv2_step_kernel<NXP, true>), grid2, dim3(256), 0, s, rb);
-            else hipLaunchKernelGGL((qm_reset_inv2_step_kernel<NXP, false>), grid2, dim3(256), 0, s, rb);
-            return hipGetLastError();
-        }
-        return hipErrorInvalidValue;
-    }
+    if (ra.step.flags & F_INVERTS) return hipErrorInvalidValue;  // (two launches: qgym_plan.hpp reset_step_fusable)
     rb.step_blocks = grid_for(ra.step.B, 256);
     const dim3 grid(rb.reset_blocks + rb.step_blocks), block(256);
     if constexpr (QmRows<NXP, HAS_Z>::R % 16 == 0) {

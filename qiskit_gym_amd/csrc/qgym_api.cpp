@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cctype>
 #include <cstdarg>
 #include <cstdio>
@@ -233,6 +234,7 @@ static int vec_free_buffers(qg_vec *v) {
     v->graphs.clear();
     if (v->capture_stream) (void)hipStreamDestroy(v->capture_stream);
     if (v->fault_word) (void)hipHostFree(v->fault_word);
+    if (v->count_seen) (void)hipHostFree(v->count_seen);
     return 0;
 }
 
@@ -309,6 +311,19 @@ static int drop_done_list(qg_vec *v, hipStream_t s) {
 static unsigned long long *kernel_clock_slot(const qg_vec *v) {
     if (!v->kclk || v->kclk_next >= v->kclk_cap) return nullptr;
     return v->kclk + 2ull * v->kclk_waves * (v->kclk_next++);
+}
+
+// Workgroups a reset_done launch sets aside for trees (InitArgs::tree_grid).  Every one of them costs a dispatch slot and ~2 us of a CU's third of its
+// LDS whether or not the list reaches it, and at three workgroups per CU whatever is dispatched late waits -- so the grid follows the list lengths
+// this handle's resets have reported (InitArgs::count_out: the latest launch that has finished; read without waiting): the length, four standard
+// deviations of a count that size and a margin, in steps of 64.  A longer list is walked in rounds: the grid's size never changes a result.
+static uint32_t reset_tree_grid(const qg_vec *v) {
+    const uint32_t most = plan::tree_grid(v->B);
+    const uint32_t seen = v->count_seen ? *(volatile const uint32_t *)v->count_seen : 0xFFFFFFFFu;
+    if (seen == 0xFFFFFFFFu) return most;
+    const uint64_t want = (uint64_t)seen + 4ull * (uint64_t)std::sqrt((double)seen) + 32ull;
+    const uint64_t g = (want + 63ull) & ~63ull;
+    return (uint32_t)std::min<uint64_t>(most, std::max<uint64_t>(64ull, g));
 }
 
 static void fill_init_args(const qg_vec *v, InitArgs &a) {
@@ -416,6 +431,7 @@ static plan::HandlePlan plan_of(const qg_vec *v) {  // the handle's fields that 
     hp.w64 = v->w64;
     hp.flags = v->flags;
     hp.has_bad = v->bad != nullptr;
+    hp.has_done_list = v->done_list != nullptr;
     hp.pt_nq = v->pt_nq;
     hp.pt_rm = v->pt_rm;
     hp.pauli_compact = v->pt_nq <= 24 && v->pt_rm == 8;
@@ -542,6 +558,8 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
         HIP_TRY_V(hipMemset(p->done_list_alt + batch, 0, 2 * sizeof(uint32_t)));
     }
     if (hp.has_done_list && v->layout == LAYOUT_TILE) {  // the finished envs of a step as one bit each (qm_step1 / qm_inv2 <LIST>)
+        HIP_TRY_V(hipHostMalloc((void **)&p->count_seen, sizeof(uint32_t), hipHostMallocMapped));
+        *p->count_seen = 0xFFFFFFFFu;
         const size_t mask_bytes = 10 * 4 * ((batch + 255) / 256);  // device_common.hpp done_mask_bytes: a word per wave of the step grid (whole workgroups of 256 envs), then a count byte per 32 envs
         for (auto &m : p->done_mask) {
             HIP_TRY_V(hipMalloc(&m, mask_bytes));
@@ -857,6 +875,10 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
         v->auto_list = true;
         ia.list = v->done_list;
         ia.list_count = v->done_list + v->B;
+        if (v->layout == LAYOUT_TILE && v->count_seen) {
+            ia.count_out = v->count_seen;
+            ia.tree_grid = reset_tree_grid(v);
+        }
         if (left_by_step && v->mask_fresh && v->done_mask[0]) {  // TILE: the step before left its finishers as bits (the list holds what the fused launch added, if anything)
             ia.mask = v->done_mask[v->mask_cur];
             ia.mask_words = (uint32_t)(4 * ((v->B + 255) / 256));
@@ -1068,10 +1090,8 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     const bool trusted = done_list_session(v, s);
     // one launch when the list of finished envs and their is_final flags were left by this handle's own previous step (same session) and the
     // reset would take the list path with counter-RNG draws; otherwise the two calls, whose step leaves both for the next time
-    // (add_inverts: the two-lanes-per-env launch has no Gauss-Jordan and no tracked-observation form)
-    const bool inverts = v->flags & F_INVERTS;
     const bool fuse = v->done_list_alt && v->done_mask[0] && trusted && v->done_list_fresh && v->mask_fresh && v->auto_list && !v->gates.empty() &&
-                      plan::reset_coop_allowed(false, v->B, v->d_rowops != nullptr) && !(inverts && (v->maybe_nonsymplectic || v->dense));
+                      plan::reset_coop_allowed(false, v->B, v->d_rowops != nullptr) && plan::reset_step_fuses(plan_of(v));
     if (plan::reset_step_in_word_kernel(plan_of(v), v->gates.size())) {
         // one uint64 per env: no list -- every wave tests its envs' is_final flags, resets the finished ones (16 lanes each) and steps all of them
         InitArgs ia;
@@ -1107,6 +1127,8 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     ia.list = v->done_list;
     ia.list_count = v->done_list + v->B;
     ia.zero_count = v->done_list_spare + v->B;
+    ia.count_out = v->count_seen;
+    ia.tree_grid = reset_tree_grid(v);
     ia.mask = v->done_mask[v->mask_cur];  // the finishers of the step before: the reset's work, and the step workgroups' "not mine" test
     ia.mask_words = (uint32_t)(4 * ((v->B + 255) / 256));
     ia.coop = 1u;
@@ -1335,8 +1357,7 @@ int qg_plan_query(const qg_config *cfg, uint64_t batch, uint32_t num_actions, in
         break;
     }
     case QG_PLAN_RESET_DONE_STEP:
-        name = plan::reset_step_fusable(hp) ? ((hp.flags & F_INVERTS) ? (nonsymplectic ? "two launches" : "qm_reset_inv2_step_kernel (after a list-leaving step)")
-                                                                      : "qm_reset_step_kernel (after a list-leaving step)")
+        name = plan::reset_step_fusable(hp) ? "qm_reset_step_kernel (after a list-leaving step)"
                : plan::reset_step_in_word_kernel(hp, num_actions) ? "word_reset_step_kernel" : "two launches";
         break;
     case QG_PLAN_OBSERVE_DENSE:

@@ -114,6 +114,8 @@ struct qg_vec {
     void *host_in = nullptr;            // qg_vec_step_host: device copies of the caller's actions [B] (8 bytes each) and coins [B]
     void *host_obs = nullptr;           // qg_vec_observe_*_host: the observation before its copy to the caller's buffer
     size_t host_obs_bytes = 0;
+    uint32_t *count_seen = nullptr;     // TILE: how many envs the latest finished reset_done launch reset (pinned, device-mapped; written by the launch, read -- without
+                                        // waiting -- when a later one is sized: qgym_api.cpp reset_tree_grid).  0xFFFFFFFF: nothing seen yet
     uint32_t *fault_word = nullptr;     // qg_vec_sync: OR of error[], one pinned, device-mapped word the host reads after the stream has drained
     uint32_t *fault_scratch = nullptr;  // its device-side accumulator and ticket (two words, zero between calls)
     uint32_t *bad = nullptr;            // TILE / TILE64 without add_inverts: per-env "differs from identity" mask (one-step kernels)

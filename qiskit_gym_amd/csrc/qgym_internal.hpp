@@ -182,6 +182,7 @@ struct InitArgs {
                                // refreshes the whole buffer after the launch)
     unsigned long long *kclk;  // qg_vec_set_kernel_clock: this launch's slot (kclk_waves wave records), or null
     uint32_t kclk_waves;
+    uint32_t *count_out;       // reset_done with a list / mask, TILE: the number of envs reset, for the host's eyes (pinned memory; sizes the next launches' tree grid), or null
 };
 
 // A handle may be given a device-resident clock (qg_vec_set_clock).  Launches replayed from a

@@ -340,9 +340,9 @@ def test_one_launch_auto_reset_with_a_tracked_observation_at_full_size(diff, L):
     assert np.array_equal(dense.cpu().numpy().reshape(B, -1), ov.observe_dense()), "resident observation"
 
 
-def test_one_launch_auto_reset_with_the_reference_defaults_at_full_size():
+def test_reset_done_step_with_the_reference_defaults_at_full_size():
     """CliffordGym(...) as a user gets it (add_inverts=True, track_solution=True) at 65 536 envs in a collector's loop: qg_vec_reset_done_step after a first
-    step -- one launch per pair (qm_reset_inv2_step_kernel) -- with the coins from the handle's counter RNG, episode ends spread evenly over time
+    step (the step leaves its finishers as one bit per env, the reset's workgroups count them) with the coins from the handle's counter RNG, episode ends spread evenly over time
     (1 / 32 of the batch per step).  Every env against the oracle after every step: reward bits, is_final, depth; states and solution lists at the end."""
     from qiskit_gym_amd.vec import VecEnv
 
@@ -372,7 +372,7 @@ def test_one_launch_auto_reset_with_the_reference_defaults_at_full_size():
         ov.reset_seeded(5000 + k, mask=(ids % L == k))
     acts = torch.randint(0, A, (B,), dtype=torch.int32, device="cuda", generator=gen)
     gv.set_counters(t, 0)
-    gv.step(acts)  # leaves its finishers for the one-launch pairs that follow
+    gv.step(acts)  # leaves its finishers for the pairs that follow
     ov.step(acts.cpu().numpy(), _coins(coin_seed, ids, t))
     t += 1
     finished = 0
