@@ -1,5 +1,5 @@
-"""rocprofv3 PMC passes of tools/profile_bench.sh -> profiles/r04/traffic.json (and the kernel-stats files copied beside it).
-  python tools/pmc_traffic.py [src = gpurun_out/prof] [dst = profiles/r04]
+"""rocprofv3 PMC passes of tools/profile_bench.sh -> profiles/r05/traffic.json (and the kernel-stats files copied beside it).
+  python tools/pmc_traffic.py [src = gpurun_out/prof] [dst = profiles/r05]
 
 HBM bytes per launch of a step kernel = 2 x FETCH_SIZE + WRITE_SIZE (both reported in KiB): MI355X_MICROARCH.md's HBM
 section -- on gfx950 FETCH_SIZE counts half the bytes of a 16 B/lane read, WRITE_SIZE is taken as is; each counter is
@@ -15,7 +15,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof")
-dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r04")
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r05")
 os.makedirs(dst, exist_ok=True)
 
 # run name -> (kernel name PREFIX -- trailing template arguments vary by call site --, envs, SURVEY 8(d) bytes per env-step, bytes the
@@ -27,9 +27,12 @@ RUNS = {
     # two lanes per env: Grid_Size is 2 x envs.  Needed: 128 B of state read; the envs whose coin fired (half) rewrite all 128 B, the others the
     # gate's <= 2 groups (~24 B): 76 B on average; action 4, coin 1, depth 4 + 4, flags 1 + 1, log lengths 8 + 8, log entry 4, reward 4, done 1, success 1
     "C3d": ("qm_inv2_kernel<16, true", 2 * 65536, 160, 245),
+    "C3d_4194304": ("qm_inv2_kernel<16, true", 2 * 4194304, 160, 245),
     "C2": ("word_step_kernel<false>", 8192, 32, 32),
     # two 12-byte qubit records read and written, the 64-byte rotation block's touched 16-bit slices + bookkeeping, 22 B of scalars
     "C5": ("ptile_step1c_kernel<20, 8", 65536, 494, 130),
+    "C5_1048576": ("ptile_step1c_kernel<20, 8", 1048576, 494, 130),
+    "C5_4194304": ("ptile_step1c_kernel<20, 8", 4194304, 494, 130),
     # SURVEY 8d's dense-observation mode (tools/bench_dense_obs.py): the full rewrite (1 KiB written, 128 B read per env), the step that keeps a
     # resident dense observation current (8d counts 1 184 B; it has to move the step's 90 B + ~2 changed rows of 32 B), and the same with the
     # reference-default options (two lanes per env: half of the envs rewrite 1 KiB, the others the gate's rows)
@@ -72,6 +75,12 @@ out = {"method": "tools/profile_bench.sh: rocprofv3 --pmc <COUNTER> --kernel-tra
                  "one pass per counter; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md HBM section: FETCH_SIZE doubled on gfx950, "
                  "WRITE_SIZE as is, both in KiB); mean over the step kernel's dispatches",
        "by_envs": {}, "configs": {}}
+try:  # a run of tools/profile_bench.sh in two parts: keep what the other part measured
+    prev = json.load(open(os.path.join(dst, "traffic.json")))
+    out["by_envs"].update(prev.get("by_envs", {}))
+    out["configs"].update(prev.get("configs", {}))
+except Exception:
+    pass
 for run, (kernel, envs, algo, needed) in RUNS.items():
     fetch, write = read(run, "FETCH_SIZE", kernel, envs), read(run, "WRITE_SIZE", kernel, envs)
     if not fetch or not write:
@@ -85,7 +94,7 @@ for run, (kernel, envs, algo, needed) in RUNS.items():
             live = json.loads(open(lp).read().strip().splitlines()[-1])
         except Exception:
             live = None
-    if run in ("C3d", "tracked_default"):
+    if run in ("C3d", "C3d_4194304", "tracked_default"):
         envs //= 2
     e = {"kernel": "qg::" + kernel + "...>", "envs": envs, "fetch_bytes": fb, "write_bytes": wb, "bytes_per_launch": fb + wb,
          "bytes_per_env": (fb + wb) / envs, "fetch_per_env": fb / envs, "write_per_env": wb / envs,
