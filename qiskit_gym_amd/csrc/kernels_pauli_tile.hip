@@ -897,7 +897,11 @@ __global__ __launch_bounds__(256) void ptile_step1c_kernel(PTArgs pa) {
         L::load_qubit(tile, lane, qa, xa, za);
         L::load_qubit(tile, lane, qb, xb, zb);  // one-qubit gates: qb == qa, the same (cached) record
         const uint32_t two = qa != qb;
+#ifdef QG_ABLATE_SLICES  // development build (tools/build_variant.sh): what the step would cost if the gate's rotation slices came with its qubit records -- results are WRONG
+        const uint32_t sva = 0u, svb = 0u;
+#else
         const uint32_t sva = *L::xz(tile, lane, qa), svb = *L::xz(tile, lane, qb);
+#endif
         pt_mix(m, xa, za, xb, zb, n);
         if (two) L::store_qubit(tile, lane, qb, n[2], n[3]);
         L::store_qubit(tile, lane, qa, n[0], n[1]);
@@ -921,8 +925,10 @@ __global__ __launch_bounds__(256) void ptile_step1c_kernel(PTArgs pa) {
         }
         planes_add(w, v.xa | v.za);
         planes_add(w, v.xb | v.zb);
+#ifndef QG_ABLATE_SLICES
         if ((v.xa ^ v0.xa) | (v.za ^ v0.za)) *L::xz(tile, lane, qa) = (uint16_t)(v.xa | (v.za << 8));
         if ((v.xb ^ v0.xb) | (v.zb ^ v0.zb)) *L::xz(tile, lane, qb) = (uint16_t)(v.xb | (v.zb << 8));
+#endif
     }
 
     if (FEAT && (a.flags & F_TRACK) && in_range) {  // pauli.rs:612-626

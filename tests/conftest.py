@@ -20,6 +20,13 @@ if "OMP_NUM_THREADS" not in os.environ:
     os.environ["OMP_NUM_THREADS"] = str(max(1, min(_n, _quota or _n)))
 
 
+# tools/run_cpu_tests_asan.sh: the CPU tests against the sanitizer build of libqgym's host side (qiskit_gym_amd/lib/libqgym_asan.so)
+if os.environ.get("QGYM_LIB_ASAN"):
+    from qiskit_gym_amd import _lib as _qg_lib
+
+    _qg_lib.LIB_PATH = os.path.join(ROOT, "qiskit_gym_amd", "lib", "libqgym_asan.so")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
 

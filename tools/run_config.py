@@ -102,7 +102,12 @@ def main():
             e1.record(stream)
             torch.cuda.synchronize()
             total += e0.elapsed_time(e1)
-    env.sync()
+    try:
+        env.sync()
+    except Exception as exc:  # (an ablation build computes wrong states on purpose: its envs may fault)
+        if not os.environ.get("QG_LIB"):
+            raise
+        print(f"run_config: variant build, faults ignored: {exc}", file=sys.stderr)
     us = total * 1e3 / (reps * T)
     print(json.dumps({"config": c, "envs": B, "actions": A, "kernel": "qg::" + KERNELS[c], "launch_us": us, "env_steps_per_s": B / us * 1e6,
                       "algorithmic_bytes_per_env_step": ALGO[c], "achieved_GBs": ALGO[c] * B / us / 1e3, "frac_of_8TBs": ALGO[c] * B / us / 1e3 / 8000,
