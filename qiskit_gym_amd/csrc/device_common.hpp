@@ -101,20 +101,25 @@ __device__ inline void done_list_append_block(uint32_t *list, uint32_t *count, b
 // The finished envs of a step as one bit each (StepArgs::done_mask): the wave's ballot, one 8-byte store per wave -- no counter, no atomics, nothing
 // to zero (every launch rewrites every word) -- and, behind the words, one byte per 32 envs with the number of bits set there (`done_mask_counts`):
 // what the reader sums, an eighth of the words' bytes.  Call from every lane of every wave of a thread-per-env grid (`fin` false past the batch's end).
-// Layout of a mask buffer for a batch of B: W = 4 * ceil(B / 256) words, then 2 W count bytes.
+// Layout of a mask buffer for a batch of B: W = 4 * ceil(B / 256) words, then 2 W count bytes, then the hint word: a wave WITH a finisher stores the
+// launch's number there (plain stores of one value: no read-modify-write), so a reader that finds another number knows every count is zero and leaves
+// without summing them (a stale equal number -- a replayed graph without a device clock -- only costs the sum).
 __host__ __device__ inline uint64_t done_mask_words(uint64_t B) { return 4ull * ((B + 255ull) / 256ull); }
-__host__ __device__ inline uint64_t done_mask_bytes(uint64_t B) { return done_mask_words(B) * 10ull; }
+__host__ __device__ inline uint64_t done_mask_bytes(uint64_t B) { return done_mask_words(B) * 10ull + 8ull; }
+__device__ inline uint32_t *done_mask_hint(uint64_t *mask, uint64_t B) { return reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(mask) + done_mask_words(B) * 10ull); }
+__device__ inline const uint32_t *done_mask_hint(const uint64_t *mask, uint64_t B) { return done_mask_hint(const_cast<uint64_t *>(mask), B); }
 __device__ inline uint8_t *done_mask_counts(uint64_t *mask, uint64_t B) { return reinterpret_cast<uint8_t *>(mask + done_mask_words(B)); }
 __device__ inline const uint8_t *done_mask_counts(const uint64_t *mask, uint64_t B) { return reinterpret_cast<const uint8_t *>(mask + done_mask_words(B)); }
-__device__ inline void done_mask_store(uint64_t *mask, uint64_t B, bool fin, uint64_t env) {
+__device__ inline void done_mask_store(uint64_t *mask, uint64_t B, bool fin, uint64_t env, uint32_t epoch) {
     const uint64_t m = __ballot(fin);
     if (__lane_id() == 0) {
+        if (m) *done_mask_hint(mask, B) = epoch;
         mask[env >> 6] = m;
         reinterpret_cast<uint16_t *>(done_mask_counts(mask, B))[env >> 6] = (uint16_t)((uint32_t)__popc((uint32_t)m) | ((uint32_t)__popc((uint32_t)(m >> 32)) << 8));
     }
 }
 // ... of a two-lanes-per-env grid (`tid` = 2 env + half; `fin` on the even lane): a wave holds 32 envs, half a word and one count byte
-__device__ inline void done_mask_store_pairs(uint64_t *mask, uint64_t B, bool fin, uint64_t tid) {
+__device__ inline void done_mask_store_pairs(uint64_t *mask, uint64_t B, bool fin, uint64_t tid, uint32_t epoch) {
     uint64_t m = __ballot(fin && !(tid & 1ull));  // bit 2k: env k of the wave
     m = (m | (m >> 1)) & 0x3333333333333333ull;
     m = (m | (m >> 2)) & 0x0F0F0F0F0F0F0F0Full;
@@ -122,6 +127,7 @@ __device__ inline void done_mask_store_pairs(uint64_t *mask, uint64_t B, bool fi
     m = (m | (m >> 8)) & 0x0000FFFF0000FFFFull;
     m = (m | (m >> 16)) & 0x00000000FFFFFFFFull;
     if (__lane_id() == 0) {
+        if (m) *done_mask_hint(mask, B) = epoch;
         reinterpret_cast<uint32_t *>(mask)[tid >> 6] = (uint32_t)m;
         done_mask_counts(mask, B)[tid >> 6] = (uint8_t)__popc((uint32_t)m);
     }

@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void qm_inv2_kernel(StepArgs a) {
         bool fin = false;
         if ((tid >> 1) < a.B) fin = qm_inv2_body<NXP / 2, FEAT, DENSE>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr, dl, &whole);  // qm_step1.hpp
         if constexpr (DENSE) qm_inv2_dense_flush(a.dense, dl, (tid - (threadIdx.x & 63u)) >> 1, whole);
-        if constexpr (LIST) done_mask_store_pairs(a.done_mask, a.B, fin, tid);
+        if constexpr (LIST) done_mask_store_pairs(a.done_mask, a.B, fin, tid, a.done_epoch + (uint32_t)clock_of(a.clock));
     } else {
         if ((tid >> 1) >= a.B) return;  // whole lane pairs leave together
         (void)qm_inv2_body<NXP / 2, FEAT, DENSE>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr, dl, &whole);  // qm_step1.hpp
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void qm_step1_kernel(StepArgs a) {
     if constexpr (LIST) {  // every thread reaches the wave's ballot
         bool fin = false;
         if (env < a.B) fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64));
-        done_mask_store(a.done_mask, a.B, fin, env);
+        done_mask_store(a.done_mask, a.B, fin, env, a.done_epoch + (uint32_t)clock_of(a.clock));
     } else {
         if (env >= a.B) return;
         const int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
@@ -812,11 +812,17 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
         // ... and, when the step before left its finishers as a mask (InitArgs::mask), this thread's share of the mask's words
         __shared__ uint32_t mask_part[257 + 5];
         DoneMaskShare share;
-        if (a.mask) done_mask_load(a.mask, a.B, a.mask_words, share);
+        uint32_t hint_v = 0;
+        if (a.mask) {
+            hint_v = done_mask_hint(a.mask, a.B)[opaque_zero];
+            done_mask_load(a.mask, a.B, a.mask_words, share);
+        }
         asm volatile("" ::: "memory");
         if (table_fits)
             for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) tree_table[i] = a.rowops[i];
-        const uint32_t mcount = a.mask ? done_mask_scan(share, mask_part) : 0u;  // (two barriers: the table is visible after them too)
+        // (the hint: no wave of the launch that wrote the mask had a finisher -- nothing to sum, no barriers; workgroup-uniform)
+        const bool mask_empty = !a.mask || (uint32_t)__builtin_amdgcn_readfirstlane((int)hint_v) != a.mask_epoch + (uint32_t)clock_of(a.clock);
+        const uint32_t mcount = mask_empty ? 0u : done_mask_scan(share, mask_part);  // (two barriers: the table is visible after them too)
         const uint32_t lcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)count_v);
         const uint32_t count_now = mcount + lcount;
         if (a.count_out && vblock == 0 && threadIdx.x == 0) *a.count_out = count_now;  // (host memory: sizes the next launches' tree grid)
@@ -978,7 +984,7 @@ __global__ __launch_bounds__(256) void qm_reset_step_kernel(ResetStepArgs ra) {
             const bool alone = D16 != 0 && ((resets >> ((env ^ 1ull) & 63u)) & 1ull);
             fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64), alone);
         }
-        done_mask_store(a.done_mask, a.B, fin, env);  // (an env being reset: bit clear -- if it is final again after its first step the reset's lane appends it to the list)
+        done_mask_store(a.done_mask, a.B, fin, env, a.done_epoch + (uint32_t)clock_of(a.clock));  // (an env being reset: bit clear -- if it is final again after its first step the reset's lane appends it to the list)
         return;
     }
     // (plain configuration: the tree's wave takes the env's first step on the rows it holds -- qm_init_finish_wave_step; otherwise the lane

@@ -283,10 +283,13 @@ void done_list_appended(qg_vec *v, bool trusted) {
     v->list_zero_known = false;
     v->mask_fresh = false;  // (the step launches that left their finishers as a mask say so themselves: step_wrote_mask)
 }
+// the number a mask-writing launch stamps its buffer's hint word with (never 0, the buffers' initial content)
+static uint32_t mask_epoch_of(const qg_vec *v) { return ((uint32_t)v->step_index & 0x7FFFFFFFu) + 1u; }
 // TILE: a list-leaving step writes the mask that is not the current one (and appends nothing: the list stays empty)
 static void step_wrote_mask(qg_vec *v, const StepArgs &a, bool trusted) {
     if (a.done_mask) {
         v->mask_cur ^= 1;
+        v->mask_epoch[v->mask_cur] = a.done_epoch;
         v->mask_fresh = trusted;
         v->list_zero_known = true;  // (nothing was appended: the length is still the zero done_list_before_append made sure of)
     }
@@ -560,7 +563,7 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     if (hp.has_done_list && v->layout == LAYOUT_TILE) {  // the finished envs of a step as one bit each (qm_step1 / qm_inv2 <LIST>)
         HIP_TRY_V(hipHostMalloc((void **)&p->count_seen, sizeof(uint32_t), hipHostMallocMapped));
         *p->count_seen = 0xFFFFFFFFu;
-        const size_t mask_bytes = 10 * 4 * ((batch + 255) / 256);  // device_common.hpp done_mask_bytes: a word per wave of the step grid (whole workgroups of 256 envs), then a count byte per 32 envs
+        const size_t mask_bytes = 10 * 4 * ((batch + 255) / 256) + 8;  // device_common.hpp done_mask_bytes: a word per wave of the step grid (whole workgroups of 256 envs), then a count byte per 32 envs
         for (auto &m : p->done_mask) {
             HIP_TRY_V(hipMalloc(&m, mask_bytes));
             HIP_TRY_V(hipMemset(m, 0, mask_bytes));
@@ -882,6 +885,7 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
         if (left_by_step && v->mask_fresh && v->done_mask[0]) {  // TILE: the step before left its finishers as bits (the list holds what the fused launch added, if anything)
             ia.mask = v->done_mask[v->mask_cur];
             ia.mask_words = (uint32_t)(4 * ((v->B + 255) / 256));
+            ia.mask_epoch = v->mask_epoch[v->mask_cur];
         }
         v->mask_fresh = false;
         ia.coop = plan::reset_coop_allowed(actions_dev != nullptr, v->B, v->d_rowops != nullptr) ? 1u : 0u;
@@ -996,7 +1000,10 @@ static bool step_leaves_done_list(const qg_vec *v, StepArgs &a) {
         a.flags |= F_DONE_LIST;
         a.done_list = v->done_list;
         a.done_count = v->done_list + v->B;
-        if (tile32) a.done_mask = v->done_mask[v->mask_cur ^ 1];  // one bit per env instead of an append (the list stays empty)
+        if (tile32) {  // one bit per env instead of an append (the list stays empty)
+            a.done_mask = v->done_mask[v->mask_cur ^ 1];
+            a.done_epoch = mask_epoch_of(v);
+        }
     }
     return lists;
 }
@@ -1131,6 +1138,7 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     ia.tree_grid = reset_tree_grid(v);
     ia.mask = v->done_mask[v->mask_cur];  // the finishers of the step before: the reset's work, and the step workgroups' "not mine" test
     ia.mask_words = (uint32_t)(4 * ((v->B + 255) / 256));
+    ia.mask_epoch = v->mask_epoch[v->mask_cur];
     ia.coop = 1u;
     ia.dense = v->dense;
     ia.depth_value = (int32_t)std::min<int64_t>((int64_t)v->cfg.depth_slope * v->difficulty, v->cfg.max_depth);  // clifford.rs:317
@@ -1145,6 +1153,7 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     a.done_list = v->done_list_alt;
     a.done_count = v->done_list_alt + v->B;
     a.done_mask = v->done_mask[v->mask_cur ^ 1];
+    a.done_epoch = mask_epoch_of(v);
     if (!v->alt_zero_known) HIP_TRY(hipMemsetAsync(v->done_list_alt + v->B, 0, 2 * sizeof(uint32_t), s));
     if (dense_rides_in_step(v)) a.dense = v->dense;
     a.kclk = kernel_clock_slot(v);
@@ -1155,6 +1164,7 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     std::swap(v->done_list, v->done_list_alt);   // (current, alt, spare) <- (alt, spare, current)
     std::swap(v->done_list_alt, v->done_list_spare);
     v->mask_cur ^= 1;
+    v->mask_epoch[v->mask_cur] = a.done_epoch;
     v->done_list_fresh = true;
     v->mask_fresh = true;
     v->list_zero_known = false;

@@ -129,6 +129,7 @@ struct qg_vec {
     // launch, which reads the current one) writes the other one, then they trade places.  Nothing to zero: a launch rewrites every word.
     uint64_t *done_mask[2] = {nullptr, nullptr};
     int mask_cur = 0;
+    uint32_t mask_epoch[2] = {0, 0};    // StepArgs::done_epoch of the launch that wrote each buffer (InitArgs::mask_epoch for its reader)
     bool mask_fresh = false;            // done_mask[mask_cur] (+ the list in done_list: envs reset and final again inside the fused launch; else empty) holds
                                         // the envs that are final, as the handle's own last step left them (believed within the session, like done_list_fresh)
     bool alt_zero_known = true;         // done_list_alt's length is known to be zero

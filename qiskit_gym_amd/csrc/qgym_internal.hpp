@@ -117,6 +117,7 @@ struct StepArgs {
                               // rewrite the rows their gate changed (read by those instantiations only)
     uint64_t *done_mask;      // F_DONE_LIST, TILE: word w = is_final of envs 64 w .. 64 w + 63 after this step, every word rewritten by the launch (no
                               // counter, nothing to zero: device_common.hpp done_mask_store); read by the next reset's workgroups (InitArgs::mask)
+    uint32_t done_epoch;      // ... and a wave with a finisher stores this launch's number (+ the device clock) to the buffer's hint word: "not empty"
 };
 
 // The argument block spans four 64-byte lines and the scalar cache is cold at every launch.  Left alone, the compiler fetches a field
@@ -170,6 +171,7 @@ struct InitArgs {
     uint32_t *bad;             // see StepArgs::bad
     const uint64_t *mask;      // reset_done, TILE: the finished envs as the bits a step launch left (StepArgs::done_mask), mask_words words; the envs to
     uint32_t mask_words;       // reset are the set bits in ascending order FOLLOWED by the list's entries (null: the list alone)
+    uint32_t mask_epoch;       // StepArgs::done_epoch of the launch that wrote `mask`: a hint word that differs says "no bit is set" without a count
     const uint32_t *list;      // reset_done, compacted: thread i resets env list[i], i < *list_count (or null: thread = env)
     uint32_t *list_count;      // [2]: length, reader ticket (device_common.hpp list_count_take)
     uint32_t tree_grid;        // workgroups of this launch that walk a list as trees (plan::tree_grid), entry i on workgroup i mod tree_grid

@@ -50,16 +50,18 @@ def run(name, env, A, slots_per_pair, labels, fused, out, reset_slots=1):
                     env.rollout(acts[t:t + 1], dones_out=fin[t:t + 1])
             env.reset_done(seed + 0x9E3779B9 * AT)
 
-        def graph():
+        def graph(n_slots=0):
+            """Eager pass, then the capture; n_slots > 0: the captured launches (and only they) carry kernel-clock slots 0, 1, ..."""
             episode()
             torch.cuda.synchronize()
+            slots = env.kernel_clock(n_slots) if n_slots else None
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=stream):
                 episode()
             torch.cuda.synchronize()
             g.replay()
             torch.cuda.synchronize()
-            return g
+            return (g, slots) if n_slots else g
 
         def period(g):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -74,10 +76,8 @@ def run(name, env, A, slots_per_pair, labels, fused, out, reset_slots=1):
         plain = min(period(g) for _ in range(3))
         del g
         n_slots = 1 + slots_per_pair * (AT - 1) + reset_slots  # the first step, AT - 1 pairs, the last reset_done
-        slots = env.kernel_clock(2 * n_slots)
-        g = graph()  # the eager pass takes the first n_slots, the captured launches the rest
+        g, view = graph(n_slots + 8)
         stamped = min(period(g) for _ in range(3))
-        view = slots[n_slots:]
         per = [[] for _ in range(slots_per_pair)]
         for _ in range(4):
             view.zero_()
@@ -89,6 +89,7 @@ def run(name, env, A, slots_per_pair, labels, fused, out, reset_slots=1):
             first = torch.where(live, t0, torch.full_like(t0, 2**62)).amin(dim=1)
             dur = ((t1.amax(dim=1) - first).double() / 100.0).cpu().numpy()  # 100 MHz -> us
             ok = live.any(dim=1).cpu().numpy()
+            assert int(ok.sum()) == n_slots and ok[:n_slots].all(), (name, int(ok.sum()), n_slots)  # the capture's launches are what this tool thinks they are
             for j in range(slots_per_pair):
                 idx = 1 + j + slots_per_pair * np.arange(3, AT - 1)  # pair t's j-th launch (the first pairs of a capture take other paths: skipped)
                 per[j].append(dur[idx][ok[idx]])

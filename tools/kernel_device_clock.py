@@ -46,11 +46,13 @@ def measure(name, env, body, stream, replays, bytes_8d, kernel, prof, before=Non
     (a reset that empties the solution log).  Returns the row."""
     before = before or (lambda: None)
 
-    def graph_of():
+    def graph_of(stamped=False):
+        """Eager pass, then the capture; `stamped`: the captured launches (and only they) carry kernel-clock slots 0 .. T-1."""
         with torch.cuda.stream(stream):
             before()
             body()
             torch.cuda.synchronize()
+            slots = env.kernel_clock(T) if stamped else None  # (armed here: the eager pass and before() take no slot)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=stream):
                 body()
@@ -58,7 +60,7 @@ def measure(name, env, body, stream, replays, bytes_8d, kernel, prof, before=Non
             before()
             g.replay()
             torch.cuda.synchronize()
-        return g
+        return (g, slots) if stamped else g
 
     def period(g, n=4):
         with torch.cuda.stream(stream):
@@ -74,8 +76,7 @@ def measure(name, env, body, stream, replays, bytes_8d, kernel, prof, before=Non
     g_plain = graph_of()
     period_plain = min(period(g_plain) for _ in range(3))
     del g_plain
-    slots = env.kernel_clock(2 * T)[T:]  # (graph_of's eager pass takes the first T slots) ...
-    g = graph_of()  # ... and every captured launch carries its own slot
+    g, slots = graph_of(stamped=True)  # every captured launch carries its own slot
     period_stamped = min(period(g) for _ in range(3))
     durs = []
     for _ in range(replays):

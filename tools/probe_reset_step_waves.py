@@ -32,8 +32,8 @@ for spread in (True, False):
             env.reset_done(seed + 13 * AT)
 
         n_slots = 1 + AT + 2
-        slots = env.kernel_clock(2 * n_slots)
         episode(); torch.cuda.synchronize()
+        slots = env.kernel_clock(n_slots)  # (armed here: the captured launches take slots 0, 1, ...)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=stream):
             episode()
