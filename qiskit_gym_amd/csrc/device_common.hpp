@@ -103,7 +103,7 @@ __device__ inline void done_list_append_block(uint32_t *list, uint32_t *count, b
 // what the reader sums, an eighth of the words' bytes.  Call from every lane of every wave of a thread-per-env grid (`fin` false past the batch's end).
 // Layout of a mask buffer for a batch of B: W = 4 * ceil(B / 256) words, then 2 W count bytes, then the hint word: a wave WITH a finisher stores the
 // launch's number there (plain stores of one value: no read-modify-write), so a reader that finds another number knows every count is zero and leaves
-// without summing them (a stale equal number -- a replayed graph without a device clock -- only costs the sum).
+// without summing them (a stale equal number -- the same launch of a replayed graph's previous replay -- only costs the sum).
 __host__ __device__ inline uint64_t done_mask_words(uint64_t B) { return 4ull * ((B + 255ull) / 256ull); }
 __host__ __device__ inline uint64_t done_mask_bytes(uint64_t B) { return done_mask_words(B) * 10ull + 8ull; }
 __device__ inline uint32_t *done_mask_hint(uint64_t *mask, uint64_t B) { return reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(mask) + done_mask_words(B) * 10ull); }

@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void qm_inv2_kernel(StepArgs a) {
         bool fin = false;
         if ((tid >> 1) < a.B) fin = qm_inv2_body<NXP / 2, FEAT, DENSE>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr, dl, &whole);  // qm_step1.hpp
         if constexpr (DENSE) qm_inv2_dense_flush(a.dense, dl, (tid - (threadIdx.x & 63u)) >> 1, whole);
-        if constexpr (LIST) done_mask_store_pairs(a.done_mask, a.B, fin, tid, a.done_epoch + (uint32_t)clock_of(a.clock));
+        if constexpr (LIST) done_mask_store_pairs(a.done_mask, a.B, fin, tid, a.done_epoch);
     } else {
         if ((tid >> 1) >= a.B) return;  // whole lane pairs leave together
         (void)qm_inv2_body<NXP / 2, FEAT, DENSE>(a, NXP / 2, tid >> 1, (uint32_t)tid & 1u, nullptr, dl, &whole);  // qm_step1.hpp
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void qm_step1_kernel(StepArgs a) {
     if constexpr (LIST) {  // every thread reaches the wave's ballot
         bool fin = false;
         if (env < a.B) fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64));
-        done_mask_store(a.done_mask, a.B, fin, env, a.done_epoch + (uint32_t)clock_of(a.clock));
+        done_mask_store(a.done_mask, a.B, fin, env, a.done_epoch);
     } else {
         if (env >= a.B) return;
         const int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
@@ -821,7 +821,7 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
         if (table_fits)
             for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) tree_table[i] = a.rowops[i];
         // (the hint: no wave of the launch that wrote the mask had a finisher -- nothing to sum, no barriers; workgroup-uniform)
-        const bool mask_empty = !a.mask || (uint32_t)__builtin_amdgcn_readfirstlane((int)hint_v) != a.mask_epoch + (uint32_t)clock_of(a.clock);
+        const bool mask_empty = !a.mask || (uint32_t)__builtin_amdgcn_readfirstlane((int)hint_v) != a.mask_epoch;
         const uint32_t mcount = mask_empty ? 0u : done_mask_scan(share, mask_part);  // (two barriers: the table is visible after them too)
         const uint32_t lcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)count_v);
         const uint32_t count_now = mcount + lcount;
@@ -984,7 +984,7 @@ __global__ __launch_bounds__(256) void qm_reset_step_kernel(ResetStepArgs ra) {
             const bool alone = D16 != 0 && ((resets >> ((env ^ 1ull) & 63u)) & 1ull);
             fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64), alone);
         }
-        done_mask_store(a.done_mask, a.B, fin, env, a.done_epoch + (uint32_t)clock_of(a.clock));  // (an env being reset: bit clear -- if it is final again after its first step the reset's lane appends it to the list)
+        done_mask_store(a.done_mask, a.B, fin, env, a.done_epoch);  // (an env being reset: bit clear -- if it is final again after its first step the reset's lane appends it to the list)
         return;
     }
     // (plain configuration: the tree's wave takes the env's first step on the rows it holds -- qm_init_finish_wave_step; otherwise the lane

@@ -117,7 +117,8 @@ struct StepArgs {
                               // rewrite the rows their gate changed (read by those instantiations only)
     uint64_t *done_mask;      // F_DONE_LIST, TILE: word w = is_final of envs 64 w .. 64 w + 63 after this step, every word rewritten by the launch (no
                               // counter, nothing to zero: device_common.hpp done_mask_store); read by the next reset's workgroups (InitArgs::mask)
-    uint32_t done_epoch;      // ... and a wave with a finisher stores this launch's number (+ the device clock) to the buffer's hint word: "not empty"
+    uint32_t done_epoch;      // ... and a wave with a finisher stores this launch's number to the buffer's hint word: "not empty" (no device clock in it: the
+                              // clock may advance between the step that writes and the reset that reads)
 };
 
 // The argument block spans four 64-byte lines and the scalar cache is cold at every launch.  Left alone, the compiler fetches a field
