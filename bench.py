@@ -363,12 +363,14 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.ranks_share_gpu0:
-        if args.handover != "direct":
-            ap.error("--ranks-share-gpu0 needs --handover direct")
-        local_rank = 0
-    if local_rank >= torch.cuda.device_count():
-        print(f"bench.py: rank {rank} has LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
+    if args.ranks_share_gpu0 and args.handover != "direct":
+        ap.error("--ranks-share-gpu0 needs --handover direct")
+    from qiskit_gym_amd.distributed import device_for_rank
+
+    try:  # GPU LOCAL_RANK (or GPU 0 for every rank of a rehearsal on a one-GPU box): tests/test_distributed_cpu.py
+        local_rank = device_for_rank(local_rank, int(world_env or 1), torch.cuda.device_count(), args.ranks_share_gpu0)
+    except RuntimeError as exc:
+        print(f"bench.py: rank {rank}: {exc}", file=sys.stderr)
         sys.exit(2)
     dist = None
     comm = None

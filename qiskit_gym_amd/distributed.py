@@ -23,6 +23,18 @@ def shard_range(total_envs: int, rank: int, world: int) -> Tuple[int, int]:
     return start, count
 
 
+def device_for_rank(local_rank: int, world: int, visible: int, share_gpu0: bool = False) -> int:
+    """The GPU a rank uses: its LOCAL_RANK (one process per GPU, whatever the node shows beyond that), or GPU 0 for every rank of a functional
+    rehearsal on a one-GPU box (`share_gpu0`).  Raises when that GPU is not visible -- never falls back to another one."""
+    if visible < 1:
+        raise RuntimeError("no GPU is visible")
+    if share_gpu0:
+        return 0
+    if not 0 <= local_rank < visible:
+        raise RuntimeError(f"LOCAL_RANK {local_rank} of a {world}-rank job, but only {visible} GPU(s) are visible")
+    return local_rank
+
+
 def local_actions(global_actions: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     """Slice of a `[..., total_envs]` action tensor that belongs to `rank`."""
     start, count = shard_range(global_actions.shape[-1], rank, world)

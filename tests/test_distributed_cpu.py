@@ -165,7 +165,7 @@ def _guarded_worker(rank, world, port, scenario, result_q):
         reached.append("exchange")
 
     def open_():
-        if scenario == "open_fails" and rank == 1:
+        if scenario == "open_fails" and rank == (5 if world == 8 else 1):
             raise RuntimeError("injected: hipIpcOpenMemHandle failed")
         if scenario == "rank_dies" and rank == 1:
             os._exit(0)  # no vote, no goodbye
@@ -212,6 +212,43 @@ def test_a_failed_phase_on_one_rank_stops_every_rank_at_the_same_phase():
         assert err["failed_on_this_rank"] == (rank == 1)
         assert elapsed < 5.0, "a rank waited for a peer that had already failed"
     assert "injected" in out[1][0]["error"] and "peer rank failed" in out[0][0]["error"]
+
+
+def test_world_of_eight_with_rank_five_failing_stops_all_eight_at_the_same_phase():
+    """Config 4's shape (8 ranks, one per GPU) on the control plane alone: every rank exchanges its handle with the seven others, rank 5 cannot map
+    its peers -- all eight stop after that phase, within seconds, with the control plane still usable for the final barrier."""
+    out = _run_guarded("open_fails", world=8)
+    assert sorted(out) == list(range(8))
+    for rank in range(8):
+        err, reached, elapsed, usable = out[rank]
+        assert err is not None and err["phase"] == "p2p_open" and "timed" not in reached and usable, rank
+        assert reached[:2] == ["export", "exchange"] and err["failed_on_this_rank"] == (rank == 5)
+        assert elapsed < 10.0, "a rank waited for a peer that had already failed"
+    assert "injected" in out[5][0]["error"] and all("peer rank failed" in out[r][0]["error"] for r in range(8) if r != 5)
+
+
+def test_world_of_eight_passes_every_phase_when_nothing_fails():
+    out = _run_guarded("ok", world=8)
+    for rank in range(8):
+        err, reached, elapsed, usable = out[rank]
+        assert err is None and reached == ["export", "exchange", "open", "timed"], rank
+
+
+def test_ranks_take_the_gpu_of_their_local_rank():
+    """bench.py / the driver's launcher: rank r of an N-rank job on a node that shows V GPUs uses GPU LOCAL_RANK -- N = 2 and N = 4 on an 8-GPU node
+    take GPUs 0..N-1, never "whatever is current"; fewer visible GPUs than ranks is an error unless every rank is told to share GPU 0 (a
+    functional rehearsal on a one-GPU box)."""
+    from qiskit_gym_amd.distributed import device_for_rank
+
+    for world in (1, 2, 4, 8):
+        assert [device_for_rank(r, world, visible=8) for r in range(world)] == list(range(world))
+    assert [device_for_rank(r, 8, visible=1, share_gpu0=True) for r in range(8)] == [0] * 8
+    for local_rank, world, visible in ((1, 2, 1), (4, 8, 4), (7, 8, 7)):
+        with pytest.raises(RuntimeError, match="visible"):
+            device_for_rank(local_rank, world, visible)
+    with pytest.raises(RuntimeError, match="visible"):
+        device_for_rank(0, 1, visible=0)
+    assert device_for_rank(3, 8, visible=4) == 3  # (a launcher that gave this process LOCAL_RANK 3 on a 4-GPU node: its business)
 
 
 def test_all_phases_pass_when_nothing_fails():

@@ -190,6 +190,29 @@ def test_bench_as_a_two_rank_job_on_one_gpu_with_the_direct_write_handover():
     assert line["value"] > 1e7 and line["scaling"] == "weak"  # (two processes share one GPU: a functional run, its rate means nothing)
 
 
+def test_bench_as_a_five_rank_job_on_one_gpu_every_window_offset_and_flag():
+    """The most ranks this pool lets a test put on one GPU (six processes may use it at once: five ranks and this test runner): bench.py --gpus 5,
+    every rank on GPU 0, 8 192 envs each, the learner shard handed over by the direct write -- five windows of 2 parities x 5 slots, five
+    arrival flags per header, every peer offset in use, an odd world size -- inside the timed region; rank 0 replays its own part and rank 4's
+    part of what arrived on the oracle, every env.  (Config 4's world of 8 needs 8 GPUs: tests/test_distributed_cpu.py runs its control plane
+    with 8 ranks, profiles/r05/bench_six_ranks_one_gpu_direct.json is the standalone 6-rank run.)"""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--handover", "direct", "--ranks-share-gpu0", "--envs", "8192",
+                          "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-large-batch", "--no-default-config", "--no-configs", "--no-collector",
+                          "--no-dense-obs"], capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    cfg = line["config"]
+    assert line["ranks"] == 5 and cfg["ranks_seen"] == 5 and cfg["total_envs"] == 5 * 8192 and cfg["env_ids_of_rank0"] == [0, 8192]
+    assert line["n_gpus"] == 1 and line["physical_gpus"] == 1 and line["ranks_share_gpu0"]
+    assert cfg["collective"]["handover"] == "direct" and cfg["collective"]["collectives_in_timed_region"] >= 1
+    par = line["parity"]
+    assert par["bit_exact"] and par["envs"] == 8192 and par["gathered_shard"]["bit_exact"]
+    assert par["gathered_shard_of_last_rank"]["bit_exact"] and par["gathered_shard_of_last_rank"]["envs"] == 8192
+
+
 def test_bench_two_ranks_with_one_rank_unable_to_map_its_peer_fails_fast_on_every_rank():
     """--handover direct with rank 1's hipIpcOpenMemHandle failing (injected): the vote after the phase stops BOTH ranks there -- the run ends
     within seconds with a non-zero exit code instead of one rank waiting in a barrier for the control plane's timeout."""
