@@ -191,11 +191,12 @@ def test_bench_as_a_two_rank_job_on_one_gpu_with_the_direct_write_handover():
 
 
 def test_bench_as_a_five_rank_job_on_one_gpu_every_window_offset_and_flag():
-    """The most ranks this pool lets a test put on one GPU (six processes may use it at once: five ranks and this test runner): bench.py --gpus 5,
+    """The most ranks this pool lets anybody put on one GPU (six processes may have it open at once: five ranks and whoever started them -- this test
+    runner, or bench.py's own launcher; a six-rank run is killed by the pool's process guard): bench.py --gpus 5,
     every rank on GPU 0, 8 192 envs each, the learner shard handed over by the direct write -- five windows of 2 parities x 5 slots, five
     arrival flags per header, every peer offset in use, an odd world size -- inside the timed region; rank 0 replays its own part and rank 4's
     part of what arrived on the oracle, every env.  (Config 4's world of 8 needs 8 GPUs: tests/test_distributed_cpu.py runs its control plane
-    with 8 ranks, profiles/r05/bench_six_ranks_one_gpu_direct.json is the standalone 6-rank run.)"""
+    with 8 ranks, profiles/r05/bench_five_ranks_one_gpu_direct.json is the same job run standalone.)"""
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
