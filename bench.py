@@ -1261,6 +1261,28 @@ def main():
             "large_batch": large,
             "policy_in_loop": collector,
         }
+
+        def r2(x):
+            return None if x is None else round(float(x), 2)
+
+        # the figures of the legs above once more, compact and LAST in the line: whoever keeps only the line's tail still has them
+        out["summary"] = {
+            "us_per_step": r2(elapsed * 1e6 / K), "launch_period_us": r2(timed_region_us), "kernel_us_device_clock": r2(device_clock_us),
+            "roofline_frac": round(achieved / HBM_PEAK_GBS, 3), "parity_envs": parity["envs"] if parity else None,
+            "cpu_env_steps_per_s": cpu["value"] if cpu else None, "cpu_cores": cpu["cores"] if cpu else None,
+            "default_config_us": r2(default_cfg["us_per_step"]) if default_cfg else None,
+            "auto_reset_us_per_pair": None if not auto_reset else {
+                "C3": r2(auto_reset["us_per_step"]), "C3_synchronised": r2(auto_reset["synchronised"]["us_per_step"]),
+                "C3_reference_defaults": r2(auto_reset["reference_defaults"]["us_per_step"]), "C2": r2(auto_reset["C2"]["us_per_step"]),
+                "C2_x65536": r2(auto_reset["C2_x65536"]["us_per_step"]), "C2_reference_defaults": r2(auto_reset["C2_reference_defaults"]["us_per_step"]),
+                "C5": r2(auto_reset["C5"]["us_per_step"]), "pauli_reset_done_1pct_eager": r2(auto_reset["pauli_reset_done"]["us_per_call"])},
+            "observation_us_per_step": None if not obs_modes else {k: r2(obs_modes[k]["us_per_step"]) for k in ("packed", "dense", "dense_tracked", "dense_tracked_reference_defaults")},
+            "dense_rewrite_kernel_frac": round(obs_modes["dense_kernel"]["roofline"]["frac"], 3) if obs_modes else None,
+            "configs_us_per_step": None if not configs else {k: r2(configs[k]["us_per_step"]) for k in ("C2", "C5", "C3d")},
+            "large_batch": None if not large else {str(b["envs"]): {"us": r2(b["launch_us"]), "frac": round(b["frac"], 3)} for b in large["by_batch"]},
+            "fused_rollout_env_steps_per_s": fused["value"] if fused else None,
+            "policy_in_loop_us_per_step": None if not collector else {str(b["envs"]): r2(b["us_per_step"]) for b in collector["by_batch"]},
+        }
     else:
         out = None
 
