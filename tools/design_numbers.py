@@ -60,11 +60,12 @@ for key, (tkey, label) in names.items():
 
     fr = [frac(algo), frac(moved), frac(needed)]
     note = ""
-    if any(x is not None and x > 1 for x in fr):
-        note = " (above 1: the working set is absorbed by the 256 MiB Infinity Cache, these are not HBM bytes)"
+    if any(x is not None and x > 1 for x in fr):  # more bytes per second than HBM delivers: no fraction of its peak is quoted
+        note = " (cache: the launch's working set is absorbed by the 256 MiB Infinity Cache -- or 8d counts bytes the kernel does not move)"
+        fr = [None if x is None or x > 1 else x for x in fr]
     out.append(f"| {label} (`{c['kernel']}`) | {envs} | **{f(us)}** ({f(d['median'])}, {f(d['p90'])}) | {f(c['launch_period_us'])} | {f(c['launch_boundary_us'])} | "
                f"{f(c.get('rocprof_committed_avg_us'))} | " + (f"{f(moved, 1)} ({f(e['fetch_per_env'], 1)} + {f(e['write_per_env'], 1)})" if e else "–") +
-               f" | {needed or '–'} | {algo} | {algo * envs / (us * 1e-6) / 1e9:.0f} · " + " / ".join("–" if x is None else f"{x:.3f}" for x in fr) + note + " |")
+               f" | {needed or '–'} | {algo} | {algo * envs / (us * 1e-6) / 1e9:.0f} · " + " / ".join("cache" if (x is None and note) else "–" if x is None else f"{x:.3f}" for x in fr) + note + " |")
 out.append("")
 for label, d in (("driver's arguments (`--gpus 1 --steps 20 --warmup 5`)", drv), ("defaults (K = 2048, W = 128)", dflt)):
     if not d:
