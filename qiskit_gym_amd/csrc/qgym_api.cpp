@@ -222,7 +222,7 @@ int qg_gate_parse(const char *name_in, const int64_t *idx, size_t n, qg_gate *ou
 
 static int vec_free_buffers(qg_vec *v) {
     void *ptrs[] = {v->state, v->own_depth ? v->depth : nullptr, v->own_reward ? v->reward : nullptr,
-                    v->own_done ? v->done : nullptr, v->own_success ? v->success : nullptr, v->inverted, v->error, v->sol,
+                    v->own_done ? v->done : nullptr, v->own_success ? v->success : nullptr, v->inverted, v->own_error ? v->error : nullptr, v->sol,
                     v->sol_len, v->layers, v->d_gates, v->d_descs, v->scratch, v->d_prog,
                     v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad, v->done_list, v->done_list_alt, v->done_list_spare, v->done_mask[0], v->done_mask[1], v->d_rowops, v->embed_dump, v->host_in, v->host_obs, v->fault_scratch};
     for (void *p : ptrs)
@@ -1546,6 +1546,17 @@ int qg_vec_solutions(qg_vec *v, uint64_t *out, size_t cap, int64_t *lens) {
 
 namespace qg {
 void fill_step_args_public(const qg_vec *v, StepArgs &a) { fill_step_args(v, a); }
+int bind_error(qg_vec *v, uint32_t *error_dev) {
+    if (!v || !error_dev) return set_error(QG_ERR_INVALID, "null argument");
+    QG_ON_DEVICE(v);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(error_dev, v->error, sizeof(uint32_t) * v->B, hipMemcpyDefault));
+    if (v->own_error) (void)hipFree(v->error);
+    v->error = error_dev;
+    v->own_error = false;
+    drop_graphs(v);
+    return QG_OK;
+}
 unsigned long long *kernel_clock_slot_public(const qg_vec *v) { return kernel_clock_slot(v); }
 int dense_refresh_public(qg_vec *v, hipStream_t s) { return dense_refresh(v, s); }
 // InitArgs of qg_vec_reset_done(v, seed) without a list: what a kernel that resets finished envs itself needs (qg_vec_mid_head_sample_step)

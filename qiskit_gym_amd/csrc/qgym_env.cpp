@@ -180,6 +180,8 @@ struct qg_env {
     bool obs_ahead = false;  // observe() is a pure function of the state (every env but PauliEnv with add_perms, whose observe() draws a
                              // permutation per call, pauli.rs:653-665): the call that changes the state writes the next observation too
     bool obs_valid = false;  // the pinned buffer holds the observation of the current state
+    bool tracked = false;    // qg_vec_track_dense on the pinned buffer: every call that changes the state keeps it current itself (the step kernel
+                             // rewrites the rows its gate changed, over PCIe) -- no observe launch per step
     bool twists_done = false;
     std::vector<Perm> obs_perms, act_perms;
 };
@@ -213,11 +215,13 @@ void env_free(qg_env *e) {
 // observe() / step() pair costs one stream synchronisation, not two.
 int env_sync(qg_env *e) {
     e->obs_valid = false;
-    if (e->obs_ahead) {
+    if (e->tracked) {
+        e->obs_valid = true;
+    } else if (e->obs_ahead) {
         if (int rc = qg_vec_observe_dense(e->v, e->obs_dev, e->st)) return rc;
         e->obs_valid = true;
     }
-    HIP_TRY(hipMemcpyAsync(&e->io->error, e->v->error, sizeof(uint32_t), hipMemcpyDeviceToHost, e->st));
+    // (the fault word lives in the I/O block: the kernels write it there, nothing to copy)
     HIP_TRY(hipStreamSynchronize(e->st));
     const uint32_t err = e->io->error;
     if (err) {
@@ -274,6 +278,17 @@ int qg_env_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, in
     // (the remaining depth stays in device memory: the step kernel reads and writes it, the trait has no getter for it)
     rc = qg_vec_bind_outputs(v, &e->io_dev->reward, &e->io_dev->done, &e->io_dev->success, nullptr);
     if (rc) return fail(rc);
+    if ((rc = qg::bind_error(v, &e->io_dev->error))) return fail(rc);
+    // a step of the scalar env was two launches, a 4-byte copy and a stream synchronisation; where the layout can keep a resident dense
+    // observation (16- / 32-row matrices) the step kernel rewrites the pinned observation's changed rows itself: one launch and the synchronisation
+    if (e->obs_ahead && qg_vec_track_dense(v, e->obs_dev, e->st) == QG_OK) {
+        e->tracked = true;
+        e->obs_valid = true;
+        if (hipStreamSynchronize(e->st) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(set_error(QG_ERR_DEVICE, "scalar env: first observation failed"));
+        }
+    }
     *out = e;
     return QG_OK;
 }
@@ -335,7 +350,7 @@ int qg_env_clone(const qg_env *e, qg_env **out) {  // Env: DynClone -- deep copy
     d->perm_draw = false;
     d->perm_in = nullptr;
     d->clock_dev = s->clock_dev;
-    d->dense = nullptr;
+    d->dense = c->tracked ? c->obs_dev : nullptr;  // (the clone's own pinned observation, made current below)
     for (auto &g : d->graphs) {  // cached rollout graphs have the previous owner's pointers and counters baked in
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         if (g.graph) (void)hipGraphDestroy(g.graph);
@@ -345,7 +360,6 @@ int qg_env_clone(const qg_env *e, qg_env **out) {  // Env: DynClone -- deep copy
         {d->state, s->state, s->state_bytes},
         {d->depth, s->depth, 4},
         {d->inverted, s->inverted, 1},
-        {d->error, s->error, 4},
         {d->sol_len, s->sol_len, 8},
         {d->sol, s->sol, (size_t)s->sol_cap * 4},
         {d->layers, s->layers, (size_t)s->layers_len * 4 * 64},  // the env's tile (layer_rec)
@@ -366,6 +380,12 @@ int qg_env_clone(const qg_env *e, qg_env **out) {  // Env: DynClone -- deep copy
     c->obs_valid = false;
     if (c->obs_ahead && e->obs_valid) {  // the source's observation is the clone's
         memcpy(c->obs, e->obs, e->obs_bytes);
+        c->obs_valid = true;
+    } else if (c->tracked) {  // (a source nobody has observed: rewrite the clone's tracked observation from the copied state)
+        if (qg::dense_refresh_public(d, c->st) != QG_OK) {
+            env_free(c);
+            return set_error(QG_ERR_DEVICE, "clone: observation refresh failed");
+        }
         c->obs_valid = true;
     }
     c->twists_done = false;

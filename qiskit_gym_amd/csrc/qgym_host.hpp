@@ -143,6 +143,7 @@ struct qg_vec {
     void *embed_dump = nullptr;         // qg_vec_embed: 1 KiB nobody reads (kernels_policy.hip), allocated by qg_vec_pack_embedding
     bool maybe_nonsymplectic = false;   // CliffordEnv + add_inverts: some env may need the Gauss-Jordan inversion
     bool own_reward = true, own_done = true, own_success = true, own_depth = true;
+    bool own_error = true;  // (the scalar env keeps its one fault word in its pinned I/O block: qg::bind_error)
 
     // PauliEnv (pauli_host.cpp, kernels_pauli_tile.hip)
     void *d_prog = nullptr;  // [num_actions] per-action programs (tableau map + micro-ops)
@@ -171,6 +172,8 @@ bool done_list_session(qg_vec *v, hipStream_t s);
 int done_list_before_append(qg_vec *v, hipStream_t s);
 void done_list_appended(qg_vec *v, bool trusted);
 void fill_step_args_public(const qg_vec *v, StepArgs &a);
+// the per-env fault words in caller-owned memory (device-visible, [B] uint32, current content carried over); not part of the C ABI: the scalar env's
+int bind_error(qg_vec *v, uint32_t *error_dev);
 unsigned long long *kernel_clock_slot_public(const qg_vec *v);  // qg_vec_set_kernel_clock: the slot of the launch about to be enqueued, or null
 // qg_vec_track_dense: rewrite the whole tracked observation from the state (after a launch that changed states without updating it)
 int dense_refresh_public(qg_vec *v, hipStream_t s);
