@@ -99,34 +99,26 @@ __device__ inline void done_list_append_block(uint32_t *list, uint32_t *count, b
 }
 
 // The finished envs of a step as one bit each (StepArgs::done_mask): the wave's ballot, one 8-byte store per wave -- no counter, no atomics, nothing
-// to zero (every launch rewrites every word) -- and, behind the words, a 16-bit DIGEST per 32 envs: how many bits are set there (6 bits) and where the
-// first two are (5 bits each).  The reader sums the digests (a quarter of the words' bytes) and, while few envs finish per step, also finds its entry in
-// them -- no second trip to memory for the mask word.  Call from every lane of every wave of a thread-per-env grid (`fin` false past the batch's end).
-// Layout of a mask buffer for a batch of B: W = 4 * ceil(B / 256) words, then 2 W digests, then the hint word: a wave WITH a finisher stores the
+// to zero (every launch rewrites every word) -- and, behind the words, one byte per 32 envs with the number of bits set there (`done_mask_counts`):
+// what the reader sums, an eighth of the words' bytes.  Call from every lane of every wave of a thread-per-env grid (`fin` false past the batch's end).
+// Layout of a mask buffer for a batch of B: W = 4 * ceil(B / 256) words, then 2 W count bytes, then the hint word: a wave WITH a finisher stores the
 // launch's number there (plain stores of one value: no read-modify-write), so a reader that finds another number knows every count is zero and leaves
 // without summing them (a stale equal number -- the same launch of a replayed graph's previous replay -- only costs the sum).
 __host__ __device__ inline uint64_t done_mask_words(uint64_t B) { return 4ull * ((B + 255ull) / 256ull); }
-__host__ __device__ inline uint64_t done_mask_bytes(uint64_t B) { return done_mask_words(B) * 12ull + 8ull; }
-__device__ inline uint16_t *done_mask_digests(uint64_t *mask, uint64_t B) { return reinterpret_cast<uint16_t *>(mask + done_mask_words(B)); }
-__device__ inline const uint16_t *done_mask_digests(const uint64_t *mask, uint64_t B) { return reinterpret_cast<const uint16_t *>(mask + done_mask_words(B)); }
-__device__ inline uint32_t *done_mask_hint(uint64_t *mask, uint64_t B) { return reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(mask) + done_mask_words(B) * 12ull); }
+__host__ __device__ inline uint64_t done_mask_bytes(uint64_t B) { return done_mask_words(B) * 10ull + 8ull; }
+__device__ inline uint32_t *done_mask_hint(uint64_t *mask, uint64_t B) { return reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(mask) + done_mask_words(B) * 10ull); }
 __device__ inline const uint32_t *done_mask_hint(const uint64_t *mask, uint64_t B) { return done_mask_hint(const_cast<uint64_t *>(mask), B); }
-__device__ inline uint32_t done_mask_digest(uint32_t half) {  // of 32 envs' bits
-    const uint32_t n = (uint32_t)__popc(half);
-    const uint32_t l0 = half ? (uint32_t)__ffs((int)half) - 1u : 0u;
-    const uint32_t rest = half & (half - 1u);
-    const uint32_t l1 = rest ? (uint32_t)__ffs((int)rest) - 1u : 0u;
-    return n | (l0 << 6) | (l1 << 11);
-}
+__device__ inline uint8_t *done_mask_counts(uint64_t *mask, uint64_t B) { return reinterpret_cast<uint8_t *>(mask + done_mask_words(B)); }
+__device__ inline const uint8_t *done_mask_counts(const uint64_t *mask, uint64_t B) { return reinterpret_cast<const uint8_t *>(mask + done_mask_words(B)); }
 __device__ inline void done_mask_store(uint64_t *mask, uint64_t B, bool fin, uint64_t env, uint32_t epoch) {
     const uint64_t m = __ballot(fin);
     if (__lane_id() == 0) {
         if (m) *done_mask_hint(mask, B) = epoch;
         mask[env >> 6] = m;
-        reinterpret_cast<uint32_t *>(done_mask_digests(mask, B))[env >> 6] = done_mask_digest((uint32_t)m) | (done_mask_digest((uint32_t)(m >> 32)) << 16);
+        reinterpret_cast<uint16_t *>(done_mask_counts(mask, B))[env >> 6] = (uint16_t)((uint32_t)__popc((uint32_t)m) | ((uint32_t)__popc((uint32_t)(m >> 32)) << 8));
     }
 }
-// ... of a two-lanes-per-env grid (`tid` = 2 env + half; `fin` on the even lane): a wave holds 32 envs, half a word and one digest
+// ... of a two-lanes-per-env grid (`tid` = 2 env + half; `fin` on the even lane): a wave holds 32 envs, half a word and one count byte
 __device__ inline void done_mask_store_pairs(uint64_t *mask, uint64_t B, bool fin, uint64_t tid, uint32_t epoch) {
     uint64_t m = __ballot(fin && !(tid & 1ull));  // bit 2k: env k of the wave
     m = (m | (m >> 1)) & 0x3333333333333333ull;
@@ -137,38 +129,38 @@ __device__ inline void done_mask_store_pairs(uint64_t *mask, uint64_t B, bool fi
     if (__lane_id() == 0) {
         if (m) *done_mask_hint(mask, B) = epoch;
         reinterpret_cast<uint32_t *>(mask)[tid >> 6] = (uint32_t)m;
-        done_mask_digests(mask, B)[tid >> 6] = (uint16_t)done_mask_digest((uint32_t)m);
+        done_mask_counts(mask, B)[tid >> 6] = (uint8_t)__popc((uint32_t)m);
     }
 }
-// The reader's side: every workgroup of the reset kernel sums the digests for itself (B / 16 bytes: 4 KB at 65 536 envs) -- thread t owns the words
-// [t c, (t + 1) c), c = ceil(words / 256), i.e. 2 c digests (one 16-byte load for batches up to 65 536 envs, kept in registers).
-//   done_mask_load   this thread's share of the digests (its load flies with whatever the caller issues next)
+// The reader's side: every workgroup of the reset kernel sums the counts for itself (B / 32 bytes: 2 KB at 65 536 envs) -- thread t owns the words
+// [t c, (t + 1) c), c = ceil(words / 256), i.e. 2 c count bytes (one 8-byte load for batches up to 65 536 envs).
+//   done_mask_load   this thread's share of the counts (its load flies with whatever the caller issues next)
 //   done_mask_scan   call from all 256 threads: two barriers; part[t] = bits before thread t's chunk, part[256] = the total, which it returns
 //   done_mask_find   "the i-th finished env" for an i that is the same on every thread of the workgroup (the tree path's entry): the thread whose
-//                    chunk holds it answers -- from its digests when the entry is one of the first two of its 32 envs, else from the mask's words --
-//                    one more barrier, no search
+//                    chunk holds it loads its words and answers; one more barrier, no search
 //   done_mask_nth    the same for any thread and any i < total: a search over the 256 partial sums and a walk over one chunk's words
 struct DoneMaskShare {
     uint32_t bits, before;
-    uint32_t dig[4];  // chunk == 4: the eight digests of this thread's four words
 };
 __device__ inline uint32_t done_mask_pick(uint64_t m, uint32_t r) {  // position of the r-th set bit (r < popcount)
     for (; r; --r) m &= m - 1ull;
     return (uint32_t)__ffsll((long long)m) - 1u;
 }
+__device__ inline uint32_t byte_sum4(uint32_t x) { return (x * 0x01010101u) >> 24; }  // (each byte <= 32: no carry out of the top byte)
 __device__ inline void done_mask_load(const uint64_t *mask, uint64_t B, uint32_t words, DoneMaskShare &sh) {
     const uint32_t chunk = (words + 255u) >> 8;
-    const uint16_t *dig = done_mask_digests(mask, B);
+    const uint8_t *cnt = done_mask_counts(mask, B);
     sh.bits = 0;
-    if (chunk == 4u) {  // eight digests
-        const uint4 v = reinterpret_cast<const uint4 *>(dig)[threadIdx.x];
-        sh.dig[0] = v.x; sh.dig[1] = v.y; sh.dig[2] = v.z; sh.dig[3] = v.w;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sh.bits += (sh.dig[k] & 63u) + ((sh.dig[k] >> 16) & 63u);
+    if (chunk == 4u) {  // 8 count bytes
+        const uint2 v = reinterpret_cast<const uint2 *>(cnt)[threadIdx.x];
+        sh.bits = byte_sum4(v.x) + byte_sum4(v.y);
     } else {
-        for (uint32_t k = 0; k < 2u * chunk; ++k) {
-            const uint32_t h = threadIdx.x * 2u * chunk + k;
-            if (h < 2u * words) sh.bits += dig[h] & 63u;
+        for (uint32_t k = 0; k < chunk; ++k) {
+            const uint32_t w = threadIdx.x * chunk + k;
+            if (w < words) {
+                const uint32_t c2 = reinterpret_cast<const uint16_t *>(cnt)[w];
+                sh.bits += (c2 & 0xFFu) + (c2 >> 8);
+            }
         }
     }
 }
@@ -190,9 +182,26 @@ __device__ inline uint32_t done_mask_scan(DoneMaskShare &sh, uint32_t *part /* L
     __syncthreads();
     return part[256];
 }
-// the r-th set bit of the chunk of thread `t`, from the mask's words
+// the r-th set bit of the chunk of thread `t`
 __device__ inline uint32_t done_mask_in_chunk(const uint64_t *mask, uint32_t words, uint32_t t, uint32_t rem) {
     const uint32_t chunk = (words + 255u) >> 8;
+    if (chunk == 4u) {  // the four words at once
+        const uint4 a = reinterpret_cast<const uint4 *>(mask)[2u * t], b = reinterpret_cast<const uint4 *>(mask)[2u * t + 1u];
+        const uint64_t w[4] = {(uint64_t)a.x | ((uint64_t)a.y << 32), (uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)b.x | ((uint64_t)b.y << 32),
+                               (uint64_t)b.z | ((uint64_t)b.w << 32)};
+        uint32_t env = 0;
+        bool found = false;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t pc = (uint32_t)__popcll(w[k]);
+            if (!found && rem < pc) {
+                env = (t * 4u + k) * 64u + done_mask_pick(w[k], rem);
+                found = true;
+            }
+            rem -= found ? 0u : pc;
+        }
+        return env;
+    }
     for (uint32_t k = 0; k < chunk; ++k) {
         const uint32_t w = t * chunk + k;
         const uint64_t m = w < words ? mask[w] : 0ull;
@@ -212,22 +221,7 @@ __device__ inline uint32_t done_mask_nth(const uint64_t *mask, uint32_t words, c
     return done_mask_in_chunk(mask, words, lo, i - part[lo]);
 }
 __device__ inline uint32_t done_mask_find(const uint64_t *mask, uint32_t words, const DoneMaskShare &sh, uint32_t *part, uint32_t i) {
-    if (sh.before <= i && i < sh.before + sh.bits) {  // exactly one thread
-        const uint32_t chunk = (words + 255u) >> 8;
-        uint32_t rem = i - sh.before, env = 0xFFFFFFFFu;
-        if (chunk == 4u) {  // from the digests: half h of the chunk = envs 32 h .. 32 h + 31 of it
-#pragma unroll
-            for (uint32_t h = 0; h < 8u; ++h) {
-                const uint32_t d = (sh.dig[h >> 1] >> (16u * (h & 1u))) & 0xFFFFu, n = d & 63u;
-                if (env == 0xFFFFFFFFu && rem < n) env = rem < 2u ? threadIdx.x * 256u + h * 32u + ((d >> (6u + 5u * rem)) & 31u) : 0xFFFFFFFEu;
-                if (env == 0xFFFFFFFFu) rem -= n;
-            }
-            if (env == 0xFFFFFFFEu) env = done_mask_in_chunk(mask, words, threadIdx.x, i - sh.before);  // (third or later finisher of its 32 envs)
-        } else {
-            env = done_mask_in_chunk(mask, words, threadIdx.x, rem);
-        }
-        part[261] = env;
-    }
+    if (sh.before <= i && i < sh.before + sh.bits) part[261] = done_mask_in_chunk(mask, words, threadIdx.x, i - sh.before);  // exactly one thread
     __syncthreads();
     return part[261];
 }

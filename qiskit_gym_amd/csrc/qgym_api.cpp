@@ -563,7 +563,7 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
     if (hp.has_done_list && v->layout == LAYOUT_TILE) {  // the finished envs of a step as one bit each (qm_step1 / qm_inv2 <LIST>)
         HIP_TRY_V(hipHostMalloc((void **)&p->count_seen, sizeof(uint32_t), hipHostMallocMapped));
         *p->count_seen = 0xFFFFFFFFu;
-        const size_t mask_bytes = 12 * 4 * ((batch + 255) / 256) + 8;  // device_common.hpp done_mask_bytes: a word per wave of the step grid (whole workgroups of 256 envs), a 16-bit digest per 32 envs, the hint word
+        const size_t mask_bytes = 10 * 4 * ((batch + 255) / 256) + 8;  // device_common.hpp done_mask_bytes: a word per wave of the step grid (whole workgroups of 256 envs), then a count byte per 32 envs
         for (auto &m : p->done_mask) {
             HIP_TRY_V(hipMalloc(&m, mask_bytes));
             HIP_TRY_V(hipMemset(m, 0, mask_bytes));
