@@ -542,8 +542,10 @@ int qg_plan_query(const qg_config *cfg, uint64_t batch, uint32_t num_actions, in
 
 /* ------------------------------------------------------------------------------------------
  * Scalar environment: the `Env` trait method for method (clifford.rs:285-382): a batch of one on the same kernels.  A call that changes the
- * state costs one kernel launch and one stream synchronisation (its results land in a pinned block the getters read as plain loads); this
- * flavour exists for API parity -- throughput comes from qg_vec_* (README: 4.6e4 env-steps/s per host thread against 1e10 batched).
+ * state costs one kernel launch and one stream synchronisation where the layout keeps a resident dense observation (16- / 32-row matrices: the
+ * step kernel rewrites the changed rows of the pinned observation itself), one more launch elsewhere; results and the fault word land in a pinned
+ * block the getters read as plain loads.  This flavour exists for API parity -- throughput comes from qg_vec_* (README: 5.7e4 env-steps/s per host
+ * thread, 1.9e5 on 32 threads -- the HIP runtime's own launch rate -- against 1e10 batched).
  * qg_env_destroy parks the handle (device buffers, stream, pinned block) in a process-wide pool for the next qg_env_clone of an env with
  * the same constructor arguments -- at most 64 per configuration, 256 in all; beyond that it frees.  qg_env_pool_clear releases the pool
  * (call it at teardown, or when a configuration will not be cloned again).
