@@ -30,246 +30,22 @@ Prints one JSON line on rank 0.
 """
 from __future__ import annotations
 
-import os
-
-# the CPU-baseline leg pins its OpenMP threads; the OpenMP runtime reads these when it is first loaded (and then binds the
-# main thread to its first place, so the CPUs this process may use are counted before that)
-NPROC = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-
-
-def _cpu_quota():
-    """CPUs this container may use at once (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited."""
-    try:
-        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
-        return None if q == "max" else float(q) / float(p)
-    except Exception:
-        pass
-    try:
-        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-        return None if q <= 0 else q / p
-    except Exception:
-        return None
-
-
-CPU_QUOTA = _cpu_quota()
-ORACLE_THREADS = NPROC if CPU_QUOTA is None else max(1, min(NPROC, int(CPU_QUOTA + 0.5)))  # never more threads than CPUs the container may run
-os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "cores")  # one thread per physical core: with "threads" 16 threads share 8 cores' SMT siblings (3.2e7 against 5.3e7 env-steps/s)
-# multi-process GPU work on this pool needs dmabuf IPC (hipIpcGetMemHandle fails otherwise): set before anything can initialise HIP -- the
-# ranks may come from the driver's launcher, not from launch_ranks() below
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import bench_common  # noqa: F401  (first: it sets the OpenMP / HSA environment before anything can load those runtimes)
+from bench_common import *  # noqa: F401,F403,E402  constants, cpu_baseline, the oracle replay, the readers of the committed profiles
+from bench_common import (ALGO_BYTES_PER_STEP, CADENCE_BUDGET_S, CHUNK, CONTROL_TIMEOUT_S, ENVS_PER_GPU, HBM_PEAK_GBS, KERNEL, NEEDED_BYTES_PER_STEP, NUM_QUBITS,  # noqa: E402
+                          RING, ROOT, SCRAMBLE, build_gateset, cpu_baseline, gathered_parity, global_actions, parity_replay, pmc_traffic, rocprof_kernel_avg_us)
 
 import argparse  # noqa: E402
-import csv  # noqa: E402
 import json  # noqa: E402
+import os  # noqa: E402
 import socket  # noqa: E402
 import subprocess  # noqa: E402
-import threading  # noqa: E402
 import sys  # noqa: E402
+import threading  # noqa: E402
 import time  # noqa: E402
-
-ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-
-NUM_QUBITS = 16
-ENVS_PER_GPU = 65536
-SCRAMBLE = 256
-CHUNK = 256  # most steps one hipGraph replay holds
-RING = 16    # pre-sampled action buffers the steps cycle through (a policy rewrites ONE buffer per step)
-OBS_WORDS = 2 * NUM_QUBITS  # packed observation: one 32-bit word per tableau row
-ALGO_BYTES_PER_STEP = 160  # SURVEY.md 8(d): 128 B state read + 16 B touched rows + 16 B scalars
-# what the one-step kernel has to move per env (DESIGN.md section 2): two 16-byte row groups read and (at most) written back,
-# action 4 R, depth 4 R + 4 W, bad mask 4 R + 4 W (written when it changes), reward 4 W, done / success 1 W each; the 8-byte gate
-# entry comes from a 1.4 KB table that stays cache resident
-NEEDED_BYTES_PER_STEP = 2 * 16 + 2 * 16 + 4 + 8 + 8 + 4 + 2
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-CONTROL_TIMEOUT_S = 90   # gloo control plane: a rank that never reaches a barrier costs its peers this long, not the driver's whole budget
-CADENCE_BUDGET_S = 240   # N > 1: wall-clock budget of the optional collective-cadence legs; past it the line is printed without them
-KERNEL = "qg::qm_step1_kernel<16, true, false"  # prefix: the trailing template arguments (feature flags, done list) vary by call site
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r05")
-
-
-def build_gateset():
-    from qiskit_gym_amd.envs.gateset import gateset_from_coupling_map, line_edges
-
-    kinds = ["H", "S", "Sdg", "SX", "SXdg", "CX", "CZ", "SWAP"]
-    return gateset_from_coupling_map(line_edges(NUM_QUBITS, True), None, kinds)
-
-
-def global_actions(seed: int, total_envs: int, num_actions: int) -> torch.Tensor:
-    """The ring of pre-sampled action buffers of the WHOLE batch, [RING, total_envs] int32 on the host: a function of
-    (seed, global env id) only, so every rank takes its slice of the same tensor."""
-    gen = torch.Generator()
-    gen.manual_seed(seed)
-    return torch.randint(0, num_actions, (RING, total_envs), dtype=torch.int32, generator=gen)
-
-
-def cpu_baseline(gateset, seed: int, budget_s: float = 2.0, repeats: int = 5):
-    """Time the CPU oracle (a C port of the reference's scalar Rust path, one env object per env, OpenMP over envs like
-    twisterl's rayon-over-clones) on this box's host cores: the configuration's own 65 536 envs, on ONE core and on ALL
-    cores the process may run on, one pinned thread per physical core (OMP_PLACES=cores, OMP_PROC_BIND=close), median of `repeats` timed repeats each."""
-    from oracle import OracleEnv, OracleVec
-
-    nproc = NPROC
-    B = ENVS_PER_GPU
-    A = len(gateset)
-    proto = OracleEnv("clifford", NUM_QUBITS, gateset, add_inverts=0, add_perms=0, track_solution=0, difficulty=SCRAMBLE)
-    ov = OracleVec(proto, B)
-    rng = np.random.default_rng(seed)
-    ov.reset_with(rng.integers(0, A, size=(SCRAMBLE, B)))
-    acts = rng.integers(0, A, size=(32, B)).astype(np.int32)
-
-    def measure(threads: int):
-        for t in range(4):  # warm-up: thread pool, first touch
-            ov.step_only(acts[t], threads=threads)
-        t0 = time.perf_counter()
-        ov.step_only(acts[4], threads=threads)
-        one = max(time.perf_counter() - t0, 1e-6)
-        n_steps = int(max(4, min(100_000, budget_s / one)))
-        for t in range(max(4, n_steps // 4)):  # untimed: the first passes after a thread-count change run slow
-            ov.step_only(acts[t % 32], threads=threads)
-        rates = []
-        for _ in range(repeats):
-            t0 = time.perf_counter()
-            for t in range(n_steps):
-                ov.step_only(acts[t % 32], threads=threads)
-            rates.append(B * n_steps / (time.perf_counter() - t0))
-        return float(np.median(rates)), [float(r) for r in rates], n_steps
-
-    quota, threads = CPU_QUOTA, ORACLE_THREADS
-    one_core, one_core_runs, n1 = measure(1)
-    all_core, all_core_runs, nall = measure(threads)
-    return {
-        "value": all_core,
-        "unit": "env-steps/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": f"CliffordGym 16q, {B} envs x {nall} steps per repeat, median of {repeats} repeats; C port of the reference scalar "
-                  f"path (byte-per-entry state, per-env objects, gcc -O3), OpenMP static over envs, one thread per physical core (OMP_PLACES=cores, OMP_PROC_BIND=close)",
-        "repeats": all_core_runs,
-        "one_core": {"value": one_core, "cores": 1, "repeats": one_core_runs, "steps_per_repeat": n1},
-        "nproc": nproc,
-        "cpu_quota": quota,
-    }
-
-
-def oracle_replay(gateset, seed, global_ids, ring_actions, trace):
-    """The run the GPU did -- same seed, same scramble draws (functions of the GLOBAL env id), same action buffers in the same
-    order -- on the CPU oracle for the sampled envs.  Returns the oracle batch and the outputs of its last step."""
-    from oracle import OracleEnv, OracleVec
-
-    proto = OracleEnv("clifford", NUM_QUBITS, gateset, add_inverts=0, add_perms=0, track_solution=0, difficulty=SCRAMBLE)
-    ov = OracleVec(proto, len(global_ids))
-    ov.reset_seeded(seed, env_ids=global_ids, threads=ORACLE_THREADS)  # Env::reset with the draws of qg_vec_reset(seed) (counter RNG, global env id)
-    last = (None, None, None, None)
-    for ring_idx in trace:
-        last = ov.step(ring_actions[ring_idx], threads=ORACLE_THREADS)
-    return ov, last
-
-
-def pack_rows_u32(dense: np.ndarray) -> np.ndarray:
-    """dense [n, 32, 32] of {0,1} -> packed [n, 32] uint32, bit c of word r = entry (r, c) (QG_FMT_PACKED)."""
-    w = (dense.astype(np.uint64) << np.arange(dense.shape[2], dtype=np.uint64)).sum(axis=2)
-    return w.astype(np.uint32)
-
-
-def parity_replay(gateset, seed, global_ids, ring_actions, trace, snap):
-    """Compare everything env.step() produces (reward bits, success, is_final, depth, dense observation) after the last timed step."""
-    import hashlib
-
-    from util import f32_bits
-
-    ov, (r, s, f, d) = oracle_replay(gateset, seed, global_ids, ring_actions, trace)
-    n = len(global_ids)
-    ok = {
-        "reward_bits": bool(np.array_equal(f32_bits(snap["reward"]), f32_bits(r))),
-        "success": bool(np.array_equal(snap["success"], s)),
-        "is_final": bool(np.array_equal(snap["done"], f)),
-        "depth": bool(np.array_equal(snap["depth"], d)),
-        "observation": bool(np.array_equal(snap["obs"].reshape(n, -1), ov.observe_dense(threads=ORACLE_THREADS))),
-    }
-
-    def digest(obs, reward, success, depth):  # SURVEY.md 8d: SHA-256 over the final (state, reward bits, success, depth) streams
-        h = hashlib.sha256()
-        for arr in (np.asarray(obs, dtype=np.uint8), f32_bits(reward).astype(np.uint32), np.asarray(success, dtype=np.uint8), np.asarray(depth, dtype=np.int32)):
-            h.update(np.ascontiguousarray(arr).tobytes())
-        return h.hexdigest()
-
-    sha_gpu = digest(snap["obs"].reshape(n, -1), snap["reward"], snap["success"], snap["depth"])
-    sha_cpu = digest(ov.observe_dense(threads=ORACLE_THREADS), r, s, d)
-    ok["sha256"] = sha_gpu == sha_cpu
-    return {"envs": int(n), "steps_replayed": len(trace), "checked": sorted(ok), "bit_exact": all(ok.values()),
-            "mismatch": [k for k, v in ok.items() if not v], "sha256_hip": sha_gpu, "sha256_oracle": sha_cpu}
-
-
-def gathered_parity(gateset, seed, global_ids, ring_actions, trace, shard):
-    """The learner-side view: the sampled envs' slice of the all-gathered shard (packed observation words, reward, is_final, success)
-    against the oracle replayed up to the step the snapshot was taken at."""
-    from util import f32_bits
-
-    ov, (r, s, f, _) = oracle_replay(gateset, seed, global_ids, ring_actions, trace)
-    n = len(global_ids)
-    want_obs = pack_rows_u32(ov.observe_dense(threads=ORACLE_THREADS).reshape(n, 2 * NUM_QUBITS, 2 * NUM_QUBITS))
-    ok = {
-        "packed_observation": bool(np.array_equal(shard["obs"].view(np.uint32), want_obs)),
-        "reward_bits": bool(np.array_equal(f32_bits(shard["reward"]), f32_bits(r))),
-        "is_final": bool(np.array_equal(shard["done"], f)),
-        "success": bool(np.array_equal(shard["success"], s)),
-    }
-    return {"envs": int(n), "steps_replayed": len(trace), "checked": sorted(ok), "bit_exact": all(ok.values()),
-            "mismatch": [k for k, v in ok.items() if not v]}
-
-
-def rocprof_kernel_avg_us(envs: int, required: bool = False):
-    """Average duration of the step kernel in the committed rocprofv3 --kernel-trace --stats summary of this command
-    (profiles/r05/, tools/profile_bench.sh).  The statistics hold one batch size (profiling runs pass --no-large-batch).  Every
-    instantiation of the kernel whose name starts with KERNEL counts (calls-weighted).  `required`: a missing file or kernel is an
-    error -- the line's roofline.frac is this figure -- unless the run IS the profiling run (--profiling-run)."""
-    path = os.path.join(PROFILE_DIR, "bench_kernel_stats.csv" if envs == ENVS_PER_GPU else f"bench_{envs}_kernel_stats.csv")
-    want = KERNEL.split("::", 1)[1]
-    calls, total_ns, mins = 0, 0.0, []
-    try:
-        with open(path) as f:
-            for row in csv.DictReader(f):
-                if want in row["Name"]:
-                    calls += int(row["Calls"])
-                    total_ns += float(row["AverageNs"]) * int(row["Calls"])
-                    mins.append(float(row["MinNs"]))
-    except OSError:
-        calls = 0
-    if calls:
-        return {"avg_us": total_ns / calls / 1e3, "min_us": min(mins) / 1e3, "calls": calls, "source": os.path.relpath(path, ROOT)}
-    if required:
-        raise SystemExit(f"bench.py: {os.path.relpath(path, ROOT)} does not hold a kernel named {want}*: re-run tools/profile_bench.sh on the "
-                         "current build and commit profiles/r05 (or pass --profiling-run)")
-    return None
-
-
-def profiled_configs():
-    """profiles/r05/traffic.json: per configuration the step kernel's rocprofv3 average, the PMC bytes per env (separate FETCH_SIZE /
-    WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), the bytes it needs and both fractions of 8 TB/s."""
-    try:
-        return json.load(open(os.path.join(PROFILE_DIR, "traffic.json")))["configs"]
-    except Exception:
-        return {}
-
-
-def pmc_traffic(envs: int):
-    """HBM bytes per launch of the step kernel from the committed PMC passes (tools/profile_bench.sh + tools/pmc_traffic.py:
-    separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), or None."""
-    path = os.path.join(PROFILE_DIR, "traffic.json")
-    try:
-        t = json.load(open(path))
-        e = t["by_envs"][str(envs)]
-        return {"bytes_per_launch": e["bytes_per_launch"], "fetch_bytes": e["fetch_bytes"], "write_bytes": e["write_bytes"],
-                "source": os.path.relpath(path, ROOT)}
-    except Exception:
-        return None
 
 
 def free_port() -> int:
@@ -759,385 +535,19 @@ def main():
     rocprof = rocprof_kernel_avg_us(B)  # the committed rocprofv3 summary of this command: reported beside the live clock, never required
     traffic = pmc_traffic(B)
 
-    # ---- fused rollout (state in LDS across steps), reported beside the headline --------
-    fused = None
-    if not multi:
-        FT = 128
-        facts = torch.randint(0, A, (FT, B), dtype=torch.int32, device=dev, generator=gen)
-        with torch.cuda.stream(stream):
-            env.rollout(facts, fused=True)
-            torch.cuda.synchronize()
-            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            f0.record(stream)
-            for _ in range(8):
-                env.rollout(facts, fused=True)
-            f1.record(stream)
-        torch.cuda.synchronize()
-        fms = f0.elapsed_time(f1)
-        fused = {"value": B * FT * 8 / (fms * 1e-3), "unit": "env-steps/s", "steps_per_launch": FT,
-                 "kernel": "qg::qm_fused_lds_kernel<16, true, false> (rows resident in LDS; actions known up front)"}
+    # ---- the legs beside the headline (bench_legs.py; N = 1 at the metric's batch size) --------
+    import bench_legs
+    from types import SimpleNamespace
 
-    def graph_period(venv, acts, replays=2):
-        with torch.cuda.stream(stream):
-            venv.rollout_ring(acts, CHUNK)
-            torch.cuda.synchronize()
-            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            b0.record(stream)
-            for _ in range(replays):
-                venv.rollout_ring(acts, CHUNK)
-            b1.record(stream)
-        torch.cuda.synchronize()
-        venv.sync()
-        return b0.elapsed_time(b1) * 1e3 / (replays * CHUNK)
-
-    # ---- the reference's DEFAULT configuration (envs/synthesis.py:182-204: add_inverts=True, track_solution=True) -------
-    default_cfg = None
-    if not multi and B == ENVS_PER_GPU and not args.no_default_config:
-        DT = 128  # = max_depth (envs/synthesis.py:188): what one episode, and its solution log, can hold
-        denv = VecEnv("clifford", n, gateset, B, add_inverts=True, add_perms=False, track_solution=True, difficulty=SCRAMBLE)
-        coins = torch.randint(0, 2, (DT, B), dtype=torch.uint8, device=dev, generator=gen)
-        dacts = torch.randint(0, A, (DT, B), dtype=torch.int32, device=dev, generator=gen)
-        dms = 0.0
-        with torch.cuda.stream(stream):
-            denv.reset(seed)
-            denv.rollout(dacts, coins=coins)  # builds the graph
-            for _ in range(4):
-                denv.reset(seed)  # a new episode: the log is empty again (not timed)
-                d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                d0.record(stream)
-                denv.rollout(dacts, coins=coins)
-                d1.record(stream)
-                torch.cuda.synchronize()
-                dms += d0.elapsed_time(d1)
-        denv.sync()
-        dus = dms * 1e3 / (4 * DT)
-        default_cfg = {"us_per_step": dus, "value": B / (dus * 1e-6), "unit": "env-steps/s",
-                       "config": "add_inverts=True (coin per env per step), track_solution=True, otherwise the headline workload; "
-                                 f"episodes of {DT} steps, each one hipGraph of {DT} launches, coins given"}
-        del denv, coins, dacts
-
-    # ---- SURVEY 8(d)'s auto-reset variant of the headline workload: qg_vec_reset_done after every step (finished episodes start over on the
-    # device: scramble from the identity), one captured graph of 128 x (step, reset_done).  Two episode schedules: "desynchronised" -- what a
-    # collector sees: episode ends spread evenly over time, 1/128 of the batch finishes in every step (Env::reset called for class
-    # env % 128 == k at warm-up step k) -- and "synchronised" (every env finishes in the same step, 127 of 128 reset_done calls find nothing) -----
-    auto_reset = None
-    if not multi and B == ENVS_PER_GPU and not args.no_default_config:
-        AT = 128  # = min(depth_slope * difficulty, max_depth) for every configuration below: the episode length
-
-        def auto_reset_leg(aenv, num_actions, spread=True):
-            """One captured graph of AT x (step, reset_done), the pair issued as qg_vec_reset_done_step (ONE launch where the layout has it: TILE without
-            add_inverts, LF8, PERM), replayed 4 times.  `spread`: Env::reset for class env % AT == k at warm-up step k, so 1 / AT of the batch finishes in
-            every step of the graph (what a collector sees); else every env finishes in the same step."""
-            nb = aenv.batch
-            aacts = torch.randint(0, num_actions, (AT, nb), dtype=torch.int32, device=dev, generator=gen)
-            afin = torch.empty((AT, nb), dtype=torch.uint8, device=dev)
-            with torch.cuda.stream(stream):
-                aenv.reset(seed)
-                if spread:
-                    cls = torch.arange(nb, device=dev) % AT
-                    for k in range(AT):  # eager warm-up: spreads the episode ends (the done flags are caller-owned memory, qg_vec_bind_outputs)
-                        aenv.set_counters(k, k)
-                        aenv.step(aacts[k])
-                        aenv.reset_done(seed + 0x51ED * (k + 1))
-                        aenv.done[cls == k] = 1
-                        aenv.reset_done(seed + 0xA5A5 * (k + 1))
-
-                def episode():  # step, then AT - 1 x (reset_done, step) as qg_vec_reset_done_step, and the last reset_done
-                    aenv.set_counters(0, 0)
-                    aenv.rollout(aacts[0:1], dones_out=afin[0:1])
-                    for t in range(1, AT):
-                        aenv.set_counters(t, t)
-                        aenv.reset_done_step(seed + 0x9E3779B9 * t, aacts[t], dones_out=afin[t])
-                    aenv.reset_done(seed + 0x9E3779B9 * AT)
-
-                episode()  # eager pass (allocations, kernel loads)
-                torch.cuda.synchronize()
-                ag = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ag, stream=stream):
-                    episode()
-                torch.cuda.synchronize()
-                ag.replay()
-                torch.cuda.synchronize()
-                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a0.record(stream)
-                for _ in range(4):
-                    ag.replay()
-                a1.record(stream)
-            torch.cuda.synchronize()
-            aenv.sync()
-            aus = a0.elapsed_time(a1) * 1e3 / (4 * AT)
-            per_step = afin.float().mean(dim=1)
-            return {"us_per_step": aus, "value": nb / (aus * 1e-6), "unit": "env-steps/s", "envs": nb, "finished_per_step": float(per_step.mean()),
-                    "finished_per_step_min_max": [float(per_step.min()), float(per_step.max())]}
-
-        from util import line_gateset as _line_gateset  # (the gateset builder the configs leg below uses)
-
-        legs = {}
-        for schedule in ("desynchronised", "synchronised", "desynchronised_reference_defaults"):
-            ref_defaults = schedule.endswith("reference_defaults")  # add_inverts + solution log: the pair is two launches behind the one call
-            aenv = VecEnv("clifford", n, gateset, B, add_inverts=ref_defaults, add_perms=False, track_solution=ref_defaults, difficulty=SCRAMBLE)
-            legs[schedule] = auto_reset_leg(aenv, A, spread=schedule != "synchronised")
-            del aenv
-        # SURVEY 8(d): "an auto-reset variant reported separately" for the other configurations too, same schedule (episode ends spread evenly over time)
-        gs2a = _line_gateset("linear_function", 8)
-        for name, nb, kw in (("C2", 8192, dict(add_inverts=False, track_solution=False)), ("C2_x65536", B, dict(add_inverts=False, track_solution=False)),
-                             ("C2_reference_defaults", 8192, dict(add_inverts=True, track_solution=True))):
-            aenv = VecEnv("linear_function", 8, gs2a, nb, add_perms=False, difficulty=64, **kw)
-            legs[name] = dict(auto_reset_leg(aenv, len(gs2a)), config=f"LinearFunctionGym 8q x {nb}, difficulty 64, {kw}: word_reset_step_kernel (one launch per pair)")
-            del aenv
-        gs5a = _line_gateset("pauli", 20)
-        aenv = VecEnv("pauli", 20, gs5a, B, add_perms=False, track_solution=False, max_rotations=5, difficulty=256, pauli_diff_scale=8)
-        legs["C5"] = dict(auto_reset_leg(aenv, len(gs5a)), config=f"PauliGym 20q x {B}, difficulty 256 (targets regenerated on the device), compact_done + "
-                                                                  "ptile_reset_tree_kernel + ptile_generate_kernel + ptile_step1c_kernel per pair")
-        del aenv
-        # ... and qg_vec_reset_done by itself where it is not a tree of row operations on a bit matrix: PauliGym 20q (config 5's env: a fresh target is
-        # generated on the device), 1 % of the batch finished, eager calls (memset + compaction + two kernels), median of 12
-        pg_n = 20
-        pg_gs = gs5a
-        penv = VecEnv("pauli", pg_n, pg_gs, B, add_perms=False, track_solution=False, difficulty=128)
-        with torch.cuda.stream(stream):
-            penv.reset(seed)
-            pmask = (torch.rand(B, device=dev, generator=gen) < 0.01).to(torch.uint8)
-            ptimes = []
-            for i in range(12):
-                penv.done.copy_(pmask)
-                p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                p0.record(stream)
-                penv.reset_done(seed + 100 + i)
-                p1.record(stream)
-                torch.cuda.synchronize()
-                ptimes.append(p0.elapsed_time(p1) * 1e3)
-        penv.sync()
-        legs["pauli_reset_done"] = {"us_per_call": sorted(ptimes)[len(ptimes) // 2], "finished": float(pmask.float().mean()),
-                                    "config": f"PauliGym {pg_n}q x {B} envs, difficulty 128, qg_vec_reset_done with 1 % of the batch finished, eager, median of 12"}
-        del penv
-        auto_reset = dict(legs["desynchronised"], synchronised=legs["synchronised"], reference_defaults=legs["desynchronised_reference_defaults"],
-                          C2=legs["C2"], C2_x65536=legs["C2_x65536"], C2_reference_defaults=legs["C2_reference_defaults"], C5=legs["C5"],
-                          pauli_reset_done=legs["pauli_reset_done"],
-                          config=f"the headline workload with qg_vec_reset_done after every step (the pair reset_done + next step issued as qg_vec_reset_done_step: one launch), episodes of min(depth_slope * difficulty, max_depth) = {AT} steps, "
-                                 f"a captured graph of {AT} x (step, reset_done) replayed 4 times; headline figures: episode ends spread evenly over time "
-                                 "(parity of this schedule: tests/test_gpu_fullsize.py::test_auto_reset_with_desynchronised_episodes_at_full_size)")
-
-    # ---- SURVEY 8(d) "report both modes": the observation handed to the learner after EVERY step of the headline workload.  The Gym adapter
-    # returns the dense int8 [32, 32] matrix per env on every step() (adapters.py:50-54,62-72).  Four graphs of 128 steps each:
-    #   packed        step + qg_vec_observe_packed (the bit-packed [B, 32] row words in env-major order: what the all-gather moves)
-    #   dense         step + qg_vec_observe_dense  (8d's 1 184 B per env-step: a full 1 KiB rewrite per env)
-    #   dense_tracked step on a handle with qg_vec_track_dense: the step kernel itself rewrites the <= 4 rows its gate changed in a RESIDENT
-    #                 dense observation (same bytes in the tensor after every step, <= 128 of the 1 024 written)
-    #   dense_kernel  qg_vec_observe_dense alone (launch period): the HBM-write roofline of the rewrite kernel on the bytes it writes
-    obs_modes = None
-    if not multi and B == ENVS_PER_GPU and not args.no_dense_obs:
-        OT = 128
-        D2 = 4 * n * n  # dense bytes per env
-        oenv = VecEnv("clifford", n, gateset, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=SCRAMBLE)
-        tenv = VecEnv("clifford", n, gateset, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=SCRAMBLE)
-        obs_d = torch.empty((B, 2 * n, 2 * n), dtype=torch.int8, device=dev)
-        obs_p = torch.empty((B, 2 * n), dtype=torch.int32, device=dev)
-
-        def graph_of(body, replays=4):
-            with torch.cuda.stream(stream):
-                body()  # eager pass
-                torch.cuda.synchronize()
-                gr = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr, stream=stream):
-                    body()
-                torch.cuda.synchronize()
-                gr.replay()
-                torch.cuda.synchronize()
-                o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                o0.record(stream)
-                for _ in range(replays):
-                    gr.replay()
-                o1.record(stream)
-            torch.cuda.synchronize()
-            return o0.elapsed_time(o1) * 1e3 / (replays * OT)
-
-        def steps_with(env_, after):
-            def body():
-                for t in range(OT):
-                    env_.step(actions[t % RING])
-                    after()
-            return body
-
-        with torch.cuda.stream(stream):
-            oenv.reset(seed)
-            tenv.reset(seed)
-            tracked = tenv.track_dense()
-        us_packed = graph_of(steps_with(oenv, lambda: oenv.observe_packed(out=obs_p)))
-        us_dense = graph_of(steps_with(oenv, lambda: oenv.observe(out=obs_d)))
-        us_kernel = graph_of(lambda: [oenv.observe(out=obs_d) for _ in range(OT)])
-        us_tracked = graph_of(steps_with(tenv, lambda: None))
-        # ... and with the reference's default options (add_inverts=True, track_solution=True; coins given): the two-lanes-per-env step rewrites
-        # an env's whole observation when its coin inverts the matrix (half of the envs per step), the gate's rows otherwise
-        denv2 = VecEnv("clifford", n, gateset, B, add_inverts=True, add_perms=False, track_solution=True, difficulty=SCRAMBLE, max_depth=7 * OT)
-        dcoins = torch.randint(0, 2, (RING, B), dtype=torch.uint8, device=dev, generator=gen)
-        with torch.cuda.stream(stream):
-            denv2.reset(seed)
-            tracked2 = denv2.track_dense()
-
-        def default_steps():
-            for t in range(OT):
-                denv2.step(actions[t % RING], dcoins[t % RING])
-
-        us_tracked_default = graph_of(default_steps)
-        denv2.sync()
-        with torch.cuda.stream(stream):
-            same2 = bool(torch.equal(tracked2, denv2.observe()))
-        if not same2:
-            raise SystemExit("bench.py: the tracked dense observation (reference-default options) differs from a full rewrite of the same state")
-        del denv2, tracked2, dcoins
-        oenv.sync()
-        tenv.sync()
-        with torch.cuda.stream(stream):
-            oenv.observe_packed(out=obs_p)  # the packed words of the final state (the packed graph ran before the dense one)
-            same = bool(torch.equal(tracked, tenv.observe())) and bool(torch.equal(obs_d, oenv.observe()))
-        if not same:
-            raise SystemExit("bench.py: the tracked dense observation differs from a full rewrite of the same state")
-        # oracle check of every env: oenv and tenv took the same steps from the same reset (eager pass + 6 replays of each graph)
-        obs_parity = None
-        if rank == 0 and not args.no_parity:
-            o_steps = 2 * 6 * OT  # oenv: two stepping graphs (eager pass + 5 replays each); tenv: one
-            t_steps = 6 * OT
-            sample = np.arange(B)  # every env
-            acts_np = host_actions[:, sample].numpy()
-            ov_o, _ = oracle_replay(gateset, seed, env_base + sample, acts_np, [t % RING for t in range(OT)] * (o_steps // OT))
-            ov_t, _ = oracle_replay(gateset, seed, env_base + sample, acts_np, [t % RING for t in range(OT)] * (t_steps // OT))
-            sidx = torch.as_tensor(sample, device=dev)
-            ok_d = bool(np.array_equal(obs_d[sidx].cpu().numpy().reshape(len(sample), -1), ov_o.observe_dense()))
-            ok_t = bool(np.array_equal(tracked[sidx].cpu().numpy().reshape(len(sample), -1), ov_t.observe_dense()))
-            ok_p = bool(np.array_equal(obs_p[sidx].cpu().numpy().view(np.uint32), pack_rows_u32(ov_o.observe_dense().reshape(len(sample), 2 * n, 2 * n))))
-            obs_parity = {"envs": int(len(sample)), "dense_rewrite": ok_d, "dense_tracked": ok_t, "packed": ok_p, "bit_exact": ok_d and ok_t and ok_p}
-            if not obs_parity["bit_exact"]:
-                raise SystemExit(f"bench.py: observation modes differ from the CPU oracle replay: {obs_parity}")
-
-        def mode(us, bytes_per_env, what):
-            gbs = bytes_per_env * B / (us * 1e-6) / 1e9
-            return {"us_per_step": us, "value": B / (us * 1e-6), "unit": "env-steps/s", "bytes_per_env_step": bytes_per_env,
-                    "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}, "what": what}
-
-        obs_modes = {
-            "packed": mode(us_packed, ALGO_BYTES_PER_STEP + 2 * 4 * 2 * n,
-                           "step + qg_vec_observe_packed per step: 8d's 160 B + the env-major copy of the 32 row words (128 B read, 128 B written)"),
-            "dense": mode(us_dense, ALGO_BYTES_PER_STEP + D2, "step + qg_vec_observe_dense per step: SURVEY 8d's 1 184 B per env-step (full 1 KiB int8 rewrite)"),
-            "dense_tracked": {"us_per_step": us_tracked, "value": B / (us_tracked * 1e-6), "unit": "env-steps/s",
-                              "bytes_moved_per_env_step": NEEDED_BYTES_PER_STEP + 64,
-                              "frac_moved": (NEEDED_BYTES_PER_STEP + 64) * B / (us_tracked * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                              "what": "qg_vec_track_dense: the step kernel rewrites the rows its gate changed in a resident dense observation; the tensor "
-                                      "holds the same bytes as after the full rewrite.  No fraction on 8d's 1 184 B: this form does not move most of them; "
-                                      "frac_moved is on the bytes it has to move"},
-            "dense_tracked_reference_defaults": {
-                "us_per_step": us_tracked_default, "value": B / (us_tracked_default * 1e-6), "unit": "env-steps/s",
-                "what": "qg_vec_track_dense with add_inverts=True, track_solution=True (coins given): qm_inv2_kernel rewrites the whole env when its coin fires "
-                        "(wave-contiguous 1 KiB stores), the gate's rows otherwise; equals a full rewrite of the final state (checked)"},
-            "dense_kernel": {"kernel": "qg::qm_dense_stream_kernel<2>", "us_per_launch": us_kernel, "bytes_written_per_launch": D2 * B,
-                             "roofline": {"bound": "hbm", "achieved": D2 * B / (us_kernel * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": D2 * B / (us_kernel * 1e-6) / 1e9 / HBM_PEAK_GBS},
-                             "what": "launch period of qg_vec_observe_dense alone (hipGraph of 128 launches); written bytes only (it reads 128 B per env)"},
-            "parity": obs_parity,
-            "config": f"the headline workload, one observation after every step, hipGraphs of {OT} steps replayed 4 times; the average changed-row count of the "
-                      "170-action gateset is 1.98 rows of 32 B per step",
-        }
-        del oenv, tenv, obs_d, obs_p, tracked
-
-    # ---- SURVEY 8(d)'s other configurations: live launch period (hipGraph of 128 single-step launches) beside the committed rocprofv3 / PMC
-    # figures of the same kernels (profiles/r05/traffic.json, tools/profile_bench.sh) -----
-    configs = None
-    if not multi and B == ENVS_PER_GPU and not args.no_configs:
-        from util import line_gateset
-
-        prof = profiled_configs()
-        configs = {}
-
-        def leg(name, venv, acts, coins=None):
-            with torch.cuda.stream(stream):
-                if coins is None:
-                    us = graph_period(venv, acts)
-                else:
-                    venv.rollout(acts, coins=coins)  # builds the graph
-                    tot = 0.0
-                    for _ in range(3):
-                        venv.reset(seed)  # a new episode: the solution log is empty again (not timed)
-                        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        c0.record(stream)
-                        venv.rollout(acts, coins=coins)
-                        c1.record(stream)
-                        torch.cuda.synchronize()
-                        tot += c0.elapsed_time(c1)
-                    venv.sync()
-                    us = tot * 1e3 / (3 * acts.shape[0])
-            p = prof.get(name) or {}
-            st = p.get("rocprof_kernel_stats") or {}
-            row = {"kernel": p.get("kernel"), "envs": venv.batch, "us_per_step": us, "value": venv.batch / (us * 1e-6), "unit": "env-steps/s",
-                   "rocprof_avg_us": st.get("avg_us"), "pmc_bytes_per_env": p.get("bytes_per_env"), "needed_bytes_per_env": p.get("needed_bytes_per_env"),
-                   "survey_8d_bytes_per_env": p.get("survey_8d_bytes_per_env"), "frac_moved": p.get("rocprof_frac_moved"),
-                   "frac_survey_8d": p.get("rocprof_frac_algorithmic"), "source": "profiles/r05/traffic.json" if p else None}
-            configs[name] = row
-
-        gs2 = line_gateset("linear_function", 8)
-        e2 = VecEnv("linear_function", 8, gs2, 8192, add_inverts=False, add_perms=False, track_solution=False, difficulty=64)
-        with torch.cuda.stream(stream):
-            e2.reset(0x5EED0002)
-        leg("C2", e2, torch.randint(0, len(gs2), (RING, 8192), dtype=torch.int32, device=dev, generator=gen))
-        del e2
-        gs5 = line_gateset("pauli", 20)
-        e5 = VecEnv("pauli", 20, gs5, B, add_perms=False, track_solution=False, max_rotations=5, difficulty=256, pauli_diff_scale=8)
-        with torch.cuda.stream(stream):
-            e5.reset(0x5EED0005)  # targets generated on the device: 1-7 rotations per env, tableau scrambled by 256 gates
-        leg("C5", e5, torch.randint(0, len(gs5), (RING, B), dtype=torch.int32, device=dev, generator=gen))
-        del e5
-        e3d = VecEnv("clifford", n, gateset, B, add_inverts=True, add_perms=False, track_solution=True, difficulty=SCRAMBLE)
-        with torch.cuda.stream(stream):
-            e3d.reset(seed)
-        leg("C3d", e3d, torch.randint(0, A, (128, B), dtype=torch.int32, device=dev, generator=gen),
-            coins=torch.randint(0, 2, (128, B), dtype=torch.uint8, device=dev, generator=gen))
-        del e3d
-        configs["note"] = ("C2 LinearFunctionGym 8q x 8 192, C5 PauliGym 20q x 65 536 (device-generated targets), C3d CliffordGym 16q x 65 536 with the "
-                           "reference's default add_inverts=True / track_solution=True; us_per_step is live (HIP events around hipGraph replays of "
-                           "single-step launches), the other columns are the committed rocprofv3 --kernel-trace --stats and --pmc passes of tools/run_config.py")
-
-    # ---- the same step kernel at larger batches: where the launch boundary (1.6 us) stops dominating, and beyond the Infinity Cache -----
-    large = None
-    if not multi and B == ENVS_PER_GPU and not args.no_large_batch:
-        sizes = []
-        for LB in (1 << 18, 1 << 20, 1 << 22):
-            big = VecEnv("clifford", n, gateset, LB, add_inverts=False, add_perms=False, track_solution=False, difficulty=SCRAMBLE)
-            bacts = torch.randint(0, A, (RING, LB), dtype=torch.int32, device=dev, generator=gen)
-            with torch.cuda.stream(stream):
-                big.reset(seed)
-            lus = graph_period(big, bacts)
-            lgb = ALGO_BYTES_PER_STEP * LB / (lus * 1e-6) / 1e9
-            sizes.append({"envs": LB, "launch_us": lus, "achieved": lgb, "unit": "GB/s", "frac": lgb / HBM_PEAK_GBS,
-                          "state_MiB": LB * 128 / 2**20, "rocprof": rocprof_kernel_avg_us(LB), "traffic": pmc_traffic(LB)})
-            del big, bacts
-        large = {"note": "same kernel and layout at 4x / 16x / 64x the batch: per-launch time is kernel time, not launch boundary; "
-                         "2^22 envs = 512 MiB of state, beyond the 256 MiB Infinity Cache", "by_batch": sizes}
-
-    # ---- with a policy in the loop (SURVEY 8f-3): the reference's default network shape (rl/configs.py:531-607, bf16, random weights) forward +
-    # categorical draw + env.step() + auto-reset per collection step, everything on the GPU; informational, not the headline metric -----
-    collector = None
-    if not multi and B == ENVS_PER_GPU and not args.no_collector:
-        from qiskit_gym_amd.collector import BasicPolicy, RolloutCollector
-        rows = []
-        for CB in (1024, B):  # the reference's num_episodes (rl/configs.py:134) and the headline batch
-            cenv = VecEnv("clifford", n, gateset, CB, add_inverts=False, add_perms=False, track_solution=False, difficulty=32)
-            col = RolloutCollector(cenv, BasicPolicy(4 * n * n, A), dtype=torch.bfloat16, seed=1, store_obs="packed", use_graph=True)
-            CT = 32
-            col.collect(CT)  # eager pass + capture
-            col.collect(CT)  # first replay (the graph's one-time upload: tens of ms now and then)
-            torch.cuda.synchronize()
-            per_replay = []
-            for _ in range(5):  # each replay timed on its own: a hipGraph launch now and then stalls for tens of ms (its upload), the median does not see it
-                t0 = time.perf_counter()
-                ro = col.collect(CT)
-                torch.cuda.synchronize()
-                per_replay.append((time.perf_counter() - t0) / CT * 1e6)
-            cus = float(np.median(per_replay))
-            cenv.sync()
-            rows.append({"envs": CB, "us_per_step": cus, "value": CB / (cus * 1e-6), "unit": "env-steps/s", "done_per_step": float(ro.dones.float().mean())})
-            del col, cenv, ro
-            torch.cuda.empty_cache()
-        collector = {"policy": f"BasicPolicy {4 * n * n}-512-256-{{{A}, 1}} bf16, random weights; packed observation stored per step; one hipGraph per 32-step collection",
-                     "clock": "host wall clock around each of 5 replays (device idle before and after), median", "by_batch": rows}
+    ctx = SimpleNamespace(multi=multi, B=B, args=args, VecEnv=VecEnv, n=n, gateset=gateset, A=A, dev=dev, gen=gen, stream=stream, seed=seed, actions=actions,
+                          host_actions=host_actions, env_base=env_base, rank=rank, env=env)
+    fused = bench_legs.fused_rollout(ctx)
+    default_cfg = bench_legs.default_config(ctx)
+    auto_reset = bench_legs.auto_reset(ctx)
+    obs_modes = bench_legs.observation_modes(ctx)
+    configs = bench_legs.other_configs(ctx)
+    large = bench_legs.large_batch(ctx)
+    collector = bench_legs.policy_in_loop(ctx)
 
     if rank == 0:
         cpu = None
