@@ -190,23 +190,23 @@ def test_bench_as_a_two_rank_job_on_one_gpu_with_the_direct_write_handover():
     assert line["value"] > 1e7 and line["scaling"] == "weak"  # (two processes share one GPU: a functional run, its rate means nothing)
 
 
-def test_bench_as_a_five_rank_job_on_one_gpu_every_window_offset_and_flag():
-    """The most ranks this pool lets anybody put on one GPU (six processes may have it open at once: five ranks and whoever started them -- this test
-    runner, or bench.py's own launcher; a six-rank run is killed by the pool's process guard): bench.py --gpus 5,
-    every rank on GPU 0, 8 192 envs each, the learner shard handed over by the direct write -- five windows of 2 parities x 5 slots, five
-    arrival flags per header, every peer offset in use, an odd world size -- inside the timed region; rank 0 replays its own part and rank 4's
-    part of what arrived on the oracle, every env.  (Config 4's world of 8 needs 8 GPUs: tests/test_distributed_cpu.py runs its control plane
-    with 8 ranks, profiles/r05/bench_five_ranks_one_gpu_direct.json is the same job run standalone.)"""
+def test_bench_as_a_four_rank_job_on_one_gpu_every_window_offset_and_flag():
+    """The most ranks this pool lets a TEST put on one GPU: six processes may have it open at once -- this test runner, bench.py's launcher and four
+    ranks (a run with one more is killed by the pool's process guard; standalone, without the test runner, five ranks fit:
+    profiles/r05/bench_five_ranks_one_gpu_direct.json).  bench.py --gpus 4, every rank on GPU 0, 8 192 envs each, the learner shard handed over by the
+    direct write -- four windows of 2 parities x 4 slots, four arrival flags per header, every peer offset in use -- inside the timed region; rank 0
+    replays its own part and rank 3's part of what arrived on the oracle, every env.  (Config 4's world of 8 needs 8 GPUs:
+    tests/test_distributed_cpu.py runs its control plane with 8 ranks.)"""
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--handover", "direct", "--ranks-share-gpu0", "--envs", "8192",
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--handover", "direct", "--ranks-share-gpu0", "--envs", "8192",
                           "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-large-batch", "--no-default-config", "--no-configs", "--no-collector",
                           "--no-dense-obs"], capture_output=True, text=True, timeout=900, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')][-1])
     cfg = line["config"]
-    assert line["ranks"] == 5 and cfg["ranks_seen"] == 5 and cfg["total_envs"] == 5 * 8192 and cfg["env_ids_of_rank0"] == [0, 8192]
+    assert line["ranks"] == 4 and cfg["ranks_seen"] == 4 and cfg["total_envs"] == 4 * 8192 and cfg["env_ids_of_rank0"] == [0, 8192]
     assert line["n_gpus"] == 1 and line["physical_gpus"] == 1 and line["ranks_share_gpu0"]
     assert cfg["collective"]["handover"] == "direct" and cfg["collective"]["collectives_in_timed_region"] >= 1
     par = line["parity"]
