@@ -584,3 +584,47 @@ def test_word_layouts_reset_finished_envs_on_16_lanes_each_and_in_the_step_launc
         for g in (one, two):
             g_sol, g_len = g.solutions(64)
             assert np.array_equal(g_len, o_len) and np.array_equal(g_sol, o_sol)
+
+
+@pytest.mark.parametrize("kind,n,B,inverts", [("clifford", 16, 64, False), ("clifford", 16, 100, True), ("clifford", 9, 257, False), ("linear_function", 20, 1000, False),
+                                              ("clifford", 16, 20000, True), ("clifford", 16, 70000, False), ("clifford", 12, 200000, True),
+                                              ("linear_function", 32, 300001, False)])
+def test_finishers_left_as_a_mask_at_assorted_batch_sizes(kind, n, B, inverts):
+    """The step leaves its finishers as one bit per env and qg_vec_reset_done's workgroups count the mask themselves (device_common.hpp done_mask_*): batches
+    below one wave, with ragged last waves and workgroups, and beyond 65 536 envs, where a thread's share of the mask is more than four words and the
+    entry is found by a search over the partial sums.  step -> reset_done -> step ... with short episodes, EVERY env against the oracle after every
+    step; reset_done_step (one launch where the handle has it) in between."""
+    from oracle import OracleVec
+    from qiskit_gym_amd.vec import VecEnv
+    from test_gpu_fullsize import _coins
+
+    gs = line_gateset(kind, n)
+    A, diff = len(gs), 3
+    cfg = dict(add_inverts=inverts, add_perms=False, track_solution=False, difficulty=diff, depth_slope=2, max_depth=128)
+    gv = VecEnv(kind, n, gs, B, seed=31, **cfg)
+    ov = OracleVec(OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()}), B)
+    gv.reset(2)
+    ov.reset_seeded(2)
+    gen = torch.Generator(device="cuda").manual_seed(B)
+    ids = np.arange(B)
+    resets = 0
+    for t in range(14):
+        acts = torch.randint(0, A, (B,), dtype=torch.int32, device="cuda", generator=gen)
+        gv.set_counters(t, 0)
+        if t % 3 == 2:
+            fin = gv.done.cpu().numpy()
+            gv.reset_done_step(700 + t, acts)
+            ov.reset_seeded(700 + t, mask=fin)
+            resets += int(fin.sum())
+        else:
+            gv.step(acts)
+        r, s, f, d = ov.step(acts.cpu().numpy(), _coins(31, ids, t) if inverts else None)
+        gv.sync()
+        assert np.array_equal(f32_bits(gv.reward.cpu().numpy()), f32_bits(r)), t
+        assert np.array_equal(gv.done.cpu().numpy(), f) and np.array_equal(gv.depth.cpu().numpy(), d), (t, np.nonzero(gv.done.cpu().numpy() != f)[0][:8])
+        if t % 3 != 1:  # (before a reset_done_step the finishers stay for it)
+            gv.reset_done(300 + t)
+            ov.reset_seeded(300 + t, mask=f)
+            resets += int(f.sum())
+    assert resets > B
+    assert np.array_equal(gv.observe().cpu().numpy().reshape(B, -1), ov.observe_dense()), "final states"
