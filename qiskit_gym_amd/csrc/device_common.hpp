@@ -132,13 +132,13 @@ __device__ inline void done_mask_store_pairs(uint64_t *mask, uint64_t B, bool fi
         done_mask_counts(mask, B)[tid >> 6] = (uint8_t)__popc((uint32_t)m);
     }
 }
-// The reader's side: every workgroup of the reset kernel sums the counts for itself (B / 32 bytes: 2 KB at 65 536 envs) -- thread t owns the words
-// [t c, (t + 1) c), c = ceil(words / 256), i.e. 2 c count bytes (one 8-byte load for batches up to 65 536 envs).
+// The reader's side: every workgroup of the reset kernel sums the counts for itself (B / 32 bytes: 2 KB at 65 536 envs) -- thread t of the workgroup's T
+// (256, or 64 for the one-wave kernels) owns the words [t c, (t + 1) c), c = ceil(words / T), i.e. 2 c count bytes (one 8-byte load at c = 4).
 //   done_mask_load   this thread's share of the counts (its load flies with whatever the caller issues next)
-//   done_mask_scan   call from all 256 threads: two barriers; part[t] = bits before thread t's chunk, part[256] = the total, which it returns
+//   done_mask_scan   call from all T threads: two barriers; part[t] = bits before thread t's chunk, part[T] = the total, which it returns
 //   done_mask_find   "the i-th finished env" for an i that is the same on every thread of the workgroup (the tree path's entry): the thread whose
 //                    chunk holds it loads its words and answers; one more barrier, no search
-//   done_mask_nth    the same for any thread and any i < total: a search over the 256 partial sums and a walk over one chunk's words
+//   done_mask_nth    the same for any thread and any i < total: a search over the T partial sums and a walk over one chunk's words
 struct DoneMaskShare {
     uint32_t bits, before;
 };
@@ -147,13 +147,22 @@ __device__ inline uint32_t done_mask_pick(uint64_t m, uint32_t r) {  // position
     return (uint32_t)__ffsll((long long)m) - 1u;
 }
 __device__ inline uint32_t byte_sum4(uint32_t x) { return (x * 0x01010101u) >> 24; }  // (each byte <= 32: no carry out of the top byte)
+template <uint32_t T = 256>
 __device__ inline void done_mask_load(const uint64_t *mask, uint64_t B, uint32_t words, DoneMaskShare &sh) {
-    const uint32_t chunk = (words + 255u) >> 8;
+    const uint32_t chunk = (words + T - 1u) / T;
     const uint8_t *cnt = done_mask_counts(mask, B);
     sh.bits = 0;
     if (chunk == 4u) {  // 8 count bytes
         const uint2 v = reinterpret_cast<const uint2 *>(cnt)[threadIdx.x];
         sh.bits = byte_sum4(v.x) + byte_sum4(v.y);
+    } else if ((chunk & 3u) == 0u) {  // whole 8-byte pieces
+        for (uint32_t k = 0; k < chunk; k += 4u) {
+            const uint32_t w = threadIdx.x * chunk + k;
+            if (w < words) {  // (words is a multiple of 4: a piece is inside or outside as a whole)
+                const uint2 v = *reinterpret_cast<const uint2 *>(cnt + 2u * w);
+                sh.bits += byte_sum4(v.x) + byte_sum4(v.y);
+            }
+        }
     } else {
         for (uint32_t k = 0; k < chunk; ++k) {
             const uint32_t w = threadIdx.x * chunk + k;
@@ -164,7 +173,8 @@ __device__ inline void done_mask_load(const uint64_t *mask, uint64_t B, uint32_t
         }
     }
 }
-__device__ inline uint32_t done_mask_scan(DoneMaskShare &sh, uint32_t *part /* LDS [257 + 5] */) {
+template <uint32_t T = 256>
+__device__ inline uint32_t done_mask_scan(DoneMaskShare &sh, uint32_t *part /* LDS [T + 1 + 5] */) {
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
     uint32_t incl = sh.bits;
 #pragma unroll
@@ -172,19 +182,20 @@ __device__ inline uint32_t done_mask_scan(DoneMaskShare &sh, uint32_t *part /* L
         const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
         if ((int)lane >= off) incl += up;
     }
-    if (lane == 63u) part[257u + wave] = incl;
+    if (lane == 63u) part[T + 1u + wave] = incl;
     __syncthreads();
     uint32_t base = 0;
-    for (uint32_t w = 0; w < wave; ++w) base += part[257u + w];
+    for (uint32_t w = 0; w < wave; ++w) base += part[T + 1u + w];
     sh.before = base + incl - sh.bits;
     part[threadIdx.x + 1u] = base + incl;
     if (threadIdx.x == 0) part[0] = 0;
     __syncthreads();
-    return part[256];
+    return part[T];
 }
 // the r-th set bit of the chunk of thread `t`
+template <uint32_t T = 256>
 __device__ inline uint32_t done_mask_in_chunk(const uint64_t *mask, uint32_t words, uint32_t t, uint32_t rem) {
-    const uint32_t chunk = (words + 255u) >> 8;
+    const uint32_t chunk = (words + T - 1u) / T;
     if (chunk == 4u) {  // the four words at once
         const uint4 a = reinterpret_cast<const uint4 *>(mask)[2u * t], b = reinterpret_cast<const uint4 *>(mask)[2u * t + 1u];
         const uint64_t w[4] = {(uint64_t)a.x | ((uint64_t)a.y << 32), (uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)b.x | ((uint64_t)b.y << 32),
@@ -211,19 +222,21 @@ __device__ inline uint32_t done_mask_in_chunk(const uint64_t *mask, uint32_t wor
     }
     return 0u;  // (unreachable for rem < the chunk's bits)
 }
+template <uint32_t T = 256>
 __device__ inline uint32_t done_mask_nth(const uint64_t *mask, uint32_t words, const uint32_t *part, uint32_t i) {
-    uint32_t lo = 0, hi = 256;  // part[lo] <= i < part[hi]
+    uint32_t lo = 0, hi = T;  // part[lo] <= i < part[hi]
     while (hi - lo > 1u) {
         const uint32_t mid = (lo + hi) >> 1;
         if (part[mid] <= i) lo = mid;
         else hi = mid;
     }
-    return done_mask_in_chunk(mask, words, lo, i - part[lo]);
+    return done_mask_in_chunk<T>(mask, words, lo, i - part[lo]);
 }
+template <uint32_t T = 256>
 __device__ inline uint32_t done_mask_find(const uint64_t *mask, uint32_t words, const DoneMaskShare &sh, uint32_t *part, uint32_t i) {
-    if (sh.before <= i && i < sh.before + sh.bits) part[261] = done_mask_in_chunk(mask, words, threadIdx.x, i - sh.before);  // exactly one thread
+    if (sh.before <= i && i < sh.before + sh.bits) part[T + 5u] = done_mask_in_chunk<T>(mask, words, threadIdx.x, i - sh.before);  // exactly one thread
     __syncthreads();
-    return part[261];
+    return part[T + 5u];
 }
 
 #define QG_COOP_LANES qg::plan::COOP_LANES  // lanes per env of the cooperative scramble (scramble_coop below; qgym_plan.hpp)

@@ -823,17 +823,12 @@ __device__ inline void planes_add(uint32_t (&w)[5], uint32_t bits) {
 // One step per launch on the compact layout: the transposed rotation region hands the kernel the gate's
 // bit-slices directly (two 16-bit gathers), the weights live as bit-planes, so no per-rotation mask is ever
 // loaded: per env the step reads two qubit records, two slice pairs and 32 bytes of bookkeeping.
+// (the body of ptile_step1c_kernel for one env; returns is_final)
 template <int NQ, int RM, bool FEAT>
-__global__ __launch_bounds__(256) void ptile_step1c_kernel(PTArgs pa) {
-    KernelClock kclk(pa.s.kclk, pa.s.kclk_waves);  // device_common.hpp
+__device__ __forceinline__ bool ptile_step1c_body(const PTArgs &pa, uint64_t env, uint32_t lane) {
     using L = PTLayout<NQ, RM>;
     static_assert(L::COMPACT && RM == 8, "compact layout only");
     const StepArgs &a = pa.s;
-    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
-    QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
-    asm volatile("" ::"s"(pa.prog), "s"(pa.n_perms));
-    if (env >= a.B) return;
     const uint32_t N = a.N;
     char *tile = L::tile(a.state, env);
 
@@ -970,6 +965,26 @@ __global__ __launch_bounds__(256) void ptile_step1c_kernel(PTArgs pa) {
     a.success[env] = (uint8_t)solved;
     if (FEAT && (a.flags & F_TRACK)) a.sol_len[env * 2] = sol_n;
     if (fault) atomicOr(&a.error[env], fault);
+    return depth == 0 || solved;
+}
+// LIST (F_DONE_LIST): the envs that finish are left as one bit each in StepArgs::done_mask for the qg_vec_reset_done that follows (device_common.hpp
+// done_mask_store: no compaction launch); its own instantiation, the plain kernel's code stays as it is
+template <int NQ, int RM, bool FEAT, bool LIST = false>
+__global__ __launch_bounds__(256) void ptile_step1c_kernel(PTArgs pa) {
+    KernelClock kclk(pa.s.kclk, pa.s.kclk_waves);  // device_common.hpp
+    const StepArgs &a = pa.s;
+    const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+    QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
+    asm volatile("" ::"s"(pa.prog), "s"(pa.n_perms));
+    if constexpr (LIST) {  // every thread reaches the wave's ballot
+        bool fin = false;
+        if (env < a.B) fin = ptile_step1c_body<NQ, RM, FEAT>(pa, env, lane);
+        done_mask_store(a.done_mask, a.B, fin, env, a.done_epoch);
+    } else {
+        if (env >= a.B) return;
+        (void)ptile_step1c_body<NQ, RM, FEAT>(pa, env, lane);
+    }
 }
 
 // Fused rollout on the compact layout (T steps per launch; plain configuration: no solution log, default weights, no
@@ -1276,6 +1291,11 @@ struct PTGenArgs {
     uint32_t *list_count;
     uint32_t tree;         // ptile_reset_tree_kernel runs before ptile_generate_kernel and takes the lists pt_tree_takes says it takes
     unsigned long long *tree_kclk;  // qg_vec_set_kernel_clock: the tree launch's slot (the generate launch's is s.kclk)
+    // only_done, the finished envs as the bits the step before left (StepArgs::done_mask) instead of a compacted list: every workgroup counts them itself
+    // (device_common.hpp done_mask_*); `count_pub` (the list's length word, unused otherwise): where the tree launch leaves the count for the generate launch
+    const uint64_t *mask;
+    uint32_t mask_words, mask_epoch;
+    uint32_t *count_pub;
 };
 constexpr uint32_t PT_CX_LDS = plan::PAULI_CX_LDS;
 using plan::pauli_tree_takes;  // short lists of long scrambles: a workgroup per listed env (ptile_reset_tree_kernel), qgym_plan.hpp
@@ -1523,17 +1543,29 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
     __shared__ PTGenTables tb;
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // the list's only reader; compact_done re-initialises the length before every use, so nobody has to zero it here (no reader tickets)
-    const uint32_t count = ga.list ? ga.list_count[0] : 0u;
-    // (before the tables are brought in: most calls with a list leave here -- ptile_reset_tree_kernel has taken it, or the wave lies past it)
-    if (ga.list && ((ga.tree && pauli_tree_takes(count, ga.difficulty, a.B, ga.n_cx)) || (tid & ~(uint64_t)(QG_WAVE - 1)) >= count)) return;
+    __shared__ uint32_t mask_part[64 + 1 + 5];
+    uint32_t count = ga.list ? ga.list_count[0] : 0u;
+    if (ga.mask) {  // (the workgroup is one wave)
+        // after a tree launch its count is in count_pub: most calls leave here; else (no tree launch, or a list too long for it) count the mask
+        const bool published = ga.tree != 0;
+        count = published ? *ga.count_pub : 0u;
+        if (published && (pauli_tree_takes(count, ga.difficulty, a.B, ga.n_cx) || (tid & ~(uint64_t)(QG_WAVE - 1)) >= count)) return;
+        DoneMaskShare share;
+        done_mask_load<64>(ga.mask, a.B, ga.mask_words, share);
+        count = *done_mask_hint(ga.mask, a.B) != ga.mask_epoch ? 0u : done_mask_scan<64>(share, mask_part);
+        if ((tid & ~(uint64_t)(QG_WAVE - 1)) >= count) return;
+    } else if (ga.list && ((ga.tree && pauli_tree_takes(count, ga.difficulty, a.B, ga.n_cx)) || (tid & ~(uint64_t)(QG_WAVE - 1)) >= count)) {
+        // (before the tables are brought in: most calls with a list leave here -- ptile_reset_tree_kernel has taken it, or the wave lies past it)
+        return;
+    }
     const bool cx_in_lds = pt_gen_tables_load(ga, tb);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     uint64_t env = tid;
-    if (ga.list) {
+    if (ga.mask) {
         if (tid >= count) return;
-        env = ga.list[tid];
-    } else {
+        env = done_mask_nth<64>(ga.mask, ga.mask_words, mask_part, (uint32_t)tid);
+    } else if (ga.list) {
         if (env >= a.B) return;
         if (ga.only_done && !a.done[env]) return;
     }
@@ -1607,10 +1639,19 @@ __global__ __launch_bounds__(256) void ptile_reset_tree_kernel(PTGenArgs ga) {
     __shared__ PTGenTables tb;
     __shared__ uint64_t rows_out[64];
     __shared__ uint64_t pre_draws[QG_TREE_THREADS];
-    const uint32_t count = ga.list_count[0];
+    uint32_t count;
+    __shared__ uint32_t mask_part[256 + 1 + 5];
+    DoneMaskShare share;
+    if (ga.mask) {  // the step before left its finishers as bits: count them (a hint word with another number: nobody finished)
+        done_mask_load(ga.mask, a.B, ga.mask_words, share);
+        count = *done_mask_hint(ga.mask, a.B) != ga.mask_epoch ? 0u : done_mask_scan(share, mask_part);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *ga.count_pub = count;  // (for the generate launch behind this one)
+    } else {
+        count = ga.list_count[0];
+    }
     if (!pauli_tree_takes(count, ga.difficulty, a.B, ga.n_cx) || blockIdx.x >= count) return;  // (uniform per workgroup)
     (void)pt_gen_tables_load(ga, tb);
-    const uint64_t env = ga.list[blockIdx.x];
+    const uint64_t env = ga.mask ? done_mask_find(ga.mask, ga.mask_words, share, mask_part, blockIdx.x) : ga.list[blockIdx.x];
     const uint32_t N = a.N, lane = threadIdx.x & (QG_WAVE - 1);
     PTStream rng{(ga.seed + QG_CLOCK_SEED_STRIDE * clock_of(a.clock)) ^ 0x7061756Cull, a.env_base + env, 0};
     pre_draws[threadIdx.x] = rng_draw(rng.seed, rng.env, threadIdx.x);  // the label generator's draws, one per thread (it rarely needs more than 256)
@@ -1696,7 +1737,10 @@ static hipError_t pt_launch_step(const PTArgs &pa, hipStream_t s) {
     switch (plan::pauli_step_kernel_of(pa.s.flags, pa.s.T, PTLayout<NQ, RM>::COMPACT, pa.n_perms != 0)) {  // qgym_plan.hpp
     case plan::SK_PTILE_STEP1C:
         if constexpr (PTLayout<NQ, RM>::COMPACT) {
-            if (feat) hipLaunchKernelGGL((ptile_step1c_kernel<NQ, RM, true>), grid, block, 0, s, pa);
+            const bool list = (pa.s.flags & F_DONE_LIST) && pa.s.done_mask;
+            if (feat && list) hipLaunchKernelGGL((ptile_step1c_kernel<NQ, RM, true, true>), grid, block, 0, s, pa);
+            else if (feat) hipLaunchKernelGGL((ptile_step1c_kernel<NQ, RM, true>), grid, block, 0, s, pa);
+            else if (list) hipLaunchKernelGGL((ptile_step1c_kernel<NQ, RM, false, true>), grid, block, 0, s, pa);
             else hipLaunchKernelGGL((ptile_step1c_kernel<NQ, RM, false>), grid, block, 0, s, pa);
         }
         break;
@@ -1860,7 +1904,7 @@ static hipError_t pt_launch_generate(const PTGenArgs &pa, hipStream_t s) {
 static hipError_t ptile_generate(const qg_vec *v, const PTGenArgs &pa, hipStream_t s) { PT_DISPATCH(pt_launch_generate) }
 
 // PauliEnv::reset for the whole batch (or, with only_done, for the finished episodes) on the device
-int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s) {
+int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s, bool from_mask) {
     const uint32_t n = v->N;
     if (!v->d_gen_tables) {  // coupling-graph tables, once per handle (PauliEnv::new, pauli.rs:360-370)
         std::vector<uint8_t> cx;
@@ -1936,7 +1980,13 @@ int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s) 
     const int64_t d = (int64_t)v->cfg.depth_slope * v->difficulty;  // pauli.rs:578
     ga.depth_value = (int32_t)std::min<int64_t>(d, v->cfg.max_depth);
     ga.only_done = only_done ? 1u : 0u;
-    if (only_done && v->done_list && v->B > QG_COMPACT_MIN_ENVS) {  // pack the finished envs: full waves instead of one live lane in every wave
+    if (only_done && from_mask && v->done_mask[0]) {  // the step before left its finishers as bits: no compaction launch
+        ga.mask = v->done_mask[v->mask_cur];
+        ga.mask_words = (uint32_t)(4 * ((v->B + 255) / 256));
+        ga.mask_epoch = v->mask_epoch[v->mask_cur];
+        ga.count_pub = v->done_list + v->B;
+        ga.tree = (ga.difficulty >= plan::TREE_MIN_DRAWS && v->B / 32u >= 1u && pauli_tree_takes(1u, ga.difficulty, v->B, ga.n_cx)) ? 1u : 0u;
+    } else if (only_done && v->done_list && v->B > QG_COMPACT_MIN_ENVS) {  // pack the finished envs: full waves instead of one live lane in every wave
         HIP_TRY(compact_done(v->done, v->B, v->done_list, v->done_list + v->B, s));
         ga.list = v->done_list;
         ga.list_count = v->done_list + v->B;

@@ -36,7 +36,7 @@ enum : uint32_t { M_NOP = 0, M_H = 1, M_S = 2, M_SX = 3, M_CNOT = 4 };
 
 // PTILE (thread-per-env) family: kernels_pauli_tile.hip
 int ptile_alloc(qg_vec *v);
-int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s);
+int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s, bool from_mask = false);
 int ptile_upload(qg_vec *v, const HostNet &h, bool do_clean, int32_t depth_value, hipStream_t s);
 hipError_t ptile_step(const qg_vec *v, const StepArgs &a, hipStream_t s);
 hipError_t ptile_export(const qg_vec *v, const ObsArgs &a, hipStream_t s);

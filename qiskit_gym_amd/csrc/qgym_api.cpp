@@ -560,9 +560,11 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
         HIP_TRY_V(hipMalloc(&p->done_list_alt, sizeof(uint32_t) * (batch + 2)));
         HIP_TRY_V(hipMemset(p->done_list_alt + batch, 0, 2 * sizeof(uint32_t)));
     }
-    if (hp.has_done_list && v->layout == LAYOUT_TILE) {  // the finished envs of a step as one bit each (qm_step1 / qm_inv2 <LIST>)
-        HIP_TRY_V(hipHostMalloc((void **)&p->count_seen, sizeof(uint32_t), hipHostMallocMapped));
-        *p->count_seen = 0xFFFFFFFFu;
+    if (hp.has_done_list && (v->layout == LAYOUT_TILE || v->layout == LAYOUT_PAULI)) {  // the finished envs of a step as one bit each (qm_step1 / qm_inv2 / ptile_step1c <LIST>)
+        if (v->layout == LAYOUT_TILE) {
+            HIP_TRY_V(hipHostMalloc((void **)&p->count_seen, sizeof(uint32_t), hipHostMallocMapped));
+            *p->count_seen = 0xFFFFFFFFu;
+        }
         const size_t mask_bytes = 10 * 4 * ((batch + 255) / 256) + 8;  // device_common.hpp done_mask_bytes: a word per wave of the step grid (whole workgroups of 256 envs), then a count byte per 32 envs
         for (auto &m : p->done_mask) {
             HIP_TRY_V(hipMalloc(&m, mask_bytes));
@@ -851,7 +853,12 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
     const bool trusted = done_list_session(v, s);
     if (!only_done)
         if (int rc = drop_done_list(v, s)) return rc;
-    if (only_done && v->layout == LAYOUT_PAULI) return ptile_reset_seeded(v, seed, true, s);
+    if (only_done && v->layout == LAYOUT_PAULI) {
+        const bool from_mask = trusted && v->done_list_fresh && v->mask_fresh;  // the step before (ptile_step1c_kernel<LIST>) left its finishers as bits
+        v->done_list_fresh = v->mask_fresh = false;
+        v->auto_list = true;  // (from now on single steps leave their finishers themselves)
+        return ptile_reset_seeded(v, seed, true, s, from_mask);
+    }
     if (v->layout == LAYOUT_PAULI) {
         if (actions_dev) return set_error(QG_ERR_UNSUPPORTED, "PauliEnv reset draws a whole target, not `difficulty` actions: use qg_vec_reset(seed) or qg_vec_pauli_reset_from");
         return pauli_reset_seeded(v, seed, s);
@@ -994,13 +1001,14 @@ int qg_vec_reset_with(qg_vec *v, const int32_t *actions_dev, size_t n_draws, voi
 // leaves the list of the envs it finished itself, and the reset that follows needs no compaction launch.
 static bool step_leaves_done_list(const qg_vec *v, StepArgs &a) {
     const bool tile32 = v->layout == LAYOUT_TILE, tile64 = v->layout == LAYOUT_TILE64;  // qm_step1 / qm_inv2 (N <= 16), q64_step1 / q64_inv2
-    const bool lists = v->auto_list && (tile32 || tile64) && v->done_list &&
-                       ((v->flags & F_INVERTS) ? (v->has_z && (tile64 || v->nxp <= 16) && !v->maybe_nonsymplectic) : v->bad != nullptr);
+    const bool pauli = v->layout == LAYOUT_PAULI && v->done_mask[0] && v->pt_nq <= 24 && v->pt_rm == 8 && v->B > QG_COMPACT_MIN_ENVS;  // ptile_step1c_kernel (compact layout)
+    const bool lists = v->auto_list && v->done_list &&
+                       (pauli || ((tile32 || tile64) && ((v->flags & F_INVERTS) ? (v->has_z && (tile64 || v->nxp <= 16) && !v->maybe_nonsymplectic) : v->bad != nullptr)));
     if (lists) {
         a.flags |= F_DONE_LIST;
         a.done_list = v->done_list;
         a.done_count = v->done_list + v->B;
-        if (tile32) {  // one bit per env instead of an append (the list stays empty)
+        if (tile32 || pauli) {  // one bit per env instead of an append (the list stays empty)
             a.done_mask = v->done_mask[v->mask_cur ^ 1];
             a.done_epoch = mask_epoch_of(v);
         }
