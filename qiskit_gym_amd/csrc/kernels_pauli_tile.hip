@@ -1566,6 +1566,9 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
         if (tid >= count) return;
         env = done_mask_nth<64>(ga.mask, ga.mask_words, mask_part, (uint32_t)tid);
     } else if (ga.list) {
+        if (tid >= count) return;
+        env = ga.list[tid];
+    } else {
         if (env >= a.B) return;
         if (ga.only_done && !a.done[env]) return;
     }
