@@ -628,3 +628,59 @@ def test_finishers_left_as_a_mask_at_assorted_batch_sizes(kind, n, B, inverts):
             resets += int(f.sum())
     assert resets > B
     assert np.array_equal(gv.observe().cpu().numpy().reshape(B, -1), ov.observe_dense()), "final states"
+
+
+@pytest.mark.parametrize("L,stagger", [(40, True), (3, False)])
+def test_pauli_finishers_left_as_a_mask_by_the_step(L, stagger):
+    """PauliGym 20q (compact layout) x 8 192 in a collector's loop: ptile_step1c_kernel<LIST> leaves its finishers as one bit per env, qg_vec_reset_done's
+    workgroups count the mask themselves -- no compaction launch.  stagger: episodes of 40 steps whose ends are spread over time (1 / 40 of the batch
+    per step: <= B / 32, a tree per finished env); else episodes of 3 steps, a third of the batch finishing in every step (the per-lane generator,
+    its entries found by a search over the partial sums).  Every env against the oracle after every step: reward bits, is_final, and the
+    observation (the regenerated targets) at the end."""
+    from oracle import OracleVec
+    from qiskit_gym_amd.vec import VecEnv
+
+    n, B = 20, 8192
+    gs = line_gateset("pauli", n)
+    A = len(gs)
+    cfg = dict(add_perms=False, track_solution=False, max_rotations=5, difficulty=64, pauli_diff_scale=8, depth_slope=1, max_depth=L)
+    gv = VecEnv("pauli", n, gs, B, **cfg)
+    ov = OracleVec(OracleEnv("pauli", n, gs, **{k: int(v) for k, v in cfg.items()}), B)
+    gv.reset(5)
+    ov.reset_seeded(5)
+    gen = torch.Generator(device="cuda").manual_seed(L)
+    ids = np.arange(B)
+    all_env = torch.arange(B, device="cuda")
+
+    def step_and_check(t):
+        acts = torch.randint(0, A, (B,), dtype=torch.int32, device="cuda", generator=gen)
+        gv.step(acts)
+        r, s, f, d = ov.step(acts.cpu().numpy())
+        gv.sync()
+        assert np.array_equal(f32_bits(gv.reward.cpu().numpy()), f32_bits(r)), t
+        assert np.array_equal(gv.done.cpu().numpy(), f), (t, np.nonzero(gv.done.cpu().numpy() != f)[0][:8])
+        return f
+
+    t = 0
+    if stagger:
+        for k in range(L):  # Env::reset for class k at time k (the caller raises the flags: these resets compact a list from them)
+            f = step_and_check(t)
+            t += 1
+            gv.reset_done(100 + k)
+            ov.reset_seeded(100 + k, mask=f)
+            gv.done[all_env % L == k] = 1
+            gv.reset_done(5000 + k)
+            ov.reset_seeded(5000 + k, mask=(ids % L == k))
+    resets = 0
+    for k in range(L + 12 if stagger else 12):
+        f = step_and_check(t)
+        t += 1
+        frac = f.mean()
+        if stagger:
+            assert frac <= 1.0 / 32, frac  # short enough for the trees
+        gv.reset_done(9000 + k)  # (the step before left the mask)
+        ov.reset_seeded(9000 + k, mask=f)
+        resets += int(f.sum())
+    assert resets > (B if stagger else 3 * B)
+    gv.sync()
+    assert np.array_equal(gv.observe().cpu().numpy().reshape(B, -1), ov.observe_dense()), "states and regenerated targets"
