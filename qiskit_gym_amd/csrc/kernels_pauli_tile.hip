@@ -1987,7 +1987,7 @@ int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s, 
         ga.mask = v->done_mask[v->mask_cur];
         ga.mask_words = (uint32_t)(4 * ((v->B + 255) / 256));
         ga.mask_epoch = v->mask_epoch[v->mask_cur];
-        ga.count_pub = v->done_list + v->B;
+        ga.count_pub = v->mask_count;
         ga.tree = (ga.difficulty >= plan::TREE_MIN_DRAWS && v->B / 32u >= 1u && pauli_tree_takes(1u, ga.difficulty, v->B, ga.n_cx)) ? 1u : 0u;
     } else if (only_done && v->done_list && v->B > QG_COMPACT_MIN_ENVS) {  // pack the finished envs: full waves instead of one live lane in every wave
         HIP_TRY(compact_done(v->done, v->B, v->done_list, v->done_list + v->B, s));

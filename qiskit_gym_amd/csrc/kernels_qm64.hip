@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256) void q64_inv2_kernel(StepArgs a) {
         if (fault) atomicOr(&a.error[env], fault);
         if (a.bad) reinterpret_cast<uint64_t *>(a.bad)[env] = (uint64_t)bad;  // the one-step kernel may run next
     }
-    if (a.flags & F_DONE_LIST) done_list_append(a.done_list, a.done_count, h == 0 && (depth == 0 || solved), env, a.B);
+    if (a.flags & F_DONE_LIST) done_mask_store_pairs(a.done_mask, a.B, h == 0 && (depth == 0 || solved), tid, a.done_epoch);  // (every lane still alive)
 }
 
 // One step per launch without holding the matrix (see qm_step1_kernel in kernels_qm.hip): the gate's
@@ -635,17 +635,16 @@ __device__ __forceinline__ bool q64_step1_body(const StepArgs &a, uint64_t env) 
     if (FEAT && fault) atomicOr(&a.error[env], fault);
     return depth == 0 || solved;
 }
-// (LIST: Q64_LIST_BLOCK threads per workgroup and one turn at the list's counter per workgroup -- done_list_append_block; a turn per wave with
-// a finished env was ~400 turns of ~12 ns at 65 536 envs)
-constexpr unsigned Q64_LIST_BLOCK = 1024;
+// (LIST: the envs that finish are left as one bit each in StepArgs::done_mask -- the wave's ballot, device_common.hpp done_mask_store; round 4 appended
+// their indices to a list with one atomic per workgroup of 1 024 threads)
 template <int NS, bool HAS_Z, bool FEAT, bool LIST = false>
-__global__ __launch_bounds__(LIST ? Q64_LIST_BLOCK : 256) void q64_step1_kernel(StepArgs a) {
+__global__ __launch_bounds__(256) void q64_step1_kernel(StepArgs a) {
     KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
     const uint64_t env = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     QG_PREFETCH_STEP_ARGS(a);  // qgym_internal.hpp
-    if constexpr (LIST) {  // every thread reaches the workgroup-wide append; qg_vec_reset_done follows (qgym_api.cpp)
+    if constexpr (LIST) {  // every thread reaches the wave's ballot; qg_vec_reset_done follows (qgym_api.cpp)
         const bool fin = env < a.B && q64_step1_body<NS, HAS_Z, FEAT>(a, env);
-        done_list_append_block<Q64_LIST_BLOCK / 64>(a.done_list, a.done_count, fin, env, a.B);
+        done_mask_store(a.done_mask, a.B, fin, env, a.done_epoch);
     } else {
         if (env >= a.B) return;
         (void)q64_step1_body<NS, HAS_Z, FEAT>(a, env);
@@ -687,13 +686,39 @@ __device__ inline void q64_init_finish(const InitArgs &a, uint64_t env, const Q6
 
 template <int NS, bool HAS_Z>
 __global__ __launch_bounds__(64) void q64_init_kernel(InitArgs a) {
+    KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
     using Rows = Q64Rows<NS>;
     // reset scramble on LDS-resident rows (device_common.hpp); one wave per block: NS * 512 B <= 32 KiB
     __shared__ uint64_t lds_rows[NS][QG_WAVE];
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t env = tid;
     Rows s;
-    if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
+    if (a.mask) {  // qg_vec_reset_done after a step that left its finishers as bits (the workgroup is one wave): count them, entry i by a search
+        __shared__ uint32_t mask_part[64 + 1 + 5];
+        uint32_t count = 0;
+        if (a.coop && a.n_draws >= 64u && a.tree_grid) {  // (q64_reset_tree_kernel ran before this launch and left the count: most calls leave here)
+            count = *a.count_pub;
+            if (!count || tree_takes(count, a.n_draws)) return;
+        }
+        DoneMaskShare share;
+        done_mask_load<64>(a.mask, a.B, a.mask_words, share);
+        count = *done_mask_hint(a.mask, a.B) != a.mask_epoch ? 0u : done_mask_scan<64>(share, mask_part);
+        const uint64_t *mask = a.mask;
+        const uint32_t words = a.mask_words;
+        auto entry = [=](uint32_t i) -> uint32_t { return done_mask_nth<64>(mask, words, mask_part, i); };
+        if (a.coop && coop_takes(count, a.B)) {  // few finished envs: 16 lanes each
+            const uint32_t N = a.N;
+            const uint64_t *rows = scramble_coop<uint64_t, NS>(a, count, &lds_rows[0][0], env, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); },
+                                                               blockIdx.x, entry);
+            if (!rows) return;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) s.r[k] = rows[k];
+            q64_init_finish<NS, HAS_Z>(a, env, s);
+            return;
+        }
+        if (tid >= count) return;
+        env = entry((uint32_t)tid);
+    } else if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
         const uint32_t len = a.list_count[0];
         const uint32_t count = list_count_take(a.list_count, len, (uint64_t)len * ((a.coop && coop_takes(len, a.B)) ? QG_COOP_LANES : 1u), blockIdx.x, a.zero_count);
         // (without reader tickets -- InitArgs::zero_count -- the list q64_reset_tree_kernel has taken is still there: the same test says so)
@@ -870,9 +895,10 @@ static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
     const bool extra = feat || a.T != 1 || a.rewards_seq || a.dones_seq;
     switch (plan::tile64_step(a.flags, a.T, a.bad != nullptr, a.rewards_seq || a.dones_seq, a.num_actions, HAS_Z)) {  // qgym_plan.hpp
     case plan::SK_Q64_STEP1:  // the env.step() path
-        if (feat && list) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, true, true>), dim3(grid_for(a.B, Q64_LIST_BLOCK)), dim3(Q64_LIST_BLOCK), 0, s, a);
+        if (list && !a.done_mask) return hipErrorInvalidValue;  // (qgym_api.cpp step_leaves_done_list gives every list-leaving step a mask)
+        if (feat && list) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, true, true>), grid, block, 0, s, a);
         else if (feat) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, true>), grid, block, 0, s, a);
-        else if (list) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, false, true>), dim3(grid_for(a.B, Q64_LIST_BLOCK)), dim3(Q64_LIST_BLOCK), 0, s, a);
+        else if (list) hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, false, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((q64_step1_kernel<NS, HAS_Z, false>), grid, block, 0, s, a);
         return hipGetLastError();
     case plan::SK_Q64_FUSED_LDS: {  // plain fused rollout: rows in LDS, one wave per workgroup
@@ -914,17 +940,27 @@ static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
 // init kernel takes it as before.
 template <int NS, bool HAS_Z>
 __global__ __launch_bounds__(256) void q64_reset_tree_kernel(InitArgs a) {
+    KernelClock kclk(a.tree_kclk, a.kclk_waves);  // device_common.hpp
     __shared__ uint64_t prod[4][64];
     __shared__ RowopMasks64 tree_gates[4][QG_WAVE];
-    const uint32_t len = a.list_count[0];
+    __shared__ uint32_t mask_part[256 + 1 + 5];
+    uint32_t len;
+    if (a.mask) {  // the step before left its finishers as bits: every workgroup counts them (a hint word with another number: nobody finished)
+        DoneMaskShare share;
+        done_mask_load(a.mask, a.B, a.mask_words, share);
+        len = *done_mask_hint(a.mask, a.B) != a.mask_epoch ? 0u : done_mask_scan(share, mask_part);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *a.count_pub = len;  // (for q64_init_kernel, the launch behind this one)
+    } else {
+        len = a.list_count[0];
+    }
     if (!tree_takes(len, a.n_draws)) return;
-    const uint32_t count = list_count_take(a.list_count, len, (uint64_t)(len < gridDim.x ? len : gridDim.x) * QG_TREE_THREADS, blockIdx.x, a.zero_count);
+    const uint32_t count = a.mask ? len : list_count_take(a.list_count, len, (uint64_t)(len < gridDim.x ? len : gridDim.x) * QG_TREE_THREADS, blockIdx.x, a.zero_count);
     const uint32_t N = a.N;
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
     // entry blockIdx.x of the list, then + gridDim.x, ...: the launch has plan::tree_grid workgroups for a list of any (tree) length
     for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
         if (item != blockIdx.x) __syncthreads();  // (the previous round's LDS has been read)
-        const uint64_t env = a.list[item];
+        const uint64_t env = a.mask ? done_mask_nth(a.mask, a.mask_words, mask_part, item) : a.list[item];
         uint64_t myrow = 0;
         // q64_init_finish with the wave's 64 lanes: lane s holds the row of slot s (scramble_tree64 runs on the transpose), stores its 8 bytes of the
         // env's tile and compares with the identity's; lane 0 writes the scalars (reset_internals, clifford.rs:272-283)

@@ -224,7 +224,7 @@ static int vec_free_buffers(qg_vec *v) {
     void *ptrs[] = {v->state, v->own_depth ? v->depth : nullptr, v->own_reward ? v->reward : nullptr,
                     v->own_done ? v->done : nullptr, v->own_success ? v->success : nullptr, v->inverted, v->own_error ? v->error : nullptr, v->sol,
                     v->sol_len, v->layers, v->d_gates, v->d_descs, v->scratch, v->d_prog,
-                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad, v->done_list, v->done_list_alt, v->done_list_spare, v->done_mask[0], v->done_mask[1], v->d_rowops, v->embed_dump, v->host_in, v->host_obs, v->fault_scratch};
+                    v->d_qubit_perms, v->d_act_perms, v->perm_idx, v->d_gen_tables, v->d_nonsymp, v->bad, v->done_list, v->done_list_alt, v->done_list_spare, v->done_mask[0], v->done_mask[1], v->mask_count, v->d_rowops, v->embed_dump, v->host_in, v->host_obs, v->fault_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &g : v->graphs) {
@@ -358,6 +358,7 @@ static void fill_init_args(const qg_vec *v, InitArgs &a) {
 
 static hipError_t launch_init(const qg_vec *v, const InitArgs &a_in, hipStream_t s) {
     InitArgs a = a_in;
+    if (v->layout == LAYOUT_TILE64 && a.list && a.coop && a.n_draws >= 64u && a.tree_grid) a.tree_kclk = kernel_clock_slot(v);  // (kernels_qm64.hip q64_launch_init: two launches)
     a.kclk = kernel_clock_slot(v);
     a.kclk_waves = v->kclk_waves;
     switch (v->layout) {
@@ -560,10 +561,13 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
         HIP_TRY_V(hipMalloc(&p->done_list_alt, sizeof(uint32_t) * (batch + 2)));
         HIP_TRY_V(hipMemset(p->done_list_alt + batch, 0, 2 * sizeof(uint32_t)));
     }
-    if (hp.has_done_list && (v->layout == LAYOUT_TILE || v->layout == LAYOUT_PAULI)) {  // the finished envs of a step as one bit each (qm_step1 / qm_inv2 / ptile_step1c <LIST>)
+    if (hp.has_done_list && (v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_PAULI)) {  // the finished envs of a step as one bit each (qm_step1 / qm_inv2 / q64_step1 / q64_inv2 / ptile_step1c <LIST>)
         if (v->layout == LAYOUT_TILE) {
             HIP_TRY_V(hipHostMalloc((void **)&p->count_seen, sizeof(uint32_t), hipHostMallocMapped));
             *p->count_seen = 0xFFFFFFFFu;
+        } else {
+            HIP_TRY_V(hipMalloc(&p->mask_count, 2 * sizeof(uint32_t)));
+            HIP_TRY_V(hipMemset(p->mask_count, 0, 2 * sizeof(uint32_t)));
         }
         const size_t mask_bytes = 10 * 4 * ((batch + 255) / 256) + 8;  // device_common.hpp done_mask_bytes: a word per wave of the step grid (whole workgroups of 256 envs), then a count byte per 32 envs
         for (auto &m : p->done_mask) {
@@ -893,6 +897,7 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
             ia.mask = v->done_mask[v->mask_cur];
             ia.mask_words = (uint32_t)(4 * ((v->B + 255) / 256));
             ia.mask_epoch = v->mask_epoch[v->mask_cur];
+            ia.count_pub = v->mask_count;
         }
         v->mask_fresh = false;
         ia.coop = plan::reset_coop_allowed(actions_dev != nullptr, v->B, v->d_rowops != nullptr) ? 1u : 0u;
@@ -1008,7 +1013,7 @@ static bool step_leaves_done_list(const qg_vec *v, StepArgs &a) {
         a.flags |= F_DONE_LIST;
         a.done_list = v->done_list;
         a.done_count = v->done_list + v->B;
-        if (tile32 || pauli) {  // one bit per env instead of an append (the list stays empty)
+        if (v->done_mask[0]) {  // one bit per env instead of an append (the list stays empty)
             a.done_mask = v->done_mask[v->mask_cur ^ 1];
             a.done_epoch = mask_epoch_of(v);
         }

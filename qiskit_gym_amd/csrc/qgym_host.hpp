@@ -128,6 +128,7 @@ struct qg_vec {
     // TILE: the finished envs of a step as one bit per env (StepArgs::done_mask), two buffers -- a list-leaving step (or the fused reset + step
     // launch, which reads the current one) writes the other one, then they trade places.  Nothing to zero: a launch rewrites every word.
     uint64_t *done_mask[2] = {nullptr, nullptr};
+    uint32_t *mask_count = nullptr;     // TILE64 / PauliEnv: a device word where a reset's first launch leaves the mask's count for its second
     int mask_cur = 0;
     uint32_t mask_epoch[2] = {0, 0};    // StepArgs::done_epoch of the launch that wrote each buffer (InitArgs::mask_epoch for its reader)
     bool mask_fresh = false;            // done_mask[mask_cur] (+ the list in done_list: envs reset and final again inside the fused launch; else empty) holds

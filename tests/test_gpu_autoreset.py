@@ -588,7 +588,8 @@ def test_word_layouts_reset_finished_envs_on_16_lanes_each_and_in_the_step_launc
 
 @pytest.mark.parametrize("kind,n,B,inverts", [("clifford", 16, 64, False), ("clifford", 16, 100, True), ("clifford", 9, 257, False), ("linear_function", 20, 1000, False),
                                               ("clifford", 16, 20000, True), ("clifford", 16, 70000, False), ("clifford", 12, 200000, True),
-                                              ("linear_function", 32, 300001, False)])
+                                              ("linear_function", 32, 300001, False), ("clifford", 24, 5000, True), ("clifford", 20, 66001, False),
+                                              ("clifford", 32, 100, True), ("linear_function", 17, 37, False)])
 def test_finishers_left_as_a_mask_at_assorted_batch_sizes(kind, n, B, inverts):
     """The step leaves its finishers as one bit per env and qg_vec_reset_done's workgroups count the mask themselves (device_common.hpp done_mask_*): batches
     below one wave, with ragged last waves and workgroups, and beyond 65 536 envs, where a thread's share of the mask is more than four words and the
@@ -684,3 +685,56 @@ def test_pauli_finishers_left_as_a_mask_by_the_step(L, stagger):
     assert resets > (B if stagger else 3 * B)
     gv.sync()
     assert np.array_equal(gv.observe().cpu().numpy().reshape(B, -1), ov.observe_dense()), "states and regenerated targets"
+
+
+@pytest.mark.parametrize("kind,n,inverts", [("clifford", 24, True), ("clifford", 20, False), ("linear_function", 32, False), ("clifford", 16, True)])
+def test_staggered_finishers_left_as_a_mask_are_reset_by_trees(kind, n, inverts):
+    """A collector's loop whose episodes (40 steps, 70 scramble gates) end spread over time: 1 / 40 of 8 192 envs per step -- <= B / 32, so
+    qg_vec_reset_done runs a tree per finished env (q64_reset_tree_kernel / the tree workgroups of qm_init_block), its entries found in the mask the
+    step left (TILE64: the tree launch counts the mask and leaves the count for q64_init_kernel, which has nothing to do).  Every env against the
+    oracle after every step, and the states at the end."""
+    from oracle import OracleVec
+    from qiskit_gym_amd.vec import VecEnv
+    from test_gpu_fullsize import _coins
+
+    B, L, diff = 8192, 40, 70
+    gs = line_gateset(kind, n)
+    A = len(gs)
+    cfg = dict(add_inverts=inverts, add_perms=False, track_solution=False, difficulty=diff, depth_slope=1, max_depth=L)
+    gv = VecEnv(kind, n, gs, B, seed=77, **cfg)
+    ov = OracleVec(OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()}), B)
+    gv.reset(5)
+    ov.reset_seeded(5)
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    ids = np.arange(B)
+    all_env = torch.arange(B, device="cuda")
+    t = 0
+
+    def step_and_check():
+        nonlocal t
+        acts = torch.randint(0, A, (B,), dtype=torch.int32, device="cuda", generator=gen)
+        gv.set_counters(t, 0)
+        gv.step(acts)
+        r, s, f, d = ov.step(acts.cpu().numpy(), _coins(77, ids, t) if inverts else None)
+        gv.sync()
+        assert np.array_equal(f32_bits(gv.reward.cpu().numpy()), f32_bits(r)), t
+        assert np.array_equal(gv.done.cpu().numpy(), f) and np.array_equal(gv.depth.cpu().numpy(), d), (t, np.nonzero(gv.done.cpu().numpy() != f)[0][:8])
+        t += 1
+        return f
+
+    for k in range(L):  # Env::reset for class k at time k (the caller raises the flags: these resets compact a list from them)
+        f = step_and_check()
+        gv.reset_done(100 + k)
+        ov.reset_seeded(100 + k, mask=f)
+        gv.done[all_env % L == k] = 1
+        gv.reset_done(5000 + k)
+        ov.reset_seeded(5000 + k, mask=(ids % L == k))
+    resets = 0
+    for k in range(L + 6):
+        f = step_and_check()
+        assert 0 < f.mean() <= 1.0 / 32, f.mean()  # short enough for the trees
+        gv.reset_done(9000 + k)  # (the step before left the mask)
+        ov.reset_seeded(9000 + k, mask=f)
+        resets += int(f.sum())
+    assert resets > B
+    assert np.array_equal(gv.observe().cpu().numpy().reshape(B, -1), ov.observe_dense()), "final states"

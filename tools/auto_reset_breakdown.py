@@ -130,9 +130,16 @@ def main():
         env = VecEnv("linear_function", 8, gs2, nb, add_inverts=False, add_perms=False, track_solution=False, difficulty=64)
         run(f"LinearFunctionGym 8q x {nb}, one launch per pair (word_reset_step_kernel)", env, len(gs2), 1, ["reset + step"], True, out)
         del env
+    gs24 = line_gateset("clifford", 24)
+    for label, kw, step in (("plain options", dict(add_inverts=False, track_solution=False), "q64_step1_kernel<LIST>"),
+                            ("reference defaults (add_inverts, solution log)", dict(add_inverts=True, track_solution=True), "q64_inv2_kernel")):
+        env = VecEnv("clifford", 24, gs24, B, add_perms=False, difficulty=256, **kw)
+        run(f"CliffordGym 24q, {label} (tree + init + step per pair; the step leaves its finishers as a mask)", env, len(gs24), 3,
+            ["q64_reset_tree_kernel", "q64_init_kernel", step], True, out, reset_slots=2)
+        del env
     gs5 = line_gateset("pauli", 20)
     env = VecEnv("pauli", 20, gs5, B, add_perms=False, track_solution=False, max_rotations=5, difficulty=256, pauli_diff_scale=8)
-    run("PauliGym 20q (compact_done + tree + generate + step per pair)", env, len(gs5), 3,
+    run("PauliGym 20q (tree + generate + step per pair; the step leaves its finishers as a mask)", env, len(gs5), 3,
         ["ptile_reset_tree_kernel", "ptile_generate_kernel", "ptile_step1c_kernel"], True, out, reset_slots=2)
     del env
     if args.out:
