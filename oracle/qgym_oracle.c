@@ -971,8 +971,11 @@ int og_pauli_reset_from(og_env *e, const uint8_t *tableau, const char *labels, s
 
 /* ------------------------------------------------------------------------------------------
  * PauliEnv::reset target generator (rust/src/envs/pauli.rs:54-271, 554-586).
- * The reference draws from rand::thread_rng(); here every draw comes from the counter RNG
- * `rng_draw(seed ^ 0x7061756C, env_index, k)`, k = 0,1,2,... (the same stream libqgym uses), with
+ * The reference draws from rand::thread_rng(); here every draw comes from the counter RNG, two streams per
+ * env (the same ones libqgym uses): the rotation labels (generate_paulis_with_difficulty) take
+ * `rng_draw(seed ^ 0x7061756C, env_index, k)`, k = 0,1,2,..., and random_clifford_tableau's gate `it` takes
+ * `rng_draw(seed ^ 0x7461626C, env_index, 2 it)` (its kind) and `(.., 2 it + 1)` (which pair / qubit) --
+ * thread_rng's draws are i.i.d., so which draw feeds which decision leaves the distribution unchanged -- with
  *   gen_range(0..n) = mulhi64(u, n)        gen::<f32>() = (u >> 40) * 2^-24.
  * `for q in &qubits` iterates a HashSet in the reference (random order); the per-qubit axis draws
  * are i.i.d., so iterating in ascending order leaves the distribution unchanged.
@@ -1096,7 +1099,9 @@ int og_pauli_reset_seeded(og_env *e, uint64_t seed, uint64_t env_index) {
     uint8_t *tab = (uint8_t *)malloc(dim * dim ? dim * dim : 1);
     mat_identity(tab, dim);
     if (e->difficulty != 0 && np != 0) {
+        rng.seed = seed ^ 0x7461626Cull; /* the tableau's own stream: gate `it` at k = 2 it, 2 it + 1 */
         for (size_t it = 0; it < e->difficulty; it++) {
+            rng.k = 2 * (uint64_t)it;
             const float r = og_f32(&rng);
             if (r > 0.3f) {
                 const size_t k = og_range(&rng, np), q0 = pa[2 * k], q1 = pa[2 * k + 1];

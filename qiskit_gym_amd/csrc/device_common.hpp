@@ -153,8 +153,10 @@ __device__ inline void done_mask_load(const uint64_t *mask, uint64_t B, uint32_t
     const uint8_t *cnt = done_mask_counts(mask, B);
     sh.bits = 0;
     if (chunk == 4u) {  // 8 count bytes
-        const uint2 v = reinterpret_cast<const uint2 *>(cnt)[threadIdx.x];
-        sh.bits = byte_sum4(v.x) + byte_sum4(v.y);
+        if (4u * threadIdx.x < words) {  // (T need not divide the words: ptile_reset_tree_kernel's 320 threads)
+            const uint2 v = reinterpret_cast<const uint2 *>(cnt)[threadIdx.x];
+            sh.bits = byte_sum4(v.x) + byte_sum4(v.y);
+        }
     } else if ((chunk & 3u) == 0u) {  // whole 8-byte pieces
         for (uint32_t k = 0; k < chunk; k += 4u) {
             const uint32_t w = threadIdx.x * chunk + k;
@@ -174,7 +176,7 @@ __device__ inline void done_mask_load(const uint64_t *mask, uint64_t B, uint32_t
     }
 }
 template <uint32_t T = 256>
-__device__ inline uint32_t done_mask_scan(DoneMaskShare &sh, uint32_t *part /* LDS [T + 1 + 5] */) {
+__device__ inline uint32_t done_mask_scan(DoneMaskShare &sh, uint32_t *part /* LDS [T + 2 + T / 64] (T + 1 + 5 holds 64 and 256) */) {
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
     uint32_t incl = sh.bits;
 #pragma unroll
@@ -234,9 +236,9 @@ __device__ inline uint32_t done_mask_nth(const uint64_t *mask, uint32_t words, c
 }
 template <uint32_t T = 256>
 __device__ inline uint32_t done_mask_find(const uint64_t *mask, uint32_t words, const DoneMaskShare &sh, uint32_t *part, uint32_t i) {
-    if (sh.before <= i && i < sh.before + sh.bits) part[T + 5u] = done_mask_in_chunk<T>(mask, words, threadIdx.x, i - sh.before);  // exactly one thread
+    if (sh.before <= i && i < sh.before + sh.bits) part[T + 1u + T / 64u] = done_mask_in_chunk<T>(mask, words, threadIdx.x, i - sh.before);  // exactly one thread
     __syncthreads();
-    return part[T + 5u];
+    return part[T + 1u + T / 64u];
 }
 
 #define QG_COOP_LANES qg::plan::COOP_LANES  // lanes per env of the cooperative scramble (scramble_coop below; qgym_plan.hpp)
@@ -409,6 +411,9 @@ __device__ inline uint32_t both_halves_xor(uint32_t v) {  // v of lane hl ^ v of
     return sw[0] ^ sw[1];
 }
 __device__ inline uint32_t lower_half_on_both(uint32_t v) { return __builtin_amdgcn_permlane32_swap(v, v, false, false)[0]; }
+// a ^ (b & c) as ONE v_bitop3_b32 (gfx950; truth table from a = 0xF0, b = 0xCC, c = 0xAA).  The scramble chains and the GF(2) products below are
+// bound by their instruction count (a lone wave issues one instruction every ~5 cycles), and this pair is most of what they do
+__device__ inline uint32_t xor_and(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x78); }
 template <int R>
 __device__ inline uint32_t gf2_cols_product_halves(const uint32_t *a_cols, uint32_t b, uint32_t half) {
     constexpr int H = (R + 1) / 2;
@@ -416,12 +421,12 @@ __device__ inline uint32_t gf2_cols_product_halves(const uint32_t *a_cols, uint3
     const uint32_t bs = b >> (H * half);
     uint32_t acc = 0;
 #pragma unroll 8
-    for (int i = 0; i < H; ++i) acc ^= (H + i < R || !half ? ac[i] : 0u) & (uint32_t)__builtin_amdgcn_sbfe((int32_t)bs, (uint32_t)i, 1u);
+    for (int i = 0; i < H; ++i) acc = xor_and(acc, H + i < R || !half ? ac[i] : 0u, (uint32_t)__builtin_amdgcn_sbfe((int32_t)bs, (uint32_t)i, 1u));
     return both_halves_xor(acc);
 }
 // one row operation in the parity form (see above)
 __device__ inline void rowop_parity(uint32_t &col, uint32_t test, uint32_t flip) {
-    col ^= (uint32_t)__builtin_amdgcn_sbfe((int32_t)__builtin_popcount(col & test), 0u, 1u) & flip;
+    col = xor_and(col, (uint32_t)__builtin_amdgcn_sbfe((int32_t)__builtin_popcount(col & test), 0u, 1u), flip);
 }
 // the four masks {test0, flip0, test1, flip1} of a gate word (two row operations, make_op with slot indices, 14 bits each)
 // (`transposed`: the masks of the row operation's transpose -- row[src] ^= row[dst]; the swap is symmetric)
@@ -512,10 +517,16 @@ __device__ inline bool scramble_tree(const InitArgs &a, uint64_t env, uint32_t &
 __device__ inline int64_t bit_mask64(uint64_t v, uint32_t off) { return (int64_t)(v << (63u - off)) >> 63; }  // bit `off` as 0 / -1
 template <int R>
 __device__ inline uint64_t gf2_cols_product64(const uint64_t *a_cols, uint64_t b) {
-    uint64_t acc = 0;
+    const uint32_t blo = (uint32_t)b, bhi = (uint32_t)(b >> 32);
+    uint32_t lo = 0, hi = 0;
 #pragma unroll
-    for (int sl = 0; sl < R; ++sl) acc ^= a_cols[sl] & (uint64_t)bit_mask64(b, (uint32_t)sl);
-    return acc;
+    for (int sl = 0; sl < R; ++sl) {  // one v_bfe_i32 per slot (a 64-bit shift pair in round 4), then the column's halves
+        const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int32_t)(sl < 32 ? blo : bhi), (uint32_t)(sl & 31), 1u);
+        const uint64_t c = a_cols[sl];
+        lo = xor_and(lo, (uint32_t)c, m);
+        hi = xor_and(hi, (uint32_t)(c >> 32), m);
+    }
+    return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 // Returns true on ALL lanes of wave 0, whose `col_out` is then the env's ROW of slot `lane` (the tree runs on the transpose, see scramble_tree:
 // a row per lane is what q64_reset_tree_kernel's finish wants -- 64 row words in one lane's registers cost 450 registers and scratch).
@@ -538,62 +549,91 @@ __device__ inline RowopMasks64 rowop_masks64(uint32_t o, bool transposed = false
     half(o >> 14, r.t1, r.f1);
     return r;
 }
-// `gates`: 4 x 64 RowopMasks64 of LDS (8 KiB): the drawing lane decodes its gate into the four parity-test masks, the serial loop reads them
-// back as a broadcast, two gates ahead (scramble_tree's scheme; a 64-column matrix fills the wave, so a wave runs one segment: four segments)
-// `op_of(t)`: the row-operation word of gate t (two make_op halves, slot indices), t < n_gates; call from all 256 threads of the workgroup.
-template <int R, typename Identity, typename OpOf>
+// `gates`: WAVES x 64 RowopMasks64 of LDS (8 KiB at four waves): the drawing lane decodes its gate into the four parity-test masks (64 gates decoded
+// at once), the serial loop reads them back as broadcasts.  A 64-column matrix fills the wave, so a wave runs one segment.  What bounds the chain is
+// the INSTRUCTION COUNT per gate, not a latency: at 512 trees per launch every SIMD holds two of these waves, each issues one instruction every
+// ~5 cycles, and the vector unit takes 4 cycles per instruction whatever wave it comes from.  Round 4's loop spent 22 vector instructions a gate on
+// 64-bit C++ (95 ns a gate, 6.1 of q64_reset_tree_kernel's 13.2 us at 256 gates); on 32-bit halves a parity is and, and, bcnt, bcnt, bfe and two
+// v_bitop3 (a ^ (b & c)): 14 a gate.  Measured and dropped (EXPERIMENTS.md round 5): decoding on the scalar unit from a v_readlane of the gate word (no
+// LDS; +4 us: ~50 scalar instructions a gate issue at the same 5 cycles each), eight waves of 32 gates (+4 us with it: twice the waves per SIMD, one more
+// level of products).
+// `op_of(t)`: the row-operation word of gate t (two make_op halves, slot indices), t < n_gates; call from all threads of the workgroup.
+__device__ inline void rowop_parity64_halves(uint32_t &lo, uint32_t &hi, uint32_t tlo, uint32_t thi, uint32_t flo, uint32_t fhi) {
+    const uint32_t c = (uint32_t)__builtin_popcount(hi & thi) + (uint32_t)__builtin_popcount(lo & tlo);  // v_bcnt_u32_b32, accumulating
+    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int32_t)c, 0u, 1u);  // parity as 0 / -1
+    lo = xor_and(lo, m, flo);
+    hi = xor_and(hi, m, fhi);
+}
+template <int R, int WAVES = 4, typename Identity, typename OpOf>
 __device__ inline bool scramble_tree64_ops(uint32_t n_gates, uint64_t &col_out, uint64_t (*prod)[64], RowopMasks64 (*gates)[QG_WAVE], Identity identity, OpOf op_of) {
     static_assert(R <= 64, "one uint64 of slots per column");
+    static_assert(WAVES == 4 || WAVES == 8 || WAVES == 16, "the workgroup's waves: a power of two");
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1), w = threadIdx.x >> 6;
-    // the transpose, as scramble_tree: tree place w holds segment k = 3 - w, its gates last one first and transposed; segment 0's place
+    // the transpose, as scramble_tree: tree place w holds segment k = WAVES - 1 - w, its gates last one first and transposed; segment 0's place
     // multiplies S0^T on at the end.  Lane s of wave 0 ends with the row of slot s.
-    const uint32_t seg = (n_gates + 3u) / 4u, k = 3u - w;
+    const uint32_t seg = (n_gates + (uint32_t)WAVES - 1u) / (uint32_t)WAVES, k = (uint32_t)WAVES - 1u - w;
     const uint32_t t0 = k * seg < n_gates ? k * seg : n_gates, t1 = (t0 + seg < n_gates) ? t0 + seg : n_gates, len = t1 - t0;
     uint64_t col = lane < (uint32_t)R ? 1ull << lane : 0ull;
-    RowopMasks64 *mine = gates[w];
+    uint32_t lo = (uint32_t)col, hi = (uint32_t)(col >> 32);
+    const uint4 *mine = reinterpret_cast<const uint4 *>(gates[w]);
     for (uint32_t c0 = 0; c0 < len; c0 += QG_WAVE) {  // 64 gates per pass
         const uint32_t u = c0 + lane;  // the u-th gate this place applies: the segment's gate len - 1 - u
+#if defined(QG_ABLATE_TREE64) && (QG_ABLATE_TREE64 & 2)
+        const uint32_t o = 0u;
+#else
         const uint32_t o = u < len ? op_of(t0 + (len - 1u - u)) : 0u;  // past the end: "no gate"
+#endif
         __builtin_amdgcn_wave_barrier();  // (the previous pass has read its masks)
-        mine[lane] = rowop_masks64(o, true);
+        gates[w][lane] = rowop_masks64(o, true);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint32_t left = len - c0, steps = left < QG_WAVE ? left : QG_WAVE;
-        RowopMasks64 g[2] = {mine[0], mine[1]};
-        for (uint32_t kk = 0; kk < steps; kk += 2u) {
-            const RowopMasks64 n0 = mine[(kk + 2u) & 63u], n1 = mine[(kk + 3u) & 63u];  // the next two gates fly while these two are applied
+#if defined(QG_ABLATE_TREE64) && (QG_ABLATE_TREE64 & 1)
+        const uint32_t steps = 0;
+#else
+        const uint32_t left = len - c0;
+        const uint32_t steps = (uint32_t)__builtin_amdgcn_readfirstlane((int)(left < QG_WAVE ? left : QG_WAVE));  // wave-uniform: a scalar loop
+#endif
+        for (uint32_t kk = 0; kk < steps; kk += 4u) {  // (entries past `steps` in the last group of four are past the segment's end: zero masks)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {  // (an entry past `steps` is past the segment's end: zero masks)
-                rowop_parity64(col, g[q].t0, g[q].f0);
-                rowop_parity64(col, g[q].t1, g[q].f1);
+            for (uint32_t q = 0; q < 4u; ++q) {
+                const uint4 g0 = mine[2u * ((kk + q) & 63u)], g1 = mine[2u * ((kk + q) & 63u) + 1u];  // {test, flip} of the gate's first and second row operation
+                rowop_parity64_halves(lo, hi, g0.x, g0.y, g0.z, g0.w);
+                rowop_parity64_halves(lo, hi, g1.x, g1.y, g1.z, g1.w);
             }
-            g[0] = n0;
-            g[1] = n1;
         }
     }
+    col = (uint64_t)lo | ((uint64_t)hi << 32);
     if (k == 0) {  // S0^T on the left (clifford.rs:307)
         uint64_t acc = 0;
 #pragma unroll 8
         for (int sl = 0; sl < R; ++sl) acc ^= identity((uint32_t)sl) & (uint64_t)bit_mask64(col, (uint32_t)sl);
         col = acc;
     }
-    if (w & 1u) prod[w][lane] = col;
-    __syncthreads();
-    if (!(w & 1u)) col = gf2_cols_product64<R>(prod[w + 1u], col);
-    if (w == 2u) prod[2][lane] = col;
-    __syncthreads();
+#if defined(QG_ABLATE_TREE64) && (QG_ABLATE_TREE64 & 4)
     if (w != 0) return false;
-    col_out = gf2_cols_product64<R>(prod[2], col);
+    col_out = col;
+    return true;
+#endif
+    // (W1 W0), (W3 W2), ...; then pairs of those; ...: wave w + s publishes, wave w multiplies it on
+#pragma unroll
+    for (uint32_t s = 1; s < (uint32_t)WAVES; s <<= 1) {
+        const uint32_t at = w & (2u * s - 1u);
+        if (at == s) prod[w][lane] = col;  // (at == s: the wave's lower bits are zero, i.e. it multiplied at every level before)
+        __syncthreads();                   // (every wave of the workgroup, at every level)
+        if (at == 0u) col = gf2_cols_product64<R>(prod[w + s], col);
+    }
+    if (w != 0) return false;
+    col_out = col;
     return true;
 }
-template <int R, typename Identity>
+template <int R, int WAVES, typename Identity>
 __device__ inline bool scramble_tree64(const InitArgs &a, uint64_t env, uint64_t &col_out, uint64_t (*prod)[64], RowopMasks64 (*gates)[QG_WAVE],
                                        Identity identity) {
     const uint64_t seed = init_seed(a), e = a.env_base + env;
     const uint32_t *rowops = a.rowops;
     const uint32_t num_actions = a.num_actions;
-    return scramble_tree64_ops<R>(a.n_draws, col_out, prod, gates, identity,
-                                  [=](uint32_t t) -> uint32_t { return rowops[rng_action(seed, e, t, num_actions)]; });
+    return scramble_tree64_ops<R, WAVES>(a.n_draws, col_out, prod, gates, identity,
+                                         [=](uint32_t t) -> uint32_t { return rowops[rng_action(seed, e, t, num_actions)]; });
 }
 
 template <typename W, int R>

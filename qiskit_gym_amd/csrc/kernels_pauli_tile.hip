@@ -1271,8 +1271,8 @@ __global__ __launch_bounds__(256) void ptile_export_kernel(PTObsArgs pa) {
 // ------------------------------------------------------------------------------------------------
 // PauliEnv::reset on the device (pauli.rs:554-586): the random target generator
 // (get_pauli_under_diff / generate_paulis_with_difficulty / random_clifford_tableau, pauli.rs:115-271)
-// one env per lane, every draw from the counter-RNG stream rng_draw(seed ^ 0x7061756C, env, k),
-// k = 0, 1, 2, ... -- the stream the oracle-side tests replay -- followed
+// one env per lane, every draw from the env's two counter-RNG streams (PT_STREAM_LABELS, PT_STREAM_TABLEAU below)
+// -- the streams the oracle-side tests replay -- followed
 // by the initial clean and the scalar resets.  Coupling-graph tables come from the host.
 // ------------------------------------------------------------------------------------------------
 struct PTGenArgs {
@@ -1302,6 +1302,12 @@ using plan::pauli_tree_takes;  // short lists of long scrambles: a workgroup per
 
 // `pre`: the stream's first `n_pre` draws computed ahead, one per thread, and parked in LDS (ptile_reset_tree_kernel): the label generator's draws
 // depend on each other through what they decide, two splitmix64 rounds each (~0.15 us) -- a counter RNG's draw k depends on k alone
+// The generator's two streams of one env: the rotation labels draw rng_draw(seed ^ PT_STREAM_LABELS, env, 0, 1, 2, ...), the tableau's gate `it` draws
+// rng_draw(seed ^ PT_STREAM_TABLEAU, env, 2 it) (its kind) and (.., 2 it + 1) (which pair / qubit).  Until round 5 the tableau went on where the labels
+// had stopped in ONE stream, so its first draw's index was known only after the labels: ptile_reset_tree_kernel's scramble (7.4 us) waited for the
+// labels (7.5 us).  The reference draws everything from rand::thread_rng() (pauli.rs:560-575): i.i.d. draws, whatever their order
+// (oracle/qgym_oracle.c og_pauli_reset_seeded restates the same two streams).
+constexpr uint64_t PT_STREAM_LABELS = 0x7061756Cull, PT_STREAM_TABLEAU = 0x7461626Cull;
 struct PTStream {
     uint64_t seed, env, k;
     const uint64_t *pre = nullptr;
@@ -1533,6 +1539,50 @@ __device__ inline void pt_gen_finish(const PTGenArgs &ga, PTState<NQ, RM> &s, ui
     }
 }
 
+// pt_gen_finish by the 64 lanes of one wave (ptile_reset_tree_kernel; all of them call it, converged, with the same labels in `s`): `rows[k]` = the
+// tableau's row of slot k (X[q] = slot q, Z[q] = slot NQ + q, in LDS).  Lane q packs and stores qubit q's group and its {xs, zs} bytes -- one lane doing
+// all NQ of them was ~2 300 instructions at 5 cycles each, 4.6 us of the kernel -- the clean is the same work on every lane, lane 0 writes the rest.
+template <int NQ, int RM>
+__device__ inline void pt_gen_finish_wave(const PTGenArgs &ga, PTState<NQ, RM> &s, uint64_t env, uint32_t N, const uint64_t *rows) {
+    using L = PTLayout<NQ, RM>;
+    const StepArgs &a = ga.s;
+    const uint32_t lane = threadIdx.x & (QG_WAVE - 1), le = (uint32_t)(env & (QG_WAVE - 1));
+    char *tile = L::tile(a.state, env);
+    const bool q_lane = lane < (uint32_t)NQ;
+    const uint64_t X = q_lane ? rows[lane] : 0ull, Z = q_lane ? rows[(uint32_t)NQ + lane] : 0ull;
+    const uint64_t ix = lane < N ? 1ull << lane : 0ull, iz = lane < N ? (1ull << N) << lane : 0ull;
+    s.bad = (uint32_t)__ballot(q_lane && (X != ix || Z != iz));  // pt_badmask
+    uint32_t n_removed = 0, fault = 0;  // clean initially trivial rotations (pauli.rs:576)
+    uint64_t rem_pos[(RM + 7) / 8];
+#pragma unroll
+    for (int i = 0; i < (RM + 7) / 8; ++i) rem_pos[i] = 0;
+    pt_clean<NQ, RM>(s, n_removed, fault, SolLog{nullptr, 0}, rem_pos);
+    const bool solved = pt_solved<NQ, RM>(s);
+    if (q_lane) L::store_qubit(tile, le, lane, X, Z);
+    if constexpr (L::COMPACT) {
+        if (q_lane) pt_store_xz<NQ, RM>(tile, le, s, lane);
+        if (lane == 0) pt_store_rotmeta<NQ, RM>(tile, le, s, true);
+    } else {
+        if (lane == 0) pt_store_rotations<NQ, RM>(tile, le, s, ~0u, ~0u, true);
+    }
+    if (lane != 0) return;
+    pt_store_meta<NQ, RM>(tile, le, s);
+    a.depth[env] = ga.depth_value;  // pauli.rs:578-585
+    a.success[env] = (uint8_t)solved;
+    a.reward[env] = solved ? 1.0f : 0.0f;
+    a.done[env] = (uint8_t)(ga.depth_value == 0 || solved);
+    a.inverted[env] = 0;
+    a.error[env] = fault;
+    a.sol_len[env * 2] = 0;
+    a.sol_len[env * 2 + 1] = 0;
+    if (a.layers) {
+        const LayerRec lay = layer_rec(a.layers, env, (2 * N + 2));
+        for (uint32_t i = 0; i < 2 * N; ++i) lay[i] = -1;
+        lay[2 * N] = 0;
+        lay[2 * N + 1] = 0;
+    }
+}
+
 template <int NQ, int RM>
 __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
     KernelClock kclk(ga.s.kclk, ga.s.kclk_waves);  // device_common.hpp
@@ -1574,7 +1624,8 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
     }
     const uint32_t L = threadIdx.x & (QG_WAVE - 1);
     const uint32_t N = a.N;
-    PTStream rng{(ga.seed + QG_CLOCK_SEED_STRIDE * clock_of(a.clock)) ^ 0x7061756Cull, a.env_base + env, 0};
+    const uint64_t base_seed = ga.seed + QG_CLOCK_SEED_STRIDE * clock_of(a.clock);
+    PTStream rng{base_seed ^ PT_STREAM_LABELS, a.env_base + env, 0};
     PTState<NQ, RM> s;
     (void)pt_gen_labels<NQ, RM>(ga, tb, rng, s, N);
 
@@ -1586,15 +1637,15 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
         lds_tab[NQ + j][L] = (uint32_t)j < N ? (1ull << N) << j : 0ull;
     }
     if (ga.difficulty != 0 && ga.n_cx != 0) {
-        // gate `it` takes draws k0 + 2 it (kind) and k0 + 2 it + 1 (which pair / qubit) of the env's stream: the counter RNG makes every draw a
+        // gate `it` takes draws 2 it (kind) and 2 it + 1 (which pair / qubit) of the env's tableau stream: the counter RNG makes every draw a
         // function of its index, so four gates' draws are computed ahead of the dependent chain of LDS row operations
-        const uint64_t k0 = rng.k;
+        const uint64_t tseed = base_seed ^ PT_STREAM_TABLEAU;
         for (uint32_t it0 = 0; it0 < ga.difficulty; it0 += 4) {
             uint64_t d1[4], d2[4];
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
-                d1[j] = rng_draw(rng.seed, rng.env, k0 + 2ull * (it0 + j));
-                d2[j] = rng_draw(rng.seed, rng.env, k0 + 2ull * (it0 + j) + 1ull);
+                d1[j] = rng_draw(tseed, rng.env, 2ull * (it0 + j));
+                d2[j] = rng_draw(tseed, rng.env, 2ull * (it0 + j) + 1ull);
             }
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
@@ -1617,7 +1668,6 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
                 }
             }
         }
-        rng.k = k0 + 2ull * ga.difficulty;
     }
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
@@ -1629,11 +1679,13 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
 
 // qg_vec_reset_done with a short list of long scrambles (pt_tree_takes): a workgroup per listed env.  A lane of the kernel above spends most
 // of its time on the scramble's 2 x `difficulty` draws (four 64-bit multiplies each) and on the dependent chain of row operations behind
-// them; here every thread draws ONE gate and the chain is cut in four and multiplied back (scramble_tree64_ops, device_common.hpp; the
-// tableau's 2 NQ <= 64 rows are the slots, X[q] = slot q, Z[q] = slot NQ + q).  The labels are generated by every thread alike (uniform
-// work: it costs what one lane costs, and tells everybody where the scramble's draws start); lane 0 of wave 0 takes the rows and finishes.
+// them; here every thread of waves 0 .. 3 draws ONE gate and the chain is cut in four and multiplied back (scramble_tree64_ops, device_common.hpp; the
+// tableau's 2 NQ <= 64 rows are the slots, X[q] = slot q, Z[q] = slot NQ + q) WHILE the fifth wave generates the labels (pt_gen_labels_wave: the two
+// draw from separate streams), then takes the rows from LDS and finishes the env on its 64 lanes (pt_gen_finish_wave).  What is left is one lone wave's
+// instruction stream at ~5 cycles an instruction: the labels' ~3 700.
+constexpr uint32_t PT_TREE_THREADS = QG_TREE_THREADS + QG_WAVE;  // four waves of scramble + the labels' wave
 template <int NQ, int RM>
-__global__ __launch_bounds__(256) void ptile_reset_tree_kernel(PTGenArgs ga) {
+__global__ __launch_bounds__(PT_TREE_THREADS) void ptile_reset_tree_kernel(PTGenArgs ga) {
     KernelClock kclk(ga.tree_kclk, ga.s.kclk_waves);  // device_common.hpp
     const StepArgs &a = ga.s;
     constexpr int R = 2 * NQ;
@@ -1643,48 +1695,44 @@ __global__ __launch_bounds__(256) void ptile_reset_tree_kernel(PTGenArgs ga) {
     __shared__ uint64_t rows_out[64];
     __shared__ uint64_t pre_draws[QG_TREE_THREADS];
     uint32_t count;
-    __shared__ uint32_t mask_part[256 + 1 + 5];
+    __shared__ uint32_t mask_part[PT_TREE_THREADS + 2 + PT_TREE_THREADS / 64];
     DoneMaskShare share;
     if (ga.mask) {  // the step before left its finishers as bits: count them (a hint word with another number: nobody finished)
-        done_mask_load(ga.mask, a.B, ga.mask_words, share);
-        count = *done_mask_hint(ga.mask, a.B) != ga.mask_epoch ? 0u : done_mask_scan(share, mask_part);
+        done_mask_load<PT_TREE_THREADS>(ga.mask, a.B, ga.mask_words, share);
+        count = *done_mask_hint(ga.mask, a.B) != ga.mask_epoch ? 0u : done_mask_scan<PT_TREE_THREADS>(share, mask_part);
         if (blockIdx.x == 0 && threadIdx.x == 0) *ga.count_pub = count;  // (for the generate launch behind this one)
     } else {
         count = ga.list_count[0];
     }
     if (!pauli_tree_takes(count, ga.difficulty, a.B, ga.n_cx) || blockIdx.x >= count) return;  // (uniform per workgroup)
     (void)pt_gen_tables_load(ga, tb);
-    const uint64_t env = ga.mask ? done_mask_find(ga.mask, ga.mask_words, share, mask_part, blockIdx.x) : ga.list[blockIdx.x];
-    const uint32_t N = a.N, lane = threadIdx.x & (QG_WAVE - 1);
-    PTStream rng{(ga.seed + QG_CLOCK_SEED_STRIDE * clock_of(a.clock)) ^ 0x7061756Cull, a.env_base + env, 0};
-    pre_draws[threadIdx.x] = rng_draw(rng.seed, rng.env, threadIdx.x);  // the label generator's draws, one per thread (it rarely needs more than 256)
-    __syncthreads();
+    const uint64_t env = ga.mask ? done_mask_find<PT_TREE_THREADS>(ga.mask, ga.mask_words, share, mask_part, blockIdx.x) : ga.list[blockIdx.x];
+    const uint32_t N = a.N, lane = threadIdx.x & (QG_WAVE - 1), wave = threadIdx.x >> 6;
+    const uint64_t base_seed = ga.seed + QG_CLOCK_SEED_STRIDE * clock_of(a.clock), renv = a.env_base + env;
+    PTStream rng{base_seed ^ PT_STREAM_LABELS, renv, 0};
+    if (threadIdx.x < QG_TREE_THREADS) pre_draws[threadIdx.x] = rng_draw(rng.seed, rng.env, threadIdx.x);  // the label generator's draws, one per thread (it rarely needs more)
+    __syncthreads();  // (the tables, the draws -- and, with a list, the entry -- are in LDS)
     rng.pre = pre_draws;
     rng.n_pre = QG_TREE_THREADS;
-#if defined(QG_PT_STOP) && QG_PT_STOP == 1  // development: phase timing by truncation (tools/build_variant.sh)
-    return;
-#endif
-    PTState<NQ, RM> s;
-    // the labels on wave 0 alone (its lane 0 finishes the env; the others need only where the scramble's draws start): four waves walking the
-    // same tables kept each other waiting for LDS
-    __shared__ uint64_t k0_shared;
-    if (threadIdx.x < QG_WAVE) {
+    // Every wave reaches the two barriers of scramble_tree64_ops' products and the one below, in this order.
+    if (wave == 4u) {  // the labels, beside the scramble
+        PTState<NQ, RM> s;
         (void)pt_gen_labels_wave<NQ, RM>(ga, tb, rng, s, N);
-        if (threadIdx.x == 0) k0_shared = rng.k;
+        __syncthreads();  // (level 1 of the products)
+        __syncthreads();  // (level 2)
+        __syncthreads();  // rows_out is written
+        pt_gen_finish_wave<NQ, RM>(ga, s, env, N, rows_out);
+        return;
     }
-    __syncthreads();
-    const uint64_t k0 = k0_shared, seed = rng.seed, renv = rng.env;
-#if defined(QG_PT_STOP) && QG_PT_STOP == 2
-    if (k0 != 0x123456789ull) return;
-#endif
     const uint32_t n_cx = ga.n_cx;
     const uint8_t *cx = tb.cx;
+    const uint64_t tseed = base_seed ^ PT_STREAM_TABLEAU;
     uint64_t row = 0;
     const bool finisher = scramble_tree64_ops<R>(
         ga.difficulty, row, prod, tree_gates,
         [N](uint32_t k) -> uint64_t { const uint32_t j = k < (uint32_t)NQ ? k : k - (uint32_t)NQ; return j < N ? (k < (uint32_t)NQ ? 1ull << j : (1ull << N) << j) : 0ull; },
         [=](uint32_t it) -> uint32_t {  // random_clifford_tableau's gate `it` as two row operations (pauli.rs:220-271)
-            const uint64_t d1 = rng_draw(seed, renv, k0 + 2ull * it), d2 = rng_draw(seed, renv, k0 + 2ull * it + 1ull);
+            const uint64_t d1 = rng_draw(tseed, renv, 2ull * it), d2 = rng_draw(tseed, renv, 2ull * it + 1ull);
             const float r = (float)(d1 >> 40) * (1.0f / 16777216.0f);
             if (r > 0.3f) {  // CX: row q1 ^= row q0 ; row n+q0 ^= row n+q1 (q0 == q1: a row xor-ed into itself is zero, in this form too)
                 const uint32_t k = (uint32_t)__umul64hi(d2, (uint64_t)n_cx);
@@ -1695,20 +1743,8 @@ __global__ __launch_bounds__(256) void ptile_reset_tree_kernel(PTGenArgs ga) {
             if (r > 0.15f) return make_op(OP_SWAP, q, (uint32_t)NQ + q);  // H: swap rows q, n+q
             return make_op(OP_XOR, (uint32_t)NQ + q, q);                    // S: row n+q ^= row q
         });
-    if (!finisher) return;  // wave 0 goes on: lane s holds the row of slot s
-#if defined(QG_PT_STOP) && QG_PT_STOP == 3
-    if (row != 0x123456789ull) return;
-#endif
-    rows_out[lane] = row;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane != 0) return;
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-        s.X[j] = rows_out[j];
-        s.Z[j] = rows_out[NQ + j];
-    }
-    pt_gen_finish<NQ, RM>(ga, s, env, N);
+    if (finisher) rows_out[lane] = row;  // wave 0: lane s holds the row of slot s
+    __syncthreads();
 }
 
 static inline unsigned grid_for(uint64_t threads, unsigned block) { return (unsigned)((threads + block - 1) / block); }
@@ -1899,7 +1935,7 @@ template <int NQ, int RM>
 static hipError_t pt_launch_generate(const PTGenArgs &pa, hipStream_t s) {
     if (pa.tree) {  // up to B / 32 listed envs get a workgroup each; the workgroups past the list leave at once
         const uint64_t blocks = pa.s.B / 32u;
-        hipLaunchKernelGGL((ptile_reset_tree_kernel<NQ, RM>), dim3((unsigned)blocks), dim3(plan::TREE_THREADS), 0, s, pa);
+        hipLaunchKernelGGL((ptile_reset_tree_kernel<NQ, RM>), dim3((unsigned)blocks), dim3(PT_TREE_THREADS), 0, s, pa);
     }
     hipLaunchKernelGGL((ptile_generate_kernel<NQ, RM>), dim3(grid_for(pa.s.B, 64)), dim3(64), 0, s, pa);
     return hipGetLastError();

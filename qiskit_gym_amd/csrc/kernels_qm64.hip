@@ -938,33 +938,37 @@ static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
 // in the same call and consumes the list (the ticket of list_count_take zeroes it, or -- no tickets, InitArgs::zero_count -- the init kernel applies
 // the same test), so that the init kernel finds nothing to do; when the list is too long or the scramble too short it leaves the list alone and the
 // init kernel takes it as before.
+// Q64_TREE_WAVES waves per workgroup, each with n / 4 gates of the chain, then two levels of products (eight waves measured: slower, device_common.hpp
+// scramble_tree64_ops)
+constexpr int Q64_TREE_WAVES = 4;
+constexpr uint32_t Q64_TREE_THREADS = 64u * Q64_TREE_WAVES;
 template <int NS, bool HAS_Z>
-__global__ __launch_bounds__(256) void q64_reset_tree_kernel(InitArgs a) {
+__global__ __launch_bounds__(Q64_TREE_THREADS) void q64_reset_tree_kernel(InitArgs a) {
     KernelClock kclk(a.tree_kclk, a.kclk_waves);  // device_common.hpp
-    __shared__ uint64_t prod[4][64];
-    __shared__ RowopMasks64 tree_gates[4][QG_WAVE];
-    __shared__ uint32_t mask_part[256 + 1 + 5];
+    __shared__ uint64_t prod[Q64_TREE_WAVES][64];
+    __shared__ RowopMasks64 tree_gates[Q64_TREE_WAVES][QG_WAVE];
+    __shared__ uint32_t mask_part[Q64_TREE_THREADS + 2 + Q64_TREE_WAVES];
     uint32_t len;
     if (a.mask) {  // the step before left its finishers as bits: every workgroup counts them (a hint word with another number: nobody finished)
         DoneMaskShare share;
-        done_mask_load(a.mask, a.B, a.mask_words, share);
-        len = *done_mask_hint(a.mask, a.B) != a.mask_epoch ? 0u : done_mask_scan(share, mask_part);
+        done_mask_load<Q64_TREE_THREADS>(a.mask, a.B, a.mask_words, share);
+        len = *done_mask_hint(a.mask, a.B) != a.mask_epoch ? 0u : done_mask_scan<Q64_TREE_THREADS>(share, mask_part);
         if (blockIdx.x == 0 && threadIdx.x == 0) *a.count_pub = len;  // (for q64_init_kernel, the launch behind this one)
     } else {
         len = a.list_count[0];
     }
     if (!tree_takes(len, a.n_draws)) return;
-    const uint32_t count = a.mask ? len : list_count_take(a.list_count, len, (uint64_t)(len < gridDim.x ? len : gridDim.x) * QG_TREE_THREADS, blockIdx.x, a.zero_count);
+    const uint32_t count = a.mask ? len : list_count_take(a.list_count, len, (uint64_t)(len < gridDim.x ? len : gridDim.x) * Q64_TREE_THREADS, blockIdx.x, a.zero_count);
     const uint32_t N = a.N;
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
     // entry blockIdx.x of the list, then + gridDim.x, ...: the launch has plan::tree_grid workgroups for a list of any (tree) length
     for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
         if (item != blockIdx.x) __syncthreads();  // (the previous round's LDS has been read)
-        const uint64_t env = a.mask ? done_mask_nth(a.mask, a.mask_words, mask_part, item) : a.list[item];
+        const uint64_t env = a.mask ? done_mask_nth<Q64_TREE_THREADS>(a.mask, a.mask_words, mask_part, item) : a.list[item];
         uint64_t myrow = 0;
         // q64_init_finish with the wave's 64 lanes: lane s holds the row of slot s (scramble_tree64 runs on the transpose), stores its 8 bytes of the
         // env's tile and compares with the identity's; lane 0 writes the scalars (reset_internals, clifford.rs:272-283)
-        if (!scramble_tree64<NS>(a, env, myrow, prod, tree_gates, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); })) continue;
+        if (!scramble_tree64<NS, Q64_TREE_WAVES>(a, env, myrow, prod, tree_gates, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); })) continue;
         const uint32_t le = (uint32_t)(env & (QG_WAVE - 1));
         uint64_t *tile = reinterpret_cast<uint64_t *>(reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Q64Rows<NS>::G * 64));
         if (lane < (uint32_t)NS) tile[((uint64_t)(lane >> 1) * 64 + le) * 2 + (lane & 1u)] = myrow;  // group lane / 2, the env's 16-byte piece, its low or high word
@@ -1002,7 +1006,7 @@ template <int NS, bool HAS_Z>
 static hipError_t q64_launch_init(const InitArgs &a, hipStream_t s) {
     if (a.list && a.coop && a.n_draws >= 64u) {
         const uint64_t blocks = a.tree_grid;
-        if (blocks) hipLaunchKernelGGL((q64_reset_tree_kernel<NS, HAS_Z>), dim3((unsigned)blocks), dim3(QG_TREE_THREADS), 0, s, a);
+        if (blocks) hipLaunchKernelGGL((q64_reset_tree_kernel<NS, HAS_Z>), dim3((unsigned)blocks), dim3(Q64_TREE_THREADS), 0, s, a);
     }
     hipLaunchKernelGGL((q64_init_kernel<NS, HAS_Z>), dim3(grid_for(a.B, 64)), dim3(64), 0, s, a);
     return hipGetLastError();

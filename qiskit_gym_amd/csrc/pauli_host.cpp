@@ -199,7 +199,7 @@ int pauli_reset_from(qg_vec *v, const uint8_t *tableaus, const char *labels, con
 
 
 // PauliEnv::reset (pauli.rs:554-586) with its random target generator (pauli.rs:54-271): on the device
-// (ptile_generate_kernel), every draw from the counter-RNG stream rng_draw(seed ^ 0x7061756C, env, k).
+// (ptile_generate_kernel), every draw from the env's two counter-RNG streams (kernels_pauli_tile.hip PT_STREAM_LABELS / PT_STREAM_TABLEAU).
 int pauli_reset_seeded(qg_vec *v, uint64_t seed, hipStream_t s) { return ptile_reset_seeded(v, seed, false, s); }
 
 }  // namespace qg

@@ -14,13 +14,21 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
 
+if os.environ.get("QG_LIB"):  # development: a variant build
+    from qiskit_gym_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(os.environ["QG_LIB"])
 from qiskit_gym_amd.vec import VecEnv
 from util import line_gateset
 
 AT = 128
 
 
+ONLY = None
+
+
 def run(name, env, A, slots_per_pair, labels, fused, out, reset_slots=1):
+    if ONLY and ONLY not in name:
+        return
     dev = env.device
     B = env.batch
     stream = torch.cuda.Stream(device=dev)
@@ -110,7 +118,10 @@ def run(name, env, A, slots_per_pair, labels, fused, out, reset_slots=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
+    ap.add_argument("--only", default=None, help="run the rows whose name holds this text")
     args = ap.parse_args()
+    global ONLY
+    ONLY = args.only
     torch.cuda.set_device(0)
     B = 65536
     gs3 = line_gateset("clifford", 16)
