@@ -1306,7 +1306,7 @@ using plan::pauli_tree_takes;  // short lists of long scrambles: a workgroup per
 // rng_draw(seed ^ PT_STREAM_TABLEAU, env, 2 it) (its kind) and (.., 2 it + 1) (which pair / qubit).  Until round 5 the tableau went on where the labels
 // had stopped in ONE stream, so its first draw's index was known only after the labels: ptile_reset_tree_kernel's scramble (7.4 us) waited for the
 // labels (7.5 us).  The reference draws everything from rand::thread_rng() (pauli.rs:560-575): i.i.d. draws, whatever their order
-// (oracle/qgym_oracle.c og_pauli_reset_seeded restates the same two streams).
+// (the tests' CPU restatement of the generator draws from the same two streams).
 constexpr uint64_t PT_STREAM_LABELS = 0x7061756Cull, PT_STREAM_TABLEAU = 0x7461626Cull;
 struct PTStream {
     uint64_t seed, env, k;
