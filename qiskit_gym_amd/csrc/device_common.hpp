@@ -36,6 +36,23 @@ struct KernelClock {
     KernelClock &operator=(const KernelClock &) = delete;
 };
 
+// Development (-DQG_PHASE_CLOCK, tools/build_variant.sh + tools/phase_clock.py): where inside a kernel the time goes.  Lane 0 of the calling wave of workgroup b
+// stores the clock into the launch's slot at record (waves - 1 - (8 b + idx)) -- the records' upper half, far beyond the grid's own waves (grids of up to
+// waves / 16 workgroups) -- after waiting for the wave's outstanding memory operations, so the stamp says "everything before this line has happened".
+// Compiled out otherwise.
+#ifdef QG_PHASE_CLOCK
+__device__ inline void phase_stamp(unsigned long long *slot, uint32_t waves, uint32_t idx) {
+    const uint32_t at = 8u * blockIdx.x + idx;
+    if (slot && __lane_id() == 0 && idx < 8u && at < waves / 2u) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long t = wall_clock64();
+        *reinterpret_cast<ulonglong2 *>(slot + 2ull * (waves - 1u - at)) = make_ulonglong2(t, t);
+    }
+}
+#else
+__device__ inline void phase_stamp(unsigned long long *, uint32_t, uint32_t) {}
+#endif
+
 __device__ inline int64_t load_action(const void *actions, uint64_t idx, bool act64) {
     return act64 ? reinterpret_cast<const int64_t *>(actions)[idx]
                  : (int64_t) reinterpret_cast<const int32_t *>(actions)[idx];
@@ -564,8 +581,13 @@ __device__ inline void rowop_parity64_halves(uint32_t &lo, uint32_t &hi, uint32_
     lo = xor_and(lo, m, flo);
     hi = xor_and(hi, m, fhi);
 }
+// `ready` (LDS, WAVES words, zero before the first call) and `seq` (a number that grows by log2(WAVES) from one call of the workgroup to the next, starting at 0):
+// the products' levels hand over through these words instead of workgroup barriers -- the publishing wave stores seq + level + 1 behind its column, the
+// multiplying wave polls for it -- so that a workgroup with MORE waves than the scramble's (ptile_reset_tree_kernel: a fifth one generates labels
+// meanwhile) does not have to bring them to every level's barrier.  Null: barriers.  Either way the caller separates two calls by a barrier of its own.
 template <int R, int WAVES = 4, typename Identity, typename OpOf>
-__device__ inline bool scramble_tree64_ops(uint32_t n_gates, uint64_t &col_out, uint64_t (*prod)[64], RowopMasks64 (*gates)[QG_WAVE], Identity identity, OpOf op_of) {
+__device__ inline bool scramble_tree64_ops(uint32_t n_gates, uint64_t &col_out, uint64_t (*prod)[64], RowopMasks64 (*gates)[QG_WAVE], Identity identity, OpOf op_of,
+                                           uint32_t *ready = nullptr, uint32_t seq = 0) {
     static_assert(R <= 64, "one uint64 of slots per column");
     static_assert(WAVES == 4 || WAVES == 8 || WAVES == 16, "the workgroup's waves: a power of two");
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1), w = threadIdx.x >> 6;
@@ -619,7 +641,17 @@ __device__ inline bool scramble_tree64_ops(uint32_t n_gates, uint64_t &col_out, 
     for (uint32_t s = 1; s < (uint32_t)WAVES; s <<= 1) {
         const uint32_t at = w & (2u * s - 1u);
         if (at == s) prod[w][lane] = col;  // (at == s: the wave's lower bits are zero, i.e. it multiplied at every level before)
-        __syncthreads();                   // (every wave of the workgroup, at every level)
+        if (ready) {
+            seq += 1u;
+            if (at == s) {  // the column is in LDS before the word that says so (one wave's LDS operations complete in order; the fence keeps the compiler to it)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(&ready[w], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (at == 0u) {
+                while (__hip_atomic_load(&ready[w + s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) __builtin_amdgcn_s_sleep(1);
+            }
+        } else {
+            __syncthreads();  // (every wave of the workgroup, at every level)
+        }
         if (at == 0u) col = gf2_cols_product64<R>(prod[w + s], col);
     }
     if (w != 0) return false;
@@ -628,9 +660,8 @@ __device__ inline bool scramble_tree64_ops(uint32_t n_gates, uint64_t &col_out, 
 }
 template <int R, int WAVES, typename Identity>
 __device__ inline bool scramble_tree64(const InitArgs &a, uint64_t env, uint64_t &col_out, uint64_t (*prod)[64], RowopMasks64 (*gates)[QG_WAVE],
-                                       Identity identity) {
+                                       const uint32_t *rowops /* InitArgs::rowops, or the caller's copy of it in LDS */, Identity identity) {
     const uint64_t seed = init_seed(a), e = a.env_base + env;
-    const uint32_t *rowops = a.rowops;
     const uint32_t num_actions = a.num_actions;
     return scramble_tree64_ops<R, WAVES>(a.n_draws, col_out, prod, gates, identity,
                                          [=](uint32_t t) -> uint32_t { return rowops[rng_action(seed, e, t, num_actions)]; });

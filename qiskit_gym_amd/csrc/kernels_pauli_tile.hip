@@ -1289,6 +1289,9 @@ struct PTGenArgs {
     uint32_t only_done;
     const uint32_t *list;  // only_done, compacted (compact_done): thread i regenerates env list[i]
     uint32_t *list_count;
+    uint32_t n_pairs;      // doff[nd]
+    uint32_t tree_grid;    // workgroups of the tree launch (entry i on workgroup i mod tree_grid); `count_out`: where it reports the list's length (host memory)
+    uint32_t *count_out;
     uint32_t tree;         // ptile_reset_tree_kernel runs before ptile_generate_kernel and takes the lists pt_tree_takes says it takes
     unsigned long long *tree_kclk;  // qg_vec_set_kernel_clock: the tree launch's slot (the generate launch's is s.kclk)
     // only_done, the finished envs as the bits the step before left (StepArgs::done_mask) instead of a compacted list: every workgroup counts them itself
@@ -1322,20 +1325,45 @@ struct PTStream {
 // behind the draw that picks it (a dependent global load per gate was most of this kernel: 256 gates x ~0.5 us) -- and the label
 // generator's loops walk the distance classes and their qubit pairs with dependent loads, ~40 per rotation label.
 struct PTGenTables {
-    uint8_t cx[2 * PT_CX_LDS];
+    alignas(4) uint8_t cx[2 * PT_CX_LDS];
     uint32_t dvals[32], doff[33];
-    uint8_t pairs[2 * 496];  // N (N - 1) / 2 pairs, N <= 32
+    alignas(4) uint8_t pairs[2 * 496];  // N (N - 1) / 2 pairs, N <= 32
 };
-// copied by the whole workgroup, before any lane leaves; the caller makes the copy visible (wave barrier / __syncthreads)
+// copied by the whole workgroup, before any lane leaves; the caller makes the copy visible (wave barrier / __syncthreads).  Every load is issued before
+// the first LDS store (four copy loops one after the other were four trips to memory one after the other, on every reset's critical path); the tables are
+// 4-byte aligned and padded in the handle's blob (ptile_reset_seeded), so the byte tables move as words.
 __device__ inline bool pt_gen_tables_load(const PTGenArgs &ga, PTGenTables &t) {
     const bool cx_in_lds = ga.n_cx <= PT_CX_LDS;
-    if (cx_in_lds)
-        for (uint32_t i = threadIdx.x; i < 2u * ga.n_cx; i += blockDim.x) t.cx[i] = ga.cx_pairs[i];
     const uint32_t nd = ga.nd < 32u ? ga.nd : 32u;
-    for (uint32_t i = threadIdx.x; i < nd; i += blockDim.x) t.dvals[i] = ga.dvals[i];
-    for (uint32_t i = threadIdx.x; i <= nd; i += blockDim.x) t.doff[i] = ga.doff[i];
-    const uint32_t n_pairs = ga.doff[nd] < 496u ? ga.doff[nd] : 496u;
-    for (uint32_t i = threadIdx.x; i < 2u * n_pairs; i += blockDim.x) t.pairs[i] = ga.pairs[i];
+    const uint32_t n_pairs = ga.n_pairs < 496u ? ga.n_pairs : 496u;  // (= doff[nd]: from the host, not behind a load)
+    const uint32_t cx_words = cx_in_lds ? (2u * ga.n_cx + 3u) / 4u : 0u, pair_words = (2u * n_pairs + 3u) / 4u;  // <= 512, <= 248
+    const uint32_t *cxw = reinterpret_cast<const uint32_t *>(ga.cx_pairs), *pw = reinterpret_cast<const uint32_t *>(ga.pairs);
+    uint32_t *t_cx = reinterpret_cast<uint32_t *>(t.cx), *t_pairs = reinterpret_cast<uint32_t *>(t.pairs);
+    constexpr uint32_t CX_PER = 8, PAIR_PER = 4;  // (a 64-thread workgroup: 512 / 64, 248 / 64)
+    uint32_t cv[CX_PER], pv[PAIR_PER];
+    const uint32_t dv = threadIdx.x < nd ? ga.dvals[threadIdx.x] : 0u, df = threadIdx.x <= nd ? ga.doff[threadIdx.x] : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < CX_PER; ++k) {
+        const uint32_t i = threadIdx.x + k * blockDim.x;
+        cv[k] = i < cx_words ? cxw[i] : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PAIR_PER; ++k) {
+        const uint32_t i = threadIdx.x + k * blockDim.x;
+        pv[k] = i < pair_words ? pw[i] : 0u;
+    }
+    if (threadIdx.x < nd) t.dvals[threadIdx.x] = dv;
+    if (threadIdx.x <= nd) t.doff[threadIdx.x] = df;
+#pragma unroll
+    for (uint32_t k = 0; k < CX_PER; ++k) {
+        const uint32_t i = threadIdx.x + k * blockDim.x;
+        if (i < cx_words) t_cx[i] = cv[k];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PAIR_PER; ++k) {
+        const uint32_t i = threadIdx.x + k * blockDim.x;
+        if (i < pair_words) t_pairs[i] = pv[k];
+    }
     return cx_in_lds;
 }
 
@@ -1697,32 +1725,53 @@ __global__ __launch_bounds__(PT_TREE_THREADS) void ptile_reset_tree_kernel(PTGen
     uint32_t count;
     __shared__ uint32_t mask_part[PT_TREE_THREADS + 2 + PT_TREE_THREADS / 64];
     DoneMaskShare share;
+    // the mask's counts (or the list's length) and the generator's tables in flight together: `opaque_zero` keeps the uniform loads vector loads, which
+    // are waited for where their values are used and not where they are issued (kernels_qm.hip qm_init_block)
+    uint32_t opaque_zero, first_v = 0;
+    asm("v_mov_b32 %0, 0" : "=v"(opaque_zero));
     if (ga.mask) {  // the step before left its finishers as bits: count them (a hint word with another number: nobody finished)
+        first_v = done_mask_hint(ga.mask, a.B)[opaque_zero];
         done_mask_load<PT_TREE_THREADS>(ga.mask, a.B, ga.mask_words, share);
-        count = *done_mask_hint(ga.mask, a.B) != ga.mask_epoch ? 0u : done_mask_scan<PT_TREE_THREADS>(share, mask_part);
+    } else {
+        first_v = ga.list_count[opaque_zero];
+    }
+    asm volatile("" ::: "memory");
+    (void)pt_gen_tables_load(ga, tb);
+    if (ga.mask) {
+        count = (uint32_t)__builtin_amdgcn_readfirstlane((int)first_v) != ga.mask_epoch ? 0u : done_mask_scan<PT_TREE_THREADS>(share, mask_part);
         if (blockIdx.x == 0 && threadIdx.x == 0) *ga.count_pub = count;  // (for the generate launch behind this one)
     } else {
-        count = ga.list_count[0];
+        count = (uint32_t)__builtin_amdgcn_readfirstlane((int)first_v);
     }
-    if (!pauli_tree_takes(count, ga.difficulty, a.B, ga.n_cx) || blockIdx.x >= count) return;  // (uniform per workgroup)
-    (void)pt_gen_tables_load(ga, tb);
-    const uint64_t env = ga.mask ? done_mask_find<PT_TREE_THREADS>(ga.mask, ga.mask_words, share, mask_part, blockIdx.x) : ga.list[blockIdx.x];
+    if (ga.count_out && blockIdx.x == 0 && threadIdx.x == 0) *ga.count_out = count;  // (host memory: sizes the next launches' tree grid)
+    if (threadIdx.x == 0) phase_stamp(ga.tree_kclk, a.kclk_waves, 0);  // the count is known
+    if (!pauli_tree_takes(count, ga.difficulty, a.B, ga.n_cx)) return;  // (uniform per workgroup)
     const uint32_t N = a.N, lane = threadIdx.x & (QG_WAVE - 1), wave = threadIdx.x >> 6;
+    __shared__ uint32_t prod_ready[4];  // scramble_tree64_ops: the products' levels hand over through these (the labels' wave is not part of them)
+    if (threadIdx.x < 4u) prod_ready[threadIdx.x] = 0u;  // (visible after the barrier below)
+    uint32_t prod_seq = 0;
+    // entry blockIdx.x of the list, then + gridDim.x, ...: the launch's grid follows the list lengths the handle has seen, a longer list is walked in rounds
+    for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+    if (item != blockIdx.x) __syncthreads();  // (the previous round's LDS has been read)
+    const uint64_t env = !ga.mask ? ga.list[item]
+                       : item == blockIdx.x ? done_mask_find<PT_TREE_THREADS>(ga.mask, ga.mask_words, share, mask_part, item)
+                                            : done_mask_nth<PT_TREE_THREADS>(ga.mask, ga.mask_words, mask_part, item);
     const uint64_t base_seed = ga.seed + QG_CLOCK_SEED_STRIDE * clock_of(a.clock), renv = a.env_base + env;
     PTStream rng{base_seed ^ PT_STREAM_LABELS, renv, 0};
     if (threadIdx.x < QG_TREE_THREADS) pre_draws[threadIdx.x] = rng_draw(rng.seed, rng.env, threadIdx.x);  // the label generator's draws, one per thread (it rarely needs more)
     __syncthreads();  // (the tables, the draws -- and, with a list, the entry -- are in LDS)
     rng.pre = pre_draws;
     rng.n_pre = QG_TREE_THREADS;
-    // Every wave reaches the two barriers of scramble_tree64_ops' products and the one below, in this order.
+    if ((threadIdx.x & 63u) == 0 && (wave == 0u || wave == 4u)) phase_stamp(ga.tree_kclk, a.kclk_waves, wave == 0u ? 1u : 2u);  // the env and the draws are in LDS
     if (wave == 4u) {  // the labels, beside the scramble
         PTState<NQ, RM> s;
         (void)pt_gen_labels_wave<NQ, RM>(ga, tb, rng, s, N);
-        __syncthreads();  // (level 1 of the products)
-        __syncthreads();  // (level 2)
+        phase_stamp(ga.tree_kclk, a.kclk_waves, 3);  // the labels
         __syncthreads();  // rows_out is written
+        phase_stamp(ga.tree_kclk, a.kclk_waves, 5);  // the rows have arrived
         pt_gen_finish_wave<NQ, RM>(ga, s, env, N, rows_out);
-        return;
+        phase_stamp(ga.tree_kclk, a.kclk_waves, 6);  // everything is stored
+        continue;
     }
     const uint32_t n_cx = ga.n_cx;
     const uint8_t *cx = tb.cx;
@@ -1742,9 +1791,12 @@ __global__ __launch_bounds__(PT_TREE_THREADS) void ptile_reset_tree_kernel(PTGen
             const uint32_t q = (uint32_t)__umul64hi(d2, (uint64_t)N);
             if (r > 0.15f) return make_op(OP_SWAP, q, (uint32_t)NQ + q);  // H: swap rows q, n+q
             return make_op(OP_XOR, (uint32_t)NQ + q, q);                    // S: row n+q ^= row q
-        });
+        }, prod_ready, prod_seq);
+    prod_seq += 2u;  // (two levels)
     if (finisher) rows_out[lane] = row;  // wave 0: lane s holds the row of slot s
+    if (finisher) phase_stamp(ga.tree_kclk, a.kclk_waves, 4);  // the scramble
     __syncthreads();
+    }
 }
 
 static inline unsigned grid_for(uint64_t threads, unsigned block) { return (unsigned)((threads + block - 1) / block); }
@@ -1934,8 +1986,8 @@ hipError_t ptile_observe_typed(qg_vec *v, void *out_dev, int out_dtype, hipStrea
 template <int NQ, int RM>
 static hipError_t pt_launch_generate(const PTGenArgs &pa, hipStream_t s) {
     if (pa.tree) {  // up to B / 32 listed envs get a workgroup each; the workgroups past the list leave at once
-        const uint64_t blocks = pa.s.B / 32u;
-        hipLaunchKernelGGL((ptile_reset_tree_kernel<NQ, RM>), dim3((unsigned)blocks), dim3(PT_TREE_THREADS), 0, s, pa);
+        const uint64_t blocks = pa.tree_grid;
+        if (blocks) hipLaunchKernelGGL((ptile_reset_tree_kernel<NQ, RM>), dim3((unsigned)blocks), dim3(PT_TREE_THREADS), 0, s, pa);
     }
     hipLaunchKernelGGL((ptile_generate_kernel<NQ, RM>), dim3(grid_for(pa.s.B, 64)), dim3(64), 0, s, pa);
     return hipGetLastError();
@@ -1986,6 +2038,7 @@ int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s, 
         HIP_TRY(hipMemcpy(v->d_gen_tables, blob.data(), total, hipMemcpyHostToDevice));
         v->gen_nd = (uint32_t)dvals.size();
         v->gen_ncx = (uint32_t)(cx.size() / 2);
+        v->gen_npairs = (uint32_t)(pairs.size() / 2);
         v->gen_off[0] = (uint32_t)o_dvals; v->gen_off[1] = (uint32_t)o_doff; v->gen_off[2] = (uint32_t)o_pairs; v->gen_off[3] = (uint32_t)o_cx;
     }
     PTGenArgs ga;
@@ -2009,6 +2062,7 @@ int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s, 
     ga.cx_pairs = base + v->gen_off[3];
     ga.nd = v->gen_nd;
     ga.n_cx = v->gen_ncx;
+    ga.n_pairs = v->gen_npairs;
     ga.seed = seed;
     a.clock = v->clock_dev;
     a.env_base = v->env_base;
@@ -2031,7 +2085,11 @@ int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s, 
         ga.list_count = v->done_list + v->B;
         ga.tree = (ga.difficulty >= plan::TREE_MIN_DRAWS && v->B / 32u >= 1u && pauli_tree_takes(1u, ga.difficulty, v->B, ga.n_cx)) ? 1u : 0u;
     }
-    if (ga.tree) ga.tree_kclk = kernel_clock_slot_public(v);
+    if (ga.tree) {
+        ga.tree_grid = reset_tree_grid_public(v, (uint32_t)(v->B / 32u));
+        ga.count_out = v->count_seen;
+        ga.tree_kclk = kernel_clock_slot_public(v);
+    }
     a.kclk = kernel_clock_slot_public(v);
     a.kclk_waves = v->kclk_waves;
     HIP_TRY(ptile_generate(v, ga, s));

@@ -948,15 +948,32 @@ __global__ __launch_bounds__(Q64_TREE_THREADS) void q64_reset_tree_kernel(InitAr
     __shared__ uint64_t prod[Q64_TREE_WAVES][64];
     __shared__ RowopMasks64 tree_gates[Q64_TREE_WAVES][QG_WAVE];
     __shared__ uint32_t mask_part[Q64_TREE_THREADS + 2 + Q64_TREE_WAVES];
+    // the row-operation table comes into LDS while the mask's counts (or the list's length) are in flight: the draws then index LDS instead of paying a
+    // third dependent trip to memory (kernels_qm.hip qm_init_block does the same; `opaque_zero` keeps the uniform loads vector loads, i.e. not waited
+    // for where they are issued)
+    __shared__ uint32_t tree_table[QG_TREE_TABLE_MAX];
+    const bool table_fits = a.num_actions <= QG_TREE_TABLE_MAX;
+    uint32_t opaque_zero;
+    asm("v_mov_b32 %0, 0" : "=v"(opaque_zero));
     uint32_t len;
+    DoneMaskShare share;
     if (a.mask) {  // the step before left its finishers as bits: every workgroup counts them (a hint word with another number: nobody finished)
-        DoneMaskShare share;
+        const uint32_t hint_v = done_mask_hint(a.mask, a.B)[opaque_zero];
         done_mask_load<Q64_TREE_THREADS>(a.mask, a.B, a.mask_words, share);
-        len = *done_mask_hint(a.mask, a.B) != a.mask_epoch ? 0u : done_mask_scan<Q64_TREE_THREADS>(share, mask_part);
+        asm volatile("" ::: "memory");
+        if (table_fits)
+            for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) tree_table[i] = a.rowops[i];
+        len = (uint32_t)__builtin_amdgcn_readfirstlane((int)hint_v) != a.mask_epoch ? 0u : done_mask_scan<Q64_TREE_THREADS>(share, mask_part);
         if (blockIdx.x == 0 && threadIdx.x == 0) *a.count_pub = len;  // (for q64_init_kernel, the launch behind this one)
     } else {
-        len = a.list_count[0];
+        const uint32_t len_v = a.list_count[opaque_zero];
+        asm volatile("" ::: "memory");
+        if (table_fits)
+            for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) tree_table[i] = a.rowops[i];
+        len = (uint32_t)__builtin_amdgcn_readfirstlane((int)len_v);
     }
+    if (a.count_out && blockIdx.x == 0 && threadIdx.x == 0) *a.count_out = len;  // (host memory: sizes the next launches' tree grid, qgym_api.cpp reset_tree_grid)
+    if (threadIdx.x == 0) phase_stamp(a.tree_kclk, a.kclk_waves, 0);  // the count is known
     if (!tree_takes(len, a.n_draws)) return;
     const uint32_t count = a.mask ? len : list_count_take(a.list_count, len, (uint64_t)(len < gridDim.x ? len : gridDim.x) * Q64_TREE_THREADS, blockIdx.x, a.zero_count);
     const uint32_t N = a.N;
@@ -964,11 +981,16 @@ __global__ __launch_bounds__(Q64_TREE_THREADS) void q64_reset_tree_kernel(InitAr
     // entry blockIdx.x of the list, then + gridDim.x, ...: the launch has plan::tree_grid workgroups for a list of any (tree) length
     for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
         if (item != blockIdx.x) __syncthreads();  // (the previous round's LDS has been read)
-        const uint64_t env = a.mask ? done_mask_nth<Q64_TREE_THREADS>(a.mask, a.mask_words, mask_part, item) : a.list[item];
+        // (the first entry from the thread that holds it in its share of the mask: a barrier, no search; the barrier also makes the table visible)
+        const uint64_t env = !a.mask ? a.list[item]
+                           : item == blockIdx.x ? done_mask_find<Q64_TREE_THREADS>(a.mask, a.mask_words, share, mask_part, item)
+                                                : done_mask_nth<Q64_TREE_THREADS>(a.mask, a.mask_words, mask_part, item);
+        if (threadIdx.x == 0) phase_stamp(a.tree_kclk, a.kclk_waves, 1);  // the env is known
         uint64_t myrow = 0;
         // q64_init_finish with the wave's 64 lanes: lane s holds the row of slot s (scramble_tree64 runs on the transpose), stores its 8 bytes of the
         // env's tile and compares with the identity's; lane 0 writes the scalars (reset_internals, clifford.rs:272-283)
-        if (!scramble_tree64<NS, Q64_TREE_WAVES>(a, env, myrow, prod, tree_gates, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); })) continue;
+        if (!scramble_tree64<NS, Q64_TREE_WAVES>(a, env, myrow, prod, tree_gates, table_fits ? tree_table : a.rowops, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); })) continue;
+        phase_stamp(a.tree_kclk, a.kclk_waves, 2);  // the scramble is done (wave 0)
         const uint32_t le = (uint32_t)(env & (QG_WAVE - 1));
         uint64_t *tile = reinterpret_cast<uint64_t *>(reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Q64Rows<NS>::G * 64));
         if (lane < (uint32_t)NS) tile[((uint64_t)(lane >> 1) * 64 + le) * 2 + (lane & 1u)] = myrow;  // group lane / 2, the env's 16-byte piece, its low or high word
@@ -999,6 +1021,7 @@ __global__ __launch_bounds__(Q64_TREE_THREADS) void q64_reset_tree_kernel(InitAr
             lay[a.layers_len - 2] = 0;
             lay[a.layers_len - 1] = 0;
         }
+        phase_stamp(a.tree_kclk, a.kclk_waves, 3);  // everything is stored
     }
 }
 

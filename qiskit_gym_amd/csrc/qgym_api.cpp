@@ -320,8 +320,7 @@ static unsigned long long *kernel_clock_slot(const qg_vec *v) {
 // LDS whether or not the list reaches it, and at three workgroups per CU whatever is dispatched late waits -- so the grid follows the list lengths
 // this handle's resets have reported (InitArgs::count_out: the latest launch that has finished; read without waiting): the length, four standard
 // deviations of a count that size and a margin, in steps of 64.  A longer list is walked in rounds: the grid's size never changes a result.
-static uint32_t reset_tree_grid(const qg_vec *v) {
-    const uint32_t most = plan::tree_grid(v->B);
+static uint32_t reset_tree_grid(const qg_vec *v, uint32_t most) {
     const uint32_t seen = v->count_seen ? *(volatile const uint32_t *)v->count_seen : 0xFFFFFFFFu;
     if (seen == 0xFFFFFFFFu) return most;
     const uint64_t want = (uint64_t)seen + 4ull * (uint64_t)std::sqrt((double)seen) + 32ull;
@@ -562,10 +561,9 @@ int qg_vec_create(const qg_config *cfg, const qg_gate *gates, size_t n_gates, ui
         HIP_TRY_V(hipMemset(p->done_list_alt + batch, 0, 2 * sizeof(uint32_t)));
     }
     if (hp.has_done_list && (v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64 || v->layout == LAYOUT_PAULI)) {  // the finished envs of a step as one bit each (qm_step1 / qm_inv2 / q64_step1 / q64_inv2 / ptile_step1c <LIST>)
-        if (v->layout == LAYOUT_TILE) {
-            HIP_TRY_V(hipHostMalloc((void **)&p->count_seen, sizeof(uint32_t), hipHostMallocMapped));
-            *p->count_seen = 0xFFFFFFFFu;
-        } else {
+        HIP_TRY_V(hipHostMalloc((void **)&p->count_seen, sizeof(uint32_t), hipHostMallocMapped));
+        *p->count_seen = 0xFFFFFFFFu;
+        if (v->layout != LAYOUT_TILE) {
             HIP_TRY_V(hipMalloc(&p->mask_count, 2 * sizeof(uint32_t)));
             HIP_TRY_V(hipMemset(p->mask_count, 0, 2 * sizeof(uint32_t)));
         }
@@ -889,9 +887,9 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
         v->auto_list = true;
         ia.list = v->done_list;
         ia.list_count = v->done_list + v->B;
-        if (v->layout == LAYOUT_TILE && v->count_seen) {
+        if ((v->layout == LAYOUT_TILE || v->layout == LAYOUT_TILE64) && v->count_seen) {
             ia.count_out = v->count_seen;
-            ia.tree_grid = reset_tree_grid(v);
+            ia.tree_grid = reset_tree_grid(v, plan::tree_grid(v->B));
         }
         if (left_by_step && v->mask_fresh && v->done_mask[0]) {  // TILE: the step before left its finishers as bits (the list holds what the fused launch added, if anything)
             ia.mask = v->done_mask[v->mask_cur];
@@ -1148,7 +1146,7 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     ia.list_count = v->done_list + v->B;
     ia.zero_count = v->done_list_spare + v->B;
     ia.count_out = v->count_seen;
-    ia.tree_grid = reset_tree_grid(v);
+    ia.tree_grid = reset_tree_grid(v, plan::tree_grid(v->B));
     ia.mask = v->done_mask[v->mask_cur];  // the finishers of the step before: the reset's work, and the step workgroups' "not mine" test
     ia.mask_words = (uint32_t)(4 * ((v->B + 255) / 256));
     ia.mask_epoch = v->mask_epoch[v->mask_cur];
@@ -1571,6 +1569,7 @@ int bind_error(qg_vec *v, uint32_t *error_dev) {
     return QG_OK;
 }
 unsigned long long *kernel_clock_slot_public(const qg_vec *v) { return kernel_clock_slot(v); }
+uint32_t reset_tree_grid_public(const qg_vec *v, uint32_t most) { return reset_tree_grid(v, most); }
 int dense_refresh_public(qg_vec *v, hipStream_t s) { return dense_refresh(v, s); }
 // InitArgs of qg_vec_reset_done(v, seed) without a list: what a kernel that resets finished envs itself needs (qg_vec_mid_head_sample_step)
 void fill_reset_done_args_public(const qg_vec *v, uint64_t seed, InitArgs &ia) {

@@ -152,7 +152,7 @@ struct qg_vec {
     uint32_t rmax_generate = 0;
     uint32_t pt_nq = 0, pt_rm = 0;
     void *d_gen_tables = nullptr;  // PTILE target generator: coupling-graph distance tables
-    uint32_t gen_nd = 0, gen_ncx = 0, gen_off[4] = {0, 0, 0, 0};  // final_pauli_layers: most rotations reset() generates
+    uint32_t gen_nd = 0, gen_ncx = 0, gen_npairs = 0, gen_off[4] = {0, 0, 0, 0};  // final_pauli_layers: most rotations reset() generates
     uint8_t *d_qubit_perms = nullptr;  // [n_perms][N]  (add_perms)
     int32_t *d_act_perms = nullptr;    // [n_perms][num_actions]
     uint32_t *perm_idx = nullptr;      // [B] current_perm_idx
@@ -175,6 +175,7 @@ void done_list_appended(qg_vec *v, bool trusted);
 void fill_step_args_public(const qg_vec *v, StepArgs &a);
 // the per-env fault words in caller-owned memory (device-visible, [B] uint32, current content carried over); not part of the C ABI: the scalar env's
 int bind_error(qg_vec *v, uint32_t *error_dev);
+uint32_t reset_tree_grid_public(const qg_vec *v, uint32_t most);  // workgroups of a reset's tree launch, from the list lengths the handle's resets have reported
 unsigned long long *kernel_clock_slot_public(const qg_vec *v);  // qg_vec_set_kernel_clock: the slot of the launch about to be enqueued, or null
 // qg_vec_track_dense: rewrite the whole tracked observation from the state (after a launch that changed states without updating it)
 int dense_refresh_public(qg_vec *v, hipStream_t s);
