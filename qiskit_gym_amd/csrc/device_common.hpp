@@ -466,6 +466,7 @@ __device__ inline bool scramble_tree(const InitArgs &a, uint64_t env, uint32_t &
                                      const uint32_t *table, Identity identity, Mid mid = Mid()) {
     static_assert(R <= 32, "one uint32 of slots per column");
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1), w = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31u;
+    if (threadIdx.x == 0) phase_stamp(a.kclk, a.kclk_waves, 1);  // the env is known
     // (`env` comes in from the caller: list[item], requested before the list's length was known)
     // tree place p = 2 w + half holds segment k = 7 - p: the gates [k seg, (k + 1) seg), last one first, transposed
     const uint32_t seg = (a.n_draws + 7u) / 8u, k = 7u - (2u * w + half);
@@ -502,6 +503,7 @@ __device__ inline bool scramble_tree(const InitArgs &a, uint64_t env, uint32_t &
             for (int q = 0; q < 4; ++q) g[q] = nx[q];
         }
     }
+    if (threadIdx.x == 0) phase_stamp(a.kclk, a.kclk_waves, 2);  // wave 0's chain
     if (k == 0) {  // S0^T on the left (clifford.rs:307): the xor of S0's rows over the set bits of the word
         uint32_t acc = 0;
 #pragma unroll 8
@@ -523,6 +525,7 @@ __device__ inline bool scramble_tree(const InitArgs &a, uint64_t env, uint32_t &
     __syncthreads();
     if (w != 0) return false;
     col = gf2_cols_product_halves<R>(prod[2], col, half);
+    if (threadIdx.x == 0) phase_stamp(a.kclk, a.kclk_waves, 3);  // the products
     // (the transpose's column hl IS the row of slot hl: lanes 0 .. R - 1 of the wave hold the env's rows, the upper half nothing)
     const uint32_t my_row = half ? 0u : col;
     row_out = my_row;

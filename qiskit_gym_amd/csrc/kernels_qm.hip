@@ -826,6 +826,7 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
         const uint32_t lcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)count_v);
         const uint32_t count_now = mcount + lcount;
         if (a.count_out && vblock == 0 && threadIdx.x == 0) *a.count_out = count_now;  // (host memory: sizes the next launches' tree grid)
+        if (threadIdx.x == 0) phase_stamp(a.kclk, a.kclk_waves, 0);  // the count is known
         // the envs to reset: the mask's set bits in ascending order, then the list's entries
         auto entry = [&](uint32_t i) -> uint32_t { return i < mcount ? done_mask_nth(a.mask, a.mask_words, mask_part, i) : a.list[i - mcount]; };
         // (a block past the list may see the count already zeroed: it has no work either way)
@@ -856,6 +857,7 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
                 bool fin = false;
                 if (sa) fin = qm_init_finish_wave_step<NXP, HAS_Z>(a, *sa, e, myrow, act, ge);
                 else qm_init_finish_wave<NXP, HAS_Z>(a, e, myrow);
+                if (threadIdx.x == 0) phase_stamp(a.kclk, a.kclk_waves, 4);  // stored
                 if ((threadIdx.x & (QG_WAVE - 1)) == 0) after(e, sa != nullptr, fin);
             };
             if (vblock >= count) return;

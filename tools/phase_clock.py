@@ -23,7 +23,9 @@ B, PH, NB = 65536, 8, 512
 CASES = [("pauli", 20, dict(add_perms=False, track_solution=False, max_rotations=5, difficulty=256, pauli_diff_scale=8),
           ["count known", "env + draws in LDS (wave 0)", "env + draws in LDS (wave 4)", "labels done (wave 4)", "scramble done (wave 0)", "rows arrived (wave 4)", "stored (wave 4)"]),
          ("clifford", 24, dict(add_inverts=False, add_perms=False, track_solution=False, difficulty=256),
-          ["count known", "env known", "scramble done", "stored"])]
+          ["count known", "env known", "scramble done", "stored"]),
+         ("clifford", 16, dict(add_inverts=True, add_perms=False, track_solution=True, difficulty=256),
+          ["count known", "env known", "chain done (wave 0)", "products done", "stored"])]
 q = lambda x: " ".join(f"{v:6.2f}" for v in np.percentile(x, [0, 10, 50, 90, 99, 100]))
 for kind, n, kw, names in CASES:
     gs = line_gateset(kind, n)
@@ -38,7 +40,7 @@ for kind, n, kw, names in CASES:
         view = env.kernel_clock(2)
         env.reset_done(100 + i)
         torch.cuda.synchronize()
-        rec = view[0].cpu().numpy().astype(np.int64)  # the tree launch: [waves, 2]
+        rec = view[0].cpu().numpy().astype(np.int64)  # the tree launch (TILE: the reset's only launch): [waves, 2]
         env.kernel_clock(0)
     W = rec.shape[0]
     body = rec[:W // 2]
@@ -53,7 +55,7 @@ for kind, n, kw, names in CASES:
     for j, name in enumerate(names):
         print(f"    {name:45s} {q(st[:, j][~np.isnan(st[:, j])])}")
     print("    time between consecutive stamps of the same wave / phase:")
-    pairs = [(0, 1), (2, 3), (1, 4), (3, 5), (5, 6)] if kind == "pauli" else [(0, 1), (1, 2), (2, 3)]
+    pairs = [(0, 1), (2, 3), (1, 4), (3, 5), (5, 6)] if kind == "pauli" else [(j, j + 1) for j in range(len(names) - 1)]
     for a, b in pairs:
         d = st[:, b] - st[:, a]
         print(f"    {names[a]:30s} -> {names[b]:30s} {q(d[~np.isnan(d)])}")
