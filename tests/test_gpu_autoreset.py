@@ -738,3 +738,81 @@ def test_staggered_finishers_left_as_a_mask_are_reset_by_trees(kind, n, inverts)
         resets += int(f.sum())
     assert resets > B
     assert np.array_equal(gv.observe().cpu().numpy().reshape(B, -1), ov.observe_dense()), "final states"
+
+
+@pytest.mark.parametrize("kind,n", [("pauli", 20), ("pauli", 12), ("clifford", 24), ("clifford", 16)])
+def test_tree_grid_sized_from_a_short_list_walks_a_longer_one_in_rounds(kind, n):
+    """The tree launch's grid follows the list lengths the handle's resets have reported (qgym_api.cpp reset_tree_grid): after a reset of 3 envs it is
+    64 workgroups, and the next reset -- 250 of 8 192 envs, still a tree's list -- is walked in four rounds by them (PauliEnv: the scramble waves and the
+    labels' wave meet again at every round's barriers, the products' hand-over words go on counting).  Both as lists compacted from raised flags and as
+    masks left by a step; every env against the oracle."""
+    from oracle import OracleVec
+    from qiskit_gym_amd.vec import VecEnv
+
+    B = 8192
+    gs = line_gateset(kind, n)
+    cfg = dict(add_perms=False, track_solution=False, difficulty=128, depth_slope=1, max_depth=200)
+    if kind == "pauli":
+        cfg.update(max_rotations=5, pauli_diff_scale=8)
+    else:
+        cfg.update(add_inverts=False)
+    gv = VecEnv(kind, n, gs, B, **cfg)
+    ov = OracleVec(OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()}), B)
+    gv.reset(2)
+    ov.reset_seeded(2)
+    rng = np.random.default_rng(n)
+    for count, seed in ((3, 11), (250, 12), (5, 13), (256, 14), (200, 15)):
+        ids = np.sort(rng.choice(B, size=count, replace=False))
+        m = np.zeros(B, dtype=np.uint8)
+        m[ids] = 1
+        gv.done.copy_(torch.as_tensor(m, device="cuda"))
+        gv.reset_done(seed)
+        gv.sync()  # (the launch has reported its list's length)
+        ov.reset_seeded(seed, mask=m)
+        assert np.array_equal(gv.observe().cpu().numpy().reshape(B, -1), ov.observe_dense()), (count, seed)
+    # ... and with the finishers left as a MASK by a step: episodes of 40 steps whose ends are spread over time (205 envs per step), and between a
+    # step's reset and the next step a reset of three hand-picked envs, which sizes the next tree launch down to 64 workgroups
+    L = 40
+    cfg2 = dict(cfg, difficulty=70, max_depth=L)
+    g2 = VecEnv(kind, n, gs, B, **cfg2)
+    o2 = OracleVec(OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg2.items()}), B)
+    g2.reset(4)
+    o2.reset_seeded(4)
+    A = len(gs)
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    ids, all_env = np.arange(B), torch.arange(B, device="cuda")
+    t = 0
+
+    def step_and_check():
+        nonlocal t
+        acts = torch.randint(0, A, (B,), dtype=torch.int32, device="cuda", generator=gen)
+        g2.set_counters(t, 0)
+        g2.step(acts)
+        f = o2.step(acts.cpu().numpy())[2]
+        g2.sync()
+        assert np.array_equal(g2.done.cpu().numpy(), f), (t, np.nonzero(g2.done.cpu().numpy() != f)[0][:8])
+        t += 1
+        return f
+
+    for k in range(L):  # Env::reset for class k at time k
+        f = step_and_check()
+        g2.reset_done(100 + k)
+        o2.reset_seeded(100 + k, mask=f)
+        g2.done[all_env % L == k] = 1
+        g2.reset_done(5000 + k)
+        o2.reset_seeded(5000 + k, mask=(ids % L == k))
+    rounds = 0
+    for k in range(12):
+        f = step_and_check()
+        assert 64 < f.sum() <= B // 32, f.sum()  # more than the sized-down grid, still a tree's list
+        g2.reset_done(9000 + k)  # (the step before left the mask; the launch before reported 3 finishers)
+        o2.reset_seeded(9000 + k, mask=f)
+        few = np.zeros(B, dtype=np.uint8)
+        few[rng.choice(B, size=3, replace=False)] = 1
+        g2.done.copy_(torch.as_tensor(few, device="cuda"))
+        g2.reset_done(9500 + k)
+        g2.sync()
+        o2.reset_seeded(9500 + k, mask=few)
+        rounds += 1
+        assert np.array_equal(g2.observe().cpu().numpy().reshape(B, -1), o2.observe_dense()), k
+    assert rounds == 12
