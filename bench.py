@@ -685,7 +685,7 @@ def main():
                 "C3": r2(auto_reset["us_per_step"]), "C3_synchronised": r2(auto_reset["synchronised"]["us_per_step"]),
                 "C3_reference_defaults": r2(auto_reset["reference_defaults"]["us_per_step"]), "C2": r2(auto_reset["C2"]["us_per_step"]),
                 "C2_x65536": r2(auto_reset["C2_x65536"]["us_per_step"]), "C2_reference_defaults": r2(auto_reset["C2_reference_defaults"]["us_per_step"]),
-                "C5": r2(auto_reset["C5"]["us_per_step"]), "pauli_reset_done_1pct_eager": r2(auto_reset["pauli_reset_done"]["us_per_call"])},
+                "C5": r2(auto_reset["C5"]["us_per_step"]), "clifford24": r2(auto_reset["clifford24"]["us_per_step"]), "pauli_reset_done_1pct_eager": r2(auto_reset["pauli_reset_done"]["us_per_call"])},
             "observation_us_per_step": None if not obs_modes else {k: r2(obs_modes[k]["us_per_step"]) for k in ("packed", "dense", "dense_tracked", "dense_tracked_reference_defaults")},
             "dense_rewrite_kernel_frac": round(obs_modes["dense_kernel"]["roofline"]["frac"], 3) if obs_modes else None,
             "configs_us_per_step": None if not configs else {k: r2(configs[k]["us_per_step"]) for k in ("C2", "C5", "C3d")},

@@ -162,10 +162,15 @@ def auto_reset(c):
             aenv = VecEnv("linear_function", 8, gs2a, nb, add_perms=False, difficulty=64, **kw)
             legs[name] = dict(auto_reset_leg(aenv, len(gs2a)), config=f"LinearFunctionGym 8q x {nb}, difficulty 64, {kw}: word_reset_step_kernel (one launch per pair)")
             del aenv
+        gs24 = _line_gateset("clifford", 24)
+        aenv = VecEnv("clifford", 24, gs24, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=256)
+        legs["clifford24"] = dict(auto_reset_leg(aenv, len(gs24)), config=f"CliffordGym 24q x {B} (64-bit rows), difficulty 256: q64_reset_tree_kernel + q64_init_kernel + "
+                                                                          "q64_step1_kernel<LIST> per pair")
+        del aenv
         gs5a = _line_gateset("pauli", 20)
         aenv = VecEnv("pauli", 20, gs5a, B, add_perms=False, track_solution=False, max_rotations=5, difficulty=256, pauli_diff_scale=8)
-        legs["C5"] = dict(auto_reset_leg(aenv, len(gs5a)), config=f"PauliGym 20q x {B}, difficulty 256 (targets regenerated on the device), compact_done + "
-                                                                  "ptile_reset_tree_kernel + ptile_generate_kernel + ptile_step1c_kernel per pair")
+        legs["C5"] = dict(auto_reset_leg(aenv, len(gs5a)), config=f"PauliGym 20q x {B}, difficulty 256 (targets regenerated on the device), "
+                                                                  "ptile_reset_tree_kernel + ptile_generate_kernel + ptile_step1c_kernel<LIST> (finishers as a mask) per pair")
         del aenv
         # ... and qg_vec_reset_done by itself where it is not a tree of row operations on a bit matrix: PauliGym 20q (config 5's env: a fresh target is
         # generated on the device), 1 % of the batch finished, eager calls (memset + compaction + two kernels), median of 12
@@ -189,7 +194,7 @@ def auto_reset(c):
                                     "config": f"PauliGym {pg_n}q x {B} envs, difficulty 128, qg_vec_reset_done with 1 % of the batch finished, eager, median of 12"}
         del penv
         auto_reset = dict(legs["desynchronised"], synchronised=legs["synchronised"], reference_defaults=legs["desynchronised_reference_defaults"],
-                          C2=legs["C2"], C2_x65536=legs["C2_x65536"], C2_reference_defaults=legs["C2_reference_defaults"], C5=legs["C5"],
+                          C2=legs["C2"], C2_x65536=legs["C2_x65536"], C2_reference_defaults=legs["C2_reference_defaults"], C5=legs["C5"], clifford24=legs["clifford24"],
                           pauli_reset_done=legs["pauli_reset_done"],
                           config=f"the headline workload with qg_vec_reset_done after every step (the pair reset_done + next step issued as qg_vec_reset_done_step: one launch), episodes of min(depth_slope * difficulty, max_depth) = {AT} steps, "
                                  f"a captured graph of {AT} x (step, reset_done) replayed 4 times; headline figures: episode ends spread evenly over time "

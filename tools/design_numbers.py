@@ -90,7 +90,8 @@ if d:
                    f"**{ar['us_per_step']:.1f} µs** a pair (one launch), every env finishing in the same step {ar['synchronised']['us_per_step']:.1f} µs, with the reference-default options "
                    f"**{ar['reference_defaults']['us_per_step']:.1f} µs** (two launches); LinearFunctionGym 8q × 8 192 **{ar['C2']['us_per_step']:.1f} µs** (one launch; × 65 536: "
                    f"{ar['C2_x65536']['us_per_step']:.1f}; reference defaults: {ar['C2_reference_defaults']['us_per_step']:.1f}); PauliGym 20q × 65 536 **{ar['C5']['us_per_step']:.1f} µs** "
-                   f"(compaction + tree + generator + step); PauliGym `reset_done` alone at 1 % finished, eager: {ar['pauli_reset_done']['us_per_call']:.0f} µs.")
+                   f"(tree + generator + step, three launches)" + (f"; CliffordGym 24q (64-bit rows) **{ar['clifford24']['us_per_step']:.1f} µs**" if 'clifford24' in ar else "") +
+                   f"; PauliGym `reset_done` alone at 1 % finished, eager: {ar['pauli_reset_done']['us_per_call']:.0f} µs.")
     om = d.get("observation_modes")
     if om:
         out.append(f"* Observation after every step (SURVEY 8d, both modes): packed {om['packed']['us_per_step']:.2f} µs per step; dense, full rewrite "
