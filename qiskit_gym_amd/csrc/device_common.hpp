@@ -345,9 +345,10 @@ struct ListEntry {  // entry i of InitArgs::list (the default source of scramble
 };
 // (`env` is set on every lane of a group that has an entry, also on the lanes that get nullptr back)
 template <typename W, int R, typename Identity, typename EnvOf>
-__device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds, uint64_t &env, Identity identity, uint32_t vblock, EnvOf env_of) {
+__device__ inline W *scramble_coop(const InitArgs &a, uint32_t count, void *lds, uint64_t &env, Identity identity, uint32_t vblock, EnvOf env_of,
+                                   uint32_t block_threads = 0 /* the threads of a workgroup that take part (0: all of blockDim.x) */) {
     constexpr uint32_t S = QG_COOP_LANES, EPW = QG_WAVE / S, CH = 64, PER_ENV = R * sizeof(W) + CH * sizeof(uint32_t);
-    const uint64_t item = ((uint64_t)vblock * blockDim.x + threadIdx.x) / S;
+    const uint64_t item = ((uint64_t)vblock * (block_threads ? block_threads : blockDim.x) + threadIdx.x) / S;
     if (item >= count) return nullptr;  // whole lane groups leave together
     const uint32_t sl = threadIdx.x & (S - 1), w = threadIdx.x >> 6, g = (threadIdx.x & (QG_WAVE - 1)) / S;
     env = env_of((uint32_t)item);

@@ -1290,6 +1290,7 @@ struct PTGenArgs {
     const uint32_t *list;  // only_done, compacted (compact_done): thread i regenerates env list[i]
     uint32_t *list_count;
     uint32_t n_pairs;      // doff[nd]
+    uint32_t gen_grid;     // workgroups of ptile_generate_kernel (0: one per 64 envs); they walk the batch with the grid's stride
     uint32_t tree_grid;    // workgroups of the tree launch (entry i on workgroup i mod tree_grid); `count_out`: where it reports the list's length (host memory)
     uint32_t *count_out;
     uint32_t tree;         // ptile_reset_tree_kernel runs before ptile_generate_kernel and takes the lists pt_tree_takes says it takes
@@ -1611,15 +1612,17 @@ __device__ inline void pt_gen_finish_wave(const PTGenArgs &ga, PTState<NQ, RM> &
     }
 }
 
+// The 64 envs of "workgroup" vblock (one wave).  Returns false -- on every lane alike -- when neither this vblock nor any later one has work (a list / mask of
+// finished envs that ends before it, or that ptile_reset_tree_kernel has taken): ptile_generate_kernel's workgroups walk the vblocks with the grid's stride, and
+// the grid behind a tree launch is a few workgroups when the handle's lists have been trees' lists (PTGenArgs::gen_grid).
 template <int NQ, int RM>
-__global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
-    KernelClock kclk(ga.s.kclk, ga.s.kclk_waves);  // device_common.hpp
+__device__ __forceinline__ bool ptile_generate_body(const PTGenArgs &ga, uint32_t vblock) {
     const StepArgs &a = ga.s;
     // the tableau scramble runs on LDS-resident rows ([row][lane], conflict-free for any per-lane row): a
     // random CX / H / S is one or two row operations instead of a select sweep over 2N 64-bit registers
     __shared__ uint64_t lds_tab[2 * NQ][QG_WAVE];
     __shared__ PTGenTables tb;
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t tid = (uint64_t)vblock * QG_WAVE + threadIdx.x;
     // the list's only reader; compact_done re-initialises the length before every use, so nobody has to zero it here (no reader tickets)
     __shared__ uint32_t mask_part[64 + 1 + 5];
     uint32_t count = ga.list ? ga.list_count[0] : 0u;
@@ -1627,28 +1630,28 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
         // after a tree launch its count is in count_pub: most calls leave here; else (no tree launch, or a list too long for it) count the mask
         const bool published = ga.tree != 0;
         count = published ? *ga.count_pub : 0u;
-        if (published && (pauli_tree_takes(count, ga.difficulty, a.B, ga.n_cx) || (tid & ~(uint64_t)(QG_WAVE - 1)) >= count)) return;
+        if (published && (pauli_tree_takes(count, ga.difficulty, a.B, ga.n_cx) || (tid & ~(uint64_t)(QG_WAVE - 1)) >= count)) return false;
         DoneMaskShare share;
         done_mask_load<64>(ga.mask, a.B, ga.mask_words, share);
         count = *done_mask_hint(ga.mask, a.B) != ga.mask_epoch ? 0u : done_mask_scan<64>(share, mask_part);
-        if ((tid & ~(uint64_t)(QG_WAVE - 1)) >= count) return;
+        if ((tid & ~(uint64_t)(QG_WAVE - 1)) >= count) return false;
     } else if (ga.list && ((ga.tree && pauli_tree_takes(count, ga.difficulty, a.B, ga.n_cx)) || (tid & ~(uint64_t)(QG_WAVE - 1)) >= count)) {
         // (before the tables are brought in: most calls with a list leave here -- ptile_reset_tree_kernel has taken it, or the wave lies past it)
-        return;
+        return false;
     }
     const bool cx_in_lds = pt_gen_tables_load(ga, tb);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     uint64_t env = tid;
     if (ga.mask) {
-        if (tid >= count) return;
+        if (tid >= count) return true;
         env = done_mask_nth<64>(ga.mask, ga.mask_words, mask_part, (uint32_t)tid);
     } else if (ga.list) {
-        if (tid >= count) return;
+        if (tid >= count) return true;
         env = ga.list[tid];
     } else {
-        if (env >= a.B) return;
-        if (ga.only_done && !a.done[env]) return;
+        if (env >= a.B) return true;
+        if (ga.only_done && !a.done[env]) return true;
     }
     const uint32_t L = threadIdx.x & (QG_WAVE - 1);
     const uint32_t N = a.N;
@@ -1703,6 +1706,21 @@ __global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
         s.Z[j] = lds_tab[NQ + j][L];
     }
     pt_gen_finish<NQ, RM>(ga, s, env, N);
+    return true;
+}
+template <int NQ, int RM>
+__global__ __launch_bounds__(64) void ptile_generate_kernel(PTGenArgs ga) {
+    KernelClock kclk(ga.s.kclk, ga.s.kclk_waves);  // device_common.hpp
+    // (the way out most launches behind a tree launch take, ahead of everything the body sets up: the trees left the mask's count, and it says they took the list)
+    if (ga.mask && ga.tree) {
+        const uint32_t count = *ga.count_pub;
+        if (!count || pauli_tree_takes(count, ga.difficulty, ga.s.B, ga.n_cx)) return;
+    }
+    const uint32_t total = (uint32_t)((ga.s.B + QG_WAVE - 1) / QG_WAVE);
+    for (uint32_t vblock = blockIdx.x; vblock < total; vblock += gridDim.x) {
+        if (!ptile_generate_body<NQ, RM>(ga, vblock)) break;
+        __builtin_amdgcn_wave_barrier();  // (the workgroup is one wave: its LDS tables and rows are free again)
+    }
 }
 
 // qg_vec_reset_done with a short list of long scrambles (pt_tree_takes): a workgroup per listed env.  A lane of the kernel above spends most
@@ -1989,7 +2007,8 @@ static hipError_t pt_launch_generate(const PTGenArgs &pa, hipStream_t s) {
         const uint64_t blocks = pa.tree_grid;
         if (blocks) hipLaunchKernelGGL((ptile_reset_tree_kernel<NQ, RM>), dim3((unsigned)blocks), dim3(PT_TREE_THREADS), 0, s, pa);
     }
-    hipLaunchKernelGGL((ptile_generate_kernel<NQ, RM>), dim3(grid_for(pa.s.B, 64)), dim3(64), 0, s, pa);
+    const unsigned all = grid_for(pa.s.B, 64);
+    hipLaunchKernelGGL((ptile_generate_kernel<NQ, RM>), dim3(pa.gen_grid && pa.gen_grid < all ? pa.gen_grid : all), dim3(64), 0, s, pa);
     return hipGetLastError();
 }
 static hipError_t ptile_generate(const qg_vec *v, const PTGenArgs &pa, hipStream_t s) { PT_DISPATCH(pt_launch_generate) }
@@ -2087,6 +2106,9 @@ int ptile_reset_seeded(qg_vec *v, uint64_t seed, bool only_done, hipStream_t s, 
     }
     if (ga.tree) {
         ga.tree_grid = reset_tree_grid_public(v, (uint32_t)(v->B / 32u));
+        ga.gen_grid = reset_second_grid_public(v, [](uint32_t count, const qg_vec *h) -> bool {
+            return pauli_tree_takes(count, (uint32_t)h->difficulty, h->B, h->gen_ncx);
+        });
         ga.count_out = v->count_seen;
         ga.tree_kclk = kernel_clock_slot_public(v);
     }

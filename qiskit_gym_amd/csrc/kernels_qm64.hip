@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256) void q64_step1_kernel(StepArgs a) {
 }
 
 // the tail of set_state / reset for one env: rows to the tile, reset_internals (clifford.rs:272-283)
-template <int NS, bool HAS_Z>
+template <int NS, bool HAS_Z, bool RESET_ONLY = false>
 __device__ inline void q64_init_finish(const InitArgs &a, uint64_t env, const Q64Rows<NS> &s) {
     using Rows = Q64Rows<NS>;
     const uint32_t lane = (uint32_t)(env & (QG_WAVE - 1));
@@ -663,7 +663,9 @@ __device__ inline void q64_init_finish(const InitArgs &a, uint64_t env, const Q6
     uint32_t symp = 0;
     if constexpr (HAS_Z) {
         if (a.check_symplectic) {
-            symp = (a.mode != 1 || q64_check_symplectic<NS>(s, a.N)) ? Q64_FLAG_SYMPLECTIC : 0u;
+            bool is_symp = true;  // (identity + gates: symplectic; set_state's matrix is checked -- 64 x 64 transposes in registers, kept out of the reset-only instantiation)
+            if constexpr (!RESET_ONLY) is_symp = a.mode != 1 || q64_check_symplectic<NS>(s, a.N);
+            symp = is_symp ? Q64_FLAG_SYMPLECTIC : 0u;
             if (!symp && a.nonsymp_flag) atomicOr(a.nonsymp_flag, 1u);
         }
     }
@@ -684,63 +686,71 @@ __device__ inline void q64_init_finish(const InitArgs &a, uint64_t env, const Q6
     }
 }
 
-template <int NS, bool HAS_Z>
-__global__ __launch_bounds__(64) void q64_init_kernel(InitArgs a) {
-    KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
+// The work of "workgroup" vblock (64 envs, or 4 with 16 lanes each) of an init launch.  Returns false -- on every thread alike -- when neither this vblock
+// nor any later one has work (a list / mask of finished envs that ends before it, or that the trees have taken).
+// T = 64: q64_init_kernel, a workgroup is one wave.  T = 256, RESET_ONLY: the workgroups behind the trees in q64_reset_done_kernel (qg_vec_reset_done in one launch; no
+// set_state code, whose symplectic check alone takes 256 registers and scratch): all four waves count the mask (or take the list's length) and learn whether the
+// trees of the same launch have taken the list -- then everybody leaves -- and three of them leave anyway before the first wave does the work.
+template <int NS, bool HAS_Z, uint32_t T = 64, bool RESET_ONLY = false>
+__device__ __forceinline__ bool q64_init_body(const InitArgs &a, uint32_t vblock) {
     using Rows = Q64Rows<NS>;
     // reset scramble on LDS-resident rows (device_common.hpp); one wave per block: NS * 512 B <= 32 KiB
     __shared__ uint64_t lds_rows[NS][QG_WAVE];
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t tid = (uint64_t)vblock * QG_WAVE + threadIdx.x;
     uint64_t env = tid;
     Rows s;
-    if (a.mask) {  // qg_vec_reset_done after a step that left its finishers as bits (the workgroup is one wave): count them, entry i by a search
-        __shared__ uint32_t mask_part[64 + 1 + 5];
+    const bool trees = T != 64 && a.coop && a.n_draws >= 64u && a.tree_grid;  // this launch's first workgroups are trees and take the lists tree_takes says
+    if (a.mask) {  // qg_vec_reset_done after a step that left its finishers as bits: count them, entry i by a search
+        __shared__ uint32_t mask_part[T + 2 + T / 64];
         uint32_t count = 0;
-        if (a.coop && a.n_draws >= 64u && a.tree_grid) {  // (q64_reset_tree_kernel ran before this launch and left the count: most calls leave here)
-            count = *a.count_pub;
-            if (!count || tree_takes(count, a.n_draws)) return;
-        }
         DoneMaskShare share;
-        done_mask_load<64>(a.mask, a.B, a.mask_words, share);
-        count = *done_mask_hint(a.mask, a.B) != a.mask_epoch ? 0u : done_mask_scan<64>(share, mask_part);
+        done_mask_load<T>(a.mask, a.B, a.mask_words, share);
+        count = *done_mask_hint(a.mask, a.B) != a.mask_epoch ? 0u : done_mask_scan<T>(share, mask_part);
+        if (T != 64 && (!count || (trees && tree_takes(count, a.n_draws)) || threadIdx.x >= QG_WAVE)) return false;  // (after the scan's barriers: nothing below has one)
+        if ((uint64_t)vblock * QG_WAVE >= (uint64_t)count * ((a.coop && coop_takes(count, a.B)) ? QG_COOP_LANES : 1u)) return false;  // (the list ends before this vblock)
         const uint64_t *mask = a.mask;
         const uint32_t words = a.mask_words;
-        auto entry = [=](uint32_t i) -> uint32_t { return done_mask_nth<64>(mask, words, mask_part, i); };
+        auto entry = [=](uint32_t i) -> uint32_t { return done_mask_nth<T>(mask, words, mask_part, i); };
         if (a.coop && coop_takes(count, a.B)) {  // few finished envs: 16 lanes each
             const uint32_t N = a.N;
             const uint64_t *rows = scramble_coop<uint64_t, NS>(a, count, &lds_rows[0][0], env, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); },
-                                                               blockIdx.x, entry);
-            if (!rows) return;
+                                                               vblock, entry, QG_WAVE);
+            if (!rows) return true;
 #pragma unroll
             for (int k = 0; k < NS; ++k) s.r[k] = rows[k];
-            q64_init_finish<NS, HAS_Z>(a, env, s);
-            return;
+            q64_init_finish<NS, HAS_Z, RESET_ONLY>(a, env, s);
+            return true;
         }
-        if (tid >= count) return;
+        if (tid >= count) return true;
         env = entry((uint32_t)tid);
     } else if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
         const uint32_t len = a.list_count[0];
-        const uint32_t count = list_count_take(a.list_count, len, (uint64_t)len * ((a.coop && coop_takes(len, a.B)) ? QG_COOP_LANES : 1u), blockIdx.x, a.zero_count);
-        // (without reader tickets -- InitArgs::zero_count -- the list q64_reset_tree_kernel has taken is still there: the same test says so)
-        if (a.zero_count && a.coop && a.n_draws >= 64u && tree_takes(count, a.n_draws)) return;
+        // (T = 256: that launch reads its lists without tickets -- the host gives it InitArgs::zero_count -- and `threads` only says which workgroups have work)
+        const uint32_t count = list_count_take(a.list_count, len, (uint64_t)len * ((a.coop && coop_takes(len, a.B)) ? QG_COOP_LANES : 1u) * (T / QG_WAVE), vblock, a.zero_count);
+        // (without reader tickets -- InitArgs::zero_count -- the list the trees have taken is still there: the same test says so)
+        if (a.zero_count && trees && tree_takes(count, a.n_draws)) return false;
+        if (T != 64 && threadIdx.x >= QG_WAVE) return false;  // (after list_count_take's barrier: nothing below has one)
+        if ((uint64_t)vblock * QG_WAVE >= (uint64_t)count * ((a.coop && coop_takes(count, a.B)) ? QG_COOP_LANES : 1u)) return false;  // (the list ends before this vblock)
         if (a.coop && coop_takes(count, a.B)) {  // few finished envs: 16 lanes each
             const uint32_t N = a.N;
-            const uint64_t *rows = scramble_coop<uint64_t, NS>(a, count, &lds_rows[0][0], env, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); });
-            if (!rows) return;
+            const uint64_t *rows = scramble_coop<uint64_t, NS>(a, count, &lds_rows[0][0], env, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); },
+                                                               vblock, ListEntry{a.list}, QG_WAVE);
+            if (!rows) return true;
 #pragma unroll
             for (int k = 0; k < NS; ++k) s.r[k] = rows[k];
-            q64_init_finish<NS, HAS_Z>(a, env, s);
-            return;
+            q64_init_finish<NS, HAS_Z, RESET_ONLY>(a, env, s);
+            return true;
         }
-        if (tid >= count) return;
+        if (tid >= count) return true;
         env = a.list[tid];
     } else {
-        if (env >= a.B) return;
-        if (a.only_done && !a.done[env]) return;
+        if (RESET_ONLY) return false;  // (that instantiation is only launched with a list)
+        if (env >= a.B) return true;
+        if (a.only_done && !a.done[env]) return true;
     }
 #pragma unroll
     for (int i = 0; i < NS; ++i) s.r[i] = q64_identity_word<NS, HAS_Z>(i, a.N);
-    if (a.mode == 1) {  // set_state (clifford.rs:299-304)
+    if (!RESET_ONLY && a.mode == 1) {  // set_state (clifford.rs:299-304)
 #pragma unroll 1
         for (int sl = 0; sl < NS; ++sl) {
             const uint32_t j = HAS_Z ? (uint32_t)sl >> 1 : (uint32_t)sl;
@@ -771,7 +781,13 @@ __global__ __launch_bounds__(64) void q64_init_kernel(InitArgs a) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) s.r[k] = lds_rows[k][L];
     }
-    q64_init_finish<NS, HAS_Z>(a, env, s);
+    q64_init_finish<NS, HAS_Z, RESET_ONLY>(a, env, s);
+    return true;
+}
+template <int NS, bool HAS_Z>
+__global__ __launch_bounds__(64) void q64_init_kernel(InitArgs a) {
+    KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
+    (void)q64_init_body<NS, HAS_Z>(a, blockIdx.x);
 }
 
 // export: one thread per (env, matrix row)
@@ -943,8 +959,7 @@ static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
 constexpr int Q64_TREE_WAVES = 4;
 constexpr uint32_t Q64_TREE_THREADS = 64u * Q64_TREE_WAVES;
 template <int NS, bool HAS_Z>
-__global__ __launch_bounds__(Q64_TREE_THREADS) void q64_reset_tree_kernel(InitArgs a) {
-    KernelClock kclk(a.tree_kclk, a.kclk_waves);  // device_common.hpp
+__device__ __forceinline__ void q64_reset_tree_body(const InitArgs &a) {  // workgroups blockIdx.x < a.tree_grid of q64_reset_done_kernel
     __shared__ uint64_t prod[Q64_TREE_WAVES][64];
     __shared__ RowopMasks64 tree_gates[Q64_TREE_WAVES][QG_WAVE];
     __shared__ uint32_t mask_part[Q64_TREE_THREADS + 2 + Q64_TREE_WAVES];
@@ -964,7 +979,6 @@ __global__ __launch_bounds__(Q64_TREE_THREADS) void q64_reset_tree_kernel(InitAr
         if (table_fits)
             for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) tree_table[i] = a.rowops[i];
         len = (uint32_t)__builtin_amdgcn_readfirstlane((int)hint_v) != a.mask_epoch ? 0u : done_mask_scan<Q64_TREE_THREADS>(share, mask_part);
-        if (blockIdx.x == 0 && threadIdx.x == 0) *a.count_pub = len;  // (for q64_init_kernel, the launch behind this one)
     } else {
         const uint32_t len_v = a.list_count[opaque_zero];
         asm volatile("" ::: "memory");
@@ -973,24 +987,24 @@ __global__ __launch_bounds__(Q64_TREE_THREADS) void q64_reset_tree_kernel(InitAr
         len = (uint32_t)__builtin_amdgcn_readfirstlane((int)len_v);
     }
     if (a.count_out && blockIdx.x == 0 && threadIdx.x == 0) *a.count_out = len;  // (host memory: sizes the next launches' tree grid, qgym_api.cpp reset_tree_grid)
-    if (threadIdx.x == 0) phase_stamp(a.tree_kclk, a.kclk_waves, 0);  // the count is known
+    if (threadIdx.x == 0) phase_stamp(a.kclk, a.kclk_waves, 0);  // the count is known
     if (!tree_takes(len, a.n_draws)) return;
-    const uint32_t count = a.mask ? len : list_count_take(a.list_count, len, (uint64_t)(len < gridDim.x ? len : gridDim.x) * Q64_TREE_THREADS, blockIdx.x, a.zero_count);
+    const uint32_t count = a.mask ? len : list_count_take(a.list_count, len, (uint64_t)(len < a.tree_grid ? len : a.tree_grid) * Q64_TREE_THREADS, blockIdx.x, a.zero_count);
     const uint32_t N = a.N;
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
-    // entry blockIdx.x of the list, then + gridDim.x, ...: the launch has plan::tree_grid workgroups for a list of any (tree) length
-    for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+    // entry blockIdx.x of the list, then + tree_grid, ...: the launch has that many tree workgroups for a list of any (tree) length
+    for (uint32_t item = blockIdx.x; item < count; item += a.tree_grid) {
         if (item != blockIdx.x) __syncthreads();  // (the previous round's LDS has been read)
         // (the first entry from the thread that holds it in its share of the mask: a barrier, no search; the barrier also makes the table visible)
         const uint64_t env = !a.mask ? a.list[item]
                            : item == blockIdx.x ? done_mask_find<Q64_TREE_THREADS>(a.mask, a.mask_words, share, mask_part, item)
                                                 : done_mask_nth<Q64_TREE_THREADS>(a.mask, a.mask_words, mask_part, item);
-        if (threadIdx.x == 0) phase_stamp(a.tree_kclk, a.kclk_waves, 1);  // the env is known
+        if (threadIdx.x == 0) phase_stamp(a.kclk, a.kclk_waves, 1);  // the env is known
         uint64_t myrow = 0;
         // q64_init_finish with the wave's 64 lanes: lane s holds the row of slot s (scramble_tree64 runs on the transpose), stores its 8 bytes of the
         // env's tile and compares with the identity's; lane 0 writes the scalars (reset_internals, clifford.rs:272-283)
         if (!scramble_tree64<NS, Q64_TREE_WAVES>(a, env, myrow, prod, tree_gates, table_fits ? tree_table : a.rowops, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); })) continue;
-        phase_stamp(a.tree_kclk, a.kclk_waves, 2);  // the scramble is done (wave 0)
+        phase_stamp(a.kclk, a.kclk_waves, 2);  // the scramble is done (wave 0)
         const uint32_t le = (uint32_t)(env & (QG_WAVE - 1));
         uint64_t *tile = reinterpret_cast<uint64_t *>(reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Q64Rows<NS>::G * 64));
         if (lane < (uint32_t)NS) tile[((uint64_t)(lane >> 1) * 64 + le) * 2 + (lane & 1u)] = myrow;  // group lane / 2, the env's 16-byte piece, its low or high word
@@ -1021,17 +1035,28 @@ __global__ __launch_bounds__(Q64_TREE_THREADS) void q64_reset_tree_kernel(InitAr
             lay[a.layers_len - 2] = 0;
             lay[a.layers_len - 1] = 0;
         }
-        phase_stamp(a.tree_kclk, a.kclk_waves, 3);  // everything is stored
+        phase_stamp(a.kclk, a.kclk_waves, 3);  // everything is stored
     }
 }
 
+// qg_vec_reset_done in ONE launch: the first InitArgs::tree_grid workgroups are trees, the workgroups behind them (one per 64 envs) apply the same test to the same
+// count and have nothing to do when the trees took the list; when the list is too long or the scramble too short the trees leave it alone and those workgroups
+// take it.  (Two launches until round 5: q64_reset_tree_kernel, then q64_init_kernel -- 1.3 us of launch boundary and a kernel with nothing to do.)
+template <int NS, bool HAS_Z>
+__global__ __launch_bounds__(Q64_TREE_THREADS) void q64_reset_done_kernel(InitArgs a) {
+    KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
+    if (blockIdx.x < a.tree_grid) q64_reset_tree_body<NS, HAS_Z>(a);
+    else (void)q64_init_body<NS, HAS_Z, Q64_TREE_THREADS, true>(a, blockIdx.x - a.tree_grid);
+}
 template <int NS, bool HAS_Z>
 static hipError_t q64_launch_init(const InitArgs &a, hipStream_t s) {
-    if (a.list && a.coop && a.n_draws >= 64u) {
-        const uint64_t blocks = a.tree_grid;
-        if (blocks) hipLaunchKernelGGL((q64_reset_tree_kernel<NS, HAS_Z>), dim3((unsigned)blocks), dim3(Q64_TREE_THREADS), 0, s, a);
-    }
-    hipLaunchKernelGGL((q64_init_kernel<NS, HAS_Z>), dim3(grid_for(a.B, 64)), dim3(64), 0, s, a);
+    const unsigned all = grid_for(a.B, 64);
+    // a list (or mask) of finished envs whose scrambles are long enough for trees: one launch, the tree workgroups first.  Its lists are read without tickets
+    // (InitArgs::zero_count: qgym_api.cpp rotates the handle's lists)
+    if (a.mode == 2 && a.list && a.coop && a.n_draws >= 64u && a.tree_grid && a.zero_count)
+        hipLaunchKernelGGL((q64_reset_done_kernel<NS, HAS_Z>), dim3((unsigned)a.tree_grid + all), dim3(Q64_TREE_THREADS), 0, s, a);
+    else
+        hipLaunchKernelGGL((q64_init_kernel<NS, HAS_Z>), dim3(all), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

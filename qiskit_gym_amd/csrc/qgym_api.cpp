@@ -328,6 +328,7 @@ static uint32_t reset_tree_grid(const qg_vec *v, uint32_t most) {
     return (uint32_t)std::min<uint64_t>(most, std::max<uint64_t>(64ull, g));
 }
 
+
 static void fill_init_args(const qg_vec *v, InitArgs &a) {
     memset(&a, 0, sizeof a);
     a.tree_grid = plan::tree_grid(v->B);
@@ -357,7 +358,6 @@ static void fill_init_args(const qg_vec *v, InitArgs &a) {
 
 static hipError_t launch_init(const qg_vec *v, const InitArgs &a_in, hipStream_t s) {
     InitArgs a = a_in;
-    if (v->layout == LAYOUT_TILE64 && a.list && a.coop && a.n_draws >= 64u && a.tree_grid) a.tree_kclk = kernel_clock_slot(v);  // (kernels_qm64.hip q64_launch_init: two launches)
     a.kclk = kernel_clock_slot(v);
     a.kclk_waves = v->kclk_waves;
     switch (v->layout) {
@@ -1570,6 +1570,14 @@ int bind_error(qg_vec *v, uint32_t *error_dev) {
 }
 unsigned long long *kernel_clock_slot_public(const qg_vec *v) { return kernel_clock_slot(v); }
 uint32_t reset_tree_grid_public(const qg_vec *v, uint32_t most) { return reset_tree_grid(v, most); }
+// The launch behind a reset's trees (PauliEnv's ptile_generate_kernel) has nothing to do when the trees took the list, and
+// finds that out from one word: a few workgroups are enough for it whenever the latest list the handle's resets have reported was a trees' list (they walk the batch
+// with the grid's stride, so a longer list is still reset -- by fewer workgroups, until the next call sees its length).  0: one workgroup per 64 envs.
+uint32_t reset_second_grid_public(const qg_vec *v, bool is_tree_list_of_that_length(uint32_t, const qg_vec *)) {
+    const uint32_t seen = v->count_seen ? *(volatile const uint32_t *)v->count_seen : 0xFFFFFFFFu;
+    return (seen != 0xFFFFFFFFu && (seen == 0 || is_tree_list_of_that_length(seen, v))) ? 32u : 0u;
+}
+
 int dense_refresh_public(qg_vec *v, hipStream_t s) { return dense_refresh(v, s); }
 // InitArgs of qg_vec_reset_done(v, seed) without a list: what a kernel that resets finished envs itself needs (qg_vec_mid_head_sample_step)
 void fill_reset_done_args_public(const qg_vec *v, uint64_t seed, InitArgs &ia) {

@@ -175,6 +175,7 @@ void done_list_appended(qg_vec *v, bool trusted);
 void fill_step_args_public(const qg_vec *v, StepArgs &a);
 // the per-env fault words in caller-owned memory (device-visible, [B] uint32, current content carried over); not part of the C ABI: the scalar env's
 int bind_error(qg_vec *v, uint32_t *error_dev);
+uint32_t reset_second_grid_public(const qg_vec *v, bool is_tree_list_of_that_length(uint32_t, const qg_vec *));  // workgroups of the launch behind a reset's trees
 uint32_t reset_tree_grid_public(const qg_vec *v, uint32_t most);  // workgroups of a reset's tree launch, from the list lengths the handle's resets have reported
 unsigned long long *kernel_clock_slot_public(const qg_vec *v);  // qg_vec_set_kernel_clock: the slot of the launch about to be enqueued, or null
 // qg_vec_track_dense: rewrite the whole tracked observation from the state (after a launch that changed states without updating it)

@@ -173,8 +173,7 @@ struct InitArgs {
     const uint64_t *mask;      // reset_done, TILE: the finished envs as the bits a step launch left (StepArgs::done_mask), mask_words words; the envs to
     uint32_t mask_words;       // reset are the set bits in ascending order FOLLOWED by the list's entries (null: the list alone)
     uint32_t mask_epoch;       // StepArgs::done_epoch of the launch that wrote `mask`: a hint word that differs says "no bit is set" without a count
-    unsigned long long *tree_kclk;  // TILE64: the tree launch's kernel-clock slot (the launch behind it takes `kclk`)
-    uint32_t *count_pub;       // TILE64 (two launches per reset: trees, then the others): where the tree launch leaves the mask's count for the launch behind it
+    uint32_t *count_pub;       // (unused by the init kernels: PauliEnv's two launches pass the mask's count through qg_vec::mask_count)
     const uint32_t *list;      // reset_done, compacted: thread i resets env list[i], i < *list_count (or null: thread = env)
     uint32_t *list_count;      // [2]: length, reader ticket (device_common.hpp list_count_take)
     uint32_t tree_grid;        // workgroups of this launch that walk a list as trees (plan::tree_grid), entry i on workgroup i mod tree_grid

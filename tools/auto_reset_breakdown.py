@@ -145,8 +145,8 @@ def main():
     for label, kw, step in (("plain options", dict(add_inverts=False, track_solution=False), "q64_step1_kernel<LIST>"),
                             ("reference defaults (add_inverts, solution log)", dict(add_inverts=True, track_solution=True), "q64_inv2_kernel")):
         env = VecEnv("clifford", 24, gs24, B, add_perms=False, difficulty=256, **kw)
-        run(f"CliffordGym 24q, {label} (tree + init + step per pair; the step leaves its finishers as a mask)", env, len(gs24), 3,
-            ["q64_reset_tree_kernel", "q64_init_kernel", step], True, out, reset_slots=2)
+        run(f"CliffordGym 24q, {label} (reset + step per pair; the step leaves its finishers as a mask)", env, len(gs24), 2,
+            ["q64_reset_done_kernel", step], True, out)
         del env
     gs5 = line_gateset("pauli", 20)
     env = VecEnv("pauli", 20, gs5, B, add_perms=False, track_solution=False, max_rotations=5, difficulty=256, pauli_diff_scale=8)
