@@ -560,11 +560,12 @@ __global__ __launch_bounds__(256) void q64_inv2_kernel(StepArgs a) {
 // and scattered at per-lane addresses, `solved` comes from the incrementally kept 64-bit `bad` mask.
 // LIST: also append the envs that finish to StepArgs::done_list (F_DONE_LIST; its own instantiation: the plain kernel's code stays as it is)
 template <int NS, bool HAS_Z, bool FEAT>
-__device__ __forceinline__ bool q64_step1_body(const StepArgs &a, uint64_t env) {  // returns is_final
-    const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+// (`act`, and `g` = gates[act] when it is in range: loaded by the caller -- q64_reset_step_kernel's reset lanes ask for them before the scramble, the env's first step
+// then has one trip to memory left, not three)
+__device__ __forceinline__ bool q64_step1_with(const StepArgs &a, uint64_t env, int64_t act, GateEntry g) {  // returns is_final
+    const uint32_t lane = (uint32_t)(env & (QG_WAVE - 1));  // (= the thread's lane in the step kernels; a reset's lane steps the env it has just written from wherever it sits)
     uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Q64Rows<NS>::G * 64);
     uint64_t *badp = reinterpret_cast<uint64_t *>(a.bad) + env;
-    const int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
     int32_t depth = a.depth[env];
     const uint64_t bad0 = *badp;
     uint64_t bad = bad0;
@@ -573,7 +574,6 @@ __device__ __forceinline__ bool q64_step1_body(const StepArgs &a, uint64_t env) 
     const bool in_range = act >= 0 && act < (int64_t)a.num_actions;  // clifford.rs:324
     float penalty = 0.0f;
     if (in_range) {
-        const GateEntry g = a.gates[act];
         penalty = g.penalty;
         if (FEAT && (a.flags & F_LAYERS)) penalty = layers_penalty(layer_rec(a.layers, env, 2 * a.N + 2), a.N, a.descs[act], a.w);
         const uint32_t q0 = g.ops & 63u, q1 = (g.ops >> 6) & 63u, m = (g.ops >> 12) & 0xFFFFu;
@@ -635,6 +635,13 @@ __device__ __forceinline__ bool q64_step1_body(const StepArgs &a, uint64_t env) 
     if (FEAT && fault) atomicOr(&a.error[env], fault);
     return depth == 0 || solved;
 }
+template <int NS, bool HAS_Z, bool FEAT>
+__device__ __forceinline__ bool q64_step1_body(const StepArgs &a, uint64_t env) {  // returns is_final
+    const int64_t act = load_action(a.actions, env, a.flags & F_ACT64);
+    GateEntry g{0u, 0.0f};
+    if (act >= 0 && act < (int64_t)a.num_actions) g = a.gates[act];
+    return q64_step1_with<NS, HAS_Z, FEAT>(a, env, act, g);
+}
 // (LIST: the envs that finish are left as one bit each in StepArgs::done_mask -- the wave's ballot, device_common.hpp done_mask_store; round 4 appended
 // their indices to a list with one atomic per workgroup of 1 024 threads)
 template <int NS, bool HAS_Z, bool FEAT, bool LIST = false>
@@ -691,8 +698,17 @@ __device__ inline void q64_init_finish(const InitArgs &a, uint64_t env, const Q6
 // T = 64: q64_init_kernel, a workgroup is one wave.  T = 256, RESET_ONLY: the workgroups behind the trees in q64_reset_done_kernel (qg_vec_reset_done in one launch; no
 // set_state code, whose symplectic check alone takes 256 registers and scratch): all four waves count the mask (or take the list's length) and learn whether the
 // trees of the same launch have taken the list -- then everybody leaves -- and three of them leave anyway before the first wave does the work.
-template <int NS, bool HAS_Z, uint32_t T = 64, bool RESET_ONLY = false>
-__device__ __forceinline__ bool q64_init_body(const InitArgs &a, uint32_t vblock) {
+// `after(env)`: called by the lane that has written env's fresh episode (state, depth, bad mask, log lengths) -- q64_reset_step_kernel's first step of that env.
+// `after.ahead(env)`: called once the env is known, before its scramble, by the lane(s) that may finish it (that step's action and gate entry are requested there).
+// WAVE_STEP (q64_reset_step_kernel without solution log / layer weights): the tree's wave takes the env's first step itself on the rows it holds across its lanes,
+// before it stores them -- nothing the reset wrote is read back (reading back: +3 us a tree: the stores' round trip, an L1 invalidate, the loads).
+struct Q64NoAfter {
+    static constexpr bool WAVE_STEP = false;
+    __device__ void ahead(uint64_t) {}
+    __device__ void operator()(uint64_t) const {}
+};
+template <int NS, bool HAS_Z, uint32_t T = 64, bool RESET_ONLY = false, typename After = Q64NoAfter>
+__device__ __forceinline__ bool q64_init_body(const InitArgs &a, uint32_t vblock, After after = After()) {
     using Rows = Q64Rows<NS>;
     // reset scramble on LDS-resident rows (device_common.hpp); one wave per block: NS * 512 B <= 32 KiB
     __shared__ uint64_t lds_rows[NS][QG_WAVE];
@@ -700,49 +716,41 @@ __device__ __forceinline__ bool q64_init_body(const InitArgs &a, uint32_t vblock
     uint64_t env = tid;
     Rows s;
     const bool trees = T != 64 && a.coop && a.n_draws >= 64u && a.tree_grid;  // this launch's first workgroups are trees and take the lists tree_takes says
-    if (a.mask) {  // qg_vec_reset_done after a step that left its finishers as bits: count them, entry i by a search
+    if (a.list) {  // qg_vec_reset_done: the finished envs are the bits of the mask the step before left (if it did), then the entries of the compacted / appended list
         __shared__ uint32_t mask_part[T + 2 + T / 64];
-        uint32_t count = 0;
         DoneMaskShare share;
-        done_mask_load<T>(a.mask, a.B, a.mask_words, share);
-        count = *done_mask_hint(a.mask, a.B) != a.mask_epoch ? 0u : done_mask_scan<T>(share, mask_part);
-        if (T != 64 && (!count || (trees && tree_takes(count, a.n_draws)) || threadIdx.x >= QG_WAVE)) return false;  // (after the scan's barriers: nothing below has one)
-        if ((uint64_t)vblock * QG_WAVE >= (uint64_t)count * ((a.coop && coop_takes(count, a.B)) ? QG_COOP_LANES : 1u)) return false;  // (the list ends before this vblock)
+        uint32_t mcount = 0;
+        if (a.mask) {
+            done_mask_load<T>(a.mask, a.B, a.mask_words, share);
+            mcount = *done_mask_hint(a.mask, a.B) != a.mask_epoch ? 0u : done_mask_scan<T>(share, mask_part);
+        }
+        const uint32_t len = mcount + a.list_count[0];
+        const uint32_t lanes = (a.coop && coop_takes(len, a.B)) ? QG_COOP_LANES : 1u;
+        // (T = 256: that launch reads its lists without tickets -- the host gives it InitArgs::zero_count -- and `threads` only says which workgroups have work)
+        const uint32_t count = list_count_take(a.list_count, len, (uint64_t)len * lanes * (T / QG_WAVE), vblock, a.zero_count);
+        // (without reader tickets -- InitArgs::zero_count -- the list the trees have taken is still there: the same test says so)
+        if (a.zero_count && trees && tree_takes(count, a.n_draws)) return false;
+        if (T != 64 && threadIdx.x >= QG_WAVE) return false;  // (after the scan's and list_count_take's barriers: nothing below has one)
+        if ((uint64_t)vblock * QG_WAVE >= (uint64_t)count * lanes) return false;  // (the list ends before this vblock)
         const uint64_t *mask = a.mask;
+        const uint32_t *list = a.list;
         const uint32_t words = a.mask_words;
-        auto entry = [=](uint32_t i) -> uint32_t { return done_mask_nth<T>(mask, words, mask_part, i); };
-        if (a.coop && coop_takes(count, a.B)) {  // few finished envs: 16 lanes each
+        auto entry = [=](uint32_t i) -> uint32_t { return i < mcount ? done_mask_nth<T>(mask, words, mask_part, i) : list[i - mcount]; };
+        if (lanes != 1u) {  // few finished envs: 16 lanes each
             const uint32_t N = a.N;
+            if (tid / QG_COOP_LANES < count) after.ahead(entry((uint32_t)(tid / QG_COOP_LANES)));
             const uint64_t *rows = scramble_coop<uint64_t, NS>(a, count, &lds_rows[0][0], env, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); },
                                                                vblock, entry, QG_WAVE);
             if (!rows) return true;
 #pragma unroll
             for (int k = 0; k < NS; ++k) s.r[k] = rows[k];
             q64_init_finish<NS, HAS_Z, RESET_ONLY>(a, env, s);
+            after(env);
             return true;
         }
         if (tid >= count) return true;
         env = entry((uint32_t)tid);
-    } else if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
-        const uint32_t len = a.list_count[0];
-        // (T = 256: that launch reads its lists without tickets -- the host gives it InitArgs::zero_count -- and `threads` only says which workgroups have work)
-        const uint32_t count = list_count_take(a.list_count, len, (uint64_t)len * ((a.coop && coop_takes(len, a.B)) ? QG_COOP_LANES : 1u) * (T / QG_WAVE), vblock, a.zero_count);
-        // (without reader tickets -- InitArgs::zero_count -- the list the trees have taken is still there: the same test says so)
-        if (a.zero_count && trees && tree_takes(count, a.n_draws)) return false;
-        if (T != 64 && threadIdx.x >= QG_WAVE) return false;  // (after list_count_take's barrier: nothing below has one)
-        if ((uint64_t)vblock * QG_WAVE >= (uint64_t)count * ((a.coop && coop_takes(count, a.B)) ? QG_COOP_LANES : 1u)) return false;  // (the list ends before this vblock)
-        if (a.coop && coop_takes(count, a.B)) {  // few finished envs: 16 lanes each
-            const uint32_t N = a.N;
-            const uint64_t *rows = scramble_coop<uint64_t, NS>(a, count, &lds_rows[0][0], env, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); },
-                                                               vblock, ListEntry{a.list}, QG_WAVE);
-            if (!rows) return true;
-#pragma unroll
-            for (int k = 0; k < NS; ++k) s.r[k] = rows[k];
-            q64_init_finish<NS, HAS_Z, RESET_ONLY>(a, env, s);
-            return true;
-        }
-        if (tid >= count) return true;
-        env = a.list[tid];
+        after.ahead(env);
     } else {
         if (RESET_ONLY) return false;  // (that instantiation is only launched with a list)
         if (env >= a.B) return true;
@@ -782,6 +790,7 @@ __device__ __forceinline__ bool q64_init_body(const InitArgs &a, uint32_t vblock
         for (int k = 0; k < NS; ++k) s.r[k] = lds_rows[k][L];
     }
     q64_init_finish<NS, HAS_Z, RESET_ONLY>(a, env, s);
+    after(env);
     return true;
 }
 template <int NS, bool HAS_Z>
@@ -958,8 +967,8 @@ static hipError_t q64_launch_step(const StepArgs &a, hipStream_t s) {
 // scramble_tree64_ops)
 constexpr int Q64_TREE_WAVES = 4;
 constexpr uint32_t Q64_TREE_THREADS = 64u * Q64_TREE_WAVES;
-template <int NS, bool HAS_Z>
-__device__ __forceinline__ void q64_reset_tree_body(const InitArgs &a) {  // workgroups blockIdx.x < a.tree_grid of q64_reset_done_kernel
+template <int NS, bool HAS_Z, typename After = Q64NoAfter>
+__device__ __forceinline__ void q64_reset_tree_body(const InitArgs &a, After after = After()) {  // workgroups blockIdx.x < a.tree_grid of q64_reset_done_kernel / q64_reset_step_kernel
     __shared__ uint64_t prod[Q64_TREE_WAVES][64];
     __shared__ RowopMasks64 tree_gates[Q64_TREE_WAVES][QG_WAVE];
     __shared__ uint32_t mask_part[Q64_TREE_THREADS + 2 + Q64_TREE_WAVES];
@@ -970,41 +979,71 @@ __device__ __forceinline__ void q64_reset_tree_body(const InitArgs &a) {  // wor
     const bool table_fits = a.num_actions <= QG_TREE_TABLE_MAX;
     uint32_t opaque_zero;
     asm("v_mov_b32 %0, 0" : "=v"(opaque_zero));
-    uint32_t len;
+    // the finished envs: the bits of the mask the step before left (if it did), then the entries of the list (compacted from raised flags; or, after a fused
+    // launch, the few envs that were reset inside it and final again after their first step)
     DoneMaskShare share;
-    if (a.mask) {  // the step before left its finishers as bits: every workgroup counts them (a hint word with another number: nobody finished)
-        const uint32_t hint_v = done_mask_hint(a.mask, a.B)[opaque_zero];
+    uint32_t hint_v = 0;
+    const uint32_t lcount_v = a.list_count[opaque_zero];
+    if (a.mask) {  // every workgroup counts the mask (a hint word with another number: nobody finished)
+        hint_v = done_mask_hint(a.mask, a.B)[opaque_zero];
         done_mask_load<Q64_TREE_THREADS>(a.mask, a.B, a.mask_words, share);
-        asm volatile("" ::: "memory");
-        if (table_fits)
-            for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) tree_table[i] = a.rowops[i];
-        len = (uint32_t)__builtin_amdgcn_readfirstlane((int)hint_v) != a.mask_epoch ? 0u : done_mask_scan<Q64_TREE_THREADS>(share, mask_part);
-    } else {
-        const uint32_t len_v = a.list_count[opaque_zero];
-        asm volatile("" ::: "memory");
-        if (table_fits)
-            for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) tree_table[i] = a.rowops[i];
-        len = (uint32_t)__builtin_amdgcn_readfirstlane((int)len_v);
     }
+    asm volatile("" ::: "memory");
+    if (table_fits)
+        for (uint32_t i = threadIdx.x; i < a.num_actions; i += blockDim.x) tree_table[i] = a.rowops[i];
+    const bool mask_empty = !a.mask || (uint32_t)__builtin_amdgcn_readfirstlane((int)hint_v) != a.mask_epoch;
+    const uint32_t mcount = mask_empty ? 0u : done_mask_scan<Q64_TREE_THREADS>(share, mask_part);
+    const uint32_t len = mcount + (uint32_t)__builtin_amdgcn_readfirstlane((int)lcount_v);
     if (a.count_out && blockIdx.x == 0 && threadIdx.x == 0) *a.count_out = len;  // (host memory: sizes the next launches' tree grid, qgym_api.cpp reset_tree_grid)
     if (threadIdx.x == 0) phase_stamp(a.kclk, a.kclk_waves, 0);  // the count is known
     if (!tree_takes(len, a.n_draws)) return;
-    const uint32_t count = a.mask ? len : list_count_take(a.list_count, len, (uint64_t)(len < a.tree_grid ? len : a.tree_grid) * Q64_TREE_THREADS, blockIdx.x, a.zero_count);
+    // (no tickets with InitArgs::zero_count: workgroup 0 zeroes the idle list's length; the barrier inside -- workgroups with work -- also makes the table visible)
+    const uint32_t count = list_count_take(a.list_count, len, (uint64_t)(len < a.tree_grid ? len : a.tree_grid) * Q64_TREE_THREADS, blockIdx.x, a.zero_count);
     const uint32_t N = a.N;
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
     // entry blockIdx.x of the list, then + tree_grid, ...: the launch has that many tree workgroups for a list of any (tree) length
     for (uint32_t item = blockIdx.x; item < count; item += a.tree_grid) {
         if (item != blockIdx.x) __syncthreads();  // (the previous round's LDS has been read)
         // (the first entry from the thread that holds it in its share of the mask: a barrier, no search; the barrier also makes the table visible)
-        const uint64_t env = !a.mask ? a.list[item]
+        const uint64_t env = item >= mcount ? a.list[item - mcount]
                            : item == blockIdx.x ? done_mask_find<Q64_TREE_THREADS>(a.mask, a.mask_words, share, mask_part, item)
                                                 : done_mask_nth<Q64_TREE_THREADS>(a.mask, a.mask_words, mask_part, item);
         if (threadIdx.x == 0) phase_stamp(a.kclk, a.kclk_waves, 1);  // the env is known
+        if (threadIdx.x < QG_WAVE) after.ahead(env);  // (wave 0 finishes the env)
         uint64_t myrow = 0;
         // q64_init_finish with the wave's 64 lanes: lane s holds the row of slot s (scramble_tree64 runs on the transpose), stores its 8 bytes of the
         // env's tile and compares with the identity's; lane 0 writes the scalars (reset_internals, clifford.rs:272-283)
         if (!scramble_tree64<NS, Q64_TREE_WAVES>(a, env, myrow, prod, tree_gates, table_fits ? tree_table : a.rowops, [N](uint32_t k) -> uint64_t { return q64_identity_word<NS, HAS_Z>((int)k, N); })) continue;
         phase_stamp(a.kclk, a.kclk_waves, 2);  // the scramble is done (wave 0)
+        float step_penalty = 0.0f;
+        if constexpr (After::WAVE_STEP) {  // the env's first step (q64_step1_with, on lanes: lane s holds the row of slot s; the gate's qubits are the same on every lane)
+            const int64_t act = after.act;
+            if (act >= 0 && act < (int64_t)after.a.num_actions) {
+                const GateEntry g = after.g;
+                step_penalty = g.penalty;
+                const uint32_t q0 = g.ops & 63u, q1 = (g.ops >> 6) & 63u, m = (g.ops >> 12) & 0xFFFFu;
+                if (m != Q64_IDENTITY) {
+                    const uint32_t s0 = HAS_Z ? 2u * q0 : q0, s1 = HAS_Z ? 2u * q1 : q1;  // the slots of x[q0], x[q1] (z: the next one)
+                    auto row_of = [&](uint32_t slot) -> uint64_t {
+                        const int l = __builtin_amdgcn_readfirstlane((int)slot);
+                        return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)myrow, l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(myrow >> 32), l) << 32);
+                    };
+                    const uint64_t x0 = row_of(s0), x1 = row_of(s1), z0 = HAS_Z ? row_of(s0 + 1u) : 0ull, z1 = HAS_Z ? row_of(s1 + 1u) : 0ull;
+                    auto mix = [&](uint32_t k) -> uint64_t {
+                        const uint32_t b = m >> (4 * k);
+                        uint64_t o = ((0ull - (uint64_t)(b & 1u)) & x0) ^ ((0ull - (uint64_t)((b >> 2) & 1u)) & x1);
+                        if (HAS_Z) o ^= ((0ull - (uint64_t)((b >> 1) & 1u)) & z0) ^ ((0ull - (uint64_t)((b >> 3) & 1u)) & z1);
+                        return o;
+                    };
+                    const uint64_t nx0 = mix(0), nx1 = mix(2), nz0 = HAS_Z ? mix(1) : 0ull, nz1 = HAS_Z ? mix(3) : 0ull;
+                    // q1's rows first, then q0's (q0's value wins when q0 == q1, as in q64_apply)
+                    myrow = lane == s1 ? nx1 : myrow;
+                    if (HAS_Z) myrow = lane == s1 + 1u ? nz1 : myrow;
+                    myrow = lane == s0 ? nx0 : myrow;
+                    if (HAS_Z) myrow = lane == s0 + 1u ? nz0 : myrow;
+                }
+            }
+        }
         const uint32_t le = (uint32_t)(env & (QG_WAVE - 1));
         uint64_t *tile = reinterpret_cast<uint64_t *>(reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Q64Rows<NS>::G * 64));
         if (lane < (uint32_t)NS) tile[((uint64_t)(lane >> 1) * 64 + le) * 2 + (lane & 1u)] = myrow;  // group lane / 2, the env's 16-byte piece, its low or high word
@@ -1021,10 +1060,27 @@ __device__ __forceinline__ void q64_reset_tree_body(const InitArgs &a) {  // wor
         }
         const bool solved = differs == 0;
         if (a.bad) reinterpret_cast<uint64_t *>(a.bad)[env] = bad;
+        if constexpr (After::WAVE_STEP) {  // reset_internals (clifford.rs:272-283), then the step's bookkeeping (clifford.rs:342-346) on top of it: the values the two calls leave
+            const StepArgs &sa = after.a;
+            const int32_t depth = a.depth_value > 0 ? a.depth_value - 1 : 0;
+            const float reward = (solved ? 1.0f : 0.0f) - step_penalty;
+            const bool fin = depth == 0 || solved;
+            if (sa.rewards_seq) sa.rewards_seq[env] = reward;
+            if (sa.dones_seq) sa.dones_seq[env] = (uint8_t)fin;
+            a.depth[env] = depth;
+            a.success[env] = (uint8_t)solved;
+            a.reward[env] = reward;
+            a.done[env] = (uint8_t)fin;
+            if (fin) {  // (rare: one atomic per env that is final again after its first step)
+                const uint32_t slot = atomicAdd(sa.done_count, 1u);
+                if (slot < sa.B) sa.done_list[slot] = (uint32_t)env;
+            }
+        } else {
         a.depth[env] = a.depth_value;
         a.success[env] = (uint8_t)solved;
         a.reward[env] = solved ? 1.0f : 0.0f;
         a.done[env] = (uint8_t)(a.depth_value == 0 || solved);
+        }
         a.inverted[env] = (uint8_t)((HAS_Z && a.check_symplectic) ? Q64_FLAG_SYMPLECTIC : 0u);  // identity + gates: symplectic (q64_init_finish, mode 2)
         a.error[env] = 0;
         a.sol_len[env * 2] = 0;
@@ -1036,6 +1092,7 @@ __device__ __forceinline__ void q64_reset_tree_body(const InitArgs &a) {  // wor
             lay[a.layers_len - 1] = 0;
         }
         phase_stamp(a.kclk, a.kclk_waves, 3);  // everything is stored
+        if constexpr (!After::WAVE_STEP) after(env);
     }
 }
 
@@ -1047,6 +1104,77 @@ __global__ __launch_bounds__(Q64_TREE_THREADS) void q64_reset_done_kernel(InitAr
     KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
     if (blockIdx.x < a.tree_grid) q64_reset_tree_body<NS, HAS_Z>(a);
     else (void)q64_init_body<NS, HAS_Z, Q64_TREE_THREADS, true>(a, blockIdx.x - a.tree_grid);
+}
+// the first step of an env a reset lane / wave of q64_reset_step_kernel has just written (q64_init_body / q64_reset_tree_body: `After`)
+template <int NS, bool HAS_Z, bool FEAT>
+struct Q64FirstStep {
+    static constexpr bool WAVE_STEP = !FEAT;
+    const StepArgs &a;
+    int64_t act;
+    GateEntry g;
+    __device__ void ahead(uint64_t env) {  // (nothing of this depends on the reset)
+        act = load_action(a.actions, env, a.flags & F_ACT64);
+        g = GateEntry{0u, 0.0f};
+        if (act >= 0 && act < (int64_t)a.num_actions) g = a.gates[act];
+    }
+    __device__ void operator()(uint64_t env) const {
+#ifdef QG_X64_NOFIRST  // development: what the first step costs the trees (results are wrong)
+        return;
+#endif
+        // the fresh episode's stores -- in the tree, by the wave's other lanes too -- are in the L2 before this lane's loads of them are issued, and those
+        // loads do not take a line this CU read earlier (a step workgroup's neighbours of this env).  Not __threadfence(): its release half writes the whole
+        // L2's dirty lines back (the L2s of the XCDs are not coherent with each other) -- 26 us a launch instead of 11
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (q64_step1_with<NS, HAS_Z, FEAT>(a, env, act, g)) {  // (rare: one atomic per env that is final again after its first step)
+            const uint32_t slot = atomicAdd(a.done_count, 1u);
+            if (slot < a.B) a.done_list[slot] = (uint32_t)env;
+        }
+    }
+};
+// qg_vec_reset_done followed by qg_vec_step in ONE launch (qg_vec_reset_done_step), as kernels_qm.hip qm_reset_step_kernel: the grid is [tree workgroups][step
+// workgroups][the per-lane / 16-lane reset workgroups].  Which envs are being reset is read from the mask of is_final bits the PREVIOUS step left (plus the
+// rare entries of the list) and nobody writes during this launch; this launch writes the OTHER mask.  A reset env's first step is taken by the lane that has just
+// written its fresh episode (q64_step1_body, reading it back: its own stores, made visible by a fence), and if the env is final again after it, that lane
+// appends it to the OTHER list.  Results are those of the two calls.
+struct Q64ResetStepArgs {
+    InitArgs reset;
+    StepArgs step;
+    uint32_t step_blocks;
+};
+template <int NS, bool HAS_Z, bool FEAT>
+__global__ __launch_bounds__(Q64_TREE_THREADS) void q64_reset_step_kernel(Q64ResetStepArgs ra) {
+    KernelClock kclk(ra.step.kclk, ra.step.kclk_waves);  // device_common.hpp
+    const StepArgs &a = ra.step;
+#ifdef QG_X64_STEPS_FIRST  // development: the grid's order
+    const uint32_t trees = ra.reset.tree_grid, b = blockIdx.x < ra.step_blocks ? blockIdx.x + trees : blockIdx.x < ra.step_blocks + trees ? blockIdx.x - ra.step_blocks : blockIdx.x;
+#else
+    const uint32_t b = blockIdx.x, trees = ra.reset.tree_grid;
+#endif
+    if (b >= trees && b < trees + ra.step_blocks) {  // a step workgroup
+        const uint64_t env = (uint64_t)(b - trees) * blockDim.x + threadIdx.x;
+        uint64_t resets = env < a.B ? ra.reset.mask[env >> 6] : 0ull;  // (one word per wave)
+        uint32_t relisted = ra.reset.list_count[0];
+        relisted = relisted < a.B ? relisted : (uint32_t)a.B;
+        for (uint32_t i = 0; i < relisted; ++i) {  // (wave-uniform; rare: envs reset in the previous launch and final again after their first step)
+            const uint32_t e = ra.reset.list[i];
+            if ((e >> 6) == (uint32_t)(env >> 6)) resets |= 1ull << (e & 63u);
+        }
+        bool fin = false;
+        if (env < a.B && !((resets >> (env & 63u)) & 1ull)) fin = q64_step1_body<NS, HAS_Z, FEAT>(a, env);
+        done_mask_store(a.done_mask, a.B, fin, env, a.done_epoch);  // (an env being reset: bit clear)
+        return;
+    }
+    Q64FirstStep<NS, HAS_Z, FEAT> first_step{a, 0, GateEntry{0u, 0.0f}};
+    if (b < trees) q64_reset_tree_body<NS, HAS_Z>(ra.reset, first_step);
+    else (void)q64_init_body<NS, HAS_Z, Q64_TREE_THREADS, true>(ra.reset, b - trees - ra.step_blocks, first_step);
+}
+template <int NS, bool HAS_Z>
+static hipError_t q64_launch_reset_step(const Q64ResetStepArgs &ra, hipStream_t s) {
+    const unsigned grid = ra.reset.tree_grid + ra.step_blocks + grid_for(ra.reset.B, 64);
+    if (ra.step.flags & (F_TRACK | F_LAYERS)) hipLaunchKernelGGL((q64_reset_step_kernel<NS, HAS_Z, true>), dim3(grid), dim3(Q64_TREE_THREADS), 0, s, ra);
+    else hipLaunchKernelGGL((q64_reset_step_kernel<NS, HAS_Z, false>), dim3(grid), dim3(Q64_TREE_THREADS), 0, s, ra);
+    return hipGetLastError();
 }
 template <int NS, bool HAS_Z>
 static hipError_t q64_launch_init(const InitArgs &a, hipStream_t s) {
@@ -1082,6 +1210,14 @@ static hipError_t q64_launch_init(const InitArgs &a, hipStream_t s) {
 hipError_t q64_step(const StepArgs &a, uint32_t ns, bool has_z, hipStream_t s) {
     if (!a.B) return hipSuccess;
     Q64_DISPATCH(q64_launch_step, a)
+}
+hipError_t q64_reset_step(const InitArgs &reset, const StepArgs &step, uint32_t ns, bool has_z, hipStream_t s) {
+    if (!reset.B) return hipSuccess;
+    Q64ResetStepArgs ra;
+    ra.reset = reset;
+    ra.step = step;
+    ra.step_blocks = grid_for(step.B, Q64_TREE_THREADS);
+    Q64_DISPATCH(q64_launch_reset_step, ra)
 }
 hipError_t q64_init(const InitArgs &a, uint32_t ns, bool has_z, hipStream_t s) {
     if (!a.B) return hipSuccess;

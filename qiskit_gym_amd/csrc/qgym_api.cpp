@@ -1169,7 +1169,7 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     if (dense_rides_in_step(v)) a.dense = v->dense;
     a.kclk = kernel_clock_slot(v);
     a.kclk_waves = v->kclk_waves;
-    HIP_TRY(qm_reset_step(ia, a, v->nxp, v->has_z, s));
+    HIP_TRY(v->layout == LAYOUT_TILE64 ? q64_reset_step(ia, a, v->nxp, v->has_z, s) : qm_reset_step(ia, a, v->nxp, v->has_z, s));
     v->step_index += 1;
     // the list just appended to is the current one, the idle list (zeroed by this launch) is the next launch's target, the one just consumed idles
     std::swap(v->done_list, v->done_list_alt);   // (current, alt, spare) <- (alt, spare, current)
@@ -1378,7 +1378,7 @@ int qg_plan_query(const qg_config *cfg, uint64_t batch, uint32_t num_actions, in
         break;
     }
     case QG_PLAN_RESET_DONE_STEP:
-        name = plan::reset_step_fusable(hp) ? "qm_reset_step_kernel (after a list-leaving step)"
+        name = plan::reset_step_fusable(hp) ? (hp.layout == LAYOUT_TILE64 ? "q64_reset_step_kernel (after a list-leaving step)" : "qm_reset_step_kernel (after a list-leaving step)")
                : plan::reset_step_in_word_kernel(hp, num_actions) ? "word_reset_step_kernel" : "two launches";
         break;
     case QG_PLAN_OBSERVE_DENSE:

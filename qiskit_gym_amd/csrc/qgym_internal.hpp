@@ -231,6 +231,7 @@ hipError_t qm_init(const InitArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
 // qg_vec_reset_done (mask + list in `reset`) + qg_vec_step (`step`, F_DONE_LIST: writes ITS mask, a reset env that is final again after its first step
 // goes to ITS list) in one launch
 hipError_t qm_reset_step(const InitArgs &reset, const StepArgs &step, uint32_t nxp, bool has_z, hipStream_t s);
+hipError_t q64_reset_step(const InitArgs &reset, const StepArgs &step, uint32_t ns, bool has_z, hipStream_t s);  // kernels_qm64.hip: the same for 64-bit rows
 hipError_t qm_export(const ObsArgs &a, uint32_t nxp, bool has_z, hipStream_t s);
 // dense {0,1} observation in an element type of `elem_size` bytes whose 1 is the bit pattern `one`
 hipError_t qm_export_typed(const void *state, uint64_t B, uint32_t N, uint32_t D, uint32_t nxp, bool has_z, void *out, uint32_t elem_size,

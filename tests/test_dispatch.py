@@ -128,7 +128,9 @@ def test_reset_done_step_in_one_launch():
     assert plan("linear_function", 8, RESET_DONE_STEP, num_actions=28, **DEFAULT) == "word_reset_step_kernel"    # ... with the reference's defaults
     assert plan("permutation", 9, RESET_DONE_STEP, num_actions=12, **DEFAULT) == "word_reset_step_kernel"
     assert plan("linear_function", 8, RESET_DONE_STEP, num_actions=0, **PLAIN) == "two launches"                  # (an empty gateset: reset is an error)
-    for kind, n, cfg in (("clifford", 16, DEFAULT), ("clifford", 24, DEFAULT), ("clifford", 24, PLAIN), ("linear_function", 24, DEFAULT), ("permutation", 27, PLAIN), ("pauli", 20, {})):
+    assert plan("clifford", 24, RESET_DONE_STEP, **PLAIN).startswith("q64_reset_step_kernel")            # 64-bit rows
+    assert plan("linear_function", 40, RESET_DONE_STEP, **PLAIN).startswith("q64_reset_step_kernel")
+    for kind, n, cfg in (("clifford", 16, DEFAULT), ("clifford", 24, DEFAULT), ("linear_function", 24, DEFAULT), ("permutation", 27, PLAIN), ("pauli", 20, {})):
         assert plan(kind, n, RESET_DONE_STEP, **cfg) == "two launches", (kind, n)
 
 

@@ -341,6 +341,10 @@ def test_reset_done_random_shapes_against_the_oracle(case):
     ("clifford", 5, 333, 4, True, False),
     ("linear_function", 12, 1000, 5, False, False),
     ("linear_function", 32, 2048, 66, False, True),
+    ("clifford", 24, 4096, 70, False, False),    # 64-bit rows (q64_reset_step_kernel): trees
+    ("clifford", 20, 777, 3, True, False),       # ... short scrambles: the 16-lane / per-lane reset workgroups behind the trees and the steps; solution log
+    ("linear_function", 40, 3000, 66, False, False),
+    ("clifford", 32, 8192, 70, True, False),
 ])
 def test_reset_done_step_in_one_launch_equals_the_two_calls(kind, n, B, diff, track, dense):
     """qg_vec_reset_done_step (from its second call on: ONE launch whose grid holds the reset's and the step's workgroups) against
@@ -476,17 +480,18 @@ def test_reset_done_step_with_the_reference_default_options_equals_the_two_calls
                 assert fused.solution(e) == envs[e].solution()
 
 
-def test_reset_done_step_inside_a_captured_graph_replays_like_eager_calls():
+@pytest.mark.parametrize("n", [16, 24])  # (32-bit rows: qm_reset_step_kernel; 64-bit rows: q64_reset_step_kernel)
+def test_reset_done_step_inside_a_captured_graph_replays_like_eager_calls(n):
     """A graph of 16 x reset_done_step (its first call compacts the list from the flags, the others are single launches) replayed three times
     against the same calls made eagerly on a twin: the device-side lists and flag arrays of consecutive replays line up whatever the
     graph's length (here even and odd)."""
     from qiskit_gym_amd.vec import VecEnv
 
-    gs = line_gateset("clifford", 16)
+    gs = line_gateset("clifford", n)
     A, B = len(gs), 8192
     for T in (16, 7):
         cfg = dict(add_inverts=False, add_perms=False, track_solution=False, difficulty=3, depth_slope=2, max_depth=128)
-        g_env, twin = VecEnv("clifford", 16, gs, B, **cfg), VecEnv("clifford", 16, gs, B, **cfg)
+        g_env, twin = VecEnv("clifford", n, gs, B, **cfg), VecEnv("clifford", n, gs, B, **cfg)
         acts = torch.randint(0, A, (T, B), dtype=torch.int32, device="cuda")
         stream = torch.cuda.Stream()
         with torch.cuda.stream(stream):

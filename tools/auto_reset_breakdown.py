@@ -142,12 +142,13 @@ def main():
         run(f"LinearFunctionGym 8q x {nb}, one launch per pair (word_reset_step_kernel)", env, len(gs2), 1, ["reset + step"], True, out)
         del env
     gs24 = line_gateset("clifford", 24)
-    for label, kw, step in (("plain options", dict(add_inverts=False, track_solution=False), "q64_step1_kernel<LIST>"),
-                            ("reference defaults (add_inverts, solution log)", dict(add_inverts=True, track_solution=True), "q64_inv2_kernel")):
-        env = VecEnv("clifford", 24, gs24, B, add_perms=False, difficulty=256, **kw)
-        run(f"CliffordGym 24q, {label} (reset + step per pair; the step leaves its finishers as a mask)", env, len(gs24), 2,
-            ["q64_reset_done_kernel", step], True, out)
-        del env
+    env = VecEnv("clifford", 24, gs24, B, add_perms=False, difficulty=256, add_inverts=False, track_solution=False)
+    run("CliffordGym 24q (64-bit rows), plain options, one launch per pair (q64_reset_step_kernel)", env, len(gs24), 1, ["reset + step"], True, out)
+    del env
+    env = VecEnv("clifford", 24, gs24, B, add_perms=False, difficulty=256, add_inverts=True, track_solution=True)
+    run("CliffordGym 24q, reference defaults (add_inverts, solution log), two launches per pair (the step leaves its finishers as a mask)", env, len(gs24), 2,
+        ["q64_reset_done_kernel", "q64_inv2_kernel"], True, out)
+    del env
     gs5 = line_gateset("pauli", 20)
     env = VecEnv("pauli", 20, gs5, B, add_perms=False, track_solution=False, max_rotations=5, difficulty=256, pauli_diff_scale=8)
     run("PauliGym 20q (tree + generate + step per pair; the step leaves its finishers as a mask)", env, len(gs5), 3,
