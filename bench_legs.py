@@ -164,8 +164,7 @@ def auto_reset(c):
             del aenv
         gs24 = _line_gateset("clifford", 24)
         aenv = VecEnv("clifford", 24, gs24, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=256)
-        legs["clifford24"] = dict(auto_reset_leg(aenv, len(gs24)), config=f"CliffordGym 24q x {B} (64-bit rows), difficulty 256: q64_reset_tree_kernel + q64_init_kernel + "
-                                                                          "q64_step1_kernel<LIST> per pair")
+        legs["clifford24"] = dict(auto_reset_leg(aenv, len(gs24)), config=f"CliffordGym 24q x {B} (64-bit rows), difficulty 256: q64_reset_step_kernel (one launch per pair)")
         del aenv
         gs5a = _line_gateset("pauli", 20)
         aenv = VecEnv("pauli", 20, gs5a, B, add_perms=False, track_solution=False, max_rotations=5, difficulty=256, pauli_diff_scale=8)

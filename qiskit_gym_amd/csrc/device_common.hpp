@@ -534,7 +534,7 @@ __device__ inline bool scramble_tree(const InitArgs &a, uint64_t env, uint32_t &
 }
 
 // The same for 64-bit rows (TILE64: CliffordEnv 16 < N <= 32, LinearFunctionEnv 32 < N <= 64): R <= 64 slots in a uint64 per column, all
-// 64 lanes hold a column.  `prod`: 4 x 64 uint64 of LDS.  Called from its own kernel (q64_reset_tree_kernel), one workgroup per listed env.
+// 64 lanes hold a column.  `prod`: 4 x 64 uint64 of LDS.  Called from the tree workgroups of q64_reset_done_kernel / q64_reset_step_kernel (q64_reset_tree_body), one workgroup per listed env.
 __device__ inline int64_t bit_mask64(uint64_t v, uint32_t off) { return (int64_t)(v << (63u - off)) >> 63; }  // bit `off` as 0 / -1
 template <int R>
 __device__ inline uint64_t gf2_cols_product64(const uint64_t *a_cols, uint64_t b) {
@@ -550,7 +550,7 @@ __device__ inline uint64_t gf2_cols_product64(const uint64_t *a_cols, uint64_t b
     return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 // Returns true on ALL lanes of wave 0, whose `col_out` is then the env's ROW of slot `lane` (the tree runs on the transpose, see scramble_tree:
-// a row per lane is what q64_reset_tree_kernel's finish wants -- 64 row words in one lane's registers cost 450 registers and scratch).
+// a row per lane is what q64_reset_tree_body's finish wants -- 64 row words in one lane's registers cost 450 registers and scratch).
 // 64-bit counterparts of rowop_parity / rowop_masks
 __device__ inline void rowop_parity64(uint64_t &col, uint64_t test, uint64_t flip) {
     col ^= (uint64_t)(0ll - (long long)(__builtin_popcountll(col & test) & 1)) & flip;
@@ -574,7 +574,7 @@ __device__ inline RowopMasks64 rowop_masks64(uint32_t o, bool transposed = false
 // at once), the serial loop reads them back as broadcasts.  A 64-column matrix fills the wave, so a wave runs one segment.  What bounds the chain is
 // the INSTRUCTION COUNT per gate, not a latency: at 512 trees per launch every SIMD holds two of these waves, each issues one instruction every
 // ~5 cycles, and the vector unit takes 4 cycles per instruction whatever wave it comes from.  Round 4's loop spent 22 vector instructions a gate on
-// 64-bit C++ (95 ns a gate, 6.1 of q64_reset_tree_kernel's 13.2 us at 256 gates); on 32-bit halves a parity is and, and, bcnt, bcnt, bfe and two
+// 64-bit C++ (95 ns a gate, 6.1 of the tree launch's 13.2 us at 256 gates); on 32-bit halves a parity is and, and, bcnt, bcnt, bfe and two
 // v_bitop3 (a ^ (b & c)): 14 a gate.  Measured and dropped (EXPERIMENTS.md round 5): decoding on the scalar unit from a v_readlane of the gate word (no
 // LDS; +4 us: ~50 scalar instructions a gate issue at the same 5 cycles each), eight waves of 32 gates (+4 us with it: twice the waves per SIMD, one more
 // level of products).

@@ -695,8 +695,8 @@ def test_pauli_finishers_left_as_a_mask_by_the_step(L, stagger):
 @pytest.mark.parametrize("kind,n,inverts", [("clifford", 24, True), ("clifford", 20, False), ("linear_function", 32, False), ("clifford", 16, True)])
 def test_staggered_finishers_left_as_a_mask_are_reset_by_trees(kind, n, inverts):
     """A collector's loop whose episodes (40 steps, 70 scramble gates) end spread over time: 1 / 40 of 8 192 envs per step -- <= B / 32, so
-    qg_vec_reset_done runs a tree per finished env (q64_reset_tree_kernel / the tree workgroups of qm_init_block), its entries found in the mask the
-    step left (TILE64: the tree launch counts the mask and leaves the count for q64_init_kernel, which has nothing to do).  Every env against the
+    qg_vec_reset_done runs a tree per finished env (the tree workgroups of q64_reset_done_kernel / qm_init_block), its entries found in the mask the
+    step left (TILE64: the workgroups behind the trees count the same mask and find nothing to do).  Every env against the
     oracle after every step, and the states at the end."""
     from oracle import OracleVec
     from qiskit_gym_amd.vec import VecEnv
