@@ -715,11 +715,17 @@ def test_staggered_finishers_left_as_a_mask_are_reset_by_trees(kind, n, inverts)
     all_env = torch.arange(B, device="cuda")
     t = 0
 
+    fuse_with = None  # the seed of a reset_done that the next step takes along (qg_vec_reset_done_step: one launch where the handle has it)
+
     def step_and_check():
-        nonlocal t
+        nonlocal t, fuse_with
         acts = torch.randint(0, A, (B,), dtype=torch.int32, device="cuda", generator=gen)
         gv.set_counters(t, 0)
-        gv.step(acts)
+        if fuse_with is None:
+            gv.step(acts)
+        else:
+            gv.reset_done_step(fuse_with, acts)
+            fuse_with = None
         r, s, f, d = ov.step(acts.cpu().numpy(), _coins(77, ids, t) if inverts else None)
         gv.sync()
         assert np.array_equal(f32_bits(gv.reward.cpu().numpy()), f32_bits(r)), t
@@ -738,10 +744,15 @@ def test_staggered_finishers_left_as_a_mask_are_reset_by_trees(kind, n, inverts)
     for k in range(L + 6):
         f = step_and_check()
         assert 0 < f.mean() <= 1.0 / 32, f.mean()  # short enough for the trees
-        gv.reset_done(9000 + k)  # (the step before left the mask)
+        if k % 3 == 1:
+            fuse_with = 9000 + k  # (reset_done + the next step as one call)
+        else:
+            gv.reset_done(9000 + k)  # (the step before left the mask)
         ov.reset_seeded(9000 + k, mask=f)
         resets += int(f.sum())
     assert resets > B
+    if fuse_with is not None:
+        gv.reset_done(fuse_with)
     assert np.array_equal(gv.observe().cpu().numpy().reshape(B, -1), ov.observe_dense()), "final states"
 
 
