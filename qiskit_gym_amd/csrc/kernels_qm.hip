@@ -619,7 +619,9 @@ __device__ inline uint32_t qm_slot(uint32_t row, uint32_t N, uint32_t nxp, bool 
 }
 
 // the tail of set_state / reset for one env: rows to the tile, reset_internals (clifford.rs:272-283)
-template <int NXP, bool HAS_Z>
+// (RESET_ONLY: the instantiation inside the one-launch reset + step kernels, whose mode is always 2 -- set_state's symplectic check, 32 x 32 transposes in
+// registers, stays out of them: the kernels' registers decide how many workgroups share a CU)
+template <int NXP, bool HAS_Z, bool RESET_ONLY = false>
 __device__ inline void qm_init_finish(const InitArgs &a, uint64_t env, const QmRows<NXP, HAS_Z> &s) {
     using Rows = QmRows<NXP, HAS_Z>;
     const uint32_t lane = (uint32_t)(env & (QG_WAVE - 1));
@@ -646,7 +648,9 @@ __device__ inline void qm_init_finish(const InitArgs &a, uint64_t env, const QmR
     uint32_t symp = 0;
     if constexpr (HAS_Z) {
         if (a.check_symplectic) {
-            symp = (a.mode != 1 || qm_check_symplectic<NXP>(s, a.N)) ? QM_FLAG_SYMPLECTIC : 0u;
+            bool is_symp = true;  // identity + gates
+            if constexpr (!RESET_ONLY) is_symp = a.mode != 1 || qm_check_symplectic<NXP>(s, a.N);
+            symp = is_symp ? QM_FLAG_SYMPLECTIC : 0u;
             if (!symp && a.nonsymp_flag) atomicOr(a.nonsymp_flag, 1u);
         }
     }
@@ -711,8 +715,9 @@ __device__ inline void qm_init_finish_wave(const InitArgs &a, uint64_t env, uint
 // finished the reset loaded depth, mask, action, gate entry and row groups back, three dependent trips (1.4 us of the launch's 11).
 // `act`, `g`: the env's action and its gate entry (requested during the scramble).  Results are those of qm_init_finish_wave + qm_step1_body.
 // Returns is_final (on every lane).
-template <int NXP, bool HAS_Z>
-__device__ inline bool qm_init_finish_wave_step(const InitArgs &a, const StepArgs &sa, uint64_t env, uint32_t myrow, int64_t act, GateEntry g) {
+// INV (qm_reset_inv2_step_kernel): the reference-default step -- the solution log's entry, then maybe_random_invert on `coin` -- i.e. qm_inv2_body.
+template <int NXP, bool HAS_Z, bool INV = false>
+__device__ inline bool qm_init_finish_wave_step(const InitArgs &a, const StepArgs &sa, uint64_t env, uint32_t myrow, int64_t act, GateEntry g, uint32_t coin = 0) {
     using Rows = QmRows<NXP, HAS_Z>;
     const uint32_t lane = threadIdx.x & (QG_WAVE - 1), le = (uint32_t)(env & (QG_WAVE - 1)), N = a.N;
     const bool in_range = act >= 0 && act < (int64_t)sa.num_actions;  // gateset.get(action) (clifford.rs:324)
@@ -734,6 +739,28 @@ __device__ inline bool qm_init_finish_wave_step(const InitArgs &a, const StepArg
         if (HAS_Z) myrow = lane == s1 + 1u ? nz1 : myrow;
         myrow = lane == s0 ? nx0 : myrow;
         if (HAS_Z) myrow = lane == s0 + 1u ? nz0 : myrow;
+    }
+    uint32_t iflags = (HAS_Z && a.check_symplectic) ? QM_FLAG_SYMPLECTIC : 0u;
+    if constexpr (INV && HAS_Z) {  // maybe_random_invert (clifford.rs:262-270) on rows held across the lanes: M^-1 = Omega M^T Omega, i.e. with sigma(k) = k +- N the
+        if (coin & 1u) {           // new row i is {bit sigma(i) of row sigma(j)}_j: the ballot of bit sigma(i) over the lanes, its odd slots (Z rows) then its even ones (X rows)
+            const uint32_t q = lane >> 1, t = lane & 1u;
+            const uint32_t my_p = (lane < (uint32_t)Rows::R && q < N) ? (t ? q : N + q) : 0xFFu;  // sigma of this lane's logical row t N + q
+            uint32_t mine = 0;
+#pragma unroll
+            for (uint32_t p = 0; p < 32u; ++p) {
+                const uint32_t b = (uint32_t)__ballot((myrow >> p) & 1u);  // (lanes past the slots hold zero rows)
+                mine = my_p == p ? b : mine;
+            }
+            auto even_bits = [](uint32_t x) -> uint32_t {  // bit 2k -> bit k
+                x &= 0x55555555u;
+                x = (x | (x >> 1)) & 0x33333333u;
+                x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+                x = (x | (x >> 4)) & 0x00FF00FFu;
+                return (x | (x >> 8)) & 0x0000FFFFu;
+            };
+            myrow = even_bits(mine >> 1) | (even_bits(mine) << N);
+            iflags ^= QM_FLAG_INVERTED;
+        }
     }
     uint32_t *tile = reinterpret_cast<uint32_t *>(reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Rows::G * 64));
     const bool slot = lane < (uint32_t)Rows::R;
@@ -764,9 +791,14 @@ __device__ inline bool qm_init_finish_wave_step(const InitArgs &a, const StepArg
     a.success[env] = (uint8_t)solved;
     a.reward[env] = reward;
     a.done[env] = (uint8_t)fin;
-    a.inverted[env] = (uint8_t)((HAS_Z && a.check_symplectic) ? QM_FLAG_SYMPLECTIC : 0u);
-    a.error[env] = 0;
-    a.sol_len[env * 2] = 0;
+    a.inverted[env] = (uint8_t)iflags;
+    uint32_t fault = 0, sol_n = 0;
+    if (INV && (sa.flags & F_TRACK)) {  // clifford.rs:334-340: the fresh episode's first entry, pushed in the frame the env is in before the coin (not inverted)
+        if (sa.sol_cap) sol_at(sa, env, sol_n++) = sol_word_framed(act, false);
+        else fault |= 8u;
+    }
+    a.error[env] = fault;
+    a.sol_len[env * 2] = (int32_t)sol_n;
     a.sol_len[env * 2 + 1] = 0;
     if (a.layers) {
         const LayerRec lay = layer_rec(a.layers, env, a.layers_len);
@@ -784,17 +816,27 @@ __device__ inline bool qm_init_finish_wave_step(const InitArgs &a, const StepArg
 // list in rounds -- entries vblock, vblock + tree_grid, ... -- so it may be called several times).
 // `sa` (qm_reset_step_kernel, plain configuration): the tree path also takes the env's first step (qm_init_finish_wave_step) and says so in
 // `stepped`, with is_final in `fin`; the other paths leave the step to `after`.
+// PAIR (qm_reset_inv2_step_kernel; list paths only): the env's first step is the reference-default one (add_inverts).  Tree path with `sa`: on the rows the wave holds
+// (qm_init_finish_wave_step<.., INV>); otherwise by TWO adjacent lanes reading the fresh episode back (qm_inv2_body): `after(env, h)` is called on an even
+// lane (h = 0) and the odd lane next to it (h = 1), both active.
 struct NoAfter { __device__ void operator()(uint64_t, bool, bool) const {} };
-template <int NXP, bool HAS_Z, typename After = NoAfter>
+template <int NXP, bool HAS_Z, bool PAIR = false, bool RESET_ONLY = false, typename After = NoAfter>
 __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock, const StepArgs *sa = nullptr, After after = After()) {
     using Rows = QmRows<NXP, HAS_Z>;
     // reset scramble (device_common.hpp): the rows live in LDS (wave-private, [slot][lane]: conflict-free for
-    // any per-lane slot), so a gate is dynamic-index reads and writes instead of a sweep over 32 registers
-    __shared__ uint32_t lds_rows[4][Rows::R][QG_WAVE];
-    const uint64_t tid = (uint64_t)vblock * blockDim.x + threadIdx.x;
+    // any per-lane slot), so a gate is dynamic-index reads and writes instead of a sweep over 32 registers.
+    // RESET_ONLY (inside the one-launch reset + step kernels): only the workgroup's FIRST wave runs the lane-per-env scramble, 64 envs per workgroup (the
+    // launcher sizes the grid for it), so the kernel keeps one wave's rows in LDS -- or what the 16-lane scramble of four waves needs, if that is more -- instead
+    // of four: 40 KB per workgroup made three workgroups a CU's limit, and the step workgroups queued behind the trees for slots
+    constexpr uint32_t FLAT_WAVES = RESET_ONLY ? 1u : 4u;
+    constexpr size_t COOP_BYTES = scramble_coop_lds_bytes<uint32_t, Rows::R>(4), FULL_BYTES = sizeof(uint32_t) * 4 * Rows::R * QG_WAVE;
+    constexpr bool coop_fits = COOP_BYTES <= FULL_BYTES;  // (the criterion of the four-wave form: qgym_plan.hpp describes one kernel family)
+    constexpr size_t LEAN_BYTES = FULL_BYTES / 4 > (coop_fits ? COOP_BYTES : 0) ? FULL_BYTES / 4 : COOP_BYTES;
+    __shared__ uint32_t lds_raw[(RESET_ONLY ? (LEAN_BYTES > 1024 ? LEAN_BYTES : 1024) : FULL_BYTES) / sizeof(uint32_t)];  // (>= 8 x 32 words: scramble_tree's products)
+    uint32_t(*lds_rows)[Rows::R][QG_WAVE] = reinterpret_cast<uint32_t(*)[Rows::R][QG_WAVE]>(lds_raw);
+    const uint64_t tid = (uint64_t)vblock * (FLAT_WAVES * QG_WAVE) + threadIdx.x;  // (lane-per-env path; RESET_ONLY: threads past the first wave leave before it)
     uint64_t env = tid;
     if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
-        constexpr bool coop_fits = scramble_coop_lds_bytes<uint32_t, Rows::R>(4) <= sizeof(lds_rows);
         static_assert(coop_fits == plan::tile_coop_fits(Rows::R, 4), "qgym_plan.hpp must describe this kernel");
         // scramble_tree's LDS: the gates' masks, and the row-operation table, which comes in while the list length is still in flight (the
         // draws then index LDS instead of paying a third dependent trip to memory)
@@ -834,7 +876,7 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
         const bool tree = path == plan::RP_TREE;
         // this kernel is the list's only reader.  The barrier inside list_count_take (workgroups with work) is also the one that makes the table visible
         const uint64_t with_work = tree ? (uint64_t)(count_now < a.tree_grid ? count_now : a.tree_grid) * QG_TREE_THREADS
-                                        : (uint64_t)count_now * (path == plan::RP_COOP ? QG_COOP_LANES : 1u);
+                                        : (uint64_t)count_now * (path == plan::RP_COOP ? QG_COOP_LANES : 4u / FLAT_WAVES);  // (threads of 256-thread workgroups with work)
         const uint32_t count = list_count_take(a.list_count, count_now, with_work, vblock, a.zero_count);
         if (tree) {  // few finished envs, long scrambles: a workgroup each, the matrix by columns, the gate sequence cut in eight (scramble_tree)
             const uint32_t N = a.N;
@@ -845,7 +887,11 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
                 // the first step's action is requested now (a vector load: see above), its gate entry between the chain and the products
                 int64_t act = 0;
                 GateEntry ge{QM_IDENTITY << 10, 0.0f};
+                uint32_t coin = 0;
                 if (sa) act = load_action(sa->actions, e + opaque_zero, sa->flags & F_ACT64);
+                if constexpr (PAIR) {  // the env's coin (qm_inv2_body): given, or the handle's counter RNG
+                    if (sa) coin = sa->coins ? sa->coins[e + opaque_zero] : (uint32_t)(rng_draw(sa->seed ^ 0x636F696Eull, sa->env_base + e, step_clock(*sa)) >> 63);
+                }
                 const bool finisher = scramble_tree<Rows::R>(a, e, myrow, reinterpret_cast<uint32_t(*)[32]>(&lds_rows[0][0][0]), tree_gates, table_fits ? tree_table : nullptr,
                                                              [N](uint32_t k) -> uint32_t {
                         const uint32_t j = HAS_Z ? k >> 1 : k;
@@ -855,10 +901,18 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
                     });
                 if (!finisher) return;  // the 64 lanes of wave 0 go on
                 bool fin = false;
-                if (sa) fin = qm_init_finish_wave_step<NXP, HAS_Z>(a, *sa, e, myrow, act, ge);
+                if (sa) fin = qm_init_finish_wave_step<NXP, HAS_Z, PAIR>(a, *sa, e, myrow, act, ge, coin);
                 else qm_init_finish_wave<NXP, HAS_Z>(a, e, myrow);
                 if (threadIdx.x == 0) phase_stamp(a.kclk, a.kclk_waves, 4);  // stored
-                if ((threadIdx.x & (QG_WAVE - 1)) == 0) after(e, sa != nullptr, fin);
+                if constexpr (PAIR) {
+                    if (sa) {
+                        if ((threadIdx.x & (QG_WAVE - 1)) == 0) after(e, 0u, true, fin);
+                    } else if ((threadIdx.x & (QG_WAVE - 1)) < 2u) {
+                        after(e, threadIdx.x & 1u, false, false);
+                    }
+                } else {
+                    if ((threadIdx.x & (QG_WAVE - 1)) == 0) after(e, sa != nullptr, fin);
+                }
             };
             if (vblock >= count) return;
             // (workgroup-uniform) the first entry: from the list's prefetched word, or from the thread that holds it in its share of the mask
@@ -877,23 +931,63 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
                 const uint32_t j = HAS_Z ? k >> 1 : k;
                 return j < N ? ((HAS_Z && (k & 1u)) ? (1u << N) << j : 1u << j) : 0u;
             }, vblock, entry);
-            if (!rows) return;
-            Rows s;
+            if constexpr (PAIR) {  // lanes 0 and 1 of every 16-lane group with an entry stay: lane 0 finishes the reset, then both take the step
+                const uint32_t sl = threadIdx.x & (QG_COOP_LANES - 1);
+                if (((uint64_t)vblock * blockDim.x + threadIdx.x) / QG_COOP_LANES >= count || sl >= 2u) return;
+                if (rows) {
+                    Rows s;
 #pragma unroll
-            for (int k = 0; k < Rows::R; ++k) s.r[k] = rows[k];
-            qm_init_finish<NXP, HAS_Z>(a, env, s);
-            after(env, false, false);
+                    for (int k = 0; k < Rows::R; ++k) s.r[k] = rows[k];
+                    qm_init_finish<NXP, HAS_Z, RESET_ONLY>(a, env, s);
+                }
+                after(env, sl, false, false);
+                return;
+            } else {
+                if (!rows) return;
+                Rows s;
+#pragma unroll
+                for (int k = 0; k < Rows::R; ++k) s.r[k] = rows[k];
+                qm_init_finish<NXP, HAS_Z, RESET_ONLY>(a, env, s);
+                after(env, false, false);
+                return;
+            }
+        }
+        if (RESET_ONLY && threadIdx.x >= QG_WAVE) return;  // (behind every barrier of the list paths: the lane-per-env scramble is the first wave's)
+        if constexpr (PAIR) {  // one lane per env for the reset; then the wave's envs one after the other on lanes 0 and 1 (no lane leaves before that)
+            const bool has = tid < count;
+            if (!__ballot(has)) return;
+            const uint32_t mine = has ? entry((uint32_t)tid) : 0u;
+            if (has) {
+                Rows s;
+                qm_identity<NXP, HAS_Z>(s, a.N);
+                uint32_t(*rows)[QG_WAVE] = lds_rows[threadIdx.x >> 6];
+                const uint32_t L = threadIdx.x & (QG_WAVE - 1);
+#pragma unroll
+                for (int sl = 0; sl < Rows::R; ++sl) rows[sl][L] = s.r[sl];
+                scramble_flat<uint32_t>(rows, L, a, mine);
+#pragma unroll
+                for (int sl = 0; sl < Rows::R; ++sl) s.r[sl] = rows[sl][L];
+                qm_init_finish<NXP, HAS_Z, RESET_ONLY>(a, mine, s);
+            }
+            uint64_t todo = __ballot(has);
+            while (todo) {  // (wave-uniform)
+                const int b = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const uint32_t e = (uint32_t)__shfl((int)mine, b);
+                if ((threadIdx.x & (QG_WAVE - 1)) < 2u) after((uint64_t)e, threadIdx.x & 1u, false, false);
+            }
             return;
         }
         if (tid >= count) return;
         env = entry((uint32_t)tid);
     } else {
+        if constexpr (PAIR || RESET_ONLY) return;  // (those instantiations are only launched with a list: set_state's code stays out of them)
         if (env >= a.B) return;
         if (a.only_done && !a.done[env]) return;  // live episodes keep running
     }
     Rows s;
     qm_identity<NXP, HAS_Z>(s, a.N);
-    if (a.mode == 1) {  // set_state (clifford.rs:299-304)
+    if (!RESET_ONLY && a.mode == 1) {  // set_state (clifford.rs:299-304)
 #pragma unroll
         for (int sl = 0; sl < Rows::R; ++sl) {
             const uint32_t j = HAS_Z ? (uint32_t)sl >> 1 : (uint32_t)sl;
@@ -924,8 +1018,8 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
 #pragma unroll
         for (int sl = 0; sl < Rows::R; ++sl) s.r[sl] = rows[sl][L];
     }
-    qm_init_finish<NXP, HAS_Z>(a, env, s);
-    after(env, false, false);
+    qm_init_finish<NXP, HAS_Z, RESET_ONLY>(a, env, s);
+    if constexpr (!PAIR) after(env, false, false);  // (PAIR: the list paths above have returned; set_state and whole resets are not followed by a step)
 }
 
 
@@ -991,9 +1085,52 @@ __global__ __launch_bounds__(256) void qm_reset_step_kernel(ResetStepArgs ra) {
     }
     // (plain configuration: the tree's wave takes the env's first step on the rows it holds -- qm_init_finish_wave_step; otherwise the lane
     // that has just written the env's fresh episode -- state, depth, bad mask, log lengths -- takes it, as qm_step1_body)
-    qm_init_block<NXP, HAS_Z>(ra.reset, role_index, FEAT ? nullptr : &a, [&](uint64_t env, bool stepped, bool fin) {
+    qm_init_block<NXP, HAS_Z, false, true>(ra.reset, role_index, FEAT ? nullptr : &a, [&](uint64_t env, bool stepped, bool fin) {
         if (!stepped) fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64), true);
         if (fin) {  // (rare: one atomic per env that is final again after its first step)
+            const uint32_t slot = atomicAdd(a.done_count, 1u);
+            if (slot < a.B) a.done_list[slot] = (uint32_t)env;
+        }
+    });
+}
+
+// The same with the reference's default options (add_inverts; CliffordEnv N <= 16, every env symplectic): the step workgroups run qm_inv2_body (two lanes
+// per env, 512 workgroups at 65 536 envs).  A reset env's first step: the tree's wave takes it on the rows it holds (gate, log entry, the coin's inversion as 32
+// ballots: qm_init_finish_wave_step<.., INV>) unless layer weights are on; the 16-lane and per-lane paths hand the fresh episode to two adjacent lanes that read it
+// back (qm_inv2_body).  Round 5's first form read back on the tree path too: 15.9 us a pair against 14.3 as two launches (a tree waits ~3 us for its own stores).
+// (WAVE: the tree's wave takes the first step -- a compile-time choice: a pointer to the by-value arguments that may be null at run time makes the compiler keep
+// all 616 bytes of them in scratch, and a launch with scratch took 46 us)
+template <int NXP, bool FEAT, bool WAVE>
+__global__ __launch_bounds__(256) void qm_reset_inv2_step_kernel(ResetStepArgs ra) {
+    KernelClock kclk(ra.step.kclk, ra.step.kclk_waves);  // device_common.hpp
+    const StepArgs &a = ra.step;
+    QG_PREFETCH_STEP_ARGS(a);
+    uint32_t role_index;
+    if (reset_step_role(ra, role_index)) {
+        const uint64_t tid = (uint64_t)role_index * blockDim.x + threadIdx.x, env = tid >> 1;
+        uint64_t resets = env < a.B ? ra.reset.mask[env >> 6] : 0ull;  // (a wave's 32 envs share a word)
+        uint32_t relisted = ra.reset.list_count[0];  // (see qm_reset_step_kernel)
+        relisted = relisted < a.B ? relisted : (uint32_t)a.B;
+        for (uint32_t i = 0; i < relisted; ++i) {
+            const uint32_t e = ra.reset.list[i];
+            if ((e >> 6) == (uint32_t)(env >> 6)) resets |= 1ull << (e & 63u);
+        }
+        bool fin = false;
+        if (env < a.B && !((resets >> (env & 63u)) & 1ull)) fin = qm_inv2_body<NXP / 2, FEAT, false>(a, NXP / 2, env, (uint32_t)tid & 1u, nullptr);  // qm_step1.hpp
+        done_mask_store_pairs(a.done_mask, a.B, fin, tid, a.done_epoch);
+        return;
+    }
+    const StepArgs *wave_step = WAVE ? &a : nullptr;  // (not with layer weights: that metric reads the record the reset has just written -- the read-back form)
+    // `after(env, h, stepped, fin)`: stepped -- the tree's wave has taken the env's step (is_final in `fin`; one lane calls); else lanes h = 0, 1 take it now
+    qm_init_block<NXP, true, true, true>(ra.reset, role_index, wave_step, [&](uint64_t env, uint32_t h, bool stepped, bool fin) {
+        if (!stepped) {
+            // the fresh episode (written by this wave's lanes) is in the L2 before the pair's loads of it are issued, and those loads do not take a line this CU read
+            // earlier (not __threadfence(): its release half writes the XCD's whole L2 back)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            fin = qm_inv2_body<NXP / 2, FEAT, false>(a, NXP / 2, env, h, nullptr);  // qm_step1.hpp
+        }
+        if (fin && h == 0) {  // (rare: final again after its first step)
             const uint32_t slot = atomicAdd(a.done_count, 1u);
             if (slot < a.B) a.done_list[slot] = (uint32_t)env;
         }
@@ -1316,16 +1453,28 @@ hipError_t qm_init(const InitArgs &a, uint32_t nxp, bool has_z, hipStream_t s) {
 template <int NXP, bool HAS_Z>
 static hipError_t launch_reset_step(const ResetStepArgs &ra, hipStream_t s) {
     const InitArgs &ia = ra.reset;
-    uint64_t threads = ia.B;  // the reset's share of the grid: as launch_init sizes it
+    uint64_t threads = 4 * ia.B;  // the reset's share of the grid: a workgroup per 64 envs (qm_init_block<.., RESET_ONLY>: the lane-per-env scramble is the first wave's)
+    uint64_t tree_blocks = 0;
     if (ia.list && ia.coop && ia.n_draws >= plan::TREE_MIN_DRAWS) {
-        const uint64_t tree_blocks = ia.tree_grid;
+        tree_blocks = ia.tree_grid;
         if (tree_blocks * QG_TREE_THREADS > threads) threads = tree_blocks * QG_TREE_THREADS;
     }
     ResetStepArgs rb = ra;
     rb.reset_blocks = grid_for(threads, 256);
-    rb.first_reset = rb.reset_blocks / 2;
+    // the grid: [the tree workgroups][the step workgroups][the other reset workgroups] (no trees: half of the reset workgroups first)
+    rb.first_reset = tree_blocks ? (uint32_t)std::min<uint64_t>(tree_blocks, rb.reset_blocks) : rb.reset_blocks / 2;
     const bool feat = ra.step.flags & (F_TRACK | F_LAYERS);
-    if (ra.step.flags & F_INVERTS) return hipErrorInvalidValue;  // (two launches: qgym_plan.hpp reset_step_fusable)
+    if (ra.step.flags & F_INVERTS) {  // the reference-default step: two lanes per env
+        if constexpr (HAS_Z && NXP <= 16) {
+            rb.step_blocks = grid_for(2 * ra.step.B, 256);
+            const dim3 grid2(rb.reset_blocks + rb.step_blocks);
+            if (ra.step.flags & F_LAYERS) hipLaunchKernelGGL((qm_reset_inv2_step_kernel<NXP, true, false>), grid2, dim3(256), 0, s, rb);
+            else if (feat) hipLaunchKernelGGL((qm_reset_inv2_step_kernel<NXP, true, true>), grid2, dim3(256), 0, s, rb);
+            else hipLaunchKernelGGL((qm_reset_inv2_step_kernel<NXP, false, true>), grid2, dim3(256), 0, s, rb);
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
+    }
     rb.step_blocks = grid_for(ra.step.B, 256);
     const dim3 grid(rb.reset_blocks + rb.step_blocks), block(256);
     if constexpr (QmRows<NXP, HAS_Z>::R % 16 == 0) {

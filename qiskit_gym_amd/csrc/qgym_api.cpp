@@ -1108,8 +1108,11 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     const bool trusted = done_list_session(v, s);
     // one launch when the list of finished envs and their is_final flags were left by this handle's own previous step (same session) and the
     // reset would take the list path with counter-RNG draws; otherwise the two calls, whose step leaves both for the next time
+    // (add_inverts: the two-lanes-per-env launch has no Gauss-Jordan and no tracked-observation form)
+    const bool inverts = v->flags & F_INVERTS;
     const bool fuse = v->done_list_alt && v->done_mask[0] && trusted && v->done_list_fresh && v->mask_fresh && v->auto_list && !v->gates.empty() &&
-                      plan::reset_coop_allowed(false, v->B, v->d_rowops != nullptr) && plan::reset_step_fuses(plan_of(v));
+                      plan::reset_coop_allowed(false, v->B, v->d_rowops != nullptr) && plan::reset_step_fuses(plan_of(v)) &&
+                      !(inverts && (v->maybe_nonsymplectic || v->dense));
     if (plan::reset_step_in_word_kernel(plan_of(v), v->gates.size())) {
         // one uint64 per env: no list -- every wave tests its envs' is_final flags, resets the finished ones (16 lanes each) and steps all of them
         InitArgs ia;
@@ -1378,7 +1381,8 @@ int qg_plan_query(const qg_config *cfg, uint64_t batch, uint32_t num_actions, in
         break;
     }
     case QG_PLAN_RESET_DONE_STEP:
-        name = plan::reset_step_fusable(hp) ? (hp.layout == LAYOUT_TILE64 ? "q64_reset_step_kernel (after a list-leaving step)" : "qm_reset_step_kernel (after a list-leaving step)")
+        name = plan::reset_step_fusable(hp) ? ((hp.flags & F_INVERTS) ? (nonsymplectic ? "two launches" : "qm_reset_inv2_step_kernel (after a list-leaving step)")
+                                               : hp.layout == LAYOUT_TILE64 ? "q64_reset_step_kernel (after a list-leaving step)" : "qm_reset_step_kernel (after a list-leaving step)")
                : plan::reset_step_in_word_kernel(hp, num_actions) ? "word_reset_step_kernel" : "two launches";
         break;
     case QG_PLAN_OBSERVE_DENSE:

@@ -251,8 +251,11 @@ constexpr bool tile_coop_fits(uint32_t R, uint32_t word_bytes) { return 16ull * 
 // (add_inverts keeps the two launches: a one-launch form -- the step on two lanes per env beside the reset workgroups, a reset env's first step on two
 // lanes of the wave that wrote its fresh episode -- was built, parity-tested and measured at 15.9 - 18.9 us a pair against 14.3: 1 150 - 1 536 workgroups of 40 KB
 // of LDS at three per CU, the step's 512 wait for slots behind the resets; as two graph branches a pair costs 10 us of fork and join.  EXPERIMENTS.md, round 5)
+// ... and CliffordEnv N <= 16 with add_inverts (qm_reset_inv2_step_kernel: two lanes per env), while every env is known to be symplectic
 inline bool reset_step_fusable(const HandlePlan &p) {
-    return (p.layout == LAYOUT_TILE || p.layout == LAYOUT_TILE64) && p.has_bad && !(p.flags & F_INVERTS) && p.has_done_list;
+    if (!p.has_done_list) return false;
+    if (p.flags & F_INVERTS) return p.layout == LAYOUT_TILE && p.has_z && p.nxp <= 16;
+    return (p.layout == LAYOUT_TILE || p.layout == LAYOUT_TILE64) && p.has_bad;
 }
 inline bool reset_step_fuses(const HandlePlan &p) { return reset_step_fusable(p); }
 // ... and on the one-word layouts (word_reset_step_kernel: the wave tests its envs' is_final flags itself, no list)

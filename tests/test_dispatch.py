@@ -130,7 +130,10 @@ def test_reset_done_step_in_one_launch():
     assert plan("linear_function", 8, RESET_DONE_STEP, num_actions=0, **PLAIN) == "two launches"                  # (an empty gateset: reset is an error)
     assert plan("clifford", 24, RESET_DONE_STEP, **PLAIN).startswith("q64_reset_step_kernel")            # 64-bit rows
     assert plan("linear_function", 40, RESET_DONE_STEP, **PLAIN).startswith("q64_reset_step_kernel")
-    for kind, n, cfg in (("clifford", 16, DEFAULT), ("clifford", 24, DEFAULT), ("linear_function", 24, DEFAULT), ("permutation", 27, PLAIN), ("pauli", 20, {})):
+    assert plan("clifford", 16, RESET_DONE_STEP, **DEFAULT).startswith("qm_reset_inv2_step_kernel")   # the reference's default options: two lanes per env
+    assert plan("clifford", 7, RESET_DONE_STEP, **DEFAULT).startswith("qm_reset_inv2_step_kernel")
+    assert plan("clifford", 16, RESET_DONE_STEP, nonsymplectic=1, **DEFAULT) == "two launches"          # (some env needs the Gauss-Jordan inversion)
+    for kind, n, cfg in (("clifford", 24, DEFAULT), ("linear_function", 24, DEFAULT), ("permutation", 27, PLAIN), ("pauli", 20, {})):
         assert plan(kind, n, RESET_DONE_STEP, **cfg) == "two launches", (kind, n)
 
 

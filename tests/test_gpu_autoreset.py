@@ -421,10 +421,10 @@ def test_reset_done_step_in_one_launch_equals_the_two_calls(kind, n, B, diff, tr
                                                          (16, 4096, 3, True, False), (12, 8192, 70, False, False),
                                                          (16, 1000, 1, False, True), (5, 8192, 64, True, True), (16, 65536, 100, False, False)])
 def test_reset_done_step_with_the_reference_default_options_equals_the_two_calls(n, B, diff, track, given_coins):
-    """CliffordEnv with add_inverts: qg_vec_reset_done_step (the two launches behind one call -- the step leaves its finishers as one bit per env,
-    the reset's workgroups count them: trees for long scrambles, 16 lanes per env for short ones, a lane per env when most of the batch finishes at
-    once: difficulty 1; one-launch forms were built and measured slower, EXPERIMENTS rounds 4 and 5) against reset_done + step on a twin and,
-    with the coins given, against the oracle; with the handle's counter-RNG coins against the twin alone."""
+    """CliffordEnv with add_inverts: qg_vec_reset_done_step -- one launch (qm_reset_inv2_step_kernel: the step on two lanes per env; a reset env's first
+    step by the tree's wave on the rows it holds -- gate, solution-log entry, the coin's inversion as ballots -- for long scrambles, on two lanes that read
+    the fresh episode back behind the 16-lane and per-lane resets: short scrambles, and most of the batch finishing at once: difficulty 1) -- against
+    reset_done + step on a twin and, with the coins given, against the oracle; with the handle's counter-RNG coins against the twin alone."""
     from qiskit_gym_amd.vec import VecEnv
 
     gs = line_gateset("clifford", n)

@@ -133,8 +133,11 @@ def main():
     run("CliffordGym 16q, plain options, two launches per pair", env, len(gs3), 2, ["reset_done (qm_init_kernel)", "step (qm_step1_kernel<LIST>)"], False, out)
     del env
     env = VecEnv("clifford", 16, gs3, B, add_inverts=True, add_perms=False, track_solution=True, difficulty=256)
+    run("CliffordGym 16q, reference defaults (add_inverts, solution log), one launch per pair (qm_reset_inv2_step_kernel)", env, len(gs3), 1, ["reset + step"], True, out)
+    del env
+    env = VecEnv("clifford", 16, gs3, B, add_inverts=True, add_perms=False, track_solution=True, difficulty=256)
     run("CliffordGym 16q, reference defaults (add_inverts, solution log), two launches per pair", env, len(gs3), 2,
-        ["reset_done (qm_init_kernel)", "step (qm_inv2_kernel<LIST>)"], True, out)
+        ["reset_done (qm_init_kernel)", "step (qm_inv2_kernel<LIST>)"], False, out)
     del env
     gs2 = line_gateset("linear_function", 8)
     for nb in (8192, B):
