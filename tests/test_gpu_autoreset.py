@@ -419,12 +419,15 @@ def test_reset_done_step_in_one_launch_equals_the_two_calls(kind, n, B, diff, tr
 
 @pytest.mark.parametrize("n,B,diff,track,given_coins", [(16, 4096, 3, True, True), (16, 2048, 70, True, True), (9, 777, 4, False, True),
                                                          (16, 4096, 3, True, False), (12, 8192, 70, False, False),
-                                                         (16, 1000, 1, False, True), (5, 8192, 64, True, True), (16, 65536, 100, False, False)])
+                                                         (16, 1000, 1, False, True), (5, 8192, 64, True, True), (16, 65536, 100, False, False),
+                                                         (24, 4096, 70, True, True), (20, 777, 3, True, True), (32, 2048, 66, False, True), (24, 1000, 1, True, True),
+                                                         (28, 8192, 70, True, False)])
 def test_reset_done_step_with_the_reference_default_options_equals_the_two_calls(n, B, diff, track, given_coins):
-    """CliffordEnv with add_inverts: qg_vec_reset_done_step -- one launch (qm_reset_inv2_step_kernel: the step on two lanes per env; a reset env's first
+    """CliffordEnv with add_inverts: qg_vec_reset_done_step -- up to 16 qubits one launch (qm_reset_inv2_step_kernel: the step on two lanes per env; a reset env's first
     step by the tree's wave on the rows it holds -- gate, solution-log entry, the coin's inversion as ballots -- for long scrambles, on two lanes that read
     the fresh episode back behind the 16-lane and per-lane resets: short scrambles, and most of the batch finishing at once: difficulty 1) -- against
-    reset_done + step on a twin and, with the coins given, against the oracle; with the handle's counter-RNG coins against the twin alone."""
+    reset_done + step on a twin and, with the coins given, against the oracle; with the handle's counter-RNG coins against the twin alone.  Beyond 16 qubits
+    (64-bit rows) the two launches behind the one call: the one-launch form was built, passed these cases and was slower (EXPERIMENTS.md, round 5)."""
     from qiskit_gym_amd.vec import VecEnv
 
     gs = line_gateset("clifford", n)
