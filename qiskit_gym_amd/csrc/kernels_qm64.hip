@@ -559,9 +559,9 @@ __global__ __launch_bounds__(256) void q64_inv2_kernel(StepArgs a) {
 // <= 2 groups ({X[q], Z[q]} of a qubit for CliffordEnv, a row pair for LinearFunctionEnv) are gathered
 // and scattered at per-lane addresses, `solved` comes from the incrementally kept 64-bit `bad` mask.
 // LIST: also append the envs that finish to StepArgs::done_list (F_DONE_LIST; its own instantiation: the plain kernel's code stays as it is)
-template <int NS, bool HAS_Z, bool FEAT>
 // (`act`, and `g` = gates[act] when it is in range: loaded by the caller -- q64_reset_step_kernel's reset lanes ask for them before the scramble, the env's first step
 // then has one trip to memory left, not three)
+template <int NS, bool HAS_Z, bool FEAT>
 __device__ __forceinline__ bool q64_step1_with(const StepArgs &a, uint64_t env, int64_t act, GateEntry g) {  // returns is_final
     const uint32_t lane = (uint32_t)(env & (QG_WAVE - 1));  // (= the thread's lane in the step kernels; a reset's lane steps the env it has just written from wherever it sits)
     uint4 *tile = reinterpret_cast<uint4 *>(a.state) + (env >> 6) * (uint64_t)(Q64Rows<NS>::G * 64);
