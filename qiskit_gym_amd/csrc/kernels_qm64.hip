@@ -1118,9 +1118,6 @@ struct Q64FirstStep {
         if (act >= 0 && act < (int64_t)a.num_actions) g = a.gates[act];
     }
     __device__ void operator()(uint64_t env) const {
-#ifdef QG_X64_NOFIRST  // development: what the first step costs the trees (results are wrong)
-        return;
-#endif
         // the fresh episode's stores -- in the tree, by the wave's other lanes too -- are in the L2 before this lane's loads of them are issued, and those
         // loads do not take a line this CU read earlier (a step workgroup's neighbours of this env).  Not __threadfence(): its release half writes the whole
         // L2's dirty lines back (the L2s of the XCDs are not coherent with each other) -- 26 us a launch instead of 11
@@ -1146,11 +1143,7 @@ template <int NS, bool HAS_Z, bool FEAT>
 __global__ __launch_bounds__(Q64_TREE_THREADS) void q64_reset_step_kernel(Q64ResetStepArgs ra) {
     KernelClock kclk(ra.step.kclk, ra.step.kclk_waves);  // device_common.hpp
     const StepArgs &a = ra.step;
-#ifdef QG_X64_STEPS_FIRST  // development: the grid's order
-    const uint32_t trees = ra.reset.tree_grid, b = blockIdx.x < ra.step_blocks ? blockIdx.x + trees : blockIdx.x < ra.step_blocks + trees ? blockIdx.x - ra.step_blocks : blockIdx.x;
-#else
     const uint32_t b = blockIdx.x, trees = ra.reset.tree_grid;
-#endif
     if (b >= trees && b < trees + ra.step_blocks) {  // a step workgroup
         const uint64_t env = (uint64_t)(b - trees) * blockDim.x + threadIdx.x;
         uint64_t resets = env < a.B ? ra.reset.mask[env >> 6] : 0ull;  // (one word per wave)
