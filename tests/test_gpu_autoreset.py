@@ -483,8 +483,8 @@ def test_reset_done_step_with_the_reference_default_options_equals_the_two_calls
                 assert fused.solution(e) == envs[e].solution()
 
 
-@pytest.mark.parametrize("n", [16, 24])  # (32-bit rows: qm_reset_step_kernel; 64-bit rows: q64_reset_step_kernel)
-def test_reset_done_step_inside_a_captured_graph_replays_like_eager_calls(n):
+@pytest.mark.parametrize("n,inverts", [(16, False), (24, False), (16, True)])  # (qm_reset_step_kernel; 64-bit rows: q64_reset_step_kernel; add_inverts: qm_reset_inv2_step_kernel)
+def test_reset_done_step_inside_a_captured_graph_replays_like_eager_calls(n, inverts):
     """A graph of 16 x reset_done_step (its first call compacts the list from the flags, the others are single launches) replayed three times
     against the same calls made eagerly on a twin: the device-side lists and flag arrays of consecutive replays line up whatever the
     graph's length (here even and odd)."""
@@ -493,9 +493,10 @@ def test_reset_done_step_inside_a_captured_graph_replays_like_eager_calls(n):
     gs = line_gateset("clifford", n)
     A, B = len(gs), 8192
     for T in (16, 7):
-        cfg = dict(add_inverts=False, add_perms=False, track_solution=False, difficulty=3, depth_slope=2, max_depth=128)
+        cfg = dict(add_inverts=inverts, add_perms=False, track_solution=inverts, difficulty=3, depth_slope=2, max_depth=128)
         g_env, twin = VecEnv("clifford", n, gs, B, **cfg), VecEnv("clifford", n, gs, B, **cfg)
         acts = torch.randint(0, A, (T, B), dtype=torch.int32, device="cuda")
+        coins = torch.randint(0, 2, (T, B), dtype=torch.uint8, device="cuda") if inverts else [None] * T  # (given: a replay has the capture's step counter)
         stream = torch.cuda.Stream()
         with torch.cuda.stream(stream):
             g_env.reset(1)
@@ -503,7 +504,7 @@ def test_reset_done_step_inside_a_captured_graph_replays_like_eager_calls(n):
 
             def body(env):
                 for t in range(T):
-                    env.reset_done_step(40 + t, acts[t])
+                    env.reset_done_step(40 + t, acts[t], coins[t])
 
             body(g_env)  # eager pass on both
             body(twin)
