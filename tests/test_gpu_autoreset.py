@@ -836,3 +836,55 @@ def test_tree_grid_sized_from_a_short_list_walks_a_longer_one_in_rounds(kind, n)
         rounds += 1
         assert np.array_equal(g2.observe().cpu().numpy().reshape(B, -1), o2.observe_dense()), k
     assert rounds == 12
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_reset_done_step_random_shapes_against_the_oracle(case):
+    """Random env kind / size / options / batch / episode length: a collector's loop of qg_vec_reset_done_step calls -- one launch where the handle has it
+    (32-bit rows plain and with add_inverts, 64-bit rows plain, the one-word layouts), the two launches behind the call elsewhere -- with EVERY env on the
+    oracle after every step: reward bits, is_final, depth; states and solution logs at the end.  Episodes are short (they end, and end again, inside the
+    loop); scrambles are short or long (the 16-lane / per-lane resets, or trees).  QGYM_FUZZ_SEED_OFFSET shifts the cases."""
+    import os
+
+    from oracle import OracleVec
+    from qiskit_gym_amd.vec import VecEnv
+    from test_gpu_fullsize import _coins
+
+    rng = np.random.default_rng(777 + case + int(os.environ.get("QGYM_FUZZ_SEED_OFFSET", "0")))
+    kind = ["clifford", "clifford", "linear_function", "permutation"][int(rng.integers(0, 4))]
+    n = int(rng.integers(3, 33)) if kind == "clifford" else int(rng.integers(3, 41)) if kind == "linear_function" else int(rng.integers(3, 17))
+    inverts = bool(rng.integers(0, 2))
+    track = bool(rng.integers(0, 2))
+    diff = int(rng.choice([1, 3, 7, 64, 70, 130]))
+    L = int(rng.choice([2, 3, 5, 9]))
+    B = int(rng.choice([70, 1000, 4097, 20000]))
+    gs = line_gateset(kind, n)
+    A = len(gs)
+    seed0 = int(rng.integers(0, 1 << 30))
+    cfg = dict(add_inverts=inverts, add_perms=False, track_solution=track, difficulty=diff, depth_slope=1, max_depth=L)
+    gv = VecEnv(kind, n, gs, B, seed=seed0, **cfg)
+    ov = OracleVec(OracleEnv(kind, n, gs, **{k: int(v) for k, v in cfg.items()}), B)
+    gv.reset(11)
+    ov.reset_seeded(11)
+    gen = torch.Generator(device="cuda").manual_seed(case)
+    ids = np.arange(B)
+    what = f"{kind} {n}q inverts={inverts} track={track} diff={diff} L={L} B={B}"
+    f = np.zeros(B, dtype=np.uint8)
+    for t in range(3 * L + 4):
+        acts = torch.randint(0, A + (1 if t % 5 == 4 else 0), (B,), dtype=torch.int32, device="cuda", generator=gen)  # (now and then an action past the gateset)
+        gv.set_counters(t, 0)
+        seed = 1000 + t
+        if t == 0:
+            gv.step(acts)
+        else:
+            gv.reset_done_step(seed, acts)
+            ov.reset_seeded(seed, mask=f)
+        r, s_, f, d = ov.step(acts.cpu().numpy(), _coins(seed0, ids, t) if inverts else None)
+        gv.sync()
+        assert np.array_equal(f32_bits(gv.reward.cpu().numpy()), f32_bits(r)), (what, t)
+        assert np.array_equal(gv.done.cpu().numpy(), f) and np.array_equal(gv.depth.cpu().numpy(), d), (what, t, np.nonzero(gv.done.cpu().numpy() != f)[0][:8])
+    assert np.array_equal(gv.observe().cpu().numpy().reshape(B, -1), ov.observe_dense()), (what, "final states")
+    if track:
+        o_sol, o_len = ov.solutions(64)
+        g_sol, g_len = gv.solutions(64)
+        assert np.array_equal(g_len, o_len) and np.array_equal(g_sol, o_sol), what
