@@ -1023,10 +1023,12 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
 }
 
 
-template <int NXP, bool HAS_Z>
+// RESET_ONLY: qg_vec_reset_done with a list (mode 2): the instantiation without set_state's code, the lane-per-env scramble on the first wave of every workgroup
+// (69 instead of 148 VGPRs, 17 instead of 40 KB of LDS: idle workgroups of a tree launch do not hold a third of a CU each)
+template <int NXP, bool HAS_Z, bool RESET_ONLY = false>
 __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
     KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
-    qm_init_block<NXP, HAS_Z>(a, blockIdx.x);
+    qm_init_block<NXP, HAS_Z, false, RESET_ONLY>(a, blockIdx.x);
 }
 
 // qg_vec_reset_done followed by qg_vec_step in ONE launch (qg_vec_reset_done_step): the grid's first `reset_blocks` workgroups are the
@@ -1411,12 +1413,14 @@ template <int NXP, bool HAS_Z>
 static hipError_t launch_init(const InitArgs &a, hipStream_t s) {
     // reset_done with a short list: scramble_tree walks the list with InitArgs::tree_grid workgroups (the workgroups
     // past the list leave at once); every other path needs at most B threads
-    uint64_t threads = a.B;
+    const bool lean = a.mode == 2 && a.list;  // (a workgroup per 64 envs there)
+    uint64_t threads = lean ? 4 * a.B : a.B;
     if (a.list && a.coop && a.n_draws >= 64u) {
         const uint64_t tree_blocks = a.tree_grid;
         if (tree_blocks * QG_TREE_THREADS > threads) threads = tree_blocks * QG_TREE_THREADS;
     }
-    hipLaunchKernelGGL((qm_init_kernel<NXP, HAS_Z>), dim3(grid_for(threads, 256)), dim3(256), 0, s, a);
+    if (lean) hipLaunchKernelGGL((qm_init_kernel<NXP, HAS_Z, true>), dim3(grid_for(threads, 256)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((qm_init_kernel<NXP, HAS_Z>), dim3(grid_for(threads, 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
