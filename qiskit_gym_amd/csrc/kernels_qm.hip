@@ -820,9 +820,13 @@ __device__ inline bool qm_init_finish_wave_step(const InitArgs &a, const StepArg
 // (qm_init_finish_wave_step<.., INV>); otherwise by TWO adjacent lanes reading the fresh episode back (qm_inv2_body): `after(env, h)` is called on an even
 // lane (h = 0) and the odd lane next to it (h = 1), both active.
 struct NoAfter { __device__ void operator()(uint64_t, bool, bool) const {} };
-template <int NXP, bool HAS_Z, bool PAIR = false, bool RESET_ONLY = false, typename After = NoAfter>
+// LEAN: 0 = everything (set_state too); 1 = RESET_ONLY below (lists: inside the one-launch kernels and qg_vec_reset_done's launch); 2 = mode 2 without a list (qg_vec_reset
+// of the whole batch, only_done from the flags): no set_state code either, but the lane-per-env scramble on all four waves as in 0 (69 VGPRs: four workgroups
+// per CU by their 32 KB of rows instead of three by 148 VGPRs)
+template <int NXP, bool HAS_Z, bool PAIR = false, int LEAN = 0, typename After = NoAfter>
 __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock, const StepArgs *sa = nullptr, After after = After()) {
     using Rows = QmRows<NXP, HAS_Z>;
+    constexpr bool RESET_ONLY = LEAN == 1, NO_SET_STATE = LEAN != 0;
     // reset scramble (device_common.hpp): the rows live in LDS (wave-private, [slot][lane]: conflict-free for
     // any per-lane slot), so a gate is dynamic-index reads and writes instead of a sweep over 32 registers.
     // RESET_ONLY (inside the one-launch reset + step kernels): only the workgroup's FIRST wave runs the lane-per-env scramble, 64 envs per workgroup (the
@@ -836,12 +840,12 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
     uint32_t(*lds_rows)[Rows::R][QG_WAVE] = reinterpret_cast<uint32_t(*)[Rows::R][QG_WAVE]>(lds_raw);
     const uint64_t tid = (uint64_t)vblock * (FLAT_WAVES * QG_WAVE) + threadIdx.x;  // (lane-per-env path; RESET_ONLY: threads past the first wave leave before it)
     uint64_t env = tid;
-    if (a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
+    if (LEAN != 2 && a.list) {  // qg_vec_reset_done, compacted: thread i owns the i-th finished env
         static_assert(coop_fits == plan::tile_coop_fits(Rows::R, 4), "qgym_plan.hpp must describe this kernel");
         // scramble_tree's LDS: the gates' masks, and the row-operation table, which comes in while the list length is still in flight (the
         // draws then index LDS instead of paying a third dependent trip to memory)
-        __shared__ uint4 tree_gates[4][QG_WAVE];
-        __shared__ uint32_t tree_table[QG_TREE_TABLE_MAX];
+        __shared__ uint4 tree_gates[LEAN == 2 ? 1 : 4][QG_WAVE];                 // (LEAN 2 is never launched with a list: its LDS is the rows)
+        __shared__ uint32_t tree_table[LEAN == 2 ? 1 : QG_TREE_TABLE_MAX];
         const bool table_fits = a.coop && a.num_actions <= QG_TREE_TABLE_MAX;
         // three trips to memory, all in flight together: the list's length, the entry this workgroup would scramble as a tree (any index below B
         // is readable) and the table.  The first two are uniform, and a uniform load is waited for where it is issued (the compiler moves its
@@ -852,7 +856,7 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
         const uint32_t count_v = a.list_count[opaque_zero];
         const uint32_t entry_v = a.coop ? a.list[(vblock < a.B ? vblock : 0u) + opaque_zero] : 0u;
         // ... and, when the step before left its finishers as a mask (InitArgs::mask), this thread's share of the mask's words
-        __shared__ uint32_t mask_part[257 + 5];
+        __shared__ uint32_t mask_part[LEAN == 2 ? 1 : 257 + 5];
         DoneMaskShare share;
         uint32_t hint_v = 0;
         if (a.mask) {
@@ -938,7 +942,7 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
                     Rows s;
 #pragma unroll
                     for (int k = 0; k < Rows::R; ++k) s.r[k] = rows[k];
-                    qm_init_finish<NXP, HAS_Z, RESET_ONLY>(a, env, s);
+                    qm_init_finish<NXP, HAS_Z, NO_SET_STATE>(a, env, s);
                 }
                 after(env, sl, false, false);
                 return;
@@ -947,7 +951,7 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
                 Rows s;
 #pragma unroll
                 for (int k = 0; k < Rows::R; ++k) s.r[k] = rows[k];
-                qm_init_finish<NXP, HAS_Z, RESET_ONLY>(a, env, s);
+                qm_init_finish<NXP, HAS_Z, NO_SET_STATE>(a, env, s);
                 after(env, false, false);
                 return;
             }
@@ -967,7 +971,7 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
                 scramble_flat<uint32_t>(rows, L, a, mine);
 #pragma unroll
                 for (int sl = 0; sl < Rows::R; ++sl) s.r[sl] = rows[sl][L];
-                qm_init_finish<NXP, HAS_Z, RESET_ONLY>(a, mine, s);
+                qm_init_finish<NXP, HAS_Z, NO_SET_STATE>(a, mine, s);
             }
             uint64_t todo = __ballot(has);
             while (todo) {  // (wave-uniform)
@@ -987,7 +991,7 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
     }
     Rows s;
     qm_identity<NXP, HAS_Z>(s, a.N);
-    if (!RESET_ONLY && a.mode == 1) {  // set_state (clifford.rs:299-304)
+    if (!NO_SET_STATE && a.mode == 1) {  // set_state (clifford.rs:299-304)
 #pragma unroll
         for (int sl = 0; sl < Rows::R; ++sl) {
             const uint32_t j = HAS_Z ? (uint32_t)sl >> 1 : (uint32_t)sl;
@@ -1018,17 +1022,17 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
 #pragma unroll
         for (int sl = 0; sl < Rows::R; ++sl) s.r[sl] = rows[sl][L];
     }
-    qm_init_finish<NXP, HAS_Z, RESET_ONLY>(a, env, s);
+    qm_init_finish<NXP, HAS_Z, NO_SET_STATE>(a, env, s);
     if constexpr (!PAIR) after(env, false, false);  // (PAIR: the list paths above have returned; set_state and whole resets are not followed by a step)
 }
 
 
 // RESET_ONLY: qg_vec_reset_done with a list (mode 2): the instantiation without set_state's code, the lane-per-env scramble on the first wave of every workgroup
 // (69 instead of 148 VGPRs, 17 instead of 40 KB of LDS: idle workgroups of a tree launch do not hold a third of a CU each)
-template <int NXP, bool HAS_Z, bool RESET_ONLY = false>
+template <int NXP, bool HAS_Z, int LEAN = 0>
 __global__ __launch_bounds__(256) void qm_init_kernel(InitArgs a) {
     KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
-    qm_init_block<NXP, HAS_Z, false, RESET_ONLY>(a, blockIdx.x);
+    qm_init_block<NXP, HAS_Z, false, LEAN>(a, blockIdx.x);
 }
 
 // qg_vec_reset_done followed by qg_vec_step in ONE launch (qg_vec_reset_done_step): the grid's first `reset_blocks` workgroups are the
@@ -1087,7 +1091,7 @@ __global__ __launch_bounds__(256) void qm_reset_step_kernel(ResetStepArgs ra) {
     }
     // (plain configuration: the tree's wave takes the env's first step on the rows it holds -- qm_init_finish_wave_step; otherwise the lane
     // that has just written the env's fresh episode -- state, depth, bad mask, log lengths -- takes it, as qm_step1_body)
-    qm_init_block<NXP, HAS_Z, false, true>(ra.reset, role_index, FEAT ? nullptr : &a, [&](uint64_t env, bool stepped, bool fin) {
+    qm_init_block<NXP, HAS_Z, false, 1>(ra.reset, role_index, FEAT ? nullptr : &a, [&](uint64_t env, bool stepped, bool fin) {
         if (!stepped) fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64), true);
         if (fin) {  // (rare: one atomic per env that is final again after its first step)
             const uint32_t slot = atomicAdd(a.done_count, 1u);
@@ -1124,7 +1128,7 @@ __global__ __launch_bounds__(256) void qm_reset_inv2_step_kernel(ResetStepArgs r
     }
     const StepArgs *wave_step = WAVE ? &a : nullptr;  // (not with layer weights: that metric reads the record the reset has just written -- the read-back form)
     // `after(env, h, stepped, fin)`: stepped -- the tree's wave has taken the env's step (is_final in `fin`; one lane calls); else lanes h = 0, 1 take it now
-    qm_init_block<NXP, true, true, true>(ra.reset, role_index, wave_step, [&](uint64_t env, uint32_t h, bool stepped, bool fin) {
+    qm_init_block<NXP, true, true, 1>(ra.reset, role_index, wave_step, [&](uint64_t env, uint32_t h, bool stepped, bool fin) {
         if (!stepped) {
             // the fresh episode (written by this wave's lanes) is in the L2 before the pair's loads of it are issued, and those loads do not take a line this CU read
             // earlier (not __threadfence(): its release half writes the XCD's whole L2 back)
@@ -1419,7 +1423,8 @@ static hipError_t launch_init(const InitArgs &a, hipStream_t s) {
         const uint64_t tree_blocks = a.tree_grid;
         if (tree_blocks * QG_TREE_THREADS > threads) threads = tree_blocks * QG_TREE_THREADS;
     }
-    if (lean) hipLaunchKernelGGL((qm_init_kernel<NXP, HAS_Z, true>), dim3(grid_for(threads, 256)), dim3(256), 0, s, a);
+    if (lean) hipLaunchKernelGGL((qm_init_kernel<NXP, HAS_Z, 1>), dim3(grid_for(threads, 256)), dim3(256), 0, s, a);
+    else if (a.mode == 2) hipLaunchKernelGGL((qm_init_kernel<NXP, HAS_Z, 2>), dim3(grid_for(threads, 256)), dim3(256), 0, s, a);  // (the whole batch, or by the flags)
     else hipLaunchKernelGGL((qm_init_kernel<NXP, HAS_Z>), dim3(grid_for(threads, 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
