@@ -752,7 +752,7 @@ __device__ __forceinline__ bool q64_init_body(const InitArgs &a, uint32_t vblock
         env = entry((uint32_t)tid);
         after.ahead(env);
     } else {
-        if (RESET_ONLY) return false;  // (that instantiation is only launched with a list)
+        if (RESET_ONLY && T != 64) return false;  // (behind the trees there is always a list; T = 64, RESET_ONLY: qg_vec_reset of the whole batch, or by the flags)
         if (env >= a.B) return true;
         if (a.only_done && !a.done[env]) return true;
     }
@@ -793,10 +793,11 @@ __device__ __forceinline__ bool q64_init_body(const InitArgs &a, uint32_t vblock
     after(env);
     return true;
 }
-template <int NS, bool HAS_Z>
+// RESET_ONLY: mode 2 (qg_vec_reset, qg_vec_reset_done) -- without set_state's code, whose symplectic check makes this kernel 256 VGPRs and 400 bytes of scratch
+template <int NS, bool HAS_Z, bool RESET_ONLY = false>
 __global__ __launch_bounds__(64) void q64_init_kernel(InitArgs a) {
     KernelClock kclk(a.kclk, a.kclk_waves);  // device_common.hpp
-    (void)q64_init_body<NS, HAS_Z>(a, blockIdx.x);
+    (void)q64_init_body<NS, HAS_Z, 64, RESET_ONLY>(a, blockIdx.x);
 }
 
 // export: one thread per (env, matrix row)
@@ -1176,6 +1177,8 @@ static hipError_t q64_launch_init(const InitArgs &a, hipStream_t s) {
     // (InitArgs::zero_count: qgym_api.cpp rotates the handle's lists)
     if (a.mode == 2 && a.list && a.coop && a.n_draws >= 64u && a.tree_grid && a.zero_count)
         hipLaunchKernelGGL((q64_reset_done_kernel<NS, HAS_Z>), dim3((unsigned)a.tree_grid + all), dim3(Q64_TREE_THREADS), 0, s, a);
+    else if (a.mode == 2)
+        hipLaunchKernelGGL((q64_init_kernel<NS, HAS_Z, true>), dim3(all), dim3(64), 0, s, a);
     else
         hipLaunchKernelGGL((q64_init_kernel<NS, HAS_Z>), dim3(all), dim3(64), 0, s, a);
     return hipGetLastError();
