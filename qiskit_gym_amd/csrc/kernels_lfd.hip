@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void lfd_step_kernel(StepArgs a, uint32_t RG) 
         const uint32_t g0 = q0 / T::RPG, g1 = q1 / T::RPG;
         uint4 ua = tile[(ra * RG + g0) * 64u], ub = tile[(ra * RG + g1) * 64u];
         if (g0 == g1) ub = ua;
-        const W r0 = T::get(ua, q0 % T::RPG), r1 = T::get(g0 == g1 ? ua : ub, q1 % T::RPG);
+        const W r0 = T::get(ua, q0 % T::RPG), r1 = T::get(ub, q1 % T::RPG)  /* (ub = ua when the rows share a group; a `c ? ua : ub` reference sends both to scratch) */;
         const W n0 = is_swap ? r1 : r0;       // swap: rows trade places (linear_function.rs:72-83)
         const W n1 = is_swap ? r0 : r1 ^ r0;  // cx(q0, q1): row q1 ^= row q0 (:62-70)
         if (g0 == g1) {
