@@ -323,9 +323,15 @@ static unsigned long long *kernel_clock_slot(const qg_vec *v) {
 static uint32_t reset_tree_grid(const qg_vec *v, uint32_t most) {
     const uint32_t seen = v->count_seen ? *(volatile const uint32_t *)v->count_seen : 0xFFFFFFFFu;
     if (seen == 0xFFFFFFFFu) return most;
+    // A launch being CAPTURED keeps its grid for every replay (eager calls correct themselves at the next call): a capture made while few envs finish -- right
+    // after a reset, say -- must not bake a small grid in, or every later list is walked in many rounds.  TILE: the whole grid (its one-launch kernels fit
+    // seven workgroups per CU since round 5: idle tree workgroups cost nothing measurable, 9.15 against 9.2 us a pair); TILE64 / PauliEnv (three per CU: the
+    // whole grid costs 1.0 / 0.5 us a pair): at least half of it, all of it when the last launch saw nobody finish.
+    const bool captured = v->list_session != 0;
+    if (captured && (v->layout == LAYOUT_TILE || seen == 0)) return most;
     const uint64_t want = (uint64_t)seen + 4ull * (uint64_t)std::sqrt((double)seen) + 32ull;
     const uint64_t g = (want + 63ull) & ~63ull;
-    return (uint32_t)std::min<uint64_t>(most, std::max<uint64_t>(64ull, g));
+    return (uint32_t)std::min<uint64_t>(most, std::max<uint64_t>(captured ? std::max<uint64_t>(64ull, most / 2) : 64ull, g));
 }
 
 
