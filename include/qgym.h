@@ -174,11 +174,12 @@ int qg_vec_reset(qg_vec *v, uint64_t seed, void *stream);
  * fresh seed per call (e.g. a step counter) so successive episodes of an env differ. */
 int qg_vec_reset_done(qg_vec *v, uint64_t seed, void *stream);
 /* qg_vec_reset_done(v, reset_seed) followed by qg_vec_step(v, actions_dev, ...) -- the auto-reset collection loop's pair of calls -- with the
- * results of exactly those two calls (rewards_dev / dones_dev: optional per-step outputs as in qg_vec_rollout).  Handles whose env.step() is
- * the one-step kernel of the 32-bit-row layout (CliffordEnv N <= 16, LinearFunctionEnv 8 < N <= 32, both without add_inverts) run the pair as
- * ONE launch from the second call of a session on: the reset's workgroups (the finished envs' scrambles) and the step's workgroups (every
- * other env) share the grid, and an env that was reset takes its first step on the lane that finished its scramble.  Everything else -- and
- * the first call of a session, whose list has to be compacted from the flags -- is the two calls. */
+ * results of exactly those two calls (rewards_dev / dones_dev: optional per-step outputs as in qg_vec_rollout).  ONE launch from the second
+ * call of a session on for: CliffordEnv N <= 16 with any options (add_inverts included, while every env is symplectic and no dense observation
+ * is tracked with it), CliffordEnv 16 < N <= 32 and LinearFunctionEnv 8 < N <= 64 without add_inverts, and always for LinearFunctionEnv N <= 8 /
+ * PermutationEnv N <= 16: the reset's workgroups (the finished envs' scrambles) and the step's workgroups (every other env) share the grid, and an
+ * env that was reset takes its first step on the wave / lane that finished its scramble.  Everything else -- and the first call of a session,
+ * whose list has to be compacted from the flags -- is the two calls.  qg_plan_query(QG_PLAN_RESET_DONE_STEP) says which. */
 int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_dev, int action_dtype, const uint8_t *coins_dev, float *rewards_dev,
                            uint8_t *dones_dev, void *stream);
 /* Capturing these calls into a caller's hipGraph: once qg_vec_reset_done is in use on a handle, a single qg_vec_step (and the sampling +
