@@ -793,7 +793,7 @@ __device__ inline bool qm_init_finish_wave_step(const InitArgs &a, const StepArg
     a.done[env] = (uint8_t)fin;
     a.inverted[env] = (uint8_t)iflags;
     uint32_t fault = 0, sol_n = 0;
-    if (INV && (sa.flags & F_TRACK)) {  // clifford.rs:334-340: the fresh episode's first entry, pushed in the frame the env is in before the coin (not inverted)
+    if (sa.flags & F_TRACK) {  // clifford.rs:334-340: the fresh episode's first entry, pushed in the frame the env is in before the coin (not inverted)
         if (sa.sol_cap) sol_at(sa, env, sol_n++) = sol_word_framed(act, false);
         else fault |= 8u;
     }
@@ -1061,7 +1061,8 @@ __device__ inline bool reset_step_role(const ResetStepArgs &ra, uint32_t &index)
     index = b < ra.first_reset ? b : b - ra.step_blocks;
     return false;
 }
-template <int NXP, bool HAS_Z, bool FEAT, bool DENSE>
+// (WAVE: the tree's wave takes a reset env's first step -- not with layer weights, whose metric reads the record the reset has just written; a compile-time choice)
+template <int NXP, bool HAS_Z, bool FEAT, bool DENSE, bool WAVE = !FEAT>
 __global__ __launch_bounds__(256) void qm_reset_step_kernel(ResetStepArgs ra) {
     KernelClock kclk(ra.step.kclk, ra.step.kclk_waves);  // device_common.hpp
     using Rows = QmRows<NXP, HAS_Z>;
@@ -1091,7 +1092,7 @@ __global__ __launch_bounds__(256) void qm_reset_step_kernel(ResetStepArgs ra) {
     }
     // (plain configuration: the tree's wave takes the env's first step on the rows it holds -- qm_init_finish_wave_step; otherwise the lane
     // that has just written the env's fresh episode -- state, depth, bad mask, log lengths -- takes it, as qm_step1_body)
-    qm_init_block<NXP, HAS_Z, false, 1>(ra.reset, role_index, FEAT ? nullptr : &a, [&](uint64_t env, bool stepped, bool fin) {
+    qm_init_block<NXP, HAS_Z, false, 1>(ra.reset, role_index, WAVE ? &a : nullptr, [&](uint64_t env, bool stepped, bool fin) {
         if (!stepped) fin = qm_step1_body<HAS_Z, FEAT, D16>(a, Rows::G, env, load_action(a.actions, env, a.flags & F_ACT64), true);
         if (fin) {  // (rare: one atomic per env that is final again after its first step)
             const uint32_t slot = atomicAdd(a.done_count, 1u);
@@ -1472,7 +1473,7 @@ static hipError_t launch_reset_step(const ResetStepArgs &ra, hipStream_t s) {
     rb.reset_blocks = grid_for(threads, 256);
     // the grid: [the tree workgroups][the step workgroups][the other reset workgroups] (no trees: half of the reset workgroups first)
     rb.first_reset = tree_blocks ? (uint32_t)std::min<uint64_t>(tree_blocks, rb.reset_blocks) : rb.reset_blocks / 2;
-    const bool feat = ra.step.flags & (F_TRACK | F_LAYERS);
+    const bool feat = ra.step.flags & (F_TRACK | F_LAYERS), layers = ra.step.flags & F_LAYERS;
     if (ra.step.flags & F_INVERTS) {  // the reference-default step: two lanes per env
         if constexpr (HAS_Z && NXP <= 16) {
             rb.step_blocks = grid_for(2 * ra.step.B, 256);
@@ -1488,12 +1489,14 @@ static hipError_t launch_reset_step(const ResetStepArgs &ra, hipStream_t s) {
     const dim3 grid(rb.reset_blocks + rb.step_blocks), block(256);
     if constexpr (QmRows<NXP, HAS_Z>::R % 16 == 0) {
         if (ra.step.dense) {
-            if (feat) hipLaunchKernelGGL((qm_reset_step_kernel<NXP, HAS_Z, true, true>), grid, block, 0, s, rb);
+            if (layers) hipLaunchKernelGGL((qm_reset_step_kernel<NXP, HAS_Z, true, true, false>), grid, block, 0, s, rb);
+            else if (feat) hipLaunchKernelGGL((qm_reset_step_kernel<NXP, HAS_Z, true, true, true>), grid, block, 0, s, rb);
             else hipLaunchKernelGGL((qm_reset_step_kernel<NXP, HAS_Z, false, true>), grid, block, 0, s, rb);
             return hipGetLastError();
         }
     }
-    if (feat) hipLaunchKernelGGL((qm_reset_step_kernel<NXP, HAS_Z, true, false>), grid, block, 0, s, rb);
+    if (layers) hipLaunchKernelGGL((qm_reset_step_kernel<NXP, HAS_Z, true, false, false>), grid, block, 0, s, rb);
+    else if (feat) hipLaunchKernelGGL((qm_reset_step_kernel<NXP, HAS_Z, true, false, true>), grid, block, 0, s, rb);  // (solution log: the wave writes the entry)
     else hipLaunchKernelGGL((qm_reset_step_kernel<NXP, HAS_Z, false, false>), grid, block, 0, s, rb);
     return hipGetLastError();
 }

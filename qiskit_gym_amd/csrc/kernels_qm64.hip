@@ -1083,8 +1083,15 @@ __device__ __forceinline__ void q64_reset_tree_body(const InitArgs &a, After aft
         a.done[env] = (uint8_t)(a.depth_value == 0 || solved);
         }
         a.inverted[env] = (uint8_t)((HAS_Z && a.check_symplectic) ? Q64_FLAG_SYMPLECTIC : 0u);  // identity + gates: symplectic (q64_init_finish, mode 2)
-        a.error[env] = 0;
-        a.sol_len[env * 2] = 0;
+        uint32_t wave_fault = 0, wave_sol_n = 0;
+        if constexpr (After::WAVE_STEP) {  // clifford.rs:334-340: the step's entry in the fresh episode's solution log
+            if (after.a.flags & F_TRACK) {
+                if (after.a.sol_cap) sol_at(after.a, env, wave_sol_n++) = sol_word_framed(after.act, false);
+                else wave_fault |= 8u;
+            }
+        }
+        a.error[env] = wave_fault;
+        a.sol_len[env * 2] = (int32_t)wave_sol_n;
         a.sol_len[env * 2 + 1] = 0;
         if (a.layers) {
             const LayerRec lay = layer_rec(a.layers, env, a.layers_len);
@@ -1107,9 +1114,10 @@ __global__ __launch_bounds__(Q64_TREE_THREADS) void q64_reset_done_kernel(InitAr
     else (void)q64_init_body<NS, HAS_Z, Q64_TREE_THREADS, true>(a, blockIdx.x - a.tree_grid);
 }
 // the first step of an env a reset lane / wave of q64_reset_step_kernel has just written (q64_init_body / q64_reset_tree_body: `After`)
-template <int NS, bool HAS_Z, bool FEAT>
+// (WAVE: the tree's wave takes the step on the rows in its lanes -- not with layer weights, whose metric reads the record the reset has just written)
+template <int NS, bool HAS_Z, bool FEAT, bool WAVE = !FEAT>
 struct Q64FirstStep {
-    static constexpr bool WAVE_STEP = !FEAT;
+    static constexpr bool WAVE_STEP = WAVE;
     const StepArgs &a;
     int64_t act;
     GateEntry g;
@@ -1140,7 +1148,7 @@ struct Q64ResetStepArgs {
     StepArgs step;
     uint32_t step_blocks;
 };
-template <int NS, bool HAS_Z, bool FEAT>
+template <int NS, bool HAS_Z, bool FEAT, bool WAVE = !FEAT>
 __global__ __launch_bounds__(Q64_TREE_THREADS) void q64_reset_step_kernel(Q64ResetStepArgs ra) {
     KernelClock kclk(ra.step.kclk, ra.step.kclk_waves);  // device_common.hpp
     const StepArgs &a = ra.step;
@@ -1159,14 +1167,15 @@ __global__ __launch_bounds__(Q64_TREE_THREADS) void q64_reset_step_kernel(Q64Res
         done_mask_store(a.done_mask, a.B, fin, env, a.done_epoch);  // (an env being reset: bit clear)
         return;
     }
-    Q64FirstStep<NS, HAS_Z, FEAT> first_step{a, 0, GateEntry{0u, 0.0f}};
+    Q64FirstStep<NS, HAS_Z, FEAT, WAVE> first_step{a, 0, GateEntry{0u, 0.0f}};
     if (b < trees) q64_reset_tree_body<NS, HAS_Z>(ra.reset, first_step);
     else (void)q64_init_body<NS, HAS_Z, Q64_TREE_THREADS, true>(ra.reset, b - trees - ra.step_blocks, first_step);
 }
 template <int NS, bool HAS_Z>
 static hipError_t q64_launch_reset_step(const Q64ResetStepArgs &ra, hipStream_t s) {
     const unsigned grid = ra.reset.tree_grid + ra.step_blocks + grid_for(ra.reset.B, 64);
-    if (ra.step.flags & (F_TRACK | F_LAYERS)) hipLaunchKernelGGL((q64_reset_step_kernel<NS, HAS_Z, true>), dim3(grid), dim3(Q64_TREE_THREADS), 0, s, ra);
+    if (ra.step.flags & F_LAYERS) hipLaunchKernelGGL((q64_reset_step_kernel<NS, HAS_Z, true, false>), dim3(grid), dim3(Q64_TREE_THREADS), 0, s, ra);
+    else if (ra.step.flags & F_TRACK) hipLaunchKernelGGL((q64_reset_step_kernel<NS, HAS_Z, true, true>), dim3(grid), dim3(Q64_TREE_THREADS), 0, s, ra);  // (solution log: the wave writes the entry)
     else hipLaunchKernelGGL((q64_reset_step_kernel<NS, HAS_Z, false>), dim3(grid), dim3(Q64_TREE_THREADS), 0, s, ra);
     return hipGetLastError();
 }
