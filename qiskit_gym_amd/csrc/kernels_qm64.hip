@@ -700,7 +700,7 @@ __device__ inline void q64_init_finish(const InitArgs &a, uint64_t env, const Q6
 // trees of the same launch have taken the list -- then everybody leaves -- and three of them leave anyway before the first wave does the work.
 // `after(env)`: called by the lane that has written env's fresh episode (state, depth, bad mask, log lengths) -- q64_reset_step_kernel's first step of that env.
 // `after.ahead(env)`: called once the env is known, before its scramble, by the lane(s) that may finish it (that step's action and gate entry are requested there).
-// WAVE_STEP (q64_reset_step_kernel without solution log / layer weights): the tree's wave takes the env's first step itself on the rows it holds across its lanes,
+// WAVE_STEP (q64_reset_step_kernel without layer weights): the tree's wave takes the env's first step itself on the rows it holds across its lanes,
 // before it stores them -- nothing the reset wrote is read back (reading back: +3 us a tree: the stores' round trip, an L1 invalidate, the loads).
 struct Q64NoAfter {
     static constexpr bool WAVE_STEP = false;
