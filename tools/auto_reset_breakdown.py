@@ -129,6 +129,9 @@ def main():
     env = VecEnv("clifford", 16, gs3, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=256)
     run("CliffordGym 16q, plain options, one launch per pair (qm_reset_step_kernel)", env, len(gs3), 1, ["reset + step"], True, out)
     del env
+    env = VecEnv("clifford", 16, gs3, B, add_inverts=False, add_perms=False, track_solution=True, difficulty=256)
+    run("CliffordGym 16q, no add_inverts but the solution log, one launch per pair (qm_reset_step_kernel<.., FEAT>)", env, len(gs3), 1, ["reset + step"], True, out)
+    del env
     env = VecEnv("clifford", 16, gs3, B, add_inverts=False, add_perms=False, track_solution=False, difficulty=256)
     run("CliffordGym 16q, plain options, two launches per pair", env, len(gs3), 2, ["reset_done (qm_init_kernel)", "step (qm_step1_kernel<LIST>)"], False, out)
     del env
