@@ -973,12 +973,15 @@ __device__ __forceinline__ void qm_init_block(const InitArgs &a, uint32_t vblock
                 for (int sl = 0; sl < Rows::R; ++sl) s.r[sl] = rows[sl][L];
                 qm_init_finish<NXP, HAS_Z, NO_SET_STATE>(a, mine, s);
             }
-            uint64_t todo = __ballot(has);
-            while (todo) {  // (wave-uniform)
-                const int b = __ffsll((long long)todo) - 1;
-                todo &= todo - 1ull;
-                const uint32_t e = (uint32_t)__shfl((int)mine, b);
-                if ((threadIdx.x & (QG_WAVE - 1)) < 2u) after((uint64_t)e, threadIdx.x & 1u, false, false);
+            // ... 32 envs at a time: lanes 2 i and 2 i + 1 take the env of lane 32 p + i (one env after the other on lanes 0 and 1 cost a wave 64 steps in a row:
+            // 273 us a pair when half of the batch finishes in every step, episodes of two steps)
+            const uint64_t owners = __ballot(has);
+            const uint32_t lane = threadIdx.x & (QG_WAVE - 1);
+#pragma unroll 1
+            for (uint32_t p = 0; p < 2u; ++p) {
+                const uint32_t src = 32u * p + (lane >> 1);
+                const uint32_t e = (uint32_t)__shfl((int)mine, (int)src);
+                if ((owners >> src) & 1ull) after((uint64_t)e, lane & 1u, false, false);
             }
             return;
         }

@@ -888,3 +888,52 @@ def test_reset_done_step_random_shapes_against_the_oracle(case):
         o_sol, o_len = ov.solutions(64)
         g_sol, g_len = gv.solutions(64)
         assert np.array_equal(g_len, o_len) and np.array_equal(g_sol, o_sol), what
+
+
+@pytest.mark.parametrize("n,inverts", [(16, True), (16, False), (24, False)])
+def test_bursts_of_finishers_inside_the_one_launch_pair(n, inverts):
+    """The one-launch pair is chosen from the list lengths the handle has seen (qg_vec_reset_done_step: it pays where the resets are trees); a list that is
+    suddenly LONG is then reset inside the fused kernel by its other roles: 6 000 of 262 144 envs finishing in one step after steps in which nobody finished
+    (the 16-lane resets; with add_inverts their first steps on lane pairs), then the other 256 144 at once (the lane-per-env resets: 32 envs' first steps at a
+    time on lane pairs).  Every env against the oracle after every step."""
+    from oracle import OracleVec
+    from qiskit_gym_amd.vec import VecEnv
+    from test_gpu_fullsize import _coins
+
+    B, K, L, diff = 262144, 6000, 8, 64
+    gs = line_gateset("clifford", n)
+    A = len(gs)
+    cfg = dict(add_inverts=inverts, add_perms=False, track_solution=inverts, difficulty=diff, depth_slope=1, max_depth=L)
+    gv = VecEnv("clifford", n, gs, B, seed=99, **cfg)
+    ov = OracleVec(OracleEnv("clifford", n, gs, **{k: int(v) for k, v in cfg.items()}), B)
+    gv.reset(3)
+    ov.reset_seeded(3)
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    ids = np.arange(B)
+    late = np.ones(B, dtype=np.uint8)
+    late[np.random.default_rng(5).choice(B, size=K, replace=False)] = 0  # everybody but K envs starts again three steps in
+    f = np.zeros(B, dtype=np.uint8)
+    bursts = []
+    for t in range(2 * L + 8):
+        acts = torch.randint(0, A, (B,), dtype=torch.int32, device="cuda", generator=gen)
+        gv.set_counters(t, 0)
+        seed = 2000 + t
+        if t == 0:
+            gv.step(acts)
+        else:
+            gv.reset_done_step(seed, acts)
+            ov.reset_seeded(seed, mask=f)
+        r, s_, f, d = ov.step(acts.cpu().numpy(), _coins(99, ids, t) if inverts else None)
+        gv.sync()
+        assert np.array_equal(f32_bits(gv.reward.cpu().numpy()), f32_bits(r)), t
+        assert np.array_equal(gv.done.cpu().numpy(), f) and np.array_equal(gv.depth.cpu().numpy(), d), (t, np.nonzero(gv.done.cpu().numpy() != f)[0][:8])
+        bursts.append(int(f.sum()))
+        if t == 2:  # (a reset from raised flags, a launch of its own: the K others are now three steps ahead)
+            gv.reset_done(seed + 7)  # nobody is final: consumes the step's mask
+            gv.done.copy_(torch.as_tensor(late, device="cuda"))
+            gv.reset_done(777)
+            ov.reset_seeded(777, mask=late)
+            f = np.zeros(B, dtype=np.uint8)
+            gv.sync()
+    assert any(K // 2 < b <= K for b in bursts) and any(b > B // 2 for b in bursts), bursts  # both bursts happened (a few envs are solved early)
+    assert np.array_equal(gv.observe().cpu().numpy().reshape(B, -1), ov.observe_dense()), "final states"
