@@ -9,13 +9,16 @@ from qiskit_gym_amd.vec import VecEnv
 from util import line_gateset
 
 B, T = 65536, 64
-for n, inverts in ((16, False), (16, True), (24, False)):
-    gs = line_gateset("clifford", n)
+import sys as _sys
+CASES = ((("linear_function", 8, False), ("linear_function", 8, True), ("permutation", 9, False)) if "--words" in _sys.argv
+         else (("clifford", 16, False), ("clifford", 16, True), ("clifford", 24, False)))
+for kind, n, inverts in CASES:
+    gs = line_gateset(kind, n)
     A = len(gs)
     for diff in (1, 4, 16, 64):
         res = {}
         for fused in (True, False):
-            env = VecEnv("clifford", n, gs, B, add_inverts=inverts, add_perms=False, track_solution=inverts, difficulty=diff, depth_slope=2, max_depth=128)
+            env = VecEnv(kind, n, gs, B, add_inverts=inverts, add_perms=False, track_solution=inverts, difficulty=diff, depth_slope=2, max_depth=128)
             stream = torch.cuda.Stream()
             acts = torch.randint(0, A, (T, B), dtype=torch.int32, device="cuda")
             fin = torch.empty((T, B), dtype=torch.uint8, device="cuda")
@@ -54,4 +57,4 @@ for n, inverts in ((16, False), (16, True), (24, False)):
                     best = min(best, e0.elapsed_time(e1) * 1e3 / (4 * T))
             res[fused] = (best, float(fin.float().mean()))
             env.close()
-        print(f"clifford{n} add_inverts={inverts} difficulty {diff:3d} (episodes of {2 * diff} steps, {res[True][1] * 100:.1f} % finishing per step): one call {res[True][0]:7.2f} us, two calls {res[False][0]:7.2f} us", flush=True)
+        print(f"{kind}{n} add_inverts={inverts} difficulty {diff:3d} (episodes of {2 * diff} steps, {res[True][1] * 100:.1f} % finishing per step): one call {res[True][0]:7.2f} us, two calls {res[False][0]:7.2f} us", flush=True)
