@@ -1116,15 +1116,8 @@ int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_d
     // reset would take the list path with counter-RNG draws; otherwise the two calls, whose step leaves both for the next time
     // (add_inverts: the two-lanes-per-env launch has no Gauss-Jordan and no tracked-observation form)
     const bool inverts = v->flags & F_INVERTS;
-    // ... and where the one launch is the faster form (tools/probe_short_episodes.py): what it gains is the tree resets' launch; when a large share of the batch
-    // finishes in every step (short episodes: the lane-per-env resets, whose envs' first steps read their episodes back) the two launches win -- with add_inverts
-    // as soon as the lists are not trees' lists (31 against 19 us a pair at 50 % finishing), without beyond a quarter of the batch (22 against 16).  The list
-    // length is the latest one this handle's resets have reported (a captured launch keeps the choice made at the capture).
-    const uint32_t seen = v->count_seen ? *(volatile const uint32_t *)v->count_seen : 0xFFFFFFFFu;
-    const uint32_t draws = (uint32_t)std::max<int64_t>(v->difficulty, 0);
-    bool pays = inverts ? (draws >= plan::TREE_MIN_DRAWS && (seen == 0xFFFFFFFFu || plan::tree_takes(seen, draws))) : (seen == 0xFFFFFFFFu || seen <= v->B / 4);
-    // (64-bit rows: behind the 16-lane resets -- short scrambles, a few per cent finishing -- the first steps read back too: 18.1 against 16.6 us at 3 % of Clifford 24q)
-    if (v->layout == LAYOUT_TILE64 && seen != 0xFFFFFFFFu && seen != 0 && !plan::tree_takes(seen, draws) && plan::coop_takes(seen, v->B)) pays = false;
+    // ... and where the one launch is the faster form (qgym_plan.hpp reset_step_pays: from the configuration)
+    const bool pays = plan::reset_step_pays(plan_of(v), v->difficulty, std::min<int64_t>((int64_t)v->cfg.depth_slope * v->difficulty, v->cfg.max_depth));
     const bool fuse = v->done_list_alt && v->done_mask[0] && trusted && v->done_list_fresh && v->mask_fresh && v->auto_list && !v->gates.empty() &&
                       plan::reset_coop_allowed(false, v->B, v->d_rowops != nullptr) && plan::reset_step_fuses(plan_of(v)) &&
                       !(inverts && (v->maybe_nonsymplectic || v->dense)) && pays;
@@ -1396,7 +1389,8 @@ int qg_plan_query(const qg_config *cfg, uint64_t batch, uint32_t num_actions, in
         break;
     }
     case QG_PLAN_RESET_DONE_STEP:
-        name = plan::reset_step_fusable(hp) ? ((hp.flags & F_INVERTS) ? (nonsymplectic ? "two launches" : "qm_reset_inv2_step_kernel (after a list-leaving step)")
+        name = (plan::reset_step_fusable(hp) && plan::reset_step_pays(hp, cfg->difficulty, std::min<int64_t>((int64_t)cfg->depth_slope * cfg->difficulty, cfg->max_depth)))
+                   ? ((hp.flags & F_INVERTS) ? (nonsymplectic ? "two launches" : "qm_reset_inv2_step_kernel (after a list-leaving step)")
                                                : hp.layout == LAYOUT_TILE64 ? "q64_reset_step_kernel (after a list-leaving step)" : "qm_reset_step_kernel (after a list-leaving step)")
                : plan::reset_step_in_word_kernel(hp, num_actions) ? "word_reset_step_kernel" : "two launches";
         break;

@@ -257,6 +257,16 @@ inline bool reset_step_fusable(const HandlePlan &p) {
     if (p.flags & F_INVERTS) return p.layout == LAYOUT_TILE && p.has_z && p.nxp <= 16;
     return (p.layout == LAYOUT_TILE || p.layout == LAYOUT_TILE64) && p.has_bad;
 }
+// ... and whether the one launch is the faster form for a steady collection with this scramble length (`draws` = difficulty) and episode length (steps):
+// what it gains is the tree resets' launch; when a large share of the batch finishes in every step (short episodes: the lane-per-env resets, whose envs' first steps
+// read their episodes back) the two launches win -- with add_inverts as soon as the resets are not trees (31 against 19 us a pair at 50 % finishing), without when
+// more than a quarter of the batch finishes per step (22 against 16); 64-bit rows also behind the 16-lane resets (18.1 against 16.6 at 3 % of Clifford 24q).
+// From the CONFIGURATION, not from past list lengths: a captured launch keeps its choice for every replay.  (tools/probe_short_episodes.py)
+inline bool reset_step_pays(const HandlePlan &p, int64_t draws, int64_t episode_steps) {
+    if (p.flags & F_INVERTS) return draws >= (int64_t)TREE_MIN_DRAWS;
+    if (p.layout == LAYOUT_TILE64 && draws < (int64_t)TREE_MIN_DRAWS && episode_steps >= 32) return false;
+    return episode_steps >= 4;
+}
 inline bool reset_step_fuses(const HandlePlan &p) { return reset_step_fusable(p); }
 // ... and on the one-word layouts (word_reset_step_kernel: the wave tests its envs' is_final flags itself, no list)
 inline bool reset_step_in_word_kernel(const HandlePlan &p, size_t num_actions) { return (p.layout == LAYOUT_LF8 || p.layout == LAYOUT_PERM) && num_actions != 0; }

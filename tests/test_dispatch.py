@@ -121,20 +121,28 @@ def test_reset_done_paths(kind, n, batch, difficulty, count, want):
 
 
 def test_reset_done_step_in_one_launch():
-    """qg_vec_reset_done_step: which handles have a kernel that resets the finished envs and steps every env in ONE launch."""
-    assert plan("clifford", 16, RESET_DONE_STEP, **PLAIN).startswith("qm_reset_step_kernel")
-    assert plan("linear_function", 24, RESET_DONE_STEP, **PLAIN).startswith("qm_reset_step_kernel")
-    assert plan("linear_function", 8, RESET_DONE_STEP, num_actions=28, **PLAIN) == "word_reset_step_kernel"      # config 2's env
+    """qg_vec_reset_done_step: which handles have a kernel that resets the finished envs and steps every env in ONE launch -- and take it: where it is the faster
+    form (long scrambles: the resets are trees; qgym_plan.hpp reset_step_pays)."""
+    LONG = dict(difficulty=256)  # (episodes of 128 steps: clifford.rs:317 with the default depth_slope 2 and max_depth 128)
+    assert plan("clifford", 16, RESET_DONE_STEP, **PLAIN, **LONG).startswith("qm_reset_step_kernel")
+    assert plan("linear_function", 24, RESET_DONE_STEP, **PLAIN, **LONG).startswith("qm_reset_step_kernel")
+    assert plan("clifford", 24, RESET_DONE_STEP, **PLAIN, **LONG).startswith("q64_reset_step_kernel")            # 64-bit rows
+    assert plan("linear_function", 40, RESET_DONE_STEP, **PLAIN, **LONG).startswith("q64_reset_step_kernel")
+    assert plan("clifford", 16, RESET_DONE_STEP, **DEFAULT, **LONG).startswith("qm_reset_inv2_step_kernel")   # the reference's default options: two lanes per env
+    assert plan("clifford", 7, RESET_DONE_STEP, **DEFAULT, **LONG).startswith("qm_reset_inv2_step_kernel")
+    assert plan("clifford", 16, RESET_DONE_STEP, nonsymplectic=1, **DEFAULT, **LONG) == "two launches"          # (some env needs the Gauss-Jordan inversion)
+    # short scrambles / short episodes: the two launches are as fast or faster
+    assert plan("clifford", 16, RESET_DONE_STEP, difficulty=8, **DEFAULT) == "two launches"                     # (not trees: the lane-per-env resets read back)
+    assert plan("clifford", 16, RESET_DONE_STEP, difficulty=1, **PLAIN) == "two launches"                       # (episodes of two steps: half of the batch per step)
+    assert plan("clifford", 16, RESET_DONE_STEP, difficulty=8, **PLAIN).startswith("qm_reset_step_kernel")
+    assert plan("clifford", 24, RESET_DONE_STEP, difficulty=16, **PLAIN) == "two launches"                      # (64-bit rows behind the 16-lane resets)
+    assert plan("clifford", 24, RESET_DONE_STEP, difficulty=4, **PLAIN).startswith("q64_reset_step_kernel")
+    assert plan("linear_function", 8, RESET_DONE_STEP, num_actions=28, **PLAIN) == "word_reset_step_kernel"      # config 2's env: always
     assert plan("linear_function", 8, RESET_DONE_STEP, num_actions=28, **DEFAULT) == "word_reset_step_kernel"    # ... with the reference's defaults
     assert plan("permutation", 9, RESET_DONE_STEP, num_actions=12, **DEFAULT) == "word_reset_step_kernel"
     assert plan("linear_function", 8, RESET_DONE_STEP, num_actions=0, **PLAIN) == "two launches"                  # (an empty gateset: reset is an error)
-    assert plan("clifford", 24, RESET_DONE_STEP, **PLAIN).startswith("q64_reset_step_kernel")            # 64-bit rows
-    assert plan("linear_function", 40, RESET_DONE_STEP, **PLAIN).startswith("q64_reset_step_kernel")
-    assert plan("clifford", 16, RESET_DONE_STEP, **DEFAULT).startswith("qm_reset_inv2_step_kernel")   # the reference's default options: two lanes per env
-    assert plan("clifford", 7, RESET_DONE_STEP, **DEFAULT).startswith("qm_reset_inv2_step_kernel")
-    assert plan("clifford", 16, RESET_DONE_STEP, nonsymplectic=1, **DEFAULT) == "two launches"          # (some env needs the Gauss-Jordan inversion)
     for kind, n, cfg in (("clifford", 24, DEFAULT), ("linear_function", 24, DEFAULT), ("permutation", 27, PLAIN), ("pauli", 20, {})):
-        assert plan(kind, n, RESET_DONE_STEP, **cfg) == "two launches", (kind, n)
+        assert plan(kind, n, RESET_DONE_STEP, **cfg, **LONG) == "two launches", (kind, n)
 
 
 def test_observation_and_state_paths():
