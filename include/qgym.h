@@ -179,7 +179,8 @@ int qg_vec_reset_done(qg_vec *v, uint64_t seed, void *stream);
  * is tracked with it), CliffordEnv 16 < N <= 32 and LinearFunctionEnv 8 < N <= 64 without add_inverts, and always for LinearFunctionEnv N <= 8 /
  * PermutationEnv N <= 16: the reset's workgroups (the finished envs' scrambles) and the step's workgroups (every other env) share the grid, and an
  * env that was reset takes its first step on the wave / lane that finished its scramble.  Everything else -- and the first call of a session,
- * whose list has to be compacted from the flags -- is the two calls.  qg_plan_query(QG_PLAN_RESET_DONE_STEP) says which. */
+ * whose list has to be compacted from the flags -- is the two calls; so is a configuration whose episodes are so short that a large share of
+ * the batch finishes in every step (there the two launches are as fast or faster).  qg_plan_query(QG_PLAN_RESET_DONE_STEP) says which. */
 int qg_vec_reset_done_step(qg_vec *v, uint64_t reset_seed, const void *actions_dev, int action_dtype, const uint8_t *coins_dev, float *rewards_dev,
                            uint8_t *dones_dev, void *stream);
 /* Capturing these calls into a caller's hipGraph: once qg_vec_reset_done is in use on a handle, a single qg_vec_step (and the sampling +
