@@ -905,6 +905,7 @@ static int do_reset(qg_vec *v, const int32_t *actions_dev, size_t n_draws, uint6
         }
         v->mask_fresh = false;
         ia.coop = plan::reset_coop_allowed(actions_dev != nullptr, v->B, v->d_rowops != nullptr) ? 1u : 0u;
+        ia.flags_current = 1u;  // (this launch is the reset alone)
         if (v->layout == LAYOUT_TILE) ia.dense = v->dense;  // the listed envs' dense observations are rewritten by the reset itself
         if (v->done_list_spare) ia.zero_count = v->done_list_spare + v->B;
     }

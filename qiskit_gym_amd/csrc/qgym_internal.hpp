@@ -167,6 +167,8 @@ struct InitArgs {
     uint32_t layers_len;
     uint32_t check_symplectic; // TILE layout with add_inverts: record whether the state is symplectic
     uint32_t only_done;        // reset only the envs whose `done` flag is set (auto-reset between episodes)
+    uint32_t flags_current;    // a launch of its own (qg_vec_reset_done, not inside a reset + step launch): nobody writes `done` meanwhile, so a LONG list's lane-per-env
+                               // resets test the env's own flag (thread = env) instead of searching the mask / list for "entry i" (TILE)
     uint32_t *nonsymp_flag;    // set_state with add_inverts: or-ed to 1 when some env is not symplectic
     const uint64_t *clock;     // device clock: the scramble seed becomes seed + 0x9E3779B9 * clock (qg_vec_set_clock)
     uint32_t *bad;             // see StepArgs::bad
